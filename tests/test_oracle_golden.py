@@ -1,0 +1,69 @@
+"""The CPU oracle (oracle/bt_regex.c) against the committed golden vectors.
+
+regex_golden.json holds full-match capture offsets on which CPython `re` and PCRE1 8.45 agree
+(generator: tests/golden/gen_regex_golden.py).  The oracle restates boost::regex_match as called at
+core/common/StringTools.cpp:183-211; boost itself is unavailable offline (parity unpinned against boost).
+"""
+import json
+import os
+
+import pytest
+
+from oracle.oracle import OracleRegex
+
+
+def _load(golden_dir):
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_matches_every_golden_vector(golden_dir):
+    d = _load(golden_dir)
+    assert d["n_cases"] > 4000 and d["n_matched"] > 1000
+    bad = []
+    for c in d["cases"]:
+        rx = OracleRegex(c["p"].encode("latin-1"))
+        assert rx.groups == c["g"], c["p"]
+        for subj, flat in c["subs"]:
+            got = rx.fullmatch(subj.encode("latin-1"))
+            got_flat = None if got is None else [v for ab in got for v in ab]
+            if got_flat != flat:
+                bad.append((c["p"], subj, got_flat, flat))
+    assert not bad, bad[:5]
+
+
+def test_survey_known_answer_vectors():
+    # SURVEY.md appendix B probes (PCRE1 8.45 + Python re.fullmatch agree)
+    ra = OracleRegex(r'([\d\.]+) \S+ \S+ \[(\S+) \S+\] \"(\w+) ([^\\"]*)\" ([\d\.]+) (\d+) (\d+) (\d+|-) \"([^\\"]*)\" \"([^\\"]*)\"')
+    line = (b'127.0.0.1 - - [07/Jul/2022:10:43:30 +0800] "POST /PutData?Category=YunOsAccountOpLog" '
+            b'0.024 18204 200 37 "-" "aliyun-sdk-java"')
+    assert ra.fullmatch(line)[1:] == [(0, 9), (15, 35), (44, 48), (49, 84), (86, 91), (92, 97), (98, 101), (102, 104),
+                                      (106, 107), (110, 125)]
+    rb = OracleRegex(r'^([^ ]*) ([^ ]*) ([^ ]*) \[([^\]]*)\] "(\S+) ([^\"]*) (\S*)" ([^ ]*) ([^ ]*) "([^\"]*)" "([^\"]*)"')
+    l2 = (b'203.0.113.45 - - [25/Jun/2024:23:59:59 +0000] "GET /wp-admin/admin-ajax.php?action=x HTTP/1.1" 200 1847 '
+          b'"https://www.google.com/" "Mozilla/5.0 (Windows NT 10.0; Win64; x64)"')
+    assert rb.fullmatch(l2)[1:] == [(0, 12), (13, 14), (15, 16), (18, 44), (47, 50), (51, 84), (85, 93), (95, 98),
+                                    (99, 103), (105, 128), (131, 172)]
+
+
+@pytest.mark.parametrize("pat", [r"(a)\1", r"(?=a)b", r"(?<!a)b", r"(?>a+)b", r"a++", r"(", r"a)", r"[a", r"a**", r"\p{L}"])
+def test_unsupported_or_invalid_patterns_fail_to_compile(pat):
+    with pytest.raises(ValueError):
+        OracleRegex(pat)
+
+
+def test_boost_line_separator_rules():
+    # restated from Boost.Regex perl_matcher::match_start_line/match_end_line (knowledge, unpinned):
+    # separators are \n \r \f; no match between \r and \n.
+    assert OracleRegex(r"a$\r\nb").fullmatch(b"a\r\nb") is not None
+    assert OracleRegex(r"a\r$\nb").fullmatch(b"a\r\nb") is None
+    assert OracleRegex(r"a\r\n^b").fullmatch(b"a\r\nb") is not None
+    assert OracleRegex(r"a\r^\nb").fullmatch(b"a\r\nb") is None
+    assert OracleRegex(r"a\f^b").fullmatch(b"a\fb") is not None
+
+
+def test_complexity_budget_reports_failure():
+    # boost throws std::runtime_error on pathological backtracking; StringTools.cpp:200-205 -> parse failure
+    rx = OracleRegex(r"(a|aa)+(a|aa)+(a|aa)+(a|aa)+(a|aa)+(a|aa)+b")
+    with pytest.raises(RuntimeError):
+        rx.fullmatch(b"a" * 64)
