@@ -1,0 +1,138 @@
+/*
+ * lc_regex_gpu.h -- C ABI of the MI355X-native regex parse engine (liblc_regex_gpu.so).
+ *
+ * This is the drop-in boundary for the matching arithmetic of LoongCollector's
+ * processor_parse_regex_native.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  Plain pointers and sizes only; no C++/torch types.
+ *
+ *   reference                                                             this ABI
+ *   --------------------------------------------------------------------  ---------------------------
+ *   boost::regex ctor, one per runner thread                              lc_regex_compile
+ *     core/plugin/processor/ProcessorParseRegexNative.cpp:64-67
+ *   IsRegexValid(regex)   core/common/ParamExtractor.cpp:199-209          lc_regex_compile (rc != 0)
+ *   what.size() (= mark_count()+1)   ProcessorParseRegexNative.cpp:227    lc_regex_mark_count
+ *   BoostRegexMatch(buf,len,reg,exception,what,match_default)            lc_regex_match_device /
+ *     core/common/StringTools.cpp:183-211, called per event at            lc_regex_match_host
+ *     ProcessorParseRegexNative.cpp:194 inside the loop at :115-124       (whole event group per call)
+ *   what[i+1].begin()/length()       ProcessorParseRegexNative.cpp:249-251  caps[line][2*i], [2*i+1]
+ *
+ * Semantics: boost::regex_match with Perl syntax and match_default -- the WHOLE line must match,
+ * leftmost-first (backtracking) sub-match rules, byte-oriented, '.' matches '\n', '^'/'$' match at
+ * embedded line separators.  Output per line: status (LC_MATCH / LC_NOMATCH) and, for every capture
+ * group g = 1..ngroups, the byte range [begin,end) relative to the start of the line; a group that did
+ * not participate is reported as (-1,-1) (the reference turns that into an empty value positioned at
+ * end-of-input, ProcessorParseRegexNative.cpp:250 -- see lc_processor.h for the stitch).
+ *
+ * The engine has NO CPU execution path: if no HIP device is usable the match calls return
+ * LC_ERR_NO_DEVICE and the caller must fail loudly.
+ */
+#ifndef LC_REGEX_GPU_H
+#define LC_REGEX_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_REGEX_ABI_VERSION 1
+
+typedef struct lc_regex lc_regex_t;
+
+/* syntax flags (0 = boost::regex(str) defaults) */
+enum {
+    LC_SYNTAX_ICASE = 1u << 0,          /* (?i) */
+    LC_SYNTAX_NO_DOTALL = 1u << 1,      /* (?-s): '.' does not match '\n' */
+    LC_SYNTAX_NO_MULTILINE = 1u << 2,   /* (?-m): '^'/'$' only at the ends of the line */
+    LC_SYNTAX_EXTENDED = 1u << 3,       /* (?x) */
+    LC_SYNTAX_NAMED_ONLY = 1u << 4      /* unnamed groups do not capture (Grok / regexp2 ExplicitCapture-style) */
+};
+
+/* device engines */
+enum {
+    LC_ENGINE_AUTO = 0,  /* TDFA if it fits the limits, else NFA */
+    LC_ENGINE_TDFA = 1,  /* tagged DFA: one line per lane, tables in LDS */
+    LC_ENGINE_NFA = 2    /* follow NFA: one line per wavefront, one lane per live thread */
+};
+
+/* per-line status bytes */
+enum {
+    LC_NOMATCH = 0,
+    LC_MATCH = 1,
+    LC_OVERFLOW = 2  /* NFA engine only: more than 64 simultaneously live threads; line not decided */
+};
+
+/* return codes */
+enum {
+    LC_OK = 0,
+    LC_ERR_SYNTAX = 1,       /* invalid regex (reference: IsRegexValid false -> Init fails) */
+    LC_ERR_UNSUPPORTED = 2,  /* valid Perl regex but not executable bit-exactly on the device engines */
+    LC_ERR_NO_DEVICE = 3,
+    LC_ERR_HIP = 4,
+    LC_ERR_ARG = 5
+};
+
+typedef struct lc_regex_info {
+    int engine;            /* LC_ENGINE_TDFA or LC_ENGINE_NFA */
+    int mark_count;        /* capture groups */
+    uint32_t positions;    /* follow-NFA positions (byte-consuming steps) */
+    uint32_t states;       /* TDFA states (0 for NFA engine) */
+    uint32_t classes;      /* byte equivalence classes */
+    uint32_t registers;    /* TDFA offset registers per line */
+    uint32_t table_bytes;  /* bytes staged into LDS per workgroup */
+} lc_regex_info_t;
+
+/* Compile `pattern` (pattern_len bytes) for the requested engine.  On failure returns LC_ERR_SYNTAX /
+ * LC_ERR_UNSUPPORTED and writes a NUL-terminated message into err (if errcap > 0). */
+int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,
+                     lc_regex_t** out, char* err, size_t errcap);
+void lc_regex_free(lc_regex_t* re);
+
+int lc_regex_mark_count(const lc_regex_t* re);
+/* name of group g (1-based) or NULL */
+const char* lc_regex_group_name(const lc_regex_t* re, int g);
+int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out);
+
+/* Read-only view of a compiled host table (introspection for tests and docs; the pointer stays valid until
+ * lc_regex_free).  `which` is one of LC_TABLE_*.  Returns LC_ERR_ARG for a table the engine does not have. */
+enum {
+    LC_TABLE_CLASSMAP = 0,    /* u8[256] */
+    LC_TABLE_TDFA_TRANS = 1,  /* u32[states*classes] */
+    LC_TABLE_TDFA_OPSSTART = 2, /* u32[lists+1] */
+    LC_TABLE_TDFA_OPS = 3,    /* u16[] */
+    LC_TABLE_TDFA_FINALID = 4, /* u16[states] */
+    LC_TABLE_TDFA_FINALMAP = 5, /* u8[nfinal*slots] */
+    LC_TABLE_TDFA_HEADER = 6, /* u32[8]: states, classes, registers, slots, start state, 0,0,0 */
+    LC_TABLE_NFA_BLOB = 7     /* the packed NFA program uploaded to the device (see csrc/device_tables.h) */
+};
+int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
+
+/* Number of visible HIP devices (0 when there is none / no driver). */
+int lc_device_count(void);
+
+/* Match n lines that already live in device memory on the current HIP device.
+ *   d_data   : line bytes (any layout); line i = d_data[d_off[i] .. d_off[i]+d_len[i])
+ *   d_len    : may be NULL, then d_off has n+1 entries and len[i] = d_off[i+1]-d_off[i]-sep_bytes
+ *   ngroups  : number of (begin,end) pairs written per line (normally lc_regex_mark_count)
+ *   d_caps   : int32[n][2*ngroups]   (groups beyond mark_count are written as -1,-1)
+ *   d_status : uint8[n]
+ *   stream   : hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
+ */
+int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                          uint32_t sep_bytes, uint32_t n, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
+                          void* stream);
+
+/* Same, for host buffers: lines are gathered through pinned staging buffers and copied with
+ * hipMemcpyAsync on two streams so that chunk k+1 uploads while chunk k is being matched and chunk k-1
+ * downloads.  Synchronous: results are in caps/status on return. */
+int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                        uint32_t ngroups, int32_t* caps, uint8_t* status);
+
+/* last HIP error string of the calling thread (for LC_ERR_HIP) */
+const char* lc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""ctypes binding of liblc_regex_gpu.so (the C ABI declared in include/lc_regex_gpu.h).
+
+The library is the product; this module is only the Python-side plumbing used by tests and bench.py
+(device memory comes from torch tensors, whose data_ptr() values are passed straight through).
+There is no CPU execution path: every match call needs a HIP device and raises otherwise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("LC_REGEX_GPU_LIB", os.path.join(_HERE, "lib", "liblc_regex_gpu.so"))
+
+LC_ENGINE_AUTO, LC_ENGINE_TDFA, LC_ENGINE_NFA = 0, 1, 2
+LC_NOMATCH, LC_MATCH, LC_OVERFLOW = 0, 1, 2
+LC_OK, LC_ERR_SYNTAX, LC_ERR_UNSUPPORTED, LC_ERR_NO_DEVICE, LC_ERR_HIP, LC_ERR_ARG = range(6)
+LC_SYNTAX_ICASE, LC_SYNTAX_NO_DOTALL, LC_SYNTAX_NO_MULTILINE, LC_SYNTAX_EXTENDED, LC_SYNTAX_NAMED_ONLY = 1, 2, 4, 8, 16
+
+(LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
+ LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB) = range(8)
+
+
+class LcRegexInfo(ctypes.Structure):
+    _fields_ = [("engine", ctypes.c_int), ("mark_count", ctypes.c_int), ("positions", ctypes.c_uint32),
+                ("states", ctypes.c_uint32), ("classes", ctypes.c_uint32), ("registers", ctypes.c_uint32),
+                ("table_bytes", ctypes.c_uint32)]
+
+
+class RegexSyntaxError(ValueError):
+    pass
+
+
+class RegexUnsupportedError(ValueError):
+    pass
+
+
+class GpuUnavailableError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load the shared library (raises OSError if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    L = ctypes.CDLL(path or LIB_PATH)
+    vp, cp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+    L.lc_regex_compile.restype = i32
+    L.lc_regex_compile.argtypes = [cp, sz, u32, i32, ctypes.POINTER(vp), cp, sz]
+    L.lc_regex_free.argtypes = [vp]
+    L.lc_regex_mark_count.argtypes = [vp]
+    L.lc_regex_group_name.restype = cp
+    L.lc_regex_group_name.argtypes = [vp, i32]
+    L.lc_regex_info.argtypes = [vp, ctypes.POINTER(LcRegexInfo)]
+    L.lc_regex_table.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.lc_device_count.restype = i32
+    L.lc_regex_match_device.restype = i32
+    L.lc_regex_match_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.lc_regex_match_host.restype = i32
+    L.lc_regex_match_host.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp]
+    L.lc_last_error.restype = cp
+    if path is None:
+        _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc == LC_OK:
+        return
+    if rc == LC_ERR_NO_DEVICE:
+        raise GpuUnavailableError("%s: no usable HIP device (the engine has no CPU path)" % what)
+    msg = load().lc_last_error()
+    raise RuntimeError("%s failed: rc=%d %s" % (what, rc, msg.decode() if msg else ""))
+
+
+class GpuRegex:
+    """Compiled pattern handle; mirrors the role of `boost::regex` in ProcessorParseRegexNative (mReg)."""
+
+    def __init__(self, pattern, syntax_flags=0, engine=LC_ENGINE_AUTO, lib=None):
+        self._L = lib or load()
+        if isinstance(pattern, str):
+            pattern = pattern.encode("utf-8")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = self._L.lc_regex_compile(pattern, len(pattern), syntax_flags, engine, ctypes.byref(h), err, 512)
+        if rc == LC_ERR_SYNTAX:
+            raise RegexSyntaxError(err.value.decode())
+        if rc != LC_OK:
+            raise RegexUnsupportedError(err.value.decode())
+        self._h = h
+        self.pattern = pattern
+        self.groups = self._L.lc_regex_mark_count(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc_regex_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        i = LcRegexInfo()
+        _check(self._L.lc_regex_info(self._h, ctypes.byref(i)), "lc_regex_info")
+        return {f: getattr(i, f) for f, _ in LcRegexInfo._fields_}
+
+    def group_name(self, g):
+        r = self._L.lc_regex_group_name(self._h, g)
+        return r.decode() if r else None
+
+    def table(self, which, dtype):
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        rc = self._L.lc_regex_table(self._h, which, ctypes.byref(p), ctypes.byref(n))
+        if rc != LC_OK:
+            return None
+        if n.value == 0 or not p.value:
+            return np.zeros((0,), dtype=dtype)
+        buf = (ctypes.c_uint8 * n.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    # ---- device-resident batch (torch tensors on the current HIP device)
+    def match_device(self, d_data, d_off, d_len, n, d_caps, d_status, ngroups=None, sep_bytes=0, stream=None):
+        G = self.groups if ngroups is None else ngroups
+        rc = self._L.lc_regex_match_device(self._h, d_data.data_ptr(), d_off.data_ptr(),
+                                           d_len.data_ptr() if d_len is not None else None, sep_bytes, n, G,
+                                           d_caps.data_ptr(), d_status.data_ptr(), stream)
+        _check(rc, "lc_regex_match_device")
+
+    # ---- host batch (numpy arrays); pinned double-buffered H2D/D2H inside the library
+    def match_host(self, data, off, length, ngroups=None):
+        G = self.groups if ngroups is None else ngroups
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        n = int(off.shape[0])
+        caps = np.empty((n, 2 * G), dtype=np.int32)
+        status = np.empty((n,), dtype=np.uint8)
+        rc = self._L.lc_regex_match_host(self._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, n, G,
+                                         caps.ctypes.data, status.ctypes.data)
+        _check(rc, "lc_regex_match_host")
+        return caps, status
+
+
+def device_count():
+    return load().lc_device_count()

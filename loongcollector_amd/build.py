@@ -1,0 +1,80 @@
+"""Build liblc_regex_gpu.so (host compilers + gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m loongcollector_amd.build          # or __graft_entry__.build()
+
+The .so lands in loongcollector_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "liblc_regex_gpu.so")
+
+SOURCES = ["regex_parse.cpp", "follow_nfa.cpp", "tdfa.cpp", "regex_handle.cpp", "gpu_runtime.hip"]
+OPTIONAL_SOURCES = ["json_min.cpp", "event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "c_processor_slot.cpp"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    out = [os.path.join(CSRC, s) for s in SOURCES]
+    out += [os.path.join(CSRC, s) for s in OPTIONAL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(HERE, "..", "include", "lc_regex_gpu.h"))
+    deps.append(os.path.join(HERE, "..", "include", "lc_processor.h"))
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include"),
+              "-I", CSRC]
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h))
+                        for h in os.listdir(CSRC) if h.endswith((".h", ".hpp")))):
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950"] + common
+        if src.endswith(".hip"):
+            cmd += ["-x", "hip"]
+        cmd += ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode()))
+        if verbose and out:
+            print(out.decode(), file=sys.stderr)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

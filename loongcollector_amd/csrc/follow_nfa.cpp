@@ -1,0 +1,214 @@
+// follow_nfa.cpp -- AST -> prioritised Thompson program -> epsilon-free follow NFA.
+#include "follow_nfa.hpp"
+
+#include <algorithm>
+
+namespace lcregex {
+
+bool condHolds(uint16_t cond, const ByteProps& prev, const ByteProps& next) {
+    auto bit = [&](AssertKind k) { return (cond >> unsigned(k)) & 1u; };
+    const bool atStart = prev.boundary, atEnd = next.boundary;
+    const bool crlf = !atStart && !atEnd && prev.cr && next.lf;
+    if (bit(AssertKind::BolMulti) && !(atStart || (prev.sep && !crlf))) return false;
+    if (bit(AssertKind::BolSingle) && !atStart) return false;
+    if (bit(AssertKind::EolMulti) && !(atEnd || (next.sep && !crlf))) return false;
+    if (bit(AssertKind::EolSingle) && !atEnd) return false;
+    const bool pw = !atStart && prev.word, nw = !atEnd && next.word;
+    if (bit(AssertKind::WordBoundary) && pw == nw) return false;
+    if (bit(AssertKind::NotWordBoundary) && pw != nw) return false;
+    if (bit(AssertKind::WordStart) && !(!pw && nw)) return false;
+    if (bit(AssertKind::WordEnd) && !(pw && !nw)) return false;
+    return true;
+}
+
+uint8_t condPrevNeeds(uint16_t cond) {
+    auto bit = [&](AssertKind k) { return (cond >> unsigned(k)) & 1u; };
+    uint8_t need = 0;
+    if (bit(AssertKind::BolMulti)) need |= kPrevAtStart | kPrevSep | kPrevCR;
+    if (bit(AssertKind::BolSingle)) need |= kPrevAtStart;
+    if (bit(AssertKind::EolMulti)) need |= kPrevCR;  // only for the "never between \r\n" rule
+    if (bit(AssertKind::WordBoundary) || bit(AssertKind::NotWordBoundary) || bit(AssertKind::WordStart) ||
+        bit(AssertKind::WordEnd))
+        need |= kPrevWord;
+    return need;
+}
+
+namespace {
+
+struct Inst {
+    enum Op : uint8_t { Char, Split, Jump, Save, Assert, Match } op;
+    int x = 0, y = 0;  // Char: position index | Split: preferred, other | Jump: target | Save: slot | Assert: kind
+};
+
+bool nullable(const Node& n) {
+    switch (n.kind) {
+        case Node::Empty:
+        case Node::Assert: return true;
+        case Node::Set: return false;
+        case Node::Cat:
+            for (auto& k : n.kids)
+                if (!nullable(*k)) return false;
+            return true;
+        case Node::Alt:
+            for (auto& k : n.kids)
+                if (nullable(*k)) return true;
+            return false;
+        case Node::Repeat: return n.min == 0 || nullable(*n.kids[0]);
+        case Node::Group: return nullable(*n.kids[0]);
+    }
+    return true;
+}
+
+class Builder {
+public:
+    std::vector<Inst> code;
+    std::vector<ByteSet> positions;
+
+    int emit(Inst::Op op, int x = 0, int y = 0) {
+        if (code.size() > 200000) throw RegexError("regex too large after repeat expansion");
+        code.push_back({op, x, y});
+        return int(code.size()) - 1;
+    }
+
+    void gen(const Node& n) {
+        switch (n.kind) {
+            case Node::Empty: break;
+            case Node::Set:
+                positions.push_back(n.set);
+                emit(Inst::Char, int(positions.size()) - 1);
+                break;
+            case Node::Cat:
+                for (auto& k : n.kids) gen(*k);
+                break;
+            case Node::Alt: {
+                std::vector<int> exits;
+                for (size_t i = 0; i < n.kids.size(); ++i) {
+                    if (i + 1 < n.kids.size()) {
+                        int sp = emit(Inst::Split);
+                        code[sp].x = int(code.size());
+                        gen(*n.kids[i]);
+                        exits.push_back(emit(Inst::Jump));
+                        code[sp].y = int(code.size());
+                    } else {
+                        gen(*n.kids[i]);
+                    }
+                }
+                for (int j : exits) code[j].x = int(code.size());
+                break;
+            }
+            case Node::Group:
+                if (n.capture) emit(Inst::Save, 2 * (n.capture - 1));
+                gen(*n.kids[0]);
+                if (n.capture) emit(Inst::Save, 2 * (n.capture - 1) + 1);
+                break;
+            case Node::Assert: emit(Inst::Assert, int(n.assertKind)); break;
+            case Node::Repeat: genRepeat(n); break;
+        }
+    }
+
+    void genRepeat(const Node& n) {
+        const Node& body = *n.kids[0];
+        if (n.max < 0) {
+            if (nullable(body))
+                throw RegexError("unsupported: unbounded repeat of a sub-expression that can match the empty string");
+            if (n.min == 0) {
+                int sp = emit(Inst::Split);
+                int top = int(code.size());
+                gen(body);
+                emit(Inst::Jump, sp);
+                int out = int(code.size());
+                code[sp].x = n.greedy ? top : out;
+                code[sp].y = n.greedy ? out : top;
+            } else {
+                for (int i = 0; i + 1 < n.min; ++i) gen(body);
+                int top = int(code.size());
+                gen(body);
+                int sp = emit(Inst::Split);
+                int out = int(code.size());
+                code[sp].x = n.greedy ? top : out;
+                code[sp].y = n.greedy ? out : top;
+            }
+            return;
+        }
+        for (int i = 0; i < n.min; ++i) gen(body);
+        std::vector<int> splits;
+        for (int i = n.min; i < n.max; ++i) {
+            int sp = emit(Inst::Split);
+            splits.push_back(sp);
+            int top = int(code.size());
+            if (n.greedy) code[sp].x = top; else code[sp].y = top;
+            gen(body);
+        }
+        int out = int(code.size());
+        for (int sp : splits) {
+            if (n.greedy) code[sp].y = out; else code[sp].x = out;
+        }
+    }
+};
+
+class PathWalker {
+public:
+    PathWalker(const std::vector<Inst>& c) : code(c) {}
+    std::vector<FollowPath> from(int pc) {
+        out.clear();
+        steps = 0;
+        walk(pc, 0, 0, 0);
+        return out;
+    }
+
+private:
+    const std::vector<Inst>& code;
+    std::vector<FollowPath> out;
+    size_t steps = 0;
+
+    void add(int target, uint64_t tags, uint16_t cond) {
+        // a later path to the same target whose condition set includes an earlier one's can never win
+        for (const auto& p : out)
+            if (p.target == target && (p.cond & ~cond) == 0) return;
+        if (out.size() >= 4096) throw RegexError("unsupported: too many epsilon paths");
+        out.push_back({target, tags, cond});
+    }
+    void walk(int pc, uint64_t tags, uint16_t cond, int depth) {
+        if (++steps > 2000000 || depth > 100000) throw RegexError("unsupported: epsilon closure too large");
+        for (;;) {
+            const Inst& in = code[pc];
+            switch (in.op) {
+                case Inst::Char: add(in.x, tags, cond); return;
+                case Inst::Match: add(kMatchTarget, tags, cond); return;
+                case Inst::Jump: pc = in.x; break;
+                case Inst::Save: tags |= uint64_t(1) << in.x; ++pc; break;
+                case Inst::Assert: cond |= uint16_t(1u << in.x); ++pc; break;
+                case Inst::Split:
+                    walk(in.x, tags, cond, depth + 1);
+                    pc = in.y;
+                    break;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+FollowNfa buildFollowNfa(const ParsedRegex& re) {
+    if (re.groupCount > kMaxGpuGroups)
+        throw RegexError("unsupported: more than " + std::to_string(kMaxGpuGroups) + " capture groups");
+    Builder b;
+    b.gen(*re.root);
+    b.emit(Inst::Match);
+
+    FollowNfa nfa;
+    nfa.groupCount = re.groupCount;
+    nfa.groupNames = re.groupNames;
+    nfa.positions = b.positions;
+    const int npos = int(b.positions.size());
+    nfa.follow.resize(npos + 1);
+    PathWalker walker(b.code);
+    for (int pc = 0; pc < int(b.code.size()); ++pc)
+        if (b.code[pc].op == Inst::Char) nfa.follow[b.code[pc].x] = walker.from(pc + 1);
+    nfa.follow[npos] = walker.from(0);
+    for (auto& lst : nfa.follow)
+        for (auto& p : lst) nfa.condsUsed |= p.cond;
+    return nfa;
+}
+
+}  // namespace lcregex

@@ -1,0 +1,404 @@
+// gpu_runtime.hip -- gfx950 kernels and the device half of the C ABI (include/lc_regex_gpu.h).
+//
+// Kernels (hand-written HIP for CDNA4, wave64):
+//   tdfa_match_kernel : one log line per lane.  The pattern's tagged-DFA tables are staged once per workgroup
+//                       into LDS; every lane walks its own line with aligned 16-byte global loads, one
+//                       class lookup + one transition lookup (both LDS) per byte, and the few capture-offset
+//                       register moves attached to a transition.  Registers live in LDS as [reg][lane] so that
+//                       data-dependent register numbers never spill to scratch and never bank-conflict.
+//   nfa_match_kernel  : one log line per wavefront, one lane per live NFA thread (priority order == lane order);
+//                       follow lists in LDS, ballot/mbcnt compaction, ds_bpermute capture transfer.
+// Byte-scan work: no MFMA.  The bound that matters is LDS lookup throughput / latency, then HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_tables.h"
+#include "regex_handle.hpp"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string tlsError;
+static int hipFail(hipError_t e, const char* what) {
+    tlsError = std::string(what) + ": " + hipGetErrorString(e);
+    return LC_ERR_HIP;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hipFail(e_, #expr); \
+    } while (0)
+
+extern "C" const char* lc_last_error(void) { return tlsError.c_str(); }
+
+extern "C" int lc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ TDFA kernel
+constexpr int kTdfaBlock = 256;
+
+struct TdfaView {  // LDS byte offsets, wave-uniform
+    uint32_t cmap, trans, finalId, finalMap, opsStart, ops, regs;
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void tdfaRunOps(const uint8_t* smem, const TdfaView& v, uint32_t list, uint32_t pos,
+                                           uint32_t tid) {
+    const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(smem + v.opsStart);
+    const uint16_t* ops = reinterpret_cast<const uint16_t*>(smem + v.ops);
+    uint32_t* regs = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(smem) + v.regs);
+    uint32_t at = opsStart[list];
+    const uint32_t cnt = ops[at];
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t w = ops[at + 1 + i];
+        const uint32_t dst = w & 0xFF, src = w >> 8;
+        const uint32_t val = (src == TD_REG_POS) ? pos : regs[src * BLOCK + tid];
+        regs[dst * BLOCK + tid] = val;
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tdfa_match_kernel(const uint8_t* __restrict__ data,
+                                                           const uint32_t* __restrict__ off,
+                                                           const uint32_t* __restrict__ len, uint32_t sepBytes,
+                                                           uint32_t nLines, const uint32_t* __restrict__ blob,
+                                                           uint32_t blobBytes, uint32_t nGroupsOut,
+                                                           int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    {  // stage the tables: 16-byte coalesced copies
+        const uint4* src = reinterpret_cast<const uint4*>(blob);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
+    TdfaView v;
+    v.cmap = hdr[TD_OFF_CLASSMAP];
+    v.trans = hdr[TD_OFF_TRANS];
+    v.finalId = hdr[TD_OFF_FINALID];
+    v.finalMap = hdr[TD_OFF_FINALMAP];
+    v.opsStart = hdr[TD_OFF_OPSSTART];
+    v.ops = hdr[TD_OFF_OPS];
+    v.regs = blobBytes;
+    const uint32_t nSlots = hdr[TD_NSLOTS];
+    const uint32_t rowBytes = hdr[TD_ROW_BYTES];
+    uint32_t row = hdr[TD_START_ROW];
+
+    const uint32_t line = blockIdx.x * BLOCK + tid;
+    const bool live = line < nLines;
+    uint32_t o = 0, L = 0;
+    if (live) {
+        o = off[line];
+        L = len ? len[line] : off[line + 1] - o - sepBytes;
+    }
+    const uint16_t* cmap = reinterpret_cast<const uint16_t*>(smem + v.cmap);
+    const uint8_t* transBase = smem + v.trans;
+
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* chunk = reinterpret_cast<const uint4*>(addr - head);
+    uint32_t nChunks = L ? (head + L + 15) / 16 : 0;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (nChunks) cur = chunk[0];
+    uint32_t base = 0u - head;  // offset within the line of byte 0 of the current chunk (wraps for the head)
+
+#define LC_TDFA_STEP(word, shift, j)                                                               \
+    {                                                                                              \
+        const uint32_t pos = base + (j);                                                           \
+        if (pos < L) {                                                                             \
+            const uint32_t b = ((word) >> (shift)) & 0xFFu;                                        \
+            const uint32_t t = *reinterpret_cast<const uint32_t*>(transBase + row + cmap[b]);      \
+            if (t >> TD_LIST_SHIFT) tdfaRunOps<BLOCK>(smem, v, t >> TD_LIST_SHIFT, pos, tid);       \
+            row = t & TD_ROW_MASK;                                                                 \
+        }                                                                                          \
+    }
+#define LC_TDFA_WORD(word, j0)      \
+    LC_TDFA_STEP(word, 0, (j0))     \
+    LC_TDFA_STEP(word, 8, (j0) + 1) \
+    LC_TDFA_STEP(word, 16, (j0) + 2) \
+    LC_TDFA_STEP(word, 24, (j0) + 3)
+
+    for (uint32_t k = 0; k < nChunks; ++k) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (k + 1 < nChunks) nxt = chunk[k + 1];  // prefetch the next 16 bytes while this chunk is stepped
+        LC_TDFA_WORD(cur.x, 0)
+        LC_TDFA_WORD(cur.y, 4)
+        LC_TDFA_WORD(cur.z, 8)
+        LC_TDFA_WORD(cur.w, 12)
+        base += 16;
+        cur = nxt;
+        if (row == 0) break;  // dead state: regex_match can no longer succeed for this line
+    }
+#undef LC_TDFA_WORD
+#undef LC_TDFA_STEP
+
+    if (!live) return;
+    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + v.finalId);
+    const uint8_t* finalMap = smem + v.finalMap;
+    const uint32_t* regs = reinterpret_cast<const uint32_t*>(smem + v.regs);
+    const uint32_t state = row / rowBytes;
+    const uint32_t fid = finalId[state];
+    const bool matched = (row != 0) && (fid != 0xFFFFu);
+    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
+    for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) {
+        int32_t val = -1;
+        if (matched && s < nSlots) {
+            const uint32_t m = finalMap[fid * nSlots + s];
+            if (m == TD_REG_POS) val = int32_t(L);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid]);
+        }
+        out[s] = val;
+    }
+    status[line] = matched ? LC_MATCH : LC_NOMATCH;
+}
+
+// ------------------------------------------------------------------------------------------------ device tables
+static int ensureUploaded(lc_regex* re, int dev, bool tdfa, void** out) {
+    std::lock_guard<std::mutex> g(re->deviceMutex);
+    void** slot = tdfa ? &re->dTdfaBlob[dev] : &re->dNfaBlob[dev];
+    if (!*slot) {
+        const std::vector<uint32_t>& blob = tdfa ? re->tdfaBlob : re->nfaBlob;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, blob.size() * 4));
+        hipError_t e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return hipFail(e, "hipMemcpy(tables)");
+        }
+        *slot = p;
+    }
+    *out = *slot;
+    return LC_OK;
+}
+
+void lcReleaseDeviceTables(lc_regex* re) {
+    int cur = 0;
+    bool haveCur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < kLcMaxDevices; ++d) {
+        if (re->dTdfaBlob[d] || re->dNfaBlob[d]) {
+            if (hipSetDevice(d) == hipSuccess) {
+                if (re->dTdfaBlob[d]) (void)hipFree(re->dTdfaBlob[d]);
+                if (re->dNfaBlob[d]) (void)hipFree(re->dNfaBlob[d]);
+            }
+            re->dTdfaBlob[d] = re->dNfaBlob[d] = nullptr;
+        }
+    }
+    if (haveCur) (void)hipSetDevice(cur);
+}
+
+static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                      uint32_t sep, uint32_t n, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
+                      hipStream_t stream) {
+    void* dBlob = nullptr;
+    int rc = ensureUploaded(re, dev, true, &dBlob);
+    if (rc != LC_OK) return rc;
+    const uint32_t blobBytes = uint32_t(re->tdfaBlob.size() * 4);
+    const size_t lds = size_t(blobBytes) + size_t(re->tdfa.nRegs) * kTdfaBlock * 4;
+    if (lds > 160 * 1024) {
+        tlsError = "tdfa tables + registers exceed LDS";
+        return LC_ERR_UNSUPPORTED;
+    }
+    static thread_local size_t ldsAttrSet = 0;
+    if (lds > 64 * 1024 && lds > ldsAttrSet) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<kTdfaBlock>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        ldsAttrSet = lds;
+    }
+    const uint32_t grid = (n + kTdfaBlock - 1) / kTdfaBlock;
+    hipLaunchKernelGGL(tdfa_match_kernel<kTdfaBlock>, dim3(grid), dim3(kTdfaBlock), lds, stream, d_data, d_off, d_len,
+                       sep, n, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
+}
+
+extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t* d_off,
+                                     const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
+                                     int32_t* d_caps, uint8_t* d_status, void* stream) {
+    if (!re || (!d_data && n) || !d_off || !d_caps || !d_status) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    if (re->engine == LC_ENGINE_TDFA)
+        return launchTdfa(re, dev, d_data, d_off, d_len, sep_bytes, n, ngroups, d_caps, d_status,
+                          static_cast<hipStream_t>(stream));
+    tlsError = "NFA engine kernel not built in this revision";
+    return LC_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------ host batches
+namespace {
+
+struct Slot {
+    uint8_t* hData = nullptr;  // pinned
+    uint32_t* hOff = nullptr;
+    uint32_t* hLen = nullptr;
+    int32_t* hCaps = nullptr;
+    uint8_t* hStatus = nullptr;
+    uint8_t* dData = nullptr;
+    uint32_t* dOff = nullptr;
+    uint32_t* dLen = nullptr;
+    int32_t* dCaps = nullptr;
+    uint8_t* dStatus = nullptr;
+    size_t dataCap = 0, lineCap = 0, capsCap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    // what is in flight
+    uint32_t first = 0, count = 0;
+    bool busy = false;
+};
+
+struct HostPipeline {
+    int device = -1;
+    Slot slots[2];
+    ~HostPipeline() { release(); }
+    void release() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        for (auto& s : slots) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            (void)hipHostFree(s.hData); (void)hipHostFree(s.hOff); (void)hipHostFree(s.hLen);
+            (void)hipHostFree(s.hCaps); (void)hipHostFree(s.hStatus);
+            (void)hipFree(s.dData); (void)hipFree(s.dOff); (void)hipFree(s.dLen);
+            (void)hipFree(s.dCaps); (void)hipFree(s.dStatus);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            s = Slot();
+        }
+        device = -1;
+    }
+};
+
+constexpr size_t kChunkBytes = 32u << 20;   // payload bytes per pipelined chunk
+constexpr uint32_t kChunkLines = 1u << 18;  // and at most this many lines
+
+int growSlot(Slot& s, size_t dataBytes, size_t lines, size_t capsInts) {
+    if (!s.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    if (dataBytes > s.dataCap) {
+        (void)hipHostFree(s.hData); (void)hipFree(s.dData);
+        s.hData = nullptr; s.dData = nullptr; s.dataCap = 0;
+        size_t cap = dataBytes + (dataBytes >> 2) + 4096;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hData), cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dData), cap));
+        s.dataCap = cap;
+    }
+    if (lines > s.lineCap) {
+        (void)hipHostFree(s.hOff); (void)hipHostFree(s.hLen); (void)hipHostFree(s.hStatus);
+        (void)hipFree(s.dOff); (void)hipFree(s.dLen); (void)hipFree(s.dStatus);
+        s.hOff = s.hLen = nullptr; s.hStatus = nullptr; s.dOff = s.dLen = nullptr; s.dStatus = nullptr; s.lineCap = 0;
+        size_t cap = lines + (lines >> 2) + 64;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hOff), cap * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hLen), cap * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hStatus), cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dOff), cap * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dLen), cap * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dStatus), cap));
+        s.lineCap = cap;
+    }
+    if (capsInts > s.capsCap) {
+        (void)hipHostFree(s.hCaps); (void)hipFree(s.dCaps);
+        s.hCaps = nullptr; s.dCaps = nullptr; s.capsCap = 0;
+        size_t cap = capsInts + (capsInts >> 2) + 64;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hCaps), cap * 4, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dCaps), cap * 4));
+        s.capsCap = cap;
+    }
+    return LC_OK;
+}
+
+int drainSlot(Slot& s, uint32_t ngroups, int32_t* caps, uint8_t* status) {
+    if (!s.busy) return LC_OK;
+    HIP_TRY(hipEventSynchronize(s.done));
+    std::memcpy(caps + size_t(s.first) * 2 * ngroups, s.hCaps, size_t(s.count) * 2 * ngroups * 4);
+    std::memcpy(status + s.first, s.hStatus, s.count);
+    s.busy = false;
+    return LC_OK;
+}
+
+}  // namespace
+
+extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len,
+                                   uint32_t n, uint32_t ngroups, int32_t* caps, uint8_t* status) {
+    if (!re || !off || !len || !caps || !status || (!data && n)) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static thread_local HostPipeline pipe;
+    if (pipe.device != dev) {
+        pipe.release();
+        pipe.device = dev;
+    }
+    uint32_t next = 0;
+    int which = 0;
+    int rc = LC_OK;
+    while (next < n) {
+        // carve a chunk: up to kChunkLines lines / kChunkBytes payload bytes
+        uint32_t cnt = 0;
+        size_t bytes = 0;
+        while (next + cnt < n && cnt < kChunkLines && (cnt == 0 || bytes + len[next + cnt] <= kChunkBytes)) {
+            bytes += len[next + cnt];
+            ++cnt;
+        }
+        Slot& s = pipe.slots[which];
+        if ((rc = drainSlot(s, ngroups, caps, status)) != LC_OK) return rc;
+        // contiguous fast path: the chunk's lines sit back to back (what ProcessorSplitLogStringNative leaves)
+        const uint32_t lo = off[next];
+        const uint64_t hi = uint64_t(off[next + cnt - 1]) + len[next + cnt - 1];
+        bool contiguous = hi >= lo && (hi - lo) <= bytes + 2ull * cnt;
+        if (contiguous)
+            for (uint32_t i = 1; i < cnt && contiguous; ++i) contiguous = off[next + i] >= off[next + i - 1];
+        const size_t stageBytes = contiguous ? size_t(hi - lo) : bytes;
+        if ((rc = growSlot(s, stageBytes + 16, cnt, size_t(cnt) * 2 * ngroups)) != LC_OK) return rc;
+        if (contiguous) {
+            std::memcpy(s.hData, data + lo, stageBytes);
+            for (uint32_t i = 0; i < cnt; ++i) {
+                s.hOff[i] = off[next + i] - lo;
+                s.hLen[i] = len[next + i];
+            }
+        } else {
+            size_t at = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                std::memcpy(s.hData + at, data + off[next + i], len[next + i]);
+                s.hOff[i] = uint32_t(at);
+                s.hLen[i] = len[next + i];
+                at += len[next + i];
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(s.dData, s.hData, stageBytes, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.dOff, s.hOff, size_t(cnt) * 4, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.dLen, s.hLen, size_t(cnt) * 4, hipMemcpyHostToDevice, s.stream));
+        rc = lc_regex_match_device(re, s.dData, s.dOff, s.dLen, 0, cnt, ngroups, s.dCaps, s.dStatus, s.stream);
+        if (rc != LC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s.hCaps, s.dCaps, size_t(cnt) * 2 * ngroups * 4, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.hStatus, s.dStatus, cnt, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipEventRecord(s.done, s.stream));
+        s.first = next;
+        s.count = cnt;
+        s.busy = true;
+        next += cnt;
+        which ^= 1;
+    }
+    for (auto& s : pipe.slots)
+        if ((rc = drainSlot(s, ngroups, caps, status)) != LC_OK) return rc;
+    return LC_OK;
+}

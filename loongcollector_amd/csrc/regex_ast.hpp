@@ -1,0 +1,92 @@
+// regex_ast.hpp -- Perl-syntax regex front-end for the MI355X parse processor (host side, C++17).
+//
+// Replaces the *compile* half of boost::regex on the reference hot path:
+//   mReg.emplace_back(mRegex)            core/plugin/processor/ProcessorParseRegexNative.cpp:64-67
+//   IsRegexValid(regex)                   core/common/ParamExtractor.cpp:199-209
+// The accepted language is the subset of Boost.Regex Perl syntax that is regular (no back-references,
+// look-around, atomic groups or recursion); anything else is reported as RegexError so that plugin Init
+// fails loudly, exactly where the reference would reject an invalid regex.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace lcregex {
+
+struct RegexError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// 256-bit byte set
+struct ByteSet {
+    std::array<uint64_t, 4> w{{0, 0, 0, 0}};
+    void add(unsigned c) { w[(c >> 6) & 3] |= uint64_t(1) << (c & 63); }
+    void addRange(unsigned lo, unsigned hi) {
+        for (unsigned c = lo; c <= hi; ++c) add(c);
+    }
+    bool has(unsigned c) const { return (w[(c >> 6) & 3] >> (c & 63)) & 1; }
+    void unite(const ByteSet& o) {
+        for (int i = 0; i < 4; ++i) w[i] |= o.w[i];
+    }
+    void invert() {
+        for (auto& x : w) x = ~x;
+    }
+    bool empty() const { return !(w[0] | w[1] | w[2] | w[3]); }
+    bool operator==(const ByteSet& o) const { return w == o.w; }
+    bool operator<(const ByteSet& o) const { return w < o.w; }
+    static ByteSet all() {
+        ByteSet s;
+        s.invert();
+        return s;
+    }
+};
+
+// Syntax options; defaults reproduce `boost::regex(str)`: Perl syntax, '.' matches '\n' (mod_s), '^'/'$' match at
+// embedded line separators (mod_m).
+struct Syntax {
+    bool icase = false;
+    bool dotAll = true;
+    bool multiLine = true;
+    bool extended = false;
+    bool namedOnly = false;  // unnamed (...) groups do not capture (Grok semantics: only named groups are emitted)
+};
+
+enum class AssertKind : uint8_t {
+    BolMulti,    // ^  with mod_m: start of buffer or after \n \r \f (never between \r\n)
+    BolSingle,   // ^  with (?-m), \A, \`
+    EolMulti,    // $  with mod_m
+    EolSingle,   // $  with (?-m), \z, \'
+    WordBoundary,
+    NotWordBoundary,
+    WordStart,   // \<
+    WordEnd,     // \>
+    kCount
+};
+
+struct Node {
+    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert } kind = Empty;
+    std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group: 1
+    ByteSet set;                               // Set
+    int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
+    bool greedy = true;                        // Repeat
+    int capture = 0;                           // Group: 1-based capture index, 0 = non-capturing
+    AssertKind assertKind = AssertKind::BolMulti;
+};
+
+struct ParsedRegex {
+    std::unique_ptr<Node> root;
+    int groupCount = 0;                    // == boost::basic_regex::mark_count()
+    std::vector<std::string> groupNames;   // [0] unused; "" when unnamed
+};
+
+ParsedRegex parseRegex(std::string_view pattern, Syntax syntax = Syntax());
+
+bool isWordByte(unsigned c);
+bool isLineSeparator(unsigned c);  // \n \r \f  (Boost is_separator<char>)
+
+}  // namespace lcregex

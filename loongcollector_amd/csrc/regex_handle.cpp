@@ -1,0 +1,247 @@
+// regex_handle.cpp -- host half of the C ABI: compile a pattern into device table blobs (no HIP calls here).
+#include "regex_handle.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "device_tables.h"
+
+namespace lcregex {
+
+namespace {
+struct BlobWriter {
+    std::vector<uint8_t> bytes;
+    uint32_t reserve(size_t n) {
+        size_t at = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(at + n, 0);
+        return uint32_t(at);
+    }
+    template <class T>
+    uint32_t put(const std::vector<T>& v) {
+        uint32_t at = reserve(v.size() * sizeof(T));
+        if (!v.empty()) std::memcpy(bytes.data() + at, v.data(), v.size() * sizeof(T));
+        return at;
+    }
+    std::vector<uint32_t> finish(uint32_t totalIndex) {
+        size_t total = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(total, 0);
+        std::vector<uint32_t> out(total / 4);
+        std::memcpy(out.data(), bytes.data(), total);
+        out[totalIndex] = uint32_t(total);
+        return out;
+    }
+};
+}  // namespace
+
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t) {
+    const uint32_t rowBytes = t.nClasses * 4;
+    if (uint64_t(t.nStates) * rowBytes > (TD_ROW_MASK + 1ull)) throw RegexError("tdfa: transition table too large");
+    if (t.opsStart.size() - 1 > (1u << (32 - TD_LIST_SHIFT))) throw RegexError("tdfa: too many register programs");
+    BlobWriter w;
+    w.reserve(TD_HEADER_WORDS * 4);
+    std::vector<uint16_t> cmap(256);
+    for (int b = 0; b < 256; ++b) cmap[size_t(b)] = uint16_t(t.classMap[size_t(b)] * 4);
+    std::vector<uint32_t> trans(t.trans.size());
+    for (size_t i = 0; i < t.trans.size(); ++i) {
+        uint32_t next = t.trans[i] & 0xFFFF, list = t.trans[i] >> 16;
+        trans[i] = (next * rowBytes) | (list << TD_LIST_SHIFT);
+    }
+    uint32_t hdr[TD_HEADER_WORDS] = {};
+    hdr[TD_MAGIC] = TD_MAGIC_VALUE;
+    hdr[TD_NSTATES] = t.nStates;
+    hdr[TD_NCLASSES] = t.nClasses;
+    hdr[TD_NREGS] = t.nRegs;
+    hdr[TD_NSLOTS] = t.nSlots;
+    hdr[TD_START_ROW] = t.startState * rowBytes;
+    hdr[TD_ROW_BYTES] = rowBytes;
+    hdr[TD_OFF_CLASSMAP] = w.put(cmap);
+    hdr[TD_OFF_TRANS] = w.put(trans);
+    hdr[TD_OFF_FINALID] = w.put(t.finalId);
+    hdr[TD_OFF_FINALMAP] = w.put(t.finalMap);
+    hdr[TD_OFF_OPSSTART] = w.put(t.opsStart);
+    hdr[TD_OFF_OPS] = w.put(t.ops);
+    std::memcpy(w.bytes.data(), hdr, sizeof hdr);
+    return w.finish(TD_TOTAL_BYTES);
+}
+
+std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut) {
+    const int npos = int(nfa.positions.size());
+    classMapOut.assign(256, 0);
+    std::map<std::vector<bool>, int> sig2cls;
+    std::vector<unsigned> rep;
+    for (unsigned b = 0; b < 256; ++b) {
+        std::vector<bool> sig;
+        for (int p = 0; p < npos; ++p) sig.push_back(nfa.positions[size_t(p)].has(b));
+        if (nfa.condsUsed) {
+            sig.push_back(isWordByte(b));
+            sig.push_back(isLineSeparator(b));
+            sig.push_back(b == '\r');
+            sig.push_back(b == '\n');
+        }
+        auto it = sig2cls.find(sig);
+        if (it == sig2cls.end()) {
+            it = sig2cls.emplace(sig, int(rep.size())).first;
+            rep.push_back(b);
+        }
+        classMapOut[b] = uint8_t(it->second);
+    }
+    if (rep.size() > 64) throw RegexError("nfa: more than 64 byte classes");
+    std::vector<uint32_t> posMask(size_t(npos) * 2 + 2, 0);
+    for (int p = 0; p < npos; ++p) {
+        uint64_t m = 0;
+        for (size_t c = 0; c < rep.size(); ++c)
+            if (nfa.positions[size_t(p)].has(rep[c])) m |= uint64_t(1) << c;
+        posMask[size_t(p) * 2] = uint32_t(m);
+        posMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+    }
+    std::vector<uint32_t> followStart, paths;
+    for (int p = 0; p <= npos; ++p) {
+        followStart.push_back(uint32_t(paths.size() / 4));
+        for (const auto& path : nfa.follow[size_t(p)]) {
+            paths.push_back(path.target == kMatchTarget ? NF_TARGET_MATCH : uint32_t(path.target));
+            paths.push_back(path.cond);
+            paths.push_back(uint32_t(path.tags));
+            paths.push_back(uint32_t(path.tags >> 32));
+        }
+    }
+    followStart.push_back(uint32_t(paths.size() / 4));
+    BlobWriter w;
+    w.reserve(NF_HEADER_WORDS * 4);
+    uint32_t hdr[NF_HEADER_WORDS] = {};
+    hdr[NF_MAGIC] = NF_MAGIC_VALUE;
+    hdr[NF_NPOS] = uint32_t(npos);
+    hdr[NF_NSLOTS] = uint32_t(nfa.slotCount());
+    hdr[NF_NCLASSES] = uint32_t(rep.size());
+    hdr[NF_NPATHS] = uint32_t(paths.size() / 4);
+    hdr[NF_CONDS_USED] = nfa.condsUsed;
+    hdr[NF_OFF_CLASSMAP] = w.put(classMapOut);
+    hdr[NF_OFF_POSMASK] = w.put(posMask);
+    hdr[NF_OFF_FOLLOWSTART] = w.put(followStart);
+    hdr[NF_OFF_PATHS] = w.put(paths);
+    std::memcpy(w.bytes.data(), hdr, sizeof hdr);
+    return w.finish(NF_TOTAL_BYTES);
+}
+
+}  // namespace lcregex
+
+using namespace lcregex;
+
+static void setErr(char* err, size_t cap, const std::string& msg) {
+    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,
+                                lc_regex_t** out, char* err, size_t errcap) {
+    if (!pattern || !out || engine < LC_ENGINE_AUTO || engine > LC_ENGINE_NFA) {
+        setErr(err, errcap, "bad argument");
+        return LC_ERR_ARG;
+    }
+    *out = nullptr;
+    Syntax syn;
+    syn.icase = syntax_flags & LC_SYNTAX_ICASE;
+    syn.dotAll = !(syntax_flags & LC_SYNTAX_NO_DOTALL);
+    syn.multiLine = !(syntax_flags & LC_SYNTAX_NO_MULTILINE);
+    syn.extended = syntax_flags & LC_SYNTAX_EXTENDED;
+    syn.namedOnly = syntax_flags & LC_SYNTAX_NAMED_ONLY;
+    auto re = new lc_regex();
+    re->pattern.assign(pattern, pattern_len);
+    re->syntaxFlags = syntax_flags;
+    try {
+        ParsedRegex parsed;
+        try {
+            parsed = parseRegex(std::string_view(pattern, pattern_len), syn);
+        } catch (const RegexError& e) {
+            const bool unsupported = std::strstr(e.what(), "unsupported") != nullptr;
+            setErr(err, errcap, e.what());
+            delete re;
+            return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
+        }
+        re->nfa = buildFollowNfa(parsed);
+        if (engine != LC_ENGINE_NFA) {
+            try {
+                re->tdfa = buildTdfa(re->nfa);
+                re->tdfaBlob = packTdfaBlob(re->tdfa);
+                re->hasTdfa = true;
+                re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
+                                  re->tdfa.startState, 0, 0, 0};
+            } catch (const RegexError& e) {
+                if (engine == LC_ENGINE_TDFA) throw;
+                re->tdfaError = e.what();
+            }
+        }
+        if (re->hasTdfa) {
+            re->engine = LC_ENGINE_TDFA;
+        } else {
+            re->engine = LC_ENGINE_NFA;
+        }
+        // the NFA blob is always packed when it fits: tests cross-check both engines on one handle
+        try {
+            re->nfaBlob = packNfaBlob(re->nfa, re->nfaClassMap);
+        } catch (const RegexError&) {
+            if (re->engine == LC_ENGINE_NFA) throw;
+        }
+    } catch (const RegexError& e) {
+        setErr(err, errcap, e.what());
+        delete re;
+        return LC_ERR_UNSUPPORTED;
+    } catch (const std::exception& e) {
+        setErr(err, errcap, e.what());
+        delete re;
+        return LC_ERR_UNSUPPORTED;
+    }
+    setErr(err, errcap, "");
+    *out = re;
+    return LC_OK;
+}
+
+extern "C" void lc_regex_free(lc_regex_t* re) {
+    if (!re) return;
+    lcReleaseDeviceTables(re);
+    delete re;
+}
+
+extern "C" int lc_regex_mark_count(const lc_regex_t* re) { return re ? re->nfa.groupCount : -1; }
+
+extern "C" const char* lc_regex_group_name(const lc_regex_t* re, int g) {
+    if (!re || g < 1 || g > re->nfa.groupCount) return nullptr;
+    const std::string& s = re->nfa.groupNames[size_t(g)];
+    return s.empty() ? nullptr : s.c_str();
+}
+
+extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
+    if (!re || !out) return LC_ERR_ARG;
+    out->engine = re->engine;
+    out->mark_count = re->nfa.groupCount;
+    out->positions = uint32_t(re->nfa.positions.size());
+    out->states = re->hasTdfa ? re->tdfa.nStates : 0;
+    out->classes = re->hasTdfa ? re->tdfa.nClasses : (re->nfaBlob.empty() ? 0 : re->nfaBlob[NF_NCLASSES]);
+    out->registers = re->hasTdfa ? re->tdfa.nRegs : 0;
+    out->table_bytes = uint32_t((re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
+    return LC_OK;
+}
+
+extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes) {
+    if (!re || !data || !bytes) return LC_ERR_ARG;
+    auto view = [&](const void* p, size_t n) {
+        *data = p;
+        *bytes = n;
+        return LC_OK;
+    };
+    if (which == LC_TABLE_NFA_BLOB) {
+        if (re->nfaBlob.empty()) return LC_ERR_ARG;
+        return view(re->nfaBlob.data(), re->nfaBlob.size() * 4);
+    }
+    if (!re->hasTdfa) return LC_ERR_ARG;
+    const TdfaTables& t = re->tdfa;
+    switch (which) {
+        case LC_TABLE_CLASSMAP: return view(t.classMap.data(), t.classMap.size());
+        case LC_TABLE_TDFA_TRANS: return view(t.trans.data(), t.trans.size() * 4);
+        case LC_TABLE_TDFA_OPSSTART: return view(t.opsStart.data(), t.opsStart.size() * 4);
+        case LC_TABLE_TDFA_OPS: return view(t.ops.data(), t.ops.size() * 2);
+        case LC_TABLE_TDFA_FINALID: return view(t.finalId.data(), t.finalId.size() * 2);
+        case LC_TABLE_TDFA_FINALMAP: return view(t.finalMap.data(), t.finalMap.size());
+        case LC_TABLE_TDFA_HEADER: return view(re->tdfaHeader.data(), re->tdfaHeader.size() * 4);
+        default: return LC_ERR_ARG;
+    }
+}

@@ -1,0 +1,41 @@
+// regex_handle.hpp -- the object behind lc_regex_t: compiled tables (host) + per-device copies.
+#pragma once
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lc_regex_gpu.h"
+#include "follow_nfa.hpp"
+#include "tdfa.hpp"
+
+constexpr int kLcMaxDevices = 16;
+
+struct lc_regex {
+    std::string pattern;
+    uint32_t syntaxFlags = 0;
+    int engine = LC_ENGINE_TDFA;
+    lcregex::FollowNfa nfa;
+    bool hasTdfa = false;
+    lcregex::TdfaTables tdfa;
+    std::vector<uint32_t> tdfaHeader;   // LC_TABLE_TDFA_HEADER view
+    std::vector<uint32_t> tdfaBlob;     // device_tables.h TDFA layout
+    std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
+    std::vector<uint8_t> nfaClassMap;
+    std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
+
+    // device residency, managed by gpu_runtime.hip
+    std::mutex deviceMutex;
+    void* dTdfaBlob[kLcMaxDevices] = {};
+    void* dNfaBlob[kLcMaxDevices] = {};
+};
+
+namespace lcregex {
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t);
+// throws RegexError when the NFA does not fit the device format (more than 64 byte classes)
+std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);
+}  // namespace lcregex
+
+// implemented in gpu_runtime.hip; frees device copies
+void lcReleaseDeviceTables(lc_regex* re);

@@ -1,0 +1,581 @@
+// regex_parse.cpp -- recursive-descent parser: pattern bytes -> lcregex::Node tree.
+// See regex_ast.hpp for what this replaces on the reference path.
+#include <cstring>
+
+#include "regex_ast.hpp"
+
+namespace lcregex {
+
+bool isWordByte(unsigned c) {
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
+}
+bool isLineSeparator(unsigned c) { return c == '\n' || c == '\r' || c == '\f'; }
+
+namespace {
+
+using NodePtr = std::unique_ptr<Node>;
+
+NodePtr mk(Node::Kind k) {
+    auto n = std::make_unique<Node>();
+    n->kind = k;
+    return n;
+}
+
+void foldCase(ByteSet& s) {
+    for (unsigned c = 'a'; c <= 'z'; ++c) {
+        if (s.has(c) || s.has(c - 32)) {
+            s.add(c);
+            s.add(c - 32);
+        }
+    }
+}
+
+// shorthand classes keyed by the lower-case escape letter
+bool shorthand(char letter, ByteSet& out) {
+    switch (letter) {
+        case 'd': out.addRange('0', '9'); return true;
+        case 'w':
+            out.addRange('0', '9');
+            out.addRange('a', 'z');
+            out.addRange('A', 'Z');
+            out.add('_');
+            return true;
+        case 's':
+            out.add(' ');
+            out.addRange(9, 13);
+            return true;
+        case 'h':
+            out.add(' ');
+            out.add('\t');
+            return true;
+        case 'v': out.addRange(10, 13); return true;
+        case 'l': out.addRange('a', 'z'); return true;
+        case 'u': out.addRange('A', 'Z'); return true;
+        default: return false;
+    }
+}
+
+bool posixClass(std::string_view name, ByteSet& out) {
+    struct Entry {
+        const char* name;
+        void (*fill)(ByteSet&);
+    };
+    static const Entry table[] = {
+        {"alpha", [](ByteSet& s) { s.addRange('a', 'z'); s.addRange('A', 'Z'); }},
+        {"digit", [](ByteSet& s) { s.addRange('0', '9'); }},
+        {"d", [](ByteSet& s) { s.addRange('0', '9'); }},
+        {"alnum", [](ByteSet& s) { s.addRange('a', 'z'); s.addRange('A', 'Z'); s.addRange('0', '9'); }},
+        {"upper", [](ByteSet& s) { s.addRange('A', 'Z'); }},
+        {"u", [](ByteSet& s) { s.addRange('A', 'Z'); }},
+        {"lower", [](ByteSet& s) { s.addRange('a', 'z'); }},
+        {"l", [](ByteSet& s) { s.addRange('a', 'z'); }},
+        {"space", [](ByteSet& s) { s.add(' '); s.addRange(9, 13); }},
+        {"s", [](ByteSet& s) { s.add(' '); s.addRange(9, 13); }},
+        {"blank", [](ByteSet& s) { s.add(' '); s.add('\t'); }},
+        {"punct", [](ByteSet& s) { s.addRange(33, 47); s.addRange(58, 64); s.addRange(91, 96); s.addRange(123, 126); }},
+        {"print", [](ByteSet& s) { s.addRange(32, 126); }},
+        {"graph", [](ByteSet& s) { s.addRange(33, 126); }},
+        {"cntrl", [](ByteSet& s) { s.addRange(0, 31); s.add(127); }},
+        {"xdigit", [](ByteSet& s) { s.addRange('0', '9'); s.addRange('a', 'f'); s.addRange('A', 'F'); }},
+        {"word", [](ByteSet& s) { shorthand('w', s); }},
+        {"w", [](ByteSet& s) { shorthand('w', s); }},
+    };
+    for (const auto& e : table) {
+        if (name == e.name) {
+            e.fill(out);
+            return true;
+        }
+    }
+    return false;
+}
+
+int hexDigit(unsigned c) {
+    if (c >= '0' && c <= '9') return int(c - '0');
+    if (c >= 'a' && c <= 'f') return int(c - 'a' + 10);
+    if (c >= 'A' && c <= 'F') return int(c - 'A' + 10);
+    return -1;
+}
+
+class Parser {
+public:
+    Parser(std::string_view p, Syntax s) : mPat(p), mSyn(s) { mNames.emplace_back(); }
+
+    ParsedRegex run() {
+        NodePtr root = alternation(0);
+        if (!atEnd()) bail(peek() == ')' ? "unmatched )" : "unexpected character");
+        ParsedRegex out;
+        out.root = std::move(root);
+        out.groupCount = mGroups;
+        out.groupNames = std::move(mNames);
+        return out;
+    }
+
+private:
+    std::string_view mPat;
+    size_t mPos = 0;
+    Syntax mSyn;
+    int mGroups = 0;
+    std::vector<std::string> mNames;
+
+    bool atEnd() const { return mPos >= mPat.size(); }
+    unsigned peek(size_t ahead = 0) const { return static_cast<unsigned char>(mPat[mPos + ahead]); }
+    bool has(size_t ahead) const { return mPos + ahead < mPat.size(); }
+    [[noreturn]] void bail(const std::string& what) const {
+        throw RegexError(what + " at offset " + std::to_string(mPos));
+    }
+
+    void skipFreeSpacing() {
+        if (!mSyn.extended) return;
+        while (!atEnd()) {
+            unsigned c = peek();
+            if (c == ' ' || (c >= 9 && c <= 13)) {
+                ++mPos;
+            } else if (c == '#') {
+                while (!atEnd() && peek() != '\n') ++mPos;
+            } else {
+                break;
+            }
+        }
+    }
+
+    NodePtr literal(unsigned c) {
+        auto n = mk(Node::Set);
+        n->set.add(c);
+        if (mSyn.icase) foldCase(n->set);
+        return n;
+    }
+
+    NodePtr assertion(AssertKind k) {
+        auto n = mk(Node::Assert);
+        n->assertKind = k;
+        return n;
+    }
+
+    // single-byte escapes shared by atoms and classes; mPos is just past the escape letter.  -1: not one.
+    int byteEscape(unsigned letter) {
+        switch (letter) {
+            case 't': return '\t';
+            case 'n': return '\n';
+            case 'r': return '\r';
+            case 'f': return '\f';
+            case 'e': return 27;
+            case 'a': return 7;
+            case 'x': {
+                if (!atEnd() && peek() == '{') {
+                    size_t j = mPos + 1;
+                    int v = 0, digits = 0;
+                    while (j < mPat.size() && hexDigit(static_cast<unsigned char>(mPat[j])) >= 0 && v <= 255) {
+                        v = v * 16 + hexDigit(static_cast<unsigned char>(mPat[j]));
+                        ++j;
+                        ++digits;
+                    }
+                    if (!digits || j >= mPat.size() || mPat[j] != '}' || v > 255) bail("bad \\x{..} escape");
+                    mPos = j + 1;
+                    return v;
+                }
+                int v = 0, digits = 0;
+                while (digits < 2 && !atEnd() && hexDigit(peek()) >= 0) {
+                    v = v * 16 + hexDigit(peek());
+                    ++mPos;
+                    ++digits;
+                }
+                if (!digits) bail("bad \\x escape");
+                return v;
+            }
+            case '0': {
+                int v = 0, digits = 0;
+                while (digits < 3 && !atEnd() && peek() >= '0' && peek() <= '7') {
+                    v = v * 8 + int(peek() - '0');
+                    ++mPos;
+                    ++digits;
+                }
+                if (v > 255) bail("octal escape out of range");
+                return v;
+            }
+            case 'c': {
+                if (atEnd()) bail("bad \\c escape");
+                unsigned v = peek();
+                ++mPos;
+                return int(v % 32);
+            }
+            default: return -1;
+        }
+    }
+
+    NodePtr bracketClass() {  // mPos just past '['
+        ByteSet acc;
+        bool negate = false;
+        if (!atEnd() && peek() == '^') {
+            negate = true;
+            ++mPos;
+        }
+        bool first = true;
+        for (;;) {
+            if (atEnd()) bail("unterminated character class");
+            unsigned c = peek();
+            if (c == ']' && !first) {
+                ++mPos;
+                break;
+            }
+            first = false;
+            int lo = -1;
+            if (c == '[' && has(1) && (peek(1) == ':' || peek(1) == '=' || peek(1) == '.')) {
+                unsigned kind = peek(1);
+                size_t j = mPos + 2;
+                while (j + 1 < mPat.size() && !(static_cast<unsigned char>(mPat[j]) == kind && mPat[j + 1] == ']')) ++j;
+                if (j + 1 >= mPat.size()) bail("unterminated [: :] in class");
+                if (kind != ':') bail("collating elements unsupported");
+                std::string_view name = mPat.substr(mPos + 2, j - (mPos + 2));
+                bool neg = false;
+                if (!name.empty() && name[0] == '^') {
+                    neg = true;
+                    name.remove_prefix(1);
+                }
+                ByteSet t;
+                if (!posixClass(name, t)) bail("unknown POSIX class");
+                if (neg) t.invert();
+                acc.unite(t);
+                mPos = j + 2;
+                continue;
+            }
+            if (c == '\\') {
+                ++mPos;
+                if (atEnd()) bail("trailing backslash");
+                unsigned e = peek();
+                ++mPos;
+                ByteSet t;
+                if (shorthand(char(e), t)) {
+                    acc.unite(t);
+                    continue;
+                }
+                if (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), t)) {
+                    t.invert();
+                    acc.unite(t);
+                    continue;
+                }
+                if (e == 'b') {
+                    lo = 8;
+                } else {
+                    int v = byteEscape(e);
+                    lo = v >= 0 ? v : int(e);
+                }
+            } else {
+                lo = int(c);
+                ++mPos;
+            }
+            if (has(1) && peek() == '-' && peek(1) != ']') {
+                size_t dash = mPos;
+                ++mPos;
+                unsigned c2 = peek();
+                int hi;
+                if (c2 == '[' && has(1) && peek(1) == ':') {
+                    mPos = dash;
+                    acc.add(unsigned(lo));
+                    continue;
+                }
+                if (c2 == '\\') {
+                    ++mPos;
+                    if (atEnd()) bail("trailing backslash");
+                    unsigned e = peek();
+                    ++mPos;
+                    ByteSet dummy;
+                    if (shorthand(char(e), dummy) || (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), dummy)))
+                        bail("class escape as range endpoint");
+                    if (e == 'b') {
+                        hi = 8;
+                    } else {
+                        int v = byteEscape(e);
+                        hi = v >= 0 ? v : int(e);
+                    }
+                } else {
+                    hi = int(c2);
+                    ++mPos;
+                }
+                if (hi < lo) bail("invalid range in character class");
+                acc.addRange(unsigned(lo), unsigned(hi));
+            } else {
+                acc.add(unsigned(lo));
+            }
+        }
+        if (mSyn.icase) foldCase(acc);
+        if (negate) acc.invert();
+        auto n = mk(Node::Set);
+        n->set = acc;
+        return n;
+    }
+
+    NodePtr group(int depth) {  // mPos just past '('
+        Syntax saved = mSyn;
+        int capture = 0;
+        bool capturing = true;
+        std::string name;
+        if (!atEnd() && peek() == '?') {
+            ++mPos;
+            if (atEnd()) bail("unterminated group");
+            unsigned d = peek();
+            if (d == '#') {
+                while (!atEnd() && peek() != ')') ++mPos;
+                if (atEnd()) bail("unterminated comment");
+                ++mPos;
+                return mk(Node::Empty);
+            }
+            if (d == ':') {
+                ++mPos;
+                capturing = false;
+            } else if (d == '=' || d == '!' || d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' ||
+                       (d >= '0' && d <= '9')) {
+                bail("unsupported group construct (look-around/atomic/recursion/conditional)");
+            } else if (d == '<' || d == 'P' || d == '\'') {
+                char close = '>';
+                if (d == 'P') {
+                    ++mPos;
+                    if (atEnd() || peek() != '<') bail("unsupported (?P construct");
+                } else if (d == '\'') {
+                    close = '\'';
+                } else if (has(1) && (peek(1) == '=' || peek(1) == '!')) {
+                    bail("unsupported group construct (look-behind)");
+                }
+                ++mPos;
+                size_t j = mPos;
+                while (j < mPat.size() && mPat[j] != close) ++j;
+                if (j >= mPat.size() || j == mPos) bail("bad group name");
+                name = std::string(mPat.substr(mPos, j - mPos));
+                mPos = j + 1;
+            } else {
+                // inline option letters
+                Syntax next = mSyn;
+                bool on = true;
+                for (;; ++mPos) {
+                    if (atEnd()) bail("unterminated flag group");
+                    d = peek();
+                    if (d == '-') {
+                        on = false;
+                    } else if (d == 'i') {
+                        next.icase = on;
+                    } else if (d == 's') {
+                        next.dotAll = on;
+                    } else if (d == 'm') {
+                        next.multiLine = on;
+                    } else if (d == 'x') {
+                        next.extended = on;
+                    } else {
+                        break;
+                    }
+                }
+                if (d == ')') {
+                    ++mPos;
+                    mSyn = next;  // applies to the remainder of the enclosing group
+                    return mk(Node::Empty);
+                }
+                if (d != ':') bail("unknown inline flag");
+                ++mPos;
+                mSyn = next;
+                capturing = false;
+            }
+        }
+        if (capturing && name.empty() && mSyn.namedOnly) capturing = false;
+        if (capturing) {
+            if (mGroups >= 255) bail("too many capture groups");
+            capture = ++mGroups;
+            mNames.push_back(name);
+        }
+        NodePtr inner = alternation(depth + 1);
+        if (atEnd() || peek() != ')') bail("missing )");
+        ++mPos;
+        mSyn = saved;
+        auto g = mk(Node::Group);
+        g->capture = capture;
+        g->kids.push_back(std::move(inner));
+        return g;
+    }
+
+    NodePtr escapeAtom() {  // mPos just past '\'
+        if (atEnd()) bail("trailing backslash");
+        unsigned e = peek();
+        ++mPos;
+        {
+            ByteSet t;
+            if (shorthand(char(e), t)) {
+                if (mSyn.icase) foldCase(t);
+                auto n = mk(Node::Set);
+                n->set = t;
+                return n;
+            }
+            if (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), t)) {
+                if (mSyn.icase) foldCase(t);
+                t.invert();
+                auto n = mk(Node::Set);
+                n->set = t;
+                return n;
+            }
+        }
+        switch (e) {
+            case 'b': return assertion(AssertKind::WordBoundary);
+            case 'B': return assertion(AssertKind::NotWordBoundary);
+            case '<': return assertion(AssertKind::WordStart);
+            case '>': return assertion(AssertKind::WordEnd);
+            case 'A':
+            case '`': return assertion(AssertKind::BolSingle);
+            case 'z':
+            case '\'': return assertion(AssertKind::EolSingle);
+            case 'Z': bail("\\Z (multi-byte look-ahead) unsupported");
+            case 'Q': {
+                auto seq = mk(Node::Cat);
+                while (!atEnd()) {
+                    if (peek() == '\\' && has(1) && peek(1) == 'E') {
+                        mPos += 2;
+                        break;
+                    }
+                    seq->kids.push_back(literal(peek()));
+                    ++mPos;
+                }
+                auto g = mk(Node::Group);
+                g->kids.push_back(std::move(seq));
+                return g;
+            }
+            case 'E': return mk(Node::Empty);
+            case 'k': case 'g': case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
+                bail("unsupported escape");
+            default: break;
+        }
+        if (e >= '1' && e <= '9') bail("back-references unsupported");
+        int v = byteEscape(e);
+        return literal(v >= 0 ? unsigned(v) : e);
+    }
+
+    // returns nullptr when the next token cannot start an atom
+    NodePtr atom(int depth, bool& isAssertion) {
+        isAssertion = false;
+        unsigned c = peek();
+        switch (c) {
+            case '(': ++mPos; return group(depth);
+            case '[': ++mPos; return bracketClass();
+            case '.': {
+                ++mPos;
+                auto n = mk(Node::Set);
+                n->set = ByteSet::all();
+                if (!mSyn.dotAll) n->set.w[0] &= ~(uint64_t(1) << '\n');
+                return n;
+            }
+            case '^':
+                ++mPos;
+                isAssertion = true;
+                return assertion(mSyn.multiLine ? AssertKind::BolMulti : AssertKind::BolSingle);
+            case '$':
+                ++mPos;
+                isAssertion = true;
+                return assertion(mSyn.multiLine ? AssertKind::EolMulti : AssertKind::EolSingle);
+            case '*': case '+': case '?': bail("nothing to repeat");
+            case '\\': {
+                ++mPos;
+                NodePtr n = escapeAtom();
+                isAssertion = n->kind == Node::Assert;
+                return n;
+            }
+            default: ++mPos; return literal(c);
+        }
+    }
+
+    bool counted(int& lo, int& hi) {  // at '{'
+        size_t j = mPos + 1;
+        long a = 0, b = -1;
+        int digits = 0;
+        while (j < mPat.size() && mPat[j] >= '0' && mPat[j] <= '9') {
+            a = a * 10 + (mPat[j] - '0');
+            if (a > 100000) return false;
+            ++j;
+            ++digits;
+        }
+        if (!digits || j >= mPat.size()) return false;
+        if (mPat[j] == '}') {
+            b = a;
+            ++j;
+        } else if (mPat[j] == ',') {
+            ++j;
+            long t = 0;
+            digits = 0;
+            while (j < mPat.size() && mPat[j] >= '0' && mPat[j] <= '9') {
+                t = t * 10 + (mPat[j] - '0');
+                if (t > 100000) return false;
+                ++j;
+                ++digits;
+            }
+            if (j >= mPat.size() || mPat[j] != '}') return false;
+            ++j;
+            b = digits ? t : -1;
+        } else {
+            return false;
+        }
+        lo = int(a);
+        hi = int(b);
+        mPos = j;
+        return true;
+    }
+
+    NodePtr sequence(int depth) {
+        auto seq = mk(Node::Cat);
+        for (;;) {
+            skipFreeSpacing();
+            if (atEnd() || peek() == '|' || peek() == ')') break;
+            bool isAssertion = false;
+            NodePtr a = atom(depth, isAssertion);
+            bool quantified = false;
+            for (;;) {
+                skipFreeSpacing();
+                if (atEnd()) break;
+                unsigned q = peek();
+                int lo, hi;
+                if (q == '*') {
+                    lo = 0; hi = -1; ++mPos;
+                } else if (q == '+') {
+                    lo = 1; hi = -1; ++mPos;
+                } else if (q == '?') {
+                    lo = 0; hi = 1; ++mPos;
+                } else if (q == '{') {
+                    if (!counted(lo, hi)) break;
+                } else {
+                    break;
+                }
+                if (quantified) bail("nested quantifier");
+                if (hi >= 0 && hi < lo) bail("bad repeat range");
+                bool greedy = true;
+                if (!atEnd() && peek() == '?') {
+                    greedy = false;
+                    ++mPos;
+                } else if (!atEnd() && peek() == '+') {
+                    bail("possessive quantifiers unsupported");
+                }
+                auto r = mk(Node::Repeat);
+                r->min = lo;
+                r->max = hi;
+                r->greedy = greedy;
+                r->kids.push_back(std::move(a));
+                a = std::move(r);
+                quantified = true;
+            }
+            seq->kids.push_back(std::move(a));
+        }
+        if (seq->kids.empty()) return mk(Node::Empty);
+        if (seq->kids.size() == 1) return std::move(seq->kids[0]);
+        return seq;
+    }
+
+    NodePtr alternation(int depth) {
+        if (depth > 200) bail("nesting too deep");
+        NodePtr first = sequence(depth);
+        if (atEnd() || peek() != '|') return first;
+        auto alt = mk(Node::Alt);
+        alt->kids.push_back(std::move(first));
+        while (!atEnd() && peek() == '|') {
+            ++mPos;
+            alt->kids.push_back(sequence(depth));
+        }
+        return alt;
+    }
+};
+
+}  // namespace
+
+ParsedRegex parseRegex(std::string_view pattern, Syntax syntax) { return Parser(pattern, syntax).run(); }
+
+}  // namespace lcregex

@@ -1,0 +1,38 @@
+// tdfa.hpp -- determinisation of the follow NFA into a tagged DFA (Laurikari-style TDFA, leftmost-first).
+//
+// One DFA state = ordered list of (NFA position, register map) items; order = backtracking priority.  Registers
+// hold byte offsets of capture-group boundaries.  Register names are canonicalised per state (first appearance),
+// so state identity is (positions, prev-byte context, register-sharing pattern) and the construction is finite.
+// The device kernel (kernels.hip: tdfa_match_kernel) steps one log line per lane through `trans`, running the
+// few register moves attached to a transition, and finishes with the per-state final map.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "follow_nfa.hpp"
+
+namespace lcregex {
+
+constexpr uint8_t kRegPos = 0xFF;   // "current offset" pseudo-register in op / final lists
+constexpr uint8_t kRegNone = 0xFE;  // capture slot never written -> -1
+constexpr int kMaxTdfaRegs = 250;
+
+struct TdfaTables {
+    uint32_t nStates = 0, nClasses = 0, nRegs = 0, nSlots = 0, startState = 0;
+    std::vector<uint8_t> classMap;    // [256] byte -> class
+    std::vector<uint32_t> trans;      // [nStates*nClasses]  low16 = next state (0 = dead), high16 = op-list id (0 = none)
+    std::vector<uint32_t> opsStart;   // [nOpLists+1] offset of each op list in `ops` (list id 0 is the empty list)
+    std::vector<uint16_t> ops;        // per list: n, then n words (dst | src<<8); src may be kRegPos
+    std::vector<uint16_t> finalId;    // [nStates] 0xFFFF = not accepting, else row in finalMap
+    std::vector<uint8_t> finalMap;    // [nFinal*nSlots] register id | kRegPos | kRegNone
+};
+
+struct TdfaLimits {
+    uint32_t maxStates = 4096;
+};
+
+// Throws RegexError("tdfa: ...") when the automaton exceeds the limits (caller falls back to the NFA engine).
+TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits());
+
+}  // namespace lcregex

@@ -219,8 +219,8 @@ static int parse_class(orx_prog* P) { /* P->i just after '[' */
             ++P->i;
             if (P->i >= P->n) { fail(P, "trailing backslash"); return -1; }
             int e = P->p[P->i++];
-            if (strchr("dwshvlu", e)) { cset t; cs_clear(&t); cs_named(&t, e); cs_or(&s, &t); continue; }
-            if (strchr("DWSHVLU", e)) { cset t; cs_clear(&t); cs_named(&t, e + 32); cs_not(&t); cs_or(&s, &t); continue; }
+            if (e && strchr("dwshvlu", e)) { cset t; cs_clear(&t); cs_named(&t, e); cs_or(&s, &t); continue; }
+            if (e && strchr("DWSHVLU", e)) { cset t; cs_clear(&t); cs_named(&t, e + 32); cs_not(&t); cs_or(&s, &t); continue; }
             if (e == 'b') lo = 8;
             else {
                 int v = escape_byte(P, e);
@@ -241,7 +241,7 @@ static int parse_class(orx_prog* P) { /* P->i just after '[' */
                 ++P->i;
                 if (P->i >= P->n) { fail(P, "trailing backslash"); return -1; }
                 int e = P->p[P->i++];
-                if (strchr("dwshvluDWSHVLU", e)) { fail(P, "class escape as range endpoint"); return -1; }
+                if (e && strchr("dwshvluDWSHVLU", e)) { fail(P, "class escape as range endpoint"); return -1; }
                 if (e == 'b') hi = 8;
                 else { int v = escape_byte(P, e); if (P->failed) return -1; hi = v >= 0 ? v : e; }
             } else { hi = c2; ++P->i; }
@@ -372,8 +372,8 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
             ++P->i;
             if (P->i >= P->n) { fail(P, "trailing backslash"); return -1; }
             int e = P->p[P->i++];
-            if (strchr("dwshvlu", e)) { cset s; cs_clear(&s); cs_named(&s, e); if (P->flags & ORX_ICASE) cs_fold_case(&s); return set_node(P, &s); }
-            if (strchr("DWSHVLU", e)) { cset s; cs_clear(&s); cs_named(&s, e + 32); if (P->flags & ORX_ICASE) cs_fold_case(&s); cs_not(&s); return set_node(P, &s); }
+            if (e && strchr("dwshvlu", e)) { cset s; cs_clear(&s); cs_named(&s, e); if (P->flags & ORX_ICASE) cs_fold_case(&s); return set_node(P, &s); }
+            if (e && strchr("DWSHVLU", e)) { cset s; cs_clear(&s); cs_named(&s, e + 32); if (P->flags & ORX_ICASE) cs_fold_case(&s); cs_not(&s); return set_node(P, &s); }
             switch (e) {
                 case 'b': *is_assert = 1; return assert_node(P, A_WORDB);
                 case 'B': *is_assert = 1; return assert_node(P, A_NWORDB);

@@ -1,0 +1,132 @@
+"""Test-only interpreters for the compiled device tables (TDFA tables / follow NFA blob).
+
+They let the `-m "not gpu"` suite check the host compilers (regex_parse -> follow_nfa -> tdfa) against the
+oracle and the golden vectors without a GPU.  They are NOT part of the product and are never imported by
+loongcollector_amd/: the product has no CPU execution path.
+"""
+import numpy as np
+
+from loongcollector_amd import binding as B
+
+
+class TdfaInterp:
+    def __init__(self, rx):
+        hdr = rx.table(B.LC_TABLE_TDFA_HEADER, np.uint32)
+        assert hdr is not None, "pattern has no TDFA"
+        self.nstates, self.ncls, self.nregs, self.nslots, self.start = [int(x) for x in hdr[:5]]
+        self.cmap = rx.table(B.LC_TABLE_CLASSMAP, np.uint8)
+        self.trans = rx.table(B.LC_TABLE_TDFA_TRANS, np.uint32)
+        self.ops_start = rx.table(B.LC_TABLE_TDFA_OPSSTART, np.uint32)
+        self.ops = rx.table(B.LC_TABLE_TDFA_OPS, np.uint16)
+        self.final_id = rx.table(B.LC_TABLE_TDFA_FINALID, np.uint16)
+        self.final_map = rx.table(B.LC_TABLE_TDFA_FINALMAP, np.uint8)
+
+    def fullmatch(self, s: bytes):
+        """-> flat caps [b1,e1,b2,e2,...] for groups 1..G, or None"""
+        state = self.start
+        regs = [-1] * (self.nregs + 1)
+        for pos, b in enumerate(s):
+            t = int(self.trans[state * self.ncls + int(self.cmap[b])])
+            lst = t >> 16
+            if lst:
+                o = int(self.ops_start[lst])
+                n = int(self.ops[o])
+                for k in range(n):
+                    w = int(self.ops[o + 1 + k])
+                    dst, src = w & 0xFF, w >> 8
+                    regs[dst] = pos if src == 0xFF else regs[src]
+            state = t & 0xFFFF
+            if state == 0:
+                return None
+        fid = int(self.final_id[state])
+        if fid == 0xFFFF:
+            return None
+        out = []
+        for sl in range(self.nslots):
+            m = int(self.final_map[fid * self.nslots + sl])
+            out.append(len(s) if m == 0xFF else (-1 if m == 0xFE else regs[m]))
+        return out
+
+
+def _props(b):
+    word = (48 <= b <= 57) or (65 <= b <= 90) or (97 <= b <= 122) or b == 95
+    return dict(boundary=False, word=word, sep=b in (10, 13, 12), cr=b == 13, lf=b == 10)
+
+
+_EDGE = dict(boundary=True, word=False, sep=False, cr=False, lf=False)
+
+
+def _cond_holds(cond, prev, nxt):
+    at_start, at_end = prev["boundary"], nxt["boundary"]
+    crlf = (not at_start) and (not at_end) and prev["cr"] and nxt["lf"]
+    pw = (not at_start) and prev["word"]
+    nw = (not at_end) and nxt["word"]
+    checks = [
+        at_start or (prev["sep"] and not crlf),   # BolMulti
+        at_start,                                  # BolSingle
+        at_end or (nxt["sep"] and not crlf),       # EolMulti
+        at_end,                                    # EolSingle
+        pw != nw,                                  # WordBoundary
+        pw == nw,                                  # NotWordBoundary
+        (not pw) and nw,                           # WordStart
+        pw and not nw,                             # WordEnd
+    ]
+    return all(ok for k, ok in enumerate(checks) if (cond >> k) & 1)
+
+
+class NfaInterp:
+    """Ordered-thread-list simulation of the packed NFA blob (what the wave-per-line kernel does)."""
+
+    def __init__(self, rx):
+        blob = rx.table(B.LC_TABLE_NFA_BLOB, np.uint32)
+        assert blob is not None
+        self.npos, self.nslots, self.ncls = int(blob[1]), int(blob[2]), int(blob[3])
+        raw = blob.view(np.uint8)
+        self.cmap = raw[int(blob[4]):int(blob[4]) + 256].copy()
+        pm = blob[int(blob[5]) // 4:int(blob[5]) // 4 + 2 * self.npos]
+        self.posmask = [int(pm[2 * p]) | (int(pm[2 * p + 1]) << 32) for p in range(self.npos)]
+        fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
+        paths = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 4 * int(blob[9])].reshape(-1, 4)
+        self.follow = []
+        for p in range(self.npos + 1):
+            lst = []
+            for i in range(int(fs[p]), int(fs[p + 1])):
+                tgt, cond, lo, hi = [int(x) for x in paths[i]]
+                lst.append((-1 if tgt == 0xFFFFFFFF else tgt, cond, lo | (hi << 32)))
+            self.follow.append(lst)
+
+    def fullmatch(self, s: bytes, max_threads=64):
+        threads = [(self.npos, [-1] * self.nslots)]  # (position, caps)
+        prev = _EDGE
+        for pos, b in enumerate(s):
+            nxt = _props(b)
+            cls = int(self.cmap[b])
+            new, seen = [], set()
+            for p, caps in threads:
+                for tgt, cond, tags in self.follow[p]:
+                    if tgt < 0 or tgt in seen or not (self.posmask[tgt] >> cls) & 1:
+                        continue
+                    if cond and not _cond_holds(cond, prev, nxt):
+                        continue
+                    seen.add(tgt)
+                    c2 = list(caps)
+                    for sl in range(self.nslots):
+                        if (tags >> sl) & 1:
+                            c2[sl] = pos
+                    new.append((tgt, c2))
+            if len(new) > max_threads:
+                return "overflow"
+            threads = new
+            prev = nxt
+            if not threads:
+                return None
+        for p, caps in threads:
+            for tgt, cond, tags in self.follow[p]:
+                if tgt >= 0 or (cond and not _cond_holds(cond, prev, _EDGE)):
+                    continue
+                c2 = list(caps)
+                for sl in range(self.nslots):
+                    if (tags >> sl) & 1:
+                        c2[sl] = len(s)
+                return c2
+        return None

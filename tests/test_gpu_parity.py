@@ -1,0 +1,149 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle and the golden vectors.
+Bit-exact bar: status bytes and int32 capture offsets must be identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from loongcollector_amd import binding as B
+from loongcollector_amd import corpus
+from oracle.oracle import OracleRegex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert B.device_count() >= 1
+    torch.cuda.set_device(0)
+    return torch
+
+
+def run_device(torch, rx, data, off, length=None, sep=0, ngroups=None):
+    """off: n entries when `length` is given, n+1 entries otherwise"""
+    G = rx.groups if ngroups is None else ngroups
+    n = len(off) if length is not None else len(off) - 1
+    dev = torch.device("cuda:0")
+    pad = np.zeros(max(1, len(data)), dtype=np.uint8)
+    pad[:len(data)] = data
+    d_data = torch.from_numpy(pad).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint32).view(np.int32)).to(dev)
+    d_len = None if length is None else torch.from_numpy(np.ascontiguousarray(length, dtype=np.uint32).view(np.int32)).to(dev)
+    d_caps = torch.full((max(n, 1), max(2 * G, 1)), -7, dtype=torch.int32, device=dev)
+    d_status = torch.full((max(n, 1),), 9, dtype=torch.uint8, device=dev)
+    rx.match_device(d_data, d_off, d_len, n, d_caps, d_status, ngroups=G, sep_bytes=sep,
+                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_caps.cpu().numpy()[:n, :2 * G], d_status.cpu().numpy()[:n]
+
+
+def pack(subjects):
+    off, length, chunks, at = [], [], [], 0
+    for s in subjects:
+        off.append(at)
+        length.append(len(s))
+        chunks.append(s)
+        at += len(s)
+    data = np.frombuffer(b"".join(chunks), dtype=np.uint8) if at else np.zeros(0, np.uint8)
+    return data, np.array(off, np.uint32), np.array(length, np.uint32)
+
+
+def test_golden_vectors_through_the_c_abi(torch_dev, golden_dir):
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    bad = []
+    checked = 0
+    for c in golden["cases"]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"))
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        caps, status = run_device(torch_dev, rx, data, off, length)
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            if flat is None:
+                ok = status[i] == B.LC_NOMATCH and (caps[i] == -1).all()
+            else:
+                ok = status[i] == B.LC_MATCH and list(caps[i]) == flat[2:]
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 4000
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_bench_corpus_bit_exact_vs_oracle(torch_dev, kind):
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    n = 20000
+    data, off, length = corpus.apache_batch(n, kind, poison_every=13)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    rx = B.GpuRegex(pattern)
+    caps, status = run_device(torch_dev, rx, data, off, None, sep=1)   # offsets[n+1] + separator form
+    assert np.array_equal(status, exp_status)
+    assert np.array_equal(caps, exp_caps)
+    caps2, status2 = run_device(torch_dev, rx, data, off[:-1], length)  # (off,len) form
+    assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps)
+
+
+def test_ragged_mixed_corpus_with_failures(torch_dev):
+    data, off, length = corpus.mixed_batch(6000)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_B).fullmatch_batch(data, off[:-1], length)
+    assert 0.2 < 1 - exp_status.mean() < 0.4  # JSON lines must fail
+    caps, status = run_device(torch_dev, B.GpuRegex(corpus.REGEX_B), data, off, None, sep=1)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+def test_edge_cases_empty_and_unaligned_and_long_lines(torch_dev):
+    pattern = r"(\w*)\t?(\w*)(.*)"
+    rng = np.random.default_rng(5)
+    subs = [b"", b"a", b"\t", b"a\tb", b"x" * 15, b"x" * 16, b"x" * 17, b"ab\tcd" + b" tail" * 3000, b""]
+    for _ in range(300):
+        L = int(rng.integers(0, 70))
+        subs.append(bytes(rng.choice(list(b"ab\t _"), size=L).astype(np.uint8)))
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    caps, status = run_device(torch_dev, B.GpuRegex(pattern), data, off, length)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+def test_zero_lines_and_extra_groups(torch_dev):
+    rx = B.GpuRegex(r"(\d+) (\d+)")
+    data, off, length = pack([b"12 34", b"x"])
+    caps, status = run_device(torch_dev, rx, data, off, length, ngroups=4)
+    assert list(status) == [1, 0]
+    assert list(caps[0]) == [0, 2, 3, 5, -1, -1, -1, -1] and (caps[1] == -1).all()
+    caps0, status0 = run_device(torch_dev, rx, np.zeros(0, np.uint8), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert caps0.shape[0] == 0 and status0.shape[0] == 0
+
+
+def test_match_host_pipeline_equals_device_path(torch_dev):
+    n = 300000  # > one pipelined chunk, so both staging slots and the drain path are exercised
+    data, off, length = corpus.apache_batch(n, "A", poison_every=1001)
+    rx = B.GpuRegex(corpus.REGEX_A)
+    caps_h, status_h = rx.match_host(data, off[:-1], length)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
+    assert np.array_equal(status_h, exp_status) and np.array_equal(caps_h, exp_caps)
+    # scattered (non-contiguous, out-of-order) views take the gather path
+    perm = np.random.default_rng(1).permutation(5000)
+    caps_p, status_p = rx.match_host(data, off[:-1][perm], length[perm])
+    assert np.array_equal(status_p, exp_status[perm]) and np.array_equal(caps_p, exp_caps[perm])
+
+
+def test_full_size_batch_properties(torch_dev):
+    """BASELINE config 2 size (1 Mi lines): size-independent properties instead of a full oracle pass --
+    (1) every line matches, (2) captures tile the line in order, (3) the checksum of the capture table equals the
+    checksum of the pool's oracle captures gathered by the same indices."""
+    n = 1 << 20
+    pool_lines = 8192
+    data, off, length = corpus.apache_batch(n, "A", pool_lines=pool_lines)
+    rx = B.GpuRegex(corpus.REGEX_A)
+    caps, status = run_device(torch_dev, rx, data, off, None, sep=1)
+    assert status.min() == 1
+    assert (caps[:, 0] == 0).all() and (np.diff(caps, axis=1) >= 0).all() and (caps[:, -1] == 511).all()
+    pool = corpus.apache_pool("A", pool_lines)
+    p_off = (np.arange(pool_lines) * 512).astype(np.uint32)
+    p_caps, _ = OracleRegex(corpus.REGEX_A).fullmatch_batch(pool.reshape(-1), p_off, np.full(pool_lines, 512, np.uint32))
+    idx = np.random.Generator(np.random.MT19937(corpus.SEED + 7919)).integers(0, pool_lines, size=n)
+    assert np.array_equal(caps, p_caps[idx])
