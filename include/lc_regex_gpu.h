@@ -123,6 +123,13 @@ int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t*
                           uint32_t sep_bytes, uint32_t n, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
                           void* stream);
 
+/* Same, but with an explicit engine (LC_ENGINE_TDFA / LC_ENGINE_NFA; LC_ENGINE_AUTO = the handle's own choice).
+ * A handle compiled with LC_ENGINE_AUTO carries both programs whenever both fit, so the two kernels can be
+ * cross-checked on identical input. */
+int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                                 const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
+                                 int32_t* d_caps, uint8_t* d_status, void* stream);
+
 /* Same, for host buffers: lines are gathered through pinned staging buffers and copied with
  * hipMemcpyAsync on two streams so that chunk k+1 uploads while chunk k is being matched and chunk k-1
  * downloads.  Synchronous: results are in caps/status on return. */

@@ -60,6 +60,8 @@ def load(path=None):
     L.lc_device_count.restype = i32
     L.lc_regex_match_device.restype = i32
     L.lc_regex_match_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.lc_regex_match_device_engine.restype = i32
+    L.lc_regex_match_device_engine.argtypes = [vp, i32, vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.lc_regex_match_host.restype = i32
     L.lc_regex_match_host.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp]
     L.lc_last_error.restype = cp
@@ -131,11 +133,12 @@ class GpuRegex:
         return np.frombuffer(buf, dtype=dtype).copy()
 
     # ---- device-resident batch (torch tensors on the current HIP device)
-    def match_device(self, d_data, d_off, d_len, n, d_caps, d_status, ngroups=None, sep_bytes=0, stream=None):
+    def match_device(self, d_data, d_off, d_len, n, d_caps, d_status, ngroups=None, sep_bytes=0, stream=None,
+                     engine=LC_ENGINE_AUTO):
         G = self.groups if ngroups is None else ngroups
-        rc = self._L.lc_regex_match_device(self._h, d_data.data_ptr(), d_off.data_ptr(),
-                                           d_len.data_ptr() if d_len is not None else None, sep_bytes, n, G,
-                                           d_caps.data_ptr(), d_status.data_ptr(), stream)
+        rc = self._L.lc_regex_match_device_engine(self._h, engine, d_data.data_ptr(), d_off.data_ptr(),
+                                                  d_len.data_ptr() if d_len is not None else None, sep_bytes, n, G,
+                                                  d_caps.data_ptr(), d_status.data_ptr(), stream)
         _check(rc, "lc_regex_match_device")
 
     # ---- host batch (numpy arrays); pinned double-buffered H2D/D2H inside the library

@@ -87,6 +87,8 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         classMapOut[b] = uint8_t(it->second);
     }
     if (rep.size() > 64) throw RegexError("nfa: more than 64 byte classes");
+    for (const auto& lst : nfa.follow)
+        if (lst.size() > 64) throw RegexError("nfa: follow list longer than 64 paths");
     std::vector<uint32_t> posMask(size_t(npos) * 2 + 2, 0);
     for (int p = 0; p < npos; ++p) {
         uint64_t m = 0;
@@ -162,6 +164,8 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             try {
                 re->tdfa = buildTdfa(re->nfa);
                 re->tdfaBlob = packTdfaBlob(re->tdfa);
+                if (!lcTdfaPickBlock(uint32_t(re->tdfaBlob.size() * 4), re->tdfa.nRegs))
+                    throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
                 re->hasTdfa = true;
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                   re->tdfa.startState, 0, 0, 0};
@@ -178,7 +182,10 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         // the NFA blob is always packed when it fits: tests cross-check both engines on one handle
         try {
             re->nfaBlob = packNfaBlob(re->nfa, re->nfaClassMap);
+            if (lcNfaLdsBytes(uint32_t(re->nfaBlob.size() * 4), uint32_t(re->nfa.positions.size())) > kLcLdsPerCu)
+                throw RegexError("nfa: program exceeds the 160 KiB LDS of a CU");
         } catch (const RegexError&) {
+            re->nfaBlob.clear();
             if (re->engine == LC_ENGINE_NFA) throw;
         }
     } catch (const RegexError& e) {

@@ -37,5 +37,23 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t);
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);
 }  // namespace lcregex
 
+// LDS budgeting shared by the compile-time engine choice (regex_handle.cpp) and the launchers (gpu_runtime.hip).
+// TDFA: tables + nRegs x BLOCK x 4 B of offset registers.  Prefer 256-lane workgroups while a workgroup stays under
+// 64 KiB (>= 2 workgroups per CU); shrink the workgroup before giving up.  0 = does not fit in 160 KiB at all.
+constexpr size_t kLcLdsPerCu = 160 * 1024;
+inline size_t lcTdfaLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
+    return size_t(blobBytes) + size_t(nRegs) * size_t(block) * 4;
+}
+inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
+    for (int b : {256, 128, 64})
+        if (lcTdfaLdsBytes(blobBytes, nRegs, b) <= 64 * 1024) return b;
+    for (int b : {256, 128, 64})
+        if (lcTdfaLdsBytes(blobBytes, nRegs, b) <= kLcLdsPerCu) return b;
+    return 0;
+}
+inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos) {
+    return size_t(blobBytes) + size_t(4) * (((nPos + 3) & ~3u) + 256) * 4;  // 4 waves x (best[nPos] + 4x64 words)
+}
+
 // implemented in gpu_runtime.hip; frees device copies
 void lcReleaseDeviceTables(lc_regex* re);

@@ -22,7 +22,7 @@ def torch_dev():
     return torch
 
 
-def run_device(torch, rx, data, off, length=None, sep=0, ngroups=None):
+def run_device(torch, rx, data, off, length=None, sep=0, ngroups=None, engine=B.LC_ENGINE_AUTO):
     """off: n entries when `length` is given, n+1 entries otherwise"""
     G = rx.groups if ngroups is None else ngroups
     n = len(off) if length is not None else len(off) - 1
@@ -35,7 +35,7 @@ def run_device(torch, rx, data, off, length=None, sep=0, ngroups=None):
     d_caps = torch.full((max(n, 1), max(2 * G, 1)), -7, dtype=torch.int32, device=dev)
     d_status = torch.full((max(n, 1),), 9, dtype=torch.uint8, device=dev)
     rx.match_device(d_data, d_off, d_len, n, d_caps, d_status, ngroups=G, sep_bytes=sep,
-                    stream=torch.cuda.current_stream().cuda_stream)
+                    stream=torch.cuda.current_stream().cuda_stream, engine=engine)
     torch.cuda.synchronize()
     return d_caps.cpu().numpy()[:n, :2 * G], d_status.cpu().numpy()[:n]
 
@@ -55,21 +55,25 @@ def test_golden_vectors_through_the_c_abi(torch_dev, golden_dir):
     with open(os.path.join(golden_dir, "regex_golden.json")) as f:
         golden = json.load(f)
     bad = []
-    checked = 0
+    checked = {B.LC_ENGINE_TDFA: 0, B.LC_ENGINE_NFA: 0}
     for c in golden["cases"]:
         rx = B.GpuRegex(c["p"].encode("latin-1"))
         subs = [s.encode("latin-1") for s, _ in c["subs"]]
         data, off, length = pack(subs)
-        caps, status = run_device(torch_dev, rx, data, off, length)
-        for i, (_, flat) in enumerate(c["subs"]):
-            checked += 1
-            if flat is None:
-                ok = status[i] == B.LC_NOMATCH and (caps[i] == -1).all()
-            else:
-                ok = status[i] == B.LC_MATCH and list(caps[i]) == flat[2:]
-            if not ok:
-                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
-    assert checked > 4000
+        engines = [B.LC_ENGINE_NFA]  # every golden pattern has an NFA program
+        if rx.info()["engine"] == B.LC_ENGINE_TDFA:
+            engines.append(B.LC_ENGINE_TDFA)
+        for eng in engines:
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+            for i, (_, flat) in enumerate(c["subs"]):
+                checked[eng] += 1
+                if flat is None:
+                    ok = status[i] == B.LC_NOMATCH and (caps[i] == -1).all()
+                else:
+                    ok = status[i] == B.LC_MATCH and list(caps[i]) == flat[2:]
+                if not ok:
+                    bad.append((eng, c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked[B.LC_ENGINE_TDFA] > 4000 and checked[B.LC_ENGINE_NFA] > 4000
     assert not bad, bad[:5]
 
 
@@ -85,6 +89,41 @@ def test_bench_corpus_bit_exact_vs_oracle(torch_dev, kind):
     assert np.array_equal(caps, exp_caps)
     caps2, status2 = run_device(torch_dev, rx, data, off[:-1], length)  # (off,len) form
     assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps)
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_nfa_kernel_bit_exact_on_bench_corpus(torch_dev, kind):
+    """The wave-per-line NFA kernel (the engine AUTO falls back to) against the oracle AND against the TDFA kernel."""
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    n = 6000
+    data, off, length = corpus.apache_batch(n, kind, poison_every=11)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    rx = B.GpuRegex(pattern)
+    caps_n, status_n = run_device(torch_dev, rx, data, off, None, sep=1, engine=B.LC_ENGINE_NFA)
+    caps_t, status_t = run_device(torch_dev, rx, data, off, None, sep=1, engine=B.LC_ENGINE_TDFA)
+    assert np.array_equal(status_n, exp_status) and np.array_equal(caps_n, exp_caps)
+    assert np.array_equal(status_t, status_n) and np.array_equal(caps_t, caps_n)
+
+
+def test_auto_falls_back_to_nfa_kernel_when_tdfa_explodes(torch_dev):
+    blowup = r"(.*)a" + "." * 14 + r"(.*)"
+    rx = B.GpuRegex(blowup)
+    assert rx.info()["engine"] == B.LC_ENGINE_NFA
+    rng = np.random.default_rng(3)
+    subs = [bytes(rng.choice(list(b"ab"), size=int(rng.integers(0, 60))).astype(np.uint8)) for _ in range(500)]
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(blowup).fullmatch_batch(data, off, length)
+    caps, status = run_device(torch_dev, rx, data, off, length)
+    assert 0 < exp_status.sum() < len(subs)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+def test_nfa_thread_overflow_is_reported_not_guessed(torch_dev):
+    # on "aaaa..." every one of the 70 '.' positions is alive at once: more than 64 simultaneous threads
+    rx = B.GpuRegex(r".*a.{70}", engine=B.LC_ENGINE_NFA)
+    data, off, length = pack([b"a" * 100, b"b" * 10, b"a" + b"b" * 70])
+    caps, status = run_device(torch_dev, rx, data, off, length)
+    assert list(status) == [B.LC_OVERFLOW, B.LC_NOMATCH, B.LC_MATCH]
 
 
 def test_ragged_mixed_corpus_with_failures(torch_dev):
