@@ -43,20 +43,30 @@ extern "C" int lc_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ TDFA kernel
-constexpr int kTdfaBlock = 256;
-
+// One log line per lane.  Per byte: one class lookup (off the dependency chain, issued 16 at a time) and one
+// transition lookup (the chain), both LDS.  Bytes outside the lane's line (alignment head / tail of the last
+// 16-byte chunk) take the row's identity column, so the byte loop has no validity branch.  Capture offsets live
+// in LDS as regs[reg][lane]; the register program of a transition is almost always "regs[d] = pos" and is then
+// encoded in the transition word itself (device_tables.h).
 struct TdfaView {  // LDS byte offsets, wave-uniform
     uint32_t cmap, trans, finalId, finalMap, opsStart, ops, regs;
 };
 
 template <int BLOCK>
-__device__ __forceinline__ void tdfaRunOps(const uint8_t* smem, const TdfaView& v, uint32_t list, uint32_t pos,
-                                           uint32_t tid) {
+__device__ __forceinline__ void tdfaRegisterProgram(uint8_t* smem, const TdfaView& v, uint32_t h, uint32_t pos,
+                                                    uint32_t tid) {
+    uint32_t* regs = reinterpret_cast<uint32_t*>(smem + v.regs);
+    if (h & TD_OP_INLINE) {
+        const uint32_t dst = h & 0xFFu;
+        regs[dst * BLOCK + tid] = pos;
+        if (h & TD_OP_PAIR) regs[(dst + 1) * BLOCK + tid] = pos;
+        return;
+    }
     const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(smem + v.opsStart);
     const uint16_t* ops = reinterpret_cast<const uint16_t*>(smem + v.ops);
-    uint32_t* regs = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(smem) + v.regs);
-    uint32_t at = opsStart[list];
+    const uint32_t at = opsStart[h];
     const uint32_t cnt = ops[at];
+#pragma unroll 1
     for (uint32_t i = 0; i < cnt; ++i) {
         const uint32_t w = ops[at + 1 + i];
         const uint32_t dst = w & 0xFF, src = w >> 8;
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(BLOCK) void tdfa_match_kernel(const uint8_t* __rest
     v.regs = blobBytes;
     const uint32_t nSlots = hdr[TD_NSLOTS];
     const uint32_t rowBytes = hdr[TD_ROW_BYTES];
+    const uint32_t idCol = hdr[TD_ID_COL];
     uint32_t row = hdr[TD_START_ROW];
 
     const uint32_t line = blockIdx.x * BLOCK + tid;
@@ -103,43 +114,51 @@ __global__ __launch_bounds__(BLOCK) void tdfa_match_kernel(const uint8_t* __rest
     const uint16_t* cmap = reinterpret_cast<const uint16_t*>(smem + v.cmap);
     const uint8_t* transBase = smem + v.trans;
 
+    // The line is walked in 64-byte windows of four aligned 16-byte loads; the next window is in flight while
+    // the current one is stepped.  An aligned 16-byte chunk that holds at least one byte of the line never leaves
+    // the line's pages, so no load can fault; chunks wholly outside the line are not loaded.
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 15);
     const uint4* chunk = reinterpret_cast<const uint4*>(addr - head);
-    uint32_t nChunks = L ? (head + L + 15) / 16 : 0;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (nChunks) cur = chunk[0];
-    uint32_t base = 0u - head;  // offset within the line of byte 0 of the current chunk (wraps for the head)
-
-#define LC_TDFA_STEP(word, shift, j)                                                               \
-    {                                                                                              \
-        const uint32_t pos = base + (j);                                                           \
-        if (pos < L) {                                                                             \
-            const uint32_t b = ((word) >> (shift)) & 0xFFu;                                        \
-            const uint32_t t = *reinterpret_cast<const uint32_t*>(transBase + row + cmap[b]);      \
-            if (t >> TD_LIST_SHIFT) tdfaRunOps<BLOCK>(smem, v, t >> TD_LIST_SHIFT, pos, tid);       \
-            row = t & TD_ROW_MASK;                                                                 \
-        }                                                                                          \
+    const uint32_t nChunks = L ? (head + L + 15) / 16 : 0;
+    const uint32_t nWindows = (nChunks + 3) / 4;
+    uint4 cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cur[q] = make_uint4(0, 0, 0, 0);
+        if (uint32_t(q) < nChunks) cur[q] = chunk[q];
     }
-#define LC_TDFA_WORD(word, j0)      \
-    LC_TDFA_STEP(word, 0, (j0))     \
-    LC_TDFA_STEP(word, 8, (j0) + 1) \
-    LC_TDFA_STEP(word, 16, (j0) + 2) \
-    LC_TDFA_STEP(word, 24, (j0) + 3)
 
-    for (uint32_t k = 0; k < nChunks; ++k) {
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (k + 1 < nChunks) nxt = chunk[k + 1];  // prefetch the next 16 bytes while this chunk is stepped
-        LC_TDFA_WORD(cur.x, 0)
-        LC_TDFA_WORD(cur.y, 4)
-        LC_TDFA_WORD(cur.z, 8)
-        LC_TDFA_WORD(cur.w, 12)
-        base += 16;
-        cur = nxt;
+    for (uint32_t w = 0; w < nWindows; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            nxt[q] = make_uint4(0, 0, 0, 0);
+            const uint32_t c = (w + 1) * 4 + q;
+            if (c < nChunks) nxt[q] = chunk[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t base = (w * 4 + q) * 16 - head;  // line offset of byte 0 of this chunk (wraps in the head)
+            const uint32_t words[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+            uint32_t col[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {  // class lookups: independent of the DFA state, issued together
+                const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                const uint32_t c4 = cmap[b];
+                col[j] = (base + j < L) ? c4 : idCol;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {  // the dependent chain: one LDS lookup per byte
+                const uint32_t t = *reinterpret_cast<const uint32_t*>(transBase + row + col[j]);
+                const uint32_t h = t >> TD_LIST_SHIFT;
+                if (h) tdfaRegisterProgram<BLOCK>(smem, v, h, base + j, tid);
+                row = t & TD_ROW_MASK;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
         if (row == 0) break;  // dead state: regex_match can no longer succeed for this line
     }
-#undef LC_TDFA_WORD
-#undef LC_TDFA_STEP
 
     if (!live) return;
     const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + v.finalId);
@@ -505,8 +524,9 @@ static int matchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_dat
 extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
                                             const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
                                             int32_t* d_caps, uint8_t* d_status, void* stream) {
-    if (!re || (!d_data && n) || !d_off || !d_caps || !d_status) return LC_ERR_ARG;
+    if (!re) return LC_ERR_ARG;
     if (n == 0) return LC_OK;
+    if (!d_data || !d_off || !d_caps || !d_status) return LC_ERR_ARG;
     if (lc_device_count() <= 0) {
         tlsError = "no HIP device";
         return LC_ERR_NO_DEVICE;

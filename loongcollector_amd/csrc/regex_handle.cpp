@@ -1,6 +1,7 @@
 // regex_handle.cpp -- host half of the C ABI: compile a pattern into device table blobs (no HIP calls here).
 #include "regex_handle.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -35,17 +36,39 @@ struct BlobWriter {
 }  // namespace
 
 std::vector<uint32_t> packTdfaBlob(const TdfaTables& t) {
-    const uint32_t rowBytes = t.nClasses * 4;
+    const uint32_t cols = t.nClasses + 1;  // + identity column
+    const uint32_t rowBytes = cols * 4;
     if (uint64_t(t.nStates) * rowBytes > (TD_ROW_MASK + 1ull)) throw RegexError("tdfa: transition table too large");
-    if (t.opsStart.size() - 1 > (1u << (32 - TD_LIST_SHIFT))) throw RegexError("tdfa: too many register programs");
+    const size_t nLists = t.opsStart.size() - 1;
+    // register programs that are "one or two consecutive registers <- pos" are folded into the transition word
+    std::vector<uint32_t> field(nLists, 0);
+    size_t general = 0;
+    for (size_t id = 1; id < nLists; ++id) {
+        const uint32_t at = t.opsStart[id];
+        const uint32_t n = t.ops[at];
+        const uint16_t* w = &t.ops[at + 1];
+        auto isPos = [&](uint32_t i) { return (w[i] >> 8) == kRegPos; };
+        if (n == 1 && isPos(0)) {
+            field[id] = TD_OP_INLINE | (w[0] & 0xFF);
+        } else if (n == 2 && isPos(0) && isPos(1) && ((w[0] & 0xFF) + 1 == (w[1] & 0xFF) || (w[1] & 0xFF) + 1 == (w[0] & 0xFF))) {
+            field[id] = TD_OP_INLINE | TD_OP_PAIR | std::min(w[0] & 0xFF, w[1] & 0xFF);
+        } else {
+            ++general;
+            field[id] = uint32_t(id);
+            if (id > TD_MAX_LISTS) throw RegexError("tdfa: too many register programs");
+        }
+    }
     BlobWriter w;
     w.reserve(TD_HEADER_WORDS * 4);
     std::vector<uint16_t> cmap(256);
     for (int b = 0; b < 256; ++b) cmap[size_t(b)] = uint16_t(t.classMap[size_t(b)] * 4);
-    std::vector<uint32_t> trans(t.trans.size());
-    for (size_t i = 0; i < t.trans.size(); ++i) {
-        uint32_t next = t.trans[i] & 0xFFFF, list = t.trans[i] >> 16;
-        trans[i] = (next * rowBytes) | (list << TD_LIST_SHIFT);
+    std::vector<uint32_t> trans(size_t(t.nStates) * cols);
+    for (uint32_t s = 0; s < t.nStates; ++s) {
+        for (uint32_t c = 0; c < t.nClasses; ++c) {
+            const uint32_t e = t.trans[size_t(s) * t.nClasses + c];
+            trans[size_t(s) * cols + c] = ((e & 0xFFFF) * rowBytes) | (field[e >> 16] << TD_LIST_SHIFT);
+        }
+        trans[size_t(s) * cols + t.nClasses] = s * rowBytes;  // identity column
     }
     uint32_t hdr[TD_HEADER_WORDS] = {};
     hdr[TD_MAGIC] = TD_MAGIC_VALUE;
@@ -55,6 +78,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t) {
     hdr[TD_NSLOTS] = t.nSlots;
     hdr[TD_START_ROW] = t.startState * rowBytes;
     hdr[TD_ROW_BYTES] = rowBytes;
+    hdr[TD_ID_COL] = t.nClasses * 4;
     hdr[TD_OFF_CLASSMAP] = w.put(cmap);
     hdr[TD_OFF_TRANS] = w.put(trans);
     hdr[TD_OFF_FINALID] = w.put(t.finalId);
