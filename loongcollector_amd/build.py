@@ -49,7 +49,7 @@ def build_native(force=False, verbose=False):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include"),
-              "-I", CSRC]
+              "-I", CSRC] + os.environ.get("LC_EXTRA_CXXFLAGS", "").split()
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

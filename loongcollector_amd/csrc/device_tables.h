@@ -1,41 +1,45 @@
 // device_tables.h -- layout of the table blobs the host compilers hand to the gfx950 kernels.
 // Shared by host C++ (packers) and HIP device code (readers).  All offsets are in bytes from the blob start and
-// are multiples of 16 so the blob can be staged into LDS with 16-byte copies.
+// are multiples of 16 so the blob can be staged into LDS with 16-byte copies.  The blob is staged at LDS
+// address 0 (the kernels use dynamic LDS only), so blob offsets are LDS addresses.
 #pragma once
 #include <stdint.h>
 
 // ---------------------------------------------------------------- TDFA blob (engine LC_ENGINE_TDFA)
-// header: 16 x u32
+// fixed prefix:  [0,64) header   [64,320) class map   [320, ...) transition table
 enum {
     TD_MAGIC = 0,        // 'TDFA'
     TD_NSTATES = 1,
     TD_NCLASSES = 2,
-    TD_NREGS = 3,        // per-line offset registers
+    TD_NREGS = 3,        // per-line offset registers, INCLUDING the trailing dummy register
     TD_NSLOTS = 4,       // 2 * capture groups
-    TD_START_ROW = 5,    // byte offset of the start state's row inside `trans`
-    TD_OFF_CLASSMAP = 6, // u16[256]: class(b) * 4
-    TD_OFF_TRANS = 7,    // u32[nStates*(nClasses+1)]: bits 0..19 next row byte offset, bits 20..31 register program (below)
+    TD_START_ROW = 5,    // LDS address of the start state's row (= TD_TRANS_OFFSET + start*rowBytes)
+    TD_OFF_CLASSMAP = 6, // == TD_CMAP_OFFSET
+    TD_OFF_TRANS = 7,    // == TD_TRANS_OFFSET
     TD_OFF_FINALID = 8,  // u16[nStates]: 0xFFFF = not accepting
     TD_OFF_FINALMAP = 9, // u8[nFinal*nSlots]
     TD_OFF_OPSSTART = 10, // u32[nLists+1] index (in u16 units) into ops
     TD_OFF_OPS = 11,     // u16[]: n, then n x (dst | src<<8)
     TD_TOTAL_BYTES = 12,
-    TD_ROW_BYTES = 13,   // (nClasses+1)*4: every row has one extra "identity" column (stay in this state, no register
-                         // program) that lanes use for bytes outside their line, so the byte loop needs no branches
+    TD_ROW_BYTES = 13,   // (nClasses+1)*4: every row has one extra "identity" column (stay in this state, stamp the
+                         // dummy register) that lanes use for bytes outside their line
     TD_ID_COL = 14,      // byte offset of the identity column inside a row (= nClasses*4)
+    TD_BLOCK = 15,       // workgroup size the register offsets were encoded for
     TD_HEADER_WORDS = 16
 };
 #define TD_MAGIC_VALUE 0x41464454u
-#define TD_ROW_MASK 0xFFFFFu
-#define TD_LIST_SHIFT 20
-// register program field h = entry >> 20:
-//   0                      : nothing to do
-//   0x800 | dst            : regs[dst] = pos                      (the overwhelmingly common case: one group boundary)
-//   0x800 | 0x100 | dst    : regs[dst] = regs[dst+1] = pos        (a group closes and the next opens at the same offset)
-//   1..0x7FF               : id of a general move list in `ops`
-#define TD_OP_INLINE 0x800u
-#define TD_OP_PAIR 0x100u
-#define TD_MAX_LISTS 0x7FFu
+#define TD_CMAP_OFFSET 64u    // u8[256]: class(b) * 4  (column byte offset inside a row; at most 63 classes)
+#define TD_TRANS_OFFSET 320u  // u32[nStates][nClasses+1]
+// transition entry:
+//   bits 0..15  LDS address of the next state's row (state 0 = dead, row address TD_TRANS_OFFSET)
+//   bits 16..31 register program:
+//       reg * BLOCK * 4          LDS offset (from regs[0][lane]) of the offset register that receives `pos`;
+//                                transitions that stamp nothing name the dummy register (index nRegs-1)
+//       (list << 1) | 1          general move list `list` in `ops` (anything that is not "one register = pos")
+#define TD_OP_GENERAL 0x1u
+#define TD_MAX_LISTS 0x7FFFu
+#define TD_MAX_TABLE_END 0x10000u     // rows must be addressable with 16 bits
+#define TD_MAX_REG_AREA 0x10000u      // nRegs*BLOCK*4: register offsets must fit the 16-bit field
 #define TD_REG_POS 0xFFu
 #define TD_REG_NONE 0xFEu
 

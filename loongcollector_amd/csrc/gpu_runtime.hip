@@ -17,7 +17,9 @@
 #include <vector>
 
 #include "device_tables.h"
+#include "nfa_kernel.hpp"
 #include "regex_handle.hpp"
+#include "tdfa_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string tlsError;
@@ -40,361 +42,6 @@ extern "C" int lc_device_count(void) {
         return 0;
     }
     return n;
-}
-
-// ------------------------------------------------------------------------------------------------ TDFA kernel
-// One log line per lane.  Per byte: one class lookup (off the dependency chain, issued 16 at a time) and one
-// transition lookup (the chain), both LDS.  Bytes outside the lane's line (alignment head / tail of the last
-// 16-byte chunk) take the row's identity column, so the byte loop has no validity branch.  Capture offsets live
-// in LDS as regs[reg][lane]; the register program of a transition is almost always "regs[d] = pos" and is then
-// encoded in the transition word itself (device_tables.h).
-struct TdfaView {  // LDS byte offsets, wave-uniform
-    uint32_t cmap, trans, finalId, finalMap, opsStart, ops, regs;
-};
-
-template <int BLOCK>
-__device__ __forceinline__ void tdfaRegisterProgram(uint8_t* smem, const TdfaView& v, uint32_t h, uint32_t pos,
-                                                    uint32_t tid) {
-    uint32_t* regs = reinterpret_cast<uint32_t*>(smem + v.regs);
-    if (h & TD_OP_INLINE) {
-        const uint32_t dst = h & 0xFFu;
-        regs[dst * BLOCK + tid] = pos;
-        if (h & TD_OP_PAIR) regs[(dst + 1) * BLOCK + tid] = pos;
-        return;
-    }
-    const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(smem + v.opsStart);
-    const uint16_t* ops = reinterpret_cast<const uint16_t*>(smem + v.ops);
-    const uint32_t at = opsStart[h];
-    const uint32_t cnt = ops[at];
-#pragma unroll 1
-    for (uint32_t i = 0; i < cnt; ++i) {
-        const uint32_t w = ops[at + 1 + i];
-        const uint32_t dst = w & 0xFF, src = w >> 8;
-        const uint32_t val = (src == TD_REG_POS) ? pos : regs[src * BLOCK + tid];
-        regs[dst * BLOCK + tid] = val;
-    }
-}
-
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void tdfa_match_kernel(const uint8_t* __restrict__ data,
-                                                           const uint32_t* __restrict__ off,
-                                                           const uint32_t* __restrict__ len, uint32_t sepBytes,
-                                                           uint32_t nLines, const uint32_t* __restrict__ blob,
-                                                           uint32_t blobBytes, uint32_t nGroupsOut,
-                                                           int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x;
-    {  // stage the tables: 16-byte coalesced copies
-        const uint4* src = reinterpret_cast<const uint4*>(blob);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
-    }
-    __syncthreads();
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
-    TdfaView v;
-    v.cmap = hdr[TD_OFF_CLASSMAP];
-    v.trans = hdr[TD_OFF_TRANS];
-    v.finalId = hdr[TD_OFF_FINALID];
-    v.finalMap = hdr[TD_OFF_FINALMAP];
-    v.opsStart = hdr[TD_OFF_OPSSTART];
-    v.ops = hdr[TD_OFF_OPS];
-    v.regs = blobBytes;
-    const uint32_t nSlots = hdr[TD_NSLOTS];
-    const uint32_t rowBytes = hdr[TD_ROW_BYTES];
-    const uint32_t idCol = hdr[TD_ID_COL];
-    uint32_t row = hdr[TD_START_ROW];
-
-    const uint32_t line = blockIdx.x * BLOCK + tid;
-    const bool live = line < nLines;
-    uint32_t o = 0, L = 0;
-    if (live) {
-        o = off[line];
-        L = len ? len[line] : off[line + 1] - o - sepBytes;
-    }
-    const uint16_t* cmap = reinterpret_cast<const uint16_t*>(smem + v.cmap);
-    const uint8_t* transBase = smem + v.trans;
-
-    // The line is walked in 64-byte windows of four aligned 16-byte loads; the next window is in flight while
-    // the current one is stepped.  An aligned 16-byte chunk that holds at least one byte of the line never leaves
-    // the line's pages, so no load can fault; chunks wholly outside the line are not loaded.
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
-    const uint32_t head = uint32_t(addr & 15);
-    const uint4* chunk = reinterpret_cast<const uint4*>(addr - head);
-    const uint32_t nChunks = L ? (head + L + 15) / 16 : 0;
-    const uint32_t nWindows = (nChunks + 3) / 4;
-    uint4 cur[4], nxt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        cur[q] = make_uint4(0, 0, 0, 0);
-        if (uint32_t(q) < nChunks) cur[q] = chunk[q];
-    }
-
-    for (uint32_t w = 0; w < nWindows; ++w) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            nxt[q] = make_uint4(0, 0, 0, 0);
-            const uint32_t c = (w + 1) * 4 + q;
-            if (c < nChunks) nxt[q] = chunk[c];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t base = (w * 4 + q) * 16 - head;  // line offset of byte 0 of this chunk (wraps in the head)
-            const uint32_t words[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
-            uint32_t col[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {  // class lookups: independent of the DFA state, issued together
-                const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                const uint32_t c4 = cmap[b];
-                col[j] = (base + j < L) ? c4 : idCol;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {  // the dependent chain: one LDS lookup per byte
-                const uint32_t t = *reinterpret_cast<const uint32_t*>(transBase + row + col[j]);
-                const uint32_t h = t >> TD_LIST_SHIFT;
-                if (h) tdfaRegisterProgram<BLOCK>(smem, v, h, base + j, tid);
-                row = t & TD_ROW_MASK;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-        if (row == 0) break;  // dead state: regex_match can no longer succeed for this line
-    }
-
-    if (!live) return;
-    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + v.finalId);
-    const uint8_t* finalMap = smem + v.finalMap;
-    const uint32_t* regs = reinterpret_cast<const uint32_t*>(smem + v.regs);
-    const uint32_t state = row / rowBytes;
-    const uint32_t fid = finalId[state];
-    const bool matched = (row != 0) && (fid != 0xFFFFu);
-    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
-    for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) {
-        int32_t val = -1;
-        if (matched && s < nSlots) {
-            const uint32_t m = finalMap[fid * nSlots + s];
-            if (m == TD_REG_POS) val = int32_t(L);
-            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid]);
-        }
-        out[s] = val;
-    }
-    status[line] = matched ? LC_MATCH : LC_NOMATCH;
-}
-
-// ------------------------------------------------------------------------------------------------ NFA kernel
-// One line per wavefront.  Lane t holds the t-th live thread of the Pike VM in backtracking-priority order:
-// (position, capture offsets in VGPRs).  Per input byte (wave-uniform, fetched with v_readlane from a 256-byte
-// chunk the wave loaded with one coalesced dword per lane):
-//   1. every lane walks its position's follow list (LDS) and keeps the paths whose target accepts the byte class
-//      and whose assertions hold; ds_min on best[target] elects, per target, the candidate of highest priority
-//      (rank = lexicographic (lane, path index));
-//   2. winners are compacted with a wave prefix sum into the new thread order and scattered through LDS;
-//   3. lane j pulls its captures from its source lane with ds_bpermute and stamps the tagged slots.
-constexpr int kNfaBlock = 256;  // 4 wavefronts = 4 lines per workgroup, sharing one LDS copy of the tables
-constexpr int kNfaWaves = kNfaBlock / 64;
-
-// LDS hand-off between lanes of ONE wavefront: order the wave's own DS operations and stop the compiler from
-// moving loads/stores across the hand-off (no s_barrier needed, the wave is the only party).
-__device__ __forceinline__ void waveLdsSync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t lane, uint32_t& total) {
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= uint32_t(d)) incl += up;
-    }
-    total = __shfl(incl, 63, 64);
-    return incl - v;
-}
-
-// bitmask of AssertKind values that hold between `prev` and `next` (wave-uniform inputs; -1 = edge of the line)
-__device__ __forceinline__ uint32_t condsTrue(int prev, int next) {
-    auto word = [](int c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
-    auto sep = [](int c) { return c == '\n' || c == '\r' || c == '\f'; };
-    const bool atStart = prev < 0, atEnd = next < 0;
-    const bool crlf = prev == '\r' && next == '\n';
-    const bool pw = !atStart && word(prev), nw = !atEnd && word(next);
-    uint32_t m = 0;
-    if (atStart || (sep(prev) && !crlf)) m |= 1u << 0;  // BolMulti
-    if (atStart) m |= 1u << 1;                           // BolSingle
-    if (atEnd || (sep(next) && !crlf)) m |= 1u << 2;     // EolMulti
-    if (atEnd) m |= 1u << 3;                             // EolSingle
-    if (pw != nw) m |= 1u << 4;                          // WordBoundary
-    if (pw == nw) m |= 1u << 5;                          // NotWordBoundary
-    if (!pw && nw) m |= 1u << 6;                         // WordStart
-    if (pw && !nw) m |= 1u << 7;                         // WordEnd
-    return m;
-}
-
-template <int NS>
-__global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __restrict__ data,
-                                                              const uint32_t* __restrict__ off,
-                                                              const uint32_t* __restrict__ len, uint32_t sepBytes,
-                                                              uint32_t nLines, const uint32_t* __restrict__ blob,
-                                                              uint32_t blobBytes, uint32_t nGroupsOut,
-                                                              int32_t* __restrict__ caps,
-                                                              uint8_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(blob);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < blobBytes / 16; i += kNfaBlock) dst[i] = src[i];
-    }
-    __syncthreads();
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
-    const uint32_t nPos = hdr[NF_NPOS];
-    const uint32_t nSlots = hdr[NF_NSLOTS];
-    const uint8_t* classMap = smem + hdr[NF_OFF_CLASSMAP];
-    const uint2* posMask = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_POSMASK]);
-    const uint32_t* followStart = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_FOLLOWSTART]);
-    const uint4* paths = reinterpret_cast<const uint4*>(smem + hdr[NF_OFF_PATHS]);
-
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newTagsLo, newTagsHi)
-    const uint32_t scratchWords = ((nPos + 3) & ~3u) + 256;
-    uint32_t* best = reinterpret_cast<uint32_t*>(smem + blobBytes) + wave * scratchWords;
-    uint32_t* newPos = best + ((nPos + 3) & ~3u);
-    uint32_t* newSrc = newPos + 64;
-    uint32_t* newTagsLo = newSrc + 64;
-    uint32_t* newTagsHi = newTagsLo + 64;
-    for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
-    waveLdsSync();
-
-    const uint32_t line = blockIdx.x * kNfaWaves + wave;
-    if (line >= nLines) return;  // wave-uniform
-    const uint32_t o = off[line];
-    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
-
-    int32_t cap[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) cap[s] = -1;
-    uint32_t nThreads = 1;
-    uint32_t myPos = nPos;  // lane 0: the start pseudo-position
-    bool overflow = false;
-
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
-    const uint32_t head = uint32_t(addr & 3);
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
-    const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
-    uint32_t curWord = (lane < nWords) ? words[lane] : 0;
-    int prevByte = -1;
-
-    for (uint32_t i = 0; i < L && nThreads; ++i) {
-        const uint32_t idx = head + i;
-        if (i && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
-            const uint32_t w = (idx >> 2) + lane;
-            curWord = (w < nWords) ? words[w] : 0;
-        }
-        const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
-        const int b = int((wsel >> ((idx & 3u) * 8)) & 0xFFu);
-        const uint32_t cls = classMap[b];
-        const uint32_t ctrue = condsTrue(prevByte, b);
-        prevByte = b;
-
-        const bool liveLane = lane < nThreads;
-        const uint32_t fs = liveLane ? followStart[myPos] : 0;
-        const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
-        uint32_t totalCand;
-        const uint32_t rankBase = waveExclusiveScan(cnt, lane, totalCand);
-        // pass 1: filter candidates, elect per-target winners
-        uint64_t passMask = 0;
-        for (uint32_t k = 0; __any(k < cnt); ++k) {
-            if (k < cnt) {
-                const uint4 p = paths[fs + k];
-                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
-                    const uint2 pm = posMask[p.x];
-                    const uint32_t bit = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
-                    if (bit) {
-                        passMask |= uint64_t(1) << k;
-                        atomicMin(&best[p.x], rankBase + k);
-                    }
-                }
-            }
-        }
-        waveLdsSync();
-        // pass 2: winners, in (lane, k) order
-        uint64_t winMask = 0;
-        for (uint64_t m = passMask; __any(m != 0);) {
-            if (m) {
-                const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
-                m &= m - 1;
-                const uint4 p = paths[fs + k];
-                if (best[p.x] == rankBase + k) winMask |= uint64_t(1) << k;
-            }
-        }
-        uint32_t totalWins;
-        uint32_t slot = waveExclusiveScan(uint32_t(__popcll(winMask)), lane, totalWins);
-        if (totalWins > 64) {
-            overflow = true;
-            break;
-        }
-        for (uint64_t m = winMask; __any(m != 0);) {
-            if (m) {
-                const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
-                m &= m - 1;
-                const uint4 p = paths[fs + k];
-                newPos[slot] = p.x;
-                newSrc[slot] = lane;
-                newTagsLo[slot] = p.z;
-                newTagsHi[slot] = p.w;
-                best[p.x] = 0xFFFFFFFFu;
-                ++slot;
-            }
-        }
-        waveLdsSync();
-        nThreads = totalWins;
-        uint32_t src = lane;
-        uint64_t tags = 0;
-        if (lane < nThreads) {
-            myPos = newPos[lane];
-            src = newSrc[lane];
-            tags = uint64_t(newTagsLo[lane]) | (uint64_t(newTagsHi[lane]) << 32);
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (uint32_t(s) < nSlots) {
-                const int32_t v = __shfl(cap[s], int(src), 64);
-                cap[s] = ((tags >> s) & 1) ? int32_t(i) : v;
-            }
-        }
-        waveLdsSync();  // newPos/newSrc are rewritten by the next byte's scatter
-    }
-
-    // acceptance at end of input: first thread (priority order) with a MATCH path whose assertions hold
-    bool accept = false;
-    uint64_t endTags = 0;
-    if (!overflow && lane < nThreads) {
-        const uint32_t ctrue = condsTrue(prevByte, -1);
-        const uint32_t fs = followStart[myPos], fe = followStart[myPos + 1];
-        for (uint32_t q = fs; q < fe; ++q) {
-            const uint4 p = paths[q];
-            if (p.x == NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
-                accept = true;
-                endTags = uint64_t(p.z) | (uint64_t(p.w) << 32);
-                break;
-            }
-        }
-    }
-    const uint64_t acc = __ballot(accept);
-    const bool matched = acc != 0;
-    const uint32_t winner = matched ? uint32_t(__ffsll((long long)acc)) - 1 : 0;
-    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
-    if (lane == winner) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (uint32_t(s) < 2 * nGroupsOut) {
-                int32_t v = -1;
-                if (matched && uint32_t(s) < nSlots) v = ((endTags >> s) & 1) ? int32_t(L) : cap[s];
-                out[s] = v;
-            }
-        }
-        status[line] = overflow ? LC_OVERFLOW : (matched ? LC_MATCH : LC_NOMATCH);
-    }
-    for (uint32_t s = NS + lane; s < 2 * nGroupsOut; s += 64) out[s] = -1;
 }
 
 // ------------------------------------------------------------------------------------------------ device tables
@@ -455,7 +102,7 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     int rc = ensureUploaded(re, dev, true, &dBlob);
     if (rc != LC_OK) return rc;
     const uint32_t blobBytes = uint32_t(re->tdfaBlob.size() * 4);
-    const int block = lcTdfaPickBlock(blobBytes, re->tdfa.nRegs);
+    const int block = re->tdfaBlock;  // the blob's register offsets are encoded for this workgroup size
     if (block == 0) {
         tlsError = "tdfa tables + registers exceed LDS";
         return LC_ERR_UNSUPPORTED;

@@ -35,52 +35,63 @@ struct BlobWriter {
 };
 }  // namespace
 
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t) {
+size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
+    auto pad = [](size_t n) { return (n + 15) & ~size_t(15); };
+    return TD_TRANS_OFFSET + pad(size_t(t.nStates) * (t.nClasses + 1) * 4) + pad(t.finalId.size() * 2) +
+           pad(t.finalMap.size()) + pad(t.opsStart.size() * 4) + pad(t.ops.size() * 2);
+}
+
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
     const uint32_t cols = t.nClasses + 1;  // + identity column
     const uint32_t rowBytes = cols * 4;
-    if (uint64_t(t.nStates) * rowBytes > (TD_ROW_MASK + 1ull)) throw RegexError("tdfa: transition table too large");
+    if (TD_TRANS_OFFSET + uint64_t(t.nStates) * rowBytes > TD_MAX_TABLE_END)
+        throw RegexError("tdfa: transition table exceeds the 64 KiB LDS window");
+    if (t.nClasses > 63) throw RegexError("tdfa: more than 63 byte classes");
+    const uint32_t dummyReg = t.nRegs;  // one past the real registers
+    const uint32_t regStride = uint32_t(block) * 4;
+    if (uint64_t(dummyReg + 1) * regStride > TD_MAX_REG_AREA) throw RegexError("tdfa: register file exceeds 64 KiB");
     const size_t nLists = t.opsStart.size() - 1;
-    // register programs that are "one or two consecutive registers <- pos" are folded into the transition word
+    // "one register = pos" is folded into the transition word; everything else stays a list
     std::vector<uint32_t> field(nLists, 0);
-    size_t general = 0;
+    field[0] = dummyReg * regStride;
     for (size_t id = 1; id < nLists; ++id) {
         const uint32_t at = t.opsStart[id];
         const uint32_t n = t.ops[at];
-        const uint16_t* w = &t.ops[at + 1];
-        auto isPos = [&](uint32_t i) { return (w[i] >> 8) == kRegPos; };
-        if (n == 1 && isPos(0)) {
-            field[id] = TD_OP_INLINE | (w[0] & 0xFF);
-        } else if (n == 2 && isPos(0) && isPos(1) && ((w[0] & 0xFF) + 1 == (w[1] & 0xFF) || (w[1] & 0xFF) + 1 == (w[0] & 0xFF))) {
-            field[id] = TD_OP_INLINE | TD_OP_PAIR | std::min(w[0] & 0xFF, w[1] & 0xFF);
+        const uint16_t w0 = t.ops[at + 1];
+        if (n == 1 && (w0 >> 8) == kRegPos) {
+            field[id] = uint32_t(w0 & 0xFF) * regStride;
         } else {
-            ++general;
-            field[id] = uint32_t(id);
             if (id > TD_MAX_LISTS) throw RegexError("tdfa: too many register programs");
+            field[id] = (uint32_t(id) << 1) | TD_OP_GENERAL;
         }
     }
     BlobWriter w;
     w.reserve(TD_HEADER_WORDS * 4);
-    std::vector<uint16_t> cmap(256);
-    for (int b = 0; b < 256; ++b) cmap[size_t(b)] = uint16_t(t.classMap[size_t(b)] * 4);
+    std::vector<uint8_t> cmap(256);
+    for (int b = 0; b < 256; ++b) cmap[size_t(b)] = uint8_t(t.classMap[size_t(b)] * 4);
     std::vector<uint32_t> trans(size_t(t.nStates) * cols);
+    auto rowAddr = [&](uint32_t state) { return TD_TRANS_OFFSET + state * rowBytes; };
     for (uint32_t s = 0; s < t.nStates; ++s) {
         for (uint32_t c = 0; c < t.nClasses; ++c) {
             const uint32_t e = t.trans[size_t(s) * t.nClasses + c];
-            trans[size_t(s) * cols + c] = ((e & 0xFFFF) * rowBytes) | (field[e >> 16] << TD_LIST_SHIFT);
+            trans[size_t(s) * cols + c] = rowAddr(e & 0xFFFF) | (field[e >> 16] << 16);
         }
-        trans[size_t(s) * cols + t.nClasses] = s * rowBytes;  // identity column
+        trans[size_t(s) * cols + t.nClasses] = rowAddr(s) | (field[0] << 16);  // identity column
     }
     uint32_t hdr[TD_HEADER_WORDS] = {};
     hdr[TD_MAGIC] = TD_MAGIC_VALUE;
     hdr[TD_NSTATES] = t.nStates;
     hdr[TD_NCLASSES] = t.nClasses;
-    hdr[TD_NREGS] = t.nRegs;
+    hdr[TD_NREGS] = t.nRegs + 1;
     hdr[TD_NSLOTS] = t.nSlots;
-    hdr[TD_START_ROW] = t.startState * rowBytes;
+    hdr[TD_START_ROW] = rowAddr(t.startState);
     hdr[TD_ROW_BYTES] = rowBytes;
     hdr[TD_ID_COL] = t.nClasses * 4;
+    hdr[TD_BLOCK] = uint32_t(block);
     hdr[TD_OFF_CLASSMAP] = w.put(cmap);
     hdr[TD_OFF_TRANS] = w.put(trans);
+    if (hdr[TD_OFF_CLASSMAP] != TD_CMAP_OFFSET || hdr[TD_OFF_TRANS] != TD_TRANS_OFFSET)
+        throw RegexError("tdfa: internal layout error");
     hdr[TD_OFF_FINALID] = w.put(t.finalId);
     hdr[TD_OFF_FINALMAP] = w.put(t.finalMap);
     hdr[TD_OFF_OPSSTART] = w.put(t.opsStart);
@@ -187,9 +198,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         if (engine != LC_ENGINE_NFA) {
             try {
                 re->tdfa = buildTdfa(re->nfa);
-                re->tdfaBlob = packTdfaBlob(re->tdfa);
-                if (!lcTdfaPickBlock(uint32_t(re->tdfaBlob.size() * 4), re->tdfa.nRegs))
-                    throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
+                re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
+                if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
+                re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
                 re->hasTdfa = true;
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                   re->tdfa.startState, 0, 0, 0};

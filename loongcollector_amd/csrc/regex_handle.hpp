@@ -21,6 +21,7 @@ struct lc_regex {
     lcregex::TdfaTables tdfa;
     std::vector<uint32_t> tdfaHeader;   // LC_TABLE_TDFA_HEADER view
     std::vector<uint32_t> tdfaBlob;     // device_tables.h TDFA layout
+    int tdfaBlock = 0;                  // workgroup size tdfaBlob was packed for
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
@@ -32,7 +33,9 @@ struct lc_regex {
 };
 
 namespace lcregex {
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t);
+// `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block);
+size_t tdfaBlobBytesEstimate(const TdfaTables& t);
 // throws RegexError when the NFA does not fit the device format (more than 64 byte classes)
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);
 }  // namespace lcregex
@@ -41,14 +44,19 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
 // TDFA: tables + nRegs x BLOCK x 4 B of offset registers.  Prefer 256-lane workgroups while a workgroup stays under
 // 64 KiB (>= 2 workgroups per CU); shrink the workgroup before giving up.  0 = does not fit in 160 KiB at all.
 constexpr size_t kLcLdsPerCu = 160 * 1024;
+// nRegs counts the real offset registers; the kernel adds one dummy register (see device_tables.h)
+inline size_t lcTdfaRegBytes(uint32_t nRegs, int block) { return size_t(nRegs + 1) * size_t(block) * 4; }
 inline size_t lcTdfaLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
-    return size_t(blobBytes) + size_t(nRegs) * size_t(block) * 4;
+    return size_t(blobBytes) + lcTdfaRegBytes(nRegs, block);
 }
 inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
+    auto fits = [&](int b, size_t budget) {
+        return lcTdfaRegBytes(nRegs, b) <= 0x10000 && lcTdfaLdsBytes(blobBytes, nRegs, b) <= budget;
+    };
     for (int b : {256, 128, 64})
-        if (lcTdfaLdsBytes(blobBytes, nRegs, b) <= 64 * 1024) return b;
+        if (fits(b, 64 * 1024)) return b;
     for (int b : {256, 128, 64})
-        if (lcTdfaLdsBytes(blobBytes, nRegs, b) <= kLcLdsPerCu) return b;
+        if (fits(b, kLcLdsPerCu)) return b;
     return 0;
 }
 inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos) {
