@@ -79,7 +79,7 @@ void lcReleaseDeviceTables(lc_regex* re) {
 }
 
 template <int BLOCK>
-static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
+static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
@@ -90,7 +90,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, size_t lds, co
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(tdfa_match_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
-                       static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+                       static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
@@ -108,10 +108,11 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
         return LC_ERR_UNSUPPORTED;
     }
     const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
+    const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
     switch (block) {
-        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-        default: return launchTdfaBlock<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
     }
 }
 

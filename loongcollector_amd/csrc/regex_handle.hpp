@@ -46,8 +46,13 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
 constexpr size_t kLcLdsPerCu = 160 * 1024;
 // nRegs counts the real offset registers; the kernel adds one dummy register (see device_tables.h)
 inline size_t lcTdfaRegBytes(uint32_t nRegs, int block) { return size_t(nRegs + 1) * size_t(block) * 4; }
+// per wavefront: 64 staging rows of 64+16 bytes (tdfa_kernel.hpp: kTdfaStagePerWave)
+#ifndef LC_TDFA_STAGE_BYTES
+#define LC_TDFA_STAGE_BYTES 64
+#endif
+inline size_t lcTdfaStageBytes(int block) { return size_t(block / 64) * 64 * (LC_TDFA_STAGE_BYTES + 16); }
 inline size_t lcTdfaLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
-    return size_t(blobBytes) + lcTdfaRegBytes(nRegs, block);
+    return size_t(blobBytes) + lcTdfaRegBytes(nRegs, block) + lcTdfaStageBytes(block);
 }
 inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
     auto fits = [&](int b, size_t budget) {

@@ -1,8 +1,18 @@
 // tdfa_kernel.hpp -- gfx950 kernel of the tagged-DFA engine (included by gpu_runtime.hip only).
 //
-// One log line per lane, 64 lines per wavefront, tables in LDS.  A line is walked in aligned 16-byte chunks;
-// every chunk is stepped in three phases so that the only serial dependency is the DFA state itself:
+// One log line per lane, 64 lines per wavefront, tables in LDS.
 //
+// HBM side.  A lane walking its own line with its own loads touches a different cache line per lane per load, and
+// with enough wavefronts in flight the lines are evicted from L2 between two visits (measured: 2.6-3.4x the
+// algorithmic bytes fetched, the kernel then sits on the HBM ceiling doing wasted traffic).  So the wavefront
+// loads COOPERATIVELY: per stage, four lanes fetch 64 contiguous bytes of one line (16 lines per
+// global_load_dwordx4, 4 loads per stage), the 64x64-byte tile goes to a per-wave LDS staging buffer, and each lane
+// then reads its own row back with ds_read_b128.  Every byte is fetched from HBM once, in 64-byte runs.  The next
+// stage's loads are in flight (in VGPRs) while the current stage is stepped.  Only the wavefront itself touches
+// its staging rows, so no workgroup barrier is involved.
+//
+// LDS side.  A stage is stepped in aligned 16-byte chunks; every chunk in three phases so that the only serial
+// dependency is the DFA state itself:
 //   phase 0  class lookups   col[j] = cmap8[byte j]                       16 x (v_add_sdwa + ds_read_u8), independent
 //   phase 1  state chain     t = lds32[(t & 0xFFFF) + col[j]]             16 x (v_add_sdwa + ds_read_b32), dependent;
 //                            the low half of a transition entry IS the LDS address of the next state's row
@@ -11,17 +21,15 @@
 //                            stamps; transitions that stamp nothing point at a dummy register, so phase 2 has no
 //                            branches and no divergence (lines hit group boundaries at different bytes: a
 //                            branch per byte would be taken by some lane almost every byte)
-//
 // Transitions whose register program is more than "one register = pos" (rare for log regexes) carry a list id
-// and a flag instead; a wave that saw such a flag anywhere in the chunk replays phase 2 in order, with branches.
+// and a flag instead; a wave that saw such a flag anywhere in the chunk replays the chunk in order, with branches.
 // Capture-offset registers live in LDS as regs[reg][lane]: the register number is data dependent (VGPRs would
-// need scratch indexing) and [reg][lane] is bank-conflict free for both phases.
+// need scratch indexing) and [reg][lane] is bank-conflict free.
 //
-// Bytes outside the lane's line (head of the first aligned chunk, tail of the last) take the row's identity
-// column.  When every lane of the wavefront is in the middle of its line a wave-uniform branch skips the
-// validity selects.  Lines are read with aligned 16-byte global loads through a ring of four chunk registers, so
-// three chunks are always ahead of the one being stepped.  An aligned 16-byte chunk holding at least one byte of the line never
-// leaves the line's pages, so no load can fault; chunks wholly outside the line are not loaded.
+// Bytes outside the lane's line (head of the first aligned chunk, tail of the last, stages past the end of a
+// short line) take the row's identity column.  When every lane of the wavefront is in the middle of its line a
+// wave-uniform branch skips the validity selects.  Loads are aligned 16-byte segments that contain at least one
+// byte of the line, so none can leave the line's pages.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,17 +38,32 @@
 #include "device_tables.h"
 
 #ifndef LC_TDFA_MIN_WAVES
-#define LC_TDFA_MIN_WAVES 6  // waves per SIMD the register allocator must leave room for (VGPR budget 80)
+#define LC_TDFA_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for
 #endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t __attribute__((address_space(3))) * LdsWordPtr;
+typedef u32x4 __attribute__((address_space(3))) * LdsQuadPtr;
 typedef const uint8_t __attribute__((address_space(3))) * LdsBytePtr;
+typedef const u32x4 __attribute__((address_space(1))) * GlobalQuadPtr;
 
-// general register program (a list of moves); rare for log regexes, kept out of line so the byte loop stays small
+#ifndef LC_TDFA_STAGE_BYTES
+#define LC_TDFA_STAGE_BYTES 64
+#endif
+constexpr uint32_t kTdfaStageBytes = LC_TDFA_STAGE_BYTES;  // bytes of each line staged per round (32 or 64)
+constexpr int kTdfaLoads = int(kTdfaStageBytes / 16);       // loads per stage == lanes that share one line
+constexpr uint32_t kTdfaRowStride = kTdfaStageBytes + 16;  // +16: rows 20 dwords apart -> conflict-free b128 reads
+constexpr uint32_t kTdfaStagePerWave = 64 * kTdfaRowStride;
+
+__device__ __forceinline__ void tdfaWaveLdsSync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// general register program (a list of moves); rare for log regexes
 template <int BLOCK>
 __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase, uint32_t list, uint32_t pos,
-                                             uint32_t tid) {
+                                                uint32_t tid) {
     uint32_t* regs = reinterpret_cast<uint32_t*>(smem + regsBase);
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_OPSSTART]);
@@ -74,11 +97,10 @@ __device__ __forceinline__ uint32_t addHighHalf(uint32_t a, uint32_t t) {
 }
 
 // In-order replay of one chunk for wavefronts that met a general register program in it: re-walks the 16 bytes
-// from the chunk's entry state and applies every register program at its own byte.  Out of line and rolled up:
-// it is rare, and keeping it small keeps the hot loop's register footprint small.
+// from the chunk's entry state and applies every register program at its own byte.  Rolled up: it is rare.
 template <int BLOCK>
 __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t t, uint32_t base, uint32_t L,
-                                             uint32_t idCol, uint32_t regsBase, uint32_t tid) {
+                                                uint32_t idCol, uint32_t regsBase, uint32_t tid) {
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
     const uint32_t regAddr0 = regsBase + tid * 4;
 #pragma unroll 1
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                            uint32_t nLines, const uint32_t* __restrict__ blob,
-                                                           uint32_t blobBytes, uint32_t nGroupsOut,
+                                                           uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -147,6 +169,9 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const uint32_t regsBase = blobBytes;
     uint32_t t = hdr[TD_START_ROW];  // low 16 bits: LDS address of the current state's row
 
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t stageBase = blobBytes + regBytes + wave * kTdfaStagePerWave;  // this wave's staging rows (LDS address)
+
     const uint32_t line = blockIdx.x * BLOCK + tid;
     const bool live = line < nLines;
     uint32_t o = 0, L = 0;
@@ -154,36 +179,66 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         o = off[line];
         L = len ? len[line] : off[line + 1] - o - sepBytes;
     }
-
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 15);
-    // address_space(1): the loads must be global_load (vmcnt only).  A generic pointer makes them flat_load, which
-    // also counts on lgkmcnt -- every LDS wait of the byte loop would then drain the prefetch.
-    typedef const u32x4 __attribute__((address_space(1))) * GlobalChunk;
-    const GlobalChunk chunk = reinterpret_cast<GlobalChunk>(addr - head);
-    const uint32_t nChunks = L ? (head + L + 15) / 16 : 0;
-    // ring of four chunks: while chunk k is stepped, chunks k+1..k+3 are in registers or in flight
-    u32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-    if (0 < nChunks) c0 = chunk[0];
-    if (1 < nChunks) c1 = chunk[1];
-    if (2 < nChunks) c2 = chunk[2];
-    if (3 < nChunks) c3 = chunk[3];
+    const uintptr_t rowStart = addr - head;              // 16-byte aligned start of this lane's line
+    const uint32_t span = L ? head + L : 0;              // staged bytes [0, span) of the aligned run are needed
+    const uint32_t myStages = (span + kTdfaStageBytes - 1) / kTdfaStageBytes;
+    uint32_t maxStages = myStages;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t other = __shfl_xor(maxStages, d, 64);
+        maxStages = other > maxStages ? other : maxStages;
+    }
 
-    for (uint32_t k = 0; k < nChunks; ++k) {
-        u32x4 incoming = {0, 0, 0, 0};
-        if (k + 4 < nChunks) incoming = chunk[k + 4];
-        const uint32_t base = k * 16 - head;  // line offset of byte 0 of the chunk (wraps in the head)
-        const bool full = base < L && L - base >= 16;
-        if (__all(full)) {
-            t = tdfaStepChunk<BLOCK, false>(smem, c0, t, base, L, idCol, regsBase, tid);
-        } else {
-            t = tdfaStepChunk<BLOCK, true>(smem, c0, t, base, L, idCol, regsBase, tid);
+    // cooperative load plan: kTdfaLoads lanes share one line; load i of a stage serves line r = (64/kTdfaLoads)*i +
+    // lane/kTdfaLoads, 16-byte segment lane%kTdfaLoads
+    const uint32_t seg = (lane % kTdfaLoads) * 16;
+    uintptr_t srcAddr[kTdfaLoads];
+    uint32_t srcSpan[kTdfaLoads], dstAddr[kTdfaLoads];
+#pragma unroll
+    for (int i = 0; i < kTdfaLoads; ++i) {
+        const int r = (64 / kTdfaLoads) * i + int(lane / kTdfaLoads);
+        const uint32_t lo = __shfl(uint32_t(rowStart), r, 64);
+        const uint32_t hi = __shfl(uint32_t(rowStart >> 32), r, 64);
+        srcAddr[i] = ((uintptr_t(hi) << 32) | lo) + seg;
+        srcSpan[i] = __shfl(span, r, 64);
+        dstAddr[i] = stageBase + uint32_t(r) * kTdfaRowStride + seg;
+    }
+    const uint32_t myRow = stageBase + lane * kTdfaRowStride;
+
+    u32x4 in[kTdfaLoads];
+#pragma unroll
+    for (int i = 0; i < kTdfaLoads; ++i) {  // stage 0
+        in[i] = u32x4{0, 0, 0, 0};
+        if (seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i]);
+    }
+
+    for (uint32_t s = 0; s < maxStages; ++s) {
+        // publish stage s to LDS, then put stage s+1 in flight
+        tdfaWaveLdsSync();
+#pragma unroll
+        for (int i = 0; i < kTdfaLoads; ++i) *reinterpret_cast<LdsQuadPtr>(dstAddr[i]) = in[i];
+        tdfaWaveLdsSync();
+        const uint32_t nextOff = (s + 1) * kTdfaStageBytes;
+#pragma unroll
+        for (int i = 0; i < kTdfaLoads; ++i) {
+            in[i] = u32x4{0, 0, 0, 0};
+            if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i] + nextOff);
         }
-        c0 = c1;
-        c1 = c2;
-        c2 = c3;
-        c3 = incoming;
-        if ((t & 0xFFFFu) == TD_TRANS_OFFSET) break;  // dead state (row 0): regex_match can no longer succeed
+#pragma unroll 1
+        for (uint32_t k = 0; k < kTdfaStageBytes / 16; ++k) {
+            const u32x4 q = *reinterpret_cast<LdsQuadPtr>(myRow + k * 16);
+            const uint32_t base = s * kTdfaStageBytes + k * 16 - head;  // line offset of byte 0 (wraps in the head)
+            const bool full = base < L && L - base >= 16;
+            if (__all(full)) {
+                t = tdfaStepChunk<BLOCK, false>(smem, q, t, base, L, idCol, regsBase, tid);
+            } else {
+                t = tdfaStepChunk<BLOCK, true>(smem, q, t, base, L, idCol, regsBase, tid);
+            }
+        }
+        // every lane dead (or past its end in the identity column): nothing left to decide for this wavefront
+        if (__all((t & 0xFFFFu) == TD_TRANS_OFFSET || s + 1 >= myStages)) break;
     }
 
     if (!live) return;
