@@ -1,0 +1,104 @@
+/*
+ * lc_processor.h -- C ABI of the processor layer: the MI355X replacement for processor_parse_regex_native, plus the
+ * dynamic C processor slot LoongCollector already loads with dlopen.
+ *
+ *   reference                                                                 this ABI
+ *   ------------------------------------------------------------------------  -----------------------------
+ *   ProcessorParseRegexNative::Init(const Json::Value&)                       lc_processor_create
+ *     core/plugin/processor/ProcessorParseRegexNative.cpp:29-106
+ *   ProcessorInstance::Process -> ProcessorParseRegexNative::Process(group)   lc_processor_process
+ *     core/collection_pipeline/plugin/instance/ProcessorInstance.cpp:46-63
+ *     core/plugin/processor/ProcessorParseRegexNative.cpp:108-168,186-253
+ *   plugin + instance counters (cpp:100-103, ProcessorInstance.cpp:37-42)      lc_processor_counters
+ *   PipelineEventGroup::FromJsonString / ToJsonString (unit-test fixtures)     lc_group_from_json / lc_group_to_json
+ *     core/models/PipelineEventGroup.h:140-146
+ *   processor_interface_t + dlsym("processor_interface")                      processor_interface (data symbol)
+ *     core/collection_pipeline/plugin/creator/CProcessor.h:23-45
+ *     core/collection_pipeline/plugin/PluginRegistry.cpp:233-290
+ *
+ * The event group handed to lc_processor_process / processor_interface.process is a logtail::PipelineEventGroup.
+ * In this repository that is the header-compatible stand-in (loongcollector_amd/csrc/event_model.hpp); built inside
+ * the reference tree with -DLC_USE_REFERENCE_HEADERS it is the reference's own class.
+ */
+#ifndef LC_PROCESSOR_H
+#define LC_PROCESSOR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lc_processor lc_processor_t;
+typedef struct lc_event_group lc_event_group_t;
+
+/* counters, in the order lc_processor_counters fills them */
+enum {
+    LC_CNT_DISCARDED_EVENTS = 0,      /* discarded_events_total */
+    LC_CNT_OUT_FAILED_EVENTS = 1,     /* out_failed_events_total */
+    LC_CNT_OUT_KEY_NOT_FOUND = 2,     /* out_key_not_found_events_total */
+    LC_CNT_OUT_SUCCESSFUL_EVENTS = 3, /* out_successful_events_total */
+    LC_CNT_IN_EVENTS = 4,             /* instance: in_events_total */
+    LC_CNT_OUT_EVENTS = 5,            /* instance: out_events_total */
+    LC_CNT_IN_SIZE_BYTES = 6,         /* instance: in_size_bytes */
+    LC_CNT_OUT_SIZE_BYTES = 7,        /* instance: out_size_bytes */
+    LC_CNT_PROCESS_TIME_US = 8,       /* instance: total_process_time (microseconds) */
+    LC_CNT_COUNT = 9
+};
+
+/* config_json: the plugin's JSON object, e.g.
+ *   {"SourceKey":"content","Regex":"(\\w+)\\t(\\w+).*","Keys":["key1","key2"],"KeepingSourceWhenParseFail":true}
+ * Returns 0 on success; non-zero (and a message in err) wherever the reference's Init returns false. */
+int lc_processor_create(const char* config_json, lc_processor_t** out, char* err, size_t errcap);
+void lc_processor_destroy(lc_processor_t* p);
+/* number of keys after the legacy ["k1,k2"] split; key i (NULL when out of range) */
+int lc_processor_key_count(const lc_processor_t* p);
+const char* lc_processor_key(const lc_processor_t* p, int i);
+
+/* Runs the processor over one event group, in place.  Returns 0, or an LC_ERR_* code when the GPU could not be
+ * used (the group is then left untouched: there is no CPU fallback). */
+int lc_processor_process(lc_processor_t* p, lc_event_group_t* group);
+int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]);
+
+/* test fixtures in the reference unit tests' JSON format */
+lc_event_group_t* lc_group_from_json(const char* json, char* err, size_t errcap);
+/* malloc'd NUL-terminated JSON; release with lc_free */
+char* lc_group_to_json(const lc_event_group_t* g);
+size_t lc_group_event_count(const lc_event_group_t* g);
+/* the logtail::PipelineEventGroup* inside the fixture wrapper (what processor_interface.process expects) */
+void* lc_group_native(lc_event_group_t* g);
+void lc_group_free(lc_event_group_t* g);
+void lc_free(void* p);
+
+/* ---- the dynamic C processor slot (layout identical to CProcessor.h:23-45) ---- */
+#define LC_PROCESSOR_INTERFACE_VERSION 100
+
+struct processor_instance_t;
+typedef int (*processor_init_func_t)(struct processor_instance_t* ins, void* config, void* context);
+typedef void (*processor_finialize_func_t)(void* plugin_state);
+typedef void (*processor_process_func_t)(void* plugin_state, void* logGroup);
+
+typedef struct processor_interface_t {
+    int version;
+    const char* name;
+    const char* language;
+    processor_init_func_t init;
+    processor_finialize_func_t finalize;
+    processor_process_func_t process;
+} processor_interface_t;
+
+typedef struct processor_instance_t {
+    const processor_interface_t* plugin;
+    void* plugin_state;
+} processor_instance_t;
+
+/* Looked up by PluginRegistry::LoadProcessorPlugin with dlsym.  init(): `config` is the plugin's JSON config as
+ * NUL-terminated text in this build (a Json::Value* when built with LC_USE_REFERENCE_HEADERS); `context` is unused.
+ * process(): `logGroup` is a logtail::PipelineEventGroup*. */
+extern processor_interface_t processor_interface;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

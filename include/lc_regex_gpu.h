@@ -136,6 +136,12 @@ int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_da
 int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
                         uint32_t ngroups, int32_t* caps, uint8_t* status);
 
+/* Same, for lines given as n independent views (pointer + length), which is what a PipelineEventGroup holds after
+ * ProcessorSplitLogStringNative: StringViews into the group's SourceBuffer.  Views that sit back to back in memory
+ * are staged with one memcpy per chunk; scattered views are gathered line by line. */
+int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* lines, const uint32_t* len, uint32_t n,
+                              uint32_t ngroups, int32_t* caps, uint8_t* status);
+
 /* last HIP error string of the calling thread (for LC_ERR_HIP) */
 const char* lc_last_error(void);
 

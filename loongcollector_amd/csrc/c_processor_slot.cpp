@@ -1,0 +1,150 @@
+// c_processor_slot.cpp -- C ABI of the processor layer (include/lc_processor.h) and the `processor_interface` data
+// symbol LoongCollector's PluginRegistry looks up with dlsym
+// (core/collection_pipeline/plugin/PluginRegistry.cpp:270-290, struct layout CProcessor.h:23-45).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "../../include/lc_processor.h"
+#include "event_model.hpp"
+#include "processor_parse_regex_gpu.hpp"
+
+using logtail::PipelineEventGroup;
+using logtail::ProcessorParseRegexGpu;
+
+struct lc_processor {
+    ProcessorParseRegexGpu impl;
+    // the part ProcessorInstance adds around every plugin (ProcessorInstance.cpp:46-63)
+    std::atomic<uint64_t> inEvents{0}, outEvents{0}, inBytes{0}, outBytes{0}, processUs{0};
+};
+
+struct lc_event_group {
+    std::shared_ptr<logtail::SourceBuffer> buffer = std::make_shared<logtail::SourceBuffer>();
+    PipelineEventGroup group{buffer};
+};
+
+static void setErr(char* err, size_t cap, const std::string& msg) {
+    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+static int processGroup(lc_processor* p, PipelineEventGroup& group) {
+    p->inEvents += group.GetEvents().size();
+    p->inBytes += group.DataSize();
+    const auto t0 = std::chrono::steady_clock::now();
+    p->impl.Process(group);
+    p->processUs += uint64_t(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    p->outEvents += group.GetEvents().size();
+    p->outBytes += group.DataSize();
+    return 0;
+}
+
+extern "C" int lc_processor_create(const char* config_json, lc_processor_t** out, char* err, size_t errcap) {
+    if (!config_json || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    lcjson::Value cfg;
+    try {
+        cfg = lcjson::parse(config_json);
+    } catch (const std::exception& e) {
+        setErr(err, errcap, e.what());
+        return LC_ERR_ARG;
+    }
+    auto p = std::make_unique<lc_processor>();
+    if (const lcjson::Value* eng = cfg.find("_Engine")) {  // test hook: "tdfa" | "nfa"
+        if (eng->str == "tdfa") p->impl.mEngineChoice = LC_ENGINE_TDFA;
+        if (eng->str == "nfa") p->impl.mEngineChoice = LC_ENGINE_NFA;
+    }
+    std::string error;
+    if (!p->impl.Init(cfg, error)) {
+        setErr(err, errcap, error);
+        return LC_ERR_SYNTAX;
+    }
+    setErr(err, errcap, "");
+    *out = p.release();
+    return LC_OK;
+}
+
+extern "C" void lc_processor_destroy(lc_processor_t* p) { delete p; }
+
+extern "C" int lc_processor_key_count(const lc_processor_t* p) { return p ? int(p->impl.mKeys.size()) : -1; }
+extern "C" const char* lc_processor_key(const lc_processor_t* p, int i) {
+    if (!p || i < 0 || size_t(i) >= p->impl.mKeys.size()) return nullptr;
+    return p->impl.mKeys[size_t(i)].c_str();
+}
+
+extern "C" int lc_processor_process(lc_processor_t* p, lc_event_group_t* g) {
+    if (!p || !g) return LC_ERR_ARG;
+    // a group that needs the device must not be half-processed when there is none: check first, fail loudly
+    if (!p->impl.IsWholeLineMode() && lc_device_count() <= 0) {
+        bool needsDevice = false;
+        for (const auto& e : g->group.GetEvents())
+            if (e.Is<logtail::LogEvent>() && e.Cast<logtail::LogEvent>().HasContent(p->impl.mSourceKey)) needsDevice = true;
+        if (needsDevice) return LC_ERR_NO_DEVICE;
+    }
+    return processGroup(p, g->group);
+}
+
+extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]) {
+    if (!p || !out) return LC_ERR_ARG;
+    out[LC_CNT_DISCARDED_EVENTS] = p->impl.mDiscardedEventsTotal;
+    out[LC_CNT_OUT_FAILED_EVENTS] = p->impl.mOutFailedEventsTotal;
+    out[LC_CNT_OUT_KEY_NOT_FOUND] = p->impl.mOutKeyNotFoundEventsTotal;
+    out[LC_CNT_OUT_SUCCESSFUL_EVENTS] = p->impl.mOutSuccessfulEventsTotal;
+    out[LC_CNT_IN_EVENTS] = p->inEvents;
+    out[LC_CNT_OUT_EVENTS] = p->outEvents;
+    out[LC_CNT_IN_SIZE_BYTES] = p->inBytes;
+    out[LC_CNT_OUT_SIZE_BYTES] = p->outBytes;
+    out[LC_CNT_PROCESS_TIME_US] = p->processUs;
+    return LC_OK;
+}
+
+extern "C" lc_event_group_t* lc_group_from_json(const char* json, char* err, size_t errcap) {
+    if (!json) return nullptr;
+    auto g = std::make_unique<lc_event_group>();
+    std::string error;
+    if (!g->group.FromJsonString(json, &error)) {
+        setErr(err, errcap, error);
+        return nullptr;
+    }
+    setErr(err, errcap, "");
+    return g.release();
+}
+
+extern "C" char* lc_group_to_json(const lc_event_group_t* g) {
+    if (!g) return nullptr;
+    const std::string s = g->group.ToJsonString();
+    char* out = static_cast<char*>(std::malloc(s.size() + 1));
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return out;
+}
+
+extern "C" size_t lc_group_event_count(const lc_event_group_t* g) { return g ? g->group.GetEvents().size() : 0; }
+extern "C" void* lc_group_native(lc_event_group_t* g) { return g ? &g->group : nullptr; }
+extern "C" void lc_group_free(lc_event_group_t* g) { delete g; }
+extern "C" void lc_free(void* p) { std::free(p); }
+
+// ---------------------------------------------------------------------------------------------- the dlsym slot
+// Call protocol (core/plugin/processor/DynamicCProcessorProxy.cpp:25-40): init(ins, &config, &context) must set
+// ins->plugin_state and return 0; process(plugin_state, &group) mutates the group in place; finalize(plugin_state).
+static int slotInit(processor_instance_t* ins, void* config, void* /*context*/) {
+    if (!ins || !config) return -1;
+    lc_processor_t* p = nullptr;
+    char err[256];
+    if (lc_processor_create(static_cast<const char*>(config), &p, err, sizeof err) != LC_OK) {
+        std::fprintf(stderr, "[processor_parse_regex_gpu] init failed: %s\n", err);
+        return -1;
+    }
+    ins->plugin_state = p;
+    return 0;
+}
+static void slotFinalize(void* state) { lc_processor_destroy(static_cast<lc_processor_t*>(state)); }
+static void slotProcess(void* state, void* logGroup) {
+    if (!state || !logGroup) return;
+    processGroup(static_cast<lc_processor_t*>(state), *static_cast<PipelineEventGroup*>(logGroup));
+}
+
+extern "C" {
+processor_interface_t processor_interface = {LC_PROCESSOR_INTERFACE_VERSION, "processor_parse_regex_gpu", "c++/hip",
+                                             slotInit, slotFinalize, slotProcess};
+}

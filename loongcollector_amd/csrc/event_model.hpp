@@ -1,0 +1,325 @@
+// event_model.hpp -- a header-compatible stand-in for the slice of LoongCollector's event model that the regex
+// parse processor touches.  Same namespace, type names and member-function names as the reference, so that
+// processor_parse_regex_gpu.cpp compiles unchanged against either this header or the reference's own
+//   core/models/PipelineEventGroup.h:71-158   core/models/LogEvent.h:64-132   core/models/PipelineEventPtr.h:32-96
+//   core/common/StringView.h:25               core/common/memory/SourceBuffer.h:29-181
+// (define LC_USE_REFERENCE_HEADERS in the reference tree).  Written from the interface, not copied: only the
+// observable semantics the reference unit tests pin are reproduced --
+//   * contents are an ordered list of (key,value,alive); lookups scan from the back; delete is a tombstone that keeps
+//     order; SetContentNoCopy overwrites in place or appends   (LogEvent.cpp:50-106)
+//   * values are views into memory owned by the group's SourceBuffer (zero copy)
+//   * the arena hands out NUL-terminated, 8-byte aligned copies from chunks that double from 4 KiB to 128 KiB and
+//     gives requests of at least half a chunk their own block   (SourceBuffer.h:45-153)
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+namespace logtail {
+
+class StringView : public std::string_view {
+public:
+    using std::string_view::string_view;
+    StringView() = default;
+    StringView(std::string_view v) : std::string_view(v) {}
+    StringView(const std::string& s) : std::string_view(s) {}
+    std::string to_string() const { return std::string(data(), size()); }
+};
+
+struct StringBuffer {
+    char* data = nullptr;
+    size_t size = 0;      // bytes in use (excluding the terminating NUL)
+    size_t capacity = 0;  // bytes reserved (including the NUL)
+};
+
+class SourceBuffer {
+public:
+    StringBuffer AllocateStringBuffer(size_t size) {
+        StringBuffer sb;
+        sb.capacity = size + 1;
+        sb.data = static_cast<char*>(allocate(sb.capacity));
+        sb.data[0] = '\0';
+        sb.data[size] = '\0';
+        sb.size = size;
+        return sb;
+    }
+    StringBuffer CopyString(const char* s, size_t len) {
+        StringBuffer sb = AllocateStringBuffer(len);
+        if (len) std::memcpy(sb.data, s, len);
+        sb.data[len] = '\0';
+        return sb;
+    }
+    StringBuffer CopyString(StringView s) { return CopyString(s.data(), s.size()); }
+    StringBuffer CopyString(const std::string& s) { return CopyString(s.data(), s.size()); }
+    size_t chunkCount() const { return mChunks.size(); }
+
+private:
+    static constexpr size_t kFirstChunk = 4096, kMaxChunk = 128 * 1024, kAlign = 8;
+    struct Chunk {
+        std::unique_ptr<char[]> mem;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Chunk> mChunks;
+    size_t mNextChunk = kFirstChunk;
+    size_t mCurrent = size_t(-1);
+
+    void* allocate(size_t bytes) {
+        bytes = (bytes + kAlign - 1) & ~(kAlign - 1);
+        if (bytes >= mNextChunk / 2) {  // big request: its own block, the running chunk stays current
+            Chunk c;
+            c.mem.reset(new char[bytes]);
+            c.cap = c.used = bytes;
+            mChunks.push_back(std::move(c));
+            if (mCurrent != size_t(-1) && mCurrent == mChunks.size() - 1) mCurrent = size_t(-1);
+            return mChunks.back().mem.get();
+        }
+        if (mCurrent == size_t(-1) || mChunks[mCurrent].used + bytes > mChunks[mCurrent].cap) {
+            Chunk c;
+            c.mem.reset(new char[mNextChunk]);
+            c.cap = mNextChunk;
+            mChunks.push_back(std::move(c));
+            mCurrent = mChunks.size() - 1;
+            if (mNextChunk < kMaxChunk) mNextChunk *= 2;
+        }
+        Chunk& cur = mChunks[mCurrent];
+        void* p = cur.mem.get() + cur.used;
+        cur.used += bytes;
+        return p;
+    }
+};
+
+enum class EventGroupMetaKey {
+    UNKNOWN,
+    LOG_FILE_PATH,
+    LOG_FILE_PATH_RESOLVED,
+    LOG_FILE_INODE,
+    LOG_FILE_OFFSET_KEY,
+    SOURCE_ID
+};
+using GroupMetadata = std::map<EventGroupMetaKey, StringView>;
+using GroupTags = std::map<StringView, StringView>;
+
+class PipelineEventGroup;
+
+class PipelineEvent {
+public:
+    enum class Type { NONE, LOG, METRIC, SPAN, RAW };
+    virtual ~PipelineEvent() = default;
+    Type GetType() const { return mType; }
+    time_t GetTimestamp() const { return mTimestamp; }
+    std::optional<uint32_t> GetTimestampNanosecond() const { return mTimestampNanosecond; }
+    void SetTimestamp(time_t t) { mTimestamp = t; }
+    void SetTimestamp(time_t t, uint32_t ns) {
+        mTimestamp = t;
+        mTimestampNanosecond = ns;
+    }
+    virtual size_t DataSize() const { return sizeof(mTimestamp) + sizeof(mTimestampNanosecond); }
+    std::shared_ptr<SourceBuffer>& GetSourceBuffer();
+
+protected:
+    PipelineEvent(Type t, PipelineEventGroup* g) : mType(t), mGroup(g) {}
+    Type mType;
+    time_t mTimestamp = 0;
+    std::optional<uint32_t> mTimestampNanosecond;
+    PipelineEventGroup* mGroup;
+};
+
+using LogContent = std::pair<StringView, StringView>;
+using ContentsContainer = std::vector<std::pair<LogContent, bool>>;
+
+class LogEvent : public PipelineEvent {
+public:
+    explicit LogEvent(PipelineEventGroup* g) : PipelineEvent(Type::LOG, g) {}
+
+    // iterates live contents in insertion order
+    class ConstContentIterator {
+    public:
+        ConstContentIterator(ContentsContainer::const_iterator it, const ContentsContainer& c) : mIt(it), mC(&c) {}
+        const LogContent& operator*() const { return mIt->first; }
+        const LogContent* operator->() const { return &mIt->first; }
+        ConstContentIterator& operator++() {
+            do {
+                ++mIt;
+            } while (mIt != mC->end() && !mIt->second);
+            return *this;
+        }
+        bool operator==(const ConstContentIterator& o) const { return mIt == o.mIt; }
+        bool operator!=(const ConstContentIterator& o) const { return mIt != o.mIt; }
+
+    private:
+        ContentsContainer::const_iterator mIt;
+        const ContentsContainer* mC;
+    };
+
+    StringView GetContent(StringView key) const {
+        const auto* e = findLive(key);
+        return e ? e->first.second : StringView();
+    }
+    bool HasContent(StringView key) const { return findLive(key) != nullptr; }
+    void SetContent(StringView key, StringView val);
+    void SetContent(const std::string& key, const std::string& val) { SetContent(StringView(key), StringView(val)); }
+    void SetContentNoCopy(StringView key, StringView val) {
+        auto* e = const_cast<std::pair<LogContent, bool>*>(findLive(key));
+        if (e) {
+            mAllocatedContentSize += key.size() + val.size() - e->first.first.size() - e->first.second.size();
+            e->first = LogContent(key, val);
+        } else {
+            ++mContentCnt;
+            mAllocatedContentSize += key.size() + val.size();
+            mContents.emplace_back(LogContent(key, val), true);
+        }
+    }
+    void DelContent(StringView key) {
+        auto* e = const_cast<std::pair<LogContent, bool>*>(findLive(key));
+        if (e) {
+            e->second = false;
+            --mContentCnt;
+            mAllocatedContentSize -= e->first.first.size() + e->first.second.size();
+        }
+    }
+    bool Empty() const { return mContentCnt == 0; }
+    size_t Size() const { return mContentCnt; }
+    ConstContentIterator cbegin() const {
+        auto it = mContents.cbegin();
+        while (it != mContents.cend() && !it->second) ++it;
+        return ConstContentIterator(it, mContents);
+    }
+    ConstContentIterator cend() const { return ConstContentIterator(mContents.cend(), mContents); }
+    ConstContentIterator begin() const { return cbegin(); }
+    ConstContentIterator end() const { return cend(); }
+    void SetPosition(uint64_t offset, uint64_t size) {
+        mFileOffset = offset;
+        mRawSize = size;
+    }
+    std::pair<uint64_t, uint64_t> GetPosition() const { return {mFileOffset, mRawSize}; }
+    size_t DataSize() const override { return PipelineEvent::DataSize() + sizeof(mContents) + mAllocatedContentSize; }
+
+private:
+    const std::pair<LogContent, bool>* findLive(StringView key) const {
+        for (auto it = mContents.crbegin(); it != mContents.crend(); ++it)
+            if (it->second && it->first.first == key) return &*it;
+        return nullptr;
+    }
+    ContentsContainer mContents;
+    size_t mAllocatedContentSize = 0;
+    size_t mContentCnt = 0;
+    uint64_t mFileOffset = 0, mRawSize = 0;
+};
+
+// any non-log event kind; the parse processor only needs to recognise "not a LogEvent"
+class RawEvent : public PipelineEvent {
+public:
+    explicit RawEvent(PipelineEventGroup* g) : PipelineEvent(Type::RAW, g) {}
+    StringView GetContent() const { return mContent; }
+    void SetContentNoCopy(StringView c) { mContent = c; }
+    size_t DataSize() const override { return PipelineEvent::DataSize() + mContent.size(); }
+
+private:
+    StringView mContent;
+};
+
+class PipelineEventPtr {
+public:
+    PipelineEventPtr() = default;
+    explicit PipelineEventPtr(std::unique_ptr<PipelineEvent>&& p) : mData(std::move(p)) {}
+    template <class T>
+    bool Is() const;
+    template <class T>
+    T& Cast() {
+        return static_cast<T&>(*mData);
+    }
+    template <class T>
+    const T& Cast() const {
+        return static_cast<const T&>(*mData);
+    }
+    PipelineEvent* operator->() { return mData.get(); }
+    const PipelineEvent* operator->() const { return mData.get(); }
+    explicit operator bool() const { return bool(mData); }
+
+private:
+    std::unique_ptr<PipelineEvent> mData;
+};
+template <>
+inline bool PipelineEventPtr::Is<LogEvent>() const {
+    return mData && mData->GetType() == PipelineEvent::Type::LOG;
+}
+template <>
+inline bool PipelineEventPtr::Is<RawEvent>() const {
+    return mData && mData->GetType() == PipelineEvent::Type::RAW;
+}
+
+using EventsContainer = std::vector<PipelineEventPtr>;
+
+class PipelineEventGroup {
+public:
+    explicit PipelineEventGroup(const std::shared_ptr<SourceBuffer>& sb) : mSourceBuffer(sb) {}
+    PipelineEventGroup(const PipelineEventGroup&) = delete;
+    PipelineEventGroup& operator=(const PipelineEventGroup&) = delete;
+
+    const EventsContainer& GetEvents() const { return mEvents; }
+    EventsContainer& MutableEvents() { return mEvents; }
+    LogEvent* AddLogEvent() {
+        auto e = std::make_unique<LogEvent>(this);
+        LogEvent* raw = e.get();
+        mEvents.emplace_back(std::move(e));
+        return raw;
+    }
+    RawEvent* AddRawEvent() {
+        auto e = std::make_unique<RawEvent>(this);
+        RawEvent* raw = e.get();
+        mEvents.emplace_back(std::move(e));
+        return raw;
+    }
+    std::shared_ptr<SourceBuffer>& GetSourceBuffer() { return mSourceBuffer; }
+
+    void SetMetadata(EventGroupMetaKey key, const std::string& val) {
+        StringBuffer b = mSourceBuffer->CopyString(val);
+        mMetadata[key] = StringView(b.data, b.size);
+    }
+    void SetMetadataNoCopy(EventGroupMetaKey key, StringView val) { mMetadata[key] = val; }
+    StringView GetMetadata(EventGroupMetaKey key) const {
+        auto it = mMetadata.find(key);
+        return it == mMetadata.end() ? StringView() : it->second;
+    }
+    bool HasMetadata(EventGroupMetaKey key) const { return mMetadata.count(key) != 0; }
+    const GroupMetadata& GetAllMetadata() const { return mMetadata; }
+
+    void SetTag(const std::string& key, const std::string& val) {
+        StringBuffer k = mSourceBuffer->CopyString(key), v = mSourceBuffer->CopyString(val);
+        mTags[StringView(k.data, k.size)] = StringView(v.data, v.size);
+    }
+    const GroupTags& GetTags() const { return mTags; }
+
+    size_t DataSize() const {
+        size_t n = sizeof(mEvents);
+        for (const auto& e : mEvents) n += e->DataSize();
+        for (const auto& kv : mTags) n += kv.first.size() + kv.second.size();
+        return n;
+    }
+
+    // fixture format of the reference unit tests (PipelineEventGroup::FromJsonString / ToJsonString,
+    // core/models/PipelineEventGroup.h:140-146, LogEvent.cpp:169-209)
+    bool FromJsonString(const std::string& json, std::string* error = nullptr);
+    std::string ToJsonString() const;
+
+private:
+    std::shared_ptr<SourceBuffer> mSourceBuffer;
+    GroupMetadata mMetadata;
+    GroupTags mTags;
+    EventsContainer mEvents;
+};
+
+inline std::shared_ptr<SourceBuffer>& PipelineEvent::GetSourceBuffer() { return mGroup->GetSourceBuffer(); }
+inline void LogEvent::SetContent(StringView key, StringView val) {
+    StringBuffer k = GetSourceBuffer()->CopyString(key), v = GetSourceBuffer()->CopyString(val);
+    SetContentNoCopy(StringView(k.data, k.size), StringView(v.data, v.size));
+}
+
+}  // namespace logtail

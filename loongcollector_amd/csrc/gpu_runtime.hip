@@ -288,9 +288,19 @@ int drainSlot(Slot& s, uint32_t ngroups, int32_t* caps, uint8_t* status) {
 
 }  // namespace
 
-extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len,
-                                   uint32_t n, uint32_t ngroups, int32_t* caps, uint8_t* status) {
-    if (!re || !off || !len || !caps || !status || (!data && n)) return LC_ERR_ARG;
+namespace {
+
+// describes where the lines of a host batch live; both public entry points funnel into runHostPipeline
+struct LineSource {
+    const uint8_t* base = nullptr;         // (off,len) form: line i = base + off[i]
+    const uint32_t* off = nullptr;
+    const uint8_t* const* ptrs = nullptr;  // views form: line i = ptrs[i]
+    const uint32_t* len = nullptr;
+    const uint8_t* at(uint32_t i) const { return ptrs ? ptrs[i] : base + off[i]; }
+};
+
+int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t ngroups, int32_t* caps,
+                    uint8_t* status) {
     if (n == 0) return LC_OK;
     if (lc_device_count() <= 0) {
         tlsError = "no HIP device";
@@ -310,33 +320,37 @@ extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const ui
         // carve a chunk: up to kChunkLines lines / kChunkBytes payload bytes
         uint32_t cnt = 0;
         size_t bytes = 0;
-        while (next + cnt < n && cnt < kChunkLines && (cnt == 0 || bytes + len[next + cnt] <= kChunkBytes)) {
-            bytes += len[next + cnt];
+        while (next + cnt < n && cnt < kChunkLines && (cnt == 0 || bytes + src.len[next + cnt] <= kChunkBytes)) {
+            bytes += src.len[next + cnt];
             ++cnt;
         }
         Slot& s = pipe.slots[which];
         if ((rc = drainSlot(s, ngroups, caps, status)) != LC_OK) return rc;
-        // contiguous fast path: the chunk's lines sit back to back (what ProcessorSplitLogStringNative leaves)
-        const uint32_t lo = off[next];
-        const uint64_t hi = uint64_t(off[next + cnt - 1]) + len[next + cnt - 1];
-        bool contiguous = hi >= lo && (hi - lo) <= bytes + 2ull * cnt;
-        if (contiguous)
-            for (uint32_t i = 1; i < cnt && contiguous; ++i) contiguous = off[next + i] >= off[next + i - 1];
+        // contiguous fast path: the chunk's lines sit back to back in memory with at most a separator byte or two
+        // between them (what one LogFileReader buffer looks like after ProcessorSplitLogStringNative): one memcpy
+        const uint8_t* lo = src.at(next);
+        const uint8_t* hi = src.at(next + cnt - 1) + src.len[next + cnt - 1];
+        bool contiguous = hi >= lo && size_t(hi - lo) <= bytes + 2ull * cnt;
+        for (uint32_t i = 1; i < cnt && contiguous; ++i) {
+            const uint8_t* prevEnd = src.at(next + i - 1) + src.len[next + i - 1];
+            const uint8_t* cur = src.at(next + i);
+            contiguous = cur >= prevEnd && size_t(cur - prevEnd) <= 2;
+        }
         const size_t stageBytes = contiguous ? size_t(hi - lo) : bytes;
         if ((rc = growSlot(s, stageBytes + 16, cnt, size_t(cnt) * 2 * ngroups)) != LC_OK) return rc;
         if (contiguous) {
-            std::memcpy(s.hData, data + lo, stageBytes);
+            std::memcpy(s.hData, lo, stageBytes);
             for (uint32_t i = 0; i < cnt; ++i) {
-                s.hOff[i] = off[next + i] - lo;
-                s.hLen[i] = len[next + i];
+                s.hOff[i] = uint32_t(src.at(next + i) - lo);
+                s.hLen[i] = src.len[next + i];
             }
         } else {
             size_t at = 0;
             for (uint32_t i = 0; i < cnt; ++i) {
-                std::memcpy(s.hData + at, data + off[next + i], len[next + i]);
+                std::memcpy(s.hData + at, src.at(next + i), src.len[next + i]);
                 s.hOff[i] = uint32_t(at);
-                s.hLen[i] = len[next + i];
-                at += len[next + i];
+                s.hLen[i] = src.len[next + i];
+                at += src.len[next + i];
             }
         }
         HIP_TRY(hipMemcpyAsync(s.dData, s.hData, stageBytes, hipMemcpyHostToDevice, s.stream));
@@ -356,4 +370,29 @@ extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const ui
     for (auto& s : pipe.slots)
         if ((rc = drainSlot(s, ngroups, caps, status)) != LC_OK) return rc;
     return LC_OK;
+}
+
+}  // namespace
+
+extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len,
+                                   uint32_t n, uint32_t ngroups, int32_t* caps, uint8_t* status) {
+    if (!re) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (!data || !off || !len || !caps || !status) return LC_ERR_ARG;
+    LineSource src;
+    src.base = data;
+    src.off = off;
+    src.len = len;
+    return runHostPipeline(re, src, n, ngroups, caps, status);
+}
+
+extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* lines, const uint32_t* len, uint32_t n,
+                                         uint32_t ngroups, int32_t* caps, uint8_t* status) {
+    if (!re) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (!lines || !len || !caps || !status) return LC_ERR_ARG;
+    LineSource src;
+    src.ptrs = lines;
+    src.len = len;
+    return runHostPipeline(re, src, n, ngroups, caps, status);
 }

@@ -1,0 +1,289 @@
+// processor_parse_regex_gpu.cpp -- see processor_parse_regex_gpu.hpp.
+#include "processor_parse_regex_gpu.hpp"
+
+#include <cstdio>
+
+namespace logtail {
+
+const std::string ProcessorParseRegexGpu::sName = "processor_parse_regex_gpu";
+const std::string CommonParserOptions::legacyUnmatchedRawLogKey = "__raw_log__";
+
+namespace {
+const std::string kDefaultContentKey = "content";      // DEFAULT_CONTENT_KEY, core/constants/Constants.cpp:25
+const std::string kContainerTimeKey = "_time_";        // ProcessorParseContainerLogNative.cpp:41
+const std::string kContainerSourceKey = "_source_";    // ProcessorParseContainerLogNative.cpp:42
+
+// GetMandatoryStringParam / GetOptional*Param (core/common/ParamExtractor.cpp:31-43,101-113,174-188)
+bool mandatoryString(const lcjson::Value& cfg, const std::string& key, std::string& out, std::string& err) {
+    const lcjson::Value* v = cfg.find(key);
+    if (!v) {
+        err = "mandatory param " + key + " is missing";
+        return false;
+    }
+    if (!v->isString()) {
+        err = "param " + key + " is not of type string";
+        return false;
+    }
+    out = v->str;
+    if (out.empty()) {
+        err = "mandatory string param " + key + " is empty";
+        return false;
+    }
+    return true;
+}
+bool optionalBool(const lcjson::Value& cfg, const std::string& key, bool& out, std::string& err) {
+    const lcjson::Value* v = cfg.find(key);
+    if (v) {
+        if (!v->isBool()) {
+            err = "param " + key + " is not of type bool";
+            return false;
+        }
+        out = v->b;
+    }
+    return true;
+}
+bool optionalString(const lcjson::Value& cfg, const std::string& key, std::string& out, std::string& err) {
+    const lcjson::Value* v = cfg.find(key);
+    if (v) {
+        if (!v->isString()) {
+            err = "param " + key + " is not of type string";
+            return false;
+        }
+        out = v->str;
+    }
+    return true;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- CommonParserOptions
+// core/plugin/processor/CommonParserOptions.cpp:28-89: a wrongly typed optional only warns and keeps the default
+bool CommonParserOptions::Init(const lcjson::Value& config, std::vector<std::string>& warnings) {
+    std::string err;
+    if (!optionalBool(config, "KeepingSourceWhenParseFail", mKeepingSourceWhenParseFail, err)) warnings.push_back(err);
+    if (!optionalBool(config, "KeepingSourceWhenParseSucceed", mKeepingSourceWhenParseSucceed, err)) warnings.push_back(err);
+    if (!optionalString(config, "RenamedSourceKey", mRenamedSourceKey, err)) warnings.push_back(err);
+    if (mRenamedSourceKey.empty()) {
+        const lcjson::Value* sk = config.find("SourceKey");  // guaranteed to exist by the caller
+        mRenamedSourceKey = sk ? sk->str : std::string();
+    }
+    if (!optionalBool(config, "CopingRawLog", mCopingRawLog, err)) warnings.push_back(err);
+    return true;
+}
+// CommonParserOptions.cpp:91-97
+bool CommonParserOptions::ShouldAddLegacyUnmatchedRawLog(bool parseSuccess) const {
+    return !parseSuccess && mKeepingSourceWhenParseFail && mCopingRawLog;
+}
+bool CommonParserOptions::ShouldAddSourceContent(bool parseSuccess) const {
+    return (parseSuccess && mKeepingSourceWhenParseSucceed) || (!parseSuccess && mKeepingSourceWhenParseFail);
+}
+// CommonParserOptions.cpp:99-117
+bool CommonParserOptions::ShouldEraseEvent(bool parseSuccess, const LogEvent& sourceEvent,
+                                           const GroupMetadata& metadata) const {
+    if (!parseSuccess && !mKeepingSourceWhenParseFail) {
+        if (sourceEvent.Empty()) return true;
+        const size_t size = sourceEvent.Size();
+        auto offsetKey = metadata.find(EventGroupMetaKey::LOG_FILE_OFFSET_KEY);
+        if (size == 1 && offsetKey != metadata.end() && sourceEvent.cbegin()->first == offsetKey->second) return true;
+        if (size == 2 && sourceEvent.HasContent(kContainerTimeKey) && sourceEvent.HasContent(kContainerSourceKey))
+            return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------- processor
+ProcessorParseRegexGpu::~ProcessorParseRegexGpu() {
+    if (mReg) lc_regex_free(mReg);
+}
+
+// ProcessorParseRegexNative::Init, core/plugin/processor/ProcessorParseRegexNative.cpp:29-106
+bool ProcessorParseRegexGpu::Init(const lcjson::Value& config, std::string& error) {
+    if (!config.isObject()) {
+        error = "plugin config is not an object";
+        return false;
+    }
+    if (!mandatoryString(config, "SourceKey", mSourceKey, error)) return false;  // :33-43
+    if (!mandatoryString(config, "Regex", mRegex, error)) return false;          // :45-53
+    mIsWholeLineMode = mRegex == "(.*)";                                         // :68
+    {
+        // :53-67: IsRegexValid + one compiled regex.  (The reference compiles one boost::regex per runner thread
+        // because match_results are per thread; the device tables are immutable and shared by every thread.)
+        char err[256];
+        int rc = lc_regex_compile(mRegex.data(), mRegex.size(), 0, mEngineChoice, &mReg, err, sizeof err);
+        if (rc == LC_ERR_SYNTAX) {
+            error = "mandatory string param Regex is not a valid regex";
+            return false;
+        }
+        if (rc != LC_OK) {
+            if (!mIsWholeLineMode) {
+                error = std::string("param Regex cannot be executed by the GPU engines: ") + err;
+                return false;
+            }
+            mReg = nullptr;
+        }
+        mMarkCount = mReg ? lc_regex_mark_count(mReg) : 1;
+    }
+    // Keys :71-88 (mandatory, non-empty list of strings; legacy ["k1,k2"] form is split on ',')
+    {
+        const lcjson::Value* keys = config.find("Keys");
+        if (!keys) {
+            error = "mandatory param Keys is missing";
+            return false;
+        }
+        if (!keys->isArray()) {
+            error = "param Keys is not of type list";
+            return false;
+        }
+        mKeys.clear();
+        for (const auto& k : keys->arr) {
+            if (!k.isString()) {
+                error = "param Keys is not of type string list";
+                return false;
+            }
+            mKeys.push_back(k.str);
+        }
+        if (mKeys.empty()) {
+            error = "mandatory list param Keys is empty";
+            return false;
+        }
+        if (mKeys.size() == 1 && mKeys[0].find(',') != std::string::npos) {
+            std::vector<std::string> parts;
+            size_t at = 0;
+            const std::string joined = mKeys[0];
+            for (;;) {
+                size_t c = joined.find(',', at);
+                parts.push_back(joined.substr(at, c == std::string::npos ? std::string::npos : c - at));
+                if (c == std::string::npos) break;
+                at = c + 1;
+            }
+            mKeys = parts;
+        }
+    }
+    mSourceKeyOverwritten = false;  // :89-94
+    for (const auto& k : mKeys)
+        if (k == mSourceKey) {
+            mSourceKeyOverwritten = true;
+            break;
+        }
+    return mCommonParserOptions.Init(config, mInitWarnings);  // :96
+}
+
+// ProcessorParseRegexNative::AddLog :176-184
+void ProcessorParseRegexGpu::AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent,
+                                    bool overwritten) {
+    if (!overwritten && targetEvent.HasContent(key)) return;
+    targetEvent.SetContentNoCopy(key, value);
+}
+
+// the tail of ProcessorParseRegexNative::ProcessEvent :153-167
+bool ProcessorParseRegexGpu::FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess,
+                                         const GroupMetadata& metadata) {
+    if (!parseSuccess || !mSourceKeyOverwritten) sourceEvent.DelContent(mSourceKey);
+    if (mCommonParserOptions.ShouldAddSourceContent(parseSuccess))
+        AddLog(mCommonParserOptions.mRenamedSourceKey, rawContent, sourceEvent, false);
+    if (mCommonParserOptions.ShouldAddLegacyUnmatchedRawLog(parseSuccess))
+        AddLog(CommonParserOptions::legacyUnmatchedRawLogKey, rawContent, sourceEvent, false);
+    if (mCommonParserOptions.ShouldEraseEvent(parseSuccess, sourceEvent, metadata)) {
+        ++mDiscardedEventsTotal;
+        return false;
+    }
+    ++mOutSuccessfulEventsTotal;
+    return true;
+}
+
+// ProcessorParseRegexNative::Process :108-126 + ProcessEvent :132-168 + RegexLogLineParser :186-253, restructured
+// as gather -> one device match for the whole group -> stitch.
+void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
+    if (logGroup.GetEvents().empty()) return;
+    EventsContainer& events = logGroup.MutableEvents();
+    const GroupMetadata& metadata = logGroup.GetAllMetadata();
+    const size_t nEvents = events.size();
+
+    enum Kind : uint8_t { Keep, Parse, WholeLine };
+    static thread_local std::vector<uint8_t> kind, status;
+    static thread_local std::vector<const uint8_t*> linePtr;
+    static thread_local std::vector<uint32_t> lineLen;
+    static thread_local std::vector<int32_t> caps;
+    kind.assign(nEvents, Keep);
+    linePtr.clear();
+    lineLen.clear();
+
+    // gather: the source values are views into the group's SourceBuffer; nothing is copied here
+    for (size_t i = 0; i < nEvents; ++i) {
+        PipelineEventPtr& e = events[i];
+        if (!IsSupportedEvent(e)) {  // :135-138
+            ++mOutFailedEventsTotal;
+            continue;
+        }
+        LogEvent& ev = e.Cast<LogEvent>();
+        if (!ev.HasContent(mSourceKey)) {  // :140-143
+            ++mOutKeyNotFoundEventsTotal;
+            continue;
+        }
+        if (mIsWholeLineMode) {  // :147-148, no regex engine involved
+            kind[i] = WholeLine;
+            continue;
+        }
+        const StringView raw = ev.GetContent(mSourceKey);
+        kind[i] = Parse;
+        linePtr.push_back(reinterpret_cast<const uint8_t*>(raw.data()));
+        lineLen.push_back(uint32_t(raw.size()));
+    }
+
+    const uint32_t nLines = uint32_t(linePtr.size());
+    const uint32_t G = uint32_t(mMarkCount);
+    bool deviceOk = true;
+    if (nLines) {
+        caps.resize(size_t(nLines) * 2 * G);
+        status.resize(nLines);
+        int rc = lc_regex_match_host_views(mReg, linePtr.data(), lineLen.data(), nLines, G, caps.data(), status.data());
+        if (rc != LC_OK) {
+            // No CPU fallback exists.  Leave the events exactly as they came in (nothing is lost) and say so loudly.
+            std::fprintf(stderr, "[%s] GPU match failed (rc=%d: %s); %u events left unparsed\n", sName.c_str(), rc,
+                         lc_last_error(), nLines);
+            deviceOk = false;
+        }
+    }
+
+    // stitch + in-place compaction (:115-124)
+    size_t wIdx = 0, line = 0;
+    for (size_t rIdx = 0; rIdx < nEvents; ++rIdx) {
+        bool keep = true;
+        if (kind[rIdx] == WholeLine) {
+            LogEvent& ev = events[rIdx].Cast<LogEvent>();
+            const StringView raw = ev.GetContent(mSourceKey);
+            AddLog(StringView(mKeys.empty() ? kDefaultContentKey : mKeys[0]), raw, ev);  // :170-174
+            keep = FinishEvent(ev, raw, true, metadata);
+        } else if (kind[rIdx] == Parse) {
+            const size_t li = line++;
+            if (deviceOk) {
+                LogEvent& ev = events[rIdx].Cast<LogEvent>();
+                const StringView raw = ev.GetContent(mSourceKey);
+                bool parseSuccess = true;
+                if (status[li] != LC_MATCH) {  // :194-226 (alarms/logging are the host agent's business)
+                    ++mOutFailedEventsTotal;
+                    parseSuccess = false;
+                } else if (size_t(G) + 1 <= mKeys.size()) {  // what.size() <= keys.size()  :227-244, no counter
+                    parseSuccess = false;
+                }
+                if (parseSuccess) {
+                    const int32_t* c = &caps[li * 2 * G];
+                    for (size_t k = 0; k < mKeys.size(); ++k) {  // :249-251
+                        const int32_t b = c[2 * k], en = c[2 * k + 1];
+                        // an unmatched group is boost's {last,last,matched=false}: empty value at end of input
+                        const StringView val = b < 0 ? StringView(raw.data() + raw.size(), 0)
+                                                     : StringView(raw.data() + b, size_t(en - b));
+                        AddLog(StringView(mKeys[k]), val, ev);
+                    }
+                }
+                keep = FinishEvent(ev, raw, parseSuccess, metadata);
+            }
+        }
+        if (keep) {
+            if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
+            ++wIdx;
+        }
+    }
+    events.resize(wIdx);
+}
+
+}  // namespace logtail

@@ -1,0 +1,74 @@
+// processor_parse_regex_gpu.hpp -- MI355X drop-in for LoongCollector's processor_parse_regex_native.
+//
+// Mirrors, member for member, the reference class
+//   core/plugin/processor/ProcessorParseRegexNative.h:28-72 / .cpp:27-257
+// and its policy helper core/plugin/processor/CommonParserOptions.{h,cpp}; the only part that differs is
+// where the regex arithmetic runs: instead of one boost::regex_match call per event
+// (ProcessorParseRegexNative.cpp:194 -> core/common/StringTools.cpp:183-211) the whole event group is matched
+// by ONE lc_regex_match_host_views() call on the GPU and the (offset,length) table is stitched back into the
+// events as zero-copy views (LogEvent::SetContentNoCopy), exactly as :249-251 does.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/lc_regex_gpu.h"
+#include "event_model.hpp"
+#include "json_min.hpp"
+
+namespace logtail {
+
+// CommonParserOptions (core/plugin/processor/CommonParserOptions.h:28-41)
+struct CommonParserOptions {
+    static const std::string legacyUnmatchedRawLogKey;  // "__raw_log__"
+    bool mKeepingSourceWhenParseFail = false;
+    bool mKeepingSourceWhenParseSucceed = false;
+    std::string mRenamedSourceKey;
+    bool mCopingRawLog = false;
+
+    bool Init(const lcjson::Value& config, std::vector<std::string>& warnings);
+    bool ShouldAddSourceContent(bool parseSuccess) const;
+    bool ShouldAddLegacyUnmatchedRawLog(bool parseSuccess) const;
+    bool ShouldEraseEvent(bool parseSuccess, const LogEvent& sourceEvent, const GroupMetadata& metadata) const;
+};
+
+class ProcessorParseRegexGpu {
+public:
+    static const std::string sName;  // "processor_parse_regex_gpu" (new Type name; static names win in PluginRegistry)
+    ~ProcessorParseRegexGpu();
+
+    const std::string& Name() const { return sName; }
+    // config: the plugin's JSON object (SourceKey, Regex, Keys, KeepingSourceWhenParseFail, ...).
+    // Returns false with `error` set exactly where the reference's Init returns false.
+    bool Init(const lcjson::Value& config, std::string& error);
+    void Process(PipelineEventGroup& logGroup);
+
+    std::string mSourceKey;
+    std::string mRegex;
+    std::vector<std::string> mKeys;
+    CommonParserOptions mCommonParserOptions;
+
+    // plugin counters (ProcessorParseRegexNative.cpp:100-103)
+    std::atomic<uint64_t> mDiscardedEventsTotal{0}, mOutFailedEventsTotal{0}, mOutKeyNotFoundEventsTotal{0},
+        mOutSuccessfulEventsTotal{0};
+    std::vector<std::string> mInitWarnings;
+    int mEngineChoice = LC_ENGINE_AUTO;  // test hook: force a device engine
+
+    bool IsWholeLineMode() const { return mIsWholeLineMode; }
+    const lc_regex_t* Regex() const { return mReg; }
+
+private:
+    bool IsSupportedEvent(const PipelineEventPtr& e) const { return e.Is<LogEvent>(); }
+    // the per-event policy of ProcessorParseRegexNative::ProcessEvent (:132-168) given the match result
+    bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata);
+    void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
+
+    bool mSourceKeyOverwritten = false;
+    bool mIsWholeLineMode = false;
+    lc_regex_t* mReg = nullptr;
+    int mMarkCount = 0;
+};
+
+}  // namespace logtail

@@ -1,0 +1,127 @@
+"""ctypes binding of the processor layer (include/lc_processor.h): create a processor_parse_regex_gpu instance from
+its JSON plugin config, run it over event groups given in the reference unit tests' JSON fixture format."""
+import ctypes
+import json
+
+from . import binding
+
+COUNTER_NAMES = ["discarded_events_total", "out_failed_events_total", "out_key_not_found_events_total",
+                 "out_successful_events_total", "in_events_total", "out_events_total", "in_size_bytes",
+                 "out_size_bytes", "total_process_time_us"]
+
+
+class ProcessorInitError(ValueError):
+    pass
+
+
+def _lib():
+    L = binding.load()
+    if not getattr(L, "_lc_processor_bound", False):
+        vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
+        L.lc_processor_create.restype = ctypes.c_int
+        L.lc_processor_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
+        L.lc_processor_destroy.argtypes = [vp]
+        L.lc_processor_key_count.argtypes = [vp]
+        L.lc_processor_key.restype = cp
+        L.lc_processor_key.argtypes = [vp, ctypes.c_int]
+        L.lc_processor_process.restype = ctypes.c_int
+        L.lc_processor_process.argtypes = [vp, vp]
+        L.lc_processor_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.lc_group_from_json.restype = vp
+        L.lc_group_from_json.argtypes = [cp, cp, sz]
+        L.lc_group_to_json.restype = vp
+        L.lc_group_to_json.argtypes = [vp]
+        L.lc_group_event_count.restype = sz
+        L.lc_group_event_count.argtypes = [vp]
+        L.lc_group_free.argtypes = [vp]
+        L.lc_free.argtypes = [vp]
+        L._lc_processor_bound = True
+    return L
+
+
+class EventGroup:
+    """A PipelineEventGroup built from the fixture JSON ({"events":[{"contents":{..},"timestamp":..,"type":1}]})."""
+
+    def __init__(self, fixture):
+        text = fixture if isinstance(fixture, str) else json.dumps(fixture)
+        err = ctypes.create_string_buffer(256)
+        self._L = _lib()
+        self._h = self._L.lc_group_from_json(text.encode("utf-8"), err, 256)
+        if not self._h:
+            raise ValueError(err.value.decode())
+
+    def to_json(self):
+        p = self._L.lc_group_to_json(self._h)
+        try:
+            return ctypes.string_at(p).decode("utf-8")
+        finally:
+            self._L.lc_free(p)
+
+    def to_dict(self):
+        return json.loads(self.to_json())
+
+    def contents(self):
+        """-> per event: ordered list of (key, value) (None for non-log events)"""
+        out = []
+        d = json.loads(self.to_json(), object_pairs_hook=list)
+        events = dict(d).get("events", [])
+        for ev in events:
+            ev = dict(ev)
+            out.append(list(ev.get("contents", [])) if ev.get("type") == 1 else None)
+        return out
+
+    def __len__(self):
+        return int(self._L.lc_group_event_count(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Processor:
+    """processor_parse_regex_gpu; same config keys as processor_parse_regex_native."""
+
+    def __init__(self, config):
+        text = config if isinstance(config, str) else json.dumps(config)
+        self._L = _lib()
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = self._L.lc_processor_create(text.encode("utf-8"), ctypes.byref(h), err, 512)
+        if rc != binding.LC_OK:
+            raise ProcessorInitError(err.value.decode())
+        self._h = h
+
+    @property
+    def keys(self):
+        n = self._L.lc_processor_key_count(self._h)
+        return [self._L.lc_processor_key(self._h, i).decode() for i in range(n)]
+
+    def process(self, group: EventGroup):
+        rc = self._L.lc_processor_process(self._h, group._h)
+        if rc == binding.LC_ERR_NO_DEVICE:
+            raise binding.GpuUnavailableError("processor_parse_regex_gpu: no usable HIP device (no CPU path)")
+        if rc != binding.LC_OK:
+            raise RuntimeError("lc_processor_process rc=%d" % rc)
+
+    def counters(self):
+        buf = (ctypes.c_uint64 * len(COUNTER_NAMES))()
+        self._L.lc_processor_counters(self._h, buf)
+        return dict(zip(COUNTER_NAMES, [int(x) for x in buf]))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc_processor_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

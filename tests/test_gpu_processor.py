@@ -1,0 +1,146 @@
+"""processor_parse_regex_gpu on the device, through the C ABI: every case of the reference's unit test, a randomized
+policy matrix against the processor oracle, and the dlsym slot (processor_interface) end to end."""
+import ctypes
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from loongcollector_amd import binding as B
+from loongcollector_amd.processor import EventGroup, Processor, _lib
+from oracle.processor_oracle import LogEventModel, ProcessorOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def vectors(golden_dir):
+    with open(os.path.join(golden_dir, "reference_unittest_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_every_reference_unit_test_case(golden_dir):
+    assert B.device_count() >= 1
+    for case in vectors(golden_dir):
+        p = Processor(case["config"])
+        if "expect_keys" in case:
+            assert p.keys == case["expect_keys"], case["name"]
+        if not case["events"]:
+            continue
+        g = EventGroup({"events": case["events"]})
+        p.process(g)
+        if "expect_contents" in case:
+            assert [dict(c) for c in g.contents()] == case["expect_contents"], case["name"]
+        c = p.counters()
+        for name, want in case.get("expect_counters", {}).items():
+            assert c[name] == want, (case["name"], name, c)
+        if case.get("expect_out_size_bytes_nonzero"):
+            assert c["out_size_bytes"] != 0, case["name"]
+        # and the oracle agrees on the full ordered content lists
+        po = ProcessorOracle(case["config"])
+        out = po.process_group([LogEventModel([(k, v.encode()) for k, v in sorted(e["contents"].items())])
+                                for e in case["events"]])
+        assert g.contents() == [[(k, v.decode()) for k, v in ev.live()] for ev in out], case["name"]
+
+
+@pytest.mark.parametrize("engine", ["tdfa", "nfa"])
+def test_policy_matrix_against_the_oracle(engine):
+    rng = np.random.default_rng(11)
+    lines = ["v1\tv2", "value3\tvalue4 tail", "nomatch", "", "a\tb\nc", "x\t", "\ty", "k\tv"]
+    for keep_fail, keep_ok, coping, renamed, keys in itertools.product(
+            [False, True], [False, True], [False, True], ["", "rawLog", "content", "key2"],
+            [["key1", "key2"], ["content", "key2"], ["key1", "key2", "key3"], ["rawLog", "x"]]):
+        cfg = {"SourceKey": "content", "Regex": r"(\w+)\t(\w*).*", "Keys": keys, "KeepingSourceWhenParseFail": keep_fail,
+               "KeepingSourceWhenParseSucceed": keep_ok, "CopingRawLog": coping, "RenamedSourceKey": renamed,
+               "_Engine": engine}
+        events, models = [], []
+        for _ in range(12):
+            kind = rng.integers(0, 10)
+            if kind == 0:
+                events.append({"content": "raw", "timestamp": 1, "type": 4})
+                models.append(None)
+                continue
+            contents = []
+            if rng.integers(0, 2):
+                contents.append(["__file_offset__", "123"])
+            if kind != 1:
+                contents.append(["content", lines[int(rng.integers(0, len(lines)))]])
+            if rng.integers(0, 3) == 0:
+                contents.append(["key2", "preexisting"])
+            events.append({"contents": contents, "timestamp": 1, "type": 1})
+            models.append(LogEventModel([(k, v.encode()) for k, v in contents]))
+        fixture = {"events": events, "metadata": {"log.file.offset": "__file_offset__"}}
+        p, g = Processor(cfg), EventGroup(fixture)
+        p.process(g)
+        ocfg = {k: v for k, v in cfg.items() if k != "_Engine"}
+        po = ProcessorOracle(ocfg)
+        out = po.process_group(models, file_offset_key="__file_offset__")
+        want = [None if ev is None else [(k, v.decode()) for k, v in ev.live()] for ev in out]
+        assert g.contents() == want, cfg
+        c = p.counters()
+        assert (c["discarded_events_total"], c["out_failed_events_total"], c["out_key_not_found_events_total"],
+                c["out_successful_events_total"], c["in_events_total"], c["out_events_total"]) == (
+            po.counters["discarded"], po.counters["out_failed"], po.counters["out_key_not_found"],
+            po.counters["out_successful"], po.counters["in_events"], po.counters["out_events"]), cfg
+
+
+def test_unmatched_optional_group_yields_empty_value_like_boost():
+    # what[i+1] of a group that did not participate is {last,last,matched=false}: an EMPTY value (cpp:249-251)
+    p = Processor({"SourceKey": "content", "Regex": r"(\d+)(?: (\w+))?", "Keys": ["num", "word"]})
+    g = EventGroup({"events": [{"contents": {"content": "12"}, "timestamp": 1, "type": 1},
+                               {"contents": {"content": "12 ab"}, "timestamp": 1, "type": 1}]})
+    p.process(g)
+    assert g.contents() == [[("num", "12"), ("word", "")], [("num", "12"), ("word", "ab")]]
+
+
+def test_large_group_of_apache_lines_zero_copy_stitch():
+    from loongcollector_amd import corpus
+    from oracle.oracle import OracleRegex
+    n = 3000
+    data, off, length = corpus.apache_batch(n, "A", poison_every=50)
+    raw = data.tobytes()
+    lines = [raw[off[i]:off[i] + length[i]].decode("latin-1") for i in range(n)]
+    p = Processor({"SourceKey": "content", "Regex": corpus.REGEX_A, "Keys": corpus.KEYS_A,
+                   "KeepingSourceWhenParseFail": True, "RenamedSourceKey": "__raw__"})
+    g = EventGroup({"events": [{"contents": {"content": s}, "timestamp": 1, "type": 1} for s in lines]})
+    p.process(g)
+    caps, status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
+    got = g.contents()
+    for i in range(n):
+        if status[i]:
+            want = [(k, lines[i][caps[i][2 * j]:caps[i][2 * j + 1]]) for j, k in enumerate(corpus.KEYS_A)]
+        else:
+            want = [("__raw__", lines[i])]
+        assert got[i] == want
+    c = p.counters()
+    assert c["out_failed_events_total"] == n // 50 and c["out_successful_events_total"] == n
+
+
+def test_dlsym_slot_end_to_end():
+    """PluginRegistry::LoadProcessorPlugin's protocol: dlsym("processor_interface"), version check, init/process/finalize
+    (PluginRegistry.cpp:270-290, DynamicCProcessorProxy.cpp:25-40)."""
+    class Iface(ctypes.Structure):
+        _fields_ = [("version", ctypes.c_int), ("name", ctypes.c_char_p), ("language", ctypes.c_char_p),
+                    ("init", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)),
+                    ("finalize", ctypes.CFUNCTYPE(None, ctypes.c_void_p)),
+                    ("process", ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p))]
+
+    class Instance(ctypes.Structure):
+        _fields_ = [("plugin", ctypes.c_void_p), ("plugin_state", ctypes.c_void_p)]
+
+    lib = ctypes.CDLL(B.LIB_PATH)
+    iface = Iface.in_dll(lib, "processor_interface")
+    assert iface.version == 100
+    ins = Instance()
+    cfg = json.dumps({"SourceKey": "content", "Regex": r"(\w+)\t(\w+).*", "Keys": ["key1", "key2"]}).encode()
+    assert iface.init(ctypes.addressof(ins), ctypes.c_char_p(cfg), None) == 0
+    g = EventGroup({"events": [{"contents": {"content": "value1\tvalue2"}, "timestamp": 1, "type": 1}]})
+    L = _lib()
+    L.lc_group_native.restype = ctypes.c_void_p
+    L.lc_group_native.argtypes = [ctypes.c_void_p]
+    iface.process(ins.plugin_state, L.lc_group_native(g._h))
+    assert g.contents() == [[("key1", "value1"), ("key2", "value2")]]
+    iface.finalize(ins.plugin_state)
+    bad = Instance()
+    assert iface.init(ctypes.addressof(bad), ctypes.c_char_p(b'{"SourceKey":"c"}'), None) != 0
