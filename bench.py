@@ -128,19 +128,29 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [ev_start.elapsed_time(ev_end) / args.steps]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     matched = int(d_status.sum().item())
+    from loongcollector_amd.shard import reduce_job
+    # the job's only collective: MAX(elapsed) and SUM(counters) over ranks (RCCL); the data path has none
+    elapsed, totals = reduce_job(elapsed, {"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps,
+                                           "matched_last": matched}, device=dev)
 
     if rank == 0:
-        total_bytes = parsed_bytes_per_step * args.steps * world
+        total_bytes = totals["bytes"]
         value = total_bytes / elapsed / 1e6
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         # algorithmic HBM bytes per line: payload L + 4 B offset + 1 B status + 8 B per group
         algo_bytes = (args.line_bytes + 5 + 8 * G) * n
         achieved = algo_bytes / avg_kernel_s / 1e9
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+        # this same command, profiles/round1_traffic.json); only quoted for the workload they were collected on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
+                    n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
+                traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "MB/s parsed (512B lines, 10-field regex) per MI355X + HBM-roofline %",
             "value": round(value, 1),
@@ -161,7 +171,7 @@ def main():
                        "lds_table_bytes": info["table_bytes"], "parallelism": "line-shard x%d" % world,
                        "matched_lines_last_batch": matched},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "tdfa_match_kernel" if info["engine"] == 1 else "nfa_match_kernel",
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},

@@ -8,8 +8,10 @@
 #include <memory>
 
 #include "../../include/lc_processor.h"
-#include "event_model.hpp"
 #include "processor_parse_regex_gpu.hpp"
+#ifdef LC_USE_REFERENCE_HEADERS
+#include "json/json.h"  // the agent hands init() a Json::Value* (DynamicCProcessorProxy.cpp:30-32)
+#endif
 
 using logtail::PipelineEventGroup;
 using logtail::ProcessorParseRegexGpu;
@@ -20,10 +22,12 @@ struct lc_processor {
     std::atomic<uint64_t> inEvents{0}, outEvents{0}, inBytes{0}, outBytes{0}, processUs{0};
 };
 
+#ifndef LC_USE_REFERENCE_HEADERS
 struct lc_event_group {
     std::shared_ptr<logtail::SourceBuffer> buffer = std::make_shared<logtail::SourceBuffer>();
     PipelineEventGroup group{buffer};
 };
+#endif
 
 static void setErr(char* err, size_t cap, const std::string& msg) {
     if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
@@ -73,6 +77,7 @@ extern "C" const char* lc_processor_key(const lc_processor_t* p, int i) {
     return p->impl.mKeys[size_t(i)].c_str();
 }
 
+#ifndef LC_USE_REFERENCE_HEADERS
 extern "C" int lc_processor_process(lc_processor_t* p, lc_event_group_t* g) {
     if (!p || !g) return LC_ERR_ARG;
     // a group that needs the device must not be half-processed when there is none: check first, fail loudly
@@ -84,6 +89,8 @@ extern "C" int lc_processor_process(lc_processor_t* p, lc_event_group_t* g) {
     }
     return processGroup(p, g->group);
 }
+
+#endif
 
 extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]) {
     if (!p || !out) return LC_ERR_ARG;
@@ -99,6 +106,7 @@ extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CN
     return LC_OK;
 }
 
+#ifndef LC_USE_REFERENCE_HEADERS  // fixture helpers exist only in the standalone build
 extern "C" lc_event_group_t* lc_group_from_json(const char* json, char* err, size_t errcap) {
     if (!json) return nullptr;
     auto g = std::make_unique<lc_event_group>();
@@ -122,6 +130,7 @@ extern "C" char* lc_group_to_json(const lc_event_group_t* g) {
 extern "C" size_t lc_group_event_count(const lc_event_group_t* g) { return g ? g->group.GetEvents().size() : 0; }
 extern "C" void* lc_group_native(lc_event_group_t* g) { return g ? &g->group : nullptr; }
 extern "C" void lc_group_free(lc_event_group_t* g) { delete g; }
+#endif
 extern "C" void lc_free(void* p) { std::free(p); }
 
 // ---------------------------------------------------------------------------------------------- the dlsym slot
@@ -131,7 +140,13 @@ static int slotInit(processor_instance_t* ins, void* config, void* /*context*/) 
     if (!ins || !config) return -1;
     lc_processor_t* p = nullptr;
     char err[256];
-    if (lc_processor_create(static_cast<const char*>(config), &p, err, sizeof err) != LC_OK) {
+#ifdef LC_USE_REFERENCE_HEADERS
+    const std::string text = static_cast<const Json::Value*>(config)->toStyledString();
+    const char* configText = text.c_str();
+#else
+    const char* configText = static_cast<const char*>(config);
+#endif
+    if (lc_processor_create(configText, &p, err, sizeof err) != LC_OK) {
         std::fprintf(stderr, "[processor_parse_regex_gpu] init failed: %s\n", err);
         return -1;
     }

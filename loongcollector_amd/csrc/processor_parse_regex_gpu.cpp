@@ -6,7 +6,7 @@
 namespace logtail {
 
 const std::string ProcessorParseRegexGpu::sName = "processor_parse_regex_gpu";
-const std::string CommonParserOptions::legacyUnmatchedRawLogKey = "__raw_log__";
+const std::string GpuCommonParserOptions::legacyUnmatchedRawLogKey = "__raw_log__";
 
 namespace {
 const std::string kDefaultContentKey = "content";      // DEFAULT_CONTENT_KEY, core/constants/Constants.cpp:25
@@ -55,9 +55,9 @@ bool optionalString(const lcjson::Value& cfg, const std::string& key, std::strin
 }
 }  // namespace
 
-// ---------------------------------------------------------------------------------------------- CommonParserOptions
+// ---------------------------------------------------------------------------------------------- GpuCommonParserOptions
 // core/plugin/processor/CommonParserOptions.cpp:28-89: a wrongly typed optional only warns and keeps the default
-bool CommonParserOptions::Init(const lcjson::Value& config, std::vector<std::string>& warnings) {
+bool GpuCommonParserOptions::Init(const lcjson::Value& config, std::vector<std::string>& warnings) {
     std::string err;
     if (!optionalBool(config, "KeepingSourceWhenParseFail", mKeepingSourceWhenParseFail, err)) warnings.push_back(err);
     if (!optionalBool(config, "KeepingSourceWhenParseSucceed", mKeepingSourceWhenParseSucceed, err)) warnings.push_back(err);
@@ -70,14 +70,14 @@ bool CommonParserOptions::Init(const lcjson::Value& config, std::vector<std::str
     return true;
 }
 // CommonParserOptions.cpp:91-97
-bool CommonParserOptions::ShouldAddLegacyUnmatchedRawLog(bool parseSuccess) const {
+bool GpuCommonParserOptions::ShouldAddLegacyUnmatchedRawLog(bool parseSuccess) const {
     return !parseSuccess && mKeepingSourceWhenParseFail && mCopingRawLog;
 }
-bool CommonParserOptions::ShouldAddSourceContent(bool parseSuccess) const {
+bool GpuCommonParserOptions::ShouldAddSourceContent(bool parseSuccess) const {
     return (parseSuccess && mKeepingSourceWhenParseSucceed) || (!parseSuccess && mKeepingSourceWhenParseFail);
 }
 // CommonParserOptions.cpp:99-117
-bool CommonParserOptions::ShouldEraseEvent(bool parseSuccess, const LogEvent& sourceEvent,
+bool GpuCommonParserOptions::ShouldEraseEvent(bool parseSuccess, const LogEvent& sourceEvent,
                                            const GroupMetadata& metadata) const {
     if (!parseSuccess && !mKeepingSourceWhenParseFail) {
         if (sourceEvent.Empty()) return true;
@@ -181,7 +181,7 @@ bool ProcessorParseRegexGpu::FinishEvent(LogEvent& sourceEvent, StringView rawCo
     if (mCommonParserOptions.ShouldAddSourceContent(parseSuccess))
         AddLog(mCommonParserOptions.mRenamedSourceKey, rawContent, sourceEvent, false);
     if (mCommonParserOptions.ShouldAddLegacyUnmatchedRawLog(parseSuccess))
-        AddLog(CommonParserOptions::legacyUnmatchedRawLogKey, rawContent, sourceEvent, false);
+        AddLog(GpuCommonParserOptions::legacyUnmatchedRawLogKey, rawContent, sourceEvent, false);
     if (mCommonParserOptions.ShouldEraseEvent(parseSuccess, sourceEvent, metadata)) {
         ++mDiscardedEventsTotal;
         return false;

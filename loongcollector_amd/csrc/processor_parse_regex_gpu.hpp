@@ -15,13 +15,19 @@
 #include <vector>
 
 #include "../../include/lc_regex_gpu.h"
+#ifdef LC_USE_REFERENCE_HEADERS  // built inside the LoongCollector tree: the real event model
+#include "models/LogEvent.h"
+#include "models/PipelineEventGroup.h"
+#else
 #include "event_model.hpp"
+#endif
 #include "json_min.hpp"
 
 namespace logtail {
 
-// CommonParserOptions (core/plugin/processor/CommonParserOptions.h:28-41)
-struct CommonParserOptions {
+// CommonParserOptions (core/plugin/processor/CommonParserOptions.h:28-41); renamed so that a build inside the
+// reference tree does not collide with the original type
+struct GpuCommonParserOptions {
     static const std::string legacyUnmatchedRawLogKey;  // "__raw_log__"
     bool mKeepingSourceWhenParseFail = false;
     bool mKeepingSourceWhenParseSucceed = false;
@@ -48,7 +54,7 @@ public:
     std::string mSourceKey;
     std::string mRegex;
     std::vector<std::string> mKeys;
-    CommonParserOptions mCommonParserOptions;
+    GpuCommonParserOptions mCommonParserOptions;
 
     // plugin counters (ProcessorParseRegexNative.cpp:100-103)
     std::atomic<uint64_t> mDiscardedEventsTotal{0}, mOutFailedEventsTotal{0}, mOutKeyNotFoundEventsTotal{0},

@@ -1,0 +1,52 @@
+"""World-size-2 gloo run of the multi-GPU plumbing (loongcollector_amd/shard.py) on CPU: slabs tile the corpus
+exactly and the job reduction is MAX(elapsed) / SUM(counters).  The data path itself has no collective."""
+import os
+import socket
+
+import torch.multiprocessing as mp
+
+from loongcollector_amd.shard import shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    from loongcollector_amd import corpus
+    from loongcollector_amd.shard import reduce_job, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 1001
+    lo, hi = shard_range(n_total, rank, world)
+    data, off, length = corpus.apache_batch(n_total, "A", pool_lines=64)
+    my_bytes = int(length[lo:hi].sum())
+    elapsed, total = reduce_job(0.5 + rank, {"bytes": my_bytes, "lines": hi - lo})
+    out[rank] = (lo, hi, elapsed, total["bytes"], total["lines"], int(length.sum()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_line_shard_and_job_reduction():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    (lo0, hi0, e0, b0, l0, all_bytes), (lo1, hi1, e1, b1, l1, _) = out[0], out[1]
+    assert (lo0, hi0, lo1, hi1) == (0, 501, 501, 1001)        # slabs tile the corpus, no overlap, no gap
+    assert e0 == e1 == 1.5                                   # MAX over ranks
+    assert b0 == b1 == all_bytes and l0 == l1 == 1001        # SUM over ranks == whole job
+
+
+def test_shard_range_tiles_for_any_world_size():
+    for n in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
