@@ -57,6 +57,8 @@ enum {
     NF_TOTAL_BYTES = 8,
     NF_NPATHS = 9,
     NF_CONDS_USED = 10,
+    NF_OFF_STABLE = 11,   // u64[nPos+1]: bit c set iff on byte class c the position's ONLY possible move is its own
+                          // unconditional, tag-free self loop (the kernel's steady-state fast path)
     NF_HEADER_WORDS = 16
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t nSlots = hdr[NF_NSLOTS];
     const uint8_t* classMap = smem + hdr[NF_OFF_CLASSMAP];
     const uint2* posMask = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_POSMASK]);
+    const uint2* stable = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_STABLE]);
     const uint32_t* followStart = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_FOLLOWSTART]);
     const uint4* paths = reinterpret_cast<const uint4*>(smem + hdr[NF_OFF_PATHS]);
 
@@ -117,10 +118,21 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
         const int b = int((wsel >> ((idx & 3u) * 8)) & 0xFFu);
         const uint32_t cls = classMap[b];
+        const bool liveLane = lane < nThreads;
+        // steady state: every live thread sits on a position whose only move on this byte class is its own
+        // unconditional, tag-free self loop (inside a field such as [^ ]* that is almost every byte) -> the thread
+        // list, its order and the captures are unchanged; skip the whole election/compaction/transfer machinery.
+        {
+            const uint2 st = stable[myPos];
+            const uint32_t bit = cls < 32 ? (st.x >> cls) & 1u : (st.y >> (cls - 32)) & 1u;
+            if (__all(!liveLane || bit)) {
+                prevByte = b;
+                continue;
+            }
+        }
         const uint32_t ctrue = condsTrue(prevByte, b);
         prevByte = b;
 
-        const bool liveLane = lane < nThreads;
         const uint32_t fs = liveLane ? followStart[myPos] : 0;
         const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
         uint32_t totalCand;

@@ -132,6 +132,22 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         posMask[size_t(p) * 2] = uint32_t(m);
         posMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
     }
+    std::vector<uint32_t> stableMask(size_t(npos + 1) * 2, 0);
+    for (int p = 0; p < npos; ++p) {
+        uint64_t m = 0;
+        for (size_t c = 0; c < rep.size(); ++c) {
+            int passing = 0;
+            bool selfOnly = true;
+            for (const auto& path : nfa.follow[size_t(p)]) {
+                if (path.target < 0 || !nfa.positions[size_t(path.target)].has(rep[c])) continue;
+                ++passing;
+                if (path.target != p || path.tags != 0 || path.cond != 0) selfOnly = false;
+            }
+            if (passing == 1 && selfOnly) m |= uint64_t(1) << c;
+        }
+        stableMask[size_t(p) * 2] = uint32_t(m);
+        stableMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+    }
     std::vector<uint32_t> followStart, paths;
     for (int p = 0; p <= npos; ++p) {
         followStart.push_back(uint32_t(paths.size() / 4));
@@ -156,6 +172,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_OFF_POSMASK] = w.put(posMask);
     hdr[NF_OFF_FOLLOWSTART] = w.put(followStart);
     hdr[NF_OFF_PATHS] = w.put(paths);
+    hdr[NF_OFF_STABLE] = w.put(stableMask);
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(NF_TOTAL_BYTES);
 }
