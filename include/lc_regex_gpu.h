@@ -46,7 +46,10 @@ enum {
     LC_SYNTAX_NO_DOTALL = 1u << 1,      /* (?-s): '.' does not match '\n' */
     LC_SYNTAX_NO_MULTILINE = 1u << 2,   /* (?-m): '^'/'$' only at the ends of the line */
     LC_SYNTAX_EXTENDED = 1u << 3,       /* (?x) */
-    LC_SYNTAX_NAMED_ONLY = 1u << 4      /* unnamed groups do not capture (Grok / regexp2 ExplicitCapture-style) */
+    LC_SYNTAX_NAMED_ONLY = 1u << 4,     /* unnamed groups do not capture (Grok / regexp2 ExplicitCapture-style) */
+    LC_SYNTAX_SEARCH = 1u << 5          /* leftmost-first SEARCH instead of whole-line match (Go processor_regex without
+                                           FullMatch, regex.go:105-129): compiled as (?s:.*?)(re)(?s:.*), so group 1 is
+                                           the whole match and the pattern's own groups are 2..mark_count */
 };
 
 /* device engines */

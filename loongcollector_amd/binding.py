@@ -16,6 +16,7 @@ LC_ENGINE_AUTO, LC_ENGINE_TDFA, LC_ENGINE_NFA = 0, 1, 2
 LC_NOMATCH, LC_MATCH, LC_OVERFLOW = 0, 1, 2
 LC_OK, LC_ERR_SYNTAX, LC_ERR_UNSUPPORTED, LC_ERR_NO_DEVICE, LC_ERR_HIP, LC_ERR_ARG = range(6)
 LC_SYNTAX_ICASE, LC_SYNTAX_NO_DOTALL, LC_SYNTAX_NO_MULTILINE, LC_SYNTAX_EXTENDED, LC_SYNTAX_NAMED_ONLY = 1, 2, 4, 8, 16
+LC_SYNTAX_SEARCH = 32
 
 (LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
  LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB) = range(8)

@@ -181,6 +181,43 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
 
 using namespace lcregex;
 
+// Leftmost-first SEARCH as a whole-line match:  search(re)  ==  regex_match( (?s:.*?)(re)(?s:.*) )
+// The lazy prefix makes the earliest start win, backtracking priority inside `re` is untouched, the greedy
+// suffix swallows the rest.  Group 1 becomes the whole match, the pattern's own groups shift up by one.
+// (Go processor_regex without FullMatch: plugins/processor/regex/regex.go:105-129; regexp2.FindStringMatch in
+// plugins/processor/grok/processor_grok.go:156.)
+static void shiftCaptures(Node& n) {
+    if (n.kind == Node::Group && n.capture) ++n.capture;
+    for (auto& k : n.kids) shiftCaptures(*k);
+}
+static void wrapForSearch(ParsedRegex& re) {
+    shiftCaptures(*re.root);
+    auto anyStar = [](bool greedy) {
+        auto set = std::make_unique<Node>();
+        set->kind = Node::Set;
+        set->set = ByteSet::all();
+        auto rep = std::make_unique<Node>();
+        rep->kind = Node::Repeat;
+        rep->min = 0;
+        rep->max = -1;
+        rep->greedy = greedy;
+        rep->kids.push_back(std::move(set));
+        return rep;
+    };
+    auto whole = std::make_unique<Node>();
+    whole->kind = Node::Group;
+    whole->capture = 1;
+    whole->kids.push_back(std::move(re.root));
+    auto cat = std::make_unique<Node>();
+    cat->kind = Node::Cat;
+    cat->kids.push_back(anyStar(false));
+    cat->kids.push_back(std::move(whole));
+    cat->kids.push_back(anyStar(true));
+    re.root = std::move(cat);
+    re.groupCount += 1;
+    re.groupNames.insert(re.groupNames.begin() + 1, std::string());
+}
+
 static void setErr(char* err, size_t cap, const std::string& msg) {
     if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
 }
@@ -211,6 +248,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             delete re;
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
         }
+        if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed);
         re->nfa = buildFollowNfa(parsed);
         if (engine != LC_ENGINE_NFA) {
             try {

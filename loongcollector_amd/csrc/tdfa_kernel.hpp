@@ -47,6 +47,12 @@ typedef u32x4 __attribute__((address_space(3))) * LdsQuadPtr;
 typedef const uint8_t __attribute__((address_space(3))) * LdsBytePtr;
 typedef const u32x4 __attribute__((address_space(1))) * GlobalQuadPtr;
 
+typedef uint32_t TdfaReg;  // capture offsets are 32-bit: a line may be as long as a 512 KiB read buffer
+typedef TdfaReg __attribute__((address_space(3))) * LdsRegPtr;
+#ifndef LC_TDFA_CHUNK
+#define LC_TDFA_CHUNK 16  // bytes stepped per three-phase round (8 halves the live col/tt registers)
+#endif
+
 #ifndef LC_TDFA_STAGE_BYTES
 #define LC_TDFA_STAGE_BYTES 64
 #endif
@@ -64,7 +70,7 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 template <int BLOCK>
 __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase, uint32_t list, uint32_t pos,
                                                 uint32_t tid) {
-    uint32_t* regs = reinterpret_cast<uint32_t*>(smem + regsBase);
+    TdfaReg* regs = reinterpret_cast<TdfaReg*>(smem + regsBase);
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_OPSSTART]);
     const uint16_t* ops = reinterpret_cast<const uint16_t*>(smem + hdr[TD_OFF_OPS]);
@@ -74,7 +80,7 @@ __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase
     for (uint32_t i = 0; i < cnt; ++i) {
         const uint32_t w = ops[at + 1 + i];
         const uint32_t dst = w & 0xFF, src = w >> 8;
-        const uint32_t val = (src == TD_REG_POS) ? pos : regs[src * BLOCK + tid];
+        const TdfaReg val = (src == TD_REG_POS) ? TdfaReg(pos) : regs[src * BLOCK + tid];
         regs[dst * BLOCK + tid] = val;
     }
 }
@@ -100,49 +106,57 @@ __device__ __forceinline__ uint32_t addHighHalf(uint32_t a, uint32_t t) {
 // from the chunk's entry state and applies every register program at its own byte.  Rolled up: it is rare.
 template <int BLOCK>
 __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t t, uint32_t base, uint32_t L,
-                                                uint32_t idCol, uint32_t regsBase, uint32_t tid) {
+                                                uint32_t idCol, uint32_t regsBase, uint32_t tid, uint32_t nBytes) {
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
-    const uint32_t regAddr0 = regsBase + tid * 4;
+    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
 #pragma unroll 1
-    for (uint32_t j = 0; j < 16; ++j) {
+    for (uint32_t j = 0; j < nBytes; ++j) {
         const uint32_t word = (j < 8) ? ((j < 4) ? q.x : q.y) : ((j < 12) ? q.z : q.w);
         const uint32_t b = (word >> ((j & 3) * 8)) & 0xFFu;
         const uint32_t col = (base + j < L) ? uint32_t(cmap[b]) : idCol;
         t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col, t));
         if (t & (TD_OP_GENERAL << 16)) tdfaRunMoveList<BLOCK>(smem, regsBase, t >> 17, base + j, tid);
-        else *reinterpret_cast<LdsWordPtr>(addHighHalf(regAddr0, t)) = base + j;
+        else *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, t)) = TdfaReg(base + j);
     }
 }
 
-// steps one aligned 16-byte chunk; CHECKED=false is the mid-line fast path (all 16 bytes belong to the line)
-template <int BLOCK, bool CHECKED>
-__device__ __forceinline__ uint32_t tdfaStepChunk(uint8_t* smem, const u32x4& q, uint32_t t, uint32_t base, uint32_t L,
-                                                  uint32_t idCol, uint32_t regsBase, uint32_t tid) {
+// steps NB (8 or 16) consecutive bytes held in `words`; CHECKED=false is the mid-line fast path (all NB bytes belong
+// to the line)
+template <int BLOCK, bool CHECKED, int NB>
+__device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
+                                                  uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
+                                                  uint32_t tid) {
     // the blob sits at LDS address 0, so table offsets are LDS addresses
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
-    const uint32_t regAddr0 = regsBase + tid * 4;  // LDS address of regs[0][lane]
-    const uint32_t words[4] = {q.x, q.y, q.z, q.w};
+    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);  // LDS address of regs[0][lane]
     const uint32_t entry = t;
-    uint32_t col[16], tt[16];
+    uint32_t col[NB], tt[NB];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {  // phase 0
+    for (int j = 0; j < NB; ++j) {  // phase 0
         const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
         const uint32_t c4 = cmap[b];
         col[j] = CHECKED ? ((base + j < L) ? c4 : idCol) : c4;
     }
     uint32_t seen = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {  // phase 1
+    for (int j = 0; j < NB; ++j) {  // phase 1
         t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col[j], t));
         tt[j] = t;
         seen |= t;
     }
     if (!__any((seen & (TD_OP_GENERAL << 16)) != 0)) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)  // phase 2
-            *reinterpret_cast<LdsWordPtr>(addHighHalf(regAddr0, tt[j])) = base + j;
+        for (int j = 0; j < NB; ++j)  // phase 2
+            *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, tt[j])) = TdfaReg(base + j);
     } else {
-        tdfaReplayChunk<BLOCK>(smem, q, entry, base, L, idCol, regsBase, tid);
+        u32x4 q = {0, 0, 0, 0};
+        q.x = words[0];
+        q.y = words[1];
+        if (NB == 16) {
+            q.z = words[2 % (NB / 4)];
+            q.w = words[3 % (NB / 4)];
+        }
+        tdfaReplayChunk<BLOCK>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
     }
     return t;
 }
@@ -231,11 +245,20 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
             const u32x4 q = *reinterpret_cast<LdsQuadPtr>(myRow + k * 16);
             const uint32_t base = s * kTdfaStageBytes + k * 16 - head;  // line offset of byte 0 (wraps in the head)
             const bool full = base < L && L - base >= 16;
+#if LC_TDFA_CHUNK == 16
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+            else t = tdfaStepBytes<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+#else
+            const uint32_t w0[2] = {q.x, q.y}, w1[2] = {q.z, q.w};
             if (__all(full)) {
-                t = tdfaStepChunk<BLOCK, false>(smem, q, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, false, 8>(smem, w0, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, false, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
             } else {
-                t = tdfaStepChunk<BLOCK, true>(smem, q, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, true, 8>(smem, w0, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, true, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
             }
+#endif
         }
         // every lane dead (or past its end in the identity column): nothing left to decide for this wavefront
         if (__all((t & 0xFFFFu) == TD_TRANS_OFFSET || s + 1 >= myStages)) break;
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     if (!live) return;
     const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + hdr[TD_OFF_FINALID]);
     const uint8_t* finalMap = smem + hdr[TD_OFF_FINALMAP];
-    const uint32_t* regs = reinterpret_cast<const uint32_t*>(smem + regsBase);
+    const TdfaReg* regs = reinterpret_cast<const TdfaReg*>(smem + regsBase);
     const uint32_t state = ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     const uint32_t fid = finalId[state];
     const bool matched = (state != 0) && (fid != 0xFFFFu);

@@ -61,6 +61,31 @@ class Pcre:
         return out
 
 
+    def search(self, pattern: bytes, subject: bytes, ngroups: int):
+        err = ctypes.c_char_p()
+        eo = ctypes.c_int()
+        code = self.lib.pcre_compile(pattern, PCRE_DOTALL | PCRE_MULTILINE, ctypes.byref(err), ctypes.byref(eo), None)
+        if not code:
+            raise ValueError(err.value)
+        n = 3 * (ngroups + 1)
+        ov = (ctypes.c_int * n)()
+        rc = self.lib.pcre_exec(code, None, subject, len(subject), 0, 0, ov, n)
+        if rc < 0:
+            return None if rc == -1 else "error%d" % rc
+        out = [[-1, -1] for _ in range(ngroups + 1)]
+        for g in range(min(rc, ngroups + 1)):
+            out[g] = [ov[2 * g], ov[2 * g + 1]]
+        return out
+
+
+def py_search(pattern: bytes, subject: bytes):
+    rx = re.compile(pattern, re.DOTALL | re.MULTILINE)
+    m = rx.search(subject)
+    if m is None:
+        return None, rx.groups
+    return [list(m.span(g)) for g in range(rx.groups + 1)], rx.groups
+
+
 def py_fullmatch(pattern: bytes, subject: bytes):
     rx = re.compile(pattern, re.DOTALL | re.MULTILINE)
     m = rx.fullmatch(subject)
@@ -268,6 +293,54 @@ def main():
             add(pb, rand_subject(rng), "random")
 
     total = sum(len(c["subs"]) for c in cases)
+    # ---- second file: leftmost-first SEARCH vectors (Go processor_regex / Grok semantics), same two engines
+    s_cases, s_bypat, s_dropped = [], {}, 0
+
+    def add_search(pattern, subject):
+        nonlocal s_dropped
+        try:
+            exp_py, ng = py_search(pattern, subject)
+            exp_pc = pcre.search(pattern, subject, ng)
+        except (re.error, ValueError):
+            return
+        if exp_py != exp_pc:
+            s_dropped += 1
+            return
+        key = pattern.decode('latin-1')
+        if key not in s_bypat:
+            s_bypat[key] = {"p": key, "g": ng, "subs": []}
+            s_cases.append(s_bypat[key])
+        flat = None if exp_py is None else [v for ab in exp_py for v in ab]
+        ent = [subject.decode('latin-1'), flat]
+        if ent not in s_bypat[key]["subs"]:
+            s_bypat[key]["subs"].append(ent)
+
+    srng = random.Random(20260922)
+    sg = Gen(srng)
+    for pat, subs in CURATED:
+        for sub in subs:
+            add_search(pat, b"junk " + sub + b" tail")
+            add_search(pat, sub)
+    nsp = 0
+    while nsp < 220:
+        p, _, smp = sg.alt(0)
+        pb = p.encode()
+        try:
+            re.compile(pb)
+        except re.error:
+            continue
+        nsp += 1
+        for _ in range(4):
+            add_search(pb, rand_subject(srng) + mutate(srng, smp()) + rand_subject(srng))
+        add_search(pb, rand_subject(srng))
+    s_total = sum(len(c["subs"]) for c in s_cases)
+    with open(os.path.join(HERE, "regex_search_golden.json"), "w") as f:
+        json.dump({"generator": "tests/golden/gen_regex_golden.py", "seed": 20260922, "semantics": "leftmost-first search",
+                   "dropped_disagreements": s_dropped, "n_patterns": len(s_cases), "n_cases": s_total,
+                   "format": "cases[i] = {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]}",
+                   "cases": s_cases}, f, separators=(",", ":"))
+    print("search: patterns", len(s_cases), "cases", s_total, "dropped", s_dropped)
+
     matched = sum(1 for c in cases for e in c["subs"] if e[1] is not None)
     out = {"generator": "tests/golden/gen_regex_golden.py", "seed": 20260921,
            "engines": ["CPython re %s (bytes, DOTALL|MULTILINE)" % sys.version.split()[0], "PCRE1 8.45 (^(?:re)\\z, DOTALL|MULTILINE)"],

@@ -186,3 +186,24 @@ def test_full_size_batch_properties(torch_dev):
     p_caps, _ = OracleRegex(corpus.REGEX_A).fullmatch_batch(pool.reshape(-1), p_off, np.full(pool_lines, 512, np.uint32))
     idx = np.random.Generator(np.random.MT19937(corpus.SEED + 7919)).integers(0, pool_lines, size=n)
     assert np.array_equal(caps, p_caps[idx])
+
+
+def test_search_mode_golden_vectors_on_both_kernels(torch_dev, golden_dir):
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for c in golden["cases"]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_SEARCH)
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        engines = [B.LC_ENGINE_NFA] + ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        for eng in engines:
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+            for i, (_, flat) in enumerate(c["subs"]):
+                checked += 1
+                ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if flat is None else (
+                    status[i] == B.LC_MATCH and list(caps[i]) == flat)
+                if not ok:
+                    bad.append((eng, c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 2000
+    assert not bad, bad[:5]

@@ -105,3 +105,26 @@ def test_forced_engines_and_tdfa_limit_fallback():
     s = b"xxa" + b"y" * 14 + b"zz"
     exp = OracleRegex(blowup).fullmatch(s)
     assert NfaInterp(rx).fullmatch(s) == [v for ab in exp[1:] for v in ab]
+
+
+def test_search_mode_tables_reproduce_every_search_vector(golden_dir):
+    """LC_SYNTAX_SEARCH compiles (?s:.*?)(re)(?s:.*): group 1 = whole match, own groups shifted by one."""
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        d = json.load(f)
+    bad, n, unsupported = [], 0, 0
+    for c in d["cases"]:
+        try:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_SEARCH)
+        except B.RegexUnsupportedError:
+            unsupported += 1
+            continue
+        assert rx.groups == c["g"] + 1
+        interps = [NfaInterp(rx)] + ([TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        for subj, flat in c["subs"]:
+            for it in interps:
+                n += 1
+                got = it.fullmatch(subj.encode("latin-1"))
+                if got != flat:
+                    bad.append((c["p"], subj, got, flat))
+    assert n > 2000 and unsupported == 0
+    assert not bad, bad[:5]

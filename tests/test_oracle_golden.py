@@ -67,3 +67,19 @@ def test_complexity_budget_reports_failure():
     rx = OracleRegex(r"(a|aa)+(a|aa)+(a|aa)+(a|aa)+(a|aa)+(a|aa)+b")
     with pytest.raises(RuntimeError):
         rx.fullmatch(b"a" * 64)
+
+
+def test_oracle_search_matches_every_search_vector(golden_dir):
+    """leftmost-first search (Go processor_regex without FullMatch, plugins/processor/regex/regex.go:105-129)"""
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        d = json.load(f)
+    assert d["n_cases"] > 1000
+    bad = []
+    for c in d["cases"]:
+        rx = OracleRegex(c["p"].encode("latin-1"))
+        for subj, flat in c["subs"]:
+            got = rx.search(subj.encode("latin-1"))
+            got_flat = None if got is None else [v for ab in got for v in ab]
+            if got_flat != flat:
+                bad.append((c["p"], subj, got_flat, flat))
+    assert not bad, bad[:5]
