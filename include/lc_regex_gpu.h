@@ -133,6 +133,26 @@ int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_da
                                  const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
                                  int32_t* d_caps, uint8_t* d_status, void* stream);
 
+/* Same as lc_regex_match_device_engine with offsets[n+1] + sep_bytes, but the line count is read from device memory
+ * (*d_nlines, clamped to max_lines) when the kernel starts: lets lc_split_lines_device and the match run back to back
+ * on one stream with no host round trip.  Lines beyond *d_nlines are not touched. */
+int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                              uint32_t sep_bytes, const uint32_t* d_nlines, uint32_t max_lines, uint32_t ngroups,
+                              int32_t* d_caps, uint8_t* d_status, void* stream);
+
+/* Line splitting on the device: the step BEFORE the parse processor in the reference pipeline,
+ * ProcessorSplitLogStringNative::ProcessEvent / GetNextLine
+ * (core/plugin/processor/inner/ProcessorSplitLogStringNative.cpp:101-174).  Scans d_data[0..nbytes) for split_char
+ * and writes the line-offset table d_off[0..nlines] in the "offsets[n+1] + sep_bytes=1" form the match entry points
+ * take (len[i] = off[i+1]-off[i]-1, also for an unterminated last line) and the line count to *d_nlines.  Same line
+ * set as the reference: empty lines are lines, a trailing split_char does not open a new line, an empty buffer has
+ * none.  If *d_nlines >= off_capacity the table was truncated (caller error).  d_scratch: lc_split_scratch_bytes().
+ * Asynchronous on `stream`. */
+size_t lc_split_scratch_bytes(uint64_t nbytes);
+int lc_split_lines_device(const uint8_t* d_data, uint64_t nbytes, uint8_t split_char, uint32_t* d_off,
+                          uint32_t off_capacity, uint32_t* d_nlines, void* d_scratch, size_t scratch_bytes,
+                          void* stream);
+
 /* Same, for host buffers: lines are gathered through pinned staging buffers and copied with
  * hipMemcpyAsync on two streams so that chunk k+1 uploads while chunk k is being matched and chunk k-1
  * downloads.  Synchronous: results are in caps/status on return. */

@@ -63,6 +63,12 @@ def load(path=None):
     L.lc_regex_match_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.lc_regex_match_device_engine.restype = i32
     L.lc_regex_match_device_engine.argtypes = [vp, i32, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.lc_regex_match_device_dyn.restype = i32
+    L.lc_regex_match_device_dyn.argtypes = [vp, i32, vp, vp, u32, vp, u32, u32, vp, vp, vp]
+    L.lc_split_scratch_bytes.restype = sz
+    L.lc_split_scratch_bytes.argtypes = [ctypes.c_uint64]
+    L.lc_split_lines_device.restype = i32
+    L.lc_split_lines_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint8, vp, u32, vp, vp, sz, vp]
     L.lc_regex_match_host.restype = i32
     L.lc_regex_match_host.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp]
     L.lc_last_error.restype = cp
@@ -142,6 +148,14 @@ class GpuRegex:
                                                   d_caps.data_ptr(), d_status.data_ptr(), stream)
         _check(rc, "lc_regex_match_device")
 
+    def match_device_dyn(self, d_data, d_off, d_nlines, max_lines, d_caps, d_status, ngroups=None, sep_bytes=1,
+                         stream=None, engine=LC_ENGINE_AUTO):
+        G = self.groups if ngroups is None else ngroups
+        rc = self._L.lc_regex_match_device_dyn(self._h, engine, d_data.data_ptr(), d_off.data_ptr(), sep_bytes,
+                                               d_nlines.data_ptr(), max_lines, G, d_caps.data_ptr(),
+                                               d_status.data_ptr(), stream)
+        _check(rc, "lc_regex_match_device_dyn")
+
     # ---- host batch (numpy arrays); pinned double-buffered H2D/D2H inside the library
     def match_host(self, data, off, length, ngroups=None):
         G = self.groups if ngroups is None else ngroups
@@ -155,6 +169,19 @@ class GpuRegex:
                                          caps.ctypes.data, status.ctypes.data)
         _check(rc, "lc_regex_match_host")
         return caps, status
+
+
+def split_lines_device(d_data, nbytes, d_off, d_nlines, d_scratch, split_char=10, stream=None):
+    """ProcessorSplitLogStringNative on the device; all arguments are torch tensors on the current HIP device."""
+    L = load()
+    rc = L.lc_split_lines_device(d_data.data_ptr(), nbytes, split_char, d_off.data_ptr(), d_off.numel(),
+                                 d_nlines.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(),
+                                 stream)
+    _check(rc, "lc_split_lines_device")
+
+
+def split_scratch_bytes(nbytes):
+    return int(load().lc_split_scratch_bytes(nbytes))
 
 
 def device_count():

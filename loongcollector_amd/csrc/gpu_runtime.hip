@@ -19,6 +19,7 @@
 #include "device_tables.h"
 #include "nfa_kernel.hpp"
 #include "regex_handle.hpp"
+#include "split_kernel.hpp"
 #include "tdfa_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -80,7 +81,7 @@ void lcReleaseDeviceTables(lc_regex* re) {
 
 template <int BLOCK>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
-                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, uint32_t ngroups,
+                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -90,14 +91,14 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(tdfa_match_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
-                       static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
+                       d_n, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                      uint32_t sep, uint32_t n, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
-                      hipStream_t stream) {
+                      uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups, int32_t* d_caps,
+                      uint8_t* d_status, hipStream_t stream) {
     void* dBlob = nullptr;
     int rc = ensureUploaded(re, dev, true, &dBlob);
     if (rc != LC_OK) return rc;
@@ -110,15 +111,15 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
     const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
     switch (block) {
-        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
     }
 }
 
 template <int NS>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
-                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, uint32_t ngroups,
+                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -128,14 +129,14 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, con
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
     hipLaunchKernelGGL(nfa_match_kernel<NS>, dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
-                       static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+                       d_n, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                     uint32_t sep, uint32_t n, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
-                     hipStream_t stream) {
+                     uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups, int32_t* d_caps,
+                     uint8_t* d_status, hipStream_t stream) {
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
         return LC_ERR_UNSUPPORTED;
@@ -150,23 +151,23 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
-    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
-    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
 }
 
 static int matchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
-                         const uint32_t* d_len, uint32_t sep, uint32_t n, uint32_t ngroups, int32_t* d_caps,
-                         uint8_t* d_status, hipStream_t stream) {
+                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
+                         int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
             return LC_ERR_UNSUPPORTED;
         }
-        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
     }
-    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, ngroups, d_caps, d_status, stream);
+    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
 }
 
 extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
@@ -183,8 +184,59 @@ extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const ui
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
-    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, ngroups, d_caps, d_status,
+    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, ngroups, d_caps, d_status,
                          static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                                         uint32_t sep_bytes, const uint32_t* d_nlines, uint32_t max_lines,
+                                         uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, void* stream) {
+    if (!re || !d_nlines) return LC_ERR_ARG;
+    if (max_lines == 0) return LC_OK;
+    if (!d_data || !d_off || !d_caps || !d_status) return LC_ERR_ARG;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    if (engine == LC_ENGINE_AUTO) engine = re->engine;
+    return matchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, ngroups, d_caps,
+                         d_status, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ line split
+extern "C" size_t lc_split_scratch_bytes(uint64_t nbytes) {
+    const uint64_t nBlocks = (nbytes + kSplitBytesPerBlock - 1) / kSplitBytesPerBlock;
+    return size_t(nBlocks + 4) * 4;
+}
+
+extern "C" int lc_split_lines_device(const uint8_t* d_data, uint64_t nbytes, uint8_t split_char, uint32_t* d_off,
+                                     uint32_t off_capacity, uint32_t* d_nlines, void* d_scratch, size_t scratch_bytes,
+                                     void* stream) {
+    if (!d_off || !d_nlines || off_capacity < 2) return LC_ERR_ARG;
+    if (nbytes >= (uint64_t(1) << 32) - 1) return LC_ERR_ARG;  // offsets are 32-bit, like the match kernels'
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nbytes == 0) {
+        HIP_TRY(hipMemsetAsync(d_nlines, 0, 4, st));
+        return LC_OK;
+    }
+    if (!d_data || !d_scratch || scratch_bytes < lc_split_scratch_bytes(nbytes)) return LC_ERR_ARG;
+    const uint32_t nBlocks = uint32_t((nbytes + kSplitBytesPerBlock - 1) / kSplitBytesPerBlock);
+    uint32_t* blockHits = static_cast<uint32_t*>(d_scratch);
+    uint32_t* nHits = blockHits + nBlocks;
+    hipLaunchKernelGGL(split_count_kernel, dim3(nBlocks), dim3(kSplitBlock), 0, st, d_data, nbytes, uint32_t(split_char),
+                       blockHits);
+    hipLaunchKernelGGL(split_scan_kernel, dim3(1), dim3(1024), 0, st, blockHits, nBlocks, nHits);
+    hipLaunchKernelGGL(split_scatter_kernel, dim3(nBlocks), dim3(kSplitBlock), 0, st, d_data, nbytes,
+                       uint32_t(split_char), blockHits, nHits, d_off, off_capacity, d_nlines);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
 }
 
 extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t* d_off,

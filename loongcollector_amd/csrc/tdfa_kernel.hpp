@@ -165,11 +165,16 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(const uint8_t* __restrict__ data,
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
-                                                           uint32_t nLines, const uint32_t* __restrict__ blob,
+                                                           uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
+                                                           const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
+    if (nLinesPtr) {  // line count produced on the device (split kernels) -- no host round trip between the launches
+        const uint32_t dyn = *nLinesPtr;
+        nLines = dyn < nLines ? dyn : nLines;
+    }
     {  // stage the tables: 16-byte coalesced copies
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);

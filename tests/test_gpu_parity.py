@@ -207,3 +207,53 @@ def test_search_mode_golden_vectors_on_both_kernels(torch_dev, golden_dir):
                     bad.append((eng, c["p"], subs[i], int(status[i]), list(caps[i]), flat))
     assert checked > 2000
     assert not bad, bad[:5]
+
+
+def test_config4_multi_tenant_64_pipelines_round_robin(torch_dev):
+    """BASELINE config 4: 64 concurrent pipelines, each with its own regex, batched round-robin onto one GPU the way
+    ProcessQueueManager::PopItem hands out groups (one ~512 KB group per pipeline per turn).  Every pipeline's tables
+    are resident in HBM once and are staged into LDS per launch (the 'per-pipeline NFA switch')."""
+    import torch
+    rng = np.random.default_rng(20260923)
+    delims = [" ", "|", "\t"]
+    pipelines = []
+    for p in range(64):
+        ngroups = int(rng.integers(6, 15))
+        d = delims[p % 3]
+        cls = {" ": r"[^ ]", "|": r"[^|]", "\t": r"[^\t]"}[d]
+        pattern = re_escape(d).join("(%s*)" % cls for _ in range(ngroups))
+        lines = []
+        for _ in range(1000):
+            fields = ["".join(chr(int(c)) for c in rng.integers(97, 123, size=int(rng.integers(0, 12))))
+                      for _ in range(ngroups + (1 if rng.integers(0, 10) == 0 else 0))]  # 10 %: one field too many
+            lines.append(d.join(fields).encode())
+        pipelines.append((B.GpuRegex(pattern), OracleRegex(pattern), lines))
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    results = []
+    for turn in range(2):                       # two round-robin turns over all 64 pipelines
+        for p, (rx, _, lines) in enumerate(pipelines):
+            part = lines[turn * 500:(turn + 1) * 500]
+            data, off, length = pack(part)
+            s = streams[p % 4]
+            with torch.cuda.stream(s):
+                d_data = torch.from_numpy(data).to(dev, non_blocking=True)
+                d_off = torch.from_numpy(off.view(np.int32)).to(dev, non_blocking=True)
+                d_len = torch.from_numpy(length.view(np.int32)).to(dev, non_blocking=True)
+                d_caps = torch.empty((len(part), 2 * rx.groups), dtype=torch.int32, device=dev)
+                d_status = torch.empty((len(part),), dtype=torch.uint8, device=dev)
+                rx.match_device(d_data, d_off, d_len, len(part), d_caps, d_status, stream=s.cuda_stream)
+            results.append((p, turn, d_caps, d_status, (d_data, d_off, d_len)))
+    torch.cuda.synchronize()
+    for p, turn, d_caps, d_status, _ in results:
+        _, orx, lines = pipelines[p]
+        part = lines[turn * 500:(turn + 1) * 500]
+        data, off, length = pack(part)
+        exp_caps, exp_status = orx.fullmatch_batch(data, off, length)
+        assert np.array_equal(d_status.cpu().numpy(), exp_status), p
+        assert np.array_equal(d_caps.cpu().numpy(), exp_caps), p
+        assert 0.8 < exp_status.mean() < 0.97
+
+
+def re_escape(d):
+    return {"|": r"\|", " ": " ", "\t": r"\t"}[d]
