@@ -14,7 +14,7 @@ def test_split_oracle_reference_behaviours():
     assert split_lines(b"a\n\nb") == [(0, 1), (2, 0), (3, 1)]   # empty lines are lines
     assert split_lines(b"\n") == [(0, 0)]
     assert split_lines(b"\n\n") == [(0, 0), (1, 0)]
-    assert split_lines(b"a\r\nb") == [(0, 2), (4, 1)]           # \r is payload
+    assert split_lines(b"a\r\nb") == [(0, 2), (3, 1)]           # \r is payload
     assert split_lines(b"a|b|", ord("|")) == [(0, 1), (2, 1)]
     off = split_table(b"ab\ncd")
     assert list(off) == [0, 3, 6]                               # len = off[i+1]-off[i]-1 -> 2, 2
