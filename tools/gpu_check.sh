@@ -1,5 +1,5 @@
 #!/bin/bash
-# helper run on the GPU box by gpurun: parity tests + bench + optional rocprof passes (outputs under gpurun_out/)
+# helper run on the GPU box by gpurun (tools/gpu_check.sh [test|notest] [prof]): parity tests + bench + optional rocprof passes (outputs under gpurun_out/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd $R
@@ -18,5 +18,5 @@ if [ "$2" == "prof" ]; then
     i=$((i+1))
     timeout 400 rocprofv3 --pmc $set -d $R/gpurun_out/prof_pmc$i -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $R/gpurun_out/prof_pmc$i.log 2>&1
   done
-  cd $R && python tools_prof_summary.py gpurun_out > gpurun_out/prof_summary.txt 2>&1; cat gpurun_out/prof_summary.txt
+  cd $R && python tools/prof_summary.py gpurun_out > gpurun_out/prof_summary.txt 2>&1; cat gpurun_out/prof_summary.txt
 fi

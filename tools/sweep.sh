@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/sweep.sh "<flags1>" "<flags2>" ...   -- rebuilds with each flag set and prints kernel ms
+# usage: tools/sweep.sh "<flags1>" "<flags2>" ...   -- rebuilds with each flag set and prints kernel ms
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for f in "$@"; do
   LC_EXTRA_CXXFLAGS="$f" python -m loongcollector_amd.build --force > /dev/null 2>&1
