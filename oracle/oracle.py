@@ -42,6 +42,9 @@ def lib():
         L.orx_fullmatch_batch.restype = ctypes.c_long
         L.orx_fullmatch_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orx_process_batch.restype = ctypes.c_ulong
+        L.orx_process_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_ulong)]
         _LIB = L
     return _LIB
 
@@ -99,3 +102,16 @@ class OracleRegex:
         lib().orx_fullmatch_batch(self._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, n, G,
                                   caps.ctypes.data, status.ctypes.data)
         return caps, status
+
+
+    def process_batch(self, data, off, length, keys):
+        """The reference processor's per-event work (match + one SetContentNoCopy per key + source tombstone + counters,
+        oracle/processor_oracle.c) over a batch; -> dict of the four plugin counters.  Used for the timed CPU baseline."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        blob = b"".join(k.encode() + b"\0" for k in keys)
+        counters = (ctypes.c_ulong * 4)()
+        lib().orx_process_batch(self._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, off.shape[0], blob,
+                                len(keys), counters)
+        return dict(zip(("discarded", "out_failed", "out_key_not_found", "out_successful"), [int(c) for c in counters]))
