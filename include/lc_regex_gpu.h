@@ -140,6 +140,16 @@ int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8_t* d_data,
                               uint32_t sep_bytes, const uint32_t* d_nlines, uint32_t max_lines, uint32_t ngroups,
                               int32_t* d_caps, uint8_t* d_status, void* stream);
 
+/* Same as lc_regex_match_device_engine, for batches whose line lengths vary: a counting sort on the device groups
+ * lines of similar length (longest first) and the match kernel visits them in that order, so that the 64 lines of a
+ * wavefront finish together (measured 2x on 128-2048 B lines).  Results land at the lines' ORIGINAL indices.
+ * d_nlines: optional device-side line count (NULL = n).  d_scratch: lc_sched_scratch_bytes(n) bytes. */
+size_t lc_sched_scratch_bytes(uint32_t max_lines);
+int lc_regex_match_device_ragged(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                                 const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, const uint32_t* d_nlines,
+                                 uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, void* d_scratch,
+                                 size_t scratch_bytes, void* stream);
+
 /* Line splitting on the device: the step BEFORE the parse processor in the reference pipeline,
  * ProcessorSplitLogStringNative::ProcessEvent / GetNextLine
  * (core/plugin/processor/inner/ProcessorSplitLogStringNative.cpp:101-174).  Scans d_data[0..nbytes) for split_char

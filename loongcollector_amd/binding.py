@@ -65,6 +65,10 @@ def load(path=None):
     L.lc_regex_match_device_engine.argtypes = [vp, i32, vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.lc_regex_match_device_dyn.restype = i32
     L.lc_regex_match_device_dyn.argtypes = [vp, i32, vp, vp, u32, vp, u32, u32, vp, vp, vp]
+    L.lc_sched_scratch_bytes.restype = sz
+    L.lc_sched_scratch_bytes.argtypes = [u32]
+    L.lc_regex_match_device_ragged.restype = i32
+    L.lc_regex_match_device_ragged.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, sz, vp]
     L.lc_split_scratch_bytes.restype = sz
     L.lc_split_scratch_bytes.argtypes = [ctypes.c_uint64]
     L.lc_split_lines_device.restype = i32
@@ -148,6 +152,16 @@ class GpuRegex:
                                                   d_caps.data_ptr(), d_status.data_ptr(), stream)
         _check(rc, "lc_regex_match_device")
 
+    def match_device_ragged(self, d_data, d_off, d_len, n, d_caps, d_status, d_scratch, ngroups=None, sep_bytes=0,
+                            d_nlines=None, stream=None, engine=LC_ENGINE_AUTO):
+        """length-scheduled match for ragged batches; d_scratch: >= sched_scratch_bytes(n) bytes on the device"""
+        G = self.groups if ngroups is None else ngroups
+        rc = self._L.lc_regex_match_device_ragged(
+            self._h, engine, d_data.data_ptr(), d_off.data_ptr(), d_len.data_ptr() if d_len is not None else None,
+            sep_bytes, n, d_nlines.data_ptr() if d_nlines is not None else None, G, d_caps.data_ptr(),
+            d_status.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(), stream)
+        _check(rc, "lc_regex_match_device_ragged")
+
     def match_device_dyn(self, d_data, d_off, d_nlines, max_lines, d_caps, d_status, ngroups=None, sep_bytes=1,
                          stream=None, engine=LC_ENGINE_AUTO):
         G = self.groups if ngroups is None else ngroups
@@ -178,6 +192,10 @@ def split_lines_device(d_data, nbytes, d_off, d_nlines, d_scratch, split_char=10
                                  d_nlines.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(),
                                  stream)
     _check(rc, "lc_split_lines_device")
+
+
+def sched_scratch_bytes(n):
+    return int(load().lc_sched_scratch_bytes(n))
 
 
 def split_scratch_bytes(nbytes):

@@ -11,6 +11,7 @@
 // Byte-scan work: no MFMA.  The bound that matters is LDS lookup throughput / latency, then HBM.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -19,6 +20,7 @@
 #include "device_tables.h"
 #include "nfa_kernel.hpp"
 #include "regex_handle.hpp"
+#include "sched_kernel.hpp"
 #include "split_kernel.hpp"
 #include "tdfa_kernel.hpp"
 
@@ -81,7 +83,7 @@ void lcReleaseDeviceTables(lc_regex* re) {
 
 template <int BLOCK>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
-                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
+                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -91,13 +93,13 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(tdfa_match_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                      uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups, int32_t* d_caps,
+                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups, int32_t* d_caps,
                       uint8_t* d_status, hipStream_t stream) {
     void* dBlob = nullptr;
     int rc = ensureUploaded(re, dev, true, &dBlob);
@@ -111,15 +113,15 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
     const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
     switch (block) {
-        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
-        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
-        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
     }
 }
 
 template <int NS>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
-                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
+                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -129,13 +131,13 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, con
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
     hipLaunchKernelGGL(nfa_match_kernel<NS>, dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                     uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups, int32_t* d_caps,
+                     uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups, int32_t* d_caps,
                      uint8_t* d_status, hipStream_t stream) {
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
@@ -151,23 +153,23 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
-    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
-    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
-    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
-    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
 }
 
 static int matchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
-                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, uint32_t ngroups,
+                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
             return LC_ERR_UNSUPPORTED;
         }
-        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
     }
-    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, ngroups, d_caps, d_status, stream);
+    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
 }
 
 extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
@@ -184,7 +186,7 @@ extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const ui
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
-    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, ngroups, d_caps, d_status,
+    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, nullptr, ngroups, d_caps, d_status,
                          static_cast<hipStream_t>(stream));
 }
 
@@ -202,8 +204,41 @@ extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
-    return matchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, ngroups, d_caps,
+    return matchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, nullptr, ngroups, d_caps,
                          d_status, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t lc_sched_scratch_bytes(uint32_t max_lines) { return (size_t(max_lines) + 2 * kSchedBuckets) * 4; }
+
+extern "C" int lc_regex_match_device_ragged(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                                            const uint32_t* d_len, uint32_t sep_bytes, uint32_t n,
+                                            const uint32_t* d_nlines, uint32_t ngroups, int32_t* d_caps,
+                                            uint8_t* d_status, void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (!re) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (!d_data || !d_off || !d_caps || !d_status || !d_scratch || scratch_bytes < lc_sched_scratch_bytes(n))
+        return LC_ERR_ARG;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    if (engine == LC_ENGINE_AUTO) engine = re->engine;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* hist = static_cast<uint32_t*>(d_scratch);
+    uint32_t* cursor = hist + kSchedBuckets;
+    uint32_t* order = cursor + kSchedBuckets;
+    HIP_TRY(hipMemsetAsync(hist, 0, kSchedBuckets * 4, st));
+    const uint32_t grid = std::min<uint32_t>((n + kSchedBlock - 1) / kSchedBlock, 2048u);
+    hipLaunchKernelGGL(sched_hist_kernel, dim3(grid), dim3(kSchedBlock), 0, st, d_off, d_len, sep_bytes, n, d_nlines, hist);
+    hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(kSchedBuckets), 0, st, hist, cursor);
+    hipLaunchKernelGGL(sched_scatter_kernel, dim3(grid), dim3(kSchedBlock), 0, st, d_off, d_len, sep_bytes, n, d_nlines,
+                       cursor, order);
+    HIP_TRY(hipGetLastError());
+    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, d_nlines, order, ngroups, d_caps, d_status,
+                         st);
 }
 
 // ------------------------------------------------------------------------------------------------ line split

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                                                               const uint32_t* __restrict__ off,
                                                               const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                               uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
+                                                              const uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ blob,
                                                               uint32_t blobBytes, uint32_t nGroupsOut,
                                                               int32_t* __restrict__ caps,
@@ -95,8 +96,9 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
 
-    const uint32_t line = blockIdx.x * kNfaWaves + wave;
-    if (line >= nLines) return;  // wave-uniform
+    const uint32_t slot = blockIdx.x * kNfaWaves + wave;
+    if (slot >= nLines) return;  // wave-uniform
+    const uint32_t line = order ? order[slot] : slot;
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
 

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                            uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
+                                                           const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stageBase = blobBytes + regBytes + wave * kTdfaStagePerWave;  // this wave's staging rows (LDS address)
 
-    const uint32_t line = blockIdx.x * BLOCK + tid;
-    const bool live = line < nLines;
+    const uint32_t slot = blockIdx.x * BLOCK + tid;
+    const bool live = slot < nLines;
+    const uint32_t line = (live && order) ? order[slot] : slot;  // length-aware schedule (sched_kernel.hpp)
     uint32_t o = 0, L = 0;
     if (live) {
         o = off[line];

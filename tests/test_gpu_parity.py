@@ -257,3 +257,30 @@ def test_config4_multi_tenant_64_pipelines_round_robin(torch_dev):
 
 def re_escape(d):
     return {"|": r"\|", " ": " ", "\t": r"\t"}[d]
+
+
+@pytest.mark.parametrize("engine", [B.LC_ENGINE_TDFA, B.LC_ENGINE_NFA])
+def test_length_scheduled_ragged_path_is_bit_exact(torch_dev, engine):
+    """lc_regex_match_device_ragged: same results, at the ORIGINAL line indices, as the plain path and the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 7001 if engine == B.LC_ENGINE_TDFA else 1500
+    data, off, length = corpus.mixed_batch(n, min_len=1, max_len=5000)
+    length[::97] = 0                       # empty lines in the mix (views of zero length)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_B).fullmatch_batch(data, off[:-1], length)
+    rx = B.GpuRegex(corpus.REGEX_B)
+    G = rx.groups
+    d_data = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(off[:-1].view(np.int32).copy()).to(dev)
+    d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev)
+    d_caps = torch.full((n, 2 * G), -7, dtype=torch.int32, device=dev)
+    d_status = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    d_scratch = torch.empty((B.sched_scratch_bytes(n) // 4 + 1,), dtype=torch.int32, device=dev)
+    rx.match_device_ragged(d_data, d_off, d_len, n, d_caps, d_status, d_scratch, engine=engine,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_status.cpu().numpy(), exp_status)
+    assert np.array_equal(d_caps.cpu().numpy(), exp_caps)
+    order = d_scratch.cpu().numpy().view(np.uint32)[512:512 + n]
+    assert sorted(order.tolist()) == list(range(n))                      # a permutation
+    assert (np.diff((length[order] >> 5).astype(np.int64)) <= 0).all()    # longest bucket first
