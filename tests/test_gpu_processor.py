@@ -144,3 +144,44 @@ def test_dlsym_slot_end_to_end():
     iface.finalize(ins.plugin_state)
     bad = Instance()
     assert iface.init(ctypes.addressof(bad), ctypes.c_char_p(b'{"SourceKey":"c"}'), None) != 0
+
+
+def test_concurrent_process_calls_on_one_instance():
+    """Up to process_thread_count runner threads may call Process on the same instance
+    (core/collection_pipeline/queue/ProcessQueueManager.cpp:167-205): device tables are shared, staging is per thread."""
+    import threading
+    from loongcollector_amd import corpus
+    n_threads, groups_per_thread, lines_per_group = 4, 6, 700
+    data, off, length = corpus.apache_batch(n_threads * groups_per_thread * lines_per_group, "B", poison_every=29)
+    raw = data.tobytes()
+    lines = [raw[off[i]:off[i] + length[i]].decode("latin-1") for i in range(len(length))]
+    p = Processor({"SourceKey": "content", "Regex": corpus.REGEX_B, "Keys": corpus.KEYS_B})
+    groups = [[EventGroup({"events": [{"contents": {"content": s}, "timestamp": 1, "type": 1}
+                                      for s in lines[(t * groups_per_thread + g) * lines_per_group:
+                                                     (t * groups_per_thread + g + 1) * lines_per_group]]})
+               for g in range(groups_per_thread)] for t in range(n_threads)]
+    errors = []
+
+    def run(t):
+        try:
+            for g in groups[t]:
+                p.process(g)
+        except Exception as e:  # noqa
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors
+    po = ProcessorOracle({"SourceKey": "content", "Regex": corpus.REGEX_B, "Keys": corpus.KEYS_B})
+    idx = 0
+    for t in range(n_threads):
+        for g in groups[t]:
+            part = lines[idx:idx + lines_per_group]
+            idx += lines_per_group
+            out = po.process_group([LogEventModel([("content", s.encode("latin-1"))]) for s in part])
+            assert g.contents() == [[(k, v.decode("latin-1")) for k, v in ev.live()] for ev in out]
+    c = p.counters()
+    assert c["in_events_total"] == len(lines) and c["out_failed_events_total"] == po.counters["out_failed"]
