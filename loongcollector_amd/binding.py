@@ -128,6 +128,12 @@ class GpuRegex:
         _check(self._L.lc_regex_info(self._h, ctypes.byref(i)), "lc_regex_info")
         return {f: getattr(i, f) for f, _ in LcRegexInfo._fields_}
 
+    def has_nfa_program(self):
+        """False when the follow NFA does not fit the NFA kernel's format (then only the TDFA engine can run it)."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        return self._L.lc_regex_table(self._h, LC_TABLE_NFA_BLOB, ctypes.byref(p), ctypes.byref(n)) == LC_OK
+
     def group_name(self, g):
         r = self._L.lc_regex_group_name(self._h, g)
         return r.decode() if r else None

@@ -59,6 +59,10 @@ enum {
     NF_CONDS_USED = 10,
     NF_OFF_STABLE = 11,   // u64[nPos+1]: bit c set iff on byte class c the position's ONLY possible move is its own
                           // unconditional, tag-free self loop (the kernel's steady-state fast path)
+    NF_OFF_BEHIND = 12,   // u32[nClasses+1]: look-behind assertions (cond bits) that hold when the previous byte has class
+                          // c; entry nClasses = start of input
+    NF_OFF_AHEAD = 13,    // u32[nClasses+1]: look-ahead assertions that hold when the next byte has class c; entry
+                          // nClasses = end of input
     NF_HEADER_WORDS = 16
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

@@ -5,32 +5,17 @@
 
 namespace lcregex {
 
-bool condHolds(uint16_t cond, const ByteProps& prev, const ByteProps& next) {
-    auto bit = [&](AssertKind k) { return (cond >> unsigned(k)) & 1u; };
-    const bool atStart = prev.boundary, atEnd = next.boundary;
-    const bool crlf = !atStart && !atEnd && prev.cr && next.lf;
-    if (bit(AssertKind::BolMulti) && !(atStart || (prev.sep && !crlf))) return false;
-    if (bit(AssertKind::BolSingle) && !atStart) return false;
-    if (bit(AssertKind::EolMulti) && !(atEnd || (next.sep && !crlf))) return false;
-    if (bit(AssertKind::EolSingle) && !atEnd) return false;
-    const bool pw = !atStart && prev.word, nw = !atEnd && next.word;
-    if (bit(AssertKind::WordBoundary) && pw == nw) return false;
-    if (bit(AssertKind::NotWordBoundary) && pw != nw) return false;
-    if (bit(AssertKind::WordStart) && !(!pw && nw)) return false;
-    if (bit(AssertKind::WordEnd) && !(pw && !nw)) return false;
-    return true;
+uint32_t FollowNfa::behindBits(int prev) const {
+    uint32_t m = 0;
+    for (size_t i = 0; i < asserts.size(); ++i)
+        if (asserts[i].behind && (prev == kEdge ? asserts[i].edgeOk : asserts[i].set.has(unsigned(prev)))) m |= 1u << i;
+    return m;
 }
-
-uint8_t condPrevNeeds(uint16_t cond) {
-    auto bit = [&](AssertKind k) { return (cond >> unsigned(k)) & 1u; };
-    uint8_t need = 0;
-    if (bit(AssertKind::BolMulti)) need |= kPrevAtStart | kPrevSep | kPrevCR;
-    if (bit(AssertKind::BolSingle)) need |= kPrevAtStart;
-    if (bit(AssertKind::EolMulti)) need |= kPrevCR;  // only for the "never between \r\n" rule
-    if (bit(AssertKind::WordBoundary) || bit(AssertKind::NotWordBoundary) || bit(AssertKind::WordStart) ||
-        bit(AssertKind::WordEnd))
-        need |= kPrevWord;
-    return need;
+uint32_t FollowNfa::aheadBits(int next) const {
+    uint32_t m = 0;
+    for (size_t i = 0; i < asserts.size(); ++i)
+        if (!asserts[i].behind && (next == kEdge ? asserts[i].edgeOk : asserts[i].set.has(unsigned(next)))) m |= 1u << i;
+    return m;
 }
 
 namespace {
@@ -63,6 +48,15 @@ class Builder {
 public:
     std::vector<Inst> code;
     std::vector<ByteSet> positions;
+    std::vector<LookAssert> asserts;
+
+    int assertIndex(const LookAssert& a) {
+        for (size_t i = 0; i < asserts.size(); ++i)
+            if (asserts[i] == a) return int(i);
+        if (int(asserts.size()) >= kMaxAsserts) throw RegexError("unsupported: too many distinct look assertions");
+        asserts.push_back(a);
+        return int(asserts.size()) - 1;
+    }
 
     int emit(Inst::Op op, int x = 0, int y = 0) {
         if (code.size() > 200000) throw RegexError("regex too large after repeat expansion");
@@ -101,7 +95,7 @@ public:
                 gen(*n.kids[0]);
                 if (n.capture) emit(Inst::Save, 2 * (n.capture - 1) + 1);
                 break;
-            case Node::Assert: emit(Inst::Assert, int(n.assertKind)); break;
+            case Node::Assert: emit(Inst::Assert, assertIndex(n.look)); break;
             case Node::Repeat: genRepeat(n); break;
         }
     }
@@ -161,14 +155,14 @@ private:
     std::vector<FollowPath> out;
     size_t steps = 0;
 
-    void add(int target, uint64_t tags, uint16_t cond) {
+    void add(int target, uint64_t tags, uint32_t cond) {
         // a later path to the same target whose condition set includes an earlier one's can never win
         for (const auto& p : out)
             if (p.target == target && (p.cond & ~cond) == 0) return;
         if (out.size() >= 4096) throw RegexError("unsupported: too many epsilon paths");
         out.push_back({target, tags, cond});
     }
-    void walk(int pc, uint64_t tags, uint16_t cond, int depth) {
+    void walk(int pc, uint64_t tags, uint32_t cond, int depth) {
         if (++steps > 2000000 || depth > 100000) throw RegexError("unsupported: epsilon closure too large");
         for (;;) {
             const Inst& in = code[pc];
@@ -177,7 +171,7 @@ private:
                 case Inst::Match: add(kMatchTarget, tags, cond); return;
                 case Inst::Jump: pc = in.x; break;
                 case Inst::Save: tags |= uint64_t(1) << in.x; ++pc; break;
-                case Inst::Assert: cond |= uint16_t(1u << in.x); ++pc; break;
+                case Inst::Assert: cond |= 1u << in.x; ++pc; break;
                 case Inst::Split:
                     walk(in.x, tags, cond, depth + 1);
                     pc = in.y;
@@ -200,6 +194,9 @@ FollowNfa buildFollowNfa(const ParsedRegex& re) {
     nfa.groupCount = re.groupCount;
     nfa.groupNames = re.groupNames;
     nfa.positions = b.positions;
+    nfa.asserts = b.asserts;
+    for (size_t i = 0; i < b.asserts.size(); ++i)
+        if (b.asserts[i].behind) nfa.behindMask |= 1u << i;
     const int npos = int(b.positions.size());
     nfa.follow.resize(npos + 1);
     PathWalker walker(b.code);

@@ -3,7 +3,8 @@
 // This is the merged-NFA form the north-star names: every *position* is one byte-consuming step of the regex;
 // follow[p] lists, in leftmost-first (Perl/boost backtracking) priority order, every position reachable after
 // consuming p, together with the capture slots written on the way (tag set) and the zero-width assertions that
-// must hold (cond set).  Both device engines are driven by it:
+// must hold (cond set: bit i = asserts[i], each a one-byte look behind or ahead).  Both device engines are driven
+// by it:
 //   * the NFA kernel keeps one wavefront lane per live thread and walks these lists directly;
 //   * the TDFA builder determinises it (tdfa.hpp).
 // Semantics restated: boost::regex_match leftmost-first backtracking == "highest-priority thread that is in
@@ -18,39 +19,15 @@
 
 namespace lcregex {
 
-constexpr int kMaxGpuGroups = 32;  // capture slots are carried in a 64-bit tag mask
+constexpr int kMaxGpuGroups = 32;   // capture slots are carried in a 64-bit tag mask
+constexpr int kMaxAsserts = 32;     // distinct one-byte look assertions per pattern (cond mask is 32 bits)
 constexpr int kMatchTarget = -1;
-
-// which facts about the neighbouring bytes an assertion set needs
-enum PrevCtxBits : uint8_t { kPrevAtStart = 1, kPrevWord = 2, kPrevSep = 4, kPrevCR = 8 };
-
-struct ByteProps {  // facts about one byte (or about END / START)
-    bool boundary = false;  // true for START (as prev) or END (as next)
-    bool word = false, sep = false, cr = false, lf = false;
-    static ByteProps of(unsigned c) {
-        ByteProps p;
-        p.word = isWordByte(c);
-        p.sep = isLineSeparator(c);
-        p.cr = c == '\r';
-        p.lf = c == '\n';
-        return p;
-    }
-    static ByteProps edge() {
-        ByteProps p;
-        p.boundary = true;
-        return p;
-    }
-};
-
-// true iff every assertion in `cond` (bit i = AssertKind i) holds between prev and next
-bool condHolds(uint16_t cond, const ByteProps& prev, const ByteProps& next);
-// PrevCtxBits an assertion set can observe
-uint8_t condPrevNeeds(uint16_t cond);
+constexpr int kEdge = -1;           // "byte" value standing for START (behind) / END (ahead)
 
 struct FollowPath {
     int target;       // position index, or kMatchTarget
     uint64_t tags;    // bit s: capture slot s is written at the current offset
-    uint16_t cond;    // bit k: AssertKind k must hold at the current offset
+    uint32_t cond;    // bit i: asserts[i] must hold at the current offset
 };
 
 struct FollowNfa {
@@ -58,13 +35,21 @@ struct FollowNfa {
     std::vector<std::string> groupNames;
     std::vector<ByteSet> positions;               // byte set consumed by each position
     std::vector<std::vector<FollowPath>> follow;  // follow[p]; follow[positions.size()] = start paths
-    uint16_t condsUsed = 0;
+    std::vector<LookAssert> asserts;              // the distinct look primitives cond bits refer to
+    uint32_t condsUsed = 0;                       // union of all path conds
+    uint32_t behindMask = 0;                      // bits of asserts that look behind
     int slotCount() const { return 2 * groupCount; }
     int startIndex() const { return int(positions.size()); }
+
+    // which behind-assertions hold when the previous byte is `prev` (kEdge = start of input)
+    uint32_t behindBits(int prev) const;
+    // which ahead-assertions hold when the next byte is `next` (kEdge = end of input)
+    uint32_t aheadBits(int next) const;
+    bool condHolds(uint32_t cond, int prev, int next) const { return (cond & ~(behindBits(prev) | aheadBits(next))) == 0; }
 };
 
 // Throws RegexError for constructs the device engines cannot honour bit-exactly (nullable loop bodies,
-// more than kMaxGpuGroups groups, path explosion).
+// more than kMaxGpuGroups groups, more than kMaxAsserts look assertions, path explosion).
 FollowNfa buildFollowNfa(const ParsedRegex& re);
 
 }  // namespace lcregex

@@ -35,25 +35,6 @@ __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t lane,
     return incl - v;
 }
 
-// bitmask of AssertKind values that hold between `prev` and `next` (wave-uniform inputs; -1 = edge of the line)
-__device__ __forceinline__ uint32_t condsTrue(int prev, int next) {
-    auto word = [](int c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
-    auto sep = [](int c) { return c == '\n' || c == '\r' || c == '\f'; };
-    const bool atStart = prev < 0, atEnd = next < 0;
-    const bool crlf = prev == '\r' && next == '\n';
-    const bool pw = !atStart && word(prev), nw = !atEnd && word(next);
-    uint32_t m = 0;
-    if (atStart || (sep(prev) && !crlf)) m |= 1u << 0;  // BolMulti
-    if (atStart) m |= 1u << 1;                           // BolSingle
-    if (atEnd || (sep(next) && !crlf)) m |= 1u << 2;     // EolMulti
-    if (atEnd) m |= 1u << 3;                             // EolSingle
-    if (pw != nw) m |= 1u << 4;                          // WordBoundary
-    if (pw == nw) m |= 1u << 5;                          // NotWordBoundary
-    if (!pw && nw) m |= 1u << 6;                         // WordStart
-    if (pw && !nw) m |= 1u << 7;                         // WordEnd
-    return m;
-}
-
 template <int NS>
 __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __restrict__ data,
                                                               const uint32_t* __restrict__ off,
@@ -82,6 +63,9 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint8_t* classMap = smem + hdr[NF_OFF_CLASSMAP];
     const uint2* posMask = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_POSMASK]);
     const uint2* stable = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_STABLE]);
+    const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_BEHIND]);
+    const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_AHEAD]);
+    const uint32_t edgeClass = hdr[NF_NCLASSES];  // table index standing for start / end of input
     const uint32_t* followStart = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_FOLLOWSTART]);
     const uint4* paths = reinterpret_cast<const uint4*>(smem + hdr[NF_OFF_PATHS]);
 
@@ -114,7 +98,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
     const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
     uint32_t curWord = (lane < nWords) ? words[lane] : 0;
-    int prevByte = -1;
+    uint32_t prevCls = edgeClass;
 
     for (uint32_t i = 0; i < L && nThreads; ++i) {
         const uint32_t idx = head + i;
@@ -133,12 +117,12 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             const uint2 st = stable[myPos];
             const uint32_t bit = cls < 32 ? (st.x >> cls) & 1u : (st.y >> (cls - 32)) & 1u;
             if (__all(!liveLane || bit)) {
-                prevByte = b;
+                prevCls = cls;
                 continue;
             }
         }
-        const uint32_t ctrue = condsTrue(prevByte, b);
-        prevByte = b;
+        const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];  // look assertions that hold at this offset
+        prevCls = cls;
 
         const uint32_t fs = liveLane ? followStart[myPos] : 0;
         const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
@@ -212,7 +196,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     bool accept = false;
     uint64_t endTags = 0;
     if (!overflow && lane < nThreads) {
-        const uint32_t ctrue = condsTrue(prevByte, -1);
+        const uint32_t ctrue = behindBits[prevCls] | aheadBits[edgeClass];
         const uint32_t fs = followStart[myPos], fe = followStart[myPos + 1];
         for (uint32_t q = fs; q < fe; ++q) {
             const uint4 p = paths[q];

@@ -56,16 +56,16 @@ struct Syntax {
     bool namedOnly = false;  // unnamed (...) groups do not capture (Grok semantics: only named groups are emitted)
 };
 
-enum class AssertKind : uint8_t {
-    BolMulti,    // ^  with mod_m: start of buffer or after \n \r \f (never between \r\n)
-    BolSingle,   // ^  with (?-m), \A, \`
-    EolMulti,    // $  with mod_m
-    EolSingle,   // $  with (?-m), \z, \'
-    WordBoundary,
-    NotWordBoundary,
-    WordStart,   // \<
-    WordEnd,     // \>
-    kCount
+// A primitive zero-width assertion looks at ONE neighbouring byte:
+//   behind: holds iff  (at start of input ? edgeOk : previous byte in set)
+//   ahead : holds iff  (at end of input   ? edgeOk : next byte in set)
+// Everything else is composed from these by the parser:  ^ $ \A \z \b \B \< \> and the one-byte look-arounds
+// (?=[..]) (?![..]) (?<=[..]) (?<![..])  (a negative look-around is the complemented set with edgeOk = true).
+struct LookAssert {
+    bool behind = false;
+    bool edgeOk = false;
+    ByteSet set;
+    bool operator==(const LookAssert& o) const { return behind == o.behind && edgeOk == o.edgeOk && set == o.set; }
 };
 
 struct Node {
@@ -75,7 +75,7 @@ struct Node {
     int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
     bool greedy = true;                        // Repeat
     int capture = 0;                           // Group: 1-based capture index, 0 = non-capturing
-    AssertKind assertKind = AssertKind::BolMulti;
+    LookAssert look;                           // Assert
 };
 
 struct ParsedRegex {

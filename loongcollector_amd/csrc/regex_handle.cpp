@@ -108,12 +108,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     for (unsigned b = 0; b < 256; ++b) {
         std::vector<bool> sig;
         for (int p = 0; p < npos; ++p) sig.push_back(nfa.positions[size_t(p)].has(b));
-        if (nfa.condsUsed) {
-            sig.push_back(isWordByte(b));
-            sig.push_back(isLineSeparator(b));
-            sig.push_back(b == '\r');
-            sig.push_back(b == '\n');
-        }
+        for (const auto& a : nfa.asserts) sig.push_back(a.set.has(b));
         auto it = sig2cls.find(sig);
         if (it == sig2cls.end()) {
             it = sig2cls.emplace(sig, int(rep.size())).first;
@@ -173,6 +168,17 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_OFF_FOLLOWSTART] = w.put(followStart);
     hdr[NF_OFF_PATHS] = w.put(paths);
     hdr[NF_OFF_STABLE] = w.put(stableMask);
+    // look assertions per byte class: behind[c] / ahead[c] = cond bits that hold when the previous / next byte has
+    // class c; entry nClasses = START / END
+    std::vector<uint32_t> behind(rep.size() + 1), ahead(rep.size() + 1);
+    for (size_t c = 0; c < rep.size(); ++c) {
+        behind[c] = nfa.behindBits(int(rep[c]));
+        ahead[c] = nfa.aheadBits(int(rep[c]));
+    }
+    behind[rep.size()] = nfa.behindBits(kEdge);
+    ahead[rep.size()] = nfa.aheadBits(kEdge);
+    hdr[NF_OFF_BEHIND] = w.put(behind);
+    hdr[NF_OFF_AHEAD] = w.put(ahead);
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(NF_TOTAL_BYTES);
 }

@@ -145,10 +145,66 @@ private:
         return n;
     }
 
-    NodePtr assertion(AssertKind k) {
+    // ---- zero-width assertions, all built from one-byte look primitives (regex_ast.hpp LookAssert)
+    static NodePtr look(bool behind, const ByteSet& set, bool edgeOk) {
         auto n = mk(Node::Assert);
-        n->assertKind = k;
+        n->look.behind = behind;
+        n->look.set = set;
+        n->look.edgeOk = edgeOk;
         return n;
+    }
+    static NodePtr both(NodePtr a, NodePtr b) {
+        auto n = mk(Node::Cat);
+        n->kids.push_back(std::move(a));
+        n->kids.push_back(std::move(b));
+        return n;
+    }
+    static NodePtr either(NodePtr a, NodePtr b) {
+        auto n = mk(Node::Alt);
+        n->kids.push_back(std::move(a));
+        n->kids.push_back(std::move(b));
+        auto g = mk(Node::Group);
+        g->kids.push_back(std::move(n));
+        return g;
+    }
+    static ByteSet setOf(std::initializer_list<unsigned> bytes) {
+        ByteSet s;
+        for (unsigned c : bytes) s.add(c);
+        return s;
+    }
+    static ByteSet complement(ByteSet s) {
+        s.invert();
+        return s;
+    }
+    static ByteSet wordSet() {
+        ByteSet w;
+        shorthand('w', w);
+        return w;
+    }
+    enum class Anchor { BolMulti, BolSingle, EolMulti, EolSingle, WordBoundary, NotWordBoundary, WordStart, WordEnd };
+    // Boost semantics: with mod_m, ^ matches at start of input or after \n \r \f, $ at end of input or before them,
+    // neither between \r and \n (perl_matcher::match_start_line / match_end_line).
+    static NodePtr assertion(Anchor k) {
+        const ByteSet none, w = wordSet(), nw = complement(w);
+        switch (k) {
+            case Anchor::BolSingle: return look(true, none, true);
+            case Anchor::EolSingle: return look(false, none, true);
+            case Anchor::BolMulti:
+                return either(look(true, setOf({'\n', '\f'}), true),
+                              both(look(true, setOf({'\r'}), false), look(false, complement(setOf({'\n'})), true)));
+            case Anchor::EolMulti:
+                return either(look(false, setOf({'\r', '\f'}), true),
+                              both(look(false, setOf({'\n'}), false), look(true, complement(setOf({'\r'})), true)));
+            case Anchor::WordBoundary:
+                return either(both(look(true, w, false), look(false, nw, true)),
+                              both(look(true, nw, true), look(false, w, false)));
+            case Anchor::NotWordBoundary:
+                return either(both(look(true, w, false), look(false, w, false)),
+                              both(look(true, nw, true), look(false, nw, true)));
+            case Anchor::WordStart: return both(look(true, nw, true), look(false, w, false));
+            case Anchor::WordEnd: return both(look(true, w, false), look(false, nw, true));
+        }
+        return mk(Node::Empty);
     }
 
     // single-byte escapes shared by atoms and classes; mPos is just past the escape letter.  -1: not one.
@@ -304,6 +360,22 @@ private:
         return n;
     }
 
+    // (?=X) (?!X) (?<=X) (?<!X) with X a single character class: a one-byte look-around.  mPos is just past the
+    // introducer.  Longer bodies would need multi-byte look-ahead/behind, which the automata do not have.
+    NodePtr lookAround(int depth, bool behind, bool negative) {
+        const Syntax saved = mSyn;
+        NodePtr body = alternation(depth + 1);
+        if (atEnd() || peek() != ')') bail("missing )");
+        ++mPos;
+        mSyn = saved;
+        const Node* n = body.get();
+        while ((n->kind == Node::Group && n->capture == 0) && n->kids.size() == 1) n = n->kids[0].get();
+        if (n->kind != Node::Set) bail("unsupported: look-around body must be a single character class");
+        ByteSet set = n->set;
+        if (negative) set.invert();
+        return look(behind, set, negative);
+    }
+
     NodePtr group(int depth) {  // mPos just past '('
         Syntax saved = mSyn;
         int capture = 0;
@@ -322,9 +394,11 @@ private:
             if (d == ':') {
                 ++mPos;
                 capturing = false;
-            } else if (d == '=' || d == '!' || d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' ||
-                       (d >= '0' && d <= '9')) {
-                bail("unsupported group construct (look-around/atomic/recursion/conditional)");
+            } else if (d == '=' || d == '!') {
+                ++mPos;
+                return lookAround(depth, false, d == '!');
+            } else if (d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' || (d >= '0' && d <= '9')) {
+                bail("unsupported group construct (atomic/recursion/conditional)");
             } else if (d == '<' || d == 'P' || d == '\'') {
                 char close = '>';
                 if (d == 'P') {
@@ -333,7 +407,9 @@ private:
                 } else if (d == '\'') {
                     close = '\'';
                 } else if (has(1) && (peek(1) == '=' || peek(1) == '!')) {
-                    bail("unsupported group construct (look-behind)");
+                    const bool negative = peek(1) == '!';
+                    mPos += 2;
+                    return lookAround(depth, true, negative);
                 }
                 ++mPos;
                 size_t j = mPos;
@@ -410,14 +486,14 @@ private:
             }
         }
         switch (e) {
-            case 'b': return assertion(AssertKind::WordBoundary);
-            case 'B': return assertion(AssertKind::NotWordBoundary);
-            case '<': return assertion(AssertKind::WordStart);
-            case '>': return assertion(AssertKind::WordEnd);
+            case 'b': return assertion(Anchor::WordBoundary);
+            case 'B': return assertion(Anchor::NotWordBoundary);
+            case '<': return assertion(Anchor::WordStart);
+            case '>': return assertion(Anchor::WordEnd);
             case 'A':
-            case '`': return assertion(AssertKind::BolSingle);
+            case '`': return assertion(Anchor::BolSingle);
             case 'z':
-            case '\'': return assertion(AssertKind::EolSingle);
+            case '\'': return assertion(Anchor::EolSingle);
             case 'Z': bail("\\Z (multi-byte look-ahead) unsupported");
             case 'Q': {
                 auto seq = mk(Node::Cat);
@@ -460,16 +536,17 @@ private:
             case '^':
                 ++mPos;
                 isAssertion = true;
-                return assertion(mSyn.multiLine ? AssertKind::BolMulti : AssertKind::BolSingle);
+                return assertion(mSyn.multiLine ? Anchor::BolMulti : Anchor::BolSingle);
             case '$':
                 ++mPos;
                 isAssertion = true;
-                return assertion(mSyn.multiLine ? AssertKind::EolMulti : AssertKind::EolSingle);
+                return assertion(mSyn.multiLine ? Anchor::EolMulti : Anchor::EolSingle);
             case '*': case '+': case '?': bail("nothing to repeat");
             case '\\': {
                 ++mPos;
+                const unsigned e = has(0) ? peek() : 0;
                 NodePtr n = escapeAtom();
-                isAssertion = n->kind == Node::Assert;
+                isAssertion = std::strchr("bB<>AzZ`'", int(e)) != nullptr && e != 0;
                 return n;
             }
             default: ++mPos; return literal(c);

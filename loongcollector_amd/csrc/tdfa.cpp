@@ -20,13 +20,13 @@ struct Item {
 };
 struct State {
     std::vector<Item> items;
-    uint8_t prevCtx = 0;
+    uint32_t prevCtx = 0;  // behind-assertions that hold at this state's offset (masked to the ones still observable)
     int nregs = 0;
 };
 
 std::string keyOf(const State& s) {
     std::string k;
-    k.push_back(char(s.prevCtx));
+    k.append(reinterpret_cast<const char*>(&s.prevCtx), sizeof s.prevCtx);
     for (const auto& it : s.items) {
         k.append(reinterpret_cast<const char*>(&it.pos), sizeof(int));
         for (int r : it.regs) {
@@ -35,15 +35,6 @@ std::string keyOf(const State& s) {
         }
     }
     return k;
-}
-
-ByteProps propsOfCtx(uint8_t ctx) {
-    ByteProps p;
-    p.boundary = ctx & kPrevAtStart;
-    p.word = ctx & kPrevWord;
-    p.sep = ctx & kPrevSep;
-    p.cr = ctx & kPrevCR;
-    return p;
 }
 
 // order a set of injective register moves (dst <- src) so that no source is clobbered before it is read
@@ -95,12 +86,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             std::vector<bool> sig;
             sig.reserve(size_t(npos) + 4);
             for (int p = 0; p < npos; ++p) sig.push_back(nfa.positions[p].has(b));
-            if (nfa.condsUsed) {
-                sig.push_back(isWordByte(b));
-                sig.push_back(isLineSeparator(b));
-                sig.push_back(b == '\r');
-                sig.push_back(b == '\n');
-            }
+            for (const auto& a : nfa.asserts) sig.push_back(a.set.has(b));
             auto it = sig2cls.find(sig);
             if (it == sig2cls.end()) {
                 it = sig2cls.emplace(sig, int(classRep.size())).first;
@@ -113,9 +99,9 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     T.nClasses = uint32_t(ncls);
 
     // which prev-byte facts each position's continuation can observe
-    std::vector<uint8_t> need(size_t(npos) + 1, 0);
+    std::vector<uint32_t> need(size_t(npos) + 1, 0);
     for (int p = 0; p <= npos; ++p)
-        for (const auto& path : nfa.follow[p]) need[p] |= condPrevNeeds(path.cond);
+        for (const auto& path : nfa.follow[p]) need[p] |= path.cond & nfa.behindMask;
 
     std::vector<State> states;
     std::unordered_map<std::string, uint32_t> index;
@@ -139,7 +125,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
         it.pos = nfa.startIndex();
         it.regs.assign(size_t(nslots), -1);
         s0.items.push_back(std::move(it));
-        s0.prevCtx = uint8_t(kPrevAtStart & need[nfa.startIndex()]);
+        s0.prevCtx = nfa.behindBits(kEdge) & need[nfa.startIndex()];
         T.startState = intern(std::move(s0));
     }
 
@@ -164,15 +150,14 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
         for (int c = 0; c < ncls; ++c) {
             const State& S = states[sid];  // re-fetched each class: intern() may reallocate `states`
             const unsigned b = classRep[c];
-            const ByteProps nextP = ByteProps::of(b);
-            const ByteProps prevP = propsOfCtx(S.prevCtx);
+            const uint32_t holds = S.prevCtx | nfa.aheadBits(int(b));
             std::vector<NewItem> ni;
             seen.assign(size_t(npos), 0);
             for (size_t k = 0; k < S.items.size(); ++k) {
                 for (const auto& path : nfa.follow[S.items[k].pos]) {
                     if (path.target < 0 || seen[path.target]) continue;
                     if (!nfa.positions[path.target].has(b)) continue;
-                    if (path.cond && !condHolds(path.cond, prevP, nextP)) continue;
+                    if (path.cond & ~holds) continue;
                     seen[path.target] = 1;
                     ni.push_back({path.target, int(k), path.tags});
                 }
@@ -180,7 +165,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             if (ni.empty()) continue;  // -> dead
             State Tn;
             std::map<int, int> rename;
-            uint8_t needMask = 0;
+            uint32_t needMask = 0;
             for (const auto& n : ni) {
                 Item it;
                 it.pos = n.pos;
@@ -201,11 +186,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             Tn.nregs = int(rename.size());
             if (Tn.nregs > kMaxTdfaRegs) throw RegexError("tdfa: register limit exceeded");
             maxRegs = std::max(maxRegs, Tn.nregs);
-            uint8_t ctx = 0;
-            if (nextP.word) ctx |= kPrevWord;
-            if (nextP.sep) ctx |= kPrevSep;
-            if (nextP.cr) ctx |= kPrevCR;
-            Tn.prevCtx = uint8_t(ctx & needMask);
+            Tn.prevCtx = nfa.behindBits(int(b)) & needMask;
 
             std::vector<std::pair<int, int>> regMoves;
             std::vector<int> posDsts;
@@ -262,13 +243,12 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     std::map<std::vector<uint8_t>, uint16_t> finIds;
     for (uint32_t s = 1; s < T.nStates; ++s) {
         const State& S = states[s];
-        const ByteProps prevP = propsOfCtx(S.prevCtx);
-        const ByteProps endP = ByteProps::edge();
+        const uint32_t holds = S.prevCtx | nfa.aheadBits(kEdge);
         bool done = false;
         for (size_t k = 0; k < S.items.size() && !done; ++k) {
             for (const auto& path : nfa.follow[size_t(S.items[k].pos)]) {
                 if (path.target != kMatchTarget) continue;
-                if (path.cond && !condHolds(path.cond, prevP, endP)) continue;
+                if (path.cond & ~holds) continue;
                 std::vector<uint8_t> fm(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
                 for (int sl = 0; sl < nslots; ++sl) {
                     if ((path.tags >> sl) & 1) fm[size_t(sl)] = kRegPos;

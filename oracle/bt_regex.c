@@ -74,7 +74,8 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
-    A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END
+    A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
+    A_LOOK /* one-byte look-around: node.set = class, node.min = behind, node.max = negative */
 };
 typedef struct {
     int kind;
@@ -271,6 +272,24 @@ static int assert_node(orx_prog* P, int kind) {
     return n;
 }
 
+/* (?=X) (?!X) (?<=X) (?<!X) with X a single character class (one-byte look-around); P->i is past the introducer */
+static int parse_lookaround(orx_prog* P, int depth, int behind, int negative) {
+    unsigned saved = P->flags;
+    int inner = parse_alt(P, depth + 1);
+    if (P->failed) return -1;
+    if (P->i >= P->n || P->p[P->i] != ')') { fail(P, "missing )"); return -1; }
+    ++P->i;
+    P->flags = saved;
+    while (P->nodes[inner].kind == N_GROUP && P->nodes[inner].cap == 0) inner = P->nodes[inner].l;
+    if (P->nodes[inner].kind != N_SET) { fail(P, "unsupported: look-around body must be a single character class"); return -1; }
+    int n = new_node(P, N_ASSERT);
+    P->nodes[n].akind = A_LOOK;
+    P->nodes[n].set = P->nodes[inner].set;
+    P->nodes[n].min = behind;
+    P->nodes[n].max = negative;
+    return n;
+}
+
 /* returns node index, -1 for "no atom" (caller decides), sets *is_assert */
 static int parse_atom(orx_prog* P, int depth, int* is_assert) {
     *is_assert = 0;
@@ -291,9 +310,12 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                     return new_node(P, N_EMPTY);
                 } else if (d == ':') {
                     ++P->i;
-                } else if (d == '=' || d == '!' || d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' ||
+                } else if (d == '=' || d == '!') {
+                    ++P->i;
+                    return parse_lookaround(P, depth, 0, d == '!');
+                } else if (d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' ||
                            (d >= '0' && d <= '9') || d == '+') {
-                    fail(P, "unsupported group construct (look-around/atomic/recursion/conditional)");
+                    fail(P, "unsupported group construct (atomic/recursion/conditional)");
                     return -1;
                 } else if (d == '<' || d == 'P' || d == '\'') {
                     int close = '>';
@@ -302,8 +324,9 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                         if (P->i >= P->n || P->p[P->i] != '<') { fail(P, "unsupported (?P construct"); return -1; }
                     } else if (d == '\'') close = '\'';
                     else if (P->i + 1 < P->n && (P->p[P->i + 1] == '=' || P->p[P->i + 1] == '!')) {
-                        fail(P, "unsupported group construct (look-behind)");
-                        return -1;
+                        int negative = P->p[P->i + 1] == '!';
+                        P->i += 2;
+                        return parse_lookaround(P, depth, 1, negative);
                     }
                     ++P->i;
                     size_t j = P->i;
@@ -528,7 +551,11 @@ static void gen(orx_prog* P, int n) {
             gen(P, nd.l);
             if (nd.cap) emit(P, I_SAVE, 2 * nd.cap + 1, 0);
             break;
-        case N_ASSERT: emit(P, I_ASSERT, nd.akind, 0); break;
+        case N_ASSERT: {
+            int k = emit(P, I_ASSERT, nd.akind, nd.set);
+            P->code[k].z = nd.min; P->code[k].w = nd.max;
+            break;
+        }
         case N_REP: {
             if (P->nodes[nd.l].kind == N_SET) { /* perl_matcher::match_set_repeat style fast path */
                 int k = emit(P, I_REPSET, P->nodes[nd.l].set, nd.min);
@@ -679,7 +706,15 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
             case I_SAVE: push(st, F_UNDO_CAP, in->x, caps[in->x], 0); caps[in->x] = (int32_t)pos; ++pc; continue;
             case I_MARK: push(st, F_UNDO_LOOP, in->x, loopregs[in->x], 0); loopregs[in->x] = pos; ++pc; continue;
             case I_CHK: if (loopregs[in->x] == pos) pc = in->y; else ++pc; continue;
-            case I_ASSERT: if (check_assert(in->x, s, n, pos)) { ++pc; continue; } goto backtrack;
+            case I_ASSERT:
+                if (in->x == A_LOOK) {
+                    int hit = in->z ? (pos > 0 && cs_has(&P->sets[in->y], s[pos - 1]))
+                                    : (pos < n && cs_has(&P->sets[in->y], s[pos]));
+                    if (hit != in->w) { ++pc; continue; }   /* positive: hit, negative: !hit */
+                    goto backtrack;
+                }
+                if (check_assert(in->x, s, n, pos)) { ++pc; continue; }
+                goto backtrack;
             case I_MATCH:
                 if (full && pos != n) goto backtrack;
                 return 1;

@@ -147,6 +147,12 @@ CURATED = [
     (rb'(.+?)=(.+)', [b'a=b=c', b'a=b']),
     (rb'(\d+)(?:ms|s|us) (\w+)', [b'12ms ok', b'3s fail', b'3m fail']),
     (rb'level=(\w+) msg="([^"]*)"(?: err="([^"]*)")?', [b'level=info msg="hi"', b'level=e msg="x" err="boom"']),
+    # one-byte look-arounds, as the Grok default patterns use them (plugins/processor/grok/processor_grok_default_patterns.go:25-36)
+    (rb'(?<![0-9])((?:[0-1]?[0-9]{1,2}|2[0-4][0-9]|25[0-5])[.](?:[0-1]?[0-9]{1,2}|2[0-4][0-9]|25[0-5]))(?![0-9])',
+     [b'10.2', b'10.255', b'10.256', b'1.1', b'256.1']),
+    (rb'(.*?)(?<![0-9.+-])([+-]?[0-9]+)(?![0-9])(.*)', [b'a 12 b', b'a+12b', b'x1.5', b'12']),
+    (rb'(\w+)(?=,)(.*)', [b'ab,cd', b'ab', b'ab,']),
+    (rb'(?<=\[)([^\]]*)\]|x(.*)', [b'a]', b'x[a]']),
 ]
 
 # ----------------------------------------------------------------------------- random pattern generator
@@ -179,13 +185,14 @@ class Gen:
                 return '(' + inner + ')', nullable, smp
             return '(?:' + inner + ')', nullable, smp
         if r < 0.80:
-            return self.rng.choice(['^', '$', r'\b']), True, (lambda: b'')
+            return self.rng.choice(['^', '$', r'\b', r'\B', '(?=[ab])', '(?![ab])', '(?<=[a ])', '(?<![a ])', r'(?!\d)',
+                                    r'(?<=\w)']), True, (lambda: b'')
         c = self.rng.choice(['a', 'b', 'c', ' '])
         return c, False, (lambda c=c: c.encode())
 
     def piece(self, depth):
         a, nullable, smp = self.atom(depth)
-        if a in ('^', '$', r'\b'):
+        if nullable and not a.startswith('(') or a.startswith('(?=') or a.startswith('(?!') or a.startswith('(?<'):
             return a, True, smp
         r = self.rng.random()
         if r < 0.45:

@@ -48,32 +48,6 @@ class TdfaInterp:
         return out
 
 
-def _props(b):
-    word = (48 <= b <= 57) or (65 <= b <= 90) or (97 <= b <= 122) or b == 95
-    return dict(boundary=False, word=word, sep=b in (10, 13, 12), cr=b == 13, lf=b == 10)
-
-
-_EDGE = dict(boundary=True, word=False, sep=False, cr=False, lf=False)
-
-
-def _cond_holds(cond, prev, nxt):
-    at_start, at_end = prev["boundary"], nxt["boundary"]
-    crlf = (not at_start) and (not at_end) and prev["cr"] and nxt["lf"]
-    pw = (not at_start) and prev["word"]
-    nw = (not at_end) and nxt["word"]
-    checks = [
-        at_start or (prev["sep"] and not crlf),   # BolMulti
-        at_start,                                  # BolSingle
-        at_end or (nxt["sep"] and not crlf),       # EolMulti
-        at_end,                                    # EolSingle
-        pw != nw,                                  # WordBoundary
-        pw == nw,                                  # NotWordBoundary
-        (not pw) and nw,                           # WordStart
-        pw and not nw,                             # WordEnd
-    ]
-    return all(ok for k, ok in enumerate(checks) if (cond >> k) & 1)
-
-
 class NfaInterp:
     """Ordered-thread-list simulation of the packed NFA blob (what the wave-per-line kernel does)."""
 
@@ -87,6 +61,9 @@ class NfaInterp:
         self.posmask = [int(pm[2 * p]) | (int(pm[2 * p + 1]) << 32) for p in range(self.npos)]
         fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
         paths = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 4 * int(blob[9])].reshape(-1, 4)
+        ncl = self.ncls
+        self.behind = [int(x) for x in blob[int(blob[12]) // 4:int(blob[12]) // 4 + ncl + 1]]   # NF_OFF_BEHIND
+        self.ahead = [int(x) for x in blob[int(blob[13]) // 4:int(blob[13]) // 4 + ncl + 1]]    # NF_OFF_AHEAD
         self.follow = []
         for p in range(self.npos + 1):
             lst = []
@@ -97,16 +74,16 @@ class NfaInterp:
 
     def fullmatch(self, s: bytes, max_threads=64):
         threads = [(self.npos, [-1] * self.nslots)]  # (position, caps)
-        prev = _EDGE
+        prev_cls = self.ncls                     # edge entry: start of input
         for pos, b in enumerate(s):
-            nxt = _props(b)
             cls = int(self.cmap[b])
+            holds = self.behind[prev_cls] | self.ahead[cls]
             new, seen = [], set()
             for p, caps in threads:
                 for tgt, cond, tags in self.follow[p]:
                     if tgt < 0 or tgt in seen or not (self.posmask[tgt] >> cls) & 1:
                         continue
-                    if cond and not _cond_holds(cond, prev, nxt):
+                    if cond & ~holds:
                         continue
                     seen.add(tgt)
                     c2 = list(caps)
@@ -117,12 +94,13 @@ class NfaInterp:
             if len(new) > max_threads:
                 return "overflow"
             threads = new
-            prev = nxt
+            prev_cls = cls
             if not threads:
                 return None
+        holds = self.behind[prev_cls] | self.ahead[self.ncls]
         for p, caps in threads:
             for tgt, cond, tags in self.follow[p]:
-                if tgt >= 0 or (cond and not _cond_holds(cond, prev, _EDGE)):
+                if tgt >= 0 or (cond & ~holds):
                     continue
                 c2 = list(caps)
                 for sl in range(self.nslots):

@@ -60,7 +60,7 @@ def test_golden_vectors_through_the_c_abi(torch_dev, golden_dir):
         rx = B.GpuRegex(c["p"].encode("latin-1"))
         subs = [s.encode("latin-1") for s, _ in c["subs"]]
         data, off, length = pack(subs)
-        engines = [B.LC_ENGINE_NFA]  # every golden pattern has an NFA program
+        engines = [B.LC_ENGINE_NFA] if rx.has_nfa_program() else []
         if rx.info()["engine"] == B.LC_ENGINE_TDFA:
             engines.append(B.LC_ENGINE_TDFA)
         for eng in engines:
@@ -196,7 +196,8 @@ def test_search_mode_golden_vectors_on_both_kernels(torch_dev, golden_dir):
         rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_SEARCH)
         subs = [s.encode("latin-1") for s, _ in c["subs"]]
         data, off, length = pack(subs)
-        engines = [B.LC_ENGINE_NFA] + ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        engines = ([B.LC_ENGINE_NFA] if rx.has_nfa_program() else []) + (
+            [B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
         for eng in engines:
             caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
             for i, (_, flat) in enumerate(c["subs"]):
