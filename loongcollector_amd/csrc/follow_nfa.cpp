@@ -21,7 +21,7 @@ uint32_t FollowNfa::aheadBits(int next) const {
 namespace {
 
 struct Inst {
-    enum Op : uint8_t { Char, Split, Jump, Save, Assert, Match } op;
+    enum Op : uint8_t { Char, Split, Jump, Save, Assert, AtomEnter, AtomExit, Match } op;
     int x = 0, y = 0;  // Char: position index | Split: preferred, other | Jump: target | Save: slot | Assert: kind
 };
 
@@ -39,7 +39,8 @@ bool nullable(const Node& n) {
                 if (nullable(*k)) return true;
             return false;
         case Node::Repeat: return n.min == 0 || nullable(*n.kids[0]);
-        case Node::Group: return nullable(*n.kids[0]);
+        case Node::Group:
+        case Node::Atomic: return nullable(*n.kids[0]);
     }
     return true;
 }
@@ -49,6 +50,7 @@ public:
     std::vector<Inst> code;
     std::vector<ByteSet> positions;
     std::vector<LookAssert> asserts;
+    int atomicCount = 0;
 
     int assertIndex(const LookAssert& a) {
         for (size_t i = 0; i < asserts.size(); ++i)
@@ -96,6 +98,14 @@ public:
                 if (n.capture) emit(Inst::Save, 2 * (n.capture - 1) + 1);
                 break;
             case Node::Assert: emit(Inst::Assert, assertIndex(n.look)); break;
+            case Node::Atomic: {
+                if (atomicCount >= 16000) throw RegexError("unsupported: too many atomic group instances");
+                const int g = atomicCount++;  // every expansion copy is its own instance
+                emit(Inst::AtomEnter, g);
+                gen(*n.kids[0]);
+                emit(Inst::AtomExit, g);
+                break;
+            }
             case Node::Repeat: genRepeat(n); break;
         }
     }
@@ -142,38 +152,50 @@ public:
 
 class PathWalker {
 public:
-    PathWalker(const std::vector<Inst>& c) : code(c) {}
+    PathWalker(const std::vector<Inst>& c, bool events) : code(c), recordEvents(events) {}
     std::vector<FollowPath> from(int pc) {
         out.clear();
         steps = 0;
-        walk(pc, 0, 0, 0);
+        std::vector<FollowPath::Event> atoms;
+        exitVisits = 0;
+        walk(pc, 0, 0, atoms, 0);
         return out;
     }
 
 private:
     const std::vector<Inst>& code;
+    bool recordEvents;
     std::vector<FollowPath> out;
     size_t steps = 0;
+    int exitVisits = 0;
 
-    void add(int target, uint64_t tags, uint32_t cond) {
-        // a later path to the same target whose condition set includes an earlier one's can never win
+    void add(int target, uint64_t tags, uint32_t cond, const std::vector<FollowPath::Event>& atoms) {
+        // a later path to the same target (same atomic history) whose condition set includes an earlier one's can
+        // never win
         for (const auto& p : out)
-            if (p.target == target && (p.cond & ~cond) == 0) return;
+            if (p.target == target && (p.cond & ~cond) == 0 && p.atoms == atoms) return;
         if (out.size() >= 4096) throw RegexError("unsupported: too many epsilon paths");
-        out.push_back({target, tags, cond});
+        out.push_back({target, tags, cond, atoms});
     }
-    void walk(int pc, uint64_t tags, uint32_t cond, int depth) {
+    void walk(int pc, uint64_t tags, uint32_t cond, std::vector<FollowPath::Event>& atoms, int depth) {
         if (++steps > 2000000 || depth > 100000) throw RegexError("unsupported: epsilon closure too large");
+        const size_t mark = atoms.size();
         for (;;) {
             const Inst& in = code[pc];
             switch (in.op) {
-                case Inst::Char: add(in.x, tags, cond); return;
-                case Inst::Match: add(kMatchTarget, tags, cond); return;
+                case Inst::Char: add(in.x, tags, cond, atoms); atoms.resize(mark); return;
+                case Inst::Match: add(kMatchTarget, tags, cond, atoms); atoms.resize(mark); return;
                 case Inst::Jump: pc = in.x; break;
                 case Inst::Save: tags |= uint64_t(1) << in.x; ++pc; break;
-                case Inst::Assert: cond |= 1u << in.x; ++pc; break;
+                case Inst::Assert:
+                    cond |= 1u << in.x;
+                    if (recordEvents) atoms.push_back({kAssertEvent + in.x, 0});
+                    ++pc;
+                    break;
+                case Inst::AtomEnter: atoms.push_back({in.x + 1, 0}); ++pc; break;
+                case Inst::AtomExit: atoms.push_back({-(in.x + 1), ++exitVisits}); ++pc; break;
                 case Inst::Split:
-                    walk(in.x, tags, cond, depth + 1);
+                    walk(in.x, tags, cond, atoms, depth + 1);
                     pc = in.y;
                     break;
             }
@@ -195,11 +217,12 @@ FollowNfa buildFollowNfa(const ParsedRegex& re) {
     nfa.groupNames = re.groupNames;
     nfa.positions = b.positions;
     nfa.asserts = b.asserts;
+    nfa.atomicCount = b.atomicCount;
     for (size_t i = 0; i < b.asserts.size(); ++i)
         if (b.asserts[i].behind) nfa.behindMask |= 1u << i;
     const int npos = int(b.positions.size());
     nfa.follow.resize(npos + 1);
-    PathWalker walker(b.code);
+    PathWalker walker(b.code, b.atomicCount > 0);
     for (int pc = 0; pc < int(b.code.size()); ++pc)
         if (b.code[pc].op == Inst::Char) nfa.follow[b.code[pc].x] = walker.from(pc + 1);
     nfa.follow[npos] = walker.from(0);

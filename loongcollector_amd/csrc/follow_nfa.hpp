@@ -22,12 +22,23 @@ namespace lcregex {
 constexpr int kMaxGpuGroups = 32;   // capture slots are carried in a 64-bit tag mask
 constexpr int kMaxAsserts = 32;     // distinct one-byte look assertions per pattern (cond mask is 32 bits)
 constexpr int kMatchTarget = -1;
+constexpr int kAssertEvent = 20000;
 constexpr int kEdge = -1;           // "byte" value standing for START (behind) / END (ahead)
 
 struct FollowPath {
     int target;       // position index, or kMatchTarget
     uint64_t tags;    // bit s: capture slot s is written at the current offset
     uint32_t cond;    // bit i: asserts[i] must hold at the current offset
+    // Only for patterns with atomic groups: what the epsilon path crosses, in order.  code +(g+1) = enter atomic
+    // group instance g, -(g+1) = leave it, kAssertEvent+i = assertion i is tested here (so that "which exits happened
+    // before an assertion failed" is known).  `visit` numbers the traversal of an exit: two paths of one follow list
+    // that share the same exit visit left the group through the very same body match and differ only afterwards.
+    struct Event {
+        int32_t code;
+        int32_t visit;
+        bool operator==(const Event& o) const { return code == o.code && visit == o.visit; }
+    };
+    std::vector<Event> atoms;
 };
 
 struct FollowNfa {
@@ -38,6 +49,7 @@ struct FollowNfa {
     std::vector<LookAssert> asserts;              // the distinct look primitives cond bits refer to
     uint32_t condsUsed = 0;                       // union of all path conds
     uint32_t behindMask = 0;                      // bits of asserts that look behind
+    int atomicCount = 0;                          // atomic group instances; > 0 means only the TDFA engine can run it
     int slotCount() const { return 2 * groupCount; }
     int startIndex() const { return int(positions.size()); }
 

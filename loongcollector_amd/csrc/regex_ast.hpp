@@ -69,8 +69,8 @@ struct LookAssert {
 };
 
 struct Node {
-    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert } kind = Empty;
-    std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group: 1
+    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic } kind = Empty;
+    std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group/Atomic: 1
     ByteSet set;                               // Set
     int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
     bool greedy = true;                        // Repeat

@@ -101,6 +101,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
 }
 
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut) {
+    if (nfa.atomicCount) throw RegexError("nfa: atomic groups / possessive quantifiers need the TDFA engine");
     const int npos = int(nfa.positions.size());
     classMapOut.assign(256, 0);
     std::map<std::vector<bool>, int> sig2cls;

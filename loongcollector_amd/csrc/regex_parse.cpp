@@ -397,8 +397,17 @@ private:
             } else if (d == '=' || d == '!') {
                 ++mPos;
                 return lookAround(depth, false, d == '!');
-            } else if (d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' || (d >= '0' && d <= '9')) {
-                bail("unsupported group construct (atomic/recursion/conditional)");
+            } else if (d == '>') {  // atomic group: the first way its body matches is final
+                ++mPos;
+                NodePtr inner = alternation(depth + 1);
+                if (atEnd() || peek() != ')') bail("missing )");
+                ++mPos;
+                mSyn = saved;
+                auto a = mk(Node::Atomic);
+                a->kids.push_back(std::move(inner));
+                return a;
+            } else if (d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' || (d >= '0' && d <= '9')) {
+                bail("unsupported group construct (recursion/conditional)");
             } else if (d == '<' || d == 'P' || d == '\'') {
                 char close = '>';
                 if (d == 'P') {
@@ -619,8 +628,11 @@ private:
                 if (!atEnd() && peek() == '?') {
                     greedy = false;
                     ++mPos;
-                } else if (!atEnd() && peek() == '+') {
-                    bail("possessive quantifiers unsupported");
+                }
+                bool possessive = false;
+                if (greedy && !atEnd() && peek() == '+') {  // X*+  ==  (?>X*)
+                    possessive = true;
+                    ++mPos;
                 }
                 auto r = mk(Node::Repeat);
                 r->min = lo;
@@ -628,6 +640,11 @@ private:
                 r->greedy = greedy;
                 r->kids.push_back(std::move(a));
                 a = std::move(r);
+                if (possessive) {
+                    auto at = mk(Node::Atomic);
+                    at->kids.push_back(std::move(a));
+                    a = std::move(at);
+                }
                 quantified = true;
             }
             seq->kids.push_back(std::move(a));

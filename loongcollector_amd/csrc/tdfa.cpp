@@ -14,10 +14,212 @@ namespace {
 constexpr uint8_t kRegTmp = 0xFD;  // placeholder, patched to the real scratch register at the end
 constexpr int kFreshBase = 1 << 20;
 
+// Atomic groups.  Every thread that entered atomic-group instance g through the same source thread at the same step
+// belongs to one SEGMENT; the first (highest-priority) member that leaves g commits the group for that entry: every
+// lower-priority member -- still inside g, or one that left earlier -- must die ("the first way the body matches is
+// final").  An item carries its unsettled memberships; one is dropped once no higher-priority member is still inside.
+struct LinEntry {
+    int g, seg;
+    bool exited;
+    bool operator==(const LinEntry& o) const { return g == o.g && seg == o.seg && exited == o.exited; }
+};
 struct Item {
     int pos;
-    std::vector<int> regs;  // per slot: register id, or -1
+    std::vector<int> regs;      // per slot: register id, or -1
+    std::vector<LinEntry> lin;  // unsettled atomic-segment memberships
 };
+struct Cand {
+    int pos, src;
+    uint64_t tags;
+    std::vector<LinEntry> lin;                        // lineage of the source item (updated by commitAtomic)
+    const std::vector<FollowPath::Event>* events;     // the path's events (nullptr: pattern has no atomic group)
+    bool targetOk;                                    // ends on a position that accepts the byte (or on MATCH at END)
+    uint32_t cond;
+};
+
+// Priority-ordered commit over ALL epsilon paths of a step, viable or not.
+//   * Leaving group g commits the group for that entry: the segment is CLOSED, by (source item, exit visit), for every
+//     lower-priority thread -- also when the leaving thread then finds no byte it can consume: the body HAS matched,
+//     which is all an atomic group asks.
+//   * A path that is a member of a closed segment is dead, unless it leaves the group through the very same exit visit
+//     of the same source item (then it IS the committed body match and merely continues differently after the group).
+//     A dead path contributes nothing.
+//   * A failing assertion stops a live path there; what it did before still happened.
+// Survivors with a consumable target are kept; memberships nobody can act on any more are dropped and indistinguishable
+// survivors collapse onto the first.
+std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
+    struct Closure {
+        int g, seg, src, visit;
+    };
+    std::vector<Cand> kept;
+    std::vector<Closure> closed;
+    std::map<std::pair<int, int>, int> freshSeg;
+    auto closureOf = [&](int g, int seg) -> const Closure* {
+        for (const auto& c : closed)
+            if (c.g == g && c.seg == seg) return &c;
+        return nullptr;
+    };
+    for (auto& c : cands) {
+        if (!c.events) {  // no atomic groups anywhere in the pattern
+            if (c.targetOk && !(c.cond & ~holds)) kept.push_back(std::move(c));
+            continue;
+        }
+        const auto& ev = *c.events;
+        // exit visit through which this path leaves a membership it holds at path start (or 0)
+        auto exitVisitFor = [&](int g, size_t fromEvent) {
+            int depth = 0;  // re-entries of the same instance cannot nest, but be safe
+            for (size_t i = fromEvent; i < ev.size(); ++i) {
+                if (ev[i].code >= kAssertEvent) {
+                    if (!((holds >> (ev[i].code - kAssertEvent)) & 1u)) return 0;  // the path stops before leaving
+                } else if (ev[i].code == g + 1) {
+                    ++depth;
+                } else if (ev[i].code == -(g + 1)) {
+                    if (depth == 0) return int(ev[i].visit);
+                    --depth;
+                }
+            }
+            return 0;
+        };
+        bool dead = false;
+        for (const auto& e : c.lin) {
+            const Closure* cl = closureOf(e.g, e.seg);
+            if (!cl) continue;
+            if (e.exited || cl->src != c.src || exitVisitFor(e.g, 0) != cl->visit) dead = true;
+        }
+        if (dead) continue;
+        bool assertsOk = true;
+        for (size_t i = 0; i < ev.size() && !dead; ++i) {
+            const int code = ev[i].code;
+            if (code >= kAssertEvent) {
+                if (!((holds >> (code - kAssertEvent)) & 1u)) {
+                    assertsOk = false;
+                    break;
+                }
+            } else if (code > 0) {
+                const int g = code - 1;
+                auto it = freshSeg.find({c.src, g});
+                if (it == freshSeg.end())
+                    it = freshSeg.emplace(std::make_pair(c.src, g), 1000000 + int(freshSeg.size())).first;
+                const Closure* cl = closureOf(g, it->second);
+                if (cl && (cl->src != c.src || exitVisitFor(g, i + 1) != cl->visit)) {
+                    dead = true;
+                    break;
+                }
+                c.lin.push_back({g, it->second, false});
+            } else {
+                const int g = -code - 1;
+                for (size_t k = c.lin.size(); k-- > 0;)
+                    if (c.lin[k].g == g && !c.lin[k].exited) {
+                        c.lin[k].exited = true;
+                        if (!closureOf(g, c.lin[k].seg)) closed.push_back({g, c.lin[k].seg, c.src, int(ev[i].visit)});
+                        break;
+                    }
+            }
+        }
+        if (dead || !assertsOk || !c.targetOk) continue;
+        kept.push_back(std::move(c));
+    }
+    for (size_t i = 0; i < kept.size(); ++i) {
+        auto& lin = kept[i].lin;
+        for (size_t k = 0; k < lin.size();) {
+            bool contested = !lin[k].exited;  // still inside: always kept
+            if (lin[k].exited)
+                for (size_t j = 0; j < i && !contested; ++j)
+                    for (const auto& e : kept[j].lin)
+                        if (e.g == lin[k].g && e.seg == lin[k].seg && !e.exited) contested = true;
+            if (contested) ++k;
+            else lin.erase(lin.begin() + long(k));
+        }
+    }
+    // A lower-priority survivor `lo` on the same position as a higher one `hi` is redundant when
+    //   (1) whatever can kill hi's line also kills lo's: each membership of hi is shared by lo, or no survivor above hi
+    //       is still inside that segment (then only hi's own descendants can ever close it, which lo's line mirrors);
+    //   (2) whatever lo's line could kill, hi's line kills too: each group lo is still inside is the very segment hi is
+    //       inside, or no survivor below lo belongs to it;
+    // lo then mirrors hi move for move at lower priority, can never outlive it and never changes anybody's fate.
+    // (Dropping one survivor can make another one redundant, so repeat until nothing changes.)
+    std::vector<Cand> out = std::move(kept);
+    auto holds_ = [](const Cand& c, const LinEntry& e, bool insideOnly) {
+        for (const auto& x : c.lin)
+            if (x.g == e.g && x.seg == e.seg && (!insideOnly || !x.exited)) return true;
+        return false;
+    };
+    auto mirrors = [&](size_t hi, size_t lo) {
+        if (out[hi].pos != out[lo].pos) return false;
+        for (const auto& e : out[hi].lin) {
+            if (holds_(out[lo], e, false)) continue;
+            for (size_t k = 0; k < hi; ++k)
+                if (holds_(out[k], e, true)) return false;
+        }
+        for (const auto& e : out[lo].lin) {
+            if (e.exited || holds_(out[hi], e, true)) continue;
+            for (size_t k = lo + 1; k < out.size(); ++k)
+                if (holds_(out[k], e, false)) return false;
+        }
+        return true;
+    };
+    // The same argument for whole families: if renaming segments (sigma) maps the survivors holding sigma's domain one
+    // to one, in priority order, onto the survivors holding its range -- same positions, same memberships after
+    // renaming, every image above its original -- the domain family replays the range family at lower priority.
+    auto familyMirror = [&](size_t hi, size_t lo, std::vector<size_t>& drop) {
+        const auto &H = out[hi].lin, &L = out[lo].lin;
+        if (out[hi].pos != out[lo].pos || H.size() != L.size()) return false;
+        std::vector<std::pair<LinEntry, LinEntry>> sigma;  // (from, to), compared on (g, seg)
+        auto same = [](const LinEntry& a, const LinEntry& b) { return a.g == b.g && a.seg == b.seg; };
+        for (size_t k = 0; k < H.size(); ++k) {
+            if (H[k].g != L[k].g || H[k].exited != L[k].exited) return false;
+            if (H[k].seg != L[k].seg) sigma.emplace_back(L[k], H[k]);
+        }
+        if (sigma.empty()) return false;
+        for (const auto& a : sigma)
+            for (const auto& b : sigma)
+                if (same(a.first, b.second) || (same(a.first, b.first) != same(a.second, b.second))) return false;
+        std::vector<size_t> dom, ran;
+        for (size_t i = 0; i < out.size(); ++i) {
+            bool inDom = false, inRan = false;
+            for (const auto& e : out[i].lin)
+                for (const auto& m : sigma) {
+                    inDom |= same(e, m.first);
+                    inRan |= same(e, m.second);
+                }
+            if (inDom && inRan) return false;
+            if (inDom) dom.push_back(i);
+            if (inRan) ran.push_back(i);
+        }
+        if (dom.size() != ran.size()) return false;
+        for (size_t t = 0; t < dom.size(); ++t) {
+            const Cand &d = out[dom[t]], &r = out[ran[t]];
+            if (ran[t] >= dom[t] || d.pos != r.pos || d.lin.size() != r.lin.size()) return false;
+            for (size_t k = 0; k < d.lin.size(); ++k) {
+                LinEntry e = d.lin[k];
+                for (const auto& m : sigma)
+                    if (same(e, m.first)) {
+                        e.seg = m.second.seg;
+                        break;
+                    }
+                if (!(e == r.lin[k])) return false;
+            }
+        }
+        drop = dom;
+        return true;
+    };
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (size_t i = 1; i < out.size() && !changed; ++i)
+            for (size_t j = 0; j < i && !changed; ++j) {
+                std::vector<size_t> drop;
+                if (mirrors(j, i)) {
+                    out.erase(out.begin() + long(i));
+                    changed = true;
+                } else if (familyMirror(j, i, drop)) {
+                    for (size_t t = drop.size(); t-- > 0;) out.erase(out.begin() + long(drop[t]));
+                    changed = true;
+                }
+            }
+    }
+    return out;
+}
+
 struct State {
     std::vector<Item> items;
     uint32_t prevCtx = 0;  // behind-assertions that hold at this state's offset (masked to the ones still observable)
@@ -33,6 +235,11 @@ std::string keyOf(const State& s) {
             int16_t v = int16_t(r);
             k.append(reinterpret_cast<const char*>(&v), sizeof v);
         }
+        for (const auto& e : it.lin) {
+            const int32_t v[3] = {e.g, e.seg, e.exited ? 1 : 0};
+            k.append(reinterpret_cast<const char*>(v), sizeof v);
+        }
+        k.push_back('|');
     }
     return k;
 }
@@ -136,12 +343,6 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     int maxRegs = 0;
     bool usedTmp = false;
 
-    struct NewItem {
-        int pos, src;
-        uint64_t tags;
-    };
-    std::vector<char> seen;
-
     while (!work.empty()) {
         uint32_t sid = work.front();
         work.pop_front();
@@ -151,24 +352,31 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             const State& S = states[sid];  // re-fetched each class: intern() may reallocate `states`
             const unsigned b = classRep[c];
             const uint32_t holds = S.prevCtx | nfa.aheadBits(int(b));
-            std::vector<NewItem> ni;
-            seen.assign(size_t(npos), 0);
+            std::vector<Cand> cands;
+            const bool atomic = nfa.atomicCount > 0;
             for (size_t k = 0; k < S.items.size(); ++k) {
                 for (const auto& path : nfa.follow[S.items[k].pos]) {
-                    if (path.target < 0 || seen[path.target]) continue;
-                    if (!nfa.positions[path.target].has(b)) continue;
-                    if (path.cond & ~holds) continue;
-                    seen[path.target] = 1;
-                    ni.push_back({path.target, int(k), path.tags});
+                    const bool targetOk = path.target >= 0 && nfa.positions[path.target].has(b);
+                    if (!atomic && (!targetOk || (path.cond & ~holds))) continue;  // cannot influence anything
+                    cands.push_back(Cand{path.target, int(k), path.tags, S.items[k].lin,
+                                         atomic ? &path.atoms : nullptr, targetOk, path.cond});
                 }
             }
+            std::vector<Cand> ni = commitAtomic(std::move(cands), holds);
             if (ni.empty()) continue;  // -> dead
             State Tn;
             std::map<int, int> rename;
+            std::map<int, int> segRename;  // segment ids are state-local names: canonical by first appearance
             uint32_t needMask = 0;
             for (const auto& n : ni) {
                 Item it;
                 it.pos = n.pos;
+                it.lin = n.lin;
+                for (auto& e : it.lin) {
+                    auto r = segRename.find(e.seg);
+                    if (r == segRename.end()) r = segRename.emplace(e.seg, int(segRename.size())).first;
+                    e.seg = r->second;
+                }
                 it.regs.resize(size_t(nslots));
                 for (int s = 0; s < nslots; ++s) {
                     int raw = ((n.tags >> s) & 1) ? kFreshBase + s : S.items[size_t(n.src)].regs[size_t(s)];
@@ -244,25 +452,31 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     for (uint32_t s = 1; s < T.nStates; ++s) {
         const State& S = states[s];
         const uint32_t holds = S.prevCtx | nfa.aheadBits(kEdge);
-        bool done = false;
-        for (size_t k = 0; k < S.items.size() && !done; ++k) {
+        std::vector<Cand> cands;
+        const bool atomic = nfa.atomicCount > 0;
+        for (size_t k = 0; k < S.items.size(); ++k)
             for (const auto& path : nfa.follow[size_t(S.items[k].pos)]) {
-                if (path.target != kMatchTarget) continue;
-                if (path.cond & ~holds) continue;
-                std::vector<uint8_t> fm(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
-                for (int sl = 0; sl < nslots; ++sl) {
-                    if ((path.tags >> sl) & 1) fm[size_t(sl)] = kRegPos;
-                    else if (S.items[k].regs[size_t(sl)] >= 0) fm[size_t(sl)] = uint8_t(S.items[k].regs[size_t(sl)]);
-                }
-                auto it = finIds.find(fm);
-                if (it == finIds.end()) {
-                    it = finIds.emplace(fm, uint16_t(finIds.size())).first;
-                    T.finalMap.insert(T.finalMap.end(), fm.begin(), fm.end());
-                }
-                T.finalId[s] = it->second;
-                done = true;
-                break;
+                const bool targetOk = path.target == kMatchTarget;
+                if (!atomic && (!targetOk || (path.cond & ~holds))) continue;
+                // pos = a unique id: survivors must not collapse here, the first one wins
+                cands.push_back(Cand{int(cands.size()), int(k), path.tags, S.items[k].lin,
+                                     atomic ? &path.atoms : nullptr, targetOk, path.cond});
             }
+        const std::vector<Cand> winners = commitAtomic(std::move(cands), holds);
+        if (!winners.empty()) {
+            const Cand& wn = winners.front();  // highest-priority thread that is in MATCH when the input is exhausted
+            std::vector<uint8_t> fm(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
+            for (int sl = 0; sl < nslots; ++sl) {
+                if ((wn.tags >> sl) & 1) fm[size_t(sl)] = kRegPos;
+                else if (S.items[size_t(wn.src)].regs[size_t(sl)] >= 0)
+                    fm[size_t(sl)] = uint8_t(S.items[size_t(wn.src)].regs[size_t(sl)]);
+            }
+            auto it = finIds.find(fm);
+            if (it == finIds.end()) {
+                it = finIds.emplace(fm, uint16_t(finIds.size())).first;
+                T.finalMap.insert(T.finalMap.end(), fm.begin(), fm.end());
+            }
+            T.finalId[s] = it->second;
         }
     }
     if (T.finalMap.empty()) T.finalMap.assign(size_t(nslots) ? size_t(nslots) : 1, kRegNone);

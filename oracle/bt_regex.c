@@ -71,7 +71,7 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 }
 
 /* ------------------------------------------------------------------ AST */
-enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT };
+enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
     A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
@@ -88,7 +88,7 @@ typedef struct {
 } node;
 
 #define ORX_MAX_GROUPS 255
-enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET };
+enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END };
 typedef struct { int op, x, y, z, w; } inst;
 /* I_REPSET: x=set, y=min, z=max(-1 inf), w=greedy */
 
@@ -313,9 +313,18 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                 } else if (d == '=' || d == '!') {
                     ++P->i;
                     return parse_lookaround(P, depth, 0, d == '!');
-                } else if (d == '>' || d == '|' || d == '(' || d == 'R' || d == '&' ||
-                           (d >= '0' && d <= '9') || d == '+') {
-                    fail(P, "unsupported group construct (atomic/recursion/conditional)");
+                } else if (d == '>') { /* atomic group */
+                    ++P->i;
+                    int inner = parse_alt(P, depth + 1);
+                    if (P->failed) return -1;
+                    if (P->i >= P->n || P->p[P->i] != ')') { fail(P, "missing )"); return -1; }
+                    ++P->i;
+                    P->flags = saved;
+                    int a = new_node(P, N_ATOMIC);
+                    P->nodes[a].l = inner;
+                    return a;
+                } else if (d == '|' || d == '(' || d == 'R' || d == '&' || (d >= '0' && d <= '9') || d == '+') {
+                    fail(P, "unsupported group construct (recursion/conditional)");
                     return -1;
                 } else if (d == '<' || d == 'P' || d == '\'') {
                     int close = '>';
@@ -476,11 +485,12 @@ static int parse_cat(orx_prog* P, int depth) {
             if (mx >= 0 && mx < mn) { fail(P, "bad repeat range"); return -1; }
             int greedy = 1;
             if (P->i < P->n && P->p[P->i] == '?') { greedy = 0; ++P->i; }
-            else if (P->i < P->n && P->p[P->i] == '+') { fail(P, "possessive quantifiers unsupported"); return -1; }
-            if (P->nodes[a].kind == N_EMPTY && is_assert == 0 && 0) {}
+            int possessive = 0;
+            if (greedy && P->i < P->n && P->p[P->i] == '+') { possessive = 1; ++P->i; }
             int r = new_node(P, N_REP);
             P->nodes[r].l = a; P->nodes[r].min = mn; P->nodes[r].max = mx; P->nodes[r].greedy = greedy;
             a = r;
+            if (possessive) { int at = new_node(P, N_ATOMIC); P->nodes[at].l = a; a = at; } /* X*+ == (?>X*) */
             quantified = 1;
         }
         acc = cat2(P, acc, a);
@@ -526,6 +536,7 @@ static int nullable(const orx_prog* P, int n) {
         case N_ALT: return nullable(P, nd->l) || nullable(P, nd->r);
         case N_REP: return nd->min == 0 || nullable(P, nd->l);
         case N_GROUP: return nullable(P, nd->l);
+        case N_ATOMIC: return nullable(P, nd->l);
     }
     return 1;
 }
@@ -550,6 +561,11 @@ static void gen(orx_prog* P, int n) {
             if (nd.cap) emit(P, I_SAVE, 2 * nd.cap, 0);
             gen(P, nd.l);
             if (nd.cap) emit(P, I_SAVE, 2 * nd.cap + 1, 0);
+            break;
+        case N_ATOMIC:
+            emit(P, I_ATOM_BEGIN, 0, 0);
+            gen(P, nd.l);
+            emit(P, I_ATOM_END, 0, 0);
             break;
         case N_ASSERT: {
             int k = emit(P, I_ASSERT, nd.akind, nd.set);
@@ -624,7 +640,7 @@ int orx_mark_count(const orx_prog* P) { return P->ngroups; }
 const char* orx_group_name(const orx_prog* P, int g) { return (g >= 1 && g <= P->ngroups) ? P->names[g] : NULL; }
 
 /* ------------------------------------------------------------------ matcher */
-enum { F_ALT, F_UNDO_CAP, F_UNDO_LOOP, F_REP_GREEDY, F_REP_LAZY };
+enum { F_ALT, F_UNDO_CAP, F_UNDO_LOOP, F_REP_GREEDY, F_REP_LAZY, F_ATOM_MARK };
 typedef struct { int kind; int a; long b; long c; } frame;
 /* F_ALT: a=pc, b=pos | F_UNDO_*: a=slot, b=old | F_REP_GREEDY: a=pc_next, b=low, c=cur | F_REP_LAZY: a=pc (of REPSET), b=cur pos, c=count */
 
@@ -706,6 +722,22 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
             case I_SAVE: push(st, F_UNDO_CAP, in->x, caps[in->x], 0); caps[in->x] = (int32_t)pos; ++pc; continue;
             case I_MARK: push(st, F_UNDO_LOOP, in->x, loopregs[in->x], 0); loopregs[in->x] = pos; ++pc; continue;
             case I_CHK: if (loopregs[in->x] == pos) pc = in->y; else ++pc; continue;
+            case I_ATOM_BEGIN: push(st, F_ATOM_MARK, 0, 0, 0); ++pc; continue;
+            case I_ATOM_END: {
+                /* commit: drop every alternative created since the matching mark, keep the undo records (they must
+                 * still be replayed if the matcher later backtracks past the whole group) */
+                size_t m = st->n;
+                int depth = 0;
+                while (m > 0) {
+                    --m;
+                    if (st->v[m].kind == F_ATOM_MARK) { if (depth == 0) break; --depth; }
+                }
+                size_t w = m; /* overwrite the mark itself */
+                for (size_t r = m + 1; r < st->n; ++r)
+                    if (st->v[r].kind == F_UNDO_CAP || st->v[r].kind == F_UNDO_LOOP) st->v[w++] = st->v[r];
+                st->n = w;
+                ++pc; continue;
+            }
             case I_ASSERT:
                 if (in->x == A_LOOK) {
                     int hit = in->z ? (pos > 0 && cs_has(&P->sets[in->y], s[pos - 1]))
@@ -725,6 +757,7 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
             frame* f = &st->v[st->n - 1];
             if (f->kind == F_UNDO_CAP) { caps[f->a] = (int32_t)f->b; --st->n; continue; }
             if (f->kind == F_UNDO_LOOP) { loopregs[f->a] = f->b; --st->n; continue; }
+            if (f->kind == F_ATOM_MARK) { --st->n; continue; }
             if (f->kind == F_ALT) { pc = f->a; pos = f->b; --st->n; break; }
             if (f->kind == F_REP_GREEDY) {
                 --f->c;

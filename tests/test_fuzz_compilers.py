@@ -49,3 +49,40 @@ def test_random_patterns_tables_vs_oracle(seed):
                     checked += 1
                     assert it.fullmatch(s) == want, (p, s, flags)
     assert checked > 2000 and unsupported <= 4  # (a few random monsters exceed the 64-path follow-list limit)
+
+
+_aspec = importlib.util.spec_from_file_location(
+    "gen_atomic_golden", os.path.join(os.path.dirname(__file__), "golden", "gen_atomic_golden.py"))
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_atomic_patterns_tdfa_tables_vs_oracle(seed):
+    """Fresh random patterns full of (?>X) / possessive quantifiers / look assertions: the TDFA builder's segment
+    lineage (tdfa.cpp commitAtomic) against the oracle's backtracking commit, full-match and search."""
+    pytest.importorskip("regex")  # the generator module imports it; the check itself is oracle-only
+    agen = importlib.util.module_from_spec(_aspec)
+    _aspec.loader.exec_module(agen)
+    rng = random.Random(7000 + seed)
+    checked = 0
+    for _ in range(250):
+        p = agen.gen(rng)
+        try:
+            orx = OracleRegex(p)
+        except ValueError:
+            continue
+        for flags, oracle_fn in ((0, orx.fullmatch), (B.LC_SYNTAX_SEARCH, orx.search)):
+            try:
+                rx = B.GpuRegex(p, syntax_flags=flags)
+            except B.RegexUnsupportedError as e:
+                assert "can match the empty string" in str(e) or "too many" in str(e) or "limit" in str(e), (p, str(e))
+                continue
+            if rx.info()["engine"] != B.LC_ENGINE_TDFA:
+                continue
+            it = TdfaInterp(rx)
+            for _ in range(8):
+                s = bytes(rng.choice(b'abc1 ') for _ in range(rng.randint(0, 8)))
+                exp = oracle_fn(s)
+                want = None if exp is None else [v for ab in (exp if flags else exp[1:]) for v in ab]
+                checked += 1
+                assert it.fullmatch(s) == want, (p, s, flags)
+    assert checked > 2500

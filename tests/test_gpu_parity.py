@@ -285,3 +285,28 @@ def test_length_scheduled_ragged_path_is_bit_exact(torch_dev, engine):
     order = d_scratch.cpu().numpy().view(np.uint32)[512:512 + n]
     assert sorted(order.tolist()) == list(range(n))                      # a permutation
     assert (np.diff((length[order] >> 5).astype(np.int64)) <= 0).all()    # longest bucket first
+
+
+def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_kernel(torch_dev, golden_dir):
+    """(?>X) / X*+ vectors (regex module ∧ PCRE1, tests/golden/gen_atomic_golden.py) through the C ABI, full and search."""
+    with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH)):
+        for c in golden[kind]:
+            try:
+                rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+            except B.RegexUnsupportedError:
+                continue
+            subs = [s.encode("latin-1") for s, _ in c["subs"]]
+            data, off, length = pack(subs)
+            caps, status = run_device(torch_dev, rx, data, off, length)
+            for i, (_, flat) in enumerate(c["subs"]):
+                checked += 1
+                exp = flat if kind == "search" or flat is None else flat[2:]
+                ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
+                    status[i] == B.LC_MATCH and list(caps[i]) == exp)
+                if not ok:
+                    bad.append((kind, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
+    assert checked > 3500
+    assert not bad, bad[:5]

@@ -72,7 +72,7 @@ def test_bench_regex_tables_are_small_enough_for_lds():
     (r"(a", B.RegexSyntaxError), (r"a)", B.RegexSyntaxError), (r"[a", B.RegexSyntaxError), (r"a**", B.RegexSyntaxError),
     (r"*a", B.RegexSyntaxError), (r"a{3,1}", B.RegexSyntaxError),
     (r"(a)\1", B.RegexUnsupportedError), (r"(?=ab)c", B.RegexUnsupportedError), (r"(?<!ab)c", B.RegexUnsupportedError),
-    (r"(?>a+)b", B.RegexUnsupportedError), (r"a++", B.RegexUnsupportedError), (r"(a*)*", B.RegexUnsupportedError),
+    (r"(?R)b", B.RegexUnsupportedError), (r"(?(1)a|b)", B.RegexUnsupportedError), (r"(a*)*", B.RegexUnsupportedError),
 ])
 def test_invalid_and_unsupported_patterns_fail_loudly(pat, code):
     # reference: IsRegexValid false -> Init fails (ParamExtractor.cpp:199-209, ProcessorParseRegexNative.cpp:53-63)
@@ -129,4 +129,35 @@ def test_search_mode_tables_reproduce_every_search_vector(golden_dir):
                 if got != flat:
                     bad.append((c["p"], subj, got, flat))
     assert n > 2000 and unsupported <= 2
+    assert not bad, bad[:5]
+
+
+def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_tables(golden_dir):
+    """Atomic groups only exist on the TDFA engine (segment lineage in tdfa.cpp); the NFA program refuses them."""
+    with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
+        d = json.load(f)
+    bad, n, unsupported = [], 0, 0
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH)):
+        for c in d[kind]:
+            try:
+                rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+            except B.RegexUnsupportedError as e:
+                # the one construct the device engines refuse here: a loop whose body can match the empty string
+                assert "unbounded repeat of a sub-expression that can match the empty string" in str(e), (c["p"], str(e))
+                unsupported += 1
+                continue
+            atomic = "(?>" in c["p"] or any(q in c["p"] for q in ("*+", "++", "?+", "}+"))
+            interps = [TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []
+            if rx.has_nfa_program():
+                assert not atomic
+                interps.append(NfaInterp(rx))
+            assert interps
+            for subj, flat in c["subs"]:
+                exp = flat if kind == "search" or flat is None else flat[2:]
+                for it in interps:
+                    n += 1
+                    got = it.fullmatch(subj.encode("latin-1"))
+                    if got != exp:
+                        bad.append((kind, c["p"], subj, got, exp))
+    assert n > 4000 and unsupported <= 40, (n, unsupported)
     assert not bad, bad[:5]

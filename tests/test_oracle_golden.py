@@ -46,7 +46,7 @@ def test_survey_known_answer_vectors():
                                     (99, 103), (105, 128), (131, 172)]
 
 
-@pytest.mark.parametrize("pat", [r"(a)\1", r"(?=ab)c", r"(?<!ab)c", r"(?>a+)b", r"a++", r"(", r"a)", r"[a", r"a**", r"\p{L}"])
+@pytest.mark.parametrize("pat", [r"(a)\1", r"(?=ab)c", r"(?<!ab)c", r"(?R)b", r"(?(1)a|b)", r"(", r"a)", r"[a", r"a**", r"\p{L}"])
 def test_unsupported_or_invalid_patterns_fail_to_compile(pat):
     with pytest.raises(ValueError):
         OracleRegex(pat)
@@ -82,4 +82,23 @@ def test_oracle_search_matches_every_search_vector(golden_dir):
             got_flat = None if got is None else [v for ab in got for v in ab]
             if got_flat != flat:
                 bad.append((c["p"], subj, got_flat, flat))
+    assert not bad, bad[:5]
+
+
+def test_oracle_matches_atomic_and_possessive_vectors(golden_dir):
+    """(?>X), X*+ ... : vectors on which the `regex` module and PCRE1 agree (tests/golden/gen_atomic_golden.py)."""
+    with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
+        d = json.load(f)
+    assert d["n_full"] > 2500 and d["n_search"] > 1000
+    bad = []
+    for kind in ("full", "search"):
+        for c in d[kind]:
+            rx = OracleRegex(c["p"].encode("latin-1"))
+            assert rx.groups == c["g"], c["p"]
+            for subj, flat in c["subs"]:
+                s = subj.encode("latin-1")
+                got = rx.fullmatch(s) if kind == "full" else rx.search(s)
+                got_flat = None if got is None else [v for ab in got for v in ab]
+                if got_flat != flat:
+                    bad.append((kind, c["p"], subj, got_flat, flat))
     assert not bad, bad[:5]
