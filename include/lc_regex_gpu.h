@@ -47,9 +47,11 @@ enum {
     LC_SYNTAX_NO_MULTILINE = 1u << 2,   /* (?-m): '^'/'$' only at the ends of the line */
     LC_SYNTAX_EXTENDED = 1u << 3,       /* (?x) */
     LC_SYNTAX_NAMED_ONLY = 1u << 4,     /* unnamed groups do not capture (Grok / regexp2 ExplicitCapture-style) */
-    LC_SYNTAX_SEARCH = 1u << 5          /* leftmost-first SEARCH instead of whole-line match (Go processor_regex without
+    LC_SYNTAX_SEARCH = 1u << 5,         /* leftmost-first SEARCH instead of whole-line match (Go processor_regex without
                                            FullMatch, regex.go:105-129): compiled as (?s:.*?)(re)(?s:.*), so group 1 is
                                            the whole match and the pattern's own groups are 2..mark_count */
+    LC_SYNTAX_REGEXP2 = 1u << 6         /* escape dialect of github.com/dlclark/regexp2 with the RE2 option (Go Grok,
+                                           processor_grok.go:343): \s = [\t\n\f\r ]; \< \> \` \' are literals */
 };
 
 /* device engines */
@@ -107,7 +109,9 @@ enum {
     LC_TABLE_TDFA_FINALID = 4, /* u16[states] */
     LC_TABLE_TDFA_FINALMAP = 5, /* u8[nfinal*slots] */
     LC_TABLE_TDFA_HEADER = 6, /* u32[8]: states, classes, registers, slots, start state, 0,0,0 */
-    LC_TABLE_NFA_BLOB = 7     /* the packed NFA program uploaded to the device (see csrc/device_tables.h) */
+    LC_TABLE_NFA_BLOB = 7,    /* the packed NFA program uploaded to the device (see csrc/device_tables.h) */
+    LC_TABLE_TDFA_STARTAFTER = 8 /* u32[classes]: search patterns only -- state a resumed search starts in, by the class
+                                    of the byte before the resume point (lc_regex_match_device_from) */
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 
@@ -132,6 +136,19 @@ int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t*
 int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
                                  const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
                                  int32_t* d_caps, uint8_t* d_status, void* stream);
+
+/* The general device entry: a SUBSET of the lines, each search optionally RESUMED inside its line.
+ *   d_lines  (optional) uint32[n]: indices of the lines to match; results land at caps[line]/status[line], lines not
+ *            listed are not touched.  d_nlines (optional): the count lives on the device (<= n).
+ *   d_from   (optional) uint32[], indexed by LINE: where the search resumes inside the line (0 = fresh search).  Only for
+ *            patterns compiled with LC_SYNTAX_SEARCH.  The resumed search sees the byte before the resume point (look-
+ *            behinds, \b, ^) exactly as regexp2's FindNextMatch / Go's FindAll do; offsets stay relative to the line.
+ * This is what an iterate-all-matches, ordered-pattern-list caller (the Grok processor, processor_grok.go:148-194) is
+ * built from. */
+int lc_regex_match_device_from(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                               const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, const uint32_t* d_lines,
+                               const uint32_t* d_nlines, const uint32_t* d_from, uint32_t ngroups, int32_t* d_caps,
+                               uint8_t* d_status, void* stream);
 
 /* Same as lc_regex_match_device_engine with offsets[n+1] + sep_bytes, but the line count is read from device memory
  * (*d_nlines, clamped to max_lines) when the kernel starts: lets lc_split_lines_device and the match run back to back

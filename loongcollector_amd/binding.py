@@ -17,9 +17,10 @@ LC_NOMATCH, LC_MATCH, LC_OVERFLOW = 0, 1, 2
 LC_OK, LC_ERR_SYNTAX, LC_ERR_UNSUPPORTED, LC_ERR_NO_DEVICE, LC_ERR_HIP, LC_ERR_ARG = range(6)
 LC_SYNTAX_ICASE, LC_SYNTAX_NO_DOTALL, LC_SYNTAX_NO_MULTILINE, LC_SYNTAX_EXTENDED, LC_SYNTAX_NAMED_ONLY = 1, 2, 4, 8, 16
 LC_SYNTAX_SEARCH = 32
+LC_SYNTAX_REGEXP2 = 64
 
 (LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
- LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB) = range(8)
+ LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB, LC_TABLE_TDFA_STARTAFTER) = range(9)
 
 
 class LcRegexInfo(ctypes.Structure):
@@ -69,6 +70,8 @@ def load(path=None):
     L.lc_sched_scratch_bytes.argtypes = [u32]
     L.lc_regex_match_device_ragged.restype = i32
     L.lc_regex_match_device_ragged.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, sz, vp]
+    L.lc_regex_match_device_from.restype = i32
+    L.lc_regex_match_device_from.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, u32, vp, vp, vp]
     L.lc_split_scratch_bytes.restype = sz
     L.lc_split_scratch_bytes.argtypes = [ctypes.c_uint64]
     L.lc_split_lines_device.restype = i32
@@ -167,6 +170,16 @@ class GpuRegex:
             sep_bytes, n, d_nlines.data_ptr() if d_nlines is not None else None, G, d_caps.data_ptr(),
             d_status.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(), stream)
         _check(rc, "lc_regex_match_device_ragged")
+
+    def match_device_from(self, d_data, d_off, d_len, n, d_caps, d_status, d_lines=None, d_nlines=None, d_from=None,
+                          ngroups=None, sep_bytes=0, stream=None, engine=LC_ENGINE_AUTO):
+        """subset of lines (d_lines) and/or searches resumed inside their line (d_from, indexed by line)"""
+        G = self.groups if ngroups is None else ngroups
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        rc = self._L.lc_regex_match_device_from(self._h, engine, d_data.data_ptr(), d_off.data_ptr(), ptr(d_len), sep_bytes,
+                                                n, ptr(d_lines), ptr(d_nlines), ptr(d_from), G, d_caps.data_ptr(),
+                                                d_status.data_ptr(), stream)
+        _check(rc, "lc_regex_match_device_from")
 
     def match_device_dyn(self, d_data, d_off, d_nlines, max_lines, d_caps, d_status, ngroups=None, sep_bytes=1,
                          stream=None, engine=LC_ENGINE_AUTO):

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblc_regex_gpu.so")
 
 SOURCES = ["regex_parse.cpp", "follow_nfa.cpp", "tdfa.cpp", "regex_handle.cpp", "gpu_runtime.hip"]
-OPTIONAL_SOURCES = ["event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "c_processor_slot.cpp"]
+OPTIONAL_SOURCES = ["event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "processor_grok_gpu.cpp", "c_processor_slot.cpp"]
 
 
 def _hipcc():
@@ -38,6 +38,8 @@ def needs_build():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(HERE, "..", "include", "lc_regex_gpu.h"))
     deps.append(os.path.join(HERE, "..", "include", "lc_processor.h"))
+    deps.append(os.path.join(HERE, "..", "include", "lc_grok.h"))
+    deps.append(os.path.join(HERE, "data", "grok_default_patterns.txt"))
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -48,8 +50,15 @@ def build_native(force=False, verbose=False):
     objs = []
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    # the Grok default library (data/grok_default_patterns.txt) is compiled in as one raw string literal
+    inc = os.path.join(objdir, "grok_defaults.inc")
+    with open(os.path.join(HERE, "data", "grok_default_patterns.txt"), encoding="utf-8") as f:
+        blob = 'R"GROKDATA(' + f.read() + ')GROKDATA"\n'
+    if not os.path.exists(inc) or open(inc, encoding="utf-8").read() != blob:
+        with open(inc, "w", encoding="utf-8") as f:
+            f.write(blob)
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include"),
-              "-I", CSRC] + os.environ.get("LC_EXTRA_CXXFLAGS", "").split()
+              "-I", CSRC, "-I", objdir] + os.environ.get("LC_EXTRA_CXXFLAGS", "").split()
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

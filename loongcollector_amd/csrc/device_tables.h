@@ -14,7 +14,8 @@ enum {
     TD_NREGS = 3,        // per-line offset registers, INCLUDING the trailing dummy register
     TD_NSLOTS = 4,       // 2 * capture groups
     TD_START_ROW = 5,    // LDS address of the start state's row (= TD_TRANS_OFFSET + start*rowBytes)
-    TD_OFF_CLASSMAP = 6, // == TD_CMAP_OFFSET
+    TD_OFF_STARTAFTER = 6, // u32[nClasses]: row address to resume a search in, by class of the byte before the resume
+                         // point (0 = the pattern is not a search pattern); the class map itself sits at TD_CMAP_OFFSET
     TD_OFF_TRANS = 7,    // == TD_TRANS_OFFSET
     TD_OFF_FINALID = 8,  // u16[nStates]: 0xFFFF = not accepting
     TD_OFF_FINALMAP = 9, // u8[nFinal*nSlots]

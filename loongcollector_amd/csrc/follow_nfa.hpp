@@ -50,6 +50,10 @@ struct FollowNfa {
     uint32_t condsUsed = 0;                       // union of all path conds
     uint32_t behindMask = 0;                      // bits of asserts that look behind
     int atomicCount = 0;                          // atomic group instances; > 0 means only the TDFA engine can run it
+    // LC_SYNTAX_SEARCH wrapper (?s:.*?)(re)(?s:.*): the positions of its two '.' (else -1).  A search can RESUME in the
+    // middle of a line (the next match of an iterate-all-matches caller): that is the state "the prefix position has
+    // just consumed the byte before the resume point".
+    int searchPrefix = -1, searchSuffix = -1;
     int slotCount() const { return 2 * groupCount; }
     int startIndex() const { return int(positions.size()); }
 

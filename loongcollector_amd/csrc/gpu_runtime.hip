@@ -83,7 +83,7 @@ void lcReleaseDeviceTables(lc_regex* re) {
 
 template <int BLOCK>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
-                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
+                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -93,13 +93,13 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(tdfa_match_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, d_order, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups, int32_t* d_caps,
+                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
                       uint8_t* d_status, hipStream_t stream) {
     void* dBlob = nullptr;
     int rc = ensureUploaded(re, dev, true, &dBlob);
@@ -113,15 +113,15 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
     const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
     switch (block) {
-        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
-        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
-        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
 }
 
 template <int NS>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
-                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
+                          const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
@@ -131,13 +131,13 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, con
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
     hipLaunchKernelGGL(nfa_match_kernel<NS>, dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, d_order, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
 
 static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
-                     uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups, int32_t* d_caps,
+                     uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
                      uint8_t* d_status, hipStream_t stream) {
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
@@ -153,23 +153,23 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
-    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
-    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
-    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
-    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
 }
 
-static int matchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
-                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, uint32_t ngroups,
+int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
+                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
             return LC_ERR_UNSUPPORTED;
         }
-        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
-    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, ngroups, d_caps, d_status, stream);
+    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
 }
 
 extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
@@ -186,8 +186,31 @@ extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const ui
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
-    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, nullptr, ngroups, d_caps, d_status,
+    return lcMatchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, nullptr, nullptr, ngroups, d_caps, d_status,
                          static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lc_regex_match_device_from(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
+                                          const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, const uint32_t* d_lines,
+                                          const uint32_t* d_nlines, const uint32_t* d_from, uint32_t ngroups,
+                                          int32_t* d_caps, uint8_t* d_status, void* stream) {
+    if (!re) return LC_ERR_ARG;
+    if (n == 0) return LC_OK;
+    if (!d_data || !d_off || !d_caps || !d_status) return LC_ERR_ARG;
+    if (d_from && re->nfa.searchPrefix < 0) {
+        tlsError = "resume offsets need a pattern compiled with LC_SYNTAX_SEARCH";
+        return LC_ERR_ARG;
+    }
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    if (engine == LC_ENGINE_AUTO) engine = re->engine;
+    return lcMatchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, d_nlines, d_lines, d_from, ngroups, d_caps,
+                           d_status, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
@@ -204,7 +227,7 @@ extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
-    return matchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, nullptr, ngroups, d_caps,
+    return lcMatchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, nullptr, nullptr, ngroups, d_caps,
                          d_status, static_cast<hipStream_t>(stream));
 }
 
@@ -237,7 +260,7 @@ extern "C" int lc_regex_match_device_ragged(lc_regex_t* re, int engine, const ui
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(grid), dim3(kSchedBlock), 0, st, d_off, d_len, sep_bytes, n, d_nlines,
                        cursor, order);
     HIP_TRY(hipGetLastError());
-    return matchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, d_nlines, order, ngroups, d_caps, d_status,
+    return lcMatchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, d_nlines, order, nullptr, ngroups, d_caps, d_status,
                          st);
 }
 

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                                                               const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                               uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
                                                               const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ resume,
                                                               const uint32_t* __restrict__ blob,
                                                               uint32_t blobBytes, uint32_t nGroupsOut,
                                                               int32_t* __restrict__ caps,
@@ -97,12 +98,25 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t head = uint32_t(addr & 3);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
     const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
-    uint32_t curWord = (lane < nWords) ? words[lane] : 0;
     uint32_t prevCls = edgeClass;
+    uint32_t from = 0;  // search patterns: resume the search here (the next match of an iterate-all-matches caller)
+    if (resume) {
+        from = resume[line];
+        from = from < L ? from : L;
+        if (from) {  // one thread, on the wrapper's prefix position, which has just consumed the byte before `from`
+            myPos = 0;
+            prevCls = classMap[data[size_t(o) + from - 1]];
+        }
+    }
+    uint32_t curWord;
+    {
+        const uint32_t w = (((head + from) >> 8) << 6) + lane;  // the 256-byte chunk the first byte lives in
+        curWord = (w < nWords) ? words[w] : 0;
+    }
 
-    for (uint32_t i = 0; i < L && nThreads; ++i) {
+    for (uint32_t i = from; i < L && nThreads; ++i) {
         const uint32_t idx = head + i;
-        if (i && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
+        if (i != from && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
             const uint32_t w = (idx >> 2) + lane;
             curWord = (w < nWords) ? words[w] : 0;
         }

@@ -54,6 +54,10 @@ struct Syntax {
     bool multiLine = true;
     bool extended = false;
     bool namedOnly = false;  // unnamed (...) groups do not capture (Grok semantics: only named groups are emitted)
+    // github.com/dlclark/regexp2 with the RE2 option (what the Go Grok plugin compiles with, processor_grok.go:343):
+    // \s is RE2's [\t\n\f\r ] (no \v), and escapes that mean nothing to it -- \< \> \` \' -- are the literal character,
+    // where boost's Perl syntax reads them as word-start/-end and buffer-start/-end assertions.
+    bool regexp2 = false;
 };
 
 // A primitive zero-width assertion looks at ONE neighbouring byte:
@@ -76,6 +80,10 @@ struct Node {
     bool greedy = true;                        // Repeat
     int capture = 0;                           // Group: 1-based capture index, 0 = non-capturing
     LookAssert look;                           // Assert
+    // parser-internal: a look-AHEAD whose body is a sequence of >= 2 character classes.  It never reaches the automata:
+    // the parser drops it when what follows already implies it, and refuses the pattern otherwise (regex_parse.cpp).
+    std::vector<ByteSet> aheadSeq;
+    bool aheadNegative = false;
 };
 
 struct ParsedRegex {

@@ -1,6 +1,8 @@
 // regex_handle.cpp -- host half of the C ABI: compile a pattern into device table blobs (no HIP calls here).
 #include "regex_handle.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -88,10 +90,15 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
     hdr[TD_ROW_BYTES] = rowBytes;
     hdr[TD_ID_COL] = t.nClasses * 4;
     hdr[TD_BLOCK] = uint32_t(block);
-    hdr[TD_OFF_CLASSMAP] = w.put(cmap);
+    const uint32_t cmapAt = w.put(cmap);
     hdr[TD_OFF_TRANS] = w.put(trans);
-    if (hdr[TD_OFF_CLASSMAP] != TD_CMAP_OFFSET || hdr[TD_OFF_TRANS] != TD_TRANS_OFFSET)
+    if (cmapAt != TD_CMAP_OFFSET || hdr[TD_OFF_TRANS] != TD_TRANS_OFFSET)
         throw RegexError("tdfa: internal layout error");
+    if (!t.startAfter.empty()) {
+        std::vector<uint32_t> rows;
+        for (uint32_t st : t.startAfter) rows.push_back(rowAddr(st));
+        hdr[TD_OFF_STARTAFTER] = w.put(rows);
+    }
     hdr[TD_OFF_FINALID] = w.put(t.finalId);
     hdr[TD_OFF_FINALMAP] = w.put(t.finalMap);
     hdr[TD_OFF_OPSSTART] = w.put(t.opsStart);
@@ -242,6 +249,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
     syn.multiLine = !(syntax_flags & LC_SYNTAX_NO_MULTILINE);
     syn.extended = syntax_flags & LC_SYNTAX_EXTENDED;
     syn.namedOnly = syntax_flags & LC_SYNTAX_NAMED_ONLY;
+    syn.regexp2 = syntax_flags & LC_SYNTAX_REGEXP2;
     auto re = new lc_regex();
     re->pattern.assign(pattern, pattern_len);
     re->syntaxFlags = syntax_flags;
@@ -257,9 +265,15 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         }
         if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed);
         re->nfa = buildFollowNfa(parsed);
+        if (syntax_flags & LC_SYNTAX_SEARCH) {  // wrapForSearch generates its prefix '.' first and its suffix '.' last
+            re->nfa.searchPrefix = 0;
+            re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;
+        }
         if (engine != LC_ENGINE_NFA) {
             try {
-                re->tdfa = buildTdfa(re->nfa);
+                TdfaLimits lim;
+                if (const char* e = getenv("LC_TDFA_MAX_STATES")) lim.maxStates = uint32_t(atoi(e));
+                re->tdfa = buildTdfa(re->nfa, lim);
                 re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
                 if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
                 re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
@@ -346,6 +360,9 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
         case LC_TABLE_TDFA_FINALID: return view(t.finalId.data(), t.finalId.size() * 2);
         case LC_TABLE_TDFA_FINALMAP: return view(t.finalMap.data(), t.finalMap.size());
         case LC_TABLE_TDFA_HEADER: return view(re->tdfaHeader.data(), re->tdfaHeader.size() * 4);
+        case LC_TABLE_TDFA_STARTAFTER:
+            if (t.startAfter.empty()) return LC_ERR_ARG;
+            return view(t.startAfter.data(), t.startAfter.size() * 4);
         default: return LC_ERR_ARG;
     }
 }

@@ -300,11 +300,11 @@ private:
                 unsigned e = peek();
                 ++mPos;
                 ByteSet t;
-                if (shorthand(char(e), t)) {
+                if (sh(char(e), t)) {
                     acc.unite(t);
                     continue;
                 }
-                if (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), t)) {
+                if (e >= 'A' && e <= 'Z' && sh(char(e + 32), t)) {
                     t.invert();
                     acc.unite(t);
                     continue;
@@ -335,7 +335,7 @@ private:
                     unsigned e = peek();
                     ++mPos;
                     ByteSet dummy;
-                    if (shorthand(char(e), dummy) || (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), dummy)))
+                    if (sh(char(e), dummy) || (e >= 'A' && e <= 'Z' && sh(char(e + 32), dummy)))
                         bail("class escape as range endpoint");
                     if (e == 'b') {
                         hi = 8;
@@ -360,6 +360,17 @@ private:
         return n;
     }
 
+    // shorthand classes of the active dialect: regexp2's RE2 mode has \d \w as here, \s = [\t\n\f\r ], and no \h \l \u
+    // (\v is the VT character there, handled by byteEscape)
+    bool sh(char letter, ByteSet& out) const {
+        if (!mSyn.regexp2) return shorthand(letter, out);
+        if (letter == 's') {
+            for (unsigned char c : {'\t', '\n', '\f', '\r', ' '}) out.add(c);
+            return true;
+        }
+        return (letter == 'd' || letter == 'w') && shorthand(letter, out);
+    }
+
     // (?=X) (?!X) (?<=X) (?<!X) with X a single character class: a one-byte look-around.  mPos is just past the
     // introducer.  Longer bodies would need multi-byte look-ahead/behind, which the automata do not have.
     NodePtr lookAround(int depth, bool behind, bool negative) {
@@ -370,6 +381,17 @@ private:
         mSyn = saved;
         const Node* n = body.get();
         while ((n->kind == Node::Group && n->capture == 0) && n->kids.size() == 1) n = n->kids[0].get();
+        if (!behind && n->kind == Node::Cat) {  // (?=AB..) / (?!AB..): decided in sequence() from what follows
+            auto a = mk(Node::Assert);
+            for (const auto& k : n->kids) {
+                const Node* e = k.get();
+                while ((e->kind == Node::Group && e->capture == 0) && e->kids.size() == 1) e = e->kids[0].get();
+                if (e->kind != Node::Set) bail("unsupported: look-ahead body must be a sequence of character classes");
+                a->aheadSeq.push_back(e->set);
+            }
+            a->aheadNegative = negative;
+            return a;
+        }
         if (n->kind != Node::Set) bail("unsupported: look-around body must be a single character class");
         ByteSet set = n->set;
         if (negative) set.invert();
@@ -480,13 +502,13 @@ private:
         ++mPos;
         {
             ByteSet t;
-            if (shorthand(char(e), t)) {
+            if (sh(char(e), t)) {
                 if (mSyn.icase) foldCase(t);
                 auto n = mk(Node::Set);
                 n->set = t;
                 return n;
             }
-            if (e >= 'A' && e <= 'Z' && shorthand(char(e + 32), t)) {
+            if (e >= 'A' && e <= 'Z' && sh(char(e + 32), t)) {
                 if (mSyn.icase) foldCase(t);
                 t.invert();
                 auto n = mk(Node::Set);
@@ -497,12 +519,20 @@ private:
         switch (e) {
             case 'b': return assertion(Anchor::WordBoundary);
             case 'B': return assertion(Anchor::NotWordBoundary);
-            case '<': return assertion(Anchor::WordStart);
-            case '>': return assertion(Anchor::WordEnd);
-            case 'A':
-            case '`': return assertion(Anchor::BolSingle);
-            case 'z':
-            case '\'': return assertion(Anchor::EolSingle);
+            case '<':
+                if (mSyn.regexp2) return literal(e);
+                return assertion(Anchor::WordStart);
+            case '>':
+                if (mSyn.regexp2) return literal(e);
+                return assertion(Anchor::WordEnd);
+            case '`':
+                if (mSyn.regexp2) return literal(e);
+                return assertion(Anchor::BolSingle);
+            case 'A': return assertion(Anchor::BolSingle);
+            case '\'':
+                if (mSyn.regexp2) return literal(e);
+                return assertion(Anchor::EolSingle);
+            case 'z': return assertion(Anchor::EolSingle);
             case 'Z': bail("\\Z (multi-byte look-ahead) unsupported");
             case 'Q': {
                 auto seq = mk(Node::Cat);
@@ -521,6 +551,9 @@ private:
             case 'E': return mk(Node::Empty);
             case 'k': case 'g': case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
                 bail("unsupported escape");
+            case 'u':
+                if (mSyn.regexp2) bail("unsupported escape");  // \uXXXX
+                break;
             default: break;
         }
         if (e >= '1' && e <= '9') bail("back-references unsupported");
@@ -555,7 +588,7 @@ private:
                 ++mPos;
                 const unsigned e = has(0) ? peek() : 0;
                 NodePtr n = escapeAtom();
-                isAssertion = std::strchr("bB<>AzZ`'", int(e)) != nullptr && e != 0;
+                isAssertion = std::strchr(mSyn.regexp2 ? "bBAzZ" : "bB<>AzZ`'", int(e)) != nullptr && e != 0;
                 return n;
             }
             default: ++mPos; return literal(c);
@@ -649,9 +682,60 @@ private:
             }
             seq->kids.push_back(std::move(a));
         }
+        // Multi-byte look-aheads (the library's "(?!<[0-9])%{HOUR}" -- a mistyped look-behind): the automata only look
+        // one byte ahead, but when the rest of this sequence cannot begin with the look-ahead's first class the answer
+        // is already known on every path that goes on to match: a negative one holds, a positive one fails.
+        for (size_t i = 0; i < seq->kids.size(); ++i) {
+            Node& k = *seq->kids[i];
+            if (k.kind != Node::Assert || k.aheadSeq.empty()) continue;
+            ByteSet first;
+            bool restNullable = true;
+            for (size_t j = i + 1; j < seq->kids.size() && restNullable; ++j) restNullable = firstOf(*seq->kids[j], first);
+            bool disjoint = !restNullable;
+            for (int w = 0; w < 4 && disjoint; ++w) disjoint = (first.w[w] & k.aheadSeq[0].w[w]) == 0;
+            if (!disjoint) bail("unsupported: multi-byte look-ahead that the following sub-expression does not decide");
+            if (k.aheadNegative) {
+                seq->kids[i] = mk(Node::Empty);
+            } else {
+                auto never = mk(Node::Set);  // empty class: this branch cannot match
+                seq->kids[i] = std::move(never);
+            }
+        }
         if (seq->kids.empty()) return mk(Node::Empty);
-        if (seq->kids.size() == 1) return std::move(seq->kids[0]);
+        if (seq->kids.size() == 1) {
+            if (seq->kids[0]->kind == Node::Assert && !seq->kids[0]->aheadSeq.empty())
+                bail("unsupported: multi-byte look-ahead that the following sub-expression does not decide");
+            return std::move(seq->kids[0]);
+        }
         return seq;
+    }
+
+    // FIRST set of a sub-expression (bytes a match of it can begin with) ORed into `out`; returns whether it can match
+    // the empty string.  Zero-width assertions are transparent.
+    static bool firstOf(const Node& n, ByteSet& out) {
+        switch (n.kind) {
+            case Node::Empty:
+            case Node::Assert: return true;
+            case Node::Set:
+                for (int w = 0; w < 4; ++w) out.w[w] |= n.set.w[w];
+                return false;
+            case Node::Cat:
+                for (const auto& k : n.kids)
+                    if (!firstOf(*k, out)) return false;
+                return true;
+            case Node::Alt: {
+                bool any = false;
+                for (const auto& k : n.kids) any |= firstOf(*k, out);
+                return any;
+            }
+            case Node::Repeat: {
+                const bool inner = firstOf(*n.kids[0], out);
+                return inner || n.min == 0;
+            }
+            case Node::Group:
+            case Node::Atomic: return firstOf(*n.kids[0], out);
+        }
+        return true;
     }
 
     NodePtr alternation(int depth) {

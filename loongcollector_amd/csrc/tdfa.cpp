@@ -335,6 +335,17 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
         s0.prevCtx = nfa.behindBits(kEdge) & need[nfa.startIndex()];
         T.startState = intern(std::move(s0));
     }
+    if (nfa.searchPrefix >= 0) {
+        for (int c = 0; c < ncls; ++c) {
+            State s;
+            Item it;
+            it.pos = nfa.searchPrefix;
+            it.regs.assign(size_t(nslots), -1);
+            s.items.push_back(std::move(it));
+            s.prevCtx = nfa.behindBits(int(classRep[size_t(c)])) & need[size_t(nfa.searchPrefix)];
+            T.startAfter.push_back(intern(std::move(s)));
+        }
+    }
 
     std::map<std::vector<uint16_t>, uint32_t> opListIds;
     std::vector<std::vector<uint16_t>> opLists(1);  // id 0 = empty

@@ -26,6 +26,9 @@ struct TdfaTables {
     std::vector<uint16_t> ops;        // per list: n, then n words (dst | src<<8); src may be kRegPos
     std::vector<uint16_t> finalId;    // [nStates] 0xFFFF = not accepting, else row in finalMap
     std::vector<uint8_t> finalMap;    // [nFinal*nSlots] register id | kRegPos | kRegNone
+    // search patterns only: [nClasses] state to RESUME a search in when the byte before the resume point has class c
+    // (only the wrapper's prefix thread is alive, no register is set); empty otherwise
+    std::vector<uint32_t> startAfter;
 };
 
 struct TdfaLimits {

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                            uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
                                                            const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ resume,
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
@@ -196,9 +197,20 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const bool live = slot < nLines;
     const uint32_t line = (live && order) ? order[slot] : slot;  // length-aware schedule (sched_kernel.hpp)
     uint32_t o = 0, L = 0;
+    uint32_t from = 0;  // search patterns: offset inside the line where this search resumes (0 = a fresh search)
     if (live) {
         o = off[line];
         L = len ? len[line] : off[line + 1] - o - sepBytes;
+        if (resume) {
+            from = resume[line];
+            from = from < L ? from : L;
+            if (from) {  // only the wrapper's prefix thread is alive; what it remembers is the class of the previous byte
+                const uint32_t* startAfter = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_STARTAFTER]);
+                t = startAfter[smem[TD_CMAP_OFFSET + data[size_t(o) + from - 1]] >> 2];
+                o += from;
+                L -= from;
+            }
+        }
     }
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 15);
@@ -283,8 +295,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         int32_t val = -1;
         if (matched && s < nSlots) {
             const uint32_t m = finalMap[fid * nSlots + s];
-            if (m == TD_REG_POS) val = int32_t(L);
-            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid]);
+            if (m == TD_REG_POS) val = int32_t(L + from);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
         }
         out[s] = val;
     }

@@ -39,11 +39,16 @@ static void cs_fold_case(cset* s) {
 static int is_word(int c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
 static int is_sep(int c) { return c == '\n' || c == '\r' || c == '\f'; }
 
+/* shorthand letters per dialect: regexp2 (RE2 option) knows \d \w \s only, and its \s has no \v */
+#define SH_LOWER(P) (((P)->flags & ORX_REGEXP2) ? "dws" : "dwshvlu")
+#define SH_UPPER(P) (((P)->flags & ORX_REGEXP2) ? "DWS" : "DWSHVLU")
+#define SH_KIND(P, e) ((((P)->flags & ORX_REGEXP2) && (e) == 's') ? 'r' : (e))
 static void cs_named(cset* s, int kind) { /* kind: 'd','w','s','h','v','l','u' */
     switch (kind) {
         case 'd': cs_range(s, '0', '9'); break;
         case 'w': cs_range(s, '0', '9'); cs_range(s, 'a', 'z'); cs_range(s, 'A', 'Z'); cs_add(s, '_'); break;
         case 's': cs_add(s, ' '); cs_range(s, 9, 13); break;
+        case 'r': cs_add(s, ' '); cs_add(s, '\t'); cs_add(s, '\n'); cs_add(s, '\f'); cs_add(s, '\r'); break; /* RE2's \s */
         case 'h': cs_add(s, ' '); cs_add(s, '\t'); break;
         case 'v': cs_range(s, 10, 13); break;
         case 'l': cs_range(s, 'a', 'z'); break;
@@ -71,7 +76,7 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 }
 
 /* ------------------------------------------------------------------ AST */
-enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC };
+enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC, N_LOOKAHEAD /* general (?=X) (?!X): max = negative */ };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
     A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
@@ -87,8 +92,8 @@ typedef struct {
     int set;           /* SET: index into sets */
 } node;
 
-#define ORX_MAX_GROUPS 255
-enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END };
+#define ORX_MAX_GROUPS 1023
+enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END, I_LOOK_BEGIN, I_LOOK_END, I_NLOOK_BEGIN, I_NLOOK_END };
 typedef struct { int op, x, y, z, w; } inst;
 /* I_REPSET: x=set, y=min, z=max(-1 inf), w=greedy */
 
@@ -220,8 +225,8 @@ static int parse_class(orx_prog* P) { /* P->i just after '[' */
             ++P->i;
             if (P->i >= P->n) { fail(P, "trailing backslash"); return -1; }
             int e = P->p[P->i++];
-            if (e && strchr("dwshvlu", e)) { cset t; cs_clear(&t); cs_named(&t, e); cs_or(&s, &t); continue; }
-            if (e && strchr("DWSHVLU", e)) { cset t; cs_clear(&t); cs_named(&t, e + 32); cs_not(&t); cs_or(&s, &t); continue; }
+            if (e && strchr(SH_LOWER(P), e)) { cset t; cs_clear(&t); cs_named(&t, SH_KIND(P, e)); cs_or(&s, &t); continue; }
+            if (e && strchr(SH_UPPER(P), e)) { cset t; cs_clear(&t); cs_named(&t, SH_KIND(P, e + 32)); cs_not(&t); cs_or(&s, &t); continue; }
             if (e == 'b') lo = 8;
             else {
                 int v = escape_byte(P, e);
@@ -281,7 +286,14 @@ static int parse_lookaround(orx_prog* P, int depth, int behind, int negative) {
     ++P->i;
     P->flags = saved;
     while (P->nodes[inner].kind == N_GROUP && P->nodes[inner].cap == 0) inner = P->nodes[inner].l;
-    if (P->nodes[inner].kind != N_SET) { fail(P, "unsupported: look-around body must be a single character class"); return -1; }
+    if (P->nodes[inner].kind != N_SET) {
+        /* a general look-AHEAD is just a sub-match the backtracker runs in place (atomic, zero-width) */
+        if (behind) { fail(P, "unsupported: look-behind body must be a single character class"); return -1; }
+        int la = new_node(P, N_LOOKAHEAD);
+        P->nodes[la].l = inner;
+        P->nodes[la].max = negative;
+        return la;
+    }
     int n = new_node(P, N_ASSERT);
     P->nodes[n].akind = A_LOOK;
     P->nodes[n].set = P->nodes[inner].set;
@@ -404,8 +416,10 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
             ++P->i;
             if (P->i >= P->n) { fail(P, "trailing backslash"); return -1; }
             int e = P->p[P->i++];
-            if (e && strchr("dwshvlu", e)) { cset s; cs_clear(&s); cs_named(&s, e); if (P->flags & ORX_ICASE) cs_fold_case(&s); return set_node(P, &s); }
-            if (e && strchr("DWSHVLU", e)) { cset s; cs_clear(&s); cs_named(&s, e + 32); if (P->flags & ORX_ICASE) cs_fold_case(&s); cs_not(&s); return set_node(P, &s); }
+            if (e && strchr(SH_LOWER(P), e)) { cset s; cs_clear(&s); cs_named(&s, SH_KIND(P, e)); if (P->flags & ORX_ICASE) cs_fold_case(&s); return set_node(P, &s); }
+            if (e && strchr(SH_UPPER(P), e)) { cset s; cs_clear(&s); cs_named(&s, SH_KIND(P, e + 32)); if (P->flags & ORX_ICASE) cs_fold_case(&s); cs_not(&s); return set_node(P, &s); }
+            if ((P->flags & ORX_REGEXP2) && e && strchr("<>`'", e)) return lit_node(P, e);   /* unknown escapes are the literal */
+            if ((P->flags & ORX_REGEXP2) && e == 'u') { fail(P, "unsupported escape"); return -1; }
             switch (e) {
                 case 'b': *is_assert = 1; return assert_node(P, A_WORDB);
                 case 'B': *is_assert = 1; return assert_node(P, A_NWORDB);
@@ -537,6 +551,7 @@ static int nullable(const orx_prog* P, int n) {
         case N_REP: return nd->min == 0 || nullable(P, nd->l);
         case N_GROUP: return nullable(P, nd->l);
         case N_ATOMIC: return nullable(P, nd->l);
+        case N_LOOKAHEAD: return 1;
     }
     return 1;
 }
@@ -567,6 +582,13 @@ static void gen(orx_prog* P, int n) {
             gen(P, nd.l);
             emit(P, I_ATOM_END, 0, 0);
             break;
+        case N_LOOKAHEAD: {
+            int b = emit(P, nd.max ? I_NLOOK_BEGIN : I_LOOK_BEGIN, 0, 0);
+            gen(P, nd.l);
+            emit(P, nd.max ? I_NLOOK_END : I_LOOK_END, 0, 0);
+            P->code[b].x = P->ncode; /* where a satisfied negative look-ahead continues */
+            break;
+        }
         case N_ASSERT: {
             int k = emit(P, I_ASSERT, nd.akind, nd.set);
             P->code[k].z = nd.min; P->code[k].w = nd.max;
@@ -640,7 +662,7 @@ int orx_mark_count(const orx_prog* P) { return P->ngroups; }
 const char* orx_group_name(const orx_prog* P, int g) { return (g >= 1 && g <= P->ngroups) ? P->names[g] : NULL; }
 
 /* ------------------------------------------------------------------ matcher */
-enum { F_ALT, F_UNDO_CAP, F_UNDO_LOOP, F_REP_GREEDY, F_REP_LAZY, F_ATOM_MARK };
+enum { F_ALT, F_UNDO_CAP, F_UNDO_LOOP, F_REP_GREEDY, F_REP_LAZY, F_ATOM_MARK, F_LOOK_MARK /* b=pos */, F_NLOOK_MARK /* a=pc after, b=pos */ };
 typedef struct { int kind; int a; long b; long c; } frame;
 /* F_ALT: a=pc, b=pos | F_UNDO_*: a=slot, b=old | F_REP_GREEDY: a=pc_next, b=low, c=cur | F_REP_LAZY: a=pc (of REPSET), b=cur pos, c=count */
 
@@ -738,6 +760,31 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
                 st->n = w;
                 ++pc; continue;
             }
+            case I_LOOK_BEGIN: push(st, F_LOOK_MARK, 0, pos, 0); ++pc; continue;
+            case I_LOOK_END: {
+                /* body matched: commit like an atomic group (captures made inside stay), but give the input back */
+                size_t m = st->n;
+                while (m > 0 && st->v[m - 1].kind != F_LOOK_MARK) --m;
+                --m;
+                pos = st->v[m].b;
+                size_t w = m;
+                for (size_t r = m + 1; r < st->n; ++r)
+                    if (st->v[r].kind == F_UNDO_CAP || st->v[r].kind == F_UNDO_LOOP) st->v[w++] = st->v[r];
+                st->n = w;
+                ++pc; continue;
+            }
+            case I_NLOOK_BEGIN: push(st, F_NLOOK_MARK, in->x, pos, 0); ++pc; continue;
+            case I_NLOOK_END: {
+                /* body matched, so the assertion fails: unwind everything the body did, mark included, and backtrack */
+                for (;;) {
+                    frame* f = &st->v[st->n - 1];
+                    if (f->kind == F_UNDO_CAP) caps[f->a] = (int32_t)f->b;
+                    else if (f->kind == F_UNDO_LOOP) loopregs[f->a] = f->b;
+                    --st->n;
+                    if (f->kind == F_NLOOK_MARK) break;
+                }
+                goto backtrack;
+            }
             case I_ASSERT:
                 if (in->x == A_LOOK) {
                     int hit = in->z ? (pos > 0 && cs_has(&P->sets[in->y], s[pos - 1]))
@@ -757,7 +804,8 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
             frame* f = &st->v[st->n - 1];
             if (f->kind == F_UNDO_CAP) { caps[f->a] = (int32_t)f->b; --st->n; continue; }
             if (f->kind == F_UNDO_LOOP) { loopregs[f->a] = f->b; --st->n; continue; }
-            if (f->kind == F_ATOM_MARK) { --st->n; continue; }
+            if (f->kind == F_ATOM_MARK || f->kind == F_LOOK_MARK) { --st->n; continue; }
+            if (f->kind == F_NLOOK_MARK) { pc = f->a; pos = f->b; --st->n; break; } /* body cannot match: assertion holds */
             if (f->kind == F_ALT) { pc = f->a; pos = f->b; --st->n; break; }
             if (f->kind == F_REP_GREEDY) {
                 --f->c;

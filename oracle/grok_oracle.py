@@ -1,0 +1,173 @@
+"""oracle/grok_oracle.py -- CPU restatement of the Go Grok plugin.  TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+Follows plugins/processor/grok/processor_grok.go of the reference:
+  Init / addPatterns* / buildPatterns / denormalizePattern / aliasizePatternName     :62-102, :197-323
+  processLog / processGrok (ordered Match list, FindStringMatch + FindNextMatch, named non-empty groups)  :115-194
+The regex engine of the reference is github.com/dlclark/regexp2 v1.11.5 compiled with the RE2 option (go.mod:19,
+processor_grok.go:343) -- a backtracking .NET-style matcher that is not vendored in /root/reference.  Its published
+behaviour is restated on top of oracle/bt_regex.c (flags ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2):
+  * leftmost-first search; '.' does not match '\\n'; '^' '$' only at the ends (RE2 option: '$' is end of text only);
+  * FindNextMatch resumes at the end of the previous match, one further if that match was empty, and look-behinds see
+    the text before the resume point;
+  * Groups(): unnamed groups first, then named groups in order of first appearance; groups sharing a name are one
+    group whose value is its last capture.  Only named groups with a non-empty value are emitted.
+Bytes, not runes: '.' and negated classes consume one byte, so results agree with regexp2 on UTF-8 input whenever such
+atoms sit under * or + (every pattern of the default library), not for counted repeats of non-ASCII text.
+Parity status: pinned on the reference's own test vectors (tests/golden/grok_expansions.json, the parse vectors of
+processor_grok_test.go:119-373 replayed in tests/test_grok_host.py) and on vectors from the Python `regex` module
+(tests/golden/gen_grok_golden.py); NOT run against regexp2 itself (no Go toolchain here): parity unpinned in that sense.
+"""
+import os
+import re
+
+from oracle.oracle import ORX_NO_MOD_M, ORX_NO_MOD_S, ORX_REGEXP2, OracleRegex
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULTS_PATH = os.path.join(_HERE, "..", "loongcollector_amd", "data", "grok_default_patterns.txt")
+
+_NORMAL = re.compile(r"%{([\w.-]+(?::[\w.-]+(?::[\w.-]+)?)?)}", re.ASCII)                      # :380
+_VALID = re.compile(r"^\w+([-.]\w+)*(:([-.\w]+)(:(string|float|int))?)?$", re.ASCII)           # :379
+_SYMBOLIC = re.compile(r"\W", re.ASCII)                                                         # :381
+
+MATCH_SUCCESS, MATCH_FAIL = 0, 1
+
+
+def read_pattern_text(text):
+    out = {}
+    for line in text.split("\n"):
+        line = line.rstrip("\r")
+        if line and line[0] != '"':                      # :219
+            name, pat = line.split(" ", 1)
+            out[name] = pat
+    return out
+
+
+def default_patterns():
+    with open(DEFAULTS_PATH, encoding="utf-8") as f:
+        return {k: v for k, v in read_pattern_text(f.read()).items() if k != "#"}
+
+
+class GrokOracle:
+    def __init__(self, match, custom_patterns=None, custom_pattern_dirs=(), source_key="content",
+                 ignore_parse_failure=True, keep_source=True):
+        self.source_key = source_key
+        self.ignore_parse_failure = ignore_parse_failure
+        self.keep_source = keep_source
+        self.original = default_patterns()                                   # :68
+        for path in custom_pattern_dirs:                                     # :70-78
+            if not os.path.exists(path):
+                raise ValueError("invalid path :" + path)
+            files = sorted(os.path.join(path, f) for f in os.listdir(path) if not f.startswith(".")) \
+                if os.path.isdir(path) else [path]
+            batch = {}
+            for fn in files:
+                if os.path.isfile(fn):
+                    with open(fn, encoding="utf-8") as f:
+                        batch.update(read_pattern_text(f.read()))
+            self.original.update(batch)
+        self.original.update(custom_patterns or {})                          # :80-82
+        self.aliases = {}
+        self.processed = {}
+        self._build()                                                        # :84
+        self.expanded = [self._denormalize(m) for m in match]                # :335-341
+        self.compiled = [OracleRegex(e.encode("utf-8"), ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2) for e in self.expanded]
+        # Groups() order of the named groups: first appearance; same-named groups are merged
+        self.fields = []
+        for rx in self.compiled:
+            names, slots = [], {}
+            for g in range(1, rx.groups + 1):
+                nm = rx.group_name(g)
+                if nm and not nm.isdigit():                                   # :169 strconv.ParseInt(name) fails
+                    if nm not in slots:
+                        names.append(nm)
+                        slots[nm] = []
+                    slots[nm].append(g)
+            self.fields.append([(nm, slots[nm]) for nm in names])
+
+    # -- buildPatterns :239-279
+    def _build(self):
+        graph = {}
+        for k, v in self.original.items():
+            deps = []
+            for tok in _NORMAL.findall(v):
+                if not _VALID.match(tok):
+                    raise ValueError("invalid pattern " + tok)
+                syntax = tok.split(":")[0]
+                if syntax not in self.original:
+                    raise ValueError("no pattern found for " + syntax)
+                deps.append(syntax)
+            graph[k] = deps
+        done, open_, order = set(), set(), []
+
+        def visit(node):
+            if node in done:
+                return
+            if node in open_:
+                raise ValueError("cannot build patterns because cyclic exist" + node)
+            open_.add(node)
+            for m in graph[node]:
+                visit(m)
+            open_.discard(node)
+            done.add(node)
+            order.append(node)
+
+        for k in sorted(graph):
+            visit(k)
+        for k in order:
+            self.processed[k] = self._denormalize(self.original[k])
+
+    # -- denormalizePattern :282-316
+    def _denormalize(self, pattern):
+        for m in list(_NORMAL.finditer(pattern)):
+            tok = m.group(1)
+            if not _VALID.match(tok):
+                raise ValueError("invalid pattern " + tok)
+            names = tok.split(":")
+            if names[0] not in self.processed:
+                raise ValueError("no pattern found for " + names[0])
+            stored = self.processed[names[0]]
+            if len(names) > 1:
+                alias = _SYMBOLIC.sub("_", names[1])                          # :319-323
+                self.aliases[alias] = names[1]
+                repl = "(?P<" + alias + ">" + stored + ")"
+            else:
+                repl = "(" + stored + ")"
+            pattern = pattern.replace(m.group(0), repl)
+        return pattern
+
+    # -- processGrok :148-194 on one value; -> (result, [(key, value bytes)])
+    def process_value(self, val):
+        for rx, fields in zip(self.compiled, self.fields):
+            out = []
+            start, n = 0, len(val)
+            while start <= n:
+                caps = rx.search(val, start)
+                if caps is None:
+                    break
+                for name, groups in fields:
+                    live = [caps[g] for g in groups if caps[g][0] >= 0]
+                    if not live:
+                        continue
+                    b, e = max(live, key=lambda be: be[0])   # "last capture" of a merged group: the one furthest along
+                    if e > b:
+                        out.append((self.aliases.get(name, name), val[b:e]))
+                b0, e0 = caps[0]
+                start = e0 if e0 > b0 else e0 + 1              # FindNextMatch
+            if out:
+                return MATCH_SUCCESS, out
+        return MATCH_FAIL, []
+
+    # -- processLog :115-146 on one log given as a list of (key, value bytes); returns the new list.
+    # `range log.Contents` walks the contents the log had on entry; fields are appended behind them; the source is
+    # removed by its index.  (With several contents under SourceKey the Go code's result depends on slice capacity --
+    # the ranged-over array may or may not be the one being shifted; that case is left unspecified here too.)
+    def process_log(self, contents):
+        contents = list(contents)
+        for i, (key, value) in enumerate(list(contents)):
+            if not self.source_key or self.source_key == key:
+                res, fields = self.process_value(value)
+                contents.extend(fields)
+                if (res == MATCH_SUCCESS and not self.keep_source) or (res != MATCH_SUCCESS and not self.ignore_parse_failure):
+                    if i < len(contents):
+                        del contents[i]
+        return contents

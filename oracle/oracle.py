@@ -16,6 +16,7 @@ ORX_ICASE = 1
 ORX_NO_MOD_S = 2
 ORX_NO_MOD_M = 4
 ORX_EXTENDED = 8
+ORX_REGEXP2 = 16
 
 
 def build(force=False):

@@ -20,12 +20,16 @@ class TdfaInterp:
         self.ops = rx.table(B.LC_TABLE_TDFA_OPS, np.uint16)
         self.final_id = rx.table(B.LC_TABLE_TDFA_FINALID, np.uint16)
         self.final_map = rx.table(B.LC_TABLE_TDFA_FINALMAP, np.uint8)
+        self.start_after = rx.table(B.LC_TABLE_TDFA_STARTAFTER, np.uint32)  # None unless a search pattern
 
-    def fullmatch(self, s: bytes):
-        """-> flat caps [b1,e1,b2,e2,...] for groups 1..G, or None"""
-        state = self.start
+    def fullmatch(self, s: bytes, start=0):
+        """-> flat caps [b1,e1,b2,e2,...] for groups 1..G, or None.  start > 0 (search patterns only): resume the search
+        at that offset, seeing the byte before it (what the kernels do for lc_regex_match_device_from)."""
+        state = self.start if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]])])
         regs = [-1] * (self.nregs + 1)
         for pos, b in enumerate(s):
+            if pos < start:
+                continue
             t = int(self.trans[state * self.ncls + int(self.cmap[b])])
             lst = t >> 16
             if lst:
@@ -72,10 +76,17 @@ class NfaInterp:
                 lst.append((-1 if tgt == 0xFFFFFFFF else tgt, cond, lo | (hi << 32)))
             self.follow.append(lst)
 
-    def fullmatch(self, s: bytes, max_threads=64):
+    def fullmatch(self, s: bytes, max_threads=64, start=0):
+        """start > 0 (search patterns only): resume at that offset -- one thread on the wrapper's prefix position
+        (position 0), having just consumed the byte before the resume point."""
         threads = [(self.npos, [-1] * self.nslots)]  # (position, caps)
         prev_cls = self.ncls                     # edge entry: start of input
+        if start:
+            threads = [(0, [-1] * self.nslots)]
+            prev_cls = int(self.cmap[s[start - 1]])
         for pos, b in enumerate(s):
+            if pos < start:
+                continue
             cls = int(self.cmap[b])
             holds = self.behind[prev_cls] | self.ahead[cls]
             new, seen = [], set()
