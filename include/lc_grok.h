@@ -1,0 +1,90 @@
+/*
+ * lc_grok.h -- C ABI of the MI355X-native Grok processor.
+ *
+ * Replaces, behind plain pointers and sizes, the Go plugin plugins/processor/grok/processor_grok.go of the reference:
+ *   lc_grok_create          <- ProcessorGrok.Init                     :62-102  (defaults + CustomPatternDir + CustomPatterns,
+ *                                                                               buildPatterns :239-279, compileMatchs :335-359)
+ *   lc_grok_match_device /  <- the loop of ProcessLogs -> processLog -> processGrok   :108-194: for every log the ordered
+ *   lc_grok_match_host         Match list, FindStringMatch + FindNextMatch, first pattern that yields a named non-empty
+ *                              capture wins.  One batch = the SourceKey values of many logs.
+ *   lc_grok_process_logs_json <- ProcessLogs including the KeepSource / IgnoreParseFailure policy :115-146 (tests, tools)
+ * The reference-side binding (cgo) is shown in INTEGRATION.md.
+ *
+ * What is matched on the device: each Match entry is expanded (%{SYNTAX:alias} -> (?P<alias>...)) and compiled with
+ * LC_SYNTAX_SEARCH | LC_SYNTAX_NAMED_ONLY | LC_SYNTAX_NO_DOTALL | LC_SYNTAX_NO_MULTILINE | LC_SYNTAX_REGEXP2 -- the
+ * semantics of regexp2.Compile(pattern, regexp2.RE2) as far as byte-oriented automata can give them (bytes
+ * not runes, no back-references, one-byte look-arounds, no time-outs because nothing backtracks).  A Match entry the
+ * device engines cannot run makes lc_grok_create FAIL with the reason: there is no CPU path.
+ */
+#ifndef LC_GROK_H
+#define LC_GROK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lc_grok lc_grok_t;
+typedef struct lc_grok_result lc_grok_result_t;
+
+/* config_json: the plugin's JSON detail, same keys as the Go struct (processor_grok.go:42-53):
+ *   {"CustomPatternDir": [...], "CustomPatterns": {...}, "SourceKey": "content", "Match": [...],
+ *    "IgnoreParseFailure": true, "KeepSource": true, "TimeoutMilliSeconds": 0, ...}
+ * Returns LC_OK (0) or an LC_ERR_* code (lc_regex_gpu.h); err receives the message ("no pattern found for X",
+ * "cannot build patterns because cyclic exist...", "Match[3]: tdfa: state limit exceeded; nfa: ..."). */
+int lc_grok_create(const char* config_json, size_t config_len, lc_grok_t** out, char* err, size_t errcap);
+void lc_grok_free(lc_grok_t* g);
+
+int lc_grok_match_count(const lc_grok_t* g);                       /* len(Match) */
+const char* lc_grok_expanded(const lc_grok_t* g, int i);           /* Match[i] after denormalizePattern (:282-316) */
+const char* lc_grok_processed(const lc_grok_t* g, const char* name); /* processedPatterns[name], NULL if unknown */
+/* denormalizePattern on any expression against this handle's library, without compiling it (malloc'ed, release with
+ * lc_grok_free_string; NULL + err on "no pattern found for X" / "invalid pattern X") */
+char* lc_grok_denormalize(lc_grok_t* g, const char* pattern, char* err, size_t errcap);
+int lc_grok_engine(const lc_grok_t* g, int i);                     /* LC_ENGINE_TDFA / LC_ENGINE_NFA chosen for Match[i] */
+
+/* Emitted keys.  A match of Match[i] writes one capture column per NAMED group; columns that share a name are one field
+ * (regexp2 merges same-named groups, the value is the one captured furthest along).  Keys are already mapped back through
+ * nameToAlias (:326-332), e.g. group `english_word` -> key "english-word". */
+int lc_grok_key_count(const lc_grok_t* g);                         /* distinct emitted keys over all Match entries */
+const char* lc_grok_key(const lc_grok_t* g, int key);
+int lc_grok_column_count(const lc_grok_t* g, int i);               /* named groups of Match[i] */
+int lc_grok_column_key(const lc_grok_t* g, int i, int column);     /* key index of that column */
+int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per capture row: 2 * (1 + max column count) */
+
+/* ---- device-resident batch (inputs and outputs in HBM; nothing is copied) ------------------------------------------
+ * d_off/d_len: uint32[n] byte offsets / lengths of the SourceKey values inside d_data.
+ * d_pattern  int32[n]            winning Match index, -1 = matchFail, -2 = undecidable on the device (the NFA engine ran out
+ *                                of its 64 threads on this value)
+ * d_first    int32[n][row]       capture row of the FIRST match that contributed a non-empty named capture:
+ *                                [whole.b, whole.e, col0.b, col0.e, ...], -1 = column did not take part
+ * d_extra    int32[cap][2+row]   further contributing matches of the same value (FindNextMatch): [line, seq>=1, row...]
+ * d_nextra   uint32[1]           rows written to d_extra; > cap means d_extra was too small (LC_ERR_OVERFLOW is returned
+ *                                and the call must be repeated with a larger d_extra)
+ * d_scratch  lc_grok_scratch_bytes(g, n) bytes
+ * The call enqueues on `stream` but synchronises with the host between rounds (it has to learn how many values are still
+ * in play); it returns after the last kernel has finished. */
+size_t lc_grok_scratch_bytes(const lc_grok_t* g, uint32_t n);
+int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
+                         int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extra_cap, uint32_t* d_nextra,
+                         void* d_scratch, size_t scratch_bytes, void* stream);
+
+/* ---- host batch: copies in, matches on the device, returns the fields of every value in emission order --------------- */
+int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                       int32_t* pattern /* [n], as d_pattern */, lc_grok_result_t** result);
+/* fields of value i: indices field_off[i] .. field_off[i+1]) into key[] / begin[] / end[] (byte range inside value i) */
+void lc_grok_result_arrays(const lc_grok_result_t* r, const uint32_t** field_off, const uint32_t** key,
+                           const uint32_t** begin, const uint32_t** end);
+void lc_grok_result_free(lc_grok_result_t* r);
+
+/* ---- whole-plugin behaviour on JSON logs (tests / tools): [[["content","..."],["k","v"]], ...] in, same shape out.
+ * *out_json is malloc'ed; release with lc_grok_free_string. */
+int lc_grok_process_logs_json(lc_grok_t* g, const char* logs_json, size_t len, char** out_json);
+void lc_grok_free_string(char* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LC_GROK_H */

@@ -75,7 +75,8 @@ enum {
     LC_ERR_UNSUPPORTED = 2,  /* valid Perl regex but not executable bit-exactly on the device engines */
     LC_ERR_NO_DEVICE = 3,
     LC_ERR_HIP = 4,
-    LC_ERR_ARG = 5
+    LC_ERR_ARG = 5,
+    LC_ERR_OVERFLOW = 6      /* a caller-provided output buffer was too small; the needed size has been reported */
 };
 
 typedef struct lc_regex_info {

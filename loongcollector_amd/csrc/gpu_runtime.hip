@@ -18,6 +18,8 @@
 #include <vector>
 
 #include "device_tables.h"
+#include "grok_kernel.hpp"
+#include "grok_runtime.hpp"
 #include "nfa_kernel.hpp"
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
@@ -161,7 +163,8 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
 
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
-                         int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
+                         int32_t* d_caps, uint8_t* d_status, void* streamPtr) {
+    hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
@@ -505,4 +508,174 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
     src.ptrs = lines;
     src.len = len;
     return runHostPipeline(re, src, n, ngroups, caps, status);
+}
+
+// ------------------------------------------------------------------------------------------------ Grok matcher
+// Batch form of ProcessorGrok.processGrok (processor_grok.go:148-194); the control flow is described in grok_kernel.hpp.
+// Scratch layout: caps int32[n][row] | status u8[n] (padded) | from, nmatch, tried, next, roundA, roundB : u32[n] each |
+// counters u32[4].
+namespace {
+size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
+    const size_t m = n ? n : 1;
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 6 * alignUp(m * 4, 256) + 256;
+}
+
+int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* d_data,
+                      const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern, int32_t* d_first,
+                      int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch, size_t scratchBytes,
+                      void* streamPtr) {
+    if (n == 0) return LC_OK;
+    if (!d_data || !d_off || !d_len || !d_pattern || !d_first || !d_nextra || !d_scratch || (extraCap && !d_extra))
+        return LC_ERR_ARG;
+    if (scratchBytes < lcGrokScratchBytes(n, row)) {
+        tlsError = "grok: scratch buffer too small";
+        return LC_ERR_ARG;
+    }
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(streamPtr);
+
+    uint8_t* base = static_cast<uint8_t*>(d_scratch);
+    int32_t* caps = reinterpret_cast<int32_t*>(base);
+    base += alignUp(size_t(n) * row * 4, 256);
+    uint8_t* status = base;
+    base += alignUp(n, 256);
+    uint32_t* lists[6];
+    for (auto& l : lists) {
+        l = reinterpret_cast<uint32_t*>(base);
+        base += alignUp(size_t(n) * 4, 256);
+    }
+    uint32_t *from = lists[0], *nmatch = lists[1], *tried = lists[2], *next = lists[3], *roundIn = lists[4],
+             *roundOut = lists[5];
+    uint32_t* counters = reinterpret_cast<uint32_t*>(base);
+
+    const uint32_t gridAll = (n + kGrokBlock - 1) / kGrokBlock;
+    hipLaunchKernelGGL(grok_init_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, n, d_pattern, tried, from, nmatch);
+    HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
+    HIP_TRY(hipMemsetAsync(counters, 0, 16, st));
+
+    uint32_t nTried = n;
+    uint32_t host[4] = {0, 0, 0, 0};
+    for (size_t p = 0; p < patterns.size() && nTried; ++p) {
+        const GrokDevicePattern& gp = patterns[p];
+        const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte
+        uint32_t nIn = nTried;
+        uint32_t* outs[2] = {roundIn, roundOut};
+        int flip = 0;
+        while (nIn) {
+            int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, row / 2, caps,
+                                     status, st);
+            if (rc != LC_OK) return rc;
+            uint32_t* out = outs[flip];
+            hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in,
+                               nIn, status, caps, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap,
+                               out, counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            nIn = host[0];
+            in = out;
+            flip ^= 1;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));  // counters[0] only; the extra-row count keeps running
+        }
+        hipLaunchKernelGGL(grok_finish_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
+                           nTried, int32_t(p), nmatch, d_pattern, from, next, counters);
+        HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        nTried = host[2];
+        std::swap(tried, next);
+        HIP_TRY(hipMemsetAsync(counters + 2, 0, 4, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d_nextra, counters + 1, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (host[1] > extraCap) {
+        tlsError = "grok: " + std::to_string(host[1]) + " extra match rows needed, buffer holds " + std::to_string(extraCap);
+        return LC_ERR_OVERFLOW;
+    }
+    return LC_OK;
+}
+
+int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* data, const uint32_t* off,
+                    const uint32_t* len, uint32_t n, int32_t* pattern, std::vector<int32_t>& first,
+                    std::vector<int32_t>& extraRows) {
+    first.clear();
+    extraRows.clear();
+    if (n == 0) return LC_OK;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    // pack the values back to back (they may come from anywhere in `data`)
+    std::vector<uint32_t> hOff(n);
+    size_t bytes = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        hOff[i] = uint32_t(bytes);
+        bytes += len[i];
+    }
+    if (bytes > 0xFFFFFFF0ull) return LC_ERR_ARG;
+    std::vector<uint8_t> hData(bytes + 16);
+    for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
+
+    struct Dev {
+        void* p = nullptr;
+        ~Dev() {
+            if (p) (void)hipFree(p);
+        }
+    } dData, dOff, dLen, dPattern, dFirst, dExtra, dNextra, dScratch;
+    const size_t scratch = lcGrokScratchBytes(n, row);
+    uint32_t extraCap = n / 4 + 1024;
+    HIP_TRY(hipMalloc(&dData.p, bytes + 16));
+    HIP_TRY(hipMalloc(&dOff.p, size_t(n) * 4));
+    HIP_TRY(hipMalloc(&dLen.p, size_t(n) * 4));
+    HIP_TRY(hipMalloc(&dPattern.p, size_t(n) * 4));
+    HIP_TRY(hipMalloc(&dFirst.p, size_t(n) * row * 4));
+    HIP_TRY(hipMalloc(&dNextra.p, 4));
+    HIP_TRY(hipMalloc(&dScratch.p, scratch));
+    HIP_TRY(hipMemcpy(dData.p, hData.data(), bytes + 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dOff.p, hOff.data(), size_t(n) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dLen.p, len, size_t(n) * 4, hipMemcpyHostToDevice));
+    uint32_t nExtra = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (dExtra.p) {
+            (void)hipFree(dExtra.p);
+            dExtra.p = nullptr;
+        }
+        HIP_TRY(hipMalloc(&dExtra.p, size_t(extraCap) * (row + 2) * 4));
+        int rc = lcGrokMatchDevice(patterns, row, static_cast<const uint8_t*>(dData.p), static_cast<const uint32_t*>(dOff.p),
+                                   static_cast<const uint32_t*>(dLen.p), n, static_cast<int32_t*>(dPattern.p),
+                                   static_cast<int32_t*>(dFirst.p), static_cast<int32_t*>(dExtra.p), extraCap,
+                                   static_cast<uint32_t*>(dNextra.p), dScratch.p, scratch, nullptr);
+        HIP_TRY(hipMemcpy(&nExtra, dNextra.p, 4, hipMemcpyDeviceToHost));
+        if (rc == LC_ERR_OVERFLOW && attempt == 0) {
+            extraCap = nExtra;  // the exact number is known now
+            continue;
+        }
+        if (rc != LC_OK) return rc;
+        break;
+    }
+    first.resize(size_t(n) * row);
+    HIP_TRY(hipMemcpy(pattern, dPattern.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first.data(), dFirst.p, size_t(n) * row * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> raw(size_t(nExtra) * (row + 2));
+    if (nExtra) HIP_TRY(hipMemcpy(raw.data(), dExtra.p, raw.size() * 4, hipMemcpyDeviceToHost));
+    // rows arrive in atomic order: sort by (line, seq)
+    std::vector<uint32_t> idx(nExtra);
+    for (uint32_t i = 0; i < nExtra; ++i) idx[i] = i;
+    const size_t w = row + 2;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (raw[a * w] != raw[b * w]) return raw[a * w] < raw[b * w];
+        return raw[a * w + 1] < raw[b * w + 1];
+    });
+    extraRows.resize(raw.size());
+    for (uint32_t i = 0; i < nExtra; ++i) std::memcpy(&extraRows[i * w], &raw[idx[i] * w], w * 4);
+    return LC_OK;
 }

@@ -1,0 +1,100 @@
+// grok_kernel.hpp -- bookkeeping kernels of the Grok matcher (gpu_runtime.hip: lcGrokMatchDevice).
+//
+// The matching itself is done by the regex kernels (tdfa_match_kernel / nfa_match_kernel) in their "subset of lines,
+// resumed search" mode.  What is restated here is the control flow of ProcessorGrok.processGrok
+// (plugins/processor/grok/processor_grok.go:148-194) for a whole batch at once:
+//     for each Match pattern, in order:            <- host loop, one pass per pattern over the values still undecided
+//         m = FindStringMatch(value)               <- round 0 of the pattern
+//         while m != nil: collect named non-empty groups; m = FindNextMatch(m)      <- further rounds (resume offsets)
+//         if anything was collected: this pattern wins, stop
+// Pure index/flag work, a few bytes per value per round: HBM-bound, no LDS, no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/lc_regex_gpu.h"
+
+constexpr int kGrokBlock = 256;
+
+// every value starts undecided, in play for Match[0], searching from its first byte
+__global__ __launch_bounds__(kGrokBlock) void grok_init_kernel(uint32_t n, int32_t* __restrict__ pattern,
+                                                              uint32_t* __restrict__ tried, uint32_t* __restrict__ from,
+                                                              uint32_t* __restrict__ nmatch) {
+    const uint32_t i = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (i >= n) return;
+    pattern[i] = -1;
+    tried[i] = i;
+    from[i] = 0;
+    nmatch[i] = 0;
+}
+
+// After one round of searches over the values listed in `in`:
+//   * a match that holds a non-empty named capture is recorded (first one -> `first`, later ones -> `extra`);
+//   * FindNextMatch: the value stays in play from the end of this match (one further after an empty match) unless
+//     that is the end of the value -- a match starting there is empty and contributes nothing;
+//   * LC_OVERFLOW (NFA engine out of threads): the value is undecidable here, pattern = -2, dropped from play.
+// counters[0] = values in `out`, counters[1] = rows wanted in `extra`.
+__global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
+    const uint32_t* __restrict__ in, uint32_t nIn, const uint8_t* __restrict__ status, const int32_t* __restrict__ caps,
+    uint32_t row, uint32_t columns, const uint32_t* __restrict__ len, uint32_t* __restrict__ from,
+    uint32_t* __restrict__ nmatch, int32_t* __restrict__ pattern, int32_t* __restrict__ first,
+    int32_t* __restrict__ extra, uint32_t extraCap, uint32_t* __restrict__ out, uint32_t* __restrict__ counters) {
+    const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t line = in[k];
+    const uint8_t st = status[line];
+    if (st == LC_OVERFLOW) {
+        pattern[line] = -2;
+        return;
+    }
+    if (st != LC_MATCH) return;
+    const int32_t* c = caps + size_t(line) * row;
+    bool contributes = false;
+    for (uint32_t g = 1; g <= columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
+    if (contributes) {
+        const uint32_t seq = nmatch[line]++;
+        int32_t* dst = nullptr;
+        if (seq == 0) {
+            dst = first + size_t(line) * row;
+        } else {
+            const uint32_t at = atomicAdd(&counters[1], 1u);
+            if (at < extraCap) {
+                dst = extra + size_t(at) * (row + 2);
+                dst[0] = int32_t(line);
+                dst[1] = int32_t(seq);
+                dst += 2;
+            }
+        }
+        if (dst) {
+            for (uint32_t s = 0; s < 2 * (columns + 1); ++s) dst[s] = c[s];
+            for (uint32_t s = 2 * (columns + 1); s < row; ++s) dst[s] = -1;
+        }
+    }
+    const uint32_t b = uint32_t(c[0]), e = uint32_t(c[1]);
+    const uint32_t next = e > b ? e : e + 1;
+    if (next < len[line]) {
+        from[line] = next;
+        out[atomicAdd(&counters[0], 1u)] = line;
+    }
+}
+
+// After the last round of pattern p over the values in `tried`: values that collected something are decided, the others
+// go on to the next pattern with a fresh search.  counters[2] = values in `next`.
+__global__ __launch_bounds__(kGrokBlock) void grok_finish_kernel(const uint32_t* __restrict__ tried, uint32_t nTried,
+                                                                int32_t p, const uint32_t* __restrict__ nmatch,
+                                                                int32_t* __restrict__ pattern, uint32_t* __restrict__ from,
+                                                                uint32_t* __restrict__ next,
+                                                                uint32_t* __restrict__ counters) {
+    const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (k >= nTried) return;
+    const uint32_t line = tried[k];
+    if (pattern[line] == -2) return;
+    if (nmatch[line]) {
+        pattern[line] = p;
+    } else {
+        from[line] = 0;
+        next[atomicAdd(&counters[2], 1u)] = line;
+    }
+}

@@ -1,0 +1,28 @@
+// grok_runtime.hpp -- device half of the Grok matcher (implemented in gpu_runtime.hip).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+struct lc_regex;
+
+// One compiled Match entry as the device loop needs it.
+struct GrokDevicePattern {
+    lc_regex* re;        // compiled with LC_SYNTAX_SEARCH | LC_SYNTAX_NAMED_ONLY: group 1 = whole match, 2.. = named groups
+    uint32_t columns;    // named groups
+};
+
+size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts);
+
+// See include/lc_grok.h: lc_grok_match_device.  rowInts = 2 * (1 + max columns).
+int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t rowInts, const uint8_t* d_data,
+                      const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern, int32_t* d_first,
+                      int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch, size_t scratchBytes,
+                      void* stream);
+
+// pinned-host convenience used by lc_grok_match_host: copies in, runs lcGrokMatchDevice, copies out.
+// extraRows receives [line, seq, row...] records sorted by (line, seq).
+int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t rowInts, const uint8_t* data,
+                    const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern, std::vector<int32_t>& first,
+                    std::vector<int32_t>& extraRows);

@@ -1,0 +1,363 @@
+// processor_grok_gpu.cpp -- see processor_grok_gpu.hpp and include/lc_grok.h.
+#include "processor_grok_gpu.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/lc_grok.h"
+#include "../../include/lc_regex_gpu.h"
+#include "json_min.hpp"
+#include "regex_handle.hpp"
+
+namespace lcgrok {
+
+namespace {
+// regexp2.Compile(pattern, regexp2.RE2) (processor_grok.go:343) as the device compilers understand it, searched
+// leftmost-first, only named groups capturing (the numbered ones are never emitted, :169)
+constexpr uint32_t kGrokSyntax =
+    LC_SYNTAX_SEARCH | LC_SYNTAX_NAMED_ONLY | LC_SYNTAX_NO_DOTALL | LC_SYNTAX_NO_MULTILINE | LC_SYNTAX_REGEXP2;
+
+bool allDigits(const std::string& s) {  // strconv.ParseInt(name, 10, 32) succeeds (:169) -> numbered group, skipped
+    if (s.empty()) return false;
+    size_t i = (s[0] == '-' || s[0] == '+') ? 1 : 0;
+    if (i == s.size()) return false;
+    for (; i < s.size(); ++i)
+        if (s[i] < '0' || s[i] > '9') return false;
+    return true;
+}
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+}  // namespace
+
+ProcessorGrokGpu::~ProcessorGrokGpu() {
+    for (lc_regex* re : mCompiled) lc_regex_free(re);
+}
+
+int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCompiled[i]->engine : 0; }
+
+void ProcessorGrokGpu::Init() {
+    for (lc_regex* re : mCompiled) lc_regex_free(re);
+    mCompiled.clear();
+    mDevice.clear();
+    mExpanded.clear();
+    mKeys.clear();
+    mColumnKey.clear();
+    mFields.clear();
+    mLibrary = PatternLibrary();
+    mLibrary.addDefaults();                                               // :68
+    for (const auto& path : CustomPatternDir) mLibrary.addFromPath(path); // :70-78
+    for (const auto& kv : CustomPatterns) mLibrary.add(kv.first, kv.second);  // :80-82
+    mLibrary.build();                                                     // :84
+    if (TimeoutMilliSeconds <= 0) TimeoutMilliSeconds = 100;              // :91-93 (kept for config parity: nothing here
+                                                                          // backtracks, so nothing can time out)
+    std::map<std::string, uint32_t> keyIndex;
+    uint32_t maxColumns = 0;
+    for (size_t i = 0; i < Match.size(); ++i) {                            // compileMatchs :335-359
+        mExpanded.push_back(mLibrary.denormalize(Match[i]));
+        lc_regex_t* re = nullptr;
+        char err[512];
+        int rc = lc_regex_compile(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, LC_ENGINE_AUTO, &re, err,
+                                  sizeof err);
+        if (rc != LC_OK) throw GrokError("Match[" + std::to_string(i) + "] " + Match[i] + ": " + err);
+        mCompiled.push_back(re);
+        const uint32_t columns = uint32_t(lc_regex_mark_count(re)) - 1;   // group 1 is the whole match
+        maxColumns = std::max(maxColumns, columns);
+        mDevice.push_back({re, columns});
+        std::vector<uint32_t> colKey(columns, kNoKey);
+        std::vector<MergedField> fields;
+        std::map<std::string, size_t> byName;
+        for (uint32_t c = 0; c < columns; ++c) {
+            const char* nm = lc_regex_group_name(re, int(c) + 2);
+            const std::string name = nm ? nm : "";
+            if (name.empty() || allDigits(name)) continue;
+            const std::string key = mLibrary.nameToAlias(name);           // :171
+            auto k = keyIndex.find(key);
+            if (k == keyIndex.end()) {
+                k = keyIndex.emplace(key, uint32_t(mKeys.size())).first;
+                mKeys.push_back(key);
+            }
+            colKey[c] = k->second;
+            auto f = byName.find(name);
+            if (f == byName.end()) {
+                byName.emplace(name, fields.size());
+                fields.push_back({k->second, {c}});
+            } else {
+                fields[f->second].columns.push_back(c);                   // same-named groups are one regexp2 group
+            }
+        }
+        mColumnKey.push_back(std::move(colKey));
+        mFields.push_back(std::move(fields));
+    }
+    mRowInts = 2 * (1 + maxColumns);
+}
+
+// named non-empty groups of one match, in Groups() order (:167-175)
+void ProcessorGrokGpu::emitRow(size_t p, const int32_t* row, std::vector<Field>& out) const {
+    for (const auto& f : mFields[p]) {
+        int32_t b = -1, e = -1;
+        for (uint32_t c : f.columns) {
+            const int32_t cb = row[2 + 2 * c], ce = row[3 + 2 * c];
+            if (cb >= 0 && cb >= b) {  // merged group: the capture furthest along is its last capture
+                b = cb;
+                e = ce;
+            }
+        }
+        if (b >= 0 && e > b) out.push_back({f.key, uint32_t(b), uint32_t(e)});
+    }
+}
+
+void ProcessorGrokGpu::MatchValues(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                                   int32_t* pattern, std::vector<uint32_t>& fieldOff, std::vector<Field>& fields) {
+    fieldOff.assign(size_t(n) + 1, 0);
+    fields.clear();
+    if (n == 0) return;
+    if (mDevice.empty()) {  // no Match entries: every value is matchFail
+        for (uint32_t i = 0; i < n; ++i) pattern[i] = -1;
+        return;
+    }
+    std::vector<int32_t> first, extra;
+    int rc = lcGrokMatchHost(mDevice, mRowInts, data, off, len, n, pattern, first, extra);
+    if (rc != LC_OK) throw GrokError(std::string("grok device match failed: ") + lc_last_error());
+    const size_t w = mRowInts + 2;
+    size_t x = 0;
+    const size_t nx = extra.size() / w;
+    for (uint32_t i = 0; i < n; ++i) {
+        fieldOff[i] = uint32_t(fields.size());
+        if (pattern[i] >= 0) {
+            emitRow(size_t(pattern[i]), &first[size_t(i) * mRowInts], fields);
+            while (x < nx && uint32_t(extra[x * w]) == i) {
+                emitRow(size_t(pattern[i]), &extra[x * w + 2], fields);
+                ++x;
+            }
+        }
+        while (x < nx && uint32_t(extra[x * w]) == i) ++x;  // rows of a pattern that did not win in the end: none exist
+    }
+    fieldOff[n] = uint32_t(fields.size());
+}
+
+// ProcessLogs :108-113 + processLog :115-146, batched: every content that the Go loop would hand to processGrok is
+// matched in one device call, then the logs are edited in the Go loop's order.
+void ProcessorGrokGpu::ProcessLogs(std::vector<Log>& logs) {
+    struct Ref {
+        uint32_t log, content;
+    };
+    std::vector<Ref> refs;
+    std::vector<uint8_t> data;
+    std::vector<uint32_t> off, len;
+    for (uint32_t l = 0; l < logs.size(); ++l)
+        for (uint32_t c = 0; c < logs[l].Contents.size(); ++c) {
+            const auto& cont = logs[l].Contents[c];
+            if (!SourceKey.empty() && SourceKey != cont.Key) continue;    // :118
+            refs.push_back({l, c});
+            off.push_back(uint32_t(data.size()));
+            len.push_back(uint32_t(cont.Value.size()));
+            data.insert(data.end(), cont.Value.begin(), cont.Value.end());
+        }
+    if (refs.empty()) return;
+    data.resize(data.size() + 16);
+    std::vector<int32_t> pattern(refs.size());
+    std::vector<uint32_t> fieldOff;
+    std::vector<Field> fields;
+    MatchValues(data.data(), off.data(), len.data(), uint32_t(refs.size()), pattern.data(), fieldOff, fields);
+    for (size_t r = 0; r < refs.size(); ++r) {
+        Log& log = logs[refs[r].log];
+        const bool success = pattern[r] >= 0;
+        for (uint32_t f = fieldOff[r]; f < fieldOff[r + 1]; ++f)          // :182-186
+            log.Contents.push_back({mKeys[fields[f].key],
+                                    std::string(reinterpret_cast<const char*>(data.data()) + off[r] + fields[f].begin,
+                                                fields[f].end - fields[f].begin)});
+        if ((success && !KeepSource) || (!success && !IgnoreParseFailure)) {  // :135-137, by the index the loop holds
+            const uint32_t i = refs[r].content;
+            if (i < log.Contents.size()) log.Contents.erase(log.Contents.begin() + i);
+        }
+    }
+}
+
+}  // namespace lcgrok
+
+// ------------------------------------------------------------------------------------------------ C ABI
+using lcgrok::ProcessorGrokGpu;
+
+struct lc_grok {
+    ProcessorGrokGpu p;
+};
+struct lc_grok_result {
+    std::vector<uint32_t> fieldOff, key, begin, end;
+};
+
+static void setErr(char* err, size_t cap, const std::string& msg) {
+    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_grok_t** out, char* err, size_t errcap) {
+    if (!config_json || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    auto g = std::make_unique<lc_grok>();
+    try {
+        const lcjson::Value cfg = lcjson::parse(std::string(config_json, config_len));
+        if (!cfg.isObject()) throw lcgrok::GrokError("config must be a JSON object");
+        auto strings = [&](const char* key, std::vector<std::string>& dst) {
+            if (const lcjson::Value* v = cfg.find(key)) {
+                if (!v->isArray()) throw lcgrok::GrokError(std::string(key) + " must be an array of strings");
+                for (const auto& e : v->arr) {
+                    if (!e.isString()) throw lcgrok::GrokError(std::string(key) + " must be an array of strings");
+                    dst.push_back(e.str);
+                }
+            }
+        };
+        auto boolean = [&](const char* key, bool& dst) {
+            if (const lcjson::Value* v = cfg.find(key)) {
+                if (!v->isBool()) throw lcgrok::GrokError(std::string(key) + " must be a boolean");
+                dst = v->b;
+            }
+        };
+        strings("CustomPatternDir", g->p.CustomPatternDir);
+        strings("Match", g->p.Match);
+        if (const lcjson::Value* v = cfg.find("CustomPatterns")) {
+            if (!v->isObject()) throw lcgrok::GrokError("CustomPatterns must be an object");
+            for (const auto& kv : v->obj) {
+                if (!kv.second.isString()) throw lcgrok::GrokError("CustomPatterns values must be strings");
+                g->p.CustomPatterns[kv.first] = kv.second.str;
+            }
+        }
+        if (const lcjson::Value* v = cfg.find("SourceKey")) {
+            if (!v->isString()) throw lcgrok::GrokError("SourceKey must be a string");
+            g->p.SourceKey = v->str;
+        }
+        if (const lcjson::Value* v = cfg.find("TimeoutMilliSeconds"))
+            if (v->isNumber()) g->p.TimeoutMilliSeconds = v->isInt ? v->inum : int64_t(v->num);
+        boolean("IgnoreParseFailure", g->p.IgnoreParseFailure);
+        boolean("KeepSource", g->p.KeepSource);
+        boolean("NoKeyError", g->p.NoKeyError);
+        boolean("NoMatchError", g->p.NoMatchError);
+        boolean("TimeoutError", g->p.TimeoutError);
+        g->p.Init();
+    } catch (const std::exception& e) {
+        setErr(err, errcap, e.what());
+        return LC_ERR_UNSUPPORTED;
+    }
+    setErr(err, errcap, "");
+    *out = g.release();
+    return LC_OK;
+}
+
+extern "C" void lc_grok_free(lc_grok_t* g) { delete g; }
+extern "C" int lc_grok_match_count(const lc_grok_t* g) { return g ? int(g->p.expanded().size()) : 0; }
+extern "C" const char* lc_grok_expanded(const lc_grok_t* g, int i) {
+    return (g && i >= 0 && size_t(i) < g->p.expanded().size()) ? g->p.expanded()[size_t(i)].c_str() : nullptr;
+}
+extern "C" const char* lc_grok_processed(const lc_grok_t* g, const char* name) {
+    if (!g || !name) return nullptr;
+    auto it = g->p.library().processed().find(name);
+    return it == g->p.library().processed().end() ? nullptr : it->second.c_str();
+}
+extern "C" char* lc_grok_denormalize(lc_grok_t* g, const char* pattern, char* err, size_t errcap) {
+    if (!g || !pattern) return nullptr;
+    try {
+        const std::string text = g->p.library().denormalize(pattern);
+        char* out = static_cast<char*>(std::malloc(text.size() + 1));
+        if (out) std::memcpy(out, text.c_str(), text.size() + 1);
+        setErr(err, errcap, "");
+        return out;
+    } catch (const std::exception& e) {
+        setErr(err, errcap, e.what());
+        return nullptr;
+    }
+}
+extern "C" int lc_grok_engine(const lc_grok_t* g, int i) { return (g && i >= 0) ? g->p.engine(size_t(i)) : 0; }
+extern "C" int lc_grok_key_count(const lc_grok_t* g) { return g ? int(g->p.keys().size()) : 0; }
+extern "C" const char* lc_grok_key(const lc_grok_t* g, int key) {
+    return (g && key >= 0 && size_t(key) < g->p.keys().size()) ? g->p.keys()[size_t(key)].c_str() : nullptr;
+}
+extern "C" int lc_grok_column_count(const lc_grok_t* g, int i) {
+    return (g && i >= 0 && size_t(i) < g->p.columnKeys().size()) ? int(g->p.columnKeys()[size_t(i)].size()) : 0;
+}
+extern "C" int lc_grok_column_key(const lc_grok_t* g, int i, int column) {
+    if (!g || i < 0 || size_t(i) >= g->p.columnKeys().size()) return -1;
+    const auto& ck = g->p.columnKeys()[size_t(i)];
+    if (column < 0 || size_t(column) >= ck.size() || ck[size_t(column)] == 0xFFFFFFFFu) return -1;
+    return int(ck[size_t(column)]);
+}
+extern "C" int lc_grok_row_ints(const lc_grok_t* g) { return g ? int(g->p.rowInts()) : 0; }
+
+extern "C" size_t lc_grok_scratch_bytes(const lc_grok_t* g, uint32_t n) {
+    return g ? lcGrokScratchBytes(n, g->p.rowInts()) : 0;
+}
+
+extern "C" int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                                    uint32_t n, int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extra_cap,
+                                    uint32_t* d_nextra, void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (!g) return LC_ERR_ARG;
+    return lcGrokMatchDevice(g->p.devicePatterns(), g->p.rowInts(), d_data, d_off, d_len, n, d_pattern, d_first, d_extra,
+                              extra_cap, d_nextra, d_scratch, scratch_bytes, stream);
+}
+
+extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                                  int32_t* pattern, lc_grok_result_t** result) {
+    if (!g || !result || (n && (!data || !off || !len || !pattern))) return LC_ERR_ARG;
+    *result = nullptr;
+    auto r = std::make_unique<lc_grok_result>();
+    try {
+        std::vector<ProcessorGrokGpu::Field> fields;
+        g->p.MatchValues(data, off, len, n, pattern, r->fieldOff, fields);
+        for (const auto& f : fields) {
+            r->key.push_back(f.key);
+            r->begin.push_back(f.begin);
+            r->end.push_back(f.end);
+        }
+    } catch (const std::exception&) {
+        return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
+    }
+    *result = r.release();
+    return LC_OK;
+}
+
+extern "C" void lc_grok_result_arrays(const lc_grok_result_t* r, const uint32_t** field_off, const uint32_t** key,
+                                      const uint32_t** begin, const uint32_t** end) {
+    if (!r) return;
+    if (field_off) *field_off = r->fieldOff.data();
+    if (key) *key = r->key.data();
+    if (begin) *begin = r->begin.data();
+    if (end) *end = r->end.data();
+}
+extern "C" void lc_grok_result_free(lc_grok_result_t* r) { delete r; }
+
+extern "C" int lc_grok_process_logs_json(lc_grok_t* g, const char* logs_json, size_t len, char** out_json) {
+    if (!g || !logs_json || !out_json) return LC_ERR_ARG;
+    *out_json = nullptr;
+    try {
+        const lcjson::Value in = lcjson::parse(std::string(logs_json, len));
+        if (!in.isArray()) return LC_ERR_ARG;
+        std::vector<lcgrok::Log> logs;
+        for (const auto& l : in.arr) {
+            if (!l.isArray()) return LC_ERR_ARG;
+            lcgrok::Log log;
+            for (const auto& c : l.arr) {
+                if (!c.isArray() || c.arr.size() != 2 || !c.arr[0].isString() || !c.arr[1].isString()) return LC_ERR_ARG;
+                log.Contents.push_back({c.arr[0].str, c.arr[1].str});
+            }
+            logs.push_back(std::move(log));
+        }
+        g->p.ProcessLogs(logs);
+        lcjson::Value out = lcjson::Value::makeArray();
+        for (const auto& log : logs) {
+            lcjson::Value l = lcjson::Value::makeArray();
+            for (const auto& c : log.Contents) {
+                lcjson::Value pair = lcjson::Value::makeArray();
+                pair.arr.push_back(lcjson::Value::makeString(c.Key));
+                pair.arr.push_back(lcjson::Value::makeString(c.Value));
+                l.arr.push_back(std::move(pair));
+            }
+            out.arr.push_back(std::move(l));
+        }
+        const std::string text = lcjson::dump(out);
+        *out_json = static_cast<char*>(std::malloc(text.size() + 1));
+        if (!*out_json) return LC_ERR_ARG;
+        std::memcpy(*out_json, text.c_str(), text.size() + 1);
+        return LC_OK;
+    } catch (const lcgrok::GrokError&) {
+        return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
+    } catch (const std::exception&) {
+        return LC_ERR_ARG;
+    }
+}
+extern "C" void lc_grok_free_string(char* s) { std::free(s); }

@@ -1,0 +1,82 @@
+// processor_grok_gpu.hpp -- host side of the Grok processor: the reference's Go plugin restated over the device matcher.
+//
+// Mirrors plugins/processor/grok/processor_grok.go: the exported fields keep their names (:42-53), Init follows :62-102,
+// ProcessLogs / processLog / processGrok follow :108-194 -- with the per-log regexp2 loop replaced by ONE batched device
+// call over the SourceKey values of all logs (lcGrokMatchHost, gpu_runtime.hip).  Logs are the protocol.Log shape: an
+// ordered list of (Key, Value) contents (duplicates allowed; fields are appended, processor_grok.go:183-185).
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "grok.hpp"
+#include "grok_runtime.hpp"
+
+struct lc_regex;
+
+namespace lcgrok {
+
+struct LogContent {
+    std::string Key, Value;
+};
+struct Log {
+    std::vector<LogContent> Contents;
+};
+
+class ProcessorGrokGpu {
+public:
+    // exported fields, names as in the Go struct
+    std::vector<std::string> CustomPatternDir;
+    std::map<std::string, std::string> CustomPatterns;
+    std::string SourceKey = "content";
+    std::vector<std::string> Match;
+    int64_t TimeoutMilliSeconds = 0;
+    bool IgnoreParseFailure = true;
+    bool KeepSource = true;
+    bool NoKeyError = false;
+    bool NoMatchError = true;
+    bool TimeoutError = true;
+
+    ~ProcessorGrokGpu();
+    void Init();                          // throws GrokError
+    void ProcessLogs(std::vector<Log>& logs);
+
+    // one field of one value: key index (keys()), byte range inside the value
+    struct Field {
+        uint32_t key, begin, end;
+    };
+    // processGrok over a batch of values: winning Match index per value (-1 matchFail, -2 undecidable) and its fields in
+    // emission order.  fieldOff has n+1 entries.
+    void MatchValues(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
+                     std::vector<uint32_t>& fieldOff, std::vector<Field>& fields);
+
+    const PatternLibrary& library() const { return mLibrary; }
+    PatternLibrary& library() { return mLibrary; }
+    const std::vector<std::string>& expanded() const { return mExpanded; }
+    const std::vector<std::string>& keys() const { return mKeys; }
+    const std::vector<std::vector<uint32_t>>& columnKeys() const { return mColumnKey; }
+    const std::vector<GrokDevicePattern>& devicePatterns() const { return mDevice; }
+    uint32_t rowInts() const { return mRowInts; }
+    int engine(size_t i) const;
+
+private:
+    PatternLibrary mLibrary;
+    std::vector<std::string> mExpanded;
+    std::vector<lc_regex*> mCompiled;
+    std::vector<GrokDevicePattern> mDevice;
+    std::vector<std::string> mKeys;                    // distinct emitted keys
+    std::vector<std::vector<uint32_t>> mColumnKey;     // [pattern][column] -> key index
+    // [pattern] fields in Groups() order: key index + the columns that share the name
+    struct MergedField {
+        uint32_t key;
+        std::vector<uint32_t> columns;
+    };
+    std::vector<std::vector<MergedField>> mFields;
+    uint32_t mRowInts = 2;
+
+    void emitRow(size_t p, const int32_t* row, std::vector<Field>& out) const;
+};
+
+}  // namespace lcgrok

@@ -70,3 +70,8 @@ inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos) {
 
 // implemented in gpu_runtime.hip; frees device copies
 void lcReleaseDeviceTables(lc_regex* re);
+// implemented in gpu_runtime.hip: one launch of the engine's kernel.  d_n (optional): line count on the device;
+// d_order (optional): the lines to process; d_resume (optional, indexed by line): resume offsets of a search pattern.
+int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                    uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                    uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, void* stream);

@@ -1,0 +1,150 @@
+"""ctypes binding of the Grok processor (include/lc_grok.h).  Plumbing for tests, tools and bench.py only: the product
+is the C ABI; matching always runs on the HIP device (there is no CPU path)."""
+import ctypes
+import json
+
+import numpy as np
+
+from . import binding
+
+
+class GrokInitError(ValueError):
+    pass
+
+
+def _lib():
+    L = binding.load()
+    if not getattr(L, "_lc_grok_bound", False):
+        vp, cp, sz, i32, u32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+        L.lc_grok_create.restype = i32
+        L.lc_grok_create.argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
+        L.lc_grok_free.argtypes = [vp]
+        for name in ("lc_grok_match_count", "lc_grok_key_count", "lc_grok_row_ints"):
+            getattr(L, name).restype = i32
+            getattr(L, name).argtypes = [vp]
+        L.lc_grok_expanded.restype = cp
+        L.lc_grok_expanded.argtypes = [vp, i32]
+        L.lc_grok_processed.restype = cp
+        L.lc_grok_processed.argtypes = [vp, cp]
+        L.lc_grok_denormalize.restype = vp
+        L.lc_grok_denormalize.argtypes = [vp, cp, cp, sz]
+        L.lc_grok_engine.restype = i32
+        L.lc_grok_engine.argtypes = [vp, i32]
+        L.lc_grok_key.restype = cp
+        L.lc_grok_key.argtypes = [vp, i32]
+        L.lc_grok_column_count.restype = i32
+        L.lc_grok_column_count.argtypes = [vp, i32]
+        L.lc_grok_column_key.restype = i32
+        L.lc_grok_column_key.argtypes = [vp, i32, i32]
+        L.lc_grok_scratch_bytes.restype = sz
+        L.lc_grok_scratch_bytes.argtypes = [vp, u32]
+        L.lc_grok_match_device.restype = i32
+        L.lc_grok_match_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]
+        L.lc_grok_match_host.restype = i32
+        L.lc_grok_match_host.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(vp)]
+        L.lc_grok_result_arrays.argtypes = [vp] + [ctypes.POINTER(vp)] * 4
+        L.lc_grok_result_free.argtypes = [vp]
+        L.lc_grok_process_logs_json.restype = i32
+        L.lc_grok_process_logs_json.argtypes = [vp, cp, sz, ctypes.POINTER(vp)]
+        L.lc_grok_free_string.argtypes = [vp]
+        L._lc_grok_bound = True
+    return L
+
+
+class Grok:
+    """processor_grok with the reference's config keys: Grok(Match=[...], CustomPatterns={...}, KeepSource=False, ...)"""
+
+    def __init__(self, **config):
+        self._L = _lib()
+        text = json.dumps(config).encode("utf-8")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(1024)
+        rc = self._L.lc_grok_create(text, len(text), ctypes.byref(h), err, 1024)
+        if rc != 0:
+            raise GrokInitError(err.value.decode("utf-8", "replace"))
+        self._h = h
+        self.n_match = self._L.lc_grok_match_count(h)
+        self.keys = [self._L.lc_grok_key(h, k).decode("utf-8") for k in range(self._L.lc_grok_key_count(h))]
+        self.row_ints = self._L.lc_grok_row_ints(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lc_grok_free(self._h)
+            self._h = None
+
+    def expanded(self, i):
+        return self._L.lc_grok_expanded(self._h, i).decode("utf-8")
+
+    def processed(self, name):
+        p = self._L.lc_grok_processed(self._h, name.encode("utf-8"))
+        return None if p is None else p.decode("utf-8")
+
+    def denormalize(self, pattern):
+        """expand %{...} references against this handle's library without compiling the result"""
+        err = ctypes.create_string_buffer(512)
+        p = self._L.lc_grok_denormalize(self._h, pattern.encode("utf-8"), err, 512)
+        if not p:
+            raise GrokInitError(err.value.decode("utf-8", "replace"))
+        try:
+            return ctypes.string_at(p).decode("utf-8")
+        finally:
+            self._L.lc_grok_free_string(p)
+
+    def engine(self, i):
+        return self._L.lc_grok_engine(self._h, i)
+
+    def columns(self, i):
+        """emitted key (or None for a numbered group) of every capture column of Match[i]"""
+        out = []
+        for c in range(self._L.lc_grok_column_count(self._h, i)):
+            k = self._L.lc_grok_column_key(self._h, i, c)
+            out.append(None if k < 0 else self.keys[k])
+        return out
+
+    # ---- processGrok over a batch of values (bytes); -> (pattern int32[n], [[(key, value bytes), ...] per value])
+    def match_host(self, values):
+        n = len(values)
+        data = np.frombuffer(b"".join(values) + b"\0" * 16, dtype=np.uint8)
+        length = np.array([len(v) for v in values], dtype=np.uint32)
+        off = np.zeros(n, dtype=np.uint32)
+        if n:
+            off[1:] = np.cumsum(length[:-1], dtype=np.uint64).astype(np.uint32)
+        pattern = np.empty(n, dtype=np.int32)
+        res = ctypes.c_void_p()
+        rc = self._L.lc_grok_match_host(self._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, n,
+                                        pattern.ctypes.data, ctypes.byref(res))
+        binding._check(rc, "lc_grok_match_host")
+        try:
+            ptrs = [ctypes.c_void_p() for _ in range(4)]
+            self._L.lc_grok_result_arrays(res, *[ctypes.byref(p) for p in ptrs])
+            foff = np.ctypeslib.as_array(ctypes.cast(ptrs[0], ctypes.POINTER(ctypes.c_uint32)), shape=(n + 1,)).copy()
+            m = int(foff[n])
+            key, beg, end = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint32)), shape=(m,)).copy()
+                             if m else np.zeros(0, np.uint32) for p in ptrs[1:]]
+        finally:
+            self._L.lc_grok_result_free(res)
+        fields = [[(self.keys[int(key[f])], values[i][int(beg[f]):int(end[f])]) for f in range(int(foff[i]), int(foff[i + 1]))]
+                  for i in range(n)]
+        return pattern, fields
+
+    # ---- device-resident batch: torch tensors in, torch tensors out (bench.py, tests)
+    def scratch_bytes(self, n):
+        return self._L.lc_grok_scratch_bytes(self._h, n)
+
+    def match_device(self, d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch, stream=None):
+        rc = self._L.lc_grok_match_device(self._h, d_data.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n,
+                                          d_pattern.data_ptr(), d_first.data_ptr(), d_extra.data_ptr(),
+                                          d_extra.shape[0], d_nextra.data_ptr(), d_scratch.data_ptr(),
+                                          d_scratch.numel() * d_scratch.element_size(), stream)
+        binding._check(rc, "lc_grok_match_device")
+
+    # ---- ProcessLogs: logs = [[(key, value str), ...], ...] -> same shape
+    def process_logs(self, logs):
+        text = json.dumps([[list(kv) for kv in log] for log in logs]).encode("utf-8")
+        out = ctypes.c_void_p()
+        rc = self._L.lc_grok_process_logs_json(self._h, text, len(text), ctypes.byref(out))
+        binding._check(rc, "lc_grok_process_logs_json")
+        try:
+            return [[tuple(kv) for kv in log] for log in json.loads(ctypes.string_at(out).decode("utf-8"))]
+        finally:
+            self._L.lc_grok_free_string(out)

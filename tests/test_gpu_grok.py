@@ -1,0 +1,154 @@
+"""Grok on the device, through the C ABI of include/lc_grok.h: the reference's own parse vectors
+(processor_grok_test.go:119-373), the regex-module golden vectors, random values against the Grok oracle, many matches per
+value (FindNextMatch), the extra-row overflow protocol and the device-resident entry point."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from loongcollector_amd import binding as B
+from loongcollector_amd.grok import Grok, GrokInitError
+from oracle.grok_oracle import GrokOracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "grok_golden.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_reference_parse_vectors_through_process_logs(torch_dev, golden):
+    ran = 0
+    for r in golden["reference"]:
+        try:
+            g = Grok(**r["config"])
+        except GrokInitError:
+            continue   # a Match entry no device engine can run yet (reported in DESIGN.md); Init fails loudly
+        ran += 1
+        got = g.process_logs([[tuple(kv) for kv in log] for log in r["in"]])
+        assert [[list(kv) for kv in log] for log in got] == r["out"], r["cite"]
+    assert ran >= 6
+
+
+def test_regex_module_golden_vectors(torch_dev, golden):
+    checked = skipped = 0
+    for c in golden["regex"]:
+        try:
+            g = Grok(**c["config"])
+        except GrokInitError:
+            skipped += 1
+            continue
+        values = [v.encode("latin-1") for v, _ in c["subs"]]
+        pattern, fields = g.match_host(values)
+        for (val, want), p, f in zip(c["subs"], pattern, fields):
+            checked += 1
+            assert [[k, v.decode("latin-1")] for k, v in f] == want, (c["config"]["Match"], val)
+            assert (p >= 0) == bool(want)
+    assert checked >= 250 and skipped <= 3
+
+
+def _random_values(rng, n):
+    words = [b"GET", b"10.0.0.1", b"192.168.001.77", b"-3.5", b"err", b"2024-01-04T14:36:10Z", b"x=1", b"k=", b"[a]", b"\"q s\"",
+             b"abc_9", b"::1", b"7", b"ERROR", b"info:", b"/p/a?x=1", b"\xe4\xbd\xa0\xe5\xa5\xbd", b""]
+    out = []
+    for _ in range(n):
+        k = rng.randint(0, 9)
+        out.append(rng.choice([b" ", b"  ", b"\t", b","]).join(rng.choice(words) for _ in range(k)))
+    return out
+
+
+@pytest.mark.parametrize("match", [
+    ["%{IPV4:ip}"],
+    ["%{LOGLEVEL:level}:? %{GREEDYDATA:msg}", "(?P<k>\\w+)=(?P<v>\\S*)", "%{INT:n}"],
+    ["%{TIMESTAMP_ISO8601:ts}", "%{WORD:a} %{WORD:b}", "%{NOTSPACE:first}"],
+    ["(?P<x>\\d+)|(?P<x>[a-z]+)_(?P<y>\\d)"],
+])
+def test_random_values_against_the_oracle(torch_dev, match):
+    rng = random.Random(99)
+    values = _random_values(rng, 3000)
+    g = Grok(Match=match)
+    o = GrokOracle(match)
+    pattern, fields = g.match_host(values)
+    nmulti = 0
+    for v, p, f in zip(values, pattern, fields):
+        res, want = o.process_value(v)
+        assert f == want, (match, v)
+        assert (p >= 0) == (res == 0)
+        nmulti += len(want) > len(g.columns(int(p))) if p >= 0 else 0
+    if match == ["%{IPV4:ip}"]:
+        assert nmulti > 50   # several matches per value really happen (FindNextMatch path)
+
+
+def test_device_resident_entry_and_extra_row_overflow(torch_dev):
+    torch = torch_dev
+    dev = torch.device("cuda:0")
+    g = Grok(Match=["%{WORD:w}"])
+    o = GrokOracle(["%{WORD:w}"])
+    values = [b"a b c d e f g h", b"", b"one", b"x y"] * 64
+    n = len(values)
+    data = np.frombuffer(b"".join(values) + b"\0" * 16, dtype=np.uint8)
+    length = np.array([len(v) for v in values], dtype=np.uint32)
+    off = np.concatenate([[0], np.cumsum(length[:-1])]).astype(np.uint32)
+    d_data = torch.from_numpy(data.copy()).to(dev)
+    d_off = torch.from_numpy(off.view(np.int32).copy()).to(dev)
+    d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev)
+    row = g.row_ints
+    d_pattern = torch.empty(n, dtype=torch.int32, device=dev)
+    d_first = torch.empty((n, row), dtype=torch.int32, device=dev)
+    d_nextra = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_scratch = torch.empty(g.scratch_bytes(n), dtype=torch.uint8, device=dev)
+    small = torch.empty((8, row + 2), dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError):   # LC_ERR_OVERFLOW: 8 rows cannot hold the further matches
+        g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, small, d_nextra, d_scratch)
+    need = int(d_nextra.cpu()[0])
+    assert need == sum(max(0, len(v.split()) - 1) for v in values)
+    d_extra = torch.empty((need, row + 2), dtype=torch.int32, device=dev)
+    g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch)
+    pattern, first, extra = d_pattern.cpu().numpy(), d_first.cpu().numpy(), d_extra.cpu().numpy()
+    rows = {}
+    for r in extra:
+        rows.setdefault(int(r[0]), []).append(r)
+    for i, v in enumerate(values):
+        _, want = o.process_value(v)
+        if not want:
+            assert pattern[i] == -1
+            continue
+        got = [v[first[i][2]:first[i][3]]] + [v[r[4]:r[5]] for r in sorted(rows.get(i, []), key=lambda r: r[1])]
+        assert got == [w for _, w in want]
+
+
+def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
+    """BASELINE.json configs[2] pattern list: every Match entry the device can run today, each fed lines the oracle says it
+    matches plus junk; first-match-wins over the whole list against the oracle."""
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    ok = []
+    for m in cfg["match"]:
+        try:
+            Grok(Match=[m], CustomPatterns=cfg["custom_patterns"])
+            ok.append(m)
+        except GrokInitError:
+            pass
+    assert len(ok) >= 30, len(ok)
+    g = Grok(Match=ok, CustomPatterns=cfg["custom_patterns"])
+    o = GrokOracle(ok, custom_patterns=cfg["custom_patterns"])
+    rng = random.Random(3)
+    values = _random_values(rng, 400) + [
+        b"Mar 16 00:01:25 evita CRON[1713]: (root) CMD (run-parts /etc/cron.hourly)",
+        b"%ASA-4-106023: Deny tcp src outside:10.1.1.1/1234 dst inside:10.2.2.2/80 by access-group \"acl\" [0x0, 0x0]",
+        b"%ASA-6-302010: 5 in use, 10 most used",
+        b"%ASA-1-104001: (Primary) Switching to ACTIVE - reason",
+        b"    at com.example.Foo.bar(Foo.java:42)",
+    ]
+    pattern, fields = g.match_host(values)
+    hits = 0
+    for v, p, f in zip(values, pattern, fields):
+        res, want = o.process_value(v)
+        assert p != -2
+        assert f == want, v
+        hits += p >= 0
+    assert hits >= 3

@@ -1,0 +1,178 @@
+"""Grok without a GPU: the pattern-library expander (C++, through the C ABI) and the Grok oracle
+against the strings and vectors the reference's own tests pin, the oracle against an independent engine, and the device
+algorithm (ordered patterns, resumed searches, named non-empty groups) emulated on the compiled tables.
+
+Reference: plugins/processor/grok/processor_grok.go + processor_grok_test.go (cited per test)."""
+import json
+import os
+
+import pytest
+
+from loongcollector_amd import binding as B
+from loongcollector_amd.grok import Grok, GrokInitError
+from oracle.grok_oracle import MATCH_SUCCESS, GrokOracle
+from tests.helpers.table_interp import NfaInterp, TdfaInterp
+
+GROK_SYNTAX = (B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_NO_DOTALL | B.LC_SYNTAX_NO_MULTILINE
+               | B.LC_SYNTAX_REGEXP2)
+
+
+@pytest.fixture(scope="module")
+def expansions(golden_dir):
+    with open(os.path.join(golden_dir, "grok_expansions.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "grok_golden.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def pattern_dir(expansions, tmp_path_factory):
+    """CustomPatternDir ./test_patterns of the reference test, rebuilt from the fixture as two files"""
+    d = tmp_path_factory.mktemp("test_patterns")
+    items = sorted(expansions["test_patterns"].items())
+    half = len(items) // 2
+    for name, part in (("aws", items[:half]), ("grok-patterns", items[half:])):
+        with open(d / name, "w", encoding="utf-8") as f:
+            f.write('""" a comment line, skipped because it starts with a quote (processor_grok.go:219)\n\n')
+            for k, v in part:
+                f.write(k + " " + v + "\n")
+    return str(d)
+
+
+def test_expander_reproduces_the_strings_the_reference_test_pins(expansions, pattern_dir):
+    """processor_grok_test.go:36-41 (expected strings), :74-116 (where they come from)"""
+    for c in expansions["cases"]:
+        cfg = {"CustomPatterns": c["custom"]}
+        if c["custom_dir"]:
+            cfg["CustomPatternDir"] = [pattern_dir]
+        g = Grok(**cfg)   # library only: whether a device engine can RUN a Match entry is a separate question
+        got = g.denormalize(c["match"]) if "match" in c else g.processed(c["processed"])
+        custom = dict(expansions["test_patterns"]) if c["custom_dir"] else {}
+        custom.update(c["custom"])
+        o = GrokOracle([c["match"]] if "match" in c else [], custom_patterns=custom)
+        want = c["expanded"]
+        assert (o.expanded[0] if "match" in c else o.processed[c["processed"]]) == want
+        assert got == want
+
+
+def test_library_only_handles_expand_every_default_pattern_like_the_oracle():
+    g, o = Grok(), GrokOracle([])
+    assert len(o.processed) >= 78
+    for name, text in o.processed.items():
+        assert g.processed(name) == text, name
+    assert g.processed("NO_SUCH_PATTERN") is None and g.n_match == 0
+
+
+@pytest.mark.parametrize("cfg, needle", [
+    ({"CustomPatternDir": ["./no_exist_path"]}, "invalid path"),                                    # :380-384
+    ({"CustomPatterns": {"TEST": "%{IP:client} ("}, "Match": ["%{TEST}"]}, "Match[0]"),              # :386-392
+    ({"CustomPatterns": {"A": "%{B:b}", "B": "%{A:a}"}}, "cyclic"),                                  # :394-402
+    ({"Match": ["%{NOPE:x}"]}, "no pattern found for NOPE"),                                         # processor_grok.go:296
+    ({"CustomPatterns": {"X": "%{WORD:a:bogus}"}}, "invalid pattern"),                               # :248
+    ({"Match": [r"(\w+) \1"]}, "back-references"),                                                   # no device engine
+])
+def test_init_errors(cfg, needle):
+    with pytest.raises(GrokInitError) as e:
+        Grok(**cfg)
+    assert needle in str(e.value)
+    if "Match" not in cfg or "Match[0]" not in needle:
+        return
+
+
+def test_keys_aliases_columns_and_defaults():
+    g = Grok(Match=["%{WORD:english-word} %{GREEDYDATA:message} (?P<message2>.*)", "%{IPV4:ip}(?P<x>a)|(?P<x>b)"])
+    assert "(?P<english_word>" in g.expanded(0)                       # aliasizePatternName :319-323
+    assert g.keys == ["english-word", "message", "message2", "ip", "x"]   # nameToAlias :326-332
+    assert g.columns(0) == ["english-word", "message", "message2"]
+    assert g.columns(1) == ["ip", "x", "x"]                           # same-named groups: two columns, one field
+    assert g.row_ints == 2 * (1 + 3)
+    assert Grok(Match=["(?s)^$"]).n_match == 1                        # zero-width Match only warns (:348-351, test :408-427)
+
+
+def test_oracle_agrees_with_the_regex_module_and_the_reference_vectors(golden):
+    n = 0
+    for c in golden["regex"]:
+        o = GrokOracle(c["config"]["Match"], custom_patterns=c["config"].get("CustomPatterns"))
+        for val, want in c["subs"]:
+            n += 1
+            _, fields = o.process_value(val.encode("latin-1"))
+            assert [[k, v.decode("latin-1")] for k, v in fields] == want, (c["config"]["Match"], val)
+    assert n >= 300
+    for r in golden["reference"]:
+        cfg = r["config"]
+        o = GrokOracle(cfg["Match"], custom_patterns=cfg.get("CustomPatterns"),
+                       ignore_parse_failure=cfg.get("IgnoreParseFailure", True), keep_source=cfg.get("KeepSource", True))
+        for log, want in zip(r["in"], r["out"]):
+            got = o.process_log([(k, v.encode("utf-8")) for k, v in log])
+            assert [[k, v.decode("utf-8")] for k, v in got] == want, r["cite"]
+
+
+class TableGrok:
+    """What lcGrokMatchDevice does, replayed on the compiled tables: per pattern a resumed-search loop, named non-empty
+    groups, merged same-named columns; first pattern that collected something wins."""
+
+    def __init__(self, g):
+        self.g = g
+        self.interps = []
+        for i in range(g.n_match):
+            rx = B.GpuRegex(g.expanded(i).encode("utf-8"), syntax_flags=GROK_SYNTAX)
+            it = TdfaInterp(rx) if rx.info()["engine"] == B.LC_ENGINE_TDFA else NfaInterp(rx)
+            assert (rx.info()["engine"] == B.LC_ENGINE_TDFA) == (g.engine(i) == B.LC_ENGINE_TDFA)
+            self.interps.append(it)
+
+    def process_value(self, val):
+        for p, it in enumerate(self.interps):
+            cols = self.g.columns(p)
+            out, start = [], 0
+            while True:
+                caps = it.fullmatch(val, start=start)
+                if caps is None:
+                    break
+                merged, order = {}, []
+                for c, key in enumerate(cols):
+                    b, e = caps[2 + 2 * c], caps[3 + 2 * c]
+                    if key is None:
+                        continue
+                    if key not in merged:
+                        merged[key] = (-1, -1)
+                        order.append(key)
+                    if b >= 0 and b >= merged[key][0]:
+                        merged[key] = (b, e)
+                out += [[k, val[merged[k][0]:merged[k][1]]] for k in order if merged[k][1] > merged[k][0]]
+                b0, e0 = caps[0], caps[1]
+                start = e0 if e0 > b0 else e0 + 1
+                if start >= len(val):
+                    break
+            if out:
+                return out
+        return []
+
+
+def test_device_algorithm_on_the_compiled_tables_reproduces_the_golden_vectors(golden):
+    checked = skipped = 0
+    for c in golden["regex"]:
+        try:
+            g = Grok(**c["config"])
+        except GrokInitError:
+            skipped += 1     # a Match entry neither device engine can run: Init fails loudly (no CPU path)
+            continue
+        t = TableGrok(g)
+        for val, want in c["subs"]:
+            checked += 1
+            got = [[k, v.decode("latin-1")] for k, v in t.process_value(val.encode("latin-1"))]
+            assert got == want, (c["config"]["Match"], val)
+    assert checked >= 250 and skipped <= 3
+
+
+def test_no_cpu_path():
+    if B.load().lc_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    g = Grok(Match=["%{WORD:w}"])
+    with pytest.raises(B.GpuUnavailableError):
+        g.match_host([b"abc"])
+    with pytest.raises(B.GpuUnavailableError):
+        g.process_logs([[("content", "abc")]])
