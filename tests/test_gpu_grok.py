@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert B.device_count() >= 1
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.fixture(scope="module")
 def golden(golden_dir):
     with open(os.path.join(golden_dir, "grok_golden.json"), encoding="utf-8") as f:
         return json.load(f)
