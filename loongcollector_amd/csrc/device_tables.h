@@ -64,7 +64,12 @@ enum {
                           // c; entry nClasses = start of input
     NF_OFF_AHEAD = 13,    // u32[nClasses+1]: look-ahead assertions that hold when the next byte has class c; entry
                           // nClasses = end of input
-    NF_HEADER_WORDS = 16
+    // patterns with atomic groups / possessive quantifiers only (all three 0 otherwise):
+    NF_OFF_PATHEV = 14,   // u32[nPaths]: (first event << 8) | event count of the path
+    NF_OFF_EVENTS = 15,   // u32[]: low16 = code (int16: +(g+1) enter group instance g, -(g+1) leave it, 20000+i assertion i
+                          // is tested here), high16 = exit visit (follow_nfa.hpp FollowPath::Event)
+    NF_OFF_ATOMICPOS = 16, // u32[(nPos+1)/32+1]: bit p = some path out of position p enters or leaves an atomic group
+    NF_HEADER_WORDS = 20
 };
 #define NF_MAGIC_VALUE 0x3141464Eu
 #define NF_TARGET_MATCH 0xFFFFFFFFu

@@ -121,18 +121,18 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     }
 }
 
-template <int NS>
+template <int NS, bool ATOMIC, bool GLOBAL>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS, ATOMIC, GLOBAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet = lds;
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
-    hipLaunchKernelGGL(nfa_match_kernel<NS>, dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
+    hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
@@ -149,16 +149,39 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     int rc = ensureUploaded(re, dev, false, &dBlob);
     if (rc != LC_OK) return rc;
     const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);
-    const size_t lds = lcNfaLdsBytes(blobBytes, uint32_t(re->nfa.positions.size()));
+    const bool atomic = re->nfa.atomicCount > 0;
+    size_t lds = lcNfaLdsBytes(blobBytes, uint32_t(re->nfa.positions.size()), atomic);
+    const bool global = lds > kLcLdsPerCu;  // program too big for LDS: tables stay in HBM (L2), only the scratch is LDS
+    if (global) lds -= blobBytes;
     if (lds > 160 * 1024) {
         tlsError = "nfa tables exceed LDS";
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
-    if (slots <= 8) return launchNfaSlots<8>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    if (slots <= 16) return launchNfaSlots<16>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    if (slots <= 32) return launchNfaSlots<32>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    return launchNfaSlots<64>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    if (slots <= 8) {
+        if (atomic && global) return launchNfaSlots<8, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<8, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<8, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<8, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
+    if (slots <= 16) {
+        if (atomic && global) return launchNfaSlots<16, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<16, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<16, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<16, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
+    if (slots <= 32) {
+        if (atomic && global) return launchNfaSlots<32, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<32, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<32, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<32, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
+    {
+        if (atomic && global) return launchNfaSlots<64, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<64, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<64, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<64, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
 }
 
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,

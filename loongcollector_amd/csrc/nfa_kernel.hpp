@@ -35,7 +35,207 @@ __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t lane,
     return incl - v;
 }
 
-template <int NS>
+// ---------------------------------------------------------------- atomic groups / possessive quantifiers
+// A thread of a pattern with atomic groups also carries its unsettled atomic-segment memberships (its LINEAGE), and a
+// step has to look at ALL epsilon paths in priority order, viable or not: a path that leaves a group commits it and
+// closes the segment for everything of lower priority, except continuations of that very exit (tdfa.cpp commitAtomic
+// states the rules; tests/helpers/nfa_atomic_interp.py is this routine in Python).  That pass is inherently ordered, so
+// lane 0 runs it serially over LDS while the other lanes wait; it is only entered on steps where some live thread has a
+// lineage or sits on a position whose paths enter/leave a group -- a few bytes around each number / quoted string of a
+// log line -- every other step takes the vector path below.
+constexpr int kNfaLineage = 6;       // memberships a thread can carry between steps (more: LC_OVERFLOW)
+constexpr int kNfaLineageWork = 10;  // ... while a step is being worked out
+constexpr uint32_t kNfaExited = 0x80000000u;
+// lineage entry: bit 31 = has left the group, bits 30..23 = group instance, bits 22..0 = segment id
+__device__ __forceinline__ uint32_t nfaLinKey(uint32_t e) { return e & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t nfaLinGroup(uint32_t e) { return (e >> 23) & 0xFFu; }
+
+// per-wave LDS scratch of the atomic path, in words
+constexpr uint32_t kNfaAtomicScratchWords = 64 /*tPos*/ + 64 /*tNlin*/ + 64 * kNfaLineage /*tLin*/ + 64 /*newNlin*/ +
+                                            64 * kNfaLineageWork /*newLin*/ + 64 /*closedKey*/ + 64 /*closedBy*/;
+static_assert(kNfaAtomicScratchWords == 1344, "keep regex_handle.hpp lcNfaLdsBytes in step");
+
+struct NfaAtomicCtx {
+    const uint32_t* followStart;
+    const uint4* paths;
+    const uint32_t* pathEv;
+    const uint32_t* events;
+    const uint2* posMask;
+    uint32_t *tPos, *tNlin, *tLin, *newNlin, *newLin, *closedKey, *closedBy;
+    uint32_t *newPos, *newSrc, *newTagsLo, *newTagsHi;
+};
+
+// exit visit through which path events [from, n) leave group g (0: they do not, or an assertion stops them first)
+__device__ inline uint32_t nfaExitVisitFor(const uint32_t* ev, uint32_t from, uint32_t n, uint32_t g, uint32_t ctrue) {
+    int depth = 0;
+    for (uint32_t i = from; i < n; ++i) {
+        const int code = int(int16_t(ev[i] & 0xFFFFu));
+        if (code >= 20000) {
+            if (!((ctrue >> (code - 20000)) & 1u)) return 0;
+        } else if (code == int(g) + 1) {
+            ++depth;
+        } else if (code == -(int(g) + 1)) {
+            if (depth == 0) return ev[i] >> 16;
+            --depth;
+        }
+    }
+    return 0;
+}
+
+// Lane 0 only.  One commit pass over the threads in c.tPos/tNlin/tLin; `final` = end of input (targets are MATCH paths,
+// survivors are not merged).  Returns the number of survivors written to new*, or 0xFFFFFFFF on overflow.
+__device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThreads, uint32_t cls, uint32_t ctrue,
+                                         uint32_t step, bool final) {
+    uint32_t nClosed = 0, nKept = 0;
+    auto findClosed = [&](uint32_t key) -> int {
+        for (uint32_t q = 0; q < nClosed; ++q)
+            if (c.closedKey[q] == key) return int(q);
+        return -1;
+    };
+    for (uint32_t t = 0; t < nThreads; ++t) {
+        const uint32_t fs = c.followStart[c.tPos[t]], fe = c.followStart[c.tPos[t] + 1];
+        const uint32_t nlin = c.tNlin[t];
+        for (uint32_t q = fs; q < fe; ++q) {
+            const uint4 p = c.paths[q];
+            const uint32_t pe = c.pathEv[q];
+            const uint32_t* ev = c.events + (pe >> 8);
+            const uint32_t nev = pe & 0xFFu;
+            bool targetOk;
+            if (final) {
+                targetOk = p.x == NF_TARGET_MATCH;
+            } else if (p.x == NF_TARGET_MATCH) {
+                targetOk = false;
+            } else {
+                const uint2 pm = c.posMask[p.x];
+                targetOk = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
+            }
+            bool dead = false;
+            for (uint32_t j = 0; j < nlin && !dead; ++j) {
+                const uint32_t e = c.tLin[t * kNfaLineage + j];
+                const int cl = findClosed(nfaLinKey(e));
+                if (cl < 0) continue;
+                const uint32_t by = c.closedBy[cl];
+                if ((e & kNfaExited) || (by >> 16) != t || nfaExitVisitFor(ev, 0, nev, nfaLinGroup(e), ctrue) != (by & 0xFFFFu))
+                    dead = true;
+            }
+            if (dead) continue;
+            uint32_t work[kNfaLineageWork];
+            uint32_t wn = nlin;
+            for (uint32_t j = 0; j < nlin; ++j) work[j] = c.tLin[t * kNfaLineage + j];
+            bool ok = true;
+            for (uint32_t i = 0; i < nev && !dead; ++i) {
+                const int code = int(int16_t(ev[i] & 0xFFFFu));
+                if (code >= 20000) {
+                    if (!((ctrue >> (code - 20000)) & 1u)) {
+                        ok = false;
+                        break;
+                    }
+                } else if (code > 0) {
+                    const uint32_t g = uint32_t(code - 1);
+                    const uint32_t key = (g << 23) | ((((step + 1) << 6) | t) & 0x7FFFFFu);
+                    const int cl = findClosed(key);
+                    if (cl >= 0) {
+                        const uint32_t by = c.closedBy[cl];
+                        if ((by >> 16) != t || nfaExitVisitFor(ev, i + 1, nev, g, ctrue) != (by & 0xFFFFu)) {
+                            dead = true;
+                            break;
+                        }
+                    }
+                    if (wn == kNfaLineageWork) return 0xFFFFFFFFu;
+                    work[wn++] = key;
+                } else {
+                    const uint32_t g = uint32_t(-code - 1);
+                    for (uint32_t j = wn; j-- > 0;)
+                        if (nfaLinGroup(work[j]) == g && !(work[j] & kNfaExited)) {
+                            if (findClosed(nfaLinKey(work[j])) < 0) {
+                                if (nClosed == 64) return 0xFFFFFFFFu;
+                                c.closedKey[nClosed] = nfaLinKey(work[j]);
+                                c.closedBy[nClosed] = (t << 16) | (ev[i] >> 16);
+                                ++nClosed;
+                            }
+                            work[j] |= kNfaExited;
+                            break;
+                        }
+                }
+            }
+            if (dead || !ok || !targetOk) continue;
+            if (nKept == 64) return 0xFFFFFFFFu;
+            c.newPos[nKept] = final ? (0x40000000u + nKept) : p.x;  // final: survivors never merge
+            c.newSrc[nKept] = t;
+            c.newTagsLo[nKept] = p.z;
+            c.newTagsHi[nKept] = p.w;
+            c.newNlin[nKept] = wn;
+            for (uint32_t j = 0; j < wn; ++j) c.newLin[nKept * kNfaLineageWork + j] = work[j];
+            ++nKept;
+        }
+    }
+    // memberships nobody can act on any more: an exited entry stays only while a higher-priority survivor is inside
+    for (uint32_t i = 0; i < nKept; ++i) {
+        uint32_t* lin = c.newLin + i * kNfaLineageWork;
+        uint32_t n = c.newNlin[i], w = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t e = lin[k];
+            bool keep = !(e & kNfaExited);
+            for (uint32_t j = 0; j < i && !keep; ++j) {
+                const uint32_t* lj = c.newLin + j * kNfaLineageWork;
+                for (uint32_t m = 0; m < c.newNlin[j]; ++m)
+                    if (lj[m] == nfaLinKey(e)) keep = true;  // same key, not exited
+            }
+            if (keep) lin[w++] = e;
+        }
+        c.newNlin[i] = w;
+    }
+    // a survivor that mirrors a higher-priority one on the same position is redundant (tdfa.cpp `mirrors`)
+    auto holds = [&](uint32_t who, uint32_t key, bool insideOnly) {
+        const uint32_t* l = c.newLin + who * kNfaLineageWork;
+        for (uint32_t m = 0; m < c.newNlin[who]; ++m)
+            if (nfaLinKey(l[m]) == key && (!insideOnly || !(l[m] & kNfaExited))) return true;
+        return false;
+    };
+    auto mirrors = [&](uint32_t hi, uint32_t lo) {
+        if (c.newPos[hi] != c.newPos[lo]) return false;
+        const uint32_t* lh = c.newLin + hi * kNfaLineageWork;
+        for (uint32_t m = 0; m < c.newNlin[hi]; ++m) {
+            const uint32_t key = nfaLinKey(lh[m]);
+            if (holds(lo, key, false)) continue;
+            for (uint32_t k = 0; k < hi; ++k)
+                if (holds(k, key, true)) return false;
+        }
+        const uint32_t* ll = c.newLin + lo * kNfaLineageWork;
+        for (uint32_t m = 0; m < c.newNlin[lo]; ++m) {
+            if (ll[m] & kNfaExited) continue;
+            const uint32_t key = nfaLinKey(ll[m]);
+            if (holds(hi, key, true)) continue;
+            for (uint32_t k = lo + 1; k < nKept; ++k)
+                if (holds(k, key, false)) return false;
+        }
+        return true;
+    };
+    for (bool changed = !final; changed;) {
+        changed = false;
+        for (uint32_t i = 1; i < nKept && !changed; ++i)
+            for (uint32_t j = 0; j < i; ++j)
+                if (mirrors(j, i)) {
+                    for (uint32_t k = i + 1; k < nKept; ++k) {
+                        c.newPos[k - 1] = c.newPos[k];
+                        c.newSrc[k - 1] = c.newSrc[k];
+                        c.newTagsLo[k - 1] = c.newTagsLo[k];
+                        c.newTagsHi[k - 1] = c.newTagsHi[k];
+                        c.newNlin[k - 1] = c.newNlin[k];
+                        for (uint32_t m = 0; m < c.newNlin[k]; ++m)
+                            c.newLin[(k - 1) * kNfaLineageWork + m] = c.newLin[k * kNfaLineageWork + m];
+                    }
+                    --nKept;
+                    changed = true;
+                    break;
+                }
+    }
+    for (uint32_t i = 0; i < nKept; ++i)
+        if (c.newNlin[i] > uint32_t(kNfaLineage)) return 0xFFFFFFFFu;
+    return nKept;
+}
+
+template <int NS, bool ATOMIC, bool GLOBAL>
 __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __restrict__ data,
                                                               const uint32_t* __restrict__ off,
                                                               const uint32_t* __restrict__ len, uint32_t sepBytes,
@@ -52,37 +252,69 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t dyn = *nLinesPtr;
         nLines = dyn < nLines ? dyn : nLines;
     }
-    {
+    // the program: staged into LDS once per workgroup -- or, for programs that do not fit next to the scratch (Grok
+    // patterns with several IPv6/hostname alternations run to 100+ KiB), read in place from HBM through L2
+    const uint8_t* tbl;
+    uint32_t scratchBase;
+    if constexpr (GLOBAL) {
+        tbl = reinterpret_cast<const uint8_t*>(blob);
+        scratchBase = 0;
+    } else {
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < blobBytes / 16; i += kNfaBlock) dst[i] = src[i];
+        __syncthreads();
+        tbl = smem;
+        scratchBase = blobBytes;
     }
-    __syncthreads();
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(tbl);
     const uint32_t nPos = hdr[NF_NPOS];
     const uint32_t nSlots = hdr[NF_NSLOTS];
-    const uint8_t* classMap = smem + hdr[NF_OFF_CLASSMAP];
-    const uint2* posMask = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_POSMASK]);
-    const uint2* stable = reinterpret_cast<const uint2*>(smem + hdr[NF_OFF_STABLE]);
-    const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_BEHIND]);
-    const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_AHEAD]);
+    const uint8_t* classMap = tbl + hdr[NF_OFF_CLASSMAP];
+    const uint2* posMask = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_POSMASK]);
+    const uint2* stable = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_STABLE]);
+    const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_BEHIND]);
+    const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
     const uint32_t edgeClass = hdr[NF_NCLASSES];  // table index standing for start / end of input
-    const uint32_t* followStart = reinterpret_cast<const uint32_t*>(smem + hdr[NF_OFF_FOLLOWSTART]);
-    const uint4* paths = reinterpret_cast<const uint4*>(smem + hdr[NF_OFF_PATHS]);
+    const uint32_t* followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
+    const uint4* paths = reinterpret_cast<const uint4*>(tbl + hdr[NF_OFF_PATHS]);
 
     const uint32_t wave = tid >> 6, lane = tid & 63;
     // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newTagsLo, newTagsHi)
     const uint32_t scratchWords = ((nPos + 3) & ~3u) + 256;
-    uint32_t* best = reinterpret_cast<uint32_t*>(smem + blobBytes) + wave * scratchWords;
+    uint32_t* best = reinterpret_cast<uint32_t*>(smem + scratchBase) + wave * scratchWords;
     uint32_t* newPos = best + ((nPos + 3) & ~3u);
     uint32_t* newSrc = newPos + 64;
     uint32_t* newTagsLo = newSrc + 64;
     uint32_t* newTagsHi = newTagsLo + 64;
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
+    // atomic path: its per-wave scratch sits behind the scratch of all waves
+    NfaAtomicCtx actx{};
+    const uint32_t* atomicPos = nullptr;
+    if constexpr (ATOMIC) {
+        uint32_t* a = reinterpret_cast<uint32_t*>(smem + scratchBase) + kNfaWaves * scratchWords + wave * kNfaAtomicScratchWords;
+        actx.followStart = followStart;
+        actx.paths = paths;
+        actx.pathEv = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_PATHEV]);
+        actx.events = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_EVENTS]);
+        actx.posMask = posMask;
+        actx.tPos = a;
+        actx.tNlin = a + 64;
+        actx.tLin = a + 128;
+        actx.newNlin = actx.tLin + 64 * kNfaLineage;
+        actx.newLin = actx.newNlin + 64;
+        actx.closedKey = actx.newLin + 64 * kNfaLineageWork;
+        actx.closedBy = actx.closedKey + 64;
+        actx.newPos = newPos;
+        actx.newSrc = newSrc;
+        actx.newTagsLo = newTagsLo;
+        actx.newTagsHi = newTagsHi;
+        atomicPos = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_ATOMICPOS]);
+    }
 
     const uint32_t slot = blockIdx.x * kNfaWaves + wave;
-    if (slot >= nLines) return;  // wave-uniform
+    if (slot >= nLines) return;  // wave-uniform (the block never synchronises again)
     const uint32_t line = order ? order[slot] : slot;
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
@@ -93,6 +325,9 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     uint32_t nThreads = 1;
     uint32_t myPos = nPos;  // lane 0: the start pseudo-position
     bool overflow = false;
+    uint32_t lin[ATOMIC ? kNfaLineage : 1];  // this thread's unsettled atomic-segment memberships
+    uint32_t nlin = 0;
+    if (ATOMIC && L >= (1u << 17) - 2) overflow = true;  // segment ids are (offset << 6 | thread) in 23 bits
 
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 3);
@@ -114,7 +349,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         curWord = (w < nWords) ? words[w] : 0;
     }
 
-    for (uint32_t i = from; i < L && nThreads; ++i) {
+    for (uint32_t i = from; i < L && nThreads && !overflow; ++i) {
         const uint32_t idx = head + i;
         if (i != from && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
             const uint32_t w = (idx >> 2) + lane;
@@ -137,6 +372,48 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         }
         const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];  // look assertions that hold at this offset
         prevCls = cls;
+
+        if constexpr (ATOMIC) {
+            const bool touchy = liveLane && (nlin != 0 || ((atomicPos[myPos >> 5] >> (myPos & 31)) & 1u));
+            if (__any(touchy)) {  // ordered commit pass, lane 0 (see nfaAtomicStep)
+                if (liveLane) {
+                    actx.tPos[lane] = myPos;
+                    actx.tNlin[lane] = nlin;
+#pragma unroll
+                    for (int j = 0; j < kNfaLineage; ++j) actx.tLin[lane * kNfaLineage + j] = lin[j];
+                }
+                waveLdsSync();
+                uint32_t kept = 0;
+                if (lane == 0) kept = nfaAtomicStep(actx, nThreads, cls, ctrue, i, false);
+                kept = __shfl(kept, 0, 64);
+                waveLdsSync();
+                if (kept == 0xFFFFFFFFu) {
+                    overflow = true;
+                    break;
+                }
+                nThreads = kept;
+                uint32_t src = lane;
+                uint64_t tags = 0;
+                nlin = 0;
+                if (lane < nThreads) {
+                    myPos = newPos[lane];
+                    src = newSrc[lane];
+                    tags = uint64_t(newTagsLo[lane]) | (uint64_t(newTagsHi[lane]) << 32);
+                    nlin = actx.newNlin[lane];
+#pragma unroll
+                    for (int j = 0; j < kNfaLineage; ++j) lin[j] = actx.newLin[lane * kNfaLineageWork + j];
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (uint32_t(s) < nSlots) {
+                        const int32_t v = __shfl(cap[s], int(src), 64);
+                        cap[s] = ((tags >> s) & 1) ? int32_t(i) : v;
+                    }
+                }
+                waveLdsSync();
+                continue;
+            }
+        }
 
         const uint32_t fs = liveLane ? followStart[myPos] : 0;
         const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
@@ -209,7 +486,35 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     // acceptance at end of input: first thread (priority order) with a MATCH path whose assertions hold
     bool accept = false;
     uint64_t endTags = 0;
-    if (!overflow && lane < nThreads) {
+    bool atomicEnd = false;
+    if constexpr (ATOMIC) {
+        // any membership left, or a MATCH path that crosses a group boundary: the ordered commit decides the winner
+        const bool touchy = !overflow && lane < nThreads && (nlin != 0 || ((atomicPos[myPos >> 5] >> (myPos & 31)) & 1u));
+        if (__any(touchy)) {
+            atomicEnd = true;
+            if (lane < nThreads) {
+                actx.tPos[lane] = myPos;
+                actx.tNlin[lane] = nlin;
+#pragma unroll
+                for (int j = 0; j < kNfaLineage; ++j) actx.tLin[lane * kNfaLineage + j] = lin[j];
+            }
+            waveLdsSync();
+            uint32_t kept = 0;
+            if (lane == 0) kept = nfaAtomicStep(actx, nThreads, 0, behindBits[prevCls] | aheadBits[edgeClass], L, true);
+            kept = __shfl(kept, 0, 64);
+            waveLdsSync();
+            if (kept == 0xFFFFFFFFu) {
+                overflow = true;
+            } else if (kept) {  // the first survivor is the match; its source thread holds the captures
+                const uint32_t win = newSrc[0];
+                if (lane == win) {
+                    accept = true;
+                    endTags = uint64_t(newTagsLo[0]) | (uint64_t(newTagsHi[0]) << 32);
+                }
+            }
+        }
+    }
+    if (!atomicEnd && !overflow && lane < nThreads) {
         const uint32_t ctrue = behindBits[prevCls] | aheadBits[edgeClass];
         const uint32_t fs = followStart[myPos], fe = followStart[myPos + 1];
         for (uint32_t q = fs; q < fe; ++q) {

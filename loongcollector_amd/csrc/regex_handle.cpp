@@ -108,7 +108,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
 }
 
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut) {
-    if (nfa.atomicCount) throw RegexError("nfa: atomic groups / possessive quantifiers need the TDFA engine");
+    if (nfa.atomicCount > 255) throw RegexError("nfa: more than 255 atomic group instances");
     const int npos = int(nfa.positions.size());
     classMapOut.assign(256, 0);
     std::map<std::vector<bool>, int> sig2cls;
@@ -144,14 +144,20 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             for (const auto& path : nfa.follow[size_t(p)]) {
                 if (path.target < 0 || !nfa.positions[size_t(path.target)].has(rep[c])) continue;
                 ++passing;
-                if (path.target != p || path.tags != 0 || path.cond != 0) selfOnly = false;
+                if (path.target != p || path.tags != 0 || path.cond != 0 || !path.atoms.empty()) selfOnly = false;
             }
             if (passing == 1 && selfOnly) m |= uint64_t(1) << c;
         }
+        // a path that enters or leaves an atomic group acts even when its target cannot take the byte (leaving commits
+        // the group): such a position is never in a steady state
+        for (const auto& path : nfa.follow[size_t(p)])
+            for (const auto& ev : path.atoms)
+                if (ev.code < kAssertEvent) m = 0;
         stableMask[size_t(p) * 2] = uint32_t(m);
         stableMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
     }
-    std::vector<uint32_t> followStart, paths;
+    std::vector<uint32_t> followStart, paths, pathEvents, events;
+    std::vector<uint32_t> atomicPos(size_t(npos) / 32 + 2, 0);  // bit p: some path out of position p enters/leaves a group
     for (int p = 0; p <= npos; ++p) {
         followStart.push_back(uint32_t(paths.size() / 4));
         for (const auto& path : nfa.follow[size_t(p)]) {
@@ -159,6 +165,16 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             paths.push_back(path.cond);
             paths.push_back(uint32_t(path.tags));
             paths.push_back(uint32_t(path.tags >> 32));
+            if (nfa.atomicCount) {
+                if (path.atoms.size() > 255 || events.size() >= (1u << 24))
+                    throw RegexError("nfa: atomic event list too long");
+                pathEvents.push_back(uint32_t(events.size() << 8) | uint32_t(path.atoms.size()));
+                for (const auto& ev : path.atoms) {
+                    if (ev.visit > 0xFFFF) throw RegexError("nfa: too many atomic exits on one follow list");
+                    events.push_back(uint32_t(uint16_t(int16_t(ev.code))) | (uint32_t(ev.visit) << 16));
+                    if (ev.code < kAssertEvent) atomicPos[size_t(p) / 32] |= 1u << (p % 32);
+                }
+            }
         }
     }
     followStart.push_back(uint32_t(paths.size() / 4));
@@ -187,6 +203,12 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     ahead[rep.size()] = nfa.aheadBits(kEdge);
     hdr[NF_OFF_BEHIND] = w.put(behind);
     hdr[NF_OFF_AHEAD] = w.put(ahead);
+    if (nfa.atomicCount) {
+        if (events.empty()) events.push_back(0);
+        hdr[NF_OFF_PATHEV] = w.put(pathEvents);
+        hdr[NF_OFF_EVENTS] = w.put(events);
+        hdr[NF_OFF_ATOMICPOS] = w.put(atomicPos);
+    }
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(NF_TOTAL_BYTES);
 }
@@ -293,8 +315,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         // the NFA blob is always packed when it fits: tests cross-check both engines on one handle
         try {
             re->nfaBlob = packNfaBlob(re->nfa, re->nfaClassMap);
-            if (lcNfaLdsBytes(uint32_t(re->nfaBlob.size() * 4), uint32_t(re->nfa.positions.size())) > kLcLdsPerCu)
-                throw RegexError("nfa: program exceeds the 160 KiB LDS of a CU");
+            // (a program that does not fit into LDS next to its scratch is read in place from HBM by the kernel)
+            if (lcNfaLdsBytes(0, uint32_t(re->nfa.positions.size()), re->nfa.atomicCount > 0) > kLcLdsPerCu)
+                throw RegexError("nfa: per-wave scratch exceeds the 160 KiB LDS of a CU");
         } catch (const RegexError&) {
             re->nfaBlob.clear();
             if (re->engine == LC_ENGINE_NFA) throw;

@@ -64,8 +64,9 @@ inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
         if (fits(b, kLcLdsPerCu)) return b;
     return 0;
 }
-inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos) {
-    return size_t(blobBytes) + size_t(4) * (((nPos + 3) & ~3u) + 256) * 4;  // 4 waves x (best[nPos] + 4x64 words)
+// 4 waves x (best[nPos] + 4x64 words) [+ 4 x the atomic path's scratch, nfa_kernel.hpp kNfaAtomicScratchWords = 1344]
+inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos, bool atomic) {
+    return size_t(blobBytes) + size_t(4) * (((nPos + 3) & ~3u) + 256) * 4 + (atomic ? size_t(4) * 1344 * 4 : 0);
 }
 
 // implemented in gpu_runtime.hip; frees device copies

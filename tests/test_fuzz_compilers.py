@@ -9,6 +9,7 @@ import pytest
 
 from loongcollector_amd import binding as B
 from oracle.oracle import OracleRegex
+from tests.helpers.nfa_atomic_interp import AtomicNfaInterp
 from tests.helpers.table_interp import NfaInterp, TdfaInterp
 
 _spec = importlib.util.spec_from_file_location(
@@ -76,13 +77,14 @@ def test_random_atomic_patterns_tdfa_tables_vs_oracle(seed):
             except B.RegexUnsupportedError as e:
                 assert "can match the empty string" in str(e) or "too many" in str(e) or "limit" in str(e), (p, str(e))
                 continue
-            if rx.info()["engine"] != B.LC_ENGINE_TDFA:
-                continue
-            it = TdfaInterp(rx)
+            its = ([TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + (
+                [AtomicNfaInterp(rx)] if rx.has_nfa_program() else [])
             for _ in range(8):
                 s = bytes(rng.choice(b'abc1 ') for _ in range(rng.randint(0, 8)))
                 exp = oracle_fn(s)
                 want = None if exp is None else [v for ab in (exp if flags else exp[1:]) for v in ab]
-                checked += 1
-                assert it.fullmatch(s) == want, (p, s, flags)
-    assert checked > 2500
+                for it in its:
+                    checked += 1
+                    got = it.fullmatch(s)
+                    assert got == want or got == "overflow", (p, s, flags, type(it).__name__)
+    assert checked > 5000

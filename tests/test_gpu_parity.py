@@ -287,7 +287,7 @@ def test_length_scheduled_ragged_path_is_bit_exact(torch_dev, engine):
     assert (np.diff((length[order] >> 5).astype(np.int64)) <= 0).all()    # longest bucket first
 
 
-def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_kernel(torch_dev, golden_dir):
+def test_atomic_groups_and_possessive_quantifiers_on_both_kernels(torch_dev, golden_dir):
     """(?>X) / X*+ vectors (regex module ∧ PCRE1, tests/golden/gen_atomic_golden.py) through the C ABI, full and search."""
     with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
         golden = json.load(f)
@@ -300,13 +300,16 @@ def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_kernel(torch_dev, 
                 continue
             subs = [s.encode("latin-1") for s, _ in c["subs"]]
             data, off, length = pack(subs)
-            caps, status = run_device(torch_dev, rx, data, off, length)
-            for i, (_, flat) in enumerate(c["subs"]):
-                checked += 1
-                exp = flat if kind == "search" or flat is None else flat[2:]
-                ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
-                    status[i] == B.LC_MATCH and list(caps[i]) == exp)
-                if not ok:
-                    bad.append((kind, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
-    assert checked > 3500
+            engines = ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + (
+                [B.LC_ENGINE_NFA] if rx.has_nfa_program() else [])
+            for eng in engines:
+                caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+                for i, (_, flat) in enumerate(c["subs"]):
+                    checked += 1
+                    exp = flat if kind == "search" or flat is None else flat[2:]
+                    ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
+                        status[i] == B.LC_MATCH and list(caps[i]) == exp)
+                    if not ok:
+                        bad.append((kind, eng, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
+    assert checked > 7000
     assert not bad, bad[:5]

@@ -11,7 +11,8 @@ import pytest
 from loongcollector_amd import binding as B
 from loongcollector_amd.grok import Grok, GrokInitError
 from oracle.grok_oracle import MATCH_SUCCESS, GrokOracle
-from tests.helpers.table_interp import NfaInterp, TdfaInterp
+from tests.helpers.nfa_atomic_interp import AtomicNfaInterp
+from tests.helpers.table_interp import TdfaInterp
 
 GROK_SYNTAX = (B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_NO_DOTALL | B.LC_SYNTAX_NO_MULTILINE
                | B.LC_SYNTAX_REGEXP2)
@@ -120,7 +121,7 @@ class TableGrok:
         self.interps = []
         for i in range(g.n_match):
             rx = B.GpuRegex(g.expanded(i).encode("utf-8"), syntax_flags=GROK_SYNTAX)
-            it = TdfaInterp(rx) if rx.info()["engine"] == B.LC_ENGINE_TDFA else NfaInterp(rx)
+            it = TdfaInterp(rx) if rx.info()["engine"] == B.LC_ENGINE_TDFA else AtomicNfaInterp(rx)
             assert (rx.info()["engine"] == B.LC_ENGINE_TDFA) == (g.engine(i) == B.LC_ENGINE_TDFA)
             self.interps.append(it)
 

@@ -9,6 +9,7 @@ import pytest
 
 from loongcollector_amd import binding as B
 from oracle.oracle import OracleRegex
+from tests.helpers.nfa_atomic_interp import AtomicNfaInterp
 from tests.helpers.table_interp import NfaInterp, TdfaInterp
 
 
@@ -132,8 +133,9 @@ def test_search_mode_tables_reproduce_every_search_vector(golden_dir):
     assert not bad, bad[:5]
 
 
-def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_tables(golden_dir):
-    """Atomic groups only exist on the TDFA engine (segment lineage in tdfa.cpp); the NFA program refuses them."""
+def test_atomic_groups_and_possessive_quantifiers_on_both_engines_tables(golden_dir):
+    """Atomic groups: segment lineage in the TDFA builder (tdfa.cpp commitAtomic), and the same commit rules applied per
+    step by the NFA engine."""
     with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
         d = json.load(f)
     bad, n, unsupported = [], 0, 0
@@ -146,11 +148,9 @@ def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_tables(golden_dir)
                 assert "unbounded repeat of a sub-expression that can match the empty string" in str(e), (c["p"], str(e))
                 unsupported += 1
                 continue
-            atomic = "(?>" in c["p"] or any(q in c["p"] for q in ("*+", "++", "?+", "}+"))
             interps = [TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []
-            if rx.has_nfa_program():
-                assert not atomic
-                interps.append(NfaInterp(rx))
+            if rx.has_nfa_program():   # the NFA engine's ordered commit pass (nfa_kernel.hpp nfaAtomicStep), in Python
+                interps.append(AtomicNfaInterp(rx))
             assert interps
             for subj, flat in c["subs"]:
                 exp = flat if kind == "search" or flat is None else flat[2:]
@@ -159,5 +159,5 @@ def test_atomic_groups_and_possessive_quantifiers_on_the_tdfa_tables(golden_dir)
                     got = it.fullmatch(subj.encode("latin-1"))
                     if got != exp:
                         bad.append((kind, c["p"], subj, got, exp))
-    assert n > 4000 and unsupported <= 40, (n, unsupported)
+    assert n > 8000 and unsupported <= 40, (n, unsupported)
     assert not bad, bad[:5]
