@@ -40,7 +40,7 @@ def test_reference_parse_vectors_through_process_logs(torch_dev, golden):
         ran += 1
         got = g.process_logs([[tuple(kv) for kv in log] for log in r["in"]])
         assert [[list(kv) for kv in log] for log in got] == r["out"], r["cite"]
-    assert ran >= 6
+    assert ran == len(golden["reference"])
 
 
 def test_regex_module_golden_vectors(torch_dev, golden):
@@ -57,7 +57,7 @@ def test_regex_module_golden_vectors(torch_dev, golden):
             checked += 1
             assert [[k, v.decode("latin-1")] for k, v in f] == want, (c["config"]["Match"], val)
             assert (p >= 0) == bool(want)
-    assert checked >= 250 and skipped <= 3
+    assert checked >= 300 and skipped == 0
 
 
 def _random_values(rng, n):
@@ -142,7 +142,7 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
             ok.append(m)
         except GrokInitError:
             pass
-    assert len(ok) >= 30, len(ok)
+    assert len(ok) >= 46, len(ok)
     g = Grok(Match=ok, CustomPatterns=cfg["custom_patterns"])
     o = GrokOracle(ok, custom_patterns=cfg["custom_patterns"])
     rng = random.Random(3)
