@@ -116,6 +116,10 @@ enum {
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 
+/* The longest byte string every match of the pattern must contain (*len = 0: none is certain).  A value without it cannot
+ * match; the Grok matcher uses it to skip the automaton for most (value, Match pattern) pairs. */
+const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t* len);
+
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int lc_device_count(void);
 

@@ -70,6 +70,8 @@ def load(path=None):
     L.lc_sched_scratch_bytes.argtypes = [u32]
     L.lc_regex_match_device_ragged.restype = i32
     L.lc_regex_match_device_ragged.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, sz, vp]
+    L.lc_regex_required_literal.restype = vp
+    L.lc_regex_required_literal.argtypes = [vp, ctypes.POINTER(sz)]
     L.lc_regex_match_device_from.restype = i32
     L.lc_regex_match_device_from.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, u32, vp, vp, vp]
     L.lc_split_scratch_bytes.restype = sz
@@ -170,6 +172,11 @@ class GpuRegex:
             sep_bytes, n, d_nlines.data_ptr() if d_nlines is not None else None, G, d_caps.data_ptr(),
             d_status.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(), stream)
         _check(rc, "lc_regex_match_device_ragged")
+
+    def required_literal(self):
+        n = ctypes.c_size_t()
+        p = self._L.lc_regex_required_literal(self._h, ctypes.byref(n))
+        return ctypes.string_at(p, n.value) if n.value else b""
 
     def match_device_from(self, d_data, d_off, d_len, n, d_caps, d_status, d_lines=None, d_nlines=None, d_from=None,
                           ngroups=None, sep_bytes=0, stream=None, engine=LC_ENGINE_AUTO):

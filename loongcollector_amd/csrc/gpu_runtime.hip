@@ -589,10 +589,24 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
     uint32_t host[4] = {0, 0, 0, 0};
     for (size_t p = 0; p < patterns.size() && nTried; ++p) {
         const GrokDevicePattern& gp = patterns[p];
-        const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte
+        const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte ...
         uint32_t nIn = nTried;
         uint32_t* outs[2] = {roundIn, roundOut};
         int flip = 0;
+        if (!gp.re->requiredLiteral.empty()) {  // ... that contains the literal every match of this pattern must contain
+            GrokLiteral lit;
+            const std::string& s = gp.re->requiredLiteral;
+            lit.len = uint32_t(std::min<size_t>(s.size(), sizeof lit.bytes));
+            std::memcpy(lit.bytes, s.data() + (s.size() - lit.len), lit.len);
+            const uint32_t perBlock = kGrokBlock / 64;
+            hipLaunchKernelGGL(grok_literal_filter_kernel, dim3((nTried + perBlock - 1) / perBlock), dim3(kGrokBlock), 0, st,
+                               tried, nTried, d_data, d_off, d_len, lit, outs[1], counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            nIn = host[0];
+            in = outs[1];
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+        }
         while (nIn) {
             int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, row / 2, caps,
                                      status, st);

@@ -226,6 +226,44 @@ static void shiftCaptures(Node& n) {
     if (n.kind == Node::Group && n.capture) ++n.capture;
     for (auto& k : n.kids) shiftCaptures(*k);
 }
+// The longest byte string every match of the sub-expression must contain (possibly empty).  A line without it cannot
+// match, which lets an ordered-pattern-list caller (Grok) skip the automaton for most (line, pattern) pairs.
+// Returns the best literal found inside `n`; `run` is the literal run being built across a concatenation.
+static std::string requiredLiteral(const Node& n) {
+    auto singleByte = [](const Node& k, unsigned& b) {
+        if (k.kind != Node::Set) return false;
+        int count = 0;
+        for (int w = 0; w < 4; ++w) count += __builtin_popcountll(k.set.w[w]);
+        if (count != 1) return false;
+        for (unsigned v = 0; v < 256; ++v)
+            if (k.set.has(v)) b = v;
+        return true;
+    };
+    auto better = [](const std::string& a, const std::string& b) { return b.size() > a.size() ? b : a; };
+    unsigned b = 0;
+    switch (n.kind) {
+        case Node::Set: return singleByte(n, b) ? std::string(1, char(b)) : std::string();
+        case Node::Cat: {
+            std::string best, run;
+            for (const auto& k : n.kids) {
+                if (singleByte(*k, b)) {
+                    run.push_back(char(b));
+                    best = better(best, run);
+                    continue;
+                }
+                if (k->kind == Node::Assert || k->kind == Node::Empty) continue;  // zero-width: the run goes on
+                run.clear();
+                best = better(best, requiredLiteral(*k));
+            }
+            return best;
+        }
+        case Node::Group:
+        case Node::Atomic: return requiredLiteral(*n.kids[0]);
+        case Node::Repeat: return n.min >= 1 ? requiredLiteral(*n.kids[0]) : std::string();
+        default: return std::string();  // Alt: no branch is certain; Assert / Empty: nothing consumed
+    }
+}
+
 static void wrapForSearch(ParsedRegex& re) {
     shiftCaptures(*re.root);
     auto anyStar = [](bool greedy) {
@@ -285,6 +323,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             delete re;
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
         }
+        re->requiredLiteral = requiredLiteral(*parsed.root);
         if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed);
         re->nfa = buildFollowNfa(parsed);
         if (syntax_flags & LC_SYNTAX_SEARCH) {  // wrapForSearch generates its prefix '.' first and its suffix '.' last
@@ -360,6 +399,12 @@ extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     out->registers = re->hasTdfa ? re->tdfa.nRegs : 0;
     out->table_bytes = uint32_t((re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
     return LC_OK;
+}
+
+extern "C" const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t* len) {
+    if (!re || !len) return nullptr;
+    *len = re->requiredLiteral.size();
+    return reinterpret_cast<const uint8_t*>(re->requiredLiteral.data());
 }
 
 extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes) {

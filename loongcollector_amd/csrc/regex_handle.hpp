@@ -25,6 +25,7 @@ struct lc_regex {
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
+    std::string requiredLiteral;        // longest byte string every match must contain ("" if none is certain)
 
     // device residency, managed by gpu_runtime.hip
     std::mutex deviceMutex;
