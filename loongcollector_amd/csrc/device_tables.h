@@ -54,7 +54,8 @@ enum {
     NF_OFF_CLASSMAP = 4,  // u8[256] byte -> class
     NF_OFF_POSMASK = 5,   // u64[nPos] (as 2 x u32): bit c set iff position accepts byte class c  (nClasses <= 64)
     NF_OFF_FOLLOWSTART = 6, // u32[nPos+2]: follow list of position p = paths[followStart[p] .. followStart[p+1])
-    NF_OFF_PATHS = 7,     // 4 x u32 per path: target (0xFFFFFFFF = MATCH), cond bits, tags lo, tags hi
+    NF_OFF_PATHS = 7,     // 2 x u32 per path: x = target (16 bits, 0xFFFF = MATCH) | aux index << 16 (0 = no cond, no tags);
+                          // y = (first event << 8) | event count (atomic patterns, else 0)
     NF_TOTAL_BYTES = 8,
     NF_NPATHS = 9,
     NF_CONDS_USED = 10,
@@ -65,10 +66,15 @@ enum {
     NF_OFF_AHEAD = 13,    // u32[nClasses+1]: look-ahead assertions that hold when the next byte has class c; entry
                           // nClasses = end of input
     // patterns with atomic groups / possessive quantifiers only (all three 0 otherwise):
-    NF_OFF_PATHEV = 14,   // u32[nPaths]: (first event << 8) | event count of the path
+    NF_ATOMIC = 14,       // number of atomic group instances
     NF_OFF_EVENTS = 15,   // u32[]: low16 = code (int16: +(g+1) enter group instance g, -(g+1) leave it, 20000+i assertion i
                           // is tested here), high16 = exit visit (follow_nfa.hpp FollowPath::Event)
     NF_OFF_ATOMICPOS = 16, // u32[(nPos+1)/32+1]: bit p = some path out of position p enters or leaves an atomic group
+    NF_OFF_AUX = 17,      // 4 x u32 per entry: cond bits, tags lo, tags hi, 0 -- the distinct (cond, tags) triples of the paths
+    NF_SEARCH = 18,       // 1: position 0 is the lazy prefix of the LC_SYNTAX_SEARCH wrapper (the kernel may skip ahead to the
+                          // next byte the pattern can start with while only that thread is alive)
+    NF_OFF_TOUCHY = 19,   // atomic patterns: u64[nPos+1], bit c = on byte class c a thread on this position needs the ordered
+                          // commit pass (a path leaves a group, or enters one towards a position that takes class c)
     NF_HEADER_WORDS = 20
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

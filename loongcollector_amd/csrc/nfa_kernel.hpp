@@ -55,14 +55,31 @@ constexpr uint32_t kNfaAtomicScratchWords = 64 /*tPos*/ + 64 /*tNlin*/ + 64 * kN
                                             64 * kNfaLineageWork /*newLin*/ + 64 /*closedKey*/ + 64 /*closedBy*/;
 static_assert(kNfaAtomicScratchWords == 1344, "keep regex_handle.hpp lcNfaLdsBytes in step");
 
+// A path record is 8 bytes: x = target (16 bits, 0xFFFF = MATCH) | index of its (cond, tags) triple in the aux table
+// (16 bits, 0 = no assertion and no tag), y = (first event << 8) | event count (patterns with atomic groups).  Unpacked
+// here into the (target, cond, tagsLo, tagsHi) shape the kernel works with.
+__device__ __forceinline__ uint4 nfaPath(const uint2* paths, const uint4* aux, uint32_t q) {
+    const uint32_t x = paths[q].x;
+    uint4 p{x & 0xFFFFu, 0u, 0u, 0u};
+    if (p.x == 0xFFFFu) p.x = NF_TARGET_MATCH;
+    if (x >> 16) {
+        const uint4 a = aux[x >> 16];
+        p.y = a.x;
+        p.z = a.y;
+        p.w = a.z;
+    }
+    return p;
+}
+
 struct NfaAtomicCtx {
     const uint32_t* followStart;
-    const uint4* paths;
-    const uint32_t* pathEv;
+    const uint2* paths;
+    const uint4* aux;
     const uint32_t* events;
     const uint2* posMask;
     uint32_t *tPos, *tNlin, *tLin, *newNlin, *newLin, *closedKey, *closedBy;
     uint32_t *newPos, *newSrc, *newTagsLo, *newTagsHi;
+    uint32_t* best;  // per-position marker array of the wave (all 0xFFFFFFFF between steps)
 };
 
 // exit visit through which path events [from, n) leave group g (0: they do not, or an assertion stops them first)
@@ -96,8 +113,8 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
         const uint32_t fs = c.followStart[c.tPos[t]], fe = c.followStart[c.tPos[t] + 1];
         const uint32_t nlin = c.tNlin[t];
         for (uint32_t q = fs; q < fe; ++q) {
-            const uint4 p = c.paths[q];
-            const uint32_t pe = c.pathEv[q];
+            const uint4 p = nfaPath(c.paths, c.aux, q);
+            const uint32_t pe = c.paths[q].y;
             const uint32_t* ev = c.events + (pe >> 8);
             const uint32_t nev = pe & 0xFFu;
             bool targetOk;
@@ -159,7 +176,17 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
                 }
             }
             if (dead || !ok || !targetOk) continue;
-            if (nKept == 64) return 0xFFFFFFFFu;
+            // Survivors without memberships mirror each other trivially: among them the first one on a position wins
+            // (the ordinary Pike rule), decided right here with the per-position marker array.
+            if (!final && wn == 0) {
+                if (c.best[p.x] != 0xFFFFFFFFu) continue;
+                c.best[p.x] = nKept;
+            }
+            if (nKept == 64) {
+                for (uint32_t k = 0; k < nKept; ++k)
+                    if (c.newPos[k] < 0x40000000u) c.best[c.newPos[k]] = 0xFFFFFFFFu;
+                return 0xFFFFFFFFu;
+            }
             c.newPos[nKept] = final ? (0x40000000u + nKept) : p.x;  // final: survivors never merge
             c.newSrc[nKept] = t;
             c.newTagsLo[nKept] = p.z;
@@ -211,24 +238,41 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
         }
         return true;
     };
-    for (bool changed = !final; changed;) {
-        changed = false;
-        for (uint32_t i = 1; i < nKept && !changed; ++i)
-            for (uint32_t j = 0; j < i; ++j)
-                if (mirrors(j, i)) {
-                    for (uint32_t k = i + 1; k < nKept; ++k) {
-                        c.newPos[k - 1] = c.newPos[k];
-                        c.newSrc[k - 1] = c.newSrc[k];
-                        c.newTagsLo[k - 1] = c.newTagsLo[k];
-                        c.newTagsHi[k - 1] = c.newTagsHi[k];
-                        c.newNlin[k - 1] = c.newNlin[k];
-                        for (uint32_t m = 0; m < c.newNlin[k]; ++m)
-                            c.newLin[(k - 1) * kNfaLineageWork + m] = c.newLin[k * kNfaLineageWork + m];
+    if (!final) {
+        // Only pairs that involve a membership need the full test (the others were settled while appending); a dropped
+        // survivor is parked on position kNfaDropped (it holds nothing, so it cannot influence a later test).
+        constexpr uint32_t kNfaDropped = 0x7FFFFFFFu;
+        for (uint32_t i = 0; i < nKept; ++i) c.best[c.newPos[i]] = 0xFFFFFFFFu;  // clear the markers set while appending
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (uint32_t i = 1; i < nKept; ++i) {
+                if (c.newPos[i] == kNfaDropped) continue;
+                for (uint32_t j = 0; j < i; ++j) {
+                    if (c.newPos[j] != c.newPos[i] || (!c.newNlin[i] && !c.newNlin[j])) continue;
+                    if (mirrors(j, i)) {
+                        c.newPos[i] = kNfaDropped;
+                        c.newNlin[i] = 0;
+                        changed = true;
+                        break;
                     }
-                    --nKept;
-                    changed = true;
-                    break;
                 }
+            }
+        }
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < nKept; ++k) {
+            if (c.newPos[k] == kNfaDropped) continue;
+            if (w != k) {
+                c.newPos[w] = c.newPos[k];
+                c.newSrc[w] = c.newSrc[k];
+                c.newTagsLo[w] = c.newTagsLo[k];
+                c.newTagsHi[w] = c.newTagsHi[k];
+                c.newNlin[w] = c.newNlin[k];
+                for (uint32_t m = 0; m < c.newNlin[k]; ++m)
+                    c.newLin[w * kNfaLineageWork + m] = c.newLin[k * kNfaLineageWork + m];
+            }
+            ++w;
+        }
+        nKept = w;
     }
     for (uint32_t i = 0; i < nKept; ++i)
         if (c.newNlin[i] > uint32_t(kNfaLineage)) return 0xFFFFFFFFu;
@@ -277,7 +321,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
     const uint32_t edgeClass = hdr[NF_NCLASSES];  // table index standing for start / end of input
     const uint32_t* followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
-    const uint4* paths = reinterpret_cast<const uint4*>(tbl + hdr[NF_OFF_PATHS]);
+    const uint2* paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
+    const uint4* aux = reinterpret_cast<const uint4*>(tbl + hdr[NF_OFF_AUX]);
 
     const uint32_t wave = tid >> 6, lane = tid & 63;
     // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newTagsLo, newTagsHi)
@@ -292,11 +337,12 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     // atomic path: its per-wave scratch sits behind the scratch of all waves
     NfaAtomicCtx actx{};
     const uint32_t* atomicPos = nullptr;
+    const uint2* touchyMask = nullptr;
     if constexpr (ATOMIC) {
         uint32_t* a = reinterpret_cast<uint32_t*>(smem + scratchBase) + kNfaWaves * scratchWords + wave * kNfaAtomicScratchWords;
         actx.followStart = followStart;
         actx.paths = paths;
-        actx.pathEv = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_PATHEV]);
+        actx.aux = aux;
         actx.events = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_EVENTS]);
         actx.posMask = posMask;
         actx.tPos = a;
@@ -310,7 +356,9 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         actx.newSrc = newSrc;
         actx.newTagsLo = newTagsLo;
         actx.newTagsHi = newTagsHi;
+        actx.best = best;
         atomicPos = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_ATOMICPOS]);
+        touchyMask = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_TOUCHY]);
     }
 
     const uint32_t slot = blockIdx.x * kNfaWaves + wave;
@@ -343,6 +391,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             prevCls = classMap[data[size_t(o) + from - 1]];
         }
     }
+    const bool searchSkip = hdr[NF_SEARCH] != 0;
+    const uint2 stable0 = stable[0];  // steady classes of the search wrapper's prefix position
     uint32_t curWord;
     {
         const uint32_t w = (((head + from) >> 8) << 6) + lane;  // the 256-byte chunk the first byte lives in
@@ -354,6 +404,33 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         if (i != from && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
             const uint32_t w = (idx >> 2) + lane;
             curWord = (w < nWords) ? words[w] : 0;
+        }
+        // Search patterns, only the wrapper's prefix thread alive (the usual state on a value this pattern does not
+        // match): nothing can happen until a byte the pattern can START with, so all 64 lanes look for that byte in the
+        // loaded chunk at once (4 bytes each) instead of stepping the automaton byte by byte.
+        if (searchSkip && nThreads == 1 && __builtin_amdgcn_readfirstlane(myPos) == 0) {
+            const uint32_t chunkBase = idx & ~255u, end = head + L;
+            uint32_t firstHit = 4;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
+                const uint32_t steady = c < 32 ? (stable0.x >> c) & 1u : (stable0.y >> (c - 32)) & 1u;
+                if (bi >= idx && bi < end && !steady) firstHit = uint32_t(j);
+            }
+            const uint64_t hit = __ballot(firstHit < 4);
+            uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                stop = chunkBase + uint32_t(l) * 4 + uint32_t(__shfl(int(firstHit), l, 64));
+            }
+            stop = __builtin_amdgcn_readfirstlane(stop);
+            if (stop > idx) {  // bytes [idx, stop) only feed the prefix loop; remember the class of the last one
+                const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
+                prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                i = stop - head - 1;
+                continue;
+            }
         }
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
         const int b = int((wsel >> ((idx & 3u) * 8)) & 0xFFu);
@@ -374,7 +451,11 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         prevCls = cls;
 
         if constexpr (ATOMIC) {
-            const bool touchy = liveLane && (nlin != 0 || ((atomicPos[myPos >> 5] >> (myPos & 31)) & 1u));
+            bool touchy = false;
+            if (liveLane) {
+                const uint2 tm = touchyMask[myPos];
+                touchy = nlin != 0 || (cls < 32 ? (tm.x >> cls) & 1u : (tm.y >> (cls - 32)) & 1u);
+            }
             if (__any(touchy)) {  // ordered commit pass, lane 0 (see nfaAtomicStep)
                 if (liveLane) {
                     actx.tPos[lane] = myPos;
@@ -423,7 +504,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         uint64_t passMask = 0;
         for (uint32_t k = 0; __any(k < cnt); ++k) {
             if (k < cnt) {
-                const uint4 p = paths[fs + k];
+                const uint4 p = nfaPath(paths, aux, fs + k);
                 if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
                     const uint2 pm = posMask[p.x];
                     const uint32_t bit = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
@@ -441,7 +522,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             if (m) {
                 const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
                 m &= m - 1;
-                const uint4 p = paths[fs + k];
+                const uint4 p = nfaPath(paths, aux, fs + k);
                 if (best[p.x] == rankBase + k) winMask |= uint64_t(1) << k;
             }
         }
@@ -455,7 +536,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             if (m) {
                 const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
                 m &= m - 1;
-                const uint4 p = paths[fs + k];
+                const uint4 p = nfaPath(paths, aux, fs + k);
                 newPos[slot] = p.x;
                 newSrc[slot] = lane;
                 newTagsLo[slot] = p.z;
@@ -518,7 +599,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t ctrue = behindBits[prevCls] | aheadBits[edgeClass];
         const uint32_t fs = followStart[myPos], fe = followStart[myPos + 1];
         for (uint32_t q = fs; q < fe; ++q) {
-            const uint4 p = paths[q];
+            const uint4 p = nfaPath(paths, aux, q);
             if (p.x == NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
                 accept = true;
                 endTags = uint64_t(p.z) | (uint64_t(p.w) << 32);

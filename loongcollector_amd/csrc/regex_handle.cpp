@@ -2,6 +2,7 @@
 #include "regex_handle.hpp"
 
 #include <cstdlib>
+#include <tuple>
 
 #include <algorithm>
 #include <cstdio>
@@ -148,36 +149,50 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             }
             if (passing == 1 && selfOnly) m |= uint64_t(1) << c;
         }
-        // a path that enters or leaves an atomic group acts even when its target cannot take the byte (leaving commits
-        // the group): such a position is never in a steady state
+        // a path that LEAVES an atomic group acts even when its target cannot take the byte (leaving commits the group):
+        // such a position is never in a steady state.  (Entering a group on a path that goes nowhere has no effect.)
         for (const auto& path : nfa.follow[size_t(p)])
             for (const auto& ev : path.atoms)
-                if (ev.code < kAssertEvent) m = 0;
+                if (ev.code < 0) m = 0;
         stableMask[size_t(p) * 2] = uint32_t(m);
         stableMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
     }
-    std::vector<uint32_t> followStart, paths, pathEvents, events;
+    if (npos >= 0xFFFF) throw RegexError("nfa: more than 65534 positions");
+    std::vector<uint32_t> followStart, paths, events, aux(4, 0);  // aux entry 0 = (no cond, no tags)
+    std::map<std::tuple<uint32_t, uint64_t>, uint32_t> auxIndex;
     std::vector<uint32_t> atomicPos(size_t(npos) / 32 + 2, 0);  // bit p: some path out of position p enters/leaves a group
     for (int p = 0; p <= npos; ++p) {
-        followStart.push_back(uint32_t(paths.size() / 4));
+        followStart.push_back(uint32_t(paths.size() / 2));
         for (const auto& path : nfa.follow[size_t(p)]) {
-            paths.push_back(path.target == kMatchTarget ? NF_TARGET_MATCH : uint32_t(path.target));
-            paths.push_back(path.cond);
-            paths.push_back(uint32_t(path.tags));
-            paths.push_back(uint32_t(path.tags >> 32));
+            uint32_t a = 0;
+            if (path.cond || path.tags) {
+                auto it = auxIndex.find({path.cond, path.tags});
+                if (it == auxIndex.end()) {
+                    if (aux.size() / 4 >= 0xFFFF) throw RegexError("nfa: too many distinct tag sets");
+                    it = auxIndex.emplace(std::make_tuple(path.cond, path.tags), uint32_t(aux.size() / 4)).first;
+                    aux.push_back(path.cond);
+                    aux.push_back(uint32_t(path.tags));
+                    aux.push_back(uint32_t(path.tags >> 32));
+                    aux.push_back(0);
+                }
+                a = it->second;
+            }
+            paths.push_back((path.target == kMatchTarget ? 0xFFFFu : uint32_t(path.target)) | (a << 16));
+            uint32_t evWord = 0;
             if (nfa.atomicCount) {
                 if (path.atoms.size() > 255 || events.size() >= (1u << 24))
                     throw RegexError("nfa: atomic event list too long");
-                pathEvents.push_back(uint32_t(events.size() << 8) | uint32_t(path.atoms.size()));
+                evWord = uint32_t(events.size() << 8) | uint32_t(path.atoms.size());
                 for (const auto& ev : path.atoms) {
                     if (ev.visit > 0xFFFF) throw RegexError("nfa: too many atomic exits on one follow list");
                     events.push_back(uint32_t(uint16_t(int16_t(ev.code))) | (uint32_t(ev.visit) << 16));
                     if (ev.code < kAssertEvent) atomicPos[size_t(p) / 32] |= 1u << (p % 32);
                 }
             }
+            paths.push_back(evWord);
         }
     }
-    followStart.push_back(uint32_t(paths.size() / 4));
+    followStart.push_back(uint32_t(paths.size() / 2));
     BlobWriter w;
     w.reserve(NF_HEADER_WORDS * 4);
     uint32_t hdr[NF_HEADER_WORDS] = {};
@@ -185,12 +200,14 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_NPOS] = uint32_t(npos);
     hdr[NF_NSLOTS] = uint32_t(nfa.slotCount());
     hdr[NF_NCLASSES] = uint32_t(rep.size());
-    hdr[NF_NPATHS] = uint32_t(paths.size() / 4);
+    hdr[NF_NPATHS] = uint32_t(paths.size() / 2);
     hdr[NF_CONDS_USED] = nfa.condsUsed;
+    hdr[NF_SEARCH] = nfa.searchPrefix == 0 ? 1u : 0u;
     hdr[NF_OFF_CLASSMAP] = w.put(classMapOut);
     hdr[NF_OFF_POSMASK] = w.put(posMask);
     hdr[NF_OFF_FOLLOWSTART] = w.put(followStart);
     hdr[NF_OFF_PATHS] = w.put(paths);
+    hdr[NF_OFF_AUX] = w.put(aux);
     hdr[NF_OFF_STABLE] = w.put(stableMask);
     // look assertions per byte class: behind[c] / ahead[c] = cond bits that hold when the previous / next byte has
     // class c; entry nClasses = START / END
@@ -204,8 +221,28 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_OFF_BEHIND] = w.put(behind);
     hdr[NF_OFF_AHEAD] = w.put(ahead);
     if (nfa.atomicCount) {
+        // touchy[p] bit c: on byte class c a thread on position p needs the ordered commit pass -- some path out of p
+        // leaves a group (acts whatever the byte is) or enters one on its way to a position that takes class c
+        std::vector<uint32_t> touchy(size_t(npos + 1) * 2, 0);
+        for (int p = 0; p <= npos; ++p) {
+            uint64_t m = 0;
+            for (const auto& path : nfa.follow[size_t(p)]) {
+                bool enters = false, leaves = false;
+                for (const auto& ev : path.atoms) {
+                    enters |= ev.code > 0 && ev.code < kAssertEvent;
+                    leaves |= ev.code < 0;
+                }
+                if (leaves) m = ~uint64_t(0);
+                if (enters && path.target >= 0)
+                    for (size_t c = 0; c < rep.size(); ++c)
+                        if (nfa.positions[size_t(path.target)].has(rep[c])) m |= uint64_t(1) << c;
+            }
+            touchy[size_t(p) * 2] = uint32_t(m);
+            touchy[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+        }
+        hdr[NF_OFF_TOUCHY] = w.put(touchy);
         if (events.empty()) events.push_back(0);
-        hdr[NF_OFF_PATHEV] = w.put(pathEvents);
+        hdr[NF_ATOMIC] = uint32_t(nfa.atomicCount);
         hdr[NF_OFF_EVENTS] = w.put(events);
         hdr[NF_OFF_ATOMICPOS] = w.put(atomicPos);
     }

@@ -28,7 +28,7 @@ class AtomicNfaInterp(NfaInterp):
         if not self.atomic:
             return
         npaths = int(blob[9])
-        pe = blob[int(blob[14]) // 4:int(blob[14]) // 4 + npaths]
+        pe = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 2 * npaths].reshape(-1, 2)[:, 1]   # path word y: events
         ev = blob[int(blob[15]) // 4:]
         fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
         for p in range(self.npos + 1):

@@ -64,7 +64,8 @@ class NfaInterp:
         pm = blob[int(blob[5]) // 4:int(blob[5]) // 4 + 2 * self.npos]
         self.posmask = [int(pm[2 * p]) | (int(pm[2 * p + 1]) << 32) for p in range(self.npos)]
         fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
-        paths = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 4 * int(blob[9])].reshape(-1, 4)
+        paths = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 2 * int(blob[9])].reshape(-1, 2)   # NF_OFF_PATHS
+        aux = blob[int(blob[17]) // 4:].reshape(-1)                                            # NF_OFF_AUX (4 words each)
         ncl = self.ncls
         self.behind = [int(x) for x in blob[int(blob[12]) // 4:int(blob[12]) // 4 + ncl + 1]]   # NF_OFF_BEHIND
         self.ahead = [int(x) for x in blob[int(blob[13]) // 4:int(blob[13]) // 4 + ncl + 1]]    # NF_OFF_AHEAD
@@ -72,8 +73,10 @@ class NfaInterp:
         for p in range(self.npos + 1):
             lst = []
             for i in range(int(fs[p]), int(fs[p + 1])):
-                tgt, cond, lo, hi = [int(x) for x in paths[i]]
-                lst.append((-1 if tgt == 0xFFFFFFFF else tgt, cond, lo | (hi << 32)))
+                x = int(paths[i][0])
+                tgt, a = x & 0xFFFF, x >> 16
+                cond, lo, hi = [int(v) for v in aux[4 * a:4 * a + 3]]
+                lst.append((-1 if tgt == 0xFFFF else tgt, cond, lo | (hi << 32)))
             self.follow.append(lst)
 
     def fullmatch(self, s: bytes, max_threads=64, start=0):
