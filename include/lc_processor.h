@@ -75,6 +75,21 @@ void lc_free(void* p);
 #define LC_PROCESSOR_INTERFACE_VERSION 100
 
 struct processor_instance_t;
+/* ---- processor_filter_regex_native (core/plugin/processor/ProcessorFilterNative.cpp) on the device: the step after the
+ * parser in the reference's benchmark pipeline.  config_json: ConditionExp | FilterKey+FilterRegex | Include, and
+ * DiscardingNonUTF8 (same keys, same precedence as ProcessorFilterNative::Init :30-157).  Each regex leaf is one device
+ * launch over the values of its key across the group; events that fail are removed in place (:159-176).
+ * lc_filter_process takes the logtail::PipelineEventGroup* (lc_group_native() of a fixture group). */
+typedef struct lc_filter lc_filter_t;
+int lc_filter_create(const char* config_json, lc_filter_t** out, char* err, size_t errcap);
+void lc_filter_destroy(lc_filter_t* f);
+int lc_filter_mode(const lc_filter_t* f);          /* 0 bypass, 1 expression, 2 rule (ProcessorFilterNative::Mode) */
+int lc_filter_process(lc_filter_t* f, void* native_group);
+void lc_filter_counters(const lc_filter_t* f, uint64_t out[2]);   /* in_events_total, out_events_total */
+/* ProcessorFilterNative::noneUtf8 (:297-379) on a buffer: returns 1 if it holds bytes that routine rejects; with modify
+ * != 0 they are overwritten with ' ' in place (what DiscardingNonUTF8 does to keys and values) */
+int lc_filter_none_utf8(char* buf, size_t n, int modify);
+
 typedef int (*processor_init_func_t)(struct processor_instance_t* ins, void* config, void* context);
 typedef void (*processor_finialize_func_t)(void* plugin_state);
 typedef void (*processor_process_func_t)(void* plugin_state, void* logGroup);

@@ -402,7 +402,7 @@ int growSlot(Slot& s, size_t dataBytes, size_t lines, size_t capsInts) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dStatus), cap));
         s.lineCap = cap;
     }
-    if (capsInts > s.capsCap) {
+    if (capsInts >= s.capsCap) {  // (>=: a status-only caller has capsInts == 0 and still gets a valid pointer)
         (void)hipHostFree(s.hCaps); (void)hipFree(s.dCaps);
         s.hCaps = nullptr; s.dCaps = nullptr; s.capsCap = 0;
         size_t cap = capsInts + (capsInts >> 2) + 64;
@@ -416,7 +416,7 @@ int growSlot(Slot& s, size_t dataBytes, size_t lines, size_t capsInts) {
 int drainSlot(Slot& s, uint32_t ngroups, int32_t* caps, uint8_t* status) {
     if (!s.busy) return LC_OK;
     HIP_TRY(hipEventSynchronize(s.done));
-    std::memcpy(caps + size_t(s.first) * 2 * ngroups, s.hCaps, size_t(s.count) * 2 * ngroups * 4);
+    if (ngroups) std::memcpy(caps + size_t(s.first) * 2 * ngroups, s.hCaps, size_t(s.count) * 2 * ngroups * 4);
     std::memcpy(status + s.first, s.hStatus, s.count);
     s.busy = false;
     return LC_OK;
@@ -494,7 +494,8 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
         HIP_TRY(hipMemcpyAsync(s.dLen, s.hLen, size_t(cnt) * 4, hipMemcpyHostToDevice, s.stream));
         rc = lc_regex_match_device(re, s.dData, s.dOff, s.dLen, 0, cnt, ngroups, s.dCaps, s.dStatus, s.stream);
         if (rc != LC_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(s.hCaps, s.dCaps, size_t(cnt) * 2 * ngroups * 4, hipMemcpyDeviceToHost, s.stream));
+        if (ngroups)
+            HIP_TRY(hipMemcpyAsync(s.hCaps, s.dCaps, size_t(cnt) * 2 * ngroups * 4, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipMemcpyAsync(s.hStatus, s.dStatus, cnt, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipEventRecord(s.done, s.stream));
         s.first = next;
@@ -526,7 +527,7 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
                                          uint32_t ngroups, int32_t* caps, uint8_t* status) {
     if (!re) return LC_ERR_ARG;
     if (n == 0) return LC_OK;
-    if (!lines || !len || !caps || !status) return LC_ERR_ARG;
+    if (!lines || !len || (ngroups && !caps) || !status) return LC_ERR_ARG;  // ngroups == 0: status only
     LineSource src;
     src.ptrs = lines;
     src.len = len;

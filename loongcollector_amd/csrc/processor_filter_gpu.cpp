@@ -1,0 +1,345 @@
+// processor_filter_gpu.cpp -- see processor_filter_gpu.hpp.
+#include "processor_filter_gpu.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "../../include/lc_processor.h"
+#include "../../include/lc_regex_gpu.h"
+
+namespace logtail {
+
+const std::string ProcessorFilterGpu::sName = "processor_filter_regex_gpu";
+
+namespace {
+std::string lower(std::string s) {
+    for (auto& c : s) c = char(std::tolower(static_cast<unsigned char>(c)));
+    return s;
+}
+std::string asString(const lcjson::Value* v) { return (v && v->isString()) ? v->str : std::string(); }  // Json::asString
+}  // namespace
+
+ProcessorFilterGpu::~ProcessorFilterGpu() {
+    for (auto& l : mLeaves) lc_regex_free(l.reg);
+}
+
+int ProcessorFilterGpu::addLeaf(const std::string& key, const std::string& exp, std::string& error) {
+    lc_regex_t* re = nullptr;
+    char err[256];
+    // IsRegexValid + boost::regex(exp) (:94-104, :133-145); a valid Perl regex no device engine can run also fails Init
+    if (lc_regex_compile(exp.data(), exp.size(), 0, LC_ENGINE_AUTO, &re, err, sizeof err) != LC_OK) {
+        error = std::string("regex `") + exp + "` : " + err;
+        return -1;
+    }
+    mLeaves.push_back({key, re});
+    return int(mLeaves.size()) - 1;
+}
+
+// ParseExpressionFromJSON :381-430
+int ProcessorFilterGpu::parseExpression(const lcjson::Value& value, std::string& error) {
+    if (!value.isObject()) return -1;
+    const lcjson::Value* op = value.find("operator");
+    const lcjson::Value* operands = value.find("operands");
+    if (op && op->isString() && operands && operands->isArray()) {
+        const std::string o = lower(op->str);
+        if (o != "not" && o != "and" && o != "or") return -1;  // GetOperatorType :432-444
+        if (o == "not" && operands->arr.size() == 1) {
+            const int child = parseExpression(operands->arr[0], error);
+            if (child < 0) return -1;
+            mNodes.push_back({NOT, child, -1, -1});
+            return int(mNodes.size()) - 1;
+        }
+        if ((o == "and" || o == "or") && operands->arr.size() == 2) {
+            const int l = parseExpression(operands->arr[0], error);
+            const int r = parseExpression(operands->arr[1], error);
+            if (l < 0 || r < 0) return -1;
+            mNodes.push_back({o == "and" ? AND : OR, l, r, -1});
+            return int(mNodes.size()) - 1;
+        }
+        return -1;
+    }
+    const lcjson::Value *key = value.find("key"), *exp = value.find("exp"), *type = value.find("type");
+    if ((key && key->isString() && exp && exp->isString()) || !(type && type->isString())) {
+        if (lower(asString(type)) != "regex") return -1;  // GetNodeFuncType :446-454
+        const int leaf = addLeaf(asString(key), asString(exp), error);
+        if (leaf < 0) return -1;
+        mNodes.push_back({LEAF, -1, -1, leaf});
+        return int(mNodes.size()) - 1;
+    }
+    return -1;
+}
+
+bool ProcessorFilterGpu::Init(const lcjson::Value& config, std::string& error) {
+    if (!config.isObject()) {
+        error = "config is not an object";
+        return false;
+    }
+    // for backward compatibility, ConditionExp prioritizes over FilterKey and FilterRegex (:33-61)
+    if (const lcjson::Value* ce = config.find("ConditionExp")) {
+        if (!ce->isObject()) {
+            error = "object param ConditionExp is not of type object";
+            return false;
+        }
+        std::string why;
+        mRoot = parseExpression(*ce, why);
+        if (mRoot < 0) {
+            error = "object param ConditionExp is not valid" + (why.empty() ? std::string() : " (" + why + ")");
+            return false;
+        }
+        mFilterMode = Mode::EXPRESSION_MODE;
+    }
+    auto stringList = [&](const char* name, std::vector<std::string>& out) {
+        const lcjson::Value* v = config.find(name);
+        if (!v) return true;
+        if (!v->isArray()) {
+            error = std::string("list param ") + name + " is not of type list";
+            return false;
+        }
+        for (const auto& e : v->arr) {
+            if (!e.isString()) {
+                error = std::string("list param ") + name + " is not of type string list";
+                return false;
+            }
+            out.push_back(e.str);
+        }
+        return true;
+    };
+    if (mFilterMode == Mode::BYPASS_MODE) {  // FilterKey + FilterRegex (:63-107)
+        std::vector<std::string> keys, regs;
+        if (!stringList("FilterKey", keys) || !stringList("FilterRegex", regs)) return false;
+        if (keys.size() != regs.size()) {
+            error = "param FilterKey and FilterRegex does not have the same size";
+            return false;
+        }
+        for (size_t i = 0; i < keys.size(); ++i) {
+            std::string why;
+            const int leaf = addLeaf(keys[i], regs[i], why);
+            if (leaf < 0) {
+                error = "value in list param FilterRegex is not a valid regex: " + why;
+                return false;
+            }
+            mRuleLeaves.push_back(leaf);
+        }
+        if (!keys.empty()) mFilterMode = Mode::RULE_MODE;
+    }
+    if (mFilterMode == Mode::BYPASS_MODE) {  // Include, deprecated (:109-143)
+        if (const lcjson::Value* inc = config.find("Include")) {
+            if (!inc->isObject()) {
+                error = "map param Include is not of type map";
+                return false;
+            }
+            for (const auto& kv : inc->obj) {
+                if (!kv.second.isString()) {
+                    error = "map param Include is not of type map<string, string>";
+                    return false;
+                }
+                std::string why;
+                const int leaf = addLeaf(kv.first, kv.second.str, why);
+                if (leaf < 0) {
+                    error = "value in map param Include is not a valid regex: " + why;
+                    return false;
+                }
+                mRuleLeaves.push_back(leaf);
+            }
+            if (!inc->obj.empty()) mFilterMode = Mode::RULE_MODE;
+        }
+    }
+    if (const lcjson::Value* d = config.find("DiscardingNonUTF8"))  // :145-155 (wrong type: warning, default kept)
+        if (d->isBool()) mDiscardingNonUTF8 = d->b;
+    return true;
+}
+
+bool ProcessorFilterGpu::eval(int node, const std::vector<std::vector<uint8_t>>& leafResult, size_t event) const {
+    const Node& n = mNodes[size_t(node)];
+    switch (n.op) {
+        case LEAF: return leafResult[size_t(n.leaf)][event] != 0;          // RegexFilterValueNode::Match :456-478
+        case NOT: return !eval(n.left, leafResult, event);                 // UnaryFilterOperatorNode::Match :480-485
+        case AND: return eval(n.left, leafResult, event) && eval(n.right, leafResult, event);  // :432-442
+        case OR: return eval(n.left, leafResult, event) || eval(n.right, leafResult, event);
+    }
+    return false;
+}
+
+// ProcessorFilterNative::noneUtf8 :297-379, restated: the same per-sequence checks in the same order
+bool ProcessorFilterGpu::NoneUtf8(char* s, size_t n, bool modify) {
+    auto cont = [&](size_t i) { return (static_cast<unsigned char>(s[i]) & 0xC0) == 0x80; };
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char c = static_cast<unsigned char>(s[i]);
+        size_t need = 0;
+        bool bad = false;
+        if ((c & 0x80) == 0x00) {
+            need = 1;
+        } else if ((c & 0xE0) == 0xC0) {
+            need = 2;
+            if (i + 1 >= n || !cont(i + 1)) bad = true;
+            else {
+                const uint16_t u = uint16_t(((c & 0x1F) << 6) | (static_cast<unsigned char>(s[i + 1]) & 0x3F));
+                bad = !(u >= 0x80 && u <= 0x7FF);
+            }
+        } else if ((c & 0xF0) == 0xE0) {
+            need = 3;
+            if (i + 2 >= n || !cont(i + 1) || !cont(i + 2)) bad = true;
+            else {
+                const uint16_t u = uint16_t(((c & 0x0F) << 12) | ((static_cast<unsigned char>(s[i + 1]) & 0x3F) << 6) |
+                                            (static_cast<unsigned char>(s[i + 2]) & 0x3F));
+                bad = !(u >= 0x800);
+            }
+        } else if ((c & 0xF8) == 0xF0) {
+            need = 4;
+            if (i + 3 >= n || !cont(i + 1) || !cont(i + 2) || !cont(i + 3)) bad = true;
+            else {
+                const uint32_t u = (uint32_t(c & 0x07) << 18) | (uint32_t(static_cast<unsigned char>(s[i + 1]) & 0x3F) << 12) |
+                                   (uint32_t(static_cast<unsigned char>(s[i + 2]) & 0x3F) << 6) |
+                                   uint32_t(static_cast<unsigned char>(s[i + 3]) & 0x3F);
+                bad = !(u >= 0x10000 && u <= 0x10FFFF);
+            }
+        } else {
+            bad = true;
+        }
+        if (bad) {  // FILL_BLUNK_AND_CONTINUE_IF_TRUE: only the offending byte is blanked, the scan resumes right after it
+            if (!modify) return true;
+            s[i] = ' ';
+            ++i;
+            continue;
+        }
+        i += need;
+    }
+    return false;
+}
+
+// DiscardingNonUTF8 :192-213
+void ProcessorFilterGpu::sanitize(LogEvent& e) const {
+    struct KV {
+        StringView key, value;
+    };
+    std::vector<KV> live;
+    for (auto it = e.begin(); it != e.end(); ++it) live.push_back({it->first, it->second});
+    std::vector<KV> renamed;
+    for (auto& kv : live) {
+        StringView value = kv.value;
+        if (NoneUtf8(const_cast<char*>(value.data()), value.size(), false)) {
+            StringBuffer b = e.GetSourceBuffer()->CopyString(value.data(), value.size());
+            NoneUtf8(b.data, b.size, true);
+            value = StringView(b.data, b.size);
+            e.SetContentNoCopy(kv.key, value);
+        }
+        if (NoneUtf8(const_cast<char*>(kv.key.data()), kv.key.size(), false)) {
+            StringBuffer b = e.GetSourceBuffer()->CopyString(kv.key.data(), kv.key.size());
+            NoneUtf8(b.data, b.size, true);
+            renamed.push_back({StringView(b.data, b.size), value});
+            e.DelContent(kv.key);
+        }
+    }
+    for (auto& kv : renamed) e.SetContentNoCopy(kv.key, kv.value);
+}
+
+bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& error) {
+    if (logGroup.GetEvents().empty()) return true;
+    EventsContainer& events = logGroup.MutableEvents();
+    const size_t n = events.size();
+    mInEventsTotal += n;
+
+    // one device launch per regex leaf over the values of its key (absent key: the leaf is false, :260-264 / :457-461)
+    std::vector<std::vector<uint8_t>> leafResult(mLeaves.size());
+    std::vector<const uint8_t*> ptr;
+    std::vector<uint32_t> len, owner;
+    std::vector<uint8_t> status;
+    for (size_t l = 0; l < mLeaves.size(); ++l) {
+        leafResult[l].assign(n, 0);
+        ptr.clear();
+        len.clear();
+        owner.clear();
+        const StringView key(mLeaves[l].key);
+        for (size_t i = 0; i < n; ++i) {
+            if (!events[i].Is<LogEvent>()) continue;
+            const LogEvent& e = events[i].Cast<LogEvent>();
+            if (!e.HasContent(key)) continue;
+            const StringView v = e.GetContent(key);
+            ptr.push_back(reinterpret_cast<const uint8_t*>(v.data()));
+            len.push_back(uint32_t(v.size()));
+            owner.push_back(uint32_t(i));
+        }
+        if (ptr.empty()) continue;
+        status.assign(ptr.size(), 0);
+        const int rc = lc_regex_match_host_views(mLeaves[l].reg, ptr.data(), len.data(), uint32_t(ptr.size()), 0, nullptr,
+                                                 status.data());
+        if (rc != LC_OK) {
+            error = rc == LC_ERR_NO_DEVICE ? "no HIP device: the filter has no CPU path" : lc_last_error();
+            mInEventsTotal -= n;
+            return false;
+        }
+        for (size_t k = 0; k < ptr.size(); ++k) leafResult[l][owner[k]] = status[k] == LC_MATCH;
+    }
+
+    size_t wIdx = 0;
+    for (size_t rIdx = 0; rIdx < n; ++rIdx) {  // Process :159-176 / ProcessEvent :178-216
+        bool res = true;
+        if (events[rIdx].Is<LogEvent>()) {
+            LogEvent& e = events[rIdx].Cast<LogEvent>();
+            if (mFilterMode == Mode::EXPRESSION_MODE) {
+                res = !e.Empty() && eval(mRoot, leafResult, rIdx);              // FilterExpressionRoot :222-238
+            } else if (mFilterMode == Mode::RULE_MODE) {
+                res = !e.Empty();                                                 // FilterFilterRule :240-256
+                for (size_t k = 0; k < mRuleLeaves.size() && res; ++k) res = leafResult[size_t(mRuleLeaves[k])][rIdx] != 0;
+            }
+            if (res && mDiscardingNonUTF8) sanitize(e);
+        }
+        if (res) {
+            if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
+            ++wIdx;
+        }
+    }
+    events.resize(wIdx);
+    mOutEventsTotal += wIdx;
+    return true;
+}
+
+}  // namespace logtail
+
+// ------------------------------------------------------------------------------------------------ C ABI
+struct lc_filter {
+    logtail::ProcessorFilterGpu impl;
+};
+
+extern "C" int lc_filter_create(const char* config_json, lc_filter_t** out, char* err, size_t errcap) {
+    if (!config_json || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    auto set = [&](const std::string& m) {
+        if (err && errcap) std::snprintf(err, errcap, "%s", m.c_str());
+    };
+    lcjson::Value cfg;
+    try {
+        cfg = lcjson::parse(config_json);
+    } catch (const std::exception& e) {
+        set(e.what());
+        return LC_ERR_ARG;
+    }
+    auto f = std::make_unique<lc_filter>();
+    std::string error;
+    if (!f->impl.Init(cfg, error)) {
+        set(error);
+        return LC_ERR_SYNTAX;
+    }
+    set("");
+    *out = f.release();
+    return LC_OK;
+}
+extern "C" void lc_filter_destroy(lc_filter_t* f) { delete f; }
+extern "C" int lc_filter_mode(const lc_filter_t* f) { return f ? int(f->impl.mFilterMode) : -1; }
+extern "C" int lc_filter_process(lc_filter_t* f, void* native_group) {
+    if (!f || !native_group) return LC_ERR_ARG;
+    std::string error;
+    if (!f->impl.Process(*static_cast<logtail::PipelineEventGroup*>(native_group), error))
+        return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
+    return LC_OK;
+}
+extern "C" int lc_filter_none_utf8(char* buf, size_t n, int modify) {
+    return (buf || n == 0) ? int(logtail::ProcessorFilterGpu::NoneUtf8(buf, n, modify != 0)) : 0;
+}
+extern "C" void lc_filter_counters(const lc_filter_t* f, uint64_t out[2]) {
+    if (!f || !out) return;
+    out[0] = f->impl.mInEventsTotal;
+    out[1] = f->impl.mOutEventsTotal;
+}

@@ -27,6 +27,17 @@ def _lib():
         L.lc_processor_process.restype = ctypes.c_int
         L.lc_processor_process.argtypes = [vp, vp]
         L.lc_processor_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.lc_filter_create.restype = ctypes.c_int
+        L.lc_filter_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
+        L.lc_filter_destroy.argtypes = [vp]
+        L.lc_filter_mode.argtypes = [vp]
+        L.lc_filter_process.restype = ctypes.c_int
+        L.lc_filter_process.argtypes = [vp, vp]
+        L.lc_filter_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.lc_filter_none_utf8.restype = ctypes.c_int
+        L.lc_filter_none_utf8.argtypes = [cp, sz, ctypes.c_int]
+        L.lc_group_native.restype = vp
+        L.lc_group_native.argtypes = [vp]
         L.lc_group_from_json.restype = vp
         L.lc_group_from_json.argtypes = [cp, cp, sz]
         L.lc_group_to_json.restype = vp
@@ -125,3 +136,49 @@ class Processor:
             self.close()
         except Exception:
             pass
+
+
+def none_utf8(data: bytes):
+    """ProcessorFilterNative::noneUtf8 as compiled into the library -> (is_bad, blanked copy)"""
+    buf = ctypes.create_string_buffer(data, len(data))
+    bad = _lib().lc_filter_none_utf8(buf, len(data), 0)    # CheckNoneUtf8
+    _lib().lc_filter_none_utf8(buf, len(data), 1)          # FilterNoneUtf8
+    return bool(bad), buf.raw[:len(data)]
+
+
+class Filter:
+    """processor_filter_regex_gpu; same config keys as processor_filter_regex_native (ConditionExp | FilterKey+FilterRegex |
+    Include, DiscardingNonUTF8)."""
+
+    MODES = ("bypass", "expression", "rule")
+
+    def __init__(self, config):
+        text = config if isinstance(config, str) else json.dumps(config)
+        self._L = _lib()
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = self._L.lc_filter_create(text.encode("utf-8"), ctypes.byref(h), err, 512)
+        if rc != binding.LC_OK:
+            raise ProcessorInitError(err.value.decode())
+        self._h = h
+
+    @property
+    def mode(self):
+        return self.MODES[self._L.lc_filter_mode(self._h)]
+
+    def process(self, group: EventGroup):
+        rc = self._L.lc_filter_process(self._h, self._L.lc_group_native(group._h))
+        if rc == binding.LC_ERR_NO_DEVICE:
+            raise binding.GpuUnavailableError("processor_filter_regex_gpu: no usable HIP device (no CPU path)")
+        if rc != binding.LC_OK:
+            raise RuntimeError("lc_filter_process rc=%d" % rc)
+
+    def counters(self):
+        buf = (ctypes.c_uint64 * 2)()
+        self._L.lc_filter_counters(self._h, buf)
+        return {"in_events_total": int(buf[0]), "out_events_total": int(buf[1])}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lc_filter_destroy(self._h)
+            self._h = None
