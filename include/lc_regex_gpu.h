@@ -50,6 +50,11 @@ enum {
     LC_SYNTAX_SEARCH = 1u << 5,         /* leftmost-first SEARCH instead of whole-line match (Go processor_regex without
                                            FullMatch, regex.go:105-129): compiled as (?s:.*?)(re)(?s:.*), so group 1 is
                                            the whole match and the pattern's own groups are 2..mark_count */
+    LC_SYNTAX_PREFIX = 1u << 7,         /* the pattern must match a PREFIX of the line: boost::regex_search with
+                                           match_continuous, what the multiline splitter asks per line for its start /
+                                           continue / end patterns (StringTools.cpp:263-289 called from
+                                           ProcessorSplitMultilineLogStringNative.cpp:184-272).  Compiled as (re)(?s:.*);
+                                           captures of the leftmost-first prefix match are reported as usual */
     LC_SYNTAX_REGEXP2 = 1u << 6         /* escape dialect of github.com/dlclark/regexp2 with the RE2 option (Go Grok,
                                            processor_grok.go:343): \s = [\t\n\f\r ]; \< \> \` \' are literals */
 };

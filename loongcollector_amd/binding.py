@@ -18,6 +18,7 @@ LC_OK, LC_ERR_SYNTAX, LC_ERR_UNSUPPORTED, LC_ERR_NO_DEVICE, LC_ERR_HIP, LC_ERR_A
 LC_SYNTAX_ICASE, LC_SYNTAX_NO_DOTALL, LC_SYNTAX_NO_MULTILINE, LC_SYNTAX_EXTENDED, LC_SYNTAX_NAMED_ONLY = 1, 2, 4, 8, 16
 LC_SYNTAX_SEARCH = 32
 LC_SYNTAX_REGEXP2 = 64
+LC_SYNTAX_PREFIX = 128
 
 (LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
  LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB, LC_TABLE_TDFA_STARTAFTER) = range(9)

@@ -329,6 +329,25 @@ static void wrapForSearch(ParsedRegex& re) {
     re.groupNames.insert(re.groupNames.begin() + 1, std::string());
 }
 
+// regex_search(match_continuous): the match must start at the first byte and may end anywhere.  As a whole-line match:
+// (re)(?s:.*) -- leftmost-first picks the same (preferred) way through `re` that the backtracker finds first.
+static void wrapForPrefix(ParsedRegex& re) {
+    auto set = std::make_unique<Node>();
+    set->kind = Node::Set;
+    set->set = ByteSet::all();
+    auto rest = std::make_unique<Node>();
+    rest->kind = Node::Repeat;
+    rest->min = 0;
+    rest->max = -1;
+    rest->greedy = true;
+    rest->kids.push_back(std::move(set));
+    auto cat = std::make_unique<Node>();
+    cat->kind = Node::Cat;
+    cat->kids.push_back(std::move(re.root));
+    cat->kids.push_back(std::move(rest));
+    re.root = std::move(cat);
+}
+
 static void setErr(char* err, size_t cap, const std::string& msg) {
     if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
 }
@@ -361,7 +380,10 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
         }
         re->requiredLiteral = requiredLiteral(*parsed.root);
+        if ((syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX))
+            throw RegexError("LC_SYNTAX_SEARCH and LC_SYNTAX_PREFIX exclude each other");
         if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed);
+        if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
         re->nfa = buildFollowNfa(parsed);
         if (syntax_flags & LC_SYNTAX_SEARCH) {  // wrapForSearch generates its prefix '.' first and its suffix '.' last
             re->nfa.searchPrefix = 0;

@@ -853,6 +853,15 @@ int orx_search(const orx_prog* P, const uint8_t* s, size_t n, size_t start, int3
     return r;
 }
 
+/* boost::regex_search(first, last, what, re, match_continuous): the match has to start at `first` (StringTools.cpp:263-289) */
+int orx_prefixmatch(const orx_prog* P, const uint8_t* s, size_t n, int32_t* caps) {
+    scratch sc; scratch_init(&sc, P);
+    long budget = ORX_STEP_BUDGET;
+    int r = run(P, s, (long)n, 0, 0, caps, &sc.st, sc.loopregs, &budget);
+    scratch_free(&sc);
+    return r;
+}
+
 long orx_fullmatch_batch(const orx_prog* P, const uint8_t* data, const uint32_t* off, const uint32_t* len, size_t nlines,
                          int ngroups, int32_t* caps, uint8_t* status) {
     scratch sc; scratch_init(&sc, P);

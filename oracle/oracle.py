@@ -40,6 +40,7 @@ def lib():
         L.orx_group_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orx_fullmatch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orx_search.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        L.orx_prefixmatch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orx_fullmatch_batch.restype = ctypes.c_long
         L.orx_fullmatch_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -85,6 +86,16 @@ class OracleRegex:
     def search(self, s, start=0):
         caps = (ctypes.c_int32 * (2 * (self.groups + 1)))()
         r = lib().orx_search(self._h, s, len(s), start, caps)
+        if r < 0:
+            raise RuntimeError("complexity exceeded")
+        if r == 0:
+            return None
+        return [(caps[2 * g], caps[2 * g + 1]) for g in range(self.groups + 1)]
+
+    def prefixmatch(self, s):
+        """boost::regex_search(..., match_continuous): the match must start at offset 0 (multiline start/continue/end)"""
+        caps = (ctypes.c_int32 * (2 * (self.groups + 1)))()
+        r = lib().orx_prefixmatch(self._h, s, len(s), caps)
         if r < 0:
             raise RuntimeError("complexity exceeded")
         if r == 0:

@@ -313,3 +313,33 @@ def test_atomic_groups_and_possessive_quantifiers_on_both_kernels(torch_dev, gol
                         bad.append((kind, eng, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
     assert checked > 7000
     assert not bad, bad[:5]
+
+
+def test_prefix_mode_on_both_kernels(torch_dev, golden_dir):
+    """LC_SYNTAX_PREFIX (regex_search with match_continuous, the multiline splitter's per-line question) vs the oracle"""
+    from oracle.oracle import OracleRegex
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for c in golden["cases"][:120]:
+        p = c["p"].encode("latin-1")
+        try:
+            rx = B.GpuRegex(p, syntax_flags=B.LC_SYNTAX_PREFIX)
+        except B.RegexUnsupportedError:
+            continue
+        o = OracleRegex(p)
+        subs = [s.encode("latin-1")[cut:] for s, _ in c["subs"] for cut in (0, 3)]
+        data, off, length = pack(subs)
+        engines = ([B.LC_ENGINE_NFA] if rx.has_nfa_program() else []) + (
+            [B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        for eng in engines:
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+            for i, s in enumerate(subs):
+                checked += 1
+                exp = o.prefixmatch(s)
+                ok = (status[i] == B.LC_NOMATCH) if exp is None else (
+                    status[i] == B.LC_MATCH and list(caps[i]) == [v for ab in exp[1:] for v in ab])
+                if not ok:
+                    bad.append((eng, c["p"], s, int(status[i]), list(caps[i]), exp))
+    assert checked > 1500
+    assert not bad, bad[:5]

@@ -161,3 +161,41 @@ def test_atomic_groups_and_possessive_quantifiers_on_both_engines_tables(golden_
                         bad.append((kind, c["p"], subj, got, exp))
     assert n > 8000 and unsupported <= 40, (n, unsupported)
     assert not bad, bad[:5]
+
+
+def test_prefix_mode_is_regex_search_match_continuous(golden_dir):
+    """LC_SYNTAX_PREFIX = boost::regex_search(match_continuous) (StringTools.cpp:263-289), the per-line question of the
+    multiline splitter (ProcessorSplitMultilineLogStringNative.cpp:184-272): tables vs the oracle's anchored search, on the
+    search corpus with the patterns' own groups."""
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        d = json.load(f)
+    from oracle.oracle import OracleRegex
+    n = hits = 0
+    for c in d["cases"][:150]:
+        p = c["p"].encode("latin-1")
+        try:
+            rx = B.GpuRegex(p, syntax_flags=B.LC_SYNTAX_PREFIX)
+        except B.RegexUnsupportedError:
+            continue
+        o = OracleRegex(p)
+        its = ([NfaInterp(rx)] if rx.has_nfa_program() else []) + (
+            [TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        for subj, _ in c["subs"]:
+            s = subj.encode("latin-1")
+            for cut in (0, 3):
+                t = s[cut:]
+                exp = o.prefixmatch(t)
+                want = None if exp is None else [v for ab in exp[1:] for v in ab]
+                hits += exp is not None
+                for it in its:
+                    n += 1
+                    assert it.fullmatch(t) == want, (c["p"], t)
+    assert n > 1500 and hits > 200
+    # the multiline idiom of the reference docs: a log starts with a timestamp
+    rx = B.GpuRegex(rb"\d{4}-\d{2}-\d{2} \d{2}:\d{2}:\d{2}", syntax_flags=B.LC_SYNTAX_PREFIX)
+    it = TdfaInterp(rx)
+    assert it.fullmatch(b"2024-01-04 14:36:10 ERROR boom") is not None
+    assert it.fullmatch(b"    at com.example.Foo.bar(Foo.java:42)") is None
+    assert it.fullmatch(b" 2024-01-04 14:36:10 leading space") is None
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(b"a", syntax_flags=B.LC_SYNTAX_PREFIX | B.LC_SYNTAX_SEARCH)
