@@ -148,3 +148,40 @@ class Grok:
             return [[tuple(kv) for kv in log] for log in json.loads(ctypes.string_at(out).decode("utf-8"))]
         finally:
             self._L.lc_grok_free_string(out)
+
+
+class GoRegex:
+    """Go plugin processor_regex (include/lc_go_regex.h): GoRegex(Regex=..., Keys=[...], FullMatch=False, ...)"""
+
+    def __init__(self, **config):
+        L = self._L = binding.load()
+        if not getattr(L, "_lc_goregex_bound", False):
+            vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
+            L.lc_goregex_create.restype = ctypes.c_int
+            L.lc_goregex_create.argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
+            L.lc_goregex_free.argtypes = [vp]
+            L.lc_goregex_process_logs_json.restype = ctypes.c_int
+            L.lc_goregex_process_logs_json.argtypes = [vp, cp, sz, ctypes.POINTER(vp)]
+            L.lc_goregex_free_string.argtypes = [vp]
+            L._lc_goregex_bound = True
+        text = json.dumps(config).encode("utf-8")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if L.lc_goregex_create(text, len(text), ctypes.byref(h), err, 512) != 0:
+            raise GrokInitError(err.value.decode("utf-8", "replace"))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lc_goregex_free(self._h)
+            self._h = None
+
+    def process_logs(self, logs):
+        text = json.dumps([[list(kv) for kv in log] for log in logs]).encode("utf-8")
+        out = ctypes.c_void_p()
+        rc = self._L.lc_goregex_process_logs_json(self._h, text, len(text), ctypes.byref(out))
+        binding._check(rc, "lc_goregex_process_logs_json")
+        try:
+            return [[tuple(kv) for kv in log] for log in json.loads(ctypes.string_at(out).decode("utf-8"))]
+        finally:
+            self._L.lc_goregex_free_string(out)
