@@ -515,7 +515,7 @@ extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const ui
                                    uint32_t n, uint32_t ngroups, int32_t* caps, uint8_t* status) {
     if (!re) return LC_ERR_ARG;
     if (n == 0) return LC_OK;
-    if (!data || !off || !len || !caps || !status) return LC_ERR_ARG;
+    if (!data || !off || !len || (ngroups && !caps) || !status) return LC_ERR_ARG;  // ngroups == 0: status only
     LineSource src;
     src.base = data;
     src.off = off;

@@ -1,0 +1,62 @@
+"""ctypes binding of the multiline splitter (include/lc_multiline.h); plumbing for tests and tools."""
+import ctypes
+import json
+
+from . import binding
+
+
+class MultilineInitError(ValueError):
+    pass
+
+
+class _Record(ctypes.Structure):
+    _fields_ = [("begin", ctypes.c_uint32), ("length", ctypes.c_uint32), ("matched", ctypes.c_uint32)]
+
+
+class Multiline:
+    def __init__(self, **config):
+        L = self._L = binding.load()
+        if not getattr(L, "_lc_multiline_bound", False):
+            vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
+            L.lc_multiline_create.restype = ctypes.c_int
+            L.lc_multiline_create.argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
+            L.lc_multiline_free.argtypes = [vp]
+            L.lc_multiline_is_multiline.argtypes = [vp]
+            L.lc_multiline_patterns.argtypes = [vp]
+            L.lc_multiline_split_host.restype = ctypes.c_int
+            L.lc_multiline_split_host.argtypes = [vp, cp, ctypes.c_uint32, ctypes.POINTER(ctypes.POINTER(_Record)),
+                                                  ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+            L.lc_multiline_free_records.argtypes = [ctypes.POINTER(_Record)]
+            L._lc_multiline_bound = True
+        text = json.dumps(config).encode("utf-8")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if L.lc_multiline_create(text, len(text), ctypes.byref(h), err, 512) != 0:
+            raise MultilineInitError(err.value.decode("utf-8", "replace"))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lc_multiline_free(self._h)
+            self._h = None
+
+    @property
+    def is_multiline(self):
+        return bool(self._L.lc_multiline_is_multiline(self._h))
+
+    @property
+    def patterns(self):
+        m = self._L.lc_multiline_patterns(self._h)
+        return {"start": bool(m & 1), "continue": bool(m & 2), "end": bool(m & 4)}
+
+    def split(self, value: bytes):
+        """-> (records [(begin, length, matched)], (input lines, unmatched lines, matched logs))"""
+        recs = ctypes.POINTER(_Record)()
+        n = ctypes.c_uint32()
+        counters = (ctypes.c_uint32 * 3)()
+        rc = self._L.lc_multiline_split_host(self._h, value, len(value), ctypes.byref(recs), ctypes.byref(n), counters)
+        binding._check(rc, "lc_multiline_split_host")
+        try:
+            return [(recs[i].begin, recs[i].length, recs[i].matched) for i in range(n.value)], tuple(counters)
+        finally:
+            self._L.lc_multiline_free_records(recs)
