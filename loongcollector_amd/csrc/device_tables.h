@@ -16,7 +16,8 @@ enum {
     TD_START_ROW = 5,    // LDS address of the start state's row (= TD_TRANS_OFFSET + start*rowBytes)
     TD_OFF_STARTAFTER = 6, // u32[nClasses]: row address to resume a search in, by class of the byte before the resume
                          // point (0 = the pattern is not a search pattern); the class map itself sits at TD_CMAP_OFFSET
-    TD_OFF_TRANS = 7,    // == TD_TRANS_OFFSET
+    TD_OFF_PAIR = 7,     // 0, or offset of the byte-PAIR extension (4 x u32, TP_*): a second transition table indexed by
+                         // (state, class of byte 2k, class of byte 2k+1) that the kernel walks two bytes per lookup
     TD_OFF_FINALID = 8,  // u16[nStates]: 0xFFFF = not accepting
     TD_OFF_FINALMAP = 9, // u8[nFinal*nSlots]
     TD_OFF_OPSSTART = 10, // u32[nLists+1] index (in u16 units) into ops
@@ -28,6 +29,19 @@ enum {
     TD_BLOCK = 15,       // workgroup size the register offsets were encoded for
     TD_HEADER_WORDS = 16
 };
+// byte-pair extension header (at TD_OFF_PAIR)
+enum {
+    TP_BASE = 0,       // LDS address of pair row 0 (the dead state): u32[nStates][(nClasses+1)^2]
+    TP_ROW_BYTES = 1,  // (nClasses+1)^2 * 4
+    TP_OFF_CMAPA = 2,  // u16[256]: class(b) * (nClasses+1) * 4 -- column offset contributed by the FIRST byte of a pair
+                       // (the second byte contributes cmap8[b] = class * 4, the table at TD_CMAP_OFFSET)
+    TP_ID_A = 3        // nClasses * (nClasses+1) * 4: first-byte offset of the identity class
+};
+// pair entry: bits 0..15 LDS address of the next state's PAIR row; bits 16..23 / 24..31 register stamped by the first /
+// second byte (index; the dummy register = "none"); bit 7 of either index set = that byte carries a general register
+// program -> the chunk is replayed byte by byte on the single-byte table
+#define TP_GENERAL 0x80u
+#define TP_MAX_TABLE_BYTES (26u << 10)
 #define TD_MAGIC_VALUE 0x41464454u
 #define TD_CMAP_OFFSET 64u    // u8[256]: class(b) * 4  (column byte offset inside a row; at most 63 classes)
 #define TD_TRANS_OFFSET 320u  // u32[nStates][nClasses+1]

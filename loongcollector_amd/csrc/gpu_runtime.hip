@@ -83,18 +83,18 @@ void lcReleaseDeviceTables(lc_regex* re) {
     if (haveCur) (void)hipSetDevice(cur);
 }
 
-template <int BLOCK>
+template <int BLOCK, bool PAIR>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(tdfa_match_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
+    hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
@@ -114,10 +114,13 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     }
     const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
     const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
+    // small automata carry a byte-pair transition table: half as many dependent LDS lookups per byte
+    static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
+    const bool pair = re->tdfaBlob[TD_OFF_PAIR] != 0 && !pairOff;
     switch (block) {
-        case 256: return launchTdfaBlock<256>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        case 128: return launchTdfaBlock<128>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        default: return launchTdfaBlock<64>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
 }
 

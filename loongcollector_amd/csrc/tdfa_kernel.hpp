@@ -161,7 +161,65 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
     return t;
 }
 
-template <int BLOCK>
+// Byte-PAIR stepping (device_tables.h TP_*): the state chain -- the only serial dependency, one LDS round trip per link --
+// has one link per TWO bytes: t = pair32[(t & 0xFFFF) + cmapA[byte 2k] + cmap8[byte 2k+1]].  The entry also names the
+// register each of the two bytes stamps.  Same phases as tdfaStepBytes; NB/2 dependent lookups instead of NB.
+struct TdfaPairInfo {
+    uint32_t base, rowBytes, cmapA, idA;
+};
+typedef const uint16_t __attribute__((address_space(3))) * LdsHalfPtr;
+
+template <int BLOCK, bool CHECKED, int NB>
+__device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
+                                                  uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
+                                                  uint32_t tid, const TdfaPairInfo& pi, uint32_t singleRowBytes) {
+    const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
+    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
+    constexpr uint32_t kRegShift = (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8));  // log2(BLOCK * sizeof(TdfaReg))
+    const uint32_t entry = t;
+    uint32_t col[NB / 2], tt[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) {  // phase 0: two class lookups per pair, independent
+        const int j = 2 * p;
+        const uint32_t b0 = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        const uint32_t b1 = (words[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFFu;
+        uint32_t a = *reinterpret_cast<LdsHalfPtr>(pi.cmapA + b0 * 2);
+        uint32_t c = cmap[b1];
+        if (CHECKED) {
+            a = (base + j < L) ? a : pi.idA;
+            c = (base + j + 1 < L) ? c : idCol;
+        }
+        col[p] = a + c;
+    }
+    uint32_t seen = 0;
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) {  // phase 1: the state chain, one link per pair
+        t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col[p], t));
+        tt[p] = t;
+        seen |= t;
+    }
+    if (!__any((seen & ((TP_GENERAL << 16) | (TP_GENERAL << 24))) != 0)) {
+#pragma unroll
+        for (int p = 0; p < NB / 2; ++p) {  // phase 2: capture writes, two per pair, independent
+            const uint32_t r0 = (tt[p] >> 16) & 0xFFu, r1 = tt[p] >> 24;
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (r0 << kRegShift)) = TdfaReg(base + 2 * p);
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (r1 << kRegShift)) = TdfaReg(base + 2 * p + 1);
+        }
+    } else {  // a general register program somewhere in the chunk: replay it byte by byte on the single-byte table
+        u32x4 q = {0, 0, 0, 0};
+        q.x = words[0];
+        q.y = words[1];
+        if (NB == 16) {
+            q.z = words[2 % (NB / 4)];
+            q.w = words[3 % (NB / 4)];
+        }
+        const uint32_t state = ((entry & 0xFFFFu) - pi.base) / pi.rowBytes;
+        tdfaReplayChunk<BLOCK>(smem, q, TD_TRANS_OFFSET + state * singleRowBytes, base, L, idCol, regsBase, tid, NB);
+    }
+    return t;
+}
+
+template <int BLOCK, bool PAIR>
 __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(const uint8_t* __restrict__ data,
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
@@ -189,6 +247,17 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const uint32_t idCol = hdr[TD_ID_COL];
     const uint32_t regsBase = blobBytes;
     uint32_t t = hdr[TD_START_ROW];  // low 16 bits: LDS address of the current state's row
+    TdfaPairInfo pi{};
+    // single-byte row address -> the row the kernel actually walks (PAIR: the same state's row in the pair table)
+    auto walkRow = [&](uint32_t singleRow) {
+        return PAIR ? pi.base + ((singleRow & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes * pi.rowBytes : singleRow;
+    };
+    if constexpr (PAIR) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_PAIR]);
+        pi = TdfaPairInfo{ph[TP_BASE], ph[TP_ROW_BYTES], ph[TP_OFF_CMAPA], ph[TP_ID_A]};
+        t = walkRow(t);
+    }
+    const uint32_t deadRow = PAIR ? pi.base : TD_TRANS_OFFSET;
 
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stageBase = blobBytes + regBytes + wave * kTdfaStagePerWave;  // this wave's staging rows (LDS address)
@@ -206,7 +275,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
             from = from < L ? from : L;
             if (from) {  // only the wrapper's prefix thread is alive; what it remembers is the class of the previous byte
                 const uint32_t* startAfter = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_STARTAFTER]);
-                t = startAfter[smem[TD_CMAP_OFFSET + data[size_t(o) + from - 1]] >> 2];
+                t = walkRow(startAfter[smem[TD_CMAP_OFFSET + data[size_t(o) + from - 1]] >> 2]);
                 o += from;
                 L -= from;
             }
@@ -266,11 +335,24 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
             const bool full = base < L && L - base >= 16;
 #if LC_TDFA_CHUNK == 16
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-            if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid);
-            else t = tdfaStepBytes<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+            if constexpr (PAIR) {
+                if (__all(full)) t = tdfaStepPairs<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                else t = tdfaStepPairs<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+            } else {
+                if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+                else t = tdfaStepBytes<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+            }
 #else
             const uint32_t w0[2] = {q.x, q.y}, w1[2] = {q.z, q.w};
-            if (__all(full)) {
+            if constexpr (PAIR) {
+                if (__all(full)) {
+                    t = tdfaStepPairs<BLOCK, false, 8>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, false, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
+                } else {
+                    t = tdfaStepPairs<BLOCK, true, 8>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, true, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
+                }
+            } else if (__all(full)) {
                 t = tdfaStepBytes<BLOCK, false, 8>(smem, w0, t, base, L, idCol, regsBase, tid);
                 t = tdfaStepBytes<BLOCK, false, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
             } else {
@@ -280,14 +362,14 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
 #endif
         }
         // every lane dead (or past its end in the identity column): nothing left to decide for this wavefront
-        if (__all((t & 0xFFFFu) == TD_TRANS_OFFSET || s + 1 >= myStages)) break;
+        if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
 
     if (!live) return;
     const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + hdr[TD_OFF_FINALID]);
     const uint8_t* finalMap = smem + hdr[TD_OFF_FINALMAP];
     const TdfaReg* regs = reinterpret_cast<const TdfaReg*>(smem + regsBase);
-    const uint32_t state = ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
+    const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     const uint32_t fid = finalId[state];
     const bool matched = (state != 0) && (fid != 0xFFFFu);
     int32_t* out = caps + size_t(line) * 2 * nGroupsOut;

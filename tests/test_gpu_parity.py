@@ -343,3 +343,36 @@ def test_prefix_mode_on_both_kernels(torch_dev, golden_dir):
                     bad.append((eng, c["p"], s, int(status[i]), list(caps[i]), exp))
     assert checked > 1500
     assert not bad, bad[:5]
+
+
+def test_byte_pair_transition_tables_are_bit_exact(torch_dev, golden_dir, monkeypatch):
+    """Opt-in byte-pair stepping of the TDFA kernel (LC_TDFA_PAIR=1 at compile time of the pattern): one dependent LDS
+    lookup per two bytes; same results as the single-byte table on the golden vectors, the bench corpus and resumed
+    searches."""
+    monkeypatch.setenv("LC_TDFA_PAIR", "1")
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked, paired = [], 0, 0
+    for c in golden["cases"][:400]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"), engine=B.LC_ENGINE_AUTO)
+        if rx.info()["engine"] != B.LC_ENGINE_TDFA:
+            continue
+        paired += rx.info()["table_bytes"] > 4096
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if flat is None else (
+                status[i] == B.LC_MATCH and list(caps[i]) == flat[2:])
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 2000 and paired > 50
+    assert not bad, bad[:5]
+    from loongcollector_amd import corpus
+    from oracle.oracle import OracleRegex
+    rx = B.GpuRegex(corpus.REGEX_A)
+    data, off, length = corpus.mixed_batch(4096, seed=5) if hasattr(corpus, "mixed_batch") else corpus.apache_batch(4096, "A", 512)
+    caps, status = run_device(torch_dev, rx, data, off[:len(length)], length)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:len(length)], length)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
