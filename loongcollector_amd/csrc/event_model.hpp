@@ -176,6 +176,18 @@ public:
             mContents.emplace_back(LogContent(key, val), true);
         }
     }
+    // Bulk form of K x SetContentNoCopy for a caller that KNOWS none of the keys is present yet (SURVEY.md section 8(f)
+    // rank 4): one reservation, no per-key reverse scan.  Not part of the reference's LogEvent; the parse processor uses it
+    // only when the event holds nothing but the source content and its Keys are pairwise distinct.
+    template <class KeyIt, class ValIt>
+    void AppendContentsNoCopy(KeyIt keys, ValIt vals, size_t n) {
+        mContents.reserve(mContents.size() + n);
+        for (size_t i = 0; i < n; ++i, ++keys, ++vals) {
+            mAllocatedContentSize += keys->size() + vals->size();
+            mContents.emplace_back(LogContent(*keys, *vals), true);
+        }
+        mContentCnt += n;
+    }
     void DelContent(StringView key) {
         auto* e = const_cast<std::pair<LogContent, bool>*>(findLive(key));
         if (e) {

@@ -158,6 +158,11 @@ bool ProcessorParseRegexGpu::Init(const lcjson::Value& config, std::string& erro
             mKeys = parts;
         }
     }
+    mKeyViews.assign(mKeys.begin(), mKeys.end());
+    mKeysDistinct = true;
+    for (size_t a = 0; a < mKeys.size(); ++a)
+        for (size_t b = a + 1; b < mKeys.size(); ++b)
+            if (mKeys[a] == mKeys[b]) mKeysDistinct = false;
     mSourceKeyOverwritten = false;  // :89-94
     for (const auto& k : mKeys)
         if (k == mSourceKey) {
@@ -267,6 +272,19 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                 }
                 if (parseSuccess) {
                     const int32_t* c = &caps[li * 2 * G];
+#ifndef LC_USE_REFERENCE_HEADERS
+                    if (mKeysDistinct && !mSourceKeyOverwritten && ev.Size() == 1) {
+                        // the event holds only the source content and no key can collide: append all K views at once
+                        // instead of K reverse scans (same contents, same order as the loop below)
+                        static thread_local std::vector<StringView> vals;
+                        vals.resize(mKeys.size());
+                        for (size_t k = 0; k < mKeys.size(); ++k) {
+                            const int32_t b = c[2 * k], en = c[2 * k + 1];
+                            vals[k] = b < 0 ? StringView(raw.data() + raw.size(), 0) : StringView(raw.data() + b, size_t(en - b));
+                        }
+                        ev.AppendContentsNoCopy(mKeyViews.begin(), vals.begin(), mKeys.size());
+                    } else
+#endif
                     for (size_t k = 0; k < mKeys.size(); ++k) {  // :249-251
                         const int32_t b = c[2 * k], en = c[2 * k + 1];
                         // an unmatched group is boost's {last,last,matched=false}: empty value at end of input

@@ -72,6 +72,8 @@ private:
     void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
 
     bool mSourceKeyOverwritten = false;
+    bool mKeysDistinct = false;             // no key appears twice: the bulk stitch is allowed
+    std::vector<StringView> mKeyViews;      // views of mKeys (what is stored in the events)
     bool mIsWholeLineMode = false;
     lc_regex_t* mReg = nullptr;
     int mMarkCount = 0;
