@@ -500,51 +500,50 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
         uint32_t totalCand;
         const uint32_t rankBase = waveExclusiveScan(cnt, lane, totalCand);
-        // pass 1: filter candidates, elect per-target winners
-        uint64_t passMask = 0;
-        for (uint32_t k = 0; __any(k < cnt); ++k) {
-            if (k < cnt) {
-                const uint4 p = nfaPath(paths, aux, fs + k);
-                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
-                    const uint2 pm = posMask[p.x];
-                    const uint32_t bit = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
-                    if (bit) {
-                        passMask |= uint64_t(1) << k;
-                        atomicMin(&best[p.x], rankBase + k);
-                    }
+        // One CANDIDATE (thread, path) per lane, 64 per round, in priority order (rank = lexicographic (thread, path index)
+        // = the candidate's index).  A thread with a long follow list -- the search prefix of a pattern that can start in
+        // dozens of ways -- no longer walks it serially in one lane while 60 lanes idle.
+        uint32_t totalWins = 0;
+        for (uint32_t r0 = 0; r0 < totalCand; r0 += 64) {
+            const uint32_t cand = r0 + lane;
+            uint32_t src = 0, q = 0;
+            for (uint32_t t = 0; t < nThreads; ++t) {  // which thread owns candidate `cand`
+                const uint32_t tb = __shfl(rankBase, int(t), 64), tn = __shfl(cnt, int(t), 64), tf = __shfl(fs, int(t), 64);
+                if (cand >= tb && cand < tb + tn) {
+                    src = t;
+                    q = tf + (cand - tb);
                 }
             }
-        }
-        waveLdsSync();
-        // pass 2: winners, in (lane, k) order
-        uint64_t winMask = 0;
-        for (uint64_t m = passMask; __any(m != 0);) {
-            if (m) {
-                const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
-                m &= m - 1;
-                const uint4 p = nfaPath(paths, aux, fs + k);
-                if (best[p.x] == rankBase + k) winMask |= uint64_t(1) << k;
+            bool pass = false;
+            uint4 p{0, 0, 0, 0};
+            if (cand < totalCand) {
+                p = nfaPath(paths, aux, q);
+                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
+                    const uint2 pm = posMask[p.x];
+                    pass = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
+                }
+                if (pass) atomicMin(&best[p.x], cand);  // per target, the candidate of highest priority
             }
-        }
-        uint32_t totalWins;
-        uint32_t slot = waveExclusiveScan(uint32_t(__popcll(winMask)), lane, totalWins);
-        if (totalWins > 64) {
-            overflow = true;
-            break;
-        }
-        for (uint64_t m = winMask; __any(m != 0);) {
-            if (m) {
-                const uint32_t k = uint32_t(__ffsll((long long)m)) - 1;
-                m &= m - 1;
-                const uint4 p = nfaPath(paths, aux, fs + k);
+            waveLdsSync();
+            const bool win = pass && best[p.x] == cand;
+            const uint64_t wins = __ballot(win);
+            const uint32_t nWins = uint32_t(__popcll(wins));
+            if (totalWins + nWins > 64) {
+                overflow = true;
+                break;
+            }
+            if (win) {
+                const uint32_t slot = totalWins + uint32_t(__popcll(wins & ((uint64_t(1) << lane) - 1)));
                 newPos[slot] = p.x;
-                newSrc[slot] = lane;
+                newSrc[slot] = src;
                 newTagsLo[slot] = p.z;
                 newTagsHi[slot] = p.w;
-                best[p.x] = 0xFFFFFFFFu;
-                ++slot;
             }
+            totalWins += nWins;
         }
+        if (overflow) break;
+        waveLdsSync();
+        if (lane < totalWins) best[newPos[lane]] = 0xFFFFFFFFu;  // clear the election marks (targets are distinct)
         waveLdsSync();
         nThreads = totalWins;
         uint32_t src = lane;
