@@ -127,6 +127,7 @@ def main():
                    "patterns_supported": len(supported), "patterns_refused": refused,
                    "engines": {"tdfa": engines.count(binding.LC_ENGINE_TDFA), "nfa": engines.count(binding.LC_ENGINE_NFA)},
                    "matched_lines": int((pattern >= 0).sum()), "undecidable_lines": int((pattern == -2).sum()),
+                   "undecidable_line_indices": [int(i) for i in np.nonzero(pattern == -2)[0][:32]],
                    "extra_match_rows": int(d_nextra.cpu()[0]),
                    "patterns_hit": int((hist > 0).sum())},
         "cpu_baseline": {"value": round(sample / cpu_s, 1), "unit": "lines/s", "cores": 1, "kind": "port",
