@@ -121,6 +121,13 @@ enum {
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 
+/* A SCREEN for a pattern whose own tagged DFA is too large for LDS: a TDFA-engine handle for the longest prefix of the
+ * pattern's top-level concatenation (captures dropped) that stays within max_states / max_table_bytes, compiled as a
+ * search.  Every match of the pattern contains a match of that prefix, so lines the screen rejects (status only,
+ * ngroups = 0) need not be handed to the NFA engine.  NULL if no useful prefix exists.  Free with lc_regex_free. */
+lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t pattern_len, uint32_t syntax_flags, uint32_t max_states,
+                                    size_t max_table_bytes);
+
 /* The longest byte string every match of the pattern must contain (*len = 0: none is certain).  A value without it cannot
  * match; the Grok matcher uses it to skip the automaton for most (value, Match pattern) pairs. */
 const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t* len);

@@ -71,6 +71,8 @@ def load(path=None):
     L.lc_sched_scratch_bytes.argtypes = [u32]
     L.lc_regex_match_device_ragged.restype = i32
     L.lc_regex_match_device_ragged.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, sz, vp]
+    L.lc_regex_compile_screen.restype = vp
+    L.lc_regex_compile_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
     L.lc_regex_required_literal.restype = vp
     L.lc_regex_required_literal.argtypes = [vp, ctypes.POINTER(sz)]
     L.lc_regex_match_device_from.restype = i32
@@ -113,6 +115,22 @@ class GpuRegex:
         self._h = h
         self.pattern = pattern
         self.groups = self._L.lc_regex_mark_count(h)
+
+    @classmethod
+    def compile_screen(cls, pattern, syntax_flags=0, max_states=1024, max_table_bytes=32 * 1024, lib=None):
+        """lc_regex_compile_screen: TDFA handle for the longest affordable prefix of `pattern`, or None"""
+        L = lib or load()
+        if isinstance(pattern, str):
+            pattern = pattern.encode("utf-8")
+        h = L.lc_regex_compile_screen(pattern, len(pattern), syntax_flags, max_states, max_table_bytes)
+        if not h:
+            return None
+        self = cls.__new__(cls)
+        self._L = L
+        self._h = ctypes.c_void_p(h)
+        self.pattern = pattern
+        self.groups = L.lc_regex_mark_count(self._h)
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

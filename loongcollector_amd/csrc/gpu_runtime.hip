@@ -611,6 +611,20 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             in = outs[1];
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
         }
+        if (gp.screen && nIn) {  // ... and a match of the pattern's prefix (fast TDFA kernel, status only)
+            int rc = lcMatchOnStream(gp.screen, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
+                                     status, st);
+            if (rc != LC_OK) return rc;
+            uint32_t* out = in == outs[0] ? outs[1] : outs[0];
+            hipLaunchKernelGGL(grok_status_filter_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in,
+                               nIn, status, out, counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            nIn = host[0];
+            in = out;
+            flip = in == outs[0] ? 1 : 0;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+        }
         while (nIn) {
             int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, row / 2, caps,
                                      status, st);

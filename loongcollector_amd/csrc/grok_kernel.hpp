@@ -67,6 +67,17 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_filter_kernel(const u
     if (__any(found) && lane == 0) out[atomicAdd(&counters[0], 1u)] = line;
 }
 
+// Keeps the values whose screen search matched (status bytes written by the TDFA kernel for the values listed in `in`).
+__global__ __launch_bounds__(kGrokBlock) void grok_status_filter_kernel(const uint32_t* __restrict__ in, uint32_t nIn,
+                                                                       const uint8_t* __restrict__ status,
+                                                                       uint32_t* __restrict__ out,
+                                                                       uint32_t* __restrict__ counters) {
+    const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t line = in[k];
+    if (status[line] == LC_MATCH) out[atomicAdd(&counters[0], 1u)] = line;
+}
+
 // After one round of searches over the values listed in `in`:
 //   * a match that holds a non-empty named capture is recorded (first one -> `first`, later ones -> `extra`);
 //   * FindNextMatch: the value stays in play from the end of this match (one further after an empty match) unless

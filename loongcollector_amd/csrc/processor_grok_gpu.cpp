@@ -30,13 +30,16 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
 ProcessorGrokGpu::~ProcessorGrokGpu() {
     for (lc_regex* re : mCompiled) lc_regex_free(re);
+    for (lc_regex* re : mScreens) lc_regex_free(re);
 }
 
 int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCompiled[i]->engine : 0; }
 
 void ProcessorGrokGpu::Init() {
     for (lc_regex* re : mCompiled) lc_regex_free(re);
+    for (lc_regex* re : mScreens) lc_regex_free(re);
     mCompiled.clear();
+    mScreens.clear();
     mDevice.clear();
     mExpanded.clear();
     mKeys.clear();
@@ -61,7 +64,12 @@ void ProcessorGrokGpu::Init() {
         mCompiled.push_back(re);
         const uint32_t columns = uint32_t(lc_regex_mark_count(re)) - 1;   // group 1 is the whole match
         maxColumns = std::max(maxColumns, columns);
-        mDevice.push_back({re, columns});
+        // patterns that run on the slow NFA kernel get a TDFA screen for their prefix when one is small enough
+        lc_regex* screen = nullptr;
+        if (re->engine == LC_ENGINE_NFA)
+            screen = lcCompilePrefixScreen(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, 1024, 32 * 1024);
+        mScreens.push_back(screen);
+        mDevice.push_back({re, columns, screen});
         std::vector<uint32_t> colKey(columns, kNoKey);
         std::vector<MergedField> fields;
         std::map<std::string, size_t> byName;

@@ -2,6 +2,7 @@
 #include "regex_handle.hpp"
 
 #include <cstdlib>
+#include <functional>
 #include <tuple>
 
 #include <algorithm>
@@ -393,6 +394,106 @@ static void wrapForPrefix(ParsedRegex& re) {
 
 static void setErr(char* err, size_t cap, const std::string& msg) {
     if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+// ---- prefix screen ---------------------------------------------------------------------------------------------
+// A pattern whose tagged DFA is far too large for LDS (Grok log formats: > 65 000 states) still has a PREFIX that is
+// small: the first k elements of its top-level concatenation, captures dropped.  Every match of the pattern contains a
+// match of that prefix, so "the prefix occurs somewhere in the line" is a necessary condition that the fast TDFA kernel
+// can test (status only) before the slow NFA kernel is asked for the captures.
+static std::unique_ptr<Node> cloneWithoutCaptures(const Node& n) {
+    auto c = std::make_unique<Node>();
+    c->kind = n.kind;
+    c->set = n.set;
+    c->min = n.min;
+    c->max = n.max;
+    c->greedy = n.greedy;
+    c->capture = 0;
+    c->look = n.look;
+    for (const auto& k : n.kids) c->kids.push_back(cloneWithoutCaptures(*k));
+    return c;
+}
+
+lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,
+                                size_t maxBlobBytes) {
+    Syntax syn;
+    syn.icase = syntax_flags & LC_SYNTAX_ICASE;
+    syn.dotAll = !(syntax_flags & LC_SYNTAX_NO_DOTALL);
+    syn.multiLine = !(syntax_flags & LC_SYNTAX_NO_MULTILINE);
+    syn.extended = syntax_flags & LC_SYNTAX_EXTENDED;
+    syn.namedOnly = true;
+    syn.regexp2 = syntax_flags & LC_SYNTAX_REGEXP2;
+    ParsedRegex parsed;
+    try {
+        parsed = parseRegex(std::string_view(pattern, len), syn);
+    } catch (const RegexError&) {
+        return nullptr;
+    }
+    // the pattern as one flat concatenation: groups (captures are dropped anyway) and nested concatenations are spliced
+    std::vector<const Node*> flat;
+    std::function<void(const Node&)> flatten = [&](const Node& n) {
+        if (n.kind == Node::Group && n.kids.size() == 1) flatten(*n.kids[0]);
+        else if (n.kind == Node::Cat)
+            for (const auto& k : n.kids) flatten(*k);
+        else if (n.kind != Node::Empty) flat.push_back(&n);
+    };
+    flatten(*parsed.root);
+    if (flat.size() < 2) return nullptr;  // nothing to cut
+    // try a long prefix first; halve until the automaton is small enough
+    for (size_t k = std::min<size_t>(flat.size() - 1, 48); k >= 1; k = k / 2) {
+        auto re = std::make_unique<lc_regex>();
+        try {
+            ParsedRegex sub;
+            auto cat = std::make_unique<Node>();
+            cat->kind = Node::Cat;
+            for (size_t i = 0; i < k; ++i) cat->kids.push_back(cloneWithoutCaptures(*flat[i]));
+            sub.root = std::move(cat);
+            sub.groupCount = 0;
+            sub.groupNames.emplace_back();
+            // a prefix that can match the empty string screens nothing
+            {
+                FollowNfa probe = buildFollowNfa(sub);
+                bool nullable = false;
+                for (const auto& path : probe.follow[size_t(probe.startIndex())])
+                    if (path.target == kMatchTarget) nullable = true;
+                if (nullable) {
+                    if (k == 1) break;
+                    continue;
+                }
+            }
+            wrapForSearch(sub);
+            re->nfa = buildFollowNfa(sub);
+            re->nfa.searchPrefix = 0;
+            re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;
+            TdfaLimits lim;
+            lim.maxStates = maxStates;
+            re->tdfa = buildTdfa(re->nfa, lim);
+            if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) throw RegexError("screen: tables too large");
+            re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
+            if (!re->tdfaBlock) throw RegexError("screen: does not fit LDS");
+            re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
+            re->hasTdfa = true;
+            re->engine = LC_ENGINE_TDFA;
+            re->pattern = "<prefix screen: first " + std::to_string(k) + " of " + std::to_string(flat.size()) + " elements>";
+            re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
+            re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots, re->tdfa.startState,
+                              uint32_t(k), uint32_t(flat.size()), 0};
+            return re.release();
+        } catch (const RegexError&) {
+            if (k == 1) break;
+        }
+    }
+    return nullptr;
+}
+
+extern "C" lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t pattern_len, uint32_t syntax_flags,
+                                               uint32_t max_states, size_t max_table_bytes) {
+    if (!pattern) return nullptr;
+    try {
+        return lcCompilePrefixScreen(pattern, pattern_len, syntax_flags, max_states, max_table_bytes);
+    } catch (const std::exception&) {
+        return nullptr;
+    }
 }
 
 extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,

@@ -70,6 +70,10 @@ inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos, bool atomic) {
     return size_t(blobBytes) + size_t(4) * (((nPos + 3) & ~3u) + 256) * 4 + (atomic ? size_t(4) * 1344 * 4 : 0);
 }
 
+// regex_handle.cpp: TDFA-only handle for the longest prefix of the pattern's top-level concatenation whose automaton stays
+// within the limits (nullptr if there is none); status-only screening before the NFA engine (Grok)
+lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,
+                                size_t maxBlobBytes);
 // implemented in gpu_runtime.hip; frees device copies
 void lcReleaseDeviceTables(lc_regex* re);
 // implemented in gpu_runtime.hip: one launch of the engine's kernel.  d_n (optional): line count on the device;

@@ -169,6 +169,43 @@ def test_device_algorithm_on_the_compiled_tables_reproduces_the_golden_vectors(g
     assert checked >= 300 and skipped == 0
 
 
+def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, golden_dir):
+    """Two prefilters sit in front of the NFA engine (lcGrokMatchDevice): the required literal and the TDFA screen of the
+    pattern's prefix.  Both must accept every value the pattern matches somewhere -- checked against the oracle's search on
+    the golden values and on the configs[2] corpus; and a screen must exist for most NFA-engine patterns."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    lib = Grok(CustomPatterns=cfg3["custom_patterns"])
+    jobs = [(e, [v.encode("latin-1") for v, _ in c["subs"]]) for c in golden["regex"]
+            for e in GrokOracle(c["config"]["Match"], custom_patterns=c["config"].get("CustomPatterns")).expanded]
+    corpus = grok_lines(150)
+    jobs += [(lib.denormalize(m), corpus) for m in cfg3["match"][4:40:3]]
+    screens = checked = rejected = 0
+    for expanded, values in jobs:
+        pat = expanded.encode("utf-8")
+        try:
+            rx = B.GpuRegex(pat, syntax_flags=GROK_SYNTAX)
+        except B.RegexUnsupportedError:
+            continue
+        from oracle.oracle import ORX_NO_MOD_M, ORX_NO_MOD_S, ORX_REGEXP2, OracleRegex
+        o = OracleRegex(pat, ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2)
+        lit = rx.required_literal()
+        screen = B.GpuRegex.compile_screen(pat, syntax_flags=GROK_SYNTAX & ~B.LC_SYNTAX_SEARCH)
+        it = TdfaInterp(screen) if screen is not None else None
+        screens += screen is not None
+        for v in values:
+            hit = o.search(v) is not None
+            checked += 1
+            if it is not None:
+                passes = it.fullmatch(v) is not None
+                assert passes or not hit, (expanded[:60], v)
+                rejected += not passes
+            if hit:
+                assert lit in v, (expanded[:60], lit, v)
+    assert checked >= 2000 and screens >= 15 and rejected > 300, (checked, screens, rejected)
+
+
 def test_no_cpu_path():
     if B.load().lc_device_count() > 0:
         pytest.skip("a HIP device is present")
