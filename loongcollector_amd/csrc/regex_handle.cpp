@@ -439,27 +439,19 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
     };
     flatten(*parsed.root);
     if (flat.size() < 2) return nullptr;  // nothing to cut
-    // try a long prefix first; halve until the automaton is small enough
-    for (size_t k = std::min<size_t>(flat.size() - 1, 48); k >= 1; k = k / 2) {
+    // compile one candidate screen (a sub-expression every match of the pattern must start with); nullptr if it is
+    // nullable (screens nothing) or its automaton is too large
+    auto tryScreen = [&](std::unique_ptr<Node> node, uint32_t k, const char* how) -> lc_regex* {
         auto re = std::make_unique<lc_regex>();
         try {
             ParsedRegex sub;
-            auto cat = std::make_unique<Node>();
-            cat->kind = Node::Cat;
-            for (size_t i = 0; i < k; ++i) cat->kids.push_back(cloneWithoutCaptures(*flat[i]));
-            sub.root = std::move(cat);
+            sub.root = std::move(node);
             sub.groupCount = 0;
             sub.groupNames.emplace_back();
-            // a prefix that can match the empty string screens nothing
             {
                 FollowNfa probe = buildFollowNfa(sub);
-                bool nullable = false;
                 for (const auto& path : probe.follow[size_t(probe.startIndex())])
-                    if (path.target == kMatchTarget) nullable = true;
-                if (nullable) {
-                    if (k == 1) break;
-                    continue;
-                }
+                    if (path.target == kMatchTarget) return nullptr;
             }
             wrapForSearch(sub);
             re->nfa = buildFollowNfa(sub);
@@ -468,19 +460,47 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
             TdfaLimits lim;
             lim.maxStates = maxStates;
             re->tdfa = buildTdfa(re->nfa, lim);
-            if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) throw RegexError("screen: tables too large");
+            if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) return nullptr;
             re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
-            if (!re->tdfaBlock) throw RegexError("screen: does not fit LDS");
+            if (!re->tdfaBlock) return nullptr;
             re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
             re->hasTdfa = true;
             re->engine = LC_ENGINE_TDFA;
-            re->pattern = "<prefix screen: first " + std::to_string(k) + " of " + std::to_string(flat.size()) + " elements>";
+            re->pattern = std::string("<prefix screen: ") + how + ", " + std::to_string(k) + " of " +
+                          std::to_string(flat.size()) + " elements>";
             re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
             re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots, re->tdfa.startState,
-                              uint32_t(k), uint32_t(flat.size()), 0};
+                              k, uint32_t(flat.size()), 0};
             return re.release();
         } catch (const RegexError&) {
-            if (k == 1) break;
+            return nullptr;
+        }
+    };
+    auto prefixOf = [&](const std::vector<const Node*>& list, size_t k) {
+        auto cat = std::make_unique<Node>();
+        cat->kind = Node::Cat;
+        for (size_t i = 0; i < k && i < list.size(); ++i) cat->kids.push_back(cloneWithoutCaptures(*list[i]));
+        return cat;
+    };
+    // 1. a long prefix of the concatenation; halve until the automaton is small enough
+    for (size_t k = std::min<size_t>(flat.size() - 1, 48); k >= 1; k = k / 2)
+        if (lc_regex* re = tryScreen(prefixOf(flat, k), uint32_t(k), "concatenation")) return re;
+    // 2. the pattern starts with an alternation that is too large as a whole (a syslog line starts with one of two
+    //    timestamp formats): a match starts with a match of SOME alternative, hence with a prefix of that alternative
+    if (flat[0]->kind == Node::Alt) {
+        std::vector<std::vector<const Node*>> alts;
+        for (const auto& kid : flat[0]->kids) {
+            std::vector<const Node*> saved;
+            saved.swap(flat);
+            flatten(*kid);
+            alts.push_back(flat);
+            flat.swap(saved);
+        }
+        for (size_t budget = 16; budget >= 1; budget /= 2) {
+            auto alt = std::make_unique<Node>();
+            alt->kind = Node::Alt;
+            for (const auto& list : alts) alt->kids.push_back(prefixOf(list, std::max<size_t>(1, std::min(list.size(), budget))));
+            if (lc_regex* re = tryScreen(std::move(alt), uint32_t(budget), "leading alternation")) return re;
         }
     }
     return nullptr;
