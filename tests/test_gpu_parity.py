@@ -2,6 +2,7 @@
 Bit-exact bar: status bytes and int32 capture offsets must be identical."""
 import json
 import os
+import random
 
 import numpy as np
 import pytest
@@ -376,3 +377,54 @@ def test_byte_pair_transition_tables_are_bit_exact(torch_dev, golden_dir, monkey
     caps, status = run_device(torch_dev, rx, data, off[:len(length)], length)
     exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:len(length)], length)
     assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
+    """lc_regex_match_device_from: a subset of the lines, each search resumed at its own offset (also beyond the first
+    256-byte chunk of the NFA kernel and across the TDFA kernel's 64-byte stages), against the oracle's search(start)."""
+    from oracle.oracle import OracleRegex
+    torch = torch_dev
+    dev = torch.device("cuda:0")
+    rng = random.Random(77)
+    words = [b"alpha", b"10.2.3.4", b"x=42", b"2024-01-04", b"beta99", b"--", b"k=", b"7"]
+    lines = []
+    for _ in range(700):
+        n = rng.choice([3, 20, 60, 150, 400])
+        lines.append(b" ".join(rng.choice(words) for _ in range(n)))
+    data, off, length = pack(lines)
+    n = len(lines)
+    pad = np.zeros(len(data) + 16, dtype=np.uint8)
+    pad[:len(data)] = data
+    d_data = torch.from_numpy(pad).to(dev)
+    d_off = torch.from_numpy(off.view(np.int32).copy()).to(dev)
+    d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev)
+    subset = np.array(sorted(rng.sample(range(n), 500)), dtype=np.uint32)
+    start = np.zeros(n, dtype=np.uint32)
+    for i in subset:
+        L = int(length[i])
+        start[i] = rng.choice([0, 1, L // 2, max(0, L - 3), L, min(L, 255), min(L, 256), min(L, 257), min(L, 700)])
+    d_sub = torch.from_numpy(subset.view(np.int32).copy()).to(dev)
+    d_from = torch.from_numpy(start.view(np.int32).copy()).to(dev)
+    for pattern in (rb"(\w+)=(\d*)", rb"(?<![0-9.])(\d+)\.(\d+)\.(\d+)\.(\d+)(?![0-9])", rb"\b(\d{4})-(\d\d)-(\d\d)\b", rb"(?>[a-z]+)(\d\d)"):
+        rx = B.GpuRegex(pattern, syntax_flags=B.LC_SYNTAX_SEARCH)
+        o = OracleRegex(pattern)
+        G = rx.groups
+        engines = ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + (
+            [B.LC_ENGINE_NFA] if rx.has_nfa_program() else [])
+        assert engines
+        for eng in engines:
+            d_caps = torch.full((n, 2 * G), -7, dtype=torch.int32, device=dev)
+            d_status = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+            rx.match_device_from(d_data, d_off, d_len, len(subset), d_caps, d_status, d_lines=d_sub, d_from=d_from, engine=eng)
+            torch.cuda.synchronize()
+            caps, status = d_caps.cpu().numpy(), d_status.cpu().numpy()
+            touched = np.zeros(n, dtype=bool)
+            touched[subset] = True
+            assert (status[~touched] == 9).all() and (caps[~touched] == -7).all()   # lines not listed are not written
+            for i in subset:
+                exp = o.search(lines[i], int(start[i]))
+                if exp is None:
+                    assert status[i] == B.LC_NOMATCH, (pattern, eng, i, int(start[i]))
+                else:
+                    assert status[i] == B.LC_MATCH and list(caps[i]) == [v for ab in exp for v in ab], (
+                        pattern, eng, lines[i][:80], int(start[i]), list(caps[i]), exp)
