@@ -428,3 +428,44 @@ def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
                 else:
                     assert status[i] == B.LC_MATCH and list(caps[i]) == [v for ab in exp for v in ab], (
                         pattern, eng, lines[i][:80], int(start[i]), list(caps[i]), exp)
+
+
+def test_random_atomic_patterns_on_both_kernels(torch_dev):
+    """Fresh random patterns with atomic groups / possessive quantifiers / look assertions (not the committed golden set),
+    full-match and search, TDFA and NFA kernels against the oracle."""
+    import importlib.util
+    pytest.importorskip("regex")
+    from oracle.oracle import OracleRegex
+    spec = importlib.util.spec_from_file_location(
+        "gen_atomic_golden", os.path.join(os.path.dirname(__file__), "golden", "gen_atomic_golden.py"))
+    agen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(agen)
+    rng = random.Random(4242)
+    checked = overflow = 0
+    for _ in range(220):
+        p = agen.gen(rng)
+        try:
+            o = OracleRegex(p)
+        except ValueError:
+            continue
+        subs = [bytes(rng.choice(b"abc1 ") for _ in range(rng.randint(0, 10))) for _ in range(10)]
+        data, off, length = pack(subs)
+        for flags, fn in ((0, o.fullmatch), (B.LC_SYNTAX_SEARCH, o.search)):
+            try:
+                rx = B.GpuRegex(p, syntax_flags=flags)
+            except B.RegexUnsupportedError:
+                continue
+            engines = ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + (
+                [B.LC_ENGINE_NFA] if rx.has_nfa_program() else [])
+            for eng in engines:
+                caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+                for i, s in enumerate(subs):
+                    if status[i] == B.LC_OVERFLOW:
+                        overflow += 1
+                        continue
+                    exp = fn(s)
+                    want = None if exp is None else [v for ab in (exp if flags else exp[1:]) for v in ab]
+                    checked += 1
+                    got = None if status[i] == B.LC_NOMATCH else list(caps[i])
+                    assert got == want, (p, s, flags, eng, got, want)
+    assert checked > 5000 and overflow < checked // 50
