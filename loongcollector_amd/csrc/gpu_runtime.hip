@@ -154,7 +154,13 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);
     const bool atomic = re->nfa.atomicCount > 0;
     size_t lds = lcNfaLdsBytes(blobBytes, uint32_t(re->nfa.positions.size()), atomic);
-    const bool global = lds > kLcLdsPerCu;  // program too big for LDS: tables stay in HBM (L2), only the scratch is LDS
+    // Program too big for LDS -- or so big that only one workgroup would fit per CU: the tables stay in HBM (L2) and
+    // only the scratch is LDS; four lines per CU with LDS-speed tables lose against a dozen with L2-speed tables.
+    static const size_t globalAbove = [] {
+        const char* e = getenv("LC_NFA_GLOBAL_KB");
+        return size_t(e ? atoi(e) : 96) * 1024;
+    }();
+    const bool global = lds > kLcLdsPerCu || lds > globalAbove;
     if (global) lds -= blobBytes;
     if (lds > 160 * 1024) {
         tlsError = "nfa tables exceed LDS";

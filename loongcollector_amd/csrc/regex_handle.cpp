@@ -204,6 +204,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     if (npos >= 0xFFFF) throw RegexError("nfa: more than 65534 positions");
     std::vector<uint32_t> followStart, paths, events, aux(4, 0);  // aux entry 0 = (no cond, no tags)
     std::map<std::tuple<uint32_t, uint64_t>, uint32_t> auxIndex;
+    std::map<std::vector<uint32_t>, uint32_t> eventSeqs;
     std::vector<uint32_t> atomicPos(size_t(npos) / 32 + 2, 0);  // bit p: some path out of position p enters/leaves a group
     for (int p = 0; p <= npos; ++p) {
         followStart.push_back(uint32_t(paths.size() / 2));
@@ -224,14 +225,20 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             paths.push_back((path.target == kMatchTarget ? 0xFFFFu : uint32_t(path.target)) | (a << 16));
             uint32_t evWord = 0;
             if (nfa.atomicCount) {
-                if (path.atoms.size() > 255 || events.size() >= (1u << 24))
-                    throw RegexError("nfa: atomic event list too long");
-                evWord = uint32_t(events.size() << 8) | uint32_t(path.atoms.size());
+                if (path.atoms.size() > 255) throw RegexError("nfa: atomic event list too long");
+                std::vector<uint32_t> seq;
                 for (const auto& ev : path.atoms) {
                     if (ev.visit > 0xFFFF) throw RegexError("nfa: too many atomic exits on one follow list");
-                    events.push_back(uint32_t(uint16_t(int16_t(ev.code))) | (uint32_t(ev.visit) << 16));
+                    seq.push_back(uint32_t(uint16_t(int16_t(ev.code))) | (uint32_t(ev.visit) << 16));
                     if (ev.code < kAssertEvent) atomicPos[size_t(p) / 32] |= 1u << (p % 32);
                 }
+                auto it = eventSeqs.find(seq);  // identical event sequences are stored once
+                if (it == eventSeqs.end()) {
+                    if (events.size() >= (1u << 24)) throw RegexError("nfa: atomic event list too long");
+                    it = eventSeqs.emplace(seq, uint32_t(events.size())).first;
+                    events.insert(events.end(), seq.begin(), seq.end());
+                }
+                evWord = (it->second << 8) | uint32_t(seq.size());
             }
             paths.push_back(evWord);
         }
