@@ -310,6 +310,9 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     for (int p = 0; p <= npos; ++p)
         for (const auto& path : nfa.follow[p]) need[p] |= path.cond & nfa.behindMask;
 
+    // The device format addresses transition rows with 16 bits (device_tables.h): states x (classes + 1) x 4 bytes must
+    // stay under 64 KiB - 320.  Knowing that up front makes hopeless determinisations (Grok log formats) fail fast.
+    const uint32_t maxStates = std::min<uint32_t>(limits.maxStates, (65536u - 320u) / (uint32_t(ncls + 1) * 4u));
     std::vector<State> states;
     std::unordered_map<std::string, uint32_t> index;
     std::deque<uint32_t> work;
@@ -318,7 +321,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
         std::string k = keyOf(s);
         auto it = index.find(k);
         if (it != index.end()) return it->second;
-        if (states.size() >= limits.maxStates) throw RegexError("tdfa: state limit exceeded");
+        if (states.size() >= maxStates) throw RegexError("tdfa: state limit exceeded");
         uint32_t id = uint32_t(states.size());
         states.push_back(std::move(s));
         index.emplace(std::move(k), id);
