@@ -686,31 +686,46 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t row
     std::vector<uint8_t> hData(bytes + 16);
     for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
 
+    // device buffers of the calling thread: grow-only, kept between calls (ProcessLogs hands over group after group)
     struct Dev {
         void* p = nullptr;
+        size_t cap = 0;
+        int device = -1;
         ~Dev() {
             if (p) (void)hipFree(p);
         }
-    } dData, dOff, dLen, dPattern, dFirst, dExtra, dNextra, dScratch;
+        hipError_t ensure(size_t bytes, int dev) {
+            if (p && device == dev && cap >= bytes) return hipSuccess;
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = bytes + (bytes >> 2) + 256;
+            hipError_t e = hipMalloc(&p, want);
+            if (e == hipSuccess) {
+                cap = want;
+                device = dev;
+            }
+            return e;
+        }
+    };
+    static thread_local Dev dData, dOff, dLen, dPattern, dFirst, dExtra, dNextra, dScratch;
+    int devNo = 0;
+    HIP_TRY(hipGetDevice(&devNo));
     const size_t scratch = lcGrokScratchBytes(n, row);
     uint32_t extraCap = n / 4 + 1024;
-    HIP_TRY(hipMalloc(&dData.p, bytes + 16));
-    HIP_TRY(hipMalloc(&dOff.p, size_t(n) * 4));
-    HIP_TRY(hipMalloc(&dLen.p, size_t(n) * 4));
-    HIP_TRY(hipMalloc(&dPattern.p, size_t(n) * 4));
-    HIP_TRY(hipMalloc(&dFirst.p, size_t(n) * row * 4));
-    HIP_TRY(hipMalloc(&dNextra.p, 4));
-    HIP_TRY(hipMalloc(&dScratch.p, scratch));
+    HIP_TRY(dData.ensure(bytes + 16, devNo));
+    HIP_TRY(dOff.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dLen.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dPattern.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dFirst.ensure(size_t(n) * row * 4, devNo));
+    HIP_TRY(dNextra.ensure(4, devNo));
+    HIP_TRY(dScratch.ensure(scratch, devNo));
     HIP_TRY(hipMemcpy(dData.p, hData.data(), bytes + 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dOff.p, hOff.data(), size_t(n) * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dLen.p, len, size_t(n) * 4, hipMemcpyHostToDevice));
     uint32_t nExtra = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (dExtra.p) {
-            (void)hipFree(dExtra.p);
-            dExtra.p = nullptr;
-        }
-        HIP_TRY(hipMalloc(&dExtra.p, size_t(extraCap) * (row + 2) * 4));
+        HIP_TRY(dExtra.ensure(size_t(extraCap) * (row + 2) * 4, devNo));
         int rc = lcGrokMatchDevice(patterns, row, static_cast<const uint8_t*>(dData.p), static_cast<const uint32_t*>(dOff.p),
                                    static_cast<const uint32_t*>(dLen.p), n, static_cast<int32_t*>(dPattern.p),
                                    static_cast<int32_t*>(dFirst.p), static_cast<int32_t*>(dExtra.p), extraCap,
