@@ -2,8 +2,9 @@
  * lc_multiline.h -- C ABI of the multiline splitter on the device.
  *
  * Replaces the record-boundary logic of core/plugin/processor/inner/ProcessorSplitMultilineLogStringNative.cpp:
- *   lc_multiline_create      <- MultilineOptions::Init / ParseRegex (core/file_server/MultilineOptions.cpp:100-262): custom
- *                               mode with StartPattern / ContinuePattern / EndPattern, UnmatchedContentTreatment
+ *   lc_multiline_create      <- ProcessorSplitMultilineLogStringNative::Init :36-84 (the three patterns compiled as written)
+ *                               + MultilineOptions::Init (core/file_server/MultilineOptions.cpp:100-222): custom mode,
+ *                               UnmatchedContentTreatment, IsMultiline
  *   lc_multiline_split_host  <- ProcessEvent :126-300 + HandleUnmatchLogs :341-380 for ONE source value (a read buffer of
  *                               '\n'-separated lines): which lines form one log, which are unmatched
  * The per-line question of the reference -- BoostRegexSearch(line, pattern) = regex_search with match_continuous
@@ -33,10 +34,11 @@ typedef struct lc_ml_record {
  *               "UnmatchedContentTreatment": "single_line" | "discard"}   (keys of the Multiline object, custom mode) */
 int lc_multiline_create(const char* config_json, size_t config_len, lc_multiline_t** out, char* err, size_t errcap);
 void lc_multiline_free(lc_multiline_t* m);
-/* MultilineOptions::IsMultiline(): 0 means "no usable pattern, split by line feed only" */
+/* MultilineOptions::IsMultiline() (:203-205, decided on the patterns with a trailing '$' / ".*" stripped): 0 means the
+ * input plugin would not install the multiline splitter at all */
 int lc_multiline_is_multiline(const lc_multiline_t* m);
-/* 1 if the pattern survived Init (bit 0 start, bit 1 continue, bit 2 end): the reference drops ContinuePattern when it is
- * the only one, or when all three are given (MultilineOptions.cpp:170-201) */
+/* which patterns the processor works with (bit 0 start, bit 1 continue, bit 2 end): Has*Pattern() = the string as written
+ * is not empty (ProcessorSplitMultilineLogStringNative.h:68-70) */
 int lc_multiline_patterns(const lc_multiline_t* m);
 
 /* counters[3] = input lines, unmatched lines, matched logs (mMatchedLinesTotal = input - unmatched).

@@ -36,11 +36,17 @@ struct lc_multiline {
     }
 };
 
-// MultilineOptions::ParseRegex :250-266 -- a trailing '$' and trailing ".*"s are stripped (the match is a prefix match
-// anyway); what is left empty means "no pattern"
-static bool parseRegex(std::string pattern, lc_regex_t** out, std::string& err) {
+// MultilineOptions::ParseRegex :250-266 strips a trailing '$' and trailing ".*"s -- but only to decide validity and
+// IsMultiline().  The PROCESSOR compiles the pattern strings as written (ProcessorSplitMultilineLogStringNative.cpp:66-76,
+// mMultiline.mStartPattern is the original string, MultilineOptions.cpp:119) and a pattern counts as present when that
+// string is not empty (Has*Pattern, .h:68-70): "END$" does need the line to end there, ".*" is a start pattern that
+// matches every line, and ContinuePattern stays in use when all three are given.
+static std::string trimmed(std::string pattern) {
     if (!pattern.empty() && endsWith(pattern, "$")) pattern.pop_back();
     while (!pattern.empty() && endsWith(pattern, ".*")) pattern.resize(pattern.size() - 2);
+    return pattern;
+}
+static bool parseRegex(const std::string& pattern, lc_regex_t** out, std::string& err) {
     if (pattern.empty()) return true;
     char buf[256];
     if (lc_regex_compile(pattern.data(), pattern.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, out, buf, sizeof buf) != LC_OK) {
@@ -72,12 +78,8 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
             throw std::runtime_error("string param Multiline.ContinuePattern is not a valid regex: " + why);
         if (!parseRegex(str("EndPattern"), &m->end, why))
             throw std::runtime_error("string param Multiline.EndPattern is not a valid regex: " + why);
-        // :170-201 -- continue alone is ignored (and the config is not multiline); with all three, continue is ignored
-        if ((!m->start && !m->end && m->cont) || (m->start && m->cont && m->end)) {
-            lc_regex_free(m->cont);
-            m->cont = nullptr;
-        }
-        m->isMultiline = m->start || m->end;                                   // :203-205
+        // MultilineOptions::IsMultiline (:203-205) goes by what is left after the stripping
+        m->isMultiline = !trimmed(str("StartPattern")).empty() || !trimmed(str("EndPattern")).empty();
         const std::string t = str("UnmatchedContentTreatment");               // :208-222
         m->discardUnmatched = t == "discard";
     } catch (const std::exception& e) {

@@ -1,27 +1,31 @@
 """oracle/multiline_oracle.py -- CPU restatement of the multiline splitter's record logic.  TEST INFRASTRUCTURE ONLY.
 
-Follows core/file_server/MultilineOptions.cpp:100-262 (ParseRegex strips a trailing '$' and trailing '.*'; continue alone
-or all three patterns -> continue is dropped) and
+Follows ProcessorSplitMultilineLogStringNative::Init :36-84 (patterns compiled as written, present when not empty),
+core/file_server/MultilineOptions.cpp:203-205,250-266 (IsMultiline on the stripped patterns) and
 core/plugin/processor/inner/ProcessorSplitMultilineLogStringNative.cpp:126-300 (ProcessEvent), :341-380 (HandleUnmatchLogs),
 :382-392 (GetNextLine).  The per-line test is boost::regex_search with match_continuous = OracleRegex.prefixmatch.
 Pinned on the 47 cases of the reference's own unit test (tests/golden/multiline_vectors.json)."""
 from oracle.oracle import OracleRegex
 
 
-def _parse(pattern):
+def _trimmed(pattern):
+    """MultilineOptions::ParseRegex :250-266 -- only validity and IsMultiline() look at the stripped form"""
     if pattern.endswith("$"):
         pattern = pattern[:-1]
     while pattern.endswith(".*"):
         pattern = pattern[:-2]
+    return pattern
+
+
+def _parse(pattern):
+    """the processor compiles the string as written and uses it when it is not empty (.cpp:66-76, .h:68-70)"""
     return OracleRegex(pattern.encode("utf-8")) if pattern else None
 
 
 class MultilineOracle:
     def __init__(self, StartPattern="", ContinuePattern="", EndPattern="", UnmatchedContentTreatment="single_line"):
         self.start, self.cont, self.end = _parse(StartPattern), _parse(ContinuePattern), _parse(EndPattern)
-        if (not self.start and not self.end and self.cont) or (self.start and self.cont and self.end):
-            self.cont = None
-        self.is_multiline = bool(self.start or self.end)
+        self.is_multiline = bool(_trimmed(StartPattern) or _trimmed(EndPattern))
         self.discard = UnmatchedContentTreatment == "discard"
 
     def split(self, val: bytes):

@@ -33,17 +33,21 @@ def test_oracle_reproduces_the_reference_unit_test_cases(vectors):
 
 
 def test_init_rules():
-    """MultilineOptions.cpp:170-205, :250-262"""
+    """ProcessorSplitMultilineLogStringNative.cpp:66-76 / .h:68-70 (patterns as written), MultilineOptions.cpp:203-205,250-266"""
     m = Multiline(StartPattern="Exception.*", ContinuePattern=r"\s+at\s.*", EndPattern=r"\s*\.\.\.\d+ more")
-    assert m.patterns == {"start": True, "continue": False, "end": True} and m.is_multiline   # all three: continue dropped
+    assert m.patterns == {"start": True, "continue": True, "end": True} and m.is_multiline   # the processor keeps all three
     m = Multiline(ContinuePattern=r"\s+at\s.*")
-    assert m.patterns == {"start": False, "continue": False, "end": False} and not m.is_multiline   # continue alone: ignored
-    assert Multiline(StartPattern=".*").patterns["start"] is False                # nothing left after stripping '.*'
+    assert m.patterns == {"start": False, "continue": True, "end": False} and not m.is_multiline
+    m = Multiline(StartPattern=".*")
+    assert m.patterns["start"] is True and not m.is_multiline    # present for the processor, "not multiline" for the input
     assert Multiline(EndPattern="x$").patterns["end"] is True
     with pytest.raises(MultilineInitError):
         Multiline(StartPattern="(")
     o = MultilineOracle(StartPattern="a", ContinuePattern="b", EndPattern="c")
-    assert o.cont is None and o.is_multiline
+    assert o.cont is not None and o.is_multiline
+    # "END$" as written: the line has to end there (the stripped form would also accept "END7x")
+    recs, _ = MultilineOracle(StartPattern="BEGIN", EndPattern=r"END\d*$").split(b"BEGIN\nEND7x\nEND7")
+    assert recs == [(0, 16, 1)]
 
 
 def test_no_cpu_path():
@@ -70,10 +74,13 @@ def test_reference_cases_on_the_device(vectors):
     {"StartPattern": "BEGIN", "EndPattern": r"END\d*$"},
     {"ContinuePattern": r"\s+.*", "EndPattern": r"\}"},
     {"EndPattern": ";$", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}$"},   # all three stay in use
+    {"ContinuePattern": r"\s+.*"},                                                           # continue alone
+    {"StartPattern": ".*"},                                                                  # every line starts a record
 ])
 def test_random_buffers_against_the_oracle(config):
     rng = random.Random(41)
-    pool = [b"2024-01-04 boom", b"  at com.example.A.b(A.java:1)", b"[ERROR] x", b"BEGIN tx", b"END7", b"END", b"}", b"{",
+    pool = [b"2024-01-04 boom", b"  at com.example.A.b(A.java:1)", b"[ERROR] x", b"BEGIN tx", b"END7", b"END", b"END7x", b"}x", b"}", b"{",
             b"stmt;", b"noise", b"", b"\tcontinued", b"2024-13-99 not checked"]
     o = MultilineOracle(**config)
     m = Multiline(**config)
