@@ -59,21 +59,21 @@ enum {
 #define TD_REG_NONE 0xFEu
 
 // ---------------------------------------------------------------- NFA blob (engine LC_ENGINE_NFA)
-// header: 16 x u32
+// header: NF_HEADER_WORDS x u32
 enum {
     NF_MAGIC = 0,         // 'NFA1'
     NF_NPOS = 1,          // positions (byte-consuming steps); start pseudo-position has index nPos
     NF_NSLOTS = 2,
     NF_NCLASSES = 3,
     NF_OFF_CLASSMAP = 4,  // u8[256] byte -> class
-    NF_OFF_POSMASK = 5,   // u64[nPos] (as 2 x u32): bit c set iff position accepts byte class c  (nClasses <= 64)
+    NF_OFF_POSMASK = 5,   // u32[nPos+1][maskWords]: bit c set iff position accepts byte class c
     NF_OFF_FOLLOWSTART = 6, // u32[nPos+2]: follow list of position p = paths[followStart[p] .. followStart[p+1])
     NF_OFF_PATHS = 7,     // 2 x u32 per path: x = target (16 bits, 0xFFFF = MATCH) | aux index << 16 (0 = no cond, no tags);
                           // y = (first event << 8) | event count (atomic patterns, else 0)
     NF_TOTAL_BYTES = 8,
     NF_NPATHS = 9,
     NF_CONDS_USED = 10,
-    NF_OFF_STABLE = 11,   // u64[nPos+1]: bit c set iff on byte class c the position's ONLY possible move is its own
+    NF_OFF_STABLE = 11,   // u32[nPos+1][maskWords]: bit c set iff on byte class c the position's ONLY possible move is its own
                           // unconditional, tag-free self loop (the kernel's steady-state fast path)
     NF_OFF_BEHIND = 12,   // u32[nClasses+1]: look-behind assertions (cond bits) that hold when the previous byte has class
                           // c; entry nClasses = start of input
@@ -84,12 +84,14 @@ enum {
     NF_OFF_EVENTS = 15,   // u32[]: low16 = code (int16: +(g+1) enter group instance g, -(g+1) leave it, 20000+i assertion i
                           // is tested here), high16 = exit visit (follow_nfa.hpp FollowPath::Event)
     NF_OFF_ATOMICPOS = 16, // u32[(nPos+1)/32+1]: bit p = some path out of position p enters or leaves an atomic group
-    NF_OFF_AUX = 17,      // 4 x u32 per entry: cond bits, tags lo, tags hi, 0 -- the distinct (cond, tags) triples of the paths
+    NF_OFF_AUX = 17,      // auxWords x u32 per entry: cond bits, then the tag words -- the distinct (cond, tags) of the paths
     NF_SEARCH = 18,       // 1: position 0 is the lazy prefix of the LC_SYNTAX_SEARCH wrapper (the kernel may skip ahead to the
                           // next byte the pattern can start with while only that thread is alive)
-    NF_OFF_TOUCHY = 19,   // atomic patterns: u64[nPos+1], bit c = on byte class c a thread on this position needs the ordered
-                          // commit pass (a path leaves a group, or enters one towards a position that takes class c)
-    NF_HEADER_WORDS = 20
+    NF_OFF_TOUCHY = 19,   // atomic patterns: u32[nPos+1][maskWords], bit c = on byte class c a thread on this position needs
+                          // the ordered commit pass (a path leaves a group, or enters one towards a position that takes class c)
+    NF_MASK_WORDS = 20,   // words per class mask: 2, or 4 for patterns with 65..128 byte classes
+    NF_AUX_WORDS = 21,    // words per aux entry: 4 (cond + 2 tag words), or 8 (cond + 4 tag words) for 65..128 capture slots
+    NF_HEADER_WORDS = 24
 };
 #define NF_MAGIC_VALUE 0x3141464Eu
 #define NF_TARGET_MATCH 0xFFFFFFFFu

@@ -169,7 +169,7 @@ private:
     size_t steps = 0;
     int exitVisits = 0;
 
-    void add(int target, uint64_t tags, uint32_t cond, const std::vector<FollowPath::Event>& atoms) {
+    void add(int target, TagSet tags, uint32_t cond, const std::vector<FollowPath::Event>& atoms) {
         // a later path to the same target (same atomic history) whose condition set includes an earlier one's can
         // never win
         for (const auto& p : out)
@@ -177,7 +177,7 @@ private:
         if (out.size() >= 4096) throw RegexError("unsupported: too many epsilon paths");
         out.push_back({target, tags, cond, atoms});
     }
-    void walk(int pc, uint64_t tags, uint32_t cond, std::vector<FollowPath::Event>& atoms, int depth) {
+    void walk(int pc, TagSet tags, uint32_t cond, std::vector<FollowPath::Event>& atoms, int depth) {
         if (++steps > 2000000 || depth > 100000) throw RegexError("unsupported: epsilon closure too large");
         const size_t mark = atoms.size();
         for (;;) {
@@ -186,7 +186,7 @@ private:
                 case Inst::Char: add(in.x, tags, cond, atoms); atoms.resize(mark); return;
                 case Inst::Match: add(kMatchTarget, tags, cond, atoms); atoms.resize(mark); return;
                 case Inst::Jump: pc = in.x; break;
-                case Inst::Save: tags |= uint64_t(1) << in.x; ++pc; break;
+                case Inst::Save: tags |= TagSet(1) << in.x; ++pc; break;
                 case Inst::Assert:
                     cond |= 1u << in.x;
                     if (recordEvents) atoms.push_back({kAssertEvent + in.x, 0});

@@ -19,7 +19,8 @@
 
 namespace lcregex {
 
-constexpr int kMaxGpuGroups = 32;   // capture slots are carried in a 64-bit tag mask
+constexpr int kMaxGpuGroups = 64;   // capture slots are carried in a 128-bit tag mask
+typedef unsigned __int128 TagSet;   // bit s: capture slot s
 constexpr int kMaxAsserts = 32;     // distinct one-byte look assertions per pattern (cond mask is 32 bits)
 constexpr int kMatchTarget = -1;
 constexpr int kAssertEvent = 20000;
@@ -27,7 +28,7 @@ constexpr int kEdge = -1;           // "byte" value standing for START (behind) 
 
 struct FollowPath {
     int target;       // position index, or kMatchTarget
-    uint64_t tags;    // bit s: capture slot s is written at the current offset
+    TagSet tags;      // bit s: capture slot s is written at the current offset
     uint32_t cond;    // bit i: asserts[i] must hold at the current offset
     // Only for patterns with atomic groups: what the epsilon path crosses, in order.  code +(g+1) = enter atomic
     // group instance g, -(g+1) = leave it, kAssertEvent+i = assertion i is tested here (so that "which exits happened

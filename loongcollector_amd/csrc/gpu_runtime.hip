@@ -185,11 +185,16 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         if (global) return launchNfaSlots<32, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         return launchNfaSlots<32, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
-    {
+    if (slots <= 64) {
         if (atomic && global) return launchNfaSlots<64, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (atomic) return launchNfaSlots<64, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (global) return launchNfaSlots<64, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         return launchNfaSlots<64, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }    {   // 65..128 slots (33..64 groups): 4 tag words per aux entry
+        if (atomic && global) return launchNfaSlots<128, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<128, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<128, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<128, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
 }
 

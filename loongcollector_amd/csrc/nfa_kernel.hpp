@@ -55,30 +55,35 @@ constexpr uint32_t kNfaAtomicScratchWords = 64 /*tPos*/ + 64 /*tNlin*/ + 64 * kN
                                             64 * kNfaLineageWork /*newLin*/ + 64 /*closedKey*/ + 64 /*closedBy*/;
 static_assert(kNfaAtomicScratchWords == 1344, "keep regex_handle.hpp lcNfaLdsBytes in step");
 
-// A path record is 8 bytes: x = target (16 bits, 0xFFFF = MATCH) | index of its (cond, tags) triple in the aux table
+// A path record is 8 bytes: x = target (16 bits, 0xFFFF = MATCH) | index of its (cond, tags) entry in the aux table
 // (16 bits, 0 = no assertion and no tag), y = (first event << 8) | event count (patterns with atomic groups).  Unpacked
-// here into the (target, cond, tagsLo, tagsHi) shape the kernel works with.
-__device__ __forceinline__ uint4 nfaPath(const uint2* paths, const uint4* aux, uint32_t q) {
-    const uint32_t x = paths[q].x;
-    uint4 p{x & 0xFFFFu, 0u, 0u, 0u};
+// here into x = target, y = cond bits, z = aux index (the tags are fetched from the aux entry by the lane that ends up
+// owning the new thread: 2 words, or 4 for patterns with more than 64 capture slots).
+struct NfaTables {
+    const uint32_t* followStart;
+    const uint2* paths;
+    const uint32_t* aux;      // auxWords per entry: cond, tag words
+    uint32_t auxShift;        // log2(auxWords)
+    const uint32_t* posMask;  // maskWords per position
+    uint32_t maskShift;       // log2(maskWords)
+};
+__device__ __forceinline__ uint4 nfaPath(const NfaTables& tb, uint32_t q) {
+    const uint32_t x = tb.paths[q].x;
+    uint4 p{x & 0xFFFFu, 0u, x >> 16, 0u};
     if (p.x == 0xFFFFu) p.x = NF_TARGET_MATCH;
-    if (x >> 16) {
-        const uint4 a = aux[x >> 16];
-        p.y = a.x;
-        p.z = a.y;
-        p.w = a.z;
-    }
+    if (p.z) p.y = tb.aux[p.z << tb.auxShift];
     return p;
+}
+// bit `cls` of the class mask of position p (cw = cls >> 5, cb = cls & 31: wave-uniform, computed once per byte)
+__device__ __forceinline__ bool nfaMaskBit(const uint32_t* masks, uint32_t maskShift, uint32_t p, uint32_t cw, uint32_t cb) {
+    return (masks[(p << maskShift) + cw] >> cb) & 1u;
 }
 
 struct NfaAtomicCtx {
-    const uint32_t* followStart;
-    const uint2* paths;
-    const uint4* aux;
+    NfaTables tb;
     const uint32_t* events;
-    const uint2* posMask;
     uint32_t *tPos, *tNlin, *tLin, *newNlin, *newLin, *closedKey, *closedBy;
-    uint32_t *newPos, *newSrc, *newTagsLo, *newTagsHi;
+    uint32_t *newPos, *newSrc, *newAux;
     uint32_t* best;  // per-position marker array of the wave (all 0xFFFFFFFF between steps)
 };
 
@@ -110,11 +115,11 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
         return -1;
     };
     for (uint32_t t = 0; t < nThreads; ++t) {
-        const uint32_t fs = c.followStart[c.tPos[t]], fe = c.followStart[c.tPos[t] + 1];
+        const uint32_t fs = c.tb.followStart[c.tPos[t]], fe = c.tb.followStart[c.tPos[t] + 1];
         const uint32_t nlin = c.tNlin[t];
         for (uint32_t q = fs; q < fe; ++q) {
-            const uint4 p = nfaPath(c.paths, c.aux, q);
-            const uint32_t pe = c.paths[q].y;
+            const uint4 p = nfaPath(c.tb, q);
+            const uint32_t pe = c.tb.paths[q].y;
             const uint32_t* ev = c.events + (pe >> 8);
             const uint32_t nev = pe & 0xFFu;
             bool targetOk;
@@ -123,8 +128,7 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
             } else if (p.x == NF_TARGET_MATCH) {
                 targetOk = false;
             } else {
-                const uint2 pm = c.posMask[p.x];
-                targetOk = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
+                targetOk = nfaMaskBit(c.tb.posMask, c.tb.maskShift, p.x, cls >> 5, cls & 31u);
             }
             bool dead = false;
             for (uint32_t j = 0; j < nlin && !dead; ++j) {
@@ -189,8 +193,7 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
             }
             c.newPos[nKept] = final ? (0x40000000u + nKept) : p.x;  // final: survivors never merge
             c.newSrc[nKept] = t;
-            c.newTagsLo[nKept] = p.z;
-            c.newTagsHi[nKept] = p.w;
+            c.newAux[nKept] = p.z;
             c.newNlin[nKept] = wn;
             for (uint32_t j = 0; j < wn; ++j) c.newLin[nKept * kNfaLineageWork + j] = work[j];
             ++nKept;
@@ -264,8 +267,7 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
             if (w != k) {
                 c.newPos[w] = c.newPos[k];
                 c.newSrc[w] = c.newSrc[k];
-                c.newTagsLo[w] = c.newTagsLo[k];
-                c.newTagsHi[w] = c.newTagsHi[k];
+                c.newAux[w] = c.newAux[k];
                 c.newNlin[w] = c.newNlin[k];
                 for (uint32_t m = 0; m < c.newNlin[k]; ++m)
                     c.newLin[w * kNfaLineageWork + m] = c.newLin[k * kNfaLineageWork + m];
@@ -315,36 +317,38 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t nPos = hdr[NF_NPOS];
     const uint32_t nSlots = hdr[NF_NSLOTS];
     const uint8_t* classMap = tbl + hdr[NF_OFF_CLASSMAP];
-    const uint2* posMask = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_POSMASK]);
-    const uint2* stable = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_STABLE]);
+    const uint32_t* stable = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_STABLE]);
     const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_BEHIND]);
     const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
     const uint32_t edgeClass = hdr[NF_NCLASSES];  // table index standing for start / end of input
-    const uint32_t* followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
-    const uint2* paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
-    const uint4* aux = reinterpret_cast<const uint4*>(tbl + hdr[NF_OFF_AUX]);
+    constexpr int TW = NS > 64 ? 4 : 2;  // tag words per aux entry (regex_handle.cpp packNfaBlob: 4 iff nSlots > 64)
+    NfaTables tb;
+    tb.followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
+    tb.paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
+    tb.aux = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AUX]);
+    tb.auxShift = TW == 4 ? 3 : 2;
+    tb.posMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_POSMASK]);
+    tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
+    const uint32_t maskShift = tb.maskShift;
+    const uint32_t* followStart = tb.followStart;
 
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newTagsLo, newTagsHi)
+    // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newAux, spare)
     const uint32_t scratchWords = ((nPos + 3) & ~3u) + 256;
     uint32_t* best = reinterpret_cast<uint32_t*>(smem + scratchBase) + wave * scratchWords;
     uint32_t* newPos = best + ((nPos + 3) & ~3u);
     uint32_t* newSrc = newPos + 64;
-    uint32_t* newTagsLo = newSrc + 64;
-    uint32_t* newTagsHi = newTagsLo + 64;
+    uint32_t* newAux = newSrc + 64;
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
     // atomic path: its per-wave scratch sits behind the scratch of all waves
     NfaAtomicCtx actx{};
     const uint32_t* atomicPos = nullptr;
-    const uint2* touchyMask = nullptr;
+    const uint32_t* touchyMask = nullptr;
     if constexpr (ATOMIC) {
         uint32_t* a = reinterpret_cast<uint32_t*>(smem + scratchBase) + kNfaWaves * scratchWords + wave * kNfaAtomicScratchWords;
-        actx.followStart = followStart;
-        actx.paths = paths;
-        actx.aux = aux;
+        actx.tb = tb;
         actx.events = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_EVENTS]);
-        actx.posMask = posMask;
         actx.tPos = a;
         actx.tNlin = a + 64;
         actx.tLin = a + 128;
@@ -354,11 +358,10 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         actx.closedBy = actx.closedKey + 64;
         actx.newPos = newPos;
         actx.newSrc = newSrc;
-        actx.newTagsLo = newTagsLo;
-        actx.newTagsHi = newTagsHi;
+        actx.newAux = newAux;
         actx.best = best;
         atomicPos = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_ATOMICPOS]);
-        touchyMask = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_TOUCHY]);
+        touchyMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_TOUCHY]);
     }
 
     const uint32_t slot = blockIdx.x * kNfaWaves + wave;
@@ -392,7 +395,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         }
     }
     const bool searchSkip = hdr[NF_SEARCH] != 0;
-    const uint2 stable0 = stable[0];  // steady classes of the search wrapper's prefix position
+    // steady classes of the search wrapper's prefix position (words 2, 3 only exist for patterns with > 64 byte classes)
+    const uint32_t stable0[4] = {stable[0], stable[1], maskShift == 2 ? stable[2] : 0u, maskShift == 2 ? stable[3] : 0u};
     uint32_t curWord;
     {
         const uint32_t w = (((head + from) >> 8) << 6) + lane;  // the 256-byte chunk the first byte lives in
@@ -415,7 +419,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             for (int j = 3; j >= 0; --j) {
                 const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
                 const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
-                const uint32_t steady = c < 32 ? (stable0.x >> c) & 1u : (stable0.y >> (c - 32)) & 1u;
+                const uint32_t sw = c < 64 ? (c < 32 ? stable0[0] : stable0[1]) : (c < 96 ? stable0[2] : stable0[3]);
+                const uint32_t steady = (sw >> (c & 31u)) & 1u;
                 if (bi >= idx && bi < end && !steady) firstHit = uint32_t(j);
             }
             const uint64_t hit = __ballot(firstHit < 4);
@@ -435,13 +440,13 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
         const int b = int((wsel >> ((idx & 3u) * 8)) & 0xFFu);
         const uint32_t cls = classMap[b];
+        const uint32_t cw = cls >> 5, cb = cls & 31u;
         const bool liveLane = lane < nThreads;
         // steady state: every live thread sits on a position whose only move on this byte class is its own
         // unconditional, tag-free self loop (inside a field such as [^ ]* that is almost every byte) -> the thread
         // list, its order and the captures are unchanged; skip the whole election/compaction/transfer machinery.
         {
-            const uint2 st = stable[myPos];
-            const uint32_t bit = cls < 32 ? (st.x >> cls) & 1u : (st.y >> (cls - 32)) & 1u;
+            const bool bit = nfaMaskBit(stable, maskShift, myPos, cw, cb);
             if (__all(!liveLane || bit)) {
                 prevCls = cls;
                 continue;
@@ -452,10 +457,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
 
         if constexpr (ATOMIC) {
             bool touchy = false;
-            if (liveLane) {
-                const uint2 tm = touchyMask[myPos];
-                touchy = nlin != 0 || (cls < 32 ? (tm.x >> cls) & 1u : (tm.y >> (cls - 32)) & 1u);
-            }
+            if (liveLane) touchy = nlin != 0 || nfaMaskBit(touchyMask, maskShift, myPos, cw, cb);
             if (__any(touchy)) {  // ordered commit pass, lane 0 (see nfaAtomicStep)
                 if (liveLane) {
                     actx.tPos[lane] = myPos;
@@ -474,12 +476,14 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                 }
                 nThreads = kept;
                 uint32_t src = lane;
-                uint64_t tags = 0;
+                uint32_t tags[TW] = {};
                 nlin = 0;
                 if (lane < nThreads) {
                     myPos = newPos[lane];
                     src = newSrc[lane];
-                    tags = uint64_t(newTagsLo[lane]) | (uint64_t(newTagsHi[lane]) << 32);
+                    const uint32_t* a = tb.aux + (newAux[lane] << tb.auxShift) + 1;
+#pragma unroll
+                    for (int k = 0; k < TW; ++k) tags[k] = a[k];
                     nlin = actx.newNlin[lane];
 #pragma unroll
                     for (int j = 0; j < kNfaLineage; ++j) lin[j] = actx.newLin[lane * kNfaLineageWork + j];
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                 for (int s = 0; s < NS; ++s) {
                     if (uint32_t(s) < nSlots) {
                         const int32_t v = __shfl(cap[s], int(src), 64);
-                        cap[s] = ((tags >> s) & 1) ? int32_t(i) : v;
+                        cap[s] = ((tags[s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : v;
                     }
                 }
                 waveLdsSync();
@@ -517,11 +521,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             bool pass = false;
             uint4 p{0, 0, 0, 0};
             if (cand < totalCand) {
-                p = nfaPath(paths, aux, q);
-                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
-                    const uint2 pm = posMask[p.x];
-                    pass = cls < 32 ? (pm.x >> cls) & 1u : (pm.y >> (cls - 32)) & 1u;
-                }
+                p = nfaPath(tb, q);
+                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, maskShift, p.x, cw, cb);
                 if (pass) atomicMin(&best[p.x], cand);  // per target, the candidate of highest priority
             }
             waveLdsSync();
@@ -536,8 +537,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                 const uint32_t slot = totalWins + uint32_t(__popcll(wins & ((uint64_t(1) << lane) - 1)));
                 newPos[slot] = p.x;
                 newSrc[slot] = src;
-                newTagsLo[slot] = p.z;
-                newTagsHi[slot] = p.w;
+                newAux[slot] = p.z;
             }
             totalWins += nWins;
         }
@@ -547,17 +547,19 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         waveLdsSync();
         nThreads = totalWins;
         uint32_t src = lane;
-        uint64_t tags = 0;
+        uint32_t tags[TW] = {};
         if (lane < nThreads) {
             myPos = newPos[lane];
             src = newSrc[lane];
-            tags = uint64_t(newTagsLo[lane]) | (uint64_t(newTagsHi[lane]) << 32);
+            const uint32_t* a = tb.aux + (newAux[lane] << tb.auxShift) + 1;
+#pragma unroll
+            for (int k = 0; k < TW; ++k) tags[k] = a[k];
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (uint32_t(s) < nSlots) {
                 const int32_t v = __shfl(cap[s], int(src), 64);
-                cap[s] = ((tags >> s) & 1) ? int32_t(i) : v;
+                cap[s] = ((tags[s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : v;
             }
         }
         waveLdsSync();  // newPos/newSrc are rewritten by the next byte's scatter
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
 
     // acceptance at end of input: first thread (priority order) with a MATCH path whose assertions hold
     bool accept = false;
-    uint64_t endTags = 0;
+    uint32_t endAux = 0;
     bool atomicEnd = false;
     if constexpr (ATOMIC) {
         // any membership left, or a MATCH path that crosses a group boundary: the ordered commit decides the winner
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                 const uint32_t win = newSrc[0];
                 if (lane == win) {
                     accept = true;
-                    endTags = uint64_t(newTagsLo[0]) | (uint64_t(newTagsHi[0]) << 32);
+                    endAux = newAux[0];
                 }
             }
         }
@@ -598,10 +600,10 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         const uint32_t ctrue = behindBits[prevCls] | aheadBits[edgeClass];
         const uint32_t fs = followStart[myPos], fe = followStart[myPos + 1];
         for (uint32_t q = fs; q < fe; ++q) {
-            const uint4 p = nfaPath(paths, aux, q);
+            const uint4 p = nfaPath(tb, q);
             if (p.x == NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
                 accept = true;
-                endTags = uint64_t(p.z) | (uint64_t(p.w) << 32);
+                endAux = p.z;
                 break;
             }
         }
@@ -611,11 +613,14 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t winner = matched ? uint32_t(__ffsll((long long)acc)) - 1 : 0;
     int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
     if (lane == winner) {
+        uint32_t endTags[TW];
+#pragma unroll
+        for (int k = 0; k < TW; ++k) endTags[k] = tb.aux[(endAux << tb.auxShift) + 1 + k];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (uint32_t(s) < 2 * nGroupsOut) {
                 int32_t v = -1;
-                if (matched && uint32_t(s) < nSlots) v = ((endTags >> s) & 1) ? int32_t(L) : cap[s];
+                if (matched && uint32_t(s) < nSlots) v = ((endTags[s >> 5] >> (s & 31)) & 1u) ? int32_t(L) : cap[s];
                 out[s] = v;
             }
         }

@@ -169,20 +169,25 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         }
         classMapOut[b] = uint8_t(it->second);
     }
-    if (rep.size() > 64) throw RegexError("nfa: more than 64 byte classes");
+    if (rep.size() > 128) throw RegexError("nfa: more than 128 byte classes (" + std::to_string(rep.size()) + ")");
     for (const auto& lst : nfa.follow)
         if (lst.size() > 64) throw RegexError("nfa: follow list longer than 64 paths");
-    std::vector<uint32_t> posMask(size_t(npos) * 2 + 2, 0);
+    // per-position class masks: 2 words per position, 4 when the pattern tells more than 64 byte classes apart
+    typedef unsigned __int128 ClassMask;
+    const size_t mw = rep.size() > 64 ? 4 : 2;
+    auto putMask = [mw](std::vector<uint32_t>& v, size_t p, ClassMask m) {
+        for (size_t k = 0; k < mw; ++k) v[p * mw + k] = uint32_t(m >> (32 * k));
+    };
+    std::vector<uint32_t> posMask(size_t(npos + 1) * mw, 0);
     for (int p = 0; p < npos; ++p) {
-        uint64_t m = 0;
+        ClassMask m = 0;
         for (size_t c = 0; c < rep.size(); ++c)
-            if (nfa.positions[size_t(p)].has(rep[c])) m |= uint64_t(1) << c;
-        posMask[size_t(p) * 2] = uint32_t(m);
-        posMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+            if (nfa.positions[size_t(p)].has(rep[c])) m |= ClassMask(1) << c;
+        putMask(posMask, size_t(p), m);
     }
-    std::vector<uint32_t> stableMask(size_t(npos + 1) * 2, 0);
+    std::vector<uint32_t> stableMask(size_t(npos + 1) * mw, 0);
     for (int p = 0; p < npos; ++p) {
-        uint64_t m = 0;
+        ClassMask m = 0;
         for (size_t c = 0; c < rep.size(); ++c) {
             int passing = 0;
             bool selfOnly = true;
@@ -191,19 +196,20 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
                 ++passing;
                 if (path.target != p || path.tags != 0 || path.cond != 0 || !path.atoms.empty()) selfOnly = false;
             }
-            if (passing == 1 && selfOnly) m |= uint64_t(1) << c;
+            if (passing == 1 && selfOnly) m |= ClassMask(1) << c;
         }
         // a path that LEAVES an atomic group acts even when its target cannot take the byte (leaving commits the group):
         // such a position is never in a steady state.  (Entering a group on a path that goes nowhere has no effect.)
         for (const auto& path : nfa.follow[size_t(p)])
             for (const auto& ev : path.atoms)
                 if (ev.code < 0) m = 0;
-        stableMask[size_t(p) * 2] = uint32_t(m);
-        stableMask[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+        putMask(stableMask, size_t(p), m);
     }
     if (npos >= 0xFFFF) throw RegexError("nfa: more than 65534 positions");
-    std::vector<uint32_t> followStart, paths, events, aux(4, 0);  // aux entry 0 = (no cond, no tags)
-    std::map<std::tuple<uint32_t, uint64_t>, uint32_t> auxIndex;
+    // aux entries: (cond, tags words...) padded to 4 words -- 8 when the pattern has more than 64 capture slots
+    const size_t aw = nfa.slotCount() > 64 ? 8 : 4;
+    std::vector<uint32_t> followStart, paths, events, aux(aw, 0);  // aux entry 0 = (no cond, no tags)
+    std::map<std::tuple<uint32_t, TagSet>, uint32_t> auxIndex;
     std::map<std::vector<uint32_t>, uint32_t> eventSeqs;
     std::vector<uint32_t> atomicPos(size_t(npos) / 32 + 2, 0);  // bit p: some path out of position p enters/leaves a group
     for (int p = 0; p <= npos; ++p) {
@@ -213,12 +219,10 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             if (path.cond || path.tags) {
                 auto it = auxIndex.find({path.cond, path.tags});
                 if (it == auxIndex.end()) {
-                    if (aux.size() / 4 >= 0xFFFF) throw RegexError("nfa: too many distinct tag sets");
-                    it = auxIndex.emplace(std::make_tuple(path.cond, path.tags), uint32_t(aux.size() / 4)).first;
+                    if (aux.size() / aw >= 0xFFFF) throw RegexError("nfa: too many distinct tag sets");
+                    it = auxIndex.emplace(std::make_tuple(path.cond, path.tags), uint32_t(aux.size() / aw)).first;
                     aux.push_back(path.cond);
-                    aux.push_back(uint32_t(path.tags));
-                    aux.push_back(uint32_t(path.tags >> 32));
-                    aux.push_back(0);
+                    for (size_t k = 0; k + 1 < aw; ++k) aux.push_back(k < 4 ? uint32_t(path.tags >> (32 * k)) : 0u);
                 }
                 a = it->second;
             }
@@ -254,6 +258,8 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_NPATHS] = uint32_t(paths.size() / 2);
     hdr[NF_CONDS_USED] = nfa.condsUsed;
     hdr[NF_SEARCH] = nfa.searchPrefix == 0 ? 1u : 0u;
+    hdr[NF_MASK_WORDS] = uint32_t(mw);
+    hdr[NF_AUX_WORDS] = uint32_t(aw);
     hdr[NF_OFF_CLASSMAP] = w.put(classMapOut);
     hdr[NF_OFF_POSMASK] = w.put(posMask);
     hdr[NF_OFF_FOLLOWSTART] = w.put(followStart);
@@ -274,22 +280,21 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     if (nfa.atomicCount) {
         // touchy[p] bit c: on byte class c a thread on position p needs the ordered commit pass -- some path out of p
         // leaves a group (acts whatever the byte is) or enters one on its way to a position that takes class c
-        std::vector<uint32_t> touchy(size_t(npos + 1) * 2, 0);
+        std::vector<uint32_t> touchy(size_t(npos + 1) * mw, 0);
         for (int p = 0; p <= npos; ++p) {
-            uint64_t m = 0;
+            ClassMask m = 0;
             for (const auto& path : nfa.follow[size_t(p)]) {
                 bool enters = false, leaves = false;
                 for (const auto& ev : path.atoms) {
                     enters |= ev.code > 0 && ev.code < kAssertEvent;
                     leaves |= ev.code < 0;
                 }
-                if (leaves) m = ~uint64_t(0);
+                if (leaves) m = ~ClassMask(0);
                 if (enters && path.target >= 0)
                     for (size_t c = 0; c < rep.size(); ++c)
-                        if (nfa.positions[size_t(path.target)].has(rep[c])) m |= uint64_t(1) << c;
+                        if (nfa.positions[size_t(path.target)].has(rep[c])) m |= ClassMask(1) << c;
             }
-            touchy[size_t(p) * 2] = uint32_t(m);
-            touchy[size_t(p) * 2 + 1] = uint32_t(m >> 32);
+            putMask(touchy, size_t(p), m);
         }
         hdr[NF_OFF_TOUCHY] = w.put(touchy);
         if (events.empty()) events.push_back(0);

@@ -30,7 +30,7 @@ struct Item {
 };
 struct Cand {
     int pos, src;
-    uint64_t tags;
+    TagSet tags;
     std::vector<LinEntry> lin;                        // lineage of the source item (updated by commitAtomic)
     const std::vector<FollowPath::Event>* events;     // the path's events (nullptr: pattern has no atomic group)
     bool targetOk;                                    // ends on a position that accepts the byte (or on MATCH at END)

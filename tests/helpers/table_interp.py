@@ -61,11 +61,13 @@ class NfaInterp:
         self.npos, self.nslots, self.ncls = int(blob[1]), int(blob[2]), int(blob[3])
         raw = blob.view(np.uint8)
         self.cmap = raw[int(blob[4]):int(blob[4]) + 256].copy()
-        pm = blob[int(blob[5]) // 4:int(blob[5]) // 4 + 2 * self.npos]
-        self.posmask = [int(pm[2 * p]) | (int(pm[2 * p + 1]) << 32) for p in range(self.npos)]
+        mw, aw = int(blob[20]), int(blob[21])                          # NF_MASK_WORDS, NF_AUX_WORDS
+        assert mw == (4 if self.ncls > 64 else 2) and aw == (8 if self.nslots > 64 else 4)
+        pm = blob[int(blob[5]) // 4:int(blob[5]) // 4 + mw * self.npos]
+        self.posmask = [sum(int(pm[mw * p + k]) << (32 * k) for k in range(mw)) for p in range(self.npos)]
         fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
         paths = blob[int(blob[7]) // 4:int(blob[7]) // 4 + 2 * int(blob[9])].reshape(-1, 2)   # NF_OFF_PATHS
-        aux = blob[int(blob[17]) // 4:].reshape(-1)                                            # NF_OFF_AUX (4 words each)
+        aux = blob[int(blob[17]) // 4:].reshape(-1)                                            # NF_OFF_AUX (aw words each)
         ncl = self.ncls
         self.behind = [int(x) for x in blob[int(blob[12]) // 4:int(blob[12]) // 4 + ncl + 1]]   # NF_OFF_BEHIND
         self.ahead = [int(x) for x in blob[int(blob[13]) // 4:int(blob[13]) // 4 + ncl + 1]]    # NF_OFF_AHEAD
@@ -75,8 +77,9 @@ class NfaInterp:
             for i in range(int(fs[p]), int(fs[p + 1])):
                 x = int(paths[i][0])
                 tgt, a = x & 0xFFFF, x >> 16
-                cond, lo, hi = [int(v) for v in aux[4 * a:4 * a + 3]]
-                lst.append((-1 if tgt == 0xFFFF else tgt, cond, lo | (hi << 32)))
+                cond = int(aux[aw * a])
+                tags = sum(int(aux[aw * a + 1 + k]) << (32 * k) for k in range(aw // 2))
+                lst.append((-1 if tgt == 0xFFFF else tgt, cond, tags))
             self.follow.append(lst)
 
     def fullmatch(self, s: bytes, max_threads=64, start=0):

@@ -1,0 +1,41 @@
+"""Values for the two example_config Grok patterns that need the wide table formats of the NFA engine: %{HTTPD_ERRORLOG}
+(68 byte classes: 4-word class masks) and %{HAPROXYHTTP} (52 named groups = 106 capture slots: 4 tag words per aux entry,
+NS=128 kernel).  Well-formed lines of each format plus seeded one-byte mutations of them."""
+import random
+
+WIDE_PATTERNS = ["HTTPD_ERRORLOG", "HAPROXYHTTP"]
+
+_LINES = [
+    b"[Mon Aug 23 15:25:35 2010] [error] [client 80.154.42.54] File does not exist: /var/www/phpmy-admin",
+    b"[Sat Apr 25 06:00:13.246302 2015] [core:error] [pid 1234:tid 140333] [client 10.1.1.1:5000] AH00126: Invalid URI in "
+    b"request GET /x",
+    b"[Sat Apr 25 06:00:13.246302 2015] [proxy:warn] [pid 99] (111)Connection refused: AH00957: HTTP: attempt to connect to "
+    b"127.0.0.1:8080 (localhost) failed",
+    b"[Mon Aug 23 15:25:35 2010] [notice] Apache/2.2.15 (Unix) configured -- resuming normal operations",
+    b"Feb  6 12:14:14 localhost haproxy[14389]: 10.0.1.2:33317 [06/Feb/2009:12:14:14.655] http-in static/srv1 10/0/30/69/109 "
+    b"200 2750 - - ---- 1/1/1/1/0 0/0 {1wt.eu|10.9.8.7|en|http://r.example/|curl/7.1} {text/html|gzip|no-cache|Mon} "
+    b"\"GET /index.html HTTP/1.1\"",
+    b"Dec  9 13:01:26 lb1 haproxy[28029]: 127.0.0.1:39759 [09/Dec/2013:12:59:46.633] loadbalancer default/instance8 "
+    b"0/51536/1/48082/99627 200 83285 - - ---- 87/87/87/1/0 0/67 \"GET /path/to/image HTTP/1.1\"",
+    b"2013-12-09T13:01:26+01:00 lb1 haproxy[28029]: 127.0.0.1:39759 [09/Dec/2013:12:59:46.633] lb default/i8 "
+    b"0/5/1/4/9 503 0 - - SC-- 8/8/8/1/0 0/6 \"<BADREQ>\"",
+    b"nothing to see here",
+]
+
+
+def wide_values(mutations=6, seed=3):
+    r = random.Random(seed)
+    out = list(_LINES)
+    for line in _LINES:
+        for _ in range(mutations):
+            b = bytearray(line)
+            k = r.randrange(len(b))
+            op = r.random()
+            if op < 0.4:
+                b[k] = r.choice(b" x[]:9\"/|")
+            elif op < 0.7:
+                del b[k]
+            else:
+                b.insert(k, r.choice(b" x[]:9|"))
+            out.append(bytes(b))
+    return out

@@ -161,3 +161,24 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
         assert f == want, v
         hits += p >= 0
     assert hits >= 3
+
+
+@pytest.mark.parametrize("name", ["HTTPD_ERRORLOG", "HAPROXYHTTP"])
+def test_wide_table_patterns_against_the_oracle(torch_dev, golden_dir, name):
+    """> 64 byte classes (4-word class masks) and > 64 capture slots (4 tag words, NS=128 kernel): tests/helpers/wide_patterns.py"""
+    from tests.helpers.wide_patterns import wide_values
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    match = ["%{" + name + "}"]
+    g = Grok(Match=match, CustomPatterns=cfg3["custom_patterns"])
+    assert g.engine(0) == B.LC_ENGINE_NFA
+    o = GrokOracle(match, custom_patterns=cfg3["custom_patterns"])
+    values = wide_values(mutations=12)
+    pattern, fields = g.match_host(values)
+    matched = 0
+    for v, p, f in zip(values, pattern, fields):
+        res, want = o.process_value(v)
+        assert p != -2, v
+        assert [(k, bytes(x)) for k, x in f] == [(k, bytes(x)) for k, x in want], (name, v)
+        matched += bool(want)
+    assert matched >= 8

@@ -206,6 +206,27 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
     assert checked >= 2000 and screens >= 15 and rejected > 300, (checked, screens, rejected)
 
 
+@pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106)])
+def test_wide_table_formats_on_the_compiled_tables(golden_dir, name, classes, slots):
+    """65..128 byte classes -> 4-word class masks; 65..128 capture slots -> 4 tag words per aux entry (device_tables.h
+    NF_MASK_WORDS / NF_AUX_WORDS).  The device algorithm replayed on those tables must give the oracle's fields."""
+    from tests.helpers.wide_patterns import wide_values
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    match = ["%{" + name + "}"]
+    g = Grok(Match=match, CustomPatterns=cfg3["custom_patterns"])
+    o = GrokOracle(match, custom_patterns=cfg3["custom_patterns"])
+    t = TableGrok(g)
+    it = t.interps[0]
+    assert (it.ncls, it.nslots) == (classes, slots)
+    matched = 0
+    for v in wide_values():
+        _, fields = o.process_value(v)
+        assert t.process_value(v) == [[k, x] for k, x in fields], (name, v)
+        matched += bool(fields)
+    assert matched >= 6
+
+
 def test_no_cpu_path():
     if B.load().lc_device_count() > 0:
         pytest.skip("a HIP device is present")
