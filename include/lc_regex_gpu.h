@@ -132,6 +132,12 @@ lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t pattern_len, uin
  * match; the Grok matcher uses it to skip the automaton for most (value, Match pattern) pairs. */
 const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t* len);
 
+/* Groups written "(?=(S*))" -- a look-ahead that always holds and only captures (Grok: "(?=%{GREEDYDATA:message})").  The
+ * tables stamp where such a group begins; its end is the end of the run of S bytes that starts there, which the match
+ * entry points fill in after the automaton (a reader of lc_regex_table has to do the same).  Returns how many such groups
+ * the pattern has; writes up to `cap` group indices (as in the caps rows) and 32-byte sets (bit b of byte b/8 = byte b). */
+int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, int cap);
+
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int lc_device_count(void);
 

@@ -75,6 +75,8 @@ def load(path=None):
     L.lc_regex_compile_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
     L.lc_regex_required_literal.restype = vp
     L.lc_regex_required_literal.argtypes = [vp, ctypes.POINTER(sz)]
+    L.lc_regex_run_captures.restype = i32
+    L.lc_regex_run_captures.argtypes = [vp, vp, vp, i32]
     L.lc_regex_match_device_from.restype = i32
     L.lc_regex_match_device_from.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, u32, vp, vp, vp]
     L.lc_split_scratch_bytes.restype = sz
@@ -196,6 +198,16 @@ class GpuRegex:
         n = ctypes.c_size_t()
         p = self._L.lc_regex_required_literal(self._h, ctypes.byref(n))
         return ctypes.string_at(p, n.value) if n.value else b""
+
+    def run_captures(self):
+        """[(group index, frozenset of bytes)] of the groups written "(?=(S*))": the tables stamp their begin only"""
+        n = self._L.lc_regex_run_captures(self._h, None, None, 0)
+        if n == 0:
+            return []
+        groups = (ctypes.c_int32 * n)()
+        sets = (ctypes.c_uint8 * (32 * n))()
+        self._L.lc_regex_run_captures(self._h, groups, sets, n)
+        return [(int(groups[i]), frozenset(b for b in range(256) if (sets[32 * i + b // 8] >> (b % 8)) & 1)) for i in range(n)]
 
     def match_device_from(self, d_data, d_off, d_len, n, d_caps, d_status, d_lines=None, d_nlines=None, d_from=None,
                           ngroups=None, sep_bytes=0, stream=None, engine=LC_ENGINE_AUTO):

@@ -51,6 +51,7 @@ public:
     std::vector<ByteSet> positions;
     std::vector<LookAssert> asserts;
     int atomicCount = 0;
+    std::vector<std::pair<int, ByteSet>> runGroups;
 
     int assertIndex(const LookAssert& a) {
         for (size_t i = 0; i < asserts.size(); ++i)
@@ -95,7 +96,17 @@ public:
             case Node::Group:
                 if (n.capture) emit(Inst::Save, 2 * (n.capture - 1));
                 gen(*n.kids[0]);
-                if (n.capture) emit(Inst::Save, 2 * (n.capture - 1) + 1);
+                if (n.runCapture) {  // end slot: filled in after the match from the begin slot (regex_ast.hpp)
+                    bool known = false;
+                    for (auto& rg : runGroups) {
+                        if (rg.first != n.capture - 1) continue;
+                        if (!(rg.second == n.set)) throw RegexError("unsupported: one group captures runs of two different sets");
+                        known = true;
+                    }
+                    if (!known) runGroups.emplace_back(n.capture - 1, n.set);
+                } else if (n.capture) {
+                    emit(Inst::Save, 2 * (n.capture - 1) + 1);
+                }
                 break;
             case Node::Assert: emit(Inst::Assert, assertIndex(n.look)); break;
             case Node::Atomic: {
@@ -218,6 +229,7 @@ FollowNfa buildFollowNfa(const ParsedRegex& re) {
     nfa.positions = b.positions;
     nfa.asserts = b.asserts;
     nfa.atomicCount = b.atomicCount;
+    nfa.runGroups = b.runGroups;
     for (size_t i = 0; i < b.asserts.size(); ++i)
         if (b.asserts[i].behind) nfa.behindMask |= 1u << i;
     const int npos = int(b.positions.size());

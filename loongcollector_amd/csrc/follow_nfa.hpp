@@ -55,6 +55,9 @@ struct FollowNfa {
     // middle of a line (the next match of an iterate-all-matches caller): that is the state "the prefix position has
     // just consumed the byte before the resume point".
     int searchPrefix = -1, searchSuffix = -1;
+    // groups written "(?=(S*))" (regex_ast.hpp Node::runCapture): 0-based group index and S.  The automata leave their
+    // end slot unset; whoever reports captures sets end = begin + length of the run of S bytes at begin.
+    std::vector<std::pair<int, ByteSet>> runGroups;
     int slotCount() const { return 2 * groupCount; }
     int startIndex() const { return int(positions.size()); }
 

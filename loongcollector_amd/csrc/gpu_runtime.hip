@@ -198,18 +198,63 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     }
 }
 
+// Groups written "(?=(S*))" (regex_ast.hpp Node::runCapture, Grok's "(?=%{GREEDYDATA:message})"): the automata stamp only
+// where the group begins; it ends where the run of S bytes that starts there ends.  One lane per matched line walks that
+// run -- a few of the line's bytes once more, through L2 right after the match kernel has read them.
+struct RunSet {
+    uint32_t w[8];  // 256-bit byte set
+};
+__global__ __launch_bounds__(256) void run_capture_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                          const uint32_t* __restrict__ nLinesPtr,
+                                                          const uint32_t* __restrict__ order, uint32_t group, RunSet set,
+                                                          uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                                          const uint8_t* __restrict__ status) {
+    if (nLinesPtr) {
+        const uint32_t dyn = *nLinesPtr;
+        nLines = dyn < nLines ? dyn : nLines;
+    }
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nLines) return;
+    const uint32_t line = order ? order[slot] : slot;
+    if (status[line] != LC_MATCH) return;
+    int32_t* c = caps + size_t(line) * 2 * nGroupsOut + 2 * group;
+    if (c[0] < 0) return;  // the group did not take part in the match
+    const uint32_t o = off[line];
+    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    uint32_t e = uint32_t(c[0]);
+    while (e < L) {
+        const uint32_t b = data[size_t(o) + e];
+        if (!((set.w[b >> 5] >> (b & 31u)) & 1u)) break;
+        ++e;
+    }
+    c[1] = int32_t(e);
+}
+
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr) {
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+    int rc;
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
             return LC_ERR_UNSUPPORTED;
         }
-        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        rc = launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    } else {
+        rc = launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
-    return launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    if (rc != LC_OK) return rc;
+    for (const auto& rg : re->nfa.runGroups) {
+        if (uint32_t(rg.first) >= ngroups) continue;  // the caller did not ask for this group
+        RunSet set;
+        for (int k = 0; k < 8; ++k) set.w[k] = uint32_t(rg.second.w[size_t(k) / 2] >> (32 * (k & 1)));
+        hipLaunchKernelGGL(run_capture_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_data, d_off, d_len, sep, n, d_n,
+                           d_order, uint32_t(rg.first), set, ngroups, d_caps, d_status);
+        HIP_TRY(hipGetLastError());
+    }
+    return LC_OK;
 }
 
 extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,

@@ -84,6 +84,11 @@ struct Node {
     // the parser drops it when what follows already implies it, and refuses the pattern otherwise (regex_parse.cpp).
     std::vector<ByteSet> aheadSeq;
     bool aheadNegative = false;
+    // Group written "(?=(S*))" -- a look-ahead that always holds and whose only effect is the capture: the group begins
+    // at the current offset and runs over the bytes of `set` that follow (Grok's "(?=%{GREEDYDATA:message})").  The
+    // automata stamp the BEGIN slot only; the end is a function of the begin and is filled in after the match
+    // (gpu_runtime.hip run_capture_kernel).  kids[0] is an Empty node.
+    bool runCapture = false;
 };
 
 struct ParsedRegex {

@@ -642,6 +642,19 @@ extern "C" const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t
     return reinterpret_cast<const uint8_t*>(re->requiredLiteral.data());
 }
 
+extern "C" int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, int cap) {
+    if (!re) return 0;
+    int n = 0;
+    for (const auto& rg : re->nfa.runGroups) {
+        if (n < cap && groups && sets) {
+            groups[n] = rg.first;
+            for (int b = 0; b < 32; ++b) sets[n * 32 + b] = uint8_t(rg.second.w[size_t(b) / 8] >> (8 * (b & 7)));
+        }
+        ++n;
+    }
+    return n;
+}
+
 extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes) {
     if (!re || !data || !bytes) return LC_ERR_ARG;
     auto view = [&](const void* p, size_t n) {

@@ -381,6 +381,24 @@ private:
         mSyn = saved;
         const Node* n = body.get();
         while ((n->kind == Node::Group && n->capture == 0) && n->kids.size() == 1) n = n->kids[0].get();
+        if (!behind && !negative) {  // (?=S*) holds everywhere; (?=(S*)) holds everywhere and captures the run of S
+            const Node* g = (n->kind == Node::Group && n->capture && n->kids.size() == 1) ? n : nullptr;
+            const Node* r = g ? g->kids[0].get() : n;
+            while ((r->kind == Node::Group && r->capture == 0) && r->kids.size() == 1) r = r->kids[0].get();
+            if (r->kind == Node::Repeat && r->min == 0 && r->max < 0 && r->greedy) {
+                const Node* e = r->kids[0].get();
+                while ((e->kind == Node::Group && e->capture == 0) && e->kids.size() == 1) e = e->kids[0].get();
+                if (e->kind == Node::Set) {
+                    if (!g) return mk(Node::Empty);
+                    auto run = mk(Node::Group);
+                    run->capture = g->capture;
+                    run->runCapture = true;
+                    run->set = e->set;
+                    run->kids.push_back(mk(Node::Empty));
+                    return run;
+                }
+            }
+        }
         if (!behind && n->kind == Node::Cat) {  // (?=AB..) / (?!AB..): decided in sequence() from what follows
             auto a = mk(Node::Assert);
             for (const auto& k : n->kids) {

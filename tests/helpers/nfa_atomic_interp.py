@@ -12,7 +12,7 @@ Threads carry their unsettled atomic-segment memberships ("lineage": [g, seg, ex
 import numpy as np
 
 from loongcollector_amd import binding as B
-from tests.helpers.table_interp import NfaInterp
+from tests.helpers.table_interp import NfaInterp, _with_run_captures
 
 ASSERT_EVENT = 20000
 MAX_LINEAGE = 6      # nfa_kernel.hpp kNfaLineage
@@ -124,6 +124,7 @@ class AtomicNfaInterp(NfaInterp):
                     break
         return kept
 
+    @_with_run_captures
     def fullmatch(self, s, max_threads=MAX_THREADS, start=0):
         if not self.atomic:
             return super().fullmatch(s, max_threads=max_threads, start=start)

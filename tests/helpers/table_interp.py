@@ -9,10 +9,28 @@ import numpy as np
 from loongcollector_amd import binding as B
 
 
+def _with_run_captures(fullmatch):
+    """groups written "(?=(S*))": the tables stamp the begin slot only; the end is where the run of S bytes that starts
+    there ends (gpu_runtime.hip run_capture_kernel does this after the match kernel)"""
+    def wrapped(self, s, *args, **kw):
+        caps = fullmatch(self, s, *args, **kw)
+        if isinstance(caps, list):
+            for g, members in self.runs:
+                b = caps[2 * g]
+                if b >= 0:
+                    e = b
+                    while e < len(s) and s[e] in members:
+                        e += 1
+                    caps[2 * g + 1] = e
+        return caps
+    return wrapped
+
+
 class TdfaInterp:
     def __init__(self, rx):
         hdr = rx.table(B.LC_TABLE_TDFA_HEADER, np.uint32)
         assert hdr is not None, "pattern has no TDFA"
+        self.runs = rx.run_captures()
         self.nstates, self.ncls, self.nregs, self.nslots, self.start = [int(x) for x in hdr[:5]]
         self.cmap = rx.table(B.LC_TABLE_CLASSMAP, np.uint8)
         self.trans = rx.table(B.LC_TABLE_TDFA_TRANS, np.uint32)
@@ -22,6 +40,7 @@ class TdfaInterp:
         self.final_map = rx.table(B.LC_TABLE_TDFA_FINALMAP, np.uint8)
         self.start_after = rx.table(B.LC_TABLE_TDFA_STARTAFTER, np.uint32)  # None unless a search pattern
 
+    @_with_run_captures
     def fullmatch(self, s: bytes, start=0):
         """-> flat caps [b1,e1,b2,e2,...] for groups 1..G, or None.  start > 0 (search patterns only): resume the search
         at that offset, seeing the byte before it (what the kernels do for lc_regex_match_device_from)."""
@@ -58,6 +77,7 @@ class NfaInterp:
     def __init__(self, rx):
         blob = rx.table(B.LC_TABLE_NFA_BLOB, np.uint32)
         assert blob is not None
+        self.runs = rx.run_captures()
         self.npos, self.nslots, self.ncls = int(blob[1]), int(blob[2]), int(blob[3])
         raw = blob.view(np.uint8)
         self.cmap = raw[int(blob[4]):int(blob[4]) + 256].copy()
@@ -82,6 +102,7 @@ class NfaInterp:
                 lst.append((-1 if tgt == 0xFFFF else tgt, cond, tags))
             self.follow.append(lst)
 
+    @_with_run_captures
     def fullmatch(self, s: bytes, max_threads=64, start=0):
         """start > 0 (search patterns only): resume at that offset -- one thread on the wrapper's prefix position
         (position 0), having just consumed the byte before the resume point."""

@@ -39,3 +39,20 @@ def wide_values(mutations=6, seed=3):
                 b.insert(k, r.choice(b" x[]:9|"))
             out.append(bytes(b))
     return out
+
+
+# "(?=(S*))" run captures (regex_ast.hpp Node::runCapture): patterns and subjects shared by the CPU and GPU tests
+RUN_CAPTURE_PATTERNS = [rb"(\w+) (?=(.*))(\w+)\((\d+)\)", rb"a(?=([0-9]*))\d*(x?)", rb"(?=.*)abc", rb"(?:(?=([a-z]*))[a-z]{2},)+",
+                        rb"(?=(?:([^\n]*)))a.*", rb"(?=(?P<rest>[^;]*))(?:(\w+)=(\d+);?)+"]
+RUN_CAPTURE_SUBJECTS = [b"pam su(12)", b"pam su(12", b"a123x", b"a12", b"abc", b"ab,cd,", b"ab,c,", b"pam su\nx(1)", b"a\nb", b"",
+                        b"k=1;kk=22;x", b"k=1;kk=22", b"a" + b"7" * 300 + b"x"]
+
+_PAM = [
+    b"Jul 11 13:30:01 ip-10-0-0-1 CRON[26176]: pam_unix(cron:session): session opened for user root by (uid=0)",
+    b"Jul 11 13:30:01 host sshd[1]: pam_unix(sshd:session): session closed for user alice",
+    b"Jul 11 13:30:01 host sshd[1]: pam_unix(sshd:session): session closed for user alice\nsecond line",
+    b"<13>Jul  1 03:00:00 host su: pam_unix(su:session): session opened for user bob by alice(uid=1000)",
+    b"Jul 11 13:30:01 host su: pam_unix(su:session) session opened for user",
+]
+WIDE_PATTERNS.append("SYSLOGPAMSESSION")
+_LINES.extend(_PAM)

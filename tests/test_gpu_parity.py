@@ -469,3 +469,23 @@ def test_random_atomic_patterns_on_both_kernels(torch_dev):
                     got = None if status[i] == B.LC_NOMATCH else list(caps[i])
                     assert got == want, (p, s, flags, eng, got, want)
     assert checked > 5000 and overflow < checked // 50
+
+
+def test_run_captures_on_both_kernels(torch_dev):
+    """"(?=(S*))" groups: begin stamped by the automaton, end filled in by run_capture_kernel (gpu_runtime.hip)"""
+    from tests.helpers.wide_patterns import RUN_CAPTURE_PATTERNS, RUN_CAPTURE_SUBJECTS
+    data, off, length = pack(RUN_CAPTURE_SUBJECTS)
+    checked = 0
+    for pat in RUN_CAPTURE_PATTERNS:
+        o = OracleRegex(pat)
+        for eng in (B.LC_ENGINE_TDFA, B.LC_ENGINE_NFA):
+            rx = B.GpuRegex(pat, engine=eng)
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+            for i, s in enumerate(RUN_CAPTURE_SUBJECTS):
+                want = o.fullmatch(s)
+                checked += 1
+                if want is None:
+                    assert status[i] == B.LC_NOMATCH and (caps[i] == -1).all(), (pat, s)
+                else:
+                    assert status[i] == B.LC_MATCH and list(caps[i]) == [v for be in want for v in be][2:], (pat, s)
+    assert checked == 2 * len(RUN_CAPTURE_PATTERNS) * len(RUN_CAPTURE_SUBJECTS)

@@ -206,7 +206,8 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
     assert checked >= 2000 and screens >= 15 and rejected > 300, (checked, screens, rejected)
 
 
-@pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106)])
+@pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106),
+                                                  ("SYSLOGPAMSESSION", None, None)])
 def test_wide_table_formats_on_the_compiled_tables(golden_dir, name, classes, slots):
     """65..128 byte classes -> 4-word class masks; 65..128 capture slots -> 4 tag words per aux entry (device_tables.h
     NF_MASK_WORDS / NF_AUX_WORDS).  The device algorithm replayed on those tables must give the oracle's fields."""
@@ -218,13 +219,16 @@ def test_wide_table_formats_on_the_compiled_tables(golden_dir, name, classes, sl
     o = GrokOracle(match, custom_patterns=cfg3["custom_patterns"])
     t = TableGrok(g)
     it = t.interps[0]
-    assert (it.ncls, it.nslots) == (classes, slots)
+    if classes:
+        assert (it.ncls, it.nslots) == (classes, slots)
+    else:
+        assert len(it.runs) == 1      # "(?=%{GREEDYDATA:message})": the tables stamp the begin only
     matched = 0
     for v in wide_values():
         _, fields = o.process_value(v)
         assert t.process_value(v) == [[k, x] for k, x in fields], (name, v)
         matched += bool(fields)
-    assert matched >= 6
+    assert matched >= 4
 
 
 def test_no_cpu_path():

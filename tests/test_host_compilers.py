@@ -199,3 +199,28 @@ def test_prefix_mode_is_regex_search_match_continuous(golden_dir):
     assert it.fullmatch(b" 2024-01-04 14:36:10 leading space") is None
     with pytest.raises(B.RegexUnsupportedError):
         B.GpuRegex(b"a", syntax_flags=B.LC_SYNTAX_PREFIX | B.LC_SYNTAX_SEARCH)
+
+
+def test_run_captures_on_both_table_formats():
+    """"(?=(S*))": a look-ahead that always holds and only captures (regex_ast.hpp Node::runCapture).  The tables stamp the
+    begin slot; the reader fills in the end (lc_regex_run_captures).  Both table formats against the oracle, which runs
+    the look-ahead for real."""
+    from oracle.oracle import OracleRegex
+    from tests.helpers.table_interp import NfaInterp, TdfaInterp
+    from tests.helpers.wide_patterns import RUN_CAPTURE_PATTERNS, RUN_CAPTURE_SUBJECTS
+    runs = 0
+    for pat in RUN_CAPTURE_PATTERNS:
+        o = OracleRegex(pat)
+        for eng, interp in ((B.LC_ENGINE_TDFA, TdfaInterp), (B.LC_ENGINE_NFA, NfaInterp)):
+            rx = B.GpuRegex(pat, engine=eng)
+            runs += len(rx.run_captures())
+            it = interp(rx)
+            for s in RUN_CAPTURE_SUBJECTS:
+                want = o.fullmatch(s)
+                want = None if want is None else [v for be in want for v in be][2:]
+                assert it.fullmatch(s) == want, (pat, s)
+    assert runs == 2 * (len(RUN_CAPTURE_PATTERNS) - 1)     # "(?=.*)abc" has nothing to capture
+    # anything else inside a look-ahead is still refused
+    for pat in (rb"(?=(a+))a*", rb"(?=(.*?))a", rb"(?!(.*))a", rb"(?=(a*)b)a*b"):
+        with pytest.raises(B.RegexUnsupportedError):
+            B.GpuRegex(pat)
