@@ -90,7 +90,8 @@ enum {
     NF_OFF_TOUCHY = 19,   // atomic patterns: u32[nPos+1][maskWords], bit c = on byte class c a thread on this position needs
                           // the ordered commit pass (a path leaves a group, or enters one towards a position that takes class c)
     NF_MASK_WORDS = 20,   // words per class mask: 2, or 4 for patterns with 65..128 byte classes
-    NF_AUX_WORDS = 21,    // words per aux entry: 4 (cond + 2 tag words), or 8 (cond + 4 tag words) for 65..128 capture slots
+    NF_AUX_WORDS = 21,    // words per aux entry: 4 (cond + 2 tag words); 8 (cond + 4) for 65..128 capture slots; 16 (cond + 10) for
+                          // 129..320
     NF_HEADER_WORDS = 24
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

@@ -169,7 +169,7 @@ public:
         steps = 0;
         std::vector<FollowPath::Event> atoms;
         exitVisits = 0;
-        walk(pc, 0, 0, atoms, 0);
+        walk(pc, TagSet(), 0, atoms, 0);
         return out;
     }
 
@@ -197,7 +197,7 @@ private:
                 case Inst::Char: add(in.x, tags, cond, atoms); atoms.resize(mark); return;
                 case Inst::Match: add(kMatchTarget, tags, cond, atoms); atoms.resize(mark); return;
                 case Inst::Jump: pc = in.x; break;
-                case Inst::Save: tags |= TagSet(1) << in.x; ++pc; break;
+                case Inst::Save: tags.set(in.x); ++pc; break;
                 case Inst::Assert:
                     cond |= 1u << in.x;
                     if (recordEvents) atoms.push_back({kAssertEvent + in.x, 0});

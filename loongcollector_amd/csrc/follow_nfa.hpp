@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cstdint>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -19,8 +20,17 @@
 
 namespace lcregex {
 
-constexpr int kMaxGpuGroups = 64;   // capture slots are carried in a 128-bit tag mask
-typedef unsigned __int128 TagSet;   // bit s: capture slot s
+constexpr int kMaxGpuGroups = 160;  // 320 capture slots (the widest NFA kernel instance carries 320 offsets per thread)
+struct TagSet {                     // bit s: capture slot s
+    std::array<uint64_t, 5> w{{0, 0, 0, 0, 0}};
+    void set(int s) { w[size_t(s) >> 6] |= uint64_t(1) << (s & 63); }
+    bool test(int s) const { return (w[size_t(s) >> 6] >> (s & 63)) & 1; }
+    bool any() const { return (w[0] | w[1] | w[2] | w[3] | w[4]) != 0; }
+    uint32_t word32(size_t k) const { return k < 10 ? uint32_t(w[k >> 1] >> (32 * (k & 1))) : 0u; }
+    bool operator==(const TagSet& o) const { return w == o.w; }
+    bool operator!=(const TagSet& o) const { return !(w == o.w); }
+    bool operator<(const TagSet& o) const { return w < o.w; }
+};
 constexpr int kMaxAsserts = 32;     // distinct one-byte look assertions per pattern (cond mask is 32 bits)
 constexpr int kMatchTarget = -1;
 constexpr int kAssertEvent = 20000;

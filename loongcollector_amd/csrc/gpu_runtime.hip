@@ -190,11 +190,19 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         if (atomic) return launchNfaSlots<64, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (global) return launchNfaSlots<64, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         return launchNfaSlots<64, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }    {   // 65..128 slots (33..64 groups): 4 tag words per aux entry
+    }    if (slots <= 128) {  // 33..64 groups: 4 tag words per aux entry
         if (atomic && global) return launchNfaSlots<128, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (atomic) return launchNfaSlots<128, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (global) return launchNfaSlots<128, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         return launchNfaSlots<128, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
+
+    {   // up to 320 slots (160 groups): 10 tag words per aux entry; the offsets of a thread no longer fit the 256
+        // architected VGPRs of a lane, the rest lives in accumulation registers
+        if (atomic && global) return launchNfaSlots<320, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (atomic) return launchNfaSlots<320, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (global) return launchNfaSlots<320, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        return launchNfaSlots<320, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
 }
 
@@ -681,13 +689,15 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             flip = in == outs[0] ? 1 : 0;
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
         }
+        // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
+        const uint32_t capsRow = 2 * (gp.columns + 1);
         while (nIn) {
-            int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, row / 2, caps,
-                                     status, st);
+            int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, capsRow / 2,
+                                     caps, status, st);
             if (rc != LC_OK) return rc;
             uint32_t* out = outs[flip];
             hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in,
-                               nIn, status, caps, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap,
+                               nIn, status, caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap,
                                out, counters);
             HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

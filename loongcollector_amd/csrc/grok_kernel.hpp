@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kGrokBlock) void grok_status_filter_kernel(const ui
 // counters[0] = values in `out`, counters[1] = rows wanted in `extra`.
 __global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
     const uint32_t* __restrict__ in, uint32_t nIn, const uint8_t* __restrict__ status, const int32_t* __restrict__ caps,
-    uint32_t row, uint32_t columns, const uint32_t* __restrict__ len, uint32_t* __restrict__ from,
+    uint32_t capsRow, uint32_t row, uint32_t columns, const uint32_t* __restrict__ len, uint32_t* __restrict__ from,
     uint32_t* __restrict__ nmatch, int32_t* __restrict__ pattern, int32_t* __restrict__ first,
     int32_t* __restrict__ extra, uint32_t extraCap, uint32_t* __restrict__ out, uint32_t* __restrict__ counters) {
     const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
         return;
     }
     if (st != LC_MATCH) return;
-    const int32_t* c = caps + size_t(line) * row;
+    const int32_t* c = caps + size_t(line) * capsRow;  // this pattern's own row: whole match + its columns
     bool contributes = false;
     for (uint32_t g = 1; g <= columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
     if (contributes) {
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
         }
         if (dst) {
             for (uint32_t s = 0; s < 2 * (columns + 1); ++s) dst[s] = c[s];
-            for (uint32_t s = 2 * (columns + 1); s < row; ++s) dst[s] = -1;
+            if (seq)  // rows of `first` were preset to -1 by the caller; rows of `extra` are not
+                for (uint32_t s = 2 * (columns + 1); s < row; ++s) dst[s] = -1;
         }
     }
     const uint32_t b = uint32_t(c[0]), e = uint32_t(c[1]);

@@ -321,12 +321,13 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_BEHIND]);
     const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
     const uint32_t edgeClass = hdr[NF_NCLASSES];  // table index standing for start / end of input
-    constexpr int TW = NS > 64 ? 4 : 2;  // tag words per aux entry (regex_handle.cpp packNfaBlob: 4 iff nSlots > 64)
+    // tag words per aux entry (regex_handle.cpp packNfaBlob: entries of 4 / 8 / 16 words for up to 64 / 128 / 320 slots)
+    constexpr int TW = NS > 128 ? 10 : (NS > 64 ? 4 : 2);
     NfaTables tb;
     tb.followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
     tb.paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
     tb.aux = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AUX]);
-    tb.auxShift = TW == 4 ? 3 : 2;
+    tb.auxShift = TW == 10 ? 4 : (TW == 4 ? 3 : 2);
     tb.posMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_POSMASK]);
     tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
     const uint32_t maskShift = tb.maskShift;

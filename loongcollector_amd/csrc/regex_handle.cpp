@@ -194,7 +194,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
             for (const auto& path : nfa.follow[size_t(p)]) {
                 if (path.target < 0 || !nfa.positions[size_t(path.target)].has(rep[c])) continue;
                 ++passing;
-                if (path.target != p || path.tags != 0 || path.cond != 0 || !path.atoms.empty()) selfOnly = false;
+                if (path.target != p || path.tags.any() || path.cond != 0 || !path.atoms.empty()) selfOnly = false;
             }
             if (passing == 1 && selfOnly) m |= ClassMask(1) << c;
         }
@@ -206,8 +206,8 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         putMask(stableMask, size_t(p), m);
     }
     if (npos >= 0xFFFF) throw RegexError("nfa: more than 65534 positions");
-    // aux entries: (cond, tags words...) padded to 4 words -- 8 when the pattern has more than 64 capture slots
-    const size_t aw = nfa.slotCount() > 64 ? 8 : 4;
+    // aux entries: (cond, tags words...) padded to 4 words -- 8 / 16 when the pattern has more than 64 / 128 capture slots
+    const size_t aw = nfa.slotCount() > 128 ? 16 : (nfa.slotCount() > 64 ? 8 : 4);
     std::vector<uint32_t> followStart, paths, events, aux(aw, 0);  // aux entry 0 = (no cond, no tags)
     std::map<std::tuple<uint32_t, TagSet>, uint32_t> auxIndex;
     std::map<std::vector<uint32_t>, uint32_t> eventSeqs;
@@ -216,13 +216,13 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         followStart.push_back(uint32_t(paths.size() / 2));
         for (const auto& path : nfa.follow[size_t(p)]) {
             uint32_t a = 0;
-            if (path.cond || path.tags) {
+            if (path.cond || path.tags.any()) {
                 auto it = auxIndex.find({path.cond, path.tags});
                 if (it == auxIndex.end()) {
                     if (aux.size() / aw >= 0xFFFF) throw RegexError("nfa: too many distinct tag sets");
                     it = auxIndex.emplace(std::make_tuple(path.cond, path.tags), uint32_t(aux.size() / aw)).first;
                     aux.push_back(path.cond);
-                    for (size_t k = 0; k + 1 < aw; ++k) aux.push_back(k < 4 ? uint32_t(path.tags >> (32 * k)) : 0u);
+                    for (size_t k = 0; k + 1 < aw; ++k) aux.push_back(path.tags.word32(k));
                 }
                 a = it->second;
             }

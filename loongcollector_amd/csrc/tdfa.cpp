@@ -393,7 +393,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
                 }
                 it.regs.resize(size_t(nslots));
                 for (int s = 0; s < nslots; ++s) {
-                    int raw = ((n.tags >> s) & 1) ? kFreshBase + s : S.items[size_t(n.src)].regs[size_t(s)];
+                    int raw = n.tags.test(s) ? kFreshBase + s : S.items[size_t(n.src)].regs[size_t(s)];
                     if (raw < 0) {
                         it.regs[size_t(s)] = -1;
                         continue;
@@ -481,7 +481,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             const Cand& wn = winners.front();  // highest-priority thread that is in MATCH when the input is exhausted
             std::vector<uint8_t> fm(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
             for (int sl = 0; sl < nslots; ++sl) {
-                if ((wn.tags >> sl) & 1) fm[size_t(sl)] = kRegPos;
+                if (wn.tags.test(sl)) fm[size_t(sl)] = kRegPos;
                 else if (S.items[size_t(wn.src)].regs[size_t(sl)] >= 0)
                     fm[size_t(sl)] = uint8_t(S.items[size_t(wn.src)].regs[size_t(sl)]);
             }

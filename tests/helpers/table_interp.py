@@ -82,7 +82,7 @@ class NfaInterp:
         raw = blob.view(np.uint8)
         self.cmap = raw[int(blob[4]):int(blob[4]) + 256].copy()
         mw, aw = int(blob[20]), int(blob[21])                          # NF_MASK_WORDS, NF_AUX_WORDS
-        assert mw == (4 if self.ncls > 64 else 2) and aw == (8 if self.nslots > 64 else 4)
+        assert mw == (4 if self.ncls > 64 else 2) and aw == (16 if self.nslots > 128 else 8 if self.nslots > 64 else 4)
         pm = blob[int(blob[5]) // 4:int(blob[5]) // 4 + mw * self.npos]
         self.posmask = [sum(int(pm[mw * p + k]) << (32 * k) for k in range(mw)) for p in range(self.npos)]
         fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + self.npos + 2]
@@ -98,7 +98,7 @@ class NfaInterp:
                 x = int(paths[i][0])
                 tgt, a = x & 0xFFFF, x >> 16
                 cond = int(aux[aw * a])
-                tags = sum(int(aux[aw * a + 1 + k]) << (32 * k) for k in range(aw // 2))
+                tags = sum(int(aux[aw * a + 1 + k]) << (32 * k) for k in range(min(aw - 1, 10)))
                 lst.append((-1 if tgt == 0xFFFF else tgt, cond, tags))
             self.follow.append(lst)
 

@@ -56,3 +56,19 @@ _PAM = [
 ]
 WIDE_PATTERNS.append("SYSLOGPAMSESSION")
 _LINES.extend(_PAM)
+
+_NAGIOS = [
+    b"[1427925600] CURRENT HOST STATE: nagios.example.com;UP;HARD;1;PING OK - Packet loss = 0%, RTA = 2.24 ms",
+    b"[1427925600] CURRENT SERVICE STATE: nagios.example.com;HTTP;OK;HARD;1;HTTP OK: HTTP/1.1 200 OK - 453 bytes",
+    b"[1427925689] SERVICE ALERT: varnish.example.com;Varnish Backend Connections;CRITICAL;SOFT;1;Current value: 154.0",
+    b"[1427956600] SERVICE NOTIFICATION: nagiosadmin;ntp.example.com;NTP;OK;notify-service-by-email;NTP OK: Offset 0.000339 secs",
+    b"[1427955600] HOST NOTIFICATION: nagiosadmin;db1.example.com;DOWN;notify-host-by-email;CRITICAL - Host Unreachable",
+    b"[1427955600] TIMEPERIOD TRANSITION: 24x7;-1;1",
+    b"[1427925600] LOG ROTATION: DAILY",
+    b"[1427925600] Warning: Return code of 127 for check of service 'x' on host 'y' was out of bounds.",
+    b"[1427925600] EXTERNAL COMMAND: SCHEDULE_SVC_DOWNTIME;host1;svc;1427925600;1427929200;1;0;3600;admin;patching",
+    b"[1427925600] PASSIVE SERVICE CHECK: host1;disk;0;DISK OK - free space: / 3326 MB (56%)",
+    b"[142792560x] SERVICE ALERT: a;b;CRITICAL;SOFT;1;c",
+]
+WIDE_PATTERNS.append("NAGIOSLOGLINE")
+_LINES.extend(_NAGIOS)

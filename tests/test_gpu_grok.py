@@ -163,9 +163,10 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
     assert hits >= 3
 
 
-@pytest.mark.parametrize("name", ["HTTPD_ERRORLOG", "HAPROXYHTTP", "SYSLOGPAMSESSION"])
+@pytest.mark.parametrize("name", ["HTTPD_ERRORLOG", "HAPROXYHTTP", "SYSLOGPAMSESSION", "NAGIOSLOGLINE"])
 def test_wide_table_patterns_against_the_oracle(torch_dev, golden_dir, name):
-    """> 64 byte classes (4-word class masks) and > 64 capture slots (4 tag words, NS=128 kernel): tests/helpers/wide_patterns.py"""
+    """> 64 byte classes (4-word class masks), > 64 / > 128 capture slots (NS=128 / NS=320 kernels), run captures:
+    tests/helpers/wide_patterns.py"""
     from tests.helpers.wide_patterns import wide_values
     with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
         cfg3 = json.load(f)

@@ -207,10 +207,10 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
 
 
 @pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106),
-                                                  ("SYSLOGPAMSESSION", None, None)])
+                                                  ("SYSLOGPAMSESSION", None, None), ("NAGIOSLOGLINE", 39, 278)])
 def test_wide_table_formats_on_the_compiled_tables(golden_dir, name, classes, slots):
-    """65..128 byte classes -> 4-word class masks; 65..128 capture slots -> 4 tag words per aux entry (device_tables.h
-    NF_MASK_WORDS / NF_AUX_WORDS).  The device algorithm replayed on those tables must give the oracle's fields."""
+    """65..128 byte classes -> 4-word class masks; 65..128 / 129..320 capture slots -> 4 / 10 tag words per aux entry
+    (device_tables.h NF_MASK_WORDS / NF_AUX_WORDS).  The device algorithm replayed on those tables must give the oracle's fields."""
     from tests.helpers.wide_patterns import wide_values
     with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
         cfg3 = json.load(f)
