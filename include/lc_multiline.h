@@ -37,6 +37,11 @@ void lc_multiline_free(lc_multiline_t* m);
 /* MultilineOptions::IsMultiline() (:203-205, decided on the patterns with a trailing '$' / ".*" stripped): 0 means the
  * input plugin would not install the multiline splitter at all */
 int lc_multiline_is_multiline(const lc_multiline_t* m);
+/* "" or one line per pattern that was ignored because it is not a valid regex (the reference warns and carries on,
+ * MultilineOptions.cpp:109-118).  lc_multiline_create fails for a pattern that is valid but not runnable on the device
+ * (there is no CPU path), and for a config without a usable StartPattern or EndPattern (the reference never builds the
+ * processor for one: InputFile.cpp:225). */
+const char* lc_multiline_warnings(const lc_multiline_t* m);
 /* which patterns the processor works with (bit 0 start, bit 1 continue, bit 2 end): Has*Pattern() = the string as written
  * is not empty (ProcessorSplitMultilineLogStringNative.h:68-70) */
 int lc_multiline_patterns(const lc_multiline_t* m);

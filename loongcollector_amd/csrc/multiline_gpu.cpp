@@ -29,6 +29,7 @@ struct lc_multiline {
     lc_regex_t *start = nullptr, *cont = nullptr, *end = nullptr;
     bool discardUnmatched = false;
     bool isMultiline = false;
+    std::string warnings;  // patterns that were ignored (MultilineOptions::Init only warns about an invalid regex)
     ~lc_multiline() {
         lc_regex_free(start);
         lc_regex_free(cont);
@@ -46,14 +47,25 @@ static std::string trimmed(std::string pattern) {
     while (!pattern.empty() && endsWith(pattern, ".*")) pattern.resize(pattern.size() - 2);
     return pattern;
 }
-static bool parseRegex(const std::string& pattern, lc_regex_t** out, std::string& err) {
-    if (pattern.empty()) return true;
+// -> LC_OK (compiled, or nothing to compile), LC_ERR_SYNTAX (the reference ignores the pattern with a warning,
+// MultilineOptions.cpp:109-118), LC_ERR_UNSUPPORTED (valid for Boost, not runnable on the device: Init must fail, there is
+// no CPU path to fall back to)
+static int parseRegex(const std::string& pattern, lc_regex_t** out, std::string& err) {
+    if (pattern.empty()) return LC_OK;
     char buf[256];
-    if (lc_regex_compile(pattern.data(), pattern.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, out, buf, sizeof buf) != LC_OK) {
-        err = buf;
-        return false;
+    const std::string t = trimmed(pattern);  // ParseRegex judges validity on the stripped form
+    if (!t.empty()) {
+        lc_regex_t* probe = nullptr;
+        const int rc = lc_regex_compile(t.data(), t.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, &probe, buf, sizeof buf);
+        lc_regex_free(probe);
+        if (rc == LC_ERR_SYNTAX) {
+            err = buf;
+            return rc;
+        }
     }
-    return true;
+    const int rc = lc_regex_compile(pattern.data(), pattern.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, out, buf, sizeof buf);
+    if (rc != LC_OK) err = buf;
+    return rc;
 }
 
 extern "C" int lc_multiline_create(const char* config_json, size_t config_len, lc_multiline_t** out, char* err,
@@ -71,15 +83,29 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
             const lcjson::Value* v = cfg.find(key);
             return (v && v->isString()) ? v->str : std::string();
         };
-        std::string why;
-        if (!parseRegex(str("StartPattern"), &m->start, why))
-            throw std::runtime_error("string param Multiline.StartPattern is not a valid regex: " + why);
-        if (!parseRegex(str("ContinuePattern"), &m->cont, why))
-            throw std::runtime_error("string param Multiline.ContinuePattern is not a valid regex: " + why);
-        if (!parseRegex(str("EndPattern"), &m->end, why))
-            throw std::runtime_error("string param Multiline.EndPattern is not a valid regex: " + why);
+        std::string kept[3];
+        const char* names[3] = {"StartPattern", "ContinuePattern", "EndPattern"};
+        lc_regex_t** regs[3] = {&m->start, &m->cont, &m->end};
+        for (int i = 0; i < 3; ++i) {
+            std::string why;
+            const std::string pattern = str(names[i]);
+            const int rc = parseRegex(pattern, regs[i], why);
+            if (rc == LC_OK) {
+                kept[i] = pattern;
+            } else if (rc == LC_ERR_SYNTAX) {  // :109-118 -- a warning, the pattern counts as not given
+                m->warnings += std::string("string param Multiline.") + names[i] + " is not a valid regex: " + why + "\n";
+            } else {
+                throw std::runtime_error(std::string("Multiline.") + names[i] + ": " + why);
+            }
+        }
+        // The reference's state machine indexes an empty regex vector when it is handed ContinuePattern alone or no
+        // pattern at all (GetStartPatternReg(), .cpp:176-184, :395) -- the input plugin never builds the processor for
+        // such a config (InputFile.cpp:225, IsMultiline() is false).  Refused here.
+        if (!m->start && !m->end)
+            throw std::runtime_error("neither Multiline.StartPattern nor Multiline.EndPattern is usable: not a multiline config"
+                                     + (m->warnings.empty() ? std::string() : " (" + m->warnings + ")"));
         // MultilineOptions::IsMultiline (:203-205) goes by what is left after the stripping
-        m->isMultiline = !trimmed(str("StartPattern")).empty() || !trimmed(str("EndPattern")).empty();
+        m->isMultiline = !trimmed(kept[0]).empty() || !trimmed(kept[2]).empty();
         const std::string t = str("UnmatchedContentTreatment");               // :208-222
         m->discardUnmatched = t == "discard";
     } catch (const std::exception& e) {
@@ -92,6 +118,7 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
 }
 extern "C" void lc_multiline_free(lc_multiline_t* m) { delete m; }
 extern "C" int lc_multiline_is_multiline(const lc_multiline_t* m) { return m && m->isMultiline; }
+extern "C" const char* lc_multiline_warnings(const lc_multiline_t* m) { return m ? m->warnings.c_str() : ""; }
 extern "C" int lc_multiline_patterns(const lc_multiline_t* m) {
     return m ? (m->start ? 1 : 0) | (m->cont ? 2 : 0) | (m->end ? 4 : 0) : 0;
 }

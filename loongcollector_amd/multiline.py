@@ -23,6 +23,8 @@ class Multiline:
             L.lc_multiline_free.argtypes = [vp]
             L.lc_multiline_is_multiline.argtypes = [vp]
             L.lc_multiline_patterns.argtypes = [vp]
+            L.lc_multiline_warnings.restype = cp
+            L.lc_multiline_warnings.argtypes = [vp]
             L.lc_multiline_split_host.restype = ctypes.c_int
             L.lc_multiline_split_host.argtypes = [vp, cp, ctypes.c_uint32, ctypes.POINTER(ctypes.POINTER(_Record)),
                                                   ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
@@ -43,6 +45,10 @@ class Multiline:
     @property
     def is_multiline(self):
         return bool(self._L.lc_multiline_is_multiline(self._h))
+
+    @property
+    def warnings(self):
+        return self._L.lc_multiline_warnings(self._h).decode("utf-8", "replace")
 
     @property
     def patterns(self):

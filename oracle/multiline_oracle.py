@@ -18,14 +18,26 @@ def _trimmed(pattern):
 
 
 def _parse(pattern):
-    """the processor compiles the string as written and uses it when it is not empty (.cpp:66-76, .h:68-70)"""
-    return OracleRegex(pattern.encode("utf-8")) if pattern else None
+    """the processor compiles the string as written and uses it when it is not empty (.cpp:66-76, .h:68-70); a pattern
+    whose stripped form is not a valid regex is ignored with a warning (MultilineOptions.cpp:109-118)"""
+    if not pattern:
+        return None
+    try:
+        if _trimmed(pattern):
+            OracleRegex(_trimmed(pattern).encode("utf-8"))
+    except ValueError:
+        return None
+    return OracleRegex(pattern.encode("utf-8"))
 
 
 class MultilineOracle:
     def __init__(self, StartPattern="", ContinuePattern="", EndPattern="", UnmatchedContentTreatment="single_line"):
         self.start, self.cont, self.end = _parse(StartPattern), _parse(ContinuePattern), _parse(EndPattern)
-        self.is_multiline = bool(_trimmed(StartPattern) or _trimmed(EndPattern))
+        if not self.start and not self.end:
+            # ContinuePattern alone / nothing: the reference's ProcessEvent would index an empty regex vector (.cpp:176-184,
+            # :395); the input plugin never builds the processor for such a config (InputFile.cpp:225)
+            raise ValueError("not a multiline config")
+        self.is_multiline = bool((self.start and _trimmed(StartPattern)) or (self.end and _trimmed(EndPattern)))
         self.discard = UnmatchedContentTreatment == "discard"
 
     def split(self, val: bytes):

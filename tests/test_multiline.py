@@ -36,13 +36,22 @@ def test_init_rules():
     """ProcessorSplitMultilineLogStringNative.cpp:66-76 / .h:68-70 (patterns as written), MultilineOptions.cpp:203-205,250-266"""
     m = Multiline(StartPattern="Exception.*", ContinuePattern=r"\s+at\s.*", EndPattern=r"\s*\.\.\.\d+ more")
     assert m.patterns == {"start": True, "continue": True, "end": True} and m.is_multiline   # the processor keeps all three
-    m = Multiline(ContinuePattern=r"\s+at\s.*")
-    assert m.patterns == {"start": False, "continue": True, "end": False} and not m.is_multiline
+    # ContinuePattern alone / no pattern: the reference's ProcessEvent has no defined behaviour (it indexes an empty regex
+    # vector, .cpp:176-184) and the input plugin never builds the processor for it -- refused
+    for cfg in ({"ContinuePattern": r"\s+at\s.*"}, {}, {"StartPattern": "("}):
+        with pytest.raises(MultilineInitError):
+            Multiline(**cfg)
+        with pytest.raises(ValueError):
+            MultilineOracle(**cfg)
     m = Multiline(StartPattern=".*")
     assert m.patterns["start"] is True and not m.is_multiline    # present for the processor, "not multiline" for the input
     assert Multiline(EndPattern="x$").patterns["end"] is True
+    # an invalid regex is ignored with a warning (MultilineOptions.cpp:109-118); one the device cannot run fails Init
+    m = Multiline(StartPattern="(", EndPattern="x")
+    assert m.patterns == {"start": False, "continue": False, "end": True} and "StartPattern is not a valid regex" in m.warnings
+    assert MultilineOracle(StartPattern="(", EndPattern="x").start is None
     with pytest.raises(MultilineInitError):
-        Multiline(StartPattern="(")
+        Multiline(StartPattern=r"(a)\1")
     o = MultilineOracle(StartPattern="a", ContinuePattern="b", EndPattern="c")
     assert o.cont is not None and o.is_multiline
     # "END$" as written: the line has to end there (the stripped form would also accept "END7x")
@@ -75,7 +84,6 @@ def test_reference_cases_on_the_device(vectors):
     {"ContinuePattern": r"\s+.*", "EndPattern": r"\}"},
     {"EndPattern": ";$", "UnmatchedContentTreatment": "discard"},
     {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}$"},   # all three stay in use
-    {"ContinuePattern": r"\s+.*"},                                                           # continue alone
     {"StartPattern": ".*"},                                                                  # every line starts a record
 ])
 def test_random_buffers_against_the_oracle(config):
