@@ -116,8 +116,10 @@ enum {
     LC_TABLE_TDFA_FINALMAP = 5, /* u8[nfinal*slots] */
     LC_TABLE_TDFA_HEADER = 6, /* u32[8]: states, classes, registers, slots, start state, 0,0,0 */
     LC_TABLE_NFA_BLOB = 7,    /* the packed NFA program uploaded to the device (see csrc/device_tables.h) */
-    LC_TABLE_TDFA_STARTAFTER = 8 /* u32[classes]: search patterns only -- state a resumed search starts in, by the class
+    LC_TABLE_TDFA_STARTAFTER = 8, /* u32[classes]: search patterns only -- state a resumed search starts in, by the class
                                     of the byte before the resume point (lc_regex_match_device_from) */
+    LC_TABLE_TDFA_BLOB = 9,      /* the packed TDFA tables uploaded to the device (csrc/device_tables.h) */
+    LC_TABLE_TDFA_WIDE_BLOB = 10 /* small automata only: the same with byte-indexed rows, for the 1024-lane kernel */
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 

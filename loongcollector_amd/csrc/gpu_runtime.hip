@@ -50,11 +50,12 @@ extern "C" int lc_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ device tables
-static int ensureUploaded(lc_regex* re, int dev, bool tdfa, void** out) {
+enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2 };
+static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     std::lock_guard<std::mutex> g(re->deviceMutex);
-    void** slot = tdfa ? &re->dTdfaBlob[dev] : &re->dNfaBlob[dev];
+    void** slot = which == kBlobTdfa ? &re->dTdfaBlob[dev] : (which == kBlobTdfaWide ? &re->dTdfaWideBlob[dev] : &re->dNfaBlob[dev]);
     if (!*slot) {
-        const std::vector<uint32_t>& blob = tdfa ? re->tdfaBlob : re->nfaBlob;
+        const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob : (which == kBlobTdfaWide ? re->tdfaWideBlob : re->nfaBlob);
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, blob.size() * 4));
         hipError_t e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
@@ -72,29 +73,30 @@ void lcReleaseDeviceTables(lc_regex* re) {
     int cur = 0;
     bool haveCur = hipGetDevice(&cur) == hipSuccess;
     for (int d = 0; d < kLcMaxDevices; ++d) {
-        if (re->dTdfaBlob[d] || re->dNfaBlob[d]) {
+        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d]) {
             if (hipSetDevice(d) == hipSuccess) {
                 if (re->dTdfaBlob[d]) (void)hipFree(re->dTdfaBlob[d]);
+                if (re->dTdfaWideBlob[d]) (void)hipFree(re->dTdfaWideBlob[d]);
                 if (re->dNfaBlob[d]) (void)hipFree(re->dNfaBlob[d]);
             }
-            re->dTdfaBlob[d] = re->dNfaBlob[d] = nullptr;
+            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = nullptr;
         }
     }
     if (haveCur) (void)hipSetDevice(cur);
 }
 
-template <int BLOCK, bool PAIR>
+template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
-                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
+                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
+    hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
     HIP_TRY(hipGetLastError());
     return LC_OK;
@@ -104,8 +106,30 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
                       uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
                       uint8_t* d_status, hipStream_t stream) {
     void* dBlob = nullptr;
-    int rc = ensureUploaded(re, dev, true, &dBlob);
+    int rc = ensureUploaded(re, dev, kBlobTdfa, &dBlob);
     if (rc != LC_OK) return rc;
+    // COMPACT variant (16-bit offset registers, more lines in flight per CU): it takes every line shorter than 64 KiB; the
+    // 32-bit kernel below then only looks at what is left (usually nothing: its workgroups read their lines' lengths and
+    // leave).  Two launches only pay on batches large enough to fill the chip several times over.
+    constexpr uint32_t kCompactMinLines = 1u << 16;
+    uint32_t minLen = 0;
+    if (!re->tdfaWideBlob.empty() && (re->tdfaWideForced || n >= kCompactMinLines)) {
+        void* dWide = nullptr;
+        rc = ensureUploaded(re, dev, kBlobTdfaWide, &dWide);
+        if (rc != LC_OK) return rc;
+        const uint32_t wideBytes = uint32_t(re->tdfaWideBlob.size() * 4);
+        const int wb = re->tdfaWideBlock;
+        const uint32_t wRegBytes = uint32_t(size_t(re->tdfa.nRegs + 1) * size_t(wb) * 2);
+        const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfa.nRegs, wb);
+        if (wb == kLcTdfaWideBlock)
+            rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        else if (wb == 512)
+            rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        else
+            rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        if (rc != LC_OK) return rc;
+        minLen = kTdfaWideMaxLine + 1;
+    }
     const uint32_t blobBytes = uint32_t(re->tdfaBlob.size() * 4);
     const int block = re->tdfaBlock;  // the blob's register offsets are encoded for this workgroup size
     if (block == 0) {
@@ -118,9 +142,9 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
     const bool pair = re->tdfaBlob[TD_OFF_PAIR] != 0 && !pairOff;
     switch (block) {
-        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     }
 }
 
@@ -149,7 +173,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     void* dBlob = nullptr;
-    int rc = ensureUploaded(re, dev, false, &dBlob);
+    int rc = ensureUploaded(re, dev, kBlobNfa, &dBlob);
     if (rc != LC_OK) return rc;
     const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);
     const bool atomic = re->nfa.atomicCount > 0;

@@ -50,14 +50,52 @@ size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
     return n;
 }
 
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
-    const uint32_t cols = t.nClasses + 1;  // + identity column
+// Tables for a COMPACT kernel variant (tdfa_kernel.hpp), chosen when the pattern is compiled.  By default the 256-lane
+// variant (class-indexed rows, 16-bit registers: 16 instead of 12 waves per CU on the headline regex, +4 % measured) is
+// packed and the launcher uses it for large batches.  LC_TDFA_COMPACT=0: none.  LC_TDFA_COMPACT=256 / 512: that workgroup
+// size, used for every batch.  LC_TDFA_COMPACT=1024: byte-indexed rows shared by one 1024-lane workgroup per CU, for
+// automata small enough to keep that table, the registers and the staging tiles in the CU's LDS (measured slower: the
+// wide rows quadruple the LDS bank conflicts).
+std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut) {
+    const char* env = getenv("LC_TDFA_COMPACT");
+    const int want = env ? atoi(env) : 256;
+    *blockOut = 0;
+    *forcedOut = env != nullptr;
+    if (want == 256 || want == 512) {
+        if (size_t(t.nRegs + 1) * size_t(want) * 2 > TD_MAX_REG_AREA) return {};
+        try {
+            std::vector<uint32_t> blob = packTdfaBlob(t, want, false, true);
+            if (lcTdfaCompactLdsBytes(uint32_t(blob.size() * 4), t.nRegs, want) > kLcLdsPerCu) return {};
+            *blockOut = want;
+            return blob;
+        } catch (const RegexError&) {
+            return {};
+        }
+    }
+    if (want != kLcTdfaWideBlock) return {};
+    const uint64_t tableEnd = TD_TRANS_OFFSET + uint64_t(t.nStates) * 257 * 4;
+    if (tableEnd > TD_MAX_TABLE_END || lcTdfaWideRegBytes(t.nRegs) > TD_MAX_REG_AREA) return {};
+    const size_t rest = tdfaBlobBytesEstimate(t) - size_t(t.nStates) * (t.nClasses + 1) * 4;  // everything but the rows
+    if (lcTdfaWideLdsBytes(uint32_t(size_t(t.nStates) * 257 * 4 + rest + 64), t.nRegs) > kLcLdsPerCu) return {};
+    try {
+        std::vector<uint32_t> blob = packTdfaBlob(t, kLcTdfaWideBlock, true, true);
+        if (lcTdfaWideLdsBytes(uint32_t(blob.size() * 4), t.nRegs) > kLcLdsPerCu) return {};
+        *blockOut = kLcTdfaWideBlock;
+        return blob;
+    } catch (const RegexError&) {
+        return {};
+    }
+}
+
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact) {
+    // wide: rows indexed by the byte itself (256 columns + identity); compact: 16-bit offset registers (tdfa_kernel.hpp)
+    const uint32_t cols = (wide ? 256 : t.nClasses) + 1;  // + identity column
     const uint32_t rowBytes = cols * 4;
     if (TD_TRANS_OFFSET + uint64_t(t.nStates) * rowBytes > TD_MAX_TABLE_END)
         throw RegexError("tdfa: transition table exceeds the 64 KiB LDS window");
     if (t.nClasses > 63) throw RegexError("tdfa: more than 63 byte classes");
     const uint32_t dummyReg = t.nRegs;  // one past the real registers
-    const uint32_t regStride = uint32_t(block) * 4;
+    const uint32_t regStride = uint32_t(block) * (compact ? 2 : 4);
     if (uint64_t(dummyReg + 1) * regStride > TD_MAX_REG_AREA) throw RegexError("tdfa: register file exceeds 64 KiB");
     const size_t nLists = t.opsStart.size() - 1;
     // "one register = pos" is folded into the transition word; everything else stays a list
@@ -81,11 +119,11 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
     std::vector<uint32_t> trans(size_t(t.nStates) * cols);
     auto rowAddr = [&](uint32_t state) { return TD_TRANS_OFFSET + state * rowBytes; };
     for (uint32_t s = 0; s < t.nStates; ++s) {
-        for (uint32_t c = 0; c < t.nClasses; ++c) {
-            const uint32_t e = t.trans[size_t(s) * t.nClasses + c];
+        for (uint32_t c = 0; c + 1 < cols; ++c) {
+            const uint32_t e = t.trans[size_t(s) * t.nClasses + (wide ? t.classMap[c] : c)];
             trans[size_t(s) * cols + c] = rowAddr(e & 0xFFFF) | (field[e >> 16] << 16);
         }
-        trans[size_t(s) * cols + t.nClasses] = rowAddr(s) | (field[0] << 16);  // identity column
+        trans[size_t(s) * cols + cols - 1] = rowAddr(s) | (field[0] << 16);  // identity column
     }
     uint32_t hdr[TD_HEADER_WORDS] = {};
     hdr[TD_MAGIC] = TD_MAGIC_VALUE;
@@ -95,7 +133,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
     hdr[TD_NSLOTS] = t.nSlots;
     hdr[TD_START_ROW] = rowAddr(t.startState);
     hdr[TD_ROW_BYTES] = rowBytes;
-    hdr[TD_ID_COL] = t.nClasses * 4;
+    hdr[TD_ID_COL] = (cols - 1) * 4;
     hdr[TD_BLOCK] = uint32_t(block);
     const uint32_t cmapAt = w.put(cmap);
     const uint32_t transAt = w.put(trans);
@@ -116,7 +154,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block) {
     // Opt-in (LC_TDFA_PAIR=1 when the pattern is compiled): measured on the headline corpus it buys ~10 % at equal
     // occupancy, but the 20 KiB table costs one of the three resident workgroups per CU.
     const char* pairEnv = getenv("LC_TDFA_PAIR");
-    if (pairEnv && pairEnv[0] == '1' && pairBytes <= TP_MAX_TABLE_BYTES && dummyReg < TP_GENERAL) {
+    if (!wide && pairEnv && pairEnv[0] == '1' && pairBytes <= TP_MAX_TABLE_BYTES && dummyReg < TP_GENERAL) {
         std::vector<uint16_t> cmapA(256);
         for (int b = 0; b < 256; ++b) cmapA[size_t(b)] = uint16_t(t.classMap[size_t(b)] * cols * 4);
         const uint32_t cmapAOff = w.put(cmapA);
@@ -476,6 +514,7 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
             re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
             if (!re->tdfaBlock) return nullptr;
             re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
+            re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced);
             re->hasTdfa = true;
             re->engine = LC_ENGINE_TDFA;
             re->pattern = std::string("<prefix screen: ") + how + ", " + std::to_string(k) + " of " +
@@ -573,6 +612,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
                 if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
                 re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
+                re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced);
                 re->hasTdfa = true;
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                   re->tdfa.startState, 0, 0, 0};
@@ -679,6 +719,10 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
         case LC_TABLE_TDFA_STARTAFTER:
             if (t.startAfter.empty()) return LC_ERR_ARG;
             return view(t.startAfter.data(), t.startAfter.size() * 4);
+        case LC_TABLE_TDFA_BLOB: return view(re->tdfaBlob.data(), re->tdfaBlob.size() * 4);
+        case LC_TABLE_TDFA_WIDE_BLOB:
+            if (re->tdfaWideBlob.empty()) return LC_ERR_ARG;
+            return view(re->tdfaWideBlob.data(), re->tdfaWideBlob.size() * 4);
         default: return LC_ERR_ARG;
     }
 }

@@ -22,6 +22,9 @@ struct lc_regex {
     std::vector<uint32_t> tdfaHeader;   // LC_TABLE_TDFA_HEADER view
     std::vector<uint32_t> tdfaBlob;     // device_tables.h TDFA layout
     int tdfaBlock = 0;                  // workgroup size tdfaBlob was packed for
+    std::vector<uint32_t> tdfaWideBlob; // tables of the COMPACT kernel variant (16-bit offset registers), or empty
+    int tdfaWideBlock = 0;              // its workgroup size: 256 / 512 (class-indexed rows) or 1024 (byte-indexed rows)
+    bool tdfaWideForced = false;        // LC_TDFA_COMPACT was set: use it for every batch, not only for large ones
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
@@ -30,12 +33,15 @@ struct lc_regex {
     // device residency, managed by gpu_runtime.hip
     std::mutex deviceMutex;
     void* dTdfaBlob[kLcMaxDevices] = {};
+    void* dTdfaWideBlob[kLcMaxDevices] = {};
     void* dNfaBlob[kLcMaxDevices] = {};
 };
 
 namespace lcregex {
 // `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block);
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide = false, bool compact = false);
+// tables of the COMPACT kernel variant (LC_TDFA_COMPACT picks it; empty: switched off, or the automaton is too large)
+std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut);
 size_t tdfaBlobBytesEstimate(const TdfaTables& t);
 // throws RegexError when the NFA does not fit the device format (more than 64 byte classes)
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);
@@ -54,6 +60,15 @@ inline size_t lcTdfaRegBytes(uint32_t nRegs, int block) { return size_t(nRegs + 
 inline size_t lcTdfaStageBytes(int block) { return size_t(block / 64) * 64 * (LC_TDFA_STAGE_BYTES + 16); }
 inline size_t lcTdfaLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
     return size_t(blobBytes) + lcTdfaRegBytes(nRegs, block) + lcTdfaStageBytes(block);
+}
+// WIDE kernel (tdfa_kernel.hpp): one 1024-lane workgroup per CU, 16-bit offset registers, 16 unpadded staging tiles
+constexpr int kLcTdfaWideBlock = 1024;
+inline size_t lcTdfaWideRegBytes(uint32_t nRegs) { return size_t(nRegs + 1) * kLcTdfaWideBlock * 2; }
+inline size_t lcTdfaWideLdsBytes(uint32_t blobBytes, uint32_t nRegs) {
+    return size_t(blobBytes) + lcTdfaWideRegBytes(nRegs) + size_t(kLcTdfaWideBlock / 64) * 64 * LC_TDFA_STAGE_BYTES;
+}
+inline size_t lcTdfaCompactLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
+    return size_t(blobBytes) + size_t(nRegs + 1) * size_t(block) * 2 + size_t(block / 64) * 64 * LC_TDFA_STAGE_BYTES;
 }
 inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
     auto fits = [&](int b, size_t budget) {

@@ -30,9 +30,17 @@
 // short line) take the row's identity column.  When every lane of the wavefront is in the middle of its line a
 // wave-uniform branch skips the validity selects.  Loads are aligned 16-byte segments that contain at least one
 // byte of the line, so none can leave the line's pages.
+//
+// COMPACT variants (regex_handle.cpp packTdfaWideBlob: 256 lanes by default for large batches): 16-bit offset registers (lines of 64 KiB and more are left to a second launch
+// of the 32-bit kernel) and an unpadded, XOR-swizzled staging tile -- 106 instead of 164 bytes of LDS per line, i.e. more
+// lines in flight per CU.  With BYTEROWS on top (small automata, one 1024-lane workgroup per CU sharing a 37 KiB table) the
+// transition rows are indexed by the BYTE itself (256 columns + the identity column, device_tables.h): phase 0 becomes
+// one VALU op per byte and the class lookup -- one of the three LDS instructions per byte -- is gone.
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "../../include/lc_regex_gpu.h"
 #include "device_tables.h"
@@ -47,8 +55,10 @@ typedef u32x4 __attribute__((address_space(3))) * LdsQuadPtr;
 typedef const uint8_t __attribute__((address_space(3))) * LdsBytePtr;
 typedef const u32x4 __attribute__((address_space(1))) * GlobalQuadPtr;
 
-typedef uint32_t TdfaReg;  // capture offsets are 32-bit: a line may be as long as a 512 KiB read buffer
-typedef TdfaReg __attribute__((address_space(3))) * LdsRegPtr;
+// capture offsets are 32-bit (a line may be as long as a 512 KiB read buffer); the COMPACT variants keep 16-bit ones
+template <typename RegT>
+using LdsRegPtrT = RegT __attribute__((address_space(3))) *;
+constexpr uint32_t kTdfaWideMaxLine = 0xFFFFu;  // longest line the COMPACT variants take
 #ifndef LC_TDFA_CHUNK
 #define LC_TDFA_CHUNK 16  // bytes stepped per three-phase round (8 halves the live col/tt registers)
 #endif
@@ -67,7 +77,7 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 }
 
 // general register program (a list of moves); rare for log regexes
-template <int BLOCK>
+template <int BLOCK, typename TdfaReg>
 __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase, uint32_t list, uint32_t pos,
                                                 uint32_t tid) {
     TdfaReg* regs = reinterpret_cast<TdfaReg*>(smem + regsBase);
@@ -104,28 +114,30 @@ __device__ __forceinline__ uint32_t addHighHalf(uint32_t a, uint32_t t) {
 
 // In-order replay of one chunk for wavefronts that met a general register program in it: re-walks the 16 bytes
 // from the chunk's entry state and applies every register program at its own byte.  Rolled up: it is rare.
-template <int BLOCK>
+template <int BLOCK, typename TdfaReg, bool WIDE>
 __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t t, uint32_t base, uint32_t L,
                                                 uint32_t idCol, uint32_t regsBase, uint32_t tid, uint32_t nBytes) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
     const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
 #pragma unroll 1
     for (uint32_t j = 0; j < nBytes; ++j) {
         const uint32_t word = (j < 8) ? ((j < 4) ? q.x : q.y) : ((j < 12) ? q.z : q.w);
         const uint32_t b = (word >> ((j & 3) * 8)) & 0xFFu;
-        const uint32_t col = (base + j < L) ? uint32_t(cmap[b]) : idCol;
+        const uint32_t col = (base + j < L) ? (WIDE ? b * 4u : uint32_t(cmap[b])) : idCol;
         t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col, t));
-        if (t & (TD_OP_GENERAL << 16)) tdfaRunMoveList<BLOCK>(smem, regsBase, t >> 17, base + j, tid);
+        if (t & (TD_OP_GENERAL << 16)) tdfaRunMoveList<BLOCK, TdfaReg>(smem, regsBase, t >> 17, base + j, tid);
         else *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, t)) = TdfaReg(base + j);
     }
 }
 
 // steps NB (8 or 16) consecutive bytes held in `words`; CHECKED=false is the mid-line fast path (all NB bytes belong
 // to the line)
-template <int BLOCK, bool CHECKED, int NB>
+template <int BLOCK, bool CHECKED, int NB, typename TdfaReg = uint32_t, bool WIDE = false>
 __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
                                                   uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
                                                   uint32_t tid) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     // the blob sits at LDS address 0, so table offsets are LDS addresses
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
     const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);  // LDS address of regs[0][lane]
@@ -133,8 +145,13 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
     uint32_t col[NB], tt[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {  // phase 0
-        const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-        const uint32_t c4 = cmap[b];
+        uint32_t c4;
+        if constexpr (WIDE) {  // rows are indexed by the byte itself: column offset = byte * 4, no lookup
+            const uint32_t w = words[j >> 2];
+            c4 = (j & 3) == 0 ? (w << 2) & 0x3FCu : (w >> ((j & 3) * 8 - 2)) & 0x3FCu;
+        } else {
+            c4 = cmap[(words[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+        }
         col[j] = CHECKED ? ((base + j < L) ? c4 : idCol) : c4;
     }
     uint32_t seen = 0;
@@ -156,7 +173,7 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
             q.z = words[2 % (NB / 4)];
             q.w = words[3 % (NB / 4)];
         }
-        tdfaReplayChunk<BLOCK>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
+        tdfaReplayChunk<BLOCK, TdfaReg, WIDE>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
     }
     return t;
 }
@@ -173,6 +190,8 @@ template <int BLOCK, bool CHECKED, int NB>
 __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
                                                   uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
                                                   uint32_t tid, const TdfaPairInfo& pi, uint32_t singleRowBytes) {
+    typedef uint32_t TdfaReg;
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
     const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
     constexpr uint32_t kRegShift = (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8));  // log2(BLOCK * sizeof(TdfaReg))
@@ -214,26 +233,60 @@ __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t 
             q.w = words[3 % (NB / 4)];
         }
         const uint32_t state = ((entry & 0xFFFFu) - pi.base) / pi.rowBytes;
-        tdfaReplayChunk<BLOCK>(smem, q, TD_TRANS_OFFSET + state * singleRowBytes, base, L, idCol, regsBase, tid, NB);
+        tdfaReplayChunk<BLOCK, uint32_t, false>(smem, q, TD_TRANS_OFFSET + state * singleRowBytes, base, L, idCol, regsBase, tid,
+                                                NB);
     }
     return t;
 }
 
-template <int BLOCK, bool PAIR>
+// minLen: lines shorter than this are not this launch's business (the 32-bit kernel mopping up behind a COMPACT one)
+template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(const uint8_t* __restrict__ data,
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
+                                                           uint32_t minLen,
                                                            uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
                                                            const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ resume,
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
+    static_assert(!(COMPACT && PAIR) && (COMPACT || !BYTEROWS), "no pair extension / byte rows outside the compact variants");
+    constexpr bool WIDE = BYTEROWS;
+    typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type TdfaReg;
+    // staging rows: padded to 80 bytes (conflict-free b128 reads), or -- COMPACT -- 64 bytes with the 16-byte segments of
+    // row r stored at segment ^ ((r >> 1) & 3), which is conflict-free without the padding
+    constexpr uint32_t kRowStride = COMPACT ? kTdfaStageBytes : kTdfaRowStride;
+    constexpr uint32_t kStagePerWave = 64 * kRowStride;
+    static_assert(!COMPACT || kTdfaStageBytes == 64, "the swizzle is written for 4 segments per row");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     if (nLinesPtr) {  // line count produced on the device (split kernels) -- no host round trip between the launches
         const uint32_t dyn = *nLinesPtr;
         nLines = dyn < nLines ? dyn : nLines;
+    }
+    if (minLen) {  // mop-up launch: usually no line of this workgroup is long enough -- leave before staging the tables
+        const uint32_t s0 = blockIdx.x * BLOCK + tid;
+        bool mine = false;
+        if (s0 < nLines) {
+            const uint32_t ln = order ? order[s0] : s0;
+            uint32_t l0 = len ? len[ln] : off[ln + 1] - off[ln] - sepBytes;
+            if (resume) {
+                const uint32_t f0 = resume[ln];
+                l0 -= f0 < l0 ? f0 : l0;
+            }
+            mine = l0 >= minLen;
+        }
+        // (not __syncthreads_or: its workgroup reduction brings static LDS of its own, and the tables must sit at LDS
+        // address 0)
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(smem);
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (mine) *flag = 1;
+        __syncthreads();
+        const bool any = *flag != 0;
+        __syncthreads();  // everybody has read the flag before the tables overwrite it
+        if (!any) return;
     }
     {  // stage the tables: 16-byte coalesced copies
         const uint4* src = reinterpret_cast<const uint4*>(blob);
@@ -260,10 +313,10 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const uint32_t deadRow = PAIR ? pi.base : TD_TRANS_OFFSET;
 
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t stageBase = blobBytes + regBytes + wave * kTdfaStagePerWave;  // this wave's staging rows (LDS address)
+    const uint32_t stageBase = blobBytes + regBytes + wave * kStagePerWave;  // this wave's staging rows (LDS address)
 
     const uint32_t slot = blockIdx.x * BLOCK + tid;
-    const bool live = slot < nLines;
+    bool live = slot < nLines;
     const uint32_t line = (live && order) ? order[slot] : slot;  // length-aware schedule (sched_kernel.hpp)
     uint32_t o = 0, L = 0;
     uint32_t from = 0;  // search patterns: offset inside the line where this search resumes (0 = a fresh search)
@@ -279,6 +332,10 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                 o += from;
                 L -= from;
             }
+        }
+        if ((COMPACT && L > kTdfaWideMaxLine) || L < minLen) {  // another launch decides this line
+            live = false;
+            L = 0;
         }
     }
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
@@ -305,9 +362,10 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         const uint32_t hi = __shfl(uint32_t(rowStart >> 32), r, 64);
         srcAddr[i] = ((uintptr_t(hi) << 32) | lo) + seg;
         srcSpan[i] = __shfl(span, r, 64);
-        dstAddr[i] = stageBase + uint32_t(r) * kTdfaRowStride + seg;
+        dstAddr[i] = stageBase + uint32_t(r) * kRowStride + (COMPACT ? seg ^ (((uint32_t(r) >> 1) & 3u) << 4) : seg);
     }
-    const uint32_t myRow = stageBase + lane * kTdfaRowStride;
+    const uint32_t myRow = stageBase + lane * kRowStride;
+    const uint32_t mySwizzle = COMPACT ? ((lane >> 1) & 3u) << 4 : 0u;
 
     u32x4 in[kTdfaLoads];
 #pragma unroll
@@ -330,7 +388,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         }
 #pragma unroll 1
         for (uint32_t k = 0; k < kTdfaStageBytes / 16; ++k) {
-            const u32x4 q = *reinterpret_cast<LdsQuadPtr>(myRow + k * 16);
+            const u32x4 q = *reinterpret_cast<LdsQuadPtr>(myRow + ((k * 16) ^ mySwizzle));
             const uint32_t base = s * kTdfaStageBytes + k * 16 - head;  // line offset of byte 0 (wraps in the head)
             const bool full = base < L && L - base >= 16;
 #if LC_TDFA_CHUNK == 16
@@ -339,8 +397,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                 if (__all(full)) t = tdfaStepPairs<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
                 else t = tdfaStepPairs<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
             } else {
-                if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid);
-                else t = tdfaStepBytes<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid);
+                if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
+                else t = tdfaStepBytes<BLOCK, true, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
             }
 #else
             const uint32_t w0[2] = {q.x, q.y}, w1[2] = {q.z, q.w};
@@ -353,11 +411,11 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                     t = tdfaStepPairs<BLOCK, true, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
                 }
             } else if (__all(full)) {
-                t = tdfaStepBytes<BLOCK, false, 8>(smem, w0, t, base, L, idCol, regsBase, tid);
-                t = tdfaStepBytes<BLOCK, false, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, false, 8, TdfaReg, WIDE>(smem, w0, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, false, 8, TdfaReg, WIDE>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
             } else {
-                t = tdfaStepBytes<BLOCK, true, 8>(smem, w0, t, base, L, idCol, regsBase, tid);
-                t = tdfaStepBytes<BLOCK, true, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, true, 8, TdfaReg, WIDE>(smem, w0, t, base, L, idCol, regsBase, tid);
+                t = tdfaStepBytes<BLOCK, true, 8, TdfaReg, WIDE>(smem, w1, t, base + 8, L, idCol, regsBase, tid);
             }
 #endif
         }

@@ -146,3 +146,55 @@ class NfaInterp:
                         c2[sl] = len(s)
                 return c2
         return None
+
+
+class TdfaBlobInterp:
+    """Walks the PACKED TDFA tables exactly as the kernel addresses them (device_tables.h): the low half of a transition
+    entry is the LDS address of the next row, the high half the byte offset of the stamped register (or a move-list id);
+    `compact` = the tables of the opt-in COMPACT kernel variant the pattern was compiled for (LC_TDFA_COMPACT=256|512|1024:
+    16-bit registers; 1024 = byte-indexed rows), LC_TABLE_TDFA_WIDE_BLOB."""
+
+    def __init__(self, rx, compact=False):
+        blob = rx.table(B.LC_TABLE_TDFA_WIDE_BLOB if compact else B.LC_TABLE_TDFA_BLOB, np.uint32)
+        assert blob is not None
+        self.blob, self.raw = blob, blob.view(np.uint8)
+        (self.nstates, self.ncls, self.nregs, self.nslots, self.start_row, off_after, _, off_finalid, off_finalmap,
+         off_opsstart, off_ops, _, self.row_bytes, self.id_col, self.block) = [int(x) for x in blob[1:16]]
+        self.compact = compact
+        self.wide = self.row_bytes == 257 * 4            # rows indexed by the byte itself
+        assert not self.wide or (compact and self.block == 1024)
+        self.reg_stride = self.block * (2 if compact else 4)
+        self.cmap = self.raw[64:320]
+        self.final_id = self.raw[off_finalid:off_finalid + 2 * self.nstates].view(np.uint16)
+        self.final_map = self.raw[off_finalmap:]
+        self.ops_start = blob[off_opsstart // 4:]
+        self.ops = self.raw[off_ops:off_ops + (len(self.raw) - off_ops) // 2 * 2].view(np.uint16)
+        self.start_after = blob[off_after // 4:off_after // 4 + self.ncls] if off_after else None
+        self.runs = rx.run_captures()
+
+    @_with_run_captures
+    def fullmatch(self, s: bytes, start=0):
+        t = self.start_row if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]]) >> 2])
+        regs = {}
+        limit = 0xFFFF if self.compact else 0xFFFFFFFF
+        for pos in range(start, len(s)):
+            col = s[pos] * 4 if self.wide else int(self.cmap[s[pos]])
+            e = int(self.blob[((t & 0xFFFF) + col) // 4])
+            t, f = e & 0xFFFF, e >> 16
+            if f & 1:                                       # general move list
+                o = int(self.ops_start[f >> 1])
+                for w in self.ops[o + 1:o + 1 + int(self.ops[o])]:
+                    dst, src = int(w) & 0xFF, int(w) >> 8
+                    regs[dst] = (pos - start) & limit if src == 0xFF else regs.get(src, -1)
+            else:
+                assert f % self.reg_stride == 0 and f // self.reg_stride < self.nregs
+                regs[f // self.reg_stride] = (pos - start) & limit
+        state = ((t & 0xFFFF) - 320) // self.row_bytes
+        fid = int(self.final_id[state])
+        if state == 0 or fid == 0xFFFF:
+            return None
+        caps = []
+        for sl in range(self.nslots):
+            m = int(self.final_map[fid * self.nslots + sl])
+            caps.append(len(s) if m == 0xFF else -1 if m == 0xFE else regs.get(m, -1) + start)
+        return caps

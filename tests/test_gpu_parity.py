@@ -489,3 +489,67 @@ def test_run_captures_on_both_kernels(torch_dev):
                 else:
                     assert status[i] == B.LC_MATCH and list(caps[i]) == [v for be in want for v in be][2:], (pat, s)
     assert checked == 2 * len(RUN_CAPTURE_PATTERNS) * len(RUN_CAPTURE_SUBJECTS)
+
+
+@pytest.mark.parametrize("compact", ["256", "512", "1024"])
+def test_compact_kernels_and_their_long_line_second_pass(torch_dev, monkeypatch, compact):
+    """Opt-in COMPACT kernel variants (LC_TDFA_COMPACT when the pattern is compiled): 16-bit offsets, swizzled staging,
+    1024 = byte-indexed rows; lines of 64 KiB and more are left to a second launch of the 32-bit kernel.  Lengths around
+    the boundary, captures at both ends, resumed searches, and the bench corpus."""
+    monkeypatch.setenv("LC_TDFA_COMPACT", compact)
+    pattern = rb"(\w+) (\d+) (.*)\|(\w*)"
+    rx = B.GpuRegex(pattern)
+    assert rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None
+    lens = [0, 1, 20, 65534, 65535, 65536, 65537, 70001, 131072, 300]
+    subs = []
+    for i, n in enumerate(lens):
+        body = b"key 12345 " + b"x" * max(0, n - 14) + b"|end"
+        subs.append(body[:n] if n < 14 else body)
+    subs += [b"key 1 " + b"y" * 65600, b"no match " * 8000]
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    assert exp_status.sum() >= 7
+    # search pattern resumed deep inside a long line: offsets are relative to the resume point inside the kernel
+    srx = B.GpuRegex(rb"(\d+)=(\w+)", syntax_flags=B.LC_SYNTAX_SEARCH)
+    assert srx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None
+    line = b"-" * 70000 + b" 77=ab " + b"-" * 70000 + b" 8=c"
+    d_data = torch_dev.from_numpy(np.frombuffer(line, np.uint8).copy()).cuda()
+    d_off = torch_dev.zeros(1, dtype=torch_dev.int32, device="cuda")
+    d_len = torch_dev.tensor([len(line)], dtype=torch_dev.int32, device="cuda")
+    got = []
+    for frm in (0, 69990, 70007, 140000):
+        d_from = torch_dev.tensor([frm], dtype=torch_dev.int32, device="cuda")
+        d_caps = torch_dev.full((1, 2 * srx.groups), -7, dtype=torch_dev.int32, device="cuda")
+        d_status = torch_dev.full((1,), 9, dtype=torch_dev.uint8, device="cuda")
+        srx.match_device_from(d_data, d_off, d_len, 1, d_caps, d_status, d_from=d_from, engine=B.LC_ENGINE_TDFA)
+        torch_dev.cuda.synchronize()
+        got.append((int(d_status[0]), d_caps.cpu().numpy()[0].tolist()))
+    a, b = 70001, 140008
+    assert got == [(1, [a, a + 5, a, a + 2, a + 3, a + 5]), (1, [a, a + 5, a, a + 2, a + 3, a + 5]),
+                   (1, [b, b + 3, b, b + 1, b + 2, b + 3]), (1, [b, b + 3, b, b + 1, b + 2, b + 3])], got
+    for kind, regex in (("A", corpus.REGEX_A), ("B", corpus.REGEX_B)):
+        data, off, length = corpus.apache_batch(5000, kind, poison_every=13)
+        brx = B.GpuRegex(regex)
+        assert brx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None
+        exp_caps, exp_status = OracleRegex(regex).fullmatch_batch(data, off[:-1], length)
+        caps, status = run_device(torch_dev, brx, data, off, None, sep=1, engine=B.LC_ENGINE_TDFA)
+        assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_large_batch_takes_the_compact_kernel_and_stays_bit_exact(torch_dev, kind):
+    """>= 64 Ki lines: the launcher picks the 16-bit-register kernel + the 32-bit mop-up launch (gpu_runtime.hip launchTdfa).
+    Matching and poisoned lines against the oracle, both input forms."""
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    rx = B.GpuRegex(pattern)
+    assert rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None
+    n = 70000
+    data, off, length = corpus.apache_batch(n, kind, poison_every=11)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    caps, status = run_device(torch_dev, rx, data, off, None, sep=1)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    caps2, status2 = run_device(torch_dev, rx, data, off[:-1], length)
+    assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps)
+    assert 0 < exp_status.sum() < n

@@ -224,3 +224,33 @@ def test_run_captures_on_both_table_formats():
     for pat in (rb"(?=(a+))a*", rb"(?=(.*?))a", rb"(?!(.*))a", rb"(?=(a*)b)a*b"):
         with pytest.raises(B.RegexUnsupportedError):
             B.GpuRegex(pat)
+
+
+@pytest.mark.parametrize("compact", ["256", "1024"])
+def test_packed_tdfa_blobs_walk_like_the_logical_tables(golden_dir, monkeypatch, compact):
+    """device_tables.h as the kernels address it: the standard blob (class-indexed rows, 32-bit registers) and the tables of
+    the opt-in COMPACT kernel variants (16-bit registers; 1024 = byte-indexed rows, small automata only) against the
+    logical-table interpreter."""
+    from tests.helpers.table_interp import TdfaBlobInterp
+    monkeypatch.setenv("LC_TDFA_COMPACT", compact)
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    wide = checked = 0
+    for c in golden["cases"][::5]:
+        try:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), engine=B.LC_ENGINE_TDFA)
+        except B.RegexUnsupportedError:
+            continue
+        ref = TdfaInterp(rx)
+        interps = [TdfaBlobInterp(rx)]
+        if rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None:
+            wide += 1
+            interps.append(TdfaBlobInterp(rx, compact=True))
+            assert interps[-1].block == int(compact) and interps[-1].wide == (compact == "1024")
+        for s, _ in c["subs"]:
+            s = s.encode("latin-1")
+            want = ref.fullmatch(s)
+            checked += 1
+            for it in interps:
+                assert it.fullmatch(s) == want, (c["p"], s, it.compact)
+    assert checked > 500 and wide > 50
