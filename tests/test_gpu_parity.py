@@ -554,4 +554,4 @@ def test_large_batch_takes_the_compact_kernel_and_stays_bit_exact(torch_dev, kin
                                caps[bad[0]].tolist(), exp_caps[bad[0]].tolist(), int(length[bad[0]]))
     same(*run_device(torch_dev, rx, data, off, None, sep=1))
     same(*run_device(torch_dev, rx, data, off[:-1], length))
-    assert 0 < exp_status.sum() < n
+    assert kind == "B" or 0 < exp_status.sum() < n      # the poisoned lines still satisfy the permissive regex B
