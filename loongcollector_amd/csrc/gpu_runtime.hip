@@ -123,8 +123,12 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
         const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfa.nRegs, wb);
         if (wb == kLcTdfaWideBlock)
             rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        else if (wb == 512 && re->tdfaWideBlob[TD_OFF_PAIR])
+            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         else if (wb == 512)
             rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        else if (re->tdfaWideBlob[TD_OFF_PAIR])
+            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         else
             rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
         if (rc != LC_OK) return rc;

@@ -186,15 +186,16 @@ struct TdfaPairInfo {
 };
 typedef const uint16_t __attribute__((address_space(3))) * LdsHalfPtr;
 
-template <int BLOCK, bool CHECKED, int NB>
+template <int BLOCK, bool CHECKED, int NB, typename TdfaReg = uint32_t>
 __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
                                                   uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
                                                   uint32_t tid, const TdfaPairInfo& pi, uint32_t singleRowBytes) {
-    typedef uint32_t TdfaReg;
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
     const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
-    constexpr uint32_t kRegShift = (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8));  // log2(BLOCK * sizeof(TdfaReg))
+    static_assert((BLOCK & (BLOCK - 1)) == 0 && BLOCK >= 64 && BLOCK <= 1024, "register stride must be a power of two");
+    constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                   (sizeof(TdfaReg) == 2 ? 1 : 0);  // log2(BLOCK * sizeof(TdfaReg))
     const uint32_t entry = t;
     uint32_t col[NB / 2], tt[NB / 2];
 #pragma unroll
@@ -233,8 +234,8 @@ __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t 
             q.w = words[3 % (NB / 4)];
         }
         const uint32_t state = ((entry & 0xFFFFu) - pi.base) / pi.rowBytes;
-        tdfaReplayChunk<BLOCK, uint32_t, false>(smem, q, TD_TRANS_OFFSET + state * singleRowBytes, base, L, idCol, regsBase, tid,
-                                                NB);
+        tdfaReplayChunk<BLOCK, TdfaReg, false>(smem, q, TD_TRANS_OFFSET + state * singleRowBytes, base, L, idCol, regsBase, tid,
+                                               NB);
     }
     return t;
 }
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
-    static_assert(!(COMPACT && PAIR) && (COMPACT || !BYTEROWS), "no pair extension / byte rows outside the compact variants");
+    static_assert(!(BYTEROWS && PAIR) && (COMPACT || !BYTEROWS), "byte rows: compact only, and no pair extension");
     constexpr bool WIDE = BYTEROWS;
     typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type TdfaReg;
     // staging rows: padded to 80 bytes (conflict-free b128 reads), or -- COMPACT -- 64 bytes with the 16-byte segments of
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
 #if LC_TDFA_CHUNK == 16
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
             if constexpr (PAIR) {
-                if (__all(full)) t = tdfaStepPairs<BLOCK, false, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
-                else t = tdfaStepPairs<BLOCK, true, 16>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                if (__all(full)) t = tdfaStepPairs<BLOCK, false, 16, TdfaReg>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                else t = tdfaStepPairs<BLOCK, true, 16, TdfaReg>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
             } else {
                 if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
                 else t = tdfaStepBytes<BLOCK, true, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
@@ -404,11 +405,11 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
             const uint32_t w0[2] = {q.x, q.y}, w1[2] = {q.z, q.w};
             if constexpr (PAIR) {
                 if (__all(full)) {
-                    t = tdfaStepPairs<BLOCK, false, 8>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
-                    t = tdfaStepPairs<BLOCK, false, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, false, 8, TdfaReg>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, false, 8, TdfaReg>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
                 } else {
-                    t = tdfaStepPairs<BLOCK, true, 8>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
-                    t = tdfaStepPairs<BLOCK, true, 8>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, true, 8, TdfaReg>(smem, w0, t, base, L, idCol, regsBase, tid, pi, rowBytes);
+                    t = tdfaStepPairs<BLOCK, true, 8, TdfaReg>(smem, w1, t, base + 8, L, idCol, regsBase, tid, pi, rowBytes);
                 }
             } else if (__all(full)) {
                 t = tdfaStepBytes<BLOCK, false, 8, TdfaReg, WIDE>(smem, w0, t, base, L, idCol, regsBase, tid);

@@ -346,11 +346,13 @@ def test_prefix_mode_on_both_kernels(torch_dev, golden_dir):
     assert not bad, bad[:5]
 
 
-def test_byte_pair_transition_tables_are_bit_exact(torch_dev, golden_dir, monkeypatch):
+@pytest.mark.parametrize("compact", ["0", "256", "512"])
+def test_byte_pair_transition_tables_are_bit_exact(torch_dev, golden_dir, monkeypatch, compact):
     """Opt-in byte-pair stepping of the TDFA kernel (LC_TDFA_PAIR=1 at compile time of the pattern): one dependent LDS
     lookup per two bytes; same results as the single-byte table on the golden vectors, the bench corpus and resumed
-    searches."""
+    searches -- on the 32-bit kernel and on the compact (16-bit register) variants."""
     monkeypatch.setenv("LC_TDFA_PAIR", "1")
+    monkeypatch.setenv("LC_TDFA_COMPACT", compact)
     with open(os.path.join(golden_dir, "regex_golden.json")) as f:
         golden = json.load(f)
     bad, checked, paired = [], 0, 0
