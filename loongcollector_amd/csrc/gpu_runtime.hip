@@ -57,8 +57,9 @@ static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     if (!*slot) {
         const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob : (which == kBlobTdfaWide ? re->tdfaWideBlob : re->nfaBlob);
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, blob.size() * 4));
-        hipError_t e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
+        HIP_TRY(hipMalloc(&p, blob.size() * 4 + 16));  // + one word behind the tables: the compact kernel's long-line flag
+        hipError_t e = hipMemset(p, 0, blob.size() * 4 + 16);
+        if (e == hipSuccess) e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(p);
             return hipFail(e, "hipMemcpy(tables)");
@@ -88,7 +89,7 @@ void lcReleaseDeviceTables(lc_regex* re) {
 template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
-                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
+                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>),
@@ -97,7 +98,8 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
-                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status,
+                       longFlag, seq);
     HIP_TRY(hipGetLastError());
     return LC_OK;
 }
@@ -113,24 +115,28 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     // leave).  Two launches only pay on batches large enough to fill the chip several times over.
     constexpr uint32_t kCompactMinLines = 1u << 16;
     uint32_t minLen = 0;
+    uint32_t* longFlag = nullptr;
+    uint32_t seq = 0;
     if (!re->tdfaWideBlob.empty() && (re->tdfaWideForced || n >= kCompactMinLines)) {
         void* dWide = nullptr;
         rc = ensureUploaded(re, dev, kBlobTdfaWide, &dWide);
         if (rc != LC_OK) return rc;
         const uint32_t wideBytes = uint32_t(re->tdfaWideBlob.size() * 4);
+        longFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dWide) + wideBytes);
+        seq = ++re->tdfaWideSeq[dev];
         const int wb = re->tdfaWideBlock;
         const uint32_t wRegBytes = uint32_t(size_t(re->tdfa.nRegs + 1) * size_t(wb) * 2);
         const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfa.nRegs, wb);
         if (wb == kLcTdfaWideBlock)
-            rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+            rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
         else if (wb == 512 && re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
         else if (wb == 512)
-            rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+            rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
         else if (re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
         else
-            rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+            rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
         if (rc != LC_OK) return rc;
         minLen = kTdfaWideMaxLine + 1;
     }
@@ -146,9 +152,9 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
     const bool pair = re->tdfaBlob[TD_OFF_PAIR] != 0 && !pairOff;
     switch (block) {
-        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
     }
 }
 

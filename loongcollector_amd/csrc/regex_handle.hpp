@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -34,6 +35,7 @@ struct lc_regex {
     std::mutex deviceMutex;
     void* dTdfaBlob[kLcMaxDevices] = {};
     void* dTdfaWideBlob[kLcMaxDevices] = {};
+    std::atomic<uint32_t> tdfaWideSeq[kLcMaxDevices] = {};  // launch sequence numbers of the compact kernel (its long-line flag)
     void* dNfaBlob[kLcMaxDevices] = {};
 };
 

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ resume,
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
-                                                           int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
+                                                           int32_t* __restrict__ caps, uint8_t* __restrict__ status,
+                                                           uint32_t* __restrict__ longFlag, uint32_t launchSeq) {
     static_assert(!(BYTEROWS && PAIR) && (COMPACT || !BYTEROWS), "byte rows: compact only, and no pair extension");
     constexpr bool WIDE = BYTEROWS;
     typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type TdfaReg;
@@ -266,6 +267,9 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         const uint32_t dyn = *nLinesPtr;
         nLines = dyn < nLines ? dyn : nLines;
     }
+    // The COMPACT launch raises *longFlag to its sequence number when it meets a line it has to leave behind; the mop-up
+    // launch that follows it on the stream has nothing to do while the flag is older than that.
+    if (minLen && longFlag && __atomic_load_n(longFlag, __ATOMIC_RELAXED) < launchSeq) return;
     if (minLen) {  // mop-up launch: usually no line of this workgroup is long enough -- leave before staging the tables
         const uint32_t s0 = blockIdx.x * BLOCK + tid;
         bool mine = false;
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
             }
         }
         if ((COMPACT && L > kTdfaWideMaxLine) || L < minLen) {  // another launch decides this line
+            if (COMPACT && L > kTdfaWideMaxLine && longFlag) atomicMax(longFlag, launchSeq);
             live = false;
             L = 0;
         }
