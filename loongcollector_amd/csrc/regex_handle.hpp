@@ -45,7 +45,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide = f
 // tables of the COMPACT kernel variant (LC_TDFA_COMPACT picks it; empty: switched off, or the automaton is too large)
 std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut);
 size_t tdfaBlobBytesEstimate(const TdfaTables& t);
-// throws RegexError when the NFA does not fit the device format (more than 64 byte classes)
+// throws RegexError when the NFA does not fit the device format (more than 128 byte classes, follow lists over 64 paths ...)
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);
 }  // namespace lcregex
 
@@ -63,7 +63,8 @@ inline size_t lcTdfaStageBytes(int block) { return size_t(block / 64) * 64 * (LC
 inline size_t lcTdfaLdsBytes(uint32_t blobBytes, uint32_t nRegs, int block) {
     return size_t(blobBytes) + lcTdfaRegBytes(nRegs, block) + lcTdfaStageBytes(block);
 }
-// WIDE kernel (tdfa_kernel.hpp): one 1024-lane workgroup per CU, 16-bit offset registers, 16 unpadded staging tiles
+// COMPACT kernel variants (tdfa_kernel.hpp): 16-bit offset registers, unpadded staging tiles; the byte-indexed one runs as
+// one 1024-lane workgroup per CU
 constexpr int kLcTdfaWideBlock = 1024;
 inline size_t lcTdfaWideRegBytes(uint32_t nRegs) { return size_t(nRegs + 1) * kLcTdfaWideBlock * 2; }
 inline size_t lcTdfaWideLdsBytes(uint32_t blobBytes, uint32_t nRegs) {
