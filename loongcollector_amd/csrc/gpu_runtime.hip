@@ -11,6 +11,8 @@
 // Byte-scan work: no MFMA.  The bound that matters is LDS lookup throughput / latency, then HBM.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -201,43 +203,26 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
-    if (slots <= 8) {
-        if (atomic && global) return launchNfaSlots<8, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<8, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<8, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<8, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }
-    if (slots <= 16) {
-        if (atomic && global) return launchNfaSlots<16, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<16, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<16, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<16, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }
-    if (slots <= 32) {
-        if (atomic && global) return launchNfaSlots<32, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<32, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<32, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<32, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }
-    if (slots <= 64) {
-        if (atomic && global) return launchNfaSlots<64, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<64, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<64, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<64, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }    if (slots <= 128) {  // 33..64 groups: 4 tag words per aux entry
-        if (atomic && global) return launchNfaSlots<128, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<128, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<128, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<128, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }
-
-    {   // up to 320 slots (160 groups): 10 tag words per aux entry; the offsets of a thread no longer fit the 256
-        // architected VGPRs of a lane, the rest lives in accumulation registers
-        if (atomic && global) return launchNfaSlots<320, true, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (atomic) return launchNfaSlots<320, true, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        if (global) return launchNfaSlots<320, false, true>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        return launchNfaSlots<320, false, false>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-    }
+    // kernel instance by capture slots carried per thread (VGPRs), atomic groups, tables in LDS or read from HBM
+    auto launch = [&](auto ns) {
+        constexpr int NS = decltype(ns)::value;
+        auto go = [&](auto a, auto g) {
+            return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n,
+                                                                              d_order, d_resume, ngroups, d_caps, d_status, stream);
+        };
+        if (atomic && global) return go(std::true_type{}, std::true_type{});
+        if (atomic) return go(std::true_type{}, std::false_type{});
+        if (global) return go(std::false_type{}, std::true_type{});
+        return go(std::false_type{}, std::false_type{});
+    };
+    if (slots <= 8) return launch(std::integral_constant<int, 8>{});
+    if (slots <= 16) return launch(std::integral_constant<int, 16>{});
+    if (slots <= 32) return launch(std::integral_constant<int, 32>{});
+    if (slots <= 64) return launch(std::integral_constant<int, 64>{});
+    if (slots <= 128) return launch(std::integral_constant<int, 128>{});  // 4 tag words per aux entry
+    // up to 320 slots (160 groups): 10 tag words per aux entry; a thread's offsets no longer fit the 256 architected VGPRs
+    // of a lane, the rest lives in accumulation registers
+    return launch(std::integral_constant<int, 320>{});
 }
 
 // Groups written "(?=(S*))" (regex_ast.hpp Node::runCapture, Grok's "(?=%{GREEDYDATA:message})"): the automata stamp only

@@ -1,6 +1,8 @@
-"""Values for the two example_config Grok patterns that need the wide table formats of the NFA engine: %{HTTPD_ERRORLOG}
-(68 byte classes: 4-word class masks) and %{HAPROXYHTTP} (52 named groups = 106 capture slots: 4 tag words per aux entry,
-NS=128 kernel).  Well-formed lines of each format plus seeded one-byte mutations of them."""
+"""Values for the four example_config Grok patterns that need the extensions of the NFA engine: %{HTTPD_ERRORLOG} (68 byte
+classes: 4-word class masks), %{HAPROXYHTTP} (53 groups = 106 capture slots: 4 tag words per aux entry, NS=128 kernel),
+%{NAGIOSLOGLINE} (139 groups = 278 slots: 10 tag words, NS=320 kernel) and %{SYSLOGPAMSESSION} (a run capture,
+"(?=%{GREEDYDATA:message})").  Well-formed lines of each format plus seeded one-byte mutations of them; below, patterns and
+subjects for run captures on their own."""
 import random
 
 WIDE_PATTERNS = ["HTTPD_ERRORLOG", "HAPROXYHTTP"]
