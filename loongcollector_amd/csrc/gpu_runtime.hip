@@ -23,6 +23,7 @@
 #include "grok_kernel.hpp"
 #include "grok_runtime.hpp"
 #include "nfa_kernel.hpp"
+#include "nfa_wide_kernel.hpp"
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
 #include "split_kernel.hpp"
@@ -161,9 +162,9 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
 }
 
 template <int NS, bool ATOMIC, bool GLOBAL>
-static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, const uint8_t* d_data,
+static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
-                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream) {
+                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq) {
     static thread_local size_t ldsAttrSet = 0;
     if (lds > 64 * 1024 && lds > ldsAttrSet) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS, ATOMIC, GLOBAL>),
@@ -172,8 +173,21 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, size_t lds, con
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
     hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status);
+                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
+                       seq);
     HIP_TRY(hipGetLastError());
+    // Second chance for the lines that needed more than 64 live threads (nfa_wide_kernel.hpp: two threads per lane), for
+    // patterns without atomic groups whose capture offsets fit twice into a lane's registers.  Its workgroups return at
+    // once unless the launch above raised the overflow flag.
+    if constexpr (!ATOMIC && NS <= 64) {
+        static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
+        const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4;
+        if (!wideOff && overflowFlag && wideLds <= 64 * 1024) {
+            hipLaunchKernelGGL((nfa_wide_kernel<NS>), dim3(n), dim3(64), wideLds, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
+                               d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, overflowFlag, seq);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     return LC_OK;
 }
 
@@ -203,12 +217,17 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return LC_ERR_UNSUPPORTED;
     }
     const int slots = re->nfa.slotCount();
+    const uint32_t nPos = uint32_t(re->nfa.positions.size());
+    // one word behind the tables (ensureUploaded): raised by the kernel to this launch's sequence number when a line overflows
+    uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
+    const uint32_t seq = ++re->nfaSeq[dev];
     // kernel instance by capture slots carried per thread (VGPRs), atomic groups, tables in LDS or read from HBM
     auto launch = [&](auto ns) {
         constexpr int NS = decltype(ns)::value;
         auto go = [&](auto a, auto g) {
-            return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, lds, d_data, d_off, d_len, sep, n, d_n,
-                                                                              d_order, d_resume, ngroups, d_caps, d_status, stream);
+            return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n,
+                                                                              d_n, d_order, d_resume, ngroups, d_caps, d_status,
+                                                                              stream, overflowFlag, seq);
         };
         if (atomic && global) return go(std::true_type{}, std::true_type{});
         if (atomic) return go(std::true_type{}, std::false_type{});

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                                                               const uint32_t* __restrict__ blob,
                                                               uint32_t blobBytes, uint32_t nGroupsOut,
                                                               int32_t* __restrict__ caps,
-                                                              uint8_t* __restrict__ status) {
+                                                              uint8_t* __restrict__ status,
+                                                              uint32_t* __restrict__ overflowFlag, uint32_t launchSeq) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     if (nLinesPtr) {  // line count produced on the device (split kernels) -- no host round trip between the launches
@@ -626,6 +627,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             }
         }
         status[line] = overflow ? LC_OVERFLOW : (matched ? LC_MATCH : LC_NOMATCH);
+        // tell the second-chance launch (nfa_wide_kernel.hpp) behind this one that there is something to do
+        if (overflow && overflowFlag) atomicMax(overflowFlag, launchSeq);
     }
     for (uint32_t s = NS + lane; s < 2 * nGroupsOut; s += 64) out[s] = -1;
 }

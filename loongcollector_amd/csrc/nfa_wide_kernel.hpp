@@ -1,0 +1,220 @@
+// nfa_wide_kernel.hpp -- second chance for lines the NFA kernel gave up on (included by gpu_runtime.hip only).
+//
+// nfa_match_kernel keeps one Pike-VM thread per lane: a line that needs more than 64 live threads at some byte is
+// reported LC_OVERFLOW.  On BASELINE configs[2] that happens to 0.04 % of the values (CISCOFW305011 on an IPv6 address
+// peaks at 71 threads).  This kernel decides those: same algorithm, same tables, but every lane holds TWO threads
+// (thread T lives in lane T & 63, slot T >> 6), so a line may have 128 live threads.  It is launched behind every
+// launch of the NFA kernel on the same stream and costs a launch of empty workgroups unless that kernel raised its
+// overflow flag (launch sequence number, atomicMax -- the same protocol as the TDFA kernel's long-line flag).
+//
+// One line per 64-lane workgroup; the tables are read in place from HBM/L2 (this is the rare path: no LDS staging, no
+// steady-state shortcut, no start-byte skip); LDS holds the election marks and the hand-off arrays only.  Patterns with
+// atomic groups are not handled here (their ordered commit pass is serial in lane 0 and has its own 64-entry work
+// arrays): their lines stay LC_OVERFLOW.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/lc_regex_gpu.h"
+#include "device_tables.h"
+#include "nfa_kernel.hpp"
+
+constexpr int kNfaWideThreads = 128;
+
+// exclusive scan over the 128 thread slots (slot 0 of all lanes first, then slot 1)
+__device__ __forceinline__ void nfaWideScan(uint32_t v0, uint32_t v1, uint32_t lane, uint32_t& e0, uint32_t& e1, uint32_t& total) {
+    uint32_t t0, t1;
+    e0 = waveExclusiveScan(v0, lane, t0);
+    e1 = waveExclusiveScan(v1, lane, t1) + t0;
+    total = t0 + t1;
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                      const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                      const uint32_t* __restrict__ nLinesPtr,
+                                                      const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ resume,
+                                                      const uint32_t* __restrict__ blob, uint32_t nGroupsOut,
+                                                      int32_t* __restrict__ caps, uint8_t* __restrict__ status,
+                                                      const uint32_t* __restrict__ overflowFlag, uint32_t launchSeq) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (__atomic_load_n(overflowFlag, __ATOMIC_RELAXED) < launchSeq) return;  // the NFA kernel decided every line
+    if (nLinesPtr) {
+        const uint32_t dyn = *nLinesPtr;
+        nLines = dyn < nLines ? dyn : nLines;
+    }
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= nLines) return;
+    const uint32_t line = order ? order[slot] : slot;
+    if (status[line] != LC_OVERFLOW) return;
+
+    const uint8_t* tbl = reinterpret_cast<const uint8_t*>(blob);
+    const uint32_t* hdr = blob;
+    const uint32_t nPos = hdr[NF_NPOS];
+    const uint32_t nSlots = hdr[NF_NSLOTS];
+    const uint8_t* classMap = tbl + hdr[NF_OFF_CLASSMAP];
+    const uint32_t* behindBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_BEHIND]);
+    const uint32_t* aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
+    const uint32_t edgeClass = hdr[NF_NCLASSES];
+    constexpr int TW = NS > 128 ? 10 : (NS > 64 ? 4 : 2);
+    NfaTables tb;
+    tb.followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
+    tb.paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
+    tb.aux = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AUX]);
+    tb.auxShift = TW == 10 ? 4 : (TW == 4 ? 3 : 2);
+    tb.posMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_POSMASK]);
+    tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
+
+    // LDS: best[nPos] then newPos / newSrc / newAux for 128 threads
+    uint32_t* best = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* newPos = best + ((nPos + 3) & ~3u);
+    uint32_t* newSrc = newPos + kNfaWideThreads;
+    uint32_t* newAux = newSrc + kNfaWideThreads;
+    for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
+    waveLdsSync();
+
+    const uint32_t o = off[line];
+    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    uint32_t from = 0;
+    uint32_t prevCls = edgeClass;
+    // thread T = lane + 64 * k: position pos[k], capture offsets cap[k][]
+    uint32_t pos[2] = {nPos, nPos};  // lane 0, slot 0: the start pseudo-position
+    int32_t cap[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cap[0][s] = cap[1][s] = -1;
+    if (resume) {
+        from = resume[line];
+        from = from < L ? from : L;
+        if (from) {
+            pos[0] = 0;
+            prevCls = classMap[data[size_t(o) + from - 1]];
+        }
+    }
+    uint32_t nThreads = 1;
+    bool overflow = false;
+
+    for (uint32_t i = from; i < L && nThreads && !overflow; ++i) {
+        const uint32_t cls = classMap[data[size_t(o) + i]];  // wave-uniform address: one broadcast load
+        const uint32_t cw = cls >> 5, cb = cls & 31u;
+        const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];
+        prevCls = cls;
+        const bool live0 = lane < nThreads, live1 = lane + 64 < nThreads;
+        const uint32_t fs0 = live0 ? tb.followStart[pos[0]] : 0, fs1 = live1 ? tb.followStart[pos[1]] : 0;
+        const uint32_t cnt0 = live0 ? tb.followStart[pos[0] + 1] - fs0 : 0, cnt1 = live1 ? tb.followStart[pos[1] + 1] - fs1 : 0;
+        uint32_t rank0, rank1, totalCand;
+        nfaWideScan(cnt0, cnt1, lane, rank0, rank1, totalCand);
+        uint32_t totalWins = 0;
+        for (uint32_t r0 = 0; r0 < totalCand && !overflow; r0 += 64) {
+            const uint32_t cand = r0 + lane;  // one candidate (thread, path) per lane, in priority order
+            uint32_t src = 0, q = 0;
+            for (uint32_t t = 0; t < nThreads; ++t) {
+                const int l = int(t & 63u);
+                const uint32_t tb0 = t < 64 ? __shfl(rank0, l, 64) : __shfl(rank1, l, 64);
+                const uint32_t tn = t < 64 ? __shfl(cnt0, l, 64) : __shfl(cnt1, l, 64);
+                const uint32_t tf = t < 64 ? __shfl(fs0, l, 64) : __shfl(fs1, l, 64);
+                if (cand >= tb0 && cand < tb0 + tn) {
+                    src = t;
+                    q = tf + (cand - tb0);
+                }
+            }
+            bool pass = false;
+            uint4 p{0, 0, 0, 0};
+            if (cand < totalCand) {
+                p = nfaPath(tb, q);
+                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, tb.maskShift, p.x, cw, cb);
+                if (pass) atomicMin(&best[p.x], cand);
+            }
+            waveLdsSync();
+            const bool win = pass && best[p.x] == cand;
+            const uint64_t wins = __ballot(win);
+            const uint32_t nWins = uint32_t(__popcll(wins));
+            if (totalWins + nWins > uint32_t(kNfaWideThreads)) {
+                overflow = true;
+                break;
+            }
+            if (win) {
+                const uint32_t w = totalWins + uint32_t(__popcll(wins & ((uint64_t(1) << lane) - 1)));
+                newPos[w] = p.x;
+                newSrc[w] = src;
+                newAux[w] = p.z;
+            }
+            totalWins += nWins;
+        }
+        if (overflow) break;
+        waveLdsSync();
+        for (uint32_t w = lane; w < totalWins; w += 64) best[newPos[w]] = 0xFFFFFFFFu;  // clear the election marks
+        waveLdsSync();
+        nThreads = totalWins;
+        // every lane takes over threads `lane` and `lane + 64` of the new list; captures come from the source thread
+        int srcLane[2] = {int(lane), int(lane)};
+        bool srcHi[2] = {false, false};
+        uint32_t tags[2][TW] = {};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t T = lane + 64u * uint32_t(k);
+            pos[k] = 0;
+            if (T < nThreads) {
+                pos[k] = newPos[T];
+                const uint32_t src = newSrc[T];
+                srcLane[k] = int(src & 63u);
+                srcHi[k] = src >= 64;
+                const uint32_t* a = tb.aux + (newAux[T] << tb.auxShift) + 1;
+#pragma unroll
+                for (int j = 0; j < TW; ++j) tags[k][j] = a[j];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {  // slot by slot: all four reads of the old values happen before the two writes
+            if (uint32_t(s) < nSlots) {
+                const int32_t a0 = __shfl(cap[0][s], srcLane[0], 64), a1 = __shfl(cap[1][s], srcLane[0], 64);
+                const int32_t b0 = __shfl(cap[0][s], srcLane[1], 64), b1 = __shfl(cap[1][s], srcLane[1], 64);
+                cap[0][s] = ((tags[0][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[0] ? a1 : a0);
+                cap[1][s] = ((tags[1][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[1] ? b1 : b0);
+            }
+        }
+        waveLdsSync();
+    }
+
+    // acceptance at end of input: first thread in priority order with a MATCH path whose assertions hold
+    bool acc[2] = {false, false};
+    uint32_t endAux[2] = {0, 0};
+    if (!overflow) {
+        const uint32_t ctrue = behindBits[prevCls] | aheadBits[edgeClass];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (lane + 64u * uint32_t(k) >= nThreads) continue;
+            const uint32_t fs = tb.followStart[pos[k]], fe = tb.followStart[pos[k] + 1];
+            for (uint32_t q = fs; q < fe; ++q) {
+                const uint4 p = nfaPath(tb, q);
+                if (p.x == NF_TARGET_MATCH && (p.y & ~ctrue) == 0) {
+                    acc[k] = true;
+                    endAux[k] = p.z;
+                    break;
+                }
+            }
+        }
+    }
+    const uint64_t a0 = __ballot(acc[0]), a1 = __ballot(acc[1]);
+    const bool matched = (a0 | a1) != 0;
+    const int wk = a0 ? 0 : 1;  // slot 0 threads outrank slot 1 threads
+    const uint32_t winner = matched ? uint32_t(__ffsll((long long)(a0 ? a0 : a1))) - 1 : 0;
+    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
+    if (lane == winner) {
+        uint32_t endTags[TW];
+        const uint32_t ea = wk == 0 ? endAux[0] : endAux[1];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) endTags[j] = tb.aux[(ea << tb.auxShift) + 1 + j];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (uint32_t(s) < 2 * nGroupsOut) {
+                int32_t v = -1;
+                if (matched && uint32_t(s) < nSlots)
+                    v = ((endTags[s >> 5] >> (s & 31)) & 1u) ? int32_t(L) : (wk == 0 ? cap[0][s] : cap[1][s]);
+                out[s] = v;
+            }
+        }
+        status[line] = overflow ? LC_OVERFLOW : (matched ? LC_MATCH : LC_NOMATCH);
+    }
+    for (uint32_t s = NS + lane; s < 2 * nGroupsOut; s += 64) out[s] = -1;
+}

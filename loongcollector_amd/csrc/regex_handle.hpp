@@ -35,6 +35,7 @@ struct lc_regex {
     std::mutex deviceMutex;
     void* dTdfaBlob[kLcMaxDevices] = {};
     void* dTdfaWideBlob[kLcMaxDevices] = {};
+    std::atomic<uint32_t> nfaSeq[kLcMaxDevices] = {};      // launch sequence numbers of the NFA kernel (its overflow flag)
     std::atomic<uint32_t> tdfaWideSeq[kLcMaxDevices] = {};  // launch sequence numbers of the compact kernel (its long-line flag)
     void* dNfaBlob[kLcMaxDevices] = {};
 };

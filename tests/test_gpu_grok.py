@@ -183,3 +183,23 @@ def test_wide_table_patterns_against_the_oracle(torch_dev, golden_dir, name):
         assert [(k, bytes(x)) for k, x in f] == [(k, bytes(x)) for k, x in want], (name, v)
         matched += bool(want)
     assert matched >= 5
+
+
+def test_values_that_need_more_than_64_threads_are_decided(torch_dev, golden_dir):
+    """CISCOFW305011 on an IPv6 address peaks at 71 live NFA threads: the second-chance kernel (two threads per lane) has
+    to decide those values -- none may come back as -2, and the fields must be the oracle's."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    match = ["%{CISCOFW305011}"]
+    g = Grok(Match=match, CustomPatterns=cfg3["custom_patterns"])
+    o = GrokOracle(match, custom_patterns=cfg3["custom_patterns"])
+    values = [v for v in grok_lines(16384) if v.startswith(b"Built dynamic")][:600]
+    pattern, fields = g.match_host(values)
+    assert (np.asarray(pattern) != -2).all()
+    hit = 0
+    for v, p, f in zip(values, pattern, fields):
+        _, want = o.process_value(v)
+        assert [(k, bytes(x)) for k, x in f] == [(k, bytes(x)) for k, x in want], v
+        hit += bool(want)
+    assert hit >= 500

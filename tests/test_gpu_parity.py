@@ -119,12 +119,37 @@ def test_auto_falls_back_to_nfa_kernel_when_tdfa_explodes(torch_dev):
     assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
 
 
-def test_nfa_thread_overflow_is_reported_not_guessed(torch_dev):
+def test_nfa_thread_overflow_second_chance_and_report(torch_dev):
+    """More than 64 live threads: the NFA kernel reports LC_OVERFLOW and raises its flag, the two-threads-per-lane kernel
+    behind it (nfa_wide_kernel.hpp) decides the line; more than 128 is still reported, never guessed."""
     # on "aaaa..." every one of the 70 '.' positions is alive at once: more than 64 simultaneous threads
-    rx = B.GpuRegex(r".*a.{70}", engine=B.LC_ENGINE_NFA)
-    data, off, length = pack([b"a" * 100, b"b" * 10, b"a" + b"b" * 70])
-    caps, status = run_device(torch_dev, rx, data, off, length)
-    assert list(status) == [B.LC_OVERFLOW, B.LC_NOMATCH, B.LC_MATCH]
+    pattern = r"(.*)a(.{70})"
+    subs = [b"a" * 100, b"b" * 10, b"a" + b"b" * 70, b"xa" * 80, b"a" * 71]
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    rx = B.GpuRegex(pattern, engine=B.LC_ENGINE_NFA)
+    caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    assert list(exp_status) == [1, 0, 1, 1, 1]
+    # a search pattern, resumed inside the line
+    srx = B.GpuRegex(r"a(.{70})b", syntax_flags=B.LC_SYNTAX_SEARCH, engine=B.LC_ENGINE_NFA)
+    line = b"b" + b"a" * 90 + b"b" + b"a" * 80 + b"b"
+    d_data = torch_dev.from_numpy(np.frombuffer(line, np.uint8).copy()).cuda()
+    d_off = torch_dev.zeros(1, dtype=torch_dev.int32, device="cuda")
+    d_len = torch_dev.tensor([len(line)], dtype=torch_dev.int32, device="cuda")
+    for frm in (0, 21):
+        d_from = torch_dev.tensor([frm], dtype=torch_dev.int32, device="cuda")
+        d_caps = torch_dev.full((1, 2 * srx.groups), -7, dtype=torch_dev.int32, device="cuda")
+        d_status = torch_dev.full((1,), 9, dtype=torch_dev.uint8, device="cuda")
+        srx.match_device_from(d_data, d_off, d_len, 1, d_caps, d_status, d_from=d_from, engine=B.LC_ENGINE_NFA)
+        torch_dev.cuda.synchronize()
+        o = OracleRegex(r"a(.{70})b").search(line, frm)
+        assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)
+    # beyond 128 threads: reported
+    rx2 = B.GpuRegex(r".*a.{140}", engine=B.LC_ENGINE_NFA)
+    data, off, length = pack([b"a" * 200, b"a" + b"b" * 140])
+    caps, status = run_device(torch_dev, rx2, data, off, length, engine=B.LC_ENGINE_NFA)
+    assert list(status) == [B.LC_OVERFLOW, B.LC_MATCH]
 
 
 def test_ragged_mixed_corpus_with_failures(torch_dev):
