@@ -57,7 +57,7 @@ int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per c
 /* ---- device-resident batch (inputs and outputs in HBM; nothing is copied) ------------------------------------------
  * d_off/d_len: uint32[n] byte offsets / lengths of the SourceKey values inside d_data.
  * d_pattern  int32[n]            winning Match index, -1 = matchFail, -2 = undecidable on the device (the NFA engine ran out
- *                                of its 64 threads on this value)
+ *                                of threads on this value: more than 128 live at once, 64 for a pattern with atomic groups)
  * d_first    int32[n][row]       capture row of the FIRST match that contributed a non-empty named capture:
  *                                [whole.b, whole.e, col0.b, col0.e, ...], -1 = column did not take part
  * d_extra    int32[cap][2+row]   further contributing matches of the same value (FindNextMatch): [line, seq>=1, row...]

@@ -70,7 +70,7 @@ enum {
 enum {
     LC_NOMATCH = 0,
     LC_MATCH = 1,
-    LC_OVERFLOW = 2  /* NFA engine only: more than 64 simultaneously live threads; line not decided */
+    LC_OVERFLOW = 2  /* NFA engine only: more live threads than the kernels hold (128; 64 with atomic groups); line not decided */
 };
 
 /* return codes */
