@@ -127,6 +127,10 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
         const uint32_t wideBytes = uint32_t(re->tdfaWideBlob.size() * 4);
         longFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dWide) + wideBytes);
         seq = ++re->tdfaWideSeq[dev];
+        if (seq == 0) {  // the 32-bit sequence wrapped: start over below every flag value seen so far
+            HIP_TRY(hipMemsetAsync(longFlag, 0, 4, stream));
+            seq = ++re->tdfaWideSeq[dev];
+        }
         const int wb = re->tdfaWideBlock;
         const uint32_t wRegBytes = uint32_t(size_t(re->tdfa.nRegs + 1) * size_t(wb) * 2);
         const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfa.nRegs, wb);
@@ -220,7 +224,11 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     const uint32_t nPos = uint32_t(re->nfa.positions.size());
     // one word behind the tables (ensureUploaded): raised by the kernel to this launch's sequence number when a line overflows
     uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
-    const uint32_t seq = ++re->nfaSeq[dev];
+    uint32_t seq = ++re->nfaSeq[dev];
+    if (seq == 0) {  // the 32-bit sequence wrapped: start over below every flag value seen so far
+        HIP_TRY(hipMemsetAsync(overflowFlag, 0, 4, stream));
+        seq = ++re->nfaSeq[dev];
+    }
     // kernel instance by capture slots carried per thread (VGPRs), atomic groups, tables in LDS or read from HBM
     auto launch = [&](auto ns) {
         constexpr int NS = decltype(ns)::value;
