@@ -46,11 +46,29 @@ class GpuUnavailableError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's) and dlopens it
+    by path; this library is linked against the SONAME.  Loaded after torch it binds to torch's copy; loaded BEFORE torch
+    (build() then smoke() in one process) the process would end up with two runtimes, and the second one to initialise
+    finds no device.  So torch's copy is mapped first whenever torch is installed -- without importing torch."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(hip):
+            ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load(path=None):
     """Load the shared library (raises OSError if it has not been built: run __graft_entry__.build())."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(path or LIB_PATH)
     vp, cp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
     L.lc_regex_compile.restype = i32
