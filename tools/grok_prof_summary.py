@@ -10,7 +10,7 @@ cur = sqlite3.connect(os.path.join(d, "r1_results.db")).cursor()
 print("## per kernel (top_kernels), times in ms")
 print("%-58s %6s %10s %9s %6s" % ("kernel", "calls", "total_ms", "avg_ms", "%"))
 for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-    print("%-58s %6d %10.3f %9.3f %6.2f" % (name[:58], calls, total / 1e6, avg / 1e6, pct))
+    print("%-58s %6d %10.3f %9.3f %6.2f" % (name[:58], calls, total / 1e3, avg / 1e3, pct))  # the view is in microseconds
 try:
     rows = list(cur.execute('select name, grid_x, ("end" - start), lds_size from kernels order by ("end" - start) desc limit 12'))
     print("\n## slowest dispatches (values handed to the automaton = grid/256*4 for the NFA kernel, grid for the TDFA kernel)")
