@@ -477,6 +477,10 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                     break;
                 }
                 nThreads = kept;
+                if (searchSkip) {  // see the vector path below; a membership could still get the suffix thread killed
+                    const uint64_t suf = __ballot(lane < nThreads && newPos[lane] == nPos - 1 && actx.newNlin[lane] == 0);
+                    if (suf) nThreads = uint32_t(__ffsll((long long)suf));
+                }
                 uint32_t src = lane;
                 uint32_t tags[TW] = {};
                 nlin = 0;
@@ -548,6 +552,13 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         if (lane < totalWins) best[newPos[lane]] = 0xFFFFFFFFu;  // clear the election marks (targets are distinct)
         waveLdsSync();
         nThreads = totalWins;
+        // Search patterns: a thread on the wrapper's suffix position ((?s:.*), the last position) takes every byte and
+        // ends on MATCH whatever follows, so nothing of lower priority can win any more -- above all the wrapper's lazy
+        // prefix thread, which would otherwise keep starting new attempts at every byte of the rest of the line.
+        if (searchSkip) {
+            const uint64_t suf = __ballot(lane < nThreads && newPos[lane] == nPos - 1);
+            if (suf) nThreads = uint32_t(__ffsll((long long)suf));
+        }
         uint32_t src = lane;
         uint32_t tags[TW] = {};
         if (lane < nThreads) {
