@@ -88,3 +88,58 @@ def test_random_atomic_patterns_tdfa_tables_vs_oracle(seed):
                     got = it.fullmatch(s)
                     assert got == want or got == "overflow", (p, s, flags, type(it).__name__)
     assert checked > 5000
+
+
+def test_random_patterns_with_run_captures_and_packed_blobs():
+    """The same differential check with a capture-only look-ahead "(?=(S*))" spliced into the random pattern, and with the
+    PACKED tables as the kernels address them (standard blob and the compact 16-bit-register blob) next to the logical
+    ones."""
+    import numpy as np
+
+    from tests.helpers.table_interp import TdfaBlobInterp
+    runs = [r"(?=(.*))", r"(?=([a-c]*))", r"(?=(?:([^ ]*)))", r"(?=(\w*))"]
+    rng = random.Random(77003)
+    g = gen.Gen(rng)
+    checked = with_runs = 0
+    for _ in range(120):
+        p, _, smp = g.alt(0)
+        if rng.random() < 0.6:
+            r = rng.choice(runs)
+            k = rng.randrange(len(p) + 1)
+            cand = p[:k] + r + p[k:]
+            try:
+                OracleRegex(cand)
+                p = cand
+            except ValueError:
+                p = r + p
+        try:
+            orx = OracleRegex(p)
+        except ValueError:
+            continue
+        for flags, oracle_fn in ((0, orx.fullmatch), (B.LC_SYNTAX_SEARCH, orx.search)):
+            try:
+                rx = B.GpuRegex(p, syntax_flags=flags)
+            except (B.RegexUnsupportedError, B.RegexSyntaxError):
+                continue
+            with_runs += bool(rx.run_captures())
+            interps = [AtomicNfaInterp(rx)] if rx.has_nfa_program() else []
+            if rx.info()["engine"] == B.LC_ENGINE_TDFA:
+                interps += [TdfaInterp(rx), TdfaBlobInterp(rx)]
+                if rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None:
+                    interps.append(TdfaBlobInterp(rx, compact=True))
+            subjects = [gen.mutate(rng, smp()) for _ in range(4)] + [gen.rand_subject(rng) for _ in range(3)]
+            if flags:
+                subjects = [gen.rand_subject(rng)[:3] + s + gen.rand_subject(rng)[:3] for s in subjects]
+            for s in subjects:
+                try:
+                    exp = oracle_fn(s)
+                except RuntimeError:      # the backtracking oracle gave up (complexity guard)
+                    continue
+                want = None if exp is None else [v for ab in (exp if flags else exp[1:]) for v in ab]
+                for it in interps:
+                    got = it.fullmatch(s)
+                    if got == "overflow":
+                        continue
+                    checked += 1
+                    assert got == want, (p, s, flags, type(it).__name__)
+    assert checked > 3000 and with_runs > 40
