@@ -516,22 +516,14 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         uint32_t totalWins = 0;
         for (uint32_t r0 = 0; r0 < totalCand; r0 += 64) {
             const uint32_t cand = r0 + lane;
-            // which thread owns candidate `cand`: the last thread whose first candidate is not after it (rankBase is a
-            // non-decreasing prefix sum; a thread without candidates shares its value with the next one).  Binary search
-            // with one cross-lane read per step instead of a scan over all threads.
-            uint32_t src = 0;
-            {
-                uint32_t hi = nThreads;  // rankBase[src] <= cand < rankBase[hi] (hi = nThreads: the total)
-#pragma unroll
-                for (int step = 0; step < 6; ++step) {
-                    const uint32_t mid = (src + hi) >> 1;
-                    const uint32_t r = __shfl(rankBase, int(mid), 64);
-                    const bool go = hi - src > 1;
-                    if (go && r <= cand) src = mid;
-                    else if (go) hi = mid;
+            uint32_t src = 0, q = 0;
+            for (uint32_t t = 0; t < nThreads; ++t) {  // which thread owns candidate `cand`
+                const uint32_t tb = __shfl(rankBase, int(t), 64), tn = __shfl(cnt, int(t), 64), tf = __shfl(fs, int(t), 64);
+                if (cand >= tb && cand < tb + tn) {
+                    src = t;
+                    q = tf + (cand - tb);
                 }
             }
-            const uint32_t q = __shfl(fs, int(src), 64) + (cand - __shfl(rankBase, int(src), 64));
             bool pass = false;
             uint4 p{0, 0, 0, 0};
             if (cand < totalCand) {

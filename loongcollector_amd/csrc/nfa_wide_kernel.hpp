@@ -107,25 +107,17 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         uint32_t totalWins = 0;
         for (uint32_t r0 = 0; r0 < totalCand && !overflow; r0 += 64) {
             const uint32_t cand = r0 + lane;  // one candidate (thread, path) per lane, in priority order
-            // the thread that owns the candidate: binary search over the 128 prefix sums (nfa_kernel.hpp)
-            auto rankOf = [&](uint32_t t) {
-                const uint32_t a = __shfl(rank0, int(t & 63u), 64), b = __shfl(rank1, int(t & 63u), 64);
-                return t < 64 ? a : b;
-            };
-            uint32_t src = 0;
-            {
-                uint32_t hi = nThreads;
-#pragma unroll
-                for (int step = 0; step < 7; ++step) {
-                    const uint32_t mid = (src + hi) >> 1;
-                    const uint32_t r = rankOf(mid);
-                    const bool go = hi - src > 1;
-                    if (go && r <= cand) src = mid;
-                    else if (go) hi = mid;
+            uint32_t src = 0, q = 0;
+            for (uint32_t t = 0; t < nThreads; ++t) {
+                const int l = int(t & 63u);
+                const uint32_t tb0 = t < 64 ? __shfl(rank0, l, 64) : __shfl(rank1, l, 64);
+                const uint32_t tn = t < 64 ? __shfl(cnt0, l, 64) : __shfl(cnt1, l, 64);
+                const uint32_t tf = t < 64 ? __shfl(fs0, l, 64) : __shfl(fs1, l, 64);
+                if (cand >= tb0 && cand < tb0 + tn) {
+                    src = t;
+                    q = tf + (cand - tb0);
                 }
             }
-            const uint32_t f0 = __shfl(fs0, int(src & 63u), 64), f1 = __shfl(fs1, int(src & 63u), 64);
-            const uint32_t q = (src < 64 ? f0 : f1) + (cand - rankOf(src));
             bool pass = false;
             uint4 p{0, 0, 0, 0};
             if (cand < totalCand) {
