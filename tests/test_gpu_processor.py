@@ -129,7 +129,7 @@ def test_dlsym_slot_end_to_end():
     class Instance(ctypes.Structure):
         _fields_ = [("plugin", ctypes.c_void_p), ("plugin_state", ctypes.c_void_p)]
 
-    lib = ctypes.CDLL(B.LIB_PATH)
+    lib = B.load()
     iface = Iface.in_dll(lib, "processor_interface")
     assert iface.version == 100
     ins = Instance()

@@ -99,7 +99,7 @@ def test_processor_interface_symbol_matches_cprocessor_h_layout():
         _fields_ = [("version", ctypes.c_int), ("name", ctypes.c_char_p), ("language", ctypes.c_char_p),
                     ("init", ctypes.c_void_p), ("finalize", ctypes.c_void_p), ("process", ctypes.c_void_p)]
 
-    lib = ctypes.CDLL(B.LIB_PATH)
+    lib = B.load()
     iface = Iface.in_dll(lib, "processor_interface")
     assert iface.version == 100                       # PROCESSOR_INTERFACE_VERSION, CProcessor.h:23
     assert iface.name == b"processor_parse_regex_gpu"
