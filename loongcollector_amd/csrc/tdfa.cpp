@@ -2,6 +2,8 @@
 #include "tdfa.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <string>
@@ -356,7 +358,16 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     transRows.emplace_back(size_t(ncls), 0u);       // dead row
     int maxRegs = 0;
     bool usedTmp = false;
+    uint64_t pathWork = 0;  // epsilon paths looked at so far (a config-supplied pattern must not buy minutes of Init)
+    std::vector<uint32_t> targetSeen(nfa.positions.size(), 0u);
+    uint32_t seenStamp = 0;
 
+    struct WorkReport {
+        const uint64_t& w;
+        ~WorkReport() {
+            if (getenv("LC_TDFA_WORK_DEBUG")) fprintf(stderr, "tdfa pathWork %llu\n", (unsigned long long)w);
+        }
+    } workReport{pathWork};
     while (!work.empty()) {
         uint32_t sid = work.front();
         work.pop_front();
@@ -368,14 +379,22 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             const uint32_t holds = S.prevCtx | nfa.aheadBits(int(b));
             std::vector<Cand> cands;
             const bool atomic = nfa.atomicCount > 0;
+            ++seenStamp;
             for (size_t k = 0; k < S.items.size(); ++k) {
+                pathWork += nfa.follow[S.items[k].pos].size();
                 for (const auto& path : nfa.follow[S.items[k].pos]) {
                     const bool targetOk = path.target >= 0 && nfa.positions[path.target].has(b);
                     if (!atomic && (!targetOk || (path.cond & ~holds))) continue;  // cannot influence anything
+                    if (!atomic) {  // without memberships the first path that reaches a position is the only one that counts
+                        if (targetSeen[size_t(path.target)] == seenStamp) continue;
+                        targetSeen[size_t(path.target)] = seenStamp;
+                    }
                     cands.push_back(Cand{path.target, int(k), path.tags, S.items[k].lin,
                                          atomic ? &path.atoms : nullptr, targetOk, path.cond});
                 }
             }
+            if (pathWork > limits.maxPathWork)
+                throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
             std::vector<Cand> ni = commitAtomic(std::move(cands), holds);
             if (ni.empty()) continue;  // -> dead
             State Tn;

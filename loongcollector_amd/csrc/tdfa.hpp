@@ -33,6 +33,9 @@ struct TdfaTables {
 
 struct TdfaLimits {
     uint32_t maxStates = 4096;
+    // epsilon paths the construction may look at: the densest automata that still fit a table (and the Grok monsters
+    // that fail on maxStates) stay under 0.7 M; "(a?){200}a{200}" would spend minutes before failing on the table size
+    uint64_t maxPathWork = 8u << 20;
 };
 
 // Throws RegexError("tdfa: ...") when the automaton exceeds the limits (caller falls back to the NFA engine).

@@ -254,3 +254,27 @@ def test_packed_tdfa_blobs_walk_like_the_logical_tables(golden_dir, monkeypatch,
             for it in interps:
                 assert it.fullmatch(s) == want, (c["p"], s, it.compact)
     assert checked > 500 and wide > 50
+
+
+def test_hostile_patterns_fail_fast_or_compile_fast():
+    """A pattern comes from a configuration file: whatever it is, Init must answer quickly -- compile, or refuse with a
+    reason.  ("(a?){200}a{200}" used to spend two minutes in the tagged-DFA construction before being refused.)"""
+    import time
+    pats = [
+        r"(?:a{1000}){1000}", r"((a*)*)*b", r"(a|aa)+$", "(" * 5000 + "a" + ")" * 5000, "|".join("w%d" % i for i in range(20000)),
+        r"(?:[a-z]{1,64}\.){1,64}[a-z]{2,63}", r"(a?){200}a{200}", r"(?>(?>(?>a+)+)+)+b", r"[\x00-\xff]{65535}", r"a{0,100000}",
+        r"(x+x+)+y", r"(?:(?:(?:(?:(?:a|b)*c)*d)*e)*f)*g", "(?=(" + "a" * 100000 + "*))b", r"\b" * 10000 + "a",
+        "(?i)" + "abcdefghijklmnopqrstuvwxyz" * 200, "(" * 70 + "a" + ")" * 70, "[" + "a-z" * 50000 + "]",
+    ]
+    outcomes = {"ok": 0, "refused": 0}
+    for p in pats:
+        for flags in (0, B.LC_SYNTAX_SEARCH):
+            t0 = time.time()
+            try:
+                B.GpuRegex(p.encode(), syntax_flags=flags)
+                outcomes["ok"] += 1
+            except (B.RegexUnsupportedError, B.RegexSyntaxError) as e:
+                assert str(e)
+                outcomes["refused"] += 1
+            assert time.time() - t0 < 10, (p[:40], time.time() - t0)
+    assert outcomes["ok"] >= 10 and outcomes["refused"] >= 10
