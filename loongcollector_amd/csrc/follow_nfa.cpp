@@ -2,6 +2,8 @@
 #include "follow_nfa.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace lcregex {
 
@@ -180,16 +182,26 @@ private:
     size_t steps = 0;
     int exitVisits = 0;
 
+public:
+    // walk steps + duplicate checks summed over ALL follow lists of a pattern: the per-list limit alone lets a pattern
+    // with thousands of positions buy minutes ("(?>(?>a?){50}){50}")
+    static constexpr uint64_t kMaxTotalWork = uint64_t(16) << 20;  // the largest library pattern needs 1.4 M
+    uint64_t totalWork = 0;
+
+private:
+
     void add(int target, TagSet tags, uint32_t cond, const std::vector<FollowPath::Event>& atoms) {
         // a later path to the same target (same atomic history) whose condition set includes an earlier one's can
         // never win
+        if ((totalWork += out.size()) > kMaxTotalWork) throw RegexError("unsupported: epsilon closure too large");
         for (const auto& p : out)
             if (p.target == target && (p.cond & ~cond) == 0 && p.atoms == atoms) return;
         if (out.size() >= 4096) throw RegexError("unsupported: too many epsilon paths");
         out.push_back({target, tags, cond, atoms});
     }
     void walk(int pc, TagSet tags, uint32_t cond, std::vector<FollowPath::Event>& atoms, int depth) {
-        if (++steps > 2000000 || depth > 100000) throw RegexError("unsupported: epsilon closure too large");
+        if (++steps > 2000000 || depth > 100000 || ++totalWork > kMaxTotalWork)
+            throw RegexError("unsupported: epsilon closure too large");
         const size_t mark = atoms.size();
         for (;;) {
             const Inst& in = code[pc];
@@ -238,6 +250,7 @@ FollowNfa buildFollowNfa(const ParsedRegex& re) {
     for (int pc = 0; pc < int(b.code.size()); ++pc)
         if (b.code[pc].op == Inst::Char) nfa.follow[b.code[pc].x] = walker.from(pc + 1);
     nfa.follow[npos] = walker.from(0);
+    if (getenv("LC_TDFA_WORK_DEBUG")) fprintf(stderr, "follow totalWork %llu\n", (unsigned long long)walker.totalWork);
     for (auto& lst : nfa.follow)
         for (auto& p : lst) nfa.condsUsed |= p.cond;
     return nfa;

@@ -49,6 +49,11 @@ struct Cand {
 //   * A failing assertion stops a live path there; what it did before still happened.
 // Survivors with a consumable target are kept; memberships nobody can act on any more are dropped and indistinguishable
 // survivors collapse onto the first.
+// pair tests of the redundancy elimination below, summed over one buildTdfa() call (reset there): the elimination is
+// cubic in the number of survivors of a step, and a configuration file must not be able to buy minutes of Init
+thread_local uint64_t tlsCommitWork = 0;
+constexpr uint64_t kMaxCommitWork = 20u << 20;  // 4x what the densest pattern that still fits needs (5.5 M)
+
 std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
     struct Closure {
         int g, seg, src, visit;
@@ -125,10 +130,13 @@ std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
         auto& lin = kept[i].lin;
         for (size_t k = 0; k < lin.size();) {
             bool contested = !lin[k].exited;  // still inside: always kept
-            if (lin[k].exited)
+            if (lin[k].exited) {
                 for (size_t j = 0; j < i && !contested; ++j)
                     for (const auto& e : kept[j].lin)
                         if (e.g == lin[k].g && e.seg == lin[k].seg && !e.exited) contested = true;
+                if ((tlsCommitWork += i) > kMaxCommitWork)
+                    throw RegexError("tdfa: construction work limit (atomic groups: too many concurrent alternatives)");
+            }
             if (contested) ++k;
             else lin.erase(lin.begin() + long(k));
         }
@@ -140,8 +148,21 @@ std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
     //       inside, or no survivor below lo belongs to it;
     // lo then mirrors hi move for move at lower priority, can never outlive it and never changes anybody's fate.
     // (Dropping one survivor can make another one redundant, so repeat until nothing changes.)
-    std::vector<Cand> out = std::move(kept);
+    std::vector<Cand> out;
+    {  // survivors without any membership: the first one on a position makes every later one redundant -- settled in one
+       // linear pass, the cubic machinery below only sees what is left
+        std::map<int, bool> plainSeen;
+        out.reserve(kept.size());
+        for (auto& c : kept) {
+            if (c.lin.empty()) {
+                auto ins = plainSeen.emplace(c.pos, true);
+                if (!ins.second) continue;
+            }
+            out.push_back(std::move(c));
+        }
+    }
     auto holds_ = [](const Cand& c, const LinEntry& e, bool insideOnly) {
+        ++tlsCommitWork;
         for (const auto& x : c.lin)
             if (x.g == e.g && x.seg == e.seg && (!insideOnly || !x.exited)) return true;
         return false;
@@ -177,6 +198,7 @@ std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
             for (const auto& b : sigma)
                 if (same(a.first, b.second) || (same(a.first, b.first) != same(a.second, b.second))) return false;
         std::vector<size_t> dom, ran;
+        tlsCommitWork += out.size();
         for (size_t i = 0; i < out.size(); ++i) {
             bool inDom = false, inRan = false;
             for (const auto& e : out[i].lin)
@@ -209,6 +231,8 @@ std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
         changed = false;
         for (size_t i = 1; i < out.size() && !changed; ++i)
             for (size_t j = 0; j < i && !changed; ++j) {
+                if (++tlsCommitWork > kMaxCommitWork)
+                    throw RegexError("tdfa: construction work limit (atomic groups: too many concurrent alternatives)");
                 std::vector<size_t> drop;
                 if (mirrors(j, i)) {
                     out.erase(out.begin() + long(i));
@@ -358,6 +382,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     transRows.emplace_back(size_t(ncls), 0u);       // dead row
     int maxRegs = 0;
     bool usedTmp = false;
+    tlsCommitWork = 0;
     uint64_t pathWork = 0;  // epsilon paths looked at so far (a config-supplied pattern must not buy minutes of Init)
     std::vector<uint32_t> targetSeen(nfa.positions.size(), 0u);
     uint32_t seenStamp = 0;
@@ -365,7 +390,8 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     struct WorkReport {
         const uint64_t& w;
         ~WorkReport() {
-            if (getenv("LC_TDFA_WORK_DEBUG")) fprintf(stderr, "tdfa pathWork %llu\n", (unsigned long long)w);
+            if (getenv("LC_TDFA_WORK_DEBUG"))
+                fprintf(stderr, "tdfa pathWork %llu commitWork %llu\n", (unsigned long long)w, (unsigned long long)tlsCommitWork);
         }
     } workReport{pathWork};
     while (!work.empty()) {
