@@ -224,6 +224,8 @@ void PatternLibrary::build() {
     }
 }
 
+constexpr size_t kMaxExpandedBytes = size_t(1) << 20;
+
 std::string PatternLibrary::denormalize(const std::string& patternIn) {
     std::string pattern = patternIn;
     for (const auto& tok : findTokens(patternIn)) {  // the token list is taken from the ORIGINAL text (:283)
@@ -239,7 +241,13 @@ std::string PatternLibrary::denormalize(const std::string& patternIn) {
         } else {
             repl = "(" + stored->second + ")";
         }
+        // "%{A}%{A}" over "%{B}%{B}" over ... doubles the text per level: the reference would grind on until it runs out of
+        // memory; the largest expansion of the shipped library is 7 KB (HAPROXYHTTP), the regex compiler stops at 1 MiB
+        if (pattern.size() + repl.size() > kMaxExpandedBytes)
+            throw GrokError("pattern grows beyond " + std::to_string(kMaxExpandedBytes) + " bytes while expanding %{" + tok.body + "}");
         replaceAll(pattern, "%{" + tok.body + "}", repl);  // every occurrence of the same token text (:312)
+        if (pattern.size() > kMaxExpandedBytes)
+            throw GrokError("pattern grows beyond " + std::to_string(kMaxExpandedBytes) + " bytes while expanding %{" + tok.body + "}");
     }
     return pattern;
 }

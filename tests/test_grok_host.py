@@ -75,6 +75,8 @@ def test_library_only_handles_expand_every_default_pattern_like_the_oracle():
     ({"Match": ["%{NOPE:x}"]}, "no pattern found for NOPE"),                                         # processor_grok.go:296
     ({"CustomPatterns": {"X": "%{WORD:a:bogus}"}}, "invalid pattern"),                               # :248
     ({"Match": [r"(\w+) \1"]}, "back-references"),                                                   # no device engine
+    ({"CustomPatterns": dict([("P0", "a")] + [("P%d" % i, "%%{P%d}%%{P%d}" % (i - 1, i - 1)) for i in range(1, 40)]),
+      "Match": ["%{P39}"]}, "grows beyond"),                                                        # 2^39 copies of "a"
 ])
 def test_init_errors(cfg, needle):
     with pytest.raises(GrokInitError) as e:
