@@ -162,7 +162,16 @@ private:
         }
         return out;
     }
+    // nesting guard (jsoncpp, the reference's parser, stops at stackLimit = 1000 as well): value() recurses
+    struct Depth {
+        int& d;
+        explicit Depth(int& x) : d(x) { ++d; }
+        ~Depth() { --d; }
+    };
+    int depth = 0;
     Value value() {
+        Depth guard(depth);
+        if (depth > 1000) fail("nesting too deep");
         ws();
         if (i >= s.size()) fail("unexpected end");
         char c = s[i];

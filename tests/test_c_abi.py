@@ -46,3 +46,15 @@ def test_match_calls_fail_loudly_without_a_device():
 def test_info_reports_engine_and_sizes():
     info = B.GpuRegex(r"(\w+)\t(\w+).*").info()
     assert info["engine"] == B.LC_ENGINE_TDFA and info["mark_count"] == 2 and info["states"] > 2
+
+
+def test_config_json_nesting_is_bounded():
+    """jsoncpp (the reference's parser) stops at 1000 levels; the plugins' JSON reader must not run out of stack either"""
+    from loongcollector_amd.multiline import Multiline
+    L = B.load()
+    for deep in (b'{"a":' + b"[" * 200000 + b"]" * 200000 + b"}", b'{"a":' * 100000 + b"1" + b"}" * 100000):
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(256)
+        Multiline(StartPattern="x")  # binds the argtypes
+        assert L.lc_multiline_create(deep, len(deep), ctypes.byref(h), err, 256) != 0
+        assert b"nesting too deep" in err.value
