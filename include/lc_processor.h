@@ -44,7 +44,11 @@ enum {
     LC_CNT_IN_SIZE_BYTES = 6,         /* instance: in_size_bytes */
     LC_CNT_OUT_SIZE_BYTES = 7,        /* instance: out_size_bytes */
     LC_CNT_PROCESS_TIME_US = 8,       /* instance: total_process_time (microseconds) */
-    LC_CNT_COUNT = 9
+    LC_CNT_COMPLEXITY_EXCEEDED = 9,   /* no reference counterpart: lines the depth-first decide kernel gave up on (LC_GAVE_UP);
+                                         counted in out_failed_events_total too, like boost's complexity exception */
+    LC_CNT_UNDECIDED_EVENTS = 10,     /* no reference counterpart: lines left LC_OVERFLOW because the decide pass was switched
+                                         off; such events pass through untouched and are in NO other plugin counter */
+    LC_CNT_COUNT = 11
 };
 
 /* config_json: the plugin's JSON object, e.g.

@@ -63,14 +63,23 @@ enum {
 enum {
     LC_ENGINE_AUTO = 0,  /* TDFA if it fits the limits, else NFA */
     LC_ENGINE_TDFA = 1,  /* tagged DFA: one line per lane, tables in LDS */
-    LC_ENGINE_NFA = 2    /* follow NFA: one line per wavefront, one lane per live thread */
+    LC_ENGINE_NFA = 2,   /* follow NFA: one line per wavefront, one lane per live thread */
+    LC_ENGINE_DECIDE = 3 /* match calls only (not lc_regex_compile): skip the thread-list kernels and settle EVERY line with the
+                            depth-first decide kernel that normally only sees the lines they overflow on.  Slow (one lane per
+                            line); for cross-checking the engines against each other and for diagnosis */
 };
 
 /* per-line status bytes */
 enum {
     LC_NOMATCH = 0,
     LC_MATCH = 1,
-    LC_OVERFLOW = 2  /* NFA engine only: more live threads than the kernels hold (128; 64 with atomic groups); line not decided */
+    LC_OVERFLOW = 2, /* transient, NFA engine only: more live threads than the thread-list kernels hold (128; 64 with atomic
+                        groups).  Every match entry point launches the depth-first decide kernel behind them, which settles
+                        these lines -- a caller only ever sees this value if the decide pass was switched off (LC_NFA_NO_DECIDE) */
+    LC_GAVE_UP = 3   /* the decide kernel ran out of its step budget (plain backtracking, when the memo of an extremely long
+                        line does not fit the scratch pool) or of scratch: the counterpart of boost's complexity-exceeded
+                        exception, which the reference counts as a parse failure (core/common/StringTools.cpp:200-205).
+                        Processors treat it as a failed parse AND count it separately (never silently) */
 };
 
 /* return codes */
@@ -219,6 +228,15 @@ int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* lines, const
 
 /* last HIP error string of the calling thread (for LC_ERR_HIP) */
 const char* lc_last_error(void);
+
+/* Frees the device resources the CALLING thread accumulated inside the match entry points (pinned staging slots, streams,
+ * the decide kernel's scratch pool).  They are otherwise released when the thread ends; a host that recycles runner threads
+ * (ProcessorRunner, core/runner/ProcessorRunner.cpp:138-142) may call this when a thread goes idle.  Safe to call any time. */
+void lc_thread_release(void);
+
+/* Statistics of the calling thread's decide passes since the last call: lines[0] = lines the thread-list kernels left
+ * undecided and the decide kernel settled, lines[1] = of those, reported LC_GAVE_UP.  Synchronises the thread's streams. */
+int lc_decide_stats(uint64_t lines[2]);
 
 #ifdef __cplusplus
 }

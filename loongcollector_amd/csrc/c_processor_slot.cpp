@@ -103,6 +103,8 @@ extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CN
     out[LC_CNT_IN_SIZE_BYTES] = p->inBytes;
     out[LC_CNT_OUT_SIZE_BYTES] = p->outBytes;
     out[LC_CNT_PROCESS_TIME_US] = p->processUs;
+    out[LC_CNT_COMPLEXITY_EXCEEDED] = p->impl.mComplexityExceededEventsTotal;
+    out[LC_CNT_UNDECIDED_EVENTS] = p->impl.mUndecidedEventsTotal;
     return LC_OK;
 }
 

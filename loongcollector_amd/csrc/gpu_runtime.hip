@@ -14,6 +14,9 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -24,6 +27,7 @@
 #include "grok_runtime.hpp"
 #include "nfa_kernel.hpp"
 #include "nfa_wide_kernel.hpp"
+#include "nfa_decide_kernel.hpp"
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
 #include "split_kernel.hpp"
@@ -42,6 +46,18 @@ static int hipFail(hipError_t e, const char* what) {
     } while (0)
 
 extern "C" const char* lc_last_error(void) { return tlsError.c_str(); }
+
+// Per-thread device resources (staging pipeline, Grok buffers, the decide pool) are freed by thread_local destructors.  A
+// thread that ends while the process is already exiting must not call into a HIP runtime that may be gone: an atexit
+// hook registered at first use (so it runs BEFORE the runtime's own teardown) turns those destructors into no-ops.
+// lc_thread_release() frees the calling thread's resources explicitly; a host that recycles runner threads calls it.
+static std::atomic<bool> gProcessExiting{false};
+static void lcMarkExiting() { gProcessExiting.store(true); }
+static void lcRegisterExitHook() {
+    static std::once_flag once;
+    std::call_once(once, [] { atexit(lcMarkExiting); });
+}
+static bool lcRuntimeUsable() { return !gProcessExiting.load(); }
 
 extern "C" int lc_device_count(void) {
     int n = 0;
@@ -93,11 +109,13 @@ template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0) {
-    static thread_local size_t ldsAttrSet = 0;
-    if (lds > 64 * 1024 && lds > ldsAttrSet) {
+    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
+    int devNow = 0;
+    if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
+    if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        ldsAttrSet = lds;
+        ldsAttrSet[devNow] = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
@@ -165,15 +183,91 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ decide pool
+// Scratch of the depth-first decide kernel (nfa_decide_kernel.hpp): one pool per host thread and device, allocated the first
+// time the thread launches an NFA program whose thread lists can overflow.  Launches of one thread on different streams
+// share the pool, so they are chained through an event (the decide launches only: the match kernels still overlap).
+namespace {
+struct DecidePool {
+    uint8_t* p = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    hipEvent_t lastUse = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool used = false;
+    uint64_t settled = 0, gaveUp = 0;  // accumulated by lc_decide_stats
+    ~DecidePool() { release(); }
+    void release() {
+        if (p && lcRuntimeUsable()) {
+            (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+            if (lastUse) (void)hipEventDestroy(lastUse);
+        }
+        p = nullptr;
+        bytes = 0;
+        device = -1;
+        lastUse = nullptr;
+        used = false;
+    }
+};
+thread_local DecidePool tlsDecidePool;
+
+size_t decidePoolBytes() {
+    static const size_t v = [] {
+        const char* e = getenv("LC_DECIDE_POOL_MB");
+        long mb = e ? atol(e) : 256;
+        if (mb < 8) mb = 8;
+        return size_t(mb) << 20;
+    }();
+    return v;
+}
+}  // namespace
+
+// The thread-list kernels of this launch may have left lines LC_OVERFLOW: settle them (plan + walk, both no-ops unless the
+// overflow flag carries this launch's sequence number).
+static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                        uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                        uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag,
+                        uint32_t seq, bool forced = false) {
+    static const bool off = getenv("LC_NFA_NO_DECIDE") != nullptr;
+    if (off && !forced) return LC_OK;
+    DecidePool& pool = tlsDecidePool;
+    lcRegisterExitHook();
+    if (pool.device != dev || !pool.p) {
+        pool.release();
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pool.p), decidePoolBytes()));
+        pool.bytes = decidePoolBytes();
+        pool.device = dev;
+        HIP_TRY(hipEventCreateWithFlags(&pool.lastUse, hipEventDisableTiming));
+        HIP_TRY(hipMemsetAsync(pool.p, 0, kDecideHeaderBytes, stream));
+    }
+    if (pool.used && pool.lastStream != stream) HIP_TRY(hipStreamWaitEvent(stream, pool.lastUse, 0));
+    const DecideShape shape{re->decideClosedCap, re->decideMaxEnter};
+    const uint32_t nPos = uint32_t(re->nfa.positions.size());
+    hipLaunchKernelGGL(nfa_decide_plan_kernel, dim3(1), dim3(256), 0, stream, d_off, d_len, sep, n, d_n, d_order, d_resume, nPos, shape,
+                       d_status, overflowFlag, seq, pool.p, uint64_t(pool.bytes));
+    hipLaunchKernelGGL(nfa_decide_kernel, dim3(kDecideWorkers), dim3(64), 0, stream, d_data, d_off, d_len, sep, d_resume,
+                       static_cast<const uint32_t*>(dBlob), shape, ngroups, d_caps, d_status, overflowFlag, seq, pool.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(pool.lastUse, stream));
+    pool.lastStream = stream;
+    pool.used = true;
+    return LC_OK;
+}
+
 template <int NS, bool ATOMIC, bool GLOBAL>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq) {
-    static thread_local size_t ldsAttrSet = 0;
-    if (lds > 64 * 1024 && lds > ldsAttrSet) {
+    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
+    int devNow = 0;
+    if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
+    if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS, ATOMIC, GLOBAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        ldsAttrSet = lds;
+        ldsAttrSet[devNow] = lds;
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
     hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
@@ -197,7 +291,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
 
 static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
-                     uint8_t* d_status, hipStream_t stream) {
+                     uint8_t* d_status, hipStream_t stream, bool decideOnly = false) {
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
         return LC_ERR_UNSUPPORTED;
@@ -229,6 +323,13 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         HIP_TRY(hipMemsetAsync(overflowFlag, 0, 4, stream));
         seq = ++re->nfaSeq[dev];
     }
+    if (decideOnly) {  // LC_ENGINE_DECIDE: every line goes to the depth-first walk
+        hipLaunchKernelGGL(nfa_decide_mark_all_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_n, d_order, d_status,
+                           overflowFlag, seq);
+        HIP_TRY(hipGetLastError());
+        return launchDecide(re, dev, dBlob, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
+                            overflowFlag, seq, true);
+    }
     // kernel instance by capture slots carried per thread (VGPRs), atomic groups, tables in LDS or read from HBM
     auto launch = [&](auto ns) {
         constexpr int NS = decltype(ns)::value;
@@ -242,14 +343,21 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         if (global) return go(std::false_type{}, std::true_type{});
         return go(std::false_type{}, std::false_type{});
     };
-    if (slots <= 8) return launch(std::integral_constant<int, 8>{});
-    if (slots <= 16) return launch(std::integral_constant<int, 16>{});
-    if (slots <= 32) return launch(std::integral_constant<int, 32>{});
-    if (slots <= 64) return launch(std::integral_constant<int, 64>{});
-    if (slots <= 128) return launch(std::integral_constant<int, 128>{});  // 4 tag words per aux entry
+    if (slots <= 8) rc = launch(std::integral_constant<int, 8>{});
+    else if (slots <= 16) rc = launch(std::integral_constant<int, 16>{});
+    else if (slots <= 32) rc = launch(std::integral_constant<int, 32>{});
+    else if (slots <= 64) rc = launch(std::integral_constant<int, 64>{});
+    else if (slots <= 128) rc = launch(std::integral_constant<int, 128>{});  // 4 tag words per aux entry
     // up to 320 slots (160 groups): 10 tag words per aux entry; a thread's offsets no longer fit the 256 architected VGPRs
     // of a lane, the rest lives in accumulation registers
-    return launch(std::integral_constant<int, 320>{});
+    else rc = launch(std::integral_constant<int, 320>{});
+    if (rc != LC_OK) return rc;
+    // Can a thread list overflow at all?  Without atomic groups a list holds at most one thread per position.
+    const bool wideApplies = !atomic && slots <= 64 && (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4 <= 64 * 1024;
+    const bool canOverflow = atomic || nPos > (wideApplies ? uint32_t(kNfaWideThreads) : 64u);
+    if (!canOverflow) return LC_OK;
+    return launchDecide(re, dev, dBlob, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
+                        overflowFlag, seq);
 }
 
 // Groups written "(?=(S*))" (regex_ast.hpp Node::runCapture, Grok's "(?=%{GREEDYDATA:message})"): the automata stamp only
@@ -297,7 +405,8 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         }
         rc = launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     } else {
-        rc = launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        rc = launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
+                       engine == LC_ENGINE_DECIDE);
     }
     if (rc != LC_OK) return rc;
     for (const auto& rg : re->nfa.runGroups) {
@@ -444,6 +553,7 @@ extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, cons
 }
 
 // ------------------------------------------------------------------------------------------------ host batches
+static void lcGrokThreadRelease();
 namespace {
 
 struct Slot {
@@ -471,6 +581,10 @@ struct HostPipeline {
     ~HostPipeline() { release(); }
     void release() {
         if (device < 0) return;
+        if (!lcRuntimeUsable()) {  // process exit: the runtime may be gone, the OS reclaims everything
+            device = -1;
+            return;
+        }
         (void)hipSetDevice(device);
         for (auto& s : slots) {
             if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -485,6 +599,8 @@ struct HostPipeline {
         device = -1;
     }
 };
+
+thread_local HostPipeline* tlsPipe = nullptr;  // for lc_thread_release
 
 constexpr size_t kChunkBytes = 32u << 20;   // payload bytes per pipelined chunk
 constexpr uint32_t kChunkLines = 1u << 18;  // and at most this many lines
@@ -558,10 +674,27 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     static thread_local HostPipeline pipe;
+    lcRegisterExitHook();
+    tlsPipe = &pipe;
     if (pipe.device != dev) {
         pipe.release();
         pipe.device = dev;
     }
+    // Whatever way this call ends, no slot may stay `busy`: the next call on this thread would otherwise drain a stale
+    // chunk (its first/count) into the new caller's buffers.  On an error path the guard waits for both streams and
+    // drops what was in flight without copying anything out.
+    struct DrainGuard {
+        HostPipeline& p;
+        ~DrainGuard() {
+            for (auto& s : p.slots) {
+                if (!s.busy) continue;
+                if (s.stream) (void)hipStreamSynchronize(s.stream);
+                s.busy = false;
+                s.first = s.count = 0;
+            }
+            (void)hipGetLastError();
+        }
+    } guard{pipe};
     uint32_t next = 0;
     int which = 0;
     int rc = LC_OK;
@@ -623,6 +756,27 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
 }
 
 }  // namespace
+
+extern "C" void lc_thread_release(void) {
+    if (tlsPipe) tlsPipe->release();
+    tlsDecidePool.release();
+    lcGrokThreadRelease();
+}
+
+extern "C" int lc_decide_stats(uint64_t lines[2]) {
+    if (!lines) return LC_ERR_ARG;
+    DecidePool& pool = tlsDecidePool;
+    lines[0] = lines[1] = 0;
+    if (!pool.p || !pool.used) return LC_OK;
+    // (per-launch numbers live in the pool header; a caller that wants them per batch calls this after each batch)
+    HIP_TRY(hipSetDevice(pool.device));
+    HIP_TRY(hipEventSynchronize(pool.lastUse));
+    DecidePlan plan;
+    HIP_TRY(hipMemcpy(&plan, pool.p, sizeof plan, hipMemcpyDeviceToHost));
+    lines[0] = plan.count;
+    lines[1] = plan.gaveUp;
+    return LC_OK;
+}
 
 extern "C" int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len,
                                    uint32_t n, uint32_t ngroups, int32_t* caps, uint8_t* status) {
@@ -771,6 +925,42 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
     return LC_OK;
 }
 
+// device buffers of a thread that calls lcGrokMatchHost: grow-only, kept between calls (ProcessLogs hands over group after group)
+namespace {
+struct GrokDev {
+    void* p = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    ~GrokDev() { release(); }
+    void release() {
+        if (p && lcRuntimeUsable()) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        device = -1;
+    }
+    hipError_t ensure(size_t bytes, int dev) {
+        if (p && device == dev && cap >= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + (bytes >> 2) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) {
+            cap = want;
+            device = dev;
+        }
+        return e;
+    }
+};
+struct GrokThreadBuffers {
+    GrokDev b[8];
+};
+thread_local GrokThreadBuffers tlsGrokBuffers;
+}  // namespace
+static void lcGrokThreadRelease() {
+    for (auto& d : tlsGrokBuffers.b) d.release();
+}
+
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* data, const uint32_t* off,
                     const uint32_t* len, uint32_t n, int32_t* pattern, std::vector<int32_t>& first,
                     std::vector<int32_t>& extraRows) {
@@ -792,29 +982,9 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t row
     std::vector<uint8_t> hData(bytes + 16);
     for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
 
-    // device buffers of the calling thread: grow-only, kept between calls (ProcessLogs hands over group after group)
-    struct Dev {
-        void* p = nullptr;
-        size_t cap = 0;
-        int device = -1;
-        ~Dev() {
-            if (p) (void)hipFree(p);
-        }
-        hipError_t ensure(size_t bytes, int dev) {
-            if (p && device == dev && cap >= bytes) return hipSuccess;
-            if (p) (void)hipFree(p);
-            p = nullptr;
-            cap = 0;
-            const size_t want = bytes + (bytes >> 2) + 256;
-            hipError_t e = hipMalloc(&p, want);
-            if (e == hipSuccess) {
-                cap = want;
-                device = dev;
-            }
-            return e;
-        }
-    };
-    static thread_local Dev dData, dOff, dLen, dPattern, dFirst, dExtra, dNextra, dScratch;
+    GrokThreadBuffers& gb = tlsGrokBuffers;
+    lcRegisterExitHook();
+    GrokDev &dData = gb.b[0], &dOff = gb.b[1], &dLen = gb.b[2], &dPattern = gb.b[3], &dFirst = gb.b[4], &dExtra = gb.b[5], &dNextra = gb.b[6], &dScratch = gb.b[7];
     int devNo = 0;
     HIP_TRY(hipGetDevice(&devNo));
     const size_t scratch = lcGrokScratchBytes(n, row);

@@ -142,7 +142,12 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
     std::vector<uint8_t> fStart(n, 0), fCont(n, 0), fEnd(n, 0);
     auto flags = [&](lc_regex_t* re, std::vector<uint8_t>& dst) -> int {
         if (!re || n == 0) return LC_OK;
-        return lc_regex_match_host(re, data, off.data(), len.data(), n, 0, nullptr, dst.data());
+        const int r = lc_regex_match_host(re, data, off.data(), len.data(), n, 0, nullptr, dst.data());
+        if (r != LC_OK) return r;
+        // "not decided" (decide pass switched off) must not drive the state machine as "no match"
+        for (uint8_t st : dst)
+            if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;
+        return LC_OK;
     };
     int rc;
     if ((rc = flags(m->start, fStart)) != LC_OK || (rc = flags(m->cont, fCont)) != LC_OK ||

@@ -270,7 +270,15 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
             mInEventsTotal -= n;
             return false;
         }
-        for (size_t k = 0; k < ptr.size(); ++k) leafResult[l][owner[k]] = status[k] == LC_MATCH;
+        for (size_t k = 0; k < ptr.size(); ++k) {
+            // "not decided" (decide pass switched off) is neither true nor false: a NOT node would turn a guess into a keep
+            if (status[k] == LC_OVERFLOW) {
+                error = "device left a value undecided (LC_NFA_NO_DECIDE is set): group untouched";
+                mInEventsTotal -= n;
+                return false;
+            }
+            leafResult[l][owner[k]] = status[k] == LC_MATCH;
+        }
     }
 
     size_t wIdx = 0;
@@ -340,6 +348,6 @@ extern "C" int lc_filter_none_utf8(char* buf, size_t n, int modify) {
 }
 extern "C" void lc_filter_counters(const lc_filter_t* f, uint64_t out[2]) {
     if (!f || !out) return;
-    out[0] = f->impl.mInEventsTotal;
-    out[1] = f->impl.mOutEventsTotal;
+    out[0] = f->impl.mInEventsTotal.load();
+    out[1] = f->impl.mOutEventsTotal.load();
 }

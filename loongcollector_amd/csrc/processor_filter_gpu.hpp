@@ -12,6 +12,7 @@
 // decides which matches are run, never the result, so evaluating every leaf is equivalent.
 #pragma once
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -34,7 +35,8 @@ public:
 
     Mode mFilterMode = Mode::BYPASS_MODE;
     bool mDiscardingNonUTF8 = false;
-    uint64_t mInEventsTotal = 0, mOutEventsTotal = 0;
+    // one instance is shared by the runner threads (like ProcessorParseRegexGpu's counters)
+    std::atomic<uint64_t> mInEventsTotal{0}, mOutEventsTotal{0};
 
     // ProcessorFilterNative::noneUtf8 (:297-379): true if `s` holds a byte sequence that is not UTF-8 as that routine
     // defines it; with modify, every offending byte is overwritten with ' '

@@ -62,6 +62,9 @@ public:
         const int rc = lc_regex_match_host(re, data.data(), off.data(), len.data(), uint32_t(refs.size()), groups, caps.data(),
                                            status.data());
         if (rc != LC_OK) throw GrokError(std::string("device match failed: ") + lc_last_error());
+        // LC_OVERFLOW = "not decided" (only possible with the decide pass switched off): never folded into "no match"
+        for (size_t r = 0; r < refs.size(); ++r)
+            if (status[r] == LC_OVERFLOW) throw GrokError("device left a value undecided (LC_NFA_NO_DECIDE is set): logs untouched");
         for (size_t r = 0; r < refs.size(); ++r) {
             Log& log = logs[refs[r].log];
             const int32_t* c = &caps[r * 2 * groups];

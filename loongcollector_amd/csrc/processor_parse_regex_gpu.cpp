@@ -264,6 +264,16 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                 LogEvent& ev = events[rIdx].Cast<LogEvent>();
                 const StringView raw = ev.GetContent(mSourceKey);
                 bool parseSuccess = true;
+                if (status[li] == LC_OVERFLOW) {
+                    // The line was NOT decided (only possible with the decide pass switched off, LC_NFA_NO_DECIDE): boost
+                    // might match it, so it is neither a success nor a parse failure.  The event goes on untouched and is
+                    // counted under its own counter.
+                    ++mUndecidedEventsTotal;
+                    if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
+                    ++wIdx;
+                    continue;
+                }
+                if (status[li] == LC_GAVE_UP) ++mComplexityExceededEventsTotal;  // boost: complexity exception -> parse failure
                 if (status[li] != LC_MATCH) {  // :194-226 (alarms/logging are the host agent's business)
                     ++mOutFailedEventsTotal;
                     parseSuccess = false;

@@ -59,6 +59,9 @@ public:
     // plugin counters (ProcessorParseRegexNative.cpp:100-103)
     std::atomic<uint64_t> mDiscardedEventsTotal{0}, mOutFailedEventsTotal{0}, mOutKeyNotFoundEventsTotal{0},
         mOutSuccessfulEventsTotal{0};
+    // no reference counterpart: lines the decide kernel gave up on (boost would have thrown its complexity exception; they
+    // are parse failures too) and lines left undecided because the decide pass was switched off (kept untouched)
+    std::atomic<uint64_t> mComplexityExceededEventsTotal{0}, mUndecidedEventsTotal{0};
     std::vector<std::string> mInitWarnings;
     int mEngineChoice = LC_ENGINE_AUTO;  // test hook: force a device engine
 

@@ -629,6 +629,16 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         // the NFA blob is always packed when it fits: tests cross-check both engines on one handle
         try {
             re->nfaBlob = packNfaBlob(re->nfa, re->nfaClassMap);
+            for (const auto& lst : re->nfa.follow)
+                for (const auto& path : lst) {
+                    uint32_t enters = 0, exits = 0;
+                    for (const auto& ev : path.atoms) {
+                        enters += ev.code > 0 && ev.code < kAssertEvent;
+                        exits += ev.code < 0;
+                    }
+                    re->decideMaxEnter = std::max(re->decideMaxEnter, enters);
+                    re->decideClosedCap = std::max(re->decideClosedCap, enters + exits);
+                }
             // (a program that does not fit into LDS next to its scratch is read in place from HBM by the kernel)
             if (lcNfaLdsBytes(0, uint32_t(re->nfa.positions.size()), re->nfa.atomicCount > 0) > kLcLdsPerCu)
                 throw RegexError("nfa: per-wave scratch exceeds the 160 KiB LDS of a CU");

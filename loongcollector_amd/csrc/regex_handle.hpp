@@ -30,6 +30,8 @@ struct lc_regex {
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
     std::string requiredLiteral;        // longest byte string every match must contain ("" if none is certain)
+    // the decide kernel's per-frame capacities (nfa_decide_kernel.hpp DecideShape): enter / enter+exit events of the longest path
+    uint32_t decideMaxEnter = 0, decideClosedCap = 0;
 
     // device residency, managed by gpu_runtime.hip
     std::mutex deviceMutex;

@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    # Plain `pytest tests` on a machine without an AMD GPU driver node: gpu-marked tests are skipped, not failed.  Where
+    # /dev/kfd exists (any GPU box) nothing is ever skipped: a library that does not load or finds no device there must
+    # show up as failures, never as a silent skip.
+    if os.path.exists("/dev/kfd") or os.environ.get("LC_REQUIRE_GPU") == "1":
+        return
+    skip = pytest.mark.skip(reason="no /dev/kfd on this machine (gpu-marked tests run with -m gpu on an MI355X)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

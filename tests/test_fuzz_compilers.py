@@ -10,6 +10,7 @@ import pytest
 from loongcollector_amd import binding as B
 from oracle.oracle import OracleRegex
 from tests.helpers.nfa_atomic_interp import AtomicNfaInterp
+from tests.helpers.nfa_dfs_interp import DfsNfaInterp
 from tests.helpers.table_interp import NfaInterp, TdfaInterp
 
 _spec = importlib.util.spec_from_file_location(
@@ -56,7 +57,7 @@ _aspec = importlib.util.spec_from_file_location(
     "gen_atomic_golden", os.path.join(os.path.dirname(__file__), "golden", "gen_atomic_golden.py"))
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_atomic_patterns_tdfa_tables_vs_oracle(seed):
     """Fresh random patterns full of (?>X) / possessive quantifiers / look assertions: the TDFA builder's segment
     lineage (tdfa.cpp commitAtomic) against the oracle's backtracking commit, full-match and search."""
@@ -87,6 +88,11 @@ def test_random_atomic_patterns_tdfa_tables_vs_oracle(seed):
                     checked += 1
                     got = it.fullmatch(s)
                     assert got == want or got == "overflow", (p, s, flags, type(it).__name__)
+                if rx.has_nfa_program():   # the depth-first decide walk: never undecided, with and without its memo
+                    dfs = DfsNfaInterp(rx)
+                    for memo in (True, False):
+                        checked += 1
+                        assert dfs.fullmatch(s, memo=memo, budget=3_000_000) == want, (p, s, flags, "dfs", memo)
     assert checked > 5000
 
 

@@ -121,7 +121,7 @@ def test_auto_falls_back_to_nfa_kernel_when_tdfa_explodes(torch_dev):
 
 def test_nfa_thread_overflow_second_chance_and_report(torch_dev):
     """More than 64 live threads: the NFA kernel reports LC_OVERFLOW and raises its flag, the two-threads-per-lane kernel
-    behind it (nfa_wide_kernel.hpp) decides the line; more than 128 is still reported, never guessed."""
+    behind it (nfa_wide_kernel.hpp) decides the line; more than 128 goes to the decide kernel."""
     # on "aaaa..." every one of the 70 '.' positions is alive at once: more than 64 simultaneous threads
     pattern = r"(.*)a(.{70})"
     subs = [b"a" * 100, b"b" * 10, b"a" + b"b" * 70, b"xa" * 80, b"a" * 71]
@@ -145,11 +145,13 @@ def test_nfa_thread_overflow_second_chance_and_report(torch_dev):
         torch_dev.cuda.synchronize()
         o = OracleRegex(r"a(.{70})b").search(line, frm)
         assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)
-    # beyond 128 threads: reported
-    rx2 = B.GpuRegex(r".*a.{140}", engine=B.LC_ENGINE_NFA)
-    data, off, length = pack([b"a" * 200, b"a" + b"b" * 140])
+    # beyond 128 threads: settled by the depth-first decide kernel behind the two (tests/test_gpu_decide.py)
+    rx2 = B.GpuRegex(r"(.*)a.{140}", engine=B.LC_ENGINE_NFA)
+    data, off, length = pack([b"a" * 200, b"a" + b"b" * 140, b"a" * 140])
+    exp_caps, exp_status = OracleRegex(r"(.*)a.{140}").fullmatch_batch(data, off, length)
     caps, status = run_device(torch_dev, rx2, data, off, length, engine=B.LC_ENGINE_NFA)
-    assert list(status) == [B.LC_OVERFLOW, B.LC_MATCH]
+    assert list(status) == [B.LC_MATCH, B.LC_MATCH, B.LC_NOMATCH] == list(exp_status)
+    assert np.array_equal(caps, exp_caps)
 
 
 def test_ragged_mixed_corpus_with_failures(torch_dev):
