@@ -76,6 +76,15 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Measurement variants (tools/tdfa_lab.hip instantiates them; the product only ever instantiates LAB = 0).  They answer "what
+// does each of the three LDS instructions per byte cost" on the real kernel instead of a model of it:
+//   kLabNoStamp    phase 2 is skipped (capture offsets come out wrong: timing only)
+//   kLabPreClass   the input bytes ARE column offsets already (host pre-classified copy of the corpus): no class lookup
+//   kLabGlobalClass the class lookup goes to the 256-byte map in global memory (vector L1) instead of LDS
+//   kLabReplicated the transition table is stored 16 times, entry e of replica r at ((e * 16) + r) * 4: lane l reads replica
+//                  l & 15, so the 32 lanes of an LDS lane group touch 16 banks at most twice -- no chain bank conflicts
+enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8 };
+
 // general register program (a list of moves); rare for log regexes
 template <int BLOCK, typename TdfaReg>
 __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase, uint32_t list, uint32_t pos,
@@ -114,7 +123,7 @@ __device__ __forceinline__ uint32_t addHighHalf(uint32_t a, uint32_t t) {
 
 // In-order replay of one chunk for wavefronts that met a general register program in it: re-walks the 16 bytes
 // from the chunk's entry state and applies every register program at its own byte.  Rolled up: it is rare.
-template <int BLOCK, typename TdfaReg, bool WIDE>
+template <int BLOCK, typename TdfaReg, bool WIDE, int LAB = 0>
 __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t t, uint32_t base, uint32_t L,
                                                 uint32_t idCol, uint32_t regsBase, uint32_t tid, uint32_t nBytes) {
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
@@ -124,7 +133,8 @@ __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t
     for (uint32_t j = 0; j < nBytes; ++j) {
         const uint32_t word = (j < 8) ? ((j < 4) ? q.x : q.y) : ((j < 12) ? q.z : q.w);
         const uint32_t b = (word >> ((j & 3) * 8)) & 0xFFu;
-        const uint32_t col = (base + j < L) ? (WIDE ? b * 4u : uint32_t(cmap[b])) : idCol;
+        uint32_t col = (base + j < L) ? (WIDE ? b * 4u : ((LAB & kLabPreClass) ? b : uint32_t(cmap[b]))) : idCol;
+        if constexpr ((LAB & kLabReplicated) != 0) col = (col << 4) + ((tid & 15u) << 2);
         t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col, t));
         if (t & (TD_OP_GENERAL << 16)) tdfaRunMoveList<BLOCK, TdfaReg>(smem, regsBase, t >> 17, base + j, tid);
         else *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, t)) = TdfaReg(base + j);
@@ -133,10 +143,10 @@ __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t
 
 // steps NB (8 or 16) consecutive bytes held in `words`; CHECKED=false is the mid-line fast path (all NB bytes belong
 // to the line)
-template <int BLOCK, bool CHECKED, int NB, typename TdfaReg = uint32_t, bool WIDE = false>
+template <int BLOCK, bool CHECKED, int NB, typename TdfaReg = uint32_t, bool WIDE = false, int LAB = 0>
 __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t (&words)[NB / 4], uint32_t t,
                                                   uint32_t base, uint32_t L, uint32_t idCol, uint32_t regsBase,
-                                                  uint32_t tid) {
+                                                  uint32_t tid, const uint8_t* __restrict__ gcmap = nullptr) {
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     // the blob sits at LDS address 0, so table offsets are LDS addresses
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
@@ -149,10 +159,15 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
         if constexpr (WIDE) {  // rows are indexed by the byte itself: column offset = byte * 4, no lookup
             const uint32_t w = words[j >> 2];
             c4 = (j & 3) == 0 ? (w << 2) & 0x3FCu : (w >> ((j & 3) * 8 - 2)) & 0x3FCu;
+        } else if constexpr ((LAB & kLabPreClass) != 0) {
+            c4 = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        } else if constexpr ((LAB & kLabGlobalClass) != 0) {
+            c4 = gcmap[(words[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
         } else {
             c4 = cmap[(words[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
         }
         col[j] = CHECKED ? ((base + j < L) ? c4 : idCol) : c4;
+        if constexpr ((LAB & kLabReplicated) != 0) col[j] = (col[j] << 4) + ((tid & 15u) << 2);
     }
     uint32_t seen = 0;
 #pragma unroll
@@ -162,9 +177,11 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
         seen |= t;
     }
     if (!__any((seen & (TD_OP_GENERAL << 16)) != 0)) {
+        if constexpr ((LAB & kLabNoStamp) == 0) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j)  // phase 2
-            *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, tt[j])) = TdfaReg(base + j);
+            for (int j = 0; j < NB; ++j)  // phase 2
+                *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, tt[j])) = TdfaReg(base + j);
+        }
     } else {
         u32x4 q = {0, 0, 0, 0};
         q.x = words[0];
@@ -173,7 +190,7 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
             q.z = words[2 % (NB / 4)];
             q.w = words[3 % (NB / 4)];
         }
-        tdfaReplayChunk<BLOCK, TdfaReg, WIDE>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
+        tdfaReplayChunk<BLOCK, TdfaReg, WIDE, LAB>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
     }
     return t;
 }
@@ -241,7 +258,7 @@ __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t 
 }
 
 // minLen: lines shorter than this are not this launch's business (the 32-bit kernel mopping up behind a COMPACT one)
-template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
+template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false, int LAB = 0>
 __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(const uint8_t* __restrict__ data,
                                                            const uint32_t* __restrict__ off,
                                                            const uint32_t* __restrict__ len, uint32_t sepBytes,
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         t = walkRow(t);
     }
     const uint32_t deadRow = PAIR ? pi.base : TD_TRANS_OFFSET;
+    const uint8_t* gcmap = reinterpret_cast<const uint8_t*>(blob) + TD_CMAP_OFFSET;  // (LAB variants only)
 
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stageBase = blobBytes + regBytes + wave * kStagePerWave;  // this wave's staging rows (LDS address)
@@ -403,8 +421,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                 if (__all(full)) t = tdfaStepPairs<BLOCK, false, 16, TdfaReg>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
                 else t = tdfaStepPairs<BLOCK, true, 16, TdfaReg>(smem, w, t, base, L, idCol, regsBase, tid, pi, rowBytes);
             } else {
-                if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
-                else t = tdfaStepBytes<BLOCK, true, 16, TdfaReg, WIDE>(smem, w, t, base, L, idCol, regsBase, tid);
+                if (__all(full)) t = tdfaStepBytes<BLOCK, false, 16, TdfaReg, WIDE, LAB>(smem, w, t, base, L, idCol, regsBase, tid, gcmap);
+                else t = tdfaStepBytes<BLOCK, true, 16, TdfaReg, WIDE, LAB>(smem, w, t, base, L, idCol, regsBase, tid, gcmap);
             }
 #else
             const uint32_t w0[2] = {q.x, q.y}, w1[2] = {q.z, q.w};

@@ -1,0 +1,238 @@
+// tdfa_lab.hip -- measurement bench for the tagged-DFA kernel: the REAL kernel (csrc/tdfa_kernel.hpp) instantiated with its
+// LAB variants on the headline corpus, to see what each LDS instruction per byte costs and what a layout change buys
+// before it is built into the product.  Not part of the product; inputs come from tools/tdfa_lab_inputs.py.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I loongcollector_amd/csrc tools/tdfa_lab.hip -o scratch/tdfa_lab
+//   python tools/tdfa_lab_inputs.py gpurun_out/lab_inputs.bin && scratch/tdfa_lab gpurun_out/lab_inputs.bin
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tdfa_kernel.hpp"
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                 \
+            exit(2);                                                                \
+        }                                                                           \
+    } while (0)
+
+struct Inputs {
+    uint32_t nLines = 0, nGroups = 0, nRegs = 0, block = 0;
+    std::vector<uint8_t> data;
+    std::vector<uint32_t> off;
+    std::vector<uint32_t> blob;  // compact blob packed for `block` lanes
+};
+
+static Inputs readInputs(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        perror(path);
+        exit(2);
+    }
+    uint32_t h[8];
+    if (fread(h, 4, 8, f) != 8 || h[0] != 0x4C414254u) {
+        fprintf(stderr, "bad header\n");
+        exit(2);
+    }
+    Inputs in;
+    in.nLines = h[1];
+    in.nGroups = h[4];
+    in.nRegs = h[5];
+    in.block = h[6];
+    in.data.resize(h[2]);
+    in.off.resize(size_t(in.nLines) + 1);
+    in.blob.resize(h[3] / 4);
+    if (fread(in.data.data(), 1, in.data.size(), f) != in.data.size() || fread(in.off.data(), 4, in.off.size(), f) != in.off.size() ||
+        fread(in.blob.data(), 4, in.blob.size(), f) != in.blob.size()) {
+        fprintf(stderr, "short file\n");
+        exit(2);
+    }
+    fclose(f);
+    return in;
+}
+
+// Re-pack the compact blob for another workgroup size and/or with the transition table replicated 16 times.
+static std::vector<uint32_t> repack(const Inputs& in, int newBlock, bool replicate) {
+    const std::vector<uint32_t>& b = in.blob;
+    const uint32_t nStates = b[TD_NSTATES], rowBytes = b[TD_ROW_BYTES], cols = rowBytes / 4;
+    const uint32_t oldStride = in.block * 2, newStride = uint32_t(newBlock) * 2;
+    const uint32_t rep = replicate ? 16u : 1u;
+    const uint32_t newRowBytes = rowBytes * rep;
+    auto newRow = [&](uint32_t oldAddr) { return TD_TRANS_OFFSET + (oldAddr - TD_TRANS_OFFSET) / rowBytes * newRowBytes; };
+    std::vector<uint8_t> out(TD_TRANS_OFFSET);
+    std::memcpy(out.data(), b.data(), TD_TRANS_OFFSET);
+    const uint32_t* trans = b.data() + TD_TRANS_OFFSET / 4;
+    std::vector<uint32_t> nt(size_t(nStates) * cols * rep);
+    for (uint32_t s = 0; s < nStates; ++s)
+        for (uint32_t c = 0; c < cols; ++c) {
+            const uint32_t e = trans[s * cols + c];
+            uint32_t hi = e >> 16;
+            if (!(hi & TD_OP_GENERAL)) hi = hi / oldStride * newStride;  // (list ids do not depend on the workgroup size)
+            const uint32_t v = newRow(e & 0xFFFFu) | (hi << 16);
+            for (uint32_t r = 0; r < rep; ++r) nt[(size_t(s) * cols + c) * rep + r] = v;
+        }
+    if (TD_TRANS_OFFSET + nt.size() * 4 > 0x10000u) {
+        fprintf(stderr, "lab: replicated table exceeds 64 KiB\n");
+        exit(2);
+    }
+    auto append = [&](const void* p, size_t n) {
+        size_t at = (out.size() + 15) & ~size_t(15);
+        out.resize(at + n);
+        std::memcpy(out.data() + at, p, n);
+        return uint32_t(at);
+    };
+    append(nt.data(), nt.size() * 4);
+    // the remaining sections, in their original order: everything between the end of the old table and the end of the blob
+    const uint32_t oldTableEnd = TD_TRANS_OFFSET + nStates * rowBytes;
+    const uint32_t oldRestAt = (oldTableEnd + 15) & ~15u;
+    const uint32_t restAt = append(reinterpret_cast<const uint8_t*>(b.data()) + oldRestAt, b.size() * 4 - oldRestAt);
+    const int32_t shift = int32_t(restAt) - int32_t(oldRestAt);
+    out.resize((out.size() + 15) & ~size_t(15));
+    std::vector<uint32_t> nb(out.size() / 4);
+    std::memcpy(nb.data(), out.data(), out.size());
+    for (int k : {TD_OFF_STARTAFTER, TD_OFF_FINALID, TD_OFF_FINALMAP, TD_OFF_OPSSTART, TD_OFF_OPS})
+        if (nb[k]) nb[k] = uint32_t(int32_t(nb[k]) + shift);
+    nb[TD_OFF_PAIR] = 0;
+    nb[TD_START_ROW] = newRow(b[TD_START_ROW]);
+    nb[TD_ROW_BYTES] = newRowBytes;
+    nb[TD_BLOCK] = uint32_t(newBlock);
+    nb[TD_TOTAL_BYTES] = uint32_t(nb.size() * 4);
+    return nb;
+}
+
+struct Dev {
+    uint8_t *data = nullptr, *dataPre = nullptr, *status = nullptr;
+    uint32_t* off = nullptr;
+    uint32_t* offPool = nullptr;
+    uint32_t* lenPool = nullptr;  // every line points into the first kPoolLines lines: the whole corpus sits in L2
+    int32_t* caps = nullptr;
+};
+
+constexpr uint32_t kPoolLines = 2048;  // 1 MiB of lines: resident in every XCD's L2 (4 MiB)
+static size_t gPadLdsTo = 0;  // occupancy sweep: ask for at least this much LDS per workgroup
+template <int BLOCK, int LAB, bool POOL = false>
+static double runVariant(const char* name, const Inputs& in, const Dev& d, std::vector<int32_t>* capsOut, std::vector<uint8_t>* statusOut,
+                         int iters) {
+    const bool repl = (LAB & kLabReplicated) != 0;
+    std::vector<uint32_t> blob = repack(in, BLOCK, repl);
+    const uint32_t blobBytes = uint32_t(blob.size() * 4);
+    void* dBlob = nullptr;
+    CK(hipMalloc(&dBlob, blobBytes + 16));
+    CK(hipMemset(dBlob, 0, blobBytes + 16));
+    CK(hipMemcpy(dBlob, blob.data(), blobBytes, hipMemcpyHostToDevice));
+    const uint32_t regBytes = (in.nRegs + 1) * BLOCK * 2;
+    size_t lds = size_t(blobBytes) + regBytes + size_t(BLOCK / 64) * 64 * 64;
+    if (gPadLdsTo > lds) lds = gPadLdsTo;
+    auto kern = tdfa_match_kernel<BLOCK, false, true, false, LAB>;
+    if (lds > 160 * 1024) {
+        printf("%-34s  skipped: %zu bytes of LDS\n", name, lds);
+        return 0;
+    }
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    const uint8_t* src = (LAB & kLabPreClass) ? d.dataPre : d.data;
+    uint32_t* longFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
+    const uint32_t grid = (in.nLines + BLOCK - 1) / BLOCK;
+    auto launch = [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, src, POOL ? d.offPool : d.off, POOL ? d.lenPool : nullptr, 1u, 0u, in.nLines, nullptr, nullptr, nullptr,
+                           static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, in.nGroups, d.caps, d.status, longFlag, 1u);
+    };
+    CK(hipMemset(d.status, 7, in.nLines));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= iters;
+    std::vector<uint8_t> st(in.nLines);
+    std::vector<int32_t> caps(size_t(in.nLines) * 2 * in.nGroups);
+    CK(hipMemcpy(st.data(), d.status, st.size(), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(caps.data(), d.caps, caps.size() * 4, hipMemcpyDeviceToHost));
+    size_t matched = 0;
+    for (uint8_t s : st) matched += s == 1;
+    const char* verdict = "";
+    if (POOL) verdict = "(L2-resident pool)";
+    else if (statusOut && !statusOut->empty()) {
+        const bool sameStatus = st == *statusOut;
+        const bool sameCaps = caps == *capsOut;
+        verdict = (LAB & kLabNoStamp) ? (sameStatus ? "status==" : "STATUS DIFFERS") : (sameStatus && sameCaps ? "bit-exact" : "MISMATCH");
+    }
+    if (!POOL && statusOut && statusOut->empty()) {
+        *statusOut = st;
+        *capsOut = caps;
+        verdict = "(reference)";
+    }
+    const double payload = double(in.nLines) * 512.0;
+    const double algo = double(in.nLines) * (512.0 + 5 + 8.0 * in.nGroups);
+    const double cyc = ms * 1e-3 * 2.4e9 / (double(in.nLines) * 512.0 / 64.0 / 256.0);
+    printf("%-34s  lds %6zu  %.4f ms  %7.1f GB/s parsed  frac %.3f  ~%.1f cyc/wave-step/CU  matched %zu  %s\n", name, lds, ms,
+           payload / ms / 1e6, algo / ms / 1e6 / 8000.0, cyc, matched, verdict);
+    fflush(stdout);
+    CK(hipFree(dBlob));
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: tdfa_lab inputs.bin [iters]\n");
+        return 2;
+    }
+    const int iters = argc > 2 ? atoi(argv[2]) : 10;
+    Inputs in = readInputs(argv[1]);
+    printf("lab: %u lines, %zu data bytes, blob %zu bytes (block %u), %u groups, %u registers\n", in.nLines, in.data.size(),
+           in.blob.size() * 4, in.block, in.nGroups, in.nRegs);
+    Dev d;
+    CK(hipMalloc(reinterpret_cast<void**>(&d.data), in.data.size() + 64));
+    CK(hipMalloc(reinterpret_cast<void**>(&d.dataPre), in.data.size() + 64));
+    CK(hipMalloc(reinterpret_cast<void**>(&d.off), in.off.size() * 4));
+    CK(hipMalloc(reinterpret_cast<void**>(&d.caps), size_t(in.nLines) * 2 * in.nGroups * 4));
+    CK(hipMalloc(reinterpret_cast<void**>(&d.status), in.nLines));
+    CK(hipMemcpy(d.data, in.data.data(), in.data.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d.off, in.off.data(), in.off.size() * 4, hipMemcpyHostToDevice));
+    {  // pre-classified copy: byte -> column offset (class * 4)
+        const uint8_t* cmap = reinterpret_cast<const uint8_t*>(in.blob.data()) + TD_CMAP_OFFSET;
+        std::vector<uint8_t> pre(in.data.size());
+        for (size_t i = 0; i < pre.size(); ++i) pre[i] = cmap[in.data[i]];
+        CK(hipMemcpy(d.dataPre, pre.data(), pre.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<uint32_t> op(in.nLines), lp(in.nLines);
+        for (uint32_t i = 0; i < in.nLines; ++i) {
+            op[i] = in.off[i % kPoolLines];
+            lp[i] = in.off[i % kPoolLines + 1] - in.off[i % kPoolLines] - 1;
+        }
+        CK(hipMalloc(reinterpret_cast<void**>(&d.offPool), op.size() * 4));
+        CK(hipMalloc(reinterpret_cast<void**>(&d.lenPool), lp.size() * 4));
+        CK(hipMemcpy(d.offPool, op.data(), op.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d.lenPool, lp.data(), lp.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> refCaps;
+    std::vector<uint8_t> refStatus;
+#define RUN(B, L, NAME) runVariant<B, L>(NAME, in, d, &refCaps, &refStatus, iters)
+#define RUNP(B, L, NAME) runVariant<B, L, true>(NAME, in, d, &refCaps, &refStatus, iters)
+    RUN(256, 0, "compact 256 (product)");
+    for (int wgs : {1, 2, 3, 4, 5}) {
+        gPadLdsTo = size_t(160 * 1024 / wgs) & ~size_t(255);
+        char nm[64];
+        snprintf(nm, sizeof nm, "product, %d WG/CU", wgs);
+        RUN(256, 0, nm);
+        snprintf(nm, sizeof nm, "product, pool, %d WG/CU", wgs);
+        RUNP(256, 0, nm);
+        snprintf(nm, sizeof nm, "bare chain, pool, %d WG/CU", wgs);
+        RUNP(256, kLabPreClass | kLabNoStamp, nm);
+    }
+    gPadLdsTo = 0;
+    return 0;
+}
