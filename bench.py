@@ -192,7 +192,7 @@ def main():
                        "matched_lines_last_batch": matched},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "tdfa_match_kernel" if info["engine"] == 1 else "nfa_match_kernel",
+                         "kernel": ("tdfa_match_kernel" if os.environ.get("LC_TDFA_STREAM") == "0" else "tdfa_stream_kernel") if info["engine"] == 1 else "nfa_match_kernel",
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,

@@ -31,7 +31,7 @@
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
 #include "split_kernel.hpp"
-#include "tdfa_kernel.hpp"
+#include "tdfa_stream_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string tlsError;
@@ -105,20 +105,31 @@ void lcReleaseDeviceTables(lc_regex* re) {
     if (haveCur) (void)hipSetDevice(cur);
 }
 
+// The kernel behind a (workgroup size, table format) pair: the interleaved-issue kernel (tdfa_stream_kernel.hpp) for the
+// class-indexed tables with or without the byte-pair extension, the phase-separated one (tdfa_kernel.hpp) for byte-indexed
+// rows -- and for everything when LC_TDFA_STREAM=0 is set (A/B measurements).
 template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0) {
-    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
+    static const bool streamOff = [] {
+        const char* e = getenv("LC_TDFA_STREAM");
+        return e && e[0] == '0';
+    }();
+    auto kern = tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>;
+    if constexpr (!BYTEROWS) {
+        if (!streamOff) kern = tdfa_stream_kernel<BLOCK, COMPACT, PAIR>;
+    }
+    static thread_local size_t ldsAttrSet[kLcMaxDevices][2] = {};  // the attribute belongs to (function, device)
+    const int which = (!BYTEROWS && !streamOff) ? 1 : 0;
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
-    if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        ldsAttrSet[devNow] = lds;
+    if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow][which]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        ldsAttrSet[devNow][which] = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL((tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status,
                        longFlag, seq);
     HIP_TRY(hipGetLastError());

@@ -83,7 +83,9 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 //   kLabGlobalClass the class lookup goes to the 256-byte map in global memory (vector L1) instead of LDS
 //   kLabReplicated the transition table is stored 16 times, entry e of replica r at ((e * 16) + r) * 4: lane l reads replica
 //                  l & 15, so the 32 lanes of an LDS lane group touch 16 banks at most twice -- no chain bank conflicts
-enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8 };
+//   kLabNoOutput / kLabNoLoop (tdfa_stream_kernel only): skip the capture-table write / the stage loop -- what a workgroup's
+//                  fixed costs are (line table reads, first loads, table staging, result write)
+enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32 };
 
 // general register program (a list of moves); rare for log regexes
 template <int BLOCK, typename TdfaReg>
@@ -193,6 +195,74 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
         tdfaReplayChunk<BLOCK, TdfaReg, WIDE, LAB>(smem, q, entry, base, L, idCol, regsBase, tid, NB);
     }
     return t;
+}
+
+// The result of a wavefront's 64 lines: status byte + 2*nGroupsOut capture offsets per line.  A lane storing its own row
+// dword by dword touches 64 different cache lines per store instruction (rows are 8*G bytes apart): measured on the headline
+// batch that write alone took a third of the kernel (tools/tdfa_lab.hip, "no output" variant).  When the wave's lines are
+// consecutive in the capture table (no schedule permutation, every lane decides its line) the rows form ONE contiguous
+// region, so they go through the wave's staging tile (free once the line is walked): lanes write their rows to LDS, then the
+// wave copies the region out 256 contiguous bytes per store instruction.  `state` = final DFA state of the lane's line.
+template <int BLOCK, typename TdfaReg>
+__device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAddr, uint32_t regsBase, uint32_t state, bool live,
+                                                 uint32_t line, uint32_t L, uint32_t from, bool permuted, uint32_t nGroupsOut,
+                                                 int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nSlots = hdr[TD_NSLOTS];
+    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + hdr[TD_OFF_FINALID]);
+    const uint8_t* finalMap = smem + hdr[TD_OFF_FINALMAP];
+    const TdfaReg* regs = reinterpret_cast<const TdfaReg*>(smem + regsBase);
+    const uint32_t fid = live ? uint32_t(finalId[state]) : 0xFFFFu;
+    const bool matched = live && (state != 0) && (fid != 0xFFFFu);
+    const uint32_t nOut = 2 * nGroupsOut;
+    auto slotValue = [&](uint32_t s) -> int32_t {
+        int32_t val = -1;
+        if (matched && s < nSlots) {
+            const uint32_t m = finalMap[fid * nSlots + s];
+            if (m == TD_REG_POS) val = int32_t(L + from);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
+        }
+        return val;
+    };
+    constexpr uint32_t kTileWords = 1024;  // 64 rows x 64 bytes: the smaller of the two tile layouts
+    if (!permuted && nOut <= kTileWords && __all(live)) {
+        int32_t* tile = reinterpret_cast<int32_t*>(smem + tileAddr);
+        const uint32_t rowsPerPass = kTileWords / nOut;
+        int32_t* gout = caps + size_t(line - lane) * nOut;  // (lines of the wave are consecutive: line - lane = lane 0's)
+        // Lines of one format end in the same accepting state: then the slot -> register map is the same for the whole wave
+        // and the row is built without a per-slot, per-lane map lookup and its branches.
+        const uint32_t fid0 = __builtin_amdgcn_readfirstlane(fid);
+        const bool sameMap = __all(fid == fid0) && fid0 != 0xFFFFu;
+        for (uint32_t p0 = 0; p0 < 64; p0 += rowsPerPass) {
+            tdfaWaveLdsSync();
+            if (lane >= p0 && lane - p0 < rowsPerPass) {
+                int32_t* row = tile + (lane - p0) * nOut;
+                if (sameMap) {
+                    const uint8_t* map = finalMap + fid0 * nSlots;
+                    const int32_t end = int32_t(L + from);
+                    for (uint32_t s = 0; s < nOut; ++s) {
+                        const uint32_t m = s < nSlots ? uint32_t(__builtin_amdgcn_readfirstlane(map[s])) : uint32_t(TD_REG_NONE);
+                        int32_t val = -1;  // (m is wave-uniform: the branches below are scalar)
+                        if (m == TD_REG_POS) val = end;
+                        else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
+                        row[s] = state != 0 ? val : -1;
+                    }
+                } else {
+#pragma unroll 4
+                    for (uint32_t s = 0; s < nOut; ++s) row[s] = slotValue(s);
+                }
+            }
+            tdfaWaveLdsSync();
+            const uint32_t rows = 64 - p0 < rowsPerPass ? 64 - p0 : rowsPerPass;
+            const uint32_t total = rows * nOut;
+            for (uint32_t d = lane; d < total; d += 64) gout[size_t(p0) * nOut + d] = tile[d];
+        }
+    } else if (live) {
+        int32_t* out = caps + size_t(line) * nOut;
+        for (uint32_t s = 0; s < nOut; ++s) out[s] = slotValue(s);
+    }
+    if (live) status[line] = matched ? LC_MATCH : LC_NOMATCH;
 }
 
 // Byte-PAIR stepping (device_tables.h TP_*): the state chain -- the only serial dependency, one LDS round trip per link --
@@ -447,22 +517,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
 
-    if (!live) return;
-    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(smem + hdr[TD_OFF_FINALID]);
-    const uint8_t* finalMap = smem + hdr[TD_OFF_FINALMAP];
-    const TdfaReg* regs = reinterpret_cast<const TdfaReg*>(smem + regsBase);
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
-    const uint32_t fid = finalId[state];
-    const bool matched = (state != 0) && (fid != 0xFFFFu);
-    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
-    for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) {
-        int32_t val = -1;
-        if (matched && s < nSlots) {
-            const uint32_t m = finalMap[fid * nSlots + s];
-            if (m == TD_REG_POS) val = int32_t(L + from);
-            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
-        }
-        out[s] = val;
-    }
-    status[line] = matched ? LC_MATCH : LC_NOMATCH;
+    tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
+                                     status);
 }

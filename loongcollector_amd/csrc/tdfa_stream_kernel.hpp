@@ -1,0 +1,376 @@
+// tdfa_stream_kernel.hpp -- the tagged-DFA engine with its LDS instructions INTERLEAVED per byte (included by
+// gpu_runtime.hip only; tdfa_kernel.hpp holds the phase-separated original, which stays for the byte-pair and byte-row
+// table formats).
+//
+// Why a second kernel.  tdfa_match_kernel steps a 16-byte chunk in three bursts: 16 class lookups, the 16 dependent chain
+// links, 16 capture stamps.  The CU's LDS serves the instructions of all its waves in arrival order, so a chain link -- the
+// only thing a wave ever waits for -- queues behind the 32..64 LDS cycles of whatever burst another wave has just issued:
+// measured, a link costs ~310 cycles in that kernel against ~115 for the same mix issued one-one-one
+// (tools/lds_chain_bench.hip mode 2), with the LDS only half busy (profiles/round1: SQ_LDS_IDX_ACTIVE 55 %).  Here every
+// step issues exactly
+//      the chain link of byte j of THIS chunk          t = lds32[(t & 0xFFFF) + col[j]]        (waited for by step j+1)
+//      the class lookup of byte j of the NEXT chunk    ncol[j] = cmap8[next byte j]            (waited for a chunk later)
+//      the capture stamp of byte j of the PREVIOUS one regs[ptt[j] >> 16][lane] = pos          (never waited for)
+// so the queue in front of a link holds at most two cheap instructions per resident wave, and nothing of the wave's own.
+//
+// The stamps trail by a whole chunk (not by a byte) because of the general register programs (tdfa_kernel.hpp): a chunk in
+// which some lane met one is replayed in order, which is only correct if none of its simple stamps has been issued yet.
+// After a replay the chunk's trailing stamps are pointed at the dummy register.
+//
+// Staging is the original's (cooperative 64-byte stages through a per-wave LDS tile), one stage further ahead: during stage
+// s the tile already holds stage s+1, because the class lookups of a stage's first chunk are issued during the last chunk of
+// the stage before.  W[k] holds the words of chunk k: of stage s until chunk k has been stepped, of stage s+1 from then on.
+#pragma once
+
+#include "tdfa_kernel.hpp"
+
+#ifndef LC_TDFA_STREAM_CHUNK
+#define LC_TDFA_STREAM_CHUNK 8  // bytes per chunk (8 or 16): col / ncol / ptt / tt hold one value per byte of a chunk
+#endif
+#ifndef LC_TDFA_STREAM_WAVES
+#define LC_TDFA_STREAM_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#endif
+
+// LDS byte address of the low byte of hdr[TD_ID_COL]: a class "lookup" of a byte outside the line reads the identity
+// column's offset from there (identity column < 256: at most 63 classes), so the checked path has no select after the read
+constexpr uint32_t kTdfaIdColByteAddr = TD_ID_COL * 4;
+
+// steps the NB (8 or 16) bytes whose classes are in col[]; nwords = the NB bytes that follow them
+template <int NB, bool CHECKED, typename TdfaReg, int LAB>
+__device__ __forceinline__ uint32_t tdfaStreamChunk(uint32_t t, const uint32_t (&col)[NB], uint32_t (&ncol)[NB],
+                                                    const uint32_t (&nwords)[NB / 4], uint32_t nbase, uint32_t L, uint32_t idCol,
+                                                    const uint32_t (&ptt)[NB], uint32_t (&tt)[NB], uint32_t pbase,
+                                                    uint32_t regAddr0, uint32_t& seenOut) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
+    uint32_t seen = 0;
+    // (the byte extraction and the running position are volatile asm: left to itself the compiler computes all NB of each
+    // ahead of the chunk -- 2*NB registers for values that cost one VALU instruction in the shadow of an LDS round trip)
+    uint32_t pos = pbase;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        t = *reinterpret_cast<LdsWordPtr>(addLowHalf(col[j], t));
+        tt[j] = t;
+        uint32_t b;
+        asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b) : "v"(nwords[j >> 2]), "n"((j & 3) * 8));
+        if constexpr ((LAB & kLabPreClass) != 0) {
+            ncol[j] = CHECKED ? ((nbase + j < L) ? b : idCol) : b;
+        } else if constexpr (CHECKED) {
+            ncol[j] = *reinterpret_cast<LdsBytePtr>((nbase + j < L) ? TD_CMAP_OFFSET + b : kTdfaIdColByteAddr);
+        } else {
+            ncol[j] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b);
+        }
+        if constexpr ((LAB & kLabNoStamp) == 0) {
+            *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, ptt[j])) = TdfaReg(pos);
+            asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
+        }
+        if (j > 0) seen |= tt[j - 1];  // (the link before this one: already waited for)
+#ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);  // keep the one-one-one order: the scheduler would cluster the reads and sink the stores
+#endif
+    }
+    seenOut = seen | t;
+    return t;
+}
+
+// Byte-PAIR tables (device_tables.h TP_*): one chain link per TWO bytes.  The chain is what a wave waits for (16 waves per CU
+// x one link in flight each, ~120 cycles per link), so halving the links per byte is worth more here than in the
+// phase-separated kernel, where it bought nothing.  Per pair: the link, the two class lookups of the
+// NEXT chunk's pair (first byte: cmapA, u16; second byte: cmap8), the two stamps of the PREVIOUS chunk's pair.
+template <int BLOCK, int NB, bool CHECKED, typename TdfaReg>
+__device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32_t (&colp)[NB / 2], uint32_t (&na)[NB / 2],
+                                                        uint32_t (&nc)[NB / 2], const uint32_t (&nwords)[NB / 4], uint32_t nbase,
+                                                        uint32_t L, uint32_t cmapA, uint32_t idAAddr,
+                                                        const uint32_t (&ptt)[NB / 2], uint32_t (&tt)[NB / 2], uint32_t pbase,
+                                                        uint32_t regAddr0, uint32_t& seenOut) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
+    constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                   (sizeof(TdfaReg) == 2 ? 1 : 0);  // log2(BLOCK * sizeof(TdfaReg))
+    uint32_t seen = 0;
+    uint32_t pos = pbase;
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) {
+        t = *reinterpret_cast<LdsWordPtr>(addLowHalf(colp[p], t));
+        tt[p] = t;
+        uint32_t b0, b1;
+        asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b0) : "v"(nwords[p >> 1]), "n"((p & 1) * 16));
+        asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b1) : "v"(nwords[p >> 1]), "n"((p & 1) * 16 + 8));
+        if constexpr (CHECKED) {
+            na[p] = *reinterpret_cast<LdsHalfPtr>((nbase + 2 * p < L) ? cmapA + b0 * 2 : idAAddr);
+            nc[p] = *reinterpret_cast<LdsBytePtr>((nbase + 2 * p + 1 < L) ? TD_CMAP_OFFSET + b1 : kTdfaIdColByteAddr);
+        } else {
+            na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
+            nc[p] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b1);
+        }
+        const uint32_t r0 = (ptt[p] >> 16) & 0xFFu, r1 = ptt[p] >> 24;
+        *reinterpret_cast<LdsRegPtr>(regAddr0 + (r0 << kRegShift)) = TdfaReg(pos);
+        asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
+        *reinterpret_cast<LdsRegPtr>(regAddr0 + (r1 << kRegShift)) = TdfaReg(pos);
+        asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
+        if (p > 0) seen |= tt[p - 1];
+#ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    seenOut = seen | t;
+    return t;
+}
+
+template <int BLOCK, bool COMPACT, bool PAIR = false, int LAB = 0>
+__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kernel(
+    const uint8_t* __restrict__ data, const uint32_t* __restrict__ off, const uint32_t* __restrict__ len, uint32_t sepBytes,
+    uint32_t minLen, uint32_t nLines, const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t regBytes,
+    uint32_t nGroupsOut, int32_t* __restrict__ caps, uint8_t* __restrict__ status, uint32_t* __restrict__ longFlag,
+    uint32_t launchSeq) {
+    static_assert(kTdfaStageBytes == 64 || kTdfaStageBytes == 128, "4 or 8 16-byte segments per stage");
+    constexpr int kLoads = kTdfaLoads;  // 16-byte segments per staged row == lanes that share one line == loads per stage
+    static_assert(!PAIR || (LAB & kLabPreClass) == 0, "no pre-classified pairs");
+    typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type TdfaReg;
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
+    constexpr uint32_t kRowStride = COMPACT ? kTdfaStageBytes : kTdfaRowStride;  // (tdfa_match_kernel's two tile layouts)
+    constexpr uint32_t kStagePerWave = 64 * kRowStride;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    if (nLinesPtr) {
+        const uint32_t dyn = *nLinesPtr;
+        nLines = dyn < nLines ? dyn : nLines;
+    }
+    if (minLen && longFlag && __atomic_load_n(longFlag, __ATOMIC_RELAXED) < launchSeq) return;
+    if (minLen) {  // mop-up launch behind a COMPACT one (see tdfa_match_kernel)
+        const uint32_t s0 = blockIdx.x * BLOCK + tid;
+        bool mine = false;
+        if (s0 < nLines) {
+            const uint32_t ln = order ? order[s0] : s0;
+            uint32_t l0 = len ? len[ln] : off[ln + 1] - off[ln] - sepBytes;
+            if (resume) {
+                const uint32_t f0 = resume[ln];
+                l0 -= f0 < l0 ? f0 : l0;
+            }
+            mine = l0 >= minLen;
+        }
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(smem);
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (mine) *flag = 1;
+        __syncthreads();
+        const bool any = *flag != 0;
+        __syncthreads();
+        if (!any) return;
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(blob);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
+    const uint32_t rowBytes = hdr[TD_ROW_BYTES];
+    const uint32_t idCol = hdr[TD_ID_COL];
+    const uint32_t regsBase = blobBytes;
+    // a transition that stamps the dummy register (the last one) and nothing else
+    const uint32_t dummyT = PAIR ? (hdr[TD_NREGS] - 1) * 0x01010000u : ((hdr[TD_NREGS] - 1) * BLOCK * uint32_t(sizeof(TdfaReg))) << 16;
+    uint32_t t = hdr[TD_START_ROW];
+    TdfaPairInfo pi{};
+    uint32_t idAAddr = 0;  // LDS address of a u16 that holds pi.idA (the first-byte offset of the identity class)
+    // single-byte row address -> the row the kernel walks (PAIR: the same state's row in the pair table)
+    auto walkRow = [&](uint32_t singleRow) {
+        return PAIR ? pi.base + ((singleRow & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes * pi.rowBytes : singleRow;
+    };
+    if constexpr (PAIR) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_PAIR]);
+        pi = TdfaPairInfo{ph[TP_BASE], ph[TP_ROW_BYTES], ph[TP_OFF_CMAPA], ph[TP_ID_A]};
+        idAAddr = hdr[TD_OFF_PAIR] + TP_ID_A * 4;
+        t = walkRow(t);
+    }
+    const uint32_t deadRow = PAIR ? pi.base : TD_TRANS_OFFSET;
+
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t stageBase = blobBytes + regBytes + wave * kStagePerWave;
+
+    const uint32_t slot = blockIdx.x * BLOCK + tid;
+    bool live = slot < nLines;
+    const uint32_t line = (live && order) ? order[slot] : slot;
+    uint32_t o = 0, L = 0;
+    uint32_t from = 0;
+    if (live) {
+        o = off[line];
+        L = len ? len[line] : off[line + 1] - o - sepBytes;
+        if (resume) {
+            from = resume[line];
+            from = from < L ? from : L;
+            if (from) {
+                const uint32_t* startAfter = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_STARTAFTER]);
+                t = walkRow(startAfter[smem[TD_CMAP_OFFSET + data[size_t(o) + from - 1]] >> 2]);
+                o += from;
+                L -= from;
+            }
+        }
+        if ((COMPACT && L > kTdfaWideMaxLine) || L < minLen) {
+            if (COMPACT && L > kTdfaWideMaxLine && longFlag) atomicMax(longFlag, launchSeq);
+            live = false;
+            L = 0;
+        }
+    }
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
+    const uint32_t head = uint32_t(addr & 15);
+    const uintptr_t rowStart = addr - head;
+    const uint32_t span = L ? head + L : 0;
+    const uint32_t myStages = (span + kTdfaStageBytes - 1) / kTdfaStageBytes;
+    uint32_t maxStages = myStages;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t other = __shfl_xor(maxStages, d, 64);
+        maxStages = other > maxStages ? other : maxStages;
+    }
+
+    const uint32_t seg = (lane % kLoads) * 16;
+    uintptr_t srcAddr[kLoads];
+    uint32_t srcSpan[kLoads], dstAddr[kLoads];
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+        const int r = (64 / kLoads) * i + int(lane / kLoads);
+        const uint32_t lo = __shfl(uint32_t(rowStart), r, 64);
+        const uint32_t hi = __shfl(uint32_t(rowStart >> 32), r, 64);
+        srcAddr[i] = ((uintptr_t(hi) << 32) | lo) + seg;
+        srcSpan[i] = __shfl(span, r, 64);
+        dstAddr[i] = stageBase + uint32_t(r) * kRowStride + (COMPACT ? seg ^ (((uint32_t(r) >> 1) & uint32_t(kLoads - 1)) << 4) : seg);
+    }
+    const uint32_t myRow = stageBase + lane * kRowStride;
+    const uint32_t mySwizzle = COMPACT ? ((lane >> 1) & uint32_t(kLoads - 1)) << 4 : 0u;
+    const uint32_t regAddr0 = regsBase + tid * uint32_t(sizeof(TdfaReg));
+
+    u32x4 in[kLoads];
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {  // stage 0
+        in[i] = u32x4{0, 0, 0, 0};
+        if (seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i]);
+    }
+    tdfaWaveLdsSync();
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) *reinterpret_cast<LdsQuadPtr>(dstAddr[i]) = in[i];
+    tdfaWaveLdsSync();
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {  // stage 1
+        in[i] = u32x4{0, 0, 0, 0};
+        if (kTdfaStageBytes + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i] + kTdfaStageBytes);
+    }
+    u32x4 W[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) W[k] = *reinterpret_cast<LdsQuadPtr>(myRow + ((uint32_t(k) * 16) ^ mySwizzle));
+    constexpr int NB = LC_TDFA_STREAM_CHUNK;  // bytes per chunk
+    constexpr int kChunksPerStage = int(kTdfaStageBytes) / NB;
+    // word w of the staged row: W[w / 4][w % 4]
+    auto rowWord = [&](int w) -> uint32_t {
+        const u32x4& q = W[(w >> 2) & (kLoads - 1)];
+        return (w & 3) == 0 ? q.x : (w & 3) == 1 ? q.y : (w & 3) == 2 ? q.z : q.w;
+    };
+    constexpr int NC = PAIR ? NB / 2 : NB;  // chain links per chunk
+    uint32_t col[NC], ptt[NC];
+    {  // classes of the very first chunk (the only burst of lookups in a line's life)
+        const uint32_t base0 = 0u - head;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const uint32_t b = (rowWord(j >> 2) >> ((j & 3) * 8)) & 0xFFu;
+            uint32_t c;
+            if constexpr ((LAB & kLabPreClass) != 0) c = (base0 + j < L) ? b : idCol;
+            else if (PAIR && (j & 1) == 0) c = *reinterpret_cast<LdsHalfPtr>((base0 + j < L) ? pi.cmapA + b * 2 : idAAddr);
+            else c = *reinterpret_cast<LdsBytePtr>((base0 + j < L) ? TD_CMAP_OFFSET + b : kTdfaIdColByteAddr);
+            if constexpr (PAIR) {
+                if ((j & 1) == 0) col[j / 2] = c;
+                else col[j / 2] += c;
+            } else {
+                col[j] = c;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) ptt[j] = dummyT;
+    }
+    uint32_t pbase = 0;
+
+    if constexpr ((LAB & kLabNoLoop) != 0) maxStages = 0;
+    for (uint32_t s = 0; s < maxStages; ++s) {
+        // the tile's stage s has been read by every lane (W): publish stage s+1, put stage s+2 in flight
+        tdfaWaveLdsSync();
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) *reinterpret_cast<LdsQuadPtr>(dstAddr[i]) = in[i];
+        tdfaWaveLdsSync();
+        const uint32_t nextOff = (s + 2) * kTdfaStageBytes;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            in[i] = u32x4{0, 0, 0, 0};
+            if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i] + nextOff);
+        }
+#pragma unroll
+        for (int c = 0; c < kChunksPerStage; ++c) {
+            const uint32_t base = s * kTdfaStageBytes + uint32_t(c) * NB - head;  // line offset of byte 0 (wraps in the head)
+            const uint32_t nbase = base + NB;
+            const bool fullNext = nbase < L && L - nbase >= uint32_t(NB);
+            const uint32_t entry = t;
+            // the NB bytes after this chunk (the first chunk of stage s+1 after the last one of stage s: its row words were
+            // re-read from the tile when chunk 0 of this stage was done)
+            uint32_t nwords[NB / 4], cwords[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < NB / 4; ++w) {
+                nwords[w] = rowWord(((c + 1) * NB / 4 + w) & (kLoads * 4 - 1));
+                cwords[w] = rowWord(c * NB / 4 + w);
+            }
+            uint32_t ncol[NC], tt[NC], seen;
+            bool general;
+            if constexpr (PAIR) {
+                uint32_t na[NC], nc[NC];
+                if (__all(fullNext)) t = tdfaStreamPairChunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
+                else t = tdfaStreamPairChunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) ncol[j] = na[j] + nc[j];
+                general = (seen & ((TP_GENERAL << 16) | (TP_GENERAL << 24))) != 0;
+            } else {
+                if (__all(fullNext)) t = tdfaStreamChunk<NB, false, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);
+                else t = tdfaStreamChunk<NB, true, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);
+                general = (seen & (TD_OP_GENERAL << 16)) != 0;
+            }
+            if (__any(general)) {
+                // (the previous chunk's stamps are all issued by now, this chunk's are not: in-order replay is exact)
+                const u32x4 q = {cwords[0], cwords[1], cwords[2], cwords[3]};
+                uint32_t single = entry;
+                if constexpr (PAIR) single = TD_TRANS_OFFSET + ((entry & 0xFFFFu) - pi.base) / pi.rowBytes * rowBytes;
+                tdfaReplayChunk<BLOCK, TdfaReg, false, LAB>(smem, q, single, base, L, idCol, regsBase, tid, NB);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) tt[j] = dummyT;
+            }
+            if ((c + 1) * NB % 16 == 0) {  // a 16-byte segment of the row is done: fetch stage s+1's
+                const int k = ((c + 1) * NB / 16 - 1) & (kLoads - 1);
+                W[k] = *reinterpret_cast<LdsQuadPtr>(myRow + ((uint32_t(k) * 16) ^ mySwizzle));
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                col[j] = ncol[j];
+                ptt[j] = tt[j];
+            }
+            pbase = base;
+        }
+        if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
+    }
+    if constexpr ((LAB & kLabNoStamp) == 0) {  // the last chunk's stamps
+        if constexpr (PAIR) {
+            constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                           (sizeof(TdfaReg) == 2 ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                *reinterpret_cast<LdsRegPtr>(regAddr0 + (((ptt[j] >> 16) & 0xFFu) << kRegShift)) = TdfaReg(pbase + 2 * j);
+                *reinterpret_cast<LdsRegPtr>(regAddr0 + ((ptt[j] >> 24) << kRegShift)) = TdfaReg(pbase + 2 * j + 1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, ptt[j])) = TdfaReg(pbase + j);
+        }
+    }
+
+    if constexpr ((LAB & kLabNoOutput) != 0) {
+        if (live && t == 0x12345u) status[line] = 3;  // (keeps the loop alive)
+        return;
+    }
+    const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
+    tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
+                                     status);
+}

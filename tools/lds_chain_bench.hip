@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <vector>
 typedef uint32_t __attribute__((address_space(3))) * LdsWordPtr;
+// modes 3..5 = mode 2 with the write under a lane mask: 3: one lane in 16 (what a capture stamp that only fires on tagged
+// transitions looks like), 4: no lane at all (EXEC = 0, instruction still issued), 5: a 16-bit write from every lane
 template <int MODE>  // 0: all lanes same address, 1: per-lane pseudo-random rows (36 rows x 12 cols), 2: +1 independent extra read and write per step
 __global__ void chain(uint32_t* out, int steps, int tableWords) {
     extern __shared__ uint32_t lds[];
@@ -21,6 +23,17 @@ __global__ void chain(uint32_t* out, int steps, int tableWords) {
         if (MODE == 2) {
             acc += *reinterpret_cast<LdsWordPtr>(((threadIdx.x + s) & 63u) * 4u);
             *reinterpret_cast<LdsWordPtr>(2048u + threadIdx.x * 4u) = acc;
+        }
+        if (MODE >= 3) {
+            acc += *reinterpret_cast<LdsWordPtr>(((threadIdx.x + s) & 63u) * 4u);
+            if (MODE == 5) {
+                *reinterpret_cast<uint16_t __attribute__((address_space(3)))*>(2048u + threadIdx.x * 2u) = uint16_t(acc);
+            } else {
+                const bool on = MODE == 3 ? ((threadIdx.x + s) & 15u) == 0u : (acc == 0x7fffffffu && s < 0);
+                // v_cmpx-style predication: the store is issued every step, under a (mostly empty) lane mask
+                const unsigned long long mask = __ballot(on);
+                asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, -1" ::"s"(mask), "v"(2048u + threadIdx.x * 4u), "v"(acc) : "memory");
+            }
         }
         if (MODE != 0) col = (col + 4u) % 48u;
     }
@@ -50,5 +63,8 @@ int main() {
     for (int bpc : {1, 2, 4, 8}) run<0>(bpc, 256, 20000);
     for (int bpc : {1, 2, 4, 8}) run<1>(bpc, 256, 20000);
     for (int bpc : {1, 2, 4, 8}) run<2>(bpc, 256, 20000);
+    for (int bpc : {2, 4, 8}) run<3>(bpc, 256, 20000);
+    for (int bpc : {2, 4, 8}) run<4>(bpc, 256, 20000);
+    for (int bpc : {2, 4, 8}) run<5>(bpc, 256, 20000);
     return 0;
 }

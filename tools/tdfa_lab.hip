@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "tdfa_kernel.hpp"
+#include "tdfa_stream_kernel.hpp"
 
 #define CK(x)                                                                       \
     do {                                                                            \
@@ -117,20 +117,31 @@ struct Dev {
 
 constexpr uint32_t kPoolLines = 2048;  // 1 MiB of lines: resident in every XCD's L2 (4 MiB)
 static size_t gPadLdsTo = 0;  // occupancy sweep: ask for at least this much LDS per workgroup
-template <int BLOCK, int LAB, bool POOL = false>
+template <int BLOCK, int LAB, bool POOL = false, bool STREAM = false, bool PAIR = false>
 static double runVariant(const char* name, const Inputs& in, const Dev& d, std::vector<int32_t>* capsOut, std::vector<uint8_t>* statusOut,
                          int iters) {
     const bool repl = (LAB & kLabReplicated) != 0;
-    std::vector<uint32_t> blob = repack(in, BLOCK, repl);
+    if (PAIR && (uint32_t(BLOCK) != in.block || !in.blob[TD_OFF_PAIR])) {
+        printf("%-34s  skipped: inputs carry no byte-pair table for %d lanes\n", name, BLOCK);
+        return 0;
+    }
+    std::vector<uint32_t> blob = PAIR ? in.blob : repack(in, BLOCK, repl);
     const uint32_t blobBytes = uint32_t(blob.size() * 4);
     void* dBlob = nullptr;
     CK(hipMalloc(&dBlob, blobBytes + 16));
     CK(hipMemset(dBlob, 0, blobBytes + 16));
     CK(hipMemcpy(dBlob, blob.data(), blobBytes, hipMemcpyHostToDevice));
     const uint32_t regBytes = (in.nRegs + 1) * BLOCK * 2;
-    size_t lds = size_t(blobBytes) + regBytes + size_t(BLOCK / 64) * 64 * 64;
+    size_t lds = size_t(blobBytes) + regBytes + size_t(BLOCK / 64) * 64 * kTdfaStageBytes;
     if (gPadLdsTo > lds) lds = gPadLdsTo;
-    auto kern = tdfa_match_kernel<BLOCK, false, true, false, LAB>;
+    auto kern = tdfa_stream_kernel<BLOCK, true, PAIR, LAB>;
+    if constexpr (!STREAM) {
+        if constexpr (kTdfaStageBytes == 64) kern = tdfa_match_kernel<BLOCK, PAIR, true, false, LAB>;
+        else {
+            printf("%-34s  skipped: the phase-separated kernel stages 64 bytes\n", name);
+            return 0;
+        }
+    }
     if (lds > 160 * 1024) {
         printf("%-34s  skipped: %zu bytes of LDS\n", name, lds);
         return 0;
@@ -144,6 +155,10 @@ static double runVariant(const char* name, const Inputs& in, const Dev& d, std::
                            static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, in.nGroups, d.caps, d.status, longFlag, 1u);
     };
     CK(hipMemset(d.status, 7, in.nLines));
+    if (getenv("LAB_TRACE")) {
+        printf("-> %s\n", name);
+        fflush(stdout);
+    }
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     hipEvent_t a, b;
@@ -167,7 +182,7 @@ static double runVariant(const char* name, const Inputs& in, const Dev& d, std::
     else if (statusOut && !statusOut->empty()) {
         const bool sameStatus = st == *statusOut;
         const bool sameCaps = caps == *capsOut;
-        verdict = (LAB & kLabNoStamp) ? (sameStatus ? "status==" : "STATUS DIFFERS") : (sameStatus && sameCaps ? "bit-exact" : "MISMATCH");
+        verdict = (LAB & (kLabNoOutput | kLabNoLoop)) ? "(timing only)" : (LAB & kLabNoStamp) ? (sameStatus ? "status==" : "STATUS DIFFERS") : (sameStatus && sameCaps ? "bit-exact" : "MISMATCH");
     }
     if (!POOL && statusOut && statusOut->empty()) {
         *statusOut = st;
@@ -222,7 +237,41 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> refStatus;
 #define RUN(B, L, NAME) runVariant<B, L>(NAME, in, d, &refCaps, &refStatus, iters)
 #define RUNP(B, L, NAME) runVariant<B, L, true>(NAME, in, d, &refCaps, &refStatus, iters)
-    RUN(256, 0, "compact 256 (product)");
+    if (kTdfaStageBytes == 64) RUN(256, 0, "compact 256 (product)");
+#define RUNS(B, L, NAME) runVariant<B, L, false, true>(NAME, in, d, &refCaps, &refStatus, iters)
+#define RUNSP(B, L, NAME) runVariant<B, L, true, true>(NAME, in, d, &refCaps, &refStatus, iters)
+    if (in.blob[TD_OFF_PAIR]) {
+        runVariant<512, 0, false, false, false>("compact 512, single-byte table", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, 0, false, false, true>("compact 512 pairs (old kernel)", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, 0, false, true, false>("stream 512, single-byte table", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, 0, false, true, true>("stream 512 pairs", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoStamp, false, true, true>("stream 512 pairs, no stamps", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoOutput, false, true, true>("stream 512 pairs, no output", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, 0, true, true, true>("stream 512 pairs, pool", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoOutput, true, true, true>("stream 512 pairs, no output, pool", in, d, &refCaps, &refStatus, iters);
+        return 0;
+    }
+    RUNS(256, 0, "stream 256");
+    if (getenv("LAB_ONLY")) {
+        RUNS(256, kLabPreClass | kLabNoStamp, "stream 256 bare chain");
+        RUNS(256, kLabNoOutput, "stream 256 no output");
+        return 0;
+    }
+    RUNS(256, kLabNoStamp, "stream 256 no stamps");
+    RUNS(256, kLabPreClass, "stream 256 pre-classified");
+    RUNS(256, kLabPreClass | kLabNoStamp, "stream 256 bare chain");
+    RUNSP(256, 0, "stream 256, pool");
+    RUNSP(256, kLabPreClass | kLabNoStamp, "stream 256 bare chain, pool");
+    RUNS(64, 0, "stream 64");
+    RUNS(128, 0, "stream 128");
+    RUNS(512, 0, "stream 512");
+    RUN(64, 0, "compact 64 (old kernel)");
+    RUNS(256, kLabNoOutput, "stream 256 no output");
+    RUNS(256, kLabNoLoop, "stream 256 no loop");
+    RUNS(256, kLabNoLoop | kLabNoOutput, "stream 256 no loop, no output");
+    RUNSP(256, kLabNoOutput, "stream 256 no output, pool");
+    RUNSP(256, kLabNoOutput | kLabPreClass | kLabNoStamp, "stream bare chain no output, pool");
+    if (getenv("LAB_SWEEP"))
     for (int wgs : {1, 2, 3, 4, 5}) {
         gPadLdsTo = size_t(160 * 1024 / wgs) & ~size_t(255);
         char nm[64];
