@@ -6,11 +6,17 @@ regex, bit-exact capture offsets), with the HBM-roofline fraction and the host-C
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (lc_regex_match_device: the replacement for the per-event
-BoostRegexMatch loop, core/plugin/processor/ProcessorParseRegexNative.cpp:115-124,194) over one batch of
-1 Mi synthetic lines already resident in HBM.  Multi-GPU is an embarrassingly parallel line shard: each rank owns
-its own batch, there is no data-path collective; only the elapsed time is max-reduced (weak scaling).
-Rank 0 prints ONE JSON line.
+Default (BASELINE configs[1]).  One "step" = one pass of the hot path (lc_regex_match_device: the replacement for the
+per-event BoostRegexMatch loop, core/plugin/processor/ProcessorParseRegexNative.cpp:115-124,194) over one batch of
+1 Mi synthetic lines already resident in HBM.  `value` is that kernel-side rate; the same line also carries
+`end_to_end` (the north-star path with the host in it: pinned staging + H2D || kernel || D2H through
+lc_regex_match_host, and the in-agent shape -- lc_processor_process on 1000-line event groups from 1 and N runner
+threads), measured in the same run, never inside the timed region.  Multi-GPU is an embarrassingly parallel line shard:
+each rank owns its own batch, there is no data-path collective; the per-GPU counters are all-gathered (RCCL) so that
+rank 0 can print the per-GPU table next to the aggregate.  Rank 0 prints ONE JSON line.
+
+    python bench.py --config 4     # BASELINE configs[3]: 64 pipelines, each its own regex, ~512 KB groups round-robin
+    python bench.py --config 5     # BASELINE configs[4]: mixed nginx/JSON corpus fed FROM HOST in 64 MiB slabs per rank
 """
 import argparse
 import json
@@ -25,26 +31,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PCIE_GEN5_X16_GBPS = 63.0  # PCIe 5.0 x16, one direction, after 128b/130b encoding
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lines", type=int, default=1 << 20, help="lines per batch per GPU")
-    ap.add_argument("--line-bytes", type=int, default=512)
-    ap.add_argument("--regex", choices=["A", "B"], default="A", help="A: 10-group doc regex, B: 11-group benchmark regex")
-    ap.add_argument("--engine", choices=["auto", "tdfa", "nfa"], default="auto")
-    ap.add_argument("--cpu-sample-lines", type=int, default=1 << 20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def setup_dist():
     import torch
     import torch.distributed as dist
-
-    from loongcollector_amd import binding, corpus
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,8 +47,173 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+    return world, rank, dev
 
+
+# ------------------------------------------------------------------------------------------------- end to end (host in the path)
+def measure_h2d(dev, nbytes=256 << 20, reps=5):
+    """Raw pinned host -> device copy rate on this box (GB/s): what bounds every host-fed path."""
+    import torch
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        d.copy_(h, non_blocking=True)
+    b.record()
+    torch.cuda.synchronize()
+    return nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
+def measure_in_agent(pattern, keys, data, off, length, group_lines, n_groups, threads):
+    """lc_processor_process (gather views -> pinned staging -> H2D -> kernel -> D2H -> zero-copy stitch + policy) on event
+    groups of `group_lines` lines, the shape ProcessorRunner hands over (core/runner/ProcessorRunner.cpp:138-142), driven by
+    `threads` runner threads that share ONE processor instance (as the agent's threads share one plugin instance).
+    -> MB/s of `content` bytes.  ctypes releases the GIL for the duration of the C call."""
+    import concurrent.futures
+    from loongcollector_amd.processor import EventGroup, Processor
+    cfg = {"SourceKey": "content", "Regex": pattern, "Keys": keys}
+    proc = Processor(cfg)
+    groups, nbytes = [], 0
+    for g in range(n_groups):
+        lo = g * group_lines
+        groups.append(EventGroup.from_lines(data, off[lo:lo + group_lines], length[lo:lo + group_lines]))
+        nbytes += int(length[lo:lo + group_lines].sum())
+    import threading
+    slices = [groups[t::threads] for t in range(threads)]
+    warm = [EventGroup.from_lines(data, off[:group_lines], length[:group_lines]) for _ in range(threads)]
+    gate = threading.Barrier(threads + 1)
+    ends = [0.0] * threads
+
+    def run(t):
+        proc.process(warm[t])  # this thread's first call allocates its pinned staging and stream: not part of the figure
+        gate.wait()
+        for g in slices[t]:
+            proc.process(g)
+        ends[t] = time.perf_counter()
+
+    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+        futs = [ex.submit(run, t) for t in range(threads)]
+        gate.wait()
+        t0 = time.perf_counter()
+        for f in futs:
+            f.result()
+    dt = max(ends) - t0
+    c = proc.counters()
+    lines = n_groups * group_lines + group_lines * threads
+    if c["out_successful_events_total"] != lines or c["out_failed_events_total"] != 0:
+        raise SystemExit("PARITY FAILURE (in-agent path): %d of %d events parsed" % (c["out_successful_events_total"], lines))
+    first = groups[0].contents()[0]
+    return nbytes / dt / 1e6, first
+
+
+def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_counts, group_lines=1000, e2e_lines=1 << 18):
+    G = rx.groups
+    n = len(length)
+    out = {}
+    h2d = measure_h2d(dev)
+    out["h2d_GBps"] = round(h2d, 1)
+    # -- the host entry point: contiguous lines, two pinned slots, two streams (copy of chunk k+1 || kernel of chunk k)
+    rx.match_host(data, off[:-1], length)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        caps, status = rx.match_host(data, off[:-1], length)
+        best = min(best, time.perf_counter() - t0)
+    if exp_caps is not None and not np.array_equal(caps[:len(exp_caps)], exp_caps):
+        raise SystemExit("PARITY FAILURE (host path): capture offsets differ from the oracle")
+    payload = float(length.sum())
+    out["host_MBps"] = round(payload / best / 1e6, 1)
+    up = float(off[n]) + 8.0 * n  # bytes that cross the bus upwards per call: lines + separators, (offset, length) per line
+    out["host_h2d_GBps"] = round(up / best / 1e9, 1)
+    out["pcie_frac"] = round(up / best / 1e9 / h2d, 3)
+    out["host_what"] = "lc_regex_match_host: %d lines gathered into 2 pinned slots, H2D || kernel || D2H on 2 streams, 1 host thread" % n
+    # -- the in-agent shape
+    m = min(e2e_lines, n) // group_lines * group_lines
+    ag = {}
+    for t in thread_counts:
+        mbps, first = measure_in_agent(pattern, keys, data, off, length, group_lines, m // group_lines, t)
+        ag[str(t)] = round(mbps, 1)
+    if exp_caps is not None:  # spot check of the stitch: the first event's fields are the oracle's captures of line 0
+        raw = data[int(off[0]):int(off[0]) + int(length[0])].tobytes()
+        want = [(k, raw[exp_caps[0][2 * i]:exp_caps[0][2 * i + 1]].decode("latin-1")) for i, k in enumerate(keys)]
+        if [tuple(kv) for kv in first] != want:
+            raise SystemExit("PARITY FAILURE (in-agent path): stitched fields differ from the oracle's captures")
+    out["in_agent_MBps"] = ag
+    out["in_agent_what"] = ("lc_processor_process on %d-line event groups (gather into pinned staging -> ONE kernel launch that reads the lines and writes the capture table through the pinned mapping -> stitch + policy), "
+                            "N runner threads sharing one instance; %d lines" % (group_lines, m))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(pattern, keys, data, off, length, sample, d_caps, d_status):
+    from oracle import oracle as O  # the checker / reported baseline, never the measured path
+    orx = O.OracleRegex(pattern)
+    t0 = time.perf_counter()
+    exp_caps, exp_status = orx.fullmatch_batch(data, off[:sample], length[:sample])
+    cpu_s = time.perf_counter() - t0
+    got_caps = d_caps[:sample].cpu().numpy()
+    got_status = d_status[:sample].cpu().numpy()
+    if not (np.array_equal(got_status, exp_status) and np.array_equal(got_caps, exp_caps)):
+        raise SystemExit("PARITY FAILURE: GPU capture offsets differ from the oracle")
+    # reported baseline: the reference processor's whole per-event work (regex_match + one SetContentNoCopy per
+    # key + source tombstone + counters, oracle/processor_oracle.c) on the same lines, 1 thread = the reference's
+    # default process_thread_count (core/app_config/AppConfig.cpp:58)
+    t0 = time.perf_counter()
+    cnt = orx.process_batch(data, off[:sample], length[:sample], keys)
+    cpu_proc_s = time.perf_counter() - t0
+    assert cnt["out_successful"] == int(exp_status.sum())
+    sample_bytes = float(length[:sample].sum())
+    # all host cores, one slab of lines per thread (ctypes releases the GIL), as mReg[threadNo] would be used
+    import concurrent.futures
+    ncores = os.cpu_count() or 1
+    slabs = [(i * sample // ncores, (i + 1) * sample // ncores) for i in range(ncores)]
+    regs = [O.OracleRegex(pattern) for _ in range(ncores)]
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(ncores) as ex:
+        list(ex.map(lambda a: regs[a[0]].process_batch(data, off[a[1][0]:a[1][1]], length[a[1][0]:a[1][1]], keys),
+                    enumerate(slabs)))
+    cpu_all_s = time.perf_counter() - t0
+    # the stand-in engine BASELINE.md section 2 names: PCRE1 8.45 behind the same full-match wrapper (match only), checked
+    # against the oracle's captures on the lines it is timed on
+    engines = [{"engine": "oracle/bt_regex.c", "match_only_MBps": round(sample_bytes / cpu_s / 1e6, 1), "cores": 1}]
+    ps = min(sample, 1 << 18)
+    pv = O.pcre_version()
+    for jit in (False, True):
+        if not pv:
+            break
+        t0 = time.perf_counter()
+        r = O.pcre_fullmatch_batch(pattern, data, off[:ps], length[:ps], orx.groups, jit)
+        dt = time.perf_counter() - t0
+        engines.append({"engine": "PCRE1 %s%s" % (pv.split()[0], " JIT" if jit else ""), "cores": 1,
+                        "match_only_MBps": round(float(length[:ps].sum()) / dt / 1e6, 1), "lines": ps,
+                        "captures_equal_oracle": bool(np.array_equal(r[0], exp_caps[:ps]) and np.array_equal(r[1], exp_status[:ps]))})
+    cpu = {"value": round(sample_bytes / cpu_proc_s / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
+           "engine": "oracle/bt_regex.c: backtracking matcher restating boost::regex_match, with counted fast paths (faster than "
+                     "PCRE1, see engines; boost 1.68 itself is not available on this box)",
+           "sample": "%d lines (%d MB) of the timed batch: oracle/bt_regex.c (boost::regex_match restated) + "
+                     "oracle/processor_oracle.c (ProcessEvent work), 1 thread" % (sample, int(sample_bytes) >> 20),
+           "match_only_MBps": round(sample_bytes / cpu_s / 1e6, 1),
+           "all_cores": {"value": round(sample_bytes / cpu_all_s / 1e6, 1), "unit": "MB/s", "cores": ncores},
+           "engines": engines}
+    return cpu, exp_caps
+
+
+# ------------------------------------------------------------------------------------------------- configs[1]: the headline
+def run_headline(args):
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    from loongcollector_amd import binding, corpus
+    from loongcollector_amd.shard import gather_job
+
+    world, rank, dev = setup_dist()
     pattern = corpus.REGEX_A if args.regex == "A" else corpus.REGEX_B
+    keys = corpus.KEYS_A if args.regex == "A" else corpus.KEYS_B
     engine = {"auto": binding.LC_ENGINE_AUTO, "tdfa": binding.LC_ENGINE_TDFA, "nfa": binding.LC_ENGINE_NFA}[args.engine]
     rx = binding.GpuRegex(pattern, engine=engine)
     G = rx.groups
@@ -73,7 +230,6 @@ def main():
 
     # one step == one lc_regex_match_device_engine() call; arguments are marshalled once so that the timed loop is
     # the C-ABI call itself and not Python argument conversion
-    import ctypes
     L = binding.load()
     call_args = (rx.handle, ctypes.c_int(binding.LC_ENGINE_AUTO), ctypes.c_void_p(d_data.data_ptr()),
                  ctypes.c_void_p(d_off.data_ptr()), ctypes.c_void_p(None), ctypes.c_uint32(1), ctypes.c_uint32(n),
@@ -86,46 +242,23 @@ def main():
         if rc != 0:
             raise SystemExit("lc_regex_match_device failed rc=%d: %s" % (rc, L.lc_last_error()))
 
+    binding.launched_kernels()
     step()  # one untimed pass to produce the capture table the parity gate below checks
     torch.cuda.synchronize()
+    kernels = binding.launched_kernels()
 
     # ---- parity gate on this rank's batch (the timed batch): GPU vs oracle on the CPU-baseline sample
-    cpu = None
+    cpu, exp_caps = None, None
     sample = min(args.cpu_sample_lines, n)
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle.oracle import OracleRegex  # the checker / reported baseline, never the measured path
-        orx = OracleRegex(pattern)
-        t0 = time.perf_counter()
-        exp_caps, exp_status = orx.fullmatch_batch(data, off[:sample], length[:sample])
-        cpu_s = time.perf_counter() - t0
-        got_caps = d_caps[:sample].cpu().numpy()
-        got_status = d_status[:sample].cpu().numpy()
-        if not (np.array_equal(got_status, exp_status) and np.array_equal(got_caps, exp_caps)):
-            raise SystemExit("PARITY FAILURE: GPU capture offsets differ from the oracle")
-        # reported baseline: the reference processor's whole per-event work (regex_match + one SetContentNoCopy per
-        # key + source tombstone + counters, oracle/processor_oracle.c) on the same lines, 1 thread = the reference's
-        # default process_thread_count (core/app_config/AppConfig.cpp:58)
-        keys = corpus.KEYS_A if args.regex == "A" else corpus.KEYS_B
-        t0 = time.perf_counter()
-        cnt = orx.process_batch(data, off[:sample], length[:sample], keys)
-        cpu_proc_s = time.perf_counter() - t0
-        assert cnt["out_successful"] == int(exp_status.sum())
-        sample_bytes = float(length[:sample].sum())
-        # all host cores, one slab of lines per thread (ctypes releases the GIL), as mReg[threadNo] would be used
-        import concurrent.futures
+        cpu, exp_caps = cpu_baseline(pattern, keys, data, off, length, sample, d_caps, d_status)
+
+    # ---- the host-inclusive figures (rank 0 only, outside the timed region, bounded: a few seconds)
+    e2e = None
+    if rank == 0 and not args.no_e2e:
         ncores = os.cpu_count() or 1
-        slabs = [(i * sample // ncores, (i + 1) * sample // ncores) for i in range(ncores)]
-        regs = [OracleRegex(pattern) for _ in range(ncores)]
-        t0 = time.perf_counter()
-        with concurrent.futures.ThreadPoolExecutor(ncores) as ex:
-            list(ex.map(lambda a: regs[a[0]].process_batch(data, off[a[1][0]:a[1][1]], length[a[1][0]:a[1][1]], keys),
-                        enumerate(slabs)))
-        cpu_all_s = time.perf_counter() - t0
-        cpu = {"value": round(sample_bytes / cpu_proc_s / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": "%d lines (%d MB) of the timed batch: oracle/bt_regex.c (boost::regex_match restated) + "
-                         "oracle/processor_oracle.c (ProcessEvent work), 1 thread" % (sample, int(sample_bytes) >> 20),
-               "match_only_MBps": round(sample_bytes / cpu_s / 1e6, 1),
-               "all_cores": {"value": round(sample_bytes / cpu_all_s / 1e6, 1), "unit": "MB/s", "cores": ncores}}
+        tc = [1] + ([min(16, ncores)] if ncores > 1 else []) + ([min(32, ncores)] if ncores > 16 else [])
+        e2e = end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, tc)
 
     # ---- timed region: exactly K steps between barrier+synchronize pairs.  One HIP event pair on the launch stream
     # brackets the K back-to-back launches (per-launch event pairs insert markers between the kernels and were
@@ -146,31 +279,33 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [ev_start.elapsed_time(ev_end) / args.steps]
+    kernel_ms = ev_start.elapsed_time(ev_end) / args.steps
 
     matched = int(d_status.sum().item())
-    from loongcollector_amd.shard import reduce_job
-    # the job's only collective: MAX(elapsed) and SUM(counters) over ranks (RCCL); the data path has none
-    elapsed, totals = reduce_job(elapsed, {"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps,
-                                           "matched_last": matched}, device=dev)
+    # the job's only collective: ONE all-gather of the per-GPU counters (RCCL); the data path has none
+    per_gpu = gather_job({"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps, "matched_last": matched,
+                          "elapsed_us": int(elapsed * 1e6), "kernel_us_per_step": int(kernel_ms * 1e3)}, device=dev)
 
     if rank == 0:
-        total_bytes = totals["bytes"]
+        elapsed = max(g["elapsed_us"] for g in per_gpu) / 1e6
+        total_bytes = sum(g["bytes"] for g in per_gpu)
         value = total_bytes / elapsed / 1e6
-        avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+        avg_kernel_s = kernel_ms / 1e3
         # algorithmic HBM bytes per line: payload L + 4 B offset + 1 B status + 8 B per group
         algo_bytes = (args.line_bytes + 5 + 8 * G) * n
         achieved = algo_bytes / avg_kernel_s / 1e9
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-        # this same command, profiles/round1_traffic.json); only quoted for the workload they were collected on
+        # this same command, profiles/round*_traffic.json); only quoted for the workload they were collected on
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
-                    n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
-                traffic = tj["hbm_bytes_per_launch"]
+        for name in ("round2_traffic.json", "round1_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
+                        n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
+                    traffic = tj["hbm_bytes_per_launch"]
+                break
         out = {
             "metric": "MB/s parsed (512B lines, 10-field regex) per MI355X + HBM-roofline %",
             "value": round(value, 1),
@@ -192,14 +327,279 @@ def main():
                        "matched_lines_last_batch": matched},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": ("tdfa_match_kernel" if os.environ.get("LC_TDFA_STREAM") == "0" else "tdfa_stream_kernel") if info["engine"] == 1 else "nfa_match_kernel",
+                         "kernel": kernels.split(",")[0].split("<")[0] if kernels else None, "kernels_launched": kernels,
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
+            "per_gpu": [{"rank": i, "MBps": round(g["bytes"] / (g["elapsed_us"] / 1e6) / 1e6, 1),
+                         "kernel_ms": g["kernel_us_per_step"] / 1e3, "lines": g["lines"], "matched_last": g["matched_last"]}
+                        for i, g in enumerate(per_gpu)],
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------- configs[3]: 64 pipelines
+def tenant_pipelines(n_pipelines, group_lines, seed=20260923):
+    """64 tenants: delimiter-separated-field regexes with 6..14 capture groups over three delimiters, and for each a pool of
+    ~512 B lines (10 % carry one field too many and must fail)."""
+    rng = np.random.default_rng(seed)
+    delims = [" ", "|", "\t"]
+    esc = {"|": r"\|", " ": " ", "\t": r"\t"}
+    out = []
+    for p in range(n_pipelines):
+        ng = int(rng.integers(6, 15))
+        d = delims[p % 3]
+        cls = {" ": r"[^ ]", "|": r"[^|]", "\t": r"[^\t]"}[d]
+        pattern = esc[d].join("(%s*)" % cls for _ in range(ng))
+        lines = []
+        for _ in range(group_lines):
+            nf = ng + (1 if rng.integers(0, 10) == 0 else 0)
+            cuts = np.sort(rng.integers(0, 512 - nf, size=nf - 1))
+            lens = np.diff(np.concatenate([[0], cuts, [512 - nf + 1]]))
+            lines.append(d.join("".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(k))) for k in lens).encode())
+        out.append((pattern, lines))
+    return out
+
+
+def pack_lines(lines):
+    length = np.array([len(s) for s in lines], dtype=np.uint32)
+    off = np.zeros(len(lines) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(length.astype(np.uint64) + 1).astype(np.uint32)
+    data = np.frombuffer(b"\n".join(lines) + b"\n", dtype=np.uint8).copy()
+    return data, off, length
+
+
+def run_multitenant(args):
+    import torch
+
+    from loongcollector_amd import binding
+
+    world, rank, dev = setup_dist()
+    P, GL = args.pipelines, args.group_lines
+    tenants = tenant_pipelines(P, GL)
+    pipes = []
+    for pattern, lines in tenants:
+        rx = binding.GpuRegex(pattern)
+        data, off, length = pack_lines(lines)
+        pipes.append({"rx": rx, "pattern": pattern, "data": data, "off": off, "length": length,
+                      "d_data": torch.from_numpy(data).to(dev), "d_off": torch.from_numpy(off.view(np.int32)).to(dev),
+                      "d_caps": torch.empty((GL, 2 * rx.groups), dtype=torch.int32, device=dev),
+                      "d_status": torch.empty((GL,), dtype=torch.uint8, device=dev), "bytes": int(length.sum())})
+    streams = [torch.cuda.Stream() for _ in range(args.streams)]
+
+    def turn():  # one round-robin turn: one group per pipeline, as ProcessQueueManager::PopItem hands them out
+        for i, p in enumerate(pipes):
+            s = streams[i % len(streams)]
+            p["rx"].match_device(p["d_data"], p["d_off"], None, GL, p["d_caps"], p["d_status"], sep_bytes=1, stream=s.cuda_stream)
+
+    turn()
+    torch.cuda.synchronize()
+    if not args.no_cpu_baseline:  # parity gate: every pipeline's group against the oracle
+        from oracle.oracle import OracleRegex
+        for p in pipes:
+            ec, es = OracleRegex(p["pattern"]).fullmatch_batch(p["data"], p["off"][:-1], p["length"])
+            if not (np.array_equal(p["d_status"].cpu().numpy(), es) and np.array_equal(p["d_caps"].cpu().numpy(), ec)):
+                raise SystemExit("PARITY FAILURE: pipeline %r differs from the oracle" % p["pattern"])
+    for _ in range(args.warmup):
+        turn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        turn()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    total = sum(p["bytes"] for p in pipes) * args.steps
+    # the same bytes with NO tenant switch: pipeline 0's regex over a batch of P groups in one launch
+    p0 = pipes[0]
+    big = pack_lines(tenants[0][1] * P)
+    d_bd, d_bo = torch.from_numpy(big[0]).to(dev), torch.from_numpy(big[1].view(np.int32)).to(dev)
+    d_bc = torch.empty((GL * P, 2 * p0["rx"].groups), dtype=torch.int32, device=dev)
+    d_bs = torch.empty((GL * P,), dtype=torch.uint8, device=dev)
+    cs = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        p0["rx"].match_device(d_bd, d_bo, None, GL * P, d_bc, d_bs, sep_bytes=1, stream=cs)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        p0["rx"].match_device(d_bd, d_bo, None, GL * P, d_bc, d_bs, sep_bytes=1, stream=cs)
+    torch.cuda.synchronize()
+    single = time.perf_counter() - t1
+    launches = P * args.steps
+    algo = sum((512 + 5 + 8 * p["rx"].groups) * GL for p in pipes) * args.steps
+    out = {"metric": "aggregate MB/s parsed, %d pipelines round-robin on 1 MI355X" % P, "value": round(total / elapsed / 1e6, 1),
+           "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "configs[3]: %d pipelines, each its own regex (6-14 groups), %d-line (~%d KB) groups resident in HBM, "
+                                  "round-robin over %d streams" % (P, GL, 512 * GL >> 10, len(streams)),
+                      "launches_per_step": P, "table_bytes": [p["rx"].info()["table_bytes"] for p in pipes][:8]},
+           "per_launch_us": round(elapsed / launches * 1e6, 2),
+           "no_switch": {"what": "the same bytes as ONE launch of pipeline 0's regex over %d lines" % (GL * P),
+                         "MBps": round(p0["bytes"] * P * args.steps / single / 1e6, 1)},
+           "per_switch_overhead_us": round((elapsed - single) / launches * 1e6, 2),
+           "roofline": {"bound": "hbm", "achieved": round(algo / elapsed / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(algo / elapsed / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                        "what": "algorithmic bytes of all launches / wall time of the turn (launches of %d lines cannot fill 256 CUs: "
+                                "the bound that binds is launch latency)" % GL}}
+    print(json.dumps(out))
+
+
+# ------------------------------------------------------------------------------------------------- configs[4]: host-fed corpus
+def run_sharded_corpus(args):
+    import torch
+    import torch.distributed as dist
+
+    from loongcollector_amd import binding, corpus
+    from loongcollector_amd.shard import gather_job
+
+    world, rank, dev = setup_dist()
+    rx = binding.GpuRegex(corpus.REGEX_B)
+    G = rx.groups
+    slab_bytes = args.slab_mib << 20
+    total_bytes = int(args.corpus_gb * (1 << 30))
+    n_slabs_total = max(world, total_bytes // slab_bytes)
+    my_slabs = list(range(rank, n_slabs_total, world))  # 64 MiB slabs dealt round-robin to the ranks (SURVEY section 8e)
+    # distinct slab contents: a few slabs of mixed nginx/JSON lines (log-uniform 128..2048 B, 30 % JSON that must fail), cycled
+    kinds = 4
+    slabs = []
+    for k in range(kinds):
+        data, off, length = corpus.mixed_batch(int(slab_bytes / 640), seed=corpus.SEED + 7 + k)
+        nl = int(np.searchsorted(off, slab_bytes, side="right")) - 1  # whole lines only
+        nb = int(off[nl])
+        h = torch.empty(slab_bytes, dtype=torch.uint8).pin_memory()
+        h[:nb] = torch.from_numpy(data[:nb])
+        slabs.append({"host": h, "nbytes": nb, "lines": nl, "payload": int(length[:nl].sum()), "data": data, "off": off, "length": length})
+    max_lines = max(s["lines"] for s in slabs) + 1
+    NBUF = 3
+    bufs = []
+    for _ in range(NBUF):
+        bufs.append({"d_data": torch.empty(slab_bytes + 64, dtype=torch.uint8, device=dev),
+                     "d_off": torch.empty(max_lines + 1, dtype=torch.int32, device=dev),
+                     "d_n": torch.zeros(1, dtype=torch.int32, device=dev),
+                     "d_scratch": torch.empty(binding.split_scratch_bytes(slab_bytes) // 4 + 1, dtype=torch.int32, device=dev),
+                     "d_caps": torch.empty((max_lines, 2 * G), dtype=torch.int32, device=dev),
+                     "d_status": torch.empty((max_lines,), dtype=torch.uint8, device=dev),
+                     "h_caps": torch.empty((max_lines, 2 * G), dtype=torch.int32).pin_memory(),
+                     "h_status": torch.empty((max_lines,), dtype=torch.uint8).pin_memory(),
+                     "ev": None})
+    s_up, s_run, s_down = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    counters = {"bytes": 0, "lines": 0, "matched": 0, "failed": 0}
+    timing = []
+
+    def feed(slab, buf):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        with torch.cuda.stream(s_up):
+            if buf["ev"] is not None:
+                s_up.wait_event(buf["ev"][5])  # the buffer's previous results have left
+            ev[0].record(s_up)
+            buf["d_data"][:slab["nbytes"]].copy_(slab["host"][:slab["nbytes"]], non_blocking=True)
+            ev[1].record(s_up)
+        with torch.cuda.stream(s_run):
+            s_run.wait_event(ev[1])
+            ev[2].record(s_run)
+            binding.split_lines_device(buf["d_data"], slab["nbytes"], buf["d_off"], buf["d_n"], buf["d_scratch"], stream=s_run.cuda_stream)
+            rx.match_device_dyn(buf["d_data"], buf["d_off"], buf["d_n"], max_lines, buf["d_caps"], buf["d_status"], sep_bytes=1,
+                                stream=s_run.cuda_stream)
+            ev[3].record(s_run)
+        with torch.cuda.stream(s_down):
+            s_down.wait_event(ev[3])
+            ev[4].record(s_down)
+            buf["h_caps"][:slab["lines"]].copy_(buf["d_caps"][:slab["lines"]], non_blocking=True)
+            buf["h_status"][:slab["lines"]].copy_(buf["d_status"][:slab["lines"]], non_blocking=True)
+            ev[5].record(s_down)
+        buf["ev"] = ev
+        return ev
+
+    def drain(slab, buf, ev):
+        ev[5].synchronize()
+        st = buf["h_status"][:slab["lines"]].numpy()
+        m = int((st == 1).sum())
+        counters["bytes"] += slab["payload"]
+        counters["lines"] += slab["lines"]
+        counters["matched"] += m
+        counters["failed"] += slab["lines"] - m
+        timing.append((ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), ev[4].elapsed_time(ev[5])))
+
+    # parity gate on the first slab (bounded sample of its lines)
+    ev = feed(slabs[0], bufs[0])
+    ev[5].synchronize()
+    if int(bufs[0]["d_n"].item()) != slabs[0]["lines"]:
+        raise SystemExit("PARITY FAILURE: split kernel found %d lines, the corpus has %d" % (int(bufs[0]["d_n"].item()), slabs[0]["lines"]))
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle.oracle import OracleRegex
+        k = min(20000, slabs[0]["lines"])
+        ec, es = OracleRegex(corpus.REGEX_B).fullmatch_batch(slabs[0]["data"], slabs[0]["off"][:k], slabs[0]["length"][:k])
+        if not (np.array_equal(bufs[0]["h_status"][:k].numpy(), es) and np.array_equal(bufs[0]["h_caps"][:k].numpy(), ec)):
+            raise SystemExit("PARITY FAILURE: host-fed slab differs from the oracle")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inflight = []
+    for i, sidx in enumerate(my_slabs):
+        slab, buf = slabs[sidx % kinds], bufs[i % NBUF]
+        if len(inflight) == NBUF:
+            drain(*inflight.pop(0))
+        inflight.append((slab, buf, feed(slab, buf)))
+    while inflight:
+        drain(*inflight.pop(0))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tsum = np.array(timing).sum(axis=0) if timing else np.zeros(3)
+    per_gpu = gather_job(dict(counters, elapsed_us=int(elapsed * 1e6), h2d_us=int(tsum[0] * 1e3), kernel_us=int(tsum[1] * 1e3),
+                              d2h_us=int(tsum[2] * 1e3), slabs=len(my_slabs)), device=dev)
+    if rank == 0:
+        el = max(g["elapsed_us"] for g in per_gpu) / 1e6
+        tot = sum(g["bytes"] for g in per_gpu)
+        raw = sum(slabs[s % kinds]["nbytes"] for s in range(n_slabs_total))
+        out = {"metric": "aggregate node MB/s parsed, mixed nginx/JSON corpus fed from host", "value": round(tot / el / 1e6, 1),
+               "unit": "MB/s", "n_gpus": world, "steps": len(my_slabs), "warmup": 1, "ms_per_step": round(el / max(1, len(my_slabs)) * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "configs[4]: %.1f GB of mixed nginx (regex B, 11 groups) / JSON lines (128-2048 B log-uniform, 30 %% JSON "
+                                      "that must fail), %d MiB slabs dealt round-robin to %d rank(s), fed from pinned host memory: "
+                                      "H2D -> split kernel -> match kernel -> D2H, %d slabs in flight per rank; the corpus is %d distinct "
+                                      "slabs cycled" % (raw / 1e9, args.slab_mib, world, NBUF, kinds),
+                          "parallelism": "line-shard x%d, no data-path collective, one all-gather of the counters" % world},
+               "pcie": {"raw_bytes_up_GBps": round(raw / el / 1e9, 2), "peak_GBps": PCIE_GEN5_X16_GBPS * world,
+                        "frac": round(raw / el / 1e9 / (PCIE_GEN5_X16_GBPS * world), 3)},
+               "per_gpu": [{"rank": i, "MBps": round(g["bytes"] / (g["elapsed_us"] / 1e6) / 1e6, 1), "lines": g["lines"],
+                            "matched": g["matched"], "failed": g["failed"], "slabs": g["slabs"], "h2d_ms": g["h2d_us"] / 1e3,
+                            "kernel_ms": g["kernel_us"] / 1e3, "d2h_ms": g["d2h_us"] / 1e3} for i, g in enumerate(per_gpu)]}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
+                    help="2: the headline (BASELINE configs[1]); 4: multi-tenant (configs[3]); 5: host-fed sharded corpus (configs[4])")
+    ap.add_argument("--lines", type=int, default=1 << 20, help="lines per batch per GPU")
+    ap.add_argument("--line-bytes", type=int, default=512)
+    ap.add_argument("--regex", choices=["A", "B"], default="A", help="A: 10-group doc regex, B: 11-group benchmark regex")
+    ap.add_argument("--engine", choices=["auto", "tdfa", "nfa"], default="auto")
+    ap.add_argument("--cpu-sample-lines", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive measurements (end_to_end)")
+    ap.add_argument("--pipelines", type=int, default=64)
+    ap.add_argument("--group-lines", type=int, default=1000)
+    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--corpus-gb", type=float, default=10.0)
+    ap.add_argument("--slab-mib", type=int, default=64)
+    args = ap.parse_args()
+    if args.config == 4:
+        run_multitenant(args)
+    elif args.config == 5:
+        run_sharded_corpus(args)
+    else:
+        run_headline(args)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,9 @@ int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]);
 /* test fixtures in the reference unit tests' JSON format */
 lc_event_group_t* lc_group_from_json(const char* json, char* err, size_t errcap);
 /* malloc'd NUL-terminated JSON; release with lc_free */
+/* the group a file input hands over: one copy of the n lines (data + off[i], len[i]) back to back in the group's SourceBuffer,
+ * one log event per line whose `key` content is a view into it (ProcessorSplitLogStringNative.cpp:130-160) */
+lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, const char* key);
 char* lc_group_to_json(const lc_event_group_t* g);
 size_t lc_group_event_count(const lc_event_group_t* g);
 /* the logtail::PipelineEventGroup* inside the fixture wrapper (what processor_interface.process expects) */

@@ -238,6 +238,11 @@ void lc_thread_release(void);
  * undecided and the decide kernel settled, lines[1] = of those, reported LC_GAVE_UP.  Synchronises the thread's streams. */
 int lc_decide_stats(uint64_t lines[2]);
 
+/* Names of the match kernels the calling thread has launched since the last call (comma separated, duplicates folded) are
+ * copied to buf (NUL terminated, at most cap bytes); returns the length of the full list and clears it.  Diagnostics only:
+ * __graft_entry__.smoke() prints it so that the GPU-box log names the native code that ran. */
+size_t lc_launched_kernels(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

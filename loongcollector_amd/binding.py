@@ -119,6 +119,16 @@ def _check(rc, what):
     raise RuntimeError("%s failed: rc=%d %s" % (what, rc, msg.decode() if msg else ""))
 
 
+def launched_kernels():
+    """Names of the match kernels this thread has launched since the last call (lc_launched_kernels)."""
+    L = load()
+    L.lc_launched_kernels.restype = ctypes.c_size_t
+    L.lc_launched_kernels.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(1024)
+    L.lc_launched_kernels(buf, 1024)
+    return buf.value.decode()
+
+
 class GpuRegex:
     """Compiled pattern handle; mirrors the role of `boost::regex` in ProcessorParseRegexNative (mReg)."""
 

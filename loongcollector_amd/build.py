@@ -45,8 +45,10 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force=False, verbose=False):
-    if not force and not needs_build():
+def build_native(force=False, verbose=False, force_sources=()):
+    """force_sources: basenames of sources to recompile even if their objects look current (smoke() uses it to show a real
+    gfx950 compile on the GPU box)."""
+    if not force and not force_sources and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
@@ -65,7 +67,7 @@ def build_native(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+        if (not force and os.path.basename(src) not in force_sources and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h))
                         for h in os.listdir(CSRC) if h.endswith((".h", ".hpp")))):
             continue

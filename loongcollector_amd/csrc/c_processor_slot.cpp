@@ -121,6 +121,31 @@ extern "C" lc_event_group_t* lc_group_from_json(const char* json, char* err, siz
     return g.release();
 }
 
+// The group a file input hands over (LogFileReader read buffer -> ProcessorSplitLogStringNative,
+// ProcessorSplitLogStringNative.cpp:130-160): ONE copy of the lines, back to back with a separator byte, in the group's
+// SourceBuffer; one LogEvent per line whose `key` content is a view into that buffer.  bench.py and the tests use it to build
+// in-agent shaped input without going through JSON.
+extern "C" lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                                                 const char* key) {
+    if (!data || !off || !len || !key) return nullptr;
+    auto g = std::make_unique<lc_event_group>();
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += size_t(len[i]) + 1;
+    logtail::StringBuffer buf = g->group.GetSourceBuffer()->AllocateStringBuffer(total);
+    const logtail::StringBuffer keyBuf = g->group.GetSourceBuffer()->CopyString(key, std::strlen(key));
+    const logtail::StringView keyView(keyBuf.data, keyBuf.size);
+    size_t at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(buf.data + at, data + off[i], len[i]);
+        buf.data[at + len[i]] = '\n';
+        logtail::LogEvent* ev = g->group.AddLogEvent();
+        ev->SetTimestamp(1);
+        ev->SetContentNoCopy(keyView, logtail::StringView(buf.data + at, len[i]));
+        at += size_t(len[i]) + 1;
+    }
+    return g.release();
+}
+
 extern "C" char* lc_group_to_json(const lc_event_group_t* g) {
     if (!g) return nullptr;
     const std::string s = g->group.ToJsonString();

@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <mutex>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -47,6 +49,25 @@ static int hipFail(hipError_t e, const char* what) {
 
 extern "C" const char* lc_last_error(void) { return tlsError.c_str(); }
 
+// Names of the match kernels the calling thread launched since it last asked (smoke() prints them, so that the GPU-box log
+// shows which native code ran; not a profiler: names only, duplicates folded, capped)
+static thread_local std::string tlsKernelLog;
+static void noteKernel(const char* name) {
+    if (tlsKernelLog.size() > 512 || tlsKernelLog.find(name) != std::string::npos) return;
+    if (!tlsKernelLog.empty()) tlsKernelLog += ", ";
+    tlsKernelLog += name;
+}
+extern "C" size_t lc_launched_kernels(char* buf, size_t cap) {
+    const size_t n = tlsKernelLog.size();
+    if (buf && cap) {
+        const size_t k = n < cap - 1 ? n : cap - 1;
+        std::memcpy(buf, tlsKernelLog.data(), k);
+        buf[k] = 0;
+    }
+    tlsKernelLog.clear();
+    return n;
+}
+
 // Per-thread device resources (staging pipeline, Grok buffers, the decide pool) are freed by thread_local destructors.  A
 // thread that ends while the process is already exiting must not call into a HIP runtime that may be gone: an atexit
 // hook registered at first use (so it runs BEFORE the runtime's own teardown) turns those destructors into no-ops.
@@ -60,11 +81,16 @@ static void lcRegisterExitHook() {
 static bool lcRuntimeUsable() { return !gProcessExiting.load(); }
 
 extern "C" int lc_device_count(void) {
-    int n = 0;
+    // (a positive answer does not change during the process's life: every match call asks, from every runner thread, and a
+    // runtime call per group is a shared lock per group)
+    static std::atomic<int> known{0};
+    int n = known.load(std::memory_order_relaxed);
+    if (n > 0) return n;
     if (hipGetDeviceCount(&n) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
+    if (n > 0) known.store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -105,6 +131,17 @@ void lcReleaseDeviceTables(lc_regex* re) {
     if (haveCur) (void)hipSetDevice(cur);
 }
 
+// A caller that wants the match's last kernel to signal completion through host memory arms this before the match call
+// (runHostPipeline's zero-copy path).  The launcher that can honour it marks it consumed; otherwise the caller queues
+// lc_signal_kernel behind the match.
+struct DoneRequest {
+    uint32_t* counter = nullptr;  // device word, zero between launches
+    uint32_t* flag = nullptr;     // pinned host word
+    uint32_t seq = 0;
+    bool armed = false, consumed = false;
+};
+static thread_local DoneRequest tlsDone;
+
 // The kernel behind a (workgroup size, table format) pair: the interleaved-issue kernel (tdfa_stream_kernel.hpp) for the
 // class-indexed tables with or without the byte-pair extension, the phase-separated one (tdfa_kernel.hpp) for byte-indexed
 // rows -- and for everything when LC_TDFA_STREAM=0 is set (A/B measurements).
@@ -129,10 +166,24 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         ldsAttrSet[devNow][which] = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, minLen, n,
-                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, ngroups, d_caps, d_status,
-                       longFlag, seq);
-    HIP_TRY(hipGetLastError());
+    noteKernel(which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
+                     : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
+    // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)
+    const uint32_t* blobArg = static_cast<const uint32_t*>(dBlob);
+    // completion signal requested by the zero-copy host path (tlsDone, below): this launch carries it when it is the match's
+    // only launch (no mop-up launch follows, nothing runs behind it)
+    uint32_t* doneCounter = nullptr;
+    uint32_t* doneFlag = nullptr;
+    uint32_t doneSeq = 0;
+    if (tlsDone.armed && minLen == 0 && longFlag == nullptr) {
+        doneCounter = tlsDone.counter;
+        doneFlag = tlsDone.flag;
+        doneSeq = tlsDone.seq;
+        tlsDone.consumed = true;
+    }
+    void* args[] = {&d_data, &d_off, &d_len, &sep, &minLen, &n, &d_n, &d_order, &d_resume, &blobArg, &blobBytes, &regBytes, &ngroups,
+                    &d_caps, &d_status, &longFlag, &seq, &doneCounter, &doneFlag, &doneSeq};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(BLOCK), args, lds, stream));
     return LC_OK;
 }
 
@@ -257,6 +308,7 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
     if (pool.used && pool.lastStream != stream) HIP_TRY(hipStreamWaitEvent(stream, pool.lastUse, 0));
     const DecideShape shape{re->decideClosedCap, re->decideMaxEnter};
     const uint32_t nPos = uint32_t(re->nfa.positions.size());
+    noteKernel("nfa_decide_kernel");
     hipLaunchKernelGGL(nfa_decide_plan_kernel, dim3(1), dim3(256), 0, stream, d_off, d_len, sep, n, d_n, d_order, d_resume, nPos, shape,
                        d_status, overflowFlag, seq, pool.p, uint64_t(pool.bytes));
     hipLaunchKernelGGL(nfa_decide_kernel, dim3(kDecideWorkers), dim3(64), 0, stream, d_data, d_off, d_len, sep, d_resume,
@@ -281,6 +333,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
         ldsAttrSet[devNow] = lds;
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
+    noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
     hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
                        seq);
@@ -292,6 +345,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
         static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
         const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4;
         if (!wideOff && overflowFlag && wideLds <= 64 * 1024) {
+            noteKernel("nfa_wide_kernel");
             hipLaunchKernelGGL((nfa_wide_kernel<NS>), dim3(n), dim3(64), wideLds, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
                                d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, overflowFlag, seq);
             HIP_TRY(hipGetLastError());
@@ -409,6 +463,7 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr) {
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int rc;
+    if (!re->nfa.runGroups.empty()) tlsDone.armed = false;  // run_capture_kernel runs behind the match: it cannot signal
     if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
@@ -567,7 +622,17 @@ extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, cons
 static void lcGrokThreadRelease();
 namespace {
 
+// Completion of a zero-copy batch is signalled by the GPU itself: a one-lane kernel queued behind the match kernels stores the
+// batch's sequence number into a pinned word the host thread polls.  (hipStreamSynchronize from many runner threads at once
+// convoys inside the runtime: measured 7 GB/s with 2 threads, 1.2 GB/s with 32.)
+__global__ void lc_signal_kernel(uint32_t* flag, uint32_t seq) {
+    __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+}
+
 struct Slot {
+    uint32_t* hFlag = nullptr;  // pinned: sequence number of the last finished zero-copy batch
+    uint32_t* dDone = nullptr;  // device: workgroups of the signalling launch that have finished (zero between launches)
+    uint32_t flagSeq = 0;
     uint8_t* hData = nullptr;  // pinned
     uint32_t* hOff = nullptr;
     uint32_t* hLen = nullptr;
@@ -600,7 +665,7 @@ struct HostPipeline {
         for (auto& s : slots) {
             if (s.stream) (void)hipStreamSynchronize(s.stream);
             (void)hipHostFree(s.hData); (void)hipHostFree(s.hOff); (void)hipHostFree(s.hLen);
-            (void)hipHostFree(s.hCaps); (void)hipHostFree(s.hStatus);
+            (void)hipHostFree(s.hCaps); (void)hipHostFree(s.hStatus); (void)hipHostFree(s.hFlag); (void)hipFree(s.dDone);
             (void)hipFree(s.dData); (void)hipFree(s.dOff); (void)hipFree(s.dLen);
             (void)hipFree(s.dCaps); (void)hipFree(s.dStatus);
             if (s.done) (void)hipEventDestroy(s.done);
@@ -620,6 +685,11 @@ int growSlot(Slot& s, size_t dataBytes, size_t lines, size_t capsInts) {
     if (!s.stream) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hFlag), 64, hipHostMallocDefault));
+        *s.hFlag = 0;
+        s.flagSeq = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.dDone), 64));
+        HIP_TRY(hipMemset(s.dDone, 0, 64));
     }
     if (dataBytes > s.dataCap) {
         (void)hipHostFree(s.hData); (void)hipFree(s.dData);
@@ -682,8 +752,12 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
         tlsError = "no HIP device";
         return LC_ERR_NO_DEVICE;
     }
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
+    // the thread's current device: asked from the runtime once in a while, not per group (a runner thread does not hop devices)
+    static thread_local int cachedDev = -1;
+    static thread_local unsigned devAge = 0;
+    if (cachedDev < 0 || (++devAge & 255u) == 0) HIP_TRY(hipGetDevice(&cachedDev));
+    const int dev = cachedDev;
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
     static thread_local HostPipeline pipe;
     lcRegisterExitHook();
     tlsPipe = &pipe;
@@ -697,18 +771,118 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
     struct DrainGuard {
         HostPipeline& p;
         ~DrainGuard() {
+            bool dropped = false;
             for (auto& s : p.slots) {
                 if (!s.busy) continue;
                 if (s.stream) (void)hipStreamSynchronize(s.stream);
                 s.busy = false;
                 s.first = s.count = 0;
+                dropped = true;
             }
-            (void)hipGetLastError();
+            if (dropped) (void)hipGetLastError();  // (error paths only: this is a runtime call, and every group passes here)
         }
     } guard{pipe};
     uint32_t next = 0;
     int which = 0;
     int rc = LC_OK;
+    // ---- small batches (one chunk: what ProcessorRunner hands over, ~1000 lines): ZERO-COPY.  The lines are gathered into
+    // the slot's pinned staging and the kernels read them -- and write the capture table -- straight through the pinned
+    // mapping: no hipMemcpyAsync at all, one kernel launch per group.  Measured with tools/inagent_bench.cpp (1000-line groups,
+    // lc_processor_process, profiles/round2_inagent.txt): the copy pipeline's five small copies per group all pass through the
+    // device's SDMA queue, where the groups of ALL runner threads serialise (1.9 GB/s with 1 thread, 7.8 GB/s with 16); a
+    // kernel that streams its 64-byte stages over PCIe overlaps transfer and compute by construction and leaves the threads
+    // independent (2.5 GB/s with 1 thread, 16.6-20 GB/s with 16-32).  Batches of several chunks keep the copy pipeline below
+    // (its copies overlap with the kernels and use the bus better: 21 GB/s on 1 Mi lines).
+    // LC_HOST_ZEROCOPY=0: never; =2: the block goes up with one copy, only the results are zero-copy (measured slower).
+    static const int zeroCopyEnv = [] {
+        const char* e = getenv("LC_HOST_ZEROCOPY");
+        return e ? atoi(e) : -1;
+    }();
+    {
+        size_t bytes = 0;
+        for (uint32_t i = 0; i < n && bytes <= kChunkBytes; ++i) bytes += src.len[i];
+        const bool oneChunk = n <= kChunkLines && bytes <= kChunkBytes;
+        if (zeroCopyEnv != 0 && oneChunk) {
+            Slot& s = pipe.slots[0];
+            const uint8_t* lo = src.at(0);
+            const uint8_t* hi = src.at(n - 1) + src.len[n - 1];
+            bool contiguous = hi >= lo && size_t(hi - lo) <= bytes + 2ull * n;
+            for (uint32_t i = 1; i < n && contiguous; ++i) {
+                const uint8_t* prevEnd = src.at(i - 1) + src.len[i - 1];
+                const uint8_t* cur = src.at(i);
+                contiguous = cur >= prevEnd && size_t(cur - prevEnd) <= 2;
+            }
+            const size_t stageBytes = contiguous ? size_t(hi - lo) : bytes;
+            // one staging block: the lines, then the (offset, length) tables -- so that the copy-up variant needs ONE copy
+            const size_t tableAt = (stageBytes + 16 + 63) & ~size_t(63);
+            const size_t blockBytes = tableAt + 8 * size_t(n);
+            if ((rc = growSlot(s, blockBytes, n, size_t(n) * 2 * ngroups)) != LC_OK) return rc;
+            uint32_t* hOff = reinterpret_cast<uint32_t*>(s.hData + tableAt);
+            uint32_t* hLen = hOff + n;
+            if (contiguous) {
+                std::memcpy(s.hData, lo, stageBytes);
+                for (uint32_t i = 0; i < n; ++i) {
+                    hOff[i] = uint32_t(src.at(i) - lo);
+                    hLen[i] = src.len[i];
+                }
+            } else {
+                size_t at = 0;
+                for (uint32_t i = 0; i < n; ++i) {
+                    std::memcpy(s.hData + at, src.at(i), src.len[i]);
+                    hOff[i] = uint32_t(at);
+                    hLen[i] = src.len[i];
+                    at += src.len[i];
+                }
+            }
+            std::memset(s.hData + stageBytes, 0, 16);
+            static const bool pollOff = getenv("LC_HOST_NO_POLL") != nullptr;
+            const uint32_t doneSeqNo = ++s.flagSeq;
+            tlsDone = DoneRequest{s.dDone, s.hFlag, doneSeqNo, !pollOff, false};
+            if (zeroCopyEnv == 2) {
+                HIP_TRY(hipMemcpyAsync(s.dData, s.hData, blockBytes, hipMemcpyHostToDevice, s.stream));
+                rc = lcMatchOnStream(re, re->engine, dev, s.dData, reinterpret_cast<uint32_t*>(s.dData + tableAt),
+                                     reinterpret_cast<uint32_t*>(s.dData + tableAt) + n, 0, n, nullptr, nullptr, nullptr, ngroups,
+                                     s.hCaps, s.hStatus, s.stream);
+            } else {
+                rc = lcMatchOnStream(re, re->engine, dev, s.hData, hOff, hLen, 0, n, nullptr, nullptr, nullptr, ngroups, s.hCaps,
+                                     s.hStatus, s.stream);
+            }
+            const bool signalled = tlsDone.consumed;
+            tlsDone = DoneRequest{};
+            if (rc != LC_OK) return rc;
+            // Waiting.  Few runner threads: spin on the pinned flag word the match kernel's last workgroup stores (the kernels of
+            // a 1000-line group last ~60 us; the runtime's wait costs ~40 us more per group than a spin: 2.5 vs 2.1 GB/s with one
+            // thread).  Many: spinning threads burn the cores the others stitch on, and the runtime's blocking wait scales better
+            // (20.0 vs 16.6 GB/s with 16 threads on a 16-core quota) -- tools/inagent_bench.cpp, profiles/round2_inagent.txt.
+            static std::atomic<int> waiters{0};
+            const int ahead = waiters.fetch_add(1, std::memory_order_relaxed);
+            hipError_t waitErr = hipSuccess;
+            if (pollOff || ahead >= 4) {
+                waitErr = hipStreamSynchronize(s.stream);
+            } else {
+                uint32_t seq = doneSeqNo;
+                if (!signalled) {  // the match was more than one launch (or not a TDFA launch): a one-lane kernel behind it signals
+                    void* fargs[] = {&s.hFlag, &seq};
+                    waitErr = hipLaunchKernel(reinterpret_cast<const void*>(lc_signal_kernel), dim3(1), dim3(1), fargs, 0, s.stream);
+                }
+                volatile uint32_t* flag = s.hFlag;
+                unsigned spins = 0;
+                while (waitErr == hipSuccess && *flag != seq) {
+                    __builtin_ia32_pause();
+                    if (++spins > 40000u) {  // ~1 ms: long kernel, or something is wrong -- the runtime's wait reports errors
+                        waitErr = hipStreamSynchronize(s.stream);
+                        break;
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            waiters.fetch_sub(1, std::memory_order_relaxed);
+            HIP_TRY(waitErr);
+            if (ngroups) std::memcpy(caps, s.hCaps, size_t(n) * 2 * ngroups * 4);
+            std::memcpy(status, s.hStatus, n);
+            return LC_OK;
+        }
+    }
     while (next < n) {
         // carve a chunk: up to kChunkLines lines / kChunkBytes payload bytes
         uint32_t cnt = 0;

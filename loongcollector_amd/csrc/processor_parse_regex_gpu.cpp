@@ -181,17 +181,17 @@ void ProcessorParseRegexGpu::AddLog(const StringView& key, const StringView& val
 
 // the tail of ProcessorParseRegexNative::ProcessEvent :153-167
 bool ProcessorParseRegexGpu::FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess,
-                                         const GroupMetadata& metadata) {
+                                         const GroupMetadata& metadata, Tally& tally) {
     if (!parseSuccess || !mSourceKeyOverwritten) sourceEvent.DelContent(mSourceKey);
     if (mCommonParserOptions.ShouldAddSourceContent(parseSuccess))
         AddLog(mCommonParserOptions.mRenamedSourceKey, rawContent, sourceEvent, false);
     if (mCommonParserOptions.ShouldAddLegacyUnmatchedRawLog(parseSuccess))
         AddLog(GpuCommonParserOptions::legacyUnmatchedRawLogKey, rawContent, sourceEvent, false);
     if (mCommonParserOptions.ShouldEraseEvent(parseSuccess, sourceEvent, metadata)) {
-        ++mDiscardedEventsTotal;
+        ++tally.discarded;
         return false;
     }
-    ++mOutSuccessfulEventsTotal;
+    ++tally.outSuccessful;
     return true;
 }
 
@@ -209,6 +209,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
     static thread_local std::vector<uint32_t> lineLen;
     static thread_local std::vector<int32_t> caps;
     kind.assign(nEvents, Keep);
+    Tally tally;
     linePtr.clear();
     lineLen.clear();
 
@@ -216,12 +217,12 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
     for (size_t i = 0; i < nEvents; ++i) {
         PipelineEventPtr& e = events[i];
         if (!IsSupportedEvent(e)) {  // :135-138
-            ++mOutFailedEventsTotal;
+            ++tally.outFailed;
             continue;
         }
         LogEvent& ev = e.Cast<LogEvent>();
         if (!ev.HasContent(mSourceKey)) {  // :140-143
-            ++mOutKeyNotFoundEventsTotal;
+            ++tally.keyNotFound;
             continue;
         }
         if (mIsWholeLineMode) {  // :147-148, no regex engine involved
@@ -257,7 +258,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             LogEvent& ev = events[rIdx].Cast<LogEvent>();
             const StringView raw = ev.GetContent(mSourceKey);
             AddLog(StringView(mKeys.empty() ? kDefaultContentKey : mKeys[0]), raw, ev);  // :170-174
-            keep = FinishEvent(ev, raw, true, metadata);
+            keep = FinishEvent(ev, raw, true, metadata, tally);
         } else if (kind[rIdx] == Parse) {
             const size_t li = line++;
             if (deviceOk) {
@@ -268,14 +269,14 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                     // The line was NOT decided (only possible with the decide pass switched off, LC_NFA_NO_DECIDE): boost
                     // might match it, so it is neither a success nor a parse failure.  The event goes on untouched and is
                     // counted under its own counter.
-                    ++mUndecidedEventsTotal;
+                    ++tally.undecided;
                     if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
                     ++wIdx;
                     continue;
                 }
-                if (status[li] == LC_GAVE_UP) ++mComplexityExceededEventsTotal;  // boost: complexity exception -> parse failure
+                if (status[li] == LC_GAVE_UP) ++tally.complexityExceeded;  // boost: complexity exception -> parse failure
                 if (status[li] != LC_MATCH) {  // :194-226 (alarms/logging are the host agent's business)
-                    ++mOutFailedEventsTotal;
+                    ++tally.outFailed;
                     parseSuccess = false;
                 } else if (size_t(G) + 1 <= mKeys.size()) {  // what.size() <= keys.size()  :227-244, no counter
                     parseSuccess = false;
@@ -303,7 +304,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                         AddLog(StringView(mKeys[k]), val, ev);
                     }
                 }
-                keep = FinishEvent(ev, raw, parseSuccess, metadata);
+                keep = FinishEvent(ev, raw, parseSuccess, metadata, tally);
             }
         }
         if (keep) {
@@ -312,6 +313,12 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
         }
     }
     events.resize(wIdx);
+    if (tally.discarded) mDiscardedEventsTotal += tally.discarded;
+    if (tally.outFailed) mOutFailedEventsTotal += tally.outFailed;
+    if (tally.keyNotFound) mOutKeyNotFoundEventsTotal += tally.keyNotFound;
+    if (tally.outSuccessful) mOutSuccessfulEventsTotal += tally.outSuccessful;
+    if (tally.complexityExceeded) mComplexityExceededEventsTotal += tally.complexityExceeded;
+    if (tally.undecided) mUndecidedEventsTotal += tally.undecided;
 }
 
 }  // namespace logtail

@@ -71,7 +71,12 @@ public:
 private:
     bool IsSupportedEvent(const PipelineEventPtr& e) const { return e.Is<LogEvent>(); }
     // the per-event policy of ProcessorParseRegexNative::ProcessEvent (:132-168) given the match result
-    bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata);
+    // per-call tallies: the runner threads share this instance, and an atomic increment per EVENT on a shared cache line is
+    // what stopped lc_processor_process from scaling with threads; Process() adds its tallies to the counters once, at the end
+    struct Tally {
+        uint64_t discarded = 0, outFailed = 0, keyNotFound = 0, outSuccessful = 0, complexityExceeded = 0, undecided = 0;
+    };
+    bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata, Tally& tally);
     void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
 
     bool mSourceKeyOverwritten = false;

@@ -265,6 +265,22 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
     if (live) status[line] = matched ? LC_MATCH : LC_NOMATCH;
 }
 
+// Completion signal of a launch whose caller polls host memory instead of asking the runtime (gpu_runtime.hip, the zero-copy
+// host path): every workgroup publishes its results system-wide and counts itself; the last one resets the counter and stores
+// the launch's sequence number into the caller's pinned flag word.  doneFlag == nullptr: nothing to do.
+__device__ __forceinline__ void tdfaSignalDone(uint32_t* doneCounter, uint32_t* doneFlag, uint32_t doneSeq) {
+    if (!doneFlag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(doneCounter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(doneCounter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Byte-PAIR stepping (device_tables.h TP_*): the state chain -- the only serial dependency, one LDS round trip per link --
 // has one link per TWO bytes: t = pair32[(t & 0xFFFF) + cmapA[byte 2k] + cmap8[byte 2k+1]].  The entry also names the
 // register each of the two bytes stamps.  Same phases as tdfaStepBytes; NB/2 dependent lookups instead of NB.
@@ -339,7 +355,9 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
                                                            const uint32_t* __restrict__ blob,
                                                            uint32_t blobBytes, uint32_t regBytes, uint32_t nGroupsOut,
                                                            int32_t* __restrict__ caps, uint8_t* __restrict__ status,
-                                                           uint32_t* __restrict__ longFlag, uint32_t launchSeq) {
+                                                           uint32_t* __restrict__ longFlag, uint32_t launchSeq,
+                                                           uint32_t* __restrict__ doneCounter, uint32_t* __restrict__ doneFlag,
+                                                           uint32_t doneSeq) {
     static_assert(!(BYTEROWS && PAIR) && (COMPACT || !BYTEROWS), "byte rows: compact only, and no pair extension");
     constexpr bool WIDE = BYTEROWS;
     typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type TdfaReg;
@@ -520,4 +538,5 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
                                      status);
+    tdfaSignalDone(doneCounter, doneFlag, doneSeq);
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kerne
     uint32_t minLen, uint32_t nLines, const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t regBytes,
     uint32_t nGroupsOut, int32_t* __restrict__ caps, uint8_t* __restrict__ status, uint32_t* __restrict__ longFlag,
-    uint32_t launchSeq) {
+    uint32_t launchSeq, uint32_t* __restrict__ doneCounter, uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
     static_assert(kTdfaStageBytes == 64 || kTdfaStageBytes == 128, "4 or 8 16-byte segments per stage");
     constexpr int kLoads = kTdfaLoads;  // 16-byte segments per staged row == lanes that share one line == loads per stage
     static_assert(!PAIR || (LAB & kLabPreClass) == 0, "no pre-classified pairs");
@@ -373,4 +373,5 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kerne
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
                                      status);
+    tdfaSignalDone(doneCounter, doneFlag, doneSeq);
 }

@@ -40,6 +40,8 @@ def _lib():
         L.lc_group_native.argtypes = [vp]
         L.lc_group_from_json.restype = vp
         L.lc_group_from_json.argtypes = [cp, cp, sz]
+        L.lc_group_from_lines.restype = vp
+        L.lc_group_from_lines.argtypes = [vp, vp, vp, ctypes.c_uint32, cp]
         L.lc_group_to_json.restype = vp
         L.lc_group_to_json.argtypes = [vp]
         L.lc_group_event_count.restype = sz
@@ -60,6 +62,21 @@ class EventGroup:
         self._h = self._L.lc_group_from_json(text.encode("utf-8"), err, 256)
         if not self._h:
             raise ValueError(err.value.decode())
+
+    @classmethod
+    def from_lines(cls, data, off, length, key="content"):
+        """The group a file input hands over: n lines (numpy: data u8[], off u32[n], length u32[n]) copied once into the group's
+        SourceBuffer, one log event per line with `key` = a view of its line (lc_group_from_lines)."""
+        import numpy as np
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        self = cls.__new__(cls)
+        self._L = _lib()
+        self._h = self._L.lc_group_from_lines(data.ctypes.data, off.ctypes.data, length.ctypes.data, len(off), key.encode("utf-8"))
+        if not self._h:
+            raise ValueError("lc_group_from_lines failed")
+        return self
 
     def to_json(self):
         p = self._L.lc_group_to_json(self._h)

@@ -22,7 +22,7 @@ ORX_REGEXP2 = 16
 def build(force=False):
     """Compile liboracle.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("bt_regex.c", "processor_oracle.c", "bt_regex.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("bt_regex.c", "processor_oracle.c", "pcre_baseline.c", "bt_regex.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -47,8 +47,37 @@ def lib():
         L.orx_process_batch.restype = ctypes.c_ulong
         L.orx_process_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_ulong)]
+        L.orx_pcre_version.restype = ctypes.c_char_p
+        L.orx_pcre_fullmatch_batch.restype = ctypes.c_long
+        L.orx_pcre_fullmatch_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
     return _LIB
+
+
+def pcre_version():
+    """Version string of the PCRE1 library the baseline leg can open ("" if none)."""
+    return lib().orx_pcre_version().decode()
+
+
+def pcre_fullmatch_batch(pattern, data, off, length, ngroups, jit=False):
+    """PCRE1 (BASELINE.md section 2's stand-in for boost::regex_match) on a batch, in the oracle's output layout:
+    -> (caps int32[n][2*ngroups], status uint8[n]) or None when no libpcre can be opened."""
+    if isinstance(pattern, str):
+        pattern = pattern.encode("utf-8")
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    length = np.ascontiguousarray(length, dtype=np.uint32)
+    n = len(off)
+    caps = np.empty((n, 2 * ngroups), dtype=np.int32)
+    status = np.empty((n,), dtype=np.uint8)
+    r = lib().orx_pcre_fullmatch_batch(pattern, len(pattern), data.ctypes.data, off.ctypes.data, length.ctypes.data, n, ngroups,
+                                       1 if jit else 0, caps.ctypes.data, status.ctypes.data)
+    if r == -1:
+        return None
+    if r < 0:
+        raise ValueError("PCRE1 rejects the pattern")
+    return caps, status
 
 
 class OracleRegex:

@@ -26,7 +26,10 @@ def _worker(rank, world, port, out):
     data, off, length = corpus.apache_batch(n_total, "A", pool_lines=64)
     my_bytes = int(length[lo:hi].sum())
     elapsed, total = reduce_job(0.5 + rank, {"bytes": my_bytes, "lines": hi - lo})
+    from loongcollector_amd.shard import gather_job, job_totals
+    table = gather_job({"bytes": my_bytes, "lines": hi - lo, "elapsed_us": 500000 + 1000000 * rank, "kernel_us": 7 + rank})
     out[rank] = (lo, hi, elapsed, total["bytes"], total["lines"], int(length.sum()))
+    out["table%d" % rank] = (table, job_totals(table))
     dist.destroy_process_group()
 
 
@@ -40,6 +43,12 @@ def test_two_rank_line_shard_and_job_reduction():
     assert (lo0, hi0, lo1, hi1) == (0, 501, 501, 1001)        # slabs tile the corpus, no overlap, no gap
     assert e0 == e1 == 1.5                                   # MAX over ranks
     assert b0 == b1 == all_bytes and l0 == l1 == 1001        # SUM over ranks == whole job
+    # the all-gathered per-GPU table (what bench.py prints as per_gpu): every rank holds both rows, in rank order
+    (t0, tot0), (t1, tot1) = out["table0"], out["table1"]
+    assert t0 == t1 and len(t0) == 2
+    assert [g["lines"] for g in t0] == [501, 500] and [g["kernel_us"] for g in t0] == [7, 8]
+    assert t0[0]["bytes"] + t0[1]["bytes"] == all_bytes
+    assert tot0 == tot1 and tot0["elapsed_us"] == 1500000 and tot0["lines"] == 1001 and tot0["bytes"] == all_bytes
 
 
 def test_shard_range_tiles_for_any_world_size():

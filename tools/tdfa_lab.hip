@@ -152,7 +152,7 @@ static double runVariant(const char* name, const Inputs& in, const Dev& d, std::
     const uint32_t grid = (in.nLines + BLOCK - 1) / BLOCK;
     auto launch = [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, src, POOL ? d.offPool : d.off, POOL ? d.lenPool : nullptr, 1u, 0u, in.nLines, nullptr, nullptr, nullptr,
-                           static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, in.nGroups, d.caps, d.status, longFlag, 1u);
+                           static_cast<const uint32_t*>(dBlob), blobBytes, regBytes, in.nGroups, d.caps, d.status, longFlag, 1u, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u);
     };
     CK(hipMemset(d.status, 7, in.nLines));
     if (getenv("LAB_TRACE")) {
