@@ -184,6 +184,23 @@ int lc_regex_match_device_from(lc_regex_t* re, int engine, const uint8_t* d_data
                                const uint32_t* d_nlines, const uint32_t* d_from, uint32_t ngroups, int32_t* d_caps,
                                uint8_t* d_status, void* stream);
 
+/* Several batches, each with its own compiled regex, in ONE call (BASELINE configs[3]: many pipelines share one GPU, and
+ * ProcessQueueManager::PopItem hands their event groups out round-robin, core/collection_pipeline/queue/ProcessQueueManager.cpp).
+ * Batches whose pattern runs on the TDFA engine are packed into a single kernel launch: every workgroup stages the tables of
+ * ITS batch into LDS (the per-pipeline switch costs what staging 1-3 KB costs), so that 64 groups of 1000 lines fill the chip
+ * the way one 64 000-line batch does.  The other batches (NFA engine, run captures) are launched one by one on the same
+ * stream.  Results are exactly those of one lc_regex_match_device call per job.  Asynchronous on `stream`. */
+typedef struct lc_match_job {
+    lc_regex_t* re;
+    const uint8_t* d_data;
+    const uint32_t* d_off;
+    const uint32_t* d_len; /* or NULL: len = off[i+1] - off[i] - sep_bytes */
+    uint32_t sep_bytes, n, ngroups;
+    int32_t* d_caps;
+    uint8_t* d_status;
+} lc_match_job;
+int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t njobs, void* stream);
+
 /* Same as lc_regex_match_device_engine with offsets[n+1] + sep_bytes, but the line count is read from device memory
  * (*d_nlines, clamped to max_lines) when the kernel starts: lets lc_split_lines_device and the match run back to back
  * on one stream with no host round trip.  Lines beyond *d_nlines are not touched. */

@@ -119,6 +119,31 @@ def _check(rc, what):
     raise RuntimeError("%s failed: rc=%d %s" % (what, rc, msg.decode() if msg else ""))
 
 
+class LcMatchJob(ctypes.Structure):
+    _fields_ = [("re", ctypes.c_void_p), ("d_data", ctypes.c_void_p), ("d_off", ctypes.c_void_p), ("d_len", ctypes.c_void_p),
+                ("sep_bytes", ctypes.c_uint32), ("n", ctypes.c_uint32), ("ngroups", ctypes.c_uint32),
+                ("d_caps", ctypes.c_void_p), ("d_status", ctypes.c_void_p)]
+
+
+def make_jobs(jobs):
+    """jobs: list of (GpuRegex, d_data, d_off, d_len or None, n, d_caps, d_status, sep_bytes) with torch device tensors
+    -> a marshalled job array for match_device_multi (keep it alive until the stream has been synchronised)."""
+    arr = (LcMatchJob * len(jobs))()
+    for k, (rx, d_data, d_off, d_len, n, d_caps, d_status, sep) in enumerate(jobs):
+        arr[k] = LcMatchJob(rx.handle, d_data.data_ptr(), d_off.data_ptr(), d_len.data_ptr() if d_len is not None else None,
+                            sep, n, rx.groups, d_caps.data_ptr(), d_status.data_ptr())
+    return arr
+
+
+def match_device_multi(job_array, stream=None):
+    """lc_regex_match_device_multi: several batches, each with its own regex, packed into one kernel launch."""
+    L = load()
+    L.lc_regex_match_device_multi.restype = ctypes.c_int
+    L.lc_regex_match_device_multi.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    _check(L.lc_regex_match_device_multi(ctypes.cast(job_array, ctypes.c_void_p), len(job_array), ctypes.c_void_p(stream or 0)),
+           "lc_regex_match_device_multi")
+
+
 def launched_kernels():
     """Names of the match kernels this thread has launched since the last call (lc_launched_kernels)."""
     L = load()

@@ -504,6 +504,151 @@ extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const ui
                          static_cast<hipStream_t>(stream));
 }
 
+// ---- lc_regex_match_device_multi: the job tables are read by the kernel straight from pinned host memory; a small ring of
+// them per thread, each guarded by an event, so that a caller may queue several multi-launches before it synchronises
+namespace {
+struct JobTableRing {
+    static constexpr int kTables = 8;
+    struct Table {
+        TdfaJob* jobs = nullptr;
+        uint32_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool inFlight = false;
+    } t[kTables];
+    int next = 0, device = -1;
+    ~JobTableRing() { release(); }
+    void release() {
+        if (device < 0 || !lcRuntimeUsable()) {
+            device = -1;
+            return;
+        }
+        (void)hipSetDevice(device);
+        for (auto& x : t) {
+            if (x.inFlight) (void)hipEventSynchronize(x.done);
+            if (x.done) (void)hipEventDestroy(x.done);
+            (void)hipHostFree(x.jobs);
+            x = Table();
+        }
+        device = -1;
+    }
+};
+thread_local JobTableRing tlsJobTables;
+
+template <int BLOCK>
+int launchTdfaMulti(const TdfaJob* table, uint32_t nJobs, uint32_t totalBlocks, size_t lds, hipStream_t stream) {
+    auto kern = tdfa_stream_multi_kernel<BLOCK, false>;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
+    int devNow = 0;
+    if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
+    if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        ldsAttrSet[devNow] = lds;
+    }
+    noteKernel("tdfa_stream_multi_kernel");
+    uint32_t* nullCounter = nullptr;
+    uint32_t* nullFlag = nullptr;
+    uint32_t zero = 0;
+    void* args[] = {&table, &nJobs, &nullCounter, &nullFlag, &zero};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(kern), dim3(totalBlocks), dim3(BLOCK), args, lds, stream));
+    return LC_OK;
+}
+}  // namespace
+
+extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t njobs, void* streamPtr) {
+    if (!jobs && njobs) return LC_ERR_ARG;
+    if (njobs == 0) return LC_OK;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+    for (uint32_t i = 0; i < njobs; ++i) {
+        const lc_match_job& j = jobs[i];
+        if (!j.re) return LC_ERR_ARG;
+        if (j.n && (!j.d_data || !j.d_off || !j.d_caps || !j.d_status)) return LC_ERR_ARG;
+    }
+    lcRegisterExitHook();
+    JobTableRing& ring = tlsJobTables;
+    if (ring.device != dev) {
+        ring.release();
+        ring.device = dev;
+    }
+    // one packed launch per workgroup size the tables were packed for (almost always one: 256)
+    for (int block : {256, 128, 64}) {
+        std::vector<TdfaJob> packed;
+        uint32_t blocks = 0;
+        size_t lds = 0;
+        for (uint32_t i = 0; i < njobs; ++i) {
+            const lc_match_job& j = jobs[i];
+            lc_regex* re = j.re;
+            if (j.n == 0 || re->engine != LC_ENGINE_TDFA || !re->hasTdfa || re->tdfaBlock != block || !re->nfa.runGroups.empty()) continue;
+            void* dBlob = nullptr;
+            const int rc = ensureUploaded(re, dev, kBlobTdfa, &dBlob);
+            if (rc != LC_OK) return rc;
+            const uint32_t blobBytes = uint32_t(re->tdfaBlob.size() * 4);
+            TdfaJob t;
+            t.data = j.d_data;
+            t.off = j.d_off;
+            t.len = j.d_len;
+            t.blob = static_cast<const uint32_t*>(dBlob);
+            t.caps = j.d_caps;
+            t.status = j.d_status;
+            t.sepBytes = j.sep_bytes;
+            t.nLines = j.n;
+            t.blobBytes = blobBytes;
+            t.regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
+            t.nGroupsOut = j.ngroups;
+            t.firstBlock = blocks;
+            blocks += (j.n + uint32_t(block) - 1) / uint32_t(block);
+            const size_t need = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
+            lds = need > lds ? need : lds;
+            packed.push_back(t);
+        }
+        if (packed.empty()) continue;
+        JobTableRing::Table& tab = ring.t[ring.next];
+        ring.next = (ring.next + 1) % JobTableRing::kTables;
+        if (!tab.done) HIP_TRY(hipEventCreateWithFlags(&tab.done, hipEventDisableTiming));
+        if (tab.inFlight) {
+            HIP_TRY(hipEventSynchronize(tab.done));
+            tab.inFlight = false;
+        }
+        if (packed.size() > tab.cap) {
+            (void)hipHostFree(tab.jobs);
+            tab.jobs = nullptr;
+            tab.cap = 0;
+            const uint32_t cap = uint32_t(packed.size()) * 2 + 16;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&tab.jobs), size_t(cap) * sizeof(TdfaJob), hipHostMallocDefault));
+            tab.cap = cap;
+        }
+        std::memcpy(tab.jobs, packed.data(), packed.size() * sizeof(TdfaJob));
+        int rc = LC_OK;
+        switch (block) {
+            case 256: rc = launchTdfaMulti<256>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 128: rc = launchTdfaMulti<128>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            default: rc = launchTdfaMulti<64>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+        }
+        if (rc != LC_OK) return rc;
+        HIP_TRY(hipEventRecord(tab.done, stream));
+        tab.inFlight = true;
+    }
+    // everything else: one launch sequence per job, as lc_regex_match_device would do
+    for (uint32_t i = 0; i < njobs; ++i) {
+        const lc_match_job& j = jobs[i];
+        lc_regex* re = j.re;
+        if (j.n == 0) continue;
+        if (re->engine == LC_ENGINE_TDFA && re->hasTdfa && re->nfa.runGroups.empty() &&
+            (re->tdfaBlock == 256 || re->tdfaBlock == 128 || re->tdfaBlock == 64))
+            continue;  // went with a packed launch
+        const int rc = lcMatchOnStream(re, re->engine, dev, j.d_data, j.d_off, j.d_len, j.sep_bytes, j.n, nullptr, nullptr, nullptr,
+                                       j.ngroups, j.d_caps, j.d_status, stream);
+        if (rc != LC_OK) return rc;
+    }
+    return LC_OK;
+}
+
 extern "C" int lc_regex_match_device_from(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
                                           const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, const uint32_t* d_lines,
                                           const uint32_t* d_nlines, const uint32_t* d_from, uint32_t ngroups,
@@ -944,6 +1089,7 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
 
 extern "C" void lc_thread_release(void) {
     if (tlsPipe) tlsPipe->release();
+    tlsJobTables.release();
     tlsDecidePool.release();
     lcGrokThreadRelease();
 }

@@ -115,13 +115,15 @@ __device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32
     return t;
 }
 
-template <int BLOCK, bool COMPACT, bool PAIR = false, int LAB = 0>
-__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kernel(
+// the kernel body; blockId = index of this workgroup among the workgroups of ITS batch (tdfa_stream_multi_kernel packs the
+// workgroups of several batches, each with its own tables, into one launch)
+template <int BLOCK, bool COMPACT, bool PAIR, int LAB>
+__device__ __forceinline__ void tdfaStreamBody(
     const uint8_t* __restrict__ data, const uint32_t* __restrict__ off, const uint32_t* __restrict__ len, uint32_t sepBytes,
     uint32_t minLen, uint32_t nLines, const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t regBytes,
     uint32_t nGroupsOut, int32_t* __restrict__ caps, uint8_t* __restrict__ status, uint32_t* __restrict__ longFlag,
-    uint32_t launchSeq, uint32_t* __restrict__ doneCounter, uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
+    uint32_t launchSeq, uint32_t blockId) {
     static_assert(kTdfaStageBytes == 64 || kTdfaStageBytes == 128, "4 or 8 16-byte segments per stage");
     constexpr int kLoads = kTdfaLoads;  // 16-byte segments per staged row == lanes that share one line == loads per stage
     static_assert(!PAIR || (LAB & kLabPreClass) == 0, "no pre-classified pairs");
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kerne
     }
     if (minLen && longFlag && __atomic_load_n(longFlag, __ATOMIC_RELAXED) < launchSeq) return;
     if (minLen) {  // mop-up launch behind a COMPACT one (see tdfa_match_kernel)
-        const uint32_t s0 = blockIdx.x * BLOCK + tid;
+        const uint32_t s0 = blockId * BLOCK + tid;
         bool mine = false;
         if (s0 < nLines) {
             const uint32_t ln = order ? order[s0] : s0;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kerne
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stageBase = blobBytes + regBytes + wave * kStagePerWave;
 
-    const uint32_t slot = blockIdx.x * BLOCK + tid;
+    const uint32_t slot = blockId * BLOCK + tid;
     bool live = slot < nLines;
     const uint32_t line = (live && order) ? order[slot] : slot;
     uint32_t o = 0, L = 0;
@@ -373,5 +375,47 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kerne
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
                                      status);
+}
+
+template <int BLOCK, bool COMPACT, bool PAIR = false, int LAB = 0>
+__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_kernel(
+    const uint8_t* __restrict__ data, const uint32_t* __restrict__ off, const uint32_t* __restrict__ len, uint32_t sepBytes,
+    uint32_t minLen, uint32_t nLines, const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t regBytes,
+    uint32_t nGroupsOut, int32_t* __restrict__ caps, uint8_t* __restrict__ status, uint32_t* __restrict__ longFlag,
+    uint32_t launchSeq, uint32_t* __restrict__ doneCounter, uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
+    tdfaStreamBody<BLOCK, COMPACT, PAIR, LAB>(data, off, len, sepBytes, minLen, nLines, nLinesPtr, order, resume, blob, blobBytes,
+                                             regBytes, nGroupsOut, caps, status, longFlag, launchSeq, blockIdx.x);
+    tdfaSignalDone(doneCounter, doneFlag, doneSeq);
+}
+
+// ---- several batches, each with its OWN tables, in ONE launch (BASELINE configs[3]: many pipelines share the GPU; a 1000-line
+// group fills 4 of 256 CUs and a launch per group leaves the chip to launch latency: measured 22 GB/s aggregate for 64
+// pipelines on 4 streams against 820 GB/s for the same bytes in one launch).  Workgroup b belongs to the job whose
+// [firstBlock, next firstBlock) holds b; it stages that job's tables into LDS -- the per-pipeline switch costs what staging
+// 1-3 KB costs -- and walks that job's lines.  The job table may live in pinned host memory (each workgroup reads 80 bytes).
+struct TdfaJob {
+    const uint8_t* data;
+    const uint32_t* off;
+    const uint32_t* len;
+    const uint32_t* blob;
+    int32_t* caps;
+    uint8_t* status;
+    uint32_t sepBytes, nLines, blobBytes, regBytes, nGroupsOut, firstBlock;
+};
+
+template <int BLOCK, bool COMPACT>
+__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_multi_kernel(const TdfaJob* __restrict__ jobs, uint32_t nJobs,
+                                                                                        uint32_t* __restrict__ doneCounter,
+                                                                                        uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
+    uint32_t lo = 0, hi = nJobs;  // the last job whose firstBlock <= blockIdx.x (wave-uniform: scalar loads)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].firstBlock <= blockIdx.x) lo = mid;
+        else hi = mid;
+    }
+    const TdfaJob j = jobs[lo];
+    tdfaStreamBody<BLOCK, COMPACT, false, 0>(j.data, j.off, j.len, j.sepBytes, 0u, j.nLines, nullptr, nullptr, nullptr, j.blob, j.blobBytes,
+                                            j.regBytes, j.nGroupsOut, j.caps, j.status, nullptr, 0u, blockIdx.x - j.firstBlock);
     tdfaSignalDone(doneCounter, doneFlag, doneSeq);
 }

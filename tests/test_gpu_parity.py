@@ -284,6 +284,62 @@ def test_config4_multi_tenant_64_pipelines_round_robin(torch_dev):
         assert 0.8 < exp_status.mean() < 0.97
 
 
+def test_multi_job_launch_equals_one_call_per_job(torch_dev):
+    """lc_regex_match_device_multi (BASELINE configs[3], one launch for many pipelines): jobs with different regexes, sizes
+    (including 1 line, a size that is not a multiple of the workgroup, an empty job), with and without a length table, one
+    pattern that runs on the NFA engine -- results bit-identical to the oracle, job by job."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    specs = [(r"([^ ]*) ([^ ]*) ([^ ]*)", " ", 1000), (r"([^|]*)\|([^|]*)", "|", 1), (r"(\w+)\t(\d+)\t(.*)", "\t", 257),
+             (r"([a-z]+) (\d+)", " ", 0), (r"(.*)a(.{70})", "", 40), (corpus.REGEX_B, None, 300), (r"([^ ]*) ([^ ]*)", " ", 513)]
+    jobs, keep, expect = [], [], []
+    for k, (pattern, d, n) in enumerate(specs):
+        if d is None:
+            data, off, length = corpus.apache_batch(n, "B", pool_lines=64)
+            off = off[:-1]
+        else:
+            lines = []
+            for _ in range(n):
+                if d:
+                    nf = int(rng.integers(1, 5))
+                    lines.append(d.join("".join(chr(int(c)) for c in rng.integers(97, 123, size=int(rng.integers(0, 9))))
+                                        if rng.integers(0, 3) else str(int(rng.integers(0, 999))) for _ in range(nf)).encode())
+                else:
+                    lines.append(("b" * int(rng.integers(0, 30)) + "a" * int(rng.integers(0, 3)) + "c" * int(rng.integers(60, 80))).encode())
+            data, off, length = pack(lines) if n else (np.zeros(16, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+            off = off[:n]
+        rx = B.GpuRegex(pattern)
+        use_len = k % 2 == 0
+        d_data = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).to(dev)
+        full_off = np.concatenate([off, [len(data)]]).astype(np.uint32) if not use_len else off.astype(np.uint32)
+        d_off = torch.from_numpy((full_off if len(full_off) else np.zeros(1, np.uint32)).view(np.int32)).to(dev)
+        d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev) if use_len and n else None
+        d_caps = torch.full((max(n, 1), 2 * rx.groups), 7, dtype=torch.int32, device=dev)
+        d_status = torch.full((max(n, 1),), 9, dtype=torch.uint8, device=dev)
+        sep = 0 if (use_len and n) or d is not None else 1  # pack() puts the lines back to back; apache_batch separates them
+        jobs.append((rx, d_data, d_off, d_len, n, d_caps, d_status, sep))
+        keep.append((d_data, d_off, d_len))
+        if n:
+            expect.append(OracleRegex(pattern).fullmatch_batch(data, off, length))
+        else:
+            expect.append(None)
+    arr = B.make_jobs(jobs)
+    B.launched_kernels()
+    B.match_device_multi(arr, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    names = B.launched_kernels()
+    assert "tdfa_stream_multi_kernel" in names                      # the TDFA jobs went out as one packed launch
+    engines = [j[0].info()["engine"] for j in jobs]
+    assert B.LC_ENGINE_NFA in engines and "nfa" in names            # ... and the NFA job on its own kernels
+    for (rx, _, _, _, n, d_caps, d_status, _), exp in zip(jobs, expect):
+        if not n:
+            assert int(d_status[0]) == 9                            # an empty job touches nothing
+            continue
+        assert np.array_equal(d_status.cpu().numpy()[:n], exp[1]), rx
+        assert np.array_equal(d_caps.cpu().numpy()[:n], exp[0]), rx
+
+
 def re_escape(d):
     return {"|": r"\|", " ": " ", "\t": r"\t"}[d]
 
