@@ -255,6 +255,16 @@ void lc_thread_release(void);
  * undecided and the decide kernel settled, lines[1] = of those, reported LC_GAVE_UP.  Synchronises the thread's streams. */
 int lc_decide_stats(uint64_t lines[2]);
 
+/* The calling thread's LAST NFA-engine launch: lines[0] = bytes of frame stack its depth-first first pass (one line per lane,
+ * nfa_dfs_kernel) carved from the pool, lines[1] = lines it left to the thread-list kernels (step budget exceeded, or no room in
+ * the pool).  Synchronises the thread's last such launch.  Diagnostics (tools/grok_bench.py, tests). */
+int lc_dfs_stats(uint64_t lines[2]);
+
+/* Switches the NFA engine's optional depth-first first pass (one line per lane, plain backtracking under a step budget; what it
+ * cannot settle goes to the thread-list kernels of the same launch, so results never change) on (1) / off (0) for the whole
+ * process, or back to the LC_NFA_DFS environment default (-1).  Off by default: measured slower on 8-64 Ki-line batches. */
+void lc_nfa_set_dfs(int on);
+
 /* Names of the match kernels the calling thread has launched since the last call (comma separated, duplicates folded) are
  * copied to buf (NUL terminated, at most cap bytes); returns the length of the full list and clears it.  Diagnostics only:
  * __graft_entry__.smoke() prints it so that the GPU-box log names the native code that ran. */

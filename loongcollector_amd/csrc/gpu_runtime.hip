@@ -276,6 +276,34 @@ struct DecidePool {
 };
 thread_local DecidePool tlsDecidePool;
 
+std::atomic<int> gNfaDfsMode{-1};  // -1: LC_NFA_DFS decides; 0 / 1: set by lc_nfa_set_dfs
+
+// Frame stacks of nfa_dfs_kernel (one line per lane): one pool per host thread and device, sized to the launch (about a
+// frame per byte of text), grow-only, capped by LC_NFA_DFS_POOL_MB (default 4096).
+struct DfsPool {
+    uint8_t* p = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    hipEvent_t lastUse = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool used = false;
+    ~DfsPool() { release(); }
+    void release() {
+        if (p && lcRuntimeUsable()) {
+            (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+            if (lastUse) (void)hipEventDestroy(lastUse);
+        }
+        p = nullptr;
+        bytes = 0;
+        device = -1;
+        lastUse = nullptr;
+        used = false;
+    }
+};
+thread_local DfsPool tlsDfsPool;
+
 size_t decidePoolBytes() {
     static const size_t v = [] {
         const char* e = getenv("LC_DECIDE_POOL_MB");
@@ -323,7 +351,8 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
 template <int NS, bool ATOMIC, bool GLOBAL>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
-                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq) {
+                          int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq,
+                          const uint32_t* pendingFlag) {
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
@@ -336,7 +365,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
     noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
     hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
                        d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
-                       seq);
+                       seq, pendingFlag);
     HIP_TRY(hipGetLastError());
     // Second chance for the lines that needed more than 64 live threads (nfa_wide_kernel.hpp: two threads per lane), for
     // patterns without atomic groups whose capture offsets fit twice into a lane's registers.  Its workgroups return at
@@ -385,8 +414,57 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
     uint32_t seq = ++re->nfaSeq[dev];
     if (seq == 0) {  // the 32-bit sequence wrapped: start over below every flag value seen so far
-        HIP_TRY(hipMemsetAsync(overflowFlag, 0, 4, stream));
+        HIP_TRY(hipMemsetAsync(overflowFlag, 0, 8, stream));
         seq = ++re->nfaSeq[dev];
+    }
+    // ---- optional first engine: the depth-first walk, one line per lane (nfa_dfs_kernel).  What it leaves pending (budget,
+    // pool) is what the thread-list kernels below look at.  OFF by default: with its frames in HBM a walk step costs ~12 us
+    // against ~2 us for a thread-list byte-step, and on the batch sizes measured (8-64 Ki lines, where every launch is bound by
+    // its longest line) it loses 5-10x (profiles/round2_grok_dfs_vs_threadlist.txt).  LC_NFA_DFS=1 or lc_nfa_set_dfs(1).
+    const uint32_t* pendingFlag = nullptr;
+    static const bool dfsEnv = [] {
+        const char* e = getenv("LC_NFA_DFS");
+        return e && e[0] == '1';
+    }();
+    const int dfsMode = gNfaDfsMode.load(std::memory_order_relaxed);
+    if (!decideOnly && (dfsMode < 0 ? dfsEnv : dfsMode != 0)) {
+        static const size_t poolCap = [] {
+            const char* e = getenv("LC_NFA_DFS_POOL_MB");
+            long mb = e ? atol(e) : 4096;
+            if (mb < 32) mb = 32;
+            return size_t(mb) << 20;
+        }();
+        static const uint32_t stepsPerByte = [] {
+            const char* e = getenv("LC_NFA_DFS_STEPS_PER_BYTE");
+            const long v = e ? atol(e) : 64;
+            return uint32_t(v < 1 ? 1 : v);
+        }();
+        const DecideShape shape{re->decideClosedCap, re->decideMaxEnter};
+        const size_t frameBytes = (size_t(kDecideFrameWords) + shape.closedCap + size_t(kDecideNodeWords) * shape.maxEnter) * 4;
+        size_t want = size_t(n) * 1024 * frameBytes + (1u << 20);  // about a frame per byte, ~1 KiB lines
+        if (want < (size_t(32) << 20)) want = size_t(32) << 20;
+        if (want > poolCap) want = poolCap;
+        DfsPool& pool = tlsDfsPool;
+        lcRegisterExitHook();
+        if (pool.device != dev || !pool.p || pool.bytes < want) {
+            pool.release();
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pool.p), want));
+            pool.bytes = want;
+            pool.device = dev;
+            HIP_TRY(hipEventCreateWithFlags(&pool.lastUse, hipEventDisableTiming));
+        }
+        if (pool.used && pool.lastStream != stream) HIP_TRY(hipStreamWaitEvent(stream, pool.lastUse, 0));
+        HIP_TRY(hipMemsetAsync(pool.p, 0, sizeof(DfsPoolHeader), stream));
+        uint32_t* pf = overflowFlag + 1;
+        noteKernel("nfa_dfs_kernel");
+        hipLaunchKernelGGL(nfa_dfs_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume,
+                           static_cast<const uint32_t*>(dBlob), shape, ngroups, d_caps, d_status, pf, seq, pool.p, uint64_t(pool.bytes),
+                           stepsPerByte);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(pool.lastUse, stream));
+        pool.lastStream = stream;
+        pool.used = true;
+        pendingFlag = pf;
     }
     if (decideOnly) {  // LC_ENGINE_DECIDE: every line goes to the depth-first walk
         hipLaunchKernelGGL(nfa_decide_mark_all_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_n, d_order, d_status,
@@ -401,7 +479,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         auto go = [&](auto a, auto g) {
             return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n,
                                                                               d_n, d_order, d_resume, ngroups, d_caps, d_status,
-                                                                              stream, overflowFlag, seq);
+                                                                              stream, overflowFlag, seq, pendingFlag);
         };
         if (atomic && global) return go(std::true_type{}, std::true_type{});
         if (atomic) return go(std::true_type{}, std::false_type{});
@@ -1088,10 +1166,27 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
 }  // namespace
 
 extern "C" void lc_thread_release(void) {
+    tlsDfsPool.release();
     if (tlsPipe) tlsPipe->release();
     tlsJobTables.release();
     tlsDecidePool.release();
     lcGrokThreadRelease();
+}
+
+extern "C" void lc_nfa_set_dfs(int on) { gNfaDfsMode.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
+
+extern "C" int lc_dfs_stats(uint64_t lines[2]) {
+    if (!lines) return LC_ERR_ARG;
+    lines[0] = lines[1] = 0;
+    DfsPool& pool = tlsDfsPool;
+    if (!pool.p || !pool.used) return LC_OK;
+    HIP_TRY(hipSetDevice(pool.device));
+    HIP_TRY(hipEventSynchronize(pool.lastUse));
+    DfsPoolHeader h;
+    HIP_TRY(hipMemcpy(&h, pool.p, sizeof h, hipMemcpyDeviceToHost));
+    lines[0] = h.cursor;
+    lines[1] = h.pending;
+    return LC_OK;
 }
 
 extern "C" int lc_decide_stats(uint64_t lines[2]) {

@@ -457,3 +457,84 @@ __global__ __launch_bounds__(64) void nfa_decide_kernel(const uint8_t* __restric
         waveLdsSync();
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------ the walk as the FIRST engine
+// nfa_dfs_kernel: ONE LINE PER LANE, plain backtracking (no memo) under a small step budget -- what regexp2 / boost do for
+// every line, 64 lines per wavefront.  The thread-list kernels keep a line's whole thread set in one wavefront and pay a
+// chain of dependent table reads per byte (2-4 us per byte-step when the tables sit in L2: 0.2 GB/s on the Grok corpus);
+// a backtracker touches one path at a time, so a lane is enough for a line and the chip holds half a million lines' walks
+// at once -- the dependent reads of one lane hide behind the other lanes'.  Lines whose walk exceeds the budget (the
+// patterns a backtracker is exponential on) or whose frame stack finds no room in the pool are marked LC_PENDING and the
+// launch's pending flag is raised: the thread-list kernels behind this launch take exactly those lines (and never blow up).
+// Frame stacks are carved from the pool with one atomicAdd per line.
+constexpr uint8_t LC_PENDING = 4;  // transient: left by nfa_dfs_kernel for the thread-list kernels of the same launch
+
+struct DfsPoolHeader {
+    unsigned long long cursor;  // bytes handed out (zeroed before every launch)
+    uint32_t pending;           // lines left to the thread-list kernels by the last launch (statistics)
+    uint32_t decided;
+};
+
+__global__ __launch_bounds__(64) void nfa_dfs_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                     const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
+                                                     DecideShape shape, uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ pendingFlag,
+                                                     uint32_t launchSeq, uint8_t* __restrict__ pool, uint64_t poolBytes,
+                                                     uint32_t stepsPerByte) {
+    if (nLinesPtr) {
+        const uint32_t dyn = *nLinesPtr;
+        nLines = dyn < nLines ? dyn : nLines;
+    }
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= nLines) return;
+    const uint32_t line = order ? order[slot] : slot;
+    DfsPoolHeader* hdrPool = reinterpret_cast<DfsPoolHeader*>(pool);
+
+    const uint8_t* tbl = reinterpret_cast<const uint8_t*>(blob);
+    const uint32_t* hdr = blob;
+    DecideTables t;
+    t.nPos = hdr[NF_NPOS];
+    t.nSlots = hdr[NF_NSLOTS];
+    t.edgeClass = hdr[NF_NCLASSES];
+    t.classMap = tbl + hdr[NF_OFF_CLASSMAP];
+    t.followStart = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_FOLLOWSTART]);
+    t.paths = reinterpret_cast<const uint2*>(tbl + hdr[NF_OFF_PATHS]);
+    t.aux = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AUX]);
+    t.auxWords = hdr[NF_AUX_WORDS];
+    t.posMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_POSMASK]);
+    t.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
+    t.behindBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_BEHIND]);
+    t.aheadBits = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_AHEAD]);
+    t.atomic = hdr[NF_ATOMIC] != 0;
+    t.events = t.atomic ? reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_EVENTS]) : nullptr;
+
+    uint32_t o, L, from;
+    decideLineSpan(off, len, sepBytes, resume, line, o, L, from);
+    const uint32_t nFrames = L - from + 1;
+    const uint64_t need = (decideFixedBytes(nFrames, shape) + 63) & ~uint64_t(63);
+    uint32_t verdict = LC_GAVE_UP;
+    const uint64_t at = kDecideHeaderBytes + atomicAdd(&hdrPool->cursor, static_cast<unsigned long long>(need));
+    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
+    if (at + need <= poolBytes) {
+        DecideWalk w;
+        w.closedCap = shape.closedCap;
+        w.frameWords = kDecideFrameWords + shape.closedCap;
+        w.nFrames = nFrames;
+        w.frames = reinterpret_cast<uint32_t*>(pool + at);
+        w.nodes = w.frames + size_t(nFrames) * w.frameWords;
+        w.memo = nullptr;
+        verdict = decideLine(t, w, data + o, L, from, nGroupsOut, out, uint64_t(stepsPerByte) * nFrames + 4096);
+    }
+    if (verdict == LC_GAVE_UP) {
+        status[line] = LC_PENDING;
+        atomicMax(pendingFlag, launchSeq);
+        atomicAdd(&hdrPool->pending, 1u);
+        return;
+    }
+    if (verdict != LC_MATCH)
+        for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) out[s] = -1;
+    status[line] = uint8_t(verdict);
+}

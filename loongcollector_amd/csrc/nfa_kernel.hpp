@@ -292,9 +292,12 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                                                               uint32_t blobBytes, uint32_t nGroupsOut,
                                                               int32_t* __restrict__ caps,
                                                               uint8_t* __restrict__ status,
-                                                              uint32_t* __restrict__ overflowFlag, uint32_t launchSeq) {
+                                                              uint32_t* __restrict__ overflowFlag, uint32_t launchSeq,
+                                                              const uint32_t* __restrict__ pendingFlag) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
+    // behind nfa_dfs_kernel (nfa_decide_kernel.hpp): only the lines it left pending are this launch's business -- usually none
+    if (pendingFlag && __atomic_load_n(pendingFlag, __ATOMIC_RELAXED) < launchSeq) return;
     if (nLinesPtr) {  // line count produced on the device (split kernels) -- no host round trip between the launches
         const uint32_t dyn = *nLinesPtr;
         nLines = dyn < nLines ? dyn : nLines;
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const uint32_t slot = blockIdx.x * kNfaWaves + wave;
     if (slot >= nLines) return;  // wave-uniform (the block never synchronises again)
     const uint32_t line = order ? order[slot] : slot;
+    if (pendingFlag && status[line] != 4 /* LC_PENDING */) return;  // settled by the depth-first walk
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
 

@@ -10,7 +10,7 @@ import random
 import numpy as np
 import pytest
 
-from loongcollector_amd import binding as B
+from loongcollector_amd import binding as B, corpus
 from oracle.oracle import OracleRegex
 from tests.test_gpu_parity import pack, run_device, torch_dev  # noqa: F401
 
@@ -185,3 +185,53 @@ def test_processors_never_see_an_undecided_line():
     kept = [dict(ev)["content"] for ev in g2.contents()]
     assert kept == [vals[2]]
     assert kept == [c["content"].decode() for c in FilterOracle(fcfg).process([{"content": v.encode()} for v in vals])]
+
+
+def test_depth_first_first_pass_gives_the_same_results(torch_dev):
+    """lc_nfa_set_dfs(1): the NFA engine settles lines with a lane-per-line backtracking walk first and hands the rest (tiny
+    step budget here, so that a good part of the lines IS handed on) to the thread-list kernels: status and capture offsets
+    equal the default path's and the oracle's, for a plain, a search and an atomic-group pattern."""
+    import ctypes
+    import torch
+    L = B.load()
+    L.lc_nfa_set_dfs.argtypes = [ctypes.c_int]
+    L.lc_dfs_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    cases = [(corpus.REGEX_B, 0), (r"(\d+)-(\w+)", B.LC_SYNTAX_SEARCH), (r"((?>a+)b|a+c)(x*)", 0)]
+    try:
+        for pattern, flags in cases:
+            if pattern == corpus.REGEX_B:
+                data, off, length = corpus.mixed_batch(3000, min_len=1, max_len=900)
+                off = off[:-1]
+            else:
+                lines = []
+                for _ in range(2000):
+                    lines.append(("".join(rng.choice(list("ab cx-19_"), size=int(rng.integers(0, 40))))).encode())
+                length = np.array([len(s) for s in lines], dtype=np.uint32)
+                off = np.zeros(len(lines), dtype=np.uint32)
+                off[1:] = np.cumsum(length[:-1])
+                data = np.frombuffer(b"".join(lines) + b"\0" * 16, dtype=np.uint8).copy()
+            n = len(off)
+            rx = B.GpuRegex(pattern, syntax_flags=flags, engine=B.LC_ENGINE_NFA)
+            d_data = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).to(dev)
+            d_off = torch.from_numpy(off.view(np.int32).copy()).to(dev)
+            d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev)
+            res = []
+            for mode in (0, 1):
+                L.lc_nfa_set_dfs(mode)
+                d_caps = torch.full((n, 2 * rx.groups), 7, dtype=torch.int32, device=dev)
+                d_status = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                B.launched_kernels()
+                rx.match_device(d_data, d_off, d_len, n, d_caps, d_status, engine=B.LC_ENGINE_NFA)
+                torch.cuda.synchronize()
+                names = B.launched_kernels()
+                assert ("nfa_dfs_kernel" in names) == bool(mode)
+                res.append((d_status.cpu().numpy(), d_caps.cpu().numpy()))
+            stats = (ctypes.c_uint64 * 2)()
+            L.lc_dfs_stats(stats)
+            assert stats[0] > 0                                     # the walk did carve frame stacks
+            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+            assert set(np.unique(res[1][0])) <= {0, 1}              # nothing pending / undecided is left behind
+    finally:
+        L.lc_nfa_set_dfs(-1)
