@@ -11,7 +11,7 @@
  * (StringTools.cpp:263-289) -- is answered for ALL lines of the buffer by one device launch per configured pattern
  * (LC_SYNTAX_PREFIX, status bytes only); the start/continue/end state machine then runs over three flag bytes per line.
  * Evaluating every pattern on every line is a superset of what the reference evaluates lazily; matches have no side
- * effects, so the records are the same.  Building the output events (CreateNewEvent :302-339) stays with the caller.
+ * effects, so the records are the same.  lc_multiline_process_group builds the output events (CreateNewEvent :302-339).
  */
 #ifndef LC_MULTILINE_H
 #define LC_MULTILINE_H
@@ -27,8 +27,11 @@ typedef struct lc_multiline lc_multiline_t;
 
 typedef struct lc_ml_record {
     uint32_t begin, length;  /* byte range inside the source value (line feeds inside a multi-line log included) */
-    uint32_t matched;        /* 1: a log delimited by the patterns; 0: an unmatched line kept as a single-line log */
+    uint32_t matched;        /* bit 0: 1 = a log delimited by the patterns, 0 = an unmatched line kept as a single-line log;
+                              * LC_ML_LAST: emitted with isLastLog = true (CreateNewEvent :327-329: its position length runs
+                              * to the end of the source event) */
 } lc_ml_record_t;
+#define LC_ML_LAST 0x80000000u
 
 /* config_json: {"StartPattern": "...", "ContinuePattern": "...", "EndPattern": "...",
  *               "UnmatchedContentTreatment": "single_line" | "discard"}   (keys of the Multiline object, custom mode) */
@@ -51,6 +54,33 @@ int lc_multiline_patterns(const lc_multiline_t* m);
 int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, uint32_t nbytes, lc_ml_record_t** records,
                             uint32_t* nrecords, uint32_t counters[3]);
 void lc_multiline_free_records(lc_ml_record_t* r);
+
+/* ProcessorSplitMultilineLogStringNative::Process :95-112 on a whole logtail::PipelineEventGroup* (lc_group_native() of a
+ * fixture group, or the agent's own group): every log event that holds exactly the SourceKey content is replaced by one event
+ * per record -- CreateNewEvent :302-339: a LogEvent (or, with EnableRawContent, a RawEvent) whose content is a VIEW into the
+ * source value, the source event's timestamp, position = (source offset + record begin, record length + 1, or the rest of the
+ * source event for a record emitted with isLastLog), and the group's LOG_FILE_OFFSET_KEY content when that metadata is set.
+ * Other events pass through untouched (:133-156).  "SourceKey" (default "content") and "EnableRawContent" are read from the
+ * config given to lc_multiline_create (:41-65).  counters[3] accumulate matched lines, unmatched lines, matched events. */
+int lc_multiline_process_group(lc_multiline_t* m, void* pipeline_event_group);
+int lc_multiline_counters(const lc_multiline_t* m, uint64_t counters[3]);
+
+/* processor_merge_multiline_log_native (core/plugin/processor/inner/ProcessorMergeMultilineLogNative.cpp) -- what file
+ * pipelines run behind the line splitter nowadays: ONE LINE PER EVENT comes in, events are merged into logs.
+ *   lc_merge_multiline_create         <- Init :33-78: {"SourceKey", "MergeType": "regex" | "flag", + the Multiline keys above}
+ *   lc_merge_multiline_process_group  <- Process :80-92 on a logtail::PipelineEventGroup*:
+ *        "regex": MergeLogsByRegex :161-330 -- the start / continue / end answers for ALL events come from one status-only device
+ *                 launch per pattern over the events' values; the state machine, MergeEvents :332-358 (the first event's value
+ *                 is extended in place over the following ones, a line feed written back between them) and HandleUnmatchLogs
+ *                 :360-392 (single_line: kept one by one; discard: dropped) are the reference's
+ *        "flag":  MergeLogsByFlag :113-159 (events carrying the "P" content are partial; runs only when the group has the
+ *                 HAS_PART_LOG metadata, which it then clears) -- no regex involved
+ *   counters[2] = merged events, unmatched events (:74-75). */
+typedef struct lc_merge_multiline lc_merge_multiline_t;
+int lc_merge_multiline_create(const char* config_json, size_t config_len, lc_merge_multiline_t** out, char* err, size_t errcap);
+void lc_merge_multiline_free(lc_merge_multiline_t* p);
+int lc_merge_multiline_process_group(lc_merge_multiline_t* p, void* pipeline_event_group);
+int lc_merge_multiline_counters(const lc_merge_multiline_t* p, uint64_t counters[2]);
 
 #ifdef __cplusplus
 }

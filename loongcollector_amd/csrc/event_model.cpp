@@ -14,6 +14,7 @@ const std::pair<const char*, EventGroupMetaKey> kMetaNames[] = {
     {"log.file.path_resolved", EventGroupMetaKey::LOG_FILE_PATH_RESOLVED},
     {"log.file.inode", EventGroupMetaKey::LOG_FILE_INODE},
     {"log.file.offset", EventGroupMetaKey::LOG_FILE_OFFSET_KEY},
+    {"has.part.log", EventGroupMetaKey::HAS_PART_LOG},
     {"source.id", EventGroupMetaKey::SOURCE_ID},
 };
 }
@@ -99,6 +100,10 @@ std::string PipelineEventGroup::ToJsonString() const {
                     for (auto it = le.cbegin(); it != le.cend(); ++it)
                         contents.obj.emplace_back(it->first.to_string(), lcjson::Value::makeString(it->second.to_string()));
                     ev.set("contents", std::move(contents));
+                }
+                if (le.GetPosition().second) {  // (LogEvent::ToJson prints the position with enableEventMeta; here: whenever one is set)
+                    ev.set("fileOffset", lcjson::Value::makeInt(int64_t(le.GetPosition().first)));
+                    ev.set("rawSize", lcjson::Value::makeInt(int64_t(le.GetPosition().second)));
                 }
             } else {
                 ev.set("content", lcjson::Value::makeString(e.Cast<RawEvent>().GetContent().to_string()));

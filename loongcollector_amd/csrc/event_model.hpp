@@ -106,6 +106,7 @@ enum class EventGroupMetaKey {
     LOG_FILE_PATH_RESOLVED,
     LOG_FILE_INODE,
     LOG_FILE_OFFSET_KEY,
+    HAS_PART_LOG,
     SOURCE_ID
 };
 using GroupMetadata = std::map<EventGroupMetaKey, StringView>;
@@ -327,6 +328,7 @@ public:
         return it == mMetadata.end() ? StringView() : it->second;
     }
     bool HasMetadata(EventGroupMetaKey key) const { return mMetadata.count(key) != 0; }
+    void DelMetadata(EventGroupMetaKey key) { mMetadata.erase(key); }
     const GroupMetadata& GetAllMetadata() const { return mMetadata; }
 
     void SetTag(const std::string& key, const std::string& val) {

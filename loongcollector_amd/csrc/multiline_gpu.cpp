@@ -25,17 +25,7 @@ bool endsWith(const std::string& s, const char* suffix) {
 
 }  // namespace
 
-struct lc_multiline {
-    lc_regex_t *start = nullptr, *cont = nullptr, *end = nullptr;
-    bool discardUnmatched = false;
-    bool isMultiline = false;
-    std::string warnings;  // patterns that were ignored (MultilineOptions::Init only warns about an invalid regex)
-    ~lc_multiline() {
-        lc_regex_free(start);
-        lc_regex_free(cont);
-        lc_regex_free(end);
-    }
-};
+#include "multiline_gpu.hpp"
 
 // MultilineOptions::ParseRegex :250-266 strips a trailing '$' and trailing ".*"s -- but only to decide validity and
 // IsMultiline().  The PROCESSOR compiles the pattern strings as written (ProcessorSplitMultilineLogStringNative.cpp:66-76,
@@ -108,6 +98,11 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
         m->isMultiline = !trimmed(kept[0]).empty() || !trimmed(kept[2]).empty();
         const std::string t = str("UnmatchedContentTreatment");               // :208-222
         m->discardUnmatched = t == "discard";
+        // the processor's own parameters (ProcessorSplitMultilineLogStringNative::Init :41-65), used by lc_multiline_process_group
+        if (const lcjson::Value* v = cfg.find("SourceKey"))
+            if (v->isString()) m->sourceKey = v->str;
+        if (const lcjson::Value* v = cfg.find("EnableRawContent"))
+            if (v->isBool()) m->enableRawContent = v->b;
     } catch (const std::exception& e) {
         set(e.what());
         return LC_ERR_SYNTAX;
@@ -156,15 +151,18 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
 
     std::vector<lc_ml_record_t> out;
     const bool hasStart = m->start, hasCont = m->cont, hasEnd = m->end;
+    // `last`: the isLastLog argument the reference passes to CreateNewEvent -- that of the line BEING PROCESSED when the
+    // record is emitted (it decides the record's position length, :327-329), true for the flush after the loop
+    bool last = false;
     auto createNewEvent = [&](int64_t b, int64_t e) {  // [b, e) of the source value
-        out.push_back({uint32_t(b), uint32_t(e > b ? e - b : 0), 1u});
+        out.push_back({uint32_t(b), uint32_t(e > b ? e - b : 0), 1u | (last ? LC_ML_LAST : 0u)});
     };
     auto handleUnmatch = [&](int64_t b, int64_t e) {   // HandleUnmatchLogs :341-380: line by line
         for (int64_t p = b; p < e;) {
             int64_t q = p;
             while (q < e && data[q] != '\n') ++q;
             ++unmatchLines;
-            if (!m->discardUnmatched) out.push_back({uint32_t(p), uint32_t(q - p), 0u});
+            if (!m->discardUnmatched) out.push_back({uint32_t(p), uint32_t(q - p), last ? LC_ML_LAST : 0u});
             p = q + 1;
         }
     };
@@ -176,6 +174,7 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
     }
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t cb = off[i], ce = int64_t(off[i]) + len[i];
+        last = ce == int64_t(nbytes);  // isLastLog :174
         ++inputLines;
         if (!isPartialLog) {
             const bool first = hasStart ? fStart[i] == LC_MATCH : fCont[i] == LC_MATCH;   // :176-184
@@ -224,6 +223,7 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
             }
         }
     }
+    last = true;
     if (isPartialLog && multiStart < int64_t(nbytes)) {                                    // :288-298
         if (!hasEnd) {
             createNewEvent(multiStart, nbytes);

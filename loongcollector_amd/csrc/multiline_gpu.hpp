@@ -1,0 +1,26 @@
+// multiline_gpu.hpp -- the compiled multiline configuration shared by multiline_gpu.cpp (record boundaries of one source value)
+// and multiline_events.cpp (the processors on whole event groups).
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+
+#include "../../include/lc_multiline.h"
+#include "../../include/lc_regex_gpu.h"
+
+struct lc_multiline {
+    lc_regex_t *start = nullptr, *cont = nullptr, *end = nullptr;
+    bool discardUnmatched = false;
+    bool isMultiline = false;
+    std::string warnings;  // patterns that were ignored (MultilineOptions::Init only warns about an invalid regex)
+    // ProcessorSplitMultilineLogStringNative's own parameters (:41-65) and counters (:78-82)
+    std::string sourceKey = "content";
+    bool enableRawContent = false;
+    std::atomic<uint64_t> matchedLinesTotal{0}, unmatchedLinesTotal{0}, matchedEventsTotal{0};
+    ~lc_multiline() {
+        lc_regex_free(start);
+        lc_regex_free(cont);
+        lc_regex_free(end);
+    }
+};

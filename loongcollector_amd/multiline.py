@@ -29,6 +29,15 @@ class Multiline:
             L.lc_multiline_split_host.argtypes = [vp, cp, ctypes.c_uint32, ctypes.POINTER(ctypes.POINTER(_Record)),
                                                   ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
             L.lc_multiline_free_records.argtypes = [ctypes.POINTER(_Record)]
+            L.lc_multiline_process_group.restype = ctypes.c_int
+            L.lc_multiline_process_group.argtypes = [vp, vp]
+            L.lc_multiline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+            L.lc_merge_multiline_create.restype = ctypes.c_int
+            L.lc_merge_multiline_create.argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
+            L.lc_merge_multiline_free.argtypes = [vp]
+            L.lc_merge_multiline_process_group.restype = ctypes.c_int
+            L.lc_merge_multiline_process_group.argtypes = [vp, vp]
+            L.lc_merge_multiline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
             L._lc_multiline_bound = True
         text = json.dumps(config).encode("utf-8")
         h = ctypes.c_void_p()
@@ -63,6 +72,52 @@ class Multiline:
         rc = self._L.lc_multiline_split_host(self._h, value, len(value), ctypes.byref(recs), ctypes.byref(n), counters)
         binding._check(rc, "lc_multiline_split_host")
         try:
-            return [(recs[i].begin, recs[i].length, recs[i].matched) for i in range(n.value)], tuple(counters)
+            return [(recs[i].begin, recs[i].length, recs[i].matched & 1) for i in range(n.value)], tuple(counters)
         finally:
             self._L.lc_multiline_free_records(recs)
+
+
+    def process(self, group):
+        """ProcessorSplitMultilineLogStringNative::Process on an EventGroup (loongcollector_amd.processor.EventGroup)."""
+        from .processor import _lib
+        binding._check(self._L.lc_multiline_process_group(self._h, _lib().lc_group_native(group._h)), "lc_multiline_process_group")
+
+    def counters(self):
+        """-> (matched lines, unmatched lines, matched events)"""
+        c = (ctypes.c_uint64 * 3)()
+        self._L.lc_multiline_counters(self._h, c)
+        return tuple(int(x) for x in c)
+
+
+class MergeMultiline:
+    """processor_merge_multiline_log_native (MergeType "regex" or "flag") on event groups."""
+
+    def __init__(self, **config):
+        Multiline.__new__(Multiline)  # (binds the library's prototypes once)
+        try:
+            Multiline(StartPattern="x")
+        except Exception:
+            pass
+        L = self._L = binding.load()
+        text = json.dumps(config).encode("utf-8")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if L.lc_merge_multiline_create(text, len(text), ctypes.byref(h), err, 512) != 0:
+            raise MultilineInitError(err.value.decode("utf-8", "replace"))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lc_merge_multiline_free(self._h)
+            self._h = None
+
+    def process(self, group):
+        from .processor import _lib
+        binding._check(self._L.lc_merge_multiline_process_group(self._h, _lib().lc_group_native(group._h)),
+                       "lc_merge_multiline_process_group")
+
+    def counters(self):
+        """-> (merged events, unmatched events)"""
+        c = (ctypes.c_uint64 * 2)()
+        self._L.lc_merge_multiline_counters(self._h, c)
+        return tuple(int(x) for x in c)

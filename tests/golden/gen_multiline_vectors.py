@@ -13,12 +13,15 @@ import os
 import re
 
 SRC = "/root/reference/core/unittest/processor/ProcessorSplitMultilineLogStringNativeUnittest.cpp"
+# the same `// case:` blocks exist for the merge processor (input split into one event per line by ProcessorSplitLogStringNative,
+# then ProcessorMergeMultilineLogNative with MergeType "regex"): written to multiline_merge_vectors.json
+SRC_MERGE = "/root/reference/core/unittest/processor/ProcessorMergeMultilineLogNativeUnittest.cpp"
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOK = {"LOG_BEGIN_STRING": "B", "LOG_CONTINUE_STRING": "C", "LOG_END_STRING": "E", "LOG_UNMATCH": "U"}
 
 
-def main():
-    text = open(SRC, encoding="utf-8").read()
+def main(src=SRC, out_name="multiline_vectors.json", kind_key="SplitType"):
+    text = open(src, encoding="utf-8").read()
     consts = {}
     for m in re.finditer(r'const std::string (\w+) = (?:R"\((.*?)\)"|"(.*?)");', text):
         consts[m.group(1)] = m.group(2) if m.group(2) is not None else m.group(3)
@@ -34,7 +37,7 @@ def main():
             if m:
                 v = m.group(2)
                 cfg[m.group(1)] = consts[v] if v in consts else (v == "true" if v in ("true", "false") else v.strip('"'))
-        if cfg.get("EnableRawContent") or "SplitType" not in cfg:
+        if cfg.get("EnableRawContent") or kind_key not in cfg or cfg[kind_key] != "regex":
             continue
         config = {k: cfg[k] for k in ("StartPattern", "ContinuePattern", "EndPattern", "UnmatchedContentTreatment") if k in cfg}
         # case blocks
@@ -67,11 +70,11 @@ def main():
             cases.append({"cite": "%s :%d (%s)" % (head.split("::")[0].split()[-1] + "::" + head.split("::")[1].split("(")[0],
                                                   start + at + 1, body[at].strip()[3:]),
                           "config": config, "in": ins[0], "out": [] if null_out else outs})
-    out = {"source": "core/unittest/processor/ProcessorSplitMultilineLogStringNativeUnittest.cpp",
+    out = {"source": src.replace("/root/reference/", ""),
            "lines": {TOK[k]: consts[k] for k in TOK},
            "patterns": {k: consts[k] for k in ("LOG_BEGIN_REGEX", "LOG_CONTINUE_REGEX", "LOG_END_REGEX")},
            "cases": cases}
-    with open(os.path.join(HERE, "multiline_vectors.json"), "w", encoding="utf-8") as f:
+    with open(os.path.join(HERE, out_name), "w", encoding="utf-8") as f:
         json.dump(out, f, indent=0)
     print("cases", len(cases))
     for c in cases[:6]:
@@ -80,3 +83,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main(SRC_MERGE, "multiline_merge_vectors.json", "MergeType")

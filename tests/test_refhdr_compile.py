@@ -24,7 +24,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("g++") is
                                 reason="needs the reference tree (/root/reference) and g++")
 
 SOURCES = ["processor_parse_regex_gpu.cpp", "c_processor_slot.cpp", "processor_filter_gpu.cpp", "processor_grok_gpu.cpp",
-           "processor_go_regex_gpu.cpp", "multiline_gpu.cpp"]
+           "processor_go_regex_gpu.cpp", "multiline_gpu.cpp", "multiline_events.cpp"]
 
 
 def _syntax_only(src, extra=()):
