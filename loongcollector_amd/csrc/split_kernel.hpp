@@ -5,9 +5,12 @@
 //   (core/plugin/processor/inner/ProcessorSplitLogStringNative.cpp:101-174)
 // walks a <= 512 KB read buffer byte by byte on the CPU and creates one event per SplitChar-delimited line.  Here the
 // raw buffer is shipped as is; three small kernels produce the line-offset table the match kernels consume:
-//   count   : every lane scans 64 bytes (four coalesced 16-byte loads), workgroup total of SplitChar hits
+//   count   : a workgroup scans a 16 KiB tile as four 4 KiB sub-tiles; in each the 256 lanes load 16 CONSECUTIVE bytes each
+//             (one fully coalesced 4 KiB request per load instruction -- until round 2 a lane walked its own 64 bytes and
+//             every load instruction touched 64 different 64-byte segments); workgroup total of SplitChar hits
 //   scan    : exclusive scan of the workgroup totals (one workgroup)
-//   scatter : every lane re-scans its 64 bytes and writes off[k+1] = p+1 for its hits (k = global rank of the hit)
+//   scatter : same loads again; hits are ranked in buffer order (sub-tile, lane, byte) and off[k+1] = p+1 is written for
+//             the k-th hit
 // Resulting table: off[0] = 0, off[i+1] = start of line i+1, off[nLines] chosen so that
 // len[i] = off[i+1] - off[i] - 1 for every line (the sep_bytes = 1 convention of lc_regex_match_device), including
 // a last line without terminator.  Same line set as the reference: empty lines are lines, a trailing SplitChar does
@@ -24,18 +27,22 @@ constexpr uint32_t kSplitBytesPerBlock = kSplitBlock * kSplitBytesPerLane;
 
 typedef uint32_t split_u32x4 __attribute__((ext_vector_type(4)));
 
-// 64-bit mask of SplitChar hits in this lane's 64 bytes (bit j = byte j); bytes past nBytes never hit
-__device__ __forceinline__ uint64_t splitLaneMask(const uint8_t* __restrict__ data, uint64_t nBytes, uint64_t laneBase,
+// 64-bit mask of SplitChar hits in this lane's four 16-byte pieces: bit 16*q + j = byte j of the piece at
+// tileBase + q * (kSplitBlock * 16) + lane * 16; bytes past nBytes never hit
+__device__ __forceinline__ uint64_t splitPieceBase(uint64_t tileBase, int q) {
+    return tileBase + uint64_t(q) * (kSplitBlock * 16) + uint64_t(threadIdx.x) * 16;
+}
+__device__ __forceinline__ uint64_t splitLaneMask(const uint8_t* __restrict__ data, uint64_t nBytes, uint64_t tileBase,
                                                   uint32_t splitChar) {
     uint64_t mask = 0;
-    if (laneBase >= nBytes) return 0;
     const uint32_t pattern = splitChar * 0x01010101u;
+    const bool aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint64_t at = laneBase + uint64_t(q) * 16;
-        if (at >= nBytes) break;
+        const uint64_t at = splitPieceBase(tileBase, q);
+        if (at >= nBytes) continue;
         uint32_t w[4] = {0, 0, 0, 0};
-        if (at + 16 <= nBytes && ((reinterpret_cast<uintptr_t>(data) + at) & 15) == 0) {
+        if (at + 16 <= nBytes && aligned) {
             const split_u32x4 v = *reinterpret_cast<const split_u32x4*>(data + at);
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         } else {  // unaligned base pointer or tail: byte loads
@@ -68,8 +75,8 @@ __device__ __forceinline__ uint32_t splitBlockReduce(uint32_t v, uint32_t* lds) 
 __global__ __launch_bounds__(kSplitBlock) void split_count_kernel(const uint8_t* __restrict__ data, uint64_t nBytes,
                                                                   uint32_t splitChar, uint32_t* __restrict__ blockHits) {
     __shared__ uint32_t lds[kSplitBlock / 64];
-    const uint64_t laneBase = uint64_t(blockIdx.x) * kSplitBytesPerBlock + uint64_t(threadIdx.x) * kSplitBytesPerLane;
-    const uint32_t hits = uint32_t(__popcll(splitLaneMask(data, nBytes, laneBase, splitChar)));
+    const uint64_t tileBase = uint64_t(blockIdx.x) * kSplitBytesPerBlock;
+    const uint32_t hits = uint32_t(__popcll(splitLaneMask(data, nBytes, tileBase, splitChar)));
     const uint32_t total = splitBlockReduce(hits, lds);
     if (threadIdx.x == 0) blockHits[blockIdx.x] = total;
 }
@@ -109,27 +116,40 @@ __global__ __launch_bounds__(kSplitBlock) void split_scatter_kernel(const uint8_
                                                                     const uint32_t* __restrict__ nHits,
                                                                     uint32_t* __restrict__ off, uint32_t offCapacity,
                                                                     uint32_t* __restrict__ nLines) {
-    __shared__ uint32_t waveHits[kSplitBlock / 64];
-    const uint64_t laneBase = uint64_t(blockIdx.x) * kSplitBytesPerBlock + uint64_t(threadIdx.x) * kSplitBytesPerLane;
-    uint64_t mask = splitLaneMask(data, nBytes, laneBase, splitChar);
-    const uint32_t hits = uint32_t(__popcll(mask));
+    __shared__ uint32_t waveHits[4][kSplitBlock / 64];
+    const uint64_t tileBase = uint64_t(blockIdx.x) * kSplitBytesPerBlock;
+    const uint64_t mask = splitLaneMask(data, nBytes, tileBase, splitChar);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = hits;
+    // hits are ranked in buffer order: sub-tile q, then lane, then byte -- one wave scan per sub-tile
+    uint32_t incl[4], hits[4];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= uint32_t(d)) incl += up;
+    for (int q = 0; q < 4; ++q) {
+        hits[q] = uint32_t(__popc(uint32_t(mask >> (16 * q)) & 0xFFFFu));
+        uint32_t v = hits[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= uint32_t(d)) v += up;
+        }
+        incl[q] = v;
+        if (lane == 63) waveHits[q][wave] = v;
     }
-    if (lane == 63) waveHits[wave] = incl;
     __syncthreads();
-    uint32_t rank = blockBase[blockIdx.x] + incl - hits;  // global rank of this lane's first hit
-    for (uint32_t w = 0; w < wave; ++w) rank += waveHits[w];
-    while (mask) {
-        const uint32_t j = uint32_t(__ffsll((long long)mask)) - 1;
-        mask &= mask - 1;
-        const uint64_t nextStart = laneBase + j + 1;  // the line after hit `rank` starts here
-        if (uint64_t(rank) + 1 < offCapacity) off[rank + 1] = uint32_t(nextStart);
-        ++rank;
+    uint32_t before = blockBase[blockIdx.x];  // hits of the whole buffer before this tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t rank = before + incl[q] - hits[q];
+        for (uint32_t w = 0; w < wave; ++w) rank += waveHits[q][w];
+        uint32_t m = uint32_t(mask >> (16 * q)) & 0xFFFFu;
+        const uint64_t pieceBase = splitPieceBase(tileBase, q);
+        while (m) {
+            const uint32_t j = uint32_t(__ffs(int(m))) - 1;
+            m &= m - 1;
+            const uint64_t nextStart = pieceBase + j + 1;  // the line after hit `rank` starts here
+            if (uint64_t(rank) + 1 < offCapacity) off[rank + 1] = uint32_t(nextStart);
+            ++rank;
+        }
+        for (uint32_t w = 0; w < kSplitBlock / 64; ++w) before += waveHits[q][w];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t total = *nHits;
