@@ -68,6 +68,32 @@ int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]);
 /* test fixtures in the reference unit tests' JSON format */
 lc_event_group_t* lc_group_from_json(const char* json, char* err, size_t errcap);
 /* malloc'd NUL-terminated JSON; release with lc_free */
+/* ---- columnar hand-off (the serializer side of the bulk stitch).
+ * The reference materialises K (key, view) pairs in every LogEvent (RegexLogLineParser :249-251) only for the serializer to
+ * walk them twice more (SLSEventGroupSerializer::CalculateLogEventSize + SerializeLogEvent, SLSSerializer.cpp:254-264,377-388:
+ * per event, per content, GetLogContentSize(key.size(), value.size()) and AddLogContent(key, value)).  What the device returns
+ * is already columnar -- one (begin, end) pair per event and key -- so a serializer can take it as is: lc_processor_parse_columnar
+ * runs the gather + device match of lc_processor_process and hands back the capture table next to the values' base pointers,
+ * WITHOUT touching the group (no stitching, no source-key policy: both stay with the caller).  content_bytes[i] is the sum the
+ * serializer's first pass computes for event i's K parsed fields (protobuf sizes: 1 + varint(len) + len per string, 1 + varint
+ * per content, LogGroupSerializer.cpp:227-252). */
+enum { LC_COL_SKIPPED = 0, LC_COL_PARSED = 1, LC_COL_FAILED = 2 };
+typedef struct lc_columnar {
+    uint32_t n_events;             /* events of the group, in order */
+    uint32_t n_keys;               /* K = number of Keys */
+    const char* const* keys;       /* [K], NUL-terminated, owned by the processor */
+    const uint32_t* key_len;       /* [K] */
+    const uint8_t* const* base;    /* [n_events] start of the event's source value (a view into the group's SourceBuffer); NULL
+                                      for an event the processor would not parse (not a log event, no SourceKey content) */
+    const uint32_t* base_len;      /* [n_events] */
+    const int32_t* spans;          /* [n_events][2K]: begin, end of field k relative to base; (-1, -1): empty value (a group
+                                      that did not take part: boost's {last, last}) */
+    const uint8_t* state;          /* [n_events] LC_COL_* */
+    const uint64_t* content_bytes; /* [n_events] sum over k of GetLogContentSize(key_len[k], end - begin); 0 unless PARSED */
+} lc_columnar_t;
+int lc_processor_parse_columnar(lc_processor_t* p, lc_event_group_t* group, lc_columnar_t** out);
+void lc_columnar_free(lc_columnar_t* c);
+
 /* the group a file input hands over: one copy of the n lines (data + off[i], len[i]) back to back in the group's SourceBuffer,
  * one log event per line whose `key` content is a view into it (ProcessorSplitLogStringNative.cpp:130-160) */
 lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, const char* key);

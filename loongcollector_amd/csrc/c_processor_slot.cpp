@@ -146,6 +146,103 @@ extern "C" lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint
     return g.release();
 }
 
+// ---- columnar hand-off (include/lc_processor.h): gather + device match, nothing stitched
+namespace {
+struct ColumnarStore {
+    lc_columnar_t pub{};
+    std::vector<const char*> keys;
+    std::vector<uint32_t> keyLen, baseLen;
+    std::vector<const uint8_t*> base;
+    std::vector<int32_t> spans;
+    std::vector<uint8_t> state;
+    std::vector<uint64_t> contentBytes;
+};
+// protobuf sizes of LogGroupSerializer.cpp:227-252
+inline uint64_t varintSize(uint64_t v) {
+    uint64_t n = 1;
+    while (v >= 128) {
+        v >>= 7;
+        ++n;
+    }
+    return n;
+}
+inline uint64_t stringSize(uint64_t len) { return 1 + varintSize(len) + len; }
+inline uint64_t logContentSize(uint64_t keyLen, uint64_t valueLen) {
+    const uint64_t inner = stringSize(keyLen) + stringSize(valueLen);
+    return inner + 1 + varintSize(inner);
+}
+}  // namespace
+
+extern "C" int lc_processor_parse_columnar(lc_processor_t* p, lc_event_group_t* g, lc_columnar_t** out) {
+    if (!p || !g || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    if (p->impl.IsWholeLineMode()) return LC_ERR_UNSUPPORTED;  // "(.*)": there is nothing to hand over but the line itself
+    const auto& events = g->group.GetEvents();
+    const size_t n = events.size();
+    const size_t K = p->impl.mKeys.size();
+    const uint32_t G = uint32_t(p->impl.MarkCount());
+    auto st = std::make_unique<ColumnarStore>();
+    for (const std::string& k : p->impl.mKeys) {
+        st->keys.push_back(k.c_str());
+        st->keyLen.push_back(uint32_t(k.size()));
+    }
+    st->base.assign(n, nullptr);
+    st->baseLen.assign(n, 0);
+    st->spans.assign(n * 2 * K, -1);
+    st->state.assign(n, LC_COL_SKIPPED);
+    st->contentBytes.assign(n, 0);
+    std::vector<const uint8_t*> linePtr;
+    std::vector<uint32_t> lineLen, lineEvent;
+    for (size_t i = 0; i < n; ++i) {
+        if (!events[i].Is<logtail::LogEvent>()) continue;
+        const logtail::LogEvent& ev = events[i].Cast<logtail::LogEvent>();
+        if (!ev.HasContent(p->impl.mSourceKey)) continue;
+        const logtail::StringView raw = ev.GetContent(p->impl.mSourceKey);
+        st->base[i] = reinterpret_cast<const uint8_t*>(raw.data());
+        st->baseLen[i] = uint32_t(raw.size());
+        linePtr.push_back(st->base[i]);
+        lineLen.push_back(st->baseLen[i]);
+        lineEvent.push_back(uint32_t(i));
+    }
+    const uint32_t nLines = uint32_t(linePtr.size());
+    if (nLines) {
+        std::vector<int32_t> caps(size_t(nLines) * 2 * G);
+        std::vector<uint8_t> status(nLines);
+        const int rc = lc_regex_match_host_views(const_cast<lc_regex_t*>(p->impl.Regex()), linePtr.data(), lineLen.data(), nLines, G,
+                                                 caps.data(), status.data());
+        if (rc != LC_OK) return rc;
+        for (uint32_t li = 0; li < nLines; ++li) {
+            const size_t i = lineEvent[li];
+            // RegexLogLineParser :194-244: no match, or fewer groups than keys, is a parse failure
+            if (status[li] != LC_MATCH || size_t(G) + 1 <= K) {
+                st->state[i] = LC_COL_FAILED;
+                continue;
+            }
+            st->state[i] = LC_COL_PARSED;
+            uint64_t bytes = 0;
+            for (size_t k = 0; k < K; ++k) {
+                const int32_t b = caps[size_t(li) * 2 * G + 2 * k], e = caps[size_t(li) * 2 * G + 2 * k + 1];
+                st->spans[(i * K + k) * 2] = b;
+                st->spans[(i * K + k) * 2 + 1] = e;
+                bytes += logContentSize(st->keyLen[k], b < 0 ? 0 : uint64_t(e - b));
+            }
+            st->contentBytes[i] = bytes;
+        }
+    }
+    st->pub.n_events = uint32_t(n);
+    st->pub.n_keys = uint32_t(K);
+    st->pub.keys = st->keys.data();
+    st->pub.key_len = st->keyLen.data();
+    st->pub.base = st->base.data();
+    st->pub.base_len = st->baseLen.data();
+    st->pub.spans = st->spans.data();
+    st->pub.state = st->state.data();
+    st->pub.content_bytes = st->contentBytes.data();
+    *out = &st.release()->pub;  // (pub is the first member: lc_columnar_free casts back)
+    return LC_OK;
+}
+extern "C" void lc_columnar_free(lc_columnar_t* c) { delete reinterpret_cast<ColumnarStore*>(c); }
+
 extern "C" char* lc_group_to_json(const lc_event_group_t* g) {
     if (!g) return nullptr;
     const std::string s = g->group.ToJsonString();

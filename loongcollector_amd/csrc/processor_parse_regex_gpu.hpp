@@ -67,6 +67,7 @@ public:
 
     bool IsWholeLineMode() const { return mIsWholeLineMode; }
     const lc_regex_t* Regex() const { return mReg; }
+    int MarkCount() const { return mMarkCount; }
 
 private:
     bool IsSupportedEvent(const PipelineEventPtr& e) const { return e.Is<LogEvent>(); }

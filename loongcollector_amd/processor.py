@@ -10,6 +10,13 @@ COUNTER_NAMES = ["discarded_events_total", "out_failed_events_total", "out_key_n
                  "out_size_bytes", "total_process_time_us", "complexity_exceeded_events_total", "undecided_events_total"]
 
 
+class LcColumnar(ctypes.Structure):
+    _fields_ = [("n_events", ctypes.c_uint32), ("n_keys", ctypes.c_uint32), ("keys", ctypes.POINTER(ctypes.c_char_p)),
+                ("key_len", ctypes.POINTER(ctypes.c_uint32)), ("base", ctypes.POINTER(ctypes.c_void_p)),
+                ("base_len", ctypes.POINTER(ctypes.c_uint32)), ("spans", ctypes.POINTER(ctypes.c_int32)),
+                ("state", ctypes.POINTER(ctypes.c_uint8)), ("content_bytes", ctypes.POINTER(ctypes.c_uint64))]
+
+
 class ProcessorInitError(ValueError):
     pass
 
@@ -40,6 +47,9 @@ def _lib():
         L.lc_group_native.argtypes = [vp]
         L.lc_group_from_json.restype = vp
         L.lc_group_from_json.argtypes = [cp, cp, sz]
+        L.lc_processor_parse_columnar.restype = ctypes.c_int
+        L.lc_processor_parse_columnar.argtypes = [vp, vp, ctypes.POINTER(ctypes.POINTER(LcColumnar))]
+        L.lc_columnar_free.argtypes = [ctypes.POINTER(LcColumnar)]
         L.lc_group_from_lines.restype = vp
         L.lc_group_from_lines.argtypes = [vp, vp, vp, ctypes.c_uint32, cp]
         L.lc_group_to_json.restype = vp
@@ -137,6 +147,34 @@ class Processor:
             raise binding.GpuUnavailableError("processor_parse_regex_gpu: no usable HIP device (no CPU path)")
         if rc != binding.LC_OK:
             raise RuntimeError("lc_processor_process rc=%d" % rc)
+
+    def parse_columnar(self, group: EventGroup):
+        """lc_processor_parse_columnar: the capture table of the group next to the values' base pointers, nothing stitched.
+        -> list per event: None (skipped), False (parse failure) or ([(key, value bytes)], content_bytes)"""
+        c = ctypes.POINTER(LcColumnar)()
+        rc = self._L.lc_processor_parse_columnar(self._h, group._h, ctypes.byref(c))
+        if rc != binding.LC_OK:
+            raise RuntimeError("lc_processor_parse_columnar rc=%d" % rc)
+        try:
+            col = c.contents
+            K = col.n_keys
+            keys = [col.keys[k].decode() for k in range(K)]
+            out = []
+            for i in range(col.n_events):
+                if col.state[i] == 0:
+                    out.append(None)
+                elif col.state[i] == 2:
+                    out.append(False)
+                else:
+                    raw = ctypes.string_at(col.base[i], col.base_len[i])
+                    fields = []
+                    for k in range(K):
+                        b, e = col.spans[(i * K + k) * 2], col.spans[(i * K + k) * 2 + 1]
+                        fields.append((keys[k], b"" if b < 0 else raw[b:e]))
+                    out.append((fields, int(col.content_bytes[i])))
+            return out
+        finally:
+            self._L.lc_columnar_free(c)
 
     def counters(self):
         buf = (ctypes.c_uint64 * len(COUNTER_NAMES))()

@@ -185,3 +185,47 @@ def test_concurrent_process_calls_on_one_instance():
             assert g.contents() == [[(k, v.decode("latin-1")) for k, v in ev.live()] for ev in out]
     c = p.counters()
     assert c["in_events_total"] == len(lines) and c["out_failed_events_total"] == po.counters["out_failed"]
+
+
+def test_columnar_hand_off_equals_the_stitched_events():
+    """lc_processor_parse_columnar (f4): the (begin, end) table + base pointers a serializer could consume directly.  For the same
+    group, the fields read through it equal the contents lc_processor_process stitches, and content_bytes equals what
+    SLSEventGroupSerializer::CalculateLogEventSize adds up for those contents (LogGroupSerializer.cpp:227-252)."""
+    import numpy as np
+    from loongcollector_amd import corpus
+    from loongcollector_amd.processor import EventGroup, Processor
+
+    def varint(v):
+        n = 1
+        while v >= 128:
+            v >>= 7
+            n += 1
+        return n
+
+    def content_size(k, v):
+        inner = (1 + varint(len(k)) + len(k)) + (1 + varint(len(v)) + len(v))
+        return inner + 1 + varint(inner)
+
+    data, off, length = corpus.apache_batch(300, "A", poison_every=7)
+    cfg = {"SourceKey": "content", "Regex": corpus.REGEX_A, "Keys": corpus.KEYS_A, "KeepingSourceWhenParseFail": True}
+    p = Processor(cfg)
+    g1 = EventGroup.from_lines(data, off[:-1], length)
+    cols = p.parse_columnar(g1)
+    assert len(g1) == 300 and g1.contents()[0][0][0] == "content"            # the group itself is untouched
+    g2 = EventGroup.from_lines(data, off[:-1], length)
+    p.process(g2)
+    stitched = g2.contents()
+    assert len(cols) == len(stitched) == 300
+    n_parsed = 0
+    for i, (col, ev) in enumerate(zip(cols, stitched)):
+        if col is False:                                                   # poisoned line: parse failure, source kept by the policy
+            assert i % 7 == 0 and [k for k, _ in ev] == ["content"]
+            continue
+        fields, nbytes = col
+        assert [(k, v.decode("latin-1")) for k, v in fields] == [tuple(kv) for kv in ev], i
+        assert nbytes == sum(content_size(k.encode(), v) for k, v in fields)
+        n_parsed += 1
+    assert n_parsed == 300 - len(range(0, 300, 7))
+    # events the processor does not parse are reported as skipped
+    g3 = EventGroup({"events": [{"contents": {"msg": "x"}, "timestamp": 1, "type": 1}, {"content": "raw", "timestamp": 1, "type": 4}]})
+    assert p.parse_columnar(g3) == [None, None]
