@@ -85,7 +85,9 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 //                  l & 15, so the 32 lanes of an LDS lane group touch 16 banks at most twice -- no chain bank conflicts
 //   kLabNoOutput / kLabNoLoop (tdfa_stream_kernel only): skip the capture-table write / the stage loop -- what a workgroup's
 //                  fixed costs are (line table reads, first loads, table staging, result write)
-enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32 };
+//   kLabNoGeneral  (tdfa_stream_kernel only): no check for general register programs (wrong for tables that have one on the
+//                  walked path): what the check costs
+enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32, kLabNoGeneral = 64 };
 
 // general register program (a list of moves); rare for log regexes
 template <int BLOCK, typename TdfaReg>

@@ -63,7 +63,8 @@ __device__ __forceinline__ uint32_t tdfaStreamChunk(uint32_t t, const uint32_t (
             *reinterpret_cast<LdsRegPtr>(addHighHalf(regAddr0, ptt[j])) = TdfaReg(pos);
             asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
         }
-        if (j > 0) seen |= tt[j - 1];  // (the link before this one: already waited for)
+        if constexpr ((LAB & kLabNoGeneral) == 0)
+            if (j > 0) seen |= tt[j - 1];  // (the link before this one: already waited for)
 #ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep the one-one-one order: the scheduler would cluster the reads and sink the stores
 #endif
@@ -226,14 +227,14 @@ __device__ __forceinline__ void tdfaStreamBody(
     }
 
     const uint32_t seg = (lane % kLoads) * 16;
-    uintptr_t srcAddr[kLoads];
-    uint32_t srcSpan[kLoads], dstAddr[kLoads];
+    // loads are addressed as (16-byte aligned buffer base, wave-uniform) + a 32-bit offset per lane: half the address registers
+    const uintptr_t dataAligned = reinterpret_cast<uintptr_t>(data) & ~uintptr_t(15);
+    const uint32_t rowOff = uint32_t(rowStart - dataAligned);  // (line offsets are 32-bit)
+    uint32_t srcOff[kLoads], srcSpan[kLoads], dstAddr[kLoads];
 #pragma unroll
     for (int i = 0; i < kLoads; ++i) {
         const int r = (64 / kLoads) * i + int(lane / kLoads);
-        const uint32_t lo = __shfl(uint32_t(rowStart), r, 64);
-        const uint32_t hi = __shfl(uint32_t(rowStart >> 32), r, 64);
-        srcAddr[i] = ((uintptr_t(hi) << 32) | lo) + seg;
+        srcOff[i] = __shfl(rowOff, r, 64) + seg;
         srcSpan[i] = __shfl(span, r, 64);
         dstAddr[i] = stageBase + uint32_t(r) * kRowStride + (COMPACT ? seg ^ (((uint32_t(r) >> 1) & uint32_t(kLoads - 1)) << 4) : seg);
     }
@@ -245,7 +246,7 @@ __device__ __forceinline__ void tdfaStreamBody(
 #pragma unroll
     for (int i = 0; i < kLoads; ++i) {  // stage 0
         in[i] = u32x4{0, 0, 0, 0};
-        if (seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i]);
+        if (seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + srcOff[i]);
     }
     tdfaWaveLdsSync();
 #pragma unroll
@@ -254,7 +255,7 @@ __device__ __forceinline__ void tdfaStreamBody(
 #pragma unroll
     for (int i = 0; i < kLoads; ++i) {  // stage 1
         in[i] = u32x4{0, 0, 0, 0};
-        if (kTdfaStageBytes + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i] + kTdfaStageBytes);
+        if (kTdfaStageBytes + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + (srcOff[i] + kTdfaStageBytes));
     }
     u32x4 W[kLoads];
 #pragma unroll
@@ -300,7 +301,7 @@ __device__ __forceinline__ void tdfaStreamBody(
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             in[i] = u32x4{0, 0, 0, 0};
-            if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(srcAddr[i] + nextOff);
+            if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + (srcOff[i] + nextOff));
         }
 #pragma unroll
         for (int c = 0; c < kChunksPerStage; ++c) {
@@ -328,7 +329,7 @@ __device__ __forceinline__ void tdfaStreamBody(
             } else {
                 if (__all(fullNext)) t = tdfaStreamChunk<NB, false, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);
                 else t = tdfaStreamChunk<NB, true, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);
-                general = (seen & (TD_OP_GENERAL << 16)) != 0;
+                general = (LAB & kLabNoGeneral) ? false : (seen & (TD_OP_GENERAL << 16)) != 0;
             }
             if (__any(general)) {
                 // (the previous chunk's stamps are all issued by now, this chunk's are not: in-order replay is exact)

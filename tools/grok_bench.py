@@ -130,6 +130,14 @@ def main():
                    "undecidable_line_indices": [int(i) for i in np.nonzero(pattern == -2)[0][:32]],
                    "extra_match_rows": int(d_nextra.cpu()[0]),
                    "patterns_hit": int((hist > 0).sum())},
+        # algorithmic HBM bytes of one step: every value read once + 4 B offset + 4 B length + the result row (pattern id +
+        # first-match row) written once per line.  The NFA kernels are nowhere near it: they are bound by the dependent table
+        # reads of a byte-step (one line per wavefront), not by HBM -- the fraction says how far.
+        "roofline": {"bound": "hbm", "achieved": round((total_bytes + n * (8 + 4 + 4 * row)) * args.steps / elapsed / 1e9, 3),
+                     "peak": 8000.0, "unit": "GB/s",
+                     "frac": round((total_bytes + n * (8 + 4 + 4 * row)) * args.steps / elapsed / 1e9 / 8000.0, 6), "traffic": None,
+                     "kernel": "nfa_match_kernel (40 of the 50 patterns) + tdfa kernels (10 patterns, prefix screens)",
+                     "algorithmic_bytes_per_step": int(total_bytes + n * (8 + 4 + 4 * row))},
         "cpu_baseline": {"value": round(sample / cpu_s, 1), "unit": "lines/s", "cores": 1, "kind": "port",
                          "MBps": round(sample_bytes / cpu_s / 1e6, 3),
                          "sample": "first %d lines of the batch: oracle/grok_oracle.py over oracle/bt_regex.c "

@@ -28,5 +28,5 @@ for sub in sorted(os.listdir(d)):
         agg[(k[:48], c)].append(v)
     print("== PMC pass %s (per-dispatch averages)" % sub)
     for (k, c), v in sorted(agg.items()):
-        if "match_kernel" in k or "split" in k:
+        if "match_kernel" in k or "stream_kernel" in k or "split" in k:
             print("%-50s %-22s n=%3d avg=%16.2f" % (k, c, len(v), sum(v) / len(v)))

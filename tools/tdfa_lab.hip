@@ -253,6 +253,7 @@ int main(int argc, char** argv) {
     }
     RUNS(256, 0, "stream 256");
     if (getenv("LAB_ONLY")) {
+        RUNS(256, kLabNoGeneral, "stream 256 no general check");
         RUNS(256, kLabPreClass | kLabNoStamp, "stream 256 bare chain");
         RUNS(256, kLabNoOutput, "stream 256 no output");
         return 0;
