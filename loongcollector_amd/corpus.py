@@ -71,12 +71,23 @@ def apache_pool(kind="A", pool_lines=8192, line_bytes=512, seed=SEED):
     return pool
 
 
-def apache_batch(n_lines, kind="A", line_bytes=512, seed=SEED, pool_lines=8192, poison_every=0):
+def blank_referrer(line: bytes) -> bytes:
+    """The same combined-format line with an EMPTY referrer field ("" -- its capture group matches the empty string) and the
+    user agent lengthened so that the line keeps its length."""
+    q = [j for j, c in enumerate(line) if c == 0x22]              # the quotes: ... "R" "U"
+    r0, r1, u0, u1 = q[-4], q[-3], q[-2], q[-1]
+    tail = b'"" "' + b"x" * ((r1 - r0 - 1) + (u1 - u0 - 1)) + b'"'
+    assert len(tail) == u1 - r0 + 1
+    return line[:r0] + tail + line[u1 + 1:]
+
+
+def apache_batch(n_lines, kind="A", line_bytes=512, seed=SEED, pool_lines=8192, poison_every=0, empty_every=0):
     """Build one batch: (data uint8[n*(line_bytes+1)], off uint32[n+1], len uint32[n]).
 
     Lines are drawn (with replacement, seeded) from a pool of `pool_lines` distinct lines and joined with '\n'.
     off has n+1 entries so that len[i] == off[i+1]-off[i]-1 (the separator).  poison_every=k replaces every k-th
-    line's first byte by '{' so that it must FAIL to match (failure-path coverage).
+    line's first byte by '{' so that it must FAIL to match (failure-path coverage); empty_every=k gives every k-th line
+    an empty referrer field (blank_referrer).
     """
     pool = apache_pool(kind, pool_lines, line_bytes, seed)
     rng = np.random.Generator(np.random.MT19937(seed + 7919))
@@ -84,6 +95,9 @@ def apache_batch(n_lines, kind="A", line_bytes=512, seed=SEED, pool_lines=8192, 
     buf = np.empty((n_lines, line_bytes + 1), dtype=np.uint8)
     buf[:, :line_bytes] = pool[idx]
     buf[:, line_bytes] = 10
+    if empty_every:
+        for i in range(0, n_lines, empty_every):
+            buf[i, :line_bytes] = np.frombuffer(blank_referrer(buf[i, :line_bytes].tobytes()), dtype=np.uint8)
     if poison_every:
         buf[::poison_every, 0] = ord("{")
     off = (np.arange(n_lines + 1, dtype=np.uint64) * (line_bytes + 1)).astype(np.uint32)

@@ -11,7 +11,12 @@ enum {
     TD_MAGIC = 0,        // 'TDFA'
     TD_NSTATES = 1,
     TD_NCLASSES = 2,
-    TD_NREGS = 3,        // per-line offset registers, INCLUDING the trailing dummy register
+    TD_NREGS = 3,        // bits 0..15: per-line offset registers, INCLUDING the trailing dummy register;
+                         // bits 16..28: offset / 16 of the FOLD WORDS (0 = none) -- u32 count, then per word
+                         //   set register | member << 8 | member << 16 | member << 24 (0xFF = no member): at the end of a
+                         //   line every member reads as max(member, set register): folded multi-stamp programs, regex_handle.cpp;
+                         // bit 31 (TD_NREGS_NO_GENERAL): no transition carries a general register program.
+                         // With fold words the offset registers are cleared to 0 at the start of a line.
     TD_NSLOTS = 4,       // 2 * capture groups
     TD_START_ROW = 5,    // LDS address of the start state's row (= TD_TRANS_OFFSET + start*rowBytes)
     TD_OFF_STARTAFTER = 6, // u32[nClasses]: row address to resume a search in, by class of the byte before the resume
@@ -52,6 +57,7 @@ enum {
 //                                transitions that stamp nothing name the dummy register (index nRegs-1)
 //       (list << 1) | 1          general move list `list` in `ops` (anything that is not "one register = pos")
 #define TD_OP_GENERAL 0x1u
+#define TD_NREGS_NO_GENERAL 0x80000000u
 #define TD_MAX_LISTS 0x7FFFu
 #define TD_MAX_TABLE_END 0x10000u     // rows must be addressable with 16 bits
 #define TD_MAX_REG_AREA 0x10000u      // nRegs*BLOCK*4: register offsets must fit the 16-bit field

@@ -148,17 +148,28 @@ static thread_local DoneRequest tlsDone;
 template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
-                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0) {
+                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0,
+                           uint32_t nregsWord = 0) {
     static const bool streamOff = [] {
         const char* e = getenv("LC_TDFA_STREAM");
         return e && e[0] == '0';
     }();
+    // tables without any general register program (TD_NREGS_NO_GENERAL: the usual case once multi-stamp programs are folded,
+    // regex_handle.cpp) run the instantiation that neither tracks nor replays them; LC_TDFA_NOGEN=0 keeps the checking one
+    static const bool noGenOff = [] {
+        const char* e = getenv("LC_TDFA_NOGEN");
+        return e && e[0] == '0';
+    }();
+    const bool noGen = !PAIR && !BYTEROWS && !streamOff && !noGenOff && (nregsWord & TD_NREGS_NO_GENERAL) != 0;
     auto kern = tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>;
     if constexpr (!BYTEROWS) {
         if (!streamOff) kern = tdfa_stream_kernel<BLOCK, COMPACT, PAIR>;
+        if constexpr (!PAIR) {
+            if (noGen) kern = tdfa_stream_kernel<BLOCK, COMPACT, false, kLabNoGeneral>;
+        }
     }
-    static thread_local size_t ldsAttrSet[kLcMaxDevices][2] = {};  // the attribute belongs to (function, device)
-    const int which = (!BYTEROWS && !streamOff) ? 1 : 0;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices][3] = {};  // the attribute belongs to (function, device)
+    const int which = noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
     if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow][which]) {
@@ -166,7 +177,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         ldsAttrSet[devNow][which] = lds;
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    noteKernel(which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
+    noteKernel(noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
     // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)
     const uint32_t* blobArg = static_cast<const uint32_t*>(dBlob);
@@ -212,18 +223,18 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
             seq = ++re->tdfaWideSeq[dev];
         }
         const int wb = re->tdfaWideBlock;
-        const uint32_t wRegBytes = uint32_t(size_t(re->tdfa.nRegs + 1) * size_t(wb) * 2);
-        const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfa.nRegs, wb);
+        const uint32_t wRegBytes = uint32_t(size_t(re->tdfaWidePackedRegs + 1) * size_t(wb) * 2);
+        const size_t wLds = lcTdfaCompactLdsBytes(wideBytes, re->tdfaWidePackedRegs, wb);
         if (wb == kLcTdfaWideBlock)
-            rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+            rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else if (wb == 512 && re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else if (wb == 512)
-            rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+            rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else if (re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else
-            rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+            rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         if (rc != LC_OK) return rc;
         minLen = kTdfaWideMaxLine + 1;
     }
@@ -233,15 +244,15 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
         tlsError = "tdfa tables + registers exceed LDS";
         return LC_ERR_UNSUPPORTED;
     }
-    const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
-    const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
+    const size_t lds = lcTdfaLdsBytes(blobBytes, re->tdfaPackedRegs, block);
+    const uint32_t regBytes = uint32_t(lcTdfaRegBytes(re->tdfaPackedRegs, block));
     // small automata carry a byte-pair transition table: half as many dependent LDS lookups per byte
     static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
     const bool pair = re->tdfaBlob[TD_OFF_PAIR] != 0 && !pairOff;
     switch (block) {
-        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
-        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
-        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq);
+        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
+        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
+        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
     }
 }
 
@@ -677,11 +688,11 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
             t.sepBytes = j.sep_bytes;
             t.nLines = j.n;
             t.blobBytes = blobBytes;
-            t.regBytes = uint32_t(lcTdfaRegBytes(re->tdfa.nRegs, block));
+            t.regBytes = uint32_t(lcTdfaRegBytes(re->tdfaPackedRegs, block));
             t.nGroupsOut = j.ngroups;
             t.firstBlock = blocks;
             blocks += (j.n + uint32_t(block) - 1) / uint32_t(block);
-            const size_t need = lcTdfaLdsBytes(blobBytes, re->tdfa.nRegs, block);
+            const size_t need = lcTdfaLdsBytes(blobBytes, re->tdfaPackedRegs, block);
             lds = need > lds ? need : lds;
             packed.push_back(t);
         }

@@ -39,10 +39,74 @@ struct BlobWriter {
 };
 }  // namespace
 
+// ---- folding of multi-stamp register programs (packing only; the logical tables stay as the builder made them).
+// A capture group that matches the EMPTY string ("" in a quoted field) stamps its begin and its end on one transition:
+// {r = pos, r' = pos}, a general register program.  The kernels replay every chunk in which some lane met one, and real logs
+// are full of them (measured: 10 % of the lines with an empty field = +22 % kernel time).  When EVERY general program of a
+// table is such a set of position stamps -- no copies anywhere -- each distinct set S gets one extra register both(S) and
+// the transition stamps that alone (a plain stamp again).  Positions only grow along a line, so "last stamp wins" is "largest
+// position wins": at the end register r reads as max(r, both(S) for the sets S that contain r), with registers cleared to 0
+// at the start of a line (an unstamped register can only lose the max).  Tables with any copy keep their general programs.
+struct TdfaFold {
+    bool ok = false;
+    std::vector<std::vector<uint8_t>> sets;  // distinct sorted destination sets
+    std::vector<int> listSet;                // per op list: index into sets, or -1
+};
+static TdfaFold planTdfaFold(const TdfaTables& t) {
+    TdfaFold f;
+    static const bool off = getenv("LC_TDFA_NO_FOLD") != nullptr;
+    const size_t nLists = t.opsStart.size() - 1;
+    f.listSet.assign(nLists, -1);
+    if (off) return f;
+    for (size_t id = 1; id < nLists; ++id) {
+        const uint32_t at = t.opsStart[id];
+        const uint32_t n = t.ops[at];
+        std::vector<uint8_t> dsts;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint16_t w = t.ops[at + 1 + k];
+            if ((w >> 8) != kRegPos) return f;  // a copy: the table keeps its general programs
+            dsts.push_back(uint8_t(w & 0xFF));
+        }
+        if (n < 2) continue;
+        std::sort(dsts.begin(), dsts.end());
+        dsts.erase(std::unique(dsts.begin(), dsts.end()), dsts.end());
+        auto it = std::find(f.sets.begin(), f.sets.end(), dsts);
+        if (it == f.sets.end()) {
+            f.sets.push_back(dsts);
+            it = f.sets.end() - 1;
+        }
+        f.listSet[id] = int(it - f.sets.begin());
+    }
+    if (f.sets.empty() || t.nRegs + f.sets.size() > size_t(kMaxTdfaRegs)) return f;
+    f.ok = true;
+    return f;
+}
+// registers the fold adds per line: one per distinct set (0: nothing to fold, or the table keeps its general programs)
+uint32_t tdfaFoldRegs(const TdfaTables& t) {
+    const TdfaFold f = planTdfaFold(t);
+    return f.ok ? uint32_t(f.sets.size()) : 0u;
+}
+
+size_t tdfaBlobBytesEstimate(const TdfaTables& t);
+}  // namespace lcregex
+
+// Workgroup size of the standard tables, and whether they fold their multi-stamp programs: the fold's extra registers must not
+// cost a smaller workgroup (or the fit).  Sets re->tdfaBlock (0 = does not fit) and re->tdfaPackedRegs.
+static bool lcPickTdfaBlockAndFold(lc_regex* re) {
+    const uint32_t est = uint32_t(lcregex::tdfaBlobBytesEstimate(re->tdfa));
+    const uint32_t foldRegs = lcregex::tdfaFoldRegs(re->tdfa);
+    re->tdfaBlock = lcTdfaPickBlock(est, re->tdfa.nRegs);
+    const bool fold = foldRegs && re->tdfaBlock && lcTdfaPickBlock(est, re->tdfa.nRegs + foldRegs) == re->tdfaBlock;
+    re->tdfaPackedRegs = re->tdfa.nRegs + (fold ? foldRegs : 0u);
+    return fold;
+}
+
+namespace lcregex {
 size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
     auto pad = [](size_t n) { return (n + 15) & ~size_t(15); };
     size_t n = TD_TRANS_OFFSET + pad(size_t(t.nStates) * (t.nClasses + 1) * 4) + pad(t.finalId.size() * 2) +
-               pad(t.finalMap.size()) + pad(t.opsStart.size() * 4) + pad(t.ops.size() * 2) + pad(t.startAfter.size() * 4);
+               pad(t.finalMap.size()) + pad(t.opsStart.size() * 4) + pad(t.ops.size() * 2) + pad(t.startAfter.size() * 4) +
+               pad(size_t(kMaxTdfaRegs) * 4 + 4);  // (+ the fold words of folded register programs)
     const size_t pairBytes = size_t(t.nStates) * (t.nClasses + 1) * (t.nClasses + 1) * 4;
     const char* pairEnv = getenv("LC_TDFA_PAIR");
     if (pairEnv && pairEnv[0] == '1' && pairBytes <= TP_MAX_TABLE_BYTES)
@@ -56,45 +120,53 @@ size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
 // size, used for every batch.  LC_TDFA_COMPACT=1024: byte-indexed rows shared by one 1024-lane workgroup per CU, for
 // automata small enough to keep that table, the registers and the staging tiles in the CU's LDS (measured slower: the
 // wide rows quadruple the LDS bank conflicts).
-std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut) {
+std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut, uint32_t* packedRegsOut) {
     const char* env = getenv("LC_TDFA_COMPACT");
     const int want = env ? atoi(env) : 256;
     *blockOut = 0;
     *forcedOut = env != nullptr;
-    if (want == 256 || want == 512) {
-        if (size_t(t.nRegs + 1) * size_t(want) * 2 > TD_MAX_REG_AREA) return {};
+    *packedRegsOut = t.nRegs;
+    const uint32_t foldRegs = tdfaFoldRegs(t);
+    // (the fold costs registers: tables that only fit without it are packed without it)
+    for (int fold = foldRegs ? 1 : 0; fold >= 0; --fold) {
+        const uint32_t packedRegs = t.nRegs + (fold ? foldRegs : 0u);
         try {
-            std::vector<uint32_t> blob = packTdfaBlob(t, want, false, true);
-            if (lcTdfaCompactLdsBytes(uint32_t(blob.size() * 4), t.nRegs, want) > kLcLdsPerCu) return {};
-            *blockOut = want;
+            if (want == 256 || want == 512) {
+                if (size_t(packedRegs + 1) * size_t(want) * 2 > TD_MAX_REG_AREA) continue;
+                std::vector<uint32_t> blob = packTdfaBlob(t, want, false, true, fold != 0);
+                if (lcTdfaCompactLdsBytes(uint32_t(blob.size() * 4), packedRegs, want) > kLcLdsPerCu) continue;
+                *blockOut = want;
+                *packedRegsOut = packedRegs;
+                return blob;
+            }
+            if (want != kLcTdfaWideBlock) return {};
+            const uint64_t tableEnd = TD_TRANS_OFFSET + uint64_t(t.nStates) * 257 * 4;
+            if (tableEnd > TD_MAX_TABLE_END) return {};
+            if (lcTdfaWideRegBytes(packedRegs) > TD_MAX_REG_AREA) continue;
+            const size_t rest = tdfaBlobBytesEstimate(t) - size_t(t.nStates) * (t.nClasses + 1) * 4;  // everything but the rows
+            if (lcTdfaWideLdsBytes(uint32_t(size_t(t.nStates) * 257 * 4 + rest + 64), packedRegs) > kLcLdsPerCu) continue;
+            std::vector<uint32_t> blob = packTdfaBlob(t, kLcTdfaWideBlock, true, true, fold != 0);
+            if (lcTdfaWideLdsBytes(uint32_t(blob.size() * 4), packedRegs) > kLcLdsPerCu) continue;
+            *blockOut = kLcTdfaWideBlock;
+            *packedRegsOut = packedRegs;
             return blob;
         } catch (const RegexError&) {
             return {};
         }
     }
-    if (want != kLcTdfaWideBlock) return {};
-    const uint64_t tableEnd = TD_TRANS_OFFSET + uint64_t(t.nStates) * 257 * 4;
-    if (tableEnd > TD_MAX_TABLE_END || lcTdfaWideRegBytes(t.nRegs) > TD_MAX_REG_AREA) return {};
-    const size_t rest = tdfaBlobBytesEstimate(t) - size_t(t.nStates) * (t.nClasses + 1) * 4;  // everything but the rows
-    if (lcTdfaWideLdsBytes(uint32_t(size_t(t.nStates) * 257 * 4 + rest + 64), t.nRegs) > kLcLdsPerCu) return {};
-    try {
-        std::vector<uint32_t> blob = packTdfaBlob(t, kLcTdfaWideBlock, true, true);
-        if (lcTdfaWideLdsBytes(uint32_t(blob.size() * 4), t.nRegs) > kLcLdsPerCu) return {};
-        *blockOut = kLcTdfaWideBlock;
-        return blob;
-    } catch (const RegexError&) {
-        return {};
-    }
+    return {};
 }
 
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact) {
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact, bool foldPrograms) {
     // wide: rows indexed by the byte itself (256 columns + identity); compact: 16-bit offset registers (tdfa_kernel.hpp)
     const uint32_t cols = (wide ? 256 : t.nClasses) + 1;  // + identity column
     const uint32_t rowBytes = cols * 4;
     if (TD_TRANS_OFFSET + uint64_t(t.nStates) * rowBytes > TD_MAX_TABLE_END)
         throw RegexError("tdfa: transition table exceeds the 64 KiB LDS window");
     if (t.nClasses > 63) throw RegexError("tdfa: more than 63 byte classes");
-    const uint32_t dummyReg = t.nRegs;  // one past the real registers
+    const TdfaFold fold = foldPrograms ? planTdfaFold(t) : TdfaFold{false, {}, std::vector<int>(t.opsStart.size() - 1, -1)};
+    const uint32_t nRegsPacked = t.nRegs + (fold.ok ? uint32_t(fold.sets.size()) : 0u);
+    const uint32_t dummyReg = nRegsPacked;  // one past the real (and the folded-set) registers
     const uint32_t regStride = uint32_t(block) * (compact ? 2 : 4);
     if (uint64_t(dummyReg + 1) * regStride > TD_MAX_REG_AREA) throw RegexError("tdfa: register file exceeds 64 KiB");
     const size_t nLists = t.opsStart.size() - 1;
@@ -107,6 +179,8 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
         const uint16_t w0 = t.ops[at + 1];
         if (n == 1 && (w0 >> 8) == kRegPos) {
             field[id] = uint32_t(w0 & 0xFF) * regStride;
+        } else if (fold.ok && fold.listSet[id] >= 0) {
+            field[id] = (t.nRegs + uint32_t(fold.listSet[id])) * regStride;  // the set's own register
         } else {
             if (id > TD_MAX_LISTS) throw RegexError("tdfa: too many register programs");
             field[id] = (uint32_t(id) << 1) | TD_OP_GENERAL;
@@ -129,7 +203,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
     hdr[TD_MAGIC] = TD_MAGIC_VALUE;
     hdr[TD_NSTATES] = t.nStates;
     hdr[TD_NCLASSES] = t.nClasses;
-    hdr[TD_NREGS] = t.nRegs + 1;
+    hdr[TD_NREGS] = nRegsPacked + 1;  // low half; the high half (fold words, "no general program" flag) is set below
     hdr[TD_NSLOTS] = t.nSlots;
     hdr[TD_START_ROW] = rowAddr(t.startState);
     hdr[TD_ROW_BYTES] = rowBytes;
@@ -186,6 +260,25 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
             hdr[TD_OFF_PAIR] = w.put(ph);
         }
     }
+    if (fold.ok) {  // fold words (device_tables.h TD_NREGS): set register + up to three members per word
+        std::vector<uint32_t> words{0};
+        for (size_t si = 0; si < fold.sets.size(); ++si) {
+            const auto& set = fold.sets[si];
+            for (size_t k = 0; k < set.size(); k += 3) {
+                uint32_t wd = (t.nRegs + uint32_t(si)) | 0xFFFFFF00u;
+                for (size_t j = 0; j < 3 && k + j < set.size(); ++j)
+                    wd = (wd & ~(0xFFu << (8 * (j + 1)))) | (uint32_t(set[k + j]) << (8 * (j + 1)));
+                words.push_back(wd);
+            }
+        }
+        words[0] = uint32_t(words.size() - 1);
+        const uint32_t at = w.put(words);
+        if (at / 16 > 0x1FFFu) throw RegexError("tdfa: internal layout error");
+        hdr[TD_NREGS] |= (at / 16) << 16;
+    }
+    bool anyGeneral = false;
+    for (size_t id = 1; id < nLists; ++id) anyGeneral = anyGeneral || (field[id] & TD_OP_GENERAL);
+    if (!anyGeneral) hdr[TD_NREGS] |= TD_NREGS_NO_GENERAL;
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(TD_TOTAL_BYTES);
 }
@@ -511,10 +604,10 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
             lim.maxStates = maxStates;
             re->tdfa = buildTdfa(re->nfa, lim);
             if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) return nullptr;
-            re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
+            const bool fold = lcPickTdfaBlockAndFold(&*re);
             if (!re->tdfaBlock) return nullptr;
-            re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
-            re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced);
+            re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
+            re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
             re->hasTdfa = true;
             re->engine = LC_ENGINE_TDFA;
             re->pattern = std::string("<prefix screen: ") + how + ", " + std::to_string(k) + " of " +
@@ -609,10 +702,10 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 TdfaLimits lim;
                 if (const char* e = getenv("LC_TDFA_MAX_STATES")) lim.maxStates = uint32_t(atoi(e));
                 re->tdfa = buildTdfa(re->nfa, lim);
-                re->tdfaBlock = lcTdfaPickBlock(uint32_t(tdfaBlobBytesEstimate(re->tdfa)), re->tdfa.nRegs);
+                const bool fold = lcPickTdfaBlockAndFold(&*re);
                 if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
-                re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock);
-                re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced);
+                re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
+                re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
                 re->hasTdfa = true;
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                   re->tdfa.startState, 0, 0, 0};

@@ -23,6 +23,8 @@ struct lc_regex {
     std::vector<uint32_t> tdfaHeader;   // LC_TABLE_TDFA_HEADER view
     std::vector<uint32_t> tdfaBlob;     // device_tables.h TDFA layout
     int tdfaBlock = 0;                  // workgroup size tdfaBlob was packed for
+    uint32_t tdfaPackedRegs = 0;        // registers per line tdfaBlob uses: tdfa.nRegs + one per folded multi-stamp set
+    uint32_t tdfaWidePackedRegs = 0;    // the same for tdfaWideBlob (each blob folds only if its register area allows)
     std::vector<uint32_t> tdfaWideBlob; // tables of the COMPACT kernel variant (16-bit offset registers), or empty
     int tdfaWideBlock = 0;              // its workgroup size: 256 / 512 (class-indexed rows) or 1024 (byte-indexed rows)
     bool tdfaWideForced = false;        // LC_TDFA_COMPACT was set: use it for every batch, not only for large ones
@@ -44,9 +46,12 @@ struct lc_regex {
 
 namespace lcregex {
 // `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide = false, bool compact = false);
+// foldPrograms: multi-stamp register programs become stamps of set registers when every program of the table allows it
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide = false, bool compact = false,
+                                   bool foldPrograms = true);
+uint32_t tdfaFoldRegs(const TdfaTables& t);  // registers that fold adds per line (0 = nothing to fold)
 // tables of the COMPACT kernel variant (LC_TDFA_COMPACT picks it; empty: switched off, or the automaton is too large)
-std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut);
+std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut, uint32_t* packedRegsOut);
 size_t tdfaBlobBytesEstimate(const TdfaTables& t);
 // throws RegexError when the NFA does not fit the device format (more than 128 byte classes, follow lists over 64 paths ...)
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut);

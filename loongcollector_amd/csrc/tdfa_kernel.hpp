@@ -199,6 +199,17 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
     return t;
 }
 
+// Tables whose multi-stamp register programs were folded into set registers (regex_handle.cpp, planTdfaFold; the fold words
+// of device_tables.h TD_NREGS) read a register as the LARGEST of itself and its sets' registers: every register starts at 0.
+template <int BLOCK>
+__device__ __forceinline__ void tdfaClearRegisters(uint8_t* smem, const uint32_t* __restrict__ blob, uint32_t blobBytes,
+                                                   uint32_t regBytes) {
+    if ((blob[TD_NREGS] >> 16) & 0x1FFFu) {  // (wave-uniform: a scalar load of the header word)
+        uint32_t* regs = reinterpret_cast<uint32_t*>(smem + blobBytes);
+        for (uint32_t i = threadIdx.x; i < regBytes / 4; i += BLOCK) regs[i] = 0;
+    }
+}
+
 // The result of a wavefront's 64 lines: status byte + 2*nGroupsOut capture offsets per line.  A lane storing its own row
 // dword by dword touches 64 different cache lines per store instruction (rows are 8*G bytes apart): measured on the headline
 // batch that write alone took a third of the kernel (tools/tdfa_lab.hip, "no output" variant).  When the wave's lines are
@@ -218,6 +229,28 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
     const uint32_t fid = live ? uint32_t(finalId[state]) : 0xFFFFu;
     const bool matched = live && (state != 0) && (fid != 0xFFFFu);
     const uint32_t nOut = 2 * nGroupsOut;
+    const uint32_t foldOff = ((hdr[TD_NREGS] >> 16) & 0x1FFFu) * 16;
+    if (foldOff) {
+        // folded multi-stamp programs: a member register reads as the larger of itself and its set's register ("latest stamp"
+        // = "largest offset", registers start at 0).  Settled here, once per line, so the row building below stays as it is.
+        // The fold words are wave-uniform: a handful of broadcast reads.
+        const uint32_t* fw = reinterpret_cast<const uint32_t*>(smem + foldOff);
+        TdfaReg* rw = reinterpret_cast<TdfaReg*>(smem + regsBase) + tid;
+        const uint32_t nWords = __builtin_amdgcn_readfirstlane(fw[0]);
+        for (uint32_t i = 0; i < nWords; ++i) {
+            const uint32_t w = __builtin_amdgcn_readfirstlane(fw[1 + i]);
+            const TdfaReg both = rw[(w & 0xFFu) * BLOCK];
+            if (!__any(both != 0)) continue;  // no line of the wave took such a transition (the usual case)
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const uint32_t r = (w >> (8 * k)) & 0xFFu;
+                if (r != 0xFFu) {
+                    const TdfaReg own = rw[r * BLOCK];
+                    rw[r * BLOCK] = both > own ? both : own;
+                }
+            }
+        }
+    }
     auto slotValue = [&](uint32_t s) -> int32_t {
         int32_t val = -1;
         if (matched && s < nSlots) {
@@ -404,6 +437,7 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
+        tdfaClearRegisters<BLOCK>(smem, blob, blobBytes, regBytes);
     }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);

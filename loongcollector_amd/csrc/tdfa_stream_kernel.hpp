@@ -164,6 +164,7 @@ __device__ __forceinline__ void tdfaStreamBody(
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
+        tdfaClearRegisters<BLOCK>(smem, blob, blobBytes, regBytes);
     }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
@@ -171,7 +172,7 @@ __device__ __forceinline__ void tdfaStreamBody(
     const uint32_t idCol = hdr[TD_ID_COL];
     const uint32_t regsBase = blobBytes;
     // a transition that stamps the dummy register (the last one) and nothing else
-    const uint32_t dummyT = PAIR ? (hdr[TD_NREGS] - 1) * 0x01010000u : ((hdr[TD_NREGS] - 1) * BLOCK * uint32_t(sizeof(TdfaReg))) << 16;
+    const uint32_t dummyT = PAIR ? ((hdr[TD_NREGS] & 0xFFFFu) - 1) * 0x01010000u : (((hdr[TD_NREGS] & 0xFFFFu) - 1) * BLOCK * uint32_t(sizeof(TdfaReg))) << 16;
     uint32_t t = hdr[TD_START_ROW];
     TdfaPairInfo pi{};
     uint32_t idAAddr = 0;  // LDS address of a u16 that holds pi.idA (the first-byte offset of the identity class)

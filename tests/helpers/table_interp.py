@@ -160,6 +160,11 @@ class TdfaBlobInterp:
         self.blob, self.raw = blob, blob.view(np.uint8)
         (self.nstates, self.ncls, self.nregs, self.nslots, self.start_row, off_after, _, off_finalid, off_finalmap,
          off_opsstart, off_ops, _, self.row_bytes, self.id_col, self.block) = [int(x) for x in blob[1:16]]
+        # TD_NREGS: low half = registers incl. dummy; bits 16..28 = offset/16 of the fold words; bit 31 = no general program
+        fold_off = ((self.nregs >> 16) & 0x1FFF) * 16
+        self.no_general = bool(self.nregs >> 31)
+        self.nregs &= 0xFFFF
+        self.fold = [int(w) for w in blob[fold_off // 4 + 1:fold_off // 4 + 1 + int(blob[fold_off // 4])]] if fold_off else None
         self.compact = compact
         self.wide = self.row_bytes == 257 * 4            # rows indexed by the byte itself
         assert not self.wide or (compact and self.block == 1024)
@@ -175,13 +180,14 @@ class TdfaBlobInterp:
     @_with_run_captures
     def fullmatch(self, s: bytes, start=0):
         t = self.start_row if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]]) >> 2])
-        regs = {}
+        regs = {r: 0 for r in range(self.nregs)} if self.fold is not None else {}   # (fold words: registers start at 0)
         limit = 0xFFFF if self.compact else 0xFFFFFFFF
         for pos in range(start, len(s)):
             col = s[pos] * 4 if self.wide else int(self.cmap[s[pos]])
             e = int(self.blob[((t & 0xFFFF) + col) // 4])
             t, f = e & 0xFFFF, e >> 16
             if f & 1:                                       # general move list
+                assert not self.no_general
                 o = int(self.ops_start[f >> 1])
                 for w in self.ops[o + 1:o + 1 + int(self.ops[o])]:
                     dst, src = int(w) & 0xFF, int(w) >> 8
@@ -189,6 +195,11 @@ class TdfaBlobInterp:
             else:
                 assert f % self.reg_stride == 0 and f // self.reg_stride < self.nregs
                 regs[f // self.reg_stride] = (pos - start) & limit
+        for w in self.fold or ():                           # a member reads as max(member, its set's register)
+            for k in (1, 2, 3):
+                r = (w >> (8 * k)) & 0xFF
+                if r != 0xFF:
+                    regs[r] = max(regs[r], regs[w & 0xFF])
         state = ((t & 0xFFFF) - 320) // self.row_bytes
         fid = int(self.final_id[state])
         if state == 0 or fid == 0xFFFF:

@@ -92,6 +92,25 @@ def test_bench_corpus_bit_exact_vs_oracle(torch_dev, kind):
     assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps)
 
 
+@pytest.mark.parametrize("n", [20000, 70000])
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_empty_captured_fields_take_the_folded_set_registers(torch_dev, kind, n):
+    """Every third line has an empty referrer: its group's begin and end are stamped by ONE transition, which the packed
+    tables turn into a stamp of the set's own register (regex_handle.cpp planTdfaFold); the kernels (32-bit registers below
+    64 Ki lines, 16-bit above) settle member = max(member, set) before the captures go out.  Against the oracle."""
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    data, off, length = corpus.apache_batch(n, kind, poison_every=17, empty_every=3)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    assert (exp_caps[exp_status == 1, 2::2] == exp_caps[exp_status == 1, 3::2]).any()     # some group IS empty
+    rx = B.GpuRegex(pattern)
+    B.launched_kernels()                                   # (forget what earlier tests launched)
+    caps, status = run_device(torch_dev, rx, data, off, None, sep=1)
+    assert np.array_equal(status, exp_status)
+    bad = np.nonzero((caps != exp_caps).any(axis=1))[0]
+    assert bad.size == 0, (bad[:8].tolist(), caps[bad[0]].tolist(), exp_caps[bad[0]].tolist())
+    assert "nogeneral" in B.launched_kernels()
+
+
 @pytest.mark.parametrize("kind", ["A", "B"])
 def test_nfa_kernel_bit_exact_on_bench_corpus(torch_dev, kind):
     """The wave-per-line NFA kernel (the engine AUTO falls back to) against the oracle AND against the TDFA kernel."""

@@ -256,6 +256,40 @@ def test_packed_tdfa_blobs_walk_like_the_logical_tables(golden_dir, monkeypatch,
     assert checked > 500 and wide > 50
 
 
+def test_multi_stamp_programs_are_folded_into_set_registers():
+    """A capture group that can match "" stamps its begin and end on ONE transition.  Packed, such a program becomes a stamp
+    of the set's own register (device_tables.h TD_NREGS, fold words) and the table has no general program left; the captures
+    stay what the logical tables give -- empty fields first, last, repeated, next to non-empty ones.  A pattern whose programs
+    copy registers keeps them."""
+    from tests.helpers.table_interp import TdfaBlobInterp
+    from loongcollector_amd import corpus
+    cases = [
+        (corpus.REGEX_A, [b'1.2.3.4 - - [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326 "" "curl/8"',
+                          b'1.2.3.4 - - [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326 "http://x" ""',
+                          b'1.2.3.4 - - [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326 "" ""',
+                          b'1.2.3.4 - - [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326 "r" "u"']),
+        (rb'(\S*) (\S*) (\S*)', [b"  ", b"a  ", b" b ", b"  c", b"aa bb cc", b"a b", b" "]),
+        (rb'"([^"]*)"(?:,"([^"]*)")*', [b'""', b'"",""', b'"a","","b"', b'"a","b",""', b'"","",""']),
+        (rb'(a*)(b*)(a*)', [b"", b"a", b"b", b"ab", b"ba", b"aba", b"aabbaa"]),
+    ]
+    for pat, lines in cases:
+        rx = B.GpuRegex(pat, engine=B.LC_ENGINE_TDFA)
+        ref, packed = TdfaInterp(rx), TdfaBlobInterp(rx)
+        assert packed.fold and packed.no_general, pat
+        interps = [packed]
+        if rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None:
+            interps.append(TdfaBlobInterp(rx, compact=True))
+        for s in lines:
+            want = ref.fullmatch(s)
+            for it in interps:
+                assert it.fullmatch(s) == want, (pat, s)
+    assert any(ref.fullmatch(s) is not None for s in lines)
+    # programs that copy registers stay general programs, and such a table folds nothing
+    for pat in (rb"((a)|(b))+", rb"(.+)=(.+)"):
+        it = TdfaBlobInterp(B.GpuRegex(pat, engine=B.LC_ENGINE_TDFA))
+        assert not it.no_general and it.fold is None, pat
+
+
 def test_hostile_patterns_fail_fast_or_compile_fast():
     """A pattern comes from a configuration file: whatever it is, Init must answer quickly -- compile, or refuse with a
     reason.  ("(a?){200}a{200}" used to spend two minutes in the tagged-DFA construction before being refused.)"""

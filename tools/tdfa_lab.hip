@@ -99,6 +99,8 @@ static std::vector<uint32_t> repack(const Inputs& in, int newBlock, bool replica
     std::memcpy(nb.data(), out.data(), out.size());
     for (int k : {TD_OFF_STARTAFTER, TD_OFF_FINALID, TD_OFF_FINALMAP, TD_OFF_OPSSTART, TD_OFF_OPS})
         if (nb[k]) nb[k] = uint32_t(int32_t(nb[k]) + shift);
+    if (const uint32_t fo = (nb[TD_NREGS] >> 16) & 0x1FFFu)  // the fold words moved with the rest
+        nb[TD_NREGS] = (nb[TD_NREGS] & 0xE000FFFFu) | ((uint32_t(int32_t(fo * 16) + shift) / 16) << 16);
     nb[TD_OFF_PAIR] = 0;
     nb[TD_START_ROW] = newRow(b[TD_START_ROW]);
     nb[TD_ROW_BYTES] = newRowBytes;
