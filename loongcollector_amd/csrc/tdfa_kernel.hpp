@@ -90,6 +90,16 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32, kLabNoGeneral = 64 };
 
 // general register program (a list of moves); rare for log regexes
+// Column of a lane in the register file.  32-bit registers: the lane itself (a wavefront's lanes hit 32 banks twice over, one
+// half-wave after the other).  16-bit registers: lanes l and l+32 share a dword -- two NEIGHBOURING lanes in one dword stamp
+// different registers most of the time, i.e. different dwords of one bank in the same LDS pass: a conflict on nearly every
+// stamp (measured: stamps + class lookups add 1.3 conflict cycles per byte-step).
+template <typename TdfaReg>
+__device__ __forceinline__ uint32_t tdfaRegLane(uint32_t tid) {
+    if constexpr (sizeof(TdfaReg) == 2) return (tid & ~63u) | ((tid & 31u) << 1) | ((tid >> 5) & 1u);
+    else return tid;
+}
+
 template <int BLOCK, typename TdfaReg>
 __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase, uint32_t list, uint32_t pos,
                                                 uint32_t tid) {
@@ -103,8 +113,8 @@ __device__ __forceinline__ void tdfaRunMoveList(uint8_t* smem, uint32_t regsBase
     for (uint32_t i = 0; i < cnt; ++i) {
         const uint32_t w = ops[at + 1 + i];
         const uint32_t dst = w & 0xFF, src = w >> 8;
-        const TdfaReg val = (src == TD_REG_POS) ? TdfaReg(pos) : regs[src * BLOCK + tid];
-        regs[dst * BLOCK + tid] = val;
+        const TdfaReg val = (src == TD_REG_POS) ? TdfaReg(pos) : regs[src * BLOCK + tdfaRegLane<TdfaReg>(tid)];
+        regs[dst * BLOCK + tdfaRegLane<TdfaReg>(tid)] = val;
     }
 }
 
@@ -132,7 +142,7 @@ __device__ __forceinline__ void tdfaReplayChunk(uint8_t* smem, u32x4 q, uint32_t
                                                 uint32_t idCol, uint32_t regsBase, uint32_t tid, uint32_t nBytes) {
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
-    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
+    const uint32_t regAddr0 = regsBase + tdfaRegLane<TdfaReg>(tid) * sizeof(TdfaReg);
 #pragma unroll 1
     for (uint32_t j = 0; j < nBytes; ++j) {
         const uint32_t word = (j < 8) ? ((j < 4) ? q.x : q.y) : ((j < 12) ? q.z : q.w);
@@ -154,7 +164,7 @@ __device__ __forceinline__ uint32_t tdfaStepBytes(uint8_t* smem, const uint32_t 
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     // the blob sits at LDS address 0, so table offsets are LDS addresses
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
-    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);  // LDS address of regs[0][lane]
+    const uint32_t regAddr0 = regsBase + tdfaRegLane<TdfaReg>(tid) * sizeof(TdfaReg);  // LDS address of regs[0][lane]
     const uint32_t entry = t;
     uint32_t col[NB], tt[NB];
 #pragma unroll
@@ -229,13 +239,14 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
     const uint32_t fid = live ? uint32_t(finalId[state]) : 0xFFFFu;
     const bool matched = live && (state != 0) && (fid != 0xFFFFu);
     const uint32_t nOut = 2 * nGroupsOut;
+    const uint32_t rl = tdfaRegLane<TdfaReg>(tid);
     const uint32_t foldOff = ((hdr[TD_NREGS] >> 16) & 0x1FFFu) * 16;
     if (foldOff) {
         // folded multi-stamp programs: a member register reads as the larger of itself and its set's register ("latest stamp"
         // = "largest offset", registers start at 0).  Settled here, once per line, so the row building below stays as it is.
         // The fold words are wave-uniform: a handful of broadcast reads.
         const uint32_t* fw = reinterpret_cast<const uint32_t*>(smem + foldOff);
-        TdfaReg* rw = reinterpret_cast<TdfaReg*>(smem + regsBase) + tid;
+        TdfaReg* rw = reinterpret_cast<TdfaReg*>(smem + regsBase) + tdfaRegLane<TdfaReg>(tid);
         const uint32_t nWords = __builtin_amdgcn_readfirstlane(fw[0]);
         for (uint32_t i = 0; i < nWords; ++i) {
             const uint32_t w = __builtin_amdgcn_readfirstlane(fw[1 + i]);
@@ -256,7 +267,7 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
         if (matched && s < nSlots) {
             const uint32_t m = finalMap[fid * nSlots + s];
             if (m == TD_REG_POS) val = int32_t(L + from);
-            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + rl] + from);
         }
         return val;
     };
@@ -280,7 +291,7 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
                         const uint32_t m = s < nSlots ? uint32_t(__builtin_amdgcn_readfirstlane(map[s])) : uint32_t(TD_REG_NONE);
                         int32_t val = -1;  // (m is wave-uniform: the branches below are scalar)
                         if (m == TD_REG_POS) val = end;
-                        else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + tid] + from);
+                        else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + rl] + from);
                         row[s] = state != 0 ? val : -1;
                     }
                 } else {
@@ -330,7 +341,7 @@ __device__ __forceinline__ uint32_t tdfaStepPairs(uint8_t* smem, const uint32_t 
                                                   uint32_t tid, const TdfaPairInfo& pi, uint32_t singleRowBytes) {
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     const LdsBytePtr cmap = reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET);
-    const uint32_t regAddr0 = regsBase + tid * sizeof(TdfaReg);
+    const uint32_t regAddr0 = regsBase + tdfaRegLane<TdfaReg>(tid) * sizeof(TdfaReg);
     static_assert((BLOCK & (BLOCK - 1)) == 0 && BLOCK >= 64 && BLOCK <= 1024, "register stride must be a power of two");
     constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
                                    (sizeof(TdfaReg) == 2 ? 1 : 0);  // log2(BLOCK * sizeof(TdfaReg))

@@ -241,7 +241,7 @@ __device__ __forceinline__ void tdfaStreamBody(
     }
     const uint32_t myRow = stageBase + lane * kRowStride;
     const uint32_t mySwizzle = COMPACT ? ((lane >> 1) & uint32_t(kLoads - 1)) << 4 : 0u;
-    const uint32_t regAddr0 = regsBase + tid * uint32_t(sizeof(TdfaReg));
+    const uint32_t regAddr0 = regsBase + tdfaRegLane<TdfaReg>(tid) * uint32_t(sizeof(TdfaReg));
 
     u32x4 in[kLoads];
 #pragma unroll
