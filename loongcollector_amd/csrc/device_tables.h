@@ -80,7 +80,8 @@ enum {
     NF_NPATHS = 9,
     NF_CONDS_USED = 10,
     NF_OFF_STABLE = 11,   // u32[nPos+1][maskWords]: bit c set iff on byte class c the position's ONLY possible move is its own
-                          // unconditional, tag-free self loop (the kernel's steady-state fast path)
+                          // unconditional, tag-free self loop (the kernel's steady-state fast path); search patterns: moves
+                          // of lower priority to the wrapper's suffix position do not count (regex_handle.cpp packNfaBlob)
     NF_OFF_BEHIND = 12,   // u32[nClasses+1]: look-behind assertions (cond bits) that hold when the previous byte has class
                           // c; entry nClasses = start of input
     NF_OFF_AHEAD = 13,    // u32[nClasses+1]: look-ahead assertions that hold when the next byte has class c; entry

@@ -1292,8 +1292,18 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
 
     uint32_t nTried = n;
     uint32_t host[4] = {0, 0, 0, 0};
+    // LC_GROK_TRACE=1: one stderr line per Match entry -- values tried / with the literal / past the screen, then (values, ms)
+    // per search round (the host waits for a counter after every step anyway, so the clock reads are exact)
+    static const bool trace = getenv("LC_GROK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto msSince = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(now() - t0).count();
+    };
     for (size_t p = 0; p < patterns.size() && nTried; ++p) {
         const GrokDevicePattern& gp = patterns[p];
+        auto tPattern = now();
+        std::string traceLine;
+        if (trace) traceLine = "grok[" + std::to_string(p) + "] engine " + std::to_string(gp.re->engine) + " tried " + std::to_string(nTried);
         const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte ...
         uint32_t nIn = nTried;
         uint32_t* outs[2] = {roundIn, roundOut};
@@ -1311,6 +1321,7 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             nIn = host[0];
             in = outs[1];
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+            if (trace) traceLine += " literal " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
         }
         if (gp.screen && nIn) {  // ... and a match of the pattern's prefix (fast TDFA kernel, status only)
             int rc = lcMatchOnStream(gp.screen, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
@@ -1325,10 +1336,13 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             in = out;
             flip = in == outs[0] ? 1 : 0;
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+            if (trace) traceLine += " screen " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
         }
         // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
         const uint32_t capsRow = 2 * (gp.columns + 1);
         while (nIn) {
+            auto tRound = now();
+            const uint32_t roundValues = nIn;
             int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, capsRow / 2,
                                      caps, status, st);
             if (rc != LC_OK) return rc;
@@ -1342,11 +1356,13 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             in = out;
             flip ^= 1;
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));  // counters[0] only; the extra-row count keeps running
+            if (trace) traceLine += " round " + std::to_string(roundValues) + " (" + std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
         }
         hipLaunchKernelGGL(grok_finish_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
                            nTried, int32_t(p), nmatch, d_pattern, from, next, counters);
         HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (trace) fprintf(stderr, "%s settled %u total %.3f ms\n", traceLine.c_str(), nTried - host[2], msSince(tPattern));
         nTried = host[2];
         std::swap(tried, next);
         HIP_TRY(hipMemsetAsync(counters + 2, 0, 4, st));

@@ -6,6 +6,7 @@
 #include <tuple>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -321,13 +322,25 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         ClassMask m = 0;
         for (size_t c = 0; c < rep.size(); ++c) {
             int passing = 0;
-            bool selfOnly = true;
+            bool steady = true;
             for (const auto& path : nfa.follow[size_t(p)]) {
                 if (path.target < 0 || !nfa.positions[size_t(path.target)].has(rep[c])) continue;
                 ++passing;
-                if (path.target != p || path.tags.any() || path.cond != 0 || !path.atoms.empty()) selfOnly = false;
+                const bool clean = path.cond == 0 && path.atoms.empty();
+                if (passing == 1) {  // the move of highest priority: the thread's own tag-free self loop
+                    if (path.target != p || path.tags.any() || !clean) steady = false;
+                } else {
+                    // Search patterns: further moves may lead to the wrapper's suffix position (the match could end here:
+                    // "%{GREEDYDATA:message}" at the end of a Grok pattern spawns such a thread at EVERY byte of the
+                    // message).  That thread ranks right below this one, replaces the one spawned a byte earlier (same
+                    // position, higher rank) and is consulted only once this thread is gone -- and the step that ends
+                    // this thread spawns it afresh from the same, unchanged captures (the path is unconditional and the
+                    // suffix position takes every byte).  At the end of the line this thread's own MATCH path outranks
+                    // it.  So the steps in between need not happen.
+                    if (path.target != nfa.searchSuffix || !clean) steady = false;
+                }
             }
-            if (passing == 1 && selfOnly) m |= ClassMask(1) << c;
+            if (passing >= 1 && steady) m |= ClassMask(1) << c;
         }
         // a path that LEAVES an atomic group acts even when its target cannot take the byte (leaving commits the group):
         // such a position is never in a steady state.  (Entering a group on a path that goes nowhere has no effect.)
@@ -701,6 +714,23 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             try {
                 TdfaLimits lim;
                 if (const char* e = getenv("LC_TDFA_MAX_STATES")) lim.maxStates = uint32_t(atoi(e));
+                if (const char* e = getenv("LC_TDFA_MAX_WORK")) lim.maxPathWork = uint64_t(atoll(e));
+                static const bool probe = getenv("LC_TDFA_PROBE") != nullptr;  // size of the automaton, whatever becomes of it
+                if (probe) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    std::string what = "ok";
+                    TdfaTables t;
+                    try {
+                        TdfaLimits big = lim;
+                        big.ldsWindow = false;
+                        t = buildTdfa(re->nfa, big);
+                    } catch (const RegexError& e) {
+                        what = e.what();
+                    }
+                    fprintf(stderr, "tdfa-probe: positions %zu states %u classes %u regs %u lists %zu  %.2f s  %s\n",
+                            re->nfa.positions.size(), t.nStates, t.nClasses, t.nRegs, t.opsStart.size(),
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what.c_str());
+                }
                 re->tdfa = buildTdfa(re->nfa, lim);
                 const bool fold = lcPickTdfaBlockAndFold(&*re);
                 if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");

@@ -338,7 +338,8 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
 
     // The device format addresses transition rows with 16 bits (device_tables.h): states x (classes + 1) x 4 bytes must
     // stay under 64 KiB - 320.  Knowing that up front makes hopeless determinisations (Grok log formats) fail fast.
-    const uint32_t maxStates = std::min<uint32_t>(limits.maxStates, (65536u - 320u) / (uint32_t(ncls + 1) * 4u));
+    const uint32_t maxStates =
+        limits.ldsWindow ? std::min<uint32_t>(limits.maxStates, (65536u - 320u) / (uint32_t(ncls + 1) * 4u)) : limits.maxStates;
     std::vector<State> states;
     std::unordered_map<std::string, uint32_t> index;
     std::deque<uint32_t> work;
