@@ -92,6 +92,8 @@ def load(path=None):
     L.lc_regex_match_device_ragged.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, sz, vp]
     L.lc_regex_compile_screen.restype = vp
     L.lc_regex_compile_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
+    L.lc_regex_compile_relaxed_screen.restype = vp
+    L.lc_regex_compile_relaxed_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
     L.lc_regex_required_literal.restype = vp
     L.lc_regex_required_literal.argtypes = [vp, ctypes.POINTER(sz)]
     L.lc_regex_run_captures.restype = i32
@@ -173,12 +175,14 @@ class GpuRegex:
         self.groups = self._L.lc_regex_mark_count(h)
 
     @classmethod
-    def compile_screen(cls, pattern, syntax_flags=0, max_states=1024, max_table_bytes=32 * 1024, lib=None):
-        """lc_regex_compile_screen: TDFA handle for the longest affordable prefix of `pattern`, or None"""
+    def compile_screen(cls, pattern, syntax_flags=0, max_states=1024, max_table_bytes=32 * 1024, lib=None, relaxed=False):
+        """lc_regex_compile_screen: TDFA handle for the longest affordable prefix of `pattern`, or None;
+        relaxed=True: lc_regex_compile_relaxed_screen, the whole pattern relaxed until its automaton is small"""
         L = lib or load()
         if isinstance(pattern, str):
             pattern = pattern.encode("utf-8")
-        h = L.lc_regex_compile_screen(pattern, len(pattern), syntax_flags, max_states, max_table_bytes)
+        fn = L.lc_regex_compile_relaxed_screen if relaxed else L.lc_regex_compile_screen
+        h = fn(pattern, len(pattern), syntax_flags, max_states, max_table_bytes)
         if not h:
             return None
         self = cls.__new__(cls)

@@ -32,6 +32,7 @@
 #include "nfa_decide_kernel.hpp"
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
+#include "screen_kernel.hpp"
 #include "split_kernel.hpp"
 #include "tdfa_stream_kernel.hpp"
 
@@ -95,12 +96,16 @@ extern "C" int lc_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ device tables
-enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2 };
+enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3 };
 static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     std::lock_guard<std::mutex> g(re->deviceMutex);
-    void** slot = which == kBlobTdfa ? &re->dTdfaBlob[dev] : (which == kBlobTdfaWide ? &re->dTdfaWideBlob[dev] : &re->dNfaBlob[dev]);
+    void** slot = which == kBlobTdfa ? &re->dTdfaBlob[dev]
+                  : which == kBlobTdfaWide ? &re->dTdfaWideBlob[dev]
+                  : which == kBlobScreen ? &re->dScreenBlob[dev] : &re->dNfaBlob[dev];
     if (!*slot) {
-        const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob : (which == kBlobTdfaWide ? re->tdfaWideBlob : re->nfaBlob);
+        const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob
+                                            : which == kBlobTdfaWide ? re->tdfaWideBlob
+                                            : which == kBlobScreen ? re->screenBlob : re->nfaBlob;
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, blob.size() * 4 + 16));  // + one word behind the tables: the compact kernel's long-line flag
         hipError_t e = hipMemset(p, 0, blob.size() * 4 + 16);
@@ -119,13 +124,14 @@ void lcReleaseDeviceTables(lc_regex* re) {
     int cur = 0;
     bool haveCur = hipGetDevice(&cur) == hipSuccess;
     for (int d = 0; d < kLcMaxDevices; ++d) {
-        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d]) {
+        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d]) {
             if (hipSetDevice(d) == hipSuccess) {
+                if (re->dScreenBlob[d]) (void)hipFree(re->dScreenBlob[d]);
                 if (re->dTdfaBlob[d]) (void)hipFree(re->dTdfaBlob[d]);
                 if (re->dTdfaWideBlob[d]) (void)hipFree(re->dTdfaWideBlob[d]);
                 if (re->dNfaBlob[d]) (void)hipFree(re->dNfaBlob[d]);
             }
-            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = nullptr;
+            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = re->dScreenBlob[d] = nullptr;
         }
     }
     if (haveCur) (void)hipSetDevice(cur);
@@ -545,6 +551,24 @@ __global__ __launch_bounds__(256) void run_capture_kernel(const uint8_t* __restr
         ++e;
     }
     c[1] = int32_t(e);
+}
+
+int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
+                     const uint32_t* d_in, uint32_t* d_out, uint32_t* d_counters, void* streamPtr) {
+    if (re->screenBlob.empty()) {
+        tlsError = "handle carries no screen table";
+        return LC_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return LC_OK;
+    void* dBlob = nullptr;
+    int rc = ensureUploaded(re, dev, kBlobScreen, &dBlob);
+    if (rc != LC_OK) return rc;
+    noteKernel("dfa_screen_kernel");
+    hipLaunchKernelGGL(dfa_screen_kernel, dim3((n + kScreenBlock - 1) / kScreenBlock), dim3(kScreenBlock), 0,
+                       static_cast<hipStream_t>(streamPtr), d_data, d_off, d_len, d_in, n, static_cast<const uint32_t*>(dBlob), d_out,
+                       d_counters);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
 }
 
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
@@ -1323,20 +1347,29 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
             if (trace) traceLine += " literal " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
         }
-        if (gp.screen && nIn) {  // ... and a match of the pattern's prefix (fast TDFA kernel, status only)
-            int rc = lcMatchOnStream(gp.screen, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
-                                     status, st);
-            if (rc != LC_OK) return rc;
+        // ... and a match of the pattern's prefix, then of the relaxed whole pattern (fast TDFA kernel, status only)
+        for (lc_regex* scr : {gp.screen, gp.relaxed}) {
+            if (!scr || !nIn) continue;
             uint32_t* out = in == outs[0] ? outs[1] : outs[0];
-            hipLaunchKernelGGL(grok_status_filter_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in,
-                               nIn, status, out, counters);
+            if (!scr->screenBlob.empty()) {  // a plain DFA with its table in L2: screens and filters in one kernel
+                int rc = lcScreenOnStream(scr, dev, d_data, d_off, d_len, nIn, in, out, counters, st);
+                if (rc != LC_OK) return rc;
+            } else {
+                int rc = lcMatchOnStream(scr, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
+                                         status, st);
+                if (rc != LC_OK) return rc;
+                hipLaunchKernelGGL(grok_status_filter_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st,
+                                   in, nIn, status, out, counters);
+            }
             HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             nIn = host[0];
             in = out;
             flip = in == outs[0] ? 1 : 0;
             HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
-            if (trace) traceLine += " screen " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
+            if (trace)
+                traceLine += std::string(scr == gp.screen ? " screen " : " relaxed ") + std::to_string(nIn) + " (" +
+                             std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
         }
         // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
         const uint32_t capsRow = 2 * (gp.columns + 1);

@@ -12,6 +12,7 @@ struct GrokDevicePattern {
     lc_regex* re;        // compiled with LC_SYNTAX_SEARCH | LC_SYNTAX_NAMED_ONLY: group 1 = whole match, 2.. = named groups
     uint32_t columns;    // named groups
     lc_regex* screen;    // optional TDFA screen for the pattern's prefix (regex_handle.hpp lcCompilePrefixScreen), or null
+    lc_regex* relaxed = nullptr;  // optional TDFA screen for the whole pattern, relaxed (lcCompileRelaxedScreen), or null
 };
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts);

@@ -68,8 +68,14 @@ void ProcessorGrokGpu::Init() {
         lc_regex* screen = nullptr;
         if (re->engine == LC_ENGINE_NFA)
             screen = lcCompilePrefixScreen(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, 1024, 32 * 1024);
+        // ... and one for the whole pattern, relaxed until it is small (LC_GROK_NO_RELAXED: A/B measurements)
+        lc_regex* relaxed = nullptr;
+        static const bool noRelaxed = getenv("LC_GROK_NO_RELAXED") != nullptr;
+        if (re->engine == LC_ENGINE_NFA && !noRelaxed)
+            relaxed = lcCompileRelaxedScreen(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, 20000, 2u << 20);
         mScreens.push_back(screen);
-        mDevice.push_back({re, columns, screen});
+        mScreens.push_back(relaxed);
+        mDevice.push_back({re, columns, screen, relaxed});
         std::vector<uint32_t> colKey(columns, kNoKey);
         std::vector<MergedField> fields;
         std::map<std::string, size_t> byName;

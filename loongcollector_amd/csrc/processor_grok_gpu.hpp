@@ -65,7 +65,7 @@ private:
     PatternLibrary mLibrary;
     std::vector<std::string> mExpanded;
     std::vector<lc_regex*> mCompiled;
-    std::vector<lc_regex*> mScreens;                   // per Match entry: prefix screen or nullptr
+    std::vector<lc_regex*> mScreens;                   // the screens of the Match entries (prefix, relaxed; nullptr = none), owned
     std::vector<GrokDevicePattern> mDevice;
     std::vector<std::string> mKeys;                    // distinct emitted keys
     std::vector<std::vector<uint32_t>> mColumnKey;     // [pattern][column] -> key index

@@ -12,6 +12,7 @@
 #include <map>
 
 #include "device_tables.h"
+#include "screen_kernel_layout.h"
 
 namespace lcregex {
 
@@ -570,8 +571,86 @@ static std::unique_ptr<Node> cloneWithoutCaptures(const Node& n) {
     return c;
 }
 
-lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,
-                                size_t maxBlobBytes) {
+// compile one candidate screen (a sub-expression every match of the pattern must contain) as a status-only search; nullptr if
+// it is nullable (screens nothing) or its automaton is too large
+static lc_regex* compileScreenNode(std::unique_ptr<Node> node, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes,
+                                   const std::string& description, uint32_t k, uint32_t n, bool plainDfa = false) {
+    auto re = std::make_unique<lc_regex>();
+    try {
+        ParsedRegex sub;
+        sub.root = std::move(node);
+        sub.groupCount = 0;
+        sub.groupNames.emplace_back();
+        {
+            FollowNfa probe = buildFollowNfa(sub);
+            for (const auto& path : probe.follow[size_t(probe.startIndex())])
+                if (path.target == kMatchTarget) return nullptr;
+        }
+        wrapForSearch(sub);
+        re->nfa = buildFollowNfa(sub);
+        re->nfa.searchPrefix = 0;
+        re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;
+        TdfaLimits lim;
+        lim.maxStates = maxStates;
+        if (plainDfa) {  // yes/no DFA, table in global memory (screen_kernel.hpp): no LDS window to respect
+            lim.ldsWindow = false;
+            re->tdfa = buildScreenDfa(re->nfa, lim);
+            const TdfaTables& t = re->tdfa;
+            const size_t tableBytes = size_t(t.nStates) * t.nClasses * 2;
+            if (getenv("LC_RELAX_DEBUG"))
+                fprintf(stderr, "  screen dfa: %u states, %u classes, %zu table bytes\n", t.nStates, t.nClasses, tableBytes);
+            if (tableBytes > maxBlobBytes || t.nStates > 0xFFFF) return nullptr;
+            uint32_t sink = 0xFFFFFFFFu;
+            for (uint32_t st = 1; st < t.nStates && sink == 0xFFFFFFFFu; ++st) {
+                bool self = t.finalId[st] != 0xFFFF;
+                for (uint32_t c = 0; c < t.nClasses && self; ++c) self = (t.trans[size_t(st) * t.nClasses + c] & 0xFFFF) == st;
+                if (self) sink = st;
+            }
+            BlobWriter w;
+            w.reserve(SC_HEADER_WORDS * 4);
+            w.put(t.classMap);
+            std::vector<uint8_t> accept(t.nStates, 0);
+            for (uint32_t st = 1; st < t.nStates; ++st) accept[st] = t.finalId[st] != 0xFFFF;
+            uint32_t hdr[SC_HEADER_WORDS] = {};
+            hdr[SC_MAGIC] = SC_MAGIC_VALUE;
+            hdr[SC_NSTATES] = t.nStates;
+            hdr[SC_NCLASSES] = t.nClasses;
+            hdr[SC_START] = t.startState;
+            hdr[SC_SINK] = sink;
+            hdr[SC_OFF_ACCEPT] = w.put(accept);
+            std::vector<uint16_t> table(size_t(t.nStates) * t.nClasses);
+            for (size_t i = 0; i < table.size(); ++i) table[i] = uint16_t(t.trans[i] & 0xFFFF);
+            hdr[SC_OFF_TABLE] = w.put(table);
+            std::memcpy(w.bytes.data(), hdr, sizeof hdr);
+            re->screenBlob = w.finish(SC_TOTAL_BYTES);
+            re->engine = LC_ENGINE_TDFA;
+            re->pattern = description;
+            re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
+            re->tdfaHeader = {t.nStates, t.nClasses, t.nRegs, t.nSlots, t.startState, k, n, 0};
+            return re.release();
+        }
+        re->tdfa = buildTdfa(re->nfa, lim);
+        if (getenv("LC_RELAX_DEBUG"))
+            fprintf(stderr, "  screen automaton: %u states, %u classes, %zu table bytes\n", re->tdfa.nStates, re->tdfa.nClasses,
+                    tdfaBlobBytesEstimate(re->tdfa));
+        if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) return nullptr;
+        const bool fold = lcPickTdfaBlockAndFold(&*re);
+        if (!re->tdfaBlock) return nullptr;
+        re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
+        re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
+        re->hasTdfa = true;
+        re->engine = LC_ENGINE_TDFA;
+        re->pattern = description;
+        re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
+        re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots, re->tdfa.startState, k, n, 0};
+        return re.release();
+    } catch (const RegexError& e) {
+        if (getenv("LC_RELAX_DEBUG")) fprintf(stderr, "  screen refused: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+static ParsedRegex parseForScreen(const char* pattern, size_t len, uint32_t syntax_flags) {
     Syntax syn;
     syn.icase = syntax_flags & LC_SYNTAX_ICASE;
     syn.dotAll = !(syntax_flags & LC_SYNTAX_NO_DOTALL);
@@ -579,9 +658,233 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
     syn.extended = syntax_flags & LC_SYNTAX_EXTENDED;
     syn.namedOnly = true;
     syn.regexp2 = syntax_flags & LC_SYNTAX_REGEXP2;
+    return parseRegex(std::string_view(pattern, len), syn);
+}
+
+// ---- relaxed screen -----------------------------------------------------------------------------------------------
+// The WHOLE pattern, made small by accepting more: captures, assertions and atomic brackets dropped, long counters opened
+// ({0,62} -> *), and every sub-expression that still needs more than `budget` positions -- the IPv6|IPv4|hostname
+// alternations, lists of month names or firewall actions -- replaced by  F C*  (F = the bytes it can start with, C = all
+// bytes it can contain; C* when it can be empty).  Every match of the pattern is a match of the relaxed pattern, so a line
+// without one cannot match: a necessary condition over the whole line, where the prefix screen only sees the first elements
+// ("... connection denied from ..." passes a prefix that ends at "connection" and fails here, where a number must follow).
+namespace {
+struct Relaxer {
+    size_t budget;
+    static size_t positions(const Node& n) {
+        switch (n.kind) {
+            case Node::Set: return 1;
+            case Node::Empty:
+            case Node::Assert: return 0;
+            case Node::Repeat: {
+                const size_t k = n.kids.empty() ? 0 : positions(*n.kids[0]);
+                const size_t copies = size_t(n.max < 0 ? std::max(n.min, 1) : std::max(n.max, 1));
+                return std::min<size_t>(k * copies, 1u << 20);
+            }
+            default: {
+                size_t t = 0;
+                for (const auto& k : n.kids) t += positions(*k);
+                return std::min<size_t>(t, 1u << 20);
+            }
+        }
+    }
+    static bool nullable(const Node& n) {
+        switch (n.kind) {
+            case Node::Set: return false;
+            case Node::Empty:
+            case Node::Assert: return true;
+            case Node::Repeat: return n.min == 0 || n.kids.empty() || nullable(*n.kids[0]);
+            case Node::Alt:
+                for (const auto& k : n.kids)
+                    if (nullable(*k)) return true;
+                return n.kids.empty();
+            default:  // Cat, Group, Atomic
+                if (n.kind == Node::Group && n.runCapture) return true;
+                for (const auto& k : n.kids)
+                    if (!nullable(*k)) return false;
+                return true;
+        }
+    }
+    static void bytes(const Node& n, ByteSet& acc) {
+        if (n.kind == Node::Set) acc.unite(n.set);
+        if (n.kind == Node::Group && n.runCapture) return;
+        for (const auto& k : n.kids) bytes(*k, acc);
+    }
+    static void first(const Node& n, ByteSet& acc) {  // bytes a non-empty match of n can start with
+        switch (n.kind) {
+            case Node::Set: acc.unite(n.set); break;
+            case Node::Empty:
+            case Node::Assert: break;
+            case Node::Alt:
+                for (const auto& k : n.kids) first(*k, acc);
+                break;
+            case Node::Repeat:
+                if (!n.kids.empty()) first(*n.kids[0], acc);
+                break;
+            default:
+                if (n.kind == Node::Group && n.runCapture) break;
+                for (const auto& k : n.kids) {
+                    first(*k, acc);
+                    if (!nullable(*k)) break;
+                }
+        }
+    }
+    static std::unique_ptr<Node> make(Node::Kind kind) {
+        auto n = std::make_unique<Node>();
+        n->kind = kind;
+        return n;
+    }
+    static std::unique_ptr<Node> collapse(const Node& n) {
+        ByteSet all;
+        bytes(n, all);
+        auto star = make(Node::Repeat);
+        star->min = 0;
+        star->max = -1;
+        auto body = make(Node::Set);
+        body->set = all;
+        star->kids.push_back(std::move(body));
+        if (nullable(n)) return star;
+        auto head = make(Node::Set);
+        first(n, head->set);
+        auto cat = make(Node::Cat);
+        cat->kids.push_back(std::move(head));
+        cat->kids.push_back(std::move(star));
+        return cat;
+    }
+    std::unique_ptr<Node> relax(const Node& n) const { return relax(n, budget); }
+    std::unique_ptr<Node> relax(const Node& n, size_t budget) const {
+        switch (n.kind) {
+            case Node::Empty:
+            case Node::Assert: return make(Node::Empty);
+            case Node::Set: {
+                auto c = make(Node::Set);
+                c->set = n.set;
+                return c;
+            }
+            case Node::Group:
+                if (n.runCapture) return make(Node::Empty);
+                [[fallthrough]];
+            case Node::Atomic: return n.kids.empty() ? make(Node::Empty) : relax(*n.kids[0], budget);
+            case Node::Cat: {
+                auto c = make(Node::Cat);
+                for (const auto& k : n.kids) c->kids.push_back(relax(*k, budget));
+                return c;
+            }
+            case Node::Alt: {
+                // too large as a whole: first coarsen the alternatives (two timestamp formats keep their shape, the month
+                // names inside them go), only then give up the alternation itself
+                for (size_t b = budget; b >= 3; b /= 2) {
+                    auto c = make(Node::Alt);
+                    for (const auto& k : n.kids) c->kids.push_back(relax(*k, b));
+                    if (positions(*c) <= 4 * budget) return c;
+                }
+                return collapse(n);
+            }
+            case Node::Repeat: {
+                if (n.kids.empty()) return make(Node::Empty);
+                auto c = make(Node::Repeat);
+                c->min = n.min;
+                c->max = n.max;
+                c->kids.push_back(relax(*n.kids[0], budget));
+                // "[^\n]*" (Grok's DATA / GREEDYDATA) -> "(?s:.)*": a universal loop, which the screen's determinisation
+                // (screen_dfa.cpp) uses to forget everything that lies before it
+                if (c->max < 0 && c->min == 0 && c->kids[0]->kind == Node::Set) {
+                    int cnt = 0;
+                    for (unsigned b = 0; b < 256; ++b) cnt += c->kids[0]->set.has(b);
+                    if (cnt >= 250) c->kids[0]->set = ByteSet::all();
+                }
+                if (positions(*c) > budget && (c->max < 0 || c->max > 2)) {  // open the counter
+                    c->min = std::min(c->min, 1);
+                    c->max = -1;
+                }
+                if (positions(*c) > budget) return collapse(n);
+                return c;
+            }
+        }
+        return make(Node::Empty);
+    }
+};
+}  // namespace
+
+// (debugging aid, LC_RELAX_DEBUG: the relaxed pattern in a readable form)
+static std::string dumpNode(const Node& n) {
+    auto setStr = [](const ByteSet& s) {
+        int cnt = 0;
+        for (unsigned c = 0; c < 256; ++c) cnt += s.has(c);
+        if (cnt == 256) return std::string(".");
+        std::string o;
+        if (cnt == 1) {
+            for (unsigned c = 0; c < 256; ++c)
+                if (s.has(c)) {
+                    if (c >= 33 && c < 127) o += char(c);
+                    else if (c == 32) o += "\\s";
+                    else o += "\\x" + std::to_string(c);
+                }
+            return o;
+        }
+        o = "[";
+        for (unsigned c = 0; c < 256;) {
+            if (!s.has(c)) {
+                ++c;
+                continue;
+            }
+            unsigned e = c;
+            while (e + 1 < 256 && s.has(e + 1)) ++e;
+            auto ch = [](unsigned x) { return (x >= 33 && x < 127) ? std::string(1, char(x)) : "\\x" + std::to_string(x); };
+            o += ch(c);
+            if (e > c) o += "-" + ch(e);
+            c = e + 1;
+        }
+        return o + "]";
+    };
+    switch (n.kind) {
+        case Node::Empty: return "";
+        case Node::Set: return setStr(n.set);
+        case Node::Assert: return "(?A)";
+        case Node::Repeat: {
+            std::string k = n.kids.empty() ? "" : dumpNode(*n.kids[0]);
+            return "(" + k + "){" + std::to_string(n.min) + "," + (n.max < 0 ? "" : std::to_string(n.max)) + "}";
+        }
+        case Node::Alt: {
+            std::string o = "(";
+            for (size_t i = 0; i < n.kids.size(); ++i) o += (i ? "|" : "") + dumpNode(*n.kids[i]);
+            return o + ")";
+        }
+        default: {
+            std::string o;
+            for (const auto& k : n.kids) o += dumpNode(*k);
+            return o;
+        }
+    }
+}
+
+lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes) {
     ParsedRegex parsed;
     try {
-        parsed = parseRegex(std::string_view(pattern, len), syn);
+        parsed = parseForScreen(pattern, len, syntax_flags);
+    } catch (const RegexError&) {
+        return nullptr;
+    }
+    for (size_t budget : {96u, 48u, 24u, 12u, 6u}) {
+        Relaxer rx{budget};
+        std::unique_ptr<Node> node = rx.relax(*parsed.root);
+        const size_t npos = Relaxer::positions(*node);
+        if (getenv("LC_RELAX_DEBUG")) fprintf(stderr, "relaxed(budget %zu, %zu positions): %s\n", budget, npos, dumpNode(*node).c_str());
+        if (npos > 3000) continue;
+        if (lc_regex* re = compileScreenNode(std::move(node), syntax_flags, maxStates, maxBlobBytes,
+                                             "<relaxed screen: budget " + std::to_string(budget) + ", " + std::to_string(npos) +
+                                                 " positions>",
+                                             uint32_t(budget), uint32_t(npos), true))
+            return re;
+    }
+    return nullptr;
+}
+
+lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,
+                                size_t maxBlobBytes) {
+    ParsedRegex parsed;
+    try {
+        parsed = parseForScreen(pattern, len, syntax_flags);
     } catch (const RegexError&) {
         return nullptr;
     }
@@ -595,43 +898,11 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
     };
     flatten(*parsed.root);
     if (flat.size() < 2) return nullptr;  // nothing to cut
-    // compile one candidate screen (a sub-expression every match of the pattern must start with); nullptr if it is
-    // nullable (screens nothing) or its automaton is too large
     auto tryScreen = [&](std::unique_ptr<Node> node, uint32_t k, const char* how) -> lc_regex* {
-        auto re = std::make_unique<lc_regex>();
-        try {
-            ParsedRegex sub;
-            sub.root = std::move(node);
-            sub.groupCount = 0;
-            sub.groupNames.emplace_back();
-            {
-                FollowNfa probe = buildFollowNfa(sub);
-                for (const auto& path : probe.follow[size_t(probe.startIndex())])
-                    if (path.target == kMatchTarget) return nullptr;
-            }
-            wrapForSearch(sub);
-            re->nfa = buildFollowNfa(sub);
-            re->nfa.searchPrefix = 0;
-            re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;
-            TdfaLimits lim;
-            lim.maxStates = maxStates;
-            re->tdfa = buildTdfa(re->nfa, lim);
-            if (tdfaBlobBytesEstimate(re->tdfa) > maxBlobBytes) return nullptr;
-            const bool fold = lcPickTdfaBlockAndFold(&*re);
-            if (!re->tdfaBlock) return nullptr;
-            re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
-            re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
-            re->hasTdfa = true;
-            re->engine = LC_ENGINE_TDFA;
-            re->pattern = std::string("<prefix screen: ") + how + ", " + std::to_string(k) + " of " +
-                          std::to_string(flat.size()) + " elements>";
-            re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
-            re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots, re->tdfa.startState,
-                              k, uint32_t(flat.size()), 0};
-            return re.release();
-        } catch (const RegexError&) {
-            return nullptr;
-        }
+        return compileScreenNode(std::move(node), syntax_flags, maxStates, maxBlobBytes,
+                                 std::string("<prefix screen: ") + how + ", " + std::to_string(k) + " of " +
+                                     std::to_string(flat.size()) + " elements>",
+                                 k, uint32_t(flat.size()));
     };
     auto prefixOf = [&](const std::vector<const Node*>& list, size_t k) {
         auto cat = std::make_unique<Node>();
@@ -668,6 +939,16 @@ extern "C" lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t patte
     if (!pattern) return nullptr;
     try {
         return lcCompilePrefixScreen(pattern, pattern_len, syntax_flags, max_states, max_table_bytes);
+    } catch (const std::exception&) {
+        return nullptr;
+    }
+}
+
+extern "C" lc_regex_t* lc_regex_compile_relaxed_screen(const char* pattern, size_t pattern_len, uint32_t syntax_flags,
+                                                       uint32_t max_states, size_t max_table_bytes) {
+    if (!pattern) return nullptr;
+    try {
+        return lcCompileRelaxedScreen(pattern, pattern_len, syntax_flags, max_states, max_table_bytes);
     } catch (const std::exception&) {
         return nullptr;
     }
@@ -802,10 +1083,12 @@ extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     out->engine = re->engine;
     out->mark_count = re->nfa.groupCount;
     out->positions = uint32_t(re->nfa.positions.size());
-    out->states = re->hasTdfa ? re->tdfa.nStates : 0;
-    out->classes = re->hasTdfa ? re->tdfa.nClasses : (re->nfaBlob.empty() ? 0 : re->nfaBlob[NF_NCLASSES]);
-    out->registers = re->hasTdfa ? re->tdfa.nRegs : 0;
-    out->table_bytes = uint32_t((re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
+    const bool tables = re->hasTdfa || !re->screenBlob.empty();
+    out->states = tables ? re->tdfa.nStates : 0;
+    out->classes = tables ? re->tdfa.nClasses : (re->nfaBlob.empty() ? 0 : re->nfaBlob[NF_NCLASSES]);
+    out->registers = tables ? re->tdfa.nRegs : 0;
+    out->table_bytes = uint32_t((!re->screenBlob.empty() ? re->screenBlob.size()
+                                 : re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
     return LC_OK;
 }
 
@@ -839,8 +1122,9 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
         if (re->nfaBlob.empty()) return LC_ERR_ARG;
         return view(re->nfaBlob.data(), re->nfaBlob.size() * 4);
     }
-    if (!re->hasTdfa) return LC_ERR_ARG;
+    if (!re->hasTdfa && re->screenBlob.empty()) return LC_ERR_ARG;  // (a screen handle shows its logical tables too)
     const TdfaTables& t = re->tdfa;
+    if ((which == LC_TABLE_TDFA_BLOB || which == LC_TABLE_TDFA_WIDE_BLOB) && !re->hasTdfa) return LC_ERR_ARG;
     switch (which) {
         case LC_TABLE_CLASSMAP: return view(t.classMap.data(), t.classMap.size());
         case LC_TABLE_TDFA_TRANS: return view(t.trans.data(), t.trans.size() * 4);

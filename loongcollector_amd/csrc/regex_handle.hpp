@@ -28,6 +28,7 @@ struct lc_regex {
     std::vector<uint32_t> tdfaWideBlob; // tables of the COMPACT kernel variant (16-bit offset registers), or empty
     int tdfaWideBlock = 0;              // its workgroup size: 256 / 512 (class-indexed rows) or 1024 (byte-indexed rows)
     bool tdfaWideForced = false;        // LC_TDFA_COMPACT was set: use it for every batch, not only for large ones
+    std::vector<uint32_t> screenBlob;   // screen_kernel.hpp layout: a yes/no DFA too large for LDS (relaxed screens), or empty
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
@@ -42,6 +43,7 @@ struct lc_regex {
     std::atomic<uint32_t> nfaSeq[kLcMaxDevices] = {};      // launch sequence numbers of the NFA kernel (its overflow flag)
     std::atomic<uint32_t> tdfaWideSeq[kLcMaxDevices] = {};  // launch sequence numbers of the compact kernel (its long-line flag)
     void* dNfaBlob[kLcMaxDevices] = {};
+    void* dScreenBlob[kLcMaxDevices] = {};
 };
 
 namespace lcregex {
@@ -100,6 +102,13 @@ inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos, bool atomic) {
 // within the limits (nullptr if there is none); status-only screening before the NFA engine (Grok)
 lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,
                                 size_t maxBlobBytes);
+// regex_handle.cpp: TDFA-only handle for the WHOLE pattern relaxed until its automaton is small (sub-expressions that are too
+// large become "any of their bytes, repeated"); a necessary condition over the whole line (nullptr if there is none)
+lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes);
+// implemented in gpu_runtime.hip: one pass of a screen handle that carries a screenBlob (dfa_screen_kernel) over the values
+// listed in d_in (nullptr: all n); accepted values are appended to d_out, their number added to d_counters[0]
+int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
+                     const uint32_t* d_in, uint32_t* d_out, uint32_t* d_counters, void* stream);
 // implemented in gpu_runtime.hip; frees device copies
 void lcReleaseDeviceTables(lc_regex* re);
 // implemented in gpu_runtime.hip: one launch of the engine's kernel.  d_n (optional): line count on the device;

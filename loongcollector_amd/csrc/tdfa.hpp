@@ -43,4 +43,9 @@ struct TdfaLimits {
 // Throws RegexError("tdfa: ...") when the automaton exceeds the limits (caller falls back to the NFA engine).
 TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits());
 
+// screen_dfa.cpp: plain yes/no DFA (no registers, no thread order) for a pattern without assertions and atomic groups; positions
+// that can only reach MATCH through a universal loop (?s:.)* that is already alive are forgotten, so "X.*Y.*Z" costs the sum, not
+// the product, of its parts.  Same table format (one empty register program); throws RegexError on the limits.
+TdfaTables buildScreenDfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits());
+
 }  // namespace lcregex

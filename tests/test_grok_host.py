@@ -172,9 +172,10 @@ def test_device_algorithm_on_the_compiled_tables_reproduces_the_golden_vectors(g
 
 
 def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, golden_dir):
-    """Two prefilters sit in front of the NFA engine (lcGrokMatchDevice): the required literal and the TDFA screen of the
-    pattern's prefix.  Both must accept every value the pattern matches somewhere -- checked against the oracle's search on
-    the golden values and on the configs[2] corpus; and a screen must exist for most NFA-engine patterns."""
+    """Three prefilters sit in front of the NFA engine (lcGrokMatchDevice): the required literal, the TDFA screen of the
+    pattern's prefix and the TDFA screen of the whole pattern, relaxed.  All must accept every value the pattern matches
+    somewhere -- checked against the oracle's search on the golden values and on the configs[2] corpus; screens must exist
+    for most NFA-engine patterns, and the relaxed one must reject values the prefix screen lets through."""
     from loongcollector_amd.grok_corpus import grok_lines
     with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
         cfg3 = json.load(f)
@@ -183,7 +184,7 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
             for e in GrokOracle(c["config"]["Match"], custom_patterns=c["config"].get("CustomPatterns")).expanded]
     corpus = grok_lines(150)
     jobs += [(lib.denormalize(m), corpus) for m in cfg3["match"][4:40:3]]
-    screens = checked = rejected = 0
+    screens = checked = rejected = relaxed_screens = relaxed_only = 0
     for expanded, values in jobs:
         pat = expanded.encode("utf-8")
         try:
@@ -196,16 +197,26 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
         screen = B.GpuRegex.compile_screen(pat, syntax_flags=GROK_SYNTAX & ~B.LC_SYNTAX_SEARCH)
         it = TdfaInterp(screen) if screen is not None else None
         screens += screen is not None
+        relaxed = B.GpuRegex.compile_screen(pat, syntax_flags=GROK_SYNTAX & ~B.LC_SYNTAX_SEARCH, max_states=20000,
+                                            max_table_bytes=2 << 20, relaxed=True)
+        it2 = TdfaInterp(relaxed) if relaxed is not None else None
+        relaxed_screens += relaxed is not None
         for v in values:
             hit = o.search(v) is not None
             checked += 1
+            passes = True
             if it is not None:
                 passes = it.fullmatch(v) is not None
                 assert passes or not hit, (expanded[:60], v)
                 rejected += not passes
+            if it2 is not None:
+                passes2 = it2.fullmatch(v) is not None
+                assert passes2 or not hit, ("relaxed", expanded[:60], v)
+                relaxed_only += passes and not passes2
             if hit:
                 assert lit in v, (expanded[:60], lit, v)
     assert checked >= 2000 and screens >= 15 and rejected > 300, (checked, screens, rejected)
+    assert relaxed_screens >= 15 and relaxed_only > 50, (relaxed_screens, relaxed_only)
 
 
 @pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106),
