@@ -144,6 +144,13 @@ lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t pattern_len, uin
  * NULL if even the coarsest relaxation is too large or accepts the empty string.  Free with lc_regex_free. */
 lc_regex_t* lc_regex_compile_relaxed_screen(const char* pattern, size_t pattern_len, uint32_t syntax_flags, uint32_t max_states,
                                             size_t max_table_bytes);
+/* One pass of a relaxed screen over device-resident values (one value per lane, the yes/no DFA's table read through L2):
+ *   d_lines (optional) uint32[n]: the values to look at (NULL: 0..n-1);  d_len: their lengths (required);
+ *   d_out   uint32[n]: receives the values the screen ACCEPTS, in no particular order;
+ *   d_count uint32: incremented by the number of accepted values (the caller zeroes it).
+ * Only for handles made by lc_regex_compile_relaxed_screen (LC_ERR_UNSUPPORTED otherwise). */
+int lc_regex_screen_device(lc_regex_t* screen, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
+                           const uint32_t* d_lines, uint32_t* d_out, uint32_t* d_count, void* stream);
 
 /* The longest byte string every match of the pattern must contain (*len = 0: none is certain).  A value without it cannot
  * match; the Grok matcher uses it to skip the automaton for most (value, Match pattern) pairs. */

@@ -94,6 +94,8 @@ def load(path=None):
     L.lc_regex_compile_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
     L.lc_regex_compile_relaxed_screen.restype = vp
     L.lc_regex_compile_relaxed_screen.argtypes = [ctypes.c_char_p, sz, u32, u32, sz]
+    L.lc_regex_screen_device.restype = i32
+    L.lc_regex_screen_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.lc_regex_required_literal.restype = vp
     L.lc_regex_required_literal.argtypes = [vp, ctypes.POINTER(sz)]
     L.lc_regex_run_captures.restype = i32
@@ -276,6 +278,13 @@ class GpuRegex:
                                                 n, ptr(d_lines), ptr(d_nlines), ptr(d_from), G, d_caps.data_ptr(),
                                                 d_status.data_ptr(), stream)
         _check(rc, "lc_regex_match_device_from")
+
+    def screen_device(self, d_data, d_off, d_len, n, d_out, d_count, d_lines=None, stream=None):
+        """lc_regex_screen_device: a relaxed screen's pass over the values; accepted values -> d_out, their number += d_count"""
+        rc = self._L.lc_regex_screen_device(self._h, d_data.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n,
+                                            d_lines.data_ptr() if d_lines is not None else None, d_out.data_ptr(),
+                                            d_count.data_ptr(), stream)
+        _check(rc, "lc_regex_screen_device")
 
     def match_device_dyn(self, d_data, d_off, d_nlines, max_lines, d_caps, d_status, ngroups=None, sep_bytes=1,
                          stream=None, engine=LC_ENGINE_AUTO):

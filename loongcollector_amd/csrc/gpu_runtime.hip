@@ -413,11 +413,13 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);
     const bool atomic = re->nfa.atomicCount > 0;
     size_t lds = lcNfaLdsBytes(blobBytes, uint32_t(re->nfa.positions.size()), atomic);
-    // Program too big for LDS -- or so big that only one workgroup would fit per CU: the tables stay in HBM (L2) and
-    // only the scratch is LDS; four lines per CU with LDS-speed tables lose against a dozen with L2-speed tables.
+    // Program too big for LDS -- or so big that fewer than three workgroups would fit per CU: the tables stay in HBM (L2) and
+    // only the scratch is LDS; four or eight lines per CU with LDS-speed tables lose against a dozen with L2-speed tables
+    // (configs[2], 256 Ki lines: CISCOFW106001, 89.6 KB with its tables, 32 -> 9.4 ms; CRONLOG 6.2 -> 3.2 ms; below 52 KB
+    // nothing moves).  LC_NFA_GLOBAL_KB overrides the bound.
     static const size_t globalAbove = [] {
         const char* e = getenv("LC_NFA_GLOBAL_KB");
-        return size_t(e ? atoi(e) : 96) * 1024;
+        return size_t(e ? atoi(e) : 52) * 1024;
     }();
     const bool global = lds > kLcLdsPerCu || lds > globalAbove;
     if (global) lds -= blobBytes;
@@ -569,6 +571,19 @@ int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
                        d_counters);
     HIP_TRY(hipGetLastError());
     return LC_OK;
+}
+
+extern "C" int lc_regex_screen_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                                      uint32_t n, const uint32_t* d_lines, uint32_t* d_out, uint32_t* d_count, void* stream) {
+    if (!re || !d_data || !d_off || !d_len || !d_out || !d_count) return LC_ERR_ARG;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    return lcScreenOnStream(re, dev, d_data, d_off, d_len, n, d_lines, d_out, d_count, stream);
 }
 
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,

@@ -166,6 +166,53 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
     assert hits >= 2800 and len(winners) >= 15
 
 
+def test_relaxed_screens_on_the_device(torch_dev, golden_dir):
+    """lc_regex_screen_device (dfa_screen_kernel: one value per lane, the yes/no DFA's table in L2) against the same tables
+    walked on the CPU, and against the oracle: a value the pattern matches somewhere is never rejected.  Whole list and a
+    listed subset; lengths 26..4096, unaligned starts."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    from oracle.oracle import ORX_NO_MOD_M, ORX_NO_MOD_S, ORX_REGEXP2, OracleRegex
+    from tests.helpers.table_interp import TdfaInterp
+    from tests.test_grok_host import GROK_SYNTAX
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    lib = Grok(CustomPatterns=cfg["custom_patterns"])
+    values = grok_lines(600) + [b"", b"x"]
+    length = np.array([len(v) for v in values], dtype=np.uint32)
+    off = np.zeros(len(values), dtype=np.uint32)
+    off[1:] = np.cumsum(length[:-1], dtype=np.uint64).astype(np.uint32)
+    data = np.frombuffer(b"".join(values) + b"\0" * 32, dtype=np.uint8).copy()
+    dev = torch_dev.device("cuda:0")
+    d_data = torch_dev.from_numpy(data).to(dev)
+    d_off = torch_dev.from_numpy(off.view(np.int32)).to(dev)
+    d_len = torch_dev.from_numpy(length.view(np.int32)).to(dev)
+    subset = np.arange(0, len(values), 3, dtype=np.uint32)
+    d_subset = torch_dev.from_numpy(subset.view(np.int32)).to(dev)
+    rejected_total = big = 0
+    for name in ("COMMONAPACHELOG", "SYSLOGLINE", "CISCOFW106001", "CISCOFW302013_302014_302015_302016", "SHOREWALL", "TOMCATLOG"):
+        pat = lib.denormalize("%{" + name + "}").encode("utf-8")
+        scr = B.GpuRegex.compile_screen(pat, syntax_flags=GROK_SYNTAX & ~B.LC_SYNTAX_SEARCH, max_states=20000,
+                                        max_table_bytes=2 << 20, relaxed=True)
+        assert scr is not None, name
+        big += scr.info()["states"] > 1000
+        it = TdfaInterp(scr)
+        want = np.array([it.fullmatch(v) is not None for v in values])
+        for lines, d_lines in ((np.arange(len(values)), None), (subset, d_subset)):
+            d_out = torch_dev.full((len(values),), -1, dtype=torch_dev.int32, device=dev)
+            d_count = torch_dev.zeros((1,), dtype=torch_dev.int32, device=dev)
+            scr.screen_device(d_data, d_off, d_len, len(lines), d_out, d_count, d_lines=d_lines,
+                              stream=torch_dev.cuda.current_stream().cuda_stream)
+            torch_dev.cuda.synchronize()
+            k = int(d_count[0])
+            got = np.sort(d_out.cpu().numpy()[:k])
+            assert np.array_equal(got, lines[want[lines]]), (name, k, int(want[lines].sum()))
+        o = OracleRegex(pat, ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2)
+        for v, w in zip(values[::5], want[::5]):
+            assert w or o.search(v) is None, (name, v)
+        rejected_total += int((~want).sum())
+    assert big >= 3 and rejected_total > 2500 and "dfa_screen_kernel" in B.launched_kernels()
+
+
 @pytest.mark.parametrize("name", ["HTTPD_ERRORLOG", "HAPROXYHTTP", "SYSLOGPAMSESSION", "NAGIOSLOGLINE"])
 def test_wide_table_patterns_against_the_oracle(torch_dev, golden_dir, name):
     """> 64 byte classes (4-word class masks), > 64 / > 128 capture slots (NS=128 / NS=320 kernels), run captures:
