@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <cstdio>
 #include <chrono>
@@ -1287,8 +1288,134 @@ size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
     const size_t m = n ? n : 1;
-    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 6 * alignUp(m * 4, 256) + 256;
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 6 * alignUp(m * 4, 256) + 256 + alignUp(m * 8, 256);
 }
+
+// ---- the literal index of a Match list (grok_kernel.hpp grok_literal_index_kernel): built the first time the list is seen,
+// kept per (literals, device) for the life of the process (a few hundred KB at most per distinct list)
+namespace {
+constexpr size_t kGrokLiteralBytes = 32;  // a longer literal is represented by its last 32 bytes (as the per-entry filter did)
+std::string grokLiteralOf(const lc_regex* re) {
+    const std::string& s = re->requiredLiteral;
+    return s.size() > kGrokLiteralBytes ? s.substr(s.size() - kGrokLiteralBytes) : s;
+}
+std::vector<uint32_t> buildGrokLiteralBlob(const std::vector<std::string>& lits) {
+    // byte classes: every byte that occurs in a literal is its own class, class 0 = everything else
+    std::vector<uint8_t> cmap(256, 0);
+    uint32_t ncls = 1;
+    for (const auto& l : lits)
+        for (unsigned char c : l)
+            if (!cmap[c]) cmap[c] = uint8_t(ncls++);
+    std::vector<unsigned> rep(ncls, 256);  // (class 0 has no representative: it leads to the root from everywhere)
+    for (unsigned b = 0; b < 256; ++b)
+        if (cmap[b]) rep[cmap[b]] = b;
+    // trie
+    std::vector<std::vector<int32_t>> go(1, std::vector<int32_t>(ncls, -1));
+    std::vector<uint64_t> out(1, 0);
+    uint64_t always = 0;
+    for (size_t p = 0; p < lits.size(); ++p) {
+        if (lits[p].empty()) {
+            always |= uint64_t(1) << p;
+            continue;
+        }
+        int32_t s = 0;
+        for (unsigned char c : lits[p]) {
+            const uint32_t k = cmap[c];
+            if (go[size_t(s)][k] < 0) {
+                go[size_t(s)][k] = int32_t(go.size());
+                go.emplace_back(ncls, -1);
+                out.push_back(0);
+            }
+            s = go[size_t(s)][k];
+        }
+        out[size_t(s)] |= uint64_t(1) << p;
+    }
+    // failure links, breadth first; goto completed into a DFA
+    const size_t nStates = go.size();
+    std::vector<int32_t> fail(nStates, 0), order;
+    for (uint32_t k = 0; k < ncls; ++k) {
+        if (go[0][k] < 0) go[0][k] = 0;
+        else order.push_back(go[0][k]);
+    }
+    for (size_t i = 0; i < order.size(); ++i) {
+        const int32_t s = order[i];
+        out[size_t(s)] |= out[size_t(fail[size_t(s)])];
+        for (uint32_t k = 0; k < ncls; ++k) {
+            const int32_t t = go[size_t(s)][k];
+            if (t < 0) {
+                go[size_t(s)][k] = go[size_t(fail[size_t(s)])][k];
+            } else {
+                fail[size_t(t)] = go[size_t(fail[size_t(s)])][k];
+                order.push_back(t);
+            }
+        }
+    }
+    if (nStates > 0x7FFF) return {};
+    std::vector<uint8_t> bytes(GL_HEADER_WORDS * 4 + 256, 0);
+    std::memcpy(bytes.data() + GL_HEADER_WORDS * 4, cmap.data(), 256);
+    auto append = [&](const void* p, size_t n) {
+        const size_t at = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(at + n);
+        std::memcpy(bytes.data() + at, p, n);
+        return uint32_t(at);
+    };
+    uint32_t hdr[GL_HEADER_WORDS] = {};
+    hdr[GL_NSTATES] = uint32_t(nStates);
+    hdr[GL_NCLASSES] = ncls;
+    hdr[GL_OFF_MASKS] = append(out.data(), out.size() * 8);
+    std::vector<uint16_t> table(nStates * ncls);
+    for (size_t s = 0; s < nStates; ++s)
+        for (uint32_t k = 0; k < ncls; ++k) {
+            const int32_t t = go[s][k];
+            table[s * ncls + k] = uint16_t(uint32_t(t) | (out[size_t(t)] ? 0x8000u : 0u));
+        }
+    hdr[GL_OFF_TABLE] = append(table.data(), table.size() * 2);
+    hdr[GL_ALWAYS_LO] = uint32_t(always);
+    hdr[GL_ALWAYS_HI] = uint32_t(always >> 32);
+    std::memcpy(bytes.data(), hdr, sizeof hdr);
+    bytes.resize((bytes.size() + 15) & ~size_t(15));
+    std::vector<uint32_t> blob(bytes.size() / 4);
+    std::memcpy(blob.data(), bytes.data(), bytes.size());
+    return blob;
+}
+struct GrokLiteralIndexCache {
+    std::mutex m;
+    std::map<std::pair<int, std::vector<std::string>>, void*> dev;  // (device, literals) -> device blob (nullptr: not indexable)
+};
+GrokLiteralIndexCache gGrokLiteralIndex;
+
+// device blob of the list's literal index, or nullptr (more than 64 entries, no literal at all, automaton too large)
+int grokLiteralIndex(const std::vector<GrokDevicePattern>& patterns, int dev, const uint32_t** out) {
+    *out = nullptr;
+    static const bool off = getenv("LC_GROK_NO_LITERAL_INDEX") != nullptr;
+    if (off || patterns.size() > 64) return LC_OK;
+    std::vector<std::string> lits;
+    size_t withLiteral = 0;
+    for (const auto& gp : patterns) {
+        lits.push_back(grokLiteralOf(gp.re));
+        withLiteral += !lits.back().empty();
+    }
+    if (withLiteral < 2) return LC_OK;
+    std::lock_guard<std::mutex> g(gGrokLiteralIndex.m);
+    auto key = std::make_pair(dev, lits);
+    auto it = gGrokLiteralIndex.dev.find(key);
+    if (it == gGrokLiteralIndex.dev.end()) {
+        void* p = nullptr;
+        const std::vector<uint32_t> blob = buildGrokLiteralBlob(lits);
+        if (!blob.empty()) {
+            HIP_TRY(hipMalloc(&p, blob.size() * 4));
+            const hipError_t e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(p);
+                return hipFail(e, "hipMemcpy(literal index)");
+            }
+        }
+        it = gGrokLiteralIndex.dev.emplace(std::move(key), p).first;
+    }
+    *out = static_cast<const uint32_t*>(it->second);
+    return LC_OK;
+}
+}  // namespace
 
 int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* d_data,
                       const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern, int32_t* d_first,
@@ -1323,9 +1450,20 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
     uint32_t *from = lists[0], *nmatch = lists[1], *tried = lists[2], *next = lists[3], *roundIn = lists[4],
              *roundOut = lists[5];
     uint32_t* counters = reinterpret_cast<uint32_t*>(base);
+    base += 256;
+    uint64_t* masks = reinterpret_cast<uint64_t*>(base);
 
     const uint32_t gridAll = (n + kGrokBlock - 1) / kGrokBlock;
     hipLaunchKernelGGL(grok_init_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, n, d_pattern, tried, from, nmatch);
+    // which Match entries' required literals each value contains: one pass for the whole list
+    const uint32_t* literalIndex = nullptr;
+    {
+        int rc = grokLiteralIndex(patterns, dev, &literalIndex);
+        if (rc != LC_OK) return rc;
+    }
+    if (literalIndex)
+        hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex,
+                           masks);
     HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
     HIP_TRY(hipMemsetAsync(counters, 0, 16, st));
 
@@ -1353,8 +1491,12 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             lit.len = uint32_t(std::min<size_t>(s.size(), sizeof lit.bytes));
             std::memcpy(lit.bytes, s.data() + (s.size() - lit.len), lit.len);
             const uint32_t perBlock = kGrokBlock / 64;
-            hipLaunchKernelGGL(grok_literal_filter_kernel, dim3((nTried + perBlock - 1) / perBlock), dim3(kGrokBlock), 0, st,
-                               tried, nTried, d_data, d_off, d_len, lit, outs[1], counters);
+            if (literalIndex)
+                hipLaunchKernelGGL(grok_mask_filter_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
+                                   nTried, masks, uint32_t(p), outs[1], counters);
+            else
+                hipLaunchKernelGGL(grok_literal_filter_kernel, dim3((nTried + perBlock - 1) / perBlock), dim3(kGrokBlock), 0, st,
+                                   tried, nTried, d_data, d_off, d_len, lit, outs[1], counters);
             HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             nIn = host[0];

@@ -67,6 +67,58 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_filter_kernel(const u
     if (__any(found) && lane == 0) out[atomicAdd(&counters[0], 1u)] = line;
 }
 
+// ---- all required literals in ONE pass.  50 Match entries used to mean 50 literal passes over the values still undecided
+// (10 % of a configs[2] step).  Instead: the Aho-Corasick automaton of all literals, as a DFA over byte classes with its table
+// in global memory (a few hundred states: L1/L2-resident), walked once per value, one value per lane; the result is a 64-bit
+// mask per value -- bit p = the value contains Match[p]'s literal (always set for entries without one) -- and each entry's
+// filter becomes a read of 8 bytes per value.
+// Blob (u32 words): GL_* header, class map u8[256], output masks u64[nStates], table u16[nStates][nClasses] whose bit 15 says
+// "the target state has an output" (so the mask table is touched only where a literal ends).
+enum { GL_NSTATES = 0, GL_NCLASSES = 1, GL_OFF_MASKS = 2, GL_OFF_TABLE = 3, GL_ALWAYS_LO = 4, GL_ALWAYS_HI = 5, GL_HEADER_WORDS = 8 };
+
+__global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                       const uint32_t* __restrict__ len, uint32_t n,
+                                                                       const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks) {
+    __shared__ uint8_t cmap[256];
+    cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
+    __syncthreads();
+    const uint32_t line = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (line >= n) return;
+    const uint32_t L = len[line], ncls = blob[GL_NCLASSES];
+    const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);
+    uint64_t mask = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + off[line];
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+    const uint32_t total = L ? head + L : 0;
+    uint32_t state = 0;
+    for (uint32_t pos = 0; pos < total; pos += 16) {
+        const uint4 v = *q++;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t bi = pos + j;
+            if (bi >= head && bi < total) {
+                const uint32_t e = table[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
+                state = e & 0x7FFFu;
+                if (e & 0x8000u) mask |= outMask[state];
+            }
+        }
+    }
+    masks[line] = mask;
+}
+
+// Match[bit]'s literal filter once the masks exist
+__global__ __launch_bounds__(kGrokBlock) void grok_mask_filter_kernel(const uint32_t* __restrict__ in, uint32_t nIn,
+                                                                     const uint64_t* __restrict__ masks, uint32_t bit,
+                                                                     uint32_t* __restrict__ out, uint32_t* __restrict__ counters) {
+    const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t line = in[k];
+    if ((masks[line] >> bit) & 1u) out[atomicAdd(&counters[0], 1u)] = line;
+}
+
 // Keeps the values whose screen search matched (status bytes written by the TDFA kernel for the values listed in `in`).
 __global__ __launch_bounds__(kGrokBlock) void grok_status_filter_kernel(const uint32_t* __restrict__ in, uint32_t nIn,
                                                                        const uint8_t* __restrict__ status,
