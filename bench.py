@@ -618,8 +618,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
-                    help="2: the headline (BASELINE configs[1]); 4: multi-tenant (configs[3]); 5: host-fed sharded corpus (configs[4])")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="2: the headline (BASELINE configs[1]); 3: Grok, 50 patterns (configs[2], = tools/grok_bench.py); "
+                         "4: multi-tenant (configs[3]); 5: host-fed sharded corpus (configs[4])")
     ap.add_argument("--lines", type=int, default=1 << 20, help="lines per batch per GPU")
     ap.add_argument("--line-bytes", type=int, default=512)
     ap.add_argument("--regex", choices=["A", "B"], default="A", help="A: 10-group doc regex, B: 11-group benchmark regex")
@@ -633,7 +634,13 @@ def main():
     ap.add_argument("--corpus-gb", type=float, default=10.0)
     ap.add_argument("--slab-mib", type=int, default=64)
     args = ap.parse_args()
-    if args.config == 4:
+    if args.config == 3:  # the Grok line has its own driver (parity gate against the Grok oracle, per-pattern engines)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import grok_bench
+        lines = args.lines if "--lines" in sys.argv else 1 << 18
+        sys.argv = [sys.argv[0], "--lines", str(lines), "--steps", str(min(args.steps, 5)), "--warmup", str(min(args.warmup, 1))]
+        grok_bench.main()
+    elif args.config == 4:
         run_multitenant(args)
     elif args.config == 5:
         run_sharded_corpus(args)

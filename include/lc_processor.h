@@ -48,7 +48,9 @@ enum {
                                          counted in out_failed_events_total too, like boost's complexity exception */
     LC_CNT_UNDECIDED_EVENTS = 10,     /* no reference counterpart: lines left LC_OVERFLOW because the decide pass was switched
                                          off; such events pass through untouched and are in NO other plugin counter */
-    LC_CNT_COUNT = 11
+    LC_CNT_DEVICE_FAILED_EVENTS = 11, /* no reference counterpart: events passed on UNPARSED because the device call of their group
+                                         failed in mid-run (there is no CPU path; lc_processor_process also returns the error) */
+    LC_CNT_COUNT = 12
 };
 
 /* config_json: the plugin's JSON object, e.g.

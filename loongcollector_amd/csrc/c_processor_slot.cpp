@@ -105,6 +105,7 @@ extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CN
     out[LC_CNT_PROCESS_TIME_US] = p->processUs;
     out[LC_CNT_COMPLEXITY_EXCEEDED] = p->impl.mComplexityExceededEventsTotal;
     out[LC_CNT_UNDECIDED_EVENTS] = p->impl.mUndecidedEventsTotal;
+    out[LC_CNT_DEVICE_FAILED_EVENTS] = p->impl.mDeviceFailedEventsTotal;
     return LC_OK;
 }
 

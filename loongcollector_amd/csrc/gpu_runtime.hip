@@ -172,7 +172,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
     if constexpr (!BYTEROWS) {
         if (!streamOff) kern = tdfa_stream_kernel<BLOCK, COMPACT, PAIR>;
         if constexpr (!PAIR) {
-            if (noGen) kern = tdfa_stream_kernel<BLOCK, COMPACT, false, kLabNoGeneral>;
+            if (noGen) kern = tdfa_stream_kernel<BLOCK, COMPACT, false, kTdfaNoGeneralPrograms>;
         }
     }
     static thread_local size_t ldsAttrSet[kLcMaxDevices][3] = {};  // the attribute belongs to (function, device)

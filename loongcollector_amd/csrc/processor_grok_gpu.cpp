@@ -1,6 +1,8 @@
 // processor_grok_gpu.cpp -- see processor_grok_gpu.hpp and include/lc_grok.h.
 #include "processor_grok_gpu.hpp"
 
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 
@@ -54,28 +56,57 @@ void ProcessorGrokGpu::Init() {
                                                                           // backtracks, so nothing can time out)
     std::map<std::string, uint32_t> keyIndex;
     uint32_t maxColumns = 0;
-    for (size_t i = 0; i < Match.size(); ++i) {                            // compileMatchs :335-359
-        mExpanded.push_back(mLibrary.denormalize(Match[i]));
+    // compileMatchs :335-359.  The entries are independent and each costs up to a second (the automata of a log format and
+    // of its two screens): they are compiled on the host's cores side by side, then booked in order.
+    struct Compiled {
         lc_regex_t* re = nullptr;
-        char err[512];
-        int rc = lc_regex_compile(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, LC_ENGINE_AUTO, &re, err,
-                                  sizeof err);
-        if (rc != LC_OK) throw GrokError("Match[" + std::to_string(i) + "] " + Match[i] + ": " + err);
-        mCompiled.push_back(re);
+        lc_regex* screen = nullptr;
+        lc_regex* relaxed = nullptr;
+        int rc = LC_OK;
+        std::string err;
+    };
+    for (size_t i = 0; i < Match.size(); ++i) mExpanded.push_back(mLibrary.denormalize(Match[i]));
+    static const bool noRelaxed = getenv("LC_GROK_NO_RELAXED") != nullptr;  // (A/B measurements)
+    auto compileOne = [this](size_t i) {
+        Compiled c;
+        char err[512] = "";
+        c.rc = lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, LC_ENGINE_AUTO, &c.re, err, sizeof err);
+        if (c.rc != LC_OK) {
+            c.err = err;
+            return c;
+        }
+        if (c.re->engine == LC_ENGINE_NFA) {
+            // patterns that run on the slow NFA kernel get a TDFA screen for their prefix when one is small enough ...
+            c.screen = lcCompilePrefixScreen(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, 1024, 32 * 1024);
+            // ... and one for the whole pattern, relaxed until it is small
+            if (!noRelaxed) c.relaxed = lcCompileRelaxedScreen(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, 20000, 2u << 20);
+        }
+        return c;
+    };
+    std::vector<Compiled> compiled(Match.size());
+    {
+        const size_t workers = std::max<size_t>(1, std::min<size_t>(Match.size(), std::min(16u, std::thread::hardware_concurrency())));
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        auto work = [&] {
+            for (size_t i = next.fetch_add(1); i < Match.size(); i = next.fetch_add(1)) compiled[i] = compileOne(i);
+        };
+        for (size_t w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    for (size_t i = 0; i < Match.size(); ++i) {  // everything that was compiled is owned from here on, whatever happens next
+        if (compiled[i].re) mCompiled.push_back(compiled[i].re);
+        mScreens.push_back(compiled[i].screen);
+        mScreens.push_back(compiled[i].relaxed);
+    }
+    for (size_t i = 0; i < Match.size(); ++i)
+        if (compiled[i].rc != LC_OK) throw GrokError("Match[" + std::to_string(i) + "] " + Match[i] + ": " + compiled[i].err);
+    for (size_t i = 0; i < Match.size(); ++i) {
+        lc_regex_t* re = compiled[i].re;
         const uint32_t columns = uint32_t(lc_regex_mark_count(re)) - 1;   // group 1 is the whole match
         maxColumns = std::max(maxColumns, columns);
-        // patterns that run on the slow NFA kernel get a TDFA screen for their prefix when one is small enough
-        lc_regex* screen = nullptr;
-        if (re->engine == LC_ENGINE_NFA)
-            screen = lcCompilePrefixScreen(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, 1024, 32 * 1024);
-        // ... and one for the whole pattern, relaxed until it is small (LC_GROK_NO_RELAXED: A/B measurements)
-        lc_regex* relaxed = nullptr;
-        static const bool noRelaxed = getenv("LC_GROK_NO_RELAXED") != nullptr;
-        if (re->engine == LC_ENGINE_NFA && !noRelaxed)
-            relaxed = lcCompileRelaxedScreen(mExpanded.back().data(), mExpanded.back().size(), kGrokSyntax, 20000, 2u << 20);
-        mScreens.push_back(screen);
-        mScreens.push_back(relaxed);
-        mDevice.push_back({re, columns, screen, relaxed});
+        mDevice.push_back({re, columns, compiled[i].screen, compiled[i].relaxed});
         std::vector<uint32_t> colKey(columns, kNoKey);
         std::vector<MergedField> fields;
         std::map<std::string, size_t> byName;

@@ -247,6 +247,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             std::fprintf(stderr, "[%s] GPU match failed (rc=%d: %s); %u events left unparsed\n", sName.c_str(), rc,
                          lc_last_error(), nLines);
             deviceOk = false;
+            mDeviceFailedEventsTotal += nLines;
         }
     }
 

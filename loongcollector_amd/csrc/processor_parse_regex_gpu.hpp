@@ -62,6 +62,7 @@ public:
     // no reference counterpart: lines the decide kernel gave up on (boost would have thrown its complexity exception; they
     // are parse failures too) and lines left undecided because the decide pass was switched off (kept untouched)
     std::atomic<uint64_t> mComplexityExceededEventsTotal{0}, mUndecidedEventsTotal{0};
+    std::atomic<uint64_t> mDeviceFailedEventsTotal{0};  // events passed on unparsed because the device call of their group failed
     std::vector<std::string> mInitWarnings;
     int mEngineChoice = LC_ENGINE_AUTO;  // test hook: force a device engine
 

@@ -76,7 +76,8 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Measurement variants (tools/tdfa_lab.hip instantiates them; the product only ever instantiates LAB = 0).  They answer "what
+// Measurement variants (tools/tdfa_lab.hip instantiates them; the product instantiates LAB = 0 and, for tables that carry no
+// general register program at all -- device_tables.h TD_NREGS_NO_GENERAL --, kTdfaNoGeneralPrograms).  They answer "what
 // does each of the three LDS instructions per byte cost" on the real kernel instead of a model of it:
 //   kLabNoStamp    phase 2 is skipped (capture offsets come out wrong: timing only)
 //   kLabPreClass   the input bytes ARE column offsets already (host pre-classified copy of the corpus): no class lookup
@@ -86,8 +87,9 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 //   kLabNoOutput / kLabNoLoop (tdfa_stream_kernel only): skip the capture-table write / the stage loop -- what a workgroup's
 //                  fixed costs are (line table reads, first loads, table staging, result write)
 //   kLabNoGeneral  (tdfa_stream_kernel only): no check for general register programs (wrong for tables that have one on the
-//                  walked path): what the check costs
+//                  walked path): what the check costs -- and what tables without such programs need not pay
 enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32, kLabNoGeneral = 64 };
+constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 
 // general register program (a list of moves); rare for log regexes
 // Column of a lane in the register file.  32-bit registers: the lane itself (a wavefront's lanes hit 32 banks twice over, one

@@ -7,7 +7,8 @@ from . import binding
 
 COUNTER_NAMES = ["discarded_events_total", "out_failed_events_total", "out_key_not_found_events_total",
                  "out_successful_events_total", "in_events_total", "out_events_total", "in_size_bytes",
-                 "out_size_bytes", "total_process_time_us", "complexity_exceeded_events_total", "undecided_events_total"]
+                 "out_size_bytes", "total_process_time_us", "complexity_exceeded_events_total", "undecided_events_total",
+                 "device_failed_events_total"]
 
 
 class LcColumnar(ctypes.Structure):
