@@ -128,7 +128,9 @@ enum {
     LC_TABLE_TDFA_STARTAFTER = 8, /* u32[classes]: search patterns only -- state a resumed search starts in, by the class
                                     of the byte before the resume point (lc_regex_match_device_from) */
     LC_TABLE_TDFA_BLOB = 9,      /* the packed TDFA tables uploaded to the device (csrc/device_tables.h) */
-    LC_TABLE_TDFA_WIDE_BLOB = 10 /* small automata only: the same with byte-indexed rows, for the 1024-lane kernel */
+    LC_TABLE_TDFA_WIDE_BLOB = 10, /* small automata only: the same with byte-indexed rows, for the 1024-lane kernel */
+    LC_TABLE_TDFA_L2_BLOB = 11   /* automata too large for the LDS kernels: the tables as the global-memory kernel reads them
+                                    (csrc/tdfa_l2_layout.h); such a handle has no LC_TABLE_TDFA_BLOB */
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 

@@ -22,7 +22,7 @@ LC_SYNTAX_PREFIX = 128
 
 (LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
  LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB, LC_TABLE_TDFA_STARTAFTER, LC_TABLE_TDFA_BLOB,
- LC_TABLE_TDFA_WIDE_BLOB) = range(11)
+ LC_TABLE_TDFA_WIDE_BLOB, LC_TABLE_TDFA_L2_BLOB) = range(12)
 
 
 class LcRegexInfo(ctypes.Structure):

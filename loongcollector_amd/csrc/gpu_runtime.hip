@@ -34,6 +34,7 @@
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
 #include "screen_kernel.hpp"
+#include "tdfa_l2_kernel.hpp"
 #include "split_kernel.hpp"
 #include "tdfa_stream_kernel.hpp"
 
@@ -97,16 +98,18 @@ extern "C" int lc_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ device tables
-enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3 };
+enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3, kBlobTdfaL2 = 4 };
 static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     std::lock_guard<std::mutex> g(re->deviceMutex);
     void** slot = which == kBlobTdfa ? &re->dTdfaBlob[dev]
                   : which == kBlobTdfaWide ? &re->dTdfaWideBlob[dev]
-                  : which == kBlobScreen ? &re->dScreenBlob[dev] : &re->dNfaBlob[dev];
+                  : which == kBlobScreen ? &re->dScreenBlob[dev]
+                  : which == kBlobTdfaL2 ? &re->dTdfaL2Blob[dev] : &re->dNfaBlob[dev];
     if (!*slot) {
         const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob
                                             : which == kBlobTdfaWide ? re->tdfaWideBlob
-                                            : which == kBlobScreen ? re->screenBlob : re->nfaBlob;
+                                            : which == kBlobScreen ? re->screenBlob
+                                            : which == kBlobTdfaL2 ? re->tdfaL2Blob : re->nfaBlob;
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, blob.size() * 4 + 16));  // + one word behind the tables: the compact kernel's long-line flag
         hipError_t e = hipMemset(p, 0, blob.size() * 4 + 16);
@@ -125,14 +128,15 @@ void lcReleaseDeviceTables(lc_regex* re) {
     int cur = 0;
     bool haveCur = hipGetDevice(&cur) == hipSuccess;
     for (int d = 0; d < kLcMaxDevices; ++d) {
-        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d]) {
+        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d] || re->dTdfaL2Blob[d]) {
             if (hipSetDevice(d) == hipSuccess) {
+                if (re->dTdfaL2Blob[d]) (void)hipFree(re->dTdfaL2Blob[d]);
                 if (re->dScreenBlob[d]) (void)hipFree(re->dScreenBlob[d]);
                 if (re->dTdfaBlob[d]) (void)hipFree(re->dTdfaBlob[d]);
                 if (re->dTdfaWideBlob[d]) (void)hipFree(re->dTdfaWideBlob[d]);
                 if (re->dNfaBlob[d]) (void)hipFree(re->dNfaBlob[d]);
             }
-            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = re->dScreenBlob[d] = nullptr;
+            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = re->dScreenBlob[d] = re->dTdfaL2Blob[d] = nullptr;
         }
     }
     if (haveCur) (void)hipSetDevice(cur);
@@ -593,7 +597,23 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int rc;
     if (!re->nfa.runGroups.empty()) tlsDone.armed = false;  // run_capture_kernel runs behind the match: it cannot signal
-    if (engine == LC_ENGINE_TDFA) {
+    if (engine == LC_ENGINE_TDFA && !re->hasTdfa && !re->tdfaL2Blob.empty()) {
+        // the automaton is too large for the LDS kernels: tables in global memory, one line per lane (tdfa_l2_kernel.hpp)
+        void* dBlob = nullptr;
+        rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
+        if (rc != LC_OK) return rc;
+        const size_t lds = size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
+        static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
+        if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > ldsAttrSet[dev]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            ldsAttrSet[dev] = lds;
+        }
+        noteKernel("tdfa_l2_kernel");
+        // (no completion signal of its own: a caller that polls queues lc_signal_kernel behind it, see tlsDone)
+        hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
+                           d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status);
+        HIP_TRY(hipGetLastError());
+    } else if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;
             return LC_ERR_UNSUPPORTED;

@@ -13,6 +13,7 @@
 
 #include "device_tables.h"
 #include "screen_kernel_layout.h"
+#include "tdfa_l2_layout.h"
 
 namespace lcregex {
 
@@ -283,6 +284,28 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
     if (!anyGeneral) hdr[TD_NREGS] |= TD_NREGS_NO_GENERAL;
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(TD_TOTAL_BYTES);
+}
+
+// tdfa_l2_layout.h: the logical tables as they are, one after the other
+std::vector<uint32_t> packTdfaL2Blob(const TdfaTables& t) {
+    BlobWriter w;
+    w.reserve(TL_HEADER_WORDS * 4);
+    w.put(t.classMap);
+    uint32_t hdr[TL_HEADER_WORDS] = {};
+    hdr[TL_MAGIC] = TL_MAGIC_VALUE;
+    hdr[TL_NSTATES] = t.nStates;
+    hdr[TL_NCLASSES] = t.nClasses;
+    hdr[TL_NREGS] = t.nRegs;
+    hdr[TL_NSLOTS] = t.nSlots;
+    hdr[TL_START] = t.startState;
+    hdr[TL_OFF_TRANS] = w.put(t.trans);
+    hdr[TL_OFF_OPSSTART] = w.put(t.opsStart);
+    hdr[TL_OFF_OPS] = w.put(t.ops);
+    hdr[TL_OFF_FINALID] = w.put(t.finalId);
+    hdr[TL_OFF_FINALMAP] = w.put(t.finalMap);
+    if (!t.startAfter.empty()) hdr[TL_OFF_STARTAFTER] = w.put(t.startAfter);
+    std::memcpy(w.bytes.data(), hdr, sizeof hdr);
+    return w.finish(TL_TOTAL_BYTES);
 }
 
 std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& classMapOut) {
@@ -1021,11 +1044,41 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                   re->tdfa.startState, 0, 0, 0};
             } catch (const RegexError& e) {
-                if (engine == LC_ENGINE_TDFA) throw;
                 re->tdfaError = e.what();
+                // Too large for the LDS kernels: the same automaton with its tables in global memory (tdfa_l2_kernel.hpp), as
+                // long as it stays a few MB -- still one line per lane, two orders of magnitude faster than the NFA kernel.
+                static const uint32_t l2States = [] {
+                    const char* v = getenv("LC_TDFA_L2_MAX_STATES");
+                    return uint32_t(v ? atoi(v) : 32768);
+                }();
+                bool l2 = false;
+                // (a construction that ran out of WORK would run out of it again; one that ran out of states is redone with
+                // the larger bound; a table that was built and only failed to pack -- byte classes, registers -- is kept)
+                const bool outOfWork = re->tdfaError.find("work limit") != std::string::npos;
+                const bool outOfStates = re->tdfaError.find("state limit") != std::string::npos;
+                if (l2States && !outOfWork) {
+                    try {
+                        if (outOfStates || re->tdfa.nStates == 0) {
+                            TdfaLimits lim;
+                            lim.maxStates = l2States;
+                            lim.ldsWindow = false;
+                            lim.maxPathWork = 4u << 20;
+                            re->tdfa = buildTdfa(re->nfa, lim);
+                        }
+                        const size_t tableBytes = size_t(re->tdfa.nStates) * re->tdfa.nClasses * 4;
+                        if (tableBytes <= (size_t(16) << 20) && size_t(re->tdfa.nRegs) * 64 * 4 <= 64 * 1024) {
+                            re->tdfaL2Blob = packTdfaL2Blob(re->tdfa);
+                            re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
+                                              re->tdfa.startState, 0, 0, 0};
+                            l2 = true;
+                        }
+                    } catch (const RegexError&) {
+                    }
+                }
+                if (!l2 && engine == LC_ENGINE_TDFA) throw RegexError(re->tdfaError);
             }
         }
-        if (re->hasTdfa) {
+        if (re->hasTdfa || !re->tdfaL2Blob.empty()) {
             re->engine = LC_ENGINE_TDFA;
         } else {
             re->engine = LC_ENGINE_NFA;
@@ -1083,11 +1136,12 @@ extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     out->engine = re->engine;
     out->mark_count = re->nfa.groupCount;
     out->positions = uint32_t(re->nfa.positions.size());
-    const bool tables = re->hasTdfa || !re->screenBlob.empty();
+    const bool tables = re->hasTdfa || !re->screenBlob.empty() || !re->tdfaL2Blob.empty();
     out->states = tables ? re->tdfa.nStates : 0;
     out->classes = tables ? re->tdfa.nClasses : (re->nfaBlob.empty() ? 0 : re->nfaBlob[NF_NCLASSES]);
     out->registers = tables ? re->tdfa.nRegs : 0;
     out->table_bytes = uint32_t((!re->screenBlob.empty() ? re->screenBlob.size()
+                                 : !re->tdfaL2Blob.empty() ? re->tdfaL2Blob.size()
                                  : re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
     return LC_OK;
 }
@@ -1122,9 +1176,13 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
         if (re->nfaBlob.empty()) return LC_ERR_ARG;
         return view(re->nfaBlob.data(), re->nfaBlob.size() * 4);
     }
-    if (!re->hasTdfa && re->screenBlob.empty()) return LC_ERR_ARG;  // (a screen handle shows its logical tables too)
+    if (!re->hasTdfa && re->screenBlob.empty() && re->tdfaL2Blob.empty()) return LC_ERR_ARG;  // (logical tables: all three)
     const TdfaTables& t = re->tdfa;
     if ((which == LC_TABLE_TDFA_BLOB || which == LC_TABLE_TDFA_WIDE_BLOB) && !re->hasTdfa) return LC_ERR_ARG;
+    if (which == LC_TABLE_TDFA_L2_BLOB) {
+        if (re->tdfaL2Blob.empty()) return LC_ERR_ARG;
+        return view(re->tdfaL2Blob.data(), re->tdfaL2Blob.size() * 4);
+    }
     switch (which) {
         case LC_TABLE_CLASSMAP: return view(t.classMap.data(), t.classMap.size());
         case LC_TABLE_TDFA_TRANS: return view(t.trans.data(), t.trans.size() * 4);

@@ -28,6 +28,8 @@ struct lc_regex {
     std::vector<uint32_t> tdfaWideBlob; // tables of the COMPACT kernel variant (16-bit offset registers), or empty
     int tdfaWideBlock = 0;              // its workgroup size: 256 / 512 (class-indexed rows) or 1024 (byte-indexed rows)
     bool tdfaWideForced = false;        // LC_TDFA_COMPACT was set: use it for every batch, not only for large ones
+    std::vector<uint32_t> tdfaL2Blob;   // tdfa_l2_layout.h: the tagged DFA with its tables in global memory, when `tdfa` is too large
+                                        // for the LDS kernels (then hasTdfa is false and tdfaBlob empty) and small enough for L2
     std::vector<uint32_t> screenBlob;   // screen_kernel.hpp layout: a yes/no DFA too large for LDS (relaxed screens), or empty
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
     std::vector<uint8_t> nfaClassMap;
@@ -44,6 +46,7 @@ struct lc_regex {
     std::atomic<uint32_t> tdfaWideSeq[kLcMaxDevices] = {};  // launch sequence numbers of the compact kernel (its long-line flag)
     void* dNfaBlob[kLcMaxDevices] = {};
     void* dScreenBlob[kLcMaxDevices] = {};
+    void* dTdfaL2Blob[kLcMaxDevices] = {};
 };
 
 namespace lcregex {

@@ -1,0 +1,95 @@
+// tdfa_l2_kernel.hpp -- the tagged DFA for automata that do not fit the 64 KiB LDS window: tables in global memory (L2).
+//
+// The LDS kernels (tdfa_stream_kernel.hpp) take automata of up to a few hundred states.  Past that a pattern used to fall to the
+// thread-list NFA kernel, which is two orders of magnitude slower per byte (one line per WAVEFRONT, several dependent table
+// reads per byte-step).  Most such automata are not large by any other measure -- 1 000 to 30 000 states, 0.2 to 8 MB of
+// transitions, which an L2 of 4 MB per XCD and the 256 MB Infinity Cache keep close.  So: one line per lane as before, the state
+// walk reads  trans[state][class]  from global memory (one dependent L2 access per byte), register programs are interpreted
+// from their lists, the offset registers of the 64 lines of a workgroup sit in LDS.  Per line that is slow (~0.3 us a byte);
+// in aggregate every line of the batch is in flight at once (dfa_screen_kernel, the same walk without registers: 184 GB/s).
+// Semantics: exactly the logical tables (tdfa.hpp), i.e. what tests/helpers/table_interp.py TdfaInterp walks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/lc_regex_gpu.h"
+#include "device_tables.h"
+#include "tdfa_l2_layout.h"
+
+constexpr int kTdfaL2Block = 64;
+
+// order (optional): the lines to look at; resume (optional, indexed by line): offset a search resumes at.
+// Dynamic LDS: (nRegs) * 64 * 4 bytes of offset registers.
+__global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                               const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                               const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
+                                                               uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                                               uint8_t* __restrict__ status) {
+    extern __shared__ uint32_t regs[];  // [nRegs][64]
+    __shared__ uint8_t cmap[256];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 256; i += kTdfaL2Block) cmap[i] = reinterpret_cast<const uint8_t*>(blob + TL_HEADER_WORDS)[i];
+    const uint32_t nRegs = blob[TL_NREGS], ncls = blob[TL_NCLASSES], nSlots = blob[TL_NSLOTS];
+    for (uint32_t r = 0; r < nRegs; ++r) regs[r * kTdfaL2Block + tid] = 0xFFFFFFFFu;  // unset = -1
+    __syncthreads();
+    if (nLinesPtr) nLines = *nLinesPtr < nLines ? *nLinesPtr : nLines;
+    const uint32_t slot = blockIdx.x * kTdfaL2Block + tid;
+    if (slot >= nLines) return;
+    const uint32_t line = order ? order[slot] : slot;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
+    const uint32_t* trans = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_TRANS]);
+    const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
+    const uint16_t* ops = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
+    const uint32_t o = off[line];
+    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    uint32_t state = blob[TL_START], from = 0;
+    if (resume) {
+        from = resume[line];
+        from = from < L ? from : L;
+        if (from) state = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_STARTAFTER])[cmap[data[size_t(o) + from - 1]]];
+    }
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o + from;
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+    const uint32_t total = L > from ? head + (L - from) : 0;
+    for (uint32_t p0 = 0; p0 < total && state != 0; p0 += 16) {
+        const uint4 v = *q++;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t bi = p0 + j;
+            if (bi >= head && bi < total && state != 0) {
+                const uint32_t t = trans[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
+                const uint32_t prog = t >> 16;
+                if (prog) {
+                    const uint32_t pos = from + (bi - head);  // offset inside the line
+                    uint32_t at = opsStart[prog];
+                    const uint32_t n = ops[at];
+                    for (uint32_t k = 0; k < n; ++k) {
+                        const uint32_t op = ops[++at];
+                        const uint32_t src = op >> 8;
+                        regs[(op & 0xFFu) * kTdfaL2Block + tid] = src == TD_REG_POS ? pos : regs[src * kTdfaL2Block + tid];
+                    }
+                }
+                state = t & 0xFFFFu;
+            }
+        }
+    }
+    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_FINALID]);
+    const uint8_t* finalMap = base + blob[TL_OFF_FINALMAP];
+    const uint32_t fid = state ? uint32_t(finalId[state]) : 0xFFFFu;
+    const bool matched = fid != 0xFFFFu;
+    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
+    for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) {
+        int32_t val = -1;
+        if (matched && s < nSlots) {
+            const uint32_t m = finalMap[fid * nSlots + s];
+            if (m == TD_REG_POS) val = int32_t(L);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m * kTdfaL2Block + tid]);
+        }
+        out[s] = val;
+    }
+    status[line] = matched ? LC_MATCH : LC_NOMATCH;
+}

@@ -1,0 +1,20 @@
+// tdfa_l2_layout.h -- blob of a tagged DFA whose tables stay in global memory (tdfa_l2_kernel.hpp); shared with the host packer.
+#pragma once
+enum {
+    TL_MAGIC = 0,          // 'TDL2'
+    TL_NSTATES = 1,
+    TL_NCLASSES = 2,
+    TL_NREGS = 3,          // offset registers per line
+    TL_NSLOTS = 4,
+    TL_START = 5,
+    TL_OFF_TRANS = 6,      // byte offsets from the start of the blob: u32[nStates][nClasses], low16 = next state (0 = dead),
+                           //   high16 = register program (0 = none)
+    TL_OFF_OPSSTART = 7,   // u32[programs + 1]
+    TL_OFF_OPS = 8,        // u16[]: per program n, then n words dst | src << 8 (src 0xFF = the current offset)
+    TL_OFF_FINALID = 9,    // u16[nStates], 0xFFFF = not accepting
+    TL_OFF_FINALMAP = 10,  // u8[finals][nSlots]: register | 0xFF = end of line | 0xFE = unset
+    TL_OFF_STARTAFTER = 11, // u32[nClasses] or 0: state a resumed search starts in, by the class of the byte before
+    TL_TOTAL_BYTES = 12,
+    TL_HEADER_WORDS = 16   // the class map (u8[256]) follows the header
+};
+#define TL_MAGIC_VALUE 0x324C4454u

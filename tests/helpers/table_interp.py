@@ -209,3 +209,52 @@ class TdfaBlobInterp:
             m = int(self.final_map[fid * self.nslots + sl])
             caps.append(len(s) if m == 0xFF else -1 if m == 0xFE else regs.get(m, -1) + start)
         return caps
+
+
+class TdfaL2BlobInterp:
+    """Walks the blob of the global-memory TDFA kernel (csrc/tdfa_l2_layout.h) exactly as tdfa_l2_kernel does: automata too
+    large for the LDS kernels."""
+
+    def __init__(self, rx):
+        blob = rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32)
+        assert blob is not None
+        raw = blob.view(np.uint8)
+        (magic, self.nstates, self.ncls, self.nregs, self.nslots, self.start, o_trans, o_opsstart, o_ops, o_finalid, o_finalmap,
+         o_after, total) = [int(x) for x in blob[:13]]
+        assert magic == 0x324C4454 and total == blob.nbytes
+        self.cmap = raw[64:320]
+        self.trans = blob[o_trans // 4:o_trans // 4 + self.nstates * self.ncls]
+        self.ops_start = blob[o_opsstart // 4:]
+        self.ops = raw[o_ops:o_ops + (o_finalid - o_ops) // 2 * 2].view(np.uint16)
+        self.final_id = raw[o_finalid:o_finalid + 2 * self.nstates].view(np.uint16)
+        self.final_map = raw[o_finalmap:]
+        self.start_after = blob[o_after // 4:o_after // 4 + self.ncls] if o_after else None
+        self.runs = rx.run_captures()
+        self.compact = False
+
+    @_with_run_captures
+    def fullmatch(self, s: bytes, start=0):
+        state = self.start if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]])])
+        regs = [-1] * max(self.nregs, 1)
+        for pos in range(start, len(s)):
+            t = int(self.trans[state * self.ncls + int(self.cmap[s[pos]])])
+            if t >> 16:
+                at = int(self.ops_start[t >> 16])
+                for w in self.ops[at + 1:at + 1 + int(self.ops[at])]:
+                    regs[int(w) & 0xFF] = pos if int(w) >> 8 == 0xFF else regs[int(w) >> 8]
+            state = t & 0xFFFF
+            if state == 0:
+                return None
+        fid = int(self.final_id[state])
+        if fid == 0xFFFF:
+            return None
+        out = []
+        for sl in range(self.nslots):
+            m = int(self.final_map[fid * self.nslots + sl])
+            out.append(len(s) if m == 0xFF else (-1 if m == 0xFE else regs[m]))
+        return out
+
+
+def packed_tdfa_interp(rx):
+    """the interpreter of whichever packed TDFA tables the handle carries: LDS kernels, or the global-memory kernel"""
+    return TdfaBlobInterp(rx) if rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32) is not None else TdfaL2BlobInterp(rx)

@@ -102,7 +102,7 @@ def test_random_patterns_with_run_captures_and_packed_blobs():
     ones."""
     import numpy as np
 
-    from tests.helpers.table_interp import TdfaBlobInterp
+    from tests.helpers.table_interp import TdfaBlobInterp, packed_tdfa_interp
     runs = [r"(?=(.*))", r"(?=([a-c]*))", r"(?=(?:([^ ]*)))", r"(?=(\w*))"]
     rng = random.Random(77003)
     g = gen.Gen(rng)
@@ -130,7 +130,7 @@ def test_random_patterns_with_run_captures_and_packed_blobs():
             with_runs += bool(rx.run_captures())
             interps = [AtomicNfaInterp(rx)] if rx.has_nfa_program() else []
             if rx.info()["engine"] == B.LC_ENGINE_TDFA:
-                interps += [TdfaInterp(rx), TdfaBlobInterp(rx)]
+                interps += [TdfaInterp(rx), packed_tdfa_interp(rx)]
                 if rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None:
                     interps.append(TdfaBlobInterp(rx, compact=True))
             subjects = [gen.mutate(rng, smp()) for _ in range(4)] + [gen.rand_subject(rng) for _ in range(3)]

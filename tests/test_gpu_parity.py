@@ -534,6 +534,72 @@ def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
                         pattern, eng, lines[i][:80], int(start[i]), list(caps[i]), exp)
 
 
+def test_automata_too_large_for_lds_run_from_global_memory(torch_dev):
+    """tdfa_l2_kernel: a tagged DFA of 1 000+ states (beyond the 64 KiB LDS window of the lane-per-line kernels) keeps its
+    tables in global memory and still runs one line per lane instead of falling to the NFA engine.  Full match in both input
+    forms, and a search with a listed subset of lines and resume offsets, against the oracle."""
+    rng = random.Random(99)
+    full = rb"(?:a|b)*a(?:a|b){12}(c+)(d*)"
+    rx = B.GpuRegex(full)
+    info = rx.info()
+    assert info["engine"] == B.LC_ENGINE_TDFA and info["states"] > 1000 and rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32) is None
+    assert rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32) is not None
+    def subject():
+        head = bytes(rng.choice(b"ab") for _ in range(rng.randint(0, 300)))
+        return head + rng.choice([b"", b"c", b"ccc", b"cd", b"ccddd", b"x", b"cdc"])
+    subs = [subject() for _ in range(3000)] + [b"", b"a" * 10 + b"c", b"ab" * 2000 + b"a" + b"b" * 12 + b"cccd"]
+    data, off, length = pack(subs)
+    o = OracleRegex(full)
+    exp_caps, exp_status = o.fullmatch_batch(data, off, length)
+    B.launched_kernels()
+    caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+    assert "tdfa_l2_kernel" in B.launched_kernels()
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps) and 100 < exp_status.sum() < len(subs) - 100
+    sep_data = np.frombuffer(b"\n".join(subs) + b"\n", dtype=np.uint8)
+    sep_off = np.zeros(len(subs) + 1, dtype=np.uint32)
+    sep_off[1:] = np.cumsum(length.astype(np.uint64) + 1).astype(np.uint32)
+    caps2, status2 = run_device(torch_dev, rx, sep_data, sep_off, None, sep=1)
+    assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps)
+    # search, subset of lines, resumed inside the line
+    spat = rb"a(?:a|b){11}(c+)"
+    srx = B.GpuRegex(spat, syntax_flags=B.LC_SYNTAX_SEARCH)
+    assert srx.info()["engine"] == B.LC_ENGINE_TDFA and srx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32) is not None
+    so = OracleRegex(spat)
+    torch = torch_dev
+    dev = torch.device("cuda:0")
+    n = len(subs)
+    pad = np.zeros(len(data) + 16, dtype=np.uint8)
+    pad[:len(data)] = data
+    d_data = torch.from_numpy(pad).to(dev)
+    d_off = torch.from_numpy(off.view(np.int32).copy()).to(dev)
+    d_len = torch.from_numpy(length.view(np.int32).copy()).to(dev)
+    subset = np.array(sorted(rng.sample(range(n), 700)), dtype=np.uint32)
+    start = np.zeros(n, dtype=np.uint32)
+    for i in subset:
+        L = int(length[i])
+        start[i] = rng.choice([0, 0, 1, L // 2, max(0, L - 3), L, min(L, 17)])
+    d_sub = torch.from_numpy(subset.view(np.int32).copy()).to(dev)
+    d_from = torch.from_numpy(start.view(np.int32).copy()).to(dev)
+    G = srx.groups
+    d_caps = torch.full((n, 2 * G), -7, dtype=torch.int32, device=dev)
+    d_status = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    srx.match_device_from(d_data, d_off, d_len, len(subset), d_caps, d_status, d_lines=d_sub, d_from=d_from, engine=B.LC_ENGINE_TDFA)
+    torch.cuda.synchronize()
+    caps, status = d_caps.cpu().numpy(), d_status.cpu().numpy()
+    touched = np.zeros(n, dtype=bool)
+    touched[subset] = True
+    assert (status[~touched] == 9).all() and (caps[~touched] == -7).all()
+    hits = 0
+    for i in subset:
+        exp = so.search(subs[i], int(start[i]))
+        if exp is None:
+            assert status[i] == B.LC_NOMATCH, (i, int(start[i]))
+        else:
+            hits += 1
+            assert status[i] == B.LC_MATCH and list(caps[i]) == [v for ab in exp for v in ab], (subs[i][-40:], int(start[i]))
+    assert hits > 50
+
+
 def test_random_atomic_patterns_on_both_kernels(torch_dev):
     """Fresh random patterns with atomic groups / possessive quantifiers / look assertions (not the committed golden set),
     full-match and search, TDFA and NFA kernels against the oracle."""

@@ -231,7 +231,7 @@ def test_packed_tdfa_blobs_walk_like_the_logical_tables(golden_dir, monkeypatch,
     """device_tables.h as the kernels address it: the standard blob (class-indexed rows, 32-bit registers) and the tables of
     the opt-in COMPACT kernel variants (16-bit registers; 1024 = byte-indexed rows, small automata only) against the
     logical-table interpreter."""
-    from tests.helpers.table_interp import TdfaBlobInterp
+    from tests.helpers.table_interp import TdfaBlobInterp, packed_tdfa_interp
     monkeypatch.setenv("LC_TDFA_COMPACT", compact)
     with open(os.path.join(golden_dir, "regex_golden.json")) as f:
         golden = json.load(f)
@@ -242,7 +242,7 @@ def test_packed_tdfa_blobs_walk_like_the_logical_tables(golden_dir, monkeypatch,
         except B.RegexUnsupportedError:
             continue
         ref = TdfaInterp(rx)
-        interps = [TdfaBlobInterp(rx)]
+        interps = [packed_tdfa_interp(rx)]
         if rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None:
             wide += 1
             interps.append(TdfaBlobInterp(rx, compact=True))
