@@ -36,6 +36,11 @@ typedef struct lc_grok_result lc_grok_result_t;
  * "cannot build patterns because cyclic exist...", "Match[3]: tdfa: state limit exceeded; nfa: ..."). */
 int lc_grok_create(const char* config_json, size_t config_len, lc_grok_t** out, char* err, size_t errcap);
 void lc_grok_free(lc_grok_t* g);
+/* Entries that run on the NFA engine also get an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX: a tagged DFA with its tables
+ * in L2), tried first on every value -- log formats match from the first byte.  Those automata take seconds to build, so they are
+ * compiled behind lc_grok_create on a warm-up thread and join the matcher as they arrive; results never depend on them.  This call
+ * returns once the thread is done (benchmarks; tests that want to pin which path runs).  Config key "AnchoredFirst": false = none. */
+void lc_grok_wait_ready(lc_grok_t* g);
 
 int lc_grok_match_count(const lc_grok_t* g);                       /* len(Match) */
 const char* lc_grok_expanded(const lc_grok_t* g, int i);           /* Match[i] after denormalizePattern (:282-316) */

@@ -54,7 +54,11 @@ enum {
                                            match_continuous, what the multiline splitter asks per line for its start /
                                            continue / end patterns (StringTools.cpp:263-289 called from
                                            ProcessorSplitMultilineLogStringNative.cpp:184-272).  Compiled as (re)(?s:.*);
-                                           captures of the leftmost-first prefix match are reported as usual */
+                                           captures of the leftmost-first prefix match are reported as usual.
+                                           Together with LC_SYNTAX_SEARCH: the ANCHORED search -- the match must start at
+                                           the first byte, groups as in a search (group 1 = the whole match).  It finds what
+                                           the search finds whenever the search's leftmost match starts at byte 0, from a
+                                           far smaller automaton (no "anywhere" prefix): the Grok matcher tries it first */
     LC_SYNTAX_REGEXP2 = 1u << 6         /* escape dialect of github.com/dlclark/regexp2 with the RE2 option (Go Grok,
                                            processor_grok.go:343): \s = [\t\n\f\r ]; \< \> \` \' are literals */
 };

@@ -1308,7 +1308,7 @@ size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
     const size_t m = n ? n : 1;
-    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 6 * alignUp(m * 4, 256) + 256 + alignUp(m * 8, 256);
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 256 + alignUp(m * 8, 256);
 }
 
 // ---- the literal index of a Match list (grok_kernel.hpp grok_literal_index_kernel): built the first time the list is seen,
@@ -1462,13 +1462,13 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
     base += alignUp(size_t(n) * row * 4, 256);
     uint8_t* status = base;
     base += alignUp(n, 256);
-    uint32_t* lists[6];
+    uint32_t* lists[7];
     for (auto& l : lists) {
         l = reinterpret_cast<uint32_t*>(base);
         base += alignUp(size_t(n) * 4, 256);
     }
     uint32_t *from = lists[0], *nmatch = lists[1], *tried = lists[2], *next = lists[3], *roundIn = lists[4],
-             *roundOut = lists[5];
+             *roundOut = lists[5], *unanchored = lists[6];
     uint32_t* counters = reinterpret_cast<uint32_t*>(base);
     base += 256;
     uint64_t* masks = reinterpret_cast<uint64_t*>(base);
@@ -1550,16 +1550,57 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
         }
         // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
         const uint32_t capsRow = 2 * (gp.columns + 1);
+        // one search round over the values listed in `list`: the pattern's kernel, then grok_advance_kernel (matches recorded,
+        // values that stay in play appended to `out`, their number added to counters[0])
+        auto searchRound = [&](lc_regex* re, const uint32_t* list, uint32_t nList, const uint32_t* resume, uint32_t* out) -> int {
+            int rc = lcMatchOnStream(re, re->engine, dev, d_data, d_off, d_len, 0, nList, nullptr, list, resume, capsRow / 2, caps,
+                                     status, st);
+            if (rc != LC_OK) return rc;
+            hipLaunchKernelGGL(grok_advance_kernel, dim3((nList + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, list, nList,
+                               status, caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out,
+                               counters);
+            return LC_OK;
+        };
+        if (gp.anchored && nIn) {
+            // Round 0 searches every value from its first byte, and a log format matches FROM the first byte: the anchored search
+            // (a tagged DFA, tables in L2, one value per lane) finds exactly what the search would find whenever the search's
+            // leftmost match starts at byte 0; the values it does not match go to the search proper (their match, if any, starts
+            // later).  Both append to the same next-round list.
+            auto tRound = now();
+            uint32_t* out = outs[flip];
+            int rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, capsRow / 2,
+                                     caps, status, st);
+            if (rc != LC_OK) return rc;
+            hipLaunchKernelGGL(grok_unmatched_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
+                               unanchored, counters + 3);
+            hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
+                               caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out, counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t nRest = host[3];
+            HIP_TRY(hipMemsetAsync(counters + 3, 0, 4, st));
+            if (trace)
+                traceLine += " anchored " + std::to_string(nIn) + " -> rest " + std::to_string(nRest) + " (" +
+                             std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
+            if (nRest) {
+                auto tRest = now();
+                rc = searchRound(gp.re, unanchored, nRest, from, out);
+                if (rc != LC_OK) return rc;
+                HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (trace) traceLine += " round " + std::to_string(nRest) + " (" + std::to_string(msSince(tRest)).substr(0, 7) + " ms)";
+            }
+            nIn = host[0];
+            in = out;
+            flip ^= 1;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+        }
         while (nIn) {
             auto tRound = now();
             const uint32_t roundValues = nIn;
-            int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, from, capsRow / 2,
-                                     caps, status, st);
-            if (rc != LC_OK) return rc;
             uint32_t* out = outs[flip];
-            hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in,
-                               nIn, status, caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap,
-                               out, counters);
+            int rc = searchRound(gp.re, in, nIn, from, out);
+            if (rc != LC_OK) return rc;
             HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             nIn = host[0];

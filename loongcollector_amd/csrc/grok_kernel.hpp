@@ -119,6 +119,16 @@ __global__ __launch_bounds__(kGrokBlock) void grok_mask_filter_kernel(const uint
     if ((masks[line] >> bit) & 1u) out[atomicAdd(&counters[0], 1u)] = line;
 }
 
+// After the anchored search of round 0: the values it did NOT match go on to the search proper
+__global__ __launch_bounds__(kGrokBlock) void grok_unmatched_kernel(const uint32_t* __restrict__ in, uint32_t nIn,
+                                                                   const uint8_t* __restrict__ status, uint32_t* __restrict__ out,
+                                                                   uint32_t* __restrict__ count) {
+    const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t line = in[k];
+    if (status[line] != LC_MATCH) out[atomicAdd(count, 1u)] = line;
+}
+
 // Keeps the values whose screen search matched (status bytes written by the TDFA kernel for the values listed in `in`).
 __global__ __launch_bounds__(kGrokBlock) void grok_status_filter_kernel(const uint32_t* __restrict__ in, uint32_t nIn,
                                                                        const uint8_t* __restrict__ status,

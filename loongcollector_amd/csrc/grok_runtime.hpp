@@ -13,6 +13,8 @@ struct GrokDevicePattern {
     uint32_t columns;    // named groups
     lc_regex* screen;    // optional TDFA screen for the pattern's prefix (regex_handle.hpp lcCompilePrefixScreen), or null
     lc_regex* relaxed = nullptr;  // optional TDFA screen for the whole pattern, relaxed (lcCompileRelaxedScreen), or null
+    lc_regex* anchored = nullptr; // optional: the same pattern as an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX) on the TDFA
+                                  // engine, same groups: tried first on values searched from their first byte
 };
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts);

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <thread>
 #include <cstdlib>
+#include <functional>
 #include <cstring>
 
 #include "../../include/lc_grok.h"
@@ -30,7 +31,36 @@ bool allDigits(const std::string& s) {  // strconv.ParseInt(name, 10, 32) succee
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 }  // namespace
 
+void ProcessorGrokGpu::stopWarmup() {
+    mStopWarmup = true;
+    {
+        std::lock_guard<std::mutex> g(mWarmupMutex);
+        if (mWarmup.joinable()) mWarmup.join();
+        mWarmupStarted = false;
+    }
+    mStopWarmup = false;
+    if (mAnchored)
+        for (size_t i = 0; i < mExpanded.size(); ++i)
+            if (lc_regex* re = mAnchored[i].exchange(nullptr)) lc_regex_free(re);
+    mAnchored.reset();
+}
+
+void ProcessorGrokGpu::WaitReady() {
+    startWarmup();
+    std::lock_guard<std::mutex> g(mWarmupMutex);
+    if (mWarmup.joinable()) mWarmup.join();
+}
+
+std::vector<GrokDevicePattern> ProcessorGrokGpu::devicePatterns() {
+    startWarmup();
+    std::vector<GrokDevicePattern> out = mDevice;
+    if (mAnchored)
+        for (size_t i = 0; i < out.size(); ++i) out[i].anchored = mAnchored[i].load(std::memory_order_acquire);
+    return out;
+}
+
 ProcessorGrokGpu::~ProcessorGrokGpu() {
+    stopWarmup();
     for (lc_regex* re : mCompiled) lc_regex_free(re);
     for (lc_regex* re : mScreens) lc_regex_free(re);
 }
@@ -38,6 +68,7 @@ ProcessorGrokGpu::~ProcessorGrokGpu() {
 int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCompiled[i]->engine : 0; }
 
 void ProcessorGrokGpu::Init() {
+    stopWarmup();
     for (lc_regex* re : mCompiled) lc_regex_free(re);
     for (lc_regex* re : mScreens) lc_regex_free(re);
     mCompiled.clear();
@@ -66,35 +97,45 @@ void ProcessorGrokGpu::Init() {
         std::string err;
     };
     for (size_t i = 0; i < Match.size(); ++i) mExpanded.push_back(mLibrary.denormalize(Match[i]));
-    static const bool noRelaxed = getenv("LC_GROK_NO_RELAXED") != nullptr;  // (A/B measurements)
-    auto compileOne = [this](size_t i) {
-        Compiled c;
-        char err[512] = "";
-        c.rc = lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, LC_ENGINE_AUTO, &c.re, err, sizeof err);
-        if (c.rc != LC_OK) {
-            c.err = err;
-            return c;
-        }
-        if (c.re->engine == LC_ENGINE_NFA) {
-            // patterns that run on the slow NFA kernel get a TDFA screen for their prefix when one is small enough ...
-            c.screen = lcCompilePrefixScreen(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, 1024, 32 * 1024);
-            // ... and one for the whole pattern, relaxed until it is small
-            if (!noRelaxed) c.relaxed = lcCompileRelaxedScreen(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, 20000, 2u << 20);
-        }
-        return c;
-    };
+    static const bool noRelaxed = getenv("LC_GROK_NO_RELAXED") != nullptr;    // (A/B measurements)
+    static const bool noAnchored = getenv("LC_GROK_NO_ANCHORED") != nullptr;
     std::vector<Compiled> compiled(Match.size());
-    {
-        const size_t workers = std::max<size_t>(1, std::min<size_t>(Match.size(), std::min(16u, std::thread::hardware_concurrency())));
+    auto inParallel = [](size_t nTasks, const std::function<void(size_t)>& task) {
+        const size_t workers = std::max<size_t>(1, std::min<size_t>(nTasks, std::min(16u, std::thread::hardware_concurrency())));
         std::atomic<size_t> next{0};
         std::vector<std::thread> pool;
         auto work = [&] {
-            for (size_t i = next.fetch_add(1); i < Match.size(); i = next.fetch_add(1)) compiled[i] = compileOne(i);
+            for (size_t i = next.fetch_add(1); i < nTasks; i = next.fetch_add(1)) task(i);
         };
         for (size_t w = 1; w < workers; ++w) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
-    }
+    };
+    // 1. the patterns themselves
+    inParallel(Match.size(), [&](size_t i) {
+        Compiled& c = compiled[i];
+        char err[512] = "";
+        c.rc = lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax, LC_ENGINE_AUTO, &c.re, err, sizeof err);
+        if (c.rc != LC_OK) c.err = err;
+    });
+    // 2. what stands in front of the slow NFA kernel, for the entries that run on it: a TDFA screen for the pattern's prefix when
+    //    one is small enough; one for the whole pattern, relaxed until it is small (the anchored searches follow on the warm-up
+    //    thread, at the end of Init)
+    std::vector<std::pair<size_t, int>> extras;
+    for (size_t i = 0; i < Match.size(); ++i)
+        if (compiled[i].re && compiled[i].re->engine == LC_ENGINE_NFA)
+            for (int kind = 0; kind < 2; ++kind) extras.emplace_back(i, kind);
+    inParallel(extras.size(), [&](size_t t) {
+        const size_t i = extras[t].first;
+        Compiled& c = compiled[i];
+        const char* pat = mExpanded[i].data();
+        const size_t len = mExpanded[i].size();
+        if (extras[t].second == 0) {
+            c.screen = lcCompilePrefixScreen(pat, len, kGrokSyntax, 1024, 32 * 1024);
+        } else if (!noRelaxed) {
+            c.relaxed = lcCompileRelaxedScreen(pat, len, kGrokSyntax, 20000, 2u << 20);
+        }
+    });
     for (size_t i = 0; i < Match.size(); ++i) {  // everything that was compiled is owned from here on, whatever happens next
         if (compiled[i].re) mCompiled.push_back(compiled[i].re);
         mScreens.push_back(compiled[i].screen);
@@ -106,7 +147,7 @@ void ProcessorGrokGpu::Init() {
         lc_regex_t* re = compiled[i].re;
         const uint32_t columns = uint32_t(lc_regex_mark_count(re)) - 1;   // group 1 is the whole match
         maxColumns = std::max(maxColumns, columns);
-        mDevice.push_back({re, columns, compiled[i].screen, compiled[i].relaxed});
+        mDevice.push_back({re, columns, compiled[i].screen, compiled[i].relaxed, nullptr});
         std::vector<uint32_t> colKey(columns, kNoKey);
         std::vector<MergedField> fields;
         std::map<std::string, size_t> byName;
@@ -133,6 +174,41 @@ void ProcessorGrokGpu::Init() {
         mFields.push_back(std::move(fields));
     }
     mRowInts = 2 * (1 + maxColumns);
+    // 3. the anchored searches, behind Init
+    mAnchored.reset(new std::atomic<lc_regex*>[Match.size() ? Match.size() : 1]);
+    for (size_t i = 0; i < Match.size(); ++i) mAnchored[i].store(nullptr);
+    mWarmupWant.clear();
+    if (AnchoredFirst && !noAnchored)
+        for (size_t i = 0; i < Match.size(); ++i)
+            if (mCompiled[i]->engine == LC_ENGINE_NFA) mWarmupWant.push_back(i);
+}
+
+void ProcessorGrokGpu::startWarmup() {
+    {
+        std::lock_guard<std::mutex> g(mWarmupMutex);
+        if (mWarmupStarted || mWarmupWant.empty()) return;
+        mWarmupStarted = true;
+        mWarmup = std::thread([this] {
+            const std::vector<size_t>& want = mWarmupWant;
+            const size_t workers = std::max<size_t>(1, std::min<size_t>(want.size(), std::min(16u, std::thread::hardware_concurrency())));
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (size_t t = next.fetch_add(1); t < want.size() && !mStopWarmup.load(); t = next.fetch_add(1)) {
+                    const size_t i = want[t];
+                    lc_regex_t* re = nullptr;
+                    char err[64];
+                    // (failure = the automaton is too large even anchored: the entry searches on the NFA engine only)
+                    if (lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax | LC_SYNTAX_PREFIX, LC_ENGINE_TDFA, &re,
+                                         err, sizeof err) == LC_OK)
+                        mAnchored[i].store(re, std::memory_order_release);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < workers; ++w) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        });
+    }
 }
 
 // named non-empty groups of one match, in Groups() order (:167-175)
@@ -160,7 +236,7 @@ void ProcessorGrokGpu::MatchValues(const uint8_t* data, const uint32_t* off, con
         return;
     }
     std::vector<int32_t> first, extra;
-    int rc = lcGrokMatchHost(mDevice, mRowInts, data, off, len, n, pattern, first, extra);
+    int rc = lcGrokMatchHost(devicePatterns(), mRowInts, data, off, len, n, pattern, first, extra);
     if (rc != LC_OK) throw GrokError(std::string("grok device match failed: ") + lc_last_error());
     const size_t w = mRowInts + 2;
     size_t x = 0;
@@ -272,6 +348,7 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
             if (v->isNumber()) g->p.TimeoutMilliSeconds = v->isInt ? v->inum : int64_t(v->num);
         boolean("IgnoreParseFailure", g->p.IgnoreParseFailure);
         boolean("KeepSource", g->p.KeepSource);
+        boolean("AnchoredFirst", g->p.AnchoredFirst);
         boolean("NoKeyError", g->p.NoKeyError);
         boolean("NoMatchError", g->p.NoMatchError);
         boolean("TimeoutError", g->p.TimeoutError);
@@ -286,6 +363,10 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
 }
 
 extern "C" void lc_grok_free(lc_grok_t* g) { delete g; }
+extern "C" void lc_grok_wait_ready(lc_grok_t* g) {
+    if (g) g->p.WaitReady();
+}
+
 extern "C" int lc_grok_match_count(const lc_grok_t* g) { return g ? int(g->p.expanded().size()) : 0; }
 extern "C" const char* lc_grok_expanded(const lc_grok_t* g, int i) {
     return (g && i >= 0 && size_t(i) < g->p.expanded().size()) ? g->p.expanded()[size_t(i)].c_str() : nullptr;

@@ -6,7 +6,10 @@
 // ordered list of (Key, Value) contents (duplicates allowed; fields are appended, processor_grok.go:183-185).
 #pragma once
 
+#include <atomic>
+#include <thread>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -35,6 +38,12 @@ public:
     int64_t TimeoutMilliSeconds = 0;
     bool IgnoreParseFailure = true;
     bool KeepSource = true;
+    // not a reference key: compile, for every entry that runs on the NFA engine, the ANCHORED search as well (the match must start
+    // at the first byte: a tagged DFA of 2 000 - 30 000 states with its tables in L2) and try it first -- log formats match from the
+    // first byte.  Those automata cost seconds each, and the entries whose automaton turns out too large cost as much: they are
+    // compiled BEHIND Init, on a warm-up thread, and join the device loop as they arrive (results do not depend on them, only speed;
+    // WaitReady() blocks until the thread is done).  Instances that only probe a pattern switch it off.
+    bool AnchoredFirst = true;
     bool NoKeyError = false;
     bool NoMatchError = true;
     bool TimeoutError = true;
@@ -57,7 +66,9 @@ public:
     const std::vector<std::string>& expanded() const { return mExpanded; }
     const std::vector<std::string>& keys() const { return mKeys; }
     const std::vector<std::vector<uint32_t>>& columnKeys() const { return mColumnKey; }
-    const std::vector<GrokDevicePattern>& devicePatterns() const { return mDevice; }
+    std::vector<GrokDevicePattern> devicePatterns();  // (a snapshot: the anchored handles arrive from the warm-up thread, which
+                                                      // the first call starts -- an instance that never matches never pays)
+    void WaitReady();                                       // returns when the warm-up thread has compiled what it can
     uint32_t rowInts() const { return mRowInts; }
     int engine(size_t i) const;
 
@@ -66,6 +77,14 @@ private:
     std::vector<std::string> mExpanded;
     std::vector<lc_regex*> mCompiled;
     std::vector<lc_regex*> mScreens;                   // the screens of the Match entries (prefix, relaxed; nullptr = none), owned
+    std::unique_ptr<std::atomic<lc_regex*>[]> mAnchored;  // [Match entry] the anchored search, once compiled (nullptr: none), owned
+    std::thread mWarmup;
+    std::atomic<bool> mStopWarmup{false};
+    std::mutex mWarmupMutex;
+    bool mWarmupStarted = false;
+    std::vector<size_t> mWarmupWant;                   // the entries the warm-up thread compiles an anchored search for
+    void startWarmup();
+    void stopWarmup();
     std::vector<GrokDevicePattern> mDevice;
     std::vector<std::string> mKeys;                    // distinct emitted keys
     std::vector<std::vector<uint32_t>> mColumnKey;     // [pattern][column] -> key index

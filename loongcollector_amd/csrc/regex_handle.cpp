@@ -525,7 +525,9 @@ static std::string requiredLiteral(const Node& n) {
     }
 }
 
-static void wrapForSearch(ParsedRegex& re) {
+// anchored: no lazy prefix -- (re)(?s:.*): the search wrapper for a match that must start at the first byte (same group layout:
+// group 1 = the whole match)
+static void wrapForSearch(ParsedRegex& re, bool anchored = false) {
     shiftCaptures(*re.root);
     auto anyStar = [](bool greedy) {
         auto set = std::make_unique<Node>();
@@ -545,7 +547,7 @@ static void wrapForSearch(ParsedRegex& re) {
     whole->kids.push_back(std::move(re.root));
     auto cat = std::make_unique<Node>();
     cat->kind = Node::Cat;
-    cat->kids.push_back(anyStar(false));
+    if (!anchored) cat->kids.push_back(anyStar(false));
     cat->kids.push_back(std::move(whole));
     cat->kids.push_back(anyStar(true));
     re.root = std::move(cat);
@@ -1005,13 +1007,14 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
         }
         re->requiredLiteral = requiredLiteral(*parsed.root);
-        if ((syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX))
-            throw RegexError("LC_SYNTAX_SEARCH and LC_SYNTAX_PREFIX exclude each other");
-        if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed);
-        if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
+        // LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX: the search whose match must START at the first byte -- what a search finds whenever
+        // its leftmost match starts there, with the search's group layout (lc_regex_gpu.h)
+        const bool anchoredSearch = (syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX);
+        if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed, anchoredSearch);
+        else if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
         re->nfa = buildFollowNfa(parsed);
         if (syntax_flags & LC_SYNTAX_SEARCH) {  // wrapForSearch generates its prefix '.' first and its suffix '.' last
-            re->nfa.searchPrefix = 0;
+            re->nfa.searchPrefix = anchoredSearch ? -1 : 0;
             re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;
         }
         if (engine != LC_ENGINE_NFA) {
@@ -1062,7 +1065,10 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             TdfaLimits lim;
                             lim.maxStates = l2States;
                             lim.ldsWindow = false;
-                            lim.maxPathWork = 4u << 20;
+                            // (an anchored search is compiled because its automaton is wanted: it may cost seconds)
+                            lim.maxPathWork = anchoredSearch ? (32u << 20) : (4u << 20);
+                            if (anchoredSearch) lim.maxStates = std::max<uint32_t>(lim.maxStates, 60000);
+                            if (const char* v = getenv("LC_TDFA_L2_MAX_WORK")) lim.maxPathWork = uint64_t(atoll(v));
                             re->tdfa = buildTdfa(re->nfa, lim);
                         }
                         const size_t tableBytes = size_t(re->tdfa.nStates) * re->tdfa.nClasses * 4;
@@ -1072,7 +1078,8 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                                               re->tdfa.startState, 0, 0, 0};
                             l2 = true;
                         }
-                    } catch (const RegexError&) {
+                    } catch (const RegexError& e2) {
+                        re->tdfaError += std::string("; with its tables in global memory: ") + e2.what();
                     }
                 }
                 if (!l2 && engine == LC_ENGINE_TDFA) throw RegexError(re->tdfaError);

@@ -19,6 +19,8 @@ def _lib():
         L.lc_grok_create.restype = i32
         L.lc_grok_create.argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
         L.lc_grok_free.argtypes = [vp]
+        L.lc_grok_wait_ready.restype = None
+        L.lc_grok_wait_ready.argtypes = [vp]
         for name in ("lc_grok_match_count", "lc_grok_key_count", "lc_grok_row_ints"):
             getattr(L, name).restype = i32
             getattr(L, name).argtypes = [vp]
@@ -71,6 +73,11 @@ class Grok:
         if getattr(self, "_h", None):
             self._L.lc_grok_free(self._h)
             self._h = None
+
+    def wait_ready(self):
+        """lc_grok_wait_ready: block until the warm-up thread has compiled the anchored searches (speed only, never results)"""
+        self._L.lc_grok_wait_ready(self._h)
+        return self
 
     def expanded(self, i):
         return self._L.lc_grok_expanded(self._h, i).decode("utf-8")

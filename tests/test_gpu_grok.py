@@ -140,7 +140,7 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
     ok = []
     for m in cfg["match"]:
         try:
-            Grok(Match=[m], CustomPatterns=cfg["custom_patterns"])
+            Grok(Match=[m], CustomPatterns=cfg["custom_patterns"], AnchoredFirst=False)
             ok.append(m)
         except GrokInitError:
             pass
@@ -155,7 +155,7 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
         b"%ASA-1-104001: (Primary) Switching to ACTIVE - reason",
         b"    at com.example.Foo.bar(Foo.java:42)",
     ] + grok_lines(3000)
-    pattern, fields = g.match_host(values)
+    pattern, fields = g.match_host(values)      # (right after Init: the warm-up thread has hardly delivered an anchored search yet)
     hits, winners = 0, set()
     for v, p, f in zip(values, pattern, fields):
         res, want = o.process_value(v)
@@ -164,6 +164,14 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
         hits += p >= 0
         winners.add(int(p))
     assert hits >= 2800 and len(winners) >= 15
+    # the same list with every anchored search in place (tried first on each value, tables in L2), and with none at all
+    B.launched_kernels()
+    pattern2, fields2 = g.wait_ready().match_host(values)
+    assert "tdfa_l2_kernel" in B.launched_kernels()
+    assert list(pattern2) == list(pattern) and fields2 == fields
+    g0 = Grok(Match=ok, CustomPatterns=cfg["custom_patterns"], AnchoredFirst=False)
+    pattern0, fields0 = g0.match_host(values)
+    assert list(pattern0) == list(pattern) and fields0 == fields
 
 
 def test_relaxed_screens_on_the_device(torch_dev, golden_dir):

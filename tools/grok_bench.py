@@ -43,13 +43,16 @@ def main():
     supported, refused = [], []
     for m in cfg["match"]:
         try:
-            Grok(Match=[m], CustomPatterns=cfg["custom_patterns"])
+            Grok(Match=[m], CustomPatterns=cfg["custom_patterns"], AnchoredFirst=False)   # (a probe: no warm-up thread)
             supported.append(m)
         except GrokInitError as e:
             refused.append((m, str(e).split(": ", 1)[-1][:80]))
     if args.patterns:
         supported = supported[:args.patterns]
     g = Grok(Match=supported, CustomPatterns=cfg["custom_patterns"])
+    t0 = time.perf_counter()
+    g.wait_ready()   # the anchored searches are compiled behind Init; the timed steps should see the matcher at full speed
+    warm_s = time.perf_counter() - t0
     engines = [g.engine(i) for i in range(g.n_match)]
 
     values = grok_lines(args.lines)
@@ -129,7 +132,8 @@ def main():
                    "matched_lines": int((pattern >= 0).sum()), "undecidable_lines": int((pattern == -2).sum()),
                    "undecidable_line_indices": [int(i) for i in np.nonzero(pattern == -2)[0][:32]],
                    "extra_match_rows": int(d_nextra.cpu()[0]),
-                   "patterns_hit": int((hist > 0).sum())},
+                   "patterns_hit": int((hist > 0).sum()),
+                   "warm_up_s": round(warm_s, 2)},
         # algorithmic HBM bytes of one step: every value read once + 4 B offset + 4 B length + the result row (pattern id +
         # first-match row) written once per line.  The NFA kernels are nowhere near it: they are bound by the dependent table
         # reads of a byte-step (one line per wavefront), not by HBM -- the fraction says how far.
