@@ -1308,7 +1308,7 @@ size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
     const size_t m = n ? n : 1;
-    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 256 + alignUp(m * 8, 256);
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 512 + alignUp(m * 8, 256);
 }
 
 // ---- the literal index of a Match list (grok_kernel.hpp grok_literal_index_kernel): built the first time the list is seen,
@@ -1471,6 +1471,8 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
              *roundOut = lists[5], *unanchored = lists[6];
     uint32_t* counters = reinterpret_cast<uint32_t*>(base);
     base += 256;
+    uint32_t* perPattern = reinterpret_cast<uint32_t*>(base);  // [64]: values that carry each entry's literal (literal index pass)
+    base += 256;
     uint64_t* masks = reinterpret_cast<uint64_t*>(base);
 
     const uint32_t gridAll = (n + kGrokBlock - 1) / kGrokBlock;
@@ -1481,9 +1483,15 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
         int rc = grokLiteralIndex(patterns, dev, &literalIndex);
         if (rc != LC_OK) return rc;
     }
-    if (literalIndex)
+    std::vector<uint32_t> carriers;  // per entry: values of the batch that carry its literal (empty: no index)
+    if (literalIndex) {
+        HIP_TRY(hipMemsetAsync(perPattern, 0, 256, st));
         hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex,
-                           masks);
+                           masks, uint32_t(patterns.size()), perPattern);
+        carriers.resize(64);
+        HIP_TRY(hipMemcpyAsync(carriers.data(), perPattern, 256, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
     HIP_TRY(hipMemsetAsync(counters, 0, 16, st));
 
@@ -1498,6 +1506,9 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
     };
     for (size_t p = 0; p < patterns.size() && nTried; ++p) {
         const GrokDevicePattern& gp = patterns[p];
+        // no value of the batch carries this entry's literal: it cannot match anything, and an entry that matches nothing
+        // leaves every list as it is
+        if (!carriers.empty() && carriers[p] == 0) continue;
         auto tPattern = now();
         std::string traceLine;
         if (trace) traceLine = "grok[" + std::to_string(p) + "] engine " + std::to_string(gp.re->engine) + " tried " + std::to_string(nTried);

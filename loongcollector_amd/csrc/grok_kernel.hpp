@@ -78,17 +78,21 @@ enum { GL_NSTATES = 0, GL_NCLASSES = 1, GL_OFF_MASKS = 2, GL_OFF_TABLE = 3, GL_A
 
 __global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                        const uint32_t* __restrict__ len, uint32_t n,
-                                                                       const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks) {
+                                                                       const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks,
+                                                                       uint32_t nPatterns, uint32_t* __restrict__ perPattern) {
     __shared__ uint8_t cmap[256];
     cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
     __syncthreads();
     const uint32_t line = blockIdx.x * kGrokBlock + threadIdx.x;
-    if (line >= n) return;
-    const uint32_t L = len[line], ncls = blob[GL_NCLASSES];
+    if (line >= n) {  // (whole trailing wavefronts leave here; a partial one takes part in the ballots below with an empty mask)
+        if ((blockIdx.x * kGrokBlock + (threadIdx.x & ~63u)) >= n) return;
+    }
+    const uint32_t L = line < n ? len[line] : 0u, ncls = blob[GL_NCLASSES];
     const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);
-    uint64_t mask = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + off[line];
+    const bool live = line < n;
+    uint64_t mask = live ? uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32) : 0;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + (live ? off[line] : 0u);
     const uint32_t head = uint32_t(addr & 15);
     const uint4* q = reinterpret_cast<const uint4*>(addr - head);
     const uint32_t total = L ? head + L : 0;
@@ -106,7 +110,12 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const ui
             }
         }
     }
-    masks[line] = mask;
+    if (live) masks[line] = mask;
+    // how many values carry each entry's literal at all: an entry nobody carries is skipped without a single launch
+    for (uint32_t p = 0; p < nPatterns; ++p) {
+        const uint64_t has = __ballot((mask >> p) & 1u);
+        if (has && (threadIdx.x & 63u) == 0) atomicAdd(&perPattern[p], uint32_t(__popcll(has)));
+    }
 }
 
 // Match[bit]'s literal filter once the masks exist
