@@ -133,6 +133,36 @@ def test_search_mode_tables_reproduce_every_search_vector(golden_dir):
     assert not bad, bad[:5]
 
 
+def test_anchored_search_is_the_search_whose_match_starts_at_the_first_byte(golden_dir):
+    """LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX compiles (re)(?s:.*) with the search's group layout.  On every search vector: when the
+    search's match starts at byte 0 the anchored search reports exactly that match -- same captures --, otherwise (later start, or
+    no match) it reports none.  (The Grok matcher tries the anchored automaton first: far smaller, no "anywhere" prefix.)"""
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        d = json.load(f)
+    bad, at0, later, none = [], 0, 0, 0
+    for c in d["cases"]:
+        try:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_PREFIX)
+        except B.RegexUnsupportedError:
+            continue
+        assert rx.groups == c["g"] + 1
+        interps = ([NfaInterp(rx)] if rx.has_nfa_program() else []) + (
+            [TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        for subj, flat in c["subs"]:
+            want = flat if flat is not None and flat[0] == 0 else None
+            # a search that starts later may still have an anchored match of lower priority... no: leftmost wins, so a match
+            # at byte 0 would have been the search's answer
+            at0 += want is not None
+            later += flat is not None and want is None
+            none += flat is None
+            for it in interps:
+                got = it.fullmatch(subj.encode("latin-1"))
+                if got != want:
+                    bad.append((c["p"], subj, got, want))
+    assert at0 > 300 and later > 100 and none > 100, (at0, later, none)
+    assert not bad, bad[:5]
+
+
 def test_atomic_groups_and_possessive_quantifiers_on_both_engines_tables(golden_dir):
     """Atomic groups: segment lineage in the TDFA builder (tdfa.cpp commitAtomic), and the same commit rules applied per
     step by the NFA engine."""
