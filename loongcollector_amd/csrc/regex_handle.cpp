@@ -890,7 +890,12 @@ lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t synta
     } catch (const RegexError&) {
         return nullptr;
     }
-    for (size_t budget : {96u, 48u, 24u, 12u, 6u}) {
+    // LC_RELAX_BUDGET (tests): start at this budget instead of 96 -- small patterns get relaxed too
+    size_t firstBudget = 96;
+    if (const char* e = getenv("LC_RELAX_BUDGET")) firstBudget = size_t(std::max(1, atoi(e)));
+    std::vector<size_t> budgets;
+    for (size_t b = firstBudget; b >= 1 && budgets.size() < 5; b = b > 6 ? b / 2 : (b > 1 ? b - 1 : 0)) budgets.push_back(b);
+    for (size_t budget : budgets) {
         Relaxer rx{budget};
         std::unique_ptr<Node> node = rx.relax(*parsed.root);
         const size_t npos = Relaxer::positions(*node);

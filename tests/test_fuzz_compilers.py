@@ -149,3 +149,42 @@ def test_random_patterns_with_run_captures_and_packed_blobs():
                     checked += 1
                     assert got == want, (p, s, flags, type(it).__name__)
     assert checked > 3000 and with_runs > 40
+
+
+@pytest.mark.parametrize("budget", ["1", "3", "8", "96"])
+def test_relaxed_screens_never_reject_a_value_the_pattern_matches(monkeypatch, budget):
+    """lcCompileRelaxedScreen + screen_dfa.cpp on fresh random patterns (plain ones and ones full of atomic groups, possessive
+    quantifiers and look assertions), relaxed down to budgets at which every alternation and counter collapses: whatever the
+    oracle's search matches, the screen accepts.  (A screen that rejected a matching value would change results, not speed.)"""
+    monkeypatch.setenv("LC_RELAX_BUDGET", budget)
+    agen = importlib.util.module_from_spec(_aspec)
+    _aspec.loader.exec_module(agen)
+    rng = random.Random(777 + int(budget))
+    g = gen.Gen(rng)
+    screens = checked = hits = rejected = 0
+    for k in range(700):
+        if k % 2:
+            p, smp = agen.gen(rng), None
+        else:
+            p, _, smp = g.alt(0)
+        try:
+            orx = OracleRegex(p)
+        except ValueError:
+            continue
+        scr = B.GpuRegex.compile_screen(p, max_states=20000, max_table_bytes=2 << 20, relaxed=True)
+        if scr is None:           # (accepts the empty string: screens nothing)
+            continue
+        screens += 1
+        it = TdfaInterp(scr)
+        subjects = [gen.rand_subject(rng) for _ in range(6)] + [bytes(rng.choice(b"abc1 ") for _ in range(rng.randint(0, 10))) for _ in range(6)]
+        if smp is not None:
+            subjects += [gen.mutate(rng, smp()) for _ in range(5)]
+        subjects += [gen.rand_subject(rng)[:3] + s + gen.rand_subject(rng)[:3] for s in subjects[:6]]
+        for s in subjects:
+            hit = orx.search(s) is not None
+            ok = it.fullmatch(s) is not None
+            checked += 1
+            hits += hit
+            rejected += not ok
+            assert ok or not hit, (p, s, budget)
+    assert screens > 60 and checked > 1500 and hits > 200 and rejected > 50, (screens, checked, hits, rejected)
