@@ -91,6 +91,11 @@ class NfaInterp:
         ncl = self.ncls
         self.behind = [int(x) for x in blob[int(blob[12]) // 4:int(blob[12]) // 4 + ncl + 1]]   # NF_OFF_BEHIND
         self.ahead = [int(x) for x in blob[int(blob[13]) // 4:int(blob[13]) // 4 + ncl + 1]]    # NF_OFF_AHEAD
+        # NF_OFF_STABLE: the steady-state fast path of the kernel (bit c: on byte class c a thread on this position only ever
+        # repeats itself -- or, in a search pattern, also re-spawns the wrapper's suffix thread, which changes nothing)
+        st = blob[int(blob[11]) // 4:int(blob[11]) // 4 + mw * (self.npos + 1)]
+        self.stable = [sum(int(st[mw * p + k]) << (32 * k) for k in range(mw)) for p in range(self.npos + 1)]
+        self.search_suffix = self.npos - 1 if int(blob[18]) else -1                                # NF_SEARCH
         self.follow = []
         for p in range(self.npos + 1):
             lst = []
@@ -103,9 +108,10 @@ class NfaInterp:
             self.follow.append(lst)
 
     @_with_run_captures
-    def fullmatch(self, s: bytes, max_threads=64, start=0):
+    def fullmatch(self, s: bytes, max_threads=64, start=0, steady=True):
         """start > 0 (search patterns only): resume at that offset -- one thread on the wrapper's prefix position
-        (position 0), having just consumed the byte before the resume point."""
+        (position 0), having just consumed the byte before the resume point.  steady: take the kernel's steady-state fast path
+        (a byte on which every live thread is steady is skipped) and its suffix pruning, as nfa_match_kernel does."""
         threads = [(self.npos, [-1] * self.nslots)]  # (position, caps)
         prev_cls = self.ncls                     # edge entry: start of input
         if start:
@@ -115,6 +121,9 @@ class NfaInterp:
             if pos < start:
                 continue
             cls = int(self.cmap[b])
+            if steady and all((self.stable[p] >> cls) & 1 for p, _ in threads):
+                prev_cls = cls
+                continue
             holds = self.behind[prev_cls] | self.ahead[cls]
             new, seen = [], set()
             for p, caps in threads:
@@ -129,6 +138,11 @@ class NfaInterp:
                         if (tags >> sl) & 1:
                             c2[sl] = pos
                     new.append((tgt, c2))
+            if steady and self.search_suffix >= 0:      # nothing ranked below a thread on the suffix position can win any more
+                for k, (p, _) in enumerate(new):
+                    if p == self.search_suffix:
+                        new = new[:k + 1]
+                        break
             if len(new) > max_threads:
                 return "overflow"
             threads = new

@@ -227,8 +227,8 @@ def test_prefix_mode_is_regex_search_match_continuous(golden_dir):
     assert it.fullmatch(b"2024-01-04 14:36:10 ERROR boom") is not None
     assert it.fullmatch(b"    at com.example.Foo.bar(Foo.java:42)") is None
     assert it.fullmatch(b" 2024-01-04 14:36:10 leading space") is None
-    with pytest.raises(B.RegexUnsupportedError):
-        B.GpuRegex(b"a", syntax_flags=B.LC_SYNTAX_PREFIX | B.LC_SYNTAX_SEARCH)
+    # together with LC_SYNTAX_SEARCH: the anchored search (group 1 = the whole match), see the test below
+    assert B.GpuRegex(b"(a)", syntax_flags=B.LC_SYNTAX_PREFIX | B.LC_SYNTAX_SEARCH).groups == 2
 
 
 def test_run_captures_on_both_table_formats():
