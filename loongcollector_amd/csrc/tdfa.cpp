@@ -2,6 +2,7 @@
 #include "tdfa.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
@@ -304,6 +305,114 @@ std::vector<uint16_t> scheduleMoves(std::vector<std::pair<int, int>> regMoves, c
 
 }  // namespace
 
+// ---- dead stores.  A search pattern that ends in a greedy field -- "(?s:.*?)(... (.*))(?s:.*)", every Grok format with a
+// GREEDYDATA tail -- re-derives, at EVERY byte of the tail, the thread that would take over if the field ended here, and with it
+// the stamps of "the field ends here, the match ends here": a register program on 90-98 % of the bytes of such lines (measured on the
+// configs[2] corpus), two stamps each, which the kernels pay for byte by byte.  Nearly all of them are dead: the byte that really
+// ends the field stamps the same registers again before anything reads them, and at the end of the line the field's own thread
+// wins, whose final map reads "end of line", not those registers.  Classic liveness over the automaton: a register is live in a
+// state if some path from it reads the register (a copy's source, or the final map of a state the line can end in) before writing
+// it; a store to a register that is not live behind the transition is dropped.  Semantics unchanged, tables smaller, and the
+// self-loop of the tail carries no program at all.
+static void eliminateDeadStores(TdfaTables& T) {
+    static const bool off = getenv("LC_TDFA_NO_DSE") != nullptr;  // (A/B measurements)
+    if (off || T.ops.empty()) return;
+    const uint32_t ncls = T.nClasses, nStates = T.nStates;
+    const size_t nLists = T.opsStart.size() - 1;
+    typedef std::array<uint64_t, 4> RegSet;  // 256 registers
+    auto has = [](const RegSet& s, unsigned r) { return (s[r >> 6] >> (r & 63)) & 1; };
+    auto add = [](RegSet& s, unsigned r) { s[r >> 6] |= uint64_t(1) << (r & 63); };
+    auto del = [](RegSet& s, unsigned r) { s[r >> 6] &= ~(uint64_t(1) << (r & 63)); };
+    std::vector<std::vector<uint16_t>> lists(nLists);
+    for (size_t id = 1; id < nLists; ++id) {
+        const uint32_t at = T.opsStart[id];
+        if (at >= T.ops.size() || T.opsStart[id + 1] == at) continue;
+        const uint32_t n = T.ops[at];
+        lists[id].assign(T.ops.begin() + at + 1, T.ops.begin() + at + 1 + n);
+    }
+    // what a line that ends in state s reads
+    std::vector<RegSet> live(nStates, RegSet{{0, 0, 0, 0}});
+    const size_t slots = T.nSlots ? T.nSlots : 1;
+    for (uint32_t s = 1; s < nStates; ++s) {
+        if (T.finalId[s] == 0xFFFF) continue;
+        for (size_t k = 0; k < slots; ++k) {
+            const uint8_t m = T.finalMap[size_t(T.finalId[s]) * slots + k];
+            if (m != kRegPos && m != kRegNone) add(live[s], m);
+        }
+    }
+    // live-in of the source state through one transition: the ops run in order, so walk them backwards
+    auto through = [&](const std::vector<uint16_t>& ops, RegSet after) {
+        for (size_t k = ops.size(); k-- > 0;) {
+            const unsigned dst = ops[k] & 0xFF, src = ops[k] >> 8;
+            if (!has(after, dst)) continue;  // a dead store reads nothing
+            del(after, dst);
+            if (src != kRegPos) add(after, src);
+        }
+        return after;
+    };
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (uint32_t s = nStates; s-- > 1;) {
+            RegSet acc = live[s];
+            for (uint32_t c = 0; c < ncls; ++c) {
+                const uint32_t e = T.trans[size_t(s) * ncls + c];
+                const uint32_t t = e & 0xFFFF;
+                if (!t) continue;
+                const RegSet in = through(lists[e >> 16], live[t]);
+                for (int w = 0; w < 4; ++w) acc[w] |= in[w];
+            }
+            if (acc != live[s]) {
+                live[s] = acc;
+                changed = true;
+            }
+        }
+    }
+    // rewrite: per transition, keep the stores that are live behind it
+    std::map<std::vector<uint16_t>, uint32_t> interned;
+    std::vector<std::vector<uint16_t>> newLists(1);
+    interned.emplace(std::vector<uint16_t>(), 0u);
+    size_t before = 0, after = 0;
+    for (uint32_t s = 1; s < nStates; ++s)
+        for (uint32_t c = 0; c < ncls; ++c) {
+            uint32_t& e = T.trans[size_t(s) * ncls + c];
+            const uint32_t t = e & 0xFFFF;
+            const std::vector<uint16_t>& ops = lists[e >> 16];
+            if (ops.empty()) continue;
+            std::vector<uint16_t> kept;
+            if (t) {
+                RegSet need = live[t];
+                std::vector<char> keep(ops.size(), 0);
+                for (size_t k = ops.size(); k-- > 0;) {
+                    const unsigned dst = ops[k] & 0xFF, src = ops[k] >> 8;
+                    if (!has(need, dst)) continue;
+                    keep[k] = 1;
+                    del(need, dst);
+                    if (src != kRegPos) add(need, src);
+                }
+                for (size_t k = 0; k < ops.size(); ++k)
+                    if (keep[k]) kept.push_back(ops[k]);
+            }
+            before += ops.size();
+            after += kept.size();
+            auto it = interned.find(kept);
+            if (it == interned.end()) {
+                it = interned.emplace(kept, uint32_t(newLists.size())).first;
+                newLists.push_back(kept);
+            }
+            e = t | (it->second << 16);
+        }
+    if (after == before) return;
+    T.opsStart.assign(1, 0);
+    T.ops.clear();
+    for (const auto& l : newLists) {
+        if (!l.empty()) {
+            T.ops.push_back(uint16_t(l.size()));
+            T.ops.insert(T.ops.end(), l.begin(), l.end());
+        }
+        T.opsStart.push_back(uint32_t(T.ops.size()));
+    }
+}
+
 TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     const int npos = int(nfa.positions.size());
     const int nslots = nfa.slotCount();
@@ -540,6 +649,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
         }
     }
     if (T.finalMap.empty()) T.finalMap.assign(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
+    eliminateDeadStores(T);
     return T;
 }
 
