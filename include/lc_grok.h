@@ -48,6 +48,11 @@ const char* lc_grok_processed(const lc_grok_t* g, const char* name); /* processe
 /* denormalizePattern on any expression against this handle's library, without compiling it (malloc'ed, release with
  * lc_grok_free_string; NULL + err on "no pattern found for X" / "invalid pattern X") */
 char* lc_grok_denormalize(lc_grok_t* g, const char* pattern, char* err, size_t errcap);
+/* The literal index of the Match list (introspection for tests): the required literals of all entries as one Aho-Corasick DFA
+ * (csrc/grok_literal_layout.h); the device walks it once per value and gets a 64-bit mask "which entries' literals does this
+ * value contain".  *words = NULL when the list is not indexable (more than 64 entries, fewer than two literals).  The pointer
+ * stays valid until lc_grok_free. */
+int lc_grok_literal_index(lc_grok_t* g, const uint32_t** words, size_t* nwords);
 int lc_grok_engine(const lc_grok_t* g, int i);                     /* LC_ENGINE_TDFA / LC_ENGINE_NFA chosen for Match[i] */
 
 /* Emitted keys.  A match of Match[i] writes one capture column per NAMED group; columns that share a name are one field

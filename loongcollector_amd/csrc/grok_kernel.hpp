@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #include "../../include/lc_regex_gpu.h"
+#include "grok_literal_layout.h"
 
 constexpr int kGrokBlock = 256;
 
@@ -72,9 +73,7 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_filter_kernel(const u
 // in global memory (a few hundred states: L1/L2-resident), walked once per value, one value per lane; the result is a 64-bit
 // mask per value -- bit p = the value contains Match[p]'s literal (always set for entries without one) -- and each entry's
 // filter becomes a read of 8 bytes per value.
-// Blob (u32 words): GL_* header, class map u8[256], output masks u64[nStates], table u16[nStates][nClasses] whose bit 15 says
-// "the target state has an output" (so the mask table is touched only where a literal ends).
-enum { GL_NSTATES = 0, GL_NCLASSES = 1, GL_OFF_MASKS = 2, GL_OFF_TABLE = 3, GL_ALWAYS_LO = 4, GL_ALWAYS_HI = 5, GL_HEADER_WORDS = 8 };
+// Blob: grok_literal_layout.h, built by grok_literal_index.cpp.
 
 __global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                        const uint32_t* __restrict__ len, uint32_t n,

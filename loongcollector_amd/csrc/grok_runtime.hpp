@@ -19,6 +19,12 @@ struct GrokDevicePattern {
 
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts);
 
+// grok_literal_index.cpp: the literal the index keeps for a pattern (its required literal; the last 32 bytes of a longer one) and
+// the index blob of a list of such literals ("" = the entry has none: its bit is always set).  Empty blob: not indexable.
+#include <string>
+std::string lcGrokLiteralOf(const lc_regex* re);
+std::vector<uint32_t> lcBuildGrokLiteralBlob(const std::vector<std::string>& literals);
+
 // See include/lc_grok.h: lc_grok_match_device.  rowInts = 2 * (1 + max columns).
 int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t rowInts, const uint8_t* d_data,
                       const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern, int32_t* d_first,

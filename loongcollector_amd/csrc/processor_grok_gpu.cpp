@@ -300,6 +300,7 @@ using lcgrok::ProcessorGrokGpu;
 
 struct lc_grok {
     ProcessorGrokGpu p;
+    std::vector<uint32_t> literalIndex;  // lc_grok_literal_index: built on first request
 };
 struct lc_grok_result {
     std::vector<uint32_t> fieldOff, key, begin, end;
@@ -363,6 +364,27 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
 }
 
 extern "C" void lc_grok_free(lc_grok_t* g) { delete g; }
+extern "C" int lc_grok_literal_index(lc_grok_t* g, const uint32_t** words, size_t* nwords) {
+    if (!g || !words || !nwords) return LC_ERR_ARG;
+    *words = nullptr;
+    *nwords = 0;
+    if (g->literalIndex.empty()) {
+        const auto& patterns = g->p.compiledPatterns();
+        std::vector<std::string> lits;
+        size_t withLiteral = 0;
+        for (const auto& gp : patterns) {
+            lits.push_back(lcGrokLiteralOf(gp.re));
+            withLiteral += !lits.back().empty();
+        }
+        if (patterns.size() <= 64 && withLiteral >= 2) g->literalIndex = lcBuildGrokLiteralBlob(lits);
+    }
+    if (!g->literalIndex.empty()) {
+        *words = g->literalIndex.data();
+        *nwords = g->literalIndex.size();
+    }
+    return LC_OK;
+}
+
 extern "C" void lc_grok_wait_ready(lc_grok_t* g) {
     if (g) g->p.WaitReady();
 }

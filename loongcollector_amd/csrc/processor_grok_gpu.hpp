@@ -68,6 +68,7 @@ public:
     const std::vector<std::vector<uint32_t>>& columnKeys() const { return mColumnKey; }
     std::vector<GrokDevicePattern> devicePatterns();  // (a snapshot: the anchored handles arrive from the warm-up thread, which
                                                       // the first call starts -- an instance that never matches never pays)
+    const std::vector<GrokDevicePattern>& compiledPatterns() const { return mDevice; }  // (without the anchored searches)
     void WaitReady();                                       // returns when the warm-up thread has compiled what it can
     uint32_t rowInts() const { return mRowInts; }
     int engine(size_t i) const;

@@ -74,6 +74,18 @@ class Grok:
             self._L.lc_grok_free(self._h)
             self._h = None
 
+    def literal_index(self):
+        """lc_grok_literal_index: the Aho-Corasick DFA over the required literals of the Match list (uint32 words), or None"""
+        import numpy as np
+        words = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        self._L.lc_grok_literal_index.restype = ctypes.c_int
+        self._L.lc_grok_literal_index.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        rc = self._L.lc_grok_literal_index(self._h, ctypes.byref(words), ctypes.byref(n))
+        if rc != 0 or not words.value:
+            return None
+        return np.ctypeslib.as_array(ctypes.cast(words.value, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,)).copy()
+
     def wait_ready(self):
         """lc_grok_wait_ready: block until the warm-up thread has compiled the anchored searches (speed only, never results)"""
         self._L.lc_grok_wait_ready(self._h)

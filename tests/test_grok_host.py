@@ -4,8 +4,10 @@ algorithm (ordered patterns, resumed searches, named non-empty groups) emulated 
 
 Reference: plugins/processor/grok/processor_grok.go + processor_grok_test.go (cited per test)."""
 import json
+import random
 import os
 
+import numpy as np
 import pytest
 
 from loongcollector_amd import binding as B
@@ -217,6 +219,50 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
                 assert lit in v, (expanded[:60], lit, v)
     assert checked >= 2000 and screens >= 15 and rejected > 300, (checked, screens, rejected)
     assert relaxed_screens >= 15 and relaxed_only > 50, (relaxed_screens, relaxed_only)
+
+
+def test_literal_index_of_the_match_list(golden_dir):
+    """The required literals of the 50-entry list as one Aho-Corasick DFA (grok_literal_index.cpp; the device walks it once per
+    value: grok_literal_index_kernel): walked here exactly as the kernel does, bit p of the mask = "the value contains
+    Match[p]'s literal" (always set for an entry without one) -- for every entry and every corpus line, plus adversarial values
+    made of literal fragments (overlaps, a literal that is a suffix of another, repeated prefixes)."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    g = Grok(Match=cfg3["match"], CustomPatterns=cfg3["custom_patterns"], AnchoredFirst=False)
+    blob = g.literal_index()
+    assert blob is not None
+    raw = blob.view(np.uint8)
+    nstates, ncls, off_masks, off_table, always_lo, always_hi = [int(x) for x in blob[:6]]
+    cmap = raw[32:288]
+    masks = raw[off_masks:off_masks + 8 * nstates].view(np.uint64)
+    table = raw[off_table:off_table + 2 * nstates * ncls].view(np.uint16)
+    always = always_lo | (always_hi << 32)
+    lits = []
+    for i in range(g.n_match):
+        rx = B.GpuRegex(g.expanded(i).encode("utf-8"), syntax_flags=GROK_SYNTAX)
+        lits.append(rx.required_literal()[-32:])
+    assert sum(1 for l in lits if l) >= 40 and always == sum(1 << i for i, l in enumerate(lits) if not l)
+
+    def walk(v):
+        state, mask = 0, always
+        for b in v:
+            e = int(table[state * ncls + int(cmap[b])])
+            state = e & 0x7FFF
+            if e & 0x8000:
+                mask |= int(masks[state])
+        return mask
+    rng = random.Random(5)
+    frags = [l[a:b] for l in lits if l for a in range(0, len(l), 3) for b in (a + 1, a + 4, len(l))]
+    values = grok_lines(300) + [b"".join(rng.choice(frags) for _ in range(rng.randint(1, 12))) for _ in range(300)] + [b"", b" "]
+    hits = 0
+    for v in values:
+        m = walk(v)
+        for i, l in enumerate(lits):
+            want = (not l) or (l in v)
+            assert ((m >> i) & 1) == want, (i, l, v[:80])
+            hits += bool(l) and want
+    assert hits > 1000
 
 
 @pytest.mark.parametrize("name, classes, slots", [("HTTPD_ERRORLOG", 68, 32), ("HAPROXYHTTP", 73, 106),
