@@ -1074,6 +1074,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             lim.maxPathWork = anchoredSearch ? (32u << 20) : (4u << 20);
                             if (anchoredSearch) lim.maxStates = std::max<uint32_t>(lim.maxStates, 60000);
                             if (const char* v = getenv("LC_TDFA_L2_MAX_WORK")) lim.maxPathWork = uint64_t(atoll(v));
+                            if (const char* v = getenv("LC_TDFA_L2_MAX_COMMIT")) lim.maxCommitWork = uint64_t(atoll(v));
                             re->tdfa = buildTdfa(re->nfa, lim);
                         }
                         const size_t tableBytes = size_t(re->tdfa.nStates) * re->tdfa.nClasses * 4;

@@ -53,7 +53,7 @@ struct Cand {
 // pair tests of the redundancy elimination below, summed over one buildTdfa() call (reset there): the elimination is
 // cubic in the number of survivors of a step, and a configuration file must not be able to buy minutes of Init
 thread_local uint64_t tlsCommitWork = 0;
-constexpr uint64_t kMaxCommitWork = 20u << 20;  // 4x what the densest pattern that still fits needs (5.5 M)
+thread_local uint64_t kMaxCommitWork = 20u << 20;  // TdfaLimits::maxCommitWork of the construction in progress
 
 std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
     struct Closure {
@@ -493,6 +493,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     int maxRegs = 0;
     bool usedTmp = false;
     tlsCommitWork = 0;
+    kMaxCommitWork = limits.maxCommitWork;
     uint64_t pathWork = 0;  // epsilon paths looked at so far (a config-supplied pattern must not buy minutes of Init)
     std::vector<uint32_t> targetSeen(nfa.positions.size(), 0u);
     uint32_t seenStamp = 0;

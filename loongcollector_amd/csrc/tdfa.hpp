@@ -36,6 +36,9 @@ struct TdfaLimits {
     // epsilon paths the construction may look at: the densest automata that still fit a table (and the Grok monsters
     // that fail on maxStates) stay under 0.7 M; "(a?){200}a{200}" would spend minutes before failing on the table size
     uint64_t maxPathWork = 8u << 20;
+    // steps the ordered commit of atomic groups may take over the whole construction (4x what the densest pattern that still fits
+    // an LDS table needs)
+    uint64_t maxCommitWork = 20u << 20;
     // true: the transition table must also fit the 64 KiB LDS window of the lane-per-line kernels (rows of (classes+1) words)
     bool ldsWindow = true;
 };
