@@ -36,7 +36,8 @@ typedef struct lc_grok_result lc_grok_result_t;
  * "cannot build patterns because cyclic exist...", "Match[3]: tdfa: state limit exceeded; nfa: ..."). */
 int lc_grok_create(const char* config_json, size_t config_len, lc_grok_t** out, char* err, size_t errcap);
 void lc_grok_free(lc_grok_t* g);
-/* Entries that run on the NFA engine also get an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX: a tagged DFA with its tables
+/* (No reference counterpart: compileMatchs, processor_grok.go:335-359, compiles each entry once and that is all.)
+ * Entries that run on the NFA engine also get an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX: a tagged DFA with its tables
  * in L2), tried first on every value -- log formats match from the first byte.  Those automata take seconds to build, so they are
  * compiled behind lc_grok_create on a warm-up thread and join the matcher as they arrive; results never depend on them.  This call
  * returns once the thread is done (benchmarks; tests that want to pin which path runs).  Config key "AnchoredFirst": false = none. */

@@ -144,7 +144,9 @@ int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* b
  * ngroups = 0) need not be handed to the NFA engine.  NULL if no useful prefix exists.  Free with lc_regex_free. */
 lc_regex_t* lc_regex_compile_screen(const char* pattern, size_t pattern_len, uint32_t syntax_flags, uint32_t max_states,
                                     size_t max_table_bytes);
-/* A second screen, over the WHOLE pattern: captures, assertions and atomic brackets dropped, long counters opened, and every
+/* A second screen, over the WHOLE pattern (what stands in front of an entry of the Grok plugin's ordered Match loop,
+ * plugins/processor/grok/processor_grok.go:148-194, when the entry runs on the NFA engine -- the reference asks regexp2 for every
+ * (value, entry) pair, :156): captures, assertions and atomic brackets dropped, long counters opened, and every
  * sub-expression that is still too large replaced by "one of the bytes it can start with, then any of the bytes it can
  * contain" until the automaton fits.  The relaxed pattern matches wherever the pattern does, so what it rejects cannot match.
  * NULL if even the coarsest relaxation is too large or accepts the empty string.  Free with lc_regex_free. */
