@@ -1077,8 +1077,29 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             if (const char* v = getenv("LC_TDFA_L2_MAX_COMMIT")) lim.maxCommitWork = uint64_t(atoll(v));
                             re->tdfa = buildTdfa(re->nfa, lim);
                         }
+                        // (built without the window, MINIMISED, the automaton may fit the LDS kernels after all: dead stores gone,
+                        // the states of a search pattern's tail collapse -- CATALINALOG 1 410 -> 136 states)
+                        bool lds = false;
+                        if (outOfStates) {
+                            try {
+                                const bool fold = lcPickTdfaBlockAndFold(&*re);
+                                if (re->tdfaBlock) {
+                                    re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
+                                    re->tdfaWideBlob =
+                                        packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
+                                    re->hasTdfa = true;
+                                    re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
+                                                      re->tdfa.startState, 0, 0, 0};
+                                    lds = l2 = true;
+                                }
+                            } catch (const RegexError&) {
+                                re->tdfaBlob.clear();
+                                re->tdfaWideBlob.clear();
+                                re->hasTdfa = false;
+                            }
+                        }
                         const size_t tableBytes = size_t(re->tdfa.nStates) * re->tdfa.nClasses * 4;
-                        if (tableBytes <= (size_t(16) << 20) && size_t(re->tdfa.nRegs) * 64 * 4 <= 64 * 1024) {
+                        if (!lds && tableBytes <= (size_t(16) << 20) && size_t(re->tdfa.nRegs) * 64 * 4 <= 64 * 1024) {
                             re->tdfaL2Blob = packTdfaL2Blob(re->tdfa);
                             re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,
                                               re->tdfa.startState, 0, 0, 0};

@@ -146,6 +146,7 @@ TdfaTables buildScreenDfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     for (uint32_t s = 1; s < T.nStates; ++s)
         for (int p : states[s])
             if (accepts[size_t(p)]) T.finalId[s] = 0;
+    minimizeTdfaStates(T);
     return T;
 }
 

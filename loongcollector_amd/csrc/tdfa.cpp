@@ -413,6 +413,86 @@ static void eliminateDeadStores(TdfaTables& T) {
     }
 }
 
+// ---- state minimisation.  The subset construction tells states apart that behave alike: the same accepting row, and on every byte
+// class the same register program into states that again behave alike.  Moore's refinement finds the coarsest such partition and
+// one state per block is kept; register programs and final maps are compared by CONTENT, register names included, so nothing
+// about the captures changes.  Search patterns shrink most -- after the dead-store pass their tail states differ in nothing that
+// is ever read: CATALINALOG 1 410 -> 136 states (back inside the LDS window), TOMCATLOG 1 602 -> 338, the anchored CRONLOG
+// 2 223 -> 898; the headline regexes are minimal as built.
+void minimizeTdfaStates(TdfaTables& T) {
+    static const bool off = getenv("LC_TDFA_NO_MINIMIZE") != nullptr;  // (A/B measurements)
+    const uint32_t n = T.nStates, ncls = T.nClasses;
+    if (off || n <= 2) return;
+    // register programs by content
+    const size_t nLists = T.opsStart.size() - 1;
+    std::vector<uint32_t> canon(nLists, 0);
+    {
+        std::map<std::vector<uint16_t>, uint32_t> byContent;
+        byContent.emplace(std::vector<uint16_t>(), 0u);
+        for (size_t id = 1; id < nLists; ++id) {
+            const uint32_t at = T.opsStart[id];
+            std::vector<uint16_t> ops;
+            if (at < T.ops.size() && T.opsStart[id + 1] != at) ops.assign(T.ops.begin() + at + 1, T.ops.begin() + at + 1 + T.ops[at]);
+            canon[id] = byContent.emplace(ops, uint32_t(byContent.size())).first->second;
+        }
+    }
+    std::vector<uint32_t> block(n), next(n);
+    uint32_t nBlocks = 0;
+    {
+        std::map<uint32_t, uint32_t> byFinal;  // (final rows are interned by content when they are built)
+        for (uint32_t s = 0; s < n; ++s) block[s] = byFinal.emplace(uint32_t(T.finalId[s]), uint32_t(byFinal.size())).first->second;
+        nBlocks = uint32_t(byFinal.size());
+    }
+    struct VecHash {
+        size_t operator()(const std::vector<uint32_t>& v) const {
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t x : v) h = (h ^ x) * 1099511628211ull;
+            return size_t(h);
+        }
+    };
+    std::vector<uint32_t> sig(1 + 2 * size_t(ncls));
+    for (;;) {
+        std::unordered_map<std::vector<uint32_t>, uint32_t, VecHash> ids;
+        ids.reserve(size_t(nBlocks) * 2);
+        for (uint32_t s = 0; s < n; ++s) {
+            sig[0] = block[s];
+            for (uint32_t c = 0; c < ncls; ++c) {
+                const uint32_t e = T.trans[size_t(s) * ncls + c];
+                sig[1 + 2 * c] = block[e & 0xFFFF];
+                sig[2 + 2 * c] = canon[e >> 16];
+            }
+            next[s] = ids.emplace(sig, uint32_t(ids.size())).first->second;
+        }
+        const uint32_t count = uint32_t(ids.size());
+        block.swap(next);
+        if (count == nBlocks) break;
+        nBlocks = count;
+    }
+    if (nBlocks == n) return;
+    // one state per block, in order of first appearance (the dead state stays state 0)
+    std::vector<uint32_t> newId(nBlocks, 0xFFFFFFFFu), rep;
+    for (uint32_t s = 0; s < n; ++s)
+        if (newId[block[s]] == 0xFFFFFFFFu) {
+            newId[block[s]] = uint32_t(rep.size());
+            rep.push_back(s);
+        }
+    auto map = [&](uint32_t s) { return newId[block[s]]; };
+    std::vector<uint32_t> trans(rep.size() * size_t(ncls));
+    std::vector<uint16_t> finalId(rep.size());
+    for (size_t k = 0; k < rep.size(); ++k) {
+        finalId[k] = T.finalId[rep[k]];
+        for (uint32_t c = 0; c < ncls; ++c) {
+            const uint32_t e = T.trans[size_t(rep[k]) * ncls + c];
+            trans[k * ncls + c] = map(e & 0xFFFF) | (e & 0xFFFF0000u);
+        }
+    }
+    T.startState = map(T.startState);
+    for (auto& st : T.startAfter) st = map(st);
+    T.trans.swap(trans);
+    T.finalId.swap(finalId);
+    T.nStates = uint32_t(rep.size());
+}
+
 TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     const int npos = int(nfa.positions.size());
     const int nslots = nfa.slotCount();
@@ -651,6 +731,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     }
     if (T.finalMap.empty()) T.finalMap.assign(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
     eliminateDeadStores(T);
+    minimizeTdfaStates(T);
     return T;
 }
 

@@ -46,6 +46,10 @@ struct TdfaLimits {
 // Throws RegexError("tdfa: ...") when the automaton exceeds the limits (caller falls back to the NFA engine).
 TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits());
 
+// tdfa.cpp: merges states that behave alike (same final row, same register programs into equivalent states); buildTdfa and
+// buildScreenDfa end with it
+void minimizeTdfaStates(TdfaTables& tables);
+
 // screen_dfa.cpp: plain yes/no DFA (no registers, no thread order) for a pattern without assertions and atomic groups; positions
 // that can only reach MATCH through a universal loop (?s:.)* that is already alive are forgotten, so "X.*Y.*Z" costs the sum, not
 // the product, of its parts.  Same table format (one empty register program); throws RegexError on the limits.
