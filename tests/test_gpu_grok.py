@@ -202,7 +202,7 @@ def test_relaxed_screens_on_the_device(torch_dev, golden_dir):
         scr = B.GpuRegex.compile_screen(pat, syntax_flags=GROK_SYNTAX & ~B.LC_SYNTAX_SEARCH, max_states=20000,
                                         max_table_bytes=2 << 20, relaxed=True)
         assert scr is not None, name
-        big += scr.info()["states"] > 1000
+        big += scr.info()["states"] > 100        # (950 - 17 000 states as built; 120 - 300 once minimised)
         it = TdfaInterp(scr)
         want = np.array([it.fullmatch(v) is not None for v in values])
         for lines, d_lines in ((np.arange(len(values)), None), (subset, d_subset)):
@@ -218,7 +218,7 @@ def test_relaxed_screens_on_the_device(torch_dev, golden_dir):
         for v, w in zip(values[::5], want[::5]):
             assert w or o.search(v) is None, (name, v)
         rejected_total += int((~want).sum())
-    assert big >= 3 and rejected_total > 2500 and "dfa_screen_kernel" in B.launched_kernels()
+    assert big >= 5 and rejected_total > 2500 and "dfa_screen_kernel" in B.launched_kernels()
 
 
 @pytest.mark.parametrize("name", ["HTTPD_ERRORLOG", "HAPROXYHTTP", "SYSLOGPAMSESSION", "NAGIOSLOGLINE"])
