@@ -451,7 +451,14 @@ void minimizeTdfaStates(TdfaTables& T) {
         }
     };
     std::vector<uint32_t> sig(1 + 2 * size_t(ncls));
-    for (;;) {
+    // Moore's refinement needs as many rounds as the longest string that tells two states apart: tens for a log format, but n for a
+    // chain ("(?i)" + 5 000 letters: n^2 work).  A pattern comes from a configuration file and Init must answer quickly: past 400
+    // rounds or this much work the automaton simply stays as it was built.
+    uint64_t budget = uint64_t(1) << 30;
+    for (int rounds = 0;; ++rounds) {
+        const uint64_t round = uint64_t(n) * (1 + 2 * uint64_t(ncls));
+        if (round > budget || rounds >= 400) return;
+        budget -= round;
         std::unordered_map<std::vector<uint32_t>, uint32_t, VecHash> ids;
         ids.reserve(size_t(nBlocks) * 2);
         for (uint32_t s = 0; s < n; ++s) {
