@@ -221,6 +221,37 @@ def test_prefix_screens_and_required_literals_are_necessary_conditions(golden, g
     assert relaxed_screens >= 15 and relaxed_only > 50, (relaxed_screens, relaxed_only)
 
 
+def test_tail_restamps_are_dead_stores_and_tail_states_collapse(golden_dir):
+    """tdfa.cpp eliminateDeadStores + minimizeTdfaStates on a Grok format with a GREEDYDATA tail (CATALINALOG, a search pattern): as
+    built, 95 % of the bytes of a matching line run a register program (the thread that would take over if the field ended here is
+    re-derived, and re-stamped, at every byte) and the automaton has 1 410 states; none of those stamps is ever read.  After the two
+    passes under 5 % of the bytes carry a program and the automaton fits the LDS window again -- with the same captures
+    (test_regex_module_golden_vectors_on_the_tables and the GPU suite compare those)."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    lib = Grok(CustomPatterns=cfg3["custom_patterns"])
+    pat = lib.denormalize("%{CATALINALOG}").encode("utf-8")
+    rx = B.GpuRegex(pat, syntax_flags=GROK_SYNTAX, engine=B.LC_ENGINE_TDFA)
+    assert rx.info()["states"] <= 200 and rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32) is not None     # (LDS kernels, not L2)
+    it = TdfaInterp(rx)
+    lit = rx.required_literal()
+    steps = programs = matched = 0
+    for v in grok_lines(600):
+        if lit not in v:
+            continue
+        state = it.start
+        for b in v:
+            t = int(it.trans[state * it.ncls + int(it.cmap[b])])
+            steps += 1
+            programs += (t >> 16) != 0
+            state = t & 0xFFFF
+            if state == 0:
+                break
+        matched += state != 0 and int(it.final_id[state]) != 0xFFFF
+    assert matched >= 10 and steps > 10000 and programs < 0.05 * steps, (matched, steps, programs)
+
+
 def test_literal_index_of_the_match_list(golden_dir):
     """The required literals of the 50-entry list as one Aho-Corasick DFA (grok_literal_index.cpp; the device walks it once per
     value: grok_literal_index_kernel): walked here exactly as the kernel does, bit p of the mask = "the value contains

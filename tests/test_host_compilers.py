@@ -133,6 +133,41 @@ def test_search_mode_tables_reproduce_every_search_vector(golden_dir):
     assert not bad, bad[:5]
 
 
+def test_resumed_searches_on_the_logical_and_the_packed_tables(golden_dir):
+    """lc_regex_match_device_from: a search RESUMED inside the line starts in the state "only the wrapper's prefix thread is
+    alive and the previous byte had class c" (startAfter).  The logical tables, the packed blobs (LDS kernels or the
+    global-memory kernel) and the NFA program -- after dead-store elimination and state minimisation -- against the oracle's
+    search from that offset (look-behinds see the byte before it)."""
+    from oracle.oracle import OracleRegex
+    from tests.helpers.table_interp import packed_tdfa_interp
+    with open(os.path.join(golden_dir, "regex_search_golden.json")) as f:
+        d = json.load(f)
+    rng = __import__("random").Random(11)
+    n = hits = 0
+    for c in d["cases"][::3]:
+        p = c["p"].encode("latin-1")
+        try:
+            rx = B.GpuRegex(p, syntax_flags=B.LC_SYNTAX_SEARCH)
+            o = OracleRegex(p)
+        except (B.RegexUnsupportedError, ValueError):
+            continue
+        interps = [NfaInterp(rx)] if rx.has_nfa_program() else []
+        if rx.info()["engine"] == B.LC_ENGINE_TDFA:
+            interps += [TdfaInterp(rx), packed_tdfa_interp(rx)]
+        for subj, _ in c["subs"][:6]:
+            s = subj.encode("latin-1")
+            for start in {0, 1, len(s) // 2, max(0, len(s) - 1), len(s)} if s else {0}:
+                if start > len(s):
+                    continue
+                exp = o.search(s, start)
+                want = None if exp is None else [v for ab in exp for v in ab]
+                hits += exp is not None
+                for it in interps:
+                    n += 1
+                    assert it.fullmatch(s, start=start) == want, (c["p"], s, start, type(it).__name__)
+    assert n > 3000 and hits > 400, (n, hits)
+
+
 def test_anchored_search_is_the_search_whose_match_starts_at_the_first_byte(golden_dir):
     """LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX compiles (re)(?s:.*) with the search's group layout.  On every search vector: when the
     search's match starts at byte 0 the anchored search reports exactly that match -- same captures --, otherwise (later start, or
