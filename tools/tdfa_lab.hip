@@ -6,6 +6,7 @@
 //   python tools/tdfa_lab_inputs.py gpurun_out/lab_inputs.bin && scratch/tdfa_lab gpurun_out/lab_inputs.bin
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -163,6 +164,15 @@ static double runVariant(const char* name, const Inputs& in, const Dev& d, std::
     }
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
+    {  // clock ramp, like bench.py's: without it the first variants run at idle clocks and the lab reads ~15 % slow (round 2: the
+       // product measured 0.219 ms in bench.py and under rocprofv3 where the lab said 0.255 for the same kernel)
+        static const double rampS = getenv("LAB_RAMP_S") ? atof(getenv("LAB_RAMP_S")) : 0.2;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < rampS) {
+            for (int i = 0; i < 8; ++i) launch();
+            CK(hipDeviceSynchronize());
+        }
+    }
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
