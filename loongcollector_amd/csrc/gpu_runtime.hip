@@ -1452,8 +1452,15 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t r
             if (trace) traceLine += " literal " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
         }
         // ... and a match of the pattern's prefix, then of the relaxed whole pattern (fast TDFA kernel, status only)
+        // (the relaxed screen rejects nearly everything the prefix screen rejects, and each pass costs a launch and a counter read,
+        // ~0.25 ms: the prefix screen only goes first where it saves the relaxed one a large candidate set -- LC_GROK_PREFIX_ABOVE)
+        static const uint32_t prefixAbove = [] {
+            const char* e = getenv("LC_GROK_PREFIX_ABOVE");
+            return uint32_t(e ? atoi(e) : 65536);
+        }();
         for (lc_regex* scr : {gp.screen, gp.relaxed}) {
             if (!scr || !nIn) continue;
+            if (scr == gp.screen && gp.relaxed && nIn <= prefixAbove) continue;
             uint32_t* out = in == outs[0] ? outs[1] : outs[0];
             if (!scr->screenBlob.empty()) {  // a plain DFA with its table in L2: screens and filters in one kernel
                 int rc = lcScreenOnStream(scr, dev, d_data, d_off, d_len, nIn, in, out, counters, st);
