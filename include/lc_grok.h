@@ -68,19 +68,29 @@ int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per c
 /* ---- device-resident batch (inputs and outputs in HBM; nothing is copied) ------------------------------------------
  * d_off/d_len: uint32[n] byte offsets / lengths of the SourceKey values inside d_data.
  * d_pattern  int32[n]            winning Match index, -1 = matchFail, -2 = undecidable on the device (the NFA engine ran out
- *                                of threads on this value: more than 128 live at once, 64 for a pattern with atomic groups)
+ *                                of threads on this value and nothing settled it), -3 = an entry gave up on the value (the
+ *                                decide kernel ran out of budget: the reference's matchTimeOut, processor_grok.go:156-160 --
+ *                                no further entry is tried, the value counts as a failed parse)
  * d_first    int32[n][row]       capture row of the FIRST match that contributed a non-empty named capture:
  *                                [whole.b, whole.e, col0.b, col0.e, ...], -1 = column did not take part
  * d_extra    int32[cap][2+row]   further contributing matches of the same value (FindNextMatch): [line, seq>=1, row...]
  * d_nextra   uint32[1]           rows written to d_extra; > cap means d_extra was too small (LC_ERR_OVERFLOW is returned
  *                                and the call must be repeated with a larger d_extra)
  * d_scratch  lc_grok_scratch_bytes(g, n) bytes
- * The call enqueues on `stream` but synchronises with the host between rounds (it has to learn how many values are still
- * in play); it returns after the last kernel has finished. */
+ * The call enqueues on `stream` (and on a few worker streams of its own that fork from it and join it) and returns after the
+ * last kernel has finished.  Default path: TWO host synchronisations per batch (candidates per entry; results) -- the number of
+ * values still in play after each search round stays on the device; an entry that needs more rounds than it queued ahead costs
+ * one more per extra round, once (csrc/grok_device.hip).  Config key "Speculative": false (or a list of more than 64 entries)
+ * selects the sequential walk of the list with a host round trip per filter / screen / round. */
 size_t lc_grok_scratch_bytes(const lc_grok_t* g, uint32_t n);
 int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
                          int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extra_cap, uint32_t* d_nextra,
                          void* d_scratch, size_t scratch_bytes, void* stream);
+
+/* what the calling thread's last lc_grok_match_device / lc_grok_match_host batch did:
+ * out[0] host synchronisations, [1] Match entries with at least one candidate, [2] (entry, value) pairs evaluated,
+ * [3] entries that needed more rounds than queued ahead, [4] 1 = speculative path */
+void lc_grok_last_batch_stats(uint32_t out[5]);
 
 /* ---- host batch: copies in, matches on the device, returns the fields of every value in emission order --------------- */
 int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,

@@ -26,8 +26,8 @@
 #include <vector>
 
 #include "device_tables.h"
-#include "grok_kernel.hpp"
 #include "grok_runtime.hpp"
+#include "runtime_internal.hpp"
 #include "nfa_kernel.hpp"
 #include "nfa_wide_kernel.hpp"
 #include "nfa_decide_kernel.hpp"
@@ -51,11 +51,16 @@ static int hipFail(hipError_t e, const char* what) {
     } while (0)
 
 extern "C" const char* lc_last_error(void) { return tlsError.c_str(); }
+// (runtime_internal.hpp: the other device translation units report through the same thread-local string)
+void lcSetLastError(const std::string& msg) { tlsError = msg; }
+int lcHipFail(hipError_t e, const char* what) { return hipFail(e, what); }
 
 // Names of the match kernels the calling thread launched since it last asked (smoke() prints them, so that the GPU-box log
 // shows which native code ran; not a profiler: names only, duplicates folded, capped)
 static thread_local std::string tlsKernelLog;
-static void noteKernel(const char* name) {
+void lcNoteKernel(const char* name);
+static void noteKernel(const char* name) { lcNoteKernel(name); }
+void lcNoteKernel(const char* name) {
     if (tlsKernelLog.size() > 512 || tlsKernelLog.find(name) != std::string::npos) return;
     if (!tlsKernelLog.empty()) tlsKernelLog += ", ";
     tlsKernelLog += name;
@@ -77,11 +82,11 @@ extern "C" size_t lc_launched_kernels(char* buf, size_t cap) {
 // lc_thread_release() frees the calling thread's resources explicitly; a host that recycles runner threads calls it.
 static std::atomic<bool> gProcessExiting{false};
 static void lcMarkExiting() { gProcessExiting.store(true); }
-static void lcRegisterExitHook() {
+void lcRegisterExitHook() {
     static std::once_flag once;
     std::call_once(once, [] { atexit(lcMarkExiting); });
 }
-static bool lcRuntimeUsable() { return !gProcessExiting.load(); }
+bool lcRuntimeUsable() { return !gProcessExiting.load(); }
 
 extern "C" int lc_device_count(void) {
     // (a positive answer does not change during the process's life: every match call asks, from every runner thread, and a
@@ -296,7 +301,12 @@ struct DecidePool {
         used = false;
     }
 };
-thread_local DecidePool tlsDecidePool;
+// One pool per STREAM SLOT of the thread: slot 0 for ordinary calls; the Grok matcher runs its entries on a few worker streams
+// (grok_device.hip) and selects slot 1.. before it queues an entry's launches, so that entries on different streams do not
+// wait for each other's decide launches.  Worker pools are a quarter of the size; all are allocated on first use.
+constexpr int kDecideSlots = 9;
+thread_local DecidePool tlsDecidePools[kDecideSlots];
+thread_local int tlsDecideSlot = 0;
 
 std::atomic<int> gNfaDfsMode{-1};  // -1: LC_NFA_DFS decides; 0 / 1: set by lc_nfa_set_dfs
 
@@ -333,9 +343,10 @@ size_t decidePoolBytes() {
         if (mb < 8) mb = 8;
         return size_t(mb) << 20;
     }();
-    return v;
+    return tlsDecideSlot == 0 ? v : std::max<size_t>(v / 4, size_t(8) << 20);
 }
 }  // namespace
+void lcSetDecideSlot(int slot) { tlsDecideSlot = slot >= 0 && slot < kDecideSlots ? slot : 0; }
 
 // The thread-list kernels of this launch may have left lines LC_OVERFLOW: settle them (plan + walk, both no-ops unless the
 // overflow flag carries this launch's sequence number).
@@ -345,7 +356,7 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
                         uint32_t seq, bool forced = false) {
     static const bool off = getenv("LC_NFA_NO_DECIDE") != nullptr;
     if (off && !forced) return LC_OK;
-    DecidePool& pool = tlsDecidePool;
+    DecidePool& pool = tlsDecidePools[tlsDecideSlot];
     lcRegisterExitHook();
     if (pool.device != dev || !pool.p) {
         pool.release();
@@ -558,6 +569,13 @@ __global__ __launch_bounds__(256) void run_capture_kernel(const uint8_t* __restr
         ++e;
     }
     c[1] = int32_t(e);
+}
+
+int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out) {
+    void* p = nullptr;
+    int rc = ensureUploaded(re, dev, kBlobScreen, &p);
+    *out = static_cast<const uint32_t*>(p);
+    return rc;
 }
 
 int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
@@ -913,7 +931,6 @@ extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, cons
 }
 
 // ------------------------------------------------------------------------------------------------ host batches
-static void lcGrokThreadRelease();
 namespace {
 
 // Completion of a zero-copy batch is signalled by the GPU itself: a one-lane kernel queued behind the match kernels stores the
@@ -1240,7 +1257,7 @@ extern "C" void lc_thread_release(void) {
     tlsDfsPool.release();
     if (tlsPipe) tlsPipe->release();
     tlsJobTables.release();
-    tlsDecidePool.release();
+    for (auto& pool : tlsDecidePools) pool.release();
     lcGrokThreadRelease();
 }
 
@@ -1262,16 +1279,18 @@ extern "C" int lc_dfs_stats(uint64_t lines[2]) {
 
 extern "C" int lc_decide_stats(uint64_t lines[2]) {
     if (!lines) return LC_ERR_ARG;
-    DecidePool& pool = tlsDecidePool;
     lines[0] = lines[1] = 0;
-    if (!pool.p || !pool.used) return LC_OK;
-    // (per-launch numbers live in the pool header; a caller that wants them per batch calls this after each batch)
-    HIP_TRY(hipSetDevice(pool.device));
-    HIP_TRY(hipEventSynchronize(pool.lastUse));
-    DecidePlan plan;
-    HIP_TRY(hipMemcpy(&plan, pool.p, sizeof plan, hipMemcpyDeviceToHost));
-    lines[0] = plan.count;
-    lines[1] = plan.gaveUp;
+    // (per-launch numbers live in the pool headers; a caller that wants them per batch calls this after each batch.  Summed over
+    // the thread's stream slots: the Grok matcher spreads its entries over several)
+    for (DecidePool& pool : tlsDecidePools) {
+        if (!pool.p || !pool.used) continue;
+        HIP_TRY(hipSetDevice(pool.device));
+        HIP_TRY(hipEventSynchronize(pool.lastUse));
+        DecidePlan plan;
+        HIP_TRY(hipMemcpy(&plan, pool.p, sizeof plan, hipMemcpyDeviceToHost));
+        lines[0] += plan.count;
+        lines[1] += plan.gaveUp;
+    }
     return LC_OK;
 }
 
@@ -1298,374 +1317,3 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
     return runHostPipeline(re, src, n, ngroups, caps, status);
 }
 
-// ------------------------------------------------------------------------------------------------ Grok matcher
-// Batch form of ProcessorGrok.processGrok (processor_grok.go:148-194); the control flow is described in grok_kernel.hpp.
-// Scratch layout: caps int32[n][row] | status u8[n] (padded) | from, nmatch, tried, next, roundA, roundB : u32[n] each |
-// counters u32[4].
-namespace {
-size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
-}  // namespace
-
-size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
-    const size_t m = n ? n : 1;
-    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 512 + alignUp(m * 8, 256);
-}
-
-// ---- the literal index of a Match list (grok_kernel.hpp grok_literal_index_kernel): built the first time the list is seen,
-// kept per (literals, device) for the life of the process (a few hundred KB at most per distinct list)
-namespace {
-struct GrokLiteralIndexCache {
-    std::mutex m;
-    std::map<std::pair<int, std::vector<std::string>>, void*> dev;  // (device, literals) -> device blob (nullptr: not indexable)
-};
-GrokLiteralIndexCache gGrokLiteralIndex;
-
-// device blob of the list's literal index, or nullptr (more than 64 entries, no literal at all, automaton too large)
-int grokLiteralIndex(const std::vector<GrokDevicePattern>& patterns, int dev, const uint32_t** out) {
-    *out = nullptr;
-    static const bool off = getenv("LC_GROK_NO_LITERAL_INDEX") != nullptr;
-    if (off || patterns.size() > 64) return LC_OK;
-    std::vector<std::string> lits;
-    size_t withLiteral = 0;
-    for (const auto& gp : patterns) {
-        lits.push_back(lcGrokLiteralOf(gp.re));
-        withLiteral += !lits.back().empty();
-    }
-    if (withLiteral < 2) return LC_OK;
-    std::lock_guard<std::mutex> g(gGrokLiteralIndex.m);
-    auto key = std::make_pair(dev, lits);
-    auto it = gGrokLiteralIndex.dev.find(key);
-    if (it == gGrokLiteralIndex.dev.end()) {
-        void* p = nullptr;
-        const std::vector<uint32_t> blob = lcBuildGrokLiteralBlob(lits);
-        if (!blob.empty()) {
-            HIP_TRY(hipMalloc(&p, blob.size() * 4));
-            const hipError_t e = hipMemcpy(p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                (void)hipFree(p);
-                return hipFail(e, "hipMemcpy(literal index)");
-            }
-        }
-        it = gGrokLiteralIndex.dev.emplace(std::move(key), p).first;
-    }
-    *out = static_cast<const uint32_t*>(it->second);
-    return LC_OK;
-}
-}  // namespace
-
-int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* d_data,
-                      const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern, int32_t* d_first,
-                      int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch, size_t scratchBytes,
-                      void* streamPtr) {
-    if (n == 0) return LC_OK;
-    if (!d_data || !d_off || !d_len || !d_pattern || !d_first || !d_nextra || !d_scratch || (extraCap && !d_extra))
-        return LC_ERR_ARG;
-    if (scratchBytes < lcGrokScratchBytes(n, row)) {
-        tlsError = "grok: scratch buffer too small";
-        return LC_ERR_ARG;
-    }
-    if (lc_device_count() <= 0) {
-        tlsError = "no HIP device";
-        return LC_ERR_NO_DEVICE;
-    }
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
-    hipStream_t st = static_cast<hipStream_t>(streamPtr);
-
-    uint8_t* base = static_cast<uint8_t*>(d_scratch);
-    int32_t* caps = reinterpret_cast<int32_t*>(base);
-    base += alignUp(size_t(n) * row * 4, 256);
-    uint8_t* status = base;
-    base += alignUp(n, 256);
-    uint32_t* lists[7];
-    for (auto& l : lists) {
-        l = reinterpret_cast<uint32_t*>(base);
-        base += alignUp(size_t(n) * 4, 256);
-    }
-    uint32_t *from = lists[0], *nmatch = lists[1], *tried = lists[2], *next = lists[3], *roundIn = lists[4],
-             *roundOut = lists[5], *unanchored = lists[6];
-    uint32_t* counters = reinterpret_cast<uint32_t*>(base);
-    base += 256;
-    uint32_t* perPattern = reinterpret_cast<uint32_t*>(base);  // [64]: values that carry each entry's literal (literal index pass)
-    base += 256;
-    uint64_t* masks = reinterpret_cast<uint64_t*>(base);
-
-    const uint32_t gridAll = (n + kGrokBlock - 1) / kGrokBlock;
-    hipLaunchKernelGGL(grok_init_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, n, d_pattern, tried, from, nmatch);
-    // which Match entries' required literals each value contains: one pass for the whole list
-    const uint32_t* literalIndex = nullptr;
-    {
-        int rc = grokLiteralIndex(patterns, dev, &literalIndex);
-        if (rc != LC_OK) return rc;
-    }
-    std::vector<uint32_t> carriers;  // per entry: values of the batch that carry its literal (empty: no index)
-    if (literalIndex) {
-        HIP_TRY(hipMemsetAsync(perPattern, 0, 256, st));
-        hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex,
-                           masks, uint32_t(patterns.size()), perPattern);
-        carriers.resize(64);
-        HIP_TRY(hipMemcpyAsync(carriers.data(), perPattern, 256, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
-    HIP_TRY(hipMemsetAsync(counters, 0, 16, st));
-
-    uint32_t nTried = n;
-    uint32_t host[4] = {0, 0, 0, 0};
-    // LC_GROK_TRACE=1: one stderr line per Match entry -- values tried / with the literal / past the screen, then (values, ms)
-    // per search round (the host waits for a counter after every step anyway, so the clock reads are exact)
-    static const bool trace = getenv("LC_GROK_TRACE") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto msSince = [&](std::chrono::steady_clock::time_point t0) {
-        return std::chrono::duration<double, std::milli>(now() - t0).count();
-    };
-    for (size_t p = 0; p < patterns.size() && nTried; ++p) {
-        const GrokDevicePattern& gp = patterns[p];
-        // no value of the batch carries this entry's literal: it cannot match anything, and an entry that matches nothing
-        // leaves every list as it is
-        if (!carriers.empty() && carriers[p] == 0) continue;
-        auto tPattern = now();
-        std::string traceLine;
-        if (trace) traceLine = "grok[" + std::to_string(p) + "] engine " + std::to_string(gp.re->engine) + " tried " + std::to_string(nTried);
-        const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte ...
-        uint32_t nIn = nTried;
-        uint32_t* outs[2] = {roundIn, roundOut};
-        int flip = 0;
-        if (!gp.re->requiredLiteral.empty()) {  // ... that contains the literal every match of this pattern must contain
-            GrokLiteral lit;
-            const std::string& s = gp.re->requiredLiteral;
-            lit.len = uint32_t(std::min<size_t>(s.size(), sizeof lit.bytes));
-            std::memcpy(lit.bytes, s.data() + (s.size() - lit.len), lit.len);
-            const uint32_t perBlock = kGrokBlock / 64;
-            if (literalIndex)
-                hipLaunchKernelGGL(grok_mask_filter_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
-                                   nTried, masks, uint32_t(p), outs[1], counters);
-            else
-                hipLaunchKernelGGL(grok_literal_filter_kernel, dim3((nTried + perBlock - 1) / perBlock), dim3(kGrokBlock), 0, st,
-                                   tried, nTried, d_data, d_off, d_len, lit, outs[1], counters);
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            nIn = host[0];
-            in = outs[1];
-            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
-            if (trace) traceLine += " literal " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
-        }
-        // ... and a match of the pattern's prefix, then of the relaxed whole pattern (fast TDFA kernel, status only)
-        // (the relaxed screen rejects nearly everything the prefix screen rejects, and each pass costs a launch and a counter read,
-        // ~0.25 ms: the prefix screen only goes first where it saves the relaxed one a large candidate set -- LC_GROK_PREFIX_ABOVE)
-        static const uint32_t prefixAbove = [] {
-            const char* e = getenv("LC_GROK_PREFIX_ABOVE");
-            return uint32_t(e ? atoi(e) : 65536);
-        }();
-        for (lc_regex* scr : {gp.screen, gp.relaxed}) {
-            if (!scr || !nIn) continue;
-            if (scr == gp.screen && gp.relaxed && nIn <= prefixAbove) continue;
-            uint32_t* out = in == outs[0] ? outs[1] : outs[0];
-            if (!scr->screenBlob.empty()) {  // a plain DFA with its table in L2: screens and filters in one kernel
-                int rc = lcScreenOnStream(scr, dev, d_data, d_off, d_len, nIn, in, out, counters, st);
-                if (rc != LC_OK) return rc;
-            } else {
-                int rc = lcMatchOnStream(scr, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
-                                         status, st);
-                if (rc != LC_OK) return rc;
-                hipLaunchKernelGGL(grok_status_filter_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st,
-                                   in, nIn, status, out, counters);
-            }
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            nIn = host[0];
-            in = out;
-            flip = in == outs[0] ? 1 : 0;
-            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
-            if (trace)
-                traceLine += std::string(scr == gp.screen ? " screen " : " relaxed ") + std::to_string(nIn) + " (" +
-                             std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
-        }
-        // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
-        const uint32_t capsRow = 2 * (gp.columns + 1);
-        // one search round over the values listed in `list`: the pattern's kernel, then grok_advance_kernel (matches recorded,
-        // values that stay in play appended to `out`, their number added to counters[0])
-        auto searchRound = [&](lc_regex* re, const uint32_t* list, uint32_t nList, const uint32_t* resume, uint32_t* out) -> int {
-            int rc = lcMatchOnStream(re, re->engine, dev, d_data, d_off, d_len, 0, nList, nullptr, list, resume, capsRow / 2, caps,
-                                     status, st);
-            if (rc != LC_OK) return rc;
-            hipLaunchKernelGGL(grok_advance_kernel, dim3((nList + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, list, nList,
-                               status, caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out,
-                               counters);
-            return LC_OK;
-        };
-        if (gp.anchored && nIn) {
-            // Round 0 searches every value from its first byte, and a log format matches FROM the first byte: the anchored search
-            // (a tagged DFA, tables in L2, one value per lane) finds exactly what the search would find whenever the search's
-            // leftmost match starts at byte 0; the values it does not match go to the search proper (their match, if any, starts
-            // later).  Both append to the same next-round list.
-            auto tRound = now();
-            uint32_t* out = outs[flip];
-            int rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, capsRow / 2,
-                                     caps, status, st);
-            if (rc != LC_OK) return rc;
-            hipLaunchKernelGGL(grok_unmatched_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
-                               unanchored, counters + 3);
-            hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
-                               caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out, counters);
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            const uint32_t nRest = host[3];
-            HIP_TRY(hipMemsetAsync(counters + 3, 0, 4, st));
-            if (trace)
-                traceLine += " anchored " + std::to_string(nIn) + " -> rest " + std::to_string(nRest) + " (" +
-                             std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
-            if (nRest) {
-                auto tRest = now();
-                rc = searchRound(gp.re, unanchored, nRest, from, out);
-                if (rc != LC_OK) return rc;
-                HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (trace) traceLine += " round " + std::to_string(nRest) + " (" + std::to_string(msSince(tRest)).substr(0, 7) + " ms)";
-            }
-            nIn = host[0];
-            in = out;
-            flip ^= 1;
-            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
-        }
-        while (nIn) {
-            auto tRound = now();
-            const uint32_t roundValues = nIn;
-            uint32_t* out = outs[flip];
-            int rc = searchRound(gp.re, in, nIn, from, out);
-            if (rc != LC_OK) return rc;
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            nIn = host[0];
-            in = out;
-            flip ^= 1;
-            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));  // counters[0] only; the extra-row count keeps running
-            if (trace) traceLine += " round " + std::to_string(roundValues) + " (" + std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
-        }
-        hipLaunchKernelGGL(grok_finish_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
-                           nTried, int32_t(p), nmatch, d_pattern, from, next, counters);
-        HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (trace) fprintf(stderr, "%s settled %u total %.3f ms\n", traceLine.c_str(), nTried - host[2], msSince(tPattern));
-        nTried = host[2];
-        std::swap(tried, next);
-        HIP_TRY(hipMemsetAsync(counters + 2, 0, 4, st));
-    }
-    HIP_TRY(hipMemcpyAsync(d_nextra, counters + 1, 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    if (host[1] > extraCap) {
-        tlsError = "grok: " + std::to_string(host[1]) + " extra match rows needed, buffer holds " + std::to_string(extraCap);
-        return LC_ERR_OVERFLOW;
-    }
-    return LC_OK;
-}
-
-// device buffers of a thread that calls lcGrokMatchHost: grow-only, kept between calls (ProcessLogs hands over group after group)
-namespace {
-struct GrokDev {
-    void* p = nullptr;
-    size_t cap = 0;
-    int device = -1;
-    ~GrokDev() { release(); }
-    void release() {
-        if (p && lcRuntimeUsable()) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        device = -1;
-    }
-    hipError_t ensure(size_t bytes, int dev) {
-        if (p && device == dev && cap >= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = bytes + (bytes >> 2) + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) {
-            cap = want;
-            device = dev;
-        }
-        return e;
-    }
-};
-struct GrokThreadBuffers {
-    GrokDev b[8];
-};
-thread_local GrokThreadBuffers tlsGrokBuffers;
-}  // namespace
-static void lcGrokThreadRelease() {
-    for (auto& d : tlsGrokBuffers.b) d.release();
-}
-
-int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, uint32_t row, const uint8_t* data, const uint32_t* off,
-                    const uint32_t* len, uint32_t n, int32_t* pattern, std::vector<int32_t>& first,
-                    std::vector<int32_t>& extraRows) {
-    first.clear();
-    extraRows.clear();
-    if (n == 0) return LC_OK;
-    if (lc_device_count() <= 0) {
-        tlsError = "no HIP device";
-        return LC_ERR_NO_DEVICE;
-    }
-    // pack the values back to back (they may come from anywhere in `data`)
-    std::vector<uint32_t> hOff(n);
-    size_t bytes = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        hOff[i] = uint32_t(bytes);
-        bytes += len[i];
-    }
-    if (bytes > 0xFFFFFFF0ull) return LC_ERR_ARG;
-    std::vector<uint8_t> hData(bytes + 16);
-    for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
-
-    GrokThreadBuffers& gb = tlsGrokBuffers;
-    lcRegisterExitHook();
-    GrokDev &dData = gb.b[0], &dOff = gb.b[1], &dLen = gb.b[2], &dPattern = gb.b[3], &dFirst = gb.b[4], &dExtra = gb.b[5], &dNextra = gb.b[6], &dScratch = gb.b[7];
-    int devNo = 0;
-    HIP_TRY(hipGetDevice(&devNo));
-    const size_t scratch = lcGrokScratchBytes(n, row);
-    uint32_t extraCap = n / 4 + 1024;
-    HIP_TRY(dData.ensure(bytes + 16, devNo));
-    HIP_TRY(dOff.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dLen.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dPattern.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dFirst.ensure(size_t(n) * row * 4, devNo));
-    HIP_TRY(dNextra.ensure(4, devNo));
-    HIP_TRY(dScratch.ensure(scratch, devNo));
-    HIP_TRY(hipMemcpy(dData.p, hData.data(), bytes + 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dOff.p, hOff.data(), size_t(n) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dLen.p, len, size_t(n) * 4, hipMemcpyHostToDevice));
-    uint32_t nExtra = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(dExtra.ensure(size_t(extraCap) * (row + 2) * 4, devNo));
-        int rc = lcGrokMatchDevice(patterns, row, static_cast<const uint8_t*>(dData.p), static_cast<const uint32_t*>(dOff.p),
-                                   static_cast<const uint32_t*>(dLen.p), n, static_cast<int32_t*>(dPattern.p),
-                                   static_cast<int32_t*>(dFirst.p), static_cast<int32_t*>(dExtra.p), extraCap,
-                                   static_cast<uint32_t*>(dNextra.p), dScratch.p, scratch, nullptr);
-        HIP_TRY(hipMemcpy(&nExtra, dNextra.p, 4, hipMemcpyDeviceToHost));
-        if (rc == LC_ERR_OVERFLOW && attempt == 0) {
-            extraCap = nExtra;  // the exact number is known now
-            continue;
-        }
-        if (rc != LC_OK) return rc;
-        break;
-    }
-    first.resize(size_t(n) * row);
-    HIP_TRY(hipMemcpy(pattern, dPattern.p, size_t(n) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(first.data(), dFirst.p, size_t(n) * row * 4, hipMemcpyDeviceToHost));
-    std::vector<int32_t> raw(size_t(nExtra) * (row + 2));
-    if (nExtra) HIP_TRY(hipMemcpy(raw.data(), dExtra.p, raw.size() * 4, hipMemcpyDeviceToHost));
-    // rows arrive in atomic order: sort by (line, seq)
-    std::vector<uint32_t> idx(nExtra);
-    for (uint32_t i = 0; i < nExtra; ++i) idx[i] = i;
-    const size_t w = row + 2;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (raw[a * w] != raw[b * w]) return raw[a * w] < raw[b * w];
-        return raw[a * w + 1] < raw[b * w + 1];
-    });
-    extraRows.resize(raw.size());
-    for (uint32_t i = 0; i < nExtra; ++i) std::memcpy(&extraRows[i * w], &raw[idx[i] * w], w * 4);
-    return LC_OK;
-}

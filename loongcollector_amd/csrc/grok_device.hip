@@ -1,0 +1,906 @@
+// grok_device.hip -- device half of the Grok processor (include/lc_grok.h):
+// ProcessorGrok.processGrok (plugins/processor/grok/processor_grok.go:148-194) for a whole batch of values.
+//
+// Two ways through a Match list, same results:
+//   * speculative (default, lists of up to 64 entries): grok_plan_kernel.hpp -- one literal pass, ONE launch for the screens of
+//     all entries, then every surviving (entry, value) pair evaluated at the same time on a few streams, the first contributing
+//     entry per value taken at the end.  Round control stays on the device; the host synchronises twice per batch.
+//   * sequential: grok_kernel.hpp -- the list walked entry by entry over the values still undecided (a host round trip per
+//     filter, screen and search round).
+// The regex kernels themselves (tdfa_* / nfa_*) live in gpu_runtime.hip and are reached through lcMatchOnStream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "grok_kernel.hpp"
+#include "grok_plan_kernel.hpp"
+#include "grok_runtime.hpp"
+#include "regex_handle.hpp"
+#include "runtime_internal.hpp"
+
+#define HIP_TRY LC_HIP_TRY
+
+namespace {
+size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+thread_local GrokBatchStats tlsStats;
+hipError_t syncCounted(hipStream_t st) {
+    ++tlsStats.hostSyncs;
+    return hipStreamSynchronize(st);
+}
+}  // namespace
+
+GrokBatchStats lcGrokLastBatchStats() { return tlsStats; }
+
+// Scratch layout.  Sequential path: caps int32[n][row] | status u8[n] (padded) | from, nmatch, tried, next, roundA, roundB,
+// unanchored : u32[n] each | counters u32[64] | perPattern u32[64] | masks u64[n].  The speculative path only uses the tail
+// (counters .. masks) plus winner / undecided u32[n] carved from the head; its per-entry arrays come from the thread's arena.
+size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
+    const size_t m = n ? n : 1;
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 512 + alignUp(m * 8, 256);
+}
+
+// ------------------------------------------------------------------------------------------------ per-handle device state
+struct GrokDeviceState {
+    std::mutex m;
+    bool literalsBuilt = false;
+    std::vector<uint32_t> literalBlob;           // empty: the list is not indexable
+    void* dLiteral[kLcMaxDevices] = {};
+    // screens of the speculative path: per device, a table of GrokScreenDev (at most one screen per entry)
+    bool screensBuilt[kLcMaxDevices] = {};
+    void* dScreens[kLcMaxDevices] = {};
+    uint32_t nScreens[kLcMaxDevices] = {};
+    uint32_t screenLdsBytes[kLcMaxDevices] = {};  // largest staged table
+};
+
+GrokDeviceState* lcGrokStateCreate() { return new GrokDeviceState(); }
+void lcGrokStateFree(GrokDeviceState* s) {
+    if (!s) return;
+    if (lcRuntimeUsable()) {
+        int cur = 0;
+        const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+        for (int d = 0; d < kLcMaxDevices; ++d) {
+            if (!s->dLiteral[d] && !s->dScreens[d]) continue;
+            if (hipSetDevice(d) != hipSuccess) continue;
+            if (s->dLiteral[d]) (void)hipFree(s->dLiteral[d]);
+            if (s->dScreens[d]) (void)hipFree(s->dScreens[d]);
+        }
+        if (haveCur) (void)hipSetDevice(cur);
+    }
+    delete s;
+}
+
+namespace {
+// device blob of the list's literal index, or nullptr (more than 64 entries, no literal at all, automaton too large).  Built once
+// per handle, uploaded once per device; freed with the handle.
+int grokLiteralIndex(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, int dev, const uint32_t** out) {
+    *out = nullptr;
+    static const bool off = getenv("LC_GROK_NO_LITERAL_INDEX") != nullptr;
+    if (off || patterns.size() > 64) return LC_OK;
+    std::lock_guard<std::mutex> g(state->m);
+    if (!state->literalsBuilt) {
+        std::vector<std::string> lits;
+        size_t withLiteral = 0;
+        for (const auto& gp : patterns) {
+            lits.push_back(lcGrokLiteralOf(gp.re));
+            withLiteral += !lits.back().empty();
+        }
+        if (withLiteral >= 2) state->literalBlob = lcBuildGrokLiteralBlob(lits);
+        state->literalsBuilt = true;
+    }
+    if (state->literalBlob.empty()) return LC_OK;
+    if (!state->dLiteral[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, state->literalBlob.size() * 4));
+        const hipError_t e = hipMemcpy(p, state->literalBlob.data(), state->literalBlob.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return lcHipFail(e, "hipMemcpy(literal index)");
+        }
+        state->dLiteral[dev] = p;
+    }
+    *out = static_cast<const uint32_t*>(state->dLiteral[dev]);
+    return LC_OK;
+}
+}  // namespace
+
+// ---- the sequential path: the Match list walked entry by entry over the values still undecided (the control flow of
+// grok_kernel.hpp).  Lists of more than 64 entries, and handles configured with "Speculative": false.
+static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts,
+                               uint32_t row, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
+                               int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra,
+                               void* d_scratch, hipStream_t st, int dev) {
+
+    uint8_t* base = static_cast<uint8_t*>(d_scratch);
+    int32_t* caps = reinterpret_cast<int32_t*>(base);
+    base += alignUp(size_t(n) * row * 4, 256);
+    uint8_t* status = base;
+    base += alignUp(n, 256);
+    uint32_t* lists[7];
+    for (auto& l : lists) {
+        l = reinterpret_cast<uint32_t*>(base);
+        base += alignUp(size_t(n) * 4, 256);
+    }
+    uint32_t *from = lists[0], *nmatch = lists[1], *tried = lists[2], *next = lists[3], *roundIn = lists[4],
+             *roundOut = lists[5], *unanchored = lists[6];
+    uint32_t* counters = reinterpret_cast<uint32_t*>(base);
+    base += 256;
+    uint32_t* perPattern = reinterpret_cast<uint32_t*>(base);  // [64]: values that carry each entry's literal (literal index pass)
+    base += 256;
+    uint64_t* masks = reinterpret_cast<uint64_t*>(base);
+
+    const uint32_t gridAll = (n + kGrokBlock - 1) / kGrokBlock;
+    hipLaunchKernelGGL(grok_init_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, n, d_pattern, tried, from, nmatch);
+    // which Match entries' required literals each value contains: one pass for the whole list
+    const uint32_t* literalIndex = nullptr;
+    {
+        int rc = grokLiteralIndex(patterns, state, dev, &literalIndex);
+        if (rc != LC_OK) return rc;
+    }
+    std::vector<uint32_t> carriers;  // per entry: values of the batch that carry its literal (empty: no index)
+    if (literalIndex) {
+        HIP_TRY(hipMemsetAsync(perPattern, 0, 256, st));
+        hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex,
+                           masks, uint32_t(patterns.size()), perPattern);
+        carriers.resize(64);
+        HIP_TRY(hipMemcpyAsync(carriers.data(), perPattern, 256, hipMemcpyDeviceToHost, st));
+        HIP_TRY(syncCounted(st));
+    }
+    HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
+    HIP_TRY(hipMemsetAsync(counters, 0, 16, st));
+
+    uint32_t nTried = n;
+    uint32_t host[4] = {0, 0, 0, 0};
+    // LC_GROK_TRACE=1: one stderr line per Match entry -- values tried / with the literal / past the screen, then (values, ms)
+    // per search round (the host waits for a counter after every step anyway, so the clock reads are exact)
+    static const bool trace = getenv("LC_GROK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto msSince = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(now() - t0).count();
+    };
+    for (size_t p = 0; p < patterns.size() && nTried; ++p) {
+        const GrokDevicePattern& gp = patterns[p];
+        // no value of the batch carries this entry's literal: it cannot match anything, and an entry that matches nothing
+        // leaves every list as it is
+        if (!carriers.empty() && carriers[p] == 0) continue;
+        auto tPattern = now();
+        std::string traceLine;
+        if (trace) traceLine = "grok[" + std::to_string(p) + "] engine " + std::to_string(gp.re->engine) + " tried " + std::to_string(nTried);
+        const uint32_t* in = tried;  // round 0 searches every value still undecided, from its first byte ...
+        uint32_t nIn = nTried;
+        uint32_t* outs[2] = {roundIn, roundOut};
+        int flip = 0;
+        if (!gp.re->requiredLiteral.empty()) {  // ... that contains the literal every match of this pattern must contain
+            GrokLiteral lit;
+            const std::string& s = gp.re->requiredLiteral;
+            lit.len = uint32_t(std::min<size_t>(s.size(), sizeof lit.bytes));
+            std::memcpy(lit.bytes, s.data() + (s.size() - lit.len), lit.len);
+            const uint32_t perBlock = kGrokBlock / 64;
+            if (literalIndex)
+                hipLaunchKernelGGL(grok_mask_filter_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
+                                   nTried, masks, uint32_t(p), outs[1], counters);
+            else
+                hipLaunchKernelGGL(grok_literal_filter_kernel, dim3((nTried + perBlock - 1) / perBlock), dim3(kGrokBlock), 0, st,
+                                   tried, nTried, d_data, d_off, d_len, lit, outs[1], counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(syncCounted(st));
+            nIn = host[0];
+            in = outs[1];
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+            if (trace) traceLine += " literal " + std::to_string(nIn) + " (" + std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
+        }
+        // ... and a match of the pattern's prefix, then of the relaxed whole pattern (fast TDFA kernel, status only)
+        // (the relaxed screen rejects nearly everything the prefix screen rejects, and each pass costs a launch and a counter read,
+        // ~0.25 ms: the prefix screen only goes first where it saves the relaxed one a large candidate set -- LC_GROK_PREFIX_ABOVE)
+        const uint32_t prefixAbove = opts.prefixScreenAbove;
+        for (lc_regex* scr : {gp.screen, gp.relaxed}) {
+            if (!scr || !nIn) continue;
+            if (scr == gp.screen && gp.relaxed && nIn <= prefixAbove) continue;
+            uint32_t* out = in == outs[0] ? outs[1] : outs[0];
+            if (!scr->hasTdfa && !scr->screenBlob.empty()) {  // a plain DFA with its table in L2: screens and filters in one kernel
+                int rc = lcScreenOnStream(scr, dev, d_data, d_off, d_len, nIn, in, out, counters, st);
+                if (rc != LC_OK) return rc;
+            } else {
+                int rc = lcMatchOnStream(scr, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, 0, caps,
+                                         status, st);
+                if (rc != LC_OK) return rc;
+                hipLaunchKernelGGL(grok_status_filter_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st,
+                                   in, nIn, status, out, counters);
+            }
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(syncCounted(st));
+            nIn = host[0];
+            in = out;
+            flip = in == outs[0] ? 1 : 0;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+            if (trace)
+                traceLine += std::string(scr == gp.screen ? " screen " : " relaxed ") + std::to_string(nIn) + " (" +
+                             std::to_string(msSince(tPattern)).substr(0, 6) + " ms)";
+        }
+        // the match kernels write this pattern's own groups only (whole match + its columns), not the widest pattern's row
+        const uint32_t capsRow = 2 * (gp.columns + 1);
+        // one search round over the values listed in `list`: the pattern's kernel, then grok_advance_kernel (matches recorded,
+        // values that stay in play appended to `out`, their number added to counters[0])
+        auto searchRound = [&](lc_regex* re, const uint32_t* list, uint32_t nList, const uint32_t* resume, uint32_t* out) -> int {
+            int rc = lcMatchOnStream(re, re->engine, dev, d_data, d_off, d_len, 0, nList, nullptr, list, resume, capsRow / 2, caps,
+                                     status, st);
+            if (rc != LC_OK) return rc;
+            hipLaunchKernelGGL(grok_advance_kernel, dim3((nList + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, list, nList,
+                               status, caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out,
+                               counters);
+            return LC_OK;
+        };
+        if (gp.anchored && nIn) {
+            // Round 0 searches every value from its first byte, and a log format matches FROM the first byte: the anchored search
+            // (a tagged DFA, tables in L2, one value per lane) finds exactly what the search would find whenever the search's
+            // leftmost match starts at byte 0; the values it does not match go to the search proper (their match, if any, starts
+            // later).  Both append to the same next-round list.
+            auto tRound = now();
+            uint32_t* out = outs[flip];
+            int rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, capsRow / 2,
+                                     caps, status, st);
+            if (rc != LC_OK) return rc;
+            hipLaunchKernelGGL(grok_unmatched_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
+                               unanchored, counters + 3);
+            hipLaunchKernelGGL(grok_advance_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
+                               caps, capsRow, row, gp.columns, d_len, from, nmatch, d_pattern, d_first, d_extra, extraCap, out, counters);
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(syncCounted(st));
+            const uint32_t nRest = host[3];
+            HIP_TRY(hipMemsetAsync(counters + 3, 0, 4, st));
+            if (trace)
+                traceLine += " anchored " + std::to_string(nIn) + " -> rest " + std::to_string(nRest) + " (" +
+                             std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
+            if (nRest) {
+                auto tRest = now();
+                rc = searchRound(gp.re, unanchored, nRest, from, out);
+                if (rc != LC_OK) return rc;
+                HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+                HIP_TRY(syncCounted(st));
+                if (trace) traceLine += " round " + std::to_string(nRest) + " (" + std::to_string(msSince(tRest)).substr(0, 7) + " ms)";
+            }
+            nIn = host[0];
+            in = out;
+            flip ^= 1;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));
+        }
+        while (nIn) {
+            auto tRound = now();
+            const uint32_t roundValues = nIn;
+            uint32_t* out = outs[flip];
+            int rc = searchRound(gp.re, in, nIn, from, out);
+            if (rc != LC_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(syncCounted(st));
+            nIn = host[0];
+            in = out;
+            flip ^= 1;
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, st));  // counters[0] only; the extra-row count keeps running
+            if (trace) traceLine += " round " + std::to_string(roundValues) + " (" + std::to_string(msSince(tRound)).substr(0, 7) + " ms)";
+        }
+        hipLaunchKernelGGL(grok_finish_kernel, dim3((nTried + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, tried,
+                           nTried, int32_t(p), nmatch, d_pattern, from, next, counters);
+        HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(syncCounted(st));
+        if (trace) fprintf(stderr, "%s settled %u total %.3f ms\n", traceLine.c_str(), nTried - host[2], msSince(tPattern));
+        nTried = host[2];
+        std::swap(tried, next);
+        HIP_TRY(hipMemsetAsync(counters + 2, 0, 4, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d_nextra, counters + 1, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(syncCounted(st));
+    HIP_TRY(hipGetLastError());
+    if (host[1] > extraCap) {
+        lcSetLastError("grok: " + std::to_string(host[1]) + " extra match rows needed, buffer holds " + std::to_string(extraCap));
+        return LC_ERR_OVERFLOW;
+    }
+    return LC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ speculative path
+namespace {
+constexpr int kGrokMaxStreams = 8;
+constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
+constexpr uint32_t kGrokMaxRounds = GC_SPARE_A - GC_ROUND0;  // search rounds that can be queued ahead per entry
+
+// Pinned host words of a thread: what the two syncs of a batch read back.
+enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_WORDS = 128 + 64 * GC_WORDS };
+// device tail words (scratch `counters`): [0] gate  [1] xcount (extra rows wanted in xtmp)
+enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16 };
+
+struct PlanThread {
+    int device = -1;
+    hipStream_t workers[kGrokMaxStreams] = {};
+    hipEvent_t fork = nullptr, join[kGrokMaxStreams] = {};
+    uint32_t* hostWords = nullptr;        // pinned, HW_*
+    GrokEntryDev* hostEntries = nullptr;  // pinned [64]
+    GrokEntryDev* dEntries = nullptr;     // device [64]
+    uint32_t* dCnt = nullptr;             // device [64][GC_WORDS]
+    void* arena = nullptr;                // device, grow-only: the per-entry arrays of the batch in flight
+    size_t arenaCap = 0;
+    ~PlanThread() { release(); }
+    void release() {
+        if (device >= 0 && lcRuntimeUsable()) {
+            int cur = 0;
+            const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+            if (hipSetDevice(device) == hipSuccess) {
+                for (auto& w : workers)
+                    if (w) {
+                        (void)hipStreamSynchronize(w);
+                        (void)hipStreamDestroy(w);
+                    }
+                if (fork) (void)hipEventDestroy(fork);
+                for (auto& e : join)
+                    if (e) (void)hipEventDestroy(e);
+                if (hostWords) (void)hipHostFree(hostWords);
+                if (hostEntries) (void)hipHostFree(hostEntries);
+                if (dEntries) (void)hipFree(dEntries);
+                if (dCnt) (void)hipFree(dCnt);
+                if (arena) (void)hipFree(arena);
+            }
+            if (haveCur) (void)hipSetDevice(cur);
+        }
+        for (auto& w : workers) w = nullptr;
+        for (auto& e : join) e = nullptr;
+        fork = nullptr;
+        hostWords = nullptr;
+        hostEntries = nullptr;
+        dEntries = nullptr;
+        dCnt = nullptr;
+        arena = nullptr;
+        arenaCap = 0;
+        device = -1;
+    }
+    int ensure(int dev, uint32_t nStreams) {
+        if (device != dev) {
+            release();
+            lcRegisterExitHook();
+            device = dev;
+            HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostWords), HW_WORDS * 4, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostEntries), 64 * sizeof(GrokEntryDev), hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dEntries), 64 * sizeof(GrokEntryDev)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dCnt), 64 * GC_WORDS * 4));
+        }
+        for (uint32_t s = 0; s < nStreams; ++s)
+            if (!workers[s]) {
+                HIP_TRY(hipStreamCreateWithFlags(&workers[s], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&join[s], hipEventDisableTiming));
+            }
+        return LC_OK;
+    }
+    int ensureArena(size_t bytes) {
+        if (arenaCap >= bytes) return LC_OK;
+        if (arena) {
+            HIP_TRY(hipDeviceSynchronize());  // (a larger batch than ever before: rare; nothing of ours is in flight here anyway)
+            (void)hipFree(arena);
+            arena = nullptr;
+            arenaCap = 0;
+        }
+        const size_t want = bytes + (bytes >> 2) + (1u << 20);
+        HIP_TRY(hipMalloc(&arena, want));
+        arenaCap = want;
+        return LC_OK;
+    }
+};
+thread_local PlanThread tlsPlan;
+
+// the screen the merged launch walks for an entry: the relaxed whole-pattern screen when there is one (it rejects nearly
+// everything the prefix screen rejects), else the prefix screen
+lc_regex* planScreenOf(const GrokDevicePattern& gp) {
+    if (gp.relaxed && !gp.relaxed->screenBlob.empty()) return gp.relaxed;
+    if (gp.screen && !gp.screen->screenBlob.empty()) return gp.screen;
+    return nullptr;
+}
+
+int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, int dev, const GrokScreenDev** table,
+                    uint32_t* count, uint32_t* ldsBytes) {
+    std::lock_guard<std::mutex> g(state->m);
+    if (!state->screensBuilt[dev]) {
+        static const bool noStage = getenv("LC_GROK_SCREEN_NO_LDS") != nullptr;
+        std::vector<GrokScreenDev> host;
+        uint32_t maxStage = 0;
+        for (size_t p = 0; p < patterns.size(); ++p) {
+            lc_regex* scr = planScreenOf(patterns[p]);
+            if (!scr) continue;
+            GrokScreenDev d{};
+            int rc = lcEnsureScreenUploaded(scr, dev, &d.blob);
+            if (rc != LC_OK) return rc;
+            d.bit = uint32_t(p);
+            const uint32_t stage = scr->screenBlob[SC_TOTAL_BYTES] - scr->screenBlob[SC_OFF_ACCEPT];
+            d.ldsBytes = (!noStage && stage <= kGrokScreenStageMax) ? (stage + 3u) & ~3u : 0u;
+            maxStage = std::max(maxStage, d.ldsBytes);
+            host.push_back(d);
+        }
+        if (!host.empty()) {
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, host.size() * sizeof(GrokScreenDev)));
+            const hipError_t e = hipMemcpy(p, host.data(), host.size() * sizeof(GrokScreenDev), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(p);
+                return lcHipFail(e, "hipMemcpy(screen table)");
+            }
+            state->dScreens[dev] = p;
+        }
+        state->nScreens[dev] = uint32_t(host.size());
+        state->screenLdsBytes[dev] = maxStage;
+        state->screensBuilt[dev] = true;
+    }
+    *table = static_cast<const GrokScreenDev*>(state->dScreens[dev]);
+    *count = state->nScreens[dev];
+    *ldsBytes = state->screenLdsBytes[dev];
+    return LC_OK;
+}
+
+// host view of one active entry of the batch
+struct PlanEntry {
+    uint32_t p = 0, cand = 0, capsRow = 0, columns = 0, rounds = 0, ran = 0;
+    int stream = 0;
+    double cost = 0;
+    GrokEntryDev dev{};
+    uint32_t *listA = nullptr, *listB = nullptr, *unanchored = nullptr;
+    int32_t* caps = nullptr;
+    uint8_t* status = nullptr;
+};
+
+int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
+                         const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern,
+                         int32_t* d_first, int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch, hipStream_t st,
+                         int dev) {
+    GrokBatchStats& stats = tlsStats;
+    const uint32_t nP = uint32_t(patterns.size());
+    static const uint32_t envStreams = [] {  // LC_GROK_STREAMS overrides the handle's option (A/B measurements)
+        const char* e = getenv("LC_GROK_STREAMS");
+        return uint32_t(e ? atoi(e) : 0);
+    }();
+    const uint32_t nStreams = std::max(1u, std::min<uint32_t>(envStreams ? envStreams : opts.streams, kGrokMaxStreams));
+    PlanThread& T = tlsPlan;
+    {
+        int rc = T.ensure(dev, nStreams);
+        if (rc != LC_OK) return rc;
+    }
+    static const bool trace = getenv("LC_GROK_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto msNow = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+
+    // scratch: winner u32[n] | undecided u32[n] from the head, tail words / perEntry / masks at their fixed places
+    uint8_t* head = static_cast<uint8_t*>(d_scratch);
+    uint32_t* winner = reinterpret_cast<uint32_t*>(head);
+    uint32_t* undecided = winner + n;
+    uint8_t* tailAt = head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256) + 7 * alignUp(size_t(n) * 4, 256);
+    uint32_t* tail = reinterpret_cast<uint32_t*>(tailAt);            // TW_*
+    uint32_t* perEntry = reinterpret_cast<uint32_t*>(tailAt + 256);  // [64]
+    uint64_t* masks = reinterpret_cast<uint64_t*>(tailAt + 512);
+
+    const uint32_t gridAll = (n + kGrokPlanBlock - 1) / kGrokPlanBlock;
+    // ---- phase 1: literal index, all screens, candidate counts
+    HIP_TRY(hipMemsetAsync(tailAt, 0, 512, st));
+    const uint32_t* literalIndex = nullptr;
+    {
+        int rc = grokLiteralIndex(patterns, state, dev, &literalIndex);
+        if (rc != LC_OK) return rc;
+    }
+    if (literalIndex) {
+        // (its per-entry carrier counts land in perEntry and are overwritten by grok_count_kernel's after the screens)
+        lcNoteKernel("grok_literal_index_kernel");
+        hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex, masks,
+                           nP, perEntry);
+        HIP_TRY(hipMemsetAsync(perEntry, 0, 256, st));
+    } else {
+        hipLaunchKernelGGL(grok_mask_fill_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n,
+                           nP >= 64 ? ~0ull : ((1ull << nP) - 1ull));
+    }
+    const GrokScreenDev* screens = nullptr;
+    uint32_t nScreens = 0, screenLds = 0;
+    {
+        int rc = grokScreenTable(patterns, state, dev, &screens, &nScreens, &screenLds);
+        if (rc != LC_OK) return rc;
+    }
+    if (nScreens) {
+        // slices: short enough that a small batch still spreads over the chip, long enough that the table staging is amortised
+        uint32_t sliceLen = ((n / 64 + 255) / 256) * 256;
+        sliceLen = std::max(256u, std::min(4096u, sliceLen));
+        const uint32_t slices = (n + sliceLen - 1) / sliceLen;
+        lcNoteKernel("grok_screen_all_kernel");
+        hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + screenLds, st, d_data,
+                           d_off, d_len, n, sliceLen, screens, reinterpret_cast<unsigned long long*>(masks));
+    }
+    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CAND, perEntry, 256, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(winner, 0xFF, size_t(n) * 8, st));
+    HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
+    HIP_TRY(hipMemsetAsync(d_nextra, 0, 4, st));
+    HIP_TRY(syncCounted(st));  // sync 1: candidates per entry
+    const double tPhase1 = msNow();
+
+    // ---- the batch's active entries and their arrays
+    std::vector<PlanEntry> act;
+    size_t arenaBytes = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = arenaBytes;
+        arenaBytes += alignUp(bytes, 256);
+        return at;
+    };
+    const uint32_t xcap = std::max<uint32_t>(extraCap, n / 4 + 1024);
+    const uint32_t xstride = row + 3;
+    const size_t xtmpAt = carve(size_t(xcap) * xstride * 4);
+    struct Offsets {
+        size_t off, len, line, from, nmatch, first, listA, listB, unanchored, caps, status;
+    };
+    std::vector<Offsets> offs;
+    for (uint32_t p = 0; p < nP; ++p) {
+        const uint32_t c = T.hostWords[HW_CAND + p];
+        if (!c) continue;
+        PlanEntry e;
+        e.p = p;
+        e.cand = c;
+        e.columns = patterns[p].columns;
+        e.capsRow = 2 * (patterns[p].columns + 1);
+        e.rounds = std::max(1u, std::min(kGrokMaxRounds, patterns[p].re->grokRounds.load(std::memory_order_relaxed)));
+        const bool nfa = patterns[p].re->engine == LC_ENGINE_NFA;
+        e.cost = double(c) * (nfa ? (patterns[p].anchored ? 8.0 : 40.0) : 1.0);
+        Offsets o;
+        o.off = carve(size_t(c) * 4);
+        o.len = carve(size_t(c) * 4);
+        o.line = carve(size_t(c) * 4);
+        o.from = carve(size_t(c) * 4);
+        o.nmatch = carve(size_t(c) * 4);
+        o.listA = carve(size_t(c) * 4);
+        o.listB = carve(size_t(c) * 4);
+        o.unanchored = carve(size_t(c) * 4);
+        o.first = carve(size_t(c) * e.capsRow * 4);
+        o.caps = carve(size_t(c) * e.capsRow * 4);
+        o.status = carve(size_t(c) + 16);
+        offs.push_back(o);
+        act.push_back(e);
+    }
+    stats.activeEntries = uint32_t(act.size());
+    GrokSlotMap map;
+    for (auto& a : map.activeOfBit) a = -1;
+    {
+        int rc = T.ensureArena(arenaBytes);
+        if (rc != LC_OK) return rc;
+    }
+    uint8_t* arena = static_cast<uint8_t*>(T.arena);
+    int32_t* xtmp = reinterpret_cast<int32_t*>(arena + xtmpAt);
+    uint32_t maxCand = 0;
+    for (size_t a = 0; a < act.size(); ++a) {
+        PlanEntry& e = act[a];
+        const Offsets& o = offs[a];
+        e.dev.off = reinterpret_cast<uint32_t*>(arena + o.off);
+        e.dev.len = reinterpret_cast<uint32_t*>(arena + o.len);
+        e.dev.line = reinterpret_cast<uint32_t*>(arena + o.line);
+        e.dev.from = reinterpret_cast<uint32_t*>(arena + o.from);
+        e.dev.nmatch = reinterpret_cast<uint32_t*>(arena + o.nmatch);
+        e.dev.first = reinterpret_cast<int32_t*>(arena + o.first);
+        e.dev.cnt = T.dCnt + a * GC_WORDS;
+        e.dev.cand = e.cand;
+        e.dev.capsRow = e.capsRow;
+        e.dev.bit = e.p;
+        e.listA = reinterpret_cast<uint32_t*>(arena + o.listA);
+        e.listB = reinterpret_cast<uint32_t*>(arena + o.listB);
+        e.unanchored = reinterpret_cast<uint32_t*>(arena + o.unanchored);
+        e.caps = reinterpret_cast<int32_t*>(arena + o.caps);
+        e.status = arena + o.status;
+        T.hostEntries[a] = e.dev;
+        map.activeOfBit[e.p] = int8_t(a);
+        maxCand = std::max(maxCand, e.cand);
+        stats.pairs += e.cand;
+    }
+    uint32_t* gate = tail + TW_GATE;
+    uint32_t* xcount = tail + TW_XCOUNT;
+    const uint32_t nAct = uint32_t(act.size());
+    if (nAct) {
+        HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(T.dCnt, 0, size_t(nAct) * GC_WORDS * 4, st));
+        hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries);
+        HIP_TRY(hipGetLastError());
+        // ---- phase 2: every entry is a batch of its own; the dearest first, dealt round-robin to the worker streams
+        std::vector<size_t> order(nAct);
+        for (size_t a = 0; a < nAct; ++a) order[a] = a;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return act[x].cost > act[y].cost; });
+        const uint32_t used = std::min<uint32_t>(nStreams, nAct);
+        HIP_TRY(hipEventRecord(T.fork, st));
+        for (uint32_t s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(T.workers[s], T.fork, 0));
+        for (size_t i = 0; i < nAct; ++i) {
+            PlanEntry& e = act[order[i]];
+            e.stream = int(i % used);
+            hipStream_t ws = T.workers[e.stream];
+            lcSetDecideSlot(1 + e.stream);
+            const GrokDevicePattern& gp = patterns[e.p];
+            const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+            auto advance = [&](const uint32_t* list, const uint32_t* countPtr, uint32_t* out, uint32_t* outCount, bool last) {
+                hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
+                                   e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out, outCount, last ? gate : nullptr);
+            };
+            int rc = LC_OK;
+            // round 0
+            const bool last0 = e.rounds == 1;
+            uint32_t* out0 = e.listA;
+            uint32_t* outCount0 = e.dev.cnt + GC_ROUND0;
+            if (gp.anchored) {
+                rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr, nullptr,
+                                     e.capsRow / 2, e.caps, e.status, ws);
+                if (rc == LC_OK) {
+                    hipLaunchKernelGGL(grok_unmatched2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.cand, e.status, e.unanchored,
+                                       e.dev.cnt + GC_UNANCHORED);
+                    advance(nullptr, nullptr, out0, outCount0, last0);
+                    rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
+                                         e.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                    if (rc == LC_OK) advance(e.unanchored, e.dev.cnt + GC_UNANCHORED, out0, outCount0, last0);
+                }
+            } else {
+                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr, e.dev.from,
+                                     e.capsRow / 2, e.caps, e.status, ws);
+                if (rc == LC_OK) advance(nullptr, nullptr, out0, outCount0, last0);
+            }
+            // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
+            for (uint32_t r = 1; r < e.rounds && rc == LC_OK; ++r) {
+                const uint32_t* list = (r & 1) ? e.listA : e.listB;
+                uint32_t* out = (r & 1) ? e.listB : e.listA;
+                const uint32_t* countPtr = e.dev.cnt + GC_ROUND0 + r - 1;
+                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
+                                     e.capsRow / 2, e.caps, e.status, ws);
+                if (rc == LC_OK) advance(list, countPtr, out, e.dev.cnt + GC_ROUND0 + r, r + 1 == e.rounds);
+            }
+            if (rc != LC_OK) {
+                lcSetDecideSlot(0);
+                for (uint32_t s = 0; s < used; ++s) (void)hipStreamSynchronize(T.workers[s]);
+                return rc;
+            }
+        }
+        lcSetDecideSlot(0);
+        HIP_TRY(hipGetLastError());
+        for (uint32_t s = 0; s < used; ++s) {
+            HIP_TRY(hipEventRecord(T.join[s], T.workers[s]));
+            HIP_TRY(hipStreamWaitEvent(st, T.join[s], 0));
+        }
+    }
+    // ---- phase 3: the first contributing entry per value; its rows go out.  All of it returns at once when values are still in
+    // play somewhere (gate != 0): the host then finishes those entries and queues it again
+    const uint32_t gridCand = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+    auto finishAll = [&](const uint32_t* g) -> int {
+        if (nAct) {
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, g);
+        }
+        hipLaunchKernelGGL(grok_resolve_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, n, winner, undecided, d_pattern, g);
+        if (nAct) {
+            hipLaunchKernelGGL(grok_commit_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, d_pattern, d_first, row, g);
+            hipLaunchKernelGGL(grok_commit_extra_kernel, dim3(64), dim3(kGrokPlanBlock), 0, st, xtmp, xcount, xcap, xstride, T.dEntries, map,
+                               d_pattern, d_extra, extraCap, row, d_nextra, g);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, tail, TW_WORDS * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS, d_nextra, 4, hipMemcpyDeviceToHost, st));
+        if (nAct) HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(syncCounted(st));
+        return LC_OK;
+    };
+    {
+        int rc = finishAll(gate);  // sync 2
+        if (rc != LC_OK) return rc;
+    }
+    const double tPhase3 = msNow();
+    if (T.hostWords[HW_TAIL + TW_GATE] != 0) {
+        // values still in play after the last queued round of some entries: finish those round by round (the host reads a
+        // count per round here -- an entry pays this once, then asks for more rounds ahead)
+        for (size_t a = 0; a < nAct; ++a) {
+            PlanEntry& e = act[a];
+            uint32_t inPlay = T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + e.rounds - 1];
+            if (!inPlay) continue;
+            ++stats.deferredEntries;
+            const GrokDevicePattern& gp = patterns[e.p];
+            uint32_t r = e.rounds;
+            uint32_t spare = GC_SPARE_A;
+            while (inPlay) {
+                const uint32_t* list = (r & 1) ? e.listA : e.listB;
+                uint32_t* out = (r & 1) ? e.listB : e.listA;
+                HIP_TRY(hipMemsetAsync(e.dev.cnt + spare, 0, 4, st));
+                int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, inPlay, nullptr, list, e.dev.from,
+                                         e.capsRow / 2, e.caps, e.status, st);
+                if (rc != LC_OK) return rc;
+                hipLaunchKernelGGL(grok_advance2_kernel, dim3((inPlay + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, st, list,
+                                   inPlay, nullptr, e.status, e.caps, e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out,
+                                   e.dev.cnt + spare, nullptr);
+                HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS + 1, e.dev.cnt + spare, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(syncCounted(st));
+                inPlay = T.hostWords[HW_TAIL + TW_WORDS + 1];
+                spare = spare == GC_SPARE_A ? GC_SPARE_B : GC_SPARE_A;
+                ++r;
+            }
+            e.ran = r;  // (what this batch needed: the hint below)
+        }
+        int rc = finishAll(nullptr);
+        if (rc != LC_OK) return rc;
+    }
+    // ---- how many rounds each entry should queue ahead next time: what this batch needed, forgotten slowly
+    for (size_t a = 0; a < nAct; ++a) {
+        PlanEntry& e = act[a];
+        uint32_t needed = 1;  // rounds that had any value to search
+        for (uint32_t r = 0; r + 1 < e.rounds; ++r)
+            if (T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + r]) needed = r + 2;
+        lc_regex* re = patterns[e.p].re;
+        const uint32_t hint = re->grokRounds.load(std::memory_order_relaxed);
+        if (e.ran > hint) {
+            re->grokRounds.store(std::min(e.ran, kGrokMaxRounds), std::memory_order_relaxed);
+            re->grokRoundsSlack.store(0, std::memory_order_relaxed);
+        } else if (needed < hint && e.ran == 0) {
+            if (re->grokRoundsSlack.fetch_add(1, std::memory_order_relaxed) + 1 >= 16) {
+                re->grokRounds.store(needed, std::memory_order_relaxed);
+                re->grokRoundsSlack.store(0, std::memory_order_relaxed);
+            }
+        } else {
+            re->grokRoundsSlack.store(0, std::memory_order_relaxed);
+        }
+    }
+    if (trace)
+        fprintf(stderr, "grok plan: n %u entries %u pairs %u screens %u | phase1 %.3f ms, entries+finish %.3f ms, total %.3f ms, syncs %u, deferred %u\n",
+                n, nAct, stats.pairs, nScreens, tPhase1, tPhase3 - tPhase1, msNow(), stats.hostSyncs, stats.deferredEntries);
+    const uint32_t xWanted = T.hostWords[HW_TAIL + TW_XCOUNT];
+    const uint32_t nextra = T.hostWords[HW_TAIL + TW_WORDS];
+    if (xWanted > xcap) {
+        // the temporary rows themselves did not fit: report an upper bound of what is needed (winners' rows <= all rows)
+        HIP_TRY(hipMemcpy(d_nextra, &xWanted, 4, hipMemcpyHostToDevice));
+        lcSetLastError("grok: " + std::to_string(xWanted) + " extra match rows needed, buffer holds " + std::to_string(extraCap));
+        return LC_ERR_OVERFLOW;
+    }
+    if (nextra > extraCap) {
+        lcSetLastError("grok: " + std::to_string(nextra) + " extra match rows needed, buffer holds " + std::to_string(extraCap));
+        return LC_ERR_OVERFLOW;
+    }
+    return LC_OK;
+}
+}  // namespace
+
+int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
+                      const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, int32_t* d_pattern,
+                      int32_t* d_first, int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch, size_t scratchBytes,
+                      void* streamPtr) {
+    tlsStats = GrokBatchStats{};
+    if (n == 0) return LC_OK;
+    if (!state || !d_data || !d_off || !d_len || !d_pattern || !d_first || !d_nextra || !d_scratch || (extraCap && !d_extra))
+        return LC_ERR_ARG;
+    if (scratchBytes < lcGrokScratchBytes(n, row)) {
+        lcSetLastError("grok: scratch buffer too small");
+        return LC_ERR_ARG;
+    }
+    if (lc_device_count() <= 0) {
+        lcSetLastError("no HIP device");
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(streamPtr);
+    static const int forced = [] {  // LC_GROK_SPECULATIVE=0/1 overrides the handle's option (A/B measurements)
+        const char* e = getenv("LC_GROK_SPECULATIVE");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    const bool speculative = (forced < 0 ? opts.speculative : forced != 0) && patterns.size() <= 64;
+    tlsStats.speculative = speculative;
+    if (speculative)
+        return grokMatchSpeculative(patterns, state, opts, row, d_data, d_off, d_len, n, d_pattern, d_first, d_extra, extraCap, d_nextra,
+                                    d_scratch, st, dev);
+    return grokMatchSequential(patterns, state, opts, row, d_data, d_off, d_len, n, d_pattern, d_first, d_extra, extraCap, d_nextra,
+                               d_scratch, st, dev);
+}
+
+// device buffers of a thread that calls lcGrokMatchHost: grow-only, kept between calls (ProcessLogs hands over group after group)
+namespace {
+struct GrokDev {
+    void* p = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    ~GrokDev() { release(); }
+    void release() {
+        if (p && lcRuntimeUsable()) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        device = -1;
+    }
+    hipError_t ensure(size_t bytes, int dev) {
+        if (p && device == dev && cap >= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + (bytes >> 2) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) {
+            cap = want;
+            device = dev;
+        }
+        return e;
+    }
+};
+struct GrokThreadBuffers {
+    GrokDev b[8];
+};
+thread_local GrokThreadBuffers tlsGrokBuffers;
+}  // namespace
+void lcGrokThreadRelease() {
+    for (auto& d : tlsGrokBuffers.b) d.release();
+    tlsPlan.release();
+}
+
+int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
+                    const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
+                    std::vector<int32_t>& first, std::vector<int32_t>& extraRows) {
+    first.clear();
+    extraRows.clear();
+    if (n == 0) return LC_OK;
+    if (lc_device_count() <= 0) {
+        lcSetLastError("no HIP device");
+        return LC_ERR_NO_DEVICE;
+    }
+    // pack the values back to back (they may come from anywhere in `data`)
+    std::vector<uint32_t> hOff(n);
+    size_t bytes = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        hOff[i] = uint32_t(bytes);
+        bytes += len[i];
+    }
+    if (bytes > 0xFFFFFFF0ull) return LC_ERR_ARG;
+    std::vector<uint8_t> hData(bytes + 16);
+    for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
+
+    GrokThreadBuffers& gb = tlsGrokBuffers;
+    lcRegisterExitHook();
+    GrokDev &dData = gb.b[0], &dOff = gb.b[1], &dLen = gb.b[2], &dPattern = gb.b[3], &dFirst = gb.b[4], &dExtra = gb.b[5], &dNextra = gb.b[6], &dScratch = gb.b[7];
+    int devNo = 0;
+    HIP_TRY(hipGetDevice(&devNo));
+    const size_t scratch = lcGrokScratchBytes(n, row);
+    uint32_t extraCap = n / 4 + 1024;
+    HIP_TRY(dData.ensure(bytes + 16, devNo));
+    HIP_TRY(dOff.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dLen.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dPattern.ensure(size_t(n) * 4, devNo));
+    HIP_TRY(dFirst.ensure(size_t(n) * row * 4, devNo));
+    HIP_TRY(dNextra.ensure(4, devNo));
+    HIP_TRY(dScratch.ensure(scratch, devNo));
+    HIP_TRY(hipMemcpy(dData.p, hData.data(), bytes + 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dOff.p, hOff.data(), size_t(n) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dLen.p, len, size_t(n) * 4, hipMemcpyHostToDevice));
+    uint32_t nExtra = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(dExtra.ensure(size_t(extraCap) * (row + 2) * 4, devNo));
+        int rc = lcGrokMatchDevice(patterns, state, opts, row, static_cast<const uint8_t*>(dData.p), static_cast<const uint32_t*>(dOff.p),
+                                   static_cast<const uint32_t*>(dLen.p), n, static_cast<int32_t*>(dPattern.p),
+                                   static_cast<int32_t*>(dFirst.p), static_cast<int32_t*>(dExtra.p), extraCap,
+                                   static_cast<uint32_t*>(dNextra.p), dScratch.p, scratch, nullptr);
+        HIP_TRY(hipMemcpy(&nExtra, dNextra.p, 4, hipMemcpyDeviceToHost));
+        if (rc == LC_ERR_OVERFLOW && attempt == 0) {
+            extraCap = nExtra;  // the exact number is known now
+            continue;
+        }
+        if (rc != LC_OK) return rc;
+        break;
+    }
+    first.resize(size_t(n) * row);
+    HIP_TRY(hipMemcpy(pattern, dPattern.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first.data(), dFirst.p, size_t(n) * row * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> raw(size_t(nExtra) * (row + 2));
+    if (nExtra) HIP_TRY(hipMemcpy(raw.data(), dExtra.p, raw.size() * 4, hipMemcpyDeviceToHost));
+    // rows arrive in atomic order: sort by (line, seq)
+    std::vector<uint32_t> idx(nExtra);
+    for (uint32_t i = 0; i < nExtra; ++i) idx[i] = i;
+    const size_t w = row + 2;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (raw[a * w] != raw[b * w]) return raw[a * w] < raw[b * w];
+        return raw[a * w + 1] < raw[b * w + 1];
+    });
+    extraRows.resize(raw.size());
+    for (uint32_t i = 0; i < nExtra; ++i) std::memcpy(&extraRows[i * w], &raw[idx[i] * w], w * 4);
+    return LC_OK;
+}

@@ -1,4 +1,4 @@
-// grok_kernel.hpp -- bookkeeping kernels of the Grok matcher (gpu_runtime.hip: lcGrokMatchDevice).
+// grok_kernel.hpp -- bookkeeping kernels of the Grok matcher (grok_device.hip: the sequential path of lcGrokMatchDevice).
 //
 // The matching itself is done by the regex kernels (tdfa_match_kernel / nfa_match_kernel) in their "subset of lines,
 // resumed search" mode.  What is restated here is the control flow of ProcessorGrok.processGrok
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(kGrokBlock) void grok_status_filter_kernel(const ui
 //   * a match that holds a non-empty named capture is recorded (first one -> `first`, later ones -> `extra`);
 //   * FindNextMatch: the value stays in play from the end of this match (one further after an empty match) unless
 //     that is the end of the value -- a match starting there is empty and contributes nothing;
-//   * LC_OVERFLOW (NFA engine out of threads): the value is undecidable here, pattern = -2, dropped from play.
+//   * LC_OVERFLOW (NFA engine out of threads, nothing settled it): the value is undecidable here, pattern = -2, dropped from
+//     play; LC_GAVE_UP (the decide kernel ran out of budget -- regexp2's match timeout, processor_grok.go:156-160: the reference
+//     returns matchTimeOut and tries no further pattern): pattern = -3, dropped from play.
 // counters[0] = values in `out`, counters[1] = rows wanted in `extra`.
 __global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
     const uint32_t* __restrict__ in, uint32_t nIn, const uint8_t* __restrict__ status, const int32_t* __restrict__ caps,
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(kGrokBlock) void grok_advance_kernel(
     if (k >= nIn) return;
     const uint32_t line = in[k];
     const uint8_t st = status[line];
-    if (st == LC_OVERFLOW) {
-        pattern[line] = -2;
+    if (st == LC_OVERFLOW || st == LC_GAVE_UP) {
+        pattern[line] = st == LC_OVERFLOW ? -2 : -3;
         return;
     }
     if (st != LC_MATCH) return;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kGrokBlock) void grok_finish_kernel(const uint32_t*
     const uint32_t k = blockIdx.x * kGrokBlock + threadIdx.x;
     if (k >= nTried) return;
     const uint32_t line = tried[k];
-    if (pattern[line] == -2) return;
+    if (pattern[line] <= -2) return;
     if (nmatch[line]) {
         pattern[line] = p;
     } else {

@@ -1,0 +1,316 @@
+// grok_plan_kernel.hpp -- kernels of the SPECULATIVE Grok matcher (grok_device.hip: lcGrokMatchDevice, plan path).
+//
+// ProcessorGrok.processGrok (plugins/processor/grok/processor_grok.go:148-194) walks the Match list in order and stops at the
+// first entry whose matches yield a non-empty named capture.  Whether entry p yields one for value v does not depend on any
+// other entry, so the batch form evaluates every (entry, value) pair that can possibly match AT THE SAME TIME and takes the
+// minimum over the entries afterwards:
+//
+//   1. grok_literal_index_kernel (grok_kernel.hpp): one pass, a 64-bit mask per value -- bit p = "contains entry p's literal";
+//   2. grok_screen_all_kernel: ONE launch for the screens of all entries -- workgroup (slice of values, entry): the entry's
+//      yes/no DFA staged into LDS, walked over the slice's carriers of bit p; a rejected value loses the bit;
+//   3. grok_count_kernel -> the host reads how many candidates each entry has (sync 1) and carves per-entry arrays;
+//   4. grok_scatter_kernel: every (entry, value) pair becomes a SLOT of the entry (offset, length, line): from here on each
+//      entry is a batch of its own -- the regex kernels see "line" = slot, nothing else changes for them;
+//   5. per entry, on one of a few streams: search rounds (FindStringMatch / FindNextMatch) with grok_advance2_kernel in
+//      between; the number of values still in play stays on the device (count pointers), a fixed number of rounds is queued;
+//   6. grok_entry_finish_kernel: atomicMin per value over the entries that contributed / could not decide;
+//      grok_resolve_kernel: the winner; grok_commit_kernel / grok_commit_extra_kernel: the winner's rows go out.
+//   The host reads one word at the end (sync 2): were values still in play after the last queued round?  (Then, and only then,
+//   it finishes those entries round by round and runs step 6 again.)
+//
+// Index / flag work: HBM-bound, a few bytes per pair; the DFA walks are bound by one dependent LDS read per byte.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/lc_regex_gpu.h"
+#include "screen_kernel_layout.h"
+
+constexpr int kGrokPlanBlock = 256;
+constexpr uint32_t kGrokNone = 0xFFFFFFFFu;
+// nmatch word of a slot: low bits = contributing matches so far, high bits = the entry could not decide the value
+constexpr uint32_t kGrokSlotOverflow = 0x80000000u;  // thread lists overflowed and nothing settled it
+constexpr uint32_t kGrokSlotGaveUp = 0x40000000u;    // the decide kernel ran out of budget (regexp2's match timeout)
+constexpr uint32_t kGrokSlotCount = 0x3FFFFFFFu;
+// per-entry counter block (u32 words)
+enum {
+    GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
+    GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
+    GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
+    GC_SPARE_A = 14,    // the host-driven continuation alternates between these two
+    GC_SPARE_B = 15,
+    GC_WORDS = 16
+};
+
+// One screen of one Match entry (device table).
+struct GrokScreenDev {
+    const uint32_t* blob;  // screen_kernel_layout.h
+    uint32_t bit;          // Match index
+    uint32_t ldsBytes;     // bytes of (accept flags + table) staged into LDS; 0 = walk the table in global memory
+};
+
+// One ACTIVE entry (device table): the entry's private batch.
+struct GrokEntryDev {
+    uint32_t* off;     // [cand] byte offset of the slot's value
+    uint32_t* len;     // [cand]
+    uint32_t* line;    // [cand] the value's index in the caller's batch
+    uint32_t* from;    // [cand] resume offset of the next search
+    uint32_t* nmatch;  // [cand] kGrokSlot*
+    int32_t* first;    // [cand][capsRow] row of the first contributing match
+    uint32_t* cnt;     // GC_*
+    uint32_t cand, capsRow, bit, pad;
+};
+
+struct GrokSlotMap {
+    int8_t activeOfBit[64];  // Match index -> index into the GrokEntryDev table (-1: not active)
+};
+
+// no literal index for this list (fewer than two literals): every entry is a candidate for every value
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_mask_fill_kernel(uint64_t* __restrict__ masks, uint32_t n, uint64_t all) {
+    const uint32_t i = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (i < n) masks[i] = all;
+}
+
+// ---- all screens in one launch.  grid = (slices, screens); dynamic LDS = candidate list [sliceLen] u32 + staged table.
+// A slice is a run of consecutive values; the workgroup compacts the slice's carriers of the entry's bit into LDS (ballot),
+// then walks them one value per lane.  Table entries are read as u16 next-state; staged tables sit behind the list.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                        const uint32_t* __restrict__ len, uint32_t n, uint32_t sliceLen,
+                                                                        const GrokScreenDev* __restrict__ screens,
+                                                                        unsigned long long* __restrict__ masks) {
+    extern __shared__ uint32_t ldsWords[];
+    __shared__ uint8_t cmap[256];
+    __shared__ uint32_t sCount;
+    const GrokScreenDev sc = screens[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lo = blockIdx.x * sliceLen;
+    const uint32_t hi = lo + sliceLen < n ? lo + sliceLen : n;
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    uint32_t* cand = ldsWords;
+    // 1. carriers of this slice
+    for (uint32_t base = lo; base < hi; base += kGrokPlanBlock) {
+        const uint32_t v = base + tid;
+        const bool has = v < hi && ((masks[v] >> sc.bit) & 1ull);
+        const uint64_t b = __ballot(has);
+        if (b) {
+            uint32_t at = 0;
+            if ((tid & 63u) == 0) at = atomicAdd(&sCount, uint32_t(__popcll(b)));
+            at = __shfl(at, 0, 64);
+            if (has) cand[at + __popcll(b & ((1ull << (tid & 63u)) - 1ull))] = v;
+        }
+    }
+    __syncthreads();
+    const uint32_t count = sCount;
+    if (count == 0) return;
+    // 2. the entry's automaton
+    const uint32_t* blob = sc.blob;
+    cmap[tid] = reinterpret_cast<const uint8_t*>(blob + SC_HEADER_WORDS)[tid];
+    const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
+    const uint8_t* accept = reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_ACCEPT];
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
+    const bool staged = sc.ldsBytes != 0;
+    if (staged) {  // accept flags .. end of table are contiguous in the blob (4-byte aligned start)
+        uint32_t* dst = ldsWords + sliceLen;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
+        for (uint32_t i = tid; i < sc.ldsBytes / 4; i += kGrokPlanBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) : accept;
+    const uint16_t* lTable = staged ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) +
+                                                                         (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]))
+                                    : table;
+    // 3. walk
+    for (uint32_t k = tid; k < count; k += kGrokPlanBlock) {
+        const uint32_t v = cand[k];
+        const uint32_t L = len[v];
+        uint32_t state = start;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + off[v];
+        const uint32_t head = uint32_t(addr & 15);
+        const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+        const uint32_t total = L ? head + L : 0;
+        for (uint32_t pos = 0; pos < total && state != sink && state != 0; pos += 16) {
+            const uint4 w4 = *q++;
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t bi = pos + j;
+                if (bi >= head && bi < total) state = lTable[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
+            }
+        }
+        const bool pass = state == sink || (state != 0 && lAccept[state]);
+        if (!pass) atomicAnd(&masks[v], ~(1ull << sc.bit));
+    }
+}
+
+// candidates per entry after the screens
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_count_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
+                                                                   uint32_t* __restrict__ perEntry) {
+    const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    const uint64_t m = v < n ? masks[v] : 0;
+    for (uint32_t p = 0; p < nPatterns; ++p) {
+        const uint64_t has = __ballot((m >> p) & 1ull);
+        if (has && (threadIdx.x & 63u) == 0) atomicAdd(&perEntry[p], uint32_t(__popcll(has)));
+    }
+}
+
+// every (entry, value) pair that passed becomes a slot of the entry
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_scatter_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
+                                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ len,
+                                                                     GrokSlotMap map, const GrokEntryDev* __restrict__ entries) {
+    const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    const uint64_t m = v < n ? masks[v] : 0;
+    const uint32_t o = v < n ? off[v] : 0, L = v < n ? len[v] : 0;
+    for (uint32_t p = 0; p < nPatterns; ++p) {
+        const bool has = (m >> p) & 1ull;
+        const uint64_t b = __ballot(has);
+        if (!b) continue;
+        const int a = map.activeOfBit[p];
+        if (a < 0) continue;
+        const GrokEntryDev& e = entries[a];
+        uint32_t at = 0;
+        if ((threadIdx.x & 63u) == 0) at = atomicAdd(&e.cnt[GC_FILL], uint32_t(__popcll(b)));
+        at = __shfl(at, 0, 64);
+        if (has) {
+            const uint32_t slot = at + __popcll(b & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            if (slot < e.cand) {
+                e.off[slot] = o;
+                e.len[slot] = L;
+                e.line[slot] = v;
+                e.from[slot] = 0;
+                e.nmatch[slot] = 0;
+            }
+        }
+    }
+}
+
+// the slots the anchored search of round 0 did not match go on to the search proper
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_unmatched2_kernel(uint32_t nSlots, const uint8_t* __restrict__ status,
+                                                                        uint32_t* __restrict__ out, uint32_t* __restrict__ count) {
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= nSlots) return;
+    if (status[k] != LC_MATCH) out[atomicAdd(count, 1u)] = k;
+}
+
+// After one search round over the slots in `in` (nullptr: all slots below the bound); see grok_advance_kernel (grok_kernel.hpp)
+// for the rules.  inCount (optional): the list's length on the device.  Extra rows go to xtmp as [line, seq, bit, row...].
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_advance2_kernel(
+    const uint32_t* __restrict__ in, uint32_t bound, const uint32_t* __restrict__ inCount, const uint8_t* __restrict__ status,
+    const int32_t* __restrict__ caps, uint32_t capsRow, uint32_t columns, GrokEntryDev e, int32_t* __restrict__ xtmp, uint32_t xcap,
+    uint32_t xstride, uint32_t* __restrict__ xcount, uint32_t* __restrict__ out, uint32_t* __restrict__ outCount,
+    uint32_t* __restrict__ gate) {
+    uint32_t nIn = bound;
+    if (inCount) {
+        const uint32_t dyn = *inCount;
+        nIn = dyn < nIn ? dyn : nIn;
+    }
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t slot = in ? in[k] : k;
+    const uint8_t st = status[slot];
+    if (st == LC_OVERFLOW || st == LC_GAVE_UP) {
+        e.nmatch[slot] |= st == LC_OVERFLOW ? kGrokSlotOverflow : kGrokSlotGaveUp;
+        return;
+    }
+    if (st != LC_MATCH) return;
+    const int32_t* c = caps + size_t(slot) * capsRow;
+    bool contributes = false;
+    for (uint32_t g = 1; g <= columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
+    if (contributes) {
+        const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
+        int32_t* dst = nullptr;
+        if (seq == 0) {
+            dst = e.first + size_t(slot) * capsRow;
+        } else {
+            const uint32_t at = atomicAdd(xcount, 1u);
+            if (at < xcap) {
+                dst = xtmp + size_t(at) * xstride;
+                dst[0] = int32_t(e.line[slot]);
+                dst[1] = int32_t(seq);
+                dst[2] = int32_t(e.bit);
+                dst += 3;
+            }
+        }
+        if (dst)
+            for (uint32_t s = 0; s < capsRow; ++s) dst[s] = c[s];
+    }
+    const uint32_t b = uint32_t(c[0]), en = uint32_t(c[1]);
+    const uint32_t next = en > b ? en : en + 1;
+    if (next < e.len[slot]) {
+        e.from[slot] = next;
+        out[atomicAdd(outCount, 1u)] = slot;
+        if (gate) atomicAdd(gate, 1u);
+    }
+}
+
+// grid = (ceil(max cand / block), active entries).  gate (optional): leave at once while values are still in play somewhere.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_entry_finish_kernel(const GrokEntryDev* __restrict__ entries,
+                                                                          uint32_t* __restrict__ winner, uint32_t* __restrict__ undecided,
+                                                                          const uint32_t* __restrict__ gate) {
+    if (gate && *gate) return;
+    const GrokEntryDev& e = entries[blockIdx.y];
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= e.cand) return;
+    const uint32_t nm = e.nmatch[k];
+    const uint32_t line = e.line[k];
+    if (nm & (kGrokSlotOverflow | kGrokSlotGaveUp))
+        atomicMin(&undecided[line], (e.bit << 1) | ((nm & kGrokSlotOverflow) ? 0u : 1u));
+    else if (nm)
+        atomicMin(&winner[line], e.bit);
+}
+
+// pattern[v] = the first entry that contributed; an entry that could not decide the value stops the list there
+// (-2: thread-list overflow nobody settled; -3: gave up = the reference's matchTimeOut, processor_grok.go:156-160)
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_resolve_kernel(uint32_t n, const uint32_t* __restrict__ winner,
+                                                                     const uint32_t* __restrict__ undecided, int32_t* __restrict__ pattern,
+                                                                     const uint32_t* __restrict__ gate) {
+    if (gate && *gate) return;
+    const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t w = winner[v], u = undecided[v];
+    int32_t p = w == kGrokNone ? -1 : int32_t(w);
+    if (u != kGrokNone && (w == kGrokNone || (u >> 1) <= w)) p = (u & 1u) ? -3 : -2;
+    pattern[v] = p;
+}
+
+// the winner's first row goes out (d_first was preset to -1: only the entry's own columns are written)
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_kernel(const GrokEntryDev* __restrict__ entries,
+                                                                    const int32_t* __restrict__ pattern, int32_t* __restrict__ first,
+                                                                    uint32_t row, const uint32_t* __restrict__ gate) {
+    if (gate && *gate) return;
+    const GrokEntryDev& e = entries[blockIdx.y];
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= e.cand) return;
+    const uint32_t nm = e.nmatch[k];
+    if (!nm || (nm & (kGrokSlotOverflow | kGrokSlotGaveUp))) return;
+    const uint32_t line = e.line[k];
+    if (pattern[line] != int32_t(e.bit)) return;
+    const int32_t* src = e.first + size_t(k) * e.capsRow;
+    int32_t* dst = first + size_t(line) * row;
+    for (uint32_t s = 0; s < e.capsRow; ++s) dst[s] = src[s];
+}
+
+// further matches of the winners: [line, seq, bit, row...] -> [line, seq, row... padded with -1]; nextra = rows wanted
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_extra_kernel(const int32_t* __restrict__ xtmp, const uint32_t* __restrict__ xcount,
+                                                                          uint32_t xcap, uint32_t xstride, const GrokEntryDev* __restrict__ entries,
+                                                                          GrokSlotMap map, const int32_t* __restrict__ pattern,
+                                                                          int32_t* __restrict__ extra, uint32_t extraCap, uint32_t row,
+                                                                          uint32_t* __restrict__ nextra, const uint32_t* __restrict__ gate) {
+    if (gate && *gate) return;
+    uint32_t total = *xcount;
+    total = total < xcap ? total : xcap;
+    for (uint32_t r = blockIdx.x * kGrokPlanBlock + threadIdx.x; r < total; r += gridDim.x * kGrokPlanBlock) {
+        const int32_t* src = xtmp + size_t(r) * xstride;
+        const int32_t line = src[0], bit = src[2];
+        if (pattern[line] != bit) continue;
+        const uint32_t at = atomicAdd(nextra, 1u);
+        if (at >= extraCap) continue;
+        const uint32_t capsRow = entries[map.activeOfBit[bit]].capsRow;
+        int32_t* dst = extra + size_t(at) * (row + 2);
+        dst[0] = line;
+        dst[1] = src[1];
+        for (uint32_t s = 0; s < row; ++s) dst[2 + s] = s < capsRow ? src[3 + s] : -1;
+    }
+}

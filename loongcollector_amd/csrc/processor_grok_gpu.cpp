@@ -59,8 +59,17 @@ std::vector<GrokDevicePattern> ProcessorGrokGpu::devicePatterns() {
     return out;
 }
 
+GrokOptions ProcessorGrokGpu::options() const {
+    GrokOptions o;
+    o.speculative = Speculative;
+    o.prefixScreenAbove = PrefixScreenAbove < 0 ? 0u : uint32_t(std::min<int64_t>(PrefixScreenAbove, 0xFFFFFFFFll));
+    o.streams = uint32_t(std::max<int64_t>(1, std::min<int64_t>(Streams, 8)));
+    return o;
+}
+
 ProcessorGrokGpu::~ProcessorGrokGpu() {
     stopWarmup();
+    lcGrokStateFree(mState);
     for (lc_regex* re : mCompiled) lc_regex_free(re);
     for (lc_regex* re : mScreens) lc_regex_free(re);
 }
@@ -69,6 +78,8 @@ int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCo
 
 void ProcessorGrokGpu::Init() {
     stopWarmup();
+    lcGrokStateFree(mState);
+    mState = lcGrokStateCreate();
     for (lc_regex* re : mCompiled) lc_regex_free(re);
     for (lc_regex* re : mScreens) lc_regex_free(re);
     mCompiled.clear();
@@ -236,7 +247,7 @@ void ProcessorGrokGpu::MatchValues(const uint8_t* data, const uint32_t* off, con
         return;
     }
     std::vector<int32_t> first, extra;
-    int rc = lcGrokMatchHost(devicePatterns(), mRowInts, data, off, len, n, pattern, first, extra);
+    int rc = lcGrokMatchHost(devicePatterns(), mState, options(), mRowInts, data, off, len, n, pattern, first, extra);
     if (rc != LC_OK) throw GrokError(std::string("grok device match failed: ") + lc_last_error());
     const size_t w = mRowInts + 2;
     size_t x = 0;
@@ -350,6 +361,11 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
         boolean("IgnoreParseFailure", g->p.IgnoreParseFailure);
         boolean("KeepSource", g->p.KeepSource);
         boolean("AnchoredFirst", g->p.AnchoredFirst);
+        boolean("Speculative", g->p.Speculative);
+        if (const lcjson::Value* v = cfg.find("PrefixScreenAbove"))
+            if (v->isNumber()) g->p.PrefixScreenAbove = v->isInt ? v->inum : int64_t(v->num);
+        if (const lcjson::Value* v = cfg.find("Streams"))
+            if (v->isNumber()) g->p.Streams = v->isInt ? v->inum : int64_t(v->num);
         boolean("NoKeyError", g->p.NoKeyError);
         boolean("NoMatchError", g->p.NoMatchError);
         boolean("TimeoutError", g->p.TimeoutError);
@@ -435,8 +451,19 @@ extern "C" int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const u
                                     uint32_t n, int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extra_cap,
                                     uint32_t* d_nextra, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!g) return LC_ERR_ARG;
-    return lcGrokMatchDevice(g->p.devicePatterns(), g->p.rowInts(), d_data, d_off, d_len, n, d_pattern, d_first, d_extra,
-                              extra_cap, d_nextra, d_scratch, scratch_bytes, stream);
+    if (!g->p.deviceState()) return LC_ERR_ARG;
+    return lcGrokMatchDevice(g->p.devicePatterns(), g->p.deviceState(), g->p.options(), g->p.rowInts(), d_data, d_off, d_len, n,
+                             d_pattern, d_first, d_extra, extra_cap, d_nextra, d_scratch, scratch_bytes, stream);
+}
+
+extern "C" void lc_grok_last_batch_stats(uint32_t out[5]) {
+    if (!out) return;
+    const GrokBatchStats s = lcGrokLastBatchStats();
+    out[0] = s.hostSyncs;
+    out[1] = s.activeEntries;
+    out[2] = s.pairs;
+    out[3] = s.deferredEntries;
+    out[4] = s.speculative;
 }
 
 extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,

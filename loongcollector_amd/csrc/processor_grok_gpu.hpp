@@ -2,7 +2,7 @@
 //
 // Mirrors plugins/processor/grok/processor_grok.go: the exported fields keep their names (:42-53), Init follows :62-102,
 // ProcessLogs / processLog / processGrok follow :108-194 -- with the per-log regexp2 loop replaced by ONE batched device
-// call over the SourceKey values of all logs (lcGrokMatchHost, gpu_runtime.hip).  Logs are the protocol.Log shape: an
+// call over the SourceKey values of all logs (lcGrokMatchHost, grok_device.hip).  Logs are the protocol.Log shape: an
 // ordered list of (Key, Value) contents (duplicates allowed; fields are appended, processor_grok.go:183-185).
 #pragma once
 
@@ -44,6 +44,12 @@ public:
     // compiled BEHIND Init, on a warm-up thread, and join the device loop as they arrive (results do not depend on them, only speed;
     // WaitReady() blocks until the thread is done).  Instances that only probe a pattern switch it off.
     bool AnchoredFirst = true;
+    // not reference keys either (GrokOptions, grok_runtime.hpp; results never depend on them): evaluate all (entry, value) pairs that
+    // pass the screens at the same time (default) or walk the list entry by entry; the sequential path's prefix-screen threshold;
+    // worker streams of the speculative path
+    bool Speculative = true;
+    int64_t PrefixScreenAbove = 65536;
+    int64_t Streams = 4;
     bool NoKeyError = false;
     bool NoMatchError = true;
     bool TimeoutError = true;
@@ -71,6 +77,8 @@ public:
     const std::vector<GrokDevicePattern>& compiledPatterns() const { return mDevice; }  // (without the anchored searches)
     void WaitReady();                                       // returns when the warm-up thread has compiled what it can
     uint32_t rowInts() const { return mRowInts; }
+    GrokDeviceState* deviceState() { return mState; }
+    GrokOptions options() const;
     int engine(size_t i) const;
 
 private:
@@ -87,6 +95,7 @@ private:
     void startWarmup();
     void stopWarmup();
     std::vector<GrokDevicePattern> mDevice;
+    GrokDeviceState* mState = nullptr;                 // literal index + screen table on the device(s), built on first use
     std::vector<std::string> mKeys;                    // distinct emitted keys
     std::vector<std::vector<uint32_t>> mColumnKey;     // [pattern][column] -> key index
     // [pattern] fields in Groups() order: key index + the columns that share the name

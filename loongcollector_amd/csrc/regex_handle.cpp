@@ -596,6 +596,34 @@ static std::unique_ptr<Node> cloneWithoutCaptures(const Node& n) {
     return c;
 }
 
+// yes/no DFA blob (screen_kernel_layout.h) from the state graph of `t` (register programs, if any, are ignored: the states of a
+// tagged DFA recognise the same language): class map, accept flags, u16 next-state table.  Needs nStates <= 65535.
+static std::vector<uint32_t> packScreenBlob(const TdfaTables& t) {
+    uint32_t sink = 0xFFFFFFFFu;
+    for (uint32_t st = 1; st < t.nStates && sink == 0xFFFFFFFFu; ++st) {
+        bool self = t.finalId[st] != 0xFFFF;
+        for (uint32_t c = 0; c < t.nClasses && self; ++c) self = (t.trans[size_t(st) * t.nClasses + c] & 0xFFFF) == st;
+        if (self) sink = st;
+    }
+    BlobWriter w;
+    w.reserve(SC_HEADER_WORDS * 4);
+    w.put(t.classMap);
+    std::vector<uint8_t> accept(t.nStates, 0);
+    for (uint32_t st = 1; st < t.nStates; ++st) accept[st] = t.finalId[st] != 0xFFFF;
+    uint32_t hdr[SC_HEADER_WORDS] = {};
+    hdr[SC_MAGIC] = SC_MAGIC_VALUE;
+    hdr[SC_NSTATES] = t.nStates;
+    hdr[SC_NCLASSES] = t.nClasses;
+    hdr[SC_START] = t.startState;
+    hdr[SC_SINK] = sink;
+    hdr[SC_OFF_ACCEPT] = w.put(accept);
+    std::vector<uint16_t> table(size_t(t.nStates) * t.nClasses);
+    for (size_t i = 0; i < table.size(); ++i) table[i] = uint16_t(t.trans[i] & 0xFFFF);
+    hdr[SC_OFF_TABLE] = w.put(table);
+    std::memcpy(w.bytes.data(), hdr, sizeof hdr);
+    return w.finish(SC_TOTAL_BYTES);
+}
+
 // compile one candidate screen (a sub-expression every match of the pattern must contain) as a status-only search; nullptr if
 // it is nullable (screens nothing) or its automaton is too large
 static lc_regex* compileScreenNode(std::unique_ptr<Node> node, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes,
@@ -625,29 +653,7 @@ static lc_regex* compileScreenNode(std::unique_ptr<Node> node, uint32_t syntax_f
             if (getenv("LC_RELAX_DEBUG"))
                 fprintf(stderr, "  screen dfa: %u states, %u classes, %zu table bytes\n", t.nStates, t.nClasses, tableBytes);
             if (tableBytes > maxBlobBytes || t.nStates > 0xFFFF) return nullptr;
-            uint32_t sink = 0xFFFFFFFFu;
-            for (uint32_t st = 1; st < t.nStates && sink == 0xFFFFFFFFu; ++st) {
-                bool self = t.finalId[st] != 0xFFFF;
-                for (uint32_t c = 0; c < t.nClasses && self; ++c) self = (t.trans[size_t(st) * t.nClasses + c] & 0xFFFF) == st;
-                if (self) sink = st;
-            }
-            BlobWriter w;
-            w.reserve(SC_HEADER_WORDS * 4);
-            w.put(t.classMap);
-            std::vector<uint8_t> accept(t.nStates, 0);
-            for (uint32_t st = 1; st < t.nStates; ++st) accept[st] = t.finalId[st] != 0xFFFF;
-            uint32_t hdr[SC_HEADER_WORDS] = {};
-            hdr[SC_MAGIC] = SC_MAGIC_VALUE;
-            hdr[SC_NSTATES] = t.nStates;
-            hdr[SC_NCLASSES] = t.nClasses;
-            hdr[SC_START] = t.startState;
-            hdr[SC_SINK] = sink;
-            hdr[SC_OFF_ACCEPT] = w.put(accept);
-            std::vector<uint16_t> table(size_t(t.nStates) * t.nClasses);
-            for (size_t i = 0; i < table.size(); ++i) table[i] = uint16_t(t.trans[i] & 0xFFFF);
-            hdr[SC_OFF_TABLE] = w.put(table);
-            std::memcpy(w.bytes.data(), hdr, sizeof hdr);
-            re->screenBlob = w.finish(SC_TOTAL_BYTES);
+            re->screenBlob = packScreenBlob(t);
             re->engine = LC_ENGINE_TDFA;
             re->pattern = description;
             re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
@@ -664,6 +670,9 @@ static lc_regex* compileScreenNode(std::unique_ptr<Node> node, uint32_t syntax_f
         re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
         re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
         re->hasTdfa = true;
+        // the same automaton as a plain yes/no DFA: the merged screen launch of the Grok matcher (grok_plan_kernel.hpp) walks
+        // every entry's screen in this one format
+        if (re->tdfa.nStates <= 0xFFFF) re->screenBlob = packScreenBlob(re->tdfa);
         re->engine = LC_ENGINE_TDFA;
         re->pattern = description;
         re->syntaxFlags = syntax_flags | LC_SYNTAX_SEARCH;
@@ -1174,7 +1183,7 @@ extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     out->states = tables ? re->tdfa.nStates : 0;
     out->classes = tables ? re->tdfa.nClasses : (re->nfaBlob.empty() ? 0 : re->nfaBlob[NF_NCLASSES]);
     out->registers = tables ? re->tdfa.nRegs : 0;
-    out->table_bytes = uint32_t((!re->screenBlob.empty() ? re->screenBlob.size()
+    out->table_bytes = uint32_t((!re->hasTdfa && !re->screenBlob.empty() ? re->screenBlob.size()
                                  : !re->tdfaL2Blob.empty() ? re->tdfaL2Blob.size()
                                  : re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
     return LC_OK;

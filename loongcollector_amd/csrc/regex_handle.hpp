@@ -47,6 +47,9 @@ struct lc_regex {
     void* dNfaBlob[kLcMaxDevices] = {};
     void* dScreenBlob[kLcMaxDevices] = {};
     void* dTdfaL2Blob[kLcMaxDevices] = {};
+    // Grok (grok_device.hip): search rounds this Match entry queues ahead per batch (FindStringMatch + FindNextMatch ...); follows
+    // what the batches turn out to need
+    std::atomic<uint32_t> grokRounds{2}, grokRoundsSlack{0};
 };
 
 namespace lcregex {

@@ -1,0 +1,26 @@
+// runtime_internal.hpp -- what the device translation units share (implemented in gpu_runtime.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+struct lc_regex;
+
+void lcSetLastError(const std::string& msg);           // the thread's lc_last_error() text
+int lcHipFail(hipError_t e, const char* what);         // sets the error text, returns LC_ERR_HIP
+void lcNoteKernel(const char* name);                   // lc_launched_kernels() log
+void lcRegisterExitHook();                             // thread_local device resources: see gpu_runtime.hip
+bool lcRuntimeUsable();
+void lcGrokThreadRelease();                            // grok_device.hip: the calling thread's Grok buffers
+// the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
+void lcSetDecideSlot(int slot);
+// device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)
+int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out);
+
+#define LC_HIP_TRY(expr)                                    \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return lcHipFail(e_, #expr);  \
+    } while (0)

@@ -49,6 +49,8 @@ def _lib():
         L.lc_grok_process_logs_json.restype = i32
         L.lc_grok_process_logs_json.argtypes = [vp, cp, sz, ctypes.POINTER(vp)]
         L.lc_grok_free_string.argtypes = [vp]
+        L.lc_grok_last_batch_stats.restype = None
+        L.lc_grok_last_batch_stats.argtypes = [vp]
         L._lc_grok_bound = True
     return L
 
@@ -156,6 +158,13 @@ class Grok:
                                           d_extra.shape[0], d_nextra.data_ptr(), d_scratch.data_ptr(),
                                           d_scratch.numel() * d_scratch.element_size(), stream)
         binding._check(rc, "lc_grok_match_device")
+
+    def last_batch_stats(self):
+        """what the calling thread's last device batch did: host syncs, active entries, (entry, value) pairs, deferred entries, path"""
+        w = (ctypes.c_uint32 * 5)()
+        self._L.lc_grok_last_batch_stats(ctypes.cast(w, ctypes.c_void_p))
+        return {"host_syncs": int(w[0]), "active_entries": int(w[1]), "pairs": int(w[2]), "deferred_entries": int(w[3]),
+                "speculative": bool(w[4])}
 
     # ---- ProcessLogs: logs = [[(key, value str), ...], ...] -> same shape
     def process_logs(self, logs):

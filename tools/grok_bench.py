@@ -2,11 +2,15 @@
 """BASELINE.json configs[2] on one MI355X: processor_grok with the example_config pattern list (the Match entries of
 tests/golden/grok_config3.json that the device engines can run), mixed 128..4096 B lines resident in HBM.
 
-One "step" = one lc_grok_match_device() call over the whole batch (all patterns, all rounds).  A parity gate compares
-the device result with the Grok oracle on a sample before anything is timed; the oracle's own speed on that sample is
-reported beside the GPU number.  Prints one JSON line (same field names as bench.py).
+One "step" = one lc_grok_match_device() call over the whole batch (all patterns, all rounds).  Before anything is timed:
+  * a parity gate compares the device result with the Grok oracle on a STRIDED sample across the whole batch (first rows and
+    further matches), the oracle's own speed on that sample is reported beside the GPU number;
+  * the speculative path (default) and the sequential walk of the list must agree on EVERY value of the batch
+    (pattern ids, first rows, extra rows).
+Prints one JSON line per batch size (same field names as bench.py).
 
     python tools/grok_bench.py --lines 65536 --steps 5 --warmup 1
+    python tools/grok_bench.py --lines 1000,16384,65536 --steps 5
 """
 import argparse
 import json
@@ -20,26 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--lines", type=int, default=1 << 16)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-sample-lines", type=int, default=2000)
-    ap.add_argument("--patterns", type=int, default=0, help="use only the first N supported patterns (0 = all)")
-    args = ap.parse_args()
-
-    import torch
-
-    from loongcollector_amd import binding
+def supported_patterns(cfg):
     from loongcollector_amd.grok import Grok, GrokInitError
-    from loongcollector_amd.grok_corpus import grok_lines
-
-    if not torch.cuda.is_available():
-        raise SystemExit("grok_bench.py needs a HIP device: the Grok matcher has no CPU path")
-    dev = torch.device("cuda", 0)
-    with open(os.path.join(ROOT, "tests", "golden", "grok_config3.json"), encoding="utf-8") as f:
-        cfg = json.load(f)
     supported, refused = [], []
     for m in cfg["match"]:
         try:
@@ -47,107 +33,190 @@ def main():
             supported.append(m)
         except GrokInitError as e:
             refused.append((m, str(e).split(": ", 1)[-1][:80]))
+    return supported, refused
+
+
+class DeviceBatch:
+    """values resident in HBM + the output buffers of lc_grok_match_device"""
+
+    def __init__(self, torch, dev, g, values):
+        n = len(values)
+        self.n = n
+        self.values = values
+        self.length = np.array([len(v) for v in values], dtype=np.uint32)
+        off = np.zeros(n, dtype=np.uint32)
+        off[1:] = np.cumsum(self.length[:-1], dtype=np.uint64).astype(np.uint32)
+        data = np.frombuffer(b"".join(values) + b"\0" * 16, dtype=np.uint8).copy()
+        self.total_bytes = int(self.length.sum())
+        self.d_data = torch.from_numpy(data).to(dev)
+        self.d_off = torch.from_numpy(off.view(np.int32)).to(dev)
+        self.d_len = torch.from_numpy(self.length.view(np.int32)).to(dev)
+        self.row = g.row_ints
+        self.d_pattern = torch.empty(n, dtype=torch.int32, device=dev)
+        self.d_first = torch.empty((n, self.row), dtype=torch.int32, device=dev)
+        self.d_extra = torch.empty((n + 1024, self.row + 2), dtype=torch.int32, device=dev)
+        self.d_nextra = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_scratch = torch.empty(g.scratch_bytes(n), dtype=torch.uint8, device=dev)
+
+    def step(self, g):
+        g.match_device(self.d_data, self.d_off, self.d_len, self.n, self.d_pattern, self.d_first, self.d_extra, self.d_nextra,
+                       self.d_scratch)
+
+    def results(self):
+        nx = int(self.d_nextra.cpu()[0])
+        extra = self.d_extra[:nx].cpu().numpy()
+        if nx:
+            extra = extra[np.lexsort((extra[:, 1], extra[:, 0]))]
+        return self.d_pattern.cpu().numpy(), self.d_first.cpu().numpy(), extra
+
+
+def fields_of(g, values, i, pattern, first, extra_rows):
+    """emitted (key, value) pairs of value i from its rows, as processGrok emits them"""
+    if pattern[i] < 0:
+        return []
+    cols = g.columns(int(pattern[i]))
+    out = []
+    for rowv in [first[i]] + [r[2:] for r in extra_rows]:
+        got, seen = [], {}
+        for c, key in enumerate(cols):
+            b, e = int(rowv[2 + 2 * c]), int(rowv[3 + 2 * c])
+            if key is None:
+                continue
+            if key not in seen:
+                seen[key] = len(got)
+                got.append([key, -1, -1])
+            if b >= 0 and b >= got[seen[key]][1]:
+                got[seen[key]][1:] = [b, e]
+        out += [(k, values[i][b:e]) for k, b, e in got if e > b]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lines", default=str(1 << 16), help="batch size, or a comma-separated list of batch sizes")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample-lines", type=int, default=2000)
+    ap.add_argument("--patterns", type=int, default=0, help="use only the first N supported patterns (0 = all)")
+    ap.add_argument("--no-sequential-check", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="time the sequential walk of the list instead")
+    args = ap.parse_args()
+
+    import torch
+
+    from loongcollector_amd import binding
+    from loongcollector_amd.grok import Grok
+    from loongcollector_amd.grok_corpus import grok_lines
+
+    if not torch.cuda.is_available():
+        raise SystemExit("grok_bench.py needs a HIP device: the Grok matcher has no CPU path")
+    dev = torch.device("cuda", 0)
+    with open(os.path.join(ROOT, "tests", "golden", "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    supported, refused = supported_patterns(cfg)
     if args.patterns:
         supported = supported[:args.patterns]
-    g = Grok(Match=supported, CustomPatterns=cfg["custom_patterns"])
+    g = Grok(Match=supported, CustomPatterns=cfg["custom_patterns"], Speculative=not args.sequential)
+    g_seq = Grok(Match=supported, CustomPatterns=cfg["custom_patterns"], Speculative=False)
     t0 = time.perf_counter()
     g.wait_ready()   # the anchored searches are compiled behind Init; the timed steps should see the matcher at full speed
+    g_seq.wait_ready()
     warm_s = time.perf_counter() - t0
     engines = [g.engine(i) for i in range(g.n_match)]
-
-    values = grok_lines(args.lines)
-    n = len(values)
-    length = np.array([len(v) for v in values], dtype=np.uint32)
-    off = np.zeros(n, dtype=np.uint32)
-    off[1:] = np.cumsum(length[:-1], dtype=np.uint64).astype(np.uint32)
-    data = np.frombuffer(b"".join(values) + b"\0" * 16, dtype=np.uint8).copy()
-    total_bytes = int(length.sum())
-    d_data = torch.from_numpy(data).to(dev)
-    d_off = torch.from_numpy(off.view(np.int32)).to(dev)
-    d_len = torch.from_numpy(length.view(np.int32)).to(dev)
-    row = g.row_ints
-    d_pattern = torch.empty(n, dtype=torch.int32, device=dev)
-    d_first = torch.empty((n, row), dtype=torch.int32, device=dev)
-    d_extra = torch.empty((n + 1024, row + 2), dtype=torch.int32, device=dev)
-    d_nextra = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_scratch = torch.empty(g.scratch_bytes(n), dtype=torch.uint8, device=dev)
-
-    def step():
-        g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch)
-
-    step()
-    torch.cuda.synchronize()
-    pattern = d_pattern.cpu().numpy()
-    first = d_first.cpu().numpy()
-
-    # ---- parity gate + CPU baseline on a sample (the oracle is the checker, never the measured path)
     from oracle.grok_oracle import GrokOracle
     o = GrokOracle(supported, custom_patterns=cfg["custom_patterns"])
-    sample = min(args.cpu_sample_lines, n)
-    t0 = time.perf_counter()
-    want = [o.process_value(values[i]) for i in range(sample)]
-    cpu_s = time.perf_counter() - t0
-    for i, (res, fields) in enumerate(want):
-        if (pattern[i] >= 0) != (res == 0):
-            raise SystemExit("PARITY FAILURE: line %d pattern %d vs oracle result %d" % (i, pattern[i], res))
-        if res == 0:
-            cols = g.columns(int(pattern[i]))
-            got = []
-            seen = {}
-            for c, key in enumerate(cols):   # first contributing match only (further matches are in d_extra)
-                b, e = int(first[i][2 + 2 * c]), int(first[i][3 + 2 * c])
-                if key is None:
-                    continue
-                if key not in seen:
-                    seen[key] = len(got)
-                    got.append([key, -1, -1])
-                if b >= 0 and b >= got[seen[key]][1]:
-                    got[seen[key]][1:] = [b, e]
-            got = [(k, values[i][b:e]) for k, b, e in got if e > b]
-            if got != fields[:len(got)] or (not got and fields):
+
+    for n_lines in [int(x) for x in args.lines.split(",")]:
+        values = grok_lines(n_lines)
+        n = len(values)
+        batch = DeviceBatch(torch, dev, g, values)
+        batch.step(g)
+        torch.cuda.synchronize()
+        stats = g.last_batch_stats()
+        pattern, first, extra = batch.results()
+
+        # ---- parity gate 1: the oracle on a strided sample across the batch (the oracle is the checker, never the measured path)
+        sample = min(args.cpu_sample_lines, n)
+        idx = np.unique(np.linspace(0, n - 1, sample).astype(np.int64))
+        by_line = {}
+        for r in extra:
+            by_line.setdefault(int(r[0]), []).append(r)
+        t0 = time.perf_counter()
+        want = [o.process_value(values[i]) for i in idx]
+        cpu_s = time.perf_counter() - t0
+        for i, (res, fields) in zip(idx, want):
+            if (pattern[i] >= 0) != (res == 0):
+                raise SystemExit("PARITY FAILURE: line %d pattern %d vs oracle result %d" % (i, pattern[i], res))
+            if fields_of(g, values, i, pattern, first, by_line.get(int(i), [])) != fields:
                 raise SystemExit("PARITY FAILURE: line %d fields differ from the oracle" % i)
-    sample_bytes = int(length[:sample].sum())
+        sample_bytes = int(batch.length[idx].sum())
+        # ---- parity gate 2: the other path through the list, on every value
+        seq_checked = False
+        if not args.no_sequential_check:
+            other = g_seq if not args.sequential else Grok(Match=supported, CustomPatterns=cfg["custom_patterns"]).wait_ready()
+            b2 = DeviceBatch(torch, dev, other, values)
+            b2.step(other)
+            torch.cuda.synchronize()
+            p2, f2, x2 = b2.results()
+            if not np.array_equal(pattern, p2):
+                bad = np.nonzero(pattern != p2)[0]
+                raise SystemExit("PARITY FAILURE: speculative and sequential paths disagree on %d pattern ids, first at line %d (%d vs %d)"
+                                 % (len(bad), bad[0], pattern[bad[0]], p2[bad[0]]))
+            won = pattern >= 0
+            if not np.array_equal(first[won], f2[won]) or not np.array_equal(extra, x2):
+                raise SystemExit("PARITY FAILURE: speculative and sequential paths disagree on capture rows")
+            seq_checked = True
+            del b2
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        for _ in range(args.warmup):
+            batch.step(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            batch.step(g)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
 
-    hist = np.bincount(pattern[pattern >= 0], minlength=g.n_match)
-    out = {
-        "metric": "Grok lines/s (50-pattern example_config list, mixed 128-4096B lines) per MI355X",
-        "value": round(n * args.steps / elapsed, 1), "unit": "lines/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "MBps": round(total_bytes * args.steps / elapsed / 1e6, 2),
-        "config": {"workload": "configs[2]: processor_grok, %d of the 50 example_config log-format patterns (ordered, first "
-                               "match wins), %d lines of %d..%d B (mean %d) resident in HBM"
-                               % (len(supported), n, int(length.min()), int(length.max()), int(length.mean())),
-                   "patterns_supported": len(supported), "patterns_refused": refused,
-                   "engines": {"tdfa": engines.count(binding.LC_ENGINE_TDFA), "nfa": engines.count(binding.LC_ENGINE_NFA)},
-                   "matched_lines": int((pattern >= 0).sum()), "undecidable_lines": int((pattern == -2).sum()),
-                   "undecidable_line_indices": [int(i) for i in np.nonzero(pattern == -2)[0][:32]],
-                   "extra_match_rows": int(d_nextra.cpu()[0]),
-                   "patterns_hit": int((hist > 0).sum()),
-                   "warm_up_s": round(warm_s, 2)},
-        # algorithmic HBM bytes of one step: every value read once + 4 B offset + 4 B length + the result row (pattern id +
-        # first-match row) written once per line.  The NFA kernels are nowhere near it: they are bound by the dependent table
-        # reads of a byte-step (one line per wavefront), not by HBM -- the fraction says how far.
-        "roofline": {"bound": "hbm", "achieved": round((total_bytes + n * (8 + 4 + 4 * row)) * args.steps / elapsed / 1e9, 3),
-                     "peak": 8000.0, "unit": "GB/s",
-                     "frac": round((total_bytes + n * (8 + 4 + 4 * row)) * args.steps / elapsed / 1e9 / 8000.0, 6), "traffic": None,
-                     "kernel": "nfa_match_kernel (40 of the 50 patterns) + tdfa kernels (10 patterns, prefix screens)",
-                     "algorithmic_bytes_per_step": int(total_bytes + n * (8 + 4 + 4 * row))},
-        "cpu_baseline": {"value": round(sample / cpu_s, 1), "unit": "lines/s", "cores": 1, "kind": "port",
-                         "MBps": round(sample_bytes / cpu_s / 1e6, 3),
-                         "sample": "first %d lines of the batch: oracle/grok_oracle.py over oracle/bt_regex.c "
-                                   "(processGrok restated), 1 thread" % sample},
-    }
-    print(json.dumps(out))
+        row = batch.row
+        total_bytes = batch.total_bytes
+        length = batch.length
+        hist = np.bincount(pattern[pattern >= 0], minlength=g.n_match)
+        alg = total_bytes + n * (8 + 4 + 4 * row)
+        out = {
+            "metric": "Grok lines/s (50-pattern example_config list, mixed 128-4096B lines) per MI355X",
+            "value": round(n * args.steps / elapsed, 1), "unit": "lines/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "MBps": round(total_bytes * args.steps / elapsed / 1e6, 2),
+            "config": {"workload": "configs[2]: processor_grok, %d of the 50 example_config log-format patterns (ordered, first "
+                                   "match wins), %d lines of %d..%d B (mean %d) resident in HBM"
+                                   % (len(supported), n, int(length.min()), int(length.max()), int(length.mean())),
+                       "path": "sequential" if args.sequential else "speculative", "batch": stats,
+                       "patterns_supported": len(supported), "patterns_refused": refused,
+                       "engines": {"tdfa": engines.count(binding.LC_ENGINE_TDFA), "nfa": engines.count(binding.LC_ENGINE_NFA)},
+                       "matched_lines": int((pattern >= 0).sum()), "undecidable_lines": int((pattern <= -2).sum()),
+                       "undecidable_line_indices": [int(i) for i in np.nonzero(pattern <= -2)[0][:32]],
+                       "extra_match_rows": int(len(extra)),
+                       "patterns_hit": int((hist > 0).sum()),
+                       "parity": {"oracle_sample": "%d lines strided across the batch" % len(idx),
+                                  "both_paths_agree_on_every_line": seq_checked},
+                       "warm_up_s": round(warm_s, 2)},
+            # algorithmic HBM bytes of one step: every value read once + 4 B offset + 4 B length + the result row (pattern id +
+            # first-match row) written once per line.  The automaton kernels are nowhere near it: they are bound by the dependent
+            # table reads of a byte-step, not by HBM -- the fraction says how far.
+            "roofline": {"bound": "hbm", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
+                         "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(alg * args.steps / elapsed / 1e9 / 8000.0, 6), "traffic": None,
+                         "kernel": "the batch's whole kernel chain (literal index, merged screens, %d nfa + %d tdfa entries)"
+                                   % (engines.count(binding.LC_ENGINE_NFA), engines.count(binding.LC_ENGINE_TDFA)),
+                         "algorithmic_bytes_per_step": int(alg)},
+            "cpu_baseline": {"value": round(len(idx) / cpu_s, 1), "unit": "lines/s", "cores": 1, "kind": "port",
+                             "MBps": round(sample_bytes / cpu_s / 1e6, 3),
+                             "sample": "%d lines strided across the batch: oracle/grok_oracle.py over oracle/bt_regex.c "
+                                       "(processGrok restated), 1 thread" % len(idx)},
+        }
+        print(json.dumps(out), flush=True)
+        del batch
 
 
 if __name__ == "__main__":
