@@ -75,7 +75,9 @@ int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per c
  *                                [whole.b, whole.e, col0.b, col0.e, ...], -1 = column did not take part
  * d_extra    int32[cap][2+row]   further contributing matches of the same value (FindNextMatch): [line, seq>=1, row...]
  * d_nextra   uint32[1]           rows written to d_extra; > cap means d_extra was too small (LC_ERR_OVERFLOW is returned
- *                                and the call must be repeated with a larger d_extra)
+ *                                and the call must be repeated with a d_extra of at least that many rows; the default path keeps
+ *                                the further matches of every candidate entry in temporary rows until the winner is known, so
+ *                                the number reported with LC_ERR_OVERFLOW can exceed the rows finally written)
  * d_scratch  lc_grok_scratch_bytes(g, n) bytes
  * The call enqueues on `stream` (and on a few worker streams of its own that fork from it and join it) and returns after the
  * last kernel has finished.  Default path: TWO host synchronisations per batch (candidates per entry; results) -- the number of

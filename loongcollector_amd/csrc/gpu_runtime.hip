@@ -88,6 +88,11 @@ void lcRegisterExitHook() {
 }
 bool lcRuntimeUsable() { return !gProcessExiting.load(); }
 
+// The Grok matcher spreads the entries of a Match list over up to 8 worker streams (grok_device.hip); the HIP runtime maps streams
+// onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the caller's), and streams that share a queue run one after the
+// other.  Ask for 8 unless the host has an opinion of its own; read by the runtime when it initialises, i.e. at the first HIP call.
+__attribute__((constructor)) static void lcAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int lc_device_count(void) {
     // (a positive answer does not change during the process's life: every match call asks, from every runner thread, and a
     // runtime call per group is a shared lock per group)
@@ -858,6 +863,20 @@ extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8
 }
 
 extern "C" size_t lc_sched_scratch_bytes(uint32_t max_lines) { return (size_t(max_lines) + 2 * kSchedBuckets) * 4; }
+
+// runtime_internal.hpp: order[] = the lines sorted by length bucket, longest first; work = 2 * kSchedBuckets words
+int lcLengthOrderOnStream(const uint32_t* d_off, const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t* work, uint32_t* order,
+                          hipStream_t st) {
+    uint32_t* hist = work;
+    uint32_t* cursor = hist + kSchedBuckets;
+    HIP_TRY(hipMemsetAsync(hist, 0, kSchedBuckets * 4, st));
+    const uint32_t grid = std::min<uint32_t>((n + kSchedBlock - 1) / kSchedBlock, 2048u);
+    hipLaunchKernelGGL(sched_hist_kernel, dim3(grid), dim3(kSchedBlock), 0, st, d_off, d_len, sep_bytes, n, nullptr, hist);
+    hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(kSchedBuckets), 0, st, hist, cursor);
+    hipLaunchKernelGGL(sched_scatter_kernel, dim3(grid), dim3(kSchedBlock), 0, st, d_off, d_len, sep_bytes, n, nullptr, cursor, order);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
+}
 
 extern "C" int lc_regex_match_device_ragged(lc_regex_t* re, int engine, const uint8_t* d_data, const uint32_t* d_off,
                                             const uint32_t* d_len, uint32_t sep_bytes, uint32_t n,

@@ -13,12 +13,14 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "grok_kernel.hpp"
@@ -33,6 +35,15 @@ namespace {
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 thread_local GrokBatchStats tlsStats;
+// lcGrokMatchHost asks the device call to queue the copies of its results (pinned host memory) behind its last kernels, so that the
+// call's final synchronisation covers them
+struct GrokTailCopy {
+    int32_t* hPattern = nullptr;
+    int32_t* hFirst = nullptr;
+    bool armed = false, done = false;
+    uint32_t nextra = 0;
+};
+thread_local GrokTailCopy tlsTail;
 hipError_t syncCounted(hipStream_t st) {
     ++tlsStats.hostSyncs;
     return hipStreamSynchronize(st);
@@ -42,11 +53,11 @@ hipError_t syncCounted(hipStream_t st) {
 GrokBatchStats lcGrokLastBatchStats() { return tlsStats; }
 
 // Scratch layout.  Sequential path: caps int32[n][row] | status u8[n] (padded) | from, nmatch, tried, next, roundA, roundB,
-// unanchored : u32[n] each | counters u32[64] | perPattern u32[64] | masks u64[n].  The speculative path only uses the tail
+// unanchored : u32[n] each | counters u32[64] | perPattern u32[64] | masks u64[n] | work u32[1024].  The speculative path only uses the tail
 // (counters .. masks) plus winner / undecided u32[n] carved from the head; its per-entry arrays come from the thread's arena.
 size_t lcGrokScratchBytes(uint32_t n, uint32_t rowInts) {
     const size_t m = n ? n : 1;
-    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 512 + alignUp(m * 8, 256);
+    return alignUp(m * rowInts * 4, 256) + alignUp(m, 256) + 7 * alignUp(m * 4, 256) + 512 + alignUp(m * 8, 256) + 4096;
 }
 
 // ------------------------------------------------------------------------------------------------ per-handle device state
@@ -60,6 +71,12 @@ struct GrokDeviceState {
     void* dScreens[kLcMaxDevices] = {};
     uint32_t nScreens[kLcMaxDevices] = {};
     uint32_t screenLdsBytes[kLcMaxDevices] = {};  // largest staged table
+    // lcGrokMatchHost: groups of runner threads that arrive while a batch is on the device travel together (group commit)
+    struct HostJob;
+    std::mutex jobsMutex;
+    std::condition_variable jobsCv;
+    std::vector<HostJob*> pending;  // groups waiting for a leader
+    int running = 0;                // merged batches in flight
 };
 
 GrokDeviceState* lcGrokStateCreate() { return new GrokDeviceState(); }
@@ -150,7 +167,7 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
     if (literalIndex) {
         HIP_TRY(hipMemsetAsync(perPattern, 0, 256, st));
         hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex,
-                           masks, uint32_t(patterns.size()), perPattern);
+                           masks, uint32_t(patterns.size()), perPattern, static_cast<const uint32_t*>(nullptr));
         carriers.resize(64);
         HIP_TRY(hipMemcpyAsync(carriers.data(), perPattern, 256, hipMemcpyDeviceToHost, st));
         HIP_TRY(syncCounted(st));
@@ -312,10 +329,11 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
 namespace {
 constexpr int kGrokMaxStreams = 8;
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
-constexpr uint32_t kGrokMaxRounds = GC_SPARE_A - GC_ROUND0;  // search rounds that can be queued ahead per entry
+constexpr uint32_t kGrokMaxRounds = GC_FILTERED - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
+constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
-enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_WORDS = 128 + 64 * GC_WORDS };
+enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_FIRST = 128 + 64 * GC_WORDS, HW_WORDS = 192 + 64 * GC_WORDS };
 // device tail words (scratch `counters`): [0] gate  [1] xcount (extra rows wanted in xtmp)
 enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16 };
 
@@ -446,6 +464,7 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
 // host view of one active entry of the batch
 struct PlanEntry {
     uint32_t p = 0, cand = 0, capsRow = 0, columns = 0, rounds = 0, ran = 0;
+    bool second = false;  // searched in the second pass, on the values nobody has won by then
     int stream = 0;
     double cost = 0;
     GrokEntryDev dev{};
@@ -484,19 +503,30 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     uint64_t* masks = reinterpret_cast<uint64_t*>(tailAt + 512);
 
     const uint32_t gridAll = (n + kGrokPlanBlock - 1) / kGrokPlanBlock;
-    // ---- phase 1: literal index, all screens, candidate counts
+    // ---- phase 1: length order, literal index, all screens, candidate counts
+    // Small batches wait for their LONGEST value (every kernel below is a dependent chain per value): chunk-parallel literal pass,
+    // screen tables in LDS.  Large batches are about values in flight and equal work per wavefront: lane-per-value in length order.
+    const bool small = n <= kGrokSmallBatch;
+    uint32_t* order = reinterpret_cast<uint32_t*>(head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256));
+    uint32_t* orderWork = reinterpret_cast<uint32_t*>(tailAt + 512 + alignUp(size_t(n) * 8, 256));  // work words behind the masks
     HIP_TRY(hipMemsetAsync(tailAt, 0, 512, st));
+    {
+        int rc = lcLengthOrderOnStream(d_off, d_len, 0, n, orderWork, order, st);
+        if (rc != LC_OK) return rc;
+    }
     const uint32_t* literalIndex = nullptr;
     {
         int rc = grokLiteralIndex(patterns, state, dev, &literalIndex);
         if (rc != LC_OK) return rc;
     }
-    if (literalIndex) {
-        // (its per-entry carrier counts land in perEntry and are overwritten by grok_count_kernel's after the screens)
+    if (literalIndex && small) {
+        lcNoteKernel("grok_literal_chunk_kernel");
+        hipLaunchKernelGGL(grok_literal_chunk_kernel, dim3((n + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64)), dim3(kGrokPlanBlock), 0, st,
+                           d_data, d_off, d_len, n, literalIndex, masks);
+    } else if (literalIndex) {
         lcNoteKernel("grok_literal_index_kernel");
         hipLaunchKernelGGL(grok_literal_index_kernel, dim3(gridAll), dim3(kGrokBlock), 0, st, d_data, d_off, d_len, n, literalIndex, masks,
-                           nP, perEntry);
-        HIP_TRY(hipMemsetAsync(perEntry, 0, 256, st));
+                           nP, static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(order));
     } else {
         hipLaunchKernelGGL(grok_mask_fill_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n,
                            nP >= 64 ? ~0ull : ((1ull << nP) - 1ull));
@@ -510,15 +540,19 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     if (nScreens) {
         // slices: short enough that a small batch still spreads over the chip, long enough that the table staging is amortised
         uint32_t sliceLen = ((n / 64 + 255) / 256) * 256;
-        sliceLen = std::max(256u, std::min(4096u, sliceLen));
+        sliceLen = std::max(256u, std::min(small ? 4096u : 1024u, sliceLen));
         const uint32_t slices = (n + sliceLen - 1) / sliceLen;
         lcNoteKernel("grok_screen_all_kernel");
-        hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + screenLds, st, d_data,
-                           d_off, d_len, n, sliceLen, screens, reinterpret_cast<unsigned long long*>(masks));
+        hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + (small ? screenLds : 0),
+                           st, d_data, d_off, d_len, n, sliceLen, screens, reinterpret_cast<unsigned long long*>(masks),
+                           static_cast<const uint32_t*>(order), small ? 1u : 0u);
     }
-    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry);
+    uint32_t* firstOf = orderWork + 512;  // [64]
+    HIP_TRY(hipMemsetAsync(firstOf, 0, 256, st));
+    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry, firstOf);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CAND, perEntry, 256, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_FIRST, firstOf, 256, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(winner, 0xFF, size_t(n) * 8, st));
     HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
     HIP_TRY(hipMemsetAsync(d_nextra, 0, 4, st));
@@ -563,8 +597,27 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         o.first = carve(size_t(c) * e.capsRow * 4);
         o.caps = carve(size_t(c) * e.capsRow * 4);
         o.status = carve(size_t(c) + 16);
+        // second pass: see phase 2
+        const uint32_t shadowed = c - std::min(c, T.hostWords[HW_FIRST + p]);
+        e.second = !small && nfa && shadowed >= 1024 && shadowed >= c / 4;
         offs.push_back(o);
         act.push_back(e);
+    }
+    // (the device table lists the entries of the first pass first: its finish kernel runs over a prefix of the table)
+    uint32_t nSecond = 0;
+    {
+        std::vector<size_t> idx(act.size());
+        for (size_t a = 0; a < idx.size(); ++a) idx[a] = a;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return act[x].second < act[y].second; });
+        std::vector<PlanEntry> act2;
+        std::vector<Offsets> offs2;
+        for (size_t a : idx) {
+            act2.push_back(act[a]);
+            offs2.push_back(offs[a]);
+            nSecond += act[a].second;
+        }
+        act.swap(act2);
+        offs.swap(offs2);
     }
     stats.activeEntries = uint32_t(act.size());
     GrokSlotMap map;
@@ -605,67 +658,103 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     if (nAct) {
         HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(T.dCnt, 0, size_t(nAct) * GC_WORDS * 4, st));
-        hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries);
+        hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries,
+                           static_cast<const uint32_t*>(order));
         HIP_TRY(hipGetLastError());
-        // ---- phase 2: every entry is a batch of its own; the dearest first, dealt round-robin to the worker streams
-        std::vector<size_t> order(nAct);
-        for (size_t a = 0; a < nAct; ++a) order[a] = a;
-        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return act[x].cost > act[y].cost; });
+        // ---- phase 2: every entry is a batch of its own; the dearest first, dealt round-robin to the worker streams.
+        // Second pass (large batches only): an NFA-engine entry many of whose candidates have an EARLIER candidate entry (a general
+        // format shadowed by specific ones: SYSLOGLINE behind CRONLOG ...) waits for the first pass and searches only the values
+        // nobody has won by then.
+        std::vector<size_t> byCost(nAct);
+        for (size_t a = 0; a < nAct; ++a) byCost[a] = a;
+        std::sort(byCost.begin(), byCost.end(), [&](size_t x, size_t y) { return act[x].cost > act[y].cost; });
         const uint32_t used = std::min<uint32_t>(nStreams, nAct);
-        HIP_TRY(hipEventRecord(T.fork, st));
-        for (uint32_t s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(T.workers[s], T.fork, 0));
-        for (size_t i = 0; i < nAct; ++i) {
-            PlanEntry& e = act[order[i]];
-            e.stream = int(i % used);
-            hipStream_t ws = T.workers[e.stream];
-            lcSetDecideSlot(1 + e.stream);
+        // one entry's launches on stream ws: (filter,) round 0 (anchored first), the rounds queued ahead
+        auto queueEntry = [&](PlanEntry& e, hipStream_t ws, bool secondPass) -> int {
             const GrokDevicePattern& gp = patterns[e.p];
             const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
             auto advance = [&](const uint32_t* list, const uint32_t* countPtr, uint32_t* out, uint32_t* outCount, bool last) {
                 hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
                                    e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out, outCount, last ? gate : nullptr);
             };
+            // round 0 over: all slots, or what the filter leaves (listB; round 1 reads listA and writes listB afterwards)
+            const uint32_t* list0 = nullptr;
+            const uint32_t* count0 = nullptr;
+            if (secondPass) {
+                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, winner, e.listB,
+                                   e.dev.cnt + GC_FILTERED);
+                list0 = e.listB;
+                count0 = e.dev.cnt + GC_FILTERED;
+            }
             int rc = LC_OK;
-            // round 0
             const bool last0 = e.rounds == 1;
             uint32_t* out0 = e.listA;
             uint32_t* outCount0 = e.dev.cnt + GC_ROUND0;
             if (gp.anchored) {
-                rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr, nullptr,
+                rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, nullptr,
                                      e.capsRow / 2, e.caps, e.status, ws);
-                if (rc == LC_OK) {
-                    hipLaunchKernelGGL(grok_unmatched2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.cand, e.status, e.unanchored,
-                                       e.dev.cnt + GC_UNANCHORED);
-                    advance(nullptr, nullptr, out0, outCount0, last0);
-                    rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
-                                         e.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                    if (rc == LC_OK) advance(e.unanchored, e.dev.cnt + GC_UNANCHORED, out0, outCount0, last0);
-                }
+                if (rc != LC_OK) return rc;
+                hipLaunchKernelGGL(grok_unmatched2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list0, e.cand, count0, e.status,
+                                   e.unanchored, e.dev.cnt + GC_UNANCHORED);
+                advance(list0, count0, out0, outCount0, last0);
+                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
+                                     e.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                if (rc != LC_OK) return rc;
+                advance(e.unanchored, e.dev.cnt + GC_UNANCHORED, out0, outCount0, last0);
             } else {
-                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr, e.dev.from,
+                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, e.dev.from,
                                      e.capsRow / 2, e.caps, e.status, ws);
-                if (rc == LC_OK) advance(nullptr, nullptr, out0, outCount0, last0);
+                if (rc != LC_OK) return rc;
+                advance(list0, count0, out0, outCount0, last0);
             }
             // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
-            for (uint32_t r = 1; r < e.rounds && rc == LC_OK; ++r) {
+            for (uint32_t r = 1; r < e.rounds; ++r) {
                 const uint32_t* list = (r & 1) ? e.listA : e.listB;
                 uint32_t* out = (r & 1) ? e.listB : e.listA;
                 const uint32_t* countPtr = e.dev.cnt + GC_ROUND0 + r - 1;
                 rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
                                      e.capsRow / 2, e.caps, e.status, ws);
-                if (rc == LC_OK) advance(list, countPtr, out, e.dev.cnt + GC_ROUND0 + r, r + 1 == e.rounds);
+                if (rc != LC_OK) return rc;
+                advance(list, countPtr, out, e.dev.cnt + GC_ROUND0 + r, r + 1 == e.rounds);
             }
+            return LC_OK;
+        };
+        auto queuePass = [&](bool secondPass) -> int {
+            HIP_TRY(hipEventRecord(T.fork, st));
+            for (uint32_t s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(T.workers[s], T.fork, 0));
+            uint32_t dealt = 0;
+            int rc = LC_OK;
+            for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+                PlanEntry& e = act[byCost[i]];
+                if (e.second != secondPass) continue;
+                e.stream = int(dealt++ % used);
+                lcSetDecideSlot(1 + e.stream);
+                rc = queueEntry(e, T.workers[e.stream], secondPass);
+            }
+            lcSetDecideSlot(0);
+            if (rc == LC_OK && hipGetLastError() != hipSuccess) rc = lcHipFail(hipGetLastError(), "grok entry launch");
             if (rc != LC_OK) {
-                lcSetDecideSlot(0);
                 for (uint32_t s = 0; s < used; ++s) (void)hipStreamSynchronize(T.workers[s]);
                 return rc;
             }
+            for (uint32_t s = 0; s < used; ++s) {
+                HIP_TRY(hipEventRecord(T.join[s], T.workers[s]));
+                HIP_TRY(hipStreamWaitEvent(st, T.join[s], 0));
+            }
+            return LC_OK;
+        };
+        {
+            int rc = queuePass(false);
+            if (rc != LC_OK) return rc;
         }
-        lcSetDecideSlot(0);
-        HIP_TRY(hipGetLastError());
-        for (uint32_t s = 0; s < used; ++s) {
-            HIP_TRY(hipEventRecord(T.join[s], T.workers[s]));
-            HIP_TRY(hipStreamWaitEvent(st, T.join[s], 0));
+        if (nSecond && nSecond < nAct)
+            // what the first pass has won so far (an entry of the first pass that still has values in play keeps the gate shut: then
+            // nothing is filtered, which costs time, never results)
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock, nAct - nSecond),
+                               dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, gate);
+        if (nSecond) {
+            int rc = queuePass(true);
+            if (rc != LC_OK) return rc;
         }
     }
     // ---- phase 3: the first contributing entry per value; its rows go out.  All of it returns at once when values are still in
@@ -685,7 +774,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, tail, TW_WORDS * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS, d_nextra, 4, hipMemcpyDeviceToHost, st));
         if (nAct) HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
+        if (tlsTail.armed) {
+            HIP_TRY(hipMemcpyAsync(tlsTail.hPattern, d_pattern, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(tlsTail.hFirst, d_first, size_t(n) * row * 4, hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(syncCounted(st));
+        if (tlsTail.armed) {
+            tlsTail.done = true;
+            tlsTail.nextra = T.hostWords[HW_TAIL + TW_WORDS];
+        }
         return LC_OK;
     };
     {
@@ -694,31 +791,41 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     }
     const double tPhase3 = msNow();
     if (T.hostWords[HW_TAIL + TW_GATE] != 0) {
-        // values still in play after the last queued round of some entries: finish those round by round (the host reads a
-        // count per round here -- an entry pays this once, then asks for more rounds ahead)
+        // values still in play after the last queued round of some entries: those entries go on, a stretch of rounds at a time (as
+        // many again as they had queued, the counts on the device as before), until nothing is left -- an entry pays this once, then
+        // asks for that many rounds ahead
         for (size_t a = 0; a < nAct; ++a) {
             PlanEntry& e = act[a];
             uint32_t inPlay = T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + e.rounds - 1];
             if (!inPlay) continue;
             ++stats.deferredEntries;
             const GrokDevicePattern& gp = patterns[e.p];
-            uint32_t r = e.rounds;
-            uint32_t spare = GC_SPARE_A;
+            uint32_t r = e.rounds;  // rounds done so far
             while (inPlay) {
-                const uint32_t* list = (r & 1) ? e.listA : e.listB;
-                uint32_t* out = (r & 1) ? e.listB : e.listA;
-                HIP_TRY(hipMemsetAsync(e.dev.cnt + spare, 0, 4, st));
-                int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, inPlay, nullptr, list, e.dev.from,
-                                         e.capsRow / 2, e.caps, e.status, st);
-                if (rc != LC_OK) return rc;
-                hipLaunchKernelGGL(grok_advance2_kernel, dim3((inPlay + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, st, list,
-                                   inPlay, nullptr, e.status, e.caps, e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out,
-                                   e.dev.cnt + spare, nullptr);
-                HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS + 1, e.dev.cnt + spare, 4, hipMemcpyDeviceToHost, st));
+                const uint32_t stretch = std::min(kGrokMaxRounds, std::max(4u, r));
+                // the list of round r was written by round r - 1: (r & 1) ? listA : listB; counters are reused from slot 0
+                HIP_TRY(hipMemsetAsync(e.dev.cnt + GC_ROUND0, 0, size_t(stretch) * 4, st));
+                for (uint32_t k = 0; k < stretch; ++k, ++r) {
+                    const uint32_t* list = (r & 1) ? e.listA : e.listB;
+                    uint32_t* out = (r & 1) ? e.listB : e.listA;
+                    const uint32_t bound = k == 0 ? inPlay : e.cand;
+                    const uint32_t* countPtr = k == 0 ? nullptr : e.dev.cnt + GC_ROUND0 + k - 1;
+                    int rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, bound, countPtr, list, e.dev.from,
+                                             e.capsRow / 2, e.caps, e.status, st);
+                    if (rc != LC_OK) return rc;
+                    hipLaunchKernelGGL(grok_advance2_kernel, dim3((bound + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, st,
+                                       list, bound, countPtr, e.status, e.caps, e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out,
+                                       e.dev.cnt + GC_ROUND0 + k, static_cast<uint32_t*>(nullptr));
+                }
+                HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT + a * GC_WORDS + GC_ROUND0, e.dev.cnt + GC_ROUND0, size_t(stretch) * 4,
+                                       hipMemcpyDeviceToHost, st));
                 HIP_TRY(syncCounted(st));
-                inPlay = T.hostWords[HW_TAIL + TW_WORDS + 1];
-                spare = spare == GC_SPARE_A ? GC_SPARE_B : GC_SPARE_A;
-                ++r;
+                inPlay = T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + stretch - 1];
+                if (!inPlay) {  // rounds that had anything to search: up to the first empty list of this stretch
+                    uint32_t usedRounds = stretch;
+                    while (usedRounds > 1 && T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + usedRounds - 2] == 0) --usedRounds;
+                    r = r - stretch + usedRounds;
+                }
             }
             e.ran = r;  // (what this batch needed: the hint below)
         }
@@ -729,7 +836,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     for (size_t a = 0; a < nAct; ++a) {
         PlanEntry& e = act[a];
         uint32_t needed = 1;  // rounds that had any value to search
-        for (uint32_t r = 0; r + 1 < e.rounds; ++r)
+        for (uint32_t r = 0; r + 1 < e.rounds && e.ran == 0; ++r)
             if (T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + r]) needed = r + 2;
         lc_regex* re = patterns[e.p].re;
         const uint32_t hint = re->grokRounds.load(std::memory_order_relaxed);
@@ -737,7 +844,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             re->grokRounds.store(std::min(e.ran, kGrokMaxRounds), std::memory_order_relaxed);
             re->grokRoundsSlack.store(0, std::memory_order_relaxed);
         } else if (needed < hint && e.ran == 0) {
-            if (re->grokRoundsSlack.fetch_add(1, std::memory_order_relaxed) + 1 >= 16) {
+            if (re->grokRoundsSlack.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
                 re->grokRounds.store(needed, std::memory_order_relaxed);
                 re->grokRoundsSlack.store(0, std::memory_order_relaxed);
             }
@@ -746,8 +853,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         }
     }
     if (trace)
-        fprintf(stderr, "grok plan: n %u entries %u pairs %u screens %u | phase1 %.3f ms, entries+finish %.3f ms, total %.3f ms, syncs %u, deferred %u\n",
-                n, nAct, stats.pairs, nScreens, tPhase1, tPhase3 - tPhase1, msNow(), stats.hostSyncs, stats.deferredEntries);
+        fprintf(stderr, "grok plan: n %u entries %u (second pass %u) pairs %u screens %u | phase1 %.3f ms, entries+finish %.3f ms, total %.3f ms, syncs %u, deferred %u\n",
+                n, nAct, nSecond, stats.pairs, nScreens, tPhase1, tPhase3 - tPhase1, msNow(), stats.hostSyncs, stats.deferredEntries);
     const uint32_t xWanted = T.hostWords[HW_TAIL + TW_XCOUNT];
     const uint32_t nextra = T.hostWords[HW_TAIL + TW_WORDS];
     if (xWanted > xcap) {
@@ -797,110 +904,276 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
                                d_scratch, st, dev);
 }
 
-// device buffers of a thread that calls lcGrokMatchHost: grow-only, kept between calls (ProcessLogs hands over group after group)
+// What a thread that calls lcGrokMatchHost keeps between calls (ProcessLogs hands over group after group): a stream of its own
+// (runner threads must not meet on the null stream), pinned staging for the way in and the way out, device buffers; grow-only.
 namespace {
 struct GrokDev {
     void* p = nullptr;
     size_t cap = 0;
-    int device = -1;
-    ~GrokDev() { release(); }
+    bool pinned = false;
     void release() {
-        if (p && lcRuntimeUsable()) (void)hipFree(p);
+        if (p && lcRuntimeUsable()) (void)(pinned ? hipHostFree(p) : hipFree(p));
         p = nullptr;
         cap = 0;
-        device = -1;
     }
-    hipError_t ensure(size_t bytes, int dev) {
-        if (p && device == dev && cap >= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (p && cap >= bytes) return hipSuccess;
+        release();
         const size_t want = bytes + (bytes >> 2) + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) {
-            cap = want;
-            device = dev;
-        }
+        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
         return e;
     }
 };
-struct GrokThreadBuffers {
-    GrokDev b[8];
+struct GrokHostThread {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    GrokDev dIn, dPattern, dFirst, dExtra, dNextra, dScratch;  // device
+    GrokDev hIn, hOut, hExtra;                                 // pinned host
+    GrokHostThread() { hIn.pinned = hOut.pinned = hExtra.pinned = true; }
+    ~GrokHostThread() { release(); }
+    void release() {
+        if (device >= 0 && lcRuntimeUsable()) {
+            int cur = 0;
+            const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+            if (hipSetDevice(device) == hipSuccess) {
+                if (stream) {
+                    (void)hipStreamSynchronize(stream);
+                    (void)hipStreamDestroy(stream);
+                }
+                for (GrokDev* d : {&dIn, &dPattern, &dFirst, &dExtra, &dNextra, &dScratch, &hIn, &hOut, &hExtra}) d->release();
+            }
+            if (haveCur) (void)hipSetDevice(cur);
+        }
+        stream = nullptr;
+        device = -1;
+    }
+    int ensure(int dev) {
+        if (device == dev) return LC_OK;
+        release();
+        lcRegisterExitHook();
+        device = dev;
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return LC_OK;
+    }
 };
-thread_local GrokThreadBuffers tlsGrokBuffers;
+thread_local GrokHostThread tlsGrokHost;
 }  // namespace
 void lcGrokThreadRelease() {
-    for (auto& d : tlsGrokBuffers.b) d.release();
+    tlsGrokHost.release();
     tlsPlan.release();
 }
 
+// One group of one runner thread, as handed to lcGrokMatchHost.
+struct GrokDeviceState::HostJob {
+    const uint8_t* data;
+    const uint32_t* off;
+    const uint32_t* len;
+    uint32_t n;
+    int32_t* pattern;
+    std::vector<int32_t>* first;      // the group's own rows (filled by its thread from firstSrc)
+    std::vector<int32_t>* extraRows;  // [line, seq, row...] sorted, lines relative to the group
+    const int32_t* firstSrc = nullptr;  // the group's rows in the leader's pinned staging
+    int rc = LC_OK;
+    std::string error;
+    bool ready = false;               // results are there (firstSrc may be read)
+    std::atomic<int>* copying = nullptr;  // the leader waits until every group has taken its rows
+};
+
+namespace {
+// the merged batch of `jobs` (one or more groups) on the calling thread's stream; fills pattern / firstSrc / extraRows of every job
+int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
+                     const std::vector<GrokDeviceState::HostJob*>& jobs) {
+    int devNo = 0;
+    HIP_TRY(hipGetDevice(&devNo));
+    GrokHostThread& H = tlsGrokHost;
+    {
+        int rc = H.ensure(devNo);
+        if (rc != LC_OK) return rc;
+    }
+    // the values of all groups packed back to back (they may come from anywhere), then offsets and lengths: one block, one copy
+    size_t bytes = 0, n64 = 0;
+    for (const auto* j : jobs) {
+        for (uint32_t i = 0; i < j->n; ++i) bytes += j->len[i];
+        n64 += j->n;
+    }
+    if (bytes > 0xFFFFFFF0ull || n64 > 0x7FFFFFFFull) return LC_ERR_ARG;
+    const uint32_t n = uint32_t(n64);
+    const size_t offAt = alignUp(bytes + 16, 256), lenAt = offAt + alignUp(size_t(n) * 4, 256), inBytes = lenAt + size_t(n) * 4;
+    HIP_TRY(H.hIn.ensure(inBytes));
+    HIP_TRY(H.dIn.ensure(inBytes));
+    uint8_t* hIn = static_cast<uint8_t*>(H.hIn.p);
+    uint32_t* hOff = reinterpret_cast<uint32_t*>(hIn + offAt);
+    uint32_t* hLen = reinterpret_cast<uint32_t*>(hIn + lenAt);
+    {
+        size_t at = 0;
+        uint32_t k = 0;
+        for (const auto* j : jobs)
+            for (uint32_t i = 0; i < j->n; ++i, ++k) {
+                hOff[k] = uint32_t(at);
+                hLen[k] = j->len[i];
+                std::memcpy(hIn + at, j->data + j->off[i], j->len[i]);
+                at += j->len[i];
+            }
+        std::memset(hIn + at, 0, 16);
+    }
+    const size_t scratch = lcGrokScratchBytes(n, row);
+    uint32_t extraCap = n / 4 + 1024;
+    const size_t firstBytes = size_t(n) * row * 4;
+    HIP_TRY(H.dPattern.ensure(size_t(n) * 4));
+    HIP_TRY(H.dFirst.ensure(firstBytes));
+    HIP_TRY(H.dNextra.ensure(4));
+    HIP_TRY(H.dScratch.ensure(scratch));
+    HIP_TRY(H.hOut.ensure(alignUp(size_t(n) * 4, 256) + firstBytes));
+    int32_t* hPattern = static_cast<int32_t*>(H.hOut.p);
+    int32_t* hFirst = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(H.hOut.p) + alignUp(size_t(n) * 4, 256));
+    const uint8_t* dIn = static_cast<const uint8_t*>(H.dIn.p);
+    HIP_TRY(hipMemcpyAsync(H.dIn.p, hIn, inBytes, hipMemcpyHostToDevice, H.stream));
+    uint32_t nExtra = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(H.dExtra.ensure(size_t(extraCap) * (row + 2) * 4));
+        // (the speculative path queues the copies of the pattern ids and the first rows behind its last kernels: its second sync
+        // covers them)
+        tlsTail = GrokTailCopy{hPattern, hFirst, true, false};
+        int rc = lcGrokMatchDevice(patterns, state, opts, row, dIn, reinterpret_cast<const uint32_t*>(dIn + offAt),
+                                   reinterpret_cast<const uint32_t*>(dIn + lenAt), n, static_cast<int32_t*>(H.dPattern.p),
+                                   static_cast<int32_t*>(H.dFirst.p), static_cast<int32_t*>(H.dExtra.p), extraCap,
+                                   static_cast<uint32_t*>(H.dNextra.p), H.dScratch.p, scratch, H.stream);
+        const bool copied = tlsTail.done;
+        nExtra = tlsTail.nextra;
+        tlsTail = GrokTailCopy{};
+        if (rc == LC_ERR_OVERFLOW || !copied) {
+            HIP_TRY(hipMemcpyAsync(hFirst, H.dNextra.p, 4, hipMemcpyDeviceToHost, H.stream));
+            HIP_TRY(syncCounted(H.stream));
+            nExtra = uint32_t(hFirst[0]);
+        }
+        if (rc == LC_ERR_OVERFLOW && attempt == 0) {
+            extraCap = nExtra;  // the number needed is known now
+            continue;
+        }
+        if (rc != LC_OK) return rc;
+        if (!copied) {
+            HIP_TRY(hipMemcpyAsync(hPattern, H.dPattern.p, size_t(n) * 4, hipMemcpyDeviceToHost, H.stream));
+            HIP_TRY(hipMemcpyAsync(hFirst, H.dFirst.p, firstBytes, hipMemcpyDeviceToHost, H.stream));
+            HIP_TRY(syncCounted(H.stream));
+        }
+        break;
+    }
+    const size_t w = row + 2;
+    std::vector<uint32_t> idx(nExtra);
+    const int32_t* raw = nullptr;
+    if (nExtra) {
+        HIP_TRY(H.hExtra.ensure(size_t(nExtra) * w * 4));
+        HIP_TRY(hipMemcpyAsync(H.hExtra.p, H.dExtra.p, size_t(nExtra) * w * 4, hipMemcpyDeviceToHost, H.stream));
+        HIP_TRY(syncCounted(H.stream));
+        raw = static_cast<const int32_t*>(H.hExtra.p);
+        // rows arrive in atomic order: sort by (line, seq)
+        for (uint32_t i = 0; i < nExtra; ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            if (raw[a * w] != raw[b * w]) return raw[a * w] < raw[b * w];
+            return raw[a * w + 1] < raw[b * w + 1];
+        });
+    }
+    uint32_t base = 0, x = 0;
+    for (auto* j : jobs) {
+        std::memcpy(j->pattern, hPattern + base, size_t(j->n) * 4);
+        j->firstSrc = hFirst + size_t(base) * row;
+        j->extraRows->clear();
+        while (x < nExtra && uint32_t(raw[idx[x] * w]) < base + j->n) {
+            const size_t at = j->extraRows->size();
+            j->extraRows->resize(at + w);
+            std::memcpy(j->extraRows->data() + at, &raw[idx[x] * w], w * 4);
+            (*j->extraRows)[at] -= int32_t(base);
+            ++x;
+        }
+        base += j->n;
+    }
+    return LC_OK;
+}
+}  // namespace
+
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
                     const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
-                    std::vector<int32_t>& first, std::vector<int32_t>& extraRows) {
-    first.clear();
+                    const int32_t** firstRows, std::vector<int32_t>& extraRows) {
+    *firstRows = nullptr;
     extraRows.clear();
     if (n == 0) return LC_OK;
+    if (!state) return LC_ERR_ARG;
     if (lc_device_count() <= 0) {
         lcSetLastError("no HIP device");
         return LC_ERR_NO_DEVICE;
     }
-    // pack the values back to back (they may come from anywhere in `data`)
-    std::vector<uint32_t> hOff(n);
-    size_t bytes = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        hOff[i] = uint32_t(bytes);
-        bytes += len[i];
-    }
-    if (bytes > 0xFFFFFFF0ull) return LC_ERR_ARG;
-    std::vector<uint8_t> hData(bytes + 16);
-    for (uint32_t i = 0; i < n; ++i) std::memcpy(hData.data() + hOff[i], data + off[i], len[i]);
-
-    GrokThreadBuffers& gb = tlsGrokBuffers;
-    lcRegisterExitHook();
-    GrokDev &dData = gb.b[0], &dOff = gb.b[1], &dLen = gb.b[2], &dPattern = gb.b[3], &dFirst = gb.b[4], &dExtra = gb.b[5], &dNextra = gb.b[6], &dScratch = gb.b[7];
-    int devNo = 0;
-    HIP_TRY(hipGetDevice(&devNo));
-    const size_t scratch = lcGrokScratchBytes(n, row);
-    uint32_t extraCap = n / 4 + 1024;
-    HIP_TRY(dData.ensure(bytes + 16, devNo));
-    HIP_TRY(dOff.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dLen.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dPattern.ensure(size_t(n) * 4, devNo));
-    HIP_TRY(dFirst.ensure(size_t(n) * row * 4, devNo));
-    HIP_TRY(dNextra.ensure(4, devNo));
-    HIP_TRY(dScratch.ensure(scratch, devNo));
-    HIP_TRY(hipMemcpy(dData.p, hData.data(), bytes + 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dOff.p, hOff.data(), size_t(n) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dLen.p, len, size_t(n) * 4, hipMemcpyHostToDevice));
-    uint32_t nExtra = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(dExtra.ensure(size_t(extraCap) * (row + 2) * 4, devNo));
-        int rc = lcGrokMatchDevice(patterns, state, opts, row, static_cast<const uint8_t*>(dData.p), static_cast<const uint32_t*>(dOff.p),
-                                   static_cast<const uint32_t*>(dLen.p), n, static_cast<int32_t*>(dPattern.p),
-                                   static_cast<int32_t*>(dFirst.p), static_cast<int32_t*>(dExtra.p), extraCap,
-                                   static_cast<uint32_t*>(dNextra.p), dScratch.p, scratch, nullptr);
-        HIP_TRY(hipMemcpy(&nExtra, dNextra.p, 4, hipMemcpyDeviceToHost));
-        if (rc == LC_ERR_OVERFLOW && attempt == 0) {
-            extraCap = nExtra;  // the exact number is known now
-            continue;
+    // Group commit.  ProcessorRunner hands over ONE ~1000-log group per call, from several threads that share the plugin instance
+    // (core/runner/ProcessorRunner.cpp:138-142), and a batch costs the device about the same from 1 000 to 16 000 values (it waits
+    // for its longest value, not for the chip).  So: a thread that finds nothing in flight runs its group at once; groups that
+    // arrive while a batch is on the device wait together and travel as ONE batch led by the first of them.  No timers.
+    using HostJob = GrokDeviceState::HostJob;
+    thread_local std::vector<int32_t> tlsFirst;
+    HostJob job{data, off, len, n, pattern, &tlsFirst, &extraRows};
+    constexpr int kMaxInFlight = 2;            // one batch on the device, one being packed
+    constexpr size_t kMaxMergedLines = 65536;  // (beyond this a batch is throughput-bound anyway)
+    std::vector<HostJob*> mine;
+    {
+        std::unique_lock<std::mutex> lk(state->jobsMutex);
+        state->pending.push_back(&job);
+        for (;;) {
+            if (job.ready) break;
+            const bool queued = std::find(state->pending.begin(), state->pending.end(), &job) != state->pending.end();
+            if (queued && state->running < kMaxInFlight) {  // lead: take what has gathered (in arrival order)
+                size_t lines = 0;
+                while (!state->pending.empty() && (mine.empty() || lines + state->pending.front()->n <= kMaxMergedLines)) {
+                    lines += state->pending.front()->n;
+                    mine.push_back(state->pending.front());
+                    state->pending.erase(state->pending.begin());
+                }
+                if (std::find(mine.begin(), mine.end(), &job) == mine.end()) {  // (cannot happen: arrival order) -- never lead others only
+                    for (auto it = mine.rbegin(); it != mine.rend(); ++it) state->pending.insert(state->pending.begin(), *it);
+                    mine.clear();
+                    state->jobsCv.wait(lk);
+                    continue;
+                }
+                ++state->running;
+                break;
+            }
+            state->jobsCv.wait(lk);
         }
-        if (rc != LC_OK) return rc;
-        break;
     }
-    first.resize(size_t(n) * row);
-    HIP_TRY(hipMemcpy(pattern, dPattern.p, size_t(n) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(first.data(), dFirst.p, size_t(n) * row * 4, hipMemcpyDeviceToHost));
-    std::vector<int32_t> raw(size_t(nExtra) * (row + 2));
-    if (nExtra) HIP_TRY(hipMemcpy(raw.data(), dExtra.p, raw.size() * 4, hipMemcpyDeviceToHost));
-    // rows arrive in atomic order: sort by (line, seq)
-    std::vector<uint32_t> idx(nExtra);
-    for (uint32_t i = 0; i < nExtra; ++i) idx[i] = i;
-    const size_t w = row + 2;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (raw[a * w] != raw[b * w]) return raw[a * w] < raw[b * w];
-        return raw[a * w + 1] < raw[b * w + 1];
-    });
-    extraRows.resize(raw.size());
-    for (uint32_t i = 0; i < nExtra; ++i) std::memcpy(&extraRows[i * w], &raw[idx[i] * w], w * 4);
+    if (!mine.empty()) {
+        std::atomic<int> copying{int(mine.size())};
+        int rc = grokRunHostBatch(patterns, state, opts, row, mine);
+        const std::string err = rc == LC_OK ? std::string() : std::string(lc_last_error());
+        {
+            std::lock_guard<std::mutex> lk(state->jobsMutex);
+            for (HostJob* j : mine) {
+                j->rc = rc;
+                j->error = err;
+                j->copying = &copying;
+                j->ready = true;
+            }
+        }
+        state->jobsCv.notify_all();
+        // my own rows, then wait until the other groups have taken theirs out of my staging
+        if (rc == LC_OK) {
+            tlsFirst.resize(size_t(n) * row);
+            std::memcpy(tlsFirst.data(), job.firstSrc, size_t(n) * row * 4);
+        }
+        copying.fetch_sub(1);
+        while (copying.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        {
+            std::lock_guard<std::mutex> lk(state->jobsMutex);
+            --state->running;
+        }
+        state->jobsCv.notify_all();
+    } else {
+        if (job.rc == LC_OK) {
+            tlsFirst.resize(size_t(n) * row);
+            std::memcpy(tlsFirst.data(), job.firstSrc, size_t(n) * row * 4);
+        } else {
+            lcSetLastError(job.error);
+        }
+        job.copying->fetch_sub(1, std::memory_order_release);
+    }
+    if (job.rc != LC_OK) return job.rc;
+    *firstRows = tlsFirst.data();
     return LC_OK;
 }

@@ -78,14 +78,17 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_filter_kernel(const u
 __global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                        const uint32_t* __restrict__ len, uint32_t n,
                                                                        const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks,
-                                                                       uint32_t nPatterns, uint32_t* __restrict__ perPattern) {
+                                                                       uint32_t nPatterns, uint32_t* __restrict__ perPattern,
+                                                                       const uint32_t* __restrict__ order) {
     __shared__ uint8_t cmap[256];
     cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
     __syncthreads();
-    const uint32_t line = blockIdx.x * kGrokBlock + threadIdx.x;
-    if (line >= n) {  // (whole trailing wavefronts leave here; a partial one takes part in the ballots below with an empty mask)
+    // order (optional): the values sorted by length, so that the lanes of a wavefront walk values of about the same length
+    const uint32_t slot = blockIdx.x * kGrokBlock + threadIdx.x;
+    if (slot >= n) {  // (whole trailing wavefronts leave here; a partial one takes part in the ballots below with an empty mask)
         if ((blockIdx.x * kGrokBlock + (threadIdx.x & ~63u)) >= n) return;
     }
+    const uint32_t line = slot < n ? (order ? order[slot] : slot) : n;
     const uint32_t L = line < n ? len[line] : 0u, ncls = blob[GL_NCLASSES];
     const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(kGrokBlock) void grok_literal_index_kernel(const ui
     }
     if (live) masks[line] = mask;
     // how many values carry each entry's literal at all: an entry nobody carries is skipped without a single launch
+    if (!perPattern) return;
     for (uint32_t p = 0; p < nPatterns; ++p) {
         const uint64_t has = __ballot((mask >> p) & 1u);
         if (has && (threadIdx.x & 63u) == 0) atomicAdd(&perPattern[p], uint32_t(__popcll(has)));

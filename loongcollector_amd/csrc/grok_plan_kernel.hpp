@@ -39,9 +39,8 @@ enum {
     GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
     GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
     GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
-    GC_SPARE_A = 14,    // the host-driven continuation alternates between these two
-    GC_SPARE_B = 15,
-    GC_WORDS = 16
+    GC_FILTERED = 63,   // second-pass entries: slots left after grok_filter_won_kernel
+    GC_WORDS = 64
 };
 
 // One screen of one Match entry (device table).
@@ -73,13 +72,56 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_mask_fill_kernel(uint64_t
     if (i < n) masks[i] = all;
 }
 
+// ---- the literal index for SMALL batches: one value per WAVEFRONT, 64-byte chunks dealt to the lanes.  An occurrence of a literal
+// (at most 32 bytes are indexed) that ends inside a chunk starts at most 31 bytes before it, and the Aho-Corasick automaton finds
+// every occurrence that lies inside the window it walks whatever state it starts in -- so every lane starts at the root, 31 bytes
+// before its chunk, and the masks are OR-ed across the wave.  95 dependent steps for a 4 KiB value instead of 4096: what a small
+// batch waits for is its longest value.  (Large batches use the lane-per-value kernel, in length order.)
+#include "grok_literal_layout.h"
+constexpr uint32_t kGrokChunk = 64, kGrokLookBehind = 31;
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_chunk_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                           const uint32_t* __restrict__ len, uint32_t n,
+                                                                           const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks) {
+    __shared__ uint8_t cmap[256];
+    cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6);
+    if (v >= n) return;  // wave-uniform
+    const uint32_t L = len[v], ncls = blob[GL_NCLASSES];
+    const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);
+    const uint8_t* p = data + off[v];
+    uint64_t mask = 0;
+    for (uint32_t c0 = lane * kGrokChunk; c0 < L; c0 += 64 * kGrokChunk) {
+        const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
+        const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
+        uint32_t state = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t e = table[state * ncls + cmap[p[i]]];
+            state = e & 0x7FFFu;
+            if (e & 0x8000u) mask |= outMask[state];
+        }
+    }
+    uint32_t mlo = uint32_t(mask), mhi = uint32_t(mask >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mlo |= uint32_t(__shfl_xor(int(mlo), d, 64));
+        mhi |= uint32_t(__shfl_xor(int(mhi), d, 64));
+    }
+    if (lane == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
+}
+
 // ---- all screens in one launch.  grid = (slices, screens); dynamic LDS = candidate list [sliceLen] u32 + staged table.
-// A slice is a run of consecutive values; the workgroup compacts the slice's carriers of the entry's bit into LDS (ballot),
-// then walks them one value per lane.  Table entries are read as u16 next-state; staged tables sit behind the list.
+// A slice is a run of values in LENGTH order (order[]: the lanes of a wavefront then walk values of about the same length); the
+// workgroup compacts the slice's carriers of the entry's bit into LDS (ballot), then walks them one value per lane.  Table entries
+// are read as u16 next-state.  stage != 0 (small batches: what counts is the latency of the longest value): the table is staged
+// into LDS behind the list; stage == 0 (large batches: what counts is values in flight per CU): it is read through L2.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                         const uint32_t* __restrict__ len, uint32_t n, uint32_t sliceLen,
                                                                         const GrokScreenDev* __restrict__ screens,
-                                                                        unsigned long long* __restrict__ masks) {
+                                                                        unsigned long long* __restrict__ masks,
+                                                                        const uint32_t* __restrict__ order, uint32_t stage) {
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     __shared__ uint32_t sCount;
@@ -92,8 +134,9 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     uint32_t* cand = ldsWords;
     // 1. carriers of this slice
     for (uint32_t base = lo; base < hi; base += kGrokPlanBlock) {
-        const uint32_t v = base + tid;
-        const bool has = v < hi && ((masks[v] >> sc.bit) & 1ull);
+        const uint32_t i = base + tid;
+        const uint32_t v = i < hi ? (order ? order[i] : i) : 0;
+        const bool has = i < hi && ((masks[v] >> sc.bit) & 1ull);
         const uint64_t b = __ballot(has);
         if (b) {
             uint32_t at = 0;
@@ -111,7 +154,7 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
     const uint8_t* accept = reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_ACCEPT];
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
-    const bool staged = sc.ldsBytes != 0;
+    const bool staged = stage && sc.ldsBytes != 0;
     if (staged) {  // accept flags .. end of table are contiguous in the blob (4-byte aligned start)
         uint32_t* dst = ldsWords + sliceLen;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
@@ -145,22 +188,33 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     }
 }
 
-// candidates per entry after the screens
+// candidates per entry after the screens; firstOf[p] = values whose FIRST candidate entry is p (the rest of p's candidates have
+// an earlier candidate that may win them: potential waste of evaluating p on them)
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_count_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
-                                                                   uint32_t* __restrict__ perEntry) {
+                                                                   uint32_t* __restrict__ perEntry, uint32_t* __restrict__ firstOf) {
     const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     const uint64_t m = v < n ? masks[v] : 0;
+    const uint32_t lowest = m ? uint32_t(__ffsll(static_cast<long long>(m))) - 1u : 64u;
     for (uint32_t p = 0; p < nPatterns; ++p) {
         const uint64_t has = __ballot((m >> p) & 1ull);
-        if (has && (threadIdx.x & 63u) == 0) atomicAdd(&perEntry[p], uint32_t(__popcll(has)));
+        if (!has) continue;
+        const uint64_t isFirst = __ballot(lowest == p);
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&perEntry[p], uint32_t(__popcll(has)));
+            if (isFirst) atomicAdd(&firstOf[p], uint32_t(__popcll(isFirst)));
+        }
     }
 }
 
 // every (entry, value) pair that passed becomes a slot of the entry
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_scatter_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
                                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ len,
-                                                                     GrokSlotMap map, const GrokEntryDev* __restrict__ entries) {
-    const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+                                                                     GrokSlotMap map, const GrokEntryDev* __restrict__ entries,
+                                                                     const uint32_t* __restrict__ order) {
+    // (in length order, longest first: an entry's slots come out roughly sorted too -- homogeneous wavefronts for its
+    // lane-per-value kernels, the long values of the wave-per-value kernels first)
+    const uint32_t i = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    const uint32_t v = i < n ? (order ? order[i] : i) : n;
     const uint64_t m = v < n ? masks[v] : 0;
     const uint32_t o = v < n ? off[v] : 0, L = v < n ? len[v] : 0;
     for (uint32_t p = 0; p < nPatterns; ++p) {
@@ -187,11 +241,36 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_scatter_kernel(const uint
 }
 
 // the slots the anchored search of round 0 did not match go on to the search proper
-__global__ __launch_bounds__(kGrokPlanBlock) void grok_unmatched2_kernel(uint32_t nSlots, const uint8_t* __restrict__ status,
+// (in: the slots that were searched, nullptr = all below the bound; inCount: the list's length on the device)
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_unmatched2_kernel(const uint32_t* __restrict__ in, uint32_t bound,
+                                                                        const uint32_t* __restrict__ inCount,
+                                                                        const uint8_t* __restrict__ status, uint32_t* __restrict__ out,
+                                                                        uint32_t* __restrict__ count) {
+    uint32_t nIn = bound;
+    if (inCount) {
+        const uint32_t dyn = *inCount;
+        nIn = dyn < nIn ? dyn : nIn;
+    }
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t slot = in ? in[k] : k;
+    if (status[slot] != LC_MATCH) out[atomicAdd(count, 1u)] = slot;
+}
+
+// Second pass (entries whose candidates are largely shadowed by earlier entries): only the slots whose value no earlier entry
+// has won by now are searched.  An entry's result on a value that an earlier entry contributes to is never looked at, so
+// dropping those slots changes nothing -- and whatever the first pass has not settled yet simply stays in.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_filter_won_kernel(GrokEntryDev e, const uint32_t* __restrict__ winner,
                                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ count) {
     const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
-    if (k >= nSlots) return;
-    if (status[k] != LC_MATCH) out[atomicAdd(count, 1u)] = k;
+    if (k >= e.cand) return;
+    const bool keep = winner[e.line[k]] >= e.bit;  // (kGrokNone included)
+    const uint64_t b = __ballot(keep);
+    if (!b) return;
+    uint32_t at = 0;
+    if ((threadIdx.x & 63u) == 0) at = atomicAdd(count, uint32_t(__popcll(b)));
+    at = __shfl(at, 0, 64);
+    if (keep) out[at + __popcll(b & ((1ull << (threadIdx.x & 63u)) - 1ull))] = k;
 }
 
 // After one search round over the slots in `in` (nullptr: all slots below the bound); see grok_advance_kernel (grok_kernel.hpp)
@@ -251,6 +330,7 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_entry_finish_kernel(const
                                                                           const uint32_t* __restrict__ gate) {
     if (gate && *gate) return;
     const GrokEntryDev& e = entries[blockIdx.y];
+    // (second-pass entries: a slot the filter dropped has nmatch == 0 and says nothing)
     const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     if (k >= e.cand) return;
     const uint32_t nm = e.nmatch[k];

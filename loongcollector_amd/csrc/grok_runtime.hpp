@@ -27,7 +27,7 @@ struct GrokOptions {
     // sequential path: an entry that has a relaxed screen runs its prefix screen first only when more than this many values carry
     // its literal
     uint32_t prefixScreenAbove = 65536;
-    uint32_t streams = 4;  // worker streams of the speculative path (1..8)
+    uint32_t streams = 8;  // worker streams of the speculative path (1..8)
 };
 
 // What a Grok handle keeps on the device(s) between batches: the literal index of its Match list, the table of its screens.
@@ -59,8 +59,9 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
                       int32_t* d_pattern, int32_t* d_first, int32_t* d_extra, uint32_t extraCap, uint32_t* d_nextra, void* d_scratch,
                       size_t scratchBytes, void* stream);
 
-// pinned-host convenience used by lc_grok_match_host: copies in, runs lcGrokMatchDevice, copies out.
+// pinned-host convenience used by lc_grok_match_host: copies in (one block, the calling thread's own stream), runs
+// lcGrokMatchDevice, copies out.  *firstRows = int32[n][rowInts] in the thread's pinned staging, valid until the thread's next call;
 // extraRows receives [line, seq, row...] records sorted by (line, seq).
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t rowInts,
                     const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
-                    std::vector<int32_t>& first, std::vector<int32_t>& extraRows);
+                    const int32_t** firstRows, std::vector<int32_t>& extraRows);

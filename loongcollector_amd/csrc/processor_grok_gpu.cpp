@@ -246,8 +246,9 @@ void ProcessorGrokGpu::MatchValues(const uint8_t* data, const uint32_t* off, con
         for (uint32_t i = 0; i < n; ++i) pattern[i] = -1;
         return;
     }
-    std::vector<int32_t> first, extra;
-    int rc = lcGrokMatchHost(devicePatterns(), mState, options(), mRowInts, data, off, len, n, pattern, first, extra);
+    std::vector<int32_t> extra;
+    const int32_t* first = nullptr;
+    int rc = lcGrokMatchHost(devicePatterns(), mState, options(), mRowInts, data, off, len, n, pattern, &first, extra);
     if (rc != LC_OK) throw GrokError(std::string("grok device match failed: ") + lc_last_error());
     const size_t w = mRowInts + 2;
     size_t x = 0;

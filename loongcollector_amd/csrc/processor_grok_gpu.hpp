@@ -49,7 +49,7 @@ public:
     // worker streams of the speculative path
     bool Speculative = true;
     int64_t PrefixScreenAbove = 65536;
-    int64_t Streams = 4;
+    int64_t Streams = 8;
     bool NoKeyError = false;
     bool NoMatchError = true;
     bool TimeoutError = true;

@@ -19,6 +19,10 @@ void lcSetDecideSlot(int slot);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)
 int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out);
 
+// order[] = the lines 0..n-1 sorted by length bucket (32 bytes), longest first (sched_kernel.hpp); work: 512 words
+int lcLengthOrderOnStream(const uint32_t* d_off, const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t* work, uint32_t* order,
+                          hipStream_t st);
+
 #define LC_HIP_TRY(expr)                                    \
     do {                                                    \
         hipError_t e_ = (expr);                             \

@@ -277,10 +277,18 @@ def _device_rows(torch, g, values, extra_cap=None):
     row = g.row_ints
     d_pattern = torch.empty(n, dtype=torch.int32, device=dev)
     d_first = torch.empty((n, row), dtype=torch.int32, device=dev)
-    d_extra = torch.empty((extra_cap if extra_cap is not None else 8 * n + 1024, row + 2), dtype=torch.int32, device=dev)
+    d_extra = torch.empty((extra_cap if extra_cap is not None else 6 * n + 1024, row + 2), dtype=torch.int32, device=dev)
     d_nextra = torch.zeros(1, dtype=torch.int32, device=dev)
     d_scratch = torch.empty(g.scratch_bytes(n), dtype=torch.uint8, device=dev)
-    g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch)
+    try:
+        g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch)
+    except RuntimeError:
+        # LC_ERR_OVERFLOW: d_nextra says how many rows are needed (the speculative path keeps the further matches of EVERY candidate
+        # entry until the winner is known, so its temporary rows can run out where the final rows would have fitted)
+        need = int(d_nextra.cpu()[0])
+        assert need > d_extra.shape[0]
+        d_extra = torch.empty((need, row + 2), dtype=torch.int32, device=dev)
+        g.match_device(d_data, d_off, d_len, n, d_pattern, d_first, d_extra, d_nextra, d_scratch)
     stats = g.last_batch_stats()
     nx = int(d_nextra.cpu()[0])
     extra = d_extra[:nx].cpu().numpy()
@@ -314,8 +322,10 @@ def test_speculative_and_sequential_paths_agree(torch_dev, match):
     # needs more rounds than can be queued) exactly two host synchronisations
     p3, f3, x3, s3 = _device_rows(torch_dev, spec, values)
     assert np.array_equal(p1, p3) and np.array_equal(f1, f3) and np.array_equal(x1, x3)
-    if match != ["%{IPV4:ip}"] and match[0] != "%{WORD:w}":
-        assert s3["host_syncs"] == 2 and s3["deferred_entries"] == 0, s3
+    assert s3["host_syncs"] <= 6, s3      # (an entry with dozens of matches per value goes on in stretches of rounds)
+    assert s3["host_syncs"] == 2 or s3["deferred_entries"] > 0, s3
+    if match[0] != "%{IPV4:ip}":          # (up to 36 addresses per value there)
+        assert s3["host_syncs"] == 2, s3
     assert s2["host_syncs"] > s3["host_syncs"]
     o = GrokOracle(match)
     pattern, fields = spec.match_host(values)
