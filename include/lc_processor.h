@@ -65,6 +65,14 @@ const char* lc_processor_key(const lc_processor_t* p, int i);
 /* Runs the processor over one event group, in place.  Returns 0, or an LC_ERR_* code when the GPU could not be
  * used (the group is then left untouched: there is no CPU fallback). */
 int lc_processor_process(lc_processor_t* p, lc_event_group_t* group);
+/* The alarms of RegexLogLineParser (core/plugin/processor/ProcessorParseRegexNative.cpp:196-244): one call per failing event with
+ * the text the reference hands to AlarmManager::SendAlarmWarning(REGEX_MATCH_ALARM, ...): kind 0 "errorlog:<line>" (no match),
+ * kind 1 "errorlog:<line> | exception:<why>" (the matcher gave up: boost's complexity exception), kind 2
+ * "parse key count not match<mark_count + 1>errorlog:<line>".  Built inside the agent (LC_USE_REFERENCE_HEADERS) the slot's init
+ * keeps the CollectionPipelineContext it is given and raises the alarms there, gated by AppConfig::IsLogParseAlarmValid() as in
+ * the reference; this sink works in every build (called from the thread that runs lc_processor_process). */
+typedef void (*lc_alarm_sink_t)(void* user, int kind, const char* message, size_t len);
+void lc_processor_set_alarm_sink(lc_processor_t* p, lc_alarm_sink_t sink, void* user);
 int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]);
 
 /* test fixtures in the reference unit tests' JSON format */

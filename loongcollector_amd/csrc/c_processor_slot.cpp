@@ -92,6 +92,10 @@ extern "C" int lc_processor_process(lc_processor_t* p, lc_event_group_t* g) {
 
 #endif
 
+extern "C" void lc_processor_set_alarm_sink(lc_processor_t* p, lc_alarm_sink_t sink, void* user) {
+    if (p) p->impl.SetAlarmSink(sink, user);
+}
+
 extern "C" int lc_processor_counters(const lc_processor_t* p, uint64_t out[LC_CNT_COUNT]) {
     if (!p || !out) return LC_ERR_ARG;
     out[LC_CNT_DISCARDED_EVENTS] = p->impl.mDiscardedEventsTotal;
@@ -261,7 +265,7 @@ extern "C" void lc_free(void* p) { std::free(p); }
 // ---------------------------------------------------------------------------------------------- the dlsym slot
 // Call protocol (core/plugin/processor/DynamicCProcessorProxy.cpp:25-40): init(ins, &config, &context) must set
 // ins->plugin_state and return 0; process(plugin_state, &group) mutates the group in place; finalize(plugin_state).
-static int slotInit(processor_instance_t* ins, void* config, void* /*context*/) {
+static int slotInit(processor_instance_t* ins, void* config, void* context) {
     if (!ins || !config) return -1;
     lc_processor_t* p = nullptr;
     char err[256];
@@ -275,6 +279,13 @@ static int slotInit(processor_instance_t* ins, void* config, void* /*context*/) 
         std::fprintf(stderr, "[processor_parse_regex_gpu] init failed: %s\n", err);
         return -1;
     }
+#ifdef LC_USE_REFERENCE_HEADERS
+    // the agent hands over its CollectionPipelineContext (DynamicCProcessorProxy.cpp:30-32): the REGEX_MATCH_ALARM paths of
+    // RegexLogLineParser go to its AlarmManager and logger
+    p->impl.SetContext(static_cast<logtail::CollectionPipelineContext*>(context));
+#else
+    (void)context;  // (the stand-in build has no context type: alarms go to the sink of lc_processor_set_alarm_sink, if any)
+#endif
     ins->plugin_state = p;
     return 0;
 }

@@ -197,10 +197,50 @@ bool ProcessorParseRegexGpu::FinishEvent(LogEvent& sourceEvent, StringView rawCo
 
 // ProcessorParseRegexNative::Process :108-126 + ProcessEvent :132-168 + RegexLogLineParser :186-253, restructured
 // as gather -> one device match for the whole group -> stitch.
+// ProcessorParseRegexNative.cpp:196-244, the alarm side of RegexLogLineParser
+void ProcessorParseRegexGpu::RaiseAlarm(int kind, StringView buffer, StringView logPath) const {
+    bool wanted = mAlarmSink != nullptr;
+#ifdef LC_USE_REFERENCE_HEADERS
+    const bool agent = mContext && AppConfig::GetInstance()->IsLogParseAlarmValid();
+    wanted = wanted || agent;
+#endif
+    if (!wanted) return;
+    static const char kGaveUp[] = "the matcher gave up: the line needs more work than the complexity budget allows";
+    std::string message;
+    if (kind == 2) message = "parse key count not match" + std::to_string(mMarkCount + 1);  // what.size() = mark_count + 1
+    message += "errorlog:";
+    message.append(buffer.data(), buffer.size());
+    if (kind == 1) message += std::string(" | exception:") + kGaveUp;
+    if (mAlarmSink) mAlarmSink(mAlarmUser, kind, message.data(), message.size());
+#ifdef LC_USE_REFERENCE_HEADERS
+    if (!agent) return;
+    if (mContext->GetAlarm().IsLowLevelAlarmValid()) {
+        if (kind == 1) {
+            LOG_ERROR(mContext->GetLogger(),
+                      ("parse regex log fail", buffer)("exception", kGaveUp)("project", mContext->GetProjectName())(
+                          "logstore", mContext->GetLogstoreName())("file", logPath));
+        } else if (kind == 2) {
+            LOG_WARNING(mContext->GetLogger(),
+                        ("parse key count not match", mMarkCount + 1)("parse regex log fail", buffer)(
+                            "project", mContext->GetProjectName())("logstore", mContext->GetLogstoreName())("file", logPath));
+        } else {
+            LOG_WARNING(mContext->GetLogger(),
+                        ("parse regex log fail", buffer)("project", mContext->GetProjectName())(
+                            "logstore", mContext->GetLogstoreName())("file", logPath));
+        }
+    }
+    mContext->GetAlarm().SendAlarmWarning(REGEX_MATCH_ALARM, message, mContext->GetRegion(), mContext->GetProjectName(),
+                                          mContext->GetConfigName(), mContext->GetLogstoreName());
+#else
+    (void)logPath;
+#endif
+}
+
 void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
     if (logGroup.GetEvents().empty()) return;
     EventsContainer& events = logGroup.MutableEvents();
     const GroupMetadata& metadata = logGroup.GetAllMetadata();
+    const StringView logPath = logGroup.GetMetadata(EventGroupMetaKey::LOG_FILE_PATH_RESOLVED);  // :110
     const size_t nEvents = events.size();
 
     enum Kind : uint8_t { Keep, Parse, WholeLine };
@@ -276,10 +316,12 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                     continue;
                 }
                 if (status[li] == LC_GAVE_UP) ++tally.complexityExceeded;  // boost: complexity exception -> parse failure
-                if (status[li] != LC_MATCH) {  // :194-226 (alarms/logging are the host agent's business)
+                if (status[li] != LC_MATCH) {  // :194-226
+                    RaiseAlarm(status[li] == LC_GAVE_UP ? 1 : 0, raw, logPath);
                     ++tally.outFailed;
                     parseSuccess = false;
                 } else if (size_t(G) + 1 <= mKeys.size()) {  // what.size() <= keys.size()  :227-244, no counter
+                    RaiseAlarm(2, raw, logPath);
                     parseSuccess = false;
                 }
                 if (parseSuccess) {

@@ -16,8 +16,14 @@
 
 #include "../../include/lc_regex_gpu.h"
 #ifdef LC_USE_REFERENCE_HEADERS  // built inside the LoongCollector tree: the real event model
+#include <memory>  // (core/app_config/AppConfig.h names std::set and std::shared_ptr without including their headers)
+#include <set>
+
+#include "app_config/AppConfig.h"
+#include "collection_pipeline/CollectionPipelineContext.h"
 #include "models/LogEvent.h"
 #include "models/PipelineEventGroup.h"
+#include "monitor/AlarmManager.h"
 #else
 #include "event_model.hpp"
 #endif
@@ -66,6 +72,20 @@ public:
     std::vector<std::string> mInitWarnings;
     int mEngineChoice = LC_ENGINE_AUTO;  // test hook: force a device engine
 
+    // The alarms of RegexLogLineParser (ProcessorParseRegexNative.cpp:196-244: REGEX_MATCH_ALARM with the texts below, raised per
+    // failing event when AppConfig::IsLogParseAlarmValid()).  kind: 0 = no match ("errorlog:<line>"), 1 = the matcher gave up on
+    // the line (boost: the complexity exception; "errorlog:<line> | exception:<text>"), 2 = key count mismatch ("parse key count
+    // not match<what.size()>errorlog:<line>").  In the agent build SetContext() routes them to the pipeline's AlarmManager and
+    // logger exactly as the reference does; any build can also install a sink (tests, hosts without a context).
+    using AlarmSink = void (*)(void* user, int kind, const char* message, size_t len);
+    void SetAlarmSink(AlarmSink sink, void* user) {
+        mAlarmSink = sink;
+        mAlarmUser = user;
+    }
+#ifdef LC_USE_REFERENCE_HEADERS
+    void SetContext(CollectionPipelineContext* context) { mContext = context; }
+#endif
+
     bool IsWholeLineMode() const { return mIsWholeLineMode; }
     const lc_regex_t* Regex() const { return mReg; }
     int MarkCount() const { return mMarkCount; }
@@ -80,6 +100,13 @@ private:
     };
     bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata, Tally& tally);
     void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
+
+    void RaiseAlarm(int kind, StringView buffer, StringView logPath) const;
+    AlarmSink mAlarmSink = nullptr;
+    void* mAlarmUser = nullptr;
+#ifdef LC_USE_REFERENCE_HEADERS
+    CollectionPipelineContext* mContext = nullptr;
+#endif
 
     bool mSourceKeyOverwritten = false;
     bool mKeysDistinct = false;             // no key appears twice: the bulk stitch is allowed

@@ -35,6 +35,8 @@ def _lib():
         L.lc_processor_process.restype = ctypes.c_int
         L.lc_processor_process.argtypes = [vp, vp]
         L.lc_processor_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.lc_processor_set_alarm_sink.restype = None
+        L.lc_processor_set_alarm_sink.argtypes = [vp, vp, vp]
         L.lc_filter_create.restype = ctypes.c_int
         L.lc_filter_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
         L.lc_filter_destroy.argtypes = [vp]
@@ -176,6 +178,15 @@ class Processor:
             return out
         finally:
             self._L.lc_columnar_free(c)
+
+    def collect_alarms(self):
+        """lc_processor_set_alarm_sink: -> the list that receives (kind, message bytes) for every REGEX_MATCH_ALARM the
+        reference would raise (ProcessorParseRegexNative.cpp:196-244)"""
+        out = []
+        proto = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char), ctypes.c_size_t)
+        self._alarm_cb = proto(lambda user, kind, msg, n: out.append((kind, ctypes.string_at(msg, n))))
+        self._L.lc_processor_set_alarm_sink(self._h, ctypes.cast(self._alarm_cb, ctypes.c_void_p), None)
+        return out
 
     def counters(self):
         buf = (ctypes.c_uint64 * len(COUNTER_NAMES))()

@@ -1,0 +1,13 @@
+// tests/refhdr -- TEST INFRASTRUCTURE: stand-in for the protoc-generated sls_logs.pb.h (core/protobuf/sls/sls_logs.proto is in the
+// reference tree, its generated header is not): the one type core/app_config/AppConfig.h names, declaration only.
+#pragma once
+#include <string>
+namespace sls_logs {
+class LogTag {
+public:
+    const std::string& key() const;
+    const std::string& value() const;
+    void set_key(const std::string&);
+    void set_value(const std::string&);
+};
+}  // namespace sls_logs

@@ -725,3 +725,24 @@ def test_large_batch_takes_the_compact_kernel_and_stays_bit_exact(torch_dev, kin
     same(*run_device(torch_dev, rx, data, off, None, sep=1))
     same(*run_device(torch_dev, rx, data, off[:-1], length))
     assert kind == "B" or 0 < exp_status.sum() < n      # the poisoned lines still satisfy the permissive regex B
+
+
+def test_reference_boost_regex_search_vectors_on_the_device(torch_dev, golden_dir):
+    """core/unittest/common/StringToolsUnittest.cpp:128-209 (TestBoostRegexSearch, regex_search + match_continuous): the
+    reference's own expectations, asked of every device engine that can run the pattern in LC_SYNTAX_PREFIX mode."""
+    with open(os.path.join(golden_dir, "boost_search_vectors.json")) as f:
+        d = json.load(f)
+    checked = 0
+    for c in d["cases"]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_PREFIX)
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        engines = ([B.LC_ENGINE_NFA] if rx.has_nfa_program() else []) + (
+            [B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        assert engines
+        for eng in engines:
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+            for i, (_, want) in enumerate(c["subs"]):
+                checked += 1
+                assert (status[i] == B.LC_MATCH) == want, (c["cite"], c["subs"][i][0], eng)
+    assert checked >= 16

@@ -229,3 +229,22 @@ def test_columnar_hand_off_equals_the_stitched_events():
     # events the processor does not parse are reported as skipped
     g3 = EventGroup({"events": [{"contents": {"msg": "x"}, "timestamp": 1, "type": 1}, {"content": "raw", "timestamp": 1, "type": 4}]})
     assert p.parse_columnar(g3) == [None, None]
+
+
+def test_regex_match_alarms_carry_the_reference_texts():
+    """RegexLogLineParser raises REGEX_MATCH_ALARM for every event that does not match ("errorlog:<line>",
+    ProcessorParseRegexNative.cpp:208-226) and for every event whose regex has fewer groups than Keys ("parse key count not
+    match<what.size()>errorlog:<line>", :227-244): the same events, the same texts, in event order, through the alarm sink."""
+    lines = ["value1\tvalue2", "nomatch", "a\tb tail", "", "x"]
+    events = [{"timestamp": 1, "contents": {"content": l}} for l in lines]
+    p = Processor({"SourceKey": "content", "Regex": r"(\w+)\t(\w+).*", "Keys": ["key1", "key2"], "KeepingSourceWhenParseFail": True})
+    alarms = p.collect_alarms()
+    p.process(EventGroup({"events": events}))
+    assert alarms == [(0, b"errorlog:" + l.encode()) for l in lines if "\t" not in l]
+    assert p.counters()["out_failed_events_total"] == 3
+    # three keys, two groups: what.size() == 3 <= keys.size() -- every MATCHING event alarms, out_failed stays 0 (:652)
+    p3 = Processor({"SourceKey": "content", "Regex": r"(\w+)\t(\w+).*", "Keys": ["key1", "key2", "key3"]})
+    alarms3 = p3.collect_alarms()
+    p3.process(EventGroup({"events": [{"timestamp": 1, "contents": {"content": l}} for l in lines[:1] + lines[2:3]]}))
+    assert alarms3 == [(2, b"parse key count not match3errorlog:" + l.encode()) for l in (lines[0], lines[2])]
+    assert p3.counters()["out_failed_events_total"] == 0

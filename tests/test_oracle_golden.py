@@ -102,3 +102,26 @@ def test_oracle_matches_atomic_and_possessive_vectors(golden_dir):
                 if got_flat != flat:
                     bad.append((kind, c["p"], subj, got_flat, flat))
     assert not bad, bad[:5]
+
+
+def test_reference_boost_regex_search_vectors(golden_dir):
+    """The reference's own boost-boundary vectors (core/unittest/common/StringToolsUnittest.cpp:128-209, TestBoostRegexSearch:
+    regex_search with match_continuous): the oracle's prefix match, and -- the same question, compiled as LC_SYNTAX_PREFIX --
+    the device tables walked by the CPU interpreters of the tests."""
+    from loongcollector_amd import binding as B
+    from tests.helpers.table_interp import NfaInterp, TdfaInterp
+    with open(os.path.join(golden_dir, "boost_search_vectors.json")) as f:
+        d = json.load(f)
+    n = 0
+    for c in d["cases"]:
+        o = OracleRegex(c["p"].encode("latin-1"))
+        rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_PREFIX)
+        its = ([NfaInterp(rx)] if rx.has_nfa_program() else []) + ([TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+        assert its
+        for subj, want in c["subs"]:
+            s = subj.encode("latin-1")
+            assert (o.prefixmatch(s) is not None) == want, (c["cite"], subj)
+            for it in its:
+                n += 1
+                assert (it.fullmatch(s) is not None) == want, (c["cite"], subj, type(it).__name__)
+    assert n >= 16

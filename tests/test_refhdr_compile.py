@@ -3,8 +3,11 @@
 `-DLC_USE_REFERENCE_HEADERS` swaps the stand-in event model (csrc/event_model.hpp) for core/models/LogEvent.h /
 PipelineEventGroup.h and makes the dlsym slot's init() take the `const Json::Value*` the agent passes
 (core/plugin/processor/DynamicCProcessorProxy.cpp:25-40).  Until round 2 that variant had never been through a compiler.
-Boost, JsonCpp and the protoc-generated checkpoint.pb.h are not in this image: tests/refhdr/ holds declarations-only
-stand-ins for exactly those three headers, everything else on the include path is the reference tree itself.
+Boost, JsonCpp, spdlog and the protoc-generated checkpoint.pb.h / sls_logs.pb.h are not in this image: tests/refhdr/ holds
+declarations-only stand-ins for exactly those headers (string_view, the few boost headers core/common/Lock.h names, json.h,
+spdlog.h, the two .pb.h), everything else on the include path is the reference tree itself.  Since round 3 the parse processor
+also includes the reference's CollectionPipelineContext / AlarmManager / AppConfig: the slot keeps the context the agent hands
+to init() and raises the REGEX_MATCH_ALARM paths of RegexLogLineParser there (ProcessorParseRegexNative.cpp:196-244).
 `g++ -fsyntax-only` parses, resolves overloads and instantiates every template the sources use -- i.e. each call the
 shim makes on LogEvent / PipelineEventGroup / SourceBuffer / Json::Value exists with those argument types.
 
@@ -33,7 +36,7 @@ def _syntax_only(src, extra=()):
     if not os.path.exists(os.path.join(objdir, "grok_defaults.inc")):
         native_build.build_native()  # (writes the generated include processor_grok_gpu.cpp needs)
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DLC_USE_REFERENCE_HEADERS", "-I", os.path.join(ROOT, "tests", "refhdr"),
-           "-I", REF, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", objdir, *extra, os.path.join(CSRC, src)]
+           "-I", REF, "-I", os.path.join(REF, "config"), "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", objdir, *extra, os.path.join(CSRC, src)]
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -53,7 +56,7 @@ def test_the_reference_headers_are_really_the_ones_parsed():
         f.write('#include "processor_parse_regex_gpu.hpp"\n'
                 "void probe(logtail::LogEvent& e, logtail::StringView* k) { e.AppendContentsNoCopy(k, k, 1); }\n")
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DLC_USE_REFERENCE_HEADERS", "-I", os.path.join(ROOT, "tests", "refhdr"), "-I", REF,
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, probe]
+           "-I", os.path.join(REF, "config"), "-I", os.path.join(ROOT, "include"), "-I", CSRC, probe]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0 and "no member named" in r.stdout and "AppendContentNoCopy" in r.stdout, r.stdout[-2000:]
     with open(os.path.join(CSRC, "event_model.hpp")) as f:
