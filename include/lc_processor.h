@@ -107,12 +107,36 @@ void lc_columnar_free(lc_columnar_t* c);
 /* the group a file input hands over: one copy of the n lines (data + off[i], len[i]) back to back in the group's SourceBuffer,
  * one log event per line whose `key` content is a view into it (ProcessorSplitLogStringNative.cpp:130-160) */
 lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, const char* key);
+/* the group the file input hands over BEFORE the line splitter: ONE log event whose `key` content is a copy of the read buffer
+ * (position = file_offset, n); file_offset_key != NULL sets the group's LOG_FILE_OFFSET_KEY metadata (the splitter then adds the
+ * offset content to every line, ProcessorSplitLogStringNative.cpp:151-156) */
+lc_event_group_t* lc_group_from_buffer(const uint8_t* data, size_t n, const char* key, uint64_t file_offset, const char* file_offset_key);
 char* lc_group_to_json(const lc_event_group_t* g);
 size_t lc_group_event_count(const lc_event_group_t* g);
 /* the logtail::PipelineEventGroup* inside the fixture wrapper (what processor_interface.process expects) */
 void* lc_group_native(lc_event_group_t* g);
 void lc_group_free(lc_event_group_t* g);
 void lc_free(void* p);
+
+/* ---- the reference's benchmark pipeline in ONE device trip per read buffer: split -> processor_parse_regex_native ->
+ * processor_filter_regex_native (test/benchmark/local/test_cases/performance_file_to_blackhole_loongcollector/loongcollector.yaml;
+ * ProcessorSplitLogStringNative.cpp:101-174, ProcessorParseRegexNative.cpp:108-253, ProcessorFilterNative.cpp:159-286).
+ * config_json: {"Split": {"SourceKey": "content", "SplitChar": "\n"}, "Parse": {<the parser's keys>}, "Filter": {<the filter's
+ * keys>}, "Fused": true}.  The raw buffer goes up once; lines are found, matched and filtered (the filter's FilterKey / FilterRegex
+ * rules run on the capture spans of the keys they name) on the device; only the survivors come back and only they become events --
+ * the same events, contents, positions and counters the three processors leave one after the other.  What the fused trip cannot
+ * express (rules on keys the parser does not produce, ConditionExp, DiscardingNonUTF8, alarms wanted, ...) runs the three steps
+ * one after the other with the same classes: lc_pipeline_is_fused says which.  lc_pipeline_process takes a group as made by
+ * lc_group_from_buffer (or any group: events that are not plain read buffers send the group down the chained path). */
+typedef struct lc_pipeline lc_pipeline_t;
+enum { LC_PIPE_FILTER_IN_EVENTS = 0, LC_PIPE_FILTER_OUT_EVENTS, LC_PIPE_GROUPS_FUSED, LC_PIPE_GROUPS_CHAINED, LC_PIPE_LINES,
+       LC_PIPE_SURVIVORS, LC_PIPE_CNT_COUNT };
+int lc_pipeline_create(const char* config_json, lc_pipeline_t** out, char* err, size_t errcap);
+void lc_pipeline_destroy(lc_pipeline_t* p);
+int lc_pipeline_is_fused(const lc_pipeline_t* p);
+int lc_pipeline_process(lc_pipeline_t* p, lc_event_group_t* group);
+/* parse[]: the parser's counters in LC_CNT_* order (instance-level entries are 0); pipe[]: LC_PIPE_* */
+int lc_pipeline_counters(const lc_pipeline_t* p, uint64_t parse[LC_CNT_COUNT], uint64_t pipe[LC_PIPE_CNT_COUNT]);
 
 /* ---- the dynamic C processor slot (layout identical to CProcessor.h:23-45) ---- */
 #define LC_PROCESSOR_INTERFACE_VERSION 100

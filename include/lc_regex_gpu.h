@@ -252,6 +252,27 @@ int lc_split_lines_device(const uint8_t* d_data, uint64_t nbytes, uint8_t split_
                           uint32_t off_capacity, uint32_t* d_nlines, void* d_scratch, size_t scratch_bytes,
                           void* stream);
 
+/* The step AFTER the parser on the parser's own output, still on the device: ProcessorFilterNative::IsMatched
+ * (core/plugin/processor/ProcessorFilterNative.cpp:258-286) for FilterKey / FilterRegex rules whose keys the parser has just
+ * produced -- the reference's benchmark pipeline filters on the captured user_agent
+ * (test/benchmark/local/test_cases/performance_file_to_blackhole_loongcollector/loongcollector.yaml:22-27).  The value of a parsed
+ * key is the span of its capture group; each rule is regex_match(span) with the rule's regex as a yes/no automaton.
+ *   lc_regex_prepare_span_filter: the rule's regex (compiled with lc_regex_compile, default syntax = regex_match) gets that
+ *       automaton; LC_ERR_UNSUPPORTED when its tagged DFA does not exist or is too large (the caller then filters on the host side)
+ *   lc_span_filter_device: after lc_split_lines_device + lc_regex_match_device_dyn on the same stream.  A line survives when the
+ *       parser matched it and every rule matches its group's span (a group that did not take part has the empty value).
+ *       d_packed[k] = [line, offset, length, 2*ngroups capture offsets] for survivor k (order unspecified), at most
+ *       packed_cap_rows rows are written; d_counts[0] = lines, [1] = survivors, [2] = lines the parser did not match,
+ *       [3] = lines left LC_OVERFLOW / LC_GAVE_UP.  Asynchronous on `stream`. */
+typedef struct lc_span_filter {
+    lc_regex_t* re;
+    uint32_t group; /* 1-based capture group of the parse regex */
+} lc_span_filter_t;
+int lc_regex_prepare_span_filter(lc_regex_t* re);
+int lc_span_filter_device(const lc_span_filter_t* filters, uint32_t nfilters, const uint8_t* d_data, const uint32_t* d_off,
+                          uint32_t sep_bytes, const uint32_t* d_nlines, uint32_t max_lines, uint32_t ngroups, const int32_t* d_caps,
+                          const uint8_t* d_status, int32_t* d_packed, uint32_t packed_cap_rows, uint32_t* d_counts, void* stream);
+
 /* Same, for host buffers: lines are gathered through pinned staging buffers and copied with
  * hipMemcpyAsync on two streams so that chunk k+1 uploads while chunk k is being matched and chunk k-1
  * downloads.  Synchronous: results are in caps/status on return. */

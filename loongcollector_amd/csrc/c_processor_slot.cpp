@@ -9,6 +9,7 @@
 
 #include "../../include/lc_processor.h"
 #include "processor_parse_regex_gpu.hpp"
+#include "processor_pipeline_gpu.hpp"
 #ifdef LC_USE_REFERENCE_HEADERS
 #include "json/json.h"  // the agent hands init() a Json::Value* (DynamicCProcessorProxy.cpp:30-32)
 #endif
@@ -149,6 +150,77 @@ extern "C" lc_event_group_t* lc_group_from_lines(const uint8_t* data, const uint
         at += size_t(len[i]) + 1;
     }
     return g.release();
+}
+
+// a group as the file input hands it over: ONE log event holding a copy of the read buffer (LogFileReader: content + position)
+extern "C" lc_event_group_t* lc_group_from_buffer(const uint8_t* data, size_t n, const char* key, uint64_t file_offset,
+                                                  const char* file_offset_key) {
+    if ((!data && n) || !key) return nullptr;
+    auto g = std::make_unique<lc_event_group>();
+    logtail::StringBuffer buf = g->group.GetSourceBuffer()->AllocateStringBuffer(n);
+    if (n) std::memcpy(buf.data, data, n);
+    const logtail::StringBuffer keyBuf = g->group.GetSourceBuffer()->CopyString(key, std::strlen(key));
+    logtail::LogEvent* ev = g->group.AddLogEvent();
+    ev->SetTimestamp(1);
+    ev->SetContentNoCopy(logtail::StringView(keyBuf.data, keyBuf.size), logtail::StringView(buf.data, n));
+    ev->SetPosition(file_offset, n);
+    if (file_offset_key) g->group.SetMetadata(logtail::EventGroupMetaKey::LOG_FILE_OFFSET_KEY, file_offset_key);
+    return g.release();
+}
+
+// ---- the fused split -> parse -> filter pipeline (processor_pipeline_gpu.hpp)
+struct lc_pipeline {
+    logtail::ProcessorPipelineGpu impl;
+};
+extern "C" int lc_pipeline_create(const char* config_json, lc_pipeline_t** out, char* err, size_t errcap) {
+    if (!config_json || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    lcjson::Value cfg;
+    try {
+        cfg = lcjson::parse(config_json);
+    } catch (const std::exception& e) {
+        setErr(err, errcap, e.what());
+        return LC_ERR_ARG;
+    }
+    auto p = std::make_unique<lc_pipeline>();
+    std::string error;
+    if (!p->impl.Init(cfg, error)) {
+        setErr(err, errcap, error);
+        return LC_ERR_SYNTAX;
+    }
+    setErr(err, errcap, "");
+    *out = p.release();
+    return LC_OK;
+}
+extern "C" void lc_pipeline_destroy(lc_pipeline_t* p) { delete p; }
+extern "C" int lc_pipeline_is_fused(const lc_pipeline_t* p) { return p && p->impl.IsFused(); }
+extern "C" int lc_pipeline_process(lc_pipeline_t* p, lc_event_group_t* g) {
+    if (!p || !g) return LC_ERR_ARG;
+    if (lc_device_count() <= 0) return LC_ERR_NO_DEVICE;
+    std::string error;
+    if (!p->impl.Process(g->group, error)) {
+        std::fprintf(stderr, "[%s] %s\n", logtail::ProcessorPipelineGpu::sName.c_str(), error.c_str());
+        return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
+    }
+    return LC_OK;
+}
+extern "C" int lc_pipeline_counters(const lc_pipeline_t* p, uint64_t parse[LC_CNT_COUNT], uint64_t pipe[LC_PIPE_CNT_COUNT]) {
+    if (!p || !parse || !pipe) return LC_ERR_ARG;
+    for (int i = 0; i < LC_CNT_COUNT; ++i) parse[i] = 0;
+    parse[LC_CNT_DISCARDED_EVENTS] = p->impl.mParse.mDiscardedEventsTotal;
+    parse[LC_CNT_OUT_FAILED_EVENTS] = p->impl.mParse.mOutFailedEventsTotal;
+    parse[LC_CNT_OUT_KEY_NOT_FOUND] = p->impl.mParse.mOutKeyNotFoundEventsTotal;
+    parse[LC_CNT_OUT_SUCCESSFUL_EVENTS] = p->impl.mParse.mOutSuccessfulEventsTotal;
+    parse[LC_CNT_COMPLEXITY_EXCEEDED] = p->impl.mParse.mComplexityExceededEventsTotal;
+    parse[LC_CNT_UNDECIDED_EVENTS] = p->impl.mParse.mUndecidedEventsTotal;
+    parse[LC_CNT_DEVICE_FAILED_EVENTS] = p->impl.mParse.mDeviceFailedEventsTotal;
+    pipe[LC_PIPE_FILTER_IN_EVENTS] = p->impl.mFilter.mInEventsTotal;
+    pipe[LC_PIPE_FILTER_OUT_EVENTS] = p->impl.mFilter.mOutEventsTotal;
+    pipe[LC_PIPE_GROUPS_FUSED] = p->impl.mGroupsFused;
+    pipe[LC_PIPE_GROUPS_CHAINED] = p->impl.mGroupsChained;
+    pipe[LC_PIPE_LINES] = p->impl.mLinesTotal;
+    pipe[LC_PIPE_SURVIVORS] = p->impl.mSurvivorsTotal;
+    return LC_OK;
 }
 
 // ---- columnar hand-off (include/lc_processor.h): gather + device match, nothing stitched

@@ -304,12 +304,15 @@ public:
 
     const EventsContainer& GetEvents() const { return mEvents; }
     EventsContainer& MutableEvents() { return mEvents; }
+    void SwapEvents(EventsContainer& other) { mEvents.swap(other); }
     LogEvent* AddLogEvent() {
         auto e = std::make_unique<LogEvent>(this);
         LogEvent* raw = e.get();
         mEvents.emplace_back(std::move(e));
         return raw;
     }
+    // (the reference draws events from the group's pool, PipelineEventGroup.h: CreateLogEvent(bool fromPool); no pool here)
+    std::unique_ptr<LogEvent> CreateLogEvent(bool = false) { return std::make_unique<LogEvent>(this); }
     RawEvent* AddRawEvent() {
         auto e = std::make_unique<RawEvent>(this);
         RawEvent* raw = e.get();

@@ -36,6 +36,7 @@
 #include "screen_kernel.hpp"
 #include "tdfa_l2_kernel.hpp"
 #include "split_kernel.hpp"
+#include "pipeline_kernel.hpp"
 #include "tdfa_stream_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -942,6 +943,45 @@ extern "C" int lc_split_lines_device(const uint8_t* d_data, uint64_t nbytes, uin
     return LC_OK;
 }
 
+// ---- the filter step on the parser's capture spans (pipeline_kernel.hpp)
+extern "C" int lc_span_filter_device(const lc_span_filter_t* filters, uint32_t nfilters, const uint8_t* d_data, const uint32_t* d_off,
+                                     uint32_t sep_bytes, const uint32_t* d_nlines, uint32_t max_lines, uint32_t ngroups,
+                                     const int32_t* d_caps, const uint8_t* d_status, int32_t* d_packed, uint32_t packed_cap_rows,
+                                     uint32_t* d_counts, void* stream) {
+    if (nfilters > kSpanFilterMax || (nfilters && !filters) || !d_nlines || !d_counts || ngroups == 0) return LC_ERR_ARG;
+    if (max_lines == 0) return LC_OK;
+    if (!d_data || !d_off || !d_caps || !d_status || (packed_cap_rows && !d_packed)) return LC_ERR_ARG;
+    if (lc_device_count() <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    SpanFilterArgs args{};
+    args.n = nfilters;
+    for (uint32_t f = 0; f < nfilters; ++f) {
+        lc_regex* re = filters[f].re;
+        if (!re || filters[f].group == 0 || filters[f].group > ngroups) return LC_ERR_ARG;
+        if (re->screenBlob.empty()) {
+            tlsError = "span filter: the rule's regex carries no yes/no DFA (lc_regex_prepare_span_filter)";
+            return LC_ERR_UNSUPPORTED;
+        }
+        void* blob = nullptr;
+        int rc = ensureUploaded(re, dev, kBlobScreen, &blob);
+        if (rc != LC_OK) return rc;
+        args.f[f].blob = static_cast<const uint32_t*>(blob);
+        args.f[f].group = filters[f].group;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 16, st));
+    noteKernel("span_filter_pack_kernel");
+    hipLaunchKernelGGL(span_filter_pack_kernel, dim3((max_lines + kSpanFilterBlock - 1) / kSpanFilterBlock), dim3(kSpanFilterBlock), 0, st,
+                       d_data, d_off, sep_bytes, d_nlines, max_lines, ngroups, d_caps, d_status, args, d_packed, packed_cap_rows, d_counts);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
+}
+
 extern "C" int lc_regex_match_device(lc_regex_t* re, const uint8_t* d_data, const uint32_t* d_off,
                                      const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t ngroups,
                                      int32_t* d_caps, uint8_t* d_status, void* stream) {
@@ -1278,6 +1318,7 @@ extern "C" void lc_thread_release(void) {
     tlsJobTables.release();
     for (auto& pool : tlsDecidePools) pool.release();
     lcGrokThreadRelease();
+    lcPipelineThreadRelease();
 }
 
 extern "C" void lc_nfa_set_dfs(int on) { gNfaDfsMode.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }

@@ -16,14 +16,23 @@
 #include <string>
 #include <vector>
 
+#ifdef LC_USE_REFERENCE_HEADERS  // built inside the LoongCollector tree: the real event model
+#include "models/LogEvent.h"
+#include "models/PipelineEventGroup.h"
+#else
 #include "event_model.hpp"
+#endif
 #include "json_min.hpp"
 
 struct lc_regex;
 
 namespace logtail {
 
+class ProcessorPipelineGpu;
+
 class ProcessorFilterGpu {
+    friend class ProcessorPipelineGpu;  // the fused split -> parse -> filter trip runs the rule leaves on the capture spans
+
 public:
     static const std::string sName;  // "processor_filter_regex_gpu"
     enum class Mode { BYPASS_MODE, EXPRESSION_MODE, RULE_MODE };

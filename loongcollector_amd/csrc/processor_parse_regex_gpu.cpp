@@ -324,29 +324,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                     RaiseAlarm(2, raw, logPath);
                     parseSuccess = false;
                 }
-                if (parseSuccess) {
-                    const int32_t* c = &caps[li * 2 * G];
-#ifndef LC_USE_REFERENCE_HEADERS
-                    if (mKeysDistinct && !mSourceKeyOverwritten && ev.Size() == 1) {
-                        // the event holds only the source content and no key can collide: append all K views at once
-                        // instead of K reverse scans (same contents, same order as the loop below)
-                        static thread_local std::vector<StringView> vals;
-                        vals.resize(mKeys.size());
-                        for (size_t k = 0; k < mKeys.size(); ++k) {
-                            const int32_t b = c[2 * k], en = c[2 * k + 1];
-                            vals[k] = b < 0 ? StringView(raw.data() + raw.size(), 0) : StringView(raw.data() + b, size_t(en - b));
-                        }
-                        ev.AppendContentsNoCopy(mKeyViews.begin(), vals.begin(), mKeys.size());
-                    } else
-#endif
-                    for (size_t k = 0; k < mKeys.size(); ++k) {  // :249-251
-                        const int32_t b = c[2 * k], en = c[2 * k + 1];
-                        // an unmatched group is boost's {last,last,matched=false}: empty value at end of input
-                        const StringView val = b < 0 ? StringView(raw.data() + raw.size(), 0)
-                                                     : StringView(raw.data() + b, size_t(en - b));
-                        AddLog(StringView(mKeys[k]), val, ev);
-                    }
-                }
+                if (parseSuccess) StitchMatched(ev, raw, &caps[li * 2 * G]);
                 keep = FinishEvent(ev, raw, parseSuccess, metadata, tally);
             }
         }
@@ -356,12 +334,46 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
         }
     }
     events.resize(wIdx);
+    AddTally(tally);
+}
+
+void ProcessorParseRegexGpu::AddTally(const Tally& tally) {
     if (tally.discarded) mDiscardedEventsTotal += tally.discarded;
     if (tally.outFailed) mOutFailedEventsTotal += tally.outFailed;
     if (tally.keyNotFound) mOutKeyNotFoundEventsTotal += tally.keyNotFound;
     if (tally.outSuccessful) mOutSuccessfulEventsTotal += tally.outSuccessful;
     if (tally.complexityExceeded) mComplexityExceededEventsTotal += tally.complexityExceeded;
     if (tally.undecided) mUndecidedEventsTotal += tally.undecided;
+}
+
+bool ProcessorParseRegexGpu::AlarmsWanted() const {
+#ifdef LC_USE_REFERENCE_HEADERS
+    if (mContext && AppConfig::GetInstance()->IsLogParseAlarmValid()) return true;
+#endif
+    return mAlarmSink != nullptr;
+}
+
+void ProcessorParseRegexGpu::StitchMatched(LogEvent& ev, StringView raw, const int32_t* c) {
+#ifndef LC_USE_REFERENCE_HEADERS
+    if (mKeysDistinct && !mSourceKeyOverwritten && ev.Size() == 1) {
+        // the event holds only the source content and no key can collide: append all K views at once
+        // instead of K reverse scans (same contents, same order as the loop below)
+        static thread_local std::vector<StringView> vals;
+        vals.resize(mKeys.size());
+        for (size_t k = 0; k < mKeys.size(); ++k) {
+            const int32_t b = c[2 * k], en = c[2 * k + 1];
+            vals[k] = b < 0 ? StringView(raw.data() + raw.size(), 0) : StringView(raw.data() + b, size_t(en - b));
+        }
+        ev.AppendContentsNoCopy(mKeyViews.begin(), vals.begin(), mKeys.size());
+        return;
+    }
+#endif
+    for (size_t k = 0; k < mKeys.size(); ++k) {  // :249-251
+        const int32_t b = c[2 * k], en = c[2 * k + 1];
+        // an unmatched group is boost's {last,last,matched=false}: empty value at end of input
+        const StringView val = b < 0 ? StringView(raw.data() + raw.size(), 0) : StringView(raw.data() + b, size_t(en - b));
+        AddLog(StringView(mKeys[k]), val, ev);
+    }
 }
 
 }  // namespace logtail

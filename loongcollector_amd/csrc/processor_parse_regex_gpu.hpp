@@ -46,7 +46,11 @@ struct GpuCommonParserOptions {
     bool ShouldEraseEvent(bool parseSuccess, const LogEvent& sourceEvent, const GroupMetadata& metadata) const;
 };
 
+class ProcessorPipelineGpu;
+
 class ProcessorParseRegexGpu {
+    friend class ProcessorPipelineGpu;  // the fused split -> parse -> filter trip stitches with this class's own code
+
 public:
     static const std::string sName;  // "processor_parse_regex_gpu" (new Type name; static names win in PluginRegistry)
     ~ProcessorParseRegexGpu();
@@ -100,6 +104,10 @@ private:
     };
     bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata, Tally& tally);
     void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
+    // the (key, view) pairs of one matched event: c = its 2 * mark_count capture offsets (:249-251)
+    void StitchMatched(LogEvent& ev, StringView raw, const int32_t* c);
+    void AddTally(const Tally& tally);
+    bool AlarmsWanted() const;
 
     void RaiseAlarm(int kind, StringView buffer, StringView logPath) const;
     AlarmSink mAlarmSink = nullptr;

@@ -1174,6 +1174,17 @@ extern "C" const char* lc_regex_group_name(const lc_regex_t* re, int g) {
     return s.empty() ? nullptr : s.c_str();
 }
 
+extern "C" int lc_regex_prepare_span_filter(lc_regex_t* re) {
+    if (!re) return LC_ERR_ARG;
+    std::lock_guard<std::mutex> g(re->deviceMutex);
+    if (!re->screenBlob.empty()) return LC_OK;
+    // the state graph of the tagged DFA (LDS-sized or the large one kept for the L2 kernel) recognises the same language
+    if ((!re->hasTdfa && re->tdfaL2Blob.empty()) || re->tdfa.nStates == 0 || re->tdfa.nStates > 0xFFFF) return LC_ERR_UNSUPPORTED;
+    if ((re->syntaxFlags & (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX)) != 0) return LC_ERR_UNSUPPORTED;  // regex_match semantics only
+    re->screenBlob = packScreenBlob(re->tdfa);
+    return LC_OK;
+}
+
 extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     if (!re || !out) return LC_ERR_ARG;
     out->engine = re->engine;

@@ -14,6 +14,7 @@ void lcNoteKernel(const char* name);                   // lc_launched_kernels() 
 void lcRegisterExitHook();                             // thread_local device resources: see gpu_runtime.hip
 bool lcRuntimeUsable();
 void lcGrokThreadRelease();                            // grok_device.hip: the calling thread's Grok buffers
+void lcPipelineThreadRelease();                        // processor_pipeline_gpu.cpp: the calling thread's staging and stream
 // the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
 void lcSetDecideSlot(int slot);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)

@@ -61,6 +61,17 @@ def _lib():
         L.lc_group_event_count.argtypes = [vp]
         L.lc_group_free.argtypes = [vp]
         L.lc_free.argtypes = [vp]
+        L.lc_group_from_buffer.restype = vp
+        L.lc_group_from_buffer.argtypes = [vp, sz, cp, ctypes.c_uint64, cp]
+        L.lc_pipeline_create.restype = ctypes.c_int
+        L.lc_pipeline_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
+        L.lc_pipeline_destroy.argtypes = [vp]
+        L.lc_pipeline_is_fused.restype = ctypes.c_int
+        L.lc_pipeline_is_fused.argtypes = [vp]
+        L.lc_pipeline_process.restype = ctypes.c_int
+        L.lc_pipeline_process.argtypes = [vp, vp]
+        L.lc_pipeline_counters.restype = ctypes.c_int
+        L.lc_pipeline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L._lc_processor_bound = True
     return L
 
@@ -89,6 +100,18 @@ class EventGroup:
         self._h = self._L.lc_group_from_lines(data.ctypes.data, off.ctypes.data, length.ctypes.data, len(off), key.encode("utf-8"))
         if not self._h:
             raise ValueError("lc_group_from_lines failed")
+        return self
+
+    @classmethod
+    def from_buffer(cls, buf, key="content", file_offset=0, file_offset_key=None):
+        """The group BEFORE the line splitter: one log event holding a copy of the read buffer (lc_group_from_buffer)."""
+        self = cls.__new__(cls)
+        self._L = _lib()
+        raw = bytes(buf)
+        self._h = self._L.lc_group_from_buffer(raw, len(raw), key.encode("utf-8"), file_offset,
+                                               None if file_offset_key is None else file_offset_key.encode("utf-8"))
+        if not self._h:
+            raise ValueError("lc_group_from_buffer failed")
         return self
 
     def to_json(self):
@@ -196,6 +219,55 @@ class Processor:
     def close(self):
         if getattr(self, "_h", None):
             self._L.lc_processor_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+PIPE_COUNTER_NAMES = ["filter_in_events", "filter_out_events", "groups_fused", "groups_chained", "lines", "survivors"]
+
+
+class Pipeline:
+    """processor_split_parse_filter_gpu (include/lc_processor.h lc_pipeline_*): the reference's benchmark pipeline
+    split -> processor_parse_regex_native -> processor_filter_regex_native, one device trip per read buffer when it can be fused.
+    config = {"Split": {...}, "Parse": {...}, "Filter": {...}, "Fused": True}"""
+
+    def __init__(self, config):
+        self._L = _lib()
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = self._L.lc_pipeline_create(json.dumps(config).encode("utf-8"), ctypes.byref(h), err, 512)
+        if rc != binding.LC_OK:
+            raise ProcessorInitError(err.value.decode("utf-8", "replace"))
+        self._h = h
+
+    @property
+    def fused(self):
+        return bool(self._L.lc_pipeline_is_fused(self._h))
+
+    def process(self, group: EventGroup):
+        rc = self._L.lc_pipeline_process(self._h, group._h)
+        if rc == binding.LC_ERR_NO_DEVICE:
+            raise binding.GpuUnavailableError("lc_pipeline_process: no usable HIP device (the pipeline has no CPU path)")
+        if rc != binding.LC_OK:
+            raise RuntimeError("lc_pipeline_process rc=%d" % rc)
+        return group
+
+    def counters(self):
+        parse = (ctypes.c_uint64 * len(COUNTER_NAMES))()
+        pipe = (ctypes.c_uint64 * len(PIPE_COUNTER_NAMES))()
+        self._L.lc_pipeline_counters(self._h, parse, pipe)
+        out = dict(zip(COUNTER_NAMES, [int(x) for x in parse]))
+        out.update(zip(PIPE_COUNTER_NAMES, [int(x) for x in pipe]))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc_pipeline_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -26,7 +26,7 @@ CSRC = os.path.join(ROOT, "loongcollector_amd", "csrc")
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("g++") is None,
                                 reason="needs the reference tree (/root/reference) and g++")
 
-SOURCES = ["processor_parse_regex_gpu.cpp", "c_processor_slot.cpp", "processor_filter_gpu.cpp", "processor_grok_gpu.cpp",
+SOURCES = ["processor_parse_regex_gpu.cpp", "c_processor_slot.cpp", "processor_filter_gpu.cpp", "processor_grok_gpu.cpp", "processor_pipeline_gpu.cpp",
            "processor_go_regex_gpu.cpp", "multiline_gpu.cpp", "multiline_events.cpp"]
 
 
@@ -42,7 +42,9 @@ def _syntax_only(src, extra=()):
 
 @pytest.mark.parametrize("src", SOURCES)
 def test_shim_type_checks_against_the_reference_headers(src):
-    r = _syntax_only(src)
+    # (the fused pipeline talks to the HIP runtime itself: its own stream and pinned staging)
+    extra = ("-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include") if src == "processor_pipeline_gpu.cpp" else ()
+    r = _syntax_only(src, extra)
     assert r.returncode == 0, r.stdout[-3000:]
 
 
