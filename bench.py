@@ -34,9 +34,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PCIE_GEN5_X16_GBPS = 63.0  # PCIe 5.0 x16, one direction, after 128b/130b encoding
 
 
+PLACEMENT = {}
+
+
 def setup_dist():
     import torch
     import torch.distributed as dist
+    from loongcollector_amd.shard import place_rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,6 +48,9 @@ def setup_dist():
         raise SystemExit("bench.py needs a HIP device: the parse engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # with several ranks on one host every rank stays on the CPUs / memory of its GPU's NUMA node: set BEFORE any pinned
+    # staging memory is allocated (first touch).  One rank keeps the whole box (its runner-thread measurements want the cores).
+    PLACEMENT.update(place_rank(local_rank, apply=world > 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -109,6 +116,71 @@ def measure_in_agent(pattern, keys, data, off, length, group_lines, n_groups, th
     return nbytes / dt / 1e6, first
 
 
+def measure_pipeline(thread_counts, buffer_bytes=512 << 10, n_buffers=64):
+    """The reference's benchmark pipeline (test/benchmark/local/test_cases/performance_file_to_blackhole_loongcollector/
+    loongcollector.yaml: split -> processor_parse_regex_native with regex B -> processor_filter_regex_native on user_agent) on
+    512 KB read buffers, the unit LogFileReader hands over: lc_pipeline_process = ONE device trip per buffer, only the survivors
+    come back and become events.  -> MB/s of raw buffer bytes per thread count, next to the same three steps run one after the
+    other (three gathers, three trips) and the reference's published 68 MB/s."""
+    import concurrent.futures
+    import threading
+    from loongcollector_amd import corpus
+    from loongcollector_amd.processor import EventGroup, Pipeline
+    parse = {"SourceKey": "content", "Regex": corpus.REGEX_B, "Keys": corpus.KEYS_B}
+    filt = {"FilterKey": ["user_agent"], "FilterRegex": ["^no-agent$"]}
+    data, off, length = corpus.apache_batch(buffer_bytes // 513 * 4, "B", 512, seed=corpus.SEED + 99, pool_lines=2048)
+    lines = [bytes(data[o:o + l]) for o, l in zip(off[:-1], length)]
+    for i in range(0, len(lines), 50):   # 2 % of the lines carry the agent the filter keeps
+        head, _, _ = lines[i].rpartition(b' "')
+        lines[i] = head + b' "no-agent"'
+    per = buffer_bytes // 513
+    buffers = [b"\n".join(lines[k * per:(k + 1) * per]) + b"\n" for k in range(4)]
+    out = {"what": "lc_pipeline_process on %d KB read buffers (%d lines of 512 B): split -> parse (regex B, 11 keys) -> filter "
+                   "user_agent ^no-agent$ (2 %% of the lines survive), one device trip per buffer, N runner threads sharing one "
+                   "instance" % (buffer_bytes >> 10, per),
+           "reference_MBps": 68.0, "reference_what": "LoongCollector's published single-thread figure for this pipeline (BASELINE.md)"}
+    expect = None
+    for label, fused in (("fused_MBps", True), ("three_steps_MBps", False)):
+        pipe = Pipeline({"Parse": parse, "Filter": filt, "Fused": fused})
+        assert pipe.fused == fused
+        res = {}
+        for t in thread_counts:
+            per_thread = max(4, n_buffers // t)
+            gate = threading.Barrier(t + 1)
+            ends = [0.0] * t
+            kept = [0] * t
+
+            def run(tid):
+                mine = [EventGroup.from_buffer(buffers[(tid + k) % len(buffers)], file_offset=k * buffer_bytes) for k in range(per_thread + 1)]
+                pipe.process(mine[0])  # this thread's first call allocates its staging and stream
+                gate.wait()
+                for g in mine[1:]:
+                    pipe.process(g)
+                    kept[tid] += len(g)
+                ends[tid] = time.perf_counter()
+
+            with concurrent.futures.ThreadPoolExecutor(t) as ex:
+                futs = [ex.submit(run, tid) for tid in range(t)]
+                gate.wait()
+                t0 = time.perf_counter()
+                for f in futs:
+                    f.result()
+            dt = max(ends) - t0
+            nbytes = sum(len(buffers[(tid + k) % len(buffers)]) for tid in range(t) for k in range(1, per_thread + 1))
+            res[str(t)] = round(nbytes / dt / 1e6, 1)
+            survivors = sum(kept)
+            want = sum(sum(1 for ln in buffers[(tid + k) % len(buffers)].split(b"\n") if ln.endswith(b'"no-agent"'))
+                       for tid in range(t) for k in range(1, per_thread + 1))
+            if survivors != want:
+                raise SystemExit("PARITY FAILURE (pipeline, %s): %d events survived, %d lines carry the kept agent" % (label, survivors, want))
+        out[label] = res
+        c = pipe.counters()
+        if expect is None:
+            expect = (c["out_failed_events_total"], c["discarded_events_total"])
+        out.setdefault("groups", {})[label] = {"fused": c["groups_fused"], "chained": c["groups_chained"]}
+    return out
+
+
 def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_counts, group_lines=1000, e2e_lines=1 << 18):
     G = rx.groups
     n = len(length)
@@ -142,6 +214,7 @@ def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_count
         if [tuple(kv) for kv in first] != want:
             raise SystemExit("PARITY FAILURE (in-agent path): stitched fields differ from the oracle's captures")
     out["in_agent_MBps"] = ag
+    out["pipeline"] = measure_pipeline(thread_counts)
     out["in_agent_what"] = ("lc_processor_process on %d-line event groups (gather into pinned staging -> ONE kernel launch that reads the lines and writes the capture table through the pinned mapping -> stitch + policy), "
                             "N runner threads sharing one instance; %d lines" % (group_lines, m))
     return out
@@ -290,6 +363,29 @@ def run_headline(args):
     kernel_ms = ev_start.elapsed_time(ev_end) / args.steps
 
     matched = int(d_status.sum().item())
+    # ---- the other BASELINE configs, bounded, AFTER the timed region (never inside it): so that the driver's one line is
+    # evidence for all five configs.  configs[4] is host-fed and collective (barriers + the counters' all-gather): every rank runs it.
+    extra = {}
+    if not args.no_configs:
+        import argparse as _ap
+        sub = _ap.Namespace(**vars(args))
+        sub.corpus_gb, sub.slab_mib, sub.no_cpu_baseline = 1.0 * world, 64, args.no_cpu_baseline
+        host_fed = compute_sharded_corpus(sub, world, rank, dev)
+        if rank == 0:
+            extra["configs[4]"] = host_fed
+        if rank == 0 and world == 1:
+            sub = _ap.Namespace(**vars(args))
+            sub.pipelines, sub.group_lines, sub.streams, sub.steps, sub.warmup = 64, 1000, 4, 20, 3
+            extra["configs[3]"] = compute_multitenant(sub, dev)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import grok_bench
+            import grok_inagent_bench
+            g = grok_bench.measure(_ap.Namespace(lines="16384,65536", steps=3, warmup=4, cpu_sample_lines=300, patterns=0,
+                                                 no_sequential_check=False, sequential=False), device_index=dev.index or 0)
+            for r in g:
+                r["config"].pop("patterns_refused", None)
+            extra["configs[2]"] = {"batches": g,
+                                   "in_agent": grok_inagent_bench.measure(_ap.Namespace(threads="1,16", group=1000, groups=20, patterns=0))}
     # the job's only collective: ONE all-gather of the per-GPU counters (RCCL); the data path has none
     per_gpu = gather_job({"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps, "matched_last": matched,
                           "elapsed_us": int(elapsed * 1e6), "kernel_us_per_step": int(kernel_ms * 1e3)}, device=dev)
@@ -304,8 +400,8 @@ def run_headline(args):
         achieved = algo_bytes / avg_kernel_s / 1e9
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
         # this same command, profiles/round*_traffic.json); only quoted for the workload they were collected on
-        traffic = None
-        for name in ("round2_traffic.json", "round1_traffic.json"):
+        traffic, traffic_source = None, None
+        for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 with open(tpath) as f:
@@ -313,6 +409,9 @@ def run_headline(args):
                 if (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
                         n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
                     traffic = tj["hbm_bytes_per_launch"]
+                    traffic_source = {"file": "profiles/" + name, "measured_in_run": False,
+                                      "what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (separate runs), "
+                                              "corrected as MI355X_MICROARCH.md prescribes"}
                 break
         out = {
             "metric": "MB/s parsed (512B lines, 10-field regex) per MI355X + HBM-roofline %",
@@ -334,14 +433,17 @@ def run_headline(args):
                        "lds_table_bytes": info["table_bytes"], "parallelism": "line-shard x%d" % world,
                        "matched_lines_last_batch": matched},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernels.split(",")[0].split("<")[0] if kernels else None, "kernels_launched": kernels,
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "configs": extra or None,
             "per_gpu": [{"rank": i, "MBps": round(g["bytes"] / (g["elapsed_us"] / 1e6) / 1e6, 1),
-                         "kernel_ms": g["kernel_us_per_step"] / 1e3, "lines": g["lines"], "matched_last": g["matched_last"]}
+                         "kernel_ms": g["kernel_us_per_step"] / 1e3, "lines": g["lines"], "matched_last": g["matched_last"],
+                         "what": "HBM-resident batch per rank (flat by construction: no shared resource); configs[4].per_gpu is the "
+                                 "host-fed table"}
                         for i, g in enumerate(per_gpu)],
         }
         print(json.dumps(out))
@@ -381,11 +483,15 @@ def pack_lines(lines):
 
 
 def run_multitenant(args):
+    world, rank, dev = setup_dist()
+    print(json.dumps(compute_multitenant(args, dev)))
+
+
+def compute_multitenant(args, dev):
     import torch
 
     from loongcollector_amd import binding
 
-    world, rank, dev = setup_dist()
     P, GL = args.pipelines, args.group_lines
     tenants = tenant_pipelines(P, GL)
     pipes = []
@@ -482,24 +588,34 @@ def run_multitenant(args):
                         "unit": "GB/s", "frac": round(algo / args.steps / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                         "kernel": "tdfa_stream_multi_kernel", "avg_kernel_ms": round(kernel_ms, 4),
                         "algorithmic_bytes_per_launch": algo // args.steps}}
-    print(json.dumps(out))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------- configs[4]: host-fed corpus
 def run_sharded_corpus(args):
+    import torch.distributed as dist
+    world, rank, dev = setup_dist()
+    out = compute_sharded_corpus(args, world, rank, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def compute_sharded_corpus(args, world, rank, dev):
+    """every rank calls this (it contains barriers and the job's all-gather); rank 0 gets the result, the others None"""
     import torch
     import torch.distributed as dist
 
     from loongcollector_amd import binding, corpus
-    from loongcollector_amd.shard import gather_job
+    from loongcollector_amd.shard import gather_job, run_slab_job
 
-    world, rank, dev = setup_dist()
     rx = binding.GpuRegex(corpus.REGEX_B)
     G = rx.groups
     slab_bytes = args.slab_mib << 20
     total_bytes = int(args.corpus_gb * (1 << 30))
     n_slabs_total = max(world, total_bytes // slab_bytes)
-    my_slabs = list(range(rank, n_slabs_total, world))  # 64 MiB slabs dealt round-robin to the ranks
+    # (64 MiB slabs dealt round-robin to the ranks, SURVEY section 8e: loongcollector_amd/shard.py deal_slabs / run_slab_job)
     # distinct slab contents: a few slabs of mixed nginx/JSON lines (log-uniform 128..2048 B, 30 % JSON that must fail), cycled
     kinds = 4
     slabs = []
@@ -576,21 +692,17 @@ def run_sharded_corpus(args):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    inflight = []
-    for i, sidx in enumerate(my_slabs):
-        slab, buf = slabs[sidx % kinds], bufs[i % NBUF]
-        if len(inflight) == NBUF:
-            drain(*inflight.pop(0))
-        inflight.append((slab, buf, feed(slab, buf)))
-    while inflight:
-        drain(*inflight.pop(0))
+    my_slabs = run_slab_job(n_slabs_total, rank, world,
+                            lambda sidx, b: (slabs[sidx % kinds], bufs[b], feed(slabs[sidx % kinds], bufs[b])),
+                            lambda ticket: drain(*ticket), in_flight=NBUF)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tsum = np.array(timing).sum(axis=0) if timing else np.zeros(3)
     per_gpu = gather_job(dict(counters, elapsed_us=int(elapsed * 1e6), h2d_us=int(tsum[0] * 1e3), kernel_us=int(tsum[1] * 1e3),
-                              d2h_us=int(tsum[2] * 1e3), slabs=len(my_slabs)), device=dev)
+                              d2h_us=int(tsum[2] * 1e3), slabs=len(my_slabs), numa_node=PLACEMENT.get("numa_node", -1),
+                              cpus=PLACEMENT.get("cpus", 0), pinned=int(bool(PLACEMENT.get("pinned")))), device=dev)
     if rank == 0:
         el = max(g["elapsed_us"] for g in per_gpu) / 1e6
         tot = sum(g["bytes"] for g in per_gpu)
@@ -607,10 +719,11 @@ def run_sharded_corpus(args):
                         "frac": round(raw / el / 1e9 / (PCIE_GEN5_X16_GBPS * world), 3)},
                "per_gpu": [{"rank": i, "MBps": round(g["bytes"] / (g["elapsed_us"] / 1e6) / 1e6, 1), "lines": g["lines"],
                             "matched": g["matched"], "failed": g["failed"], "slabs": g["slabs"], "h2d_ms": g["h2d_us"] / 1e3,
-                            "kernel_ms": g["kernel_us"] / 1e3, "d2h_ms": g["d2h_us"] / 1e3} for i, g in enumerate(per_gpu)]}
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+                            "kernel_ms": g["kernel_us"] / 1e3, "d2h_ms": g["d2h_us"] / 1e3,
+                            "placement": {"numa_node": g["numa_node"], "cpus": g["cpus"], "pinned_to_node": bool(g["pinned"])}}
+                           for i, g in enumerate(per_gpu)]}
+        return out
+    return None
 
 
 def main():
@@ -628,6 +741,7 @@ def main():
     ap.add_argument("--cpu-sample-lines", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive measurements (end_to_end)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs (configs)")
     ap.add_argument("--pipelines", type=int, default=64)
     ap.add_argument("--group-lines", type=int, default=1000)
     ap.add_argument("--streams", type=int, default=4)
@@ -638,7 +752,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import grok_bench
         lines = args.lines if "--lines" in sys.argv else 1 << 18
-        sys.argv = [sys.argv[0], "--lines", str(lines), "--steps", str(min(args.steps, 5)), "--warmup", str(min(args.warmup, 1))]
+        sys.argv = [sys.argv[0], "--lines", str(lines), "--steps", str(min(args.steps, 5)), "--warmup", str(max(args.warmup, 4))]
         grok_bench.main()
     elif args.config == 4:
         run_multitenant(args)

@@ -285,6 +285,11 @@ int lc_regex_match_host(lc_regex_t* re, const uint8_t* data, const uint32_t* off
 int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* lines, const uint32_t* len, uint32_t n,
                               uint32_t ngroups, int32_t* caps, uint8_t* status);
 
+/* Values that the consumers without a parse-failure counter of their own (filter leaves, multiline start / continue / end flags,
+ * the Go regex plugin) took as "no match" because the matcher gave up on them (LC_GAVE_UP: where boost would have thrown its
+ * complexity exception and BoostRegexMatch / BoostRegexSearch would have returned false).  Process-wide, monotonically growing. */
+uint64_t lc_gave_up_values_total(void);
+
 /* last HIP error string of the calling thread (for LC_ERR_HIP) */
 const char* lc_last_error(void);
 

@@ -1207,7 +1207,22 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
             std::memset(s.hData + stageBytes, 0, 16);
             static const bool pollOff = getenv("LC_HOST_NO_POLL") != nullptr;
             const uint32_t doneSeqNo = ++s.flagSeq;
+            // Whatever way this block is left: the completion request is disarmed (a later, unrelated launch of this thread must
+            // not signal a stale flag), and after an error nothing queued here may still be reading the staging block or writing
+            // the pinned capture table when the next call reuses them.
+            struct ZeroCopyGuard {
+                hipStream_t stream;
+                bool queued = false, ok = false;
+                ~ZeroCopyGuard() {
+                    tlsDone = DoneRequest{};
+                    if (queued && !ok) {
+                        (void)hipStreamSynchronize(stream);
+                        (void)hipGetLastError();
+                    }
+                }
+            } zc{s.stream};
             tlsDone = DoneRequest{s.dDone, s.hFlag, doneSeqNo, !pollOff, false};
+            zc.queued = true;
             if (zeroCopyEnv == 2) {
                 HIP_TRY(hipMemcpyAsync(s.dData, s.hData, blockBytes, hipMemcpyHostToDevice, s.stream));
                 rc = lcMatchOnStream(re, re->engine, dev, s.dData, reinterpret_cast<uint32_t*>(s.dData + tableAt),
@@ -1250,6 +1265,7 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
             HIP_TRY(waitErr);
             if (ngroups) std::memcpy(caps, s.hCaps, size_t(n) * 2 * ngroups * 4);
             std::memcpy(status, s.hStatus, n);
+            zc.ok = true;
             return LC_OK;
         }
     }

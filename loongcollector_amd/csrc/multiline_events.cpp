@@ -19,6 +19,7 @@
 #include "../../include/lc_multiline.h"
 #include "../../include/lc_regex_gpu.h"
 #include "json_min.hpp"
+#include "regex_handle.hpp"
 #include "multiline_gpu.hpp"
 #ifdef LC_USE_REFERENCE_HEADERS
 #include "models/LogEvent.h"
@@ -279,8 +280,12 @@ int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
         if (!re || n == 0) return LC_OK;
         const int r = lc_regex_match_host_views(re, ptrs.data(), lens.data(), n, 0, nullptr, dst.data());
         if (r != LC_OK) return r;
-        for (uint8_t st : dst)
-            if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;  // "not decided" must not drive the state machine as "no match"
+        uint64_t gaveUp = 0;
+        for (uint8_t st : dst) {
+            if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;
+            gaveUp += st == LC_GAVE_UP;  // BoostRegexSearch failed with an exception (StringTools.cpp:277-282): false, and counted
+        }
+        if (gaveUp) lcNoteGaveUp(gaveUp);  // "not decided" must not drive the state machine as "no match"
         return LC_OK;
     };
     int rc;

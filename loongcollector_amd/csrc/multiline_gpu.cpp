@@ -15,6 +15,7 @@
 #include "../../include/lc_multiline.h"
 #include "../../include/lc_regex_gpu.h"
 #include "json_min.hpp"
+#include "regex_handle.hpp"
 
 namespace {
 
@@ -140,8 +141,12 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
         const int r = lc_regex_match_host(re, data, off.data(), len.data(), n, 0, nullptr, dst.data());
         if (r != LC_OK) return r;
         // "not decided" (decide pass switched off) must not drive the state machine as "no match"
-        for (uint8_t st : dst)
+        uint64_t gaveUp = 0;
+        for (uint8_t st : dst) {
             if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;
+            gaveUp += st == LC_GAVE_UP;  // BoostRegexSearch failed with an exception (StringTools.cpp:277-282): false, and counted
+        }
+        if (gaveUp) lcNoteGaveUp(gaveUp);
         return LC_OK;
     };
     int rc;

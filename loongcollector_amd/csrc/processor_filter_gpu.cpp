@@ -7,6 +7,7 @@
 
 #include "../../include/lc_processor.h"
 #include "../../include/lc_regex_gpu.h"
+#include "regex_handle.hpp"
 
 namespace logtail {
 
@@ -243,6 +244,7 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
 
     // one device launch per regex leaf over the values of its key (absent key: the leaf is false, :260-264 / :457-461)
     std::vector<std::vector<uint8_t>> leafResult(mLeaves.size());
+    uint64_t gaveUp = 0;
     std::vector<const uint8_t*> ptr;
     std::vector<uint32_t> len, owner;
     std::vector<uint8_t> status;
@@ -278,9 +280,14 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
                 return false;
             }
             leafResult[l][owner[k]] = status[k] == LC_MATCH;
+            gaveUp += status[k] == LC_GAVE_UP;  // regex_match in Filter fail (:266-281): false, and counted
         }
     }
 
+    if (gaveUp) {
+        mComplexityExceededTotal += gaveUp;
+        lcNoteGaveUp(gaveUp);
+    }
     size_t wIdx = 0;
     for (size_t rIdx = 0; rIdx < n; ++rIdx) {  // Process :159-176 / ProcessEvent :178-216
         bool res = true;

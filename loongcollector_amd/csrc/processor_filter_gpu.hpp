@@ -46,6 +46,7 @@ public:
     bool mDiscardingNonUTF8 = false;
     // one instance is shared by the runner threads (like ProcessorParseRegexGpu's counters)
     std::atomic<uint64_t> mInEventsTotal{0}, mOutEventsTotal{0};
+    std::atomic<uint64_t> mComplexityExceededTotal{0};  // leaf values the matcher gave up on: taken as false (regex_match failed)
 
     // ProcessorFilterNative::noneUtf8 (:297-379): true if `s` holds a byte sequence that is not UTF-8 as that routine
     // defines it; with modify, every offending byte is overwritten with ' '

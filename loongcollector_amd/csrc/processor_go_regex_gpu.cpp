@@ -11,6 +11,7 @@
 
 #include "../../include/lc_go_regex.h"
 #include "json_min.hpp"
+#include "regex_handle.hpp"
 #include "processor_grok_gpu.hpp"  // lcgrok::Log / LogContent: the protocol.Log shape
 
 namespace lcgrok {
@@ -63,8 +64,12 @@ public:
                                            status.data());
         if (rc != LC_OK) throw GrokError(std::string("device match failed: ") + lc_last_error());
         // LC_OVERFLOW = "not decided" (only possible with the decide pass switched off): never folded into "no match"
-        for (size_t r = 0; r < refs.size(); ++r)
+        uint64_t gaveUp = 0;
+        for (size_t r = 0; r < refs.size(); ++r) {
             if (status[r] == LC_OVERFLOW) throw GrokError("device left a value undecided (LC_NFA_NO_DECIDE is set): logs untouched");
+            gaveUp += status[r] == LC_GAVE_UP;  // (Go's regexp never gives up; here such a value is a parse error, and counted)
+        }
+        if (gaveUp) lcNoteGaveUp(gaveUp);
         for (size_t r = 0; r < refs.size(); ++r) {
             Log& log = logs[refs[r].log];
             const int32_t* c = &caps[r * 2 * groups];

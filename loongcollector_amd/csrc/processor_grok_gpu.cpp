@@ -189,6 +189,7 @@ void ProcessorGrokGpu::Init() {
     mAnchored.reset(new std::atomic<lc_regex*>[Match.size() ? Match.size() : 1]);
     for (size_t i = 0; i < Match.size(); ++i) mAnchored[i].store(nullptr);
     mWarmupWant.clear();
+    mAnchoredBytes = 0;
     if (AnchoredFirst && !noAnchored)
         for (size_t i = 0; i < Match.size(); ++i)
             if (mCompiled[i]->engine == LC_ENGINE_NFA) mWarmupWant.push_back(i);
@@ -201,17 +202,29 @@ void ProcessorGrokGpu::startWarmup() {
         mWarmupStarted = true;
         mWarmup = std::thread([this] {
             const std::vector<size_t>& want = mWarmupWant;
-            const size_t workers = std::max<size_t>(1, std::min<size_t>(want.size(), std::min(16u, std::thread::hardware_concurrency())));
+            // a log agent has other uses for its cores and memory: a few workers, and a budget for the tables (an anchored automaton
+            // is kept as the L2 blob on the host plus its copy on the device; the entries are taken in list order until it is spent)
+            const size_t workers = std::max<size_t>(1, std::min<size_t>(want.size(), std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2))));
+            const int64_t budget = std::max<int64_t>(0, AnchoredBudgetMB) << 20;
+            std::atomic<int64_t> spent{0};
             std::atomic<size_t> next{0};
             auto work = [&] {
                 for (size_t t = next.fetch_add(1); t < want.size() && !mStopWarmup.load(); t = next.fetch_add(1)) {
+                    if (spent.load() >= budget) break;
                     const size_t i = want[t];
                     lc_regex_t* re = nullptr;
                     char err[64];
                     // (failure = the automaton is too large even anchored: the entry searches on the NFA engine only)
                     if (lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax | LC_SYNTAX_PREFIX, LC_ENGINE_TDFA, &re,
-                                         err, sizeof err) == LC_OK)
-                        mAnchored[i].store(re, std::memory_order_release);
+                                         err, sizeof err) != LC_OK)
+                        continue;
+                    const int64_t bytes = 2 * int64_t((re->tdfaL2Blob.size() + re->tdfaBlob.size() + re->tdfaWideBlob.size()) * 4);
+                    if (spent.fetch_add(bytes) + bytes > budget) {
+                        lc_regex_free(re);  // over the budget: this entry keeps searching on the NFA engine
+                        continue;
+                    }
+                    mAnchoredBytes += uint64_t(bytes);
+                    mAnchored[i].store(re, std::memory_order_release);
                 }
             };
             std::vector<std::thread> pool;
@@ -363,6 +376,8 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
         boolean("KeepSource", g->p.KeepSource);
         boolean("AnchoredFirst", g->p.AnchoredFirst);
         boolean("Speculative", g->p.Speculative);
+        if (const lcjson::Value* v = cfg.find("AnchoredBudgetMB"))
+            if (v->isNumber()) g->p.AnchoredBudgetMB = v->isInt ? v->inum : int64_t(v->num);
         if (const lcjson::Value* v = cfg.find("PrefixScreenAbove"))
             if (v->isNumber()) g->p.PrefixScreenAbove = v->isInt ? v->inum : int64_t(v->num);
         if (const lcjson::Value* v = cfg.find("Streams"))

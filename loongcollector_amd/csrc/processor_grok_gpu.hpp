@@ -44,6 +44,7 @@ public:
     // compiled BEHIND Init, on a warm-up thread, and join the device loop as they arrive (results do not depend on them, only speed;
     // WaitReady() blocks until the thread is done).  Instances that only probe a pattern switch it off.
     bool AnchoredFirst = true;
+    int64_t AnchoredBudgetMB = 256;   // host + device bytes all anchored automata of this instance may take together
     // not reference keys either (GrokOptions, grok_runtime.hpp; results never depend on them): evaluate all (entry, value) pairs that
     // pass the screens at the same time (default) or walk the list entry by entry; the sequential path's prefix-screen threshold;
     // worker streams of the speculative path
@@ -77,6 +78,7 @@ public:
     const std::vector<GrokDevicePattern>& compiledPatterns() const { return mDevice; }  // (without the anchored searches)
     void WaitReady();                                       // returns when the warm-up thread has compiled what it can
     uint32_t rowInts() const { return mRowInts; }
+    uint64_t anchoredBytes() const { return mAnchoredBytes.load(); }
     GrokDeviceState* deviceState() { return mState; }
     GrokOptions options() const;
     int engine(size_t i) const;
@@ -91,6 +93,7 @@ private:
     std::atomic<bool> mStopWarmup{false};
     std::mutex mWarmupMutex;
     bool mWarmupStarted = false;
+    std::atomic<uint64_t> mAnchoredBytes{0};
     std::vector<size_t> mWarmupWant;                   // the entries the warm-up thread compiles an anchored search for
     void startWarmup();
     void stopWarmup();

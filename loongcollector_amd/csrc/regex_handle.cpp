@@ -1174,6 +1174,10 @@ extern "C" const char* lc_regex_group_name(const lc_regex_t* re, int g) {
     return s.empty() ? nullptr : s.c_str();
 }
 
+static std::atomic<uint64_t> gGaveUpValues{0};
+void lcNoteGaveUp(uint64_t n) { gGaveUpValues += n; }
+extern "C" uint64_t lc_gave_up_values_total(void) { return gGaveUpValues.load(); }
+
 extern "C" int lc_regex_prepare_span_filter(lc_regex_t* re) {
     if (!re) return LC_ERR_ARG;
     std::lock_guard<std::mutex> g(re->deviceMutex);

@@ -52,6 +52,11 @@ struct lc_regex {
     std::atomic<uint32_t> grokRounds{2}, grokRoundsSlack{0};
 };
 
+// Values a consumer without a parse-failure notion of its own (filter leaves, multiline flags, the Go regex plugin) had to take as
+// "no match" because the decide kernel gave up on them (LC_GAVE_UP: boost's complexity exception -- BoostRegexMatch / BoostRegexSearch
+// return false there too, core/common/StringTools.cpp:200-205,277-282).  Never silent: counted here, lc_gave_up_values_total().
+void lcNoteGaveUp(uint64_t n);
+
 namespace lcregex {
 // `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
 // foldPrograms: multi-stamp register programs become stamps of set registers when every program of the table allows it

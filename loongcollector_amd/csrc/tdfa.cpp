@@ -401,7 +401,9 @@ static void eliminateDeadStores(TdfaTables& T) {
             }
             e = t | (it->second << 16);
         }
-    if (after == before) return;
+    // (always rebuilt: the transitions above now carry the ids of newLists, whatever was or was not dropped)
+    (void)before;
+    (void)after;
     T.opsStart.assign(1, 0);
     T.ops.clear();
     for (const auto& l : newLists) {

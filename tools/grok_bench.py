@@ -101,7 +101,12 @@ def main():
     ap.add_argument("--no-sequential-check", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="time the sequential walk of the list instead")
     args = ap.parse_args()
+    for out in measure(args):
+        print(json.dumps(out), flush=True)
 
+
+def measure(args, device_index=0):
+    """-> one result dict per batch size (bench.py embeds them in its line as configs[2])"""
     import torch
 
     from loongcollector_amd import binding
@@ -110,7 +115,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("grok_bench.py needs a HIP device: the Grok matcher has no CPU path")
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device_index)
+    results = []
     with open(os.path.join(ROOT, "tests", "golden", "grok_config3.json"), encoding="utf-8") as f:
         cfg = json.load(f)
     supported, refused = supported_patterns(cfg)
@@ -215,8 +221,9 @@ def main():
                              "sample": "%d lines strided across the batch: oracle/grok_oracle.py over oracle/bt_regex.c "
                                        "(processGrok restated), 1 thread" % len(idx)},
         }
-        print(json.dumps(out), flush=True)
+        results.append(out)
         del batch
+    return results
 
 
 if __name__ == "__main__":

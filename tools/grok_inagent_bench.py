@@ -27,6 +27,13 @@ def main():
     ap.add_argument("--groups", type=int, default=40, help="groups per thread in the timed region")
     ap.add_argument("--patterns", type=int, default=0)
     args = ap.parse_args()
+    for out in measure(args):
+        print(json.dumps(out), flush=True)
+
+
+def measure(args):
+    """-> one result dict per thread count (bench.py embeds them under configs[2])"""
+    results = []
 
     from loongcollector_amd import binding
     from loongcollector_amd.grok import Grok, _lib
@@ -94,12 +101,13 @@ def main():
         wall = time.perf_counter() - t0
         lines = t * args.groups * args.group
         mean_bytes = float(np.mean([gr[2].sum() for gr in groups])) / args.group
-        print(json.dumps({
+        results.append({
             "metric": "Grok lines/s, in-agent shape (%d-line groups through lc_grok_match_host)" % args.group,
             "value": round(lines / wall, 1), "unit": "lines/s", "runner_threads": t, "groups_per_thread": args.groups,
             "ms_per_group": round(wall / args.groups * 1e3, 3), "MBps": round(lines * mean_bytes / wall / 1e6, 2),
             "config": {"workload": "configs[2] corpus in %d-line groups, %d Match entries, host memory in, fields out" % (args.group, len(supported)),
-                       "parity": "group 0 against the oracle, every 10th value"}}), flush=True)
+                       "parity": "group 0 against the oracle, every 10th value"}})
+    return results
 
 
 if __name__ == "__main__":
