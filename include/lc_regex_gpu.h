@@ -264,6 +264,9 @@ int lc_split_lines_device(const uint8_t* d_data, uint64_t nbytes, uint8_t split_
  *       d_packed[k] = [line, offset, length, 2*ngroups capture offsets] for survivor k (order unspecified), at most
  *       packed_cap_rows rows are written; d_counts[0] = lines, [1] = survivors, [2] = lines the parser did not match,
  *       [3] = lines left LC_OVERFLOW / LC_GAVE_UP.  Asynchronous on `stream`. */
+/* nbytes (rounded up to 16) from a PINNED host block (hipHostMalloc, 16-byte aligned) to device memory by a kernel that reads the
+ * block through its PCIe mapping -- not by the copy engine, whose queue the uploads of all runner threads would share. */
+int lc_upload_pinned(const void* pinned_src, void* d_dst, size_t nbytes, void* stream);
 typedef struct lc_span_filter {
     lc_regex_t* re;
     uint32_t group; /* 1-based capture group of the parse regex */

@@ -84,3 +84,10 @@ __global__ __launch_bounds__(kSpanFilterBlock) void span_filter_pack_kernel(
         }
     }
 }
+
+// A read buffer's way up WITHOUT the copy engine: the lanes read the pinned host block through the PCIe mapping (16 bytes each,
+// coalesced) and write it to device memory.  hipMemcpyAsync of every runner thread's buffer goes through the device's SDMA queue,
+// where the trips of all threads line up behind each other; a kernel does not.
+__global__ __launch_bounds__(256) void pinned_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
+}

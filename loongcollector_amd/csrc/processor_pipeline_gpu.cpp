@@ -248,10 +248,12 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
         PIPE_TRY(T.dScratch.ensure(splitScratch));
         std::memcpy(T.hIn.p, sourceVal.data(), nbytes);
         std::memset(static_cast<uint8_t*>(T.hIn.p) + nbytes, 0, 16);
-        PIPE_TRY(hipMemcpyAsync(T.dData.p, T.hIn.p, nbytes + 16, hipMemcpyHostToDevice, T.stream));
-        uint32_t* dCounts = static_cast<uint32_t*>(T.dCounts.p);
-        uint32_t* dNLines = dCounts + 8;
-        int rc = lc_split_lines_device(static_cast<const uint8_t*>(T.dData.p), nbytes, uint8_t(mSplitChar), static_cast<uint32_t*>(T.dOff.p),
+        // no copy engine anywhere in the trip (its queue is shared by all runner threads): a kernel pulls
+        // the buffer out of the pinned staging, and the filter kernel writes counts and survivors straight into pinned memory
+        int rc = lc_upload_pinned(T.hIn.p, T.dData.p, nbytes + 16, T.stream);
+        uint32_t* dNLines = static_cast<uint32_t*>(T.dCounts.p);
+        if (rc == LC_OK)
+            rc = lc_split_lines_device(static_cast<const uint8_t*>(T.dData.p), nbytes, uint8_t(mSplitChar), static_cast<uint32_t*>(T.dOff.p),
                                        maxLines + 2, dNLines, T.dScratch.p, splitScratch, T.stream);
         if (rc == LC_OK)
             rc = lc_regex_match_device_dyn(mParse.mReg, mParse.mEngineChoice, static_cast<const uint8_t*>(T.dData.p),
@@ -259,16 +261,13 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
                                            static_cast<int32_t*>(T.dCaps.p), static_cast<uint8_t*>(T.dStatus.p), T.stream);
         for (int attempt = 0; attempt < 2 && rc == LC_OK; ++attempt) {
             const uint32_t cap = attempt == 0 ? std::min(maxLines, T.survivorGuess) : trips[s].survivors;
-            PIPE_TRY(T.dPacked.ensure(size_t(cap) * rowInts * 4 + 16));
             PIPE_TRY(T.hOut.ensure(64 + size_t(cap) * rowInts * 4));
             rc = lc_span_filter_device(rules.data(), uint32_t(rules.size()), static_cast<const uint8_t*>(T.dData.p),
                                        static_cast<const uint32_t*>(T.dOff.p), 1, dNLines, maxLines, G, static_cast<const int32_t*>(T.dCaps.p),
-                                       static_cast<const uint8_t*>(T.dStatus.p), static_cast<int32_t*>(T.dPacked.p), cap, dCounts, T.stream);
+                                       static_cast<const uint8_t*>(T.dStatus.p),
+                                       reinterpret_cast<int32_t*>(static_cast<uint8_t*>(T.hOut.p) + 64), cap,
+                                       static_cast<uint32_t*>(T.hOut.p), T.stream);
             if (rc != LC_OK) break;
-            PIPE_TRY(hipMemcpyAsync(T.hOut.p, dCounts, 16, hipMemcpyDeviceToHost, T.stream));
-            if (cap)
-                PIPE_TRY(hipMemcpyAsync(static_cast<uint8_t*>(T.hOut.p) + 64, T.dPacked.p, size_t(cap) * rowInts * 4, hipMemcpyDeviceToHost,
-                                        T.stream));
             PIPE_TRY(hipStreamSynchronize(T.stream));
             const uint32_t* c = static_cast<const uint32_t*>(T.hOut.p);
             trips[s].lines = c[0];
