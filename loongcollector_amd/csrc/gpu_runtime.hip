@@ -35,6 +35,7 @@
 #include "sched_kernel.hpp"
 #include "screen_kernel.hpp"
 #include "tdfa_l2_kernel.hpp"
+#include "tdfa_l2_layout.h"
 #include "split_kernel.hpp"
 #include "pipeline_kernel.hpp"
 #include "tdfa_stream_kernel.hpp"
@@ -631,7 +632,15 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         void* dBlob = nullptr;
         rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
         if (rc != LC_OK) return rc;
-        const size_t lds = size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
+        size_t lds = size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
+        // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
+        uint32_t stageBytes = 0;
+        {
+            static const bool stageOff = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
+            const uint32_t progBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_OPSSTART] + 3u) & ~3u;
+            if (!stageOff && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stageBytes = progBytes;
+        }
+        lds += stageBytes;
         static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
         if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > ldsAttrSet[dev]) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -640,7 +649,7 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         noteKernel("tdfa_l2_kernel");
         // (no completion signal of its own: a caller that polls queues lc_signal_kernel behind it, see tlsDone)
         hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
-                           d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status);
+                           d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, stageBytes);
         HIP_TRY(hipGetLastError());
     } else if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {

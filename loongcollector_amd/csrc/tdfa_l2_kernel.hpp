@@ -26,13 +26,21 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
                                                                const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
                                                                uint32_t nGroupsOut, int32_t* __restrict__ caps,
-                                                               uint8_t* __restrict__ status) {
-    extern __shared__ uint32_t regs[];  // [nRegs][64]
+                                                               uint8_t* __restrict__ status, uint32_t stageBytes) {
+    extern __shared__ uint32_t regs[];  // [nRegs][64], then (stageBytes != 0) the register programs: opsStart, ops
     __shared__ uint8_t cmap[256];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < 256; i += kTdfaL2Block) cmap[i] = reinterpret_cast<const uint8_t*>(blob + TL_HEADER_WORDS)[i];
     const uint32_t nRegs = blob[TL_NREGS], ncls = blob[TL_NCLASSES], nSlots = blob[TL_NSLOTS];
     for (uint32_t r = 0; r < nRegs; ++r) regs[r * kTdfaL2Block + tid] = 0xFFFFFFFFu;  // unset = -1
+    // SMALL batches wait for their longest line, and a byte that carries a register program used to cost three more dependent
+    // global reads (opsStart[prog], the list's length, each op) behind the transition's own: with the programs in LDS it is the
+    // transition's read plus LDS latency.  (Large batches keep them in global memory: there the LDS is better spent on waves.)
+    if (stageBytes) {
+        uint32_t* dst = regs + nRegs * kTdfaL2Block;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[TL_OFF_OPSSTART]);
+        for (uint32_t i = tid; i < stageBytes / 4; i += kTdfaL2Block) dst[i] = src[i];
+    }
     __syncthreads();
     if (nLinesPtr) nLines = *nLinesPtr < nLines ? *nLinesPtr : nLines;
     const uint32_t slot = blockIdx.x * kTdfaL2Block + tid;
@@ -40,8 +48,12 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
     const uint32_t line = order ? order[slot] : slot;
     const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
     const uint32_t* trans = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_TRANS]);
-    const uint32_t* opsStart = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
-    const uint16_t* ops = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
+    // (staged: opsStart sits at the start of the staged block, ops behind it at the distance it has in the blob)
+    const uint8_t* staged = reinterpret_cast<const uint8_t*>(regs + nRegs * kTdfaL2Block);
+    const uint32_t* opsStart = stageBytes ? reinterpret_cast<const uint32_t*>(staged)
+                                          : reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
+    const uint16_t* ops = stageBytes ? reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]))
+                                     : reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
     uint32_t state = blob[TL_START], from = 0;
