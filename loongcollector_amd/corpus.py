@@ -124,3 +124,40 @@ def mixed_batch(n_lines, seed=SEED + 3, min_len=128, max_len=2048, json_fraction
     off[1:] = np.cumsum(length.astype(np.uint64) + 1).astype(np.uint32)
     data = np.frombuffer(b"\n".join(chunks) + b"\n", dtype=np.uint8).copy()
     return data, off, length
+
+
+# ---- multi-line logs (Java stack traces): what the multiline processors are configured for in practice
+MULTILINE_START = r"\d{4}-\d{2}-\d{2} \d{2}:\d{2}:\d{2}.*"
+_ML_CLASSES = ["com.example.order.OrderService", "org.springframework.web.servlet.DispatcherServlet", "java.util.concurrent.ThreadPoolExecutor",
+               "io.netty.channel.AbstractChannelHandlerContext", "com.zaxxer.hikari.pool.HikariPool", "org.apache.catalina.core.StandardWrapperValve"]
+
+
+def multiline_buffer(target_bytes, seed=SEED + 17, unmatched_head=0):
+    """-> bytes: logs of one start line ("2024-.. ERROR ...") followed by 0..40 stack-frame lines ("\tat ..."), sometimes a
+    "Caused by:" section; `unmatched_head` frame lines come first (a read buffer that begins inside a log).  Ends with '\n'."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    size = 0
+    for _ in range(unmatched_head):
+        out.append(b"\tat %s.run(%s.java:%d)" % (rng.choice(_ML_CLASSES).encode(), b"Worker", rng.randint(1, 999)))
+        size += len(out[-1]) + 1
+    sec = 0
+    while size < target_bytes:
+        sec += rng.randint(0, 3)
+        head = b"2024-01-%02d %02d:%02d:%02d.%03d %s [%s-%d] %s - %s" % (
+            1 + sec // 86400 % 28, sec // 3600 % 24, sec // 60 % 60, sec % 60, rng.randint(0, 999),
+            rng.choice([b"ERROR", b"WARN", b"INFO"]), rng.choice([b"http-nio-8080-exec", b"pool-1-thread", b"main"]), rng.randint(1, 64),
+            rng.choice(_ML_CLASSES).encode(), b"request %d failed: timeout after %d ms" % (rng.randint(1, 10 ** 6), rng.randint(10, 30000)))
+        out.append(head)
+        size += len(head) + 1
+        frames = int(rng.choice([0, 0, 1, 3, 8, 15, 25, 40]) * rng.random())
+        for k in range(frames):
+            if k and rng.random() < 0.05:
+                ln = b"Caused by: java.lang.IllegalStateException: " + rng.choice(_ML_CLASSES).encode()
+            else:
+                ln = b"\tat %s.%s(%s.java:%d)" % (rng.choice(_ML_CLASSES).encode(), rng.choice([b"invoke", b"run", b"doFilter", b"process"]),
+                                                   rng.choice([b"Service", b"Filter", b"Handler"]), rng.randint(1, 2000))
+            out.append(ln)
+            size += len(ln) + 1
+    return b"\n".join(out) + b"\n"

@@ -1360,6 +1360,7 @@ extern "C" void lc_thread_release(void) {
     for (auto& pool : tlsDecidePools) pool.release();
     lcGrokThreadRelease();
     lcPipelineThreadRelease();
+    lcMultilineThreadRelease();
 }
 
 extern "C" void lc_nfa_set_dfs(int on) { gNfaDfsMode.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }

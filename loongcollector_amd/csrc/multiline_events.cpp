@@ -21,6 +21,7 @@
 #include "json_min.hpp"
 #include "regex_handle.hpp"
 #include "multiline_gpu.hpp"
+#include "multiline_scan.hpp"
 #ifdef LC_USE_REFERENCE_HEADERS
 #include "models/LogEvent.h"
 #include "models/PipelineEventGroup.h"
@@ -207,13 +208,6 @@ void mergeEvents(lc_merge_multiline& p, std::vector<LogEvent*>& logEvents, bool 
     logEvents.clear();
 }
 
-// HandleUnmatchLogs :360-392 (without the alarms)
-void handleUnmatch(lc_merge_multiline& p, std::vector<PipelineEventPtr>& logEvents, size_t& newSize, size_t begin, size_t end) {
-    p.unmatchedEventsTotal += end - begin + 1;
-    if (p.ml->discardUnmatched) return;
-    for (size_t i = begin; i <= end; ++i) logEvents[newSize++] = std::move(logEvents[i]);
-}
-
 void mergeLogsByFlag(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // :113-159
     auto& sourceEvents = logGroup.MutableEvents();
     size_t size = 0;
@@ -256,127 +250,73 @@ void mergeLogsByFlag(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
 
 int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // :161-330
     auto& sourceEvents = logGroup.MutableEvents();
-    const lc_multiline& ml = *p.ml;
-    const bool hasStart = ml.start, hasCont = ml.cont, hasEnd = ml.end;
+    lc_multiline& ml = *p.ml;
     const StringView key(p.sourceKey.data(), p.sourceKey.size());
-    // the device pass: the flags of every event the loop below can reach (it stops for good at the first event that is not a
-    // log event or lacks the source key)
+    // the ITEMS of the walk: the non-empty log events that carry the source key, up to the first event the reference's loop stops
+    // at for good (not a log event :180-188, or without the key :193-216)
     std::vector<const uint8_t*> ptrs;
-    std::vector<uint32_t> lens;
-    std::vector<int32_t> flagIndex(sourceEvents.size(), -1);
+    std::vector<uint32_t> lens, itemEvent;
+    size_t stopAt = sourceEvents.size();
     for (size_t i = 0; i < sourceEvents.size(); ++i) {
-        if (!sourceEvents[i].Is<LogEvent>()) break;
+        if (!sourceEvents[i].Is<LogEvent>()) {
+            stopAt = i;
+            break;
+        }
         const LogEvent& ev = sourceEvents[i].Cast<LogEvent>();
         if (ev.Empty()) continue;
-        if (!ev.HasContent(key)) break;
+        if (!ev.HasContent(key)) {
+            stopAt = i;
+            break;
+        }
         const StringView v = ev.GetContent(key);
-        flagIndex[i] = int32_t(ptrs.size());
+        itemEvent.push_back(uint32_t(i));
         ptrs.push_back(reinterpret_cast<const uint8_t*>(v.data()));
         lens.push_back(uint32_t(v.size()));
     }
+    const bool truncated = stopAt < sourceEvents.size();
     const uint32_t n = uint32_t(ptrs.size());
-    std::vector<uint8_t> fStart(n, 0), fCont(n, 0), fEnd(n, 0);
-    auto flags = [&](lc_regex_t* re, std::vector<uint8_t>& dst) -> int {
-        if (!re || n == 0) return LC_OK;
-        const int r = lc_regex_match_host_views(re, ptrs.data(), lens.data(), n, 0, nullptr, dst.data());
-        if (r != LC_OK) return r;
-        uint64_t gaveUp = 0;
-        for (uint8_t st : dst) {
-            if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;
-            gaveUp += st == LC_GAVE_UP;  // BoostRegexSearch failed with an exception (StringTools.cpp:277-282): false, and counted
-        }
-        if (gaveUp) lcNoteGaveUp(gaveUp);  // "not decided" must not drive the state machine as "no match"
-        return LC_OK;
-    };
-    int rc;
-    if ((rc = flags(ml.start, fStart)) != LC_OK || (rc = flags(ml.cont, fCont)) != LC_OK || (rc = flags(ml.end, fEnd)) != LC_OK)
-        return rc;
-    auto isStart = [&](size_t cur) { return fStart[size_t(flagIndex[cur])] == LC_MATCH; };
-    auto isCont = [&](size_t cur) { return fCont[size_t(flagIndex[cur])] == LC_MATCH; };
-    auto isEnd = [&](size_t cur) { return fEnd[size_t(flagIndex[cur])] == LC_MATCH; };
+    // ONE device trip: the values go up once, a status-only launch per pattern, the walk as a scan over the flags
+    // (multiline_scan.hpp); records = item ranges, in the order the reference emits them.  UnmatchedContentTreatment is applied
+    // here: HandleUnmatchLogs counts EVENTS (:360-392), the empty ones between two items included, and those are no items.
+    std::vector<lc_ml_record_t> recs;
+    uint32_t counts[ML_CNT_WORDS];
+    const bool discard = ml.discardUnmatched;
+    ml.discardUnmatched = false;
+    const int rc = lcMultilineViewsTrip(&ml, ptrs.data(), lens.data(), n, !truncated, recs, counts);
+    ml.discardUnmatched = discard;
+    if (rc != LC_OK) return rc;
 
-    size_t begin = 0, newSize = 0;
+    size_t newSize = 0, prevEvent = 0;
     std::vector<LogEvent*> events;
-    bool isPartialLog = false;
-    if (!hasStart && !hasCont && hasEnd) isPartialLog = true;  // only an end pattern: it sticks to this state (:174-178)
-    for (size_t cur = 0; cur < sourceEvents.size(); ++cur) {
-        if (!sourceEvents[cur].Is<LogEvent>()) {  // :180-188
-            if (events.empty()) begin = cur;
-            for (size_t i = begin; i < sourceEvents.size(); ++i) sourceEvents[newSize++] = std::move(sourceEvents[i]);
-            sourceEvents.resize(newSize);
-            return LC_OK;
-        }
-        LogEvent* sourceEvent = &sourceEvents[cur].Cast<LogEvent>();
-        if (sourceEvent->Empty()) continue;
-        if (!sourceEvent->HasContent(key)) {  // :193-216
-            if (events.empty()) begin = cur;
-            for (size_t i = begin; i < sourceEvents.size(); ++i) sourceEvents[newSize++] = std::move(sourceEvents[i]);
-            sourceEvents.resize(newSize);
-            return LC_OK;
-        }
-        if (!isPartialLog) {
-            if (hasStart ? isStart(cur) : isCont(cur)) {  // :219-230
-                events.emplace_back(sourceEvent);
-                begin = cur;
-                isPartialLog = true;
-            } else if (hasEnd && !hasStart && hasCont && isEnd(cur)) {  // continue + end: matched against the end pattern (:231-239)
-                begin = cur;
-                p.mergedEventsTotal += 1;
-                sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-            } else {
-                handleUnmatch(p, sourceEvents, newSize, cur, cur);
-            }
-        } else {
-            if (hasCont && isCont(cur)) {  // :244-249
-                events.emplace_back(sourceEvent);
-                continue;
-            }
-            if (hasEnd) {
-                events.emplace_back(sourceEvent);  // start + end, continue + end, or end (:250-252)
-                if (hasCont) {
-                    if (isEnd(cur)) {
-                        mergeEvents(p, events, true);
-                        sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-                    } else {
-                        handleUnmatch(p, sourceEvents, newSize, begin, cur);
-                        events.clear();
-                    }
-                    isPartialLog = false;
-                } else if (isEnd(cur)) {  // :266-280
-                    mergeEvents(p, events, true);
-                    sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-                    if (hasStart) isPartialLog = false;
-                    else begin = cur + 1;  // only an end pattern: the next log starts by itself
-                }
-            } else if (!hasCont) {  // start only (:283-294)
-                if (!isStart(cur)) {
-                    events.emplace_back(sourceEvent);
-                } else {
-                    mergeEvents(p, events, true);
-                    sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-                    begin = cur;
-                    events.emplace_back(sourceEvent);
-                }
-            } else {  // start + continue, and the line is no continuation (:295-311)
-                mergeEvents(p, events, true);
-                sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-                if (!isStart(cur)) {
-                    handleUnmatch(p, sourceEvents, newSize, cur, cur);
-                    isPartialLog = false;
-                } else {
-                    begin = cur;
-                    events.emplace_back(sourceEvent);
-                }
-            }
-        }
-    }
-    if (isPartialLog && begin < sourceEvents.size()) {  // :316-323
-        if (!hasEnd) {
+    auto handleUnmatch = [&](size_t b, size_t e) {  // HandleUnmatchLogs :360-392 (without the alarms)
+        p.unmatchedEventsTotal += e - b + 1;
+        if (!discard)
+            for (size_t i = b; i <= e; ++i) sourceEvents[newSize++] = std::move(sourceEvents[i]);
+    };
+    for (size_t r = 0; r < recs.size(); ++r) {
+        const uint32_t first = recs[r].begin, cnt = recs[r].length;
+        if (recs[r].matched & 1u) {  // MergeEvents :332-358 + the move of the log's first event
+            events.clear();
+            for (uint32_t k = first; k < first + cnt; ++k) events.push_back(&sourceEvents[itemEvent[k]].Cast<LogEvent>());
             mergeEvents(p, events, true);
-            sourceEvents[newSize++] = std::move(sourceEvents[begin]);
-        } else {
-            handleUnmatch(p, sourceEvents, newSize, begin, sourceEvents.size() - 1);
+            sourceEvents[newSize++] = std::move(sourceEvents[itemEvent[first]]);
+            continue;
         }
+        size_t b = itemEvent[first], e = b;
+        if (recs[r].matched & LC_ML_RUN) b = prevEvent + 1;  // one [begin, cur] call: the empty events in between go with it
+        if ((recs[r].matched & LC_ML_LAST) && r + 1 == recs.size()) e = sourceEvents.size() - 1;  // the flush runs to the group's end (:321)
+        handleUnmatch(b, e);
+        prevEvent = e;
+    }
+    if (truncated) {  // the rest passes through, from the log under construction on (`if (events.empty()) begin = cur`)
+        const bool open = counts[ML_CNT_FINAL_PARTIAL] && counts[ML_CNT_FINAL_START] < n;
+        for (size_t i = open ? itemEvent[counts[ML_CNT_FINAL_START]] : stopAt; i < sourceEvents.size(); ++i)
+            sourceEvents[newSize++] = std::move(sourceEvents[i]);
+    } else if (counts[ML_CNT_FINAL_PARTIAL] && counts[ML_CNT_FINAL_START] >= n) {
+        // only an end pattern, and the last item closed a log (begin = cur + 1): events behind it -- empty ones -- are what
+        // `begin < sourceEvents.size()` (:316) still hands to HandleUnmatchLogs
+        const size_t b = n ? size_t(itemEvent[n - 1]) + 1 : 0;
+        if (b < sourceEvents.size()) handleUnmatch(b, sourceEvents.size() - 1);
     }
     sourceEvents.resize(newSize);
     return LC_OK;

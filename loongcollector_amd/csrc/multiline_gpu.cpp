@@ -27,6 +27,7 @@ bool endsWith(const std::string& s, const char* suffix) {
 }  // namespace
 
 #include "multiline_gpu.hpp"
+#include "multiline_scan.hpp"
 
 // MultilineOptions::ParseRegex :250-266 strips a trailing '$' and trailing ".*"s -- but only to decide validity and
 // IsMultiline().  The PROCESSOR compiles the pattern strings as written (ProcessorSplitMultilineLogStringNative.cpp:66-76,
@@ -124,123 +125,16 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
     if (!m || !records || !nrecords || (nbytes && !data)) return LC_ERR_ARG;
     *records = nullptr;
     *nrecords = 0;
-    uint32_t inputLines = 0, unmatchLines = 0, matchedEvents = 0;
-    // GetNextLine :382-392: lines are separated by '\n'; a trailing '\n' does not open an empty last line
-    std::vector<uint32_t> off, len;
-    for (uint32_t b = 0; b < nbytes;) {
-        uint32_t e = b;
-        while (e < nbytes && data[e] != '\n') ++e;
-        off.push_back(b);
-        len.push_back(e - b);
-        b = e + 1;
-    }
-    const uint32_t n = uint32_t(off.size());
-    std::vector<uint8_t> fStart(n, 0), fCont(n, 0), fEnd(n, 0);
-    auto flags = [&](lc_regex_t* re, std::vector<uint8_t>& dst) -> int {
-        if (!re || n == 0) return LC_OK;
-        const int r = lc_regex_match_host(re, data, off.data(), len.data(), n, 0, nullptr, dst.data());
-        if (r != LC_OK) return r;
-        // "not decided" (decide pass switched off) must not drive the state machine as "no match"
-        uint64_t gaveUp = 0;
-        for (uint8_t st : dst) {
-            if (st == LC_OVERFLOW) return LC_ERR_UNSUPPORTED;
-            gaveUp += st == LC_GAVE_UP;  // BoostRegexSearch failed with an exception (StringTools.cpp:277-282): false, and counted
-        }
-        if (gaveUp) lcNoteGaveUp(gaveUp);
-        return LC_OK;
-    };
-    int rc;
-    if ((rc = flags(m->start, fStart)) != LC_OK || (rc = flags(m->cont, fCont)) != LC_OK ||
-        (rc = flags(m->end, fEnd)) != LC_OK)
-        return rc;
-
+    // one device trip: upload, split, a status-only launch per pattern, the record scan (multiline_device.hip); what comes back
+    // is what ProcessEvent :161-298 + HandleUnmatchLogs :341-380 would have emitted, in their order
     std::vector<lc_ml_record_t> out;
-    const bool hasStart = m->start, hasCont = m->cont, hasEnd = m->end;
-    // `last`: the isLastLog argument the reference passes to CreateNewEvent -- that of the line BEING PROCESSED when the
-    // record is emitted (it decides the record's position length, :327-329), true for the flush after the loop
-    bool last = false;
-    auto createNewEvent = [&](int64_t b, int64_t e) {  // [b, e) of the source value
-        out.push_back({uint32_t(b), uint32_t(e > b ? e - b : 0), 1u | (last ? LC_ML_LAST : 0u)});
-    };
-    auto handleUnmatch = [&](int64_t b, int64_t e) {   // HandleUnmatchLogs :341-380: line by line
-        for (int64_t p = b; p < e;) {
-            int64_t q = p;
-            while (q < e && data[q] != '\n') ++q;
-            ++unmatchLines;
-            if (!m->discardUnmatched) out.push_back({uint32_t(p), uint32_t(q - p), last ? LC_ML_LAST : 0u});
-            p = q + 1;
-        }
-    };
-    int64_t multiStart = -1;
-    bool isPartialLog = false;
-    if (!hasStart && !hasCont && hasEnd) {  // only an end pattern: it sticks to this state (:161-165)
-        isPartialLog = true;
-        multiStart = 0;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        const int64_t cb = off[i], ce = int64_t(off[i]) + len[i];
-        last = ce == int64_t(nbytes);  // isLastLog :174
-        ++inputLines;
-        if (!isPartialLog) {
-            const bool first = hasStart ? fStart[i] == LC_MATCH : fCont[i] == LC_MATCH;   // :176-184
-            if (first) {
-                multiStart = cb;
-                isPartialLog = true;
-            } else if (hasEnd && !hasStart && hasCont && fEnd[i] == LC_MATCH) {            // continue + end (:187-192)
-                createNewEvent(cb, ce);
-                multiStart = ce + 1;
-                ++matchedEvents;
-            } else {
-                handleUnmatch(cb, ce);
-            }
-        } else {
-            if (hasCont && fCont[i] == LC_MATCH) continue;                                // :199-203
-            if (hasEnd) {
-                if (hasCont) {                                                            // :206-228
-                    if (fEnd[i] == LC_MATCH) {
-                        createNewEvent(multiStart, ce);
-                        ++matchedEvents;
-                    } else {
-                        handleUnmatch(multiStart, ce);
-                    }
-                    isPartialLog = false;
-                } else if (fEnd[i] == LC_MATCH) {                                          // start + end, or end (:229-246)
-                    createNewEvent(multiStart, ce);
-                    if (hasStart) isPartialLog = false;
-                    else multiStart = ce + 1;
-                    ++matchedEvents;
-                }
-            } else if (!hasCont) {                                                         // start only (:250-260)
-                if (fStart[i] == LC_MATCH) {
-                    createNewEvent(multiStart, cb - 1);
-                    multiStart = cb;
-                    ++matchedEvents;
-                }
-            } else {                                                                       // start + continue (:261-282)
-                createNewEvent(multiStart, cb - 1);
-                ++matchedEvents;
-                if (fStart[i] != LC_MATCH) {
-                    handleUnmatch(cb, ce);
-                    isPartialLog = false;
-                } else {
-                    multiStart = cb;
-                }
-            }
-        }
-    }
-    last = true;
-    if (isPartialLog && multiStart < int64_t(nbytes)) {                                    // :288-298
-        if (!hasEnd) {
-            createNewEvent(multiStart, nbytes);
-            ++matchedEvents;
-        } else {
-            handleUnmatch(multiStart, nbytes);
-        }
-    }
+    uint32_t counts[ML_CNT_WORDS];
+    const int rc = lcMultilineSplitTrip(m, data, nbytes, out, counts);
+    if (rc != LC_OK) return rc;
     if (counters) {
-        counters[0] = inputLines;
-        counters[1] = unmatchLines;
-        counters[2] = matchedEvents;
+        counters[0] = counts[ML_CNT_ITEMS];
+        counters[1] = counts[ML_CNT_UNMATCHED];
+        counters[2] = counts[ML_CNT_MATCHED_LOGS];
     }
     *nrecords = uint32_t(out.size());
     if (!out.empty()) {
@@ -248,6 +142,46 @@ extern "C" int lc_multiline_split_host(lc_multiline_t* m, const uint8_t* data, u
         if (!*records) return LC_ERR_ARG;
         std::memcpy(*records, out.data(), out.size() * sizeof(lc_ml_record_t));
     }
+    return LC_OK;
+}
+
+// The kernel's four phases with the threads run one after the other (multiline_scan.hpp is the code of both).
+namespace {
+struct MlHostWriter {
+    lc_ml_record_t* records;
+    uint32_t recCap;
+    const uint32_t* off;
+    uint32_t n, nbytes, lastItemIsLast;
+    std::vector<MlJob>* jobs;
+    void record(uint32_t slot, uint32_t first, uint32_t last, uint32_t matched, uint32_t emitter) const {
+        if (slot >= recCap) return;
+        const uint32_t fl = matched | ((emitter >= n || (emitter + 1 == n && lastItemIsLast)) ? LC_ML_LAST : 0u);
+        if (off) records[slot] = lc_ml_record_t{off[first], (matched & 1u) && emitter >= n ? nbytes - off[first] : off[last + 1] - 1u - off[first], fl};
+        else records[slot] = lc_ml_record_t{first, last - first + 1u, fl};
+    }
+    void job(const MlJob& j) const { jobs->push_back(j); }
+};
+}  // namespace
+extern "C" int lc_multiline_bounds_model(uint32_t mode, const uint8_t* flags, uint32_t n, const uint32_t* off, uint32_t nbytes,
+                                         lc_ml_record_t* records, uint32_t record_cap, uint32_t counts[LC_ML_CNT_WORDS]) {
+    if (!counts || (n && !flags) || (record_cap && !records)) return LC_ERR_ARG;
+    static_assert(LC_ML_RUN == ML_REC_RUN, "header and scan agree");
+    static_assert(int(LC_ML_CNT_WORDS) == int(ML_CNT_WORDS) && LC_ML_FLUSH == ML_FLUSH && LC_ML_DISCARD == ML_DISCARD, "header and scan agree");
+    std::memset(counts, 0, ML_CNT_WORDS * 4);
+    const uint32_t slices = mlSliceCount(n);
+    std::vector<MlSummary> summaries(2 * size_t(slices) + 2);
+    std::vector<MlEntry> entries(size_t(slices) + 1);
+    for (uint32_t t = 0; t < slices; ++t) mlPhaseA(t, n, mode, flags, &summaries[2 * size_t(t)]);
+    MlJob flush{};
+    uint32_t flushMatchedFirst = kMlInherit;
+    mlPhaseB(n, mode, summaries.data(), entries.data(), counts, flush, flushMatchedFirst);
+    std::vector<MlJob> jobs;
+    if (flush.first != kMlInherit) jobs.push_back(flush);
+    MlHostWriter w{records, record_cap, off, n, nbytes, (off && n && off[n] == nbytes + 1u) ? 1u : 0u, &jobs};
+    for (uint32_t t = 0; t < slices; ++t) mlPhaseC(t, n, mode, flags, entries[t], w);
+    if (flushMatchedFirst != kMlInherit) w.record(flush.recBase, flushMatchedFirst, n - 1, 1u, n);
+    for (const MlJob& job : jobs)
+        for (uint32_t k = job.first; k <= job.last; ++k) w.record(job.recBase + (k - job.first), k, k, k > job.first ? ML_REC_RUN : 0u, job.emitter);
     return LC_OK;
 }
 extern "C" void lc_multiline_free_records(lc_ml_record_t* r) { std::free(r); }

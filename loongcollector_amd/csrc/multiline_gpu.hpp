@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/lc_multiline.h"
 #include "../../include/lc_regex_gpu.h"
@@ -24,3 +25,10 @@ struct lc_multiline {
         lc_regex_free(end);
     }
 };
+
+// multiline_device.hip -- the device trips (one upload, one synchronisation); counts: ML_CNT_* of multiline_scan.hpp
+int lcMultilineSplitTrip(lc_multiline* m, const uint8_t* data, uint32_t nbytes, std::vector<lc_ml_record_t>& out, uint32_t counts[8]);
+// records carry ITEM indices (begin = first item, length = number of items); flush = false leaves the log under construction open
+// and reports it in counts[ML_CNT_FINAL_PARTIAL] / counts[ML_CNT_FINAL_START]
+int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint32_t* lens, uint32_t n, bool flush,
+                         std::vector<lc_ml_record_t>& out, uint32_t counts[8]);

@@ -77,6 +77,18 @@ class Multiline:
             self._L.lc_multiline_free_records(recs)
 
 
+    def split_raw(self, value: bytes):
+        """-> records [(begin, length, flag word)] with the LC_ML_LAST / LC_ML_RUN bits"""
+        recs = ctypes.POINTER(_Record)()
+        n = ctypes.c_uint32()
+        counters = (ctypes.c_uint32 * 3)()
+        rc = self._L.lc_multiline_split_host(self._h, value, len(value), ctypes.byref(recs), ctypes.byref(n), counters)
+        binding._check(rc, "lc_multiline_split_host")
+        try:
+            return [(recs[i].begin, recs[i].length, recs[i].matched) for i in range(n.value)]
+        finally:
+            self._L.lc_multiline_free_records(recs)
+
     def process(self, group):
         """ProcessorSplitMultilineLogStringNative::Process on an EventGroup (loongcollector_amd.processor.EventGroup)."""
         from .processor import _lib
@@ -121,3 +133,28 @@ class MergeMultiline:
         c = (ctypes.c_uint64 * 2)()
         self._L.lc_merge_multiline_counters(self._h, c)
         return tuple(int(x) for x in c)
+
+
+ML_HAS_START, ML_HAS_CONT, ML_HAS_END, ML_DISCARD, ML_FLUSH = 1, 2, 4, 8, 16
+ML_LAST, ML_RUN = 0x80000000, 2
+
+
+def bounds_model(mode, flags, off=None, nbytes=0):
+    """lc_multiline_bounds_model: the device scan's code run on the host, slice by slice.  flags: one byte per item (bit 0 start,
+    bit 1 continue, bit 2 end matched); off: the offsets[n+1] + separator table (byte records) or None (item records).
+    -> (records [(begin, length, flags)], counts[8])"""
+    import numpy as np
+    L = binding.load()
+    L.lc_multiline_bounds_model.restype = ctypes.c_int
+    L.lc_multiline_bounds_model.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                            ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    fl = np.ascontiguousarray(np.asarray(flags, dtype=np.uint8))
+    n = int(fl.size)
+    cap = n + 2
+    recs = np.zeros((cap, 3), dtype=np.uint32)
+    counts = np.zeros(8, dtype=np.uint32)
+    o = None if off is None else np.ascontiguousarray(np.asarray(off, dtype=np.uint32))
+    rc = L.lc_multiline_bounds_model(mode, fl.ctypes.data if n else None, n, None if o is None else o.ctypes.data, nbytes,
+                                     recs.ctypes.data, cap, counts.ctypes.data)
+    binding._check(rc, "lc_multiline_bounds_model")
+    return [tuple(int(x) for x in r) for r in recs[:int(counts[3])]], [int(x) for x in counts]

@@ -230,3 +230,165 @@ def test_merge_processor_flag_mode():
         MergeMultiline(MergeType="nope")
     with pytest.raises(MultilineInitError):
         MergeMultiline()
+
+
+# ---------------------------------------------------------------------------------------------- the record scan (CPU model of the kernel)
+from loongcollector_amd import multiline as ML  # noqa: E402
+
+
+def _flags_and_table(o, val):
+    """what the device computes before the scan: the split kernels' line table and the three answers per line (here: the oracle's
+    regexes, line by line)"""
+    lines = val.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()          # a trailing line feed does not open an empty last line (GetNextLine :382-392)
+    off, at = [], 0
+    for ln in lines:
+        off.append(at)
+        at += len(ln) + 1
+    off.append(at)           # len[i] = off[i+1] - off[i] - 1, also for an unterminated last line
+    hit = lambda rx, ln: 1 if (rx is not None and rx.prefixmatch(ln) is not None) else 0
+    flags = [hit(o.start, ln) | hit(o.cont, ln) << 1 | hit(o.end, ln) << 2 | (8 if not ln else 0) for ln in lines]
+    mode = (ML.ML_HAS_START if o.start else 0) | (ML.ML_HAS_CONT if o.cont else 0) | (ML.ML_HAS_END if o.end else 0) | \
+        (ML.ML_DISCARD if o.discard else 0) | ML.ML_FLUSH
+    return mode, flags, off
+
+
+def _scan_equals_the_walk(config, val):
+    o = MultilineOracle(**config)
+    mode, flags, off = _flags_and_table(o, val)
+    recs, counts = ML.bounds_model(mode, flags, off, len(val))
+    exp_recs, exp_counters = o.split(val)
+    assert [(b, l, f & 1) for b, l, f in recs] == exp_recs, (config, val)
+    assert tuple(counts[:3]) == exp_counters, (config, val)
+    # the same scan with item records: the same ranges, named by item
+    if b"\n\n" in b"\n" + val + b"\n":
+        return recs          # (an empty line at the end of an unmatched run is a line-splitter rule, not one of the event walk)
+    items, _ = ML.bounds_model(mode, flags)
+    assert [(off[b], exp_recs[k][1] if (f & ML.ML_LAST and f & 1 and k == len(items) - 1) else off[b + c] - 1 - off[b], f & 1)
+            for k, (b, c, f) in enumerate(items)] == exp_recs
+    return recs
+
+
+def test_scan_model_reproduces_the_reference_unit_test_cases(vectors):
+    for c in vectors["cases"]:
+        _scan_equals_the_walk(c["config"], _value(vectors, c["in"]))
+
+
+SCAN_CONFIGS = [
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*"},
+    {"StartPattern": r"\[\w+\]", "ContinuePattern": r"\s+at\s.*", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": r"\[\w+\]", "ContinuePattern": r"\s+at\s.*"},
+    {"StartPattern": "BEGIN", "EndPattern": r"END\d*$"},
+    {"StartPattern": "BEGIN", "EndPattern": r"END\d*$", "UnmatchedContentTreatment": "discard"},
+    {"ContinuePattern": r"\s+.*", "EndPattern": r"\}"},
+    {"ContinuePattern": r"\s+.*", "EndPattern": r"\}", "UnmatchedContentTreatment": "discard"},
+    {"EndPattern": ";$", "UnmatchedContentTreatment": "discard"},
+    {"EndPattern": ";$"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}$"},
+    {"StartPattern": ".*"},
+]
+POOL = [b"2024-01-04 boom", b"  at com.example.A.b(A.java:1)", b"[ERROR] x", b"BEGIN tx", b"END7", b"END", b"END7x", b"}x", b"}", b"{",
+        b"stmt;", b"noise", b"", b"\tcontinued", b"2024-13-99 not checked"]
+
+
+@pytest.mark.parametrize("config", SCAN_CONFIGS)
+def test_scan_model_on_random_buffers_of_many_slices(config):
+    """buffers long enough for many slices (16 items each at least), with runs that cross slice borders: long continuations, long
+    unmatched runs handed to HandleUnmatchLogs in one call, logs that never end (the flush)"""
+    rng = random.Random(1234)
+    for trial in range(120):
+        n = rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 100, 700, 5000]) if trial < 60 else rng.randint(0, 400)
+        bias = rng.choice([None, 1, 11, 13, 12])           # some buffers are dominated by one kind of line
+        val = b"\n".join(POOL[bias] if bias is not None and rng.random() < 0.9 else rng.choice(POOL) for _ in range(n))
+        if rng.random() < 0.3:
+            val += b"\n"
+        _scan_equals_the_walk(config, val)
+
+
+def test_scan_model_empty_lines_at_the_end_of_unmatched_ranges():
+    """HandleUnmatchLogs' loop (:350) stops before an empty LAST line of the range it is handed; the flush hands over the rest of
+    the value, where an empty last line still has its line feed behind it"""
+    for val in (b"BEGIN\n\n", b"BEGIN\nx\n\n", b"BEGIN\n", b"a\n\n", b"\n", b"\n\n", b"a\n\nb", b" a\n\nEND\n\n\n"):
+        for cfg in ({"StartPattern": "BEGIN", "EndPattern": "END"}, {"EndPattern": "END"}, {"StartPattern": "BEGIN"},
+                    {"ContinuePattern": r"\s+.*", "EndPattern": "END"}, {"StartPattern": "BEGIN", "ContinuePattern": r"\s+.*"}):
+            _scan_equals_the_walk(cfg, val)
+
+
+def test_scan_model_marks_last_and_runs():
+    # continue + end: a log that fails its end pattern goes to HandleUnmatchLogs as ONE run; the flush marks LAST
+    o = {"ContinuePattern": r"\s+.*", "EndPattern": r"\}"}
+    val = b" a\n b\nnoise\n c\n d"
+    recs = _scan_equals_the_walk(o, val)
+    assert [(f >> 1) & 1 for _, _, f in recs] == [0, 1, 1, 0, 1]           # [" a", " b", "noise"] one run, [" c", " d"] the flush
+    assert [bool(f & ML.ML_LAST) for _, _, f in recs] == [False, False, False, True, True]
+    # start only: the record emitted while the LAST line is processed carries isLastLog (:174, :327-329), and so does the flush
+    recs = _scan_equals_the_walk({"StartPattern": "S"}, b"S1\nx\nS2")
+    assert [bool(f & ML.ML_LAST) for _, _, f in recs] == [True, True]
+    recs = _scan_equals_the_walk({"StartPattern": "S"}, b"S1\nx\nS2\n")
+    assert [bool(f & ML.ML_LAST) for _, _, f in recs] == [False, True]
+
+
+# ---------------------------------------------------------------------------------------------- the device scan at size
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", SCAN_CONFIGS)
+def test_device_trip_on_buffers_of_many_slices(config):
+    """the whole trip (upload, split kernels, status launches, flags, scan) on buffers of up to 5000 lines: many slices, runs that
+    cross slice borders, the flush; records, LAST / RUN bits and counters equal the oracle's walk and the scan's host model"""
+    rng = random.Random(77)
+    o = MultilineOracle(**config)
+    m = Multiline(**config)
+    for trial in range(30):
+        n = rng.choice([1, 16, 17, 33, 100, 700, 2500, 5000])
+        bias = rng.choice([None, 1, 11, 13, 12])
+        val = b"\n".join(POOL[bias] if bias is not None and rng.random() < 0.9 else rng.choice(POOL) for _ in range(n))
+        if rng.random() < 0.3:
+            val += b"\n"
+        assert m.split(val) == o.split(val), (config, n, bias)
+        mode, flags, off = _flags_and_table(o, val)
+        model, _ = ML.bounds_model(mode, flags, off, len(val))
+        assert m.split_raw(val) == model, (config, n, bias)
+
+
+@pytest.mark.gpu
+def test_device_trip_on_a_stack_trace_corpus():
+    from loongcollector_amd import corpus
+    for head in (0, 7):
+        val = corpus.multiline_buffer(512 << 10, unmatched_head=head)
+        cfg = {"StartPattern": corpus.MULTILINE_START}
+        recs, counters = Multiline(**cfg).split(val)
+        assert (recs, counters) == MultilineOracle(**cfg).split(val)
+        assert counters[1] == head and counters[2] > 500
+        assert all(recs[k + 1][0] == recs[k][0] + recs[k][1] + 1 for k in range(len(recs) - 1))  # the records tile the buffer
+        assert recs[0][0] == 0 and recs[-1][0] + recs[-1][1] == len(val)                          # (the flush keeps the last line feed)
+
+
+@pytest.mark.gpu
+def test_merge_processor_counts_empty_events_like_the_reference():
+    """HandleUnmatchLogs of the merge processor counts and moves EVENTS [begin, cur] (:360-392): events without any content, which the
+    walk skips (:190), are inside such a range when a log fails its end pattern, and behind the last item at the flush"""
+    from loongcollector_amd.multiline import MergeMultiline
+    from loongcollector_amd.processor import EventGroup
+
+    def ev(text, ts):
+        return {"contents": [["content", text]] if text is not None else [], "timestamp": ts, "type": 1}
+
+    # continue + end: " a", (empty), " b", "x" -- "x" is neither continuation nor end: the three events before it and "x" go to
+    # HandleUnmatchLogs as ONE range of 4 events
+    g = EventGroup({"events": [ev(" a", 1), ev(None, 2), ev(" b", 3), ev("x", 4), ev(" c", 5), ev(None, 6)]})
+    p = MergeMultiline(MergeType="regex", ContinuePattern=r"\s+.*", EndPattern="END")
+    p.process(g)
+    assert [e.get("timestamp") for e in g.to_dict()["events"]] == [1, 2, 3, 4, 5, 6]
+    assert p.counters() == (0, 6)   # [1..4] one call, then the flush [5..6] with the empty event behind the last item
+    # discard: the same events are counted and dropped
+    g = EventGroup({"events": [ev(" a", 1), ev(None, 2), ev(" b", 3), ev("x", 4), ev(" c", 5), ev(None, 6)]})
+    p = MergeMultiline(MergeType="regex", ContinuePattern=r"\s+.*", EndPattern="END", UnmatchedContentTreatment="discard")
+    p.process(g)
+    assert g.to_json() == "null" or not g.to_dict().get("events")
+    assert p.counters() == (0, 6)
+    # only an end pattern: the last item closes a log, empty events behind it still reach HandleUnmatchLogs (:316)
+    g = EventGroup({"events": [ev("END", 1), ev(None, 2)]})
+    p = MergeMultiline(MergeType="regex", EndPattern="END")
+    p.process(g)
+    assert [e["timestamp"] for e in g.to_dict()["events"]] == [1, 2]
+    assert p.counters() == (1, 1)
