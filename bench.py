@@ -181,6 +181,118 @@ def measure_pipeline(thread_counts, buffer_bytes=512 << 10, n_buffers=64):
     return out
 
 
+def _run_threads(threads, per_thread, make_work, do_work):
+    """t runner threads, each with its own work items (the first is its warm-up: staging and stream are allocated there)
+    -> seconds for per_thread items per thread"""
+    import concurrent.futures
+    import threading
+    gate = threading.Barrier(threads + 1)
+    ends = [0.0] * threads
+
+    def run(tid):
+        mine = [make_work(tid, k) for k in range(per_thread + 1)]
+        do_work(tid, mine[0])
+        gate.wait()
+        for w in mine[1:]:
+            do_work(tid, w)
+        ends[tid] = time.perf_counter()
+
+    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+        futs = [ex.submit(run, tid) for tid in range(threads)]
+        gate.wait()
+        t0 = time.perf_counter()
+        for f in futs:
+            f.result()
+    return max(ends) - t0
+
+
+def measure_multiline(thread_counts, buffer_bytes=512 << 10, n_buffers=48):
+    """The multiline splitter (ProcessorSplitMultilineLogStringNative) on 512 KB read buffers of Java stack traces:
+    lc_multiline_split_host = ONE device trip per buffer (upload, split kernels, one status-only launch per pattern, the
+    start/continue/end walk as a scan on the device), only the records come back.  Next to the reference's published 238 MB/s
+    for multi-line collection (README.md:66-67).  Parity gate: the records of every distinct buffer equal the oracle's."""
+    from loongcollector_amd import corpus
+    from loongcollector_amd.multiline import Multiline
+    from oracle.multiline_oracle import MultilineOracle
+    cfg = {"StartPattern": corpus.MULTILINE_START}
+    buffers = [corpus.multiline_buffer(buffer_bytes, seed=corpus.SEED + 17 + k, unmatched_head=3 * k) for k in range(4)]
+    m = Multiline(**cfg)
+    o = MultilineOracle(**cfg)
+    logs = 0
+    for b in buffers:
+        got = m.split(b)
+        if got != o.split(b):
+            raise SystemExit("PARITY FAILURE (multiline): records differ from the oracle's walk")
+        logs += got[1][2]
+    out = {"what": "lc_multiline_split_host on %d KB read buffers of stack traces (StartPattern %s; %d lines, %d logs per buffer): "
+                   "upload -> split kernels -> status-only match -> record scan on the device, records come back; N runner threads "
+                   "sharing one instance" % (buffer_bytes >> 10, corpus.MULTILINE_START, buffers[0].count(b"\n"), logs // len(buffers)),
+           "reference_MBps": 238.0, "reference_what": "LoongCollector's published multi-line figure (README.md:66-67), whole agent, 1 thread"}
+    res = {}
+    for t in thread_counts:
+        per_thread = max(4, n_buffers // t)
+        dt = _run_threads(t, per_thread, lambda tid, k: buffers[(tid + k) % len(buffers)], lambda tid, b: m.split_raw(b))
+        nbytes = sum(len(buffers[(tid + k) % len(buffers)]) for tid in range(t) for k in range(1, per_thread + 1))
+        res[str(t)] = round(nbytes / dt / 1e6, 1)
+    out["MBps"] = res
+    # three patterns (start + continue + end all in use): three status launches over the same device copy
+    cfg3 = {"StartPattern": corpus.MULTILINE_START, "ContinuePattern": r"(\tat |Caused by: ).*", "EndPattern": r"\tat \S+\(Handler\.java:\d+\)$"}
+    m3, o3 = Multiline(**cfg3), MultilineOracle(**cfg3)
+    if m3.split(buffers[1]) != o3.split(buffers[1]):
+        raise SystemExit("PARITY FAILURE (multiline, three patterns): records differ from the oracle's walk")
+    dt = _run_threads(1, 16, lambda tid, k: buffers[k % len(buffers)], lambda tid, b: m3.split_raw(b))
+    out["three_patterns_MBps"] = {"1": round(sum(len(buffers[k % len(buffers)]) for k in range(1, 17)) / dt / 1e6, 1)}
+    return out
+
+
+def measure_filter(thread_counts, group_lines=1000, n_groups=128):
+    """processor_filter_regex_native on event groups of 1000 parsed events (the keys of regex B's captures): a ConditionExp of three
+    regex leaves -- ONE device trip per group (one upload of the three keys' values, the leaves as jobs of one packed launch, one
+    copy back).  Parity gate: the surviving events equal oracle/filter_oracle.py's."""
+    from loongcollector_amd import corpus
+    from loongcollector_amd.processor import EventGroup, Filter
+    from oracle.filter_oracle import FilterOracle
+    cond = {"operator": "and", "operands": [
+        {"operator": "or", "operands": [{"key": "method", "exp": "GET|HEAD", "type": "regex"},
+                                        {"key": "response_code", "exp": "5\\d\\d", "type": "regex"}]},
+        {"operator": "not", "operands": [{"key": "user_agent", "exp": ".*(bot|spider|crawl).*", "type": "regex"}]}]}
+    config = {"ConditionExp": cond}
+    data, off, length = corpus.apache_batch(group_lines * 4, "B", 512, seed=corpus.SEED + 5, pool_lines=2048)
+    from oracle.oracle import OracleRegex
+    rx = OracleRegex(corpus.REGEX_B)
+    caps, status = rx.fullmatch_batch(data, off[:-1], length)
+    events = []
+    for i in range(len(length)):
+        raw = data[int(off[i]):int(off[i]) + int(length[i])].tobytes()
+        events.append({"contents": [[k, raw[caps[i][2 * g]:caps[i][2 * g + 1]].decode("latin-1")] for g, k in enumerate(corpus.KEYS_B)],
+                       "timestamp": 1, "type": 1})
+    fixtures = [{"events": events[k * group_lines:(k + 1) * group_lines]} for k in range(4)]
+    value_bytes = [sum(len(v) for ev in fx["events"] for k, v in ev["contents"] if k in ("method", "response_code", "user_agent")) for fx in fixtures]
+    group_bytes = [sum(len(k) + len(v) for ev in fx["events"] for k, v in ev["contents"]) for fx in fixtures]
+    f = Filter(config)
+    fo = FilterOracle(config)
+    for fx in fixtures:
+        g = EventGroup(fx)
+        f.process(g)
+        got = [dict(ev) for ev in g.contents()]
+        want = [{k: v.decode("latin-1") for k, v in c.items()}
+                for c in fo.process([{k: v.encode("latin-1") for k, v in ev["contents"]} for ev in fx["events"]])]
+        if got != want or not 0 < len(want) < len(fx["events"]):
+            raise SystemExit("PARITY FAILURE (filter): surviving events differ from the oracle's")
+    out = {"what": "lc_filter_process on groups of %d parsed events (11 keys); ConditionExp (method ~ GET|HEAD or response_code ~ 5xx) and "
+                   "not user_agent ~ bot: three regex leaves = ONE device trip per group; N runner threads sharing one instance; "
+                   "MB/s of the groups' content bytes (the three keys' values that go up are %.0f %% of them)"
+                   % (group_lines, 100.0 * sum(value_bytes) / sum(group_bytes))}
+    res = {}
+    for t in thread_counts:
+        per_thread = max(4, n_groups // t)
+        dt = _run_threads(t, per_thread, lambda tid, k: EventGroup(fixtures[(tid + k) % 4]), lambda tid, g: f.process(g))
+        nbytes = sum(group_bytes[(tid + k) % 4] for tid in range(t) for k in range(1, per_thread + 1))
+        res[str(t)] = round(nbytes / dt / 1e6, 1)
+    out["MBps"] = res
+    return out
+
+
 def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_counts, group_lines=1000, e2e_lines=1 << 18):
     G = rx.groups
     n = len(length)
@@ -215,6 +327,8 @@ def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_count
             raise SystemExit("PARITY FAILURE (in-agent path): stitched fields differ from the oracle's captures")
     out["in_agent_MBps"] = ag
     out["pipeline"] = measure_pipeline(thread_counts)
+    out["multiline"] = measure_multiline(thread_counts)
+    out["filter"] = measure_filter(thread_counts)
     out["in_agent_what"] = ("lc_processor_process on %d-line event groups (gather into pinned staging -> ONE kernel launch that reads the lines and writes the capture table through the pinned mapping -> stitch + policy), "
                             "N runner threads sharing one instance; %d lines" % (group_lines, m))
     return out

@@ -1361,6 +1361,7 @@ extern "C" void lc_thread_release(void) {
     lcGrokThreadRelease();
     lcPipelineThreadRelease();
     lcMultilineThreadRelease();
+    lcFilterThreadRelease();
 }
 
 extern "C" void lc_nfa_set_dfs(int on) { gNfaDfsMode.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }

@@ -23,6 +23,7 @@
 #include "multiline_kernel.hpp"
 #include "regex_handle.hpp"
 #include "runtime_internal.hpp"
+#include "trip_buffers.hpp"
 
 extern "C" int lc_multiline_bounds_device(uint32_t mode, const uint8_t* d_start, const uint8_t* d_cont, const uint8_t* d_end,
                                           const uint32_t* d_nitems, uint32_t max_items, const uint32_t* d_off, uint32_t nbytes,
@@ -50,24 +51,7 @@ extern "C" int lc_multiline_bounds_device(uint32_t mode, const uint8_t* d_start,
 namespace {
 
 // per runner thread: a stream, pinned staging, device buffers; grow-only
-struct MlBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    bool pinned = false;
-    void release() {
-        if (p) (void)(pinned ? hipHostFree(p) : hipFree(p));
-        p = nullptr;
-        cap = 0;
-    }
-    hipError_t ensure(size_t bytes) {
-        if (p && cap >= bytes) return hipSuccess;
-        release();
-        const size_t want = bytes + (bytes >> 2) + 256;
-        const hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-};
+typedef TripBuf MlBuf;
 struct MlThread {
     hipStream_t stream = nullptr;
     int device = -1;
@@ -233,12 +217,16 @@ int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint
     if (n) rc = lc_upload_pinned(T.hIn.p, T.dData.p, upBytes, T.stream);
     lc_regex_t* const res[3] = {m->start, m->cont, m->end};
     const uint8_t* status[3] = {nullptr, nullptr, nullptr};
-    for (int k = 0; k < 3 && rc == LC_OK && n; ++k) {
+    // the patterns are the jobs of ONE lc_regex_match_device_multi call over the same device copy (patterns on the tagged-DFA engine
+    // share a single launch)
+    std::vector<lc_match_job> jobs;
+    for (int k = 0; k < 3 && n; ++k) {
         if (!res[k]) continue;
         uint8_t* st = static_cast<uint8_t*>(T.dStatus.p) + size_t(k) * statusStride;
         status[k] = st;
-        rc = lcMatchOnStream(res[k], res[k]->engine, dev, dData, dOff, dLen, 0, n, nullptr, nullptr, nullptr, 0, dCapsDummy, st, T.stream);
+        jobs.push_back({res[k], dData, dOff, dLen, 0u, n, 0u, dCapsDummy, st});
     }
+    if (rc == LC_OK && !jobs.empty()) rc = lc_regex_match_device_multi(jobs.data(), uint32_t(jobs.size()), T.stream);
     if (rc != LC_OK) return rc;
     rc = boundsAndFetch(T, modeOf(*m, flush), status, nullptr, n, nullptr, 0, out, counts);
     if (rc != LC_OK) return rc;

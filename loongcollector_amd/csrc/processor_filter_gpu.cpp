@@ -8,6 +8,33 @@
 #include "../../include/lc_processor.h"
 #include "../../include/lc_regex_gpu.h"
 #include "regex_handle.hpp"
+#include <hip/hip_runtime_api.h>
+
+#include "trip_buffers.hpp"
+
+void lcFilterThreadRelease();  // (runtime_internal.hpp; that header is for the device translation units)
+
+namespace {
+// per runner thread: a stream, pinned staging, device buffers; grow-only
+struct FilterThread {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    TripBuf hIn, hStatus;  // pinned
+    TripBuf dIn, dStatus;  // device
+    FilterThread() { hIn.pinned = hStatus.pinned = true; }
+};
+thread_local FilterThread tlsFilter;
+}  // namespace
+void lcFilterThreadRelease() {
+    FilterThread& T = tlsFilter;
+    if (T.stream) {
+        (void)hipStreamSynchronize(T.stream);
+        (void)hipStreamDestroy(T.stream);
+        T.stream = nullptr;
+    }
+    for (TripBuf* b : {&T.hIn, &T.hStatus, &T.dIn, &T.dStatus}) b->release();
+    T.device = -1;
+}
 
 namespace logtail {
 
@@ -242,46 +269,103 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
     const size_t n = events.size();
     mInEventsTotal += n;
 
-    // one device launch per regex leaf over the values of its key (absent key: the leaf is false, :260-264 / :457-461)
+    // ONE device trip for all regex leaves: the values of every leaf's key (absent key: the leaf is false, :260-264 / :457-461)
+    // are gathered into one pinned block and go up once; every leaf is a job of ONE lc_regex_match_device_multi call (leaves on
+    // the tagged-DFA engine share a single launch, each workgroup staging its own leaf's tables); the status bytes of all values
+    // come back with one copy, one synchronisation per group.  (Round 2: a gather, an upload, a launch and a download per leaf.)
     std::vector<std::vector<uint8_t>> leafResult(mLeaves.size());
     uint64_t gaveUp = 0;
-    std::vector<const uint8_t*> ptr;
-    std::vector<uint32_t> len, owner;
-    std::vector<uint8_t> status;
+    struct Val {
+        const uint8_t* p;
+        uint32_t len, owner;
+    };
+    std::vector<std::vector<Val>> vals(mLeaves.size());
+    uint64_t totalBytes = 0;
+    size_t totalVals = 0;
     for (size_t l = 0; l < mLeaves.size(); ++l) {
         leafResult[l].assign(n, 0);
-        ptr.clear();
-        len.clear();
-        owner.clear();
         const StringView key(mLeaves[l].key);
         for (size_t i = 0; i < n; ++i) {
             if (!events[i].Is<LogEvent>()) continue;
             const LogEvent& e = events[i].Cast<LogEvent>();
             if (!e.HasContent(key)) continue;
             const StringView v = e.GetContent(key);
-            ptr.push_back(reinterpret_cast<const uint8_t*>(v.data()));
-            len.push_back(uint32_t(v.size()));
-            owner.push_back(uint32_t(i));
+            vals[l].push_back({reinterpret_cast<const uint8_t*>(v.data()), uint32_t(v.size()), uint32_t(i)});
+            totalBytes += v.size();
         }
-        if (ptr.empty()) continue;
-        status.assign(ptr.size(), 0);
-        const int rc = lc_regex_match_host_views(mLeaves[l].reg, ptr.data(), len.data(), uint32_t(ptr.size()), 0, nullptr,
-                                                 status.data());
-        if (rc != LC_OK) {
-            error = rc == LC_ERR_NO_DEVICE ? "no HIP device: the filter has no CPU path" : lc_last_error();
-            mInEventsTotal -= n;
-            return false;
+        totalVals += vals[l].size();
+    }
+    auto fail = [&](const std::string& why) {
+        error = why;
+        mInEventsTotal -= n;
+        return false;
+    };
+    if (totalVals) {
+        if (lc_device_count() <= 0) return fail("no HIP device: the filter has no CPU path");
+        if (totalBytes >= 0xFFFFFFF0ull) return fail("filter: more than 4 GiB of values in one group");
+        FilterThread& T = tlsFilter;
+        int dev = 0;
+#define FILTER_TRY(expr)                                                                  \
+    do {                                                                                  \
+        const hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+        FILTER_TRY(hipGetDevice(&dev));
+        if (!T.stream || T.device != dev) {
+            FILTER_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));
+            T.device = dev;
         }
-        for (size_t k = 0; k < ptr.size(); ++k) {
-            // "not decided" (decide pass switched off) is neither true nor false: a NOT node would turn a guess into a keep
-            if (status[k] == LC_OVERFLOW) {
-                error = "device left a value undecided (LC_NFA_NO_DECIDE is set): group untouched";
-                mInEventsTotal -= n;
-                return false;
+        // staging: [value bytes, back to back][off: one word per value][len: one word per value]
+        const size_t dataBytes = (size_t(totalBytes) + 31) & ~size_t(15);
+        const size_t upBytes = dataBytes + totalVals * 8 + 16;
+        FILTER_TRY(T.hIn.ensure(upBytes));
+        FILTER_TRY(T.dIn.ensure(upBytes));
+        FILTER_TRY(T.dStatus.ensure(totalVals + 64));
+        FILTER_TRY(T.hStatus.ensure(totalVals + 64));
+        uint8_t* h = static_cast<uint8_t*>(T.hIn.p);
+        uint32_t* hOff = reinterpret_cast<uint32_t*>(h + dataBytes);
+        uint32_t* hLen = hOff + totalVals;
+        uint32_t at = 0;
+        size_t k = 0;
+        for (size_t l = 0; l < mLeaves.size(); ++l)
+            for (const Val& v : vals[l]) {
+                hOff[k] = at;
+                hLen[k] = v.len;
+                if (v.len) std::memcpy(h + at, v.p, v.len);
+                at += v.len;
+                ++k;
             }
-            leafResult[l][owner[k]] = status[k] == LC_MATCH;
-            gaveUp += status[k] == LC_GAVE_UP;  // regex_match in Filter fail (:266-281): false, and counted
+        std::memset(h + at, 0, dataBytes - at);
+        if (lc_upload_pinned(T.hIn.p, T.dIn.p, upBytes, T.stream) != LC_OK) return fail(lc_last_error());
+        const uint8_t* dData = static_cast<const uint8_t*>(T.dIn.p);
+        const uint32_t* dOff = reinterpret_cast<const uint32_t*>(dData + dataBytes);
+        const uint32_t* dLen = dOff + totalVals;
+        uint8_t* dStatus = static_cast<uint8_t*>(T.dStatus.p);
+        int32_t* dCapsDummy = reinterpret_cast<int32_t*>(dStatus + ((totalVals + 15) & ~size_t(15)));  // (no group is asked for)
+        std::vector<lc_match_job> jobs;
+        size_t base = 0;
+        for (size_t l = 0; l < mLeaves.size(); ++l) {
+            if (!vals[l].empty())
+                jobs.push_back({mLeaves[l].reg, dData, dOff + base, dLen + base, 0u, uint32_t(vals[l].size()), 0u, dCapsDummy, dStatus + base});
+            base += vals[l].size();
         }
+        if (lc_regex_match_device_multi(jobs.data(), uint32_t(jobs.size()), T.stream) != LC_OK) {
+            (void)hipStreamSynchronize(T.stream);
+            return fail(lc_last_error());
+        }
+        FILTER_TRY(hipMemcpyAsync(T.hStatus.p, dStatus, totalVals, hipMemcpyDeviceToHost, T.stream));
+        FILTER_TRY(hipStreamSynchronize(T.stream));
+#undef FILTER_TRY
+        const uint8_t* status = static_cast<const uint8_t*>(T.hStatus.p);
+        k = 0;
+        for (size_t l = 0; l < mLeaves.size(); ++l)
+            for (const Val& v : vals[l]) {
+                // "not decided" (decide pass switched off) is neither true nor false: a NOT node would turn a guess into a keep
+                if (status[k] == LC_OVERFLOW) return fail("device left a value undecided (LC_NFA_NO_DECIDE is set): group untouched");
+                leafResult[l][v.owner] = status[k] == LC_MATCH;
+                gaveUp += status[k] == LC_GAVE_UP;  // regex_match in Filter fail (:266-281): false, and counted
+                ++k;
+            }
     }
 
     if (gaveUp) {

@@ -16,6 +16,7 @@ bool lcRuntimeUsable();
 void lcGrokThreadRelease();                            // grok_device.hip: the calling thread's Grok buffers
 void lcPipelineThreadRelease();                        // processor_pipeline_gpu.cpp: the calling thread's staging and stream
 void lcMultilineThreadRelease();                       // multiline_device.hip: the same for the multiline processors
+void lcFilterThreadRelease();                          // processor_filter_gpu.cpp: the same for the filter
 // the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
 void lcSetDecideSlot(int slot);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)

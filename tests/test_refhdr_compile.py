@@ -43,7 +43,7 @@ def _syntax_only(src, extra=()):
 @pytest.mark.parametrize("src", SOURCES)
 def test_shim_type_checks_against_the_reference_headers(src):
     # (the fused pipeline talks to the HIP runtime itself: its own stream and pinned staging)
-    extra = ("-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include") if src == "processor_pipeline_gpu.cpp" else ()
+    extra = ("-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include") if src in ("processor_pipeline_gpu.cpp", "processor_filter_gpu.cpp") else ()
     r = _syntax_only(src, extra)
     assert r.returncode == 0, r.stdout[-3000:]
 
