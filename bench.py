@@ -231,7 +231,7 @@ def measure_multiline(thread_counts, buffer_bytes=512 << 10, n_buffers=48):
     res = {}
     for t in thread_counts:
         per_thread = max(4, n_buffers // t)
-        dt = _run_threads(t, per_thread, lambda tid, k: buffers[(tid + k) % len(buffers)], lambda tid, b: m.split_raw(b))
+        dt = _run_threads(t, per_thread, lambda tid, k: buffers[(tid + k) % len(buffers)], lambda tid, b: m.split_count(b))
         nbytes = sum(len(buffers[(tid + k) % len(buffers)]) for tid in range(t) for k in range(1, per_thread + 1))
         res[str(t)] = round(nbytes / dt / 1e6, 1)
     out["MBps"] = res
@@ -240,7 +240,7 @@ def measure_multiline(thread_counts, buffer_bytes=512 << 10, n_buffers=48):
     m3, o3 = Multiline(**cfg3), MultilineOracle(**cfg3)
     if m3.split(buffers[1]) != o3.split(buffers[1]):
         raise SystemExit("PARITY FAILURE (multiline, three patterns): records differ from the oracle's walk")
-    dt = _run_threads(1, 16, lambda tid, k: buffers[k % len(buffers)], lambda tid, b: m3.split_raw(b))
+    dt = _run_threads(1, 16, lambda tid, k: buffers[k % len(buffers)], lambda tid, b: m3.split_count(b))
     out["three_patterns_MBps"] = {"1": round(sum(len(buffers[k % len(buffers)]) for k in range(1, 17)) / dt / 1e6, 1)}
     return out
 

@@ -199,6 +199,16 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet[devNow][which] = lds;
     }
+    // (measurement knob: LC_TDFA_EXTRA_LDS=<bytes> of unused LDS per workgroup lowers the number of resident workgroups -- how the
+    // kernel's time scales with the lines in flight per CU says whether it waits for latency or for a pipe)
+    static const size_t extraLds = [] {
+        const char* e = getenv("LC_TDFA_EXTRA_LDS");
+        return e ? size_t(atol(e)) : size_t(0);
+    }();
+    if (extraLds) {
+        lds += extraLds;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
     noteKernel(noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));

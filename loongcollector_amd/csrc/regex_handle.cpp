@@ -163,15 +163,7 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
 std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact, bool foldPrograms) {
     // wide: rows indexed by the byte itself (256 columns + identity); compact: 16-bit offset registers (tdfa_kernel.hpp)
     const uint32_t cols = (wide ? 256 : t.nClasses) + 1;  // + identity column
-    // Row stride in words: ODD, so that the rows of different states start in different LDS banks (32 banks of 4 bytes: with an
-    // even stride of 12 words the rows of states s and s+8 cover the same banks, and the lanes of a wave sit in a handful of hot
-    // (state, class) entries).  LC_TDFA_ROW_PAD=0 keeps the dense layout.
-    static const bool rowPadOff = [] {
-        const char* e = getenv("LC_TDFA_ROW_PAD");
-        return !(e && e[0] == '1');
-    }();
-    const uint32_t rowWords = cols + ((!wide && !rowPadOff && cols % 2 == 0) ? 1u : 0u);
-    const uint32_t rowBytes = rowWords * 4;
+    const uint32_t rowBytes = cols * 4;
     if (TD_TRANS_OFFSET + uint64_t(t.nStates) * rowBytes > TD_MAX_TABLE_END)
         throw RegexError("tdfa: transition table exceeds the 64 KiB LDS window");
     if (t.nClasses > 63) throw RegexError("tdfa: more than 63 byte classes");
@@ -201,14 +193,14 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
     w.reserve(TD_HEADER_WORDS * 4);
     std::vector<uint8_t> cmap(256);
     for (int b = 0; b < 256; ++b) cmap[size_t(b)] = uint8_t(t.classMap[size_t(b)] * 4);
-    std::vector<uint32_t> trans(size_t(t.nStates) * rowWords);
+    std::vector<uint32_t> trans(size_t(t.nStates) * cols);
     auto rowAddr = [&](uint32_t state) { return TD_TRANS_OFFSET + state * rowBytes; };
     for (uint32_t s = 0; s < t.nStates; ++s) {
         for (uint32_t c = 0; c + 1 < cols; ++c) {
             const uint32_t e = t.trans[size_t(s) * t.nClasses + (wide ? t.classMap[c] : c)];
-            trans[size_t(s) * rowWords + c] = rowAddr(e & 0xFFFF) | (field[e >> 16] << 16);
+            trans[size_t(s) * cols + c] = rowAddr(e & 0xFFFF) | (field[e >> 16] << 16);
         }
-        trans[size_t(s) * rowWords + cols - 1] = rowAddr(s) | (field[0] << 16);  // identity column
+        trans[size_t(s) * cols + cols - 1] = rowAddr(s) | (field[0] << 16);  // identity column
     }
     uint32_t hdr[TD_HEADER_WORDS] = {};
     hdr[TD_MAGIC] = TD_MAGIC_VALUE;

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t tdfaStreamChunk(uint32_t t, const uint32_t (
 // x one link in flight each, ~120 cycles per link), so halving the links per byte is worth more here than in the
 // phase-separated kernel, where it bought nothing.  Per pair: the link, the two class lookups of the
 // NEXT chunk's pair (first byte: cmapA, u16; second byte: cmap8), the two stamps of the PREVIOUS chunk's pair.
-template <int BLOCK, int NB, bool CHECKED, typename TdfaReg>
+template <int BLOCK, int NB, bool CHECKED, typename TdfaReg, int LAB = 0>
 __device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32_t (&colp)[NB / 2], uint32_t (&na)[NB / 2],
                                                         uint32_t (&nc)[NB / 2], const uint32_t (&nwords)[NB / 4], uint32_t nbase,
                                                         uint32_t L, uint32_t cmapA, uint32_t idAAddr,
@@ -102,12 +102,20 @@ __device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32
             na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
             nc[p] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b1);
         }
-        const uint32_t r0 = (ptt[p] >> 16) & 0xFFu, r1 = ptt[p] >> 24;
-        *reinterpret_cast<LdsRegPtr>(regAddr0 + (r0 << kRegShift)) = TdfaReg(pos);
-        asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
-        *reinterpret_cast<LdsRegPtr>(regAddr0 + (r1 << kRegShift)) = TdfaReg(pos);
-        asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
-        if (p > 0) seen |= tt[p - 1];
+        if constexpr ((LAB & kLabOneStamp) != 0) {
+            // (timing only, profiles/round3_tdfa_experiments.txt: what ONE stamp per pair would cost.  A register row that exists:
+            // the real thing would be one SDWA add on a pre-scaled field, this is two instructions)
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (((ptt[p] >> 16) & 0xFu) << kRegShift)) = TdfaReg(pos);
+            asm volatile("v_add_u32 %0, 2, %0" : "+v"(pos));
+        } else {
+            const uint32_t r0 = (ptt[p] >> 16) & 0xFFu, r1 = ptt[p] >> 24;
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (r0 << kRegShift)) = TdfaReg(pos);
+            asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (r1 << kRegShift)) = TdfaReg(pos);
+            asm volatile("v_add_u32 %0, 1, %0" : "+v"(pos));
+        }
+        if constexpr ((LAB & kLabNoGeneral) == 0)
+            if (p > 0) seen |= tt[p - 1];
 #ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -322,11 +330,11 @@ __device__ __forceinline__ void tdfaStreamBody(
             bool general;
             if constexpr (PAIR) {
                 uint32_t na[NC], nc[NC];
-                if (__all(fullNext)) t = tdfaStreamPairChunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
-                else t = tdfaStreamPairChunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
+                if (__all(fullNext)) t = tdfaStreamPairChunk<BLOCK, NB, false, TdfaReg, LAB>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
+                else t = tdfaStreamPairChunk<BLOCK, NB, true, TdfaReg, LAB>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
 #pragma unroll
                 for (int j = 0; j < NC; ++j) ncol[j] = na[j] + nc[j];
-                general = (seen & ((TP_GENERAL << 16) | (TP_GENERAL << 24))) != 0;
+                general = (LAB & kLabNoGeneral) ? false : (seen & ((TP_GENERAL << 16) | (TP_GENERAL << 24))) != 0;
             } else {
                 if (__all(fullNext)) t = tdfaStreamChunk<NB, false, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);
                 else t = tdfaStreamChunk<NB, true, TdfaReg, LAB>(t, col, ncol, nwords, nbase, L, idCol, ptt, tt, pbase, regAddr0, seen);

@@ -77,6 +77,17 @@ class Multiline:
             self._L.lc_multiline_free_records(recs)
 
 
+    def split_count(self, value: bytes):
+        """the same call without building Python objects for the records (throughput measurements: the list of tuples costs more
+        than the device trip) -> (number of records, counters)"""
+        recs = ctypes.POINTER(_Record)()
+        n = ctypes.c_uint32()
+        counters = (ctypes.c_uint32 * 3)()
+        rc = self._L.lc_multiline_split_host(self._h, value, len(value), ctypes.byref(recs), ctypes.byref(n), counters)
+        binding._check(rc, "lc_multiline_split_host")
+        self._L.lc_multiline_free_records(recs)
+        return n.value, tuple(counters)
+
     def split_raw(self, value: bytes):
         """-> records [(begin, length, flag word)] with the LC_ML_LAST / LC_ML_RUN bits"""
         recs = ctypes.POINTER(_Record)()

@@ -257,6 +257,9 @@ int main(int argc, char** argv) {
         runVariant<512, 0, false, false, true>("compact 512 pairs (old kernel)", in, d, &refCaps, &refStatus, iters);
         runVariant<512, 0, false, true, false>("stream 512, single-byte table", in, d, &refCaps, &refStatus, iters);
         runVariant<512, 0, false, true, true>("stream 512 pairs", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral, false, true, true>("stream 512 pairs, no general", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabOneStamp | kLabNoStamp, false, true, true>("stream 512 pairs, ONE stamp/pair", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral, false, true, false>("stream 512 single, no general", in, d, &refCaps, &refStatus, iters);
         runVariant<512, kLabNoStamp, false, true, true>("stream 512 pairs, no stamps", in, d, &refCaps, &refStatus, iters);
         runVariant<512, kLabNoOutput, false, true, true>("stream 512 pairs, no output", in, d, &refCaps, &refStatus, iters);
         runVariant<512, 0, true, true, true>("stream 512 pairs, pool", in, d, &refCaps, &refStatus, iters);
