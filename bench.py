@@ -326,6 +326,28 @@ def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_count
         if [tuple(kv) for kv in first] != want:
             raise SystemExit("PARITY FAILURE (in-agent path): stitched fields differ from the oracle's captures")
     out["in_agent_MBps"] = ag
+    # -- the same groups through the columnar entry (lc_processor_parse_columnar: capture table + base pointers + per-event protobuf
+    # content sizes, no event materialised): what a serializer downstream can consume directly
+    from loongcollector_amd.processor import EventGroup, Processor
+    colp = Processor({"SourceKey": "content", "Regex": pattern, "Keys": keys})
+    col = {}
+    for t in thread_counts:
+        per_thread = max(4, (m // group_lines) // t)
+
+        def mk(tid, k):
+            lo = ((tid * per_thread + k) * group_lines) % (m - group_lines + 1)
+            return EventGroup.from_lines(data, off[lo:lo + group_lines], length[lo:lo + group_lines])
+
+        seen = []
+
+        def work(tid, g):
+            seen.append(colp.parse_columnar_count(g))
+
+        dt = _run_threads(t, per_thread, mk, work)
+        if any(n != group_lines or ok != group_lines for n, ok, _ in seen):
+            raise SystemExit("PARITY FAILURE (columnar path): not every event of a group was parsed")
+        col[str(t)] = round(t * per_thread * group_lines * float(length[:group_lines].mean()) / dt / 1e6, 1)
+    out["in_agent_columnar_MBps"] = col
     out["pipeline"] = measure_pipeline(thread_counts)
     out["multiline"] = measure_multiline(thread_counts)
     out["filter"] = measure_filter(thread_counts)
@@ -685,6 +707,32 @@ def compute_multitenant(args, dev):
     single = time.perf_counter() - t1
     launches = P * args.steps
     algo = sum((512 + 5 + 8 * p["rx"].groups) * GL for p in pipes) * args.steps
+    # several PENDING groups per pipeline in one packed launch (the process queues hold more than one group per pipeline when the
+    # agent is busy, ProcessQueueManager.cpp; a 1000-line group is only 4 workgroups, so 64 of them leave most of the chip waiting)
+    pending = {}
+    for M in (4, 16):
+        caps_m = [torch.empty((M, GL, 2 * p["rx"].groups), dtype=torch.int32, device=dev) for p in pipes]
+        stat_m = [torch.full((M, GL), 9, dtype=torch.uint8, device=dev) for p in pipes]
+        jobs_m = binding.make_jobs([(p["rx"], p["d_data"], p["d_off"], None, GL, caps_m[i][k], stat_m[i][k], 1)
+                                    for k in range(M) for i, p in enumerate(pipes)])
+        binding.match_device_multi(jobs_m, cur)
+        torch.cuda.synchronize()
+        for i, p in enumerate(pipes):  # parity: every copy equals the single-group result checked against the oracle above
+            if not (torch.equal(stat_m[i], p["d_status"].expand(M, GL)) and torch.equal(caps_m[i], p["d_caps"].expand(M, GL, -1))):
+                raise SystemExit("PARITY FAILURE: %d pending groups per launch differ from the single-group results" % M)
+        for _ in range(args.warmup):
+            binding.match_device_multi(jobs_m, cur)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            binding.match_device_multi(jobs_m, cur)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        pending[str(M)] = {"MBps": round(sum(p["bytes"] for p in pipes) * M / (ms * 1e-3) / 1e6, 1), "ms_per_launch": round(ms, 4),
+                           "roofline_frac": round(algo / args.steps * M / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        del caps_m, stat_m, jobs_m
     out = {"metric": "aggregate MB/s parsed, %d pipelines round-robin on 1 MI355X" % P, "value": round(total / elapsed / 1e6, 1),
            "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -698,6 +746,7 @@ def compute_multitenant(args, dev):
            "no_switch": {"what": "the same bytes as ONE launch of pipeline 0's regex over %d lines" % (GL * P),
                          "MBps": round(p0["bytes"] * P * args.steps / single / 1e6, 1)},
            "per_switch_overhead_us": round((elapsed - single) / launches * 1e6, 3),
+           "pending_groups_per_pipeline": dict(pending, what="the packed launch with M groups queued per pipeline (64 x M jobs in ONE launch)"),
            "roofline": {"bound": "hbm", "achieved": round(algo / args.steps / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(algo / args.steps / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                         "kernel": "tdfa_stream_multi_kernel", "avg_kernel_ms": round(kernel_ms, 4),

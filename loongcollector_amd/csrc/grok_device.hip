@@ -585,6 +585,14 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.rounds = std::max(1u, std::min(kGrokMaxRounds, patterns[p].re->grokRounds.load(std::memory_order_relaxed)));
         const bool nfa = patterns[p].re->engine == LC_ENGINE_NFA;
         e.cost = double(c) * (nfa ? (patterns[p].anchored ? 8.0 : 40.0) : 1.0);
+        // an automaton that walks its tables in global memory (tdfa_l2_kernel) takes as long as its LONGEST candidate -- one dependent
+        // read per byte, ~0.7 us per byte, 2.8 ms for a 4 KiB line -- on a grid of a few waves: it goes to the head of its stream,
+        // where it runs beside everything else, instead of behind the cheap entries (measured: the step's last 2.8 ms were this)
+        auto walksGlobalTables = [](const lc_regex* re) { return re && re->engine == LC_ENGINE_TDFA && !re->hasTdfa && !re->tdfaL2Blob.empty(); };
+        // (small batches only -- measured 6.36 -> 4.02 ms on 1000 values, 5.67 -> 6.34 ms on 16 Ki: the runtime maps the worker streams
+        // onto a few hardware queues, and with thousands of candidates per entry the wide thread-list kernels, not these, are the
+        // long poles; sharing half of the streams among these entries was worse for both sizes)
+        if (small && (walksGlobalTables(patterns[p].re) || walksGlobalTables(patterns[p].anchored))) e.cost += 1e12;
         Offsets o;
         o.off = carve(size_t(c) * 4);
         o.len = carve(size_t(c) * 4);

@@ -202,6 +202,22 @@ class Processor:
         finally:
             self._L.lc_columnar_free(c)
 
+    def parse_columnar_count(self, group: EventGroup):
+        """the same call without building Python objects (throughput measurements) -> (events, parsed events, content bytes)"""
+        c = ctypes.POINTER(LcColumnar)()
+        rc = self._L.lc_processor_parse_columnar(self._h, group._h, ctypes.byref(c))
+        if rc != binding.LC_OK:
+            raise RuntimeError("lc_processor_parse_columnar rc=%d" % rc)
+        try:
+            col = c.contents
+            n = int(col.n_events)
+            import numpy as np
+            state = np.ctypeslib.as_array(col.state, shape=(n,)) if n else np.zeros(0, np.uint8)
+            sizes = np.ctypeslib.as_array(col.content_bytes, shape=(n,)) if n else np.zeros(0, np.uint64)
+            return n, int((state == 1).sum()), int(sizes.sum())
+        finally:
+            self._L.lc_columnar_free(c)
+
     def collect_alarms(self):
         """lc_processor_set_alarm_sink: -> the list that receives (kind, message bytes) for every REGEX_MATCH_ALARM the
         reference would raise (ProcessorParseRegexNative.cpp:196-244)"""
