@@ -89,7 +89,9 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 //   kLabNoGeneral  (tdfa_stream_kernel only): no check for general register programs (wrong for tables that have one on the
 //                  walked path): what the check costs -- and what tables without such programs need not pay
 enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32, kLabNoGeneral = 64,
-       kLabOneStamp = 128 /* byte-pair chunks only: one stamp per pair (timing only) */ };
+       kLabOneStamp = 128 /* byte-pair chunks only: one stamp per pair (timing only) */,
+       kLabDmaStage = 256 /* tdfa_stream_kernel, COMPACT: the staging tile is filled by global_load_lds_dwordx4 (no staging VGPRs) */,
+       kLabWaves5 = 512 /* tdfa_stream_kernel: register budget of 5 waves per SIMD (96 VGPRs) */ };
 constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 
 // general register program (a list of moves); rare for log regexes

@@ -252,6 +252,15 @@ int main(int argc, char** argv) {
     if (kTdfaStageBytes == 64) RUN(256, 0, "compact 256 (product)");
 #define RUNS(B, L, NAME) runVariant<B, L, false, true>(NAME, in, d, &refCaps, &refStatus, iters)
 #define RUNSP(B, L, NAME) runVariant<B, L, true, true>(NAME, in, d, &refCaps, &refStatus, iters)
+    if (in.blob[TD_OFF_PAIR] && getenv("LAB_DMA")) {
+        runVariant<512, kLabNoGeneral, false, true, true>("stream 512 pairs, no general", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabDmaStage, false, true, true>("stream 512 pairs, nogen, DMA", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabOneStamp | kLabNoStamp, false, true, true>("stream 512 pairs, ONE stamp/pair", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabOneStamp | kLabNoStamp | kLabDmaStage, false, true, true>("stream 512 pairs, ONE stamp, DMA", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabOneStamp | kLabNoStamp | kLabDmaStage | kLabNoOutput, false, true, true>("512 pairs, ONE stamp, DMA, no out", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabOneStamp | kLabNoStamp | kLabDmaStage, true, true, true>("512 pairs, ONE stamp, DMA, pool", in, d, &refCaps, &refStatus, iters);
+        return 0;
+    }
     if (in.blob[TD_OFF_PAIR]) {
         runVariant<512, 0, false, false, false>("compact 512, single-byte table", in, d, &refCaps, &refStatus, iters);
         runVariant<512, 0, false, false, true>("compact 512 pairs (old kernel)", in, d, &refCaps, &refStatus, iters);
@@ -267,6 +276,19 @@ int main(int argc, char** argv) {
         return 0;
     }
     RUNS(256, 0, "stream 256");
+    if (getenv("LAB_DMA")) {  // round 3: the staging tile filled by LDS-DMA (global_load_lds_dwordx4)
+        RUNS(256, kLabNoGeneral, "stream 256 no general (product)");
+        RUNS(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA staging");
+        gPadLdsTo = size_t(160 * 1024 / 4) & ~size_t(255);
+        RUNS(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA, 4 WG/CU");
+        gPadLdsTo = 0;
+        RUNS(256, kLabDmaStage, "stream 256 general, DMA staging");
+        RUNS(256, kLabNoGeneral | kLabDmaStage | kLabNoOutput, "stream 256 nogen, DMA, no output");
+        RUNSP(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA, pool");
+        RUNS(128, kLabNoGeneral | kLabDmaStage, "stream 128 nogen, DMA staging");
+        RUNS(512, kLabNoGeneral | kLabDmaStage, "stream 512 nogen, DMA staging");
+        return 0;
+    }
     if (getenv("LAB_ONLY")) {
         RUNS(256, kLabNoGeneral, "stream 256 no general check");
         RUNS(256, kLabPreClass | kLabNoStamp, "stream 256 bare chain");
