@@ -184,15 +184,27 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         return e && e[0] == '0';
     }();
     const bool noGen = !PAIR && !BYTEROWS && !streamOff && !noGenOff && (nregsWord & TD_NREGS_NO_GENERAL) != 0;
+    // COMPACT tiles (rows of exactly 64 bytes) are filled by LDS-DMA: no staging VGPRs (113 -> 89: 20 instead of 16 waves per CU),
+    // no ds_write_b128 (tdfa_stream_kernel.hpp, kLabDmaStage; round 3: 0.217 -> 0.208 ms on the headline batch).  LC_TDFA_DMA=0:
+    // the register-staged original (A/B measurements).
+    static const bool dmaOff = [] {
+        const char* e = getenv("LC_TDFA_DMA");
+        return e && e[0] == '0';
+    }();
+    const bool dma = COMPACT && !PAIR && !BYTEROWS && !streamOff && !dmaOff;
     auto kern = tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>;
     if constexpr (!BYTEROWS) {
         if (!streamOff) kern = tdfa_stream_kernel<BLOCK, COMPACT, PAIR>;
         if constexpr (!PAIR) {
             if (noGen) kern = tdfa_stream_kernel<BLOCK, COMPACT, false, kTdfaNoGeneralPrograms>;
+            if constexpr (COMPACT) {
+                if (dma) kern = noGen ? tdfa_stream_kernel<BLOCK, true, false, kTdfaNoGeneralPrograms | kLabDmaStage>
+                                      : tdfa_stream_kernel<BLOCK, true, false, kLabDmaStage>;
+            }
         }
     }
-    static thread_local size_t ldsAttrSet[kLcMaxDevices][3] = {};  // the attribute belongs to (function, device)
-    const int which = noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices][5] = {};  // the attribute belongs to (function, device)
+    const int which = dma ? (noGen ? 4 : 3) : noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
     if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow][which]) {
@@ -210,7 +222,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    noteKernel(noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
+    noteKernel(dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
     // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)
     const uint32_t* blobArg = static_cast<const uint32_t*>(dBlob);

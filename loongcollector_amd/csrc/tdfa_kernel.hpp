@@ -235,6 +235,10 @@ template <int BLOCK, typename TdfaReg>
 __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAddr, uint32_t regsBase, uint32_t state, bool live,
                                                  uint32_t line, uint32_t L, uint32_t from, bool permuted, uint32_t nGroupsOut,
                                                  int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
+    // Round 3: this epilogue was a chain of ~100 dependent LDS round trips per wave (a map byte, then a register, per slot and
+    // pass; a dword per lane and store in the copy) -- 9 % of the kernel with nothing to overlap it when the workgroups of a CU
+    // run in lockstep.  Now: the wave-uniform words (fold words, slot map) are read ONCE, one per lane, and handed round with
+    // v_readlane; registers are read eight at a time; the tile leaves in 16-byte pieces.
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t nSlots = hdr[TD_NSLOTS];
@@ -249,20 +253,33 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
     if (foldOff) {
         // folded multi-stamp programs: a member register reads as the larger of itself and its set's register ("latest stamp"
         // = "largest offset", registers start at 0).  Settled here, once per line, so the row building below stays as it is.
-        // The fold words are wave-uniform: a handful of broadcast reads.
         const uint32_t* fw = reinterpret_cast<const uint32_t*>(smem + foldOff);
         TdfaReg* rw = reinterpret_cast<TdfaReg*>(smem + regsBase) + tdfaRegLane<TdfaReg>(tid);
         const uint32_t nWords = __builtin_amdgcn_readfirstlane(fw[0]);
-        for (uint32_t i = 0; i < nWords; ++i) {
-            const uint32_t w = __builtin_amdgcn_readfirstlane(fw[1 + i]);
-            const TdfaReg both = rw[(w & 0xFFu) * BLOCK];
-            if (!__any(both != 0)) continue;  // no line of the wave took such a transition (the usual case)
+        for (uint32_t i0 = 0; i0 < nWords; i0 += 64) {
+            const uint32_t fwv = (i0 + lane < nWords) ? fw[1 + i0 + lane] : 0xFFFFFF00u;  // (lane i holds word i0 + i)
+            const uint32_t cnt = nWords - i0 < 64 ? nWords - i0 : 64;
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
+                uint32_t w[4];
+                TdfaReg both[4];
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                const uint32_t r = (w >> (8 * k)) & 0xFFu;
-                if (r != 0xFFu) {
-                    const TdfaReg own = rw[r * BLOCK];
-                    rw[r * BLOCK] = both > own ? both : own;
+                for (int k = 0; k < 4; ++k) {  // four set registers per round trip
+                    w[k] = uint32_t(__builtin_amdgcn_readlane(int(fwv), int((j0 + k) & 63)));
+                    both[k] = rw[(w[k] & 0xFFu) * BLOCK];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + k >= cnt) break;
+                    if (!__any(both[k] != 0)) continue;  // no line of the wave took such a transition (the usual case)
+                    // (a set register is never the member of another set: the four reads above stay valid)
+#pragma unroll
+                    for (int m = 1; m < 4; ++m) {
+                        const uint32_t r = (w[k] >> (8 * m)) & 0xFFu;
+                        if (r != 0xFFu) {
+                            const TdfaReg own = rw[r * BLOCK];
+                            rw[r * BLOCK] = both[k] > own ? both[k] : own;
+                        }
+                    }
                 }
             }
         }
@@ -277,37 +294,70 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
         return val;
     };
     constexpr uint32_t kTileWords = 1024;  // 64 rows x 64 bytes: the smaller of the two tile layouts
-    if (!permuted && nOut <= kTileWords && __all(live)) {
+    if (!permuted && nOut != 0 && nOut <= kTileWords && __all(live)) {
         int32_t* tile = reinterpret_cast<int32_t*>(smem + tileAddr);
-        const uint32_t rowsPerPass = kTileWords / nOut;
+        uint32_t rowsPerPass = kTileWords / nOut;
+        if (rowsPerPass > 64) rowsPerPass = 64;
+        if (rowsPerPass > 1) rowsPerPass &= ~1u;  // even: every pass starts on a 16-byte boundary of the capture table (nOut is even)
         int32_t* gout = caps + size_t(line - lane) * nOut;  // (lines of the wave are consecutive: line - lane = lane 0's)
         // Lines of one format end in the same accepting state: then the slot -> register map is the same for the whole wave
         // and the row is built without a per-slot, per-lane map lookup and its branches.
         const uint32_t fid0 = __builtin_amdgcn_readfirstlane(fid);
         const bool sameMap = __all(fid == fid0) && fid0 != 0xFFFFu;
+        const int32_t end = int32_t(L + from);
         for (uint32_t p0 = 0; p0 < 64; p0 += rowsPerPass) {
             tdfaWaveLdsSync();
-            if (lane >= p0 && lane - p0 < rowsPerPass) {
-                int32_t* row = tile + (lane - p0) * nOut;
-                if (sameMap) {
-                    const uint8_t* map = finalMap + fid0 * nSlots;
-                    const int32_t end = int32_t(L + from);
-                    for (uint32_t s = 0; s < nOut; ++s) {
-                        const uint32_t m = s < nSlots ? uint32_t(__builtin_amdgcn_readfirstlane(map[s])) : uint32_t(TD_REG_NONE);
-                        int32_t val = -1;  // (m is wave-uniform: the branches below are scalar)
-                        if (m == TD_REG_POS) val = end;
-                        else if (m != TD_REG_NONE) val = int32_t(regs[m * BLOCK + rl] + from);
-                        row[s] = state != 0 ? val : -1;
+            const bool inPass = lane >= p0 && lane - p0 < rowsPerPass;
+            int32_t* row = tile + (inPass ? lane - p0 : 0u) * nOut;
+            if (sameMap) {
+                const uint8_t* map = finalMap + fid0 * nSlots;
+                for (uint32_t s0 = 0; s0 < nOut; s0 += 64) {  // (one trip unless the pattern has more than 32 groups)
+                    const uint32_t sl = s0 + lane;
+                    const uint32_t mapv = (sl < nSlots && sl < nOut) ? uint32_t(map[sl]) : uint32_t(TD_REG_NONE);  // lane i: slot s0 + i
+                    const uint32_t cnt = nOut - s0 < 64 ? nOut - s0 : 64;
+                    for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+                        int32_t v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {  // (m is wave-uniform; the register read is issued whatever m says)
+                            const uint32_t m = uint32_t(__builtin_amdgcn_readlane(int(mapv), int((k0 + k) & 63)));
+                            const uint32_t r = m < TD_REG_NONE ? m : 0u;
+                            const int32_t reg = int32_t(regs[r * BLOCK + rl] + from);
+                            int32_t val = m == TD_REG_POS ? end : reg;
+                            val = m == TD_REG_NONE ? -1 : val;
+                            v[k] = state != 0 ? val : -1;
+                        }
+                        if (inPass) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if (k0 + k < cnt) row[s0 + k0 + k] = v[k];
+                        }
                     }
-                } else {
-#pragma unroll 4
-                    for (uint32_t s = 0; s < nOut; ++s) row[s] = slotValue(s);
                 }
+            } else if (inPass) {
+#pragma unroll 4
+                for (uint32_t s = 0; s < nOut; ++s) row[s] = slotValue(s);
             }
             tdfaWaveLdsSync();
             const uint32_t rows = 64 - p0 < rowsPerPass ? 64 - p0 : rowsPerPass;
             const uint32_t total = rows * nOut;
-            for (uint32_t d = lane; d < total; d += 64) gout[size_t(p0) * nOut + d] = tile[d];
+            int32_t* g = gout + size_t(p0) * nOut;
+            if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (total & 3u) == 0) {  // (wave-uniform)
+                typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+                const uint32_t nq = total / 4;  // <= 256: at most four 16-byte pieces per lane
+                i32x4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t at = lane + 64u * uint32_t(i);
+                    if (at < nq) q[i] = *reinterpret_cast<const i32x4 __attribute__((address_space(3)))*>(tileAddr + at * 16u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t at = lane + 64u * uint32_t(i);
+                    if (at < nq) reinterpret_cast<i32x4*>(g)[at] = q[i];
+                }
+            } else {
+                for (uint32_t d = lane; d < total; d += 64) g[d] = tile[d];
+            }
         }
     } else if (live) {
         int32_t* out = caps + size_t(line) * nOut;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, call 7: the rewritten result epilogue + DMA staging as the product's compact kernel -- lab, parity suite, bench line
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+python tools/tdfa_lab_inputs.py /tmp/lab_in.bin > /dev/null || exit 1
+echo "== product tables"; LAB_DMA=1 timeout 200 scratch/tdfa_lab /tmp/lab_in.bin 20 2>&1 | cut -c1-170 | tee gpurun_out/r3_lab_epilogue.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_processor.py -m gpu -x -q 2>&1 | grep -v "^  File \"/usr" | tail -12 | cut -c1-300
+timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-configs > gpurun_out/r3_bench_dma.json 2>gpurun_out/r3_bench_dma.err
+python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/r3_bench_dma.json").read())
+    print("bench", "MB/s", d["value"], "ms/step", d["ms_per_step"], "kernel ms", d["roofline"]["avg_kernel_ms"], "frac", d["roofline"]["frac"], d["roofline"]["kernels_launched"])
+except Exception as e:
+    print("bench failed", e); print(open("gpurun_out/r3_bench_dma.err").read()[-1500:])
+PY
