@@ -91,7 +91,8 @@ __device__ __forceinline__ void tdfaWaveLdsSync() {
 enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 8, kLabNoOutput = 16, kLabNoLoop = 32, kLabNoGeneral = 64,
        kLabOneStamp = 128 /* byte-pair chunks only: one stamp per pair (timing only) */,
        kLabDmaStage = 256 /* tdfa_stream_kernel, COMPACT: the staging tile is filled by global_load_lds_dwordx4 (no staging VGPRs) */,
-       kLabWaves5 = 512 /* tdfa_stream_kernel: register budget of 5 waves per SIMD (96 VGPRs) */ };
+       kLabWaves5 = 512 /* tdfa_stream_kernel: register budget of 5 waves per SIMD (96 VGPRs) */,
+       kLabNoDmaWait = 1024 /* DMA staging without the wait for the stage (wrong bytes: timing only -- what the wave loses there) */ };
 constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 
 // general register program (a list of moves); rare for log regexes
@@ -231,7 +232,7 @@ __device__ __forceinline__ void tdfaClearRegisters(uint8_t* smem, const uint32_t
 // consecutive in the capture table (no schedule permutation, every lane decides its line) the rows form ONE contiguous
 // region, so they go through the wave's staging tile (free once the line is walked): lanes write their rows to LDS, then the
 // wave copies the region out 256 contiguous bytes per store instruction.  `state` = final DFA state of the lane's line.
-template <int BLOCK, typename TdfaReg>
+template <int BLOCK, typename TdfaReg, int LAB = 0>
 __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAddr, uint32_t regsBase, uint32_t state, bool live,
                                                  uint32_t line, uint32_t L, uint32_t from, bool permuted, uint32_t nGroupsOut,
                                                  int32_t* __restrict__ caps, uint8_t* __restrict__ status) {
@@ -353,7 +354,8 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t at = lane + 64u * uint32_t(i);
-                    if (at < nq) reinterpret_cast<i32x4*>(g)[at] = q[i];
+                    // (non-temporal: the capture table is written once and not read again by this kernel; round 3 lab: -1 %)
+                    if (at < nq) __builtin_nontemporal_store(q[i], reinterpret_cast<i32x4*>(g) + at);
                 }
             } else {
                 for (uint32_t d = lane; d < total; d += 64) g[d] = tile[d];

@@ -395,7 +395,7 @@ __device__ __forceinline__ void tdfaStreamBody(
                 // the row's last segment is all chunks kChunksPerStage-2 and -1 still read: the others take stage s+1 now (the
                 // last chunk's NEXT bytes are the first ones of stage s+1), the last one when the stage is done
                 if (c == kChunksPerStage - 2) {
-                    tdfaDmaWait();
+                    if constexpr ((LAB & kLabNoDmaWait) == 0) tdfaDmaWait();
 #pragma unroll
                     for (int k = 0; k < kLoads - 1; ++k) W[k] = *reinterpret_cast<LdsQuadPtr>(myRow + ((uint32_t(k) * 16) ^ mySwizzle));
                 } else if (c == kChunksPerStage - 1) {
@@ -436,7 +436,7 @@ __device__ __forceinline__ void tdfaStreamBody(
         return;
     }
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
-    tdfaWriteResults<BLOCK, TdfaReg>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
+    tdfaWriteResults<BLOCK, TdfaReg, LAB>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
                                      status);
 }
 

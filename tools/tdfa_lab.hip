@@ -194,7 +194,7 @@ static double runVariant(const char* name, const Inputs& in, const Dev& d, std::
     else if (statusOut && !statusOut->empty()) {
         const bool sameStatus = st == *statusOut;
         const bool sameCaps = caps == *capsOut;
-        verdict = (LAB & (kLabNoOutput | kLabNoLoop)) ? "(timing only)" : (LAB & kLabNoStamp) ? (sameStatus ? "status==" : "STATUS DIFFERS") : (sameStatus && sameCaps ? "bit-exact" : "MISMATCH");
+        verdict = (LAB & (kLabNoOutput | kLabNoLoop | kLabNoDmaWait)) ? "(timing only)" : (LAB & kLabNoStamp) ? (sameStatus ? "status==" : "STATUS DIFFERS") : (sameStatus && sameCaps ? "bit-exact" : "MISMATCH");
     }
     if (!POOL && statusOut && statusOut->empty()) {
         *statusOut = st;
@@ -282,6 +282,13 @@ int main(int argc, char** argv) {
         gPadLdsTo = size_t(160 * 1024 / 4) & ~size_t(255);
         RUNS(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA, 4 WG/CU");
         gPadLdsTo = 0;
+        RUNS(256, kLabNoGeneral, "stream 256 no general (again)");
+        RUNS(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA (again)");
+        RUNS(256, kLabNoGeneral, "stream 256 no general (3rd)");
+        RUNS(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA (3rd)");
+        RUNS(256, kLabNoGeneral | kLabDmaStage | kLabNoDmaWait, "stream 256 nogen, DMA, NO WAIT");
+        RUNSP(256, kLabNoGeneral | kLabDmaStage | kLabNoDmaWait, "stream 256 nogen, DMA, NO WAIT, pool");
+        RUNS(256, kLabNoGeneral | kLabDmaStage | kLabNoDmaWait | kLabNoOutput, "stream 256 nogen, DMA, NO WAIT, no out");
         RUNS(256, kLabDmaStage, "stream 256 general, DMA staging");
         RUNS(256, kLabNoGeneral | kLabDmaStage | kLabNoOutput, "stream 256 nogen, DMA, no output");
         RUNSP(256, kLabNoGeneral | kLabDmaStage, "stream 256 nogen, DMA, pool");
