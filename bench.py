@@ -29,6 +29,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# hardware queues behind the HIP streams (default 4): the library sets this when it is loaded (csrc/gpu_runtime.hip), but torch
+# initialises the runtime first in this script -- so the same default goes in before that
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PCIE_GEN5_X16_GBPS = 63.0  # PCIe 5.0 x16, one direction, after 128b/130b encoding

@@ -84,6 +84,16 @@ extern "C" size_t lc_launched_kernels(char* buf, size_t cap) {
 // lc_thread_release() frees the calling thread's resources explicitly; a host that recycles runner threads calls it.
 static std::atomic<bool> gProcessExiting{false};
 static void lcMarkExiting() { gProcessExiting.store(true); }
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams beyond that share a queue and their
+// kernels run one after the other.  A Grok batch queues ~40 entries' latency-bound kernels (tiny grids, 0.3-2 ms each) on its
+// worker streams -- measured on configs[2] (profiles/round3_grok_streams.txt): 16 Ki values 6.39 ms with 8 streams on 4 queues,
+// 3.85 ms with 16 streams on 16 queues.  The variable is read when the runtime initialises, so it is set here, when the library
+// is loaded -- only if the process has not set it, and without effect if the process initialised HIP before loading the plugin.
+static const int gHwQueuesSet = [] {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    return 0;
+}();
+
 void lcRegisterExitHook() {
     static std::once_flag once;
     std::call_once(once, [] { atexit(lcMarkExiting); });
@@ -338,7 +348,7 @@ struct DecidePool {
 // One pool per STREAM SLOT of the thread: slot 0 for ordinary calls; the Grok matcher runs its entries on a few worker streams
 // (grok_device.hip) and selects slot 1.. before it queues an entry's launches, so that entries on different streams do not
 // wait for each other's decide launches.  Worker pools are a quarter of the size; all are allocated on first use.
-constexpr int kDecideSlots = 9;
+constexpr int kDecideSlots = 17;  // slot 0 + one per Grok worker stream (grok_device.hip kGrokMaxStreams)
 thread_local DecidePool tlsDecidePools[kDecideSlots];
 thread_local int tlsDecideSlot = 0;
 

@@ -327,7 +327,7 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
 
 // ------------------------------------------------------------------------------------------------ speculative path
 namespace {
-constexpr int kGrokMaxStreams = 8;
+constexpr int kGrokMaxStreams = 16;  // (LC_GROK_STREAMS; the default stays opts.streams = 8)
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
 constexpr uint32_t kGrokMaxRounds = GC_FILTERED - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
 constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1

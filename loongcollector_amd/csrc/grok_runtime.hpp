@@ -27,7 +27,7 @@ struct GrokOptions {
     // sequential path: an entry that has a relaxed screen runs its prefix screen first only when more than this many values carry
     // its literal
     uint32_t prefixScreenAbove = 65536;
-    uint32_t streams = 8;  // worker streams of the speculative path (1..8)
+    uint32_t streams = 16;  // worker streams of the speculative path (1..16)
 };
 
 // What a Grok handle keeps on the device(s) between batches: the literal index of its Match list, the table of its screens.

@@ -63,7 +63,7 @@ GrokOptions ProcessorGrokGpu::options() const {
     GrokOptions o;
     o.speculative = Speculative;
     o.prefixScreenAbove = PrefixScreenAbove < 0 ? 0u : uint32_t(std::min<int64_t>(PrefixScreenAbove, 0xFFFFFFFFll));
-    o.streams = uint32_t(std::max<int64_t>(1, std::min<int64_t>(Streams, 8)));
+    o.streams = uint32_t(std::max<int64_t>(1, std::min<int64_t>(Streams, 16)));
     return o;
 }
 

@@ -50,7 +50,7 @@ public:
     // worker streams of the speculative path
     bool Speculative = true;
     int64_t PrefixScreenAbove = 65536;
-    int64_t Streams = 8;
+    int64_t Streams = 16;  // worker streams of a batch's entries (1..16; see gpu_runtime.hip on GPU_MAX_HW_QUEUES)
     bool NoKeyError = false;
     bool NoMatchError = true;
     bool TimeoutError = true;
