@@ -509,7 +509,6 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_MIN_WAVES) void tdfa_match_kernel(co
     }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
-    const uint32_t nSlots = hdr[TD_NSLOTS];
     const uint32_t rowBytes = hdr[TD_ROW_BYTES];
     const uint32_t idCol = hdr[TD_ID_COL];
     const uint32_t regsBase = blobBytes;
