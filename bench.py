@@ -29,9 +29,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# hardware queues behind the HIP streams (default 4): the library sets this when it is loaded (csrc/gpu_runtime.hip), but torch
-# initialises the runtime first in this script -- so the same default goes in before that
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PCIE_GEN5_X16_GBPS = 63.0  # PCIe 5.0 x16, one direction, after 128b/130b encoding
@@ -516,15 +513,22 @@ def run_headline(args):
             sub = _ap.Namespace(**vars(args))
             sub.pipelines, sub.group_lines, sub.streams, sub.steps, sub.warmup = 64, 1000, 4, 20, 3
             extra["configs[3]"] = compute_multitenant(sub, dev)
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import grok_bench
-            import grok_inagent_bench
-            g = grok_bench.measure(_ap.Namespace(lines="16384,65536", steps=3, warmup=4, cpu_sample_lines=300, patterns=0,
-                                                 no_sequential_check=False, sequential=False), device_index=dev.index or 0)
-            for r in g:
-                r["config"].pop("patterns_refused", None)
-            extra["configs[2]"] = {"batches": g,
-                                   "in_agent": grok_inagent_bench.measure(_ap.Namespace(threads="1,16", group=1000, groups=20, patterns=0))}
+            # configs[2] runs in a process of its own: a process that hosts a Grok processor asks the HIP runtime for 16 hardware
+            # queues (csrc/gpu_runtime.hip lcPreferHwQueuesForGrok; the runtime reads GPU_MAX_HW_QUEUES when it initialises, and
+            # torch has initialised it in THIS process long ago).  The other legs keep the runtime's default: 16 queues cost the
+            # one-stream-per-runner-thread paths 15-20 % (profiles/round3_grok_streams.txt).
+            import subprocess
+            env = dict(os.environ)
+            env.setdefault("GPU_MAX_HW_QUEUES", "16")
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "grok_config2.py"), "--device", str(dev.index or 0)],
+                                     env=env, capture_output=True, text=True, timeout=900)
+                rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+                if out.returncode != 0 or not rows:
+                    raise RuntimeError("tools/grok_config2.py failed: " + out.stderr[-800:])
+                extra["configs[2]"] = rows[-1]
+            except subprocess.TimeoutExpired:
+                extra["configs[2]"] = {"error": "tools/grok_config2.py did not finish in 900 s"}
     # the job's only collective: ONE all-gather of the per-GPU counters (RCCL); the data path has none
     per_gpu = gather_job({"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps, "matched_last": matched,
                           "elapsed_us": int(elapsed * 1e6), "kernel_us_per_step": int(kernel_ms * 1e3)}, device=dev)

@@ -87,12 +87,11 @@ static void lcMarkExiting() { gProcessExiting.store(true); }
 // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams beyond that share a queue and their
 // kernels run one after the other.  A Grok batch queues ~40 entries' latency-bound kernels (tiny grids, 0.3-2 ms each) on its
 // worker streams -- measured on configs[2] (profiles/round3_grok_streams.txt): 16 Ki values 6.39 ms with 8 streams on 4 queues,
-// 3.85 ms with 16 streams on 16 queues.  The variable is read when the runtime initialises, so it is set here, when the library
-// is loaded -- only if the process has not set it, and without effect if the process initialised HIP before loading the plugin.
-static const int gHwQueuesSet = [] {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    return 0;
-}();
+// 3.85 ms with 16 streams on 16 queues.  The same 16 queues COST the paths that are one stream per runner thread 15-20 % at 16
+// threads (in-agent parse 18.4 -> 14.8 GB/s, fused pipeline 13.1 -> 10.5; same file).  So the library asks for them only in a
+// process that creates a Grok processor (lc_grok_create calls this), only if the process has not set the variable itself, and --
+// the runtime reads it when it initialises -- without effect once HIP is up.
+void lcPreferHwQueuesForGrok() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 void lcRegisterExitHook() {
     static std::once_flag once;

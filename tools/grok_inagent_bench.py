@@ -16,6 +16,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # a process that hosts a Grok processor (csrc/gpu_runtime.hip); before torch touches the GPU
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
