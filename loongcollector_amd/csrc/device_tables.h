@@ -40,8 +40,21 @@ enum {
     TP_ROW_BYTES = 1,  // (nClasses+1)^2 * 4
     TP_OFF_CMAPA = 2,  // u16[256]: class(b) * (nClasses+1) * 4 -- column offset contributed by the FIRST byte of a pair
                        // (the second byte contributes cmap8[b] = class * 4, the table at TD_CMAP_OFFSET)
-    TP_ID_A = 3        // nClasses * (nClasses+1) * 4: first-byte offset of the identity class
+    TP_ID_A = 3,       // nClasses * (nClasses+1) * 4: first-byte offset of the identity class
+    TP_FORMAT = 4,     // 0: two stamps per pair entry (below); 1: ONE stamp per pair entry (TP1_*, LC_TDFA_PAIR=2)
+    TP_OFF_DERIVE = 5, // format 1: offset of the DERIVE WORDS (0 = none): u32 count, then per word  b | a << 8 | delta << 16:
+                       //   at the end of a line, AFTER the fold words, register b reads as register a + delta (regex_handle.cpp
+                       //   planTdfaDerive: b is only ever stamped one byte behind a, so its own stamps were dropped)
+    TP_HEADER_WORDS = 8
 };
+// pair entry, format 1 (one stamp per byte pair; tdfa_stream_kernel.hpp tdfaStreamPair1Chunk):
+//   bits 0..15   LDS address of the next state's PAIR row
+//   bits 16..22  rA: the register the pair stamps (index; the dummy register = "none")      bit 23  its value is pos + 1 (else pos)
+//   bits 24..30  rB: DOUBLE entries only -- the second byte's register (value pos + 1; rA is then the first byte's, value pos)
+//   bit 31       DOUBLE: both bytes stamp, different registers.  The kernel writes rA in line, and -- per chunk, only when some
+//                lane of the wavefront met a DOUBLE -- rB as max(register, pos + 1) behind the chunk's rA stamps
+#define TP1_DELTA 0x00800000u
+#define TP1_DOUBLE 0x80000000u
 // pair entry: bits 0..15 LDS address of the next state's PAIR row; bits 16..23 / 24..31 register stamped by the first /
 // second byte (index; the dummy register = "none"); bit 7 of either index set = that byte carries a general register
 // program -> the chunk is replayed byte by byte on the single-byte table

@@ -181,7 +181,7 @@ template <int BLOCK, bool PAIR, bool COMPACT = false, bool BYTEROWS = false>
 static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBytes, size_t lds, const uint8_t* d_data,
                            const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t minLen, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                            int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* longFlag = nullptr, uint32_t seq = 0,
-                           uint32_t nregsWord = 0) {
+                           uint32_t nregsWord = 0, bool pairOne = false) {
     static const bool streamOff = [] {
         const char* e = getenv("LC_TDFA_STREAM");
         return e && e[0] == '0';
@@ -210,10 +210,19 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
                 if (dma) kern = noGen ? tdfa_stream_kernel<BLOCK, true, false, kTdfaNoGeneralPrograms | kLabDmaStage>
                                       : tdfa_stream_kernel<BLOCK, true, false, kLabDmaStage>;
             }
+        } else {
+            // a ONE-STAMP pair table (LC_TDFA_PAIR=2, device_tables.h TP_FORMAT 1) is only understood by the instantiation made for it
+            if (pairOne) {
+                if (streamOff) {
+                    tlsError = "one-stamp pair tables need the stream kernel (LC_TDFA_STREAM=0 is set)";
+                    return LC_ERR_UNSUPPORTED;
+                }
+                kern = tdfa_stream_kernel<BLOCK, COMPACT, true, kTdfaNoGeneralPrograms | kLabPairOne | (COMPACT ? kLabDmaStage : 0)>;
+            }
         }
     }
-    static thread_local size_t ldsAttrSet[kLcMaxDevices][5] = {};  // the attribute belongs to (function, device)
-    const int which = dma ? (noGen ? 4 : 3) : noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices][6] = {};  // the attribute belongs to (function, device)
+    const int which = (PAIR && pairOne) ? 5 : dma ? (noGen ? 4 : 3) : noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
     if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow][which]) {
@@ -231,7 +240,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    noteKernel(dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
+    noteKernel((PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
     // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)
     const uint32_t* blobArg = static_cast<const uint32_t*>(dBlob);
@@ -255,6 +264,12 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
                     &d_caps, &d_status, &longFlag, &seq, &doneCounter, &doneFlag, &doneSeq};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(BLOCK), args, lds, stream));
     return LC_OK;
+}
+
+// the byte-pair extension of a packed blob is a ONE-STAMP table (device_tables.h TP_FORMAT)
+static bool lcPairOneFormat(const std::vector<uint32_t>& blob) {
+    const uint32_t po = blob[TD_OFF_PAIR];
+    return po != 0 && po / 4 + TP_FORMAT < blob.size() && blob[po / 4 + TP_FORMAT] == 1;
 }
 
 static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
@@ -287,11 +302,11 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
         if (wb == kLcTdfaWideBlock)
             rc = launchTdfaBlock<kLcTdfaWideBlock, false, true, true>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else if (wb == 512 && re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
+            rc = launchTdfaBlock<512, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS], lcPairOneFormat(re->tdfaWideBlob));
         else if (wb == 512)
             rc = launchTdfaBlock<512, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         else if (re->tdfaWideBlob[TD_OFF_PAIR])
-            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
+            rc = launchTdfaBlock<256, true, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS], lcPairOneFormat(re->tdfaWideBlob));
         else
             rc = launchTdfaBlock<256, false, true, false>(dWide, wideBytes, wRegBytes, wLds, d_data, d_off, d_len, sep, 0, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaWideBlob[TD_NREGS]);
         if (rc != LC_OK) return rc;
@@ -309,9 +324,9 @@ static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32
     static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
     const bool pair = re->tdfaBlob[TD_OFF_PAIR] != 0 && !pairOff;
     switch (block) {
-        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
-        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
-        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
+        case 256: return pair ? launchTdfaBlock<256, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS], lcPairOneFormat(re->tdfaBlob)) : launchTdfaBlock<256, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
+        case 128: return pair ? launchTdfaBlock<128, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS], lcPairOneFormat(re->tdfaBlob)) : launchTdfaBlock<128, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
+        default: return pair ? launchTdfaBlock<64, true>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS], lcPairOneFormat(re->tdfaBlob)) : launchTdfaBlock<64, false>(dBlob, blobBytes, regBytes, lds, d_data, d_off, d_len, sep, minLen, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream, longFlag, seq, re->tdfaBlob[TD_NREGS]);
     }
 }
 

@@ -91,6 +91,179 @@ uint32_t tdfaFoldRegs(const TdfaTables& t) {
 }
 
 size_t tdfaBlobBytesEstimate(const TdfaTables& t);
+
+// ---- fixed-distance registers (one-stamp pair tables, LC_TDFA_PAIR=2).  In a log-format regex the end of field k is stamped on
+// the separator byte and the start of field k+1 on the byte behind it -- ALWAYS: two real stamps in two consecutive bytes, on every
+// line, four or five times per line.  A table that stamps once per byte PAIR cannot carry both when they fall into one pair.  Such
+// a register b is not stamped at all: it reads as a + 1 at the end of the line (device_tables.h TP_OFF_DERIVE).  Proved on the
+// automaton, for a table without general register programs (stamps(t) = the registers transition t sets to its position: one
+// register, the members of a folded set, or none):
+//   P1  every live transition t2 with b in stamps(t2) leaves a state that is no entry state and ALL of whose live incoming
+//       transitions t1 have a in stamps(t1); and a is not in stamps(t2)                 (b is only ever stamped one byte behind a)
+//   P2  every live transition t1 with a in stamps(t1) leads to a state ALL of whose live outgoing transitions t2 have b in
+//       stamps(t2), and whose final row -- if the line may end there -- does not read b      (behind a, b always follows)
+// Then, wherever a line can end with b in the final map, b == a + 1.  (live: between states the start state reaches, not into the
+// dead state.)  -> derive[k] = (b, a), in an order in which every a is settled before it is used.
+struct TdfaDerive {
+    std::vector<std::pair<uint8_t, uint8_t>> pairs;  // (b, a): b = a + 1
+    std::vector<bool> derived;                       // per register
+};
+static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
+    TdfaDerive d;
+    d.derived.assign(t.nRegs, false);
+    const size_t nLists = t.opsStart.size() - 1;
+    // stamps of a list: bit set of registers (nRegs <= 250: four words)
+    struct RegSet {
+        uint64_t w[4] = {0, 0, 0, 0};
+        void add(uint32_t r) { w[r >> 6] |= 1ull << (r & 63); }
+        bool has(uint32_t r) const { return (w[r >> 6] >> (r & 63)) & 1ull; }
+        bool empty() const { return !(w[0] | w[1] | w[2] | w[3]); }
+    };
+    std::vector<RegSet> stamps(nLists);
+    for (size_t id = 1; id < nLists; ++id) {
+        const uint32_t at = t.opsStart[id];
+        const uint32_t n = t.ops[at];
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint16_t w = t.ops[at + 1 + k];
+            if ((w >> 8) != kRegPos) return d;  // a copy: no derivation on tables with general programs
+            stamps[id].add(w & 0xFFu);
+        }
+        if (n >= 2 && !(fold.ok && fold.listSet[id] >= 0)) return d;  // a multi-stamp list that is not folded stays general
+    }
+    const uint32_t nS = t.nStates, nC = t.nClasses;
+    // reachable states and entry states
+    std::vector<char> reach(nS, 0), entry(nS, 0);
+    std::vector<uint32_t> stack;
+    auto seed = [&](uint32_t s0) {
+        if (s0 == 0 || s0 >= nS) return;
+        entry[s0] = 1;
+        if (!reach[s0]) {
+            reach[s0] = 1;
+            stack.push_back(s0);
+        }
+    };
+    seed(t.startState);
+    for (uint32_t s0 : t.startAfter) seed(s0);
+    while (!stack.empty()) {
+        const uint32_t s = stack.back();
+        stack.pop_back();
+        for (uint32_t c = 0; c < nC; ++c) {
+            const uint32_t nx = t.trans[size_t(s) * nC + c] & 0xFFFFu;
+            if (nx && !reach[nx]) {
+                reach[nx] = 1;
+                stack.push_back(nx);
+            }
+        }
+    }
+    // per state: the intersection of the stamps of its live incoming transitions (entry states: empty), and whether it has any
+    std::vector<RegSet> inAll(nS);
+    std::vector<char> hasIn(nS, 0);
+    for (uint32_t s = 1; s < nS; ++s) {
+        if (!reach[s]) continue;
+        for (uint32_t c = 0; c < nC; ++c) {
+            const uint32_t e = t.trans[size_t(s) * nC + c];
+            const uint32_t nx = e & 0xFFFFu;
+            if (!nx) continue;
+            const RegSet& st = stamps[e >> 16];
+            if (!hasIn[nx]) {
+                inAll[nx] = st;
+                hasIn[nx] = 1;
+            } else {
+                for (int k = 0; k < 4; ++k) inAll[nx].w[k] &= st.w[k];
+            }
+        }
+    }
+    for (uint32_t s = 1; s < nS; ++s)
+        if (entry[s]) inAll[s] = RegSet();
+    // per state: the intersection of the stamps of its live outgoing transitions
+    std::vector<RegSet> outAll(nS);
+    std::vector<char> hasOut(nS, 0);
+    for (uint32_t s = 1; s < nS; ++s) {
+        if (!reach[s]) continue;
+        for (uint32_t c = 0; c < nC; ++c) {
+            const uint32_t e = t.trans[size_t(s) * nC + c];
+            if (!(e & 0xFFFFu)) continue;
+            const RegSet& st = stamps[e >> 16];
+            if (!hasOut[s]) {
+                outAll[s] = st;
+                hasOut[s] = 1;
+            } else {
+                for (int k = 0; k < 4; ++k) outAll[s].w[k] &= st.w[k];
+            }
+        }
+    }
+    auto finalReads = [&](uint32_t s, uint32_t r) {
+        const uint32_t fid = t.finalId[s];
+        if (fid == 0xFFFFu) return false;
+        for (uint32_t sl = 0; sl < t.nSlots; ++sl)
+            if (t.finalMap[size_t(fid) * t.nSlots + sl] == r) return true;
+        return false;
+    };
+    std::vector<int> base(t.nRegs, -1);  // derived b -> its a
+    for (uint32_t b = 0; b < t.nRegs; ++b) {
+        // P1: candidates = intersection over every transition that stamps b of inAll[source]; none of them may stamp the candidate
+        RegSet cand;
+        bool any = false, ok = true;
+        RegSet alsoStamped;  // registers stamped together with b somewhere: not candidates
+        for (uint32_t s = 1; s < nS && ok; ++s) {
+            if (!reach[s]) continue;
+            for (uint32_t c = 0; c < nC; ++c) {
+                const uint32_t e = t.trans[size_t(s) * nC + c];
+                if (!(e & 0xFFFFu) || !stamps[e >> 16].has(b)) continue;
+                if (entry[s] || !hasIn[s]) {
+                    ok = false;
+                    break;
+                }
+                if (!any) {
+                    cand = inAll[s];
+                    any = true;
+                } else {
+                    for (int k = 0; k < 4; ++k) cand.w[k] &= inAll[s].w[k];
+                }
+                for (int k = 0; k < 4; ++k) alsoStamped.w[k] |= stamps[e >> 16].w[k];
+            }
+        }
+        if (!ok || !any) continue;
+        for (int k = 0; k < 4; ++k) cand.w[k] &= ~alsoStamped.w[k];
+        for (uint32_t a = 0; a < t.nRegs && base[b] < 0; ++a) {
+            if (a == b || !cand.has(a)) continue;
+            // no cycle: a must not (transitively) read b
+            bool cyc = false;
+            for (int x = int(a), hops = 0; x >= 0 && hops <= int(t.nRegs); x = base[size_t(x)], ++hops)
+                if (uint32_t(x) == b) cyc = true;
+            if (cyc) continue;
+            // P2
+            bool p2 = true;
+            for (uint32_t s = 1; s < nS && p2; ++s) {
+                if (!reach[s]) continue;
+                for (uint32_t c = 0; c < nC; ++c) {
+                    const uint32_t e = t.trans[size_t(s) * nC + c];
+                    const uint32_t nx = e & 0xFFFFu;
+                    if (!nx || !stamps[e >> 16].has(a)) continue;
+                    if ((hasOut[nx] && !outAll[nx].has(b)) || finalReads(nx, b)) {
+                        p2 = false;
+                        break;
+                    }
+                }
+            }
+            if (p2) base[b] = int(a);
+        }
+    }
+    // order: every a settled before it is used
+    std::vector<char> done(t.nRegs, 0);
+    for (uint32_t r = 0; r < t.nRegs; ++r) done[r] = base[r] < 0;
+    for (bool progress = true; progress;) {
+        progress = false;
+        for (uint32_t b = 0; b < t.nRegs; ++b)
+            if (!done[b] && done[size_t(base[b])]) {
+                d.pairs.push_back({uint8_t(b), uint8_t(base[b])});
+                d.derived[b] = true;
+                done[b] = 1;
+                progress = true;
+            }
+    }
+    return d;
+}
 }  // namespace lcregex
 
 // Workgroup size of the standard tables, and whether they fold their multi-stamp programs: the fold's extra registers must not
@@ -112,8 +285,8 @@ size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
                pad(size_t(kMaxTdfaRegs) * 4 + 4);  // (+ the fold words of folded register programs)
     const size_t pairBytes = size_t(t.nStates) * (t.nClasses + 1) * (t.nClasses + 1) * 4;
     const char* pairEnv = getenv("LC_TDFA_PAIR");
-    if (pairEnv && pairEnv[0] == '1' && pairBytes <= TP_MAX_TABLE_BYTES)
-        n += 512 + pad(pairBytes) + 16;  // packTdfaBlob's byte-pair extension
+    if (pairEnv && (pairEnv[0] == '1' || pairEnv[0] == '2') && pairBytes <= TP_MAX_TABLE_BYTES)
+        n += 512 + pad(pairBytes) + 32 + pad(size_t(kMaxTdfaRegs) * 4 + 4);  // packTdfaBlob's byte-pair extension (+ derive words)
     return n;
 }
 
@@ -130,6 +303,34 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
     *forcedOut = env != nullptr;
     *packedRegsOut = t.nRegs;
     const uint32_t foldRegs = tdfaFoldRegs(t);
+    // Default (neither LC_TDFA_COMPACT nor LC_TDFA_PAIR set), round 3: small automata whose byte-pair table is a ONE-STAMP table with
+    // few DOUBLE entries take 512 lanes and that table -- the capture stamp is issued once per two bytes (headline batch: 0.2025 ->
+    // 0.1915 ms, profiles/round3_lab_pair1.txt).  "Few": a DOUBLE is settled by a read-modify-write behind its chunk, for the whole
+    // wavefront; regex A keeps 0.7 % of its entries as DOUBLEs after the fixed-distance registers are derived (one-byte fields),
+    // regex B 2.3 % (fields that may be empty on both sides of a separator) -- B stays on the single-byte table.
+    if (!env && !getenv("LC_TDFA_PAIR")) {
+        for (int fold = foldRegs ? 1 : 0; fold >= 0; --fold) {
+            const uint32_t packedRegs = t.nRegs + (fold ? foldRegs : 0u);
+            try {
+                if (size_t(packedRegs + 1) * 512 * 2 > TD_MAX_REG_AREA) continue;
+                std::vector<uint32_t> blob = packTdfaBlob(t, 512, false, true, fold != 0, 2);
+                const uint32_t po = blob[TD_OFF_PAIR];
+                if (!po || blob[po / 4 + TP_FORMAT] != 1) break;  // (general programs, or the pair table is too large)
+                if (lcTdfaCompactLdsBytes(uint32_t(blob.size() * 4), packedRegs, 512) * 2 > kLcLdsPerCu) break;  // two workgroups per CU
+                const uint32_t cols = t.nClasses + 1;
+                const uint32_t* pair = blob.data() + blob[po / 4 + TP_BASE] / 4;
+                size_t doubles = 0;
+                const size_t entries = size_t(t.nStates) * cols * cols;
+                for (size_t i = 0; i < entries; ++i) doubles += pair[i] >> 31;
+                if (doubles * 100 > entries) break;  // more than 1 % DOUBLE entries
+                *blockOut = 512;
+                *packedRegsOut = packedRegs;
+                return blob;
+            } catch (const RegexError&) {
+                break;
+            }
+        }
+    }
     // (the fold costs registers: tables that only fit without it are packed without it)
     for (int fold = foldRegs ? 1 : 0; fold >= 0; --fold) {
         const uint32_t packedRegs = t.nRegs + (fold ? foldRegs : 0u);
@@ -160,7 +361,7 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
     return {};
 }
 
-std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact, bool foldPrograms) {
+std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bool compact, bool foldPrograms, int pairMode) {
     // wide: rows indexed by the byte itself (256 columns + identity); compact: 16-bit offset registers (tdfa_kernel.hpp)
     const uint32_t cols = (wide ? 256 : t.nClasses) + 1;  // + identity column
     const uint32_t rowBytes = cols * 4;
@@ -230,13 +431,28 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
     const uint64_t pairBytes = pairRowBytes * t.nStates;
     // Opt-in (LC_TDFA_PAIR=1 when the pattern is compiled): measured on the headline corpus it buys ~10 % at equal
     // occupancy, but the 20 KiB table costs one of the three resident workgroups per CU.
-    const char* pairEnv = getenv("LC_TDFA_PAIR");
-    if (!wide && pairEnv && pairEnv[0] == '1' && pairBytes <= TP_MAX_TABLE_BYTES && dummyReg < TP_GENERAL) {
+    if (pairMode < 0) {
+        const char* pairEnv = getenv("LC_TDFA_PAIR");
+        pairMode = (pairEnv && (pairEnv[0] == '1' || pairEnv[0] == '2')) ? pairEnv[0] - '0' : 0;
+    }
+    const bool pairOne = pairMode == 2;  // ONE stamp per pair entry (device_tables.h TP1_*)
+    bool anyGeneralList = false;
+    for (size_t id = 1; id < nLists; ++id) anyGeneralList = anyGeneralList || (field[id] & TD_OP_GENERAL);
+    if (!wide && (pairMode == 1 || (pairOne && !anyGeneralList)) && pairBytes <= TP_MAX_TABLE_BYTES && dummyReg < TP_GENERAL) {
         std::vector<uint16_t> cmapA(256);
         for (int b = 0; b < 256; ++b) cmapA[size_t(b)] = uint16_t(t.classMap[size_t(b)] * cols * 4);
         const uint32_t cmapAOff = w.put(cmapA);
         const uint32_t pairBase = w.reserve(size_t(pairBytes));
         if (uint64_t(pairBase) + pairBytes <= TD_MAX_TABLE_END) {
+            // registers that read as another one + 1 at the end of the line: their own stamps are dropped from the pair table
+            const TdfaDerive derive = pairOne ? planTdfaDerive(t, fold) : TdfaDerive();
+            std::vector<char> dropList(nLists, 0);
+            if (pairOne) {
+                for (size_t id = 1; id < nLists; ++id) {
+                    const uint32_t at = t.opsStart[id];
+                    if (t.ops[at] == 1 && (t.ops[at + 1] >> 8) == kRegPos && derive.derived[t.ops[at + 1] & 0xFFu]) dropList[id] = 1;
+                }
+            }
             // one single-byte step: next state + what it stamps (register index, dummy, or "general")
             auto step = [&](uint32_t s, uint32_t c, uint32_t& next, uint32_t& stamp) {
                 if (c == t.nClasses) {  // identity class: bytes outside the line
@@ -247,7 +463,7 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
                 const uint32_t e = t.trans[size_t(s) * t.nClasses + c];
                 next = e & 0xFFFF;
                 const uint32_t f = field[e >> 16];
-                stamp = (f & TD_OP_GENERAL) ? TP_GENERAL : f / regStride;
+                stamp = (f & TD_OP_GENERAL) ? TP_GENERAL : dropList[e >> 16] ? dummyReg : f / regStride;
             };
             uint32_t* pair = reinterpret_cast<uint32_t*>(w.bytes.data() + pairBase);
             for (uint32_t s = 0; s < t.nStates; ++s)
@@ -256,10 +472,31 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
                         uint32_t s1, s2, st1, st2;
                         step(s, c1, s1, st1);
                         step(s1, c2, s2, st2);
-                        pair[(size_t(s) * cols + c1) * cols + c2] =
-                            (pairBase + s2 * uint32_t(pairRowBytes)) | (st1 << 16) | (st2 << 24);
+                        uint32_t hi;
+                        if (!pairOne) {
+                            hi = st1 | (st2 << 8);
+                        } else if (st2 == dummyReg) {
+                            hi = st1;  // (the first byte's register, or nothing)
+                        } else if (st1 == dummyReg || st1 == st2) {
+                            hi = st2 | (TP1_DELTA >> 16);
+                        } else {
+                            hi = st1 | (st2 << 8) | (TP1_DOUBLE >> 16);
+                        }
+                        pair[(size_t(s) * cols + c1) * cols + c2] = (pairBase + s2 * uint32_t(pairRowBytes)) | (hi << 16);
                     }
-            const std::vector<uint32_t> ph = {pairBase, uint32_t(pairRowBytes), cmapAOff, t.nClasses * cols * 4};
+            std::vector<uint32_t> ph(TP_HEADER_WORDS, 0u);
+            ph[TP_BASE] = pairBase;
+            ph[TP_ROW_BYTES] = uint32_t(pairRowBytes);
+            ph[TP_OFF_CMAPA] = cmapAOff;
+            ph[TP_ID_A] = t.nClasses * cols * 4;
+            if (pairOne) {
+                ph[TP_FORMAT] = 1;
+                if (!derive.pairs.empty()) {
+                    std::vector<uint32_t> words{uint32_t(derive.pairs.size())};
+                    for (const auto& ba : derive.pairs) words.push_back(uint32_t(ba.first) | (uint32_t(ba.second) << 8) | (1u << 16));
+                    ph[TP_OFF_DERIVE] = w.put(words);
+                }
+            }
             hdr[TD_OFF_PAIR] = w.put(ph);
         }
     }

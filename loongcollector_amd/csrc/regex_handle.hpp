@@ -60,8 +60,10 @@ void lcNoteGaveUp(uint64_t n);
 namespace lcregex {
 // `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
 // foldPrograms: multi-stamp register programs become stamps of set registers when every program of the table allows it
+// pairMode: the byte-pair extension -- -1: what LC_TDFA_PAIR says (unset / 0: none, 1: two stamps per entry, 2: one stamp);
+// 0 / 1 / 2: that, whatever the environment says
 std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide = false, bool compact = false,
-                                   bool foldPrograms = true);
+                                   bool foldPrograms = true, int pairMode = -1);
 uint32_t tdfaFoldRegs(const TdfaTables& t);  // registers that fold adds per line (0 = nothing to fold)
 // tables of the COMPACT kernel variant (LC_TDFA_COMPACT picks it; empty: switched off, or the automaton is too large)
 std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool* forcedOut, uint32_t* packedRegsOut);

@@ -92,7 +92,8 @@ enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 
        kLabOneStamp = 128 /* byte-pair chunks only: one stamp per pair (timing only) */,
        kLabDmaStage = 256 /* tdfa_stream_kernel, COMPACT: the staging tile is filled by global_load_lds_dwordx4 (no staging VGPRs) */,
        kLabWaves5 = 512 /* tdfa_stream_kernel: register budget of 5 waves per SIMD (96 VGPRs) */,
-       kLabNoDmaWait = 1024 /* DMA staging without the wait for the stage (wrong bytes: timing only -- what the wave loses there) */ };
+       kLabNoDmaWait = 1024 /* DMA staging without the wait for the stage (wrong bytes: timing only -- what the wave loses there) */,
+       kLabPairOne = 4096 /* byte-pair chunks on a ONE-STAMP pair table (device_tables.h TP1_*, LC_TDFA_PAIR=2): exact */ };
 constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 
 // general register program (a list of moves); rare for log regexes
@@ -282,6 +283,21 @@ __device__ __forceinline__ void tdfaWriteResults(uint8_t* smem, uint32_t tileAdd
                         }
                     }
                 }
+            }
+        }
+    }
+    if constexpr ((LAB & kLabPairOne) != 0) {
+        // one-stamp pair tables: a register that is only ever stamped one byte behind another one lost its own stamps and reads
+        // as that one + delta (device_tables.h TP_OFF_DERIVE; in table order: every source is settled before it is used)
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(smem + hdr[TD_OFF_PAIR]);
+        const uint32_t dOff = ph[TP_OFF_DERIVE];
+        if (dOff) {
+            const uint32_t* dw = reinterpret_cast<const uint32_t*>(smem + dOff);
+            TdfaReg* rw = reinterpret_cast<TdfaReg*>(smem + regsBase) + tdfaRegLane<TdfaReg>(tid);
+            const uint32_t nWords = __builtin_amdgcn_readfirstlane(dw[0]);
+            for (uint32_t i = 0; i < nWords; ++i) {
+                const uint32_t w = __builtin_amdgcn_readfirstlane(dw[1 + i]);
+                rw[(w & 0xFFu) * BLOCK] = TdfaReg(rw[((w >> 8) & 0xFFu) * BLOCK] + TdfaReg(w >> 16));
             }
         }
     }

@@ -124,6 +124,68 @@ __device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32
     return t;
 }
 
+// ONE-STAMP pair tables (device_tables.h TP1_*, regex_handle.cpp: LC_TDFA_PAIR=2).  A pair entry names ONE register (rA) and
+// whether it takes the position of the pair's first or second byte; the capture stamp -- the dearest LDS instruction of the walk
+// (4 cycles: address + data) -- is issued once per TWO bytes.  Registers that are always stamped one byte behind another one (end
+// of field k on the separator, start of field k+1 behind it: every line, several times) have no stamps of their own (derive words,
+// applied with the results).  What is left are DOUBLE entries (a one-byte field: begin and end stamped in consecutive bytes that
+// happen to share a pair): rA is the first byte's register, and the second one's (rB) is settled behind the chunk's stamps as
+// max(register, pos + 1) -- only in chunks in which some lane of the wavefront met a DOUBLE.  Positions only grow along a line
+// and registers start at 0, so "latest" is "largest" and the order of the two kinds of store among themselves does not matter:
+// tests/helpers/table_interp.py TdfaPair1Interp is this function, store for store.
+template <int BLOCK, int NB, bool CHECKED, typename TdfaReg>
+__device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint32_t (&colp)[NB / 2], uint32_t (&na)[NB / 2],
+                                                         uint32_t (&nc)[NB / 2], const uint32_t (&nwords)[NB / 4], uint32_t nbase,
+                                                         uint32_t L, uint32_t cmapA, uint32_t idAAddr,
+                                                         const uint32_t (&ptt)[NB / 2], uint32_t (&tt)[NB / 2], uint32_t pbase,
+                                                         uint32_t regAddr0) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
+    constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                   (sizeof(TdfaReg) == 2 ? 1 : 0);  // log2(BLOCK * sizeof(TdfaReg))
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) {
+        t = *reinterpret_cast<LdsWordPtr>(addLowHalf(colp[p], t));
+        tt[p] = t;
+        uint32_t b0, b1;
+        asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b0) : "v"(nwords[p >> 1]), "n"((p & 1) * 16));
+        asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b1) : "v"(nwords[p >> 1]), "n"((p & 1) * 16 + 8));
+        if constexpr (CHECKED) {
+            na[p] = *reinterpret_cast<LdsHalfPtr>((nbase + 2 * p < L) ? cmapA + b0 * 2 : idAAddr);
+            nc[p] = *reinterpret_cast<LdsBytePtr>((nbase + 2 * p + 1 < L) ? TD_CMAP_OFFSET + b1 : kTdfaIdColByteAddr);
+        } else {
+            na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
+            nc[p] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b1);
+        }
+        // the previous chunk's pair p: ONE stamp
+        const uint32_t ra = (ptt[p] >> 16) & 0x7Fu;
+        *reinterpret_cast<LdsRegPtr>(regAddr0 + (ra << kRegShift)) = TdfaReg(pbase + uint32_t(2 * p) + ((ptt[p] >> 23) & 1u));
+#ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return t;
+}
+// the second registers of the DOUBLE entries among ptt[] (the pairs at line offset pbase, pbase + 2, ...): behind their chunk's stamps
+template <int BLOCK, int NP, typename TdfaReg>
+__device__ __forceinline__ void tdfaSettleDoubles(const uint32_t (&ptt)[NP], uint32_t pbase, uint32_t regAddr0) {
+    typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
+    constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                   (sizeof(TdfaReg) == 2 ? 1 : 0);
+    uint32_t any = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) any |= ptt[p];
+    if (!__any(int32_t(any) < 0)) return;  // (the usual case: no lane of the wavefront met a DOUBLE in this chunk)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (int32_t(ptt[p]) < 0) {
+            const LdsRegPtr reg = reinterpret_cast<LdsRegPtr>(regAddr0 + (((ptt[p] >> 24) & 0x7Fu) << kRegShift));
+            const TdfaReg val = TdfaReg(pbase + uint32_t(2 * p) + 1u);
+            const TdfaReg cur = *reg;
+            *reg = cur > val ? cur : val;
+        }
+    }
+}
+
 // ---- LDS-DMA staging (kLabDmaStage; COMPACT tiles only: rows of exactly 64 bytes).  global_load_lds_dwordx4 writes the 16 bytes
 // of lane l at (wave-uniform LDS base in M0) + 16 * l, so one instruction fills 16 rows of the tile: lane l carries position
 // l % 4 of row l / 4.  The tile is XOR-swizzled (segment g of row r sits at position g ^ ((r >> 1) & 3)), and the destination
@@ -159,6 +221,8 @@ __device__ __forceinline__ void tdfaStreamBody(
     constexpr uint32_t kRowStride = COMPACT ? kTdfaStageBytes : kTdfaRowStride;  // (tdfa_match_kernel's two tile layouts)
     constexpr uint32_t kStagePerWave = 64 * kRowStride;
     constexpr bool DMA = COMPACT && (LAB & kLabDmaStage) != 0 && kTdfaStageBytes == 64;
+    constexpr bool PAIR1 = PAIR && (LAB & kLabPairOne) != 0;  // the pair table is a ONE-STAMP table (the launcher checks TP_FORMAT)
+    static_assert(!PAIR1 || (LAB & kLabNoGeneral) != 0, "one-stamp pair tables have no general register programs");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     if (nLinesPtr) {
@@ -192,6 +256,12 @@ __device__ __forceinline__ void tdfaStreamBody(
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
         tdfaClearRegisters<BLOCK>(smem, blob, blobBytes, regBytes);
+        if constexpr (PAIR1) {  // ("latest stamp" = "largest offset" for the settled doubles: every register starts at 0)
+            if (((blob[TD_NREGS] >> 16) & 0x1FFFu) == 0) {
+                uint32_t* regs = reinterpret_cast<uint32_t*>(smem + blobBytes);
+                for (uint32_t i = threadIdx.x; i < regBytes / 4; i += BLOCK) regs[i] = 0;
+            }
+        }
     }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(smem);
@@ -199,7 +269,7 @@ __device__ __forceinline__ void tdfaStreamBody(
     const uint32_t idCol = hdr[TD_ID_COL];
     const uint32_t regsBase = blobBytes;
     // a transition that stamps the dummy register (the last one) and nothing else
-    const uint32_t dummyT = PAIR ? ((hdr[TD_NREGS] & 0xFFFFu) - 1) * 0x01010000u : (((hdr[TD_NREGS] & 0xFFFFu) - 1) * BLOCK * uint32_t(sizeof(TdfaReg))) << 16;
+    const uint32_t dummyT = PAIR1 ? ((hdr[TD_NREGS] & 0xFFFFu) - 1) << 16 : PAIR ? ((hdr[TD_NREGS] & 0xFFFFu) - 1) * 0x01010000u : (((hdr[TD_NREGS] & 0xFFFFu) - 1) * BLOCK * uint32_t(sizeof(TdfaReg))) << 16;
     uint32_t t = hdr[TD_START_ROW];
     TdfaPairInfo pi{};
     uint32_t idAAddr = 0;  // LDS address of a u16 that holds pi.idA (the first-byte offset of the identity class)
@@ -370,7 +440,16 @@ __device__ __forceinline__ void tdfaStreamBody(
             }
             uint32_t ncol[NC], tt[NC], seen;
             bool general;
-            if constexpr (PAIR) {
+            if constexpr (PAIR1) {
+                uint32_t na[NC], nc[NC];
+                if (__all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) ncol[j] = na[j] + nc[j];
+                seen = 0;
+                general = false;
+            } else if constexpr (PAIR) {
                 uint32_t na[NC], nc[NC];
                 if (__all(fullNext)) t = tdfaStreamPairChunk<BLOCK, NB, false, TdfaReg, LAB>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
                 else t = tdfaStreamPairChunk<BLOCK, NB, true, TdfaReg, LAB>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, seen);
@@ -415,7 +494,14 @@ __device__ __forceinline__ void tdfaStreamBody(
         if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
     if constexpr (DMA) tdfaDmaWait();  // (a stage in flight when the loop was left would land in the result tile)
-    if constexpr ((LAB & kLabNoStamp) == 0) {  // the last chunk's stamps
+    if constexpr (PAIR1) {  // the last chunk's stamps
+        constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                       (sizeof(TdfaReg) == 2 ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (((ptt[j] >> 16) & 0x7Fu) << kRegShift)) = TdfaReg(pbase + 2 * j + ((ptt[j] >> 23) & 1u));
+        tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
+    } else if constexpr ((LAB & kLabNoStamp) == 0) {  // the last chunk's stamps
         if constexpr (PAIR) {
             constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
                                            (sizeof(TdfaReg) == 2 ? 1 : 0);

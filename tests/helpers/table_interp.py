@@ -225,6 +225,76 @@ class TdfaBlobInterp:
         return caps
 
 
+class TdfaPair1Interp(TdfaBlobInterp):
+    """The ONE-STAMP byte-pair table of a compact blob (LC_TDFA_PAIR=2; device_tables.h TP1_*), walked as the pair kernel walks it:
+    pairs and 8-byte chunks are aligned in MEMORY (`head` = the line's offset in its first aligned 16 bytes), a pair entry stamps
+    rA in line (value pos, or pos + 1 with the DELTA bit), the second register of a DOUBLE entry is settled behind its chunk as
+    max(register, pos + 1), registers start at 0, and at the end of the line the fold words and then the DERIVE words apply
+    (register b reads as a + delta: its own stamps were dropped from the table, regex_handle.cpp planTdfaDerive)."""
+
+    def __init__(self, rx):
+        super().__init__(rx, compact=True)
+        po = int(self.blob[7])
+        assert po, "the blob carries no byte-pair extension"
+        ph = [int(x) for x in self.blob[po // 4:po // 4 + 8]]
+        self.p_base, self.p_row, off_cmapa, self.p_ida, fmt, off_derive = ph[:6]
+        assert fmt == 1, "not a one-stamp pair table"
+        self.cmapa = self.raw[off_cmapa:off_cmapa + 512].view(np.uint16)
+        self.derive = []
+        if off_derive:
+            n = int(self.blob[off_derive // 4])
+            self.derive = [(int(w) & 0xFF, (int(w) >> 8) & 0xFF, int(w) >> 16) for w in self.blob[off_derive // 4 + 1:off_derive // 4 + 1 + n]]
+        self.doubles = 0
+
+    @_with_run_captures
+    def fullmatch_pair1(self, s: bytes, head=0, chunk=8):
+        assert self.start_after is None or True
+        L = len(s)
+        dummy = self.nregs - 1
+        regs = [0] * self.nregs
+        state_row = self.p_base + (self.start_row - 320) // self.row_bytes * self.p_row
+        id_col = self.id_col                                  # byte offset of the identity column in a single-byte row
+        total = head + L if L else 0
+        self.doubles = 0
+        m = 0
+        while m * chunk < total:
+            pending = []                                      # DOUBLE entries of this chunk: (rB, value)
+            for p in range(chunk // 2):
+                i0 = m * chunk + 2 * p
+                inside0, inside1 = head <= i0 < total, head <= i0 + 1 < total
+                ca = int(self.cmapa[s[i0 - head]]) if inside0 else self.p_ida
+                cb = int(self.cmap[s[i0 + 1 - head]]) if inside1 else id_col
+                e = int(self.blob[(state_row + ca + cb) // 4])
+                state_row = e & 0xFFFF
+                pbase = i0 - head                             # line offset of the pair's first byte
+                ra, delta = (e >> 16) & 0x7F, (e >> 23) & 1
+                if ra != dummy:
+                    assert 0 <= pbase + delta < L
+                    regs[ra] = (pbase + delta) & 0xFFFF
+                if e >> 31:
+                    pending.append(((e >> 24) & 0x7F, (pbase + 1) & 0xFFFF))
+            for rb, val in pending:                           # behind the chunk's rA stamps
+                regs[rb] = max(regs[rb], val)
+                self.doubles += 1
+            m += 1
+        for w in self.fold or ():
+            for k in (1, 2, 3):
+                r = (w >> (8 * k)) & 0xFF
+                if r != 0xFF:
+                    regs[r] = max(regs[r], regs[w & 0xFF])
+        for b, a, delta in self.derive:
+            regs[b] = (regs[a] + delta) & 0xFFFF
+        state = (state_row - self.p_base) // self.p_row
+        fid = int(self.final_id[state])
+        if state == 0 or fid == 0xFFFF:
+            return None
+        caps = []
+        for sl in range(self.nslots):
+            mm = int(self.final_map[fid * self.nslots + sl])
+            caps.append(L if mm == 0xFF else -1 if mm == 0xFE else regs[mm])
+        return caps
+
+
 class TdfaL2BlobInterp:
     """Walks the blob of the global-memory TDFA kernel (csrc/tdfa_l2_layout.h) exactly as tdfa_l2_kernel does: automata too
     large for the LDS kernels."""

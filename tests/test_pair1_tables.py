@@ -1,0 +1,93 @@
+"""ONE-STAMP byte-pair tables (regex_handle.cpp planTdfaDerive + packTdfaBlob pairMode 2; device_tables.h TP1_*): what the compact
+512-lane kernel walks by default for small automata since round 3.  The walk of tdfaStreamPair1Chunk / tdfaSettleDoubles is restated
+store for store in tests/helpers/table_interp.py TdfaPair1Interp; here it is pinned against the single-byte walk of the same blob and
+against the oracle, for every alignment of the line in memory (pairs and chunks are aligned in memory, not in the line).  The kernel
+itself is compared with the oracle in the GPU suite (and was, bit-exact, in profiles/round3_lab_pair1.txt)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from loongcollector_amd import binding as B, corpus
+from oracle.oracle import OracleRegex
+from tests.helpers.table_interp import TdfaBlobInterp, TdfaPair1Interp
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pair1(rx):
+    blob = rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32)
+    if blob is None or not int(blob[7]):
+        return None
+    po = int(blob[7]) // 4
+    return TdfaPair1Interp(rx) if int(blob[po + 4]) == 1 else None
+
+
+def test_default_tables_of_the_headline_regex_are_one_stamp_pair_tables():
+    rx = B.GpuRegex(corpus.REGEX_A)
+    blob = rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32)
+    assert int(blob[15]) == 512 and int(blob[7]) != 0           # TD_BLOCK, TD_OFF_PAIR
+    it = _pair1(rx)
+    assert it is not None
+    # end of field k on the separator, start of field k+1 on the byte behind it: the start registers are derived, not stamped
+    assert sorted((b, a, d) for b, a, d in it.derive) == [(6, 5, 1), (10, 9, 1), (12, 11, 1), (14, 13, 1)]
+    # the benchmark regex keeps too many DOUBLE entries (fields that may be empty on both sides of a separator): single-byte tables
+    blob_b = B.GpuRegex(corpus.REGEX_B).table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32)
+    assert int(blob_b[15]) == 256 and int(blob_b[7]) == 0
+    # the standard tables (small batches, the in-agent shape, the multi-tenant launch) are untouched
+    std = rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32)
+    assert int(std[7]) == 0
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_pair_walk_equals_single_byte_walk_and_oracle_on_the_bench_corpus(kind, monkeypatch):
+    if kind == "B":
+        monkeypatch.setenv("LC_TDFA_PAIR", "2")                 # (B does not take the pair table by default: forced, it must still be exact)
+        monkeypatch.setenv("LC_TDFA_COMPACT", "512")
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    rx = B.GpuRegex(pattern)
+    p1, plain = _pair1(rx), TdfaBlobInterp(rx, compact=True)
+    assert p1 is not None
+    data, off, length = corpus.apache_batch(160, kind, poison_every=7, empty_every=3)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    lines = [bytes(data[off[i]:off[i] + length[i]]) for i in range(160)]
+    lines += [b"", b"x", b'1 - - [t z] "G /" 0 1 2 - "-" "-"', b'1.1 a b [x y] "GET " 0.1 12 200 5 "" ""',
+              b'9 - - [a b] "P u" 1 2 3 4 "r" "b"', b'a b c [d] "e f g" h i "j" "k"', b'a b c [] " " h i "" ""']
+    doubles = 0
+    for i, s in enumerate(lines):
+        want = plain.fullmatch(s)
+        if i < 160:
+            assert (want is not None) == bool(exp_status[i]) and (want is None or want == [int(v) for v in exp_caps[i]])
+        for head in range(16):
+            assert p1.fullmatch_pair1(s, head=head) == want, (kind, i, head, s[:60])
+            doubles += p1.doubles
+    assert doubles > 0                                          # (the settled-double path ran)
+
+
+def test_pair_walk_on_the_golden_patterns_that_take_a_pair_table(monkeypatch):
+    """every golden full-match pattern whose automaton takes a one-stamp pair table when asked to (small, no general register
+    program): the pair walk against the vectors' captures (PCRE1 and CPython re agree on them), three alignments each"""
+    monkeypatch.setenv("LC_TDFA_PAIR", "2")
+    monkeypatch.setenv("LC_TDFA_COMPACT", "512")
+    with open(os.path.join(GOLDEN, "regex_golden.json"), encoding="utf-8") as f:
+        golden = json.load(f)
+    took = checked = 0
+    for c in golden["cases"]:
+        try:
+            rx = B.GpuRegex(c["p"].encode("latin-1"))
+        except B.RegexUnsupportedError:
+            continue
+        if rx.info()["engine"] != B.LC_ENGINE_TDFA:
+            continue
+        p1 = _pair1(rx)
+        if p1 is None:
+            continue
+        took += 1
+        for sub, want in c["subs"][:10]:
+            s = sub.encode("latin-1")
+            exp = None if want is None else [int(v) for v in want[2:]]      # (the vectors carry group 0 first)
+            for head in (0, 5, 15):
+                assert p1.fullmatch_pair1(s, head=head) == exp, (c["p"], s[:40], head)
+                checked += 1
+    assert took >= 20 and checked >= 500, (took, checked)

@@ -252,6 +252,15 @@ int main(int argc, char** argv) {
     if (kTdfaStageBytes == 64) RUN(256, 0, "compact 256 (product)");
 #define RUNS(B, L, NAME) runVariant<B, L, false, true>(NAME, in, d, &refCaps, &refStatus, iters)
 #define RUNSP(B, L, NAME) runVariant<B, L, true, true>(NAME, in, d, &refCaps, &refStatus, iters)
+    if (in.blob[TD_OFF_PAIR] && in.blob[in.blob[TD_OFF_PAIR] / 4 + TP_FORMAT] == 1) {  // a ONE-STAMP pair table (LC_TDFA_PAIR=2)
+        runVariant<512, kLabNoGeneral | kLabDmaStage, false, true, false>("stream 512 single, nogen, DMA", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabPairOne, false, true, true>("stream 512 PAIR1 (one stamp/pair)", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabPairOne | kLabDmaStage, false, true, true>("stream 512 PAIR1, DMA", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabPairOne | kLabDmaStage, false, true, true>("stream 512 PAIR1, DMA (again)", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabPairOne | kLabDmaStage | kLabNoOutput, false, true, true>("stream 512 PAIR1, DMA, no output", in, d, &refCaps, &refStatus, iters);
+        runVariant<512, kLabNoGeneral | kLabPairOne | kLabDmaStage, true, true, true>("stream 512 PAIR1, DMA, pool", in, d, &refCaps, &refStatus, iters);
+        return 0;
+    }
     if (in.blob[TD_OFF_PAIR] && getenv("LAB_DMA")) {
         runVariant<512, kLabNoGeneral, false, true, true>("stream 512 pairs, no general", in, d, &refCaps, &refStatus, iters);
         runVariant<512, kLabNoGeneral | kLabDmaStage, false, true, true>("stream 512 pairs, nogen, DMA", in, d, &refCaps, &refStatus, iters);
