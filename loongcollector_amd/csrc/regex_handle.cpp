@@ -308,7 +308,9 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
     // 0.1915 ms, profiles/round3_lab_pair1.txt).  "Few": a DOUBLE is settled by a read-modify-write behind its chunk, for the whole
     // wavefront; regex A keeps 0.7 % of its entries as DOUBLEs after the fixed-distance registers are derived (one-byte fields),
     // regex B 2.3 % (fields that may be empty on both sides of a separator) -- B stays on the single-byte table.
-    if (!env && !getenv("LC_TDFA_PAIR")) {
+    // (full-match patterns only -- the parse processor's regex_match: that is what the GPU validation of the round covered; search
+    // patterns, i.e. Grok entries and the Go regex plugin, keep the single-byte tables unless LC_TDFA_PAIR=2 asks)
+    if (!env && !getenv("LC_TDFA_PAIR") && t.startAfter.empty()) {
         for (int fold = foldRegs ? 1 : 0; fold >= 0; --fold) {
             const uint32_t packedRegs = t.nRegs + (fold ? foldRegs : 0u);
             try {
