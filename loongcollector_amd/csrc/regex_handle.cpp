@@ -100,9 +100,12 @@ size_t tdfaBlobBytesEstimate(const TdfaTables& t);
 // register, the members of a folded set, or none):
 //   P1  every live transition t2 with b in stamps(t2) leaves a state that is no entry state and ALL of whose live incoming
 //       transitions t1 have a in stamps(t1); and a is not in stamps(t2)                 (b is only ever stamped one byte behind a)
-//   P2  every live transition t1 with a in stamps(t1) leads to a state ALL of whose live outgoing transitions t2 have b in
-//       stamps(t2), and whose final row -- if the line may end there -- does not read b      (behind a, b always follows)
-// Then, wherever a line can end with b in the final map, b == a + 1.  (live: between states the start state reaches, not into the
+//   P2  every live transition t1 with a in stamps(t1) leads to a state ALL of whose live outgoing transitions t2 have b OR a in
+//       stamps(t2), and whose final row -- if the line may end there -- does not read b   (behind a, b follows or a is stamped anew)
+// Then, wherever a line can end with b in the final map, b == a + 1: take the LAST stamp of a, at p.  The transition behind it
+// cannot stamp a, so it stamps b = p + 1; and a later stamp of b would have a stamp of a in front of it (P1) -- later than p.
+// (A greedy field that may contain its own separator -- "([^\"]*) (\S*)" -- restamps a at every separator and b behind it, except
+// behind a second separator in a row: that stale b is exactly what the "or a" covers.)  (live: between states the start state reaches, not into the
 // dead state.)  -> derive[k] = (b, a), in an order in which every a is settled before it is used.
 struct TdfaDerive {
     std::vector<std::pair<uint8_t, uint8_t>> pairs;  // (b, a): b = a + 1
@@ -175,7 +178,7 @@ static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
     }
     for (uint32_t s = 1; s < nS; ++s)
         if (entry[s]) inAll[s] = RegSet();
-    // per state: the intersection of the stamps of its live outgoing transitions
+    // per state: the intersection of the stamps of its live outgoing transitions (diagnostics: LC_TDFA_PROBE)
     std::vector<RegSet> outAll(nS);
     std::vector<char> hasOut(nS, 0);
     for (uint32_t s = 1; s < nS; ++s) {
@@ -232,17 +235,20 @@ static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
             for (int x = int(a), hops = 0; x >= 0 && hops <= int(t.nRegs); x = base[size_t(x)], ++hops)
                 if (uint32_t(x) == b) cyc = true;
             if (cyc) continue;
-            // P2
+            // P2 (a transition that stamps a AGAIN instead of b renews the obligation: see the comment above)
             bool p2 = true;
             for (uint32_t s = 1; s < nS && p2; ++s) {
                 if (!reach[s]) continue;
-                for (uint32_t c = 0; c < nC; ++c) {
+                for (uint32_t c = 0; c < nC && p2; ++c) {
                     const uint32_t e = t.trans[size_t(s) * nC + c];
                     const uint32_t nx = e & 0xFFFFu;
                     if (!nx || !stamps[e >> 16].has(a)) continue;
-                    if ((hasOut[nx] && !outAll[nx].has(b)) || finalReads(nx, b)) {
-                        p2 = false;
-                        break;
+                    if (finalReads(nx, b)) p2 = false;
+                    for (uint32_t c2 = 0; c2 < nC && p2; ++c2) {
+                        const uint32_t e2 = t.trans[size_t(nx) * nC + c2];
+                        if (!(e2 & 0xFFFFu)) continue;
+                        const RegSet& st2 = stamps[e2 >> 16];
+                        if (!st2.has(b) && !st2.has(a)) p2 = false;
                     }
                 }
             }
