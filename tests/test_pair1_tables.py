@@ -91,3 +91,14 @@ def test_pair_walk_on_the_golden_patterns_that_take_a_pair_table(monkeypatch):
                 assert p1.fullmatch_pair1(s, head=head) == exp, (c["p"], s[:40], head)
                 checked += 1
     assert took >= 20 and checked >= 500, (took, checked)
+
+
+def test_differential_fuzz_of_the_pair_tables_short():
+    """tools/fuzz_pair1.py on two seeds (the long run -- 100 seeds, 12 698 tables, 355 538 checks -- is in
+    profiles/round3_tdfa_experiments.txt): random patterns, full-match and search mode, random alignments, against the oracle"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pair1.py"), "200", "202"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok:"), (out.stdout[-400:], out.stderr[-1200:])
