@@ -157,6 +157,28 @@ class GrokOracle:
                 return MATCH_SUCCESS, out
         return MATCH_FAIL, []
 
+    # -- the same walk for a batch, driven from C (oracle/grok_baseline.c): only the winning entry per value comes back.  It exists
+    # to be TIMED (the cpu_baseline leg of tools/grok_bench.py); the parity gates use process_value.
+    def first_match_batch(self, data, off, length):
+        import ctypes
+        import numpy as np
+        from oracle.oracle import lib
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        progs = (ctypes.c_void_p * len(self.compiled))(*[rx._h for rx in self.compiled])
+        named, named_off = [], [0]
+        for fields in self.fields:
+            for _, groups in fields:
+                named.extend(groups)
+            named_off.append(len(named))
+        named = np.asarray(named or [0], dtype=np.int32)
+        named_off = np.asarray(named_off, dtype=np.int32)
+        pattern = np.empty(len(off), dtype=np.int32)
+        lib().orx_grok_first_match(progs, len(self.compiled), named.ctypes.data, named_off.ctypes.data, data.ctypes.data,
+                                   off.ctypes.data, length.ctypes.data, len(off), pattern.ctypes.data)
+        return pattern
+
     # -- processLog :115-146 on one log given as a list of (key, value bytes); returns the new list.
     # `range log.Contents` walks the contents the log had on entry; fields are appended behind them; the source is
     # removed by its index.  (With several contents under SourceKey the Go code's result depends on slice capacity --

@@ -22,7 +22,7 @@ ORX_REGEXP2 = 16
 def build(force=False):
     """Compile liboracle.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("bt_regex.c", "processor_oracle.c", "pcre_baseline.c", "bt_regex.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("bt_regex.c", "processor_oracle.c", "pcre_baseline.c", "grok_baseline.c", "bt_regex.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -51,6 +51,9 @@ def lib():
         L.orx_pcre_fullmatch_batch.restype = ctypes.c_long
         L.orx_pcre_fullmatch_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orx_grok_first_match.restype = ctypes.c_long
+        L.orx_grok_first_match.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         _LIB = L
     return _LIB
 

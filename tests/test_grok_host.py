@@ -329,3 +329,26 @@ def test_no_cpu_path():
         g.match_host([b"abc"])
     with pytest.raises(B.GpuUnavailableError):
         g.process_logs([[("content", "abc")]])
+
+
+def test_c_driven_oracle_walk_names_the_same_winners(golden_dir):
+    """oracle/grok_baseline.c (the cpu_baseline leg of tools/grok_bench.py: processGrok driven from C) against the Python-driven walk
+    of oracle/grok_oracle.py on generated values: the same values are won, by the same entry."""
+    import json
+    import numpy as np
+    from loongcollector_amd.grok_corpus import grok_lines
+    from oracle.grok_oracle import GrokOracle
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    o = GrokOracle(cfg["match"][:12], custom_patterns=cfg["custom_patterns"])
+    vals = grok_lines(60)
+    length = np.array([len(v) for v in vals], dtype=np.uint32)
+    off = np.zeros(len(vals), dtype=np.uint32)
+    off[1:] = np.cumsum(length[:-1])
+    winner = o.first_match_batch(np.frombuffer(b"".join(vals), dtype=np.uint8), off, length)
+    for v, w in zip(vals, winner):
+        res, fields = o.process_value(v)
+        assert (w >= 0) == (res == 0)
+        if w >= 0:      # the winning entry is the first one whose own walk yields fields
+            solo = GrokOracle([cfg["match"][int(w)]], custom_patterns=cfg["custom_patterns"])
+            assert solo.process_value(v)[1] == fields
