@@ -100,12 +100,15 @@ size_t tdfaBlobBytesEstimate(const TdfaTables& t);
 // register, the members of a folded set, or none):
 //   P1  every live transition t2 with b in stamps(t2) leaves a state that is no entry state and ALL of whose live incoming
 //       transitions t1 have a in stamps(t1); and a is not in stamps(t2)                 (b is only ever stamped one byte behind a)
-//   P2  every live transition t1 with a in stamps(t1) leads to a state ALL of whose live outgoing transitions t2 have b OR a in
-//       stamps(t2), and whose final row -- if the line may end there -- does not read b   (behind a, b follows or a is stamped anew)
-// Then, wherever a line can end with b in the final map, b == a + 1: take the LAST stamp of a, at p.  The transition behind it
-// cannot stamp a, so it stamps b = p + 1; and a later stamp of b would have a stamp of a in front of it (P1) -- later than p.
-// (A greedy field that may contain its own separator -- "([^\"]*) (\S*)" -- restamps a at every separator and b behind it, except
-// behind a second separator in a row: that stale b is exactly what the "or a" covers.)  (live: between states the start state reaches, not into the
+//   P2  every live transition t1 with a in stamps(t1) leads to a state s whose final row -- if the line may end there -- does not
+//       read b, and every live transition t2 out of s has b in stamps(t2), or a in stamps(t2), or leads to a state from which no line
+//       can end with b in the final row unless a is stamped again on the way      (behind the LAST stamp of a, b follows)
+// Then, wherever a line ends with b in the final map, b == a + 1: take the LAST stamp of a, at p (there is one: b was stamped, P1).
+// The line does not end there; the transition behind it cannot stamp a; if it stamped neither, the line could not end with b in the
+// final row without another stamp of a -- so it stamps b = p + 1; and a later stamp of b would have a stamp of a in front of it
+// (P1), later than p.  (A greedy field that may contain its own separator -- "([^\"]*) (\S*)\"" -- restamps a at every separator
+// and b behind it, except behind a second separator in a row or a byte the next field cannot start with: stale values that the
+// "or a" and the "unless a is stamped again" clauses cover.)  (live: between states the start state reaches, not into the
 // dead state.)  -> derive[k] = (b, a), in an order in which every a is settled before it is used.
 struct TdfaDerive {
     std::vector<std::pair<uint8_t, uint8_t>> pairs;  // (b, a): b = a + 1
@@ -156,6 +159,15 @@ static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
                 reach[nx] = 1;
                 stack.push_back(nx);
             }
+        }
+    }
+    // reverse adjacency between reachable states: (source, op list) per live transition
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> incoming(nS);
+    for (uint32_t s = 1; s < nS; ++s) {
+        if (!reach[s]) continue;
+        for (uint32_t c = 0; c < nC; ++c) {
+            const uint32_t e = t.trans[size_t(s) * nC + c];
+            if (e & 0xFFFFu) incoming[e & 0xFFFFu].push_back({s, e >> 16});
         }
     }
     // per state: the intersection of the stamps of its live incoming transitions (entry states: empty), and whether it has any
@@ -235,7 +247,26 @@ static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
             for (int x = int(a), hops = 0; x >= 0 && hops <= int(t.nRegs); x = base[size_t(x)], ++hops)
                 if (uint32_t(x) == b) cyc = true;
             if (cyc) continue;
-            // P2 (a transition that stamps a AGAIN instead of b renews the obligation: see the comment above)
+            // P2.  stale[s]: from s a line can END in a state whose final row reads b WITHOUT a being stamped on the way (backward
+            // reachability over the transitions that do not stamp a)
+            std::vector<char> stale(nS, 0);
+            {
+                std::vector<uint32_t> work;
+                for (uint32_t s = 1; s < nS; ++s)
+                    if (reach[s] && finalReads(s, b)) {
+                        stale[s] = 1;
+                        work.push_back(s);
+                    }
+                while (!work.empty()) {
+                    const uint32_t s2 = work.back();
+                    work.pop_back();
+                    for (const auto& in : incoming[s2]) {
+                        if (stale[in.first] || stamps[in.second].has(a)) continue;
+                        stale[in.first] = 1;
+                        work.push_back(in.first);
+                    }
+                }
+            }
             bool p2 = true;
             for (uint32_t s = 1; s < nS && p2; ++s) {
                 if (!reach[s]) continue;
@@ -243,12 +274,13 @@ static TdfaDerive planTdfaDerive(const TdfaTables& t, const TdfaFold& fold) {
                     const uint32_t e = t.trans[size_t(s) * nC + c];
                     const uint32_t nx = e & 0xFFFFu;
                     if (!nx || !stamps[e >> 16].has(a)) continue;
-                    if (finalReads(nx, b)) p2 = false;
+                    if (finalReads(nx, b)) p2 = false;  // (the line may end right behind the stamp of a)
                     for (uint32_t c2 = 0; c2 < nC && p2; ++c2) {
                         const uint32_t e2 = t.trans[size_t(nx) * nC + c2];
-                        if (!(e2 & 0xFFFFu)) continue;
+                        const uint32_t nx2 = e2 & 0xFFFFu;
+                        if (!nx2) continue;
                         const RegSet& st2 = stamps[e2 >> 16];
-                        if (!st2.has(b) && !st2.has(a)) p2 = false;
+                        if (!st2.has(b) && !st2.has(a) && stale[nx2]) p2 = false;
                     }
                 }
             }
