@@ -91,7 +91,10 @@ static void lcMarkExiting() { gProcessExiting.store(true); }
 // threads (in-agent parse 18.4 -> 14.8 GB/s, fused pipeline 13.1 -> 10.5; same file).  So the library asks for them only in a
 // process that creates a Grok processor (lc_grok_create calls this), only if the process has not set the variable itself, and --
 // the runtime reads it when it initialises -- without effect once HIP is up.
-void lcPreferHwQueuesForGrok() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+void lcPreferHwQueuesForGrok() {
+    static std::once_flag once;  // (setenv is not safe against concurrent getenv: once, from the first Grok processor's Init)
+    std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+}
 
 void lcRegisterExitHook() {
     static std::once_flag once;
