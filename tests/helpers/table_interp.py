@@ -232,8 +232,8 @@ class TdfaPair1Interp(TdfaBlobInterp):
     max(register, pos + 1), registers start at 0, and at the end of the line the fold words and then the DERIVE words apply
     (register b reads as a + delta: its own stamps were dropped from the table, regex_handle.cpp planTdfaDerive)."""
 
-    def __init__(self, rx):
-        super().__init__(rx, compact=True)
+    def __init__(self, rx, compact=True):
+        super().__init__(rx, compact=compact)
         po = int(self.blob[7])
         assert po, "the blob carries no byte-pair extension"
         ph = [int(x) for x in self.blob[po // 4:po // 4 + 8]]
@@ -270,9 +270,9 @@ class TdfaPair1Interp(TdfaBlobInterp):
                 ra, delta = (e >> 16) & 0x7F, (e >> 23) & 1
                 if ra != dummy:
                     assert 0 <= pbase + delta < L
-                    regs[ra] = (pbase + delta) & 0xFFFF
+                    regs[ra] = (pbase + delta) & (0xFFFF if self.compact else 0xFFFFFFFF)
                 if e >> 31:
-                    pending.append(((e >> 24) & 0x7F, (pbase + 1) & 0xFFFF))
+                    pending.append(((e >> 24) & 0x7F, (pbase + 1) & (0xFFFF if self.compact else 0xFFFFFFFF)))
             for rb, val in pending:                           # behind the chunk's rA stamps
                 regs[rb] = max(regs[rb], val)
                 self.doubles += 1
@@ -283,7 +283,7 @@ class TdfaPair1Interp(TdfaBlobInterp):
                 if r != 0xFF:
                     regs[r] = max(regs[r], regs[w & 0xFF])
         for b, a, delta in self.derive:
-            regs[b] = (regs[a] + delta) & 0xFFFF
+            regs[b] = (regs[a] + delta) & (0xFFFF if self.compact else 0xFFFFFFFF)
         state = (state_row - self.p_base) // self.p_row
         fid = int(self.final_id[state])
         if state == 0 or fid == 0xFFFF:

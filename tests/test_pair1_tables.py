@@ -93,6 +93,21 @@ def test_pair_walk_on_the_golden_patterns_that_take_a_pair_table(monkeypatch):
     assert took >= 20 and checked >= 500, (took, checked)
 
 
+def test_standard_tables_pack_the_same_pair_table_when_asked(monkeypatch):
+    """LC_TDFA_PAIR=2 without LC_TDFA_COMPACT: the standard tables (32-bit registers: small batches, the in-agent shape) carry the
+    one-stamp pair table too -- prepared for the next round, walked here on the CPU"""
+    monkeypatch.setenv("LC_TDFA_PAIR", "2")
+    rx = B.GpuRegex(corpus.REGEX_A)
+    std = rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32)
+    assert int(std[7]) != 0 and int(std[int(std[7]) // 4 + 4]) == 1
+    p1, plain = TdfaPair1Interp(rx, compact=False), TdfaBlobInterp(rx)
+    data, off, length = corpus.apache_batch(40, "A", poison_every=5, empty_every=3)
+    for i in range(40):
+        s = bytes(data[off[i]:off[i] + length[i]])
+        for head in (0, 3, 8, 13):
+            assert p1.fullmatch_pair1(s, head=head) == plain.fullmatch(s)
+
+
 def test_differential_fuzz_of_the_pair_tables_short():
     """tools/fuzz_pair1.py on two seeds (the long run -- 100 seeds, 12 698 tables, 355 538 checks -- is in
     profiles/round3_tdfa_experiments.txt): random patterns, full-match and search mode, random alignments, against the oracle"""
