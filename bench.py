@@ -530,6 +530,8 @@ def run_headline(args):
                     extra["configs[2]"] = rows[-1]
             except subprocess.TimeoutExpired:
                 extra["configs[2]"] = {"error": "tools/grok_config2.py did not finish in 900 s"}
+            except Exception as ex:  # noqa: BLE001 -- reported, not fatal
+                extra["configs[2]"] = {"error": "tools/grok_config2.py: %r" % (ex,)}
     # the job's only collective: ONE all-gather of the per-GPU counters (RCCL); the data path has none
     per_gpu = gather_job({"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps, "matched_last": matched,
                           "elapsed_us": int(elapsed * 1e6), "kernel_us_per_step": int(kernel_ms * 1e3)}, device=dev)
