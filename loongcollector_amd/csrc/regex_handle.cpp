@@ -362,7 +362,12 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
                 size_t doubles = 0;
                 const size_t entries = size_t(t.nStates) * cols * cols;
                 for (size_t i = 0; i < entries; ++i) doubles += pair[i] >> 31;
-                if (doubles * 100 > entries) break;  // more than 1 % DOUBLE entries
+                // more than 1 % DOUBLE entries (LC_TDFA_PAIR_DOUBLE_PCT: the threshold, for A/B runs -- regex B sits at 1.8 %)
+                static const size_t pct = [] {
+                    const char* e = getenv("LC_TDFA_PAIR_DOUBLE_PCT");
+                    return e ? size_t(atol(e)) : size_t(1);
+                }();
+                if (doubles * 100 > entries * pct) break;
                 *blockOut = 512;
                 *packedRegsOut = packedRegs;
                 return blob;

@@ -23,7 +23,7 @@ timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/prof_stats -o r1 -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-configs > $R/$O/stats.log 2>&1
 cd $R && python tools/prof_summary.py $O > $O/tdfa_kernel_rocprofv3.txt 2>&1; rm -rf $O/prof_stats; head -6 $O/tdfa_kernel_rocprofv3.txt | cut -c1-140
-LC_TDFA_PAIR=2 LC_TDFA_COMPACT=512 timeout 200 python bench.py --regex B --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | cut -c1-400
+for pct in 1 3; do echo "regex B, LC_TDFA_PAIR_DOUBLE_PCT=$pct"; LC_TDFA_PAIR_DOUBLE_PCT=$pct timeout 200 python bench.py --regex B --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | cut -c1-400; done
 LC_TDFA_PAIR=2 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_processor.py -m gpu -q -x 2>&1 | tail -4 | cut -c1-300
 LC_TDFA_PAIR=2 timeout 300 python bench.py --no-cpu-baseline --no-configs 2>/dev/null | python -c "
 import sys, json
