@@ -37,6 +37,19 @@ PCIE_GEN5_X16_GBPS = 63.0  # PCIe 5.0 x16, one direction, after 128b/130b encodi
 PLACEMENT = {}
 
 
+def compact_tables(rx):
+    from loongcollector_amd import binding
+    try:
+        blob = rx.table(binding.LC_TABLE_TDFA_WIDE_BLOB, np.uint32)
+        if blob is None or len(blob) < 16:
+            return None
+        po = int(blob[7]) // 4
+        return {"block": int(blob[15]), "bytes": int(blob.nbytes),
+                "pair_table": None if not po else ("one stamp per pair" if int(blob[po + 4]) == 1 else "two stamps per pair")}
+    except Exception:  # noqa: BLE001 -- informational
+        return None
+
+
 def setup_dist():
     import torch
     import torch.distributed as dist
@@ -577,7 +590,10 @@ def run_headline(args):
                        "engine": {1: "tdfa", 2: "nfa"}[info["engine"]], "lines_per_batch": n,
                        "tdfa_states": info["states"], "byte_classes": info["classes"],
                        "lds_table_bytes": info["table_bytes"], "parallelism": "line-shard x%d" % world,
-                       "matched_lines_last_batch": matched},
+                       "matched_lines_last_batch": matched,
+                       # the tables the large-batch kernel stages (LC_TABLE_TDFA_WIDE_BLOB): workgroup size, bytes, and whether
+                       # they carry the one-stamp byte-pair table (device_tables.h TP_FORMAT 1)
+                       "compact_tables": compact_tables(rx)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernels.split(",")[0].split("<")[0] if kernels else None, "kernels_launched": kernels,
