@@ -915,6 +915,25 @@ def compute_sharded_corpus(args, world, rank, dev):
     return None
 
 
+def run_launch_check(args):
+    """The launch path without a device (CPU test of `--gpus N`): rendezvous, ONE all-gather of a counter row (the job's only
+    collective, shard.gather_job), rank 0 prints the launch fields of the line.  No parsing happens and the line says so."""
+    import torch.distributed as dist
+    from loongcollector_amd.shard import gather_job
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    per_gpu = gather_job({"bytes": 0, "lines": 0, "rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "elapsed_us": 1}, device="cpu")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "data": "none (launch path only: no device work, no parsing)",
+                          "per_gpu": [{"rank": g["rank"], "local_rank": g["local_rank"]} for g in per_gpu]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -936,7 +955,15 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--corpus-gb", type=float, default=10.0)
     ap.add_argument("--slab-mib", type=int, default=64)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="(tests) no device work: the ranks rendezvous over gloo, all-gather a fixed counter row and rank 0 prints the "
+                         "line's launch fields -- what tests/test_bench_launch.py runs on a box without a GPU")
     args = ap.parse_args()
+    # one process per GPU: under a launcher WORLD_SIZE must equal --gpus; without one, --gpus N > 1 starts the N ranks itself
+    from loongcollector_amd.launch import ensure_ranks
+    ensure_ranks(args.gpus, need_devices=not args.launch_check)
+    if args.launch_check:
+        return run_launch_check(args)
     if args.config == 3:  # the Grok line has its own driver (parity gate against the Grok oracle, per-pattern engines)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import grok_bench

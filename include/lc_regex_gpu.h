@@ -173,6 +173,12 @@ int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, 
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int lc_device_count(void);
 
+/* Hardware queues behind the HIP streams (ROCm: GPU_MAX_HW_QUEUES, default 4, read ONCE when the HIP runtime initialises).  The
+ * library never changes the process environment on its own -- not at load time, not from a processor's Init.  A host that
+ * wants n queues (a process hosting Grok processors gains from 16) either exports the variable or calls
+ * this BEFORE the first HIP call of the process; a value the host has already exported is kept.  LC_OK / LC_ERR_ARG. */
+int lc_runtime_prefer_hw_queues(int n);
+
 /* Match n lines that already live in device memory on the current HIP device.
  *   d_data   : line bytes (any layout); line i = d_data[d_off[i] .. d_off[i]+d_len[i])
  *   d_len    : may be NULL, then d_off has n+1 entries and len[i] = d_off[i+1]-d_off[i]-sep_bytes

@@ -84,16 +84,21 @@ extern "C" size_t lc_launched_kernels(char* buf, size_t cap) {
 // lc_thread_release() frees the calling thread's resources explicitly; a host that recycles runner threads calls it.
 static std::atomic<bool> gProcessExiting{false};
 static void lcMarkExiting() { gProcessExiting.store(true); }
-// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams beyond that share a queue and their
-// kernels run one after the other.  A Grok batch queues ~40 entries' latency-bound kernels (tiny grids, 0.3-2 ms each) on its
-// worker streams -- measured on configs[2] (profiles/round3_grok_streams.txt): 16 Ki values 6.39 ms with 8 streams on 4 queues,
-// 3.85 ms with 16 streams on 16 queues.  The same 16 queues COST the paths that are one stream per runner thread 15-20 % at 16
-// threads (in-agent parse 18.4 -> 14.8 GB/s, fused pipeline 13.1 -> 10.5; same file).  So the library asks for them only in a
-// process that creates a Grok processor (lc_grok_create calls this), only if the process has not set the variable itself, and --
-// the runtime reads it when it initialises -- without effect once HIP is up.
-void lcPreferHwQueuesForGrok() {
-    static std::once_flag once;  // (setenv is not safe against concurrent getenv: once, from the first Grok processor's Init)
-    std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+// Hardware queues.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams beyond that share a
+// queue and their kernels run one after the other.  A Grok batch queues its entries' latency-bound kernels on up to 16 worker streams
+// and gains from 16 queues (profiles/round3_grok_streams.txt: 16 Ki values 6.39 ms with 8 streams on 4 queues, 3.85 ms with 16 on
+// 16); the paths that are one stream per runner thread LOSE 15-20 % at 16 threads with 16 queues (same file).  The variable is
+// process-wide and read once, when the runtime initialises: it is the HOST's decision.  The library never touches the environment
+// on its own (round 3 did, from a constructor and from the Grok processor's Init: removed); a host that wants more queues either
+// exports GPU_MAX_HW_QUEUES itself or calls lc_runtime_prefer_hw_queues(n) before the first HIP call of the process.
+extern "C" int lc_runtime_prefer_hw_queues(int n) {
+    if (n < 1 || n > 64) return LC_ERR_ARG;
+    static std::mutex mu;  // (setenv is not safe against itself)
+    std::lock_guard<std::mutex> lock(mu);
+    if (getenv("GPU_MAX_HW_QUEUES")) return LC_OK;  // the host (or an earlier call) has an opinion already: kept
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", n);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? LC_OK : LC_ERR_ARG;
 }
 
 void lcRegisterExitHook() {
@@ -101,11 +106,6 @@ void lcRegisterExitHook() {
     std::call_once(once, [] { atexit(lcMarkExiting); });
 }
 bool lcRuntimeUsable() { return !gProcessExiting.load(); }
-
-// The Grok matcher spreads the entries of a Match list over up to 8 worker streams (grok_device.hip); the HIP runtime maps streams
-// onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the caller's), and streams that share a queue run one after the
-// other.  Ask for 8 unless the host has an opinion of its own; read by the runtime when it initialises, i.e. at the first HIP call.
-__attribute__((constructor)) static void lcAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int lc_device_count(void) {
     // (a positive answer does not change during the process's life: every match call asks, from every runner thread, and a

@@ -170,7 +170,7 @@ int lcMultilineSplitTrip(lc_multiline* m, const uint8_t* data, uint32_t nbytes, 
     return checkUndecided(counts);
 }
 
-int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint32_t* lens, uint32_t n, bool flush,
+int lcMultilineViewsTrip(const lc_multiline* m, const uint8_t* const* ptrs, const uint32_t* lens, uint32_t n, bool flush, bool keepUnmatched,
                          std::vector<lc_ml_record_t>& out, uint32_t counts[ML_CNT_WORDS]) {
     out.clear();
     std::memset(counts, 0, ML_CNT_WORDS * 4);
@@ -180,9 +180,10 @@ int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint
     if (rc != LC_OK) return rc;
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += lens[i];
-    if (total >= 0xFFFFFFF0ull) return LC_ERR_ARG;
-    // staging: [bytes of all values, padded to 16][off: n words][len: n words]
-    const size_t dataBytes = (size_t(total) + 31) & ~size_t(15);
+    // adjacent values are copied WITH the one byte between them (the run fast path below): at most total + (n - 1) bytes land
+    if (total + n >= 0xFFFFFFE0ull) return LC_ERR_ARG;
+    // staging: [bytes of all values and of the joins between adjacent ones, padded to 16][off: n words][len: n words]
+    const size_t dataBytes = (size_t(total) + size_t(n) + 31) & ~size_t(15);
     const size_t upBytes = dataBytes + size_t(n) * 8 + 16;
     const size_t statusStride = (size_t(n) + 16 + 15) & ~size_t(15);
     LC_HIP_TRY(T.hIn.ensure(upBytes));
@@ -209,6 +210,7 @@ int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint
         at += run;
         i = j;
     }
+    if (size_t(at) > dataBytes) return LC_ERR_OVERFLOW;  // (cannot happen: at <= total + n - 1)
     std::memset(h + at, 0, dataBytes - at);
     int32_t* dCapsDummy = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(T.dSmall.p) + 64);
     const uint8_t* dData = static_cast<const uint8_t*>(T.dData.p);
@@ -228,7 +230,9 @@ int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint
     }
     if (rc == LC_OK && !jobs.empty()) rc = lc_regex_match_device_multi(jobs.data(), uint32_t(jobs.size()), T.stream);
     if (rc != LC_OK) return rc;
-    rc = boundsAndFetch(T, modeOf(*m, flush), status, nullptr, n, nullptr, 0, out, counts);
+    // keepUnmatched: the caller applies UnmatchedContentTreatment itself (it counts EVENTS, multiline_events.cpp) -- a parameter, not a
+    // write to the processor's shared state (runner threads share the instance)
+    rc = boundsAndFetch(T, modeOf(*m, flush) & ~(keepUnmatched ? uint32_t(ML_DISCARD) : 0u), status, nullptr, n, nullptr, 0, out, counts);
     if (rc != LC_OK) return rc;
     return checkUndecided(counts);
 }

@@ -281,9 +281,7 @@ int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
     std::vector<lc_ml_record_t> recs;
     uint32_t counts[ML_CNT_WORDS];
     const bool discard = ml.discardUnmatched;
-    ml.discardUnmatched = false;
-    const int rc = lcMultilineViewsTrip(&ml, ptrs.data(), lens.data(), n, !truncated, recs, counts);
-    ml.discardUnmatched = discard;
+    const int rc = lcMultilineViewsTrip(&ml, ptrs.data(), lens.data(), n, !truncated, /*keepUnmatched=*/true, recs, counts);
     if (rc != LC_OK) return rc;
 
     size_t newSize = 0, prevEvent = 0;

@@ -30,5 +30,5 @@ struct lc_multiline {
 int lcMultilineSplitTrip(lc_multiline* m, const uint8_t* data, uint32_t nbytes, std::vector<lc_ml_record_t>& out, uint32_t counts[8]);
 // records carry ITEM indices (begin = first item, length = number of items); flush = false leaves the log under construction open
 // and reports it in counts[ML_CNT_FINAL_PARTIAL] / counts[ML_CNT_FINAL_START]
-int lcMultilineViewsTrip(lc_multiline* m, const uint8_t* const* ptrs, const uint32_t* lens, uint32_t n, bool flush,
+int lcMultilineViewsTrip(const lc_multiline* m, const uint8_t* const* ptrs, const uint32_t* lens, uint32_t n, bool flush, bool keepUnmatched,
                          std::vector<lc_ml_record_t>& out, uint32_t counts[8]);

@@ -12,7 +12,6 @@
 #include "json_min.hpp"
 #include "regex_handle.hpp"
 
-void lcPreferHwQueuesForGrok();  // gpu_runtime.hip: 16 hardware queues for a process that hosts a Grok processor
 
 namespace lcgrok {
 
@@ -79,7 +78,6 @@ ProcessorGrokGpu::~ProcessorGrokGpu() {
 int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCompiled[i]->engine : 0; }
 
 void ProcessorGrokGpu::Init() {
-    ::lcPreferHwQueuesForGrok();
     stopWarmup();
     lcGrokStateFree(mState);
     mState = lcGrokStateCreate();

@@ -58,3 +58,33 @@ def test_config_json_nesting_is_bounded():
         Multiline(StartPattern="x")  # binds the argtypes
         assert L.lc_multiline_create(deep, len(deep), ctypes.byref(h), err, 256) != 0
         assert b"nesting too deep" in err.value
+
+
+def test_loading_the_library_leaves_the_process_environment_alone():
+    """Round 3 shipped a constructor that set GPU_MAX_HW_QUEUES at load time (and a second setenv in the Grok processor's Init that
+    could then never take effect).  The variable is process-wide and belongs to the host: a fresh interpreter loads the library,
+    creates a Grok processor and a parse processor, and must see its environment unchanged; the explicit request
+    (lc_runtime_prefer_hw_queues) sets it once and keeps a value that is already there."""
+    import subprocess
+    import sys
+    code = r"""
+import os, ctypes, json
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+before = dict(os.environ)
+libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; libc.getenv.argtypes = [ctypes.c_char_p]
+from loongcollector_amd import binding as B, grok
+L = B.load()
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None, "library load changed the environment"
+g = grok.Grok(Match=["%{WORD:w} %{NUMBER:n}"], SourceKey="content")
+rx = B.GpuRegex(r"(\w+) (\d+)")
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None, "creating processors changed the environment"
+L.lc_runtime_prefer_hw_queues.restype = ctypes.c_int; L.lc_runtime_prefer_hw_queues.argtypes = [ctypes.c_int]
+assert L.lc_runtime_prefer_hw_queues(0) != 0 and L.lc_runtime_prefer_hw_queues(1000) != 0
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None
+assert L.lc_runtime_prefer_hw_queues(16) == 0 and libc.getenv(b"GPU_MAX_HW_QUEUES") == b"16"
+assert L.lc_runtime_prefer_hw_queues(8) == 0 and libc.getenv(b"GPU_MAX_HW_QUEUES") == b"16"   # an existing value is kept
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-1500:])

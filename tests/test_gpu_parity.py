@@ -483,6 +483,103 @@ def test_byte_pair_transition_tables_are_bit_exact(torch_dev, golden_dir, monkey
     assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
 
 
+def _golden_on_tdfa(torch_dev, golden_dir, name, flags, skip, limit):
+    """golden vectors of `name` through the TDFA engine; -> (checked, patterns whose launch was the one-stamp kernel, bad)"""
+    with open(os.path.join(golden_dir, name)) as f:
+        golden = json.load(f)
+    bad, checked, pair1 = [], 0, 0
+    for c in golden["cases"][:limit]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+        if rx.info()["engine"] != B.LC_ENGINE_TDFA:
+            continue
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        B.launched_kernels()
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+        pair1 += "pair1" in B.launched_kernels()
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if flat is None else (
+                status[i] == B.LC_MATCH and list(caps[i]) == flat[skip:])
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    return checked, pair1, bad
+
+
+@pytest.mark.parametrize("compact", [None, "512"])
+def test_one_stamp_pair_tables_forced_on_every_table_format(torch_dev, golden_dir, monkeypatch, compact):
+    """The ONE-STAMP byte-pair tables (LC_TDFA_PAIR=2, device_tables.h TP_FORMAT 1; the default of large regex-A batches) forced
+    onto every pattern that can carry them: the STANDARD 32-bit tables (compact unset: launches below 64 Ki lines) and the
+    COMPACT 512-lane tables used for every batch (LC_TDFA_COMPACT=512).  Golden vectors (full match and search), the bench
+    corpora A and B with failing lines and empty fields, ragged JSON/nginx lines, unaligned / empty / 64 KiB+ lines -- each
+    against the oracle or the third-party goldens, each asserting that the one-stamp kernel is what ran.
+    Semantics protected: core/common/StringTools.cpp:183-211 (regex_match) / :213-236 (regex_search)."""
+    monkeypatch.setenv("LC_TDFA_PAIR", "2")
+    if compact is None:
+        monkeypatch.delenv("LC_TDFA_COMPACT", raising=False)
+    else:
+        monkeypatch.setenv("LC_TDFA_COMPACT", compact)
+    checked, pair1, bad = _golden_on_tdfa(torch_dev, golden_dir, "regex_golden.json", 0, 2, 100000)
+    assert not bad, bad[:5]
+    assert checked > 3000 and pair1 > 100, (checked, pair1)
+    checked, pair1, bad = _golden_on_tdfa(torch_dev, golden_dir, "regex_search_golden.json", B.LC_SYNTAX_SEARCH, 0, 100000)
+    assert not bad, bad[:5]
+    assert checked > 1000 and pair1 > 30, (checked, pair1)
+
+    def on_device(pattern, data, off, length, sep, label):
+        rx = B.GpuRegex(pattern)
+        B.launched_kernels()
+        caps, status = run_device(torch_dev, rx, data, off, length, sep=sep)
+        names = B.launched_kernels()
+        wide = compact is not None or len(status) >= 65536
+        blob = rx.table(B.LC_TABLE_TDFA_WIDE_BLOB if wide else B.LC_TABLE_TDFA_BLOB, np.uint32)
+        one_stamp = int(blob[7]) != 0 and int(blob[int(blob[7]) // 4 + 4]) == 1      # TD_OFF_PAIR, TP_FORMAT
+        assert one_stamp or label[0] == "B", label          # (regex B's STANDARD tables: see test_pair1_tables.py)
+        assert ("pair1" in names) == one_stamp, (label, names)
+        assert ("compact" in names) == wide, (label, names)
+        ran.append((label, names))
+        return caps, status
+
+    ran = []
+
+    for kind, pattern in (("A", corpus.REGEX_A), ("B", corpus.REGEX_B)):
+        for n, kw in ((20000, dict(poison_every=13)), (20000, dict(poison_every=17, empty_every=3)), (70000, dict(poison_every=11, empty_every=5))):
+            data, off, length = corpus.apache_batch(n, kind, **kw)
+            exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+            caps, status = on_device(pattern, data, off, None, 1, (kind, n, kw))
+            bad = np.nonzero((status != exp_status) | (caps != exp_caps).any(axis=1))[0]
+            assert bad.size == 0, (kind, n, kw, bad[:8].tolist(), caps[bad[0]].tolist(), exp_caps[bad[0]].tolist())
+            caps, status = on_device(pattern, data, off[:-1], length, 0, (kind, n, kw, "off+len"))
+            assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    # ragged nginx / JSON lines (regex B; the JSON lines fail)
+    data, off, length = corpus.mixed_batch(6000)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_B).fullmatch_batch(data, off[:-1], length)
+    caps, status = on_device(corpus.REGEX_B, data, off, None, 1, ("B", "mixed"))
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    # empty, one-byte, 15/16/17-byte, random short and long lines at unaligned offsets
+    pattern = r"(\w*)\t?(\w*)(.*)"
+    rng = np.random.default_rng(5)
+    subs = [b"", b"a", b"\t", b"a\tb", b"x" * 15, b"x" * 16, b"x" * 17, b"ab\tcd" + b" tail" * 3000, b""]
+    for _ in range(300):
+        subs.append(bytes(rng.choice(list(b"ab\t _"), size=int(rng.integers(0, 70))).astype(np.uint8)))
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    caps, status = on_device(pattern, data, off, length, 0, "edge")
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    # lines around and beyond 64 KiB: the compact kernel hands them to the 32-bit tables' launch (which carries pair tables too)
+    pattern = rb"(\w+) (\d+) (.*)\|(\w*)"
+    subs = []
+    for n in [0, 1, 20, 65534, 65535, 65536, 65537, 70001, 131072, 300]:
+        body = b"key 12345 " + b"x" * max(0, n - 14) + b"|end"
+        subs.append(body[:n] if n < 14 else body)
+    subs += [b"key 1 " + b"y" * 65600, b"no match " * 8000]
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    caps, status = on_device(pattern, data, off, length, 0, "long")
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    assert exp_status.sum() >= 7
+
+
 def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
     """lc_regex_match_device_from: a subset of the lines, each search resumed at its own offset (also beyond the first
     256-byte chunk of the NFA kernel and across the TDFA kernel's 64-byte stages), against the oracle's search(start)."""

@@ -392,3 +392,73 @@ def test_merge_processor_counts_empty_events_like_the_reference():
     p.process(g)
     assert [e["timestamp"] for e in g.to_dict()["events"]] == [1, 2]
     assert p.counters() == (1, 1)
+
+
+def _events_of_lines(val):
+    """one event per line of `val`, lying back to back in the group's buffer (what ProcessorSplitLogStringNative leaves)"""
+    import numpy as np
+    from loongcollector_amd.processor import EventGroup
+    lines = val.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    length = np.array([len(s) for s in lines], dtype=np.uint32)
+    off = np.zeros(len(lines), dtype=np.uint32)
+    off[1:] = np.cumsum(length[:-1].astype(np.uint64) + 1).astype(np.uint32)
+    data = np.frombuffer(b"\n".join(lines) + b"\n", dtype=np.uint8)
+    return EventGroup.from_lines(data, off, length), len(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("treatment", ["single_line", "discard"])
+def test_merge_processor_on_thousands_of_adjacent_events(treatment):
+    """Thousands of events that lie back to back (split -> merge, the usual chain): the views trip copies a run of adjacent values
+    WITH the byte between them, so its staging is sized from the bytes it copies, not from the sum of the lengths (round 3 sized it
+    from the sum and overran into its own offset table beyond a few dozen joins).  Against the oracle's records of the same buffer.
+    Reference: ProcessorMergeMultilineLogNative.cpp:226-298 (MergeLogsByRegex)."""
+    from loongcollector_amd import corpus
+    from loongcollector_amd.multiline import MergeMultiline
+    val = corpus.multiline_buffer(384 << 10, unmatched_head=5)
+    g, n = _events_of_lines(val)
+    assert n > 3000
+    cfg = {"StartPattern": corpus.MULTILINE_START, "UnmatchedContentTreatment": treatment}
+    p = MergeMultiline(MergeType="regex", **cfg)
+    p.process(g)
+    got = [dict(ev)["content"] for ev in g.contents()]
+    recs, counters = MultilineOracle(**cfg).split(val)
+    want = [val[b:b + l].rstrip(b"\n").decode("utf-8") if k + 1 == len(recs) else val[b:b + l].decode("utf-8")
+            for k, (b, l, *_rest) in enumerate(recs)]
+    assert got == want
+    merged, unmatched = p.counters()
+    assert unmatched == 5 and merged + unmatched == n
+
+
+@pytest.mark.gpu
+def test_merge_processor_shared_by_threads_with_discard():
+    """Runner threads share a processor instance (ProcessQueueManager.cpp:167-205).  UnmatchedContentTreatment = discard is applied by
+    the host walk (it counts EVENTS); the device trip is told so by a parameter -- round 3 flipped the shared flag around the trip, and
+    a second thread could read it in between."""
+    import threading
+    from loongcollector_amd import corpus
+    from loongcollector_amd.multiline import MergeMultiline
+    cfg = {"StartPattern": corpus.MULTILINE_START, "UnmatchedContentTreatment": "discard"}
+    vals = [corpus.multiline_buffer(48 << 10, unmatched_head=3 + t) for t in range(4)]
+    p = MergeMultiline(MergeType="regex", **cfg)
+    want = []
+    for v in vals:
+        recs, _ = MultilineOracle(**cfg).split(v)
+        want.append([v[b:b + l].rstrip(b"\n").decode() if k + 1 == len(recs) else v[b:b + l].decode() for k, (b, l, *_r) in enumerate(recs)])
+    bad = []
+
+    def run(t):
+        for _ in range(25):
+            g, _n = _events_of_lines(vals[t])
+            p.process(g)
+            got = [dict(ev)["content"] for ev in g.contents()]
+            if got != want[t]:
+                bad.append((t, len(got), len(want[t])))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad[:4]
