@@ -560,18 +560,20 @@ def run_headline(args):
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
         # this same command, profiles/round*_traffic.json); only quoted for the workload they were collected on
         traffic, traffic_source = None, None
-        for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
-                        n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
-                    traffic = tj["hbm_bytes_per_launch"]
-                    traffic_source = {"file": "profiles/" + name, "measured_in_run": False,
-                                      "what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (separate runs), "
-                                              "corrected as MI355X_MICROARCH.md prescribes"}
-                break
+        # (the newest round's file; quoted only when it was collected on this workload AND on the kernels this run launched)
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
+            with open(tpath) as f:
+                tj = json.load(f)
+            same_kernels = tj.get("kernels_launched") in (None, kernels)
+            if same_kernels and (tj.get("lines"), tj.get("regex"), tj.get("line_bytes"), tj.get("engine")) == (
+                    n, args.regex, args.line_bytes, {1: "tdfa", 2: "nfa"}[info["engine"]]):
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_source = {"file": "profiles/" + os.path.basename(tpath), "measured_in_run": False,
+                                  "kernels": tj.get("kernels_launched"), "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"),
+                                  "what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (separate runs), "
+                                          "corrected as MI355X_MICROARCH.md prescribes"}
+            break
         out = {
             "metric": "MB/s parsed (512B lines, 10-field regex) per MI355X + HBM-roofline %",
             "value": round(value, 1),
