@@ -55,6 +55,11 @@ char* lc_grok_denormalize(lc_grok_t* g, const char* pattern, char* err, size_t e
  * stays valid until lc_grok_free. */
 int lc_grok_literal_index(lc_grok_t* g, const uint32_t** words, size_t* nwords);
 int lc_grok_engine(const lc_grok_t* g, int i);                     /* LC_ENGINE_TDFA / LC_ENGINE_NFA chosen for Match[i] */
+/* diagnostics: how Match[i] is run -- out[0] engine of the search form, [1] states of its tagged DFA (0: none), [2] 1 = tables in
+ * LDS / 2 = in global memory, [3] prefix-screen states, [4] relaxed-screen states, [5] anchored search present (they arrive behind
+ * lc_grok_create: lc_grok_wait_ready), [6] its states, [7] LDS / global, [8] bytes of its global tables, [9] its offset registers,
+ * [10] its byte classes, [11] bytes of the search form's global tables. */
+int lc_grok_entry_info(lc_grok_t* g, int i, uint32_t out[12]);
 
 /* Emitted keys.  A match of Match[i] writes one capture column per NAMED group; columns that share a name are one field
  * (regexp2 merges same-named groups, the value is the one captured furthest along).  Keys are already mapped back through

@@ -170,6 +170,11 @@ const uint8_t* lc_regex_required_literal(const lc_regex_t* re, size_t* len);
  * the pattern has; writes up to `cap` group indices (as in the caps rows) and 32-byte sets (bit b of byte b/8 = byte b). */
 int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, int cap);
 
+/* Atomic groups / possessive quantifiers of the pattern: *kept = instances the engines honour (ordered commit pass), *elided = groups
+ * that were turned into plain groups at compile time because they provably change no match and no capture (csrc/atomic_elide.cpp:
+ * whole-line language unchanged and prefix-free, nothing captured or asserted inside).  Diagnostics and tests. */
+void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided);
+
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int lc_device_count(void);
 

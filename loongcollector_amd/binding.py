@@ -214,6 +214,14 @@ class GpuRegex:
         _check(self._L.lc_regex_info(self._h, ctypes.byref(i)), "lc_regex_info")
         return {f: getattr(i, f) for f, _ in LcRegexInfo._fields_}
 
+    def atomic_groups(self):
+        """-> (kept, elided): atomic group instances the engines honour / groups made plain at compile time (atomic_elide.cpp)"""
+        k, e = ctypes.c_uint32(), ctypes.c_uint32()
+        self._L.lc_regex_atomic_groups.restype = None
+        self._L.lc_regex_atomic_groups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        self._L.lc_regex_atomic_groups(self._h, ctypes.byref(k), ctypes.byref(e))
+        return int(k.value), int(e.value)
+
     def has_nfa_program(self):
         """False when the follow NFA does not fit the NFA kernel's format (then only the TDFA engine can run it)."""
         p = ctypes.c_void_p()

@@ -445,6 +445,33 @@ extern "C" char* lc_grok_denormalize(lc_grok_t* g, const char* pattern, char* er
     }
 }
 extern "C" int lc_grok_engine(const lc_grok_t* g, int i) { return (g && i >= 0) ? g->p.engine(size_t(i)) : 0; }
+// diagnostics (tools/grok_entries.py): how Match[i] is run.  out[0] engine of the search form, [1] its tagged DFA's states (0: none),
+// [2] 1 = that DFA's tables fit LDS, 2 = they live in global memory; [3] prefix screen states, [4] relaxed screen states;
+// [5] anchored search present, [6] its states, [7] 1 = LDS / 2 = global tables, [8] bytes of its global-memory tables, [9] its registers,
+// [10] its byte classes, [11] bytes of the search form's global-memory tables
+extern "C" int lc_grok_entry_info(lc_grok_t* g, int i, uint32_t out[12]) {
+    if (!g || !out || i < 0) return LC_ERR_ARG;
+    const std::vector<GrokDevicePattern> dp = g->p.devicePatterns();
+    if (size_t(i) >= dp.size()) return LC_ERR_ARG;
+    auto where = [](const lc_regex* re) { return !re ? 0u : re->hasTdfa ? 1u : !re->tdfaL2Blob.empty() ? 2u : 0u; };
+    std::memset(out, 0, 12 * sizeof(uint32_t));
+    const GrokDevicePattern& e = dp[size_t(i)];
+    out[0] = uint32_t(e.re->engine);
+    out[1] = where(e.re) ? e.re->tdfa.nStates : 0;
+    out[2] = where(e.re);
+    out[3] = e.screen ? e.screen->tdfa.nStates : 0;
+    out[4] = e.relaxed ? (e.relaxed->screenBlob.empty() ? e.relaxed->tdfa.nStates : e.relaxed->screenBlob[1]) : 0;
+    out[5] = e.anchored != nullptr;
+    if (e.anchored) {
+        out[6] = e.anchored->tdfa.nStates;
+        out[7] = where(e.anchored);
+        out[8] = uint32_t(e.anchored->tdfaL2Blob.size() * 4);
+        out[9] = e.anchored->tdfa.nRegs;
+        out[10] = e.anchored->tdfa.nClasses;
+    }
+    out[11] = uint32_t(e.re->tdfaL2Blob.size() * 4);
+    return LC_OK;
+}
 extern "C" int lc_grok_key_count(const lc_grok_t* g) { return g ? int(g->p.keys().size()) : 0; }
 extern "C" const char* lc_grok_key(const lc_grok_t* g, int key) {
     return (g && key >= 0 && size_t(key) < g->p.keys().size()) ? g->p.keys()[size_t(key)].c_str() : nullptr;

@@ -1275,6 +1275,11 @@ extern "C" lc_regex_t* lc_regex_compile_relaxed_screen(const char* pattern, size
     }
 }
 
+extern "C" void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided) {
+    if (kept) *kept = re ? uint32_t(re->nfa.atomicCount) : 0u;
+    if (elided) *elided = re ? re->atomicsElided : 0u;
+}
+
 extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,
                                 lc_regex_t** out, char* err, size_t errcap) {
     if (!pattern || !out || engine < LC_ENGINE_AUTO || engine > LC_ENGINE_NFA) {
@@ -1301,6 +1306,11 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             setErr(err, errcap, e.what());
             delete re;
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
+        }
+        // atomic groups that provably change nothing become plain groups (atomic_elide.cpp); LC_NO_ATOMIC_ELIDE: A/B measurements
+        {
+            static const bool off = getenv("LC_NO_ATOMIC_ELIDE") != nullptr;
+            if (!off) re->atomicsElided = uint32_t(lcregex::elideRedundantAtomics(parsed));
         }
         re->requiredLiteral = requiredLiteral(*parsed.root);
         // LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX: the search whose match must START at the first byte -- what a search finds whenever

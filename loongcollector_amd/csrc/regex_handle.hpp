@@ -35,6 +35,7 @@ struct lc_regex {
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
     std::string requiredLiteral;        // longest byte string every match must contain ("" if none is certain)
+    uint32_t atomicsElided = 0;         // atomic groups turned into plain groups because they provably change nothing (atomic_elide.cpp)
     // the decide kernel's per-frame capacities (nfa_decide_kernel.hpp DecideShape): enter / enter+exit events of the longest path
     uint32_t decideMaxEnter = 0, decideClosedCap = 0;
 
@@ -58,6 +59,8 @@ struct lc_regex {
 void lcNoteGaveUp(uint64_t n);
 
 namespace lcregex {
+// atomic_elide.cpp: (?>X) -> (?:X) wherever that provably changes no match and no capture; returns how many groups went plain
+int elideRedundantAtomics(ParsedRegex& re);
 // `block` = workgroup size the register offsets are encoded for (lcTdfaPickBlock)
 // foldPrograms: multi-stamp register programs become stamps of set registers when every program of the table allows it
 // pairMode: the byte-pair extension -- -1: what LC_TDFA_PAIR says (unset / 0: none, 1: two stamps per entry, 2: one stamp);

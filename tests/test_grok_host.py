@@ -352,3 +352,27 @@ def test_c_driven_oracle_walk_names_the_same_winners(golden_dir):
         if w >= 0:      # the winning entry is the first one whose own walk yields fields
             solo = GrokOracle([cfg["match"][int(w)]], custom_patterns=cfg["custom_patterns"])
             assert solo.process_value(v)[1] == fields
+
+
+def test_configs2_corpus_has_the_baseline_shape(golden_dir):
+    """BASELINE.json configs[2]: "mixed 128-4096B lines", 50 patterns.  Every line within 128..4096 bytes, lengths log-uniform (mean
+    ~1.1 KB), and -- by the ORACLE's first-match-wins walk, not by assumption -- at least 35 of the 50 Match entries win some line
+    (44 can: SYSLOGLINE / COMMONAPACHELOG shadow six entries in the reference's file order, loongcollector_amd/grok_corpus.py)."""
+    import numpy as np
+    from loongcollector_amd.grok_corpus import MAX_LINE, MIN_LINE, grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    big = grok_lines(20000)
+    lens = np.array([len(v) for v in big])
+    assert lens.min() >= MIN_LINE == 128 and lens.max() <= MAX_LINE == 4096
+    assert 1050 < lens.mean() < 1250 and 600 < np.median(lens) < 850          # log-uniform over 128..4096: mean 1145, median 724
+    vals = big[:1500]
+    o = GrokOracle(cfg3["match"], custom_patterns=cfg3["custom_patterns"])
+    data = np.frombuffer(b"".join(vals), dtype=np.uint8)
+    length = np.array([len(v) for v in vals], dtype=np.uint32)
+    off = np.zeros(len(vals), dtype=np.uint32)
+    off[1:] = np.cumsum(length[:-1])
+    win = o.first_match_batch(data, off, length)
+    winners = set(int(w) for w in win if w >= 0)
+    assert len(winners) >= 35, sorted(winners)
+    assert 0.02 < float((win < 0).mean()) < 0.09                               # ~5 % free text that no format takes

@@ -377,3 +377,53 @@ def test_hostile_patterns_fail_fast_or_compile_fast():
                 outcomes["refused"] += 1
             assert time.time() - t0 < 10, (p[:40], time.time() - t0)
     assert outcomes["ok"] >= 10 and outcomes["refused"] >= 10
+
+
+ELIDE_CASES = [
+    # (pattern, atomic instances kept, groups elided)
+    (r"(?>\d\d){1,2}", 0, 1),                                                   # Grok YEAR: fixed length
+    (r"""(?>(?<!\\)(?>"(?>\\.|[^\\"]+)+"|""|(?>'(?>\\.|[^\\']+)+')|''|(?>`(?>\\.|[^\\`]+)+`)|``))""", 0, 1),   # Grok QUOTEDSTRING
+    (r"(?>[A-Za-z]+:|\\)(?:\\[^\\?*]*)+", 0, 1),                                # Grok WINPATH: delimiter-terminated
+    (r"(?<![0-9.+-])(?>[+-]?(?:(?:[0-9]+(?:\.[0-9]+)?)|(?:\.[0-9]+)))", 1, 0),  # Grok BASE10NUM: "12" is a prefix of "12.5" -> kept
+    (r"(?>a|ab)c", 1, 0),                                                       # the textbook case: kept
+    (r"(?>a+)b", 1, 0), (r"[^,]*+,", 1, 0),                                     # possessive runs are not prefix-free: kept
+    (r"(?>ab|cd)e", 0, 1), (r"x(?>[0-9]+;)y", 0, 1),
+    (r"(?>(\d)\d)", 1, 0),                                                      # captures inside: never touched
+    (r"(?>a(?=b))b", 1, 0),                                                     # look-ahead inside: never touched
+]
+
+
+def test_redundant_atomic_groups_become_plain_groups():
+    """csrc/atomic_elide.cpp: (?>X) with a prefix-free language that the plain form shares, nothing captured or asserted inside, is
+    compiled as (?:X) -- no ordered commit pass in the NFA kernel, no commit bookkeeping in the determinisation.  What is elided and
+    what is kept; and, for every case, the tables against the oracle (which implements atomic groups natively) on subjects made of
+    the patterns' own alphabet, full match and search."""
+    import random
+    rng = random.Random(11)
+    checked = 0
+    for pat, kept, elided in ELIDE_CASES:
+        rx = B.GpuRegex(pat)
+        assert rx.atomic_groups() == (kept, elided), (pat, rx.atomic_groups())
+        alphabet = sorted(set(c for c in pat if c.isalnum() or c in "\"'`\\:;,.+- ")) + ["7", "q", " "]
+        subs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 9))) for _ in range(250)]
+        subs += ["12", "12.5", "1999", "19", "\"a\\\"b\"", "\"\"", "'x y'", "`z`", "c:\\dir\\f", "abc", "ac", "aab", "a,b,", "x12;y", "abe", "cde"]
+        for flags in (0, B.LC_SYNTAX_SEARCH):
+            rxf = B.GpuRegex(pat, syntax_flags=flags)
+            interps = [TdfaInterp(rxf)] if rxf.info()["engine"] == B.LC_ENGINE_TDFA else []
+            if rxf.has_nfa_program():
+                interps.append(AtomicNfaInterp(rxf) if rxf.atomic_groups()[0] else NfaInterp(rxf))
+            o = OracleRegex(pat)
+            for s in subs:
+                sb = s.encode("latin-1")
+                want = o.search(sb) if flags else o.fullmatch(sb)
+                exp = None if want is None else [v for be in want for v in be][0 if flags else 2:]
+                for it in interps:
+                    checked += 1
+                    assert it.fullmatch(sb) == exp, (pat, flags, s, type(it).__name__)
+    assert checked > 8000
+    # the Grok library: every time stamp carries YEAR, the access-log formats QUOTEDSTRING
+    from loongcollector_amd.grok import Grok
+    g = Grok(Match=["%{TIMESTAMP_ISO8601:ts} %{QS:q}"])
+    rx = B.GpuRegex(g.expanded(0).encode(), syntax_flags=B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2)
+    kept, elided = rx.atomic_groups()
+    assert kept == 0 and elided >= 2
