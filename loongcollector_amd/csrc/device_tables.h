@@ -112,6 +112,9 @@ enum {
     NF_MASK_WORDS = 20,   // words per class mask: 2, or 4 for patterns with 65..128 byte classes
     NF_AUX_WORDS = 21,    // words per aux entry: 4 (cond + 2 tag words); 8 (cond + 4) for 65..128 capture slots; 16 (cond + 10) for
                           // 129..320
+    NF_SUFFIX = 22,       // 1: the LAST position is the greedy suffix (?s:.*) of the search wrapper (LC_SYNTAX_SEARCH, with or without
+                          // LC_SYNTAX_PREFIX): a thread on it takes every byte and ends on MATCH whatever follows, so nothing ranked
+                          // below it can win, and a thread list that is that thread alone is decided -- the kernels stop there
     NF_HEADER_WORDS = 24
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

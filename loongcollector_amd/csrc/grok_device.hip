@@ -71,6 +71,7 @@ struct GrokDeviceState {
     void* dScreens[kLcMaxDevices] = {};
     uint32_t nScreens[kLcMaxDevices] = {};
     uint32_t screenLdsBytes[kLcMaxDevices] = {};  // largest staged table
+    std::vector<GrokScreenDev> hostScreens[kLcMaxDevices];  // the same table on the host (kernel arguments of the remainder screens)
     // lcGrokMatchHost: groups of runner threads that arrive while a batch is on the device travel together (group commit)
     struct HostJob;
     std::mutex jobsMutex;
@@ -263,7 +264,7 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
             // later).  Both append to the same next-round list.
             auto tRound = now();
             uint32_t* out = outs[flip];
-            int rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, capsRow / 2,
+            int rc = lcMatchOnStream(gp.anchored, gp.anchored->engine, dev, d_data, d_off, d_len, 0, nIn, nullptr, in, nullptr, capsRow / 2,
                                      caps, status, st);
             if (rc != LC_OK) return rc;
             hipLaunchKernelGGL(grok_unmatched_kernel, dim3((nIn + kGrokBlock - 1) / kGrokBlock), dim3(kGrokBlock), 0, st, in, nIn, status,
@@ -329,7 +330,7 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
 namespace {
 constexpr int kGrokMaxStreams = 16;  // (LC_GROK_STREAMS; the default stays opts.streams = 8)
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
-constexpr uint32_t kGrokMaxRounds = GC_FILTERED - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
+constexpr uint32_t kGrokMaxRounds = GC_REMAINDER - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
 constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
@@ -452,6 +453,7 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
             state->dScreens[dev] = p;
         }
         state->nScreens[dev] = uint32_t(host.size());
+        state->hostScreens[dev] = host;
         state->screenLdsBytes[dev] = maxStage;
         state->screensBuilt[dev] = true;
     }
@@ -465,6 +467,7 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
 struct PlanEntry {
     uint32_t p = 0, cand = 0, capsRow = 0, columns = 0, rounds = 0, ran = 0;
     bool second = false;  // searched in the second pass, on the values nobody has won by then
+    const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
     int stream = 0;
     double cost = 0;
     GrokEntryDev dev{};
@@ -583,6 +586,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.columns = patterns[p].columns;
         e.capsRow = 2 * (patterns[p].columns + 1);
         e.rounds = std::max(1u, std::min(kGrokMaxRounds, patterns[p].re->grokRounds.load(std::memory_order_relaxed)));
+        for (const GrokScreenDev& sd : state->hostScreens[dev])
+            if (sd.bit == p) e.remainderScreen = &sd;
+        if (e.remainderScreen) e.rounds = std::max(2u, e.rounds);  // (round 1 reads the screened list: it has to be queued)
         const bool nfa = patterns[p].re->engine == LC_ENGINE_NFA;
         e.cost = double(c) * (nfa ? (patterns[p].anchored ? 8.0 : 40.0) : 1.0);
         // an automaton that walks its tables in global memory (tdfa_l2_kernel) takes as long as its LONGEST candidate -- one dependent
@@ -699,7 +705,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             uint32_t* out0 = e.listA;
             uint32_t* outCount0 = e.dev.cnt + GC_ROUND0;
             if (gp.anchored) {
-                rc = lcMatchOnStream(gp.anchored, LC_ENGINE_TDFA, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, nullptr,
+                rc = lcMatchOnStream(gp.anchored, gp.anchored->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, nullptr,
                                      e.capsRow / 2, e.caps, e.status, ws);
                 if (rc != LC_OK) return rc;
                 hipLaunchKernelGGL(grok_unmatched2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list0, e.cand, count0, e.status,
@@ -715,11 +721,22 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (rc != LC_OK) return rc;
                 advance(list0, count0, out0, outCount0, last0);
             }
+            // What is still in play behind its first match goes on only if its REMAINDER passes the entry's screen (a further match
+            // lies inside it and contains a match of the screen): round 1 then reads that list -- usually an empty one -- instead of
+            // searching kilobytes in which nothing will be found on the thread-list engine.
+            const GrokScreenDev* rs = e.remainderScreen;
+            if (rs && e.rounds > 1) {
+                lcNoteKernel("grok_remainder_screen_kernel");
+                hipLaunchKernelGGL(grok_remainder_screen_kernel, dim3(grid), dim3(kGrokPlanBlock), small ? rs->ldsBytes : 0, ws, d_data, e.dev,
+                                   static_cast<const uint32_t*>(out0), static_cast<const uint32_t*>(outCount0), *rs, small ? 1u : 0u,
+                                   e.unanchored, e.dev.cnt + GC_REMAINDER);
+            }
             // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
             for (uint32_t r = 1; r < e.rounds; ++r) {
-                const uint32_t* list = (r & 1) ? e.listA : e.listB;
+                const bool screened = rs && r == 1;
+                const uint32_t* list = screened ? e.unanchored : (r & 1) ? e.listA : e.listB;
                 uint32_t* out = (r & 1) ? e.listB : e.listA;
-                const uint32_t* countPtr = e.dev.cnt + GC_ROUND0 + r - 1;
+                const uint32_t* countPtr = screened ? e.dev.cnt + GC_REMAINDER : e.dev.cnt + GC_ROUND0 + r - 1;
                 rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
                                      e.capsRow / 2, e.caps, e.status, ws);
                 if (rc != LC_OK) return rc;

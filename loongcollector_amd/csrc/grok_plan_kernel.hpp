@@ -39,6 +39,7 @@ enum {
     GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
     GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
     GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
+    GC_REMAINDER = 62,  // slots still in play after round 0 whose REMAINDER passes the entry's screen (grok_remainder_screen_kernel)
     GC_FILTERED = 63,   // second-pass entries: slots left after grok_filter_won_kernel
     GC_WORDS = 64
 };
@@ -271,6 +272,58 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_filter_won_kernel(GrokEnt
     if ((threadIdx.x & 63u) == 0) at = atomicAdd(count, uint32_t(__popcll(b)));
     at = __shfl(at, 0, 64);
     if (keep) out[at + __popcll(b & ((1ull << (threadIdx.x & 63u)) - 1ull))] = k;
+}
+
+// FindNextMatch (processor_grok.go:176) searches what is left of the value behind a match -- for a format that ends 150 bytes into a
+// 4 KiB value that is 3.9 KiB in which nothing will be found, on the slowest engine there is (an unanchored search on the thread-list
+// kernel starts an attempt at every byte the format can begin with).  A further match lies entirely inside [from, len), and every
+// match of the entry contains a match of the entry's screen (the relaxed whole pattern, or the prefix; no assertions), so the slots
+// whose remainder the screen rejects are done: one lane per slot, the yes/no DFA walked from `from`.  stage != 0: tables of up to
+// ldsBytes are staged into LDS (dynamic LDS = sc.ldsBytes).
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_screen_kernel(const uint8_t* __restrict__ data, GrokEntryDev e,
+                                                                              const uint32_t* __restrict__ in,
+                                                                              const uint32_t* __restrict__ inCount, GrokScreenDev sc,
+                                                                              uint32_t stage, uint32_t* __restrict__ out,
+                                                                              uint32_t* __restrict__ outCount) {
+    extern __shared__ uint32_t ldsWords[];
+    __shared__ uint8_t cmap[256];
+    const uint32_t tid = threadIdx.x;
+    uint32_t nIn = *inCount;
+    nIn = nIn < e.cand ? nIn : e.cand;
+    if (blockIdx.x * kGrokPlanBlock >= nIn) return;
+    const uint32_t* blob = sc.blob;
+    cmap[tid] = reinterpret_cast<const uint8_t*>(blob + SC_HEADER_WORDS)[tid];
+    const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
+    const uint8_t* accept = reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_ACCEPT];
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
+    const bool staged = stage && sc.ldsBytes != 0;
+    if (staged) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
+        for (uint32_t i = tid; i < sc.ldsBytes / 4; i += kGrokPlanBlock) ldsWords[i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;
+    const uint16_t* lTable = staged ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]))
+                                    : table;
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + tid;
+    if (k >= nIn) return;
+    const uint32_t slot = in[k];
+    const uint32_t L = e.len[slot], from = e.from[slot];
+    uint32_t state = start;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + e.off[slot] + from;
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+    const uint32_t total = L > from ? head + (L - from) : 0;
+    for (uint32_t pos = 0; pos < total && state != sink && state != 0; pos += 16) {
+        const uint4 w4 = *q++;
+        const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t bi = pos + j;
+            if (bi >= head && bi < total) state = lTable[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
+        }
+    }
+    if (state == sink || (state != 0 && lAccept[state])) out[atomicAdd(outCount, 1u)] = slot;
 }
 
 // After one search round over the slots in `in` (nullptr: all slots below the bound); see grok_advance_kernel (grok_kernel.hpp)

@@ -14,8 +14,9 @@ struct GrokDevicePattern {
     uint32_t columns;    // named groups
     lc_regex* screen;    // optional screen for the pattern's prefix (regex_handle.hpp lcCompilePrefixScreen), or null
     lc_regex* relaxed = nullptr;  // optional screen for the whole pattern, relaxed (lcCompileRelaxedScreen), or null
-    lc_regex* anchored = nullptr; // optional: the same pattern as an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX) on the TDFA
-                                  // engine, same groups: tried first on values searched from their first byte
+    lc_regex* anchored = nullptr; // optional: the same pattern as an ANCHORED search (LC_SYNTAX_SEARCH | LC_SYNTAX_PREFIX), same groups --
+                                  // on the TDFA engine where the automaton builds, else on the NFA engine: tried first on values
+                                  // searched from their first byte
 };
 
 // How a handle wants its batches matched (ProcessorGrokGpu carries one; nothing here changes a result).

@@ -16,6 +16,7 @@
 //   3. lane j pulls its captures from its source lane with ds_bpermute and stamps the tagged slots.
 constexpr int kNfaBlock = 256;  // 4 wavefronts = 4 lines per workgroup, sharing one LDS copy of the tables
 constexpr int kNfaWaves = kNfaBlock / 64;
+constexpr uint32_t kNfaSteadyScanThreads = 6;  // live threads up to which a steady byte triggers the scan for the end of its run
 
 // LDS hand-off between lanes of ONE wavefront: order the wave's own DS operations and stop the compiler from
 // moving loads/stores across the hand-off (no s_barrier needed, the wave is the only party).
@@ -401,6 +402,8 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         }
     }
     const bool searchSkip = hdr[NF_SEARCH] != 0;
+    // the last position is the search wrapper's greedy suffix (search and anchored search, device_tables.h NF_SUFFIX)
+    const bool hasSuffix = hdr[NF_SUFFIX] != 0;
     // steady classes of the search wrapper's prefix position (words 2, 3 only exist for patterns with > 64 byte classes)
     const uint32_t stable0[4] = {stable[0], stable[1], maskShift == 2 ? stable[2] : 0u, maskShift == 2 ? stable[3] : 0u};
     uint32_t curWord;
@@ -410,6 +413,12 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     }
 
     for (uint32_t i = from; i < L && nThreads && !overflow; ++i) {
+        // The thread list is the suffix thread alone: it takes every byte that is left and ends on MATCH, no other thread can appear
+        // (threads only come from threads) and no capture moves -- the value is decided, whatever its length.  A log format that ends
+        // 150 bytes into a 4 KiB value used to walk the other 3.9 KiB.
+        if (hasSuffix && nThreads == 1 && __builtin_amdgcn_readfirstlane(myPos) == nPos - 1 &&
+            (!ATOMIC || __builtin_amdgcn_readfirstlane(nlin) == 0))
+            break;
         const uint32_t idx = head + i;
         if (i != from && (idx & 255u) == 0) {  // next 256-byte chunk: one coalesced dword per lane
             const uint32_t w = (idx >> 2) + lane;
@@ -455,6 +464,34 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
             const bool bit = nfaMaskBit(stable, maskShift, myPos, cw, cb);
             if (__all(!liveLane || bit)) {
                 prevCls = cls;
+                // A steady byte is usually the first of a RUN of them (inside a field, inside GREEDYDATA): with a few live threads all
+                // 64 lanes test the rest of the loaded 256-byte chunk at once -- 4 bytes each against every live thread's steady mask --
+                // and the walk resumes at the first byte that is not steady for some thread (or at the end of the chunk).
+                if (nThreads <= kNfaSteadyScanThreads) {
+                    const uint32_t chunkBase = idx & ~255u, end = head + L;
+                    uint32_t firstHit = 4;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                        const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
+                        bool steadyAll = true;
+                        for (uint32_t t = 0; t < nThreads; ++t)
+                            steadyAll = steadyAll && nfaMaskBit(stable, maskShift, __builtin_amdgcn_readlane(myPos, t), c >> 5, c & 31u);
+                        if (bi > idx && bi < end && !steadyAll) firstHit = uint32_t(j);
+                    }
+                    const uint64_t hit = __ballot(firstHit < 4);
+                    uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;
+                    if (hit) {
+                        const int l = __ffsll((long long)hit) - 1;
+                        stop = chunkBase + uint32_t(l) * 4 + uint32_t(__shfl(int(firstHit), l, 64));
+                    }
+                    stop = __builtin_amdgcn_readfirstlane(stop);
+                    if (stop > idx + 1) {  // bytes (idx, stop) are steady too; remember the class of the last one
+                        const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
+                        prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                        i = stop - head - 1;
+                    }
+                }
                 continue;
             }
         }
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                     break;
                 }
                 nThreads = kept;
-                if (searchSkip) {  // see the vector path below; a membership could still get the suffix thread killed
+                if (hasSuffix) {  // see the vector path below; a membership could still get the suffix thread killed
                     const uint64_t suf = __ballot(lane < nThreads && newPos[lane] == nPos - 1 && actx.newNlin[lane] == 0);
                     if (suf) nThreads = uint32_t(__ffsll((long long)suf));
                 }
@@ -559,7 +596,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         // Search patterns: a thread on the wrapper's suffix position ((?s:.*), the last position) takes every byte and
         // ends on MATCH whatever follows, so nothing of lower priority can win any more -- above all the wrapper's lazy
         // prefix thread, which would otherwise keep starting new attempts at every byte of the rest of the line.
-        if (searchSkip) {
+        if (hasSuffix) {
             const uint64_t suf = __ballot(lane < nThreads && newPos[lane] == nPos - 1);
             if (suf) nThreads = uint32_t(__ffsll((long long)suf));
         }

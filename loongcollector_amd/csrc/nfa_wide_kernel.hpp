@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         for (uint32_t w = lane; w < totalWins; w += 64) best[newPos[w]] = 0xFFFFFFFFu;  // clear the election marks
         waveLdsSync();
         nThreads = totalWins;
-        if (hdr[NF_SEARCH]) {  // nothing ranked below a thread on the wrapper's suffix position can win (nfa_kernel.hpp)
+        if (hdr[NF_SUFFIX]) {  // nothing ranked below a thread on the wrapper's suffix position can win (nfa_kernel.hpp)
             const uint64_t s0 = __ballot(lane < nThreads && newPos[lane] == nPos - 1);
             const uint64_t s1 = __ballot(lane + 64 < nThreads && newPos[(lane + 64) & 127u] == nPos - 1);
             if (s0) nThreads = uint32_t(__ffsll((long long)s0));

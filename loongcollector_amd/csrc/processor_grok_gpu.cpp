@@ -215,8 +215,13 @@ void ProcessorGrokGpu::startWarmup() {
                     const size_t i = want[t];
                     lc_regex_t* re = nullptr;
                     char err[64];
-                    // (failure = the automaton is too large even anchored: the entry searches on the NFA engine only)
+                    // The automaton may be too large even anchored (a format with two or three IPv6 alternations).  The anchored search
+                    // still pays on the thread-list engine: without the wrapper's lazy prefix no new attempt is started at every byte
+                    // that can begin the format -- a log format matches FROM the first byte, and then its thread list is one or two
+                    // threads whose steady runs the kernel skips (nfa_kernel.hpp), instead of a list that changes on every byte.
                     if (lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax | LC_SYNTAX_PREFIX, LC_ENGINE_TDFA, &re,
+                                         err, sizeof err) != LC_OK &&
+                        lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax | LC_SYNTAX_PREFIX, LC_ENGINE_NFA, &re,
                                          err, sizeof err) != LC_OK)
                         continue;
                     const int64_t bytes = 2 * int64_t((re->tdfaL2Blob.size() + re->tdfaBlob.size() + re->tdfaWideBlob.size()) * 4);
@@ -464,7 +469,7 @@ extern "C" int lc_grok_entry_info(lc_grok_t* g, int i, uint32_t out[12]) {
     out[5] = e.anchored != nullptr;
     if (e.anchored) {
         out[6] = e.anchored->tdfa.nStates;
-        out[7] = where(e.anchored);
+        out[7] = e.anchored->engine == LC_ENGINE_NFA ? 3u : where(e.anchored);  // (3: anchored search on the thread-list engine)
         out[8] = uint32_t(e.anchored->tdfaL2Blob.size() * 4);
         out[9] = e.anchored->tdfa.nRegs;
         out[10] = e.anchored->tdfa.nClasses;

@@ -586,6 +586,11 @@ std::vector<uint32_t> packTdfaL2Blob(const TdfaTables& t) {
     hdr[TL_OFF_FINALID] = w.put(t.finalId);
     hdr[TL_OFF_FINALMAP] = w.put(t.finalMap);
     if (!t.startAfter.empty()) hdr[TL_OFF_STARTAFTER] = w.put(t.startAfter);
+    for (uint32_t st = 1; st < t.nStates && !hdr[TL_ABSORB]; ++st) {
+        bool self = t.finalId[st] != 0xFFFF;
+        for (uint32_t c = 0; c < t.nClasses && self; ++c) self = t.trans[size_t(st) * t.nClasses + c] == st;  // (next = st, program 0)
+        if (self) hdr[TL_ABSORB] = st;
+    }
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(TL_TOTAL_BYTES);
 }
@@ -708,6 +713,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_NPATHS] = uint32_t(paths.size() / 2);
     hdr[NF_CONDS_USED] = nfa.condsUsed;
     hdr[NF_SEARCH] = nfa.searchPrefix == 0 ? 1u : 0u;
+    hdr[NF_SUFFIX] = (nfa.searchSuffix >= 0 && nfa.searchSuffix == npos - 1) ? 1u : 0u;
     hdr[NF_MASK_WORDS] = uint32_t(mw);
     hdr[NF_AUX_WORDS] = uint32_t(aw);
     hdr[NF_OFF_CLASSMAP] = w.put(classMapOut);

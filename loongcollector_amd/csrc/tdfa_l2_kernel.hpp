@@ -66,13 +66,15 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
     const uint32_t head = uint32_t(addr & 15);
     const uint4* q = reinterpret_cast<const uint4*>(addr - head);
     const uint32_t total = L > from ? head + (L - from) : 0;
-    for (uint32_t p0 = 0; p0 < total && state != 0; p0 += 16) {
+    // (a line in the absorbing state is decided: nothing it still holds can change its state or a register -- TL_ABSORB)
+    const uint32_t absorb = blob[TL_ABSORB];
+    for (uint32_t p0 = 0; p0 < total && state != 0 && state != absorb; p0 += 16) {
         const uint4 v = *q++;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t bi = p0 + j;
-            if (bi >= head && bi < total && state != 0) {
+            if (bi >= head && bi < total && state != 0 && state != absorb) {
                 const uint32_t t = trans[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
                 const uint32_t prog = t >> 16;
                 if (prog) {

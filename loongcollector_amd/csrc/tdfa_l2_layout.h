@@ -15,6 +15,8 @@ enum {
     TL_OFF_FINALMAP = 10,  // u8[finals][nSlots]: register | 0xFF = end of line | 0xFE = unset
     TL_OFF_STARTAFTER = 11, // u32[nClasses] or 0: state a resumed search starts in, by the class of the byte before
     TL_TOTAL_BYTES = 12,
+    TL_ABSORB = 13,        // a state that accepts, moves to itself on every byte class and runs no register program (the search wrapper's
+                           // suffix (?s:.*) on its own), or 0: a line that reaches it is decided -- the kernel stops reading it
     TL_HEADER_WORDS = 16   // the class map (u8[256]) follows the header
 };
 #define TL_MAGIC_VALUE 0x324C4454u

@@ -95,7 +95,7 @@ class NfaInterp:
         # repeats itself -- or, in a search pattern, also re-spawns the wrapper's suffix thread, which changes nothing)
         st = blob[int(blob[11]) // 4:int(blob[11]) // 4 + mw * (self.npos + 1)]
         self.stable = [sum(int(st[mw * p + k]) << (32 * k) for k in range(mw)) for p in range(self.npos + 1)]
-        self.search_suffix = self.npos - 1 if int(blob[18]) else -1                                # NF_SEARCH
+        self.search_suffix = self.npos - 1 if int(blob[22]) else -1                                # NF_SUFFIX (search and anchored search)
         self.follow = []
         for p in range(self.npos + 1):
             lst = []
@@ -120,6 +120,9 @@ class NfaInterp:
         for pos, b in enumerate(s):
             if pos < start:
                 continue
+            # (the kernel stops when the suffix thread is the only one left: it takes every byte and ends on MATCH)
+            if steady and self.search_suffix >= 0 and len(threads) == 1 and threads[0][0] == self.search_suffix:
+                break
             cls = int(self.cmap[b])
             if steady and all((self.stable[p] >> cls) & 1 for p, _ in threads):
                 prev_cls = cls

@@ -21,7 +21,7 @@ L = binding.load()
 L.lc_grok_entry_info.restype = ctypes.c_int
 L.lc_grok_entry_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
 print("%2s %-46s %-4s %7s %3s %6s %6s | %3s %7s %3s %9s %4s %4s" % ("i", "entry", "eng", "states", "mem", "pscr", "rscr", "anc", "states", "mem", "bytes", "regs", "cls"))
-where = {0: "-", 1: "LDS", 2: "L2"}
+where = {0: "-", 1: "LDS", 2: "L2", 3: "NFA"}
 for i, m in enumerate(cfg["match"]):
     o = (ctypes.c_uint32 * 12)()
     assert L.lc_grok_entry_info(g._h, i, o) == 0
