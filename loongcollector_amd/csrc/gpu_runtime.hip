@@ -681,7 +681,14 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         void* dBlob = nullptr;
         rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
         if (rc != LC_OK) return rc;
-        size_t lds = size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
+        // Small and medium batches wait for their longest value: ONE VALUE PER WAVEFRONT (tdfa_wave_kernel: wave-uniform state, quiet
+        // runs crossed 256 bytes at a time).  Large batches are about values in flight: one value per lane.  LC_TDFA_WAVE_MAX: the
+        // largest batch that takes the wave kernel (0 = never; A/B measurements).
+        // (read at every launch: the GPU tests run both kernels in one process)
+        const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
+        const uint32_t waveMax = uint32_t(waveEnv ? atol(waveEnv) : 65536);
+        const bool perWave = n <= waveMax;
+        size_t lds = perWave ? size_t(re->tdfa.nRegs) * kTdfaWaveValues * 4 : size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
         // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
         uint32_t stageBytes = 0;
         {
@@ -689,6 +696,19 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
             const uint32_t progBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_OPSSTART] + 3u) & ~3u;
             if (!stageOff && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stageBytes = progBytes;
         }
+        if (perWave) {
+            lds += stageBytes;
+            static thread_local size_t waveLdsAttrSet[kLcMaxDevices] = {};
+            if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > waveLdsAttrSet[dev]) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                waveLdsAttrSet[dev] = lds;
+            }
+            noteKernel("tdfa_l2_kernel:wave");
+            hipLaunchKernelGGL(tdfa_wave_kernel, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream, d_data,
+                               d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status,
+                               stageBytes);
+            HIP_TRY(hipGetLastError());
+        } else {
         lds += stageBytes;
         static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
         if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > ldsAttrSet[dev]) {
@@ -700,6 +720,7 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
                            d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, stageBytes);
         HIP_TRY(hipGetLastError());
+        }
     } else if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;

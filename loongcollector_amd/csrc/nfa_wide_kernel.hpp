@@ -7,8 +7,8 @@
 // launch of the NFA kernel on the same stream and costs a launch of empty workgroups unless that kernel raised its
 // overflow flag (launch sequence number, atomicMax -- the same protocol as the TDFA kernel's long-line flag).
 //
-// One line per 64-lane workgroup; the tables are read in place from HBM/L2 (this is the rare path: no LDS staging, no
-// steady-state shortcut, no start-byte skip); LDS holds the election marks and the hand-off arrays only.  Patterns with
+// One line per 64-lane workgroup; the tables are read in place from HBM/L2 (no LDS staging, no start-byte skip; the steady-state
+// shortcuts of nfa_match_kernel since round 4); LDS holds the election marks and the hand-off arrays only.  Patterns with
 // atomic groups are not handled here (their ordered commit pass is serial in lane 0 and has its own 64-entry work
 // arrays): their lines stay LC_OVERFLOW.
 #pragma once
@@ -93,10 +93,65 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     }
     uint32_t nThreads = 1;
     bool overflow = false;
+    // Round 4: a value lands here because ONE stretch of it (an IPv6 address) needs more than 64 threads; the rest of it is the same
+    // walk as in nfa_match_kernel and takes the same shortcuts -- bytes come from a 256-byte chunk held one dword per lane, a thread
+    // list that is the suffix thread alone ends the walk, and a steady byte (every live thread on a tag-free self loop) starts a scan
+    // of the chunk for the end of its run.  (Before: one dependent global load per byte, 3.6 us a byte, 15 ms for a 4 KiB value.)
+    const bool hasSuffix = hdr[NF_SUFFIX] != 0;
+    const uint32_t* stable = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_STABLE]);
+    const uint32_t maskShift = tb.maskShift;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
+    const uint32_t head = uint32_t(addr & 3);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
+    const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
+    uint32_t curWord;
+    {
+        const uint32_t w = (((head + from) >> 8) << 6) + lane;
+        curWord = (w < nWords) ? words[w] : 0;
+    }
 
     for (uint32_t i = from; i < L && nThreads && !overflow; ++i) {
-        const uint32_t cls = classMap[data[size_t(o) + i]];  // wave-uniform address: one broadcast load
+        if (hasSuffix && nThreads == 1 && __builtin_amdgcn_readfirstlane(pos[0]) == nPos - 1) break;  // decided (nfa_kernel.hpp)
+        const uint32_t idx = head + i;
+        if (i != from && (idx & 255u) == 0) {
+            const uint32_t w = (idx >> 2) + lane;
+            curWord = (w < nWords) ? words[w] : 0;
+        }
+        const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
+        const uint32_t cls = classMap[(wsel >> ((idx & 3u) * 8)) & 0xFFu];
         const uint32_t cw = cls >> 5, cb = cls & 31u;
+        if (nThreads <= 64) {  // steady byte: nothing moves (nfa_kernel.hpp); with few threads, look for the end of the run
+            const bool bit = lane < nThreads && nfaMaskBit(stable, maskShift, pos[0], cw, cb);
+            if (__all(lane >= nThreads || bit)) {
+                prevCls = cls;
+                if (nThreads <= kNfaSteadyScanThreads) {
+                    const uint32_t chunkBase = idx & ~255u, end = head + L;
+                    uint32_t firstHit = 4;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                        const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
+                        bool steadyAll = true;
+                        for (uint32_t t = 0; t < nThreads; ++t)
+                            steadyAll = steadyAll && nfaMaskBit(stable, maskShift, __builtin_amdgcn_readlane(pos[0], t), c >> 5, c & 31u);
+                        if (bi > idx && bi < end && !steadyAll) firstHit = uint32_t(j);
+                    }
+                    const uint64_t hit = __ballot(firstHit < 4);
+                    uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;
+                    if (hit) {
+                        const int l = __ffsll((long long)hit) - 1;
+                        stop = chunkBase + uint32_t(l) * 4 + uint32_t(__shfl(int(firstHit), l, 64));
+                    }
+                    stop = __builtin_amdgcn_readfirstlane(stop);
+                    if (stop > idx + 1) {
+                        const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
+                        prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                        i = stop - head - 1;
+                    }
+                }
+                continue;
+            }
+        }
         const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];
         prevCls = cls;
         const bool live0 = lane < nThreads, live1 = lane + 64 < nThreads;

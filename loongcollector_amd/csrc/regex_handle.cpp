@@ -468,8 +468,19 @@ std::vector<uint32_t> packTdfaBlob(const TdfaTables& t, int block, bool wide, bo
     }
     hdr[TD_OFF_FINALID] = w.put(t.finalId);
     hdr[TD_OFF_FINALMAP] = w.put(t.finalMap);
-    hdr[TD_OFF_OPSSTART] = w.put(t.opsStart);
-    hdr[TD_OFF_OPS] = w.put(t.ops);
+    {
+        // (no transition of this blob names a general program -- every list is one stamp, or folded into its set's register: the
+        // lists themselves are never read; 200-300 bytes of LDS that decide whether regex B's pair tables fit two workgroups per CU)
+        bool anyList = false;
+        for (size_t id = 1; id < nLists; ++id) anyList = anyList || (field[id] & TD_OP_GENERAL);
+        if (anyList) {
+            hdr[TD_OFF_OPSSTART] = w.put(t.opsStart);
+            hdr[TD_OFF_OPS] = w.put(t.ops);
+        } else {
+            hdr[TD_OFF_OPSSTART] = w.put(std::vector<uint32_t>{0u, 0u});
+            hdr[TD_OFF_OPS] = w.put(std::vector<uint16_t>{0});
+        }
+    }
     // ---- byte-pair extension: one dependent LDS lookup per TWO bytes.  Only for small automata (log-format regexes
     // have 10-20 byte classes and a few dozen states): the table grows with (classes+1)^2.
     const uint64_t pairRowBytes = uint64_t(cols) * cols * 4;
@@ -586,6 +597,13 @@ std::vector<uint32_t> packTdfaL2Blob(const TdfaTables& t) {
     hdr[TL_OFF_FINALID] = w.put(t.finalId);
     hdr[TL_OFF_FINALMAP] = w.put(t.finalMap);
     if (!t.startAfter.empty()) hdr[TL_OFF_STARTAFTER] = w.put(t.startAfter);
+    {
+        std::vector<uint64_t> quiet(t.nStates, 0);
+        for (uint32_t st = 1; st < t.nStates; ++st)
+            for (uint32_t c = 0; c < t.nClasses && c < 64; ++c)
+                if (t.trans[size_t(st) * t.nClasses + c] == st) quiet[st] |= uint64_t(1) << c;
+        hdr[TL_OFF_QUIET] = w.put(quiet);
+    }
     for (uint32_t st = 1; st < t.nStates && !hdr[TL_ABSORB]; ++st) {
         bool self = t.finalId[st] != 0xFFFF;
         for (uint32_t c = 0; c < t.nClasses && self; ++c) self = t.trans[size_t(st) * t.nClasses + c] == st;  // (next = st, program 0)

@@ -77,7 +77,8 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
 
 // LDS budgeting shared by the compile-time engine choice (regex_handle.cpp) and the launchers (gpu_runtime.hip).
 // TDFA: tables + nRegs x BLOCK x 4 B of offset registers.  Prefer 256-lane workgroups while a workgroup stays under
-// 64 KiB (>= 2 workgroups per CU); shrink the workgroup before giving up.  0 = does not fit in 160 KiB at all.
+// 80 KiB (2 workgroups per CU; round 4: was 64 KiB, which cost regex B's byte-pair tables their folded registers); shrink the
+// workgroup before giving up.  0 = does not fit in 160 KiB at all.
 constexpr size_t kLcLdsPerCu = 160 * 1024;
 // nRegs counts the real offset registers; the kernel adds one dummy register (see device_tables.h)
 inline size_t lcTdfaRegBytes(uint32_t nRegs, int block) { return size_t(nRegs + 1) * size_t(block) * 4; }
@@ -104,7 +105,7 @@ inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
         return lcTdfaRegBytes(nRegs, b) <= 0x10000 && lcTdfaLdsBytes(blobBytes, nRegs, b) <= budget;
     };
     for (int b : {256, 128, 64})
-        if (fits(b, 64 * 1024)) return b;
+        if (fits(b, kLcLdsPerCu / 2)) return b;  // (two workgroups per CU; above 64 KiB the launcher raises the function's dynamic-LDS limit)
     for (int b : {256, 128, 64})
         if (fits(b, kLcLdsPerCu)) return b;
     return 0;

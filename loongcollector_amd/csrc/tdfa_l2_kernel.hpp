@@ -107,3 +107,139 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
     }
     status[line] = matched ? LC_MATCH : LC_NOMATCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// tdfa_wave_kernel -- the same automaton, ONE VALUE PER WAVEFRONT: what small and medium batches want (round 4).
+//
+// A batch of a few thousand values (a Grok entry's candidates, an event group) leaves most of the chip idle whatever the kernel, and
+// what it waits for is its LONGEST value.  One value per lane makes that 4096 dependent table reads through L2 (0.7 ms for a 4 KiB
+// value, 2.1 ms when the rows come from the Infinity Cache), every lane of the wavefront waiting for the slowest one at every byte.
+// Here the state is wave-uniform (table reads are single requests, register programs run once), and the 64 lanes earn their keep on
+// the part of a log line that is NOT structure: a byte whose transition is "stay, stamp nothing" starts a run of such bytes in
+// practice (GREEDYDATA, a quoted string, a path), and all lanes look for the end of the run at once -- 4 bytes each of the 256-byte
+// chunk the wave holds, against the state's QUIET mask (TL_OFF_QUIET: bit c = class c stays in the state without a program).  A
+// log line is ~150 bytes of structure and the rest runs; the absorbing state (TL_ABSORB) ends the walk.
+// Semantics: exactly tdfa_l2_kernel's (same blob, same results -- tests/test_gpu_parity.py runs both on the same lines).
+// LDS: cmap[256] | per wave: registers [nRegs] | (stageBytes != 0) the register programs.
+constexpr int kTdfaWaveBlock = 256;
+constexpr int kTdfaWaveValues = kTdfaWaveBlock / 64;
+
+__global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                  const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                                  const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+                                                                  const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
+                                                                  uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                                                  uint8_t* __restrict__ status, uint32_t stageBytes) {
+    extern __shared__ uint32_t wregs[];  // [kTdfaWaveValues][nRegs], then (stageBytes != 0) opsStart, ops
+    __shared__ uint8_t cmap[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    cmap[tid] = reinterpret_cast<const uint8_t*>(blob + TL_HEADER_WORDS)[tid];
+    const uint32_t nRegs = blob[TL_NREGS], ncls = blob[TL_NCLASSES], nSlots = blob[TL_NSLOTS];
+    uint32_t* regs = wregs + wave * nRegs;
+    for (uint32_t r = lane; r < nRegs; r += 64) regs[r] = 0xFFFFFFFFu;  // unset = -1
+    if (stageBytes) {
+        uint32_t* dst = wregs + kTdfaWaveValues * nRegs;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[TL_OFF_OPSSTART]);
+        for (uint32_t i = tid; i < stageBytes / 4; i += kTdfaWaveBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (nLinesPtr) nLines = *nLinesPtr < nLines ? *nLinesPtr : nLines;
+    const uint32_t slot = blockIdx.x * kTdfaWaveValues + wave;
+    if (slot >= nLines) return;  // wave-uniform; the workgroup does not synchronise again
+    const uint32_t line = order ? order[slot] : slot;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
+    const uint32_t* trans = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_TRANS]);
+    const uint2* quietTab = reinterpret_cast<const uint2*>(base + blob[TL_OFF_QUIET]);
+    const uint8_t* staged = reinterpret_cast<const uint8_t*>(wregs + kTdfaWaveValues * nRegs);
+    const uint32_t* opsStart = stageBytes ? reinterpret_cast<const uint32_t*>(staged)
+                                          : reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
+    const uint16_t* ops = stageBytes ? reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]))
+                                     : reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
+    const uint32_t o = off[line];
+    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    uint32_t state = blob[TL_START], from = 0;
+    if (resume) {
+        from = resume[line];
+        from = from < L ? from : L;
+        if (from) state = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_STARTAFTER])[cmap[data[size_t(o) + from - 1]]];
+    }
+    const uint32_t absorb = blob[TL_ABSORB];
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
+    const uint32_t head = uint32_t(addr & 3);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
+    const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
+    const uint32_t end = head + L;
+    uint32_t chunk = ((head + from) >> 8);  // index of the 256-byte chunk held in curWord
+    uint32_t curWord;
+    {
+        const uint32_t w = (chunk << 6) + lane;
+        curWord = (w < nWords) ? words[w] : 0;
+    }
+    uint32_t idx = head + from;  // position in the word-aligned view
+    while (idx < end && state != 0 && state != absorb) {
+        if ((idx >> 8) != chunk) {
+            chunk = idx >> 8;
+            const uint32_t w = (chunk << 6) + lane;
+            curWord = (w < nWords) ? words[w] : 0;
+        }
+        const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
+        const uint32_t cls = cmap[(wsel >> ((idx & 3u) * 8)) & 0xFFu];
+        const uint32_t t = trans[__builtin_amdgcn_readfirstlane(state * ncls + cls)];
+        const uint32_t prog = t >> 16, next = t & 0xFFFFu;
+        if (prog) {
+            const uint32_t pos = idx - head;
+            uint32_t at = opsStart[prog];
+            const uint32_t n = ops[at];
+            for (uint32_t k = 0; k < n; ++k) {  // (every lane stores the same word: one LDS write)
+                const uint32_t op = ops[++at];
+                const uint32_t src = op >> 8;
+                regs[op & 0xFFu] = src == TD_REG_POS ? pos : regs[src];
+            }
+        } else if (next == state) {
+            // a quiet byte: find the end of the run -- every lane tests its 4 bytes of the chunk, chunk after chunk
+            const uint2 q2 = quietTab[__builtin_amdgcn_readfirstlane(state)];
+            const uint64_t quiet = (uint64_t(q2.y) << 32) | q2.x;
+            uint32_t stop = end;
+            for (;;) {
+                const uint32_t chunkBase = chunk << 8;
+                uint32_t firstHit = 4;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                    const uint32_t c = cmap[(curWord >> (8 * j)) & 0xFFu];
+                    const bool isQuiet = c < 64 && ((quiet >> c) & 1ull);
+                    if (bi > idx && bi < end && !isQuiet) firstHit = uint32_t(j);
+                }
+                const uint64_t hit = __ballot(firstHit < 4);
+                if (hit) {
+                    const int l = __ffsll((long long)hit) - 1;
+                    stop = __builtin_amdgcn_readfirstlane(chunkBase + uint32_t(l) * 4 + uint32_t(__shfl(int(firstHit), l, 64)));
+                    break;
+                }
+                if (chunkBase + 256 >= end) break;  // the run reaches the end of the value
+                ++chunk;
+                const uint32_t w = (chunk << 6) + lane;
+                curWord = (w < nWords) ? words[w] : 0;
+            }
+            idx = stop;
+            continue;
+        }
+        state = next;
+        ++idx;
+    }
+    const uint16_t* finalId = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_FINALID]);
+    const uint8_t* finalMap = base + blob[TL_OFF_FINALMAP];
+    const uint32_t fid = state ? uint32_t(finalId[state]) : 0xFFFFu;
+    const bool matched = fid != 0xFFFFu;
+    int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
+    for (uint32_t s = lane; s < 2 * nGroupsOut; s += 64) {
+        int32_t val = -1;
+        if (matched && s < nSlots) {
+            const uint32_t m = finalMap[fid * nSlots + s];
+            if (m == TD_REG_POS) val = int32_t(L);
+            else if (m != TD_REG_NONE) val = int32_t(regs[m]);
+        }
+        out[s] = val;
+    }
+    if (lane == 0) status[line] = matched ? LC_MATCH : LC_NOMATCH;
+}

@@ -17,6 +17,8 @@ enum {
     TL_TOTAL_BYTES = 12,
     TL_ABSORB = 13,        // a state that accepts, moves to itself on every byte class and runs no register program (the search wrapper's
                            // suffix (?s:.*) on its own), or 0: a line that reaches it is decided -- the kernel stops reading it
+    TL_OFF_QUIET = 14,     // u64[nStates]: bit c = byte class c (< 64) keeps the state and runs no register program -- the bytes the
+                           // wave-per-value kernel crosses without a table read (tdfa_wave_kernel)
     TL_HEADER_WORDS = 16   // the class map (u8[256]) follows the header
 };
 #define TL_MAGIC_VALUE 0x324C4454u

@@ -318,6 +318,41 @@ class TdfaL2BlobInterp:
         self.start_after = blob[o_after // 4:o_after // 4 + self.ncls] if o_after else None
         self.runs = rx.run_captures()
         self.compact = False
+        self.absorb = int(blob[13])                                                     # TL_ABSORB
+        o_quiet = int(blob[14])                                                         # TL_OFF_QUIET: u64[nStates]
+        self.quiet = raw[o_quiet:o_quiet + 8 * self.nstates].view(np.uint64)
+
+    @_with_run_captures
+    def fullmatch_wave(self, s: bytes, start=0):
+        """tdfa_wave_kernel's walk: stops in the absorbing state; a byte whose transition is "stay, no program" starts a scan for
+        the first byte of a class outside the state's QUIET mask (the kernel does that 256 bytes at a time)."""
+        state = self.start if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]])])
+        regs = [-1] * max(self.nregs, 1)
+        pos, n = start, len(s)
+        while pos < n and state != 0 and state != self.absorb:
+            t = int(self.trans[state * self.ncls + int(self.cmap[s[pos]])])
+            if t >> 16:
+                at = int(self.ops_start[t >> 16])
+                for w in self.ops[at + 1:at + 1 + int(self.ops[at])]:
+                    regs[int(w) & 0xFF] = pos if int(w) >> 8 == 0xFF else regs[int(w) >> 8]
+            elif (t & 0xFFFF) == state:
+                q = int(self.quiet[state])
+                pos += 1
+                while pos < n and int(self.cmap[s[pos]]) < 64 and (q >> int(self.cmap[s[pos]])) & 1:
+                    pos += 1
+                continue
+            state = t & 0xFFFF
+            pos += 1
+        if state == 0:
+            return None
+        fid = int(self.final_id[state])
+        if fid == 0xFFFF:
+            return None
+        out = []
+        for sl in range(self.nslots):
+            m = int(self.final_map[fid * self.nslots + sl])
+            out.append(len(s) if m == 0xFF else (-1 if m == 0xFE else regs[m]))
+        return out
 
     @_with_run_captures
     def fullmatch(self, s: bytes, start=0):

@@ -534,7 +534,7 @@ def test_one_stamp_pair_tables_forced_on_every_table_format(torch_dev, golden_di
         wide = compact is not None or len(status) >= 65536
         blob = rx.table(B.LC_TABLE_TDFA_WIDE_BLOB if wide else B.LC_TABLE_TDFA_BLOB, np.uint32)
         one_stamp = int(blob[7]) != 0 and int(blob[int(blob[7]) // 4 + 4]) == 1      # TD_OFF_PAIR, TP_FORMAT
-        assert one_stamp or label[0] == "B", label          # (regex B's STANDARD tables: see test_pair1_tables.py)
+        assert one_stamp, label
         assert ("pair1" in names) == one_stamp, (label, names)
         assert ("compact" in names) == wide, (label, names)
         ran.append((label, names))
@@ -631,10 +631,14 @@ def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
                         pattern, eng, lines[i][:80], int(start[i]), list(caps[i]), exp)
 
 
-def test_automata_too_large_for_lds_run_from_global_memory(torch_dev):
-    """tdfa_l2_kernel: a tagged DFA of 1 000+ states (beyond the 64 KiB LDS window of the lane-per-line kernels) keeps its
-    tables in global memory and still runs one line per lane instead of falling to the NFA engine.  Full match in both input
-    forms, and a search with a listed subset of lines and resume offsets, against the oracle."""
+@pytest.mark.parametrize("wave_max", ["0", "65536"])
+def test_automata_too_large_for_lds_run_from_global_memory(torch_dev, monkeypatch, wave_max):
+    """tdfa_l2_kernel / tdfa_wave_kernel: a tagged DFA of 1 000+ states (beyond the 64 KiB LDS window of the LDS kernels) keeps its
+    tables in global memory and still runs as a DFA instead of falling to the NFA engine -- one value per LANE (large batches;
+    LC_TDFA_WAVE_MAX=0 forces it here) or one value per WAVEFRONT (batches up to 64 Ki values: wave-uniform state, quiet runs
+    crossed chunk-wise).  Full match in both input forms, values with long quiet runs and runs that end at chunk boundaries, and
+    a search with a listed subset of lines and resume offsets, against the oracle."""
+    monkeypatch.setenv("LC_TDFA_WAVE_MAX", wave_max)
     rng = random.Random(99)
     full = rb"(?:a|b)*a(?:a|b){12}(c+)(d*)"
     rx = B.GpuRegex(full)
@@ -645,12 +649,17 @@ def test_automata_too_large_for_lds_run_from_global_memory(torch_dev):
         head = bytes(rng.choice(b"ab") for _ in range(rng.randint(0, 300)))
         return head + rng.choice([b"", b"c", b"ccc", b"cd", b"ccddd", b"x", b"cdc"])
     subs = [subject() for _ in range(3000)] + [b"", b"a" * 10 + b"c", b"ab" * 2000 + b"a" + b"b" * 12 + b"cccd"]
+    # quiet runs: "c+" and "d*" stay in their states -- runs of 1 .. 1100 bytes that end on, before and behind 256-byte chunk borders
+    for run in (1, 2, 3, 5, 200, 254, 255, 256, 257, 258, 511, 512, 513, 1100):
+        for lead in (0, 1, 2, 3, 13):
+            subs.append(b"b" * lead + b"a" + b"b" * 12 + b"c" * run + b"d" * (run // 3))
+            subs.append(b"b" * lead + b"a" + b"b" * 12 + b"c" * run + b"x")
     data, off, length = pack(subs)
     o = OracleRegex(full)
     exp_caps, exp_status = o.fullmatch_batch(data, off, length)
     B.launched_kernels()
     caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
-    assert "tdfa_l2_kernel" in B.launched_kernels()
+    assert ("tdfa_l2_kernel:wave" in B.launched_kernels()) == (wave_max != "0")
     assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps) and 100 < exp_status.sum() < len(subs) - 100
     sep_data = np.frombuffer(b"\n".join(subs) + b"\n", dtype=np.uint8)
     sep_off = np.zeros(len(subs) + 1, dtype=np.uint32)

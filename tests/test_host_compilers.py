@@ -427,3 +427,47 @@ def test_redundant_atomic_groups_become_plain_groups():
     rx = B.GpuRegex(g.expanded(0).encode(), syntax_flags=B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2)
     kept, elided = rx.atomic_groups()
     assert kept == 0 and elided >= 2
+
+
+def test_wave_walk_of_global_memory_automata_equals_the_byte_walk(golden_dir):
+    """tdfa_wave_kernel (one value per wavefront) crosses quiet runs without table reads and stops in the absorbing state: its walk,
+    restated in tests/helpers/table_interp.py TdfaL2BlobInterp.fullmatch_wave, against the plain byte walk of the same blob and the
+    oracle -- on an automaton of 1 000+ states, on an anchored Grok search with a GREEDYDATA tail, and on the quiet-mask table itself
+    (bit c of state s  <=>  class c keeps s and runs no program)."""
+    import random
+    from tests.helpers.table_interp import TdfaL2BlobInterp
+    rng = random.Random(3)
+    cases = [(rb"(?:a|b)*a(?:a|b){12}(c+)(d*)", 0, b"abcdx")]
+    from loongcollector_amd.grok import Grok
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    g = Grok(Match=["%{SYSLOG5424LINE}"], CustomPatterns=cfg3["custom_patterns"])
+    grok_flags = (B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_NO_DOTALL | B.LC_SYNTAX_NO_MULTILINE | B.LC_SYNTAX_REGEXP2)
+    cases.append((g.expanded(0).encode(), grok_flags | B.LC_SYNTAX_PREFIX, None))
+    checked = runs = 0
+    for pat, flags, alphabet in cases:
+        rx = B.GpuRegex(pat, syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
+        assert rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32) is not None, pat[:40]
+        it = TdfaL2BlobInterp(rx)
+        for st in range(1, it.nstates):                       # the quiet table says what the transition table says
+            for c in range(min(it.ncls, 64)):
+                assert bool((int(it.quiet[st]) >> c) & 1) == (int(it.trans[st * it.ncls + c]) == st), (st, c)
+        if it.absorb:
+            assert all(int(it.trans[it.absorb * it.ncls + c]) == it.absorb for c in range(it.ncls)) and int(it.final_id[it.absorb]) != 0xFFFF
+        if alphabet:
+            subs = [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 60))) for _ in range(400)]
+            subs += [b"ab" * 9 + b"a" + b"b" * 12 + b"c" * k + b"d" * (k // 2) for k in (1, 2, 255, 256, 257, 600)]
+        else:
+            subs = [b"<34>1 - host%d app 1 ID%d - " % (k, k) + b" ".join(rng.choice([b"alpha", b"beta7", b"x=1"]) for _ in range(rng.randint(0, 200)))
+                    for k in range(60)]
+            subs += [b"<34>1 2014-10-11T22:14:15.003Z h a 1 I [x y=\"1\"] tail\nmore", b"no match here", b""]
+        o = OracleRegex(pat, 0) if not flags else None
+        for s in subs:
+            a, b = it.fullmatch(s), it.fullmatch_wave(s)
+            assert a == b, (pat[:40], s[:80])
+            checked += 1
+            runs += a is not None
+            if o is not None:
+                want = o.fullmatch(s)
+                assert a == (None if want is None else [v for be in want for v in be][2:]), s
+    assert checked > 450 and runs > 60
