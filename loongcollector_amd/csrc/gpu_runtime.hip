@@ -442,11 +442,15 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
     return LC_OK;
 }
 
+// which part of the NFA engine's chain a launch queues: all of it, the thread-list kernel only (lines that overflow keep LC_OVERFLOW),
+// or the second chance only (nfa_wide_kernel + the depth-first decide kernels, for the lines that still say LC_OVERFLOW)
+enum { kNfaWholeChain = 0, kNfaFirstChance = 1, kNfaSecondChance = 2 };
+
 template <int NS, bool ATOMIC, bool GLOBAL>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq,
-                          const uint32_t* pendingFlag) {
+                          const uint32_t* pendingFlag, int chance = 0) {
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
@@ -456,11 +460,14 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
         ldsAttrSet[devNow] = lds;
     }
     const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
-    noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
-    hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
-                       d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
-                       seq, pendingFlag);
-    HIP_TRY(hipGetLastError());
+    if (chance != kNfaSecondChance) {
+        noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
+        hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
+                           d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
+                           seq, pendingFlag);
+        HIP_TRY(hipGetLastError());
+    }
+    if (chance == kNfaFirstChance) return LC_OK;
     // Second chance for the lines that needed more than 64 live threads (nfa_wide_kernel.hpp: two threads per lane), for
     // patterns without atomic groups whose capture offsets fit twice into a lane's registers.  Its workgroups return at
     // once unless the launch above raised the overflow flag.
@@ -479,7 +486,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
 
 static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
-                     uint8_t* d_status, hipStream_t stream, bool decideOnly = false) {
+                     uint8_t* d_status, hipStream_t stream, bool decideOnly = false, int chance = kNfaWholeChain, uint32_t* seqInOut = nullptr) {
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
         return LC_ERR_UNSUPPORTED;
@@ -508,10 +515,17 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     const uint32_t nPos = uint32_t(re->nfa.positions.size());
     // one word behind the tables (ensureUploaded): raised by the kernel to this launch's sequence number when a line overflows
     uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
-    uint32_t seq = ++re->nfaSeq[dev];
-    if (seq == 0) {  // the 32-bit sequence wrapped: start over below every flag value seen so far
-        HIP_TRY(hipMemsetAsync(overflowFlag, 0, 8, stream));
+    uint32_t seq;
+    if (chance == kNfaSecondChance) {
+        seq = seqInOut ? *seqInOut : 0;  // the first-chance launch's number: its overflow flag is what the kernels test
+        if (!seq) return LC_OK;
+    } else {
         seq = ++re->nfaSeq[dev];
+        if (seq == 0) {  // the 32-bit sequence wrapped: start over below every flag value seen so far
+            HIP_TRY(hipMemsetAsync(overflowFlag, 0, 8, stream));
+            seq = ++re->nfaSeq[dev];
+        }
+        if (seqInOut) *seqInOut = seq;
     }
     // ---- optional first engine: the depth-first walk, one line per lane (nfa_dfs_kernel).  What it leaves pending (budget,
     // pool) is what the thread-list kernels below look at.  OFF by default: with its frames in HBM a walk step costs ~12 us
@@ -575,7 +589,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         auto go = [&](auto a, auto g) {
             return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n,
                                                                               d_n, d_order, d_resume, ngroups, d_caps, d_status,
-                                                                              stream, overflowFlag, seq, pendingFlag);
+                                                                              stream, overflowFlag, seq, pendingFlag, chance);
         };
         if (atomic && global) return go(std::true_type{}, std::true_type{});
         if (atomic) return go(std::true_type{}, std::false_type{});
@@ -594,7 +608,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // Can a thread list overflow at all?  Without atomic groups a list holds at most one thread per position.
     const bool wideApplies = !atomic && slots <= 64 && (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4 <= 64 * 1024;
     const bool canOverflow = atomic || nPos > (wideApplies ? uint32_t(kNfaWideThreads) : 64u);
-    if (!canOverflow) return LC_OK;
+    if (!canOverflow || chance == kNfaFirstChance) return LC_OK;
     return launchDecide(re, dev, dBlob, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
                         overflowFlag, seq);
 }
@@ -670,9 +684,37 @@ extern "C" int lc_regex_screen_device(lc_regex_t* re, const uint8_t* d_data, con
     return lcScreenOnStream(re, dev, d_data, d_off, d_len, n, d_lines, d_out, d_count, stream);
 }
 
+static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
+                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
+                         int32_t* d_caps, uint8_t* d_status, void* streamPtr, int chance, uint32_t* seqInOut);
+
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr) {
+    return lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, streamPtr,
+                                kNfaWholeChain, nullptr);
+}
+// The engine's main kernel only; *seq = what lcMatchSecondChanceOnStream needs to finish the lines that came back LC_OVERFLOW
+// (0: this engine has no second chance -- a DFA decides every line).  The Grok matcher queues the second chance only for the
+// entries whose first chance reported overflows (grok_device.hip).
+int lcMatchFirstOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                         uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
+                         int32_t* d_caps, uint8_t* d_status, uint32_t* seq, void* streamPtr) {
+    *seq = 0;
+    return lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, streamPtr,
+                                kNfaFirstChance, seq);
+}
+int lcMatchSecondChanceOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                                uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                                uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, uint32_t seq, void* streamPtr) {
+    if (!seq || engine != LC_ENGINE_NFA) return LC_OK;
+    return lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, streamPtr,
+                                kNfaSecondChance, &seq);
+}
+
+static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
+                         const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
+                         int32_t* d_caps, uint8_t* d_status, void* streamPtr, int chance, uint32_t* seqInOut) {
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int rc;
     if (!re->nfa.runGroups.empty()) tlsDone.armed = false;  // run_capture_kernel runs behind the match: it cannot signal
@@ -729,7 +771,7 @@ int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, co
         rc = launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
     } else {
         rc = launchNfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
-                       engine == LC_ENGINE_DECIDE);
+                       engine == LC_ENGINE_DECIDE, engine == LC_ENGINE_DECIDE ? kNfaWholeChain : chance, seqInOut);
     }
     if (rc != LC_OK) return rc;
     for (const auto& rg : re->nfa.runGroups) {

@@ -346,6 +346,8 @@ struct PlanThread {
     GrokEntryDev* hostEntries = nullptr;  // pinned [64]
     GrokEntryDev* dEntries = nullptr;     // device [64]
     uint32_t* dCnt = nullptr;             // device [64][GC_WORDS]
+    GrokScreenDev* hostRemScreens = nullptr;  // pinned [64]: per ACTIVE entry, its screen (blob == nullptr: none)
+    GrokScreenDev* dRemScreens = nullptr;     // device [64]
     void* arena = nullptr;                // device, grow-only: the per-entry arrays of the batch in flight
     size_t arenaCap = 0;
     ~PlanThread() { release(); }
@@ -366,6 +368,8 @@ struct PlanThread {
                 if (hostEntries) (void)hipHostFree(hostEntries);
                 if (dEntries) (void)hipFree(dEntries);
                 if (dCnt) (void)hipFree(dCnt);
+                if (hostRemScreens) (void)hipHostFree(hostRemScreens);
+                if (dRemScreens) (void)hipFree(dRemScreens);
                 if (arena) (void)hipFree(arena);
             }
             if (haveCur) (void)hipSetDevice(cur);
@@ -377,6 +381,8 @@ struct PlanThread {
         hostEntries = nullptr;
         dEntries = nullptr;
         dCnt = nullptr;
+        hostRemScreens = nullptr;
+        dRemScreens = nullptr;
         arena = nullptr;
         arenaCap = 0;
         device = -1;
@@ -391,6 +397,8 @@ struct PlanThread {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostEntries), 64 * sizeof(GrokEntryDev), hipHostMallocDefault));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dEntries), 64 * sizeof(GrokEntryDev)));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dCnt), 64 * GC_WORDS * 4));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostRemScreens), 64 * sizeof(GrokScreenDev), hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dRemScreens), 64 * sizeof(GrokScreenDev)));
         }
         for (uint32_t s = 0; s < nStreams; ++s)
             if (!workers[s]) {
@@ -466,7 +474,9 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
 // host view of one active entry of the batch
 struct PlanEntry {
     uint32_t p = 0, cand = 0, capsRow = 0, columns = 0, rounds = 0, ran = 0;
-    bool second = false;  // searched in the second pass, on the values nobody has won by then
+    bool second = false;  // (round 3's second pass over shadowed entries: retired with the round-4 phases, always false)
+    bool queued = false;  // rounds behind the first match were queued for this entry
+    uint32_t seq0 = 0;    // launch sequence of round 0's first-chance kernel (lcMatchSecondChanceOnStream)
     const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
     int stream = 0;
     double cost = 0;
@@ -574,7 +584,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     const uint32_t xstride = row + 3;
     const size_t xtmpAt = carve(size_t(xcap) * xstride * 4);
     struct Offsets {
-        size_t off, len, line, from, nmatch, first, listA, listB, unanchored, caps, status;
+        size_t off, len, line, from, nmatch, first, listA, listB, unanchored, ovList, caps, status;
     };
     std::vector<Offsets> offs;
     for (uint32_t p = 0; p < nP; ++p) {
@@ -588,7 +598,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.rounds = std::max(1u, std::min(kGrokMaxRounds, patterns[p].re->grokRounds.load(std::memory_order_relaxed)));
         for (const GrokScreenDev& sd : state->hostScreens[dev])
             if (sd.bit == p) e.remainderScreen = &sd;
-        if (e.remainderScreen) e.rounds = std::max(2u, e.rounds);  // (round 1 reads the screened list: it has to be queued)
+        e.rounds = std::max(2u, e.rounds);  // (round 0 is a phase of its own; round 1 reads the screened list)
         const bool nfa = patterns[p].re->engine == LC_ENGINE_NFA;
         e.cost = double(c) * (nfa ? (patterns[p].anchored ? 8.0 : 40.0) : 1.0);
         // an automaton that walks its tables in global memory (tdfa_l2_kernel) takes as long as its LONGEST candidate -- one dependent
@@ -608,12 +618,14 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         o.listA = carve(size_t(c) * 4);
         o.listB = carve(size_t(c) * 4);
         o.unanchored = carve(size_t(c) * 4);
+        o.ovList = carve(size_t(c) * 4);
         o.first = carve(size_t(c) * e.capsRow * 4);
         o.caps = carve(size_t(c) * e.capsRow * 4);
         o.status = carve(size_t(c) + 16);
         // second pass: see phase 2
         const uint32_t shadowed = c - std::min(c, T.hostWords[HW_FIRST + p]);
-        e.second = !small && nfa && shadowed >= 1024 && shadowed >= c / 4;
+        (void)shadowed;
+        e.second = false;
         offs.push_back(o);
         act.push_back(e);
     }
@@ -642,7 +654,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     }
     uint8_t* arena = static_cast<uint8_t*>(T.arena);
     int32_t* xtmp = reinterpret_cast<int32_t*>(arena + xtmpAt);
-    uint32_t maxCand = 0;
+    uint32_t maxCand = 0, nRemScreens = 0, remScreenLds = 0;
     for (size_t a = 0; a < act.size(); ++a) {
         PlanEntry& e = act[a];
         const Offsets& o = offs[a];
@@ -661,7 +673,19 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.unanchored = reinterpret_cast<uint32_t*>(arena + o.unanchored);
         e.caps = reinterpret_cast<int32_t*>(arena + o.caps);
         e.status = arena + o.status;
+        e.dev.status = e.status;
+        e.dev.caps = e.caps;
+        e.dev.listA = e.listA;
+        e.dev.unanchored = e.unanchored;
+        e.dev.ovList = reinterpret_cast<uint32_t*>(arena + o.ovList);
+        e.dev.columns = e.columns;
+        e.dev.anchored = patterns[e.p].anchored ? 1u : 0u;
         T.hostEntries[a] = e.dev;
+        T.hostRemScreens[a] = e.remainderScreen ? *e.remainderScreen : GrokScreenDev{nullptr, e.p, 0u};
+        if (e.remainderScreen) {
+            ++nRemScreens;
+            remScreenLds = std::max(remScreenLds, e.remainderScreen->ldsBytes);
+        }
         map.activeOfBit[e.p] = int8_t(a);
         maxCand = std::max(maxCand, e.cand);
         stats.pairs += e.cand;
@@ -671,91 +695,32 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     const uint32_t nAct = uint32_t(act.size());
     if (nAct) {
         HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(T.dRemScreens, T.hostRemScreens, nAct * sizeof(GrokScreenDev), hipMemcpyHostToDevice, st));
+        (void)nRemScreens;
         HIP_TRY(hipMemsetAsync(T.dCnt, 0, size_t(nAct) * GC_WORDS * 4, st));
         hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries,
                            static_cast<const uint32_t*>(order));
         HIP_TRY(hipGetLastError());
-        // ---- phase 2: every entry is a batch of its own; the dearest first, dealt round-robin to the worker streams.
-        // Second pass (large batches only): an NFA-engine entry many of whose candidates have an EARLIER candidate entry (a general
-        // format shadowed by specific ones: SYSLOGLINE behind CRONLOG ...) waits for the first pass and searches only the values
-        // nobody has won by then.
+        // ---- phase 2 (round 4).  A batch used to queue 14-17 launches per entry -- 560 for the 46 active entries of configs[2] -- most of
+        // them over lists that turn out empty, and the host could not queue them as fast as the device finished them (18 us a launch).
+        // Now:  2a  round 0, ONE launch per entry (the engine's main kernel, the anchored search where the entry has one), dearest
+        //           entry first, dealt round-robin to the worker streams;
+        //       2b  grok_post_kernel, ONE launch for all entries: overflowed slots -> the entry's overflow list, slots the anchored
+        //           search did not match -> its unanchored list, matches recorded, what is still in play -> listA;   counts -> host
+        //       2c  only the entries that have any: the second chance for the overflowed slots, the search proper for the unanchored
+        //           ones, each followed by a post launch over that list;
+        //       2d  grok_remainder_all_kernel, ONE launch: the remainder of every slot in play against its entry's screen; counts -> host
+        //       2e  only the entries with survivors: the search rounds behind the first match, queued ahead as before.
         std::vector<size_t> byCost(nAct);
         for (size_t a = 0; a < nAct; ++a) byCost[a] = a;
         std::sort(byCost.begin(), byCost.end(), [&](size_t x, size_t y) { return act[x].cost > act[y].cost; });
         const uint32_t used = std::min<uint32_t>(nStreams, nAct);
-        // one entry's launches on stream ws: (filter,) round 0 (anchored first), the rounds queued ahead
-        auto queueEntry = [&](PlanEntry& e, hipStream_t ws, bool secondPass) -> int {
-            const GrokDevicePattern& gp = patterns[e.p];
-            const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-            auto advance = [&](const uint32_t* list, const uint32_t* countPtr, uint32_t* out, uint32_t* outCount, bool last) {
-                hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
-                                   e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out, outCount, last ? gate : nullptr);
-            };
-            // round 0 over: all slots, or what the filter leaves (listB; round 1 reads listA and writes listB afterwards)
-            const uint32_t* list0 = nullptr;
-            const uint32_t* count0 = nullptr;
-            if (secondPass) {
-                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, winner, e.listB,
-                                   e.dev.cnt + GC_FILTERED);
-                list0 = e.listB;
-                count0 = e.dev.cnt + GC_FILTERED;
-            }
-            int rc = LC_OK;
-            const bool last0 = e.rounds == 1;
-            uint32_t* out0 = e.listA;
-            uint32_t* outCount0 = e.dev.cnt + GC_ROUND0;
-            if (gp.anchored) {
-                rc = lcMatchOnStream(gp.anchored, gp.anchored->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, nullptr,
-                                     e.capsRow / 2, e.caps, e.status, ws);
-                if (rc != LC_OK) return rc;
-                hipLaunchKernelGGL(grok_unmatched2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list0, e.cand, count0, e.status,
-                                   e.unanchored, e.dev.cnt + GC_UNANCHORED);
-                advance(list0, count0, out0, outCount0, last0);
-                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
-                                     e.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                if (rc != LC_OK) return rc;
-                advance(e.unanchored, e.dev.cnt + GC_UNANCHORED, out0, outCount0, last0);
-            } else {
-                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count0, list0, e.dev.from,
-                                     e.capsRow / 2, e.caps, e.status, ws);
-                if (rc != LC_OK) return rc;
-                advance(list0, count0, out0, outCount0, last0);
-            }
-            // What is still in play behind its first match goes on only if its REMAINDER passes the entry's screen (a further match
-            // lies inside it and contains a match of the screen): round 1 then reads that list -- usually an empty one -- instead of
-            // searching kilobytes in which nothing will be found on the thread-list engine.
-            const GrokScreenDev* rs = e.remainderScreen;
-            if (rs && e.rounds > 1) {
-                lcNoteKernel("grok_remainder_screen_kernel");
-                hipLaunchKernelGGL(grok_remainder_screen_kernel, dim3(grid), dim3(kGrokPlanBlock), small ? rs->ldsBytes : 0, ws, d_data, e.dev,
-                                   static_cast<const uint32_t*>(out0), static_cast<const uint32_t*>(outCount0), *rs, small ? 1u : 0u,
-                                   e.unanchored, e.dev.cnt + GC_REMAINDER);
-            }
-            // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
-            for (uint32_t r = 1; r < e.rounds; ++r) {
-                const bool screened = rs && r == 1;
-                const uint32_t* list = screened ? e.unanchored : (r & 1) ? e.listA : e.listB;
-                uint32_t* out = (r & 1) ? e.listB : e.listA;
-                const uint32_t* countPtr = screened ? e.dev.cnt + GC_REMAINDER : e.dev.cnt + GC_ROUND0 + r - 1;
-                rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
-                                     e.capsRow / 2, e.caps, e.status, ws);
-                if (rc != LC_OK) return rc;
-                advance(list, countPtr, out, e.dev.cnt + GC_ROUND0 + r, r + 1 == e.rounds);
-            }
-            return LC_OK;
-        };
-        auto queuePass = [&](bool secondPass) -> int {
+        auto fork = [&]() -> int {
             HIP_TRY(hipEventRecord(T.fork, st));
             for (uint32_t s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(T.workers[s], T.fork, 0));
-            uint32_t dealt = 0;
-            int rc = LC_OK;
-            for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
-                PlanEntry& e = act[byCost[i]];
-                if (e.second != secondPass) continue;
-                e.stream = int(dealt++ % used);
-                lcSetDecideSlot(1 + e.stream);
-                rc = queueEntry(e, T.workers[e.stream], secondPass);
-            }
+            return LC_OK;
+        };
+        auto join = [&](int rc) -> int {
             lcSetDecideSlot(0);
             if (rc == LC_OK && hipGetLastError() != hipSuccess) rc = lcHipFail(hipGetLastError(), "grok entry launch");
             if (rc != LC_OK) {
@@ -768,18 +733,124 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             }
             return LC_OK;
         };
+        auto readCounts = [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(syncCounted(st));
+            return LC_OK;
+        };
+        auto cnt = [&](size_t a, uint32_t word) { return T.hostWords[HW_CNT + a * GC_WORDS + word]; };
+        // 2a
         {
-            int rc = queuePass(false);
+            int rc = fork();
+            if (rc != LC_OK) return rc;
+            uint32_t dealt = 0;
+            for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+                PlanEntry& e = act[byCost[i]];
+                const GrokDevicePattern& gp = patterns[e.p];
+                e.stream = int(dealt++ % used);
+                lcSetDecideSlot(1 + e.stream);
+                lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
+                                          gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
+                if (trace)
+                    fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d\n", e.p, e.cand, e.stream,
+                            first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2", gp.anchored ? " (anchored)" : "",
+                            first->nfa.positions.size(), first->nfa.slotCount());
+            }
+            rc = join(rc);
             if (rc != LC_OK) return rc;
         }
-        if (nSecond && nSecond < nAct)
-            // what the first pass has won so far (an entry of the first pass that still has values in play keeps the gate shut: then
-            // nothing is filtered, which costs time, never results)
-            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock, nAct - nSecond),
-                               dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, gate);
-        if (nSecond) {
-            int rc = queuePass(true);
+        // 2b
+        const uint32_t gridCand0 = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+        lcNoteKernel("grok_post_kernel");
+        hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u, static_cast<const uint32_t*>(nullptr),
+                           static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
+        HIP_TRY(hipGetLastError());
+        {
+            int rc = readCounts();  // sync 2
             if (rc != LC_OK) return rc;
+        }
+        // 2c
+        {
+            bool any = false;
+            for (size_t a = 0; a < nAct; ++a) any = any || cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED);
+            if (any) {
+                int rc = fork();
+                if (rc != LC_OK) return rc;
+                for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+                    const size_t a = byCost[i];
+                    PlanEntry& e = act[a];
+                    const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
+                    if (!ov && !un) continue;
+                    if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    hipStream_t ws = T.workers[e.stream];
+                    lcSetDecideSlot(1 + e.stream);
+                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+                    if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
+                        lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                        rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
+                                                         e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
+                        if (rc != LC_OK) break;
+                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a),
+                                           static_cast<const uint32_t*>(e.dev.ovList), static_cast<const uint32_t*>(e.dev.cnt + GC_OVERFLOW),
+                                           uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL), xtmp, xcap, xstride, xcount);
+                    }
+                    if (gp.anchored) {  // the search proper over what the anchored search did not match (the whole chain: nothing reads counts in between)
+                        rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
+                                             e.dev.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                        if (rc != LC_OK) break;
+                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a),
+                                           static_cast<const uint32_t*>(e.dev.unanchored), static_cast<const uint32_t*>(e.dev.cnt + GC_UNANCHORED),
+                                           uint32_t(GP_OVERFLOW_FINAL), xtmp, xcap, xstride, xcount);
+                    }
+                }
+                rc = join(rc);
+                if (rc != LC_OK) return rc;
+            }
+        }
+        // 2d
+        lcNoteKernel("grok_remainder_all_kernel");
+        hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
+                           static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+        {
+            int rc = readCounts();  // sync 3
+            if (rc != LC_OK) return rc;
+        }
+        // 2e
+        {
+            bool any = false;
+            for (size_t a = 0; a < nAct; ++a) any = any || cnt(a, GC_REMAINDER);
+            if (any) {
+                int rc = fork();
+                if (rc != LC_OK) return rc;
+                for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+                    const size_t a = byCost[i];
+                    PlanEntry& e = act[a];
+                    if (!cnt(a, GC_REMAINDER)) continue;
+                    if (trace) fprintf(stderr, "grok plan 2e: entry %u in play %u survivors %u\n", e.p, cnt(a, GC_ROUND0), cnt(a, GC_REMAINDER));
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    hipStream_t ws = T.workers[e.stream];
+                    lcSetDecideSlot(1 + e.stream);
+                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+                    e.queued = true;
+                    // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
+                    for (uint32_t r = 1; r < e.rounds && rc == LC_OK; ++r) {
+                        const uint32_t* list = r == 1 ? e.unanchored : (r & 1) ? e.listA : e.listB;
+                        uint32_t* out = (r & 1) ? e.listB : e.listA;
+                        const uint32_t* countPtr = r == 1 ? e.dev.cnt + GC_REMAINDER : e.dev.cnt + GC_ROUND0 + r - 1;
+                        rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
+                                             e.capsRow / 2, e.caps, e.status, ws);
+                        if (rc != LC_OK) break;
+                        hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
+                                           e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out, e.dev.cnt + GC_ROUND0 + r,
+                                           r + 1 == e.rounds ? gate : static_cast<uint32_t*>(nullptr));
+                    }
+                }
+                rc = join(rc);
+                if (rc != LC_OK) return rc;
+            }
         }
     }
     // ---- phase 3: the first contributing entry per value; its rows go out.  All of it returns at once when values are still in

@@ -39,7 +39,8 @@ enum {
     GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
     GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
     GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
-    GC_REMAINDER = 62,  // slots still in play after round 0 whose REMAINDER passes the entry's screen (grok_remainder_screen_kernel)
+    GC_OVERFLOW = 61,   // slots whose thread lists overflowed in the first-chance kernel of round 0 (they get the second chance)
+    GC_REMAINDER = 62,  // slots still in play after round 0 whose REMAINDER passes the entry's screen (grok_remainder_all_kernel)
     GC_FILTERED = 63,   // second-pass entries: slots left after grok_filter_won_kernel
     GC_WORDS = 64
 };
@@ -61,6 +62,20 @@ struct GrokEntryDev {
     int32_t* first;    // [cand][capsRow] row of the first contributing match
     uint32_t* cnt;     // GC_*
     uint32_t cand, capsRow, bit, pad;
+    // round 0 as one launch over all entries (grok_post_kernel) and the remainder screens (grok_remainder_all_kernel)
+    const uint8_t* status;  // [cand] what the match kernels reported
+    const int32_t* caps;    // [cand][capsRow]
+    uint32_t* listA;        // slots in play after round 0
+    uint32_t* unanchored;   // slots the anchored search did not match; later: the screened in-play list round 1 reads
+    uint32_t* ovList;       // slots the first-chance kernel could not decide (thread-list overflow)
+    uint32_t columns;       // named groups
+    uint32_t anchored;      // 1: round 0 ran the ANCHORED search (what it does not match goes on to the search proper)
+};
+
+// flags of grok_post_kernel
+enum {
+    GP_ANCHORED_PASS = 1,   // the statuses come from the anchored searches (entries that have one): NOMATCH -> the unanchored list
+    GP_OVERFLOW_FINAL = 2   // LC_OVERFLOW is final (the second chance has run): the slot is undecided; else it goes to the overflow list
 };
 
 struct GrokSlotMap {
@@ -278,19 +293,84 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_filter_won_kernel(GrokEnt
 // 4 KiB value that is 3.9 KiB in which nothing will be found, on the slowest engine there is (an unanchored search on the thread-list
 // kernel starts an attempt at every byte the format can begin with).  A further match lies entirely inside [from, len), and every
 // match of the entry contains a match of the entry's screen (the relaxed whole pattern, or the prefix; no assertions), so the slots
-// whose remainder the screen rejects are done: one lane per slot, the yes/no DFA walked from `from`.  stage != 0: tables of up to
-// ldsBytes are staged into LDS (dynamic LDS = sc.ldsBytes).
-__global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_screen_kernel(const uint8_t* __restrict__ data, GrokEntryDev e,
-                                                                              const uint32_t* __restrict__ in,
-                                                                              const uint32_t* __restrict__ inCount, GrokScreenDev sc,
-                                                                              uint32_t stage, uint32_t* __restrict__ out,
-                                                                              uint32_t* __restrict__ outCount) {
+// whose remainder the screen rejects are done: grok_remainder_all_kernel below, one lane per slot, the yes/no DFA walked from `from`.
+
+// ---- round 0 in ONE launch for all entries (grid.y = entries from entryBase): what grok_unmatched2_kernel + grok_advance2_kernel did
+// per entry.  in / inCount (single-entry launches only): the slots to look at and their number on the device; nullptr = every slot.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEntryDev* __restrict__ entries, uint32_t entryBase,
+                                                                  const uint32_t* __restrict__ in, const uint32_t* __restrict__ inCount,
+                                                                  uint32_t flags, int32_t* __restrict__ xtmp, uint32_t xcap, uint32_t xstride,
+                                                                  uint32_t* __restrict__ xcount) {
+    const GrokEntryDev& e = entries[entryBase + blockIdx.y];
+    uint32_t nIn = e.cand;
+    if (inCount) {
+        const uint32_t dyn = *inCount;
+        nIn = dyn < nIn ? dyn : nIn;
+    }
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    if (k >= nIn) return;
+    const uint32_t slot = in ? in[k] : k;
+    const uint8_t st = e.status[slot];
+    if (st == LC_OVERFLOW && !(flags & GP_OVERFLOW_FINAL)) {
+        e.ovList[atomicAdd(&e.cnt[GC_OVERFLOW], 1u)] = slot;
+        return;
+    }
+    if (st == LC_OVERFLOW || st == LC_GAVE_UP) {
+        e.nmatch[slot] |= st == LC_OVERFLOW ? kGrokSlotOverflow : kGrokSlotGaveUp;
+        return;
+    }
+    if (st != LC_MATCH) {
+        if ((flags & GP_ANCHORED_PASS) && e.anchored) e.unanchored[atomicAdd(&e.cnt[GC_UNANCHORED], 1u)] = slot;
+        return;
+    }
+    const uint32_t capsRow = e.capsRow;
+    const int32_t* c = e.caps + size_t(slot) * capsRow;
+    bool contributes = false;
+    for (uint32_t g = 1; g <= e.columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
+    if (contributes) {
+        const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
+        int32_t* dst = nullptr;
+        if (seq == 0) {
+            dst = e.first + size_t(slot) * capsRow;
+        } else {
+            const uint32_t at = atomicAdd(xcount, 1u);
+            if (at < xcap) {
+                dst = xtmp + size_t(at) * xstride;
+                dst[0] = int32_t(e.line[slot]);
+                dst[1] = int32_t(seq);
+                dst[2] = int32_t(e.bit);
+                dst += 3;
+            }
+        }
+        if (dst)
+            for (uint32_t s = 0; s < capsRow; ++s) dst[s] = c[s];
+    }
+    const uint32_t b = uint32_t(c[0]), en = uint32_t(c[1]);
+    const uint32_t next = en > b ? en : en + 1;
+    if (next < e.len[slot]) {
+        e.from[slot] = next;
+        e.listA[atomicAdd(&e.cnt[GC_ROUND0], 1u)] = slot;
+    }
+}
+
+// ---- the remainder screens of ALL entries in one launch (grid.y = entries): see above.  screens[a].blob ==
+// nullptr: the entry has no screen, every slot in play goes on.  In: e.listA / GC_ROUND0; out: e.unanchored / GC_REMAINDER.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(const uint8_t* __restrict__ data,
+                                                                           const GrokEntryDev* __restrict__ entries,
+                                                                           const GrokScreenDev* __restrict__ screens, uint32_t stage) {
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
+    const GrokEntryDev& e = entries[blockIdx.y];
+    const GrokScreenDev sc = screens[blockIdx.y];
     const uint32_t tid = threadIdx.x;
-    uint32_t nIn = *inCount;
+    uint32_t nIn = e.cnt[GC_ROUND0];
     nIn = nIn < e.cand ? nIn : e.cand;
     if (blockIdx.x * kGrokPlanBlock >= nIn) return;
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + tid;
+    if (!sc.blob) {
+        if (k < nIn) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = e.listA[k];
+        return;
+    }
     const uint32_t* blob = sc.blob;
     cmap[tid] = reinterpret_cast<const uint8_t*>(blob + SC_HEADER_WORDS)[tid];
     const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
@@ -305,9 +385,8 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_screen_kernel(c
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;
     const uint16_t* lTable = staged ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]))
                                     : table;
-    const uint32_t k = blockIdx.x * kGrokPlanBlock + tid;
     if (k >= nIn) return;
-    const uint32_t slot = in[k];
+    const uint32_t slot = e.listA[k];
     const uint32_t L = e.len[slot], from = e.from[slot];
     uint32_t state = start;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + e.off[slot] + from;
@@ -323,7 +402,7 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_screen_kernel(c
             if (bi >= head && bi < total) state = lTable[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
         }
     }
-    if (state == sink || (state != 0 && lAccept[state])) out[atomicAdd(outCount, 1u)] = slot;
+    if (state == sink || (state != 0 && lAccept[state])) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
 }
 
 // After one search round over the slots in `in` (nullptr: all slots below the bound); see grok_advance_kernel (grok_kernel.hpp)

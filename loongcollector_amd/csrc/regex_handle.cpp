@@ -345,7 +345,9 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
     // few DOUBLE entries take 512 lanes and that table -- the capture stamp is issued once per two bytes (headline batch: 0.2025 ->
     // 0.1915 ms, profiles/round3_lab_pair1.txt).  "Few": a DOUBLE is settled by a read-modify-write behind its chunk, for the whole
     // wavefront; regex A keeps 0.7 % of its entries as DOUBLEs after the fixed-distance registers are derived (one-byte fields),
-    // regex B 2.3 % (fields that may be empty on both sides of a separator) -- B stays on the single-byte table.
+    // regex B 1.8 % (fields that may be empty on both sides of a separator).  Round 4: B's tables fit two workgroups per CU once the
+    // unused op lists were dropped, and measured on the GPU the pair table pays for B too (0.2060 -> 0.1944 ms, frac 0.385 -> 0.408):
+    // the threshold went from 1 % to 2 %.
     // (full-match patterns only -- the parse processor's regex_match: that is what the GPU validation of the round covered; search
     // patterns, i.e. Grok entries and the Go regex plugin, keep the single-byte tables unless LC_TDFA_PAIR=2 asks)
     if (!env && !getenv("LC_TDFA_PAIR") && t.startAfter.empty()) {
@@ -362,10 +364,10 @@ std::vector<uint32_t> packTdfaWideBlob(const TdfaTables& t, int* blockOut, bool*
                 size_t doubles = 0;
                 const size_t entries = size_t(t.nStates) * cols * cols;
                 for (size_t i = 0; i < entries; ++i) doubles += pair[i] >> 31;
-                // more than 1 % DOUBLE entries (LC_TDFA_PAIR_DOUBLE_PCT: the threshold, for A/B runs -- regex B sits at 1.8 %)
+                // more than 2 % DOUBLE entries (LC_TDFA_PAIR_DOUBLE_PCT: the threshold, for A/B runs -- regex B sits at 1.8 %)
                 static const size_t pct = [] {
                     const char* e = getenv("LC_TDFA_PAIR_DOUBLE_PCT");
-                    return e ? size_t(atol(e)) : size_t(1);
+                    return e ? size_t(atol(e)) : size_t(2);
                 }();
                 if (doubles * 100 > entries * pct) break;
                 *blockOut = 512;

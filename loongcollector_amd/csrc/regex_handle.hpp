@@ -133,3 +133,10 @@ void lcReleaseDeviceTables(lc_regex* re);
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
                     uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
                     uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, void* stream);
+// the engine's main kernel only (*seq: see below), and the second chance for the lines it left LC_OVERFLOW (gpu_runtime.hip)
+int lcMatchFirstOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                         uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
+                         int32_t* d_caps, uint8_t* d_status, uint32_t* seq, void* streamPtr);
+int lcMatchSecondChanceOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                                uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                                uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, uint32_t seq, void* streamPtr);

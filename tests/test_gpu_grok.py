@@ -319,13 +319,14 @@ def test_speculative_and_sequential_paths_agree(torch_dev, match):
     assert s1["speculative"] and not s2["speculative"]
     assert np.array_equal(p1, p2) and np.array_equal(f1, f2) and np.array_equal(x1, x2)
     # a second batch: the entries have learned how many rounds to queue ahead -- still the same rows, and (unless an entry
-    # needs more rounds than can be queued) exactly two host synchronisations
+    # needs more rounds than can be queued) exactly FOUR host synchronisations: candidates per entry, round 0's counts, the remainder
+    # screens' survivors, the end (round 4: the two in the middle replaced ~400 launches over lists that turn out empty)
     p3, f3, x3, s3 = _device_rows(torch_dev, spec, values)
     assert np.array_equal(p1, p3) and np.array_equal(f1, f3) and np.array_equal(x1, x3)
-    assert s3["host_syncs"] <= 6, s3      # (an entry with dozens of matches per value goes on in stretches of rounds)
-    assert s3["host_syncs"] == 2 or s3["deferred_entries"] > 0, s3
+    assert s3["host_syncs"] <= 8, s3      # (an entry with dozens of matches per value goes on in stretches of rounds)
+    assert s3["host_syncs"] == 4 or s3["deferred_entries"] > 0, s3
     if match[0] != "%{IPV4:ip}":          # (up to 36 addresses per value there)
-        assert s3["host_syncs"] == 2, s3
+        assert s3["host_syncs"] == 4, s3
     assert s2["host_syncs"] > s3["host_syncs"]
     o = GrokOracle(match)
     pattern, fields = spec.match_host(values)

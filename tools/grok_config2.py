@@ -7,7 +7,9 @@ import json
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # (before torch touches the GPU)
+# The HOST's decision (the library never touches the environment: include/lc_regex_gpu.h lc_runtime_prefer_hw_queues): a process that
+# hosts Grok processors asks for 16 hardware queues, before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -20,7 +22,8 @@ def main():
     args = ap.parse_args()
     import grok_bench
     import grok_inagent_bench
-    g = grok_bench.measure(argparse.Namespace(lines=args.lines, steps=3, warmup=4, cpu_sample_lines=300, patterns=0,
+    # (parity gate: 3 000 lines strided across every batch through the oracle before anything is timed -- ~10 s per batch size)
+    g = grok_bench.measure(argparse.Namespace(lines=args.lines, steps=10, warmup=4, cpu_sample_lines=3000, patterns=0,
                                               no_sequential_check=False, sequential=False), device_index=args.device)
     for r in g:
         r["config"].pop("patterns_refused", None)
