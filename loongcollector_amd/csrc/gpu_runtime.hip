@@ -505,7 +505,15 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         const char* e = getenv("LC_NFA_GLOBAL_KB");
         return size_t(e ? atoi(e) : 52) * 1024;
     }();
-    const bool global = lds > kLcLdsPerCu || lds > globalAbove;
+    // (round 4) ... on LARGE batches.  A small batch -- a Grok entry's few hundred candidates, an event group -- does not fill the
+    // chip either way and waits for its longest value, i.e. for the latency of a byte-step: with the program in LDS a step's
+    // dependent table reads (follow list bounds, paths, masks) cost LDS latency instead of L2 latency.  LC_NFA_SMALL_BATCH: the
+    // largest batch that stages whatever fits the CU's 160 KiB (0 = never; A/B measurements).
+    static const uint32_t smallBatch = [] {
+        const char* e = getenv("LC_NFA_SMALL_BATCH");
+        return uint32_t(e ? atol(e) : 8192);
+    }();
+    const bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
     if (global) lds -= blobBytes;
     if (lds > 160 * 1024) {
         tlsError = "nfa tables exceed LDS";
@@ -718,7 +726,11 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int rc;
     if (!re->nfa.runGroups.empty()) tlsDone.armed = false;  // run_capture_kernel runs behind the match: it cannot signal
-    if (engine == LC_ENGINE_TDFA && !re->hasTdfa && !re->tdfaL2Blob.empty()) {
+    // (a handle that asked for it -- lcPreferWaveTdfa: the Grok matcher's entries -- takes the wave-per-value kernel on small batches
+    // even though its automaton fits the LDS kernels: those walk one value per lane, and a batch of a few hundred 4 KiB values waits
+    // 0.3-1.4 ms for the longest of them)
+    const bool waveByChoice = engine == LC_ENGINE_TDFA && re->hasTdfa && re->preferWave && !re->tdfaL2Blob.empty() && n <= 16384;
+    if (engine == LC_ENGINE_TDFA && (waveByChoice || !re->hasTdfa) && !re->tdfaL2Blob.empty()) {
         // the automaton is too large for the LDS kernels: tables in global memory, one line per lane (tdfa_l2_kernel.hpp)
         void* dBlob = nullptr;
         rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
@@ -729,7 +741,10 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
         // (read at every launch: the GPU tests run both kernels in one process)
         const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
         const uint32_t waveMax = uint32_t(waveEnv ? atol(waveEnv) : 65536);
-        const bool perWave = n <= waveMax;
+        const bool perWave = n <= waveMax && (waveMax != 0 || !waveByChoice);
+        if (waveByChoice && !perWave) {  // (LC_TDFA_WAVE_MAX=0: the LDS kernels, as if the handle had not asked)
+            rc = launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+        } else {
         size_t lds = perWave ? size_t(re->tdfa.nRegs) * kTdfaWaveValues * 4 : size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
         // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
         uint32_t stageBytes = 0;
@@ -762,6 +777,7 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
         hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
                            d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, stageBytes);
         HIP_TRY(hipGetLastError());
+        }
         }
     } else if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {

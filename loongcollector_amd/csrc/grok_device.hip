@@ -334,7 +334,8 @@ constexpr uint32_t kGrokMaxRounds = GC_REMAINDER - GC_ROUND0 - 1;  // search rou
 constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
-enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_FIRST = 128 + 64 * GC_WORDS, HW_WORDS = 192 + 64 * GC_WORDS };
+enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_FIRST = 128 + 64 * GC_WORDS, HW_SHADOW = 192 + 64 * GC_WORDS,
+       HW_WORDS = 192 + 64 * GC_WORDS + 64 * 64 };
 // device tail words (scratch `counters`): [0] gate  [1] xcount (extra rows wanted in xtmp)
 enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16 };
 
@@ -348,6 +349,7 @@ struct PlanThread {
     uint32_t* dCnt = nullptr;             // device [64][GC_WORDS]
     GrokScreenDev* hostRemScreens = nullptr;  // pinned [64]: per ACTIVE entry, its screen (blob == nullptr: none)
     GrokScreenDev* dRemScreens = nullptr;     // device [64]
+    uint32_t* dShadow = nullptr;              // device [64][64]: candidates of entry p whose value's first candidate is entry f
     void* arena = nullptr;                // device, grow-only: the per-entry arrays of the batch in flight
     size_t arenaCap = 0;
     ~PlanThread() { release(); }
@@ -370,6 +372,7 @@ struct PlanThread {
                 if (dCnt) (void)hipFree(dCnt);
                 if (hostRemScreens) (void)hipHostFree(hostRemScreens);
                 if (dRemScreens) (void)hipFree(dRemScreens);
+                if (dShadow) (void)hipFree(dShadow);
                 if (arena) (void)hipFree(arena);
             }
             if (haveCur) (void)hipSetDevice(cur);
@@ -383,6 +386,7 @@ struct PlanThread {
         dCnt = nullptr;
         hostRemScreens = nullptr;
         dRemScreens = nullptr;
+        dShadow = nullptr;
         arena = nullptr;
         arenaCap = 0;
         device = -1;
@@ -399,6 +403,7 @@ struct PlanThread {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dCnt), 64 * GC_WORDS * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostRemScreens), 64 * sizeof(GrokScreenDev), hipHostMallocDefault));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dRemScreens), 64 * sizeof(GrokScreenDev)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dShadow), 64 * 64 * 4));
         }
         for (uint32_t s = 0; s < nStreams; ++s)
             if (!workers[s]) {
@@ -474,7 +479,9 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
 // host view of one active entry of the batch
 struct PlanEntry {
     uint32_t p = 0, cand = 0, capsRow = 0, columns = 0, rounds = 0, ran = 0;
-    bool second = false;  // (round 3's second pass over shadowed entries: retired with the round-4 phases, always false)
+    bool second = false;  // level > 0
+    uint32_t level = 0;   // 0: evaluated at once; L > 0: most of its candidates have an EARLIER candidate entry (of level < L) -- it waits
+                          // for those and only looks at the values none of them has won (a general format behind specific ones)
     bool queued = false;  // rounds behind the first match were queued for this entry
     uint32_t seq0 = 0;    // launch sequence of round 0's first-chance kernel (lcMatchSecondChanceOnStream)
     const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
@@ -562,10 +569,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     }
     uint32_t* firstOf = orderWork + 512;  // [64]
     HIP_TRY(hipMemsetAsync(firstOf, 0, 256, st));
-    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry, firstOf);
+    HIP_TRY(hipMemsetAsync(T.dShadow, 0, 64 * 64 * 4, st));
+    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry, firstOf, T.dShadow);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CAND, perEntry, 256, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(T.hostWords + HW_FIRST, firstOf, 256, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_SHADOW, T.dShadow, 64 * 64 * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(winner, 0xFF, size_t(n) * 8, st));
     HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
     HIP_TRY(hipMemsetAsync(d_nextra, 0, 4, st));
@@ -587,6 +596,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         size_t off, len, line, from, nmatch, first, listA, listB, unanchored, ovList, caps, status;
     };
     std::vector<Offsets> offs;
+    uint32_t levelOf[64] = {};
     for (uint32_t p = 0; p < nP; ++p) {
         const uint32_t c = T.hostWords[HW_CAND + p];
         if (!c) continue;
@@ -624,8 +634,17 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         o.status = carve(size_t(c) + 16);
         // second pass: see phase 2
         const uint32_t shadowed = c - std::min(c, T.hostWords[HW_FIRST + p]);
-        (void)shadowed;
-        e.second = false;
+        // levels: an entry half of whose candidates have an earlier candidate entry waits for the entries that shadow a quarter of
+        // them or more (SYSLOGLINE behind CRONLOG / HTTPD_ERRORLOG; SHOREWALL behind SYSLOGLINE; COMBINEDAPACHELOG behind
+        // COMMONAPACHELOG): what those win it never looks at.  Results do not depend on the order -- only the work does.
+        if (shadowed * 2 >= c) {
+            uint32_t lv = 1;
+            for (uint32_t f = 0; f < p; ++f)
+                if (T.hostWords[HW_SHADOW + p * 64 + f] * 4 >= c) lv = std::max(lv, levelOf[f] + 1);
+            e.level = std::min(lv, 3u);
+        }
+        levelOf[p] = e.level;
+        e.second = e.level != 0;
         offs.push_back(o);
         act.push_back(e);
     }
@@ -634,7 +653,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     {
         std::vector<size_t> idx(act.size());
         for (size_t a = 0; a < idx.size(); ++a) idx[a] = a;
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return act[x].second < act[y].second; });
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return act[x].level < act[y].level; });
         std::vector<PlanEntry> act2;
         std::vector<Offsets> offs2;
         for (size_t a : idx) {
@@ -748,6 +767,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 PlanEntry& e = act[byCost[i]];
                 const GrokDevicePattern& gp = patterns[e.p];
                 e.stream = int(dealt++ % used);
+                if (e.level) continue;  // (waits for the entries that shadow it: phase 2c)
                 lcSetDecideSlot(1 + e.stream);
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
                 rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
@@ -763,46 +783,95 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // 2b
         const uint32_t gridCand0 = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
         lcNoteKernel("grok_post_kernel");
-        hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u, static_cast<const uint32_t*>(nullptr),
-                           static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
+        const uint32_t nLevel0 = nAct - nSecond;  // (the table lists the entries by level)
+        if (nLevel0)
+            hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nLevel0), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u,
+                               static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap,
+                               xstride, xcount);
         HIP_TRY(hipGetLastError());
         {
             int rc = readCounts();  // sync 2
             if (rc != LC_OK) return rc;
         }
-        // 2c
+        // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
+        // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
+        // entries on the values nobody before them has won.  Their chains are queued whole: they are few.
         {
-            bool any = false;
-            for (size_t a = 0; a < nAct; ++a) any = any || cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED);
-            if (any) {
+            uint32_t maxLevel = 0;
+            for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
+            bool any0 = false;
+            for (size_t a = 0; a < nAct; ++a) any0 = any0 || cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED);
+            if (any0 || maxLevel) {
+                // the values won so far (atomicMin per value: idempotent, finishAll runs it again at the end)
+                hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                                   static_cast<const uint32_t*>(nullptr), 0u);
                 int rc = fork();
                 if (rc != LC_OK) return rc;
+                // ONE fork for all of it: the leftovers of level 0 and the entries of level 1 depend on round 0 only; an entry of level
+                // 2 or 3 is queued on the stream of the entry that shadows most of its candidates, behind that entry's chain and a
+                // finish step for it -- stream order instead of a barrier per level.
+                for (uint32_t level = 0; level <= maxLevel && rc == LC_OK; ++level)
                 for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
                     const size_t a = byCost[i];
                     PlanEntry& e = act[a];
-                    const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
-                    if (!ov && !un) continue;
-                    if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
+                    if (e.level != level) continue;
                     const GrokDevicePattern& gp = patterns[e.p];
-                    hipStream_t ws = T.workers[e.stream];
-                    lcSetDecideSlot(1 + e.stream);
-                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-                    if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
-                        lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                        rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
-                                                         e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
-                        if (rc != LC_OK) break;
-                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a),
-                                           static_cast<const uint32_t*>(e.dev.ovList), static_cast<const uint32_t*>(e.dev.cnt + GC_OVERFLOW),
-                                           uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL), xtmp, xcap, xstride, xcount);
+                    if (level >= 2) {  // behind its main shadower
+                        uint32_t best = 0, bestF = 0;
+                        for (uint32_t f = 0; f < e.p; ++f)
+                            if (T.hostWords[HW_SHADOW + e.p * 64 + f] > best && map.activeOfBit[f] >= 0) {
+                                best = T.hostWords[HW_SHADOW + e.p * 64 + f];
+                                bestF = f;
+                            }
+                        if (best) {
+                            const size_t sa = size_t(map.activeOfBit[bestF]);
+                            e.stream = act[sa].stream;
+                            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
+                                               0, T.workers[e.stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
+                        }
                     }
-                    if (gp.anchored) {  // the search proper over what the anchored search did not match (the whole chain: nothing reads counts in between)
-                        rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_UNANCHORED,
-                                             e.dev.unanchored, e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                    hipStream_t ws = T.workers[e.stream];
+                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+                    auto post = [&](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
+                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a), in, inCount, flags, xtmp,
+                                           xcap, xstride, xcount);
+                    };
+                    // the search proper over the slots in `list`, minus the values an earlier entry has won; then its post step
+                    auto searchProper = [&](const uint32_t* list, const uint32_t* count) -> int {
+                        hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner), list,
+                                           count, e.listB, e.dev.cnt + GC_FILTERED);
+                        int r2 = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_FILTERED, e.listB,
+                                                 e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                        if (r2 != LC_OK) return r2;
+                        post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
+                        return LC_OK;
+                    };
+                    if (level == 0) {
+                        const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
+                        if (!ov && !un) continue;
+                        if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
+                        lcSetDecideSlot(1 + e.stream);
+                        if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
+                            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                            rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
+                                                             e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
+                            if (rc != LC_OK) break;
+                            post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                        }
+                        if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
+                    } else {
+                        if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u stream %d\n", e.p, e.level, e.cand, e.stream);
+                        lcSetDecideSlot(1 + e.stream);
+                        // every slot whose value nobody before has won: the anchored search (or the search) in full, then the rest
+                        uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
+                        hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner),
+                                           static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), mine, e.dev.cnt + GC_OVERFLOW);
+                        lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                        rc = lcMatchOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW, mine,
+                                             gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
                         if (rc != LC_OK) break;
-                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a),
-                                           static_cast<const uint32_t*>(e.dev.unanchored), static_cast<const uint32_t*>(e.dev.cnt + GC_UNANCHORED),
-                                           uint32_t(GP_OVERFLOW_FINAL), xtmp, xcap, xstride, xcount);
+                        post(mine, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                        if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
                     }
                 }
                 rc = join(rc);
@@ -858,7 +927,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     const uint32_t gridCand = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
     auto finishAll = [&](const uint32_t* g) -> int {
         if (nAct) {
-            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, g);
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, g, 0u);
         }
         hipLaunchKernelGGL(grok_resolve_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, n, winner, undecided, d_pattern, g);
         if (nAct) {

@@ -206,11 +206,22 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
 
 // candidates per entry after the screens; firstOf[p] = values whose FIRST candidate entry is p (the rest of p's candidates have
 // an earlier candidate that may win them: potential waste of evaluating p on them)
+// shadowBy[p * 64 + f] (optional): candidates of p whose value's FIRST candidate is the earlier entry f -- who shadows whom, for the
+// order in which the entries are evaluated (grok_device.hip: levels)
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_count_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
-                                                                   uint32_t* __restrict__ perEntry, uint32_t* __restrict__ firstOf) {
+                                                                   uint32_t* __restrict__ perEntry, uint32_t* __restrict__ firstOf,
+                                                                   uint32_t* __restrict__ shadowBy) {
     const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     const uint64_t m = v < n ? masks[v] : 0;
     const uint32_t lowest = m ? uint32_t(__ffsll(static_cast<long long>(m))) - 1u : 64u;
+    if (shadowBy && m) {
+        uint64_t rest = m & (m - 1);  // the candidates behind the first one (a value has one to three)
+        while (rest) {
+            const uint32_t p = uint32_t(__ffsll(static_cast<long long>(rest))) - 1u;
+            rest &= rest - 1;
+            atomicAdd(&shadowBy[p * 64 + lowest], 1u);
+        }
+    }
     for (uint32_t p = 0; p < nPatterns; ++p) {
         const uint64_t has = __ballot((m >> p) & 1ull);
         if (!has) continue;
@@ -276,11 +287,18 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_unmatched2_kernel(const u
 // Second pass (entries whose candidates are largely shadowed by earlier entries): only the slots whose value no earlier entry
 // has won by now are searched.  An entry's result on a value that an earlier entry contributes to is never looked at, so
 // dropping those slots changes nothing -- and whatever the first pass has not settled yet simply stays in.
+// in / inCount (optional): the slots to look at (a list and its length on the device); nullptr = every slot of the entry
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_filter_won_kernel(GrokEntryDev e, const uint32_t* __restrict__ winner,
+                                                                        const uint32_t* __restrict__ in, const uint32_t* __restrict__ inCount,
                                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ count) {
-    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
-    if (k >= e.cand) return;
-    const bool keep = winner[e.line[k]] >= e.bit;  // (kGrokNone included)
+    uint32_t nIn = e.cand;
+    if (inCount) {
+        const uint32_t dyn = *inCount;
+        nIn = dyn < nIn ? dyn : nIn;
+    }
+    const uint32_t i = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    const uint32_t k = i < nIn ? (in ? in[i] : i) : 0;
+    const bool keep = i < nIn && winner[e.line[k]] >= e.bit;  // (kGrokNone included)
     const uint64_t b = __ballot(keep);
     if (!b) return;
     uint32_t at = 0;
@@ -459,9 +477,9 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_advance2_kernel(
 // grid = (ceil(max cand / block), active entries).  gate (optional): leave at once while values are still in play somewhere.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_entry_finish_kernel(const GrokEntryDev* __restrict__ entries,
                                                                           uint32_t* __restrict__ winner, uint32_t* __restrict__ undecided,
-                                                                          const uint32_t* __restrict__ gate) {
+                                                                          const uint32_t* __restrict__ gate, uint32_t entryBase) {
     if (gate && *gate) return;
-    const GrokEntryDev& e = entries[blockIdx.y];
+    const GrokEntryDev& e = entries[entryBase + blockIdx.y];
     // (second-pass entries: a slot the filter dropped has nmatch == 0 and says nothing)
     const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     if (k >= e.cand) return;

@@ -59,6 +59,9 @@ struct MlThread {
     MlBuf dData, dOff, dStatus, dFlags, dScratch, dSmall;        // device
     uint32_t recordGuess = 1024;
     MlThread() { hIn.pinned = hOut.pinned = true; }
+    ~MlThread() {
+        if (lcRuntimeUsable() && (stream || hIn.p || dData.p)) lcMultilineThreadRelease();
+    }
 };
 thread_local MlThread tlsMl;
 
@@ -68,7 +71,8 @@ int prepare(MlThread& T, int& dev) {
         return LC_ERR_NO_DEVICE;
     }
     LC_HIP_TRY(hipGetDevice(&dev));
-    if (!T.stream || T.device != dev) {
+    if (T.stream && T.device != dev) lcMultilineThreadRelease();  // (another device: old stream and buffers go)
+    if (!T.stream) {
         LC_HIP_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));
         T.device = dev;
         lcRegisterExitHook();
@@ -89,9 +93,14 @@ int boundsAndFetch(MlThread& T, uint32_t mode, const uint8_t* const status[3], c
         LC_HIP_TRY(T.hOut.ensure(64 + size_t(cap) * sizeof(lc_ml_record_t)));
         uint32_t* hCounts = static_cast<uint32_t*>(T.hOut.p);
         lc_ml_record_t* hRecs = reinterpret_cast<lc_ml_record_t*>(static_cast<uint8_t*>(T.hOut.p) + 64);
+        // (the flag kernel counts with device atomics: the counters live in device memory -- atomics on pinned host memory need PCIe
+        // atomic support -- and come down behind the kernels; the records are plain stores into the pinned block)
+        LC_HIP_TRY(T.dSmall.ensure(256));
+        uint32_t* dCounts = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(T.dSmall.p) + 128);
         const int rc = lc_multiline_bounds_device(mode, status[0], status[1], status[2], dN, maxItems, dOff, nbytes,
-                                                  static_cast<uint8_t*>(T.dFlags.p), hRecs, cap, hCounts, T.stream);
+                                                  static_cast<uint8_t*>(T.dFlags.p), hRecs, cap, dCounts, T.stream);
         if (rc != LC_OK) return rc;
+        LC_HIP_TRY(hipMemcpyAsync(hCounts, dCounts, ML_CNT_WORDS * 4, hipMemcpyDeviceToHost, T.stream));
         LC_HIP_TRY(hipStreamSynchronize(T.stream));
         std::memcpy(counts, hCounts, ML_CNT_WORDS * 4);
         if (counts[ML_CNT_RECORDS] <= cap) {

@@ -22,9 +22,12 @@ struct FilterThread {
     TripBuf hIn, hStatus;  // pinned
     TripBuf dIn, dStatus;  // device
     FilterThread() { hIn.pinned = hStatus.pinned = true; }
+    ~FilterThread();
 };
 thread_local FilterThread tlsFilter;
 }  // namespace
+void lcRegisterExitHook();
+bool lcRuntimeUsable();  // gpu_runtime.hip
 void lcFilterThreadRelease() {
     FilterThread& T = tlsFilter;
     if (T.stream) {
@@ -35,6 +38,11 @@ void lcFilterThreadRelease() {
     for (TripBuf* b : {&T.hIn, &T.hStatus, &T.dIn, &T.dStatus}) b->release();
     T.device = -1;
 }
+namespace {
+FilterThread::~FilterThread() {
+    if (lcRuntimeUsable() && (stream || hIn.p || dIn.p)) lcFilterThreadRelease();
+}
+}  // namespace
 
 namespace logtail {
 
@@ -311,7 +319,9 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
         FILTER_TRY(hipGetDevice(&dev));
-        if (!T.stream || T.device != dev) {
+        if (T.stream && T.device != dev) lcFilterThreadRelease();  // (another device: old stream and buffers go, see PipeThread)
+        if (!T.stream) {
+        lcRegisterExitHook();
             FILTER_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));
             T.device = dev;
         }

@@ -150,6 +150,7 @@ void ProcessorGrokGpu::Init() {
     });
     for (size_t i = 0; i < Match.size(); ++i) {  // everything that was compiled is owned from here on, whatever happens next
         if (compiled[i].re) mCompiled.push_back(compiled[i].re);
+        if (compiled[i].re) lcPreferWaveTdfa(compiled[i].re);  // an entry's batch is a few hundred long values: one value per wavefront
         mScreens.push_back(compiled[i].screen);
         mScreens.push_back(compiled[i].relaxed);
     }
@@ -224,6 +225,7 @@ void ProcessorGrokGpu::startWarmup() {
                         lc_regex_compile(mExpanded[i].data(), mExpanded[i].size(), kGrokSyntax | LC_SYNTAX_PREFIX, LC_ENGINE_NFA, &re,
                                          err, sizeof err) != LC_OK)
                         continue;
+                    lcPreferWaveTdfa(re);
                     const int64_t bytes = 2 * int64_t((re->tdfaL2Blob.size() + re->tdfaBlob.size() + re->tdfaWideBlob.size()) * 4);
                     if (spent.fetch_add(bytes) + bytes > budget) {
                         lc_regex_free(re);  // over the budget: this entry keeps searching on the NFA engine

@@ -161,10 +161,13 @@ struct PipeThread {
     PipeBuf dData, dOff, dCaps, dStatus, dPacked, dCounts, dScratch;  // device
     uint32_t survivorGuess = 64;
     PipeThread() { hIn.pinned = hOut.pinned = true; }
+    ~PipeThread();  // a runner thread that ends without lc_thread_release() does not leak its stream and buffers
 };
 thread_local PipeThread tlsPipe;
 }  // namespace
 }  // namespace logtail
+void lcRegisterExitHook();
+bool lcRuntimeUsable();  // gpu_runtime.hip: false once the process is exiting (the HIP runtime may be gone)
 // lc_thread_release(): the calling thread's staging and stream
 void lcPipelineThreadRelease() {
     logtail::PipeThread& T = logtail::tlsPipe;
@@ -178,6 +181,9 @@ void lcPipelineThreadRelease() {
 }
 namespace logtail {
 namespace {
+PipeThread::~PipeThread() {
+    if (lcRuntimeUsable() && (stream || hIn.p || dData.p)) lcPipelineThreadRelease();
+}
 
 struct Trip {
     uint32_t lines = 0, survivors = 0, failed = 0, undecided = 0;
@@ -219,7 +225,11 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
     PipeThread& T = tlsPipe;
     int dev = 0;
     PIPE_TRY(hipGetDevice(&dev));
-    if (!T.stream || T.device != dev) {
+    // (a thread that moved to another device starts over: its stream is destroyed, its grow-only buffers -- allocated on the old
+    // device -- are released; they used to be kept and handed to kernels of the new device)
+    if (T.stream && T.device != dev) lcPipelineThreadRelease();
+    if (!T.stream) {
+        lcRegisterExitHook();
         PIPE_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));
         T.device = dev;
     }
@@ -244,12 +254,12 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
         PIPE_TRY(T.dOff.ensure((size_t(maxLines) + 2) * 4));
         PIPE_TRY(T.dCaps.ensure(size_t(maxLines) * 2 * G * 4));
         PIPE_TRY(T.dStatus.ensure(size_t(maxLines) + 16));
-        PIPE_TRY(T.dCounts.ensure(64));
+        PIPE_TRY(T.dCounts.ensure(128));  // [0] line count of the split | [8..11] the filter's counters
         PIPE_TRY(T.dScratch.ensure(splitScratch));
         std::memcpy(T.hIn.p, sourceVal.data(), nbytes);
         std::memset(static_cast<uint8_t*>(T.hIn.p) + nbytes, 0, 16);
         // no copy engine anywhere in the trip (its queue is shared by all runner threads): a kernel pulls
-        // the buffer out of the pinned staging, and the filter kernel writes counts and survivors straight into pinned memory
+        // the buffer out of the pinned staging, and the filter kernel writes its survivors straight into pinned memory
         int rc = lc_upload_pinned(T.hIn.p, T.dData.p, nbytes + 16, T.stream);
         uint32_t* dNLines = static_cast<uint32_t*>(T.dCounts.p);
         if (rc == LC_OK)
@@ -266,8 +276,11 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
                                        static_cast<const uint32_t*>(T.dOff.p), 1, dNLines, maxLines, G, static_cast<const int32_t*>(T.dCaps.p),
                                        static_cast<const uint8_t*>(T.dStatus.p),
                                        reinterpret_cast<int32_t*>(static_cast<uint8_t*>(T.hOut.p) + 64), cap,
-                                       static_cast<uint32_t*>(T.hOut.p), T.stream);
+                                       static_cast<uint32_t*>(T.dCounts.p) + 8, T.stream);
             if (rc != LC_OK) break;
+            // (the kernel's counters are device atomics: they live in device memory and 16 bytes come down behind the kernel --
+            // atomics on pinned host memory need PCIe atomic support the platform may not have; the survivor rows are plain stores)
+            PIPE_TRY(hipMemcpyAsync(T.hOut.p, static_cast<uint32_t*>(T.dCounts.p) + 8, 16, hipMemcpyDeviceToHost, T.stream));
             PIPE_TRY(hipStreamSynchronize(T.stream));
             const uint32_t* c = static_cast<const uint32_t*>(T.hOut.p);
             trips[s].lines = c[0];

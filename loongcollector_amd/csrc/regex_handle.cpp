@@ -1301,6 +1301,20 @@ extern "C" lc_regex_t* lc_regex_compile_relaxed_screen(const char* pattern, size
     }
 }
 
+void lcPreferWaveTdfa(lc_regex* re) {
+    if (!re || re->engine != LC_ENGINE_TDFA) return;
+    if (re->tdfaL2Blob.empty() && re->hasTdfa) {
+        const size_t tableBytes = size_t(re->tdfa.nStates) * re->tdfa.nClasses * 4;
+        if (tableBytes > (size_t(16) << 20) || size_t(re->tdfa.nRegs) * 64 * 4 > 64 * 1024) return;
+        try {
+            re->tdfaL2Blob = lcregex::packTdfaL2Blob(re->tdfa);
+        } catch (const lcregex::RegexError&) {
+            return;
+        }
+    }
+    re->preferWave = !re->tdfaL2Blob.empty();
+}
+
 extern "C" void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided) {
     if (kept) *kept = re ? uint32_t(re->nfa.atomicCount) : 0u;
     if (elided) *elided = re ? re->atomicsElided : 0u;

@@ -35,6 +35,9 @@ struct lc_regex {
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
     std::string requiredLiteral;        // longest byte string every match must contain ("" if none is certain)
+    bool preferWave = false;            // lcPreferWaveTdfa: small batches of this handle run one value per wavefront (tdfa_wave_kernel)
+                                        // even when the automaton fits the LDS kernels -- callers whose batches wait for their longest
+                                        // value (the Grok matcher's per-entry batches of long values)
     uint32_t atomicsElided = 0;         // atomic groups turned into plain groups because they provably change nothing (atomic_elide.cpp)
     // the decide kernel's per-frame capacities (nfa_decide_kernel.hpp DecideShape): enter / enter+exit events of the longest path
     uint32_t decideMaxEnter = 0, decideClosedCap = 0;
@@ -128,6 +131,9 @@ int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
                      const uint32_t* d_in, uint32_t* d_out, uint32_t* d_counters, void* stream);
 // implemented in gpu_runtime.hip; frees device copies
 void lcReleaseDeviceTables(lc_regex* re);
+// regex_handle.cpp: ask for the wave-per-value kernel on small batches of this handle (packs the global-memory form of its tagged
+// DFA beside the LDS form; no effect on handles without a tagged DFA).  Call before the handle's first launch.
+void lcPreferWaveTdfa(lc_regex* re);
 // implemented in gpu_runtime.hip: one launch of the engine's kernel.  d_n (optional): line count on the device;
 // d_order (optional): the lines to process; d_resume (optional, indexed by line): resume offsets of a search pattern.
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
