@@ -511,7 +511,8 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // largest batch that stages whatever fits the CU's 160 KiB (0 = never; A/B measurements).
     static const uint32_t smallBatch = [] {
         const char* e = getenv("LC_NFA_SMALL_BATCH");
-        return uint32_t(e ? atol(e) : 8192);
+        return uint32_t(e ? atol(e) : 0);  // (measured on configs[2], round 4: 4.57 vs 4.84 ms at 1000 values, 8.16 vs 8.18 ms at 16 Ki -- staging
+                                           // 100+ KiB per workgroup of four values eats what the faster steps save: off by default)
     }();
     const bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
     if (global) lds -= blobBytes;

@@ -343,6 +343,7 @@ struct PlanThread {
     int device = -1;
     hipStream_t workers[kGrokMaxStreams] = {};
     hipEvent_t fork = nullptr, join[kGrokMaxStreams] = {};
+    hipEvent_t tick[2 * 64 + 2 * 64] = {};  // calibration batches: [2a begin/end per entry | 2c begin/end per entry], created on first use
     uint32_t* hostWords = nullptr;        // pinned, HW_*
     GrokEntryDev* hostEntries = nullptr;  // pinned [64]
     GrokEntryDev* dEntries = nullptr;     // device [64]
@@ -364,6 +365,8 @@ struct PlanThread {
                         (void)hipStreamDestroy(w);
                     }
                 if (fork) (void)hipEventDestroy(fork);
+                for (auto& e : tick)
+                    if (e) (void)hipEventDestroy(e);
                 for (auto& e : join)
                     if (e) (void)hipEventDestroy(e);
                 if (hostWords) (void)hipHostFree(hostWords);
@@ -379,6 +382,7 @@ struct PlanThread {
         }
         for (auto& w : workers) w = nullptr;
         for (auto& e : join) e = nullptr;
+        for (auto& e : tick) e = nullptr;
         fork = nullptr;
         hostWords = nullptr;
         hostEntries = nullptr;
@@ -486,7 +490,7 @@ struct PlanEntry {
     uint32_t seq0 = 0;    // launch sequence of round 0's first-chance kernel (lcMatchSecondChanceOnStream)
     const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
     int stream = 0;
-    double cost = 0;
+    double cost = 0, cost0 = 0, cost1 = 0;  // heuristic; measured round 0 / leftovers (ns, 0 = unknown)
     GrokEntryDev dev{};
     uint32_t *listA = nullptr, *listB = nullptr, *unanchored = nullptr;
     int32_t* caps = nullptr;
@@ -611,6 +615,10 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.rounds = std::max(2u, e.rounds);  // (round 0 is a phase of its own; round 1 reads the screened list)
         const bool nfa = patterns[p].re->engine == LC_ENGINE_NFA;
         e.cost = double(c) * (nfa ? (patterns[p].anchored ? 8.0 : 40.0) : 1.0);
+        // (measured, once a calibration batch has run: ns per candidate of round 0 and of the leftovers)
+        const uint32_t c0 = patterns[p].re->grokCost0Ns.load(std::memory_order_relaxed), c1 = patterns[p].re->grokCost1Ns.load(std::memory_order_relaxed);
+        e.cost0 = c0 ? double(c0) * c : 0.0;
+        e.cost1 = c1 ? double(c1) * c : 0.0;
         // an automaton that walks its tables in global memory (tdfa_l2_kernel) takes as long as its LONGEST candidate -- one dependent
         // read per byte, ~0.7 us per byte, 2.8 ms for a 4 KiB line -- on a grid of a few waves: it goes to the head of its stream,
         // where it runs beside everything else, instead of behind the cheap entries (measured: the step's last 2.8 ms were this)
@@ -758,20 +766,56 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             return LC_OK;
         };
         auto cnt = [&](size_t a, uint32_t word) { return T.hostWords[HW_CNT + a * GC_WORDS + word]; };
+        // Which stream an entry goes to.  A phase lasts as long as its most loaded stream, and the entries differ by a factor of ten
+        // (an anchored DFA over 300 values: 0.1 ms; the thread-list engine on a format with a free-text field in the middle: 3 ms).
+        // Calibration batches (the first three of a handle, then every 64th) time every entry's launches with events; the matcher
+        // then deals longest-first to the least loaded stream.  Before the first measurement: the static estimate.
+        bool calibrate = false;
+        {
+            bool allKnown = true;
+            for (size_t a = 0; a < nAct; ++a) allKnown = allKnown && act[a].cost0 > 0;
+            const uint32_t seen = patterns[act[0].p].re->grokBatches.fetch_add(1, std::memory_order_relaxed);
+            calibrate = !allKnown || seen < 3 || (seen & 63u) == 0;
+            if (calibrate)
+                for (size_t k = 0; k < 4 * nAct; ++k)
+                    if (!T.tick[k]) HIP_TRY(hipEventCreate(&T.tick[k]));
+        }
+        std::vector<char> busy2c(nAct, 0);  // phase 2c: the entries that have anything to do in it
+        auto deal = [&](bool leftovers) {  // longest first, each to the least loaded stream
+            std::vector<size_t> idx;
+            for (size_t a = 0; a < nAct; ++a) idx.push_back(a);
+            auto costOf = [&](size_t a) {
+                const double known = leftovers ? act[a].cost1 : act[a].cost0;
+                return known > 0 ? known : act[a].cost * 50.0;
+            };
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return costOf(x) > costOf(y); });
+            double load[kGrokMaxStreams] = {};
+            for (size_t a : idx) {
+                if (leftovers ? (!busy2c[a] || act[a].level >= 2) : act[a].level != 0) continue;
+                uint32_t best = 0;
+                for (uint32_t s2 = 1; s2 < used; ++s2)
+                    if (load[s2] < load[best]) best = s2;
+                act[a].stream = int(best);
+                load[best] += costOf(a) + 20000.0;  // (+ a launch)
+            }
+            return idx;
+        };
         // 2a
         {
             int rc = fork();
             if (rc != LC_OK) return rc;
-            uint32_t dealt = 0;
+            const std::vector<size_t> order0 = deal(false);
             for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
-                PlanEntry& e = act[byCost[i]];
+                const size_t a = order0[i];
+                PlanEntry& e = act[a];
                 const GrokDevicePattern& gp = patterns[e.p];
-                e.stream = int(dealt++ % used);
                 if (e.level) continue;  // (waits for the entries that shadow it: phase 2c)
                 lcSetDecideSlot(1 + e.stream);
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * a], T.workers[e.stream]));
                 rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
                                           gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
+                if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]));
                 if (trace)
                     fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d\n", e.p, e.cand, e.stream,
                             first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2", gp.anchored ? " (anchored)" : "",
@@ -793,6 +837,19 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             int rc = readCounts();  // sync 2
             if (rc != LC_OK) return rc;
         }
+        auto learn = [&](std::atomic<uint32_t>& slot, hipEvent_t b, hipEvent_t e2, uint32_t cand) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, b, e2) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            const uint32_t ns = uint32_t(std::min(4.0e9, std::max(1.0, double(ms) * 1e6 / std::max(1u, cand))));
+            const uint32_t old = slot.load(std::memory_order_relaxed);
+            slot.store(old ? (old + ns) / 2 : ns, std::memory_order_relaxed);
+        };
+        if (calibrate)
+            for (size_t a = 0; a < nAct; ++a)
+                if (!act[a].level) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
         // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
         // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
         // entries on the values nobody before them has won.  Their chains are queued whole: they are few.
@@ -807,15 +864,24 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                    static_cast<const uint32_t*>(nullptr), 0u);
                 int rc = fork();
                 if (rc != LC_OK) return rc;
+                for (size_t a = 0; a < nAct; ++a) busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
+                const std::vector<size_t> order1 = deal(true);
                 // ONE fork for all of it: the leftovers of level 0 and the entries of level 1 depend on round 0 only; an entry of level
                 // 2 or 3 is queued on the stream of the entry that shadows most of its candidates, behind that entry's chain and a
                 // finish step for it -- stream order instead of a barrier per level.
                 for (uint32_t level = 0; level <= maxLevel && rc == LC_OK; ++level)
                 for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
-                    const size_t a = byCost[i];
+                    const size_t a = order1[i];
                     PlanEntry& e = act[a];
-                    if (e.level != level) continue;
+                    if (e.level != level || !busy2c[a]) continue;
                     const GrokDevicePattern& gp = patterns[e.p];
+                    struct Tock {  // (the entry's chain, timed on calibration batches -- whichever way the iteration is left)
+                        hipEvent_t ev;
+                        hipStream_t* ws;
+                        ~Tock() {
+                            if (ev) (void)hipEventRecord(ev, *ws);
+                        }
+                    };
                     if (level >= 2) {  // behind its main shadower
                         uint32_t best = 0, bestF = 0;
                         for (uint32_t f = 0; f < e.p; ++f)
@@ -831,6 +897,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                         }
                     }
                     hipStream_t ws = T.workers[e.stream];
+                    if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * nAct + 2 * a], ws));
+                    Tock tock{calibrate ? T.tick[2 * nAct + 2 * a + 1] : nullptr, &ws};
                     const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
                     auto post = [&](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
                         hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a), in, inCount, flags, xtmp,
@@ -887,6 +955,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             int rc = readCounts();  // sync 3
             if (rc != LC_OK) return rc;
         }
+        if (calibrate)
+            for (size_t a = 0; a < nAct; ++a)
+                if (busy2c[a]) learn(patterns[act[a].p].re->grokCost1Ns, T.tick[2 * nAct + 2 * a], T.tick[2 * nAct + 2 * a + 1], act[a].cand);
         // 2e
         {
             bool any = false;

@@ -54,6 +54,10 @@ struct lc_regex {
     // Grok (grok_device.hip): search rounds this Match entry queues ahead per batch (FindStringMatch + FindNextMatch ...); follows
     // what the batches turn out to need
     std::atomic<uint32_t> grokRounds{2}, grokRoundsSlack{0};
+    // ... and what its round 0 (first-chance launch) and its leftovers (second chance, search proper) cost on the device, in ns per
+    // candidate, as measured with events on calibration batches (0 = not measured yet): the matcher deals the entries to its worker
+    // streams longest-first by these
+    std::atomic<uint32_t> grokCost0Ns{0}, grokCost1Ns{0}, grokBatches{0};
 };
 
 // Values a consumer without a parse-failure notion of its own (filter leaves, multiline flags, the Go regex plugin) had to take as
