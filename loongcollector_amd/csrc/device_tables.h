@@ -115,6 +115,13 @@ enum {
     NF_SUFFIX = 22,       // 1: the LAST position is the greedy suffix (?s:.*) of the search wrapper (LC_SYNTAX_SEARCH, with or without
                           // LC_SYNTAX_PREFIX): a thread on it takes every byte and ends on MATCH whatever follows, so nothing ranked
                           // below it can win, and a thread list that is that thread alone is decided -- the kernels stop there
+    NF_OFF_QUASI = 23,    // 0, or the offset of the DOOMED-SPAWN tables (round 4): u32 rows, u32 offset of the rows, then u16 idx[nPos + 1]
+                          // (0 = the position has no row, else row + 1); rows: u32[rows][nClasses][maskWords] -- bit d of row r, class c:
+                          // a thread on the position, on a byte of class c FOLLOWED by a byte of class d, does nothing but repeat
+                          // itself: its one clean self loop passes, and every other path that passes leads to a position none of
+                          // whose follow paths takes d -- a thread that would live for exactly one byte and touch nothing
+                          // (the " SA (SPI=" behind a GREEDYDATA tried at every space; the lazy search prefix tried at every byte a
+                          // format can begin with).  Such a byte is as steady as one whose only move is the self loop.
     NF_HEADER_WORDS = 24
 };
 #define NF_MAGIC_VALUE 0x3141464Eu

@@ -80,6 +80,33 @@ __device__ __forceinline__ bool nfaMaskBit(const uint32_t* masks, uint32_t maskS
     return (masks[(p << maskShift) + cw] >> cb) & 1u;
 }
 
+// doomed spawns (device_tables.h NF_OFF_QUASI): on class c followed by class d the thread on position p only repeats itself
+struct NfaQuasi {
+    const uint16_t* idx = nullptr;  // nullptr: the pattern has no such rows
+    const uint32_t* rows = nullptr;
+    uint32_t nCls = 0;
+};
+__device__ __forceinline__ NfaQuasi nfaQuasiOf(const uint8_t* tbl, const uint32_t* hdr) {
+    NfaQuasi q;
+    const uint32_t at = hdr[NF_OFF_QUASI];
+    if (at) {
+        q.idx = reinterpret_cast<const uint16_t*>(tbl + at + 8);
+        q.rows = reinterpret_cast<const uint32_t*>(tbl + reinterpret_cast<const uint32_t*>(tbl + at)[1]);
+        q.nCls = hdr[NF_NCLASSES];
+    }
+    return q;
+}
+// steady on class c: the stable mask says so, or (d = class of the NEXT byte, 0xFFFFFFFF = none / unknown) every thread the byte
+// would spawn is gone again behind the next one
+__device__ __forceinline__ bool nfaQuiet(const uint32_t* stable, uint32_t maskShift, const NfaQuasi& q, uint32_t p, uint32_t c, uint32_t d) {
+    if (nfaMaskBit(stable, maskShift, p, c >> 5, c & 31u)) return true;
+    if (!q.idx || d == 0xFFFFFFFFu) return false;
+    const uint32_t r = q.idx[p];
+    if (!r) return false;
+    const uint32_t* row = q.rows + (((r - 1) * q.nCls + c) << maskShift);
+    return (row[d >> 5] >> (d & 31u)) & 1u;
+}
+
 struct NfaAtomicCtx {
     NfaTables tb;
     const uint32_t* events;
@@ -404,6 +431,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     const bool searchSkip = hdr[NF_SEARCH] != 0;
     // the last position is the search wrapper's greedy suffix (search and anchored search, device_tables.h NF_SUFFIX)
     const bool hasSuffix = hdr[NF_SUFFIX] != 0;
+    const NfaQuasi quasi = nfaQuasiOf(tbl, hdr);
     // steady classes of the search wrapper's prefix position (words 2, 3 only exist for patterns with > 64 byte classes)
     const uint32_t stable0[4] = {stable[0], stable[1], maskShift == 2 ? stable[2] : 0u, maskShift == 2 ? stable[3] : 0u};
     uint32_t curWord;
@@ -430,13 +458,18 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         if (searchSkip && nThreads == 1 && __builtin_amdgcn_readfirstlane(myPos) == 0) {
             const uint32_t chunkBase = idx & ~255u, end = head + L;
             uint32_t firstHit = 4;
+            const uint32_t nextWord = __shfl_down(curWord, 1, 64);  // (lane 63: its own word -- its last byte is never looked ahead from)
+            uint32_t dNext = (lane < 63 && chunkBase + lane * 4 + 4 < end) ? uint32_t(classMap[nextWord & 0xFFu]) : 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
                 const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
                 const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
                 const uint32_t sw = c < 64 ? (c < 32 ? stable0[0] : stable0[1]) : (c < 96 ? stable0[2] : stable0[3]);
-                const uint32_t steady = (sw >> (c & 31u)) & 1u;
+                uint32_t steady = (sw >> (c & 31u)) & 1u;
+                // (a byte the format can begin with, followed by one its second position cannot take: the attempt is gone again)
+                if (!steady && quasi.idx && bi >= idx && bi + 1 < end) steady = nfaQuiet(stable, maskShift, quasi, 0u, c, dNext) ? 1u : 0u;
                 if (bi >= idx && bi < end && !steady) firstHit = uint32_t(j);
+                dNext = c;
             }
             const uint64_t hit = __ballot(firstHit < 4);
             uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;
@@ -461,7 +494,13 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         // unconditional, tag-free self loop (inside a field such as [^ ]* that is almost every byte) -> the thread
         // list, its order and the captures are unchanged; skip the whole election/compaction/transfer machinery.
         {
-            const bool bit = nfaMaskBit(stable, maskShift, myPos, cw, cb);
+            // (the class of the byte behind this one, for the doomed-spawn test: known when it lies in the loaded chunk)
+            uint32_t clsNext = 0xFFFFFFFFu;
+            if (quasi.idx && i + 1 < L && ((idx + 1) >> 8) == (idx >> 8)) {
+                const uint32_t wn = __builtin_amdgcn_readlane(curWord, ((idx + 1) >> 2) & 63u);
+                clsNext = classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu];
+            }
+            const bool bit = liveLane && nfaQuiet(stable, maskShift, quasi, myPos, cls, clsNext);
             if (__all(!liveLane || bit)) {
                 prevCls = cls;
                 // A steady byte is usually the first of a RUN of them (inside a field, inside GREEDYDATA): with a few live threads all
@@ -470,14 +509,18 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
                 if (nThreads <= kNfaSteadyScanThreads) {
                     const uint32_t chunkBase = idx & ~255u, end = head + L;
                     uint32_t firstHit = 4;
+                    const uint32_t nextWord = __shfl_down(curWord, 1, 64);
+                    uint32_t dNext = (lane < 63 && chunkBase + lane * 4 + 4 < end) ? uint32_t(classMap[nextWord & 0xFFu]) : 0xFFFFFFFFu;
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
                         const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
                         const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
                         bool steadyAll = true;
                         for (uint32_t t = 0; t < nThreads; ++t)
-                            steadyAll = steadyAll && nfaMaskBit(stable, maskShift, __builtin_amdgcn_readlane(myPos, t), c >> 5, c & 31u);
+                            steadyAll = steadyAll && nfaQuiet(stable, maskShift, quasi, __builtin_amdgcn_readlane(myPos, t), c,
+                                                              bi + 1 < end ? dNext : 0xFFFFFFFFu);  // (the value's last byte has no next one)
                         if (bi > idx && bi < end && !steadyAll) firstHit = uint32_t(j);
+                        dNext = c;
                     }
                     const uint64_t hit = __ballot(firstHit < 4);
                     uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     const bool hasSuffix = hdr[NF_SUFFIX] != 0;
     const uint32_t* stable = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_STABLE]);
     const uint32_t maskShift = tb.maskShift;
+    const NfaQuasi quasi = nfaQuasiOf(tbl, hdr);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 3);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
@@ -121,20 +122,29 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         const uint32_t cls = classMap[(wsel >> ((idx & 3u) * 8)) & 0xFFu];
         const uint32_t cw = cls >> 5, cb = cls & 31u;
         if (nThreads <= 64) {  // steady byte: nothing moves (nfa_kernel.hpp); with few threads, look for the end of the run
-            const bool bit = lane < nThreads && nfaMaskBit(stable, maskShift, pos[0], cw, cb);
+            uint32_t clsNext = 0xFFFFFFFFu;
+            if (quasi.idx && i + 1 < L && ((idx + 1) >> 8) == (idx >> 8)) {
+                const uint32_t wn = __builtin_amdgcn_readlane(curWord, ((idx + 1) >> 2) & 63u);
+                clsNext = classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu];
+            }
+            const bool bit = lane < nThreads && nfaQuiet(stable, maskShift, quasi, pos[0], cls, clsNext);
             if (__all(lane >= nThreads || bit)) {
                 prevCls = cls;
                 if (nThreads <= kNfaSteadyScanThreads) {
                     const uint32_t chunkBase = idx & ~255u, end = head + L;
                     uint32_t firstHit = 4;
+                    const uint32_t nextWord = __shfl_down(curWord, 1, 64);
+                    uint32_t dNext = (lane < 63 && chunkBase + lane * 4 + 4 < end) ? uint32_t(classMap[nextWord & 0xFFu]) : 0xFFFFFFFFu;
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
                         const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
                         const uint32_t c = classMap[(curWord >> (8 * j)) & 0xFFu];
                         bool steadyAll = true;
                         for (uint32_t t = 0; t < nThreads; ++t)
-                            steadyAll = steadyAll && nfaMaskBit(stable, maskShift, __builtin_amdgcn_readlane(pos[0], t), c >> 5, c & 31u);
+                            steadyAll = steadyAll && nfaQuiet(stable, maskShift, quasi, __builtin_amdgcn_readlane(pos[0], t), c,
+                                                              bi + 1 < end ? dNext : 0xFFFFFFFFu);
                         if (bi > idx && bi < end && !steadyAll) firstHit = uint32_t(j);
+                        dNext = c;
                     }
                     const uint64_t hit = __ballot(firstHit < 4);
                     uint32_t stop = chunkBase + 256 < end ? chunkBase + 256 : end;

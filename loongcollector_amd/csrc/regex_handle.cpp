@@ -681,6 +681,56 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         putMask(stableMask, size_t(p), m);
     }
     if (npos >= 0xFFFF) throw RegexError("nfa: more than 65534 positions");
+    // ---- doomed spawns (device_tables.h NF_OFF_QUASI).  cont[t]: the byte classes some follow path of t takes (MATCH paths take no
+    // byte; assertions are ignored: a superset).  For (p, c) that is not stable: exactly one passing path is p's clean self loop, the
+    // others are plain (no atomic events) moves to positions t != p; then the classes d outside every cont[t] are the bytes behind
+    // which the spawned threads are gone again.  A position that leaves an atomic group on some path is never steady (as above).
+    std::vector<uint16_t> quasiIdx(size_t(npos) + 1, 0);
+    std::vector<uint32_t> quasiRows;
+    {
+        static const bool off = getenv("LC_NFA_NO_QUASI") != nullptr;  // (A/B measurements)
+        std::vector<ClassMask> cont(size_t(npos), 0);
+        const ClassMask allClasses = rep.size() >= 128 ? ~ClassMask(0) : ((ClassMask(1) << rep.size()) - 1);
+        for (int t = 0; t < npos; ++t)
+            for (const auto& g : nfa.follow[size_t(t)])
+                if (g.target >= 0)
+                    for (size_t d = 0; d < rep.size(); ++d)
+                        if (nfa.positions[size_t(g.target)].has(rep[d])) cont[size_t(t)] |= ClassMask(1) << d;
+        for (int p = 0; p < npos && !off; ++p) {
+            bool leaves = false;
+            for (const auto& path : nfa.follow[size_t(p)])
+                for (const auto& ev : path.atoms) leaves = leaves || ev.code < 0;
+            if (leaves) continue;
+            std::vector<ClassMask> row(rep.size(), 0);
+            bool any = false;
+            for (size_t c = 0; c < rep.size(); ++c) {
+                if ((ClassMask(stableMask[size_t(p) * mw]) | (ClassMask(stableMask[size_t(p) * mw + 1]) << 32) |
+                     (mw == 4 ? (ClassMask(stableMask[size_t(p) * mw + 2]) << 64) | (ClassMask(stableMask[size_t(p) * mw + 3]) << 96) : 0)) >> c & 1)
+                    continue;  // stable already
+                int selfLoops = 0;
+                bool plain = true;
+                ClassMask survive = 0;
+                for (const auto& path : nfa.follow[size_t(p)]) {
+                    if (path.target < 0 || !nfa.positions[size_t(path.target)].has(rep[c])) continue;
+                    if (!path.atoms.empty()) plain = false;
+                    if (path.target == p) {
+                        if (path.tags.any() || path.cond != 0) plain = false;  // (a tagged or conditional self loop is a real move)
+                        ++selfLoops;
+                    } else {
+                        survive |= cont[size_t(path.target)];
+                    }
+                }
+                if (!plain || selfLoops != 1) continue;
+                row[c] = allClasses & ~survive;
+                any = any || row[c] != 0;
+            }
+            if (!any) continue;
+            quasiIdx[size_t(p)] = uint16_t(quasiRows.size() / (rep.size() * mw) + 1);
+            for (size_t c = 0; c < rep.size(); ++c)
+                for (size_t k = 0; k < mw; ++k) quasiRows.push_back(uint32_t(row[c] >> (32 * k)));
+            if (quasiRows.size() / (rep.size() * mw) >= 0xFFFE) break;
+        }
+    }
     // aux entries: (cond, tags words...) padded to 4 words -- 8 / 16 when the pattern has more than 64 / 128 capture slots
     const size_t aw = nfa.slotCount() > 128 ? 16 : (nfa.slotCount() > 64 ? 8 : 4);
     std::vector<uint32_t> followStart, paths, events, aux(aw, 0);  // aux entry 0 = (no cond, no tags)
@@ -742,6 +792,17 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     hdr[NF_OFF_PATHS] = w.put(paths);
     hdr[NF_OFF_AUX] = w.put(aux);
     hdr[NF_OFF_STABLE] = w.put(stableMask);
+    if (!quasiRows.empty()) {
+        const uint32_t rowsAt = w.put(quasiRows);
+        std::vector<uint16_t> block(4, 0);  // u32 rows | u32 offset of the rows | idx...
+        const uint32_t nRows = uint32_t(quasiRows.size() / (rep.size() * mw));
+        block[0] = uint16_t(nRows & 0xFFFF);
+        block[1] = uint16_t(nRows >> 16);
+        block[2] = uint16_t(rowsAt & 0xFFFF);
+        block[3] = uint16_t(rowsAt >> 16);
+        block.insert(block.end(), quasiIdx.begin(), quasiIdx.end());
+        hdr[NF_OFF_QUASI] = w.put(block);
+    }
     // look assertions per byte class: behind[c] / ahead[c] = cond bits that hold when the previous / next byte has
     // class c; entry nClasses = START / END
     std::vector<uint32_t> behind(rep.size() + 1), ahead(rep.size() + 1);

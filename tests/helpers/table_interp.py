@@ -96,6 +96,15 @@ class NfaInterp:
         st = blob[int(blob[11]) // 4:int(blob[11]) // 4 + mw * (self.npos + 1)]
         self.stable = [sum(int(st[mw * p + k]) << (32 * k) for k in range(mw)) for p in range(self.npos + 1)]
         self.search_suffix = self.npos - 1 if int(blob[22]) else -1                                # NF_SUFFIX (search and anchored search)
+        # NF_OFF_QUASI: doomed spawns -- (position, class c, next class d) on which the thread only repeats itself
+        self.quasi_idx, self.quasi_rows = None, None
+        if int(blob[23]):
+            q = int(blob[23])
+            nrows, rows_at = int(blob[q // 4]), int(blob[q // 4 + 1])
+            self.quasi_idx = raw[q + 8:q + 8 + 2 * (self.npos + 1)].view(np.uint16)
+            rows = blob[rows_at // 4:rows_at // 4 + nrows * self.ncls * mw]
+            self.quasi_rows = [[sum(int(rows[(r * self.ncls + c) * mw + k]) << (32 * k) for k in range(mw)) for c in range(self.ncls)]
+                               for r in range(nrows)]
         self.follow = []
         for p in range(self.npos + 1):
             lst = []
@@ -124,7 +133,15 @@ class NfaInterp:
             if steady and self.search_suffix >= 0 and len(threads) == 1 and threads[0][0] == self.search_suffix:
                 break
             cls = int(self.cmap[b])
-            if steady and all((self.stable[p] >> cls) & 1 for p, _ in threads):
+            nxt = int(self.cmap[s[pos + 1]]) if pos + 1 < len(s) else -1
+
+            def quiet(p):
+                if (self.stable[p] >> cls) & 1:
+                    return True
+                if nxt < 0 or self.quasi_idx is None or p >= len(self.quasi_idx) or not int(self.quasi_idx[p]):
+                    return False
+                return bool((self.quasi_rows[int(self.quasi_idx[p]) - 1][cls] >> nxt) & 1)
+            if steady and all(quiet(p) for p, _ in threads):
                 prev_cls = cls
                 continue
             holds = self.behind[prev_cls] | self.ahead[cls]

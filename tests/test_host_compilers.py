@@ -471,3 +471,51 @@ def test_wave_walk_of_global_memory_automata_equals_the_byte_walk(golden_dir):
                 want = o.fullmatch(s)
                 assert a == (None if want is None else [v for be in want for v in be][2:]), s
     assert checked > 450 and runs > 60
+
+
+QUASI_PATTERNS = [
+    r"(\w+): An (\w+) (.*) SA \(SPI= (.*?)\) between (\d+) and (\d+)",      # GREEDYDATA in the middle, a literal behind it
+    r"\((?:Primary|Secondary)\) Monitoring on [Ii]nterface (.*) waiting",
+    r"Group = (.*), IP = (\d+), NAT",
+    r"a(.*)bcd(.*)bce",
+    r"(?:denied|discarded|dropped) (\w+) src (.*?):(\d+) dst",                 # lazy field, several alternatives at the start
+    r"x([^,]*),([^,]*),y",
+]
+
+
+def test_doomed_spawns_are_skipped_without_changing_a_result():
+    """NF_OFF_QUASI (regex_handle.cpp packNfaBlob): a byte on which a thread's only lasting move is its own clean self loop -- every
+    other path that passes leads to a position no follow path of which takes the NEXT byte -- is as steady as a self-loop-only byte.
+    The NFA walk with the shortcut (what nfa_match_kernel does) against the walk without any shortcut and the oracle, full match,
+    search and anchored search, on subjects built from the patterns' own words; and the tables exist for these shapes."""
+    import random
+    rng = random.Random(23)
+    words = ["IPSEC:", "An", "outbound", "SA", "S", "SP", "(SPI=", "0x1f)", "between", "12", "and", "34", " ", "(Primary)", "(Secondary)", "Monitoring",
+             "on", "interface", "Interface", "waiting", "wait", "w", "Group", "=", ",", "IP", "NAT", "a", "b", "bc", "bcd", "bce", "denied", "den",
+             "discarded", "dropped", "tcp", "src", "dst", "in:", "7", "x", "y", "x1,2,y", ",y"]
+    rows = checked = 0
+    for pat in QUASI_PATTERNS:
+        for flags in (0, B.LC_SYNTAX_SEARCH, B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_PREFIX):
+            rx = B.GpuRegex(pat, syntax_flags=flags, engine=B.LC_ENGINE_NFA)
+            it = NfaInterp(rx)
+            rows += 0 if it.quasi_rows is None else len(it.quasi_rows)
+            o = OracleRegex(pat)
+            for _ in range(120):
+                s = " ".join(rng.choice(words) for _ in range(rng.randint(1, 40))).encode()
+                if rng.random() < 0.5:   # half of the subjects contain a real match
+                    s = rng.choice([b"", b"junk "]) + {0: b"IPSEC: An outbound tunnel mode SA (SPI= 0x7) between 1 and 2", 1: b"(Primary) Monitoring on interface " + s + b" waiting",
+                                                        2: b"Group = " + s + b", IP = 9, NAT", 3: b"a" + s + b"bcd" + s + b"bce", 4: b"denied tcp src " + s + b":80 dst",
+                                                        5: b"x1,2,y"}[QUASI_PATTERNS.index(pat)] + rng.choice([b"", b" tail " + s])
+                fast, slow = it.fullmatch(s), it.fullmatch(s, steady=False)
+                assert fast == slow, (pat, flags, s)
+                if flags == 0:
+                    want = o.fullmatch(s)
+                    exp = None if want is None else [v for be in want for v in be][2:]
+                elif flags == B.LC_SYNTAX_SEARCH:
+                    want = o.search(s)
+                    exp = None if want is None else [v for be in want for v in be]
+                else:
+                    exp = fast   # (anchored search: the two walks against each other)
+                assert fast == exp, (pat, flags, s, fast, exp)
+                checked += 1
+    assert rows >= 10 and checked > 2000
