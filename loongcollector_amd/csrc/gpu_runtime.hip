@@ -647,10 +647,31 @@ __global__ __launch_bounds__(256) void run_capture_kernel(const uint8_t* __restr
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
     uint32_t e = uint32_t(c[0]);
-    while (e < L) {
-        const uint32_t b = data[size_t(o) + e];
-        if (!((set.w[b >> 5] >> (b & 31u)) & 1u)) break;
-        ++e;
+    // (16 bytes per load once the address is aligned: the run of a GREEDYDATA group is the rest of the value -- 4 KiB of one
+    // dependent byte load per iteration was 0.8 ms of a Grok step)
+    const uint8_t* base = data + size_t(o);
+    bool stop = false;
+    while (e < L && !stop && ((reinterpret_cast<uintptr_t>(base) + e) & 15u)) {
+        const uint32_t b = base[e];
+        if (!((set.w[b >> 5] >> (b & 31u)) & 1u)) stop = true;
+        else ++e;
+    }
+    while (e + 16 <= L && !stop) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + e);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t run = 16;  // bytes of this load that belong to the run
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+            if (!((set.w[b >> 5] >> (b & 31u)) & 1u)) run = uint32_t(j);
+        }
+        e += run;
+        stop = run < 16;
+    }
+    while (e < L && !stop) {
+        const uint32_t b = base[e];
+        if (!((set.w[b >> 5] >> (b & 31u)) & 1u)) stop = true;
+        else ++e;
     }
     c[1] = int32_t(e);
 }

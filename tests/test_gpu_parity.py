@@ -852,3 +852,38 @@ def test_reference_boost_regex_search_vectors_on_the_device(torch_dev, golden_di
                 checked += 1
                 assert (status[i] == B.LC_MATCH) == want, (c["cite"], c["subs"][i][0], eng)
     assert checked >= 16
+
+
+def test_doomed_spawn_skipping_on_the_device(torch_dev):
+    """nfa_match_kernel / nfa_wide_kernel cross bytes whose spawned threads are gone behind the next byte (NF_OFF_QUASI) -- free text
+    in the middle of a format, long values, matches and near-misses, full match / search / anchored search on the NFA engine, against
+    the oracle.  The CPU twin (tests/test_host_compilers.py) checks the same shapes on the table interpreter."""
+    from tests.test_host_compilers import QUASI_PATTERNS
+    rng = random.Random(31)
+    words = [b"IPSEC:", b"An", b"outbound", b"SA", b"S", b"SP", b"(SPI=", b"0x1f)", b"between", b"12", b"and", b"34", b"(Primary)", b"Monitoring",
+             b"on", b"interface", b"waiting", b"wait", b"w", b"Group", b"=", b",", b"IP", b"NAT", b"a", b"b", b"bc", b"bcd", b"bce", b"denied", b"den",
+             b"dropped", b"tcp", b"src", b"dst", b"7", b"x", b"y", b"x1,2,y", b",y"]
+    heads = {0: b"IPSEC: An outbound %s SA (SPI= 0x7) between 1 and 2", 1: b"(Primary) Monitoring on interface %s waiting", 2: b"Group = %s, IP = 9, NAT",
+             3: b"a%sbcd%sbce", 4: b"denied tcp src %s:80 dst", 5: b"x1,%s,y"}
+    checked = 0
+    for k, pat in enumerate(QUASI_PATTERNS):
+        subs = []
+        for _ in range(300):
+            filler = b" ".join(rng.choice(words) for _ in range(rng.choice([1, 5, 40, 300, 800])))
+            s = heads[k].replace(b"%s", filler) if rng.random() < 0.6 else filler
+            subs.append(rng.choice([b"", b"junk "]) + s + rng.choice([b"", b" tail"]))
+        data, off, length = pack(subs)
+        o = OracleRegex(pat)
+        for flags in (0, B.LC_SYNTAX_SEARCH):
+            rx = B.GpuRegex(pat, syntax_flags=flags, engine=B.LC_ENGINE_NFA)
+            assert rx.table(B.LC_TABLE_NFA_BLOB, np.uint32)[23] != 0 or k == 5      # NF_OFF_QUASI: the tables exist for these shapes
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+            for i, s in enumerate(subs):
+                want = o.search(s) if flags else o.fullmatch(s)
+                checked += 1
+                if want is None:
+                    assert status[i] == B.LC_NOMATCH, (pat, flags, s[:80])
+                else:
+                    exp = [v for be in want for v in be]
+                    assert status[i] == B.LC_MATCH and list(caps[i]) == (exp if flags else exp[2:]), (pat, flags, s[:80])
+    assert checked == 2 * 300 * len(QUASI_PATTERNS)
