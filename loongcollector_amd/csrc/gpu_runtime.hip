@@ -871,9 +871,9 @@ struct JobTableRing {
 };
 thread_local JobTableRing tlsJobTables;
 
-template <int BLOCK>
+template <int BLOCK, bool PAIR1>
 int launchTdfaMulti(const TdfaJob* table, uint32_t nJobs, uint32_t totalBlocks, size_t lds, hipStream_t stream) {
-    auto kern = tdfa_stream_multi_kernel<BLOCK, false>;
+    auto kern = tdfa_stream_multi_kernel<BLOCK, false, PAIR1>;
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
@@ -881,7 +881,7 @@ int launchTdfaMulti(const TdfaJob* table, uint32_t nJobs, uint32_t totalBlocks, 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet[devNow] = lds;
     }
-    noteKernel("tdfa_stream_multi_kernel");
+    noteKernel(PAIR1 ? "tdfa_stream_multi_kernel<pair1>" : "tdfa_stream_multi_kernel");
     uint32_t* nullCounter = nullptr;
     uint32_t* nullFlag = nullptr;
     uint32_t zero = 0;
@@ -914,7 +914,9 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
         ring.device = dev;
     }
     // one packed launch per workgroup size the tables were packed for (almost always one: 256)
-    for (int block : {256, 128, 64}) {
+    for (int variant = 0; variant < 6; ++variant) {
+        const int block = variant < 2 ? 256 : variant < 4 ? 128 : 64;
+        const bool pairOne = (variant & 1) != 0;  // jobs whose standard tables carry a one-stamp pair table go together
         std::vector<TdfaJob> packed;
         uint32_t blocks = 0;
         size_t lds = 0;
@@ -922,6 +924,8 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
             const lc_match_job& j = jobs[i];
             lc_regex* re = j.re;
             if (j.n == 0 || re->engine != LC_ENGINE_TDFA || !re->hasTdfa || re->tdfaBlock != block || !re->nfa.runGroups.empty()) continue;
+            static const bool pairOff = getenv("LC_TDFA_NO_PAIR") != nullptr;
+            if ((lcPairOneFormat(re->tdfaBlob) && !pairOff) != pairOne) continue;
             void* dBlob = nullptr;
             const int rc = ensureUploaded(re, dev, kBlobTdfa, &dBlob);
             if (rc != LC_OK) return rc;
@@ -962,10 +966,13 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
         }
         std::memcpy(tab.jobs, packed.data(), packed.size() * sizeof(TdfaJob));
         int rc = LC_OK;
-        switch (block) {
-            case 256: rc = launchTdfaMulti<256>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            case 128: rc = launchTdfaMulti<128>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            default: rc = launchTdfaMulti<64>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+        switch (variant) {
+            case 0: rc = launchTdfaMulti<256, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 1: rc = launchTdfaMulti<256, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 2: rc = launchTdfaMulti<128, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 3: rc = launchTdfaMulti<128, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 4: rc = launchTdfaMulti<64, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            default: rc = launchTdfaMulti<64, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
         }
         if (rc != LC_OK) return rc;
         HIP_TRY(hipEventRecord(tab.done, stream));

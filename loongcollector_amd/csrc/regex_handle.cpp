@@ -315,6 +315,33 @@ static bool lcPickTdfaBlockAndFold(lc_regex* re) {
     return fold;
 }
 
+// Round 4: the STANDARD tables (small batches: event groups, the multi-tenant launch, the fused pipeline) take the one-stamp byte-pair
+// table by default under the conditions the compact tables take it under -- a full-match pattern without general register programs,
+// at most 2 % DOUBLE entries -- and only if the workgroup size chosen without it still leaves two workgroups per CU with it.  A small
+// launch is a dependent chain of one LDS lookup per byte per line; the pair table halves the chain.  LC_TDFA_PAIR (any value) keeps
+// the round-3 behaviour (the environment decides), LC_TDFA_STD_PAIR=0 switches this default off.
+static void lcTryStandardPairTable(lc_regex* re, bool fold) {
+    static const bool off = [] {
+        const char* e = getenv("LC_TDFA_STD_PAIR");
+        return e && e[0] == '0';
+    }();
+    if (off || getenv("LC_TDFA_PAIR") || !re->tdfa.startAfter.empty() || !re->tdfaBlock) return;
+    try {
+        std::vector<uint32_t> blob = lcregex::packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold, 2);
+        const uint32_t po = blob[TD_OFF_PAIR];
+        if (!po || blob[po / 4 + TP_FORMAT] != 1) return;  // (general programs left, or the pair table is too large)
+        if (lcTdfaLdsBytes(uint32_t(blob.size() * 4), re->tdfaPackedRegs, re->tdfaBlock) > kLcLdsPerCu / 2) return;
+        const uint32_t cols = re->tdfa.nClasses + 1;
+        const uint32_t* pair = blob.data() + blob[po / 4 + TP_BASE] / 4;
+        const size_t entries = size_t(re->tdfa.nStates) * cols * cols;
+        size_t doubles = 0;
+        for (size_t i = 0; i < entries; ++i) doubles += pair[i] >> 31;
+        if (doubles * 100 > entries * 2) return;
+        re->tdfaBlob.swap(blob);
+    } catch (const lcregex::RegexError&) {
+    }
+}
+
 namespace lcregex {
 size_t tdfaBlobBytesEstimate(const TdfaTables& t) {
     auto pad = [](size_t n) { return (n + 15) & ~size_t(15); };
@@ -1449,6 +1476,7 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 const bool fold = lcPickTdfaBlockAndFold(&*re);
                 if (!re->tdfaBlock) throw RegexError("tdfa: tables + registers exceed the 160 KiB LDS of a CU");
                 re->tdfaBlob = packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold);
+                lcTryStandardPairTable(&*re, fold);
                 re->tdfaWideBlob = packTdfaWideBlob(re->tdfa, &re->tdfaWideBlock, &re->tdfaWideForced, &re->tdfaWidePackedRegs);
                 re->hasTdfa = true;
                 re->tdfaHeader = {re->tdfa.nStates, re->tdfa.nClasses, re->tdfa.nRegs, re->tdfa.nSlots,

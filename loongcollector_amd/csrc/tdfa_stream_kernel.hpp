@@ -553,7 +553,8 @@ struct TdfaJob {
     uint32_t sepBytes, nLines, blobBytes, regBytes, nGroupsOut, firstBlock;
 };
 
-template <int BLOCK, bool COMPACT>
+// PAIR1: every job of the launch carries a ONE-STAMP byte-pair table (the launcher packs jobs with and without into separate launches)
+template <int BLOCK, bool COMPACT, bool PAIR1 = false>
 __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_multi_kernel(const TdfaJob* __restrict__ jobs, uint32_t nJobs,
                                                                                         uint32_t* __restrict__ doneCounter,
                                                                                         uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_multi
         else hi = mid;
     }
     const TdfaJob j = jobs[lo];
-    tdfaStreamBody<BLOCK, COMPACT, false, 0>(j.data, j.off, j.len, j.sepBytes, 0u, j.nLines, nullptr, nullptr, nullptr, j.blob, j.blobBytes,
-                                            j.regBytes, j.nGroupsOut, j.caps, j.status, nullptr, 0u, blockIdx.x - j.firstBlock);
+    tdfaStreamBody<BLOCK, COMPACT, PAIR1, PAIR1 ? (kTdfaNoGeneralPrograms | kLabPairOne) : 0>(
+        j.data, j.off, j.len, j.sepBytes, 0u, j.nLines, nullptr, nullptr, nullptr, j.blob, j.blobBytes, j.regBytes, j.nGroupsOut, j.caps, j.status,
+        nullptr, 0u, blockIdx.x - j.firstBlock);
     tdfaSignalDone(doneCounter, doneFlag, doneSeq);
 }

@@ -66,7 +66,9 @@ def test_bench_regex_tables_are_small_enough_for_lds():
     for p in (corpus.REGEX_A, corpus.REGEX_B):
         info = B.GpuRegex(p).info()
         assert info["engine"] == B.LC_ENGINE_TDFA
-        assert info["table_bytes"] < 8192 and info["states"] < 64 and info["registers"] <= 2 * info["mark_count"] + 1
+        # (round 4: the standard tables carry the one-stamp byte-pair table -- states x (classes + 1)^2 words -- beside the 2 KB of
+        # single-byte rows)
+        assert info["table_bytes"] < 26 * 1024 and info["states"] < 64 and info["registers"] <= 2 * info["mark_count"] + 1
 
 
 @pytest.mark.parametrize("pat,code", [

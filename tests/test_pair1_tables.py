@@ -37,9 +37,14 @@ def test_default_tables_of_the_headline_regex_are_one_stamp_pair_tables():
     blob_b = rxb.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32)
     assert int(blob_b[15]) == 512 and int(blob_b[7]) != 0 and _pair1(rxb) is not None
     assert blob_b.nbytes + 33 * 512 * 2 + 8 * 64 * 64 <= 80 * 1024          # two workgroups per CU (tables + 16-bit registers + tiles)
-    # the standard tables (small batches, the in-agent shape, the multi-tenant launch) are untouched
-    std = rx.table(B.LC_TABLE_TDFA_BLOB, np.uint32)
-    assert int(std[7]) == 0
+    # the standard tables (small batches, the in-agent shape, the multi-tenant launch) carry them too since round 4, at the workgroup
+    # size they had without (two workgroups per CU: tables + 32-bit registers + padded tiles <= 80 KiB); search patterns do not
+    for r in (rx, rxb):
+        std = r.table(B.LC_TABLE_TDFA_BLOB, np.uint32)
+        po = int(std[7]) // 4
+        assert po and int(std[po + 4]) == 1 and int(std[15]) == 256
+    srch = B.GpuRegex(corpus.REGEX_A, syntax_flags=B.LC_SYNTAX_SEARCH).table(B.LC_TABLE_TDFA_BLOB, np.uint32)
+    assert int(srch[7]) == 0
 
 
 @pytest.mark.parametrize("kind", ["A", "B"])
@@ -119,3 +124,20 @@ def test_differential_fuzz_of_the_pair_tables_short():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pair1.py"), "200", "202"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("ok:"), (out.stdout[-400:], out.stderr[-1200:])
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_pair_walk_on_the_standard_tables(kind):
+    """Round 4: the STANDARD (32-bit register) tables carry the one-stamp pair table by default; the pair walk over them against the
+    single-byte walk of the same blob and the oracle, at several alignments of the line in memory."""
+    pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+    rx = B.GpuRegex(pattern)
+    p1, plain = TdfaPair1Interp(rx, compact=False), TdfaBlobInterp(rx)
+    data, off, length = corpus.apache_batch(120, kind, poison_every=7, empty_every=3)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+    for i in range(120):
+        s = bytes(data[off[i]:off[i] + length[i]])
+        want = plain.fullmatch(s)
+        assert (want is not None) == bool(exp_status[i]) and (want is None or want == [int(v) for v in exp_caps[i]])
+        for head in (0, 3, 7, 15):
+            assert p1.fullmatch_pair1(s, head=head) == want, (kind, i, head)
