@@ -200,7 +200,7 @@ public:
         } else {
             ++mContentCnt;
             mAllocatedContentSize += key.size() + val.size();
-            mContents.emplace_back(LogContent(key, val), true);
+            appendLive(key, val);
         }
     }
     // Bulk form of K x SetContentNoCopy for a caller that KNOWS none of the keys is present yet (SURVEY.md section 8(f)
@@ -211,9 +211,51 @@ public:
         mContents.reserve(mContents.size() + n);
         for (size_t i = 0; i < n; ++i, ++keys, ++vals) {
             mAllocatedContentSize += keys->size() + vals->size();
-            mContents.emplace_back(LogContent(*keys, *vals), true);
+            appendLive(*keys, *vals);
         }
         mContentCnt += n;
+    }
+    // The K fields of a parsed line in one go: value k is raw[c[2k], c[2k+1]) -- or the empty view at the end of `raw` for a group
+    // that took no part in the match (c[2k] < 0: boost's {last, last, matched = false}).  Same preconditions and the same result as
+    // AppendContentsNoCopy; the views are built in place instead of going through a caller's array.
+    // With dropKey (a key that is none of `keys`): followed by DelContent(*dropKey), whose scan from the back then starts below the new
+    // entries -- and whose one-byte tombstone store comes after the array has moved, not right before the move reads it back.
+    void AppendCapturesNoCopy(const StringView* keys, size_t n, StringView raw, const int32_t* c, const StringView* dropKey = nullptr) {
+        // (resize, then assign member by member: emplace_back(LogContent(key, val), true) builds the pair on the stack with two
+        // 8-byte stores per view and copies it with 16-byte loads -- a store-forwarding stall per field, 3x the cost of the loop)
+        const size_t old = mContents.size();
+        mContents.resize(old + n);
+        std::pair<LogContent, bool>* out = mContents.data() + old;
+        size_t bytes = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const int32_t b = c[2 * k], e = c[2 * k + 1];
+            const char* at = b < 0 ? raw.data() + raw.size() : raw.data() + b;
+            const size_t len = b < 0 ? 0 : size_t(e - b);
+            bytes += keys[k].size() + len;
+            out[k].first.first = keys[k];
+            out[k].first.second = StringView(at, len);
+            out[k].second = true;
+        }
+        size_t live = mContentCnt + n;
+        if (dropKey) {
+            std::pair<LogContent, bool>* const first = mContents.data();
+            for (std::pair<LogContent, bool>* e = first + old; e != first;) {
+                --e;
+                if (e->second && e->first.first == *dropKey) {
+                    e->second = false;
+                    --live;
+                    bytes -= e->first.first.size() + e->first.second.size();  // (modulo 2^64: the += below makes it exact)
+                    break;
+                }
+            }
+        }
+        mAllocatedContentSize += bytes;
+        mContentCnt = live;
+    }
+    // HasContent + GetContent in one scan: the live value of `key`, or nullptr (an empty value is not a missing one)
+    const StringView* FindContent(StringView key) const {
+        const auto* e = findLive(key);
+        return e ? &e->first.second : nullptr;
     }
     void DelContent(StringView key) {
         auto* e = const_cast<std::pair<LogContent, bool>*>(findLive(key));
@@ -241,6 +283,15 @@ public:
     size_t DataSize() const override { return PipelineEvent::DataSize() + sizeof(mContents) + mAllocatedContentSize; }
 
 private:
+    // emplace_back(LogContent(key, val), true) builds the pair on the stack (two 8-byte stores per view) and copies it with 16-byte
+    // loads: a store-forwarding stall per entry.  Assigning the members of a new entry does not.
+    void appendLive(StringView key, StringView val) {
+        mContents.emplace_back();
+        std::pair<LogContent, bool>& e = mContents.back();
+        e.first.first = key;
+        e.first.second = val;
+        e.second = true;
+    }
     const std::pair<LogContent, bool>* findLive(StringView key) const {
         for (auto it = mContents.crbegin(); it != mContents.crend(); ++it)
             if (it->second && it->first.first == key) return &*it;

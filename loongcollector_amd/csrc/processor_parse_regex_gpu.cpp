@@ -53,6 +53,29 @@ bool optionalString(const lcjson::Value& cfg, const std::string& key, std::strin
     }
     return true;
 }
+
+// One runner thread's scratch for Process(), reached with ONE thread-local lookup per call (a function-scope thread_local of class
+// type goes through an init-check wrapper at every use; inside the per-event loops that was measurable).
+struct ProcessScratch {
+    std::vector<uint8_t> kind, status;
+    std::vector<const uint8_t*> linePtr;
+    std::vector<uint32_t> lineLen;
+    std::vector<int32_t> caps;
+};
+
+// HasContent + GetContent (:140-150) -- one scan of the event's contents where the event model offers it
+inline bool sourceOf(const LogEvent& ev, const std::string& key, StringView& out) {
+#ifdef LC_USE_REFERENCE_HEADERS
+    if (!ev.HasContent(key)) return false;
+    out = ev.GetContent(key);
+    return true;
+#else
+    const StringView* v = ev.FindContent(key);
+    if (!v) return false;
+    out = *v;
+    return true;
+#endif
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- GpuCommonParserOptions
@@ -183,6 +206,12 @@ void ProcessorParseRegexGpu::AddLog(const StringView& key, const StringView& val
 bool ProcessorParseRegexGpu::FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess,
                                          const GroupMetadata& metadata, Tally& tally) {
     if (!parseSuccess || !mSourceKeyOverwritten) sourceEvent.DelContent(mSourceKey);
+    return FinishSourceDropped(sourceEvent, rawContent, parseSuccess, metadata, tally);
+}
+
+// :156-167, what follows the handling of the source key
+bool ProcessorParseRegexGpu::FinishSourceDropped(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess,
+                                                 const GroupMetadata& metadata, Tally& tally) {
     if (mCommonParserOptions.ShouldAddSourceContent(parseSuccess))
         AddLog(mCommonParserOptions.mRenamedSourceKey, rawContent, sourceEvent, false);
     if (mCommonParserOptions.ShouldAddLegacyUnmatchedRawLog(parseSuccess))
@@ -244,16 +273,18 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
     const size_t nEvents = events.size();
 
     enum Kind : uint8_t { Keep, Parse, WholeLine };
-    static thread_local std::vector<uint8_t> kind, status;
-    static thread_local std::vector<const uint8_t*> linePtr;
-    static thread_local std::vector<uint32_t> lineLen;
-    static thread_local std::vector<int32_t> caps;
-    kind.assign(nEvents, Keep);
+    static thread_local ProcessScratch tScratch;
+    ProcessScratch& scratch = tScratch;
+    scratch.kind.assign(nEvents, Keep);
+    scratch.linePtr.resize(nEvents);
+    scratch.lineLen.resize(nEvents);
+    uint8_t* const kind = scratch.kind.data();
+    const uint8_t** const linePtr = scratch.linePtr.data();
+    uint32_t* const lineLen = scratch.lineLen.data();
     Tally tally;
-    linePtr.clear();
-    lineLen.clear();
 
     // gather: the source values are views into the group's SourceBuffer; nothing is copied here
+    uint32_t nLines = 0;
     for (size_t i = 0; i < nEvents; ++i) {
         PipelineEventPtr& e = events[i];
         if (!IsSupportedEvent(e)) {  // :135-138
@@ -261,7 +292,8 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             continue;
         }
         LogEvent& ev = e.Cast<LogEvent>();
-        if (!ev.HasContent(mSourceKey)) {  // :140-143
+        StringView raw;
+        if (!sourceOf(ev, mSourceKey, raw)) {  // :140-143
             ++tally.keyNotFound;
             continue;
         }
@@ -269,19 +301,18 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             kind[i] = WholeLine;
             continue;
         }
-        const StringView raw = ev.GetContent(mSourceKey);
         kind[i] = Parse;
-        linePtr.push_back(reinterpret_cast<const uint8_t*>(raw.data()));
-        lineLen.push_back(uint32_t(raw.size()));
+        linePtr[nLines] = reinterpret_cast<const uint8_t*>(raw.data());
+        lineLen[nLines] = uint32_t(raw.size());
+        ++nLines;
     }
 
-    const uint32_t nLines = uint32_t(linePtr.size());
     const uint32_t G = uint32_t(mMarkCount);
     bool deviceOk = true;
     if (nLines) {
-        caps.resize(size_t(nLines) * 2 * G);
-        status.resize(nLines);
-        int rc = lc_regex_match_host_views(mReg, linePtr.data(), lineLen.data(), nLines, G, caps.data(), status.data());
+        scratch.caps.resize(size_t(nLines) * 2 * G);
+        scratch.status.resize(nLines);
+        int rc = lc_regex_match_host_views(mReg, linePtr, lineLen, nLines, G, scratch.caps.data(), scratch.status.data());
         if (rc != LC_OK) {
             // No CPU fallback exists.  Leave the events exactly as they came in (nothing is lost) and say so loudly.
             std::fprintf(stderr, "[%s] GPU match failed (rc=%d: %s); %u events left unparsed\n", sName.c_str(), rc,
@@ -292,6 +323,16 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
     }
 
     // stitch + in-place compaction (:115-124)
+    const int32_t* const caps = scratch.caps.data();
+    const uint8_t* const status = scratch.status.data();
+    const bool keyCountOk = size_t(G) + 1 > mKeys.size();  // what.size() > keys.size()  :227
+#ifndef LC_USE_REFERENCE_HEADERS
+    // no key equals the source key or another key: an event that holds the source content and nothing else takes its K fields and
+    // loses its source in one call (same contents, order and size accounting as :249-251 followed by :153-155; the scan for the
+    // source skips the K new entries, none of which can be it)
+    const bool bulk = mKeysDistinct && !mSourceKeyOverwritten;
+    const StringView sourceKey(mSourceKey);
+#endif
     size_t wIdx = 0, line = 0;
     for (size_t rIdx = 0; rIdx < nEvents; ++rIdx) {
         bool keep = true;
@@ -304,7 +345,17 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             const size_t li = line++;
             if (deviceOk) {
                 LogEvent& ev = events[rIdx].Cast<LogEvent>();
-                const StringView raw = ev.GetContent(mSourceKey);
+                const StringView raw(reinterpret_cast<const char*>(linePtr[li]), lineLen[li]);  // = ev.GetContent(mSourceKey)
+#ifndef LC_USE_REFERENCE_HEADERS
+                if (status[li] == LC_MATCH && keyCountOk && bulk && ev.Size() == 1) {
+                    ev.AppendCapturesNoCopy(mKeyViews.data(), mKeyViews.size(), raw, &caps[li * 2 * G], &sourceKey);
+                    if (FinishSourceDropped(ev, raw, true, metadata, tally)) {
+                        if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
+                        ++wIdx;
+                    }
+                    continue;
+                }
+#endif
                 bool parseSuccess = true;
                 if (status[li] == LC_OVERFLOW) {
                     // The line was NOT decided (only possible with the decide pass switched off, LC_NFA_NO_DECIDE): boost
@@ -320,7 +371,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                     RaiseAlarm(status[li] == LC_GAVE_UP ? 1 : 0, raw, logPath);
                     ++tally.outFailed;
                     parseSuccess = false;
-                } else if (size_t(G) + 1 <= mKeys.size()) {  // what.size() <= keys.size()  :227-244, no counter
+                } else if (!keyCountOk) {  // what.size() <= keys.size()  :227-244, no counter
                     RaiseAlarm(2, raw, logPath);
                     parseSuccess = false;
                 }
@@ -358,13 +409,7 @@ void ProcessorParseRegexGpu::StitchMatched(LogEvent& ev, StringView raw, const i
     if (mKeysDistinct && !mSourceKeyOverwritten && ev.Size() == 1) {
         // the event holds only the source content and no key can collide: append all K views at once
         // instead of K reverse scans (same contents, same order as the loop below)
-        static thread_local std::vector<StringView> vals;
-        vals.resize(mKeys.size());
-        for (size_t k = 0; k < mKeys.size(); ++k) {
-            const int32_t b = c[2 * k], en = c[2 * k + 1];
-            vals[k] = b < 0 ? StringView(raw.data() + raw.size(), 0) : StringView(raw.data() + b, size_t(en - b));
-        }
-        ev.AppendContentsNoCopy(mKeyViews.begin(), vals.begin(), mKeys.size());
+        ev.AppendCapturesNoCopy(mKeyViews.data(), mKeyViews.size(), raw, c);
         return;
     }
 #endif

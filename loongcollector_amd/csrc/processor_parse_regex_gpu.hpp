@@ -103,6 +103,9 @@ private:
         uint64_t discarded = 0, outFailed = 0, keyNotFound = 0, outSuccessful = 0, complexityExceeded = 0, undecided = 0;
     };
     bool FinishEvent(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata, Tally& tally);
+    // the same after the source key has been dealt with (:156-167)
+    bool FinishSourceDropped(LogEvent& sourceEvent, StringView rawContent, bool parseSuccess, const GroupMetadata& metadata,
+                             Tally& tally);
     void AddLog(const StringView& key, const StringView& value, LogEvent& targetEvent, bool overwritten = true);
     // the (key, view) pairs of one matched event: c = its 2 * mark_count capture offsets (:249-251)
     void StitchMatched(LogEvent& ev, StringView raw, const int32_t* c);

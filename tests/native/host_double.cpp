@@ -1,0 +1,222 @@
+// tests/native/host_double.cpp -- TEST INFRASTRUCTURE ONLY: the host side of processor_parse_regex_gpu on a box without a GPU.
+//
+// The processor's host work (gather -> ONE match call -> stitch + policy + compaction, csrc/processor_parse_regex_gpu.cpp, which
+// follows ProcessorParseRegexNative.cpp:108-253) only talks to the device through five C-ABI calls of include/lc_regex_gpu.h.  This
+// translation unit provides test doubles of exactly those five on top of the CPU oracle (oracle/bt_regex.h), so that
+// tests/test_processor_host_double.py can build  processor_parse_regex_gpu.cpp + event_model.cpp + this file  into
+// tests/_build/libhost_double.so and run every reference unit-test vector and the policy matrix through the PRODUCT's host
+// translation units here, where there is no device -- and time the stitch (hd_bench_stitch) without a device in the way.
+//
+// It lives under tests/, is built only by the test that uses it and is never linked into loongcollector_amd/lib: the product
+// library has no such path and fails loudly without the HIP runtime (tests/test_processor_host.py).
+#include <sys/resource.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/lc_regex_gpu.h"
+#include "../../loongcollector_amd/csrc/processor_parse_regex_gpu.hpp"
+#include "../../oracle/bt_regex.h"
+
+// ---------------------------------------------------------------------------------------------- the five doubles
+struct lc_regex {
+    orx_prog* prog = nullptr;
+    int marks = 0;
+};
+static thread_local std::string tLastError;
+static int gForceStatus = -1;  // >= 0: every line gets this status byte (LC_GAVE_UP / LC_OVERFLOW policy paths)
+static int gForceRc = 0;       // != 0: the match call fails with this code (the "device call failed" path)
+// hd_bench_stitch: the answer of the next match calls, computed beforehand (the oracle's speed must not be in the stitch figure)
+struct Precomputed {
+    const int32_t* caps = nullptr;
+    const uint8_t* status = nullptr;
+    uint32_t n = 0, ngroups = 0;
+};
+static Precomputed gPre;
+
+extern "C" int lc_regex_compile(const char* pattern, size_t n, uint32_t flags, int, lc_regex_t** out, char* err, size_t errcap) {
+    if (!pattern || !out) return LC_ERR_ARG;
+    *out = nullptr;
+    unsigned oflags = 0;
+    if (flags & LC_SYNTAX_ICASE) oflags |= ORX_ICASE;
+    orx_prog* p = orx_compile(pattern, n, oflags, err, errcap);
+    if (!p) return LC_ERR_SYNTAX;
+    auto* re = new lc_regex;
+    re->prog = p;
+    re->marks = orx_mark_count(p);
+    *out = re;
+    return LC_OK;
+}
+extern "C" void lc_regex_free(lc_regex_t* re) {
+    if (!re) return;
+    orx_free(re->prog);
+    delete re;
+}
+extern "C" int lc_regex_mark_count(const lc_regex_t* re) { return re ? re->marks : -1; }
+extern "C" const char* lc_last_error(void) { return tLastError.c_str(); }
+extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* lines, const uint32_t* len, uint32_t n, uint32_t ngroups,
+                                         int32_t* caps, uint8_t* status) {
+    if (!re || (n && (!lines || !len || !status))) return LC_ERR_ARG;
+    if (gForceRc) {
+        tLastError = "forced failure of the test double";
+        return gForceRc;
+    }
+    if (gPre.caps && n == gPre.n && ngroups == gPre.ngroups) {
+        std::memcpy(caps, gPre.caps, size_t(n) * ngroups * 2 * sizeof(int32_t));
+        std::memcpy(status, gPre.status, n);
+        return LC_OK;
+    }
+    std::vector<int32_t> what(size_t(re->marks + 1) * 2);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int r = orx_fullmatch(re->prog, lines[i], len[i], what.data());
+        status[i] = r == 1 ? LC_MATCH : r == 0 ? LC_NOMATCH : LC_GAVE_UP;
+        if (gForceStatus >= 0) status[i] = uint8_t(gForceStatus);
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            const bool have = r == 1 && int(g) < re->marks;
+            caps[(size_t(i) * ngroups + g) * 2] = have ? what[(g + 1) * 2] : -1;
+            caps[(size_t(i) * ngroups + g) * 2 + 1] = have ? what[(g + 1) * 2 + 1] : -1;
+        }
+    }
+    return LC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- what the test drives
+struct hd_processor {
+    logtail::ProcessorParseRegexGpu impl;
+    std::string alarms;  // kind \t message \n ...
+};
+
+extern "C" {
+void hd_force(int status, int rc) {
+    gForceStatus = status;
+    gForceRc = rc;
+}
+
+hd_processor* hd_create(const char* configJson, char* err, size_t errcap) {
+    auto p = std::make_unique<hd_processor>();
+    std::string error;
+    try {
+        const lcjson::Value cfg = lcjson::parse(configJson);
+        if (!p->impl.Init(cfg, error)) {
+            std::snprintf(err, errcap, "%s", error.c_str());
+            return nullptr;
+        }
+    } catch (const std::exception& e) {
+        std::snprintf(err, errcap, "%s", e.what());
+        return nullptr;
+    }
+    return p.release();
+}
+void hd_destroy(hd_processor* p) { delete p; }
+
+void hd_want_alarms(hd_processor* p) {
+    p->impl.SetAlarmSink(
+        [](void* user, int kind, const char* m, size_t n) {
+            auto* s = static_cast<std::string*>(user);
+            *s += std::to_string(kind) + "\t" + std::string(m, n) + "\n";
+        },
+        &p->alarms);
+}
+char* hd_take_alarms(hd_processor* p) {
+    char* out = strdup(p->alarms.c_str());
+    p->alarms.clear();
+    return out;
+}
+
+// fixture JSON in -> Process -> fixture JSON out (malloc'ed; hd_free).  NULL + err on a bad fixture.
+char* hd_process_json(hd_processor* p, const char* groupJson, char* err, size_t errcap) {
+    auto sb = std::make_shared<logtail::SourceBuffer>();
+    logtail::PipelineEventGroup group(sb);
+    std::string error;
+    if (!group.FromJsonString(groupJson, &error)) {
+        std::snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    p->impl.Process(group);
+    return strdup(group.ToJsonString().c_str());
+}
+void hd_free(void* p) { std::free(p); }
+
+void hd_counters(const hd_processor* p, uint64_t out[7]) {
+    out[0] = p->impl.mDiscardedEventsTotal;
+    out[1] = p->impl.mOutFailedEventsTotal;
+    out[2] = p->impl.mOutKeyNotFoundEventsTotal;
+    out[3] = p->impl.mOutSuccessfulEventsTotal;
+    out[4] = p->impl.mComplexityExceededEventsTotal;
+    out[5] = p->impl.mUndecidedEventsTotal;
+    out[6] = p->impl.mDeviceFailedEventsTotal;
+}
+
+// The host share of one in-agent group, timed without a device: `groups` groups of `n` events whose `key` content is lines[i]
+// (one copy in the group's SourceBuffer, as the file reader leaves them), Process()ed with the match call answered from a capture
+// table computed ONCE beforehand (so the oracle's speed is not in the figure).  Returns microseconds per group: gather + stitch +
+// policy + compaction -- everything Process() does except the device trip.
+}  // extern "C"
+
+static double gLastMinorFaultsPerGroup = 0;
+extern "C" double hd_last_minor_faults_per_group(void) { return gLastMinorFaultsPerGroup; }  // of the last repeat
+
+extern "C" double hd_bench_stitch(hd_processor* p, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
+                                  uint32_t groups, const char* key, uint32_t repeats, double* buildUs, double* dataSizeUs) {
+    using clk = std::chrono::steady_clock;
+    const uint32_t G = uint32_t(p->impl.MarkCount());
+    // the capture table of the n lines, once
+    std::vector<const uint8_t*> ptr(n);
+    for (uint32_t i = 0; i < n; ++i) ptr[i] = data + off[i];
+    std::vector<int32_t> caps(size_t(n) * G * 2);
+    std::vector<uint8_t> status(n);
+    lc_regex_match_host_views(const_cast<lc_regex_t*>(p->impl.Regex()), ptr.data(), len, n, G, caps.data(), status.data());
+    double best = 1e30, bestBuild = 1e30, bestSize = 1e30;
+    const size_t keyLen = std::strlen(key);
+    for (uint32_t r = 0; r < repeats; ++r) {
+        std::vector<std::unique_ptr<logtail::PipelineEventGroup>> gs;
+        std::vector<std::shared_ptr<logtail::SourceBuffer>> sbs;
+        const auto b0 = clk::now();
+        for (uint32_t g = 0; g < groups; ++g) {
+            auto sb = std::make_shared<logtail::SourceBuffer>();
+            auto grp = std::make_unique<logtail::PipelineEventGroup>(sb);
+            size_t total = 0;
+            for (uint32_t i = 0; i < n; ++i) total += size_t(len[i]) + 1;
+            logtail::StringBuffer buf = sb->AllocateStringBuffer(total);
+            const logtail::StringBuffer kb = sb->CopyString(key, keyLen);
+            size_t at = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                std::memcpy(buf.data + at, data + off[i], len[i]);
+                buf.data[at + len[i]] = '\n';
+                grp->AddLogEvent()->SetContentNoCopy(logtail::StringView(kb.data, kb.size), logtail::StringView(buf.data + at, len[i]));
+                at += size_t(len[i]) + 1;
+            }
+            sbs.push_back(sb);
+            gs.push_back(std::move(grp));
+        }
+        const auto b1 = clk::now();
+        gPre.caps = caps.data();
+        gPre.status = status.data();
+        gPre.n = n;
+        gPre.ngroups = G;
+        rusage ru0, ru1;
+        getrusage(RUSAGE_SELF, &ru0);
+        const auto t0 = clk::now();
+        for (auto& g : gs) p->impl.Process(*g);
+        const auto t1 = clk::now();
+        getrusage(RUSAGE_SELF, &ru1);
+        gLastMinorFaultsPerGroup = double(ru1.ru_minflt - ru0.ru_minflt) / groups;
+        gPre = Precomputed{};
+        size_t sink = 0;
+        const auto s0 = clk::now();
+        for (auto& g : gs) sink += g->DataSize();
+        const auto s1 = clk::now();
+        if (sink == 1) std::fprintf(stderr, " ");
+        best = std::min(best, std::chrono::duration<double, std::micro>(t1 - t0).count() / groups);
+        bestBuild = std::min(bestBuild, std::chrono::duration<double, std::micro>(b1 - b0).count() / groups);
+        bestSize = std::min(bestSize, std::chrono::duration<double, std::micro>(s1 - s0).count() / groups);
+    }
+    if (buildUs) *buildUs = bestBuild;
+    if (dataSizeUs) *dataSizeUs = bestSize;
+    return best;
+}

@@ -1,0 +1,270 @@
+"""The HOST translation units of processor_parse_regex_gpu (csrc/processor_parse_regex_gpu.cpp + csrc/event_model.cpp: gather -> one
+match call -> stitch + policy + compaction, after ProcessorParseRegexNative.cpp:108-253) on a machine without a GPU.
+
+The processor reaches the device through five C-ABI calls only; tests/native/host_double.cpp answers those five from the CPU oracle
+and is linked with the product's two source files into tests/_build/libhost_double.so -- test infrastructure, built here, never
+part of loongcollector_amd/lib (which has no such path: tests/test_processor_host.py asserts the loud failure).  What the GPU suite
+checks through the real library (tests/test_gpu_processor.py) is checked here for the host code alone, so that a change to the
+stitch or the policy is caught where it is made:
+  * every case of the reference's unit test (tests/golden/reference_unittest_vectors.json);
+  * the policy matrix (every combination of the four CommonParserOptions x key collisions x event shapes) against the processor
+    oracle -- contents, order and counters;
+  * the paths the device decides: LC_GAVE_UP (a parse failure that is counted), LC_OVERFLOW (event untouched), a failed device call
+    (group untouched, counted, loud);
+  * the one-call stitch (LogEvent::AppendCapturesNoCopy) against K x SetContentNoCopy + DelContent on the same events."""
+import ctypes
+import itertools
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as _oracle  # builds oracle/liboracle.so
+from oracle.processor_oracle import LogEventModel, ProcessorOracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LC_NOMATCH, LC_MATCH, LC_OVERFLOW, LC_GAVE_UP = 0, 1, 2, 3
+LC_ERR_HIP = 4
+
+
+@pytest.fixture(scope="module")
+def double():
+    _oracle.build() if hasattr(_oracle, "build") else None
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libhost_double.so")
+    csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "native", "host_double.cpp"), os.path.join(csrc, "processor_parse_regex_gpu.cpp"),
+            os.path.join(csrc, "event_model.cpp")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("event_model.hpp", "processor_parse_regex_gpu.hpp", "json_min.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-o", so] + srcs +
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    L = ctypes.CDLL(so)
+    vp, cp = ctypes.c_void_p, ctypes.c_char_p
+    L.hd_create.restype = vp
+    L.hd_create.argtypes = [cp, cp, ctypes.c_size_t]
+    L.hd_destroy.argtypes = [vp]
+    L.hd_process_json.restype = vp
+    L.hd_process_json.argtypes = [vp, cp, cp, ctypes.c_size_t]
+    L.hd_free.argtypes = [vp]
+    L.hd_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.hd_want_alarms.argtypes = [vp]
+    L.hd_take_alarms.restype = vp
+    L.hd_take_alarms.argtypes = [vp]
+    L.hd_force.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.hd_bench_stitch.restype = ctypes.c_double
+    L.hd_bench_stitch.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, cp, ctypes.c_uint32,
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    yield L
+    L.hd_force(-1, 0)
+
+
+class HostProcessor:
+    COUNTERS = ["discarded", "out_failed", "out_key_not_found", "out_successful", "complexity_exceeded", "undecided", "device_failed"]
+
+    def __init__(self, L, config):
+        self.L = L
+        err = ctypes.create_string_buffer(512)
+        self.h = L.hd_create(json.dumps(config).encode(), err, 512)
+        if not self.h:
+            raise ValueError(err.value.decode())
+
+    def process(self, fixture):
+        """-> per event: ordered (key, value) list, None for a non-log event"""
+        err = ctypes.create_string_buffer(512)
+        p = self.L.hd_process_json(self.h, json.dumps(fixture).encode(), err, 512)
+        assert p, err.value
+        try:
+            d = json.loads(ctypes.string_at(p).decode(), object_pairs_hook=list)
+        finally:
+            self.L.hd_free(p)
+        out = []
+        for ev in dict(d).get("events", []):
+            ev = dict(ev)
+            out.append(list(ev.get("contents", [])) if ev.get("type") == 1 else None)
+        return out
+
+    def counters(self):
+        c = (ctypes.c_uint64 * 7)()
+        self.L.hd_counters(self.h, c)
+        return dict(zip(self.COUNTERS, [int(x) for x in c]))
+
+    def alarms(self):
+        p = self.L.hd_take_alarms(self.h)
+        try:
+            text = ctypes.string_at(p)
+        finally:
+            self.L.hd_free(p)
+        return [(int(l.split(b"\t", 1)[0]), l.split(b"\t", 1)[1]) for l in text.split(b"\n") if l]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hd_destroy(self.h)
+            self.h = None
+
+
+def test_every_reference_unit_test_case_through_the_host_code(double, golden_dir):
+    with open(os.path.join(golden_dir, "reference_unittest_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    ran = 0
+    for case in cases:
+        if not case["events"]:
+            continue
+        p = HostProcessor(double, case["config"])
+        got = p.process({"events": case["events"]})
+        if "expect_contents" in case:
+            assert [dict(c) for c in got] == case["expect_contents"], case["name"]
+        c = p.counters()
+        names = {"discarded_events_total": "discarded", "out_failed_events_total": "out_failed",
+                 "out_key_not_found_events_total": "out_key_not_found", "out_successful_events_total": "out_successful"}
+        for name, want in case.get("expect_counters", {}).items():
+            if name in names:
+                assert c[names[name]] == want, (case["name"], name, c)
+        po = ProcessorOracle(case["config"])
+        out = po.process_group([LogEventModel([(k, v.encode()) for k, v in sorted(e["contents"].items())]) for e in case["events"]])
+        assert got == [[(k, v.decode()) for k, v in ev.live()] for ev in out], case["name"]
+        ran += 1
+    assert ran >= 7
+
+
+def _matrix_group(rng, lines):
+    events, models = [], []
+    for _ in range(16):
+        kind = rng.integers(0, 10)
+        if kind == 0:
+            events.append({"content": "raw", "timestamp": 1, "type": 4})
+            models.append(None)
+            continue
+        contents = []
+        if rng.integers(0, 2):
+            contents.append(["__file_offset__", "123"])
+        if kind != 1:
+            contents.append(["content", lines[int(rng.integers(0, len(lines)))]])
+        if rng.integers(0, 3) == 0:
+            contents.append(["key2", "preexisting"])
+        if rng.integers(0, 8) == 0:
+            contents.append(["_time_", "t"])
+            contents.append(["_source_", "stdout"])
+        events.append({"contents": contents, "timestamp": 1, "type": 1})
+        models.append(LogEventModel([(k, v.encode()) for k, v in contents]))
+    return events, models
+
+
+def test_policy_matrix_against_the_oracle_through_the_host_code(double):
+    rng = np.random.default_rng(23)
+    lines = ["v1\tv2", "value3\tvalue4 tail", "nomatch", "", "a\tb\nc", "x\t", "\ty", "k\tv"]
+    combos = 0
+    for keep_fail, keep_ok, coping, renamed, keys in itertools.product(
+            [False, True], [False, True], [False, True], ["", "rawLog", "content", "key2"],
+            [["key1", "key2"], ["content", "key2"], ["key1", "key2", "key3"], ["rawLog", "x"], ["key1", "key1"]]):
+        cfg = {"SourceKey": "content", "Regex": r"(\w+)\t(\w*).*", "Keys": keys, "KeepingSourceWhenParseFail": keep_fail,
+               "KeepingSourceWhenParseSucceed": keep_ok, "CopingRawLog": coping, "RenamedSourceKey": renamed}
+        events, models = _matrix_group(rng, lines)
+        p = HostProcessor(double, cfg)
+        got = p.process({"events": events, "metadata": {"log.file.offset": "__file_offset__"}})
+        po = ProcessorOracle(cfg)
+        out = po.process_group(models, file_offset_key="__file_offset__")
+        assert got == [None if ev is None else [(k, v.decode()) for k, v in ev.live()] for ev in out], cfg
+        c = p.counters()
+        assert (c["discarded"], c["out_failed"], c["out_key_not_found"], c["out_successful"]) == (
+            po.counters["discarded"], po.counters["out_failed"], po.counters["out_key_not_found"], po.counters["out_successful"]), cfg
+        combos += 1
+    assert combos == 2 * 2 * 2 * 4 * 5
+
+
+def test_unmatched_optional_group_is_an_empty_value_at_the_end_of_the_line(double):
+    p = HostProcessor(double, {"SourceKey": "content", "Regex": r"(\d+)(?: (\w+))?", "Keys": ["num", "word"]})
+    got = p.process({"events": [{"contents": {"content": "12"}, "timestamp": 1, "type": 1},
+                               {"contents": {"content": "12 ab"}, "timestamp": 1, "type": 1}]})
+    assert got == [[("num", "12"), ("word", "")], [("num", "12"), ("word", "ab")]]
+
+
+def test_alarm_texts_and_order(double):
+    lines = ["value1\tvalue2", "nomatch", "a\tb tail", "", "x"]
+    events = [{"timestamp": 1, "type": 1, "contents": {"content": l}} for l in lines]
+    p = HostProcessor(double, {"SourceKey": "content", "Regex": r"(\w+)\t(\w+).*", "Keys": ["key1", "key2"], "KeepingSourceWhenParseFail": True})
+    double.hd_want_alarms(p.h)
+    p.process({"events": events})
+    assert p.alarms() == [(0, b"errorlog:" + l.encode()) for l in lines if "\t" not in l]
+    assert p.counters()["out_failed"] == 3
+    p3 = HostProcessor(double, {"SourceKey": "content", "Regex": r"(\w+)\t(\w+).*", "Keys": ["key1", "key2", "key3"]})
+    double.hd_want_alarms(p3.h)
+    p3.process({"events": [events[0], events[2]]})
+    assert p3.alarms() == [(2, b"parse key count not match3errorlog:" + l.encode()) for l in (lines[0], lines[2])]
+    assert p3.counters()["out_failed"] == 0
+
+
+def test_what_the_device_can_answer_besides_match_and_no_match(double):
+    cfg = {"SourceKey": "content", "Regex": r"(\w+) (\w+)", "Keys": ["a", "b"], "KeepingSourceWhenParseFail": True}
+    events = [{"timestamp": 1, "type": 1, "contents": {"content": "x y"}}, {"timestamp": 1, "type": 1, "contents": {"content": "p q"}}]
+    try:
+        # the matcher gave up on the line: boost's complexity exception -> a parse failure (StringTools.cpp:200-205), counted twice over
+        double.hd_force(LC_GAVE_UP, 0)
+        p = HostProcessor(double, cfg)
+        double.hd_want_alarms(p.h)
+        assert p.process({"events": events}) == [[("content", "x y")], [("content", "p q")]]
+        c = p.counters()
+        assert (c["out_failed"], c["complexity_exceeded"], c["out_successful"]) == (2, 2, 2)
+        assert [k for k, _ in p.alarms()] == [1, 1]
+        # undecided (only with the decide pass switched off): the event goes on untouched under its own counter
+        double.hd_force(LC_OVERFLOW, 0)
+        p = HostProcessor(double, cfg)
+        assert p.process({"events": events}) == [[("content", "x y")], [("content", "p q")]]
+        c = p.counters()
+        assert (c["undecided"], c["out_failed"], c["out_successful"], c["discarded"]) == (2, 0, 0, 0)
+        # the device call failed: nothing is lost, nothing is parsed, the events are counted
+        double.hd_force(-1, LC_ERR_HIP)
+        p = HostProcessor(double, dict(cfg, KeepingSourceWhenParseFail=False))
+        assert p.process({"events": events}) == [[("content", "x y")], [("content", "p q")]]
+        c = p.counters()
+        assert (c["device_failed"], c["out_failed"], c["out_successful"], c["discarded"]) == (2, 0, 0, 0)
+    finally:
+        double.hd_force(-1, 0)
+
+
+def test_one_call_stitch_equals_the_per_key_form_on_a_large_group(double):
+    """3000 Apache lines, 2 % of them poisoned: events that hold only the source take the one-call stitch
+    (LogEvent::AppendCapturesNoCopy with the source dropped in the same call); the same lines in events that carry a second content
+    take K x SetContentNoCopy + DelContent.  Both must leave what the oracle's captures say, in Keys order."""
+    from loongcollector_amd import corpus
+    from oracle.oracle import OracleRegex
+    n = 3000
+    data, off, length = corpus.apache_batch(n, "A", poison_every=50)
+    raw = data.tobytes()
+    lines = [raw[off[i]:off[i] + length[i]].decode("latin-1") for i in range(n)]
+    caps, status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
+    for extra, keep_ok in itertools.product([False, True], [False, True]):
+        p = HostProcessor(double, {"SourceKey": "content", "Regex": corpus.REGEX_A, "Keys": corpus.KEYS_A, "KeepingSourceWhenParseFail": True,
+                                   "KeepingSourceWhenParseSucceed": keep_ok, "RenamedSourceKey": "__raw__"})
+        events = [{"contents": ([["tag", "t"]] if extra else []) + [["content", s]], "timestamp": 1, "type": 1} for s in lines]
+        got = p.process({"events": events})
+        head = [("tag", "t")] if extra else []
+        for i in range(n):
+            if status[i]:
+                want = head + [(k, lines[i][caps[i][2 * j]:caps[i][2 * j + 1]]) for j, k in enumerate(corpus.KEYS_A)]
+                if keep_ok:
+                    want.append(("__raw__", lines[i]))
+            else:
+                want = head + [("__raw__", lines[i])]
+            assert got[i] == want, (extra, keep_ok, i)
+        c = p.counters()
+        assert c["out_failed"] == n // 50 and c["out_successful"] == n
+
+
+def test_the_stitch_bench_entry_runs(double):
+    """hd_bench_stitch is what DESIGN.md's host-share figures come from (gather + stitch + policy per 1000-event group, the match call
+    answered from a table computed beforehand); here only that it runs and parses every event."""
+    from loongcollector_amd import corpus
+    data, off, length = corpus.apache_batch(1000, "A")
+    data = np.ascontiguousarray(data)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    length = np.ascontiguousarray(length, dtype=np.uint32)
+    p = HostProcessor(double, {"SourceKey": "content", "Regex": corpus.REGEX_A, "Keys": corpus.KEYS_A})
+    build, size = ctypes.c_double(), ctypes.c_double()
+    us = double.hd_bench_stitch(p.h, data.ctypes.data, off.ctypes.data, length.ctypes.data, 1000, 4, b"content", 2, ctypes.byref(build),
+                                ctypes.byref(size))
+    assert us > 0 and build.value > 0
+    assert p.counters()["out_successful"] == 2 * 4 * 1000
