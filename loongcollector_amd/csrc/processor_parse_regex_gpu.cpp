@@ -265,8 +265,11 @@ void ProcessorParseRegexGpu::RaiseAlarm(int kind, StringView buffer, StringView 
 #endif
 }
 
-void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
+void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) { Process(logGroup, nullptr); }
+
+void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup, EventBytes* eventBytes) {
     if (logGroup.GetEvents().empty()) return;
+    size_t bytesIn = 0, bytesOut = 0;  // sums of PipelineEvent::DataSize(), taken while each event is in hand anyway
     EventsContainer& events = logGroup.MutableEvents();
     const GroupMetadata& metadata = logGroup.GetAllMetadata();
     const StringView logPath = logGroup.GetMetadata(EventGroupMetaKey::LOG_FILE_PATH_RESOLVED);  // :110
@@ -289,9 +292,11 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
         PipelineEventPtr& e = events[i];
         if (!IsSupportedEvent(e)) {  // :135-138
             ++tally.outFailed;
+            if (eventBytes) bytesIn += e->DataSize();
             continue;
         }
         LogEvent& ev = e.Cast<LogEvent>();
+        if (eventBytes) bytesIn += ev.LogEvent::DataSize();
         StringView raw;
         if (!sourceOf(ev, mSourceKey, raw)) {  // :140-143
             ++tally.keyNotFound;
@@ -350,6 +355,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                 if (status[li] == LC_MATCH && keyCountOk && bulk && ev.Size() == 1) {
                     ev.AppendCapturesNoCopy(mKeyViews.data(), mKeyViews.size(), raw, &caps[li * 2 * G], &sourceKey);
                     if (FinishSourceDropped(ev, raw, true, metadata, tally)) {
+                        if (eventBytes) bytesOut += ev.LogEvent::DataSize();
                         if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
                         ++wIdx;
                     }
@@ -362,6 +368,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
                     // might match it, so it is neither a success nor a parse failure.  The event goes on untouched and is
                     // counted under its own counter.
                     ++tally.undecided;
+                    if (eventBytes) bytesOut += ev.LogEvent::DataSize();
                     if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
                     ++wIdx;
                     continue;
@@ -380,11 +387,16 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) {
             }
         }
         if (keep) {
+            if (eventBytes) bytesOut += events[rIdx]->DataSize();
             if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
             ++wIdx;
         }
     }
     events.resize(wIdx);
+    if (eventBytes) {
+        eventBytes->in = bytesIn;
+        eventBytes->out = bytesOut;
+    }
     AddTally(tally);
 }
 

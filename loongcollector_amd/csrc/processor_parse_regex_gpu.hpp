@@ -60,6 +60,13 @@ public:
     // Returns false with `error` set exactly where the reference's Init returns false.
     bool Init(const lcjson::Value& config, std::string& error);
     void Process(PipelineEventGroup& logGroup);
+    // The same, and the sum of the events' DataSize() before and after -- the part of ProcessorInstance's in/out_size_bytes
+    // (ProcessorInstance.cpp:46-63) that costs a walk over every event; here each event is measured while the gather / the stitch
+    // has it in hand (two extra passes over a 1000-event group are 9 us of its ~60 us of host work).
+    struct EventBytes {
+        size_t in = 0, out = 0;
+    };
+    void Process(PipelineEventGroup& logGroup, EventBytes* eventBytes);
 
     std::string mSourceKey;
     std::string mRegex;

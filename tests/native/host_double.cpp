@@ -89,6 +89,7 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
 struct hd_processor {
     logtail::ProcessorParseRegexGpu impl;
     std::string alarms;  // kind \t message \n ...
+    uint64_t sizes[4] = {0, 0, 0, 0};
 };
 
 extern "C" {
@@ -137,8 +138,17 @@ char* hd_process_json(hd_processor* p, const char* groupJson, char* err, size_t 
         std::snprintf(err, errcap, "%s", error.c_str());
         return nullptr;
     }
-    p->impl.Process(group);
+    // (the sizes lc_processor_process reports as in/out_size_bytes come from the processor's own sums: checked against the walks)
+    logtail::ProcessorParseRegexGpu::EventBytes bytes;
+    p->sizes[0] = group.DataSize();
+    p->impl.Process(group, &bytes);
+    p->sizes[1] = group.DataSize();
+    p->sizes[2] = group.DataSizeWithoutEvents() + bytes.in;
+    p->sizes[3] = group.DataSizeWithoutEvents() + bytes.out;
     return strdup(group.ToJsonString().c_str());
+}
+void hd_last_sizes(const hd_processor* p, uint64_t out[4]) {  // DataSize() before, after; the processor's sums for the same two
+    for (int i = 0; i < 4; ++i) out[i] = p->sizes[i];
 }
 void hd_free(void* p) { std::free(p); }
 
@@ -155,7 +165,8 @@ void hd_counters(const hd_processor* p, uint64_t out[7]) {
 // The host share of one in-agent group, timed without a device: `groups` groups of `n` events whose `key` content is lines[i]
 // (one copy in the group's SourceBuffer, as the file reader leaves them), Process()ed with the match call answered from a capture
 // table computed ONCE beforehand (so the oracle's speed is not in the figure).  Returns microseconds per group: gather + stitch +
-// policy + compaction -- everything Process() does except the device trip.
+// policy + compaction + the in/out size sums -- everything lc_processor_process does except the device trip.  *dataSizeUs: one
+// PipelineEventGroup::DataSize() walk over a processed group (what the size sums cost as passes of their own, twice per group).
 }  // extern "C"
 
 static double gLastMinorFaultsPerGroup = 0;
@@ -202,8 +213,14 @@ extern "C" double hd_bench_stitch(hd_processor* p, const uint8_t* data, const ui
         rusage ru0, ru1;
         getrusage(RUSAGE_SELF, &ru0);
         const auto t0 = clk::now();
-        for (auto& g : gs) p->impl.Process(*g);
+        size_t sizeSink = 0;
+        for (auto& g : gs) {  // what lc_processor_process does around the device trip (csrc/c_processor_slot.cpp processGroup)
+            logtail::ProcessorParseRegexGpu::EventBytes bytes;
+            p->impl.Process(*g, &bytes);
+            sizeSink += g->DataSizeWithoutEvents() * 2 + bytes.in + bytes.out;
+        }
         const auto t1 = clk::now();
+        if (sizeSink == 1) std::fprintf(stderr, " ");
         getrusage(RUSAGE_SELF, &ru1);
         gLastMinorFaultsPerGroup = double(ru1.ru_minflt - ru0.ru_minflt) / groups;
         gPre = Precomputed{};

@@ -55,6 +55,7 @@ def double():
     L.hd_take_alarms.restype = vp
     L.hd_take_alarms.argtypes = [vp]
     L.hd_force.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.hd_last_sizes.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.hd_bench_stitch.restype = ctypes.c_double
     L.hd_bench_stitch.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, cp, ctypes.c_uint32,
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -81,6 +82,11 @@ class HostProcessor:
             d = json.loads(ctypes.string_at(p).decode(), object_pairs_hook=list)
         finally:
             self.L.hd_free(p)
+        # in/out_size_bytes: the processor's running sums are PipelineEventGroup::DataSize() before and after (ProcessorInstance.cpp:46-63)
+        sizes = (ctypes.c_uint64 * 4)()
+        self.L.hd_last_sizes(self.h, sizes)
+        assert (sizes[2], sizes[3]) == (sizes[0], sizes[1]), list(sizes)
+        self.last_sizes = (int(sizes[0]), int(sizes[1]))
         out = []
         for ev in dict(d).get("events", []):
             ev = dict(ev)
