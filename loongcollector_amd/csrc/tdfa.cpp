@@ -5,6 +5,7 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <map>
 #include <string>
@@ -161,6 +162,14 @@ std::vector<Cand> commitAtomic(std::vector<Cand> cands, uint32_t holds) {
             }
             out.push_back(std::move(c));
         }
+    }
+    {  // Nobody holds a membership (a pattern whose events are assertions only, or a step outside every atomic group): positions
+       // are unique after the pass above, `mirrors` needs two survivors on one position and `familyMirror` a segment to rename --
+       // there is nothing for the pair loop to find, and on an automaton of tens of thousands of states its n^2 tests per step were
+       // what exhausted maxCommitWork ("too many concurrent alternatives" for SYSLOGLINE, which has no atomic group left at all).
+        bool anyMembership = false;
+        for (const auto& c : out) anyMembership |= !c.lin.empty();
+        if (!anyMembership) return out;
     }
     auto holds_ = [](const Cand& c, const LinEntry& e, bool insideOnly) {
         ++tlsCommitWork;
@@ -539,7 +548,26 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     const uint32_t maxStates =
         limits.ldsWindow ? std::min<uint32_t>(limits.maxStates, (65536u - 320u) / (uint32_t(ncls + 1) * 4u)) : limits.maxStates;
     std::vector<State> states;
-    std::unordered_map<std::string, uint32_t> index;
+    // (keys are tens of kilobytes for the automata that take long: eight bytes per multiply instead of std::hash's one per step.
+    // The map is only ever looked up, never walked: the numbering of the states does not depend on the hash.)
+    struct KeyHash {
+        size_t operator()(const std::string& k) const {
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t(k.size()) * 0xD6E8FEB86659FD93ull);
+            const char* p = k.data();
+            size_t n = k.size();
+            for (; n >= 8; n -= 8, p += 8) {
+                uint64_t w;
+                std::memcpy(&w, p, 8);
+                h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+                h ^= h >> 29;
+            }
+            uint64_t w = 0;
+            if (n) std::memcpy(&w, p, n);
+            h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+            return size_t(h ^ (h >> 32));
+        }
+    };
+    std::unordered_map<std::string, uint32_t, KeyHash> index;
     std::deque<uint32_t> work;
     states.emplace_back();  // state 0 = dead
     auto intern = [&](State&& s) -> uint32_t {
@@ -594,6 +622,169 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
                 fprintf(stderr, "tdfa pathWork %llu commitWork %llu\n", (unsigned long long)w, (unsigned long long)tlsCommitWork);
         }
     } workReport{pathWork};
+    // ---- Patterns without atomic groups (every one whose groups the elision pass removed, and most others): the step of one
+    // (state, byte class) without the general machinery.  No memberships: the survivors are the first path per target position, in
+    // priority order, that consumes the byte and whose assertions hold; nothing to commit, nothing to collapse.  Same states, same
+    // numbering, same register programs as the general loop below (which patterns with atomic groups still take) -- 98 % of the
+    // steps of a large automaton land on a state that exists already, and this path finds that out from a key assembled in a reused
+    // buffer, without building the State: no map, no vector, no allocation per step.  (An anchored Grok format of 30 000 states:
+    // 10 s -> 2.6 s of construction.)
+    const bool atomicPattern = nfa.atomicCount > 0;
+    std::vector<uint32_t> viableStart, viablePath;  // per (position, class): the follow paths whose target takes the class
+    if (!atomicPattern) {
+        viableStart.reserve((size_t(npos) + 1) * size_t(ncls) + 1);
+        for (int p = 0; p <= npos; ++p)
+            for (int c = 0; c < ncls; ++c) {
+                viableStart.push_back(uint32_t(viablePath.size()));
+                const auto& lst = nfa.follow[size_t(p)];
+                for (size_t i = 0; i < lst.size(); ++i)
+                    if (lst[i].target >= 0 && nfa.positions[size_t(lst[i].target)].has(classRep[size_t(c)])) viablePath.push_back(uint32_t(i));
+            }
+        viableStart.push_back(uint32_t(viablePath.size()));
+    }
+    struct Survivor {
+        int pos, src;
+        const TagSet* tags;
+    };
+    std::vector<Survivor> survivors;
+    std::vector<int> newRegs;                       // survivors x slots
+    std::vector<int> oldToNew(size_t(kMaxTdfaRegs) + 8, -1), freshToNew(size_t(nslots) + 1, -1);
+    std::vector<int> oldTouched, freshTouched;
+    std::vector<std::pair<int, int>> regMovesBuf;
+    std::vector<int> posDstsBuf;
+    std::string keyBuf;
+    while (!atomicPattern && !work.empty()) {
+        const uint32_t sid = work.front();
+        work.pop_front();
+        std::vector<uint32_t> row(size_t(ncls), 0u);
+        for (int c = 0; c < ncls; ++c) {
+            const unsigned b = classRep[size_t(c)];
+            const uint32_t holds = states[sid].prevCtx | nfa.aheadBits(int(b));
+            ++seenStamp;
+            survivors.clear();
+            {
+                const State& S = states[sid];
+                for (size_t k = 0; k < S.items.size(); ++k) {
+                    const size_t p = size_t(S.items[k].pos);
+                    const auto& lst = nfa.follow[p];
+                    pathWork += lst.size();
+                    const size_t v0 = viableStart[p * size_t(ncls) + size_t(c)], v1 = viableStart[p * size_t(ncls) + size_t(c) + 1];
+                    for (size_t v = v0; v < v1; ++v) {
+                        const FollowPath& path = lst[viablePath[v]];
+                        if (path.cond & ~holds) continue;
+                        if (targetSeen[size_t(path.target)] == seenStamp) continue;
+                        targetSeen[size_t(path.target)] = seenStamp;
+                        survivors.push_back({path.target, int(k), &path.tags});
+                    }
+                }
+            }
+            if (pathWork > limits.maxPathWork)
+                throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
+            if (survivors.empty()) continue;  // -> dead
+            // registers of the target state: canonical names by first appearance (items in order, slots in order)
+            for (int r : oldTouched) oldToNew[size_t(r)] = -1;
+            for (int sl : freshTouched) freshToNew[size_t(sl)] = -1;
+            oldTouched.clear();
+            freshTouched.clear();
+            int nNew = 0;
+            uint32_t needMask = 0;
+            newRegs.resize(survivors.size() * size_t(nslots));
+            {
+                const State& S = states[sid];
+                for (size_t i = 0; i < survivors.size(); ++i) {
+                    const Survivor& n = survivors[i];
+                    const std::vector<int>& srcRegs = S.items[size_t(n.src)].regs;
+                    int* out = newRegs.data() + i * size_t(nslots);
+                    for (int sl = 0; sl < nslots; ++sl) {
+                        if (n.tags->test(sl)) {
+                            int& m = freshToNew[size_t(sl)];
+                            if (m < 0) {
+                                m = nNew++;
+                                freshTouched.push_back(sl);
+                            }
+                            out[sl] = m;
+                        } else {
+                            const int raw = srcRegs[size_t(sl)];
+                            if (raw < 0) {
+                                out[sl] = -1;
+                                continue;
+                            }
+                            int& m = oldToNew[size_t(raw)];
+                            if (m < 0) {
+                                m = nNew++;
+                                oldTouched.push_back(raw);
+                            }
+                            out[sl] = m;
+                        }
+                    }
+                    needMask |= need[size_t(n.pos)];
+                }
+            }
+            if (nNew > kMaxTdfaRegs) throw RegexError("tdfa: register limit exceeded");
+            maxRegs = std::max(maxRegs, nNew);
+            const uint32_t prevCtx = nfa.behindBits(int(b)) & needMask;
+            // the register program of the step: old registers in ascending order of their old names, then the fresh stamps in slot
+            // order (the order std::map gave the general loop)
+            regMovesBuf.clear();
+            posDstsBuf.clear();
+            std::sort(oldTouched.begin(), oldTouched.end());
+            for (int r : oldTouched)
+                if (oldToNew[size_t(r)] != r) regMovesBuf.emplace_back(oldToNew[size_t(r)], r);
+            std::sort(freshTouched.begin(), freshTouched.end());
+            for (int sl : freshTouched) posDstsBuf.push_back(freshToNew[size_t(sl)]);
+            uint32_t listId = 0;
+            if (!regMovesBuf.empty() || !posDstsBuf.empty()) {
+                std::vector<uint16_t> sched = scheduleMoves(regMovesBuf, posDstsBuf);
+                for (uint16_t w : sched)
+                    if ((w & 0xFF) == kRegTmp || (w >> 8) == kRegTmp) usedTmp = true;
+                auto it = opListIds.find(sched);
+                if (it == opListIds.end()) {
+                    if (opLists.size() >= 0xFFFF) throw RegexError("tdfa: too many distinct register programs");
+                    it = opListIds.emplace(sched, uint32_t(opLists.size())).first;
+                    opLists.push_back(sched);
+                }
+                listId = it->second;
+            }
+            // the target state: looked up by the key keyOf() would give it
+            {
+                const size_t perItem = sizeof(int) + size_t(nslots) * sizeof(int16_t) + 1;
+                keyBuf.resize(sizeof prevCtx + survivors.size() * perItem);
+                char* k = &keyBuf[0];
+                std::memcpy(k, &prevCtx, sizeof prevCtx);
+                k += sizeof prevCtx;
+                for (size_t i = 0; i < survivors.size(); ++i) {
+                    std::memcpy(k, &survivors[i].pos, sizeof(int));
+                    k += sizeof(int);
+                    const int* regs = newRegs.data() + i * size_t(nslots);
+                    for (int sl = 0; sl < nslots; ++sl) {
+                        const int16_t v = int16_t(regs[sl]);
+                        std::memcpy(k, &v, sizeof v);
+                        k += sizeof v;
+                    }
+                    *k++ = '|';
+                }
+            }
+            uint32_t tid;
+            auto known = index.find(keyBuf);
+            if (known != index.end()) {
+                tid = known->second;
+            } else {
+                State Tn;
+                Tn.items.resize(survivors.size());
+                for (size_t i = 0; i < survivors.size(); ++i) {
+                    Tn.items[i].pos = survivors[i].pos;
+                    Tn.items[i].regs.assign(newRegs.begin() + long(i * size_t(nslots)), newRegs.begin() + long((i + 1) * size_t(nslots)));
+                }
+                Tn.nregs = nNew;
+                Tn.prevCtx = prevCtx;
+                tid = intern(std::move(Tn));
+            }
+            if (tid > 0xFFFF) throw RegexError("tdfa: state limit exceeded");
+            row[size_t(c)] = tid | (listId << 16);
+        }
+        if (transRows.size() <= sid) transRows.resize(sid + 1);
+        transRows[sid] = std::move(row);
+    }
     while (!work.empty()) {
         uint32_t sid = work.front();
         work.pop_front();
