@@ -1501,7 +1501,8 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             lim.maxStates = l2States;
                             lim.ldsWindow = false;
                             // (an anchored search is compiled because its automaton is wanted: it may cost seconds)
-                            lim.maxPathWork = anchoredSearch ? (32u << 20) : (4u << 20);
+                            // (80 M: the anchored Grok formats of configs[2] that build at all need 24-69 M path steps and 2-5 s)
+                            lim.maxPathWork = anchoredSearch ? (80u << 20) : (4u << 20);
                             if (anchoredSearch) lim.maxStates = std::max<uint32_t>(lim.maxStates, 60000);
                             if (const char* v = getenv("LC_TDFA_L2_MAX_WORK")) lim.maxPathWork = uint64_t(atoll(v));
                             if (const char* v = getenv("LC_TDFA_L2_MAX_COMMIT")) lim.maxCommitWork = uint64_t(atoll(v));

@@ -16,7 +16,6 @@ namespace lcregex {
 namespace {
 
 constexpr uint8_t kRegTmp = 0xFD;  // placeholder, patched to the real scratch register at the end
-constexpr int kFreshBase = 1 << 20;
 
 // Atomic groups.  Every thread that entered atomic-group instance g through the same source thread at the same step
 // belongs to one SEGMENT; the first (highest-priority) member that leaves g commits the group for that entry: every
@@ -645,6 +644,7 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     struct Survivor {
         int pos, src;
         const TagSet* tags;
+        const std::vector<LinEntry>* lin;  // unsettled memberships (patterns with atomic groups), or nullptr
     };
     std::vector<Survivor> survivors;
     std::vector<int> newRegs;                       // survivors x slots
@@ -653,6 +653,131 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
     std::vector<std::pair<int, int>> regMovesBuf;
     std::vector<int> posDstsBuf;
     std::string keyBuf;
+    // the step's target state and register program from `survivors` (priority order) -> the transition word
+    std::vector<int> segNames;
+    auto emitTransition = [&](uint32_t sid, unsigned b) -> uint32_t {
+        // registers of the target state: canonical names by first appearance (items in order, slots in order)
+        for (int r : oldTouched) oldToNew[size_t(r)] = -1;
+        for (int sl : freshTouched) freshToNew[size_t(sl)] = -1;
+        oldTouched.clear();
+        freshTouched.clear();
+        int nNew = 0;
+        uint32_t needMask = 0;
+        newRegs.resize(survivors.size() * size_t(nslots));
+        {
+            const State& S = states[sid];
+            for (size_t i = 0; i < survivors.size(); ++i) {
+                const Survivor& n = survivors[i];
+                const std::vector<int>& srcRegs = S.items[size_t(n.src)].regs;
+                int* out = newRegs.data() + i * size_t(nslots);
+                for (int sl = 0; sl < nslots; ++sl) {
+                    if (n.tags->test(sl)) {
+                        int& m = freshToNew[size_t(sl)];
+                        if (m < 0) {
+                            m = nNew++;
+                            freshTouched.push_back(sl);
+                        }
+                        out[sl] = m;
+                    } else {
+                        const int raw = srcRegs[size_t(sl)];
+                        if (raw < 0) {
+                            out[sl] = -1;
+                            continue;
+                        }
+                        int& m = oldToNew[size_t(raw)];
+                        if (m < 0) {
+                            m = nNew++;
+                            oldTouched.push_back(raw);
+                        }
+                        out[sl] = m;
+                    }
+                }
+                needMask |= need[size_t(n.pos)];
+            }
+        }
+        if (nNew > kMaxTdfaRegs) throw RegexError("tdfa: register limit exceeded");
+        maxRegs = std::max(maxRegs, nNew);
+        const uint32_t prevCtx = nfa.behindBits(int(b)) & needMask;
+        // the register program of the step: old registers in ascending order of their old names, then the fresh stamps in slot
+        // order (the order std::map gave the general loop)
+        regMovesBuf.clear();
+        posDstsBuf.clear();
+        std::sort(oldTouched.begin(), oldTouched.end());
+        for (int r : oldTouched)
+            if (oldToNew[size_t(r)] != r) regMovesBuf.emplace_back(oldToNew[size_t(r)], r);
+        std::sort(freshTouched.begin(), freshTouched.end());
+        for (int sl : freshTouched) posDstsBuf.push_back(freshToNew[size_t(sl)]);
+        uint32_t listId = 0;
+        if (!regMovesBuf.empty() || !posDstsBuf.empty()) {
+            std::vector<uint16_t> sched = scheduleMoves(regMovesBuf, posDstsBuf);
+            for (uint16_t w : sched)
+                if ((w & 0xFF) == kRegTmp || (w >> 8) == kRegTmp) usedTmp = true;
+            auto it = opListIds.find(sched);
+            if (it == opListIds.end()) {
+                if (opLists.size() >= 0xFFFF) throw RegexError("tdfa: too many distinct register programs");
+                it = opListIds.emplace(sched, uint32_t(opLists.size())).first;
+                opLists.push_back(sched);
+            }
+            listId = it->second;
+        }
+        // the target state: looked up by the key keyOf() would give it
+        {
+            const size_t perItem = sizeof(int) + size_t(nslots) * sizeof(int16_t) + 1;
+            size_t linEntries = 0;
+            segNames.clear();
+            for (const Survivor& n : survivors)
+                if (n.lin) linEntries += n.lin->size();
+            keyBuf.resize(sizeof prevCtx + survivors.size() * perItem + linEntries * 3 * sizeof(int32_t));
+            char* k = &keyBuf[0];
+            std::memcpy(k, &prevCtx, sizeof prevCtx);
+            k += sizeof prevCtx;
+            for (size_t i = 0; i < survivors.size(); ++i) {
+                std::memcpy(k, &survivors[i].pos, sizeof(int));
+                k += sizeof(int);
+                const int* regs = newRegs.data() + i * size_t(nslots);
+                for (int sl = 0; sl < nslots; ++sl) {
+                    const int16_t v = int16_t(regs[sl]);
+                    std::memcpy(k, &v, sizeof v);
+                    k += sizeof v;
+                }
+                if (survivors[i].lin)
+                    for (const LinEntry& e : *survivors[i].lin) {  // segment ids are state-local names: canonical by first appearance
+                        size_t name = 0;
+                        while (name < segNames.size() && segNames[name] != e.seg) ++name;
+                        if (name == segNames.size()) segNames.push_back(e.seg);
+                        const int32_t v[3] = {e.g, int32_t(name), e.exited ? 1 : 0};
+                        std::memcpy(k, v, sizeof v);
+                        k += sizeof v;
+                    }
+                *k++ = '|';
+            }
+        }
+        uint32_t tid;
+        auto known = index.find(keyBuf);
+        if (known != index.end()) {
+            tid = known->second;
+        } else {
+            State Tn;
+            Tn.items.resize(survivors.size());
+            for (size_t i = 0; i < survivors.size(); ++i) {
+                Tn.items[i].pos = survivors[i].pos;
+                Tn.items[i].regs.assign(newRegs.begin() + long(i * size_t(nslots)), newRegs.begin() + long((i + 1) * size_t(nslots)));
+                if (survivors[i].lin) {
+                    Tn.items[i].lin = *survivors[i].lin;
+                    for (LinEntry& e : Tn.items[i].lin) {
+                        size_t name = 0;
+                        while (segNames[name] != e.seg) ++name;
+                        e.seg = int(name);
+                    }
+                }
+            }
+            Tn.nregs = nNew;
+            Tn.prevCtx = prevCtx;
+            tid = intern(std::move(Tn));
+        }
+        if (tid > 0xFFFF) throw RegexError("tdfa: state limit exceeded");
+        return tid | (listId << 16);
+    };
     while (!atomicPattern && !work.empty()) {
         const uint32_t sid = work.front();
         work.pop_front();
@@ -674,113 +799,14 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
                         if (path.cond & ~holds) continue;
                         if (targetSeen[size_t(path.target)] == seenStamp) continue;
                         targetSeen[size_t(path.target)] = seenStamp;
-                        survivors.push_back({path.target, int(k), &path.tags});
+                        survivors.push_back({path.target, int(k), &path.tags, nullptr});
                     }
                 }
             }
             if (pathWork > limits.maxPathWork)
                 throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
             if (survivors.empty()) continue;  // -> dead
-            // registers of the target state: canonical names by first appearance (items in order, slots in order)
-            for (int r : oldTouched) oldToNew[size_t(r)] = -1;
-            for (int sl : freshTouched) freshToNew[size_t(sl)] = -1;
-            oldTouched.clear();
-            freshTouched.clear();
-            int nNew = 0;
-            uint32_t needMask = 0;
-            newRegs.resize(survivors.size() * size_t(nslots));
-            {
-                const State& S = states[sid];
-                for (size_t i = 0; i < survivors.size(); ++i) {
-                    const Survivor& n = survivors[i];
-                    const std::vector<int>& srcRegs = S.items[size_t(n.src)].regs;
-                    int* out = newRegs.data() + i * size_t(nslots);
-                    for (int sl = 0; sl < nslots; ++sl) {
-                        if (n.tags->test(sl)) {
-                            int& m = freshToNew[size_t(sl)];
-                            if (m < 0) {
-                                m = nNew++;
-                                freshTouched.push_back(sl);
-                            }
-                            out[sl] = m;
-                        } else {
-                            const int raw = srcRegs[size_t(sl)];
-                            if (raw < 0) {
-                                out[sl] = -1;
-                                continue;
-                            }
-                            int& m = oldToNew[size_t(raw)];
-                            if (m < 0) {
-                                m = nNew++;
-                                oldTouched.push_back(raw);
-                            }
-                            out[sl] = m;
-                        }
-                    }
-                    needMask |= need[size_t(n.pos)];
-                }
-            }
-            if (nNew > kMaxTdfaRegs) throw RegexError("tdfa: register limit exceeded");
-            maxRegs = std::max(maxRegs, nNew);
-            const uint32_t prevCtx = nfa.behindBits(int(b)) & needMask;
-            // the register program of the step: old registers in ascending order of their old names, then the fresh stamps in slot
-            // order (the order std::map gave the general loop)
-            regMovesBuf.clear();
-            posDstsBuf.clear();
-            std::sort(oldTouched.begin(), oldTouched.end());
-            for (int r : oldTouched)
-                if (oldToNew[size_t(r)] != r) regMovesBuf.emplace_back(oldToNew[size_t(r)], r);
-            std::sort(freshTouched.begin(), freshTouched.end());
-            for (int sl : freshTouched) posDstsBuf.push_back(freshToNew[size_t(sl)]);
-            uint32_t listId = 0;
-            if (!regMovesBuf.empty() || !posDstsBuf.empty()) {
-                std::vector<uint16_t> sched = scheduleMoves(regMovesBuf, posDstsBuf);
-                for (uint16_t w : sched)
-                    if ((w & 0xFF) == kRegTmp || (w >> 8) == kRegTmp) usedTmp = true;
-                auto it = opListIds.find(sched);
-                if (it == opListIds.end()) {
-                    if (opLists.size() >= 0xFFFF) throw RegexError("tdfa: too many distinct register programs");
-                    it = opListIds.emplace(sched, uint32_t(opLists.size())).first;
-                    opLists.push_back(sched);
-                }
-                listId = it->second;
-            }
-            // the target state: looked up by the key keyOf() would give it
-            {
-                const size_t perItem = sizeof(int) + size_t(nslots) * sizeof(int16_t) + 1;
-                keyBuf.resize(sizeof prevCtx + survivors.size() * perItem);
-                char* k = &keyBuf[0];
-                std::memcpy(k, &prevCtx, sizeof prevCtx);
-                k += sizeof prevCtx;
-                for (size_t i = 0; i < survivors.size(); ++i) {
-                    std::memcpy(k, &survivors[i].pos, sizeof(int));
-                    k += sizeof(int);
-                    const int* regs = newRegs.data() + i * size_t(nslots);
-                    for (int sl = 0; sl < nslots; ++sl) {
-                        const int16_t v = int16_t(regs[sl]);
-                        std::memcpy(k, &v, sizeof v);
-                        k += sizeof v;
-                    }
-                    *k++ = '|';
-                }
-            }
-            uint32_t tid;
-            auto known = index.find(keyBuf);
-            if (known != index.end()) {
-                tid = known->second;
-            } else {
-                State Tn;
-                Tn.items.resize(survivors.size());
-                for (size_t i = 0; i < survivors.size(); ++i) {
-                    Tn.items[i].pos = survivors[i].pos;
-                    Tn.items[i].regs.assign(newRegs.begin() + long(i * size_t(nslots)), newRegs.begin() + long((i + 1) * size_t(nslots)));
-                }
-                Tn.nregs = nNew;
-                Tn.prevCtx = prevCtx;
-                tid = intern(std::move(Tn));
-            }
-            if (tid > 0xFFFF) throw RegexError("tdfa: state limit exceeded");
-            row[size_t(c)] = tid | (listId << 16);
+            row[size_t(c)] = emitTransition(sid, b);
         }
         if (transRows.size() <= sid) transRows.resize(sid + 1);
         transRows[sid] = std::move(row);
@@ -806,6 +832,10 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
                         if (targetSeen[size_t(path.target)] == seenStamp) continue;
                         targetSeen[size_t(path.target)] = seenStamp;
                     }
+                    // (a path that cannot consume the byte, crosses no group border or assertion and comes from an item without
+                    // memberships closes nothing, opens nothing and is dropped at the end of commitAtomic: most paths of a large
+                    // pattern, not worth a candidate)
+                    if (!targetOk && path.atoms.empty() && S.items[k].lin.empty()) continue;
                     cands.push_back(Cand{path.target, int(k), path.tags, S.items[k].lin,
                                          atomic ? &path.atoms : nullptr, targetOk, path.cond});
                 }
@@ -814,60 +844,9 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
                 throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
             std::vector<Cand> ni = commitAtomic(std::move(cands), holds);
             if (ni.empty()) continue;  // -> dead
-            State Tn;
-            std::map<int, int> rename;
-            std::map<int, int> segRename;  // segment ids are state-local names: canonical by first appearance
-            uint32_t needMask = 0;
-            for (const auto& n : ni) {
-                Item it;
-                it.pos = n.pos;
-                it.lin = n.lin;
-                for (auto& e : it.lin) {
-                    auto r = segRename.find(e.seg);
-                    if (r == segRename.end()) r = segRename.emplace(e.seg, int(segRename.size())).first;
-                    e.seg = r->second;
-                }
-                it.regs.resize(size_t(nslots));
-                for (int s = 0; s < nslots; ++s) {
-                    int raw = n.tags.test(s) ? kFreshBase + s : S.items[size_t(n.src)].regs[size_t(s)];
-                    if (raw < 0) {
-                        it.regs[size_t(s)] = -1;
-                        continue;
-                    }
-                    auto r = rename.find(raw);
-                    if (r == rename.end()) r = rename.emplace(raw, int(rename.size())).first;
-                    it.regs[size_t(s)] = r->second;
-                }
-                needMask |= need[size_t(n.pos)];
-                Tn.items.push_back(std::move(it));
-            }
-            Tn.nregs = int(rename.size());
-            if (Tn.nregs > kMaxTdfaRegs) throw RegexError("tdfa: register limit exceeded");
-            maxRegs = std::max(maxRegs, Tn.nregs);
-            Tn.prevCtx = nfa.behindBits(int(b)) & needMask;
-
-            std::vector<std::pair<int, int>> regMoves;
-            std::vector<int> posDsts;
-            for (const auto& kv : rename) {
-                if (kv.first >= kFreshBase) posDsts.push_back(kv.second);
-                else if (kv.first != kv.second) regMoves.emplace_back(kv.second, kv.first);
-            }
-            std::vector<uint16_t> sched = scheduleMoves(std::move(regMoves), posDsts);
-            uint32_t listId = 0;
-            if (!sched.empty()) {
-                for (uint16_t w : sched)
-                    if ((w & 0xFF) == kRegTmp || (w >> 8) == kRegTmp) usedTmp = true;
-                auto it = opListIds.find(sched);
-                if (it == opListIds.end()) {
-                    if (opLists.size() >= 0xFFFF) throw RegexError("tdfa: too many distinct register programs");
-                    it = opListIds.emplace(sched, uint32_t(opLists.size())).first;
-                    opLists.push_back(sched);
-                }
-                listId = it->second;
-            }
-            uint32_t tid = intern(std::move(Tn));
-            if (tid > 0xFFFF) throw RegexError("tdfa: state limit exceeded");
-            row[size_t(c)] = tid | (listId << 16);
+            survivors.clear();
+            for (const auto& n : ni) survivors.push_back({n.pos, n.src, &n.tags, n.lin.empty() ? nullptr : &n.lin});
+            row[size_t(c)] = emitTransition(sid, b);
         }
         if (transRows.size() <= sid) transRows.resize(sid + 1);
         transRows[sid] = std::move(row);

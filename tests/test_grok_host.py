@@ -376,3 +376,40 @@ def test_configs2_corpus_has_the_baseline_shape(golden_dir):
     winners = set(int(w) for w in win if w >= 0)
     assert len(winners) >= 35, sorted(winners)
     assert 0.02 < float((win < 0).mean()) < 0.09                               # ~5 % free text that no format takes
+
+
+ANCHORED_IN_GLOBAL_MEMORY = ["%{HTTPD_ERRORLOG}", "%{CISCOFW106015}", "%{CISCOFW110002}", "%{CISCOFW402119}", "%{CISCOFW419001}",
+                             "%{CISCOFW419002}", "%{CISCOFW710001_710002_710003_710005_710006}", "%{COMMONAPACHELOG}"]
+
+
+def test_anchored_automata_of_formats_that_searched_on_the_thread_list_engine(golden_dir):
+    """Seven more Match entries of configs[2] get a tagged DFA for their anchored search since the construction stopped spending its
+    commit budget on patterns without memberships and got a larger path budget (tdfa.cpp, regex_handle.cpp): HTTPD_ERRORLOG (the
+    first entry of the list), five CISCOFW formats... -- 2 365..5 898 states, tables in global memory, walked by tdfa_wave_kernel.
+    Until now these entries ran on the thread-list engine, so that engine's tables (same handle) are the reference here: on corpus
+    lines the entry takes and on lines it does not, byte walk = wave walk = thread-list walk, captures included.  (End to end
+    against the Grok oracle: tests/test_gpu_grok.py, on the device.)"""
+    from loongcollector_amd.grok_corpus import grok_lines
+    from tests.helpers.table_interp import NfaInterp, TdfaL2BlobInterp
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    g = Grok(Match=ANCHORED_IN_GLOBAL_MEMORY, CustomPatterns=cfg3["custom_patterns"], AnchoredFirst=False)
+    flags = (B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_NO_DOTALL | B.LC_SYNTAX_NO_MULTILINE | B.LC_SYNTAX_REGEXP2 |
+             B.LC_SYNTAX_PREFIX)
+    lines = grok_lines(3000, seed=77)
+    taken = 0
+    for i, name in enumerate(ANCHORED_IN_GLOBAL_MEMORY):
+        rx = B.GpuRegex(g.expanded(i).encode(), syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
+        assert rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32) is not None and rx.has_nfa_program(), name
+        l2 = TdfaL2BlobInterp(rx)
+        assert 2000 < l2.nstates < 10000, (name, l2.nstates)
+        res = [l2.fullmatch(l) for l in lines]
+        hits = [k for k, r in enumerate(res) if r is not None]
+        assert len(hits) >= 40, (name, len(hits))
+        taken += len(hits)
+        nfa = (AtomicNfaInterp if rx.atomic_groups()[0] else NfaInterp)(rx)
+        for k in hits[:150] + [k for k, r in enumerate(res) if r is None][:150]:
+            assert l2.fullmatch_wave(lines[k]) == res[k], (name, k)
+            got = nfa.fullmatch(lines[k]) if rx.atomic_groups()[0] else nfa.fullmatch(lines[k], max_threads=128)
+            assert got == res[k], (name, k, lines[k][:80])
+    assert taken > 400
