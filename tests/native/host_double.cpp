@@ -169,6 +169,46 @@ void hd_counters(const hd_processor* p, uint64_t out[7]) {
 // PipelineEventGroup::DataSize() walk over a processed group (what the size sums cost as passes of their own, twice per group).
 }  // extern "C"
 
+// The arena chunk pool of the event model (csrc/event_model.hpp ArenaChunkPool): full-size chunks of a dead SourceBuffer are handed
+// to the next one, smaller chunks and big blocks are not, the pool is bounded.  Returns 0, or the number of the check that failed.
+extern "C" int hd_arena_pool_check(void) {
+    using logtail::ArenaChunkPool;
+    using logtail::SourceBuffer;
+    ArenaChunkPool& pool = ArenaChunkPool::instance();
+    while (char* p = pool.take()) delete[] p;  // start from an empty pool
+    std::vector<char*> seen;
+    {
+        SourceBuffer sb;
+        for (int i = 0; i < 3000; ++i) seen.push_back(sb.CopyString("0123456789012345678901234567890123456789", 40).data);  // 144 KB in small pieces
+        sb.AllocateStringBuffer(512 * 1024);  // a big block of its own
+        if (pool.pooled() != 0) return 1;
+    }
+    // 4 K + 8 K + 16 K + 32 K + 64 K chunks hold the first 124 KB; the rest went into ONE full-size chunk: that one is pooled
+    if (pool.pooled() != 1) return 2;
+    {
+        SourceBuffer sb;
+        char* last = nullptr;
+        for (int i = 0; i < 3000; ++i) last = sb.CopyString("x", 1).data;  // 8 bytes each: 24 KB, the doubling chunks only
+        (void)last;
+        if (pool.pooled() != 1) return 3;
+        for (int i = 0; i < 3000; ++i) last = sb.CopyString("0123456789012345678901234567890123456789", 40).data;
+        if (pool.pooled() != 0) return 4;  // ... the full-size chunk came from the pool
+        const char* inFirst = seen.back();  // the first buffer's last string lay in its full-size chunk
+        if (!(last > inFirst - 128 * 1024 && last < inFirst + 128 * 1024)) return 5;  // same 128 KiB of memory
+    }
+    if (pool.pooled() != 1) return 6;
+    {
+        std::vector<std::unique_ptr<SourceBuffer>> many;
+        for (size_t i = 0; i < ArenaChunkPool::kMaxPooled + 8; ++i) {
+            many.push_back(std::make_unique<SourceBuffer>());
+            for (int k = 0; k < 3000; ++k) many.back()->CopyString("0123456789012345678901234567890123456789", 40);
+        }
+    }
+    if (pool.pooled() != ArenaChunkPool::kMaxPooled) return 7;  // bounded: the surplus went back to the allocator
+    while (char* p = pool.take()) delete[] p;
+    return 0;
+}
+
 static double gLastMinorFaultsPerGroup = 0;
 extern "C" double hd_last_minor_faults_per_group(void) { return gLastMinorFaultsPerGroup; }  // of the last repeat
 

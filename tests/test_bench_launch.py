@@ -54,3 +54,71 @@ def test_under_torch_distributed_run():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bounded_window_in_agent_leg_round_logic_without_a_device():
+    """bench.py measure_in_agent_window (the in-agent leg with a bounded number of groups alive): rounds, barriers, accounting and
+    the failure path, driven with stand-ins for the ctypes wrappers -- every group is processed exactly once by exactly one thread, the
+    first round is not timed, a failing process() call surfaces instead of hanging the barrier."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Group:
+        alive = 0
+        peak = 0
+        lock = threading.Lock()
+
+        def __init__(self, lines):
+            self.lines, self.done, self.closed = lines, 0, False
+            with Group.lock:
+                Group.alive += 1
+                Group.peak = max(Group.peak, Group.alive)
+
+        @classmethod
+        def from_lines(cls, data, off, length):
+            return cls(len(off))
+
+        def contents(self):
+            return [[("k", "v")]]
+
+        def close(self):
+            assert not self.closed and self.done == 1
+            self.closed = True
+            with Group.lock:
+                Group.alive -= 1
+
+    class Proc:
+        fail_after = None
+
+        def __init__(self, cfg):
+            self.n = 0
+            self.lock = threading.Lock()
+
+        def process(self, g):
+            with self.lock:
+                self.n += g.lines
+                g.done += 1
+                if Proc.fail_after is not None and self.n > Proc.fail_after:
+                    raise RuntimeError("device lost")
+
+        def counters(self):
+            return {"out_successful_events_total": self.n, "out_failed_events_total": 0}
+
+    n_groups, group_lines = 70, 10
+    length = np.full(n_groups * group_lines, 512, dtype=np.uint32)
+    off = np.arange(n_groups * group_lines, dtype=np.uint32) * 513
+    for threads in (1, 4):
+        Group.alive = Group.peak = 0
+        mbps, first = bench.measure_in_agent_window(b"x", ["k"], None, off, length, group_lines, n_groups, threads, window=4, _types=(Group, Proc))
+        assert mbps > 0 and first == [("k", "v")]
+        assert Group.alive == 0 and Group.peak <= 4 * threads + threads   # a window per thread (+ the warm-up groups), never the whole run
+    Proc.fail_after = 300
+    try:
+        bench.measure_in_agent_window(b"x", ["k"], None, off, length, group_lines, n_groups, 2, window=4, _types=(Group, Proc))
+        raise AssertionError("the failing call was swallowed")
+    except RuntimeError as e:
+        assert "device lost" in str(e)
+    finally:
+        Proc.fail_after = None

@@ -274,3 +274,10 @@ def test_the_stitch_bench_entry_runs(double):
                                 ctypes.byref(size))
     assert us > 0 and build.value > 0
     assert p.counters()["out_successful"] == 2 * 4 * 1000
+
+
+def test_arena_chunks_go_round_through_the_pool(double):
+    """csrc/event_model.hpp ArenaChunkPool: a dead group's full-size arena chunks serve the next group's stitch (no first-touch page
+    faults in an agent's steady state); smaller chunks and big blocks are not pooled; the pool is bounded."""
+    double.hd_arena_pool_check.restype = ctypes.c_int
+    assert double.hd_arena_pool_check() == 0

@@ -3,6 +3,9 @@
 // match entry point alone (lc_regex_match_host_views) on the same groups, to see what the host side costs.
 //   g++ -O2 -std=c++17 -I include tools/inagent_bench.cpp -o scratch/inagent_bench -L loongcollector_amd/lib -llc_regex_gpu -lpthread
 //   LD_LIBRARY_PATH=loongcollector_amd/lib scratch/inagent_bench [lines] [group_lines] [threads...]
+#include <sys/resource.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -139,15 +142,81 @@ int main(int argc, char** argv) {
                         }
                     gate.finished();
                 });
+            struct rusage ru0, ru1;
+            getrusage(RUSAGE_SELF, &ru0);
             const auto t0 = gate.open(T);
             for (auto& x : th) x.join();
+            getrusage(RUSAGE_SELF, &ru1);
             const double dt = gate.secondsSince(t0);
             for (auto* g : warm) lc_group_free(g);
             uint64_t c[LC_CNT_COUNT];
             lc_processor_counters(proc, c);
-            printf("threads %2d  lc_processor_process   : %8.1f MB/s  (%.1f us per group per thread; %llu events parsed so far)\n", T,
-                   payload / dt / 1e6, dt * 1e6 * T / nGroups, (unsigned long long)c[LC_CNT_OUT_SUCCESSFUL_EVENTS]);
+            printf("threads %2d  lc_processor_process   : %8.1f MB/s  (%.1f us per group per thread; %.0f minor faults per group; %llu events parsed so far)\n", T,
+                   payload / dt / 1e6, dt * 1e6 * T / nGroups, double(ru1.ru_minflt - ru0.ru_minflt) / nGroups,
+                   (unsigned long long)c[LC_CNT_OUT_SUCCESSFUL_EVENTS]);
             for (auto* g : groups) lc_group_free(g);
+        }
+        // (c) the same with a bounded number of groups alive -- what an agent's queues allow: WINDOW groups per thread are built
+        // (the reader's job, untimed), processed by the T runner threads (timed), dropped (the flusher's job, untimed), round after
+        // round.  Part (b) keeps all its groups alive, so every arena chunk a stitch takes is memory nobody has touched yet: 108
+        // first-touch page faults per 1000-event group.  Here the chunks of the groups dropped a round ago come back through the
+        // event model's pool (csrc/event_model.hpp ArenaChunkPool).  INAGENT_WINDOW=0 skips this part.
+        const unsigned window = getenv("INAGENT_WINDOW") ? unsigned(atoi(getenv("INAGENT_WINDOW"))) : 16u;
+        if (window) {
+            const unsigned perRound = window * unsigned(T);
+            const unsigned rounds = std::max(2u, nGroups / perRound);
+            std::vector<lc_event_group_t*> cur(perRound, nullptr);
+            std::atomic<unsigned> roundNo{0}, done{0};
+            std::atomic<bool> stop{false};
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    lc_event_group_t* w = lc_group_from_lines(data.data(), &off[0], &len[0], groupLines, "content");
+                    lc_processor_process(proc, w);  // this thread's first call: staging, stream
+                    lc_group_free(w);
+                    done.fetch_add(1);
+                    for (unsigned r = 1;; ++r) {
+                        while (roundNo.load(std::memory_order_acquire) < r && !stop.load()) std::this_thread::yield();
+                        if (stop.load()) return;
+                        for (unsigned k = 0; k < window; ++k)
+                            if (lc_processor_process(proc, cur[size_t(t) * window + k]) != 0) {
+                                fprintf(stderr, "process failed\n");
+                                exit(3);
+                            }
+                        done.fetch_add(1, std::memory_order_release);
+                    }
+                });
+            while (done.load() < unsigned(T)) std::this_thread::yield();
+            double timed = 0;
+            long faults = 0;
+            unsigned next = 0;
+            for (unsigned r = 1; r <= rounds; ++r) {
+                for (unsigned k = 0; k < perRound; ++k) {
+                    const unsigned g = next++ % nGroups;
+                    cur[k] = lc_group_from_lines(data.data(), &off[g * groupLines], &len[g * groupLines], groupLines, "content");
+                }
+                done.store(0);
+                struct rusage ru0, ru1;
+                getrusage(RUSAGE_SELF, &ru0);
+                const auto t0 = std::chrono::steady_clock::now();
+                roundNo.store(r, std::memory_order_release);
+                while (done.load(std::memory_order_acquire) < unsigned(T)) std::this_thread::yield();
+                const auto t1 = std::chrono::steady_clock::now();
+                getrusage(RUSAGE_SELF, &ru1);
+                if (r > 1) {  // the first round fills the pool
+                    timed += std::chrono::duration<double>(t1 - t0).count();
+                    faults += ru1.ru_minflt - ru0.ru_minflt;
+                }
+                for (auto*& g : cur) {
+                    lc_group_free(g);
+                    g = nullptr;
+                }
+            }
+            stop.store(true);
+            for (auto& x : th) x.join();
+            const double groupsTimed = double(rounds - 1) * perRound;
+            printf("threads %2d  lc_processor_process, %u groups alive per thread: %8.1f MB/s  (%.1f us per group per thread; %.0f minor faults per group)\n",
+                   T, window, groupsTimed * groupLines * 512.0 / timed / 1e6, timed * 1e6 * T / groupsTimed, double(faults) / groupsTimed);
         }
         fflush(stdout);
     }
