@@ -1503,7 +1503,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             // (an anchored search is compiled because its automaton is wanted: it may cost seconds)
                             // (80 M: the anchored Grok formats of configs[2] that build at all need 24-69 M path steps and 2-5 s)
                             lim.maxPathWork = anchoredSearch ? (80u << 20) : (4u << 20);
-                            if (anchoredSearch) lim.maxStates = std::max<uint32_t>(lim.maxStates, 60000);
+                            // (the table format's state ids are 16 bits: CISCOFW713172 anchored needs 61 034 of them before
+                            // minimisation; the formats that do not build even so pass 170 000-600 000)
+                            if (anchoredSearch) lim.maxStates = std::max<uint32_t>(lim.maxStates, 65535);
                             if (const char* v = getenv("LC_TDFA_L2_MAX_WORK")) lim.maxPathWork = uint64_t(atoll(v));
                             if (const char* v = getenv("LC_TDFA_L2_MAX_COMMIT")) lim.maxCommitWork = uint64_t(atoll(v));
                             re->tdfa = buildTdfa(re->nfa, lim);

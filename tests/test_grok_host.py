@@ -379,13 +379,14 @@ def test_configs2_corpus_has_the_baseline_shape(golden_dir):
 
 
 ANCHORED_IN_GLOBAL_MEMORY = ["%{HTTPD_ERRORLOG}", "%{CISCOFW106015}", "%{CISCOFW110002}", "%{CISCOFW402119}", "%{CISCOFW419001}",
-                             "%{CISCOFW419002}", "%{CISCOFW710001_710002_710003_710005_710006}", "%{COMMONAPACHELOG}"]
+                             "%{CISCOFW419002}", "%{CISCOFW710001_710002_710003_710005_710006}", "%{COMMONAPACHELOG}", "%{CISCOFW713172}"]
 
 
 def test_anchored_automata_of_formats_that_searched_on_the_thread_list_engine(golden_dir):
-    """Seven more Match entries of configs[2] get a tagged DFA for their anchored search since the construction stopped spending its
+    """Eight more Match entries of configs[2] get a tagged DFA for their anchored search since the construction stopped spending its
     commit budget on patterns without memberships and got a larger path budget (tdfa.cpp, regex_handle.cpp): HTTPD_ERRORLOG (the
-    first entry of the list), five CISCOFW formats... -- 2 365..5 898 states, tables in global memory, walked by tdfa_wave_kernel.
+    first entry of the list), six CISCOFW formats... -- 2 365..23 108 states (CISCOFW713172 needs 61 034 before minimisation: the
+    table format's 16-bit state ids are the bound now), tables in global memory, walked by tdfa_wave_kernel.
     Until now these entries ran on the thread-list engine, so that engine's tables (same handle) are the reference here: on corpus
     lines the entry takes and on lines it does not, byte walk = wave walk = thread-list walk, captures included.  (End to end
     against the Grok oracle: tests/test_gpu_grok.py, on the device.)"""
@@ -402,10 +403,10 @@ def test_anchored_automata_of_formats_that_searched_on_the_thread_list_engine(go
         rx = B.GpuRegex(g.expanded(i).encode(), syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
         assert rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32) is not None and rx.has_nfa_program(), name
         l2 = TdfaL2BlobInterp(rx)
-        assert 2000 < l2.nstates < 10000, (name, l2.nstates)
+        assert 2000 < l2.nstates < 30000, (name, l2.nstates)
         res = [l2.fullmatch(l) for l in lines]
         hits = [k for k, r in enumerate(res) if r is not None]
-        assert len(hits) >= 40, (name, len(hits))
+        assert len(hits) >= 12, (name, len(hits))
         taken += len(hits)
         nfa = (AtomicNfaInterp if rx.atomic_groups()[0] else NfaInterp)(rx)
         for k in hits[:150] + [k for k, r in enumerate(res) if r is None][:150]:
