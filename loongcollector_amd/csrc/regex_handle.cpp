@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 
 #include "device_tables.h"
 #include "screen_kernel_layout.h"
@@ -1408,6 +1411,29 @@ extern "C" void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uin
     if (elided) *elided = re ? re->atomicsElided : 0u;
 }
 
+// verdicts of global-memory constructions that failed on their limits (see lc_regex_compile); LC_TDFA_NO_FAILURE_MEMO: off
+namespace {
+std::mutex gTdfaFailureMutex;
+std::unordered_map<std::string, std::string> gTdfaFailures;
+bool tdfaFailureMemoOn() {
+    static const bool on = getenv("LC_TDFA_NO_FAILURE_MEMO") == nullptr;
+    return on;
+}
+bool lcRecallTdfaFailure(const std::string& key, std::string& suffix) {
+    if (!tdfaFailureMemoOn()) return false;
+    std::lock_guard<std::mutex> g(gTdfaFailureMutex);
+    auto it = gTdfaFailures.find(key);
+    if (it == gTdfaFailures.end()) return false;
+    suffix = it->second;
+    return true;
+}
+void lcRememberTdfaFailure(const std::string& key, const std::string& suffix) {
+    if (!tdfaFailureMemoOn()) return;
+    std::lock_guard<std::mutex> g(gTdfaFailureMutex);
+    if (gTdfaFailures.size() < 1024) gTdfaFailures.emplace(key, suffix);  // (bounded: patterns come from configuration files)
+}
+}  // namespace
+
 extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,
                                 lc_regex_t** out, char* err, size_t errcap) {
     if (!pattern || !out || engine < LC_ENGINE_AUTO || engine > LC_ENGINE_NFA) {
@@ -1494,7 +1520,15 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 // the larger bound; a table that was built and only failed to pack -- byte classes, registers -- is kept)
                 const bool outOfWork = re->tdfaError.find("work limit") != std::string::npos;
                 const bool outOfStates = re->tdfaError.find("state limit") != std::string::npos;
-                if (l2States && !outOfWork) {
+                // A construction that failed on its limits fails the same way every time, and finding that out is the expensive part
+                // of an anchored Grok format that does not determinise (5-50 s of a core each, 16 of the 50 entries of configs[2]):
+                // the verdict is remembered for the life of the process, so that reloading a pipeline -- the agent does that in
+                // place -- does not pay for it again.  Same return code, same message; nothing is remembered about successes.
+                const std::string memoKey = re->pattern + '\0' + std::to_string(syntax_flags) + '/' + std::to_string(engine);
+                std::string remembered;
+                if (l2States && !outOfWork && lcRecallTdfaFailure(memoKey, remembered)) {
+                    re->tdfaError += remembered;
+                } else if (l2States && !outOfWork) {
                     try {
                         if (outOfStates || re->tdfa.nStates == 0) {
                             TdfaLimits lim;
@@ -1539,7 +1573,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                             l2 = true;
                         }
                     } catch (const RegexError& e2) {
-                        re->tdfaError += std::string("; with its tables in global memory: ") + e2.what();
+                        const std::string suffix = std::string("; with its tables in global memory: ") + e2.what();
+                        re->tdfaError += suffix;
+                        lcRememberTdfaFailure(memoKey, suffix);
                     }
                 }
                 if (!l2 && engine == LC_ENGINE_TDFA) throw RegexError(re->tdfaError);

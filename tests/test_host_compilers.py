@@ -521,3 +521,31 @@ def test_doomed_spawns_are_skipped_without_changing_a_result():
                 assert fast == exp, (pat, flags, s, fast, exp)
                 checked += 1
     assert rows >= 10 and checked > 2000
+
+
+def test_a_construction_that_failed_on_its_limits_is_not_repeated(golden_dir):
+    """An anchored Grok format that does not determinise within the table format's 65 535 states costs seconds of a core to find
+    out; the verdict is remembered for the life of the process (lc_regex_compile), so a pipeline reload does not pay again.  Same
+    return code and message both times; a handle that builds is not affected."""
+    import time
+    from loongcollector_amd.grok import Grok
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg3 = json.load(f)
+    g = Grok(Match=["%{CISCOFW302020_302021}", "%{CISCOFW106021}"], CustomPatterns=cfg3["custom_patterns"], AnchoredFirst=False)
+    flags = (B.LC_SYNTAX_SEARCH | B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_NO_DOTALL | B.LC_SYNTAX_NO_MULTILINE | B.LC_SYNTAX_REGEXP2 |
+             B.LC_SYNTAX_PREFIX)
+    took, said = [], []
+    hopeless = g.expanded(0).encode() + b"(?:qz7-memo-test)?"   # (a pattern no other test of this process has compiled before)
+    for _ in range(2):
+        t0 = time.perf_counter()
+        with pytest.raises(B.RegexUnsupportedError) as e:
+            B.GpuRegex(hopeless, syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
+        took.append(time.perf_counter() - t0)
+        said.append(str(e.value))
+    assert said[0] == said[1] and "with its tables in global memory: tdfa: state limit exceeded" in said[0]
+    assert took[1] * 5 < took[0], took
+    sizes = []
+    for _ in range(2):
+        rx = B.GpuRegex(g.expanded(1).encode(), syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
+        sizes.append(rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32).tobytes())
+    assert sizes[0] == sizes[1] and len(sizes[0]) > 100000
