@@ -439,7 +439,10 @@ def test_wave_walk_of_global_memory_automata_equals_the_byte_walk(golden_dir):
     import random
     from tests.helpers.table_interp import TdfaL2BlobInterp
     rng = random.Random(3)
-    cases = [(rb"(?:a|b)*a(?:a|b){12}(c+)(d*)", 0, b"abcdx")]
+    cases = [(rb"(?:a|b)*a(?:a|b){12}(c+)(d*)", 0, b"abcdx"),
+             # quiet runs in the middle of the walk ([^x]* keeps its state without a program), behind and in front of captures
+             (rb"([^x]*)x(?:a|b)*a(?:a|b){11}([^y]*)y(.*)", 0, b"abxy q"),
+             (rb"(?:a|b|c)*c(?:a|b|c){12}(\d+)-([a-c]*)", 0, b"abc1-")]
     from loongcollector_amd.grok import Grok
     with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
         cfg3 = json.load(f)
@@ -459,6 +462,8 @@ def test_wave_walk_of_global_memory_automata_equals_the_byte_walk(golden_dir):
         if alphabet:
             subs = [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 60))) for _ in range(400)]
             subs += [b"ab" * 9 + b"a" + b"b" * 12 + b"c" * k + b"d" * (k // 2) for k in (1, 2, 255, 256, 257, 600)]
+            subs += [b"q" * k + b"x" + b"ab" * 5 + b"a" + b"b" * 11 + b" " * j + b"y" + b"tail" * 70 for k in (0, 3, 254, 255, 256, 700) for j in (0, 257)]
+            subs += [b"ab" * 4 + b"c" + b"abcabcabcabc" + b"7" * k + b"-" + b"abc" * k for k in (1, 85, 86, 300)]
         else:
             subs = [b"<34>1 - host%d app 1 ID%d - " % (k, k) + b" ".join(rng.choice([b"alpha", b"beta7", b"x=1"]) for _ in range(rng.randint(0, 200)))
                     for k in range(60)]
@@ -472,7 +477,7 @@ def test_wave_walk_of_global_memory_automata_equals_the_byte_walk(golden_dir):
             if o is not None:
                 want = o.fullmatch(s)
                 assert a == (None if want is None else [v for be in want for v in be][2:]), s
-    assert checked > 450 and runs > 60
+    assert checked > 1300 and runs > 80
 
 
 QUASI_PATTERNS = [
