@@ -40,7 +40,7 @@ def double():
             os.path.join(csrc, "event_model.cpp")]
     deps = srcs + [os.path.join(csrc, h) for h in ("event_model.hpp", "processor_parse_regex_gpu.hpp", "json_min.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-o", so] + srcs +
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so] + srcs +
                               ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     L = ctypes.CDLL(so)
     vp, cp = ctypes.c_void_p, ctypes.c_char_p
