@@ -563,7 +563,11 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
             uint64_t w = 0;
             if (n) std::memcpy(&w, p, n);
             h = (h ^ w) * 0xD6E8FEB86659FD93ull;
-            return size_t(h ^ (h >> 32));
+            h ^= h >> 33;  // (murmur3's finaliser: the buckets are taken modulo a prime, but equal low halves must not cluster)
+            h *= 0xFF51AFD7ED558CCDull;
+            h ^= h >> 33;
+            h *= 0xC4CEB9FE1A85EC53ull;
+            return size_t(h ^ (h >> 33));
         }
     };
     std::unordered_map<std::string, uint32_t, KeyHash> index;
