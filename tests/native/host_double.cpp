@@ -209,6 +209,44 @@ extern "C" int hd_arena_pool_check(void) {
     return 0;
 }
 
+// ArenaVector (the events' contents array): growth keeps the entries and their order, in the arena and -- for an event made outside
+// a group -- on the heap; unzeroed appends are constructed by the caller.  Returns 0, or the number of the check that failed.
+extern "C" int hd_contents_container_check(void) {
+    using namespace logtail;
+    static const char* kKeys[] = {"k0", "k1", "k2", "k3", "k4", "k5", "k6", "k7", "k8", "k9"};
+    for (int where = 0; where < 2; ++where) {
+        auto sb = std::make_shared<SourceBuffer>();
+        PipelineEventGroup group(sb);
+        std::unique_ptr<LogEvent> heapEvent = where ? std::make_unique<LogEvent>(nullptr) : nullptr;
+        LogEvent* ev = where ? heapEvent.get() : group.AddLogEvent();
+        std::vector<std::string> values;
+        for (int i = 0; i < 100; ++i) values.push_back("value-" + std::to_string(i));
+        for (int i = 0; i < 100; ++i) ev->SetContentNoCopy(StringView(kKeys[i % 10]), StringView(values[size_t(i)]));  // overwrites from i = 10 on
+        if (ev->Size() != 10) return 10 * where + 1;
+        for (int k = 0; k < 10; ++k)
+            if (ev->GetContent(kKeys[k]) != StringView(values[size_t(90 + k)])) return 10 * where + 2;
+        ev->DelContent("k3");
+        const std::string raw = "0123456789abcdefghij";
+        const int32_t caps[6] = {0, 4, -1, -1, 10, 20};
+        const StringView fresh[3] = {StringView("f0"), StringView("f1"), StringView("f2")};
+        const StringView drop("k5");
+        ev->AppendCapturesNoCopy(fresh, 3, StringView(raw), caps, &drop);
+        if (ev->Size() != 11 || ev->HasContent("k3") || ev->HasContent("k5")) return 10 * where + 3;
+        if (ev->GetContent("f0") != StringView("0123") || !ev->HasContent("f1") || !ev->GetContent("f1").empty() ||
+            ev->GetContent("f1").data() != raw.data() + raw.size() || ev->GetContent("f2") != StringView("abcdefghij"))
+            return 10 * where + 4;
+        std::string order;
+        size_t bytes = 0;
+        for (auto it = ev->begin(); it != ev->end(); ++it) {
+            order += std::string(it->first) + ",";
+            bytes += it->first.size() + it->second.size();
+        }
+        if (order != "k0,k1,k2,k4,k6,k7,k8,k9,f0,f1,f2,") return 10 * where + 5;
+        if (ev->DataSize() != sizeof(time_t) + sizeof(std::optional<uint32_t>) + sizeof(std::vector<int>) + bytes) return 10 * where + 6;
+    }
+    return 0;
+}
+
 static double gLastMinorFaultsPerGroup = 0;
 extern "C" double hd_last_minor_faults_per_group(void) { return gLastMinorFaultsPerGroup; }  // of the last repeat
 

@@ -281,3 +281,10 @@ def test_arena_chunks_go_round_through_the_pool(double):
     faults in an agent's steady state); smaller chunks and big blocks are not pooled; the pool is bounded."""
     double.hd_arena_pool_check.restype = ctypes.c_int
     assert double.hd_arena_pool_check() == 0
+
+
+def test_contents_container_in_the_arena_and_on_the_heap(double):
+    """csrc/event_model.hpp ArenaVector behind LogEvent: overwrite, tombstone, growth and the one-call stitch keep contents, order
+    and size accounting -- for an event of a group (arena) and for one made outside any group (heap)."""
+    double.hd_contents_container_check.restype = ctypes.c_int
+    assert double.hd_contents_container_check() == 0
