@@ -184,6 +184,32 @@ int lc_device_count(void);
  * this BEFORE the first HIP call of the process; a value the host has already exported is kept.  LC_OK / LC_ERR_ARG. */
 int lc_runtime_prefer_hw_queues(int n);
 
+/* Which GPU a thread's work goes to ("In-agent: map runner thread -> GPU (threadNo % nGPU)").
+ * The reference calls Process from process_thread_count runner threads (core/runner/ProcessorRunner.cpp:138-142, the thread index
+ * ProcessorRunner.h:40 selects mReg[threadNo], ProcessorParseRegexNative.cpp:255-257); the index does not cross the C slot and an
+ * agent never selects a HIP device, so the library does:
+ *   - HOST entry points (lc_processor_process and the other processors, lc_regex_match_host*, lc_grok_match_host, lc_multiline_*,
+ *     lc_filter_*, lc_pipeline_*): the first such call of a thread BINDS the thread to a device by the process-wide policy and makes
+ *     it the thread's current HIP device; staging, streams and table uploads of the thread live there.
+ *       LC_BIND_ROUND_ROBIN (default): device = (thread ordinal) % lc_device_count(), ordinal = order of the threads' first host entry;
+ *                                      a thread whose current device is already non-zero was placed by its host and keeps it.
+ *       LC_BIND_FIXED:                 every thread -> `device` (a process that owns one GPU, e.g. one rank of a launcher).
+ *       LC_BIND_INHERIT:               never switch: whatever device is current for the thread (rounds 1-4 behaviour).
+ *     Environment: LC_BIND_POLICY = inherit | rr | fixed:<d> (read once, overridden by lc_runtime_set_bind_policy).
+ *   - DEVICE-pointer entry points (lc_regex_match_device*, lc_grok_match_device, ...) never switch devices: they run on the caller's
+ *     current device and return LC_ERR_ARG when d_data belongs to another device.
+ * lc_runtime_set_bind_policy: process-wide, affects threads not yet bound.  lc_runtime_bind_thread(policy): bind the calling thread now
+ * (policy < 0: the process-wide one); returns the device index, or -LC_ERR_*.  lc_runtime_set_thread_device(d): explicit binding
+ * (LC_OK / LC_ERR_ARG / LC_ERR_NO_DEVICE).  lc_runtime_thread_device(): the calling thread's bound device, -1 when unbound.
+ * lc_runtime_device_for_ordinal: the round-robin rule itself (pure; -1 when ndevices <= 0). */
+enum { LC_BIND_INHERIT = 0, LC_BIND_ROUND_ROBIN = 1, LC_BIND_FIXED = 2 };
+int lc_runtime_set_bind_policy(int policy, int device);
+int lc_runtime_bind_policy(void);
+int lc_runtime_bind_thread(int policy);
+int lc_runtime_set_thread_device(int device);
+int lc_runtime_thread_device(void);
+int lc_runtime_device_for_ordinal(uint32_t ordinal, int ndevices);
+
 /* Match n lines that already live in device memory on the current HIP device.
  *   d_data   : line bytes (any layout); line i = d_data[d_off[i] .. d_off[i]+d_len[i])
  *   d_len    : may be NULL, then d_off has n+1 entries and len[i] = d_off[i+1]-d_off[i]-sep_bytes

@@ -336,3 +336,53 @@ def split_scratch_bytes(nbytes):
 
 def device_count():
     return load().lc_device_count()
+
+
+# ---- thread -> device binding (include/lc_regex_gpu.h: lc_runtime_*bind*)
+LC_BIND_INHERIT, LC_BIND_ROUND_ROBIN, LC_BIND_FIXED = 0, 1, 2
+
+
+def _bind_lib():
+    L = load()
+    L.lc_runtime_set_bind_policy.restype = ctypes.c_int
+    L.lc_runtime_set_bind_policy.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.lc_runtime_bind_policy.restype = ctypes.c_int
+    L.lc_runtime_bind_thread.restype = ctypes.c_int
+    L.lc_runtime_bind_thread.argtypes = [ctypes.c_int]
+    L.lc_runtime_set_thread_device.restype = ctypes.c_int
+    L.lc_runtime_set_thread_device.argtypes = [ctypes.c_int]
+    L.lc_runtime_thread_device.restype = ctypes.c_int
+    L.lc_runtime_device_for_ordinal.restype = ctypes.c_int
+    L.lc_runtime_device_for_ordinal.argtypes = [ctypes.c_uint32, ctypes.c_int]
+    return L
+
+
+def set_bind_policy(policy, device=0):
+    """Process-wide placement of the threads that enter the library through its HOST entry points (processors, match_host ...):
+    LC_BIND_ROUND_ROBIN (library default: thread ordinal % visible devices), LC_BIND_FIXED (every thread -> `device`; what a
+    process that owns ONE GPU -- a rank of bench.py -- says), LC_BIND_INHERIT (never switch)."""
+    _check(_bind_lib().lc_runtime_set_bind_policy(policy, device), "lc_runtime_set_bind_policy")
+
+
+def bind_policy():
+    return _bind_lib().lc_runtime_bind_policy()
+
+
+def bind_thread(policy=-1):
+    """Bind the calling thread now; returns its device."""
+    d = _bind_lib().lc_runtime_bind_thread(policy)
+    if d < 0:
+        _check(-d, "lc_runtime_bind_thread")
+    return d
+
+
+def set_thread_device(device):
+    _check(_bind_lib().lc_runtime_set_thread_device(device), "lc_runtime_set_thread_device")
+
+
+def thread_device():
+    return _bind_lib().lc_runtime_thread_device()
+
+
+def device_for_ordinal(ordinal, ndevices):
+    return _bind_lib().lc_runtime_device_for_ordinal(ordinal, ndevices)

@@ -121,6 +121,170 @@ extern "C" int lc_device_count(void) {
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------ thread -> device
+// "In-agent: map runner thread -> GPU (threadNo % nGPU)".  The reference calls Process from
+// process_thread_count runner threads (core/runner/ProcessorRunner.cpp:138-142; the index is ProcessorRunner::GetThreadNo,
+// ProcessorRunner.h:40, and selects the thread's regex copy, ProcessorParseRegexNative.cpp:255-257).  The index does not cross the
+// C slot, and an agent never calls hipSetDevice: a fresh thread's current HIP device is 0, so through round 4 a plugin on an
+// 8-GPU node ran on GPU 0.  Now every HOST entry point (processors, lc_*_match_host, multiline, filter, pipeline) asks
+// lcHostEntryDevice: the first call of a thread binds it -- by the process-wide policy -- and makes that device current for
+// the thread; the thread's staging, streams and table uploads follow (they are per device already).  Entry points that take DEVICE
+// pointers never switch devices: the caller owns the placement, and lcDeviceEntryDevice refuses a pointer of another device.
+namespace {
+std::atomic<int> gBindPolicy{-1};  // -1: not decided yet (LC_BIND_POLICY is read at first use)
+std::atomic<int> gBindFixedDevice{0};
+std::atomic<uint32_t> gThreadOrdinals{0};
+struct ThreadBinding {
+    int device = -1;       // bound device, -1 = not bound
+    int ordinal = -1;      // this thread's ordinal (order of first host entry), -1 = none taken
+    unsigned age = 0;
+    int inherited = -1;    // LC_BIND_INHERIT: the current device as last asked from the runtime
+    bool inheritOnly = false;  // this thread asked for LC_BIND_INHERIT itself: the process-wide policy does not bind it
+};
+thread_local ThreadBinding tlsBind;
+
+int bindPolicyNow() {
+    int p = gBindPolicy.load(std::memory_order_relaxed);
+    if (p >= 0) return p;
+    p = LC_BIND_ROUND_ROBIN;
+    int fixedDev = 0;
+    if (const char* e = getenv("LC_BIND_POLICY")) {  // inherit | rr | fixed:<d>
+        if (!strcmp(e, "inherit")) p = LC_BIND_INHERIT;
+        else if (!strncmp(e, "fixed:", 6)) {
+            p = LC_BIND_FIXED;
+            fixedDev = atoi(e + 6);
+        }
+    }
+    int expected = -1;
+    if (gBindPolicy.compare_exchange_strong(expected, p)) {
+        if (p == LC_BIND_FIXED) gBindFixedDevice.store(fixedDev);
+        return p;
+    }
+    return expected;
+}
+
+int applyBinding(int device) {
+    const int n = lc_device_count();
+    if (n <= 0) {
+        tlsError = "no HIP device";
+        return LC_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n || device >= kLcMaxDevices) {
+        tlsError = "thread binding: device " + std::to_string(device) + " of " + std::to_string(n) + " visible";
+        return LC_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    tlsBind.device = device;
+    tlsBind.inheritOnly = false;
+    tlsBind.age = 0;
+    return LC_OK;
+}
+}  // namespace
+
+extern "C" int lc_runtime_device_for_ordinal(uint32_t ordinal, int ndevices) {
+    return ndevices > 0 ? int(ordinal % uint32_t(ndevices)) : -1;
+}
+
+extern "C" int lc_runtime_set_bind_policy(int policy, int device) {
+    if (policy != LC_BIND_INHERIT && policy != LC_BIND_ROUND_ROBIN && policy != LC_BIND_FIXED) return LC_ERR_ARG;
+    if (policy == LC_BIND_FIXED && device < 0) return LC_ERR_ARG;
+    if (policy == LC_BIND_FIXED) gBindFixedDevice.store(device);
+    gBindPolicy.store(policy);
+    return LC_OK;
+}
+
+extern "C" int lc_runtime_bind_policy(void) { return bindPolicyNow(); }
+
+extern "C" int lc_runtime_bind_thread(int policy) {
+    if (policy < 0) policy = bindPolicyNow();
+    ThreadBinding& b = tlsBind;
+    if (policy == LC_BIND_INHERIT) {
+        b.device = -1;
+        b.inheritOnly = true;
+        int cur = 0;
+        if (lc_device_count() <= 0) {
+            tlsError = "no HIP device";
+            return -LC_ERR_NO_DEVICE;
+        }
+        if (hipGetDevice(&cur) != hipSuccess) return -LC_ERR_HIP;
+        b.inherited = cur;
+        return cur;
+    }
+    int want = 0;
+    if (policy == LC_BIND_FIXED) {
+        want = gBindFixedDevice.load();
+    } else if (policy == LC_BIND_ROUND_ROBIN) {
+        const int n = lc_device_count();
+        if (n <= 0) {
+            tlsError = "no HIP device";
+            return -LC_ERR_NO_DEVICE;
+        }
+        // a thread whose current device is not the runtime's default has been placed by its host (hipSetDevice, torch.cuda.set_device):
+        // that is kept.  Device 0 is what a thread gets without asking -- those threads are dealt out by their ordinal.
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return -LC_ERR_HIP;
+        if (cur != 0) want = cur;
+        else {
+            if (b.ordinal < 0) b.ordinal = int(gThreadOrdinals.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu);
+            want = lc_runtime_device_for_ordinal(uint32_t(b.ordinal), n);
+        }
+    } else {
+        return -LC_ERR_ARG;
+    }
+    const int rc = applyBinding(want);
+    return rc == LC_OK ? want : -rc;
+}
+
+extern "C" int lc_runtime_set_thread_device(int device) { return applyBinding(device); }
+
+extern "C" int lc_runtime_thread_device(void) { return tlsBind.device; }
+
+int lcHostEntryDevice(int* dev) {
+    ThreadBinding& b = tlsBind;
+    if (b.device >= 0) {
+        // (a host library may have moved the thread's current device under us: looked at once in a while, not per group)
+        if ((++b.age & 255u) == 0) {
+            int cur = -1;
+            HIP_TRY(hipGetDevice(&cur));
+            if (cur != b.device) HIP_TRY(hipSetDevice(b.device));
+        }
+        *dev = b.device;
+        return LC_OK;
+    }
+    if (b.inheritOnly || bindPolicyNow() == LC_BIND_INHERIT) {
+        if (b.inherited < 0 || (++b.age & 255u) == 0) HIP_TRY(hipGetDevice(&b.inherited));
+        *dev = b.inherited;
+        return *dev < kLcMaxDevices ? LC_OK : LC_ERR_ARG;
+    }
+    const int d = lc_runtime_bind_thread(-1);
+    if (d < 0) return -d;
+    *dev = d;
+    return LC_OK;
+}
+
+int lcDeviceEntryDevice(const void* d_ptr, int* dev) {
+    HIP_TRY(hipGetDevice(dev));
+    if (*dev >= kLcMaxDevices) return LC_ERR_ARG;
+    // where the caller's buffer lives: asked once per (pointer, current device), a caller hands over the same buffers batch after batch
+    static thread_local const void* lastPtr = nullptr;
+    static thread_local int lastDev = -1;
+    if (!d_ptr || (d_ptr == lastPtr && lastDev == *dev)) return LC_OK;
+    if (lc_device_count() > 1) {
+        hipPointerAttribute_t attr;
+        const hipError_t e = hipPointerGetAttributes(&attr, d_ptr);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (not a pointer the runtime knows: e.g. fine-grained host memory mapped by someone else; not ours to judge)
+        } else if (attr.type == hipMemoryTypeDevice && attr.device != *dev) {
+            tlsError = "device pointer belongs to device " + std::to_string(attr.device) + ", the calling thread's current device is " +
+                       std::to_string(*dev);
+            return LC_ERR_ARG;
+        }
+    }
+    lastPtr = d_ptr;
+    lastDev = *dev;
+    return LC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device tables
 enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3, kBlobTdfaL2 = 4 };
 static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
@@ -709,8 +873,10 @@ extern "C" int lc_regex_screen_device(lc_regex_t* re, const uint8_t* d_data, con
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     return lcScreenOnStream(re, dev, d_data, d_off, d_len, n, d_lines, d_out, d_count, stream);
 }
 
@@ -834,21 +1000,25 @@ extern "C" int lc_regex_match_device_engine(lc_regex_t* re, int engine, const ui
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
     return lcMatchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, nullptr, nullptr, nullptr, ngroups, d_caps, d_status,
                          static_cast<hipStream_t>(stream));
 }
 
-// ---- lc_regex_match_device_multi: the job tables are read by the kernel straight from pinned host memory; a small ring of
-// them per thread, each guarded by an event, so that a caller may queue several multi-launches before it synchronises
+// ---- lc_regex_match_device_multi: a job table (TdfaJob[] + u16 blockToJob[]) is packed in pinned host memory and copied to its
+// device mirror on the launch stream; the kernel reads the device copy only.  A small ring of them per thread, each guarded by an
+// event, so that a caller may queue several multi-launches before it synchronises
 namespace {
 struct JobTableRing {
     static constexpr int kTables = 8;
     struct Table {
-        TdfaJob* jobs = nullptr;
-        uint32_t cap = 0;
+        uint8_t* host = nullptr;  // pinned
+        uint8_t* dev = nullptr;   // device mirror
+        size_t cap = 0;           // bytes
         hipEvent_t done = nullptr;
         bool inFlight = false;
     } t[kTables];
@@ -863,7 +1033,8 @@ struct JobTableRing {
         for (auto& x : t) {
             if (x.inFlight) (void)hipEventSynchronize(x.done);
             if (x.done) (void)hipEventDestroy(x.done);
-            (void)hipHostFree(x.jobs);
+            (void)hipHostFree(x.host);
+            (void)hipFree(x.dev);
             x = Table();
         }
         device = -1;
@@ -872,7 +1043,7 @@ struct JobTableRing {
 thread_local JobTableRing tlsJobTables;
 
 template <int BLOCK, bool PAIR1>
-int launchTdfaMulti(const TdfaJob* table, uint32_t nJobs, uint32_t totalBlocks, size_t lds, hipStream_t stream) {
+int launchTdfaMulti(const TdfaJob* table, const uint16_t* blockToJob, uint32_t totalBlocks, size_t lds, hipStream_t stream) {
     auto kern = tdfa_stream_multi_kernel<BLOCK, false, PAIR1>;
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
     int devNow = 0;
@@ -885,7 +1056,7 @@ int launchTdfaMulti(const TdfaJob* table, uint32_t nJobs, uint32_t totalBlocks, 
     uint32_t* nullCounter = nullptr;
     uint32_t* nullFlag = nullptr;
     uint32_t zero = 0;
-    void* args[] = {&table, &nJobs, &nullCounter, &nullFlag, &zero};
+    void* args[] = {&table, &blockToJob, &nullCounter, &nullFlag, &zero};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(kern), dim3(totalBlocks), dim3(BLOCK), args, lds, stream));
     return LC_OK;
 }
@@ -899,8 +1070,10 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(jobs[0].d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     for (uint32_t i = 0; i < njobs; ++i) {
         const lc_match_job& j = jobs[i];
@@ -956,23 +1129,40 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
             HIP_TRY(hipEventSynchronize(tab.done));
             tab.inFlight = false;
         }
-        if (packed.size() > tab.cap) {
-            (void)hipHostFree(tab.jobs);
-            tab.jobs = nullptr;
+        if (packed.size() > 0xFFFFu) {
+            tlsError = "lc_regex_match_device_multi: more than 65535 jobs in one call";
+            return LC_ERR_ARG;
+        }
+        const size_t mapAt = (packed.size() * sizeof(TdfaJob) + 15) & ~size_t(15), tableBytes = mapAt + size_t(blocks) * 2;
+        if (tableBytes > tab.cap) {
+            (void)hipHostFree(tab.host);
+            (void)hipFree(tab.dev);
+            tab.host = tab.dev = nullptr;
             tab.cap = 0;
-            const uint32_t cap = uint32_t(packed.size()) * 2 + 16;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&tab.jobs), size_t(cap) * sizeof(TdfaJob), hipHostMallocDefault));
+            const size_t cap = tableBytes * 2 + 4096;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&tab.host), cap, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tab.dev), cap));
             tab.cap = cap;
         }
-        std::memcpy(tab.jobs, packed.data(), packed.size() * sizeof(TdfaJob));
+        std::memcpy(tab.host, packed.data(), packed.size() * sizeof(TdfaJob));
+        {
+            uint16_t* map = reinterpret_cast<uint16_t*>(tab.host + mapAt);
+            for (size_t k = 0; k < packed.size(); ++k) {
+                const uint32_t end = k + 1 < packed.size() ? packed[k + 1].firstBlock : blocks;
+                for (uint32_t b = packed[k].firstBlock; b < end; ++b) map[b] = uint16_t(k);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(tab.dev, tab.host, tableBytes, hipMemcpyHostToDevice, stream));
+        const TdfaJob* dJobs = reinterpret_cast<const TdfaJob*>(tab.dev);
+        const uint16_t* dMap = reinterpret_cast<const uint16_t*>(tab.dev + mapAt);
         int rc = LC_OK;
         switch (variant) {
-            case 0: rc = launchTdfaMulti<256, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            case 1: rc = launchTdfaMulti<256, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            case 2: rc = launchTdfaMulti<128, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            case 3: rc = launchTdfaMulti<128, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            case 4: rc = launchTdfaMulti<64, false>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
-            default: rc = launchTdfaMulti<64, true>(tab.jobs, uint32_t(packed.size()), blocks, lds, stream); break;
+            case 0: rc = launchTdfaMulti<256, false>(dJobs, dMap, blocks, lds, stream); break;
+            case 1: rc = launchTdfaMulti<256, true>(dJobs, dMap, blocks, lds, stream); break;
+            case 2: rc = launchTdfaMulti<128, false>(dJobs, dMap, blocks, lds, stream); break;
+            case 3: rc = launchTdfaMulti<128, true>(dJobs, dMap, blocks, lds, stream); break;
+            case 4: rc = launchTdfaMulti<64, false>(dJobs, dMap, blocks, lds, stream); break;
+            default: rc = launchTdfaMulti<64, true>(dJobs, dMap, blocks, lds, stream); break;
         }
         if (rc != LC_OK) return rc;
         HIP_TRY(hipEventRecord(tab.done, stream));
@@ -1009,8 +1199,10 @@ extern "C" int lc_regex_match_device_from(lc_regex_t* re, int engine, const uint
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
     return lcMatchOnStream(re, engine, dev, d_data, d_off, d_len, sep_bytes, n, d_nlines, d_lines, d_from, ngroups, d_caps,
                            d_status, static_cast<hipStream_t>(stream));
@@ -1027,8 +1219,10 @@ extern "C" int lc_regex_match_device_dyn(lc_regex_t* re, int engine, const uint8
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
     return lcMatchOnStream(re, engine, dev, d_data, d_off, nullptr, sep_bytes, max_lines, d_nlines, nullptr, nullptr, ngroups, d_caps,
                          d_status, static_cast<hipStream_t>(stream));
@@ -1063,8 +1257,10 @@ extern "C" int lc_regex_match_device_ragged(lc_regex_t* re, int engine, const ui
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     if (engine == LC_ENGINE_AUTO) engine = re->engine;
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t* hist = static_cast<uint32_t*>(d_scratch);
@@ -1138,8 +1334,10 @@ extern "C" int lc_span_filter_device(const lc_span_filter_t* filters, uint32_t n
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     SpanFilterArgs args{};
     args.n = nfilters;
     for (uint32_t f = 0; f < nfilters; ++f) {
@@ -1304,12 +1502,12 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
         tlsError = "no HIP device";
         return LC_ERR_NO_DEVICE;
     }
-    // the thread's current device: asked from the runtime once in a while, not per group (a runner thread does not hop devices)
-    static thread_local int cachedDev = -1;
-    static thread_local unsigned devAge = 0;
-    if (cachedDev < 0 || (++devAge & 255u) == 0) HIP_TRY(hipGetDevice(&cachedDev));
-    const int dev = cachedDev;
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    // the thread's device: its binding (lc_runtime_bind_thread; by default the thread's ordinal modulo the visible devices)
+    int dev = 0;
+    {
+        const int rcDev = lcHostEntryDevice(&dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     static thread_local HostPipeline pipe;
     lcRegisterExitHook();
     tlsPipe = &pipe;

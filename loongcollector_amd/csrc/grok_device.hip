@@ -1124,8 +1124,10 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
         return LC_ERR_NO_DEVICE;
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev >= kLcMaxDevices) return LC_ERR_ARG;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
     hipStream_t st = static_cast<hipStream_t>(streamPtr);
     static const int forced = [] {  // LC_GROK_SPECULATIVE=0/1 overrides the handle's option (A/B measurements)
         const char* e = getenv("LC_GROK_SPECULATIVE");
@@ -1221,7 +1223,10 @@ namespace {
 int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
                      const std::vector<GrokDeviceState::HostJob*>& jobs) {
     int devNo = 0;
-    HIP_TRY(hipGetDevice(&devNo));
+    {
+        const int rcDev = lcHostEntryDevice(&devNo);
+        if (rcDev != LC_OK) return rcDev;
+    }
     GrokHostThread& H = tlsGrokHost;
     {
         int rc = H.ensure(devNo);

@@ -70,7 +70,10 @@ int prepare(MlThread& T, int& dev) {
         lcSetLastError("no HIP device: the multiline processors have no CPU path");
         return LC_ERR_NO_DEVICE;
     }
-    LC_HIP_TRY(hipGetDevice(&dev));
+    {
+        const int rcDev = lcHostEntryDevice(&dev);  // the thread's binding (runtime_internal.hpp)
+        if (rcDev != LC_OK) return rcDev;
+    }
     if (T.stream && T.device != dev) lcMultilineThreadRelease();  // (another device: old stream and buffers go)
     if (!T.stream) {
         LC_HIP_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));

@@ -28,6 +28,7 @@ thread_local FilterThread tlsFilter;
 }  // namespace
 void lcRegisterExitHook();
 bool lcRuntimeUsable();  // gpu_runtime.hip
+int lcHostEntryDevice(int* dev);  // gpu_runtime.hip: the calling thread's device binding
 void lcFilterThreadRelease() {
     FilterThread& T = tlsFilter;
     if (T.stream) {
@@ -318,7 +319,7 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
         const hipError_t e_ = (expr);                                                     \
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-        FILTER_TRY(hipGetDevice(&dev));
+        if (lcHostEntryDevice(&dev) != LC_OK) return fail(std::string("filter: ") + lc_last_error());  // the thread's binding
         if (T.stream && T.device != dev) lcFilterThreadRelease();  // (another device: old stream and buffers go, see PipeThread)
         if (!T.stream) {
         lcRegisterExitHook();

@@ -168,6 +168,7 @@ thread_local PipeThread tlsPipe;
 }  // namespace logtail
 void lcRegisterExitHook();
 bool lcRuntimeUsable();  // gpu_runtime.hip: false once the process is exiting (the HIP runtime may be gone)
+int lcHostEntryDevice(int* dev);  // gpu_runtime.hip: the calling thread's device binding
 // lc_thread_release(): the calling thread's staging and stream
 void lcPipelineThreadRelease() {
     logtail::PipeThread& T = logtail::tlsPipe;
@@ -224,7 +225,10 @@ bool ProcessorPipelineGpu::ProcessFused(PipelineEventGroup& logGroup, std::strin
     }
     PipeThread& T = tlsPipe;
     int dev = 0;
-    PIPE_TRY(hipGetDevice(&dev));
+    if (lcHostEntryDevice(&dev) != LC_OK) {  // the thread's binding
+        error = std::string("pipeline: ") + lc_last_error();
+        return false;
+    }
     // (a thread that moved to another device starts over: its stream is destroyed, its grow-only buffers -- allocated on the old
     // device -- are released; they used to be kept and handed to kernels of the new device)
     if (T.stream && T.device != dev) lcPipelineThreadRelease();

@@ -17,6 +17,11 @@ void lcGrokThreadRelease();                            // grok_device.hip: the c
 void lcPipelineThreadRelease();                        // processor_pipeline_gpu.cpp: the calling thread's staging and stream
 void lcMultilineThreadRelease();                       // multiline_device.hip: the same for the multiline processors
 void lcFilterThreadRelease();                          // processor_filter_gpu.cpp: the same for the filter
+// The device a HOST entry point (processors, lc_*_match_host, multiline, filter, pipeline) runs on for the calling thread: the thread's
+// binding (lc_runtime_bind_thread; first call binds by the process-wide policy), made current for the thread.  LC_OK or an error code.
+int lcHostEntryDevice(int* dev);
+// The device a DEVICE-pointer entry point runs on: the caller's current HIP device; LC_ERR_ARG when d_ptr lives on another device.
+int lcDeviceEntryDevice(const void* d_ptr, int* dev);
 // the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
 void lcSetDecideSlot(int slot);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(BLOCK, (LAB & kLabWaves5) ? 5 : LC_TDFA_STREAM_WAVE
 // group fills 4 of 256 CUs and a launch per group leaves the chip to launch latency: measured 22 GB/s aggregate for 64
 // pipelines on 4 streams against 820 GB/s for the same bytes in one launch).  Workgroup b belongs to the job whose
 // [firstBlock, next firstBlock) holds b; it stages that job's tables into LDS -- the per-pipeline switch costs what staging
-// 1-3 KB costs -- and walks that job's lines.  The job table may live in pinned host memory (each workgroup reads 80 bytes).
+// 1-3 KB costs -- and walks that job's lines.
 struct TdfaJob {
     const uint8_t* data;
     const uint32_t* off;
@@ -554,17 +554,15 @@ struct TdfaJob {
 };
 
 // PAIR1: every job of the launch carries a ONE-STAMP byte-pair table (the launcher packs jobs with and without into separate launches)
+// blockToJob[b] = the job workgroup b belongs to.  Both tables live in DEVICE memory (copied there on the launch stream): through
+// round 4 every workgroup binary-searched the job table in pinned host memory -- six dependent reads across PCIe at the head of each
+// of the launch's ~250 workgroups, two thirds of the launch's duration.
 template <int BLOCK, bool COMPACT, bool PAIR1 = false>
-__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_multi_kernel(const TdfaJob* __restrict__ jobs, uint32_t nJobs,
+__global__ __launch_bounds__(BLOCK, LC_TDFA_STREAM_WAVES) void tdfa_stream_multi_kernel(const TdfaJob* __restrict__ jobs,
+                                                                                        const uint16_t* __restrict__ blockToJob,
                                                                                         uint32_t* __restrict__ doneCounter,
                                                                                         uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
-    uint32_t lo = 0, hi = nJobs;  // the last job whose firstBlock <= blockIdx.x (wave-uniform: scalar loads)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (jobs[mid].firstBlock <= blockIdx.x) lo = mid;
-        else hi = mid;
-    }
-    const TdfaJob j = jobs[lo];
+    const TdfaJob j = jobs[blockToJob[blockIdx.x]];  // (wave-uniform: scalar loads)
     tdfaStreamBody<BLOCK, COMPACT, PAIR1, PAIR1 ? (kTdfaNoGeneralPrograms | kLabPairOne) : 0>(
         j.data, j.off, j.len, j.sepBytes, 0u, j.nLines, nullptr, nullptr, nullptr, j.blob, j.blobBytes, j.regBytes, j.nGroupsOut, j.caps, j.status,
         nullptr, 0u, blockIdx.x - j.firstBlock);

@@ -43,6 +43,54 @@ def test_match_calls_fail_loudly_without_a_device():
         rx.match_host(data, np.array([0], np.uint32), np.array([3], np.uint32))
 
 
+def test_thread_to_device_rule_and_policy_calls():
+    """runner thread -> GPU as threadNo % nGPU (core/runner/ProcessorRunner.h:40 is the index the reference
+    uses for its per-thread regex copies).  The rule itself is a pure function; the policy calls validate their arguments and, on
+    a box without a device, an explicit binding fails loudly instead of pretending."""
+    for n in (1, 2, 4, 8):
+        got = [B.device_for_ordinal(t, n) for t in range(3 * n)]
+        assert got == [t % n for t in range(3 * n)]
+        # every device gets the same number of the first k*n threads
+        assert sorted(got) == sorted(list(range(n)) * 3)
+    assert B.device_for_ordinal(5, 0) == -1 and B.device_for_ordinal(5, -3) == -1
+    assert B.device_for_ordinal(2 ** 32 - 1, 8) == (2 ** 32 - 1) % 8
+    L = B.load()
+    assert L.lc_runtime_set_bind_policy(7, 0) == B.LC_ERR_ARG
+    assert L.lc_runtime_set_bind_policy(B.LC_BIND_FIXED, -1) == B.LC_ERR_ARG
+    import subprocess
+    import sys
+    code = r"""
+import threading
+from loongcollector_amd import binding as B
+assert B.bind_policy() == B.LC_BIND_ROUND_ROBIN          # the library's default
+assert B.thread_device() == -1                           # nobody is bound before a host entry
+B.set_bind_policy(B.LC_BIND_FIXED, 0)
+assert B.bind_policy() == B.LC_BIND_FIXED
+n = B.device_count()
+L = B.load()
+if n == 0:
+    assert L.lc_runtime_set_thread_device(0) == B.LC_ERR_NO_DEVICE
+    assert L.lc_runtime_bind_thread(-1) == -B.LC_ERR_NO_DEVICE
+else:
+    assert L.lc_runtime_set_thread_device(n) == B.LC_ERR_ARG
+    seen = []
+    def run():
+        seen.append((B.bind_thread(), B.thread_device()))
+    ts = [threading.Thread(target=run) for _ in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert seen == [(0, 0)] * 4
+print("ok")
+"""
+    env = dict(os.environ)
+    env.pop("LC_BIND_POLICY", None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    env["LC_BIND_POLICY"] = "inherit"
+    out = subprocess.run([sys.executable, "-c", "from loongcollector_amd import binding as B; print(B.bind_policy())"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == str(B.LC_BIND_INHERIT), out.stdout + out.stderr
+
+
 def test_info_reports_engine_and_sizes():
     info = B.GpuRegex(r"(\w+)\t(\w+).*").info()
     assert info["engine"] == B.LC_ENGINE_TDFA and info["mark_count"] == 2 and info["states"] > 2
