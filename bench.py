@@ -61,6 +61,10 @@ def setup_dist():
         raise SystemExit("bench.py needs a HIP device: the parse engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # this process owns ONE GPU: every thread that enters the library's host entry points (the runner threads of the in-agent legs,
+    # the slab feeders) goes to it -- the library's own default would deal threads over every visible device
+    from loongcollector_amd import binding as _binding
+    _binding.set_bind_policy(_binding.LC_BIND_FIXED, local_rank)
     # with several ranks on one host every rank stays on the CPUs / memory of its GPU's NUMA node: set BEFORE any pinned
     # staging memory is allocated (first touch).  One rank keeps the whole box (its runner-thread measurements want the cores).
     PLACEMENT.update(place_rank(local_rank, apply=world > 1))
@@ -613,6 +617,7 @@ def run_headline(args):
             import subprocess
             env = dict(os.environ)
             env.setdefault("GPU_MAX_HW_QUEUES", "16")
+            env["LC_BIND_POLICY"] = "fixed:%d" % (dev.index or 0)  # (one GPU per process: see setup_dist)
             try:
                 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "grok_config2.py"), "--device", str(dev.index or 0)],
                                      env=env, capture_output=True, text=True, timeout=900)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/gpu_r5.sh STAGE: the GPU calls of round 5 (profiles/round5_* come from them; profiles/ROUND5.md indexes the files).
+#   first    full GPU suite, configs[3] (packed multi-pipeline launch) bench line + kernel trace, the Grok step's profile
+#   multi    configs[3] only
+#   grok     Grok GPU tests + the Grok step's profile (bench lines, phase trace, kernel trace, timeline)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; O=gpurun_out/r5_$1; mkdir -p $O scratch
+multi() {
+  timeout 200 python bench.py --config 4 --steps 50 --warmup 5 > $O/multi.json 2> $O/multi.err; cut -c1-900 $O/multi.json; tail -2 $O/multi.err | cut -c1-300
+  (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/multi_prof -o r1 -- python $R/bench.py --config 4 --steps 50 --warmup 5 > $R/$O/multi_prof.log 2>&1)
+  python tools/grok_prof_summary.py $O/multi_prof > $O/multi_kernel_rocprofv3.txt 2>&1; rm -rf $O/multi_prof
+  head -12 $O/multi_kernel_rocprofv3.txt | cut -c1-200
+}
+case "$1" in
+first)
+  timeout 400 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 | cut -c1-300 | tee $O/pytest_gpu.txt
+  multi
+  GPU_MAX_HW_QUEUES=16 bash tools/gpu_grok_profile.sh r5_first_grok 16384 2>&1 | head -12 | cut -c1-250 ;;
+multi) multi ;;
+grok)
+  timeout 120 python -m pytest tests/test_gpu_grok.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-200 | tee $O/pytest_grok.txt
+  GPU_MAX_HW_QUEUES=16 bash tools/gpu_grok_profile.sh r5_grok_$2 16384 2>&1 | head -14 | cut -c1-250 ;;
+*) echo "usage: $0 first|multi|grok"; exit 2 ;;
+esac
