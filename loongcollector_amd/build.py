@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblc_regex_gpu.so")
+# the same library with the stand-in event model built in the REFERENCE's shape (csrc/event_model.hpp LC_REFERENCE_SHAPED_EVENT_MODEL:
+# heap std::vector contents, no chunk pool, K x SetContentNoCopy + DelContent).  bench.py loads it in a process of its own for
+# end_to_end.in_agent_reference_shape_MBps -- what an agent build's event model lets one runner thread do; never the default.
+LIB_REFSHAPE = os.path.join(LIBDIR, "liblc_regex_gpu_refshape.so")
 
 SOURCES = ["regex_parse.cpp", "atomic_elide.cpp", "follow_nfa.cpp", "tdfa.cpp", "screen_dfa.cpp", "regex_handle.cpp", "gpu_runtime.hip", "grok_device.hip", "multiline_device.hip"]
 OPTIONAL_SOURCES = ["event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "grok_literal_index.cpp", "processor_grok_gpu.cpp", "processor_filter_gpu.cpp", "processor_go_regex_gpu.cpp", "multiline_gpu.cpp", "multiline_events.cpp", "processor_pipeline_gpu.cpp", "c_processor_slot.cpp"]
@@ -48,7 +52,8 @@ def needs_build():
 def build_native(force=False, verbose=False, force_sources=()):
     """force_sources: basenames of sources to recompile even if their objects look current (smoke() uses it to show a real
     gfx950 compile on the GPU box)."""
-    if not force and not force_sources and not needs_build():
+    if not force and not force_sources and not needs_build() and os.path.exists(LIB_REFSHAPE) and \
+            os.path.getmtime(LIB_REFSHAPE) >= os.path.getmtime(LIB):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
@@ -86,6 +91,27 @@ def build_native(force=False, verbose=False, force_sources=()):
             print(out.decode(), file=sys.stderr)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    # the reference-shaped variant: only the host translation units that see the event model are compiled again (with the switch);
+    # the regex compilers and every gfx950 object are the ones just linked above
+    shape_objs, procs = [], []
+    for src, obj in zip(sources(), objs):
+        base = os.path.basename(src)
+        if base not in OPTIONAL_SOURCES:
+            shape_objs.append(obj)
+            continue
+        sobj = os.path.join(objdir, base + ".refshape.o")
+        shape_objs.append(sobj)
+        if (not force and os.path.exists(sobj) and os.path.getmtime(sobj) > os.path.getmtime(src)
+                and all(os.path.getmtime(sobj) > os.path.getmtime(os.path.join(CSRC, h))
+                        for h in os.listdir(CSRC) if h.endswith((".h", ".hpp")))):
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950"] + common + ["-DLC_REFERENCE_SHAPED_EVENT_MODEL", "-c", src, "-o", sobj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed for %s (reference-shaped variant):\n%s" % (src, out.decode()))
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_REFSHAPE] + shape_objs)
     return LIB
 
 

@@ -57,6 +57,9 @@ public:
         return *pool;
     }
     char* take() {
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+        return nullptr;  // (the reference's SourceBuffer has no pool: every chunk comes from the allocator, SourceBuffer.h:98-131)
+#endif
         std::lock_guard<std::mutex> g(mMutex);
         if (mFree.empty()) return nullptr;
         char* p = mFree.back();
@@ -64,6 +67,10 @@ public:
         return p;
     }
     bool give(char* p) {
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+        (void)p;
+        return false;
+#endif
         std::lock_guard<std::mutex> g(mMutex);
         if (mFree.size() >= kMaxPooled) return false;
         mFree.push_back(p);
@@ -255,7 +262,16 @@ private:
     uint32_t mSize = 0, mCap = 0;
     SourceBuffer* mArena;
 };
+// LC_REFERENCE_SHAPED_EVENT_MODEL (build switch, bench.py end_to_end.in_agent_reference_shape_MBps): the event model shaped like the
+// reference's -- contents in a heap std::vector reserved to default_log_event_capacity = 16 by the constructor (LogEvent.cpp:21-29),
+// no chunk pool, and no bulk stitch (the processor then writes its K fields with K x SetContentNoCopy and drops the source with
+// DelContent, exactly the calls a build against the reference headers makes: ProcessorParseRegexNative.cpp:249-251, :153-155).
+// What the library's default event model gains over this shape is gained by types the agent owns; an agent build gets this shape.
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+using ContentsContainer = std::vector<std::pair<LogContent, bool>>;
+#else
 using ContentsContainer = ArenaVector<std::pair<LogContent, bool>>;
+#endif
 static_assert(sizeof(ContentsContainer) == sizeof(std::vector<int>), "LogEvent::DataSize counts sizeof(mContents) as the reference does");
 static_assert(std::is_trivially_destructible<std::pair<LogContent, bool>>::value, "ArenaVector never runs destructors");
 
@@ -318,6 +334,7 @@ public:
     // AppendContentsNoCopy; the views are built in place instead of going through a caller's array.
     // With dropKey (a key that is none of `keys`): followed by DelContent(*dropKey), whose scan from the back then starts below the new
     // entries -- and whose one-byte tombstone store comes after the array has moved, not right before the move reads it back.
+#ifndef LC_REFERENCE_SHAPED_EVENT_MODEL
     void AppendCapturesNoCopy(const StringView* keys, size_t n, StringView raw, const int32_t* c, const StringView* dropKey = nullptr) {
         const size_t old = mContents.size();
         std::pair<LogContent, bool>* out = mContents.appendUninitialized(n);
@@ -356,6 +373,7 @@ public:
         mAllocatedContentSize += bytes;
         mContentCnt = live;
     }
+#endif
     // HasContent + GetContent in one scan: the live value of `key`, or nullptr (an empty value is not a missing one)
     const StringView* FindContent(StringView key) const {
         const auto* e = findLive(key);
@@ -390,6 +408,10 @@ private:
     // (piecewise: emplace_back(LogContent(key, val), true) builds the inner pair on the stack with 8-byte stores and copies it with
     // 16-byte loads -- a store-forwarding stall per entry, three times the cost of the append itself)
     void appendLive(StringView key, StringView val) {
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+        mContents.emplace_back(std::make_pair(key, val), true);  // (as LogEvent.cpp:93 has it -- the stall described above included)
+        return;
+#endif
         mContents.emplace_back(std::piecewise_construct,
                                std::forward_as_tuple(std::piecewise_construct, std::forward_as_tuple(key), std::forward_as_tuple(val)),
                                std::forward_as_tuple(true));
@@ -518,9 +540,13 @@ private:
 };
 
 inline std::shared_ptr<SourceBuffer>& PipelineEvent::GetSourceBuffer() { return mGroup->GetSourceBuffer(); }
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+inline LogEvent::LogEvent(PipelineEventGroup* g) : PipelineEvent(Type::LOG, g) { mContents.reserve(16); }
+#else
 inline LogEvent::LogEvent(PipelineEventGroup* g)
     : PipelineEvent(Type::LOG, g),
       mContents(g ? g->GetSourceBuffer().get() : nullptr) {}
+#endif
 inline void LogEvent::SetContent(StringView key, StringView val) {
     StringBuffer k = GetSourceBuffer()->CopyString(key), v = GetSourceBuffer()->CopyString(val);
     SetContentNoCopy(StringView(k.data, k.size), StringView(v.data, v.size));

@@ -63,11 +63,21 @@ struct ProcessScratch {
     std::vector<int32_t> caps;
 };
 
+// LC_PER_KEY_STITCH: the K fields go in with K x LogEvent::SetContentNoCopy and the source goes with DelContent -- the only way the
+// reference's LogEvent offers (its AppendContentNoCopy is private, LogEvent.h:112-118).  A build against the reference headers takes
+// it, and so does the stand-in when it is built in the reference's shape (event_model.hpp LC_REFERENCE_SHAPED_EVENT_MODEL).
+#if defined(LC_USE_REFERENCE_HEADERS) || defined(LC_REFERENCE_SHAPED_EVENT_MODEL)
+#define LC_PER_KEY_STITCH 1
+#endif
+
 // HasContent + GetContent (:140-150) -- one scan of the event's contents where the event model offers it
 inline bool sourceOf(const LogEvent& ev, const std::string& key, StringView& out) {
 #ifdef LC_USE_REFERENCE_HEADERS
-    if (!ev.HasContent(key)) return false;
-    out = ev.GetContent(key);
+    // (the reference's public single-scan lookup, LogEvent.cpp:123-131 -- HasContent + GetContent are two scans)
+    const LogEvent& cev = ev;
+    const auto it = cev.FindContent(key);
+    if (it == cev.end()) return false;
+    out = it->second;
     return true;
 #else
     const StringView* v = ev.FindContent(key);
@@ -229,7 +239,7 @@ bool ProcessorParseRegexGpu::FinishSourceDropped(LogEvent& sourceEvent, StringVi
 // ProcessorParseRegexNative.cpp:196-244, the alarm side of RegexLogLineParser
 void ProcessorParseRegexGpu::RaiseAlarm(int kind, StringView buffer, StringView logPath) const {
     bool wanted = mAlarmSink != nullptr;
-#ifdef LC_USE_REFERENCE_HEADERS
+#ifdef LC_HAVE_AGENT_CONTEXT
     const bool agent = mContext && AppConfig::GetInstance()->IsLogParseAlarmValid();
     wanted = wanted || agent;
 #endif
@@ -241,7 +251,7 @@ void ProcessorParseRegexGpu::RaiseAlarm(int kind, StringView buffer, StringView 
     message.append(buffer.data(), buffer.size());
     if (kind == 1) message += std::string(" | exception:") + kGaveUp;
     if (mAlarmSink) mAlarmSink(mAlarmUser, kind, message.data(), message.size());
-#ifdef LC_USE_REFERENCE_HEADERS
+#ifdef LC_HAVE_AGENT_CONTEXT
     if (!agent) return;
     if (mContext->GetAlarm().IsLowLevelAlarmValid()) {
         if (kind == 1) {
@@ -263,6 +273,34 @@ void ProcessorParseRegexGpu::RaiseAlarm(int kind, StringView buffer, StringView 
 #else
     (void)logPath;
 #endif
+}
+
+// A failed device call: the group goes on unparsed (there is no CPU path) and the failure is reported where the parse alarms go --
+// the installed sink (kind 3), in an agent build the pipeline's logger and alarm manager under the alarm's own rate limit.  Only a
+// host with neither hears it on stderr, and there once per 1024 failures: a dead device fails every group of every runner thread.
+void ProcessorParseRegexGpu::ReportDeviceFailure(int rc, uint32_t nLines) const {
+    const std::string message = "GPU match failed (rc=" + std::to_string(rc) + ": " + lc_last_error() + "); " + std::to_string(nLines) +
+                                " events left unparsed";
+    bool heard = false;
+    if (mAlarmSink) {
+        mAlarmSink(mAlarmUser, 3, message.data(), message.size());
+        heard = true;
+    }
+#ifdef LC_HAVE_AGENT_CONTEXT
+    if (mContext) {
+        if (mContext->GetAlarm().IsLowLevelAlarmValid())
+            LOG_ERROR(mContext->GetLogger(), ("processor_parse_regex_gpu", message)("project", mContext->GetProjectName())(
+                                                 "logstore", mContext->GetLogstoreName()));
+        mContext->GetAlarm().SendAlarmWarning(REGEX_MATCH_ALARM, message, mContext->GetRegion(), mContext->GetProjectName(),
+                                              mContext->GetConfigName(), mContext->GetLogstoreName());
+        heard = true;
+    }
+#endif
+    if (heard) return;
+    static std::atomic<uint64_t> failures{0};
+    const uint64_t k = failures.fetch_add(1, std::memory_order_relaxed);
+    if ((k & 1023u) == 0)
+        std::fprintf(stderr, "[%s] %s%s\n", sName.c_str(), message.c_str(), k ? " (and 1023 more such groups since the last line)" : "");
 }
 
 void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup) { Process(logGroup, nullptr); }
@@ -320,8 +358,7 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup, EventBytes* e
         int rc = lc_regex_match_host_views(mReg, linePtr, lineLen, nLines, G, scratch.caps.data(), scratch.status.data());
         if (rc != LC_OK) {
             // No CPU fallback exists.  Leave the events exactly as they came in (nothing is lost) and say so loudly.
-            std::fprintf(stderr, "[%s] GPU match failed (rc=%d: %s); %u events left unparsed\n", sName.c_str(), rc,
-                         lc_last_error(), nLines);
+            ReportDeviceFailure(rc, nLines);
             deviceOk = false;
             mDeviceFailedEventsTotal += nLines;
         }
@@ -331,13 +368,18 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup, EventBytes* e
     const int32_t* const caps = scratch.caps.data();
     const uint8_t* const status = scratch.status.data();
     const bool keyCountOk = size_t(G) + 1 > mKeys.size();  // what.size() > keys.size()  :227
-#ifndef LC_USE_REFERENCE_HEADERS
+#ifndef LC_PER_KEY_STITCH
     // no key equals the source key or another key: an event that holds the source content and nothing else takes its K fields and
     // loses its source in one call (same contents, order and size accounting as :249-251 followed by :153-155; the scan for the
     // source skips the K new entries, none of which can be it)
     const bool bulk = mKeysDistinct && !mSourceKeyOverwritten;
-    const StringView sourceKey(mSourceKey);
+#else
+    // Per-key form.  When no key is the source key and a successful parse drops the source (:153-155), the source is dropped BEFORE
+    // the K fields go in: DelContent's scan from the back then meets one entry instead of K + 1, and the list that results is the
+    // same -- the tombstone stays where the source was, the fields follow in Keys order (:249-251), the sizes add up alike.
+    const bool dropSourceFirst = !mSourceKeyOverwritten;
 #endif
+    const StringView sourceKey(mSourceKey);
     size_t wIdx = 0, line = 0;
     for (size_t rIdx = 0; rIdx < nEvents; ++rIdx) {
         bool keep = true;
@@ -351,9 +393,14 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup, EventBytes* e
             if (deviceOk) {
                 LogEvent& ev = events[rIdx].Cast<LogEvent>();
                 const StringView raw(reinterpret_cast<const char*>(linePtr[li]), lineLen[li]);  // = ev.GetContent(mSourceKey)
-#ifndef LC_USE_REFERENCE_HEADERS
+#ifndef LC_PER_KEY_STITCH
                 if (status[li] == LC_MATCH && keyCountOk && bulk && ev.Size() == 1) {
                     ev.AppendCapturesNoCopy(mKeyViews.data(), mKeyViews.size(), raw, &caps[li * 2 * G], &sourceKey);
+#else
+                if (status[li] == LC_MATCH && keyCountOk && dropSourceFirst) {
+                    ev.DelContent(sourceKey);
+                    StitchMatched(ev, raw, &caps[li * 2 * G]);
+#endif
                     if (FinishSourceDropped(ev, raw, true, metadata, tally)) {
                         if (eventBytes) bytesOut += ev.LogEvent::DataSize();
                         if (wIdx != rIdx) events[wIdx] = std::move(events[rIdx]);
@@ -361,7 +408,6 @@ void ProcessorParseRegexGpu::Process(PipelineEventGroup& logGroup, EventBytes* e
                     }
                     continue;
                 }
-#endif
                 bool parseSuccess = true;
                 if (status[li] == LC_OVERFLOW) {
                     // The line was NOT decided (only possible with the decide pass switched off, LC_NFA_NO_DECIDE): boost
@@ -410,14 +456,14 @@ void ProcessorParseRegexGpu::AddTally(const Tally& tally) {
 }
 
 bool ProcessorParseRegexGpu::AlarmsWanted() const {
-#ifdef LC_USE_REFERENCE_HEADERS
+#ifdef LC_HAVE_AGENT_CONTEXT
     if (mContext && AppConfig::GetInstance()->IsLogParseAlarmValid()) return true;
 #endif
     return mAlarmSink != nullptr;
 }
 
 void ProcessorParseRegexGpu::StitchMatched(LogEvent& ev, StringView raw, const int32_t* c) {
-#ifndef LC_USE_REFERENCE_HEADERS
+#ifndef LC_PER_KEY_STITCH
     if (mKeysDistinct && !mSourceKeyOverwritten && ev.Size() == 1) {
         // the event holds only the source content and no key can collide: append all K views at once
         // instead of K reverse scans (same contents, same order as the loop below)

@@ -19,11 +19,17 @@
 #include <memory>  // (core/app_config/AppConfig.h names std::set and std::shared_ptr without including their headers)
 #include <set>
 
+// LC_REFERENCE_MODELS_ONLY: the reference's event model without the agent around it (no AppConfig, pipeline context or alarm
+// manager) -- what tests/test_processor_host_double.py links against oracle/_ref/libref_models.so, the reference's own
+// core/models/*.cpp compiled here
+#ifndef LC_REFERENCE_MODELS_ONLY
+#define LC_HAVE_AGENT_CONTEXT 1
 #include "app_config/AppConfig.h"
 #include "collection_pipeline/CollectionPipelineContext.h"
+#include "monitor/AlarmManager.h"
+#endif
 #include "models/LogEvent.h"
 #include "models/PipelineEventGroup.h"
-#include "monitor/AlarmManager.h"
 #else
 #include "event_model.hpp"
 #endif
@@ -86,14 +92,15 @@ public:
     // The alarms of RegexLogLineParser (ProcessorParseRegexNative.cpp:196-244: REGEX_MATCH_ALARM with the texts below, raised per
     // failing event when AppConfig::IsLogParseAlarmValid()).  kind: 0 = no match ("errorlog:<line>"), 1 = the matcher gave up on
     // the line (boost: the complexity exception; "errorlog:<line> | exception:<text>"), 2 = key count mismatch ("parse key count
-    // not match<what.size()>errorlog:<line>").  In the agent build SetContext() routes them to the pipeline's AlarmManager and
+    // not match<what.size()>errorlog:<line>"), 3 = the device call of a group failed (no reference counterpart: the group goes on
+    // unparsed).  In the agent build SetContext() routes them to the pipeline's AlarmManager and
     // logger exactly as the reference does; any build can also install a sink (tests, hosts without a context).
     using AlarmSink = void (*)(void* user, int kind, const char* message, size_t len);
     void SetAlarmSink(AlarmSink sink, void* user) {
         mAlarmSink = sink;
         mAlarmUser = user;
     }
-#ifdef LC_USE_REFERENCE_HEADERS
+#ifdef LC_HAVE_AGENT_CONTEXT
     void SetContext(CollectionPipelineContext* context) { mContext = context; }
 #endif
 
@@ -120,9 +127,10 @@ private:
     bool AlarmsWanted() const;
 
     void RaiseAlarm(int kind, StringView buffer, StringView logPath) const;
+    void ReportDeviceFailure(int rc, uint32_t nLines) const;  // alarm kind 3: "GPU match failed (rc=..: ..); N events left unparsed"
     AlarmSink mAlarmSink = nullptr;
     void* mAlarmUser = nullptr;
-#ifdef LC_USE_REFERENCE_HEADERS
+#ifdef LC_HAVE_AGENT_CONTEXT
     CollectionPipelineContext* mContext = nullptr;
 #endif
 

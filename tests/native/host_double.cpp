@@ -7,6 +7,12 @@
 // tests/_build/libhost_double.so and run every reference unit-test vector and the policy matrix through the PRODUCT's host
 // translation units here, where there is no device -- and time the stitch (hd_bench_stitch) without a device in the way.
 //
+// Second variant (-DLC_USE_REFERENCE_HEADERS -DLC_REFERENCE_MODELS_ONLY): the same product translation unit compiled against the
+// REFERENCE's own event-model headers and linked with oracle/_ref/libref_models.so -- core/models/LogEvent.cpp, PipelineEventGroup.cpp,
+// SourceBuffer.h ... compiled from /root/reference by oracle/ref_models/Makefile.  There the stitch is the per-key form an agent build
+// takes (K x LogEvent::SetContentNoCopy + DelContent, LogEvent.cpp:83-106) and runs against the real thing; fixtures go in and out
+// through tests/native/ref_group_io.cpp (the reference's FromJsonString exists only in its own unit-test builds and needs jsoncpp).
+//
 // It lives under tests/, is built only by the test that uses it and is never linked into loongcollector_amd/lib: the product
 // library has no such path and fails loudly without the HIP runtime (tests/test_processor_host.py).
 #include <sys/resource.h>
@@ -85,6 +91,17 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
     return LC_OK;
 }
 
+#ifdef LC_USE_REFERENCE_HEADERS
+bool hdGroupFromJson(logtail::PipelineEventGroup& group, const std::string& json, std::string* error);  // ref_group_io.cpp
+std::string hdGroupToJson(const logtail::PipelineEventGroup& group);
+#endif
+// PipelineEventGroup::DataSize() minus its events' own sizes (tags + container), with either event model
+static size_t groupBytesWithoutEvents(const logtail::PipelineEventGroup& group) {
+    size_t n = group.DataSize();
+    for (const auto& e : group.GetEvents()) n -= e->DataSize();
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------- what the test drives
 struct hd_processor {
     logtail::ProcessorParseRegexGpu impl;
@@ -134,7 +151,11 @@ char* hd_process_json(hd_processor* p, const char* groupJson, char* err, size_t 
     auto sb = std::make_shared<logtail::SourceBuffer>();
     logtail::PipelineEventGroup group(sb);
     std::string error;
+#ifdef LC_USE_REFERENCE_HEADERS
+    if (!hdGroupFromJson(group, groupJson, &error)) {
+#else
     if (!group.FromJsonString(groupJson, &error)) {
+#endif
         std::snprintf(err, errcap, "%s", error.c_str());
         return nullptr;
     }
@@ -143,9 +164,13 @@ char* hd_process_json(hd_processor* p, const char* groupJson, char* err, size_t 
     p->sizes[0] = group.DataSize();
     p->impl.Process(group, &bytes);
     p->sizes[1] = group.DataSize();
-    p->sizes[2] = group.DataSizeWithoutEvents() + bytes.in;
-    p->sizes[3] = group.DataSizeWithoutEvents() + bytes.out;
+    p->sizes[2] = groupBytesWithoutEvents(group) + bytes.in;
+    p->sizes[3] = groupBytesWithoutEvents(group) + bytes.out;
+#ifdef LC_USE_REFERENCE_HEADERS
+    return strdup(hdGroupToJson(group).c_str());
+#else
     return strdup(group.ToJsonString().c_str());
+#endif
 }
 void hd_last_sizes(const hd_processor* p, uint64_t out[4]) {  // DataSize() before, after; the processor's sums for the same two
     for (int i = 0; i < 4; ++i) out[i] = p->sizes[i];
@@ -171,6 +196,17 @@ void hd_counters(const hd_processor* p, uint64_t out[7]) {
 
 // The arena chunk pool of the event model (csrc/event_model.hpp ArenaChunkPool): full-size chunks of a dead SourceBuffer are handed
 // to the next one, smaller chunks and big blocks are not, the pool is bounded.  Returns 0, or the number of the check that failed.
+#ifdef LC_USE_REFERENCE_HEADERS
+extern "C" int hd_arena_pool_check(void) { return -1; }          // (the stand-in's pool and container: not in this variant)
+extern "C" int hd_contents_container_check(void) { return -1; }
+extern "C" int hd_event_model_is_reference(void) { return 1; }
+#else
+#ifdef LC_REFERENCE_SHAPED_EVENT_MODEL
+extern "C" int hd_event_model_is_reference(void) { return 2; }  // the stand-in built in the reference's shape
+extern "C" int hd_arena_pool_check(void) { return -1; }
+extern "C" int hd_contents_container_check(void) { return -1; }
+#else
+extern "C" int hd_event_model_is_reference(void) { return 0; }
 extern "C" int hd_arena_pool_check(void) {
     using logtail::ArenaChunkPool;
     using logtail::SourceBuffer;
@@ -247,6 +283,9 @@ extern "C" int hd_contents_container_check(void) {
     return 0;
 }
 
+#endif  // LC_REFERENCE_SHAPED_EVENT_MODEL
+#endif  // LC_USE_REFERENCE_HEADERS
+
 static double gLastMinorFaultsPerGroup = 0;
 extern "C" double hd_last_minor_faults_per_group(void) { return gLastMinorFaultsPerGroup; }  // of the last repeat
 
@@ -295,7 +334,7 @@ extern "C" double hd_bench_stitch(hd_processor* p, const uint8_t* data, const ui
         for (auto& g : gs) {  // what lc_processor_process does around the device trip (csrc/c_processor_slot.cpp processGroup)
             logtail::ProcessorParseRegexGpu::EventBytes bytes;
             p->impl.Process(*g, &bytes);
-            sizeSink += g->DataSizeWithoutEvents() * 2 + bytes.in + bytes.out;
+            sizeSink += bytes.in + bytes.out;
         }
         const auto t1 = clk::now();
         if (sizeSink == 1) std::fprintf(stderr, " ");

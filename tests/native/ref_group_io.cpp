@@ -1,0 +1,119 @@
+// tests/native/ref_group_io.cpp -- TEST INFRASTRUCTURE: fixture JSON <-> the REFERENCE's PipelineEventGroup, through its public interface
+// only (core/models/PipelineEventGroup.h:80-158, LogEvent.h:64-132, RawEvent.h).  The reference's own FromJsonString / ToJsonString
+// exist only under APSARA_UNIT_TEST_MAIN and need jsoncpp (core/models/LogEvent.cpp:169-209); this file reads and writes the same
+// fixture format with the repo's small JSON reader, so that tests/native/host_double.cpp can drive the product's processor against
+// oracle/_ref/libref_models.so.  Same conventions as csrc/event_model.cpp: object contents are applied in key order (jsoncpp's
+// iteration order), the [[key, value], ...] form keeps the given order; live contents are written in list order.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../loongcollector_amd/csrc/json_min.hpp"
+#include "models/LogEvent.h"
+#include "models/PipelineEventGroup.h"
+#include "models/RawEvent.h"
+
+namespace {
+using logtail::EventGroupMetaKey;
+const std::pair<const char*, EventGroupMetaKey> kMetaNames[] = {
+    {"log.file.path_resolved", EventGroupMetaKey::LOG_FILE_PATH_RESOLVED},
+    {"log.file.offset", EventGroupMetaKey::LOG_FILE_OFFSET_KEY},
+    {"has.part.log", EventGroupMetaKey::HAS_PART_LOG},
+    {"source.id", EventGroupMetaKey::SOURCE_ID},
+};
+}  // namespace
+
+bool hdGroupFromJson(logtail::PipelineEventGroup& group, const std::string& json, std::string* error) {
+    using namespace logtail;
+    lcjson::Value root;
+    try {
+        root = lcjson::parse(json);
+    } catch (const std::exception& e) {
+        if (error) *error = e.what();
+        return false;
+    }
+    if (const lcjson::Value* md = root.find("metadata"))
+        for (const auto& kv : md->obj)
+            for (const auto& name : kMetaNames)
+                if (kv.first == name.first) group.SetMetadata(name.second, kv.second.str);
+    if (const lcjson::Value* tags = root.find("tags"))
+        for (const auto& kv : tags->obj) group.SetTag(kv.first, kv.second.str);
+    const lcjson::Value* events = root.find("events");
+    if (!events) return true;
+    for (const lcjson::Value& ev : events->arr) {
+        const lcjson::Value* type = ev.find("type");
+        const int t = type ? int(type->inum) : 1;
+        PipelineEvent* base = nullptr;
+        if (t == int(PipelineEvent::Type::LOG)) {
+            LogEvent* le = group.AddLogEvent();
+            base = le;
+            if (const lcjson::Value* contents = ev.find("contents")) {
+                if (contents->isObject()) {
+                    std::vector<const std::pair<std::string, lcjson::Value>*> members;
+                    for (const auto& kv : contents->obj) members.push_back(&kv);
+                    std::stable_sort(members.begin(), members.end(), [](const auto* a, const auto* b) { return a->first < b->first; });
+                    for (const auto* kv : members) le->SetContent(kv->first, kv->second.str);
+                } else {
+                    for (const auto& pair : contents->arr)
+                        if (pair.arr.size() == 2) le->SetContent(pair.arr[0].str, pair.arr[1].str);
+                }
+            }
+            const lcjson::Value* fo = ev.find("fileOffset");
+            const lcjson::Value* rs = ev.find("rawSize");
+            if (fo && rs) le->SetPosition(uint64_t(fo->inum), uint64_t(rs->inum));
+        } else {
+            RawEvent* re = group.AddRawEvent();
+            base = re;
+            if (const lcjson::Value* c = ev.find("content")) re->SetContent(c->str);
+        }
+        const lcjson::Value* ts = ev.find("timestamp");
+        const lcjson::Value* ns = ev.find("timestampNanosecond");
+        if (ts && ns) base->SetTimestamp(time_t(ts->inum), uint32_t(ns->inum));
+        else if (ts) base->SetTimestamp(time_t(ts->inum));
+    }
+    return true;
+}
+
+std::string hdGroupToJson(const logtail::PipelineEventGroup& group) {
+    using namespace logtail;
+    lcjson::Value root = lcjson::Value::makeObject();
+    if (!group.GetAllMetadata().empty()) {
+        lcjson::Value md = lcjson::Value::makeObject();
+        for (const auto& kv : group.GetAllMetadata())
+            for (const auto& name : kMetaNames)
+                if (kv.first == name.second) md.set(name.first, lcjson::Value::makeString(kv.second.to_string()));
+        root.set("metadata", std::move(md));
+    }
+    if (!group.GetTags().empty()) {
+        lcjson::Value tags = lcjson::Value::makeObject();
+        for (const auto& kv : group.GetTags()) tags.set(kv.first.to_string(), lcjson::Value::makeString(kv.second.to_string()));
+        root.set("tags", std::move(tags));
+    }
+    if (!group.GetEvents().empty()) {
+        lcjson::Value events = lcjson::Value::makeArray();
+        for (const auto& e : group.GetEvents()) {
+            lcjson::Value ev = lcjson::Value::makeObject();
+            if (e.Is<LogEvent>()) {
+                const LogEvent& le = e.Cast<LogEvent>();
+                if (!le.Empty()) {
+                    lcjson::Value contents = lcjson::Value::makeObject();
+                    for (auto it = le.cbegin(); it != le.cend(); ++it)
+                        contents.obj.emplace_back(it->first.to_string(), lcjson::Value::makeString(it->second.to_string()));
+                    ev.set("contents", std::move(contents));
+                }
+                if (le.GetPosition().second) {
+                    ev.set("fileOffset", lcjson::Value::makeInt(int64_t(le.GetPosition().first)));
+                    ev.set("rawSize", lcjson::Value::makeInt(int64_t(le.GetPosition().second)));
+                }
+            } else if (e.Is<RawEvent>()) {
+                ev.set("content", lcjson::Value::makeString(e.Cast<RawEvent>().GetContent().to_string()));
+            }
+            ev.set("timestamp", lcjson::Value::makeInt(int64_t(e->GetTimestamp())));
+            if (e->GetTimestampNanosecond()) ev.set("timestampNanosecond", lcjson::Value::makeInt(int64_t(*e->GetTimestampNanosecond())));
+            ev.set("type", lcjson::Value::makeInt(int64_t(e->GetType())));
+            events.arr.push_back(std::move(ev));
+        }
+        root.set("events", std::move(events));
+    }
+    return lcjson::dump(root);
+}

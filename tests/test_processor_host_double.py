@@ -29,19 +29,58 @@ LC_NOMATCH, LC_MATCH, LC_OVERFLOW, LC_GAVE_UP = 0, 1, 2, 3
 LC_ERR_HIP = 4
 
 
-@pytest.fixture(scope="module")
-def double():
-    _oracle.build() if hasattr(_oracle, "build") else None
-    out_dir = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libhost_double.so")
+REF = "/root/reference/core"
+
+
+def _build_standin(out_dir, refshape=False):
+    """refshape: csrc/event_model.hpp built with LC_REFERENCE_SHAPED_EVENT_MODEL (heap std::vector contents reserved to 16, no chunk
+    pool, per-key stitch) -- the shape bench.py's in_agent_reference_shape_MBps leg measures on the GPU box"""
+    so = os.path.join(out_dir, "libhost_double_refshape.so" if refshape else "libhost_double.so")
     csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "host_double.cpp"), os.path.join(csrc, "processor_parse_regex_gpu.cpp"),
             os.path.join(csrc, "event_model.cpp")]
     deps = srcs + [os.path.join(csrc, h) for h in ("event_model.hpp", "processor_parse_regex_gpu.hpp", "json_min.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so] + srcs +
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so] +
+                              (["-DLC_REFERENCE_SHAPED_EVENT_MODEL"] if refshape else []) + srcs +
                               ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return so
+
+
+def _build_reference(out_dir):
+    """the product's processor_parse_regex_gpu.cpp compiled against the REFERENCE's event-model headers and linked with
+    oracle/_ref/libref_models.so = core/models/*.cpp of /root/reference compiled by oracle/ref_models/Makefile (the per-key stitch
+    an agent build takes, on the real LogEvent::SetContentNoCopy / DelContent / SourceBuffer)"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_models")])
+    so = os.path.join(out_dir, "libhost_double_ref.so")
+    csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "native", "host_double.cpp"), os.path.join(ROOT, "tests", "native", "ref_group_io.cpp"),
+            os.path.join(csrc, "processor_parse_regex_gpu.cpp")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("processor_parse_regex_gpu.hpp", "json_min.hpp")] + [
+        os.path.join(ROOT, "oracle", "_ref", "libref_models.so")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        ref_lib = os.path.join(ROOT, "oracle", "_ref")
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-DLC_USE_REFERENCE_HEADERS", "-DLC_REFERENCE_MODELS_ONLY",
+                               "-I", os.path.join(ROOT, "oracle", "ref_models", "stubs"), "-I", os.path.join(ROOT, "tests", "refhdr"),
+                               "-I", REF, "-I", os.path.join(REF, "config"), "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so] + srcs +
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-L" + ref_lib, "-lref_models",
+                               "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath," + ref_lib, "-Wl,-z,defs"])
+    return so
+
+
+@pytest.fixture(scope="module", params=["standin", "refshape", "reference"])
+def double(request):
+    """standin: the product's host code on csrc/event_model.hpp (what the standalone library ships).  reference: the same product
+    source on the reference's OWN LogEvent / PipelineEventGroup / SourceBuffer, compiled from /root/reference (oracle/_ref)."""
+    _oracle.build() if hasattr(_oracle, "build") else None
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    if request.param == "reference":
+        if not os.path.isdir(REF):
+            pytest.skip("needs the reference tree (/root/reference): its event model is compiled from there")
+        so = _build_reference(out_dir)
+    else:
+        so = _build_standin(out_dir, refshape=request.param == "refshape")
     L = ctypes.CDLL(so)
     vp, cp = ctypes.c_void_p, ctypes.c_char_p
     L.hd_create.restype = vp
@@ -59,6 +98,8 @@ def double():
     L.hd_bench_stitch.restype = ctypes.c_double
     L.hd_bench_stitch.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, cp, ctypes.c_uint32,
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.hd_event_model_is_reference.restype = ctypes.c_int
+    assert L.hd_event_model_is_reference() == {"standin": 0, "reference": 1, "refshape": 2}[request.param]
     yield L
     L.hd_force(-1, 0)
 
@@ -221,10 +262,13 @@ def test_what_the_device_can_answer_besides_match_and_no_match(double):
         assert p.process({"events": events}) == [[("content", "x y")], [("content", "p q")]]
         c = p.counters()
         assert (c["undecided"], c["out_failed"], c["out_successful"], c["discarded"]) == (2, 0, 0, 0)
-        # the device call failed: nothing is lost, nothing is parsed, the events are counted
+        # the device call failed: nothing is lost, nothing is parsed, the events are counted -- and the failure is reported through the
+        # alarm sink (kind 3), not as a line on stderr per group
         double.hd_force(-1, LC_ERR_HIP)
         p = HostProcessor(double, dict(cfg, KeepingSourceWhenParseFail=False))
+        double.hd_want_alarms(p.h)
         assert p.process({"events": events}) == [[("content", "x y")], [("content", "p q")]]
+        assert p.alarms() == [(3, b"GPU match failed (rc=4: forced failure of the test double); 2 events left unparsed")]
         c = p.counters()
         assert (c["device_failed"], c["out_failed"], c["out_successful"], c["discarded"]) == (2, 0, 0, 0)
     finally:
@@ -279,6 +323,8 @@ def test_the_stitch_bench_entry_runs(double):
 def test_arena_chunks_go_round_through_the_pool(double):
     """csrc/event_model.hpp ArenaChunkPool: a dead group's full-size arena chunks serve the next group's stitch (no first-touch page
     faults in an agent's steady state); smaller chunks and big blocks are not pooled; the pool is bounded."""
+    if double.hd_event_model_is_reference():
+        pytest.skip("the chunk pool belongs to the stand-in event model")
     double.hd_arena_pool_check.restype = ctypes.c_int
     assert double.hd_arena_pool_check() == 0
 
@@ -286,5 +332,7 @@ def test_arena_chunks_go_round_through_the_pool(double):
 def test_contents_container_in_the_arena_and_on_the_heap(double):
     """csrc/event_model.hpp ArenaVector behind LogEvent: overwrite, tombstone, growth and the one-call stitch keep contents, order
     and size accounting -- for an event of a group (arena) and for one made outside any group (heap)."""
+    if double.hd_event_model_is_reference():
+        pytest.skip("ArenaVector belongs to the stand-in event model")
     double.hd_contents_container_check.restype = ctypes.c_int
     assert double.hd_contents_container_check() == 0
