@@ -71,6 +71,9 @@ int lc_grok_column_key(const lc_grok_t* g, int i, int column);     /* key index 
 int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per capture row: 2 * (1 + max column count) */
 
 /* ---- device-resident batch (inputs and outputs in HBM; nothing is copied) ------------------------------------------
+ * d_data: the values' bytes; 16-byte aligned, its allocation ending on a 16-byte boundary at or behind the last value (the kernels
+ *             read aligned 4- and 16-byte units around a value's ends: lc_regex_gpu.h, "the contract for d_data"; any hipMalloc /
+ *             torch allocation qualifies).
  * d_off/d_len: uint32[n] byte offsets / lengths of the SourceKey values inside d_data.
  * d_pattern  int32[n]            winning Match index, -1 = matchFail, -2 = undecidable on the device (the NFA engine ran out
  *                                of threads on this value and nothing settled it), -3 = an entry gave up on the value (the

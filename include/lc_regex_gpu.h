@@ -210,7 +210,15 @@ int lc_runtime_set_thread_device(int device);
 int lc_runtime_thread_device(void);
 int lc_runtime_device_for_ordinal(uint32_t ordinal, int ndevices);
 
-/* Match n lines that already live in device memory on the current HIP device.
+/* Device buffers handed to the lc_*_device entry points -- the contract for d_data:
+ *   the kernels read d_data in naturally ALIGNED units of up to 16 bytes (dword / dwordx4 loads, LDS-DMA rows), i.e. they may touch
+ *   the bytes between a line's first byte and the 16-byte boundary below it, and between its last byte and the 16-byte boundary above
+ *   it.  Those bytes are never interpreted, but they must be readable: d_data must be 16-byte aligned and its ALLOCATION must end on
+ *   a 16-byte boundary at or behind the last line's end.  Every hipMalloc / hipMallocAsync / torch allocation satisfies this (256-byte
+ *   granularity); a sub-range carved by the caller out of a larger allocation does too as long as the range starts 16-byte aligned.
+ *   Lines themselves may start and end anywhere.  d_off / d_len / d_caps are 4-byte aligned arrays of their element type.
+ *
+ * Match n lines that already live in device memory on the current HIP device.
  *   d_data   : line bytes (any layout); line i = d_data[d_off[i] .. d_off[i]+d_len[i])
  *   d_len    : may be NULL, then d_off has n+1 entries and len[i] = d_off[i+1]-d_off[i]-sep_bytes
  *   ngroups  : number of (begin,end) pairs written per line (normally lc_regex_mark_count)

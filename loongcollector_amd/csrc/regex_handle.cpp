@@ -328,7 +328,13 @@ static void lcTryStandardPairTable(lc_regex* re, bool fold) {
         const char* e = getenv("LC_TDFA_STD_PAIR");
         return e && e[0] == '0';
     }();
-    if (off || getenv("LC_TDFA_PAIR") || !re->tdfa.startAfter.empty() || !re->tdfaBlock) return;
+    // (LC_TDFA_STREAM=0, the A/B knob that sends every launch to the phase-separated kernel, cannot run one-stamp tables: the
+    // standard blob then keeps its single-byte tables instead of making default patterns fail)
+    static const bool streamOff = [] {
+        const char* e = getenv("LC_TDFA_STREAM");
+        return e && e[0] == '0';
+    }();
+    if (off || streamOff || getenv("LC_TDFA_PAIR") || !re->tdfa.startAfter.empty() || !re->tdfaBlock) return;
     try {
         std::vector<uint32_t> blob = lcregex::packTdfaBlob(re->tdfa, re->tdfaBlock, false, false, fold, 2);
         const uint32_t po = blob[TD_OFF_PAIR];
@@ -1524,7 +1530,12 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                 // of an anchored Grok format that does not determinise (5-50 s of a core each, 16 of the 50 entries of configs[2]):
                 // the verdict is remembered for the life of the process, so that reloading a pipeline -- the agent does that in
                 // place -- does not pay for it again.  Same return code, same message; nothing is remembered about successes.
-                const std::string memoKey = re->pattern + '\0' + std::to_string(syntax_flags) + '/' + std::to_string(engine);
+                // (the limits that produce the verdict are part of the key: a process that changes LC_TDFA_L2_MAX_* between two
+                // compiles must not get the old verdict back)
+                const char* envWork = getenv("LC_TDFA_L2_MAX_WORK");
+                const char* envCommit = getenv("LC_TDFA_L2_MAX_COMMIT");
+                const std::string memoKey = re->pattern + '\0' + std::to_string(syntax_flags) + '/' + std::to_string(engine) + '/' +
+                                            std::to_string(l2States) + '/' + (envWork ? envWork : "") + '/' + (envCommit ? envCommit : "");
                 std::string remembered;
                 if (l2States && !outOfWork && lcRecallTdfaFailure(memoKey, remembered)) {
                     re->tdfaError += remembered;
@@ -1575,7 +1586,8 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
                     } catch (const RegexError& e2) {
                         const std::string suffix = std::string("; with its tables in global memory: ") + e2.what();
                         re->tdfaError += suffix;
-                        lcRememberTdfaFailure(memoKey, suffix);
+                        // only what is expensive to find out again: a construction that ran into its state or work limit
+                        if (suffix.find("limit") != std::string::npos) lcRememberTdfaFailure(memoKey, suffix);
                     }
                 }
                 if (!l2 && engine == LC_ENGINE_TDFA) throw RegexError(re->tdfaError);
