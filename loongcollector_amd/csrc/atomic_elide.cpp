@@ -45,6 +45,7 @@ std::unique_ptr<Node> cloneNode(const Node& n, bool stripAtomics) {
     c->look = n.look;
     c->aheadSeq = n.aheadSeq;
     c->aheadNegative = n.aheadNegative;
+    c->window = n.window;
     c->runCapture = n.runCapture;
     for (const auto& k : n.kids) c->kids.push_back(cloneNode(*k, stripAtomics));
     return c;

@@ -84,6 +84,14 @@ struct Node {
     // the parser drops it when what follows already implies it, and refuses the pattern otherwise (regex_parse.cpp).
     std::vector<ByteSet> aheadSeq;
     bool aheadNegative = false;
+    // round 5: ... and when what follows does NOT decide it, the look-ahead stays in the tree as a WINDOW (window = true): the next
+    // aheadSeq.size() bytes must (positive) / must not (negative) be in aheadSeq[0], aheadSeq[1], ...  buildFollowNfa turns windows into
+    // a product of the follow NFA with the window's chain (follow_nfa.cpp): "(?= } ntoreturn:)" of the library's MONGO_QUERY.
+    bool window = false;
+    // parser-internal: a look-BEHIND whose body is a sequence of >= 2 character classes ("(?<={ )").  Decided by the parser from the
+    // fixed-width sub-expressions in front of it, or the pattern is refused.
+    std::vector<ByteSet> behindSeq;
+    bool behindNegative = false;
     // Group written "(?=(S*))" -- a look-ahead that always holds and whose only effect is the capture: the group begins
     // at the current offset and runs over the bytes of `set` that follow (Grok's "(?=%{GREEDYDATA:message})").  The
     // automata stamp the BEGIN slot only; the end is a function of the begin and is filled in after the match

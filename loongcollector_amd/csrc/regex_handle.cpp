@@ -990,6 +990,7 @@ static void setErr(char* err, size_t cap, const std::string& msg) {
 // can test (status only) before the slow NFA kernel is asked for the captures.
 static std::unique_ptr<Node> cloneWithoutCaptures(const Node& n) {
     auto c = std::make_unique<Node>();
+    if (n.kind == Node::Assert && n.window) return c;  // (a look-ahead window only narrows the matches: a screen may ignore it)
     c->kind = n.kind;
     c->set = n.set;
     c->min = n.min;

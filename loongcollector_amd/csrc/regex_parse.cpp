@@ -410,6 +410,17 @@ private:
             a->aheadNegative = negative;
             return a;
         }
+        if (behind && n->kind == Node::Cat) {  // (?<=AB..) / (?<!AB..): decided in sequence() from what stands in front of it
+            auto a = mk(Node::Assert);
+            for (const auto& k : n->kids) {
+                const Node* e = k.get();
+                while ((e->kind == Node::Group && e->capture == 0) && e->kids.size() == 1) e = e->kids[0].get();
+                if (e->kind != Node::Set) bail("unsupported: look-behind body must be a sequence of character classes");
+                a->behindSeq.push_back(e->set);
+            }
+            a->behindNegative = negative;
+            return a;
+        }
         if (n->kind != Node::Set) bail("unsupported: look-around body must be a single character class");
         ByteSet set = n->set;
         if (negative) set.invert();
@@ -702,16 +713,20 @@ private:
         }
         // Multi-byte look-aheads (the library's "(?!<[0-9])%{HOUR}" -- a mistyped look-behind): the automata only look
         // one byte ahead, but when the rest of this sequence cannot begin with the look-ahead's first class the answer
-        // is already known on every path that goes on to match: a negative one holds, a positive one fails.
+        // is already known on every path that goes on to match: a negative one holds, a positive one fails.  What the rest of the
+        // sequence does not decide stays in the tree as a window (regex_ast.hpp; follow_nfa.cpp builds the product).
         for (size_t i = 0; i < seq->kids.size(); ++i) {
             Node& k = *seq->kids[i];
-            if (k.kind != Node::Assert || k.aheadSeq.empty()) continue;
+            if (k.kind != Node::Assert || k.aheadSeq.empty() || k.window) continue;
             ByteSet first;
             bool restNullable = true;
             for (size_t j = i + 1; j < seq->kids.size() && restNullable; ++j) restNullable = firstOf(*seq->kids[j], first);
             bool disjoint = !restNullable;
             for (int w = 0; w < 4 && disjoint; ++w) disjoint = (first.w[w] & k.aheadSeq[0].w[w]) == 0;
-            if (!disjoint) bail("unsupported: multi-byte look-ahead that the following sub-expression does not decide");
+            if (!disjoint) {
+                k.window = true;
+                continue;
+            }
             if (k.aheadNegative) {
                 seq->kids[i] = mk(Node::Empty);
             } else {
@@ -719,13 +734,85 @@ private:
                 seq->kids[i] = std::move(never);
             }
         }
+        // Multi-byte look-behinds ("\\{ (?<={ )" of the library's MONGO_QUERY): decided here when the sub-expressions in front of the
+        // assertion, inside this sequence, have a fixed width that covers the body -- the bytes the body looks at are then bytes this
+        // sequence has just consumed, position by position.  Body class j holds for certain when it contains every byte the pattern
+        // allows there, and fails for certain when it contains none of them.  Anything else (the body reaches back beyond this sequence,
+        // or a class overlaps without containing) would need the history of the input in the automaton: refused.
+        for (size_t i = 0; i < seq->kids.size(); ++i) {
+            Node& k = *seq->kids[i];
+            if (k.kind != Node::Assert || k.behindSeq.empty()) continue;
+            std::vector<ByteSet> before;  // before[d] = bytes the pattern allows d + 1 bytes in front of the assertion
+            for (size_t j = i; j-- > 0 && before.size() < k.behindSeq.size();) {
+                std::vector<ByteSet> w;
+                if (!fixedWidthSets(*seq->kids[j], w)) break;
+                for (size_t q = w.size(); q-- > 0;) before.push_back(w[q]);
+            }
+            if (before.size() < k.behindSeq.size())
+                bail("unsupported: multi-byte look-behind that the preceding sub-expression does not decide");
+            bool holds = true, fails = false;
+            const size_t n = k.behindSeq.size();
+            for (size_t d = 0; d < n; ++d) {
+                const ByteSet& want = k.behindSeq[n - 1 - d];
+                const ByteSet& have = before[d];
+                bool subset = true, meet = false;
+                for (int w = 0; w < 4; ++w) {
+                    subset = subset && (have.w[w] & ~want.w[w]) == 0;
+                    meet = meet || (have.w[w] & want.w[w]) != 0;
+                }
+                holds = holds && subset;
+                fails = fails || !meet;
+            }
+            if (!holds && !fails) bail("unsupported: multi-byte look-behind that the preceding sub-expression does not decide");
+            const bool truth = k.behindNegative ? fails : holds;
+            if (truth) seq->kids[i] = mk(Node::Empty);
+            else seq->kids[i] = mk(Node::Set);  // empty class: this branch cannot match
+        }
         if (seq->kids.empty()) return mk(Node::Empty);
         if (seq->kids.size() == 1) {
-            if (seq->kids[0]->kind == Node::Assert && !seq->kids[0]->aheadSeq.empty())
-                bail("unsupported: multi-byte look-ahead that the following sub-expression does not decide");
+            if (seq->kids[0]->kind == Node::Assert && !seq->kids[0]->aheadSeq.empty()) seq->kids[0]->window = true;
             return std::move(seq->kids[0]);
         }
         return seq;
+    }
+
+    // the byte classes of a sub-expression every match of which has the same length (appended to `out` in input order); false if it has
+    // no such form (a repeat with a range, alternatives of different shapes, assertions inside)
+    static bool fixedWidthSets(const Node& n, std::vector<ByteSet>& out) {
+        switch (n.kind) {
+            case Node::Empty: return true;
+            case Node::Set: out.push_back(n.set); return true;
+            case Node::Cat:
+                for (const auto& k : n.kids)
+                    if (!fixedWidthSets(*k, out)) return false;
+                return true;
+            case Node::Group:
+                if (n.runCapture) return false;
+                return fixedWidthSets(*n.kids[0], out);
+            case Node::Repeat: {
+                if (n.min != n.max || n.min < 0 || n.min > 64) return false;
+                for (int r = 0; r < n.min; ++r)
+                    if (!fixedWidthSets(*n.kids[0], out)) return false;
+                return true;
+            }
+            case Node::Alt: {  // alternatives of one width: position by position the union
+                std::vector<ByteSet> acc;
+                for (size_t a = 0; a < n.kids.size(); ++a) {
+                    std::vector<ByteSet> w;
+                    if (!fixedWidthSets(*n.kids[a], w)) return false;
+                    if (a == 0) acc = w;
+                    else {
+                        if (w.size() != acc.size()) return false;
+                        for (size_t q = 0; q < w.size(); ++q) acc[q].unite(w[q]);
+                    }
+                }
+                out.insert(out.end(), acc.begin(), acc.end());
+                return true;
+            }
+            case Node::Assert: return n.aheadSeq.empty() && n.behindSeq.empty();  // (one-byte assertions are zero-width: transparent)
+            case Node::Atomic: return false;
+        }
+        return false;
     }
 
     // FIRST set of a sub-expression (bytes a match of it can begin with) ORed into `out`; returns whether it can match

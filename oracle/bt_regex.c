@@ -13,7 +13,7 @@
  *   - a repeat whose body last matched the empty string stops iterating (match_rep's null check);
  *   - a state-count budget; exceeding it returns -1 (boost throws std::runtime_error, which the
  *     reference swallows into "parse failed", StringTools.cpp:200-205).
- * Unsupported (compile error): back-references, look-around, atomic/possessive, recursion,
+ * Unsupported (compile error): back-references, look-behind bodies of variable length, atomic/possessive, recursion,
  * conditionals, \p{..}, collating elements.
  */
 #include "bt_regex.h"
@@ -76,7 +76,8 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 }
 
 /* ------------------------------------------------------------------ AST */
-enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC, N_LOOKAHEAD /* general (?=X) (?!X): max = negative */ };
+enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC,
+       N_LOOKAHEAD /* general (?=X) (?!X): max = negative; min = k > 0: the look-BEHIND (?<=X) (?<!X) of a body of fixed length k */ };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
     A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
@@ -93,7 +94,8 @@ typedef struct {
 } node;
 
 #define ORX_MAX_GROUPS 1023
-enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END, I_LOOK_BEGIN, I_LOOK_END, I_NLOOK_BEGIN, I_NLOOK_END };
+enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END, I_LOOK_BEGIN, I_LOOK_END, I_NLOOK_BEGIN, I_NLOOK_END,
+       I_BACK /* x = k: step back k bytes (inside a look-behind, right behind its mark); fewer than k behind: backtrack */ };
 typedef struct { int op, x, y, z, w; } inst;
 /* I_REPSET: x=set, y=min, z=max(-1 inf), w=greedy */
 
@@ -277,6 +279,21 @@ static int assert_node(orx_prog* P, int kind) {
     return n;
 }
 
+/* length of every match of node n if that is one number (a look-behind body must have one: Perl, PCRE, regexp2 and boost agree on
+ * "fixed length" for the bodies the log patterns use), else -1 */
+static int fixed_len(const orx_prog* P, int n) {
+    const node* nd = &P->nodes[n];
+    switch (nd->kind) {
+        case N_EMPTY: case N_ASSERT: case N_LOOKAHEAD: return 0;
+        case N_SET: return 1;
+        case N_CAT: { int a = fixed_len(P, nd->l), b = fixed_len(P, nd->r); return (a < 0 || b < 0) ? -1 : a + b; }
+        case N_ALT: { int a = fixed_len(P, nd->l), b = fixed_len(P, nd->r); return (a < 0 || a != b) ? -1 : a; }
+        case N_REP: { int a = fixed_len(P, nd->l); return (a < 0 || nd->min != nd->max) ? -1 : a * nd->min; }
+        case N_GROUP: case N_ATOMIC: return fixed_len(P, nd->l);
+    }
+    return -1;
+}
+
 /* (?=X) (?!X) (?<=X) (?<!X) with X a single character class (one-byte look-around); P->i is past the introducer */
 static int parse_lookaround(orx_prog* P, int depth, int behind, int negative) {
     unsigned saved = P->flags;
@@ -288,10 +305,15 @@ static int parse_lookaround(orx_prog* P, int depth, int behind, int negative) {
     while (P->nodes[inner].kind == N_GROUP && P->nodes[inner].cap == 0) inner = P->nodes[inner].l;
     if (P->nodes[inner].kind != N_SET) {
         /* a general look-AHEAD is just a sub-match the backtracker runs in place (atomic, zero-width) */
-        if (behind) { fail(P, "unsupported: look-behind body must be a single character class"); return -1; }
+        int back = 0;
+        if (behind) { /* a body of fixed length k: the same sub-match, started k bytes back (it then ends where the assertion stands) */
+            back = fixed_len(P, inner);
+            if (back <= 0) { fail(P, "unsupported: look-behind body must have a fixed, non-zero length"); return -1; }
+        }
         int la = new_node(P, N_LOOKAHEAD);
         P->nodes[la].l = inner;
         P->nodes[la].max = negative;
+        P->nodes[la].min = back;
         return la;
     }
     int n = new_node(P, N_ASSERT);
@@ -584,6 +606,7 @@ static void gen(orx_prog* P, int n) {
             break;
         case N_LOOKAHEAD: {
             int b = emit(P, nd.max ? I_NLOOK_BEGIN : I_LOOK_BEGIN, 0, 0);
+            if (nd.min > 0) emit(P, I_BACK, nd.min, 0);
             gen(P, nd.l);
             emit(P, nd.max ? I_NLOOK_END : I_LOOK_END, 0, 0);
             P->code[b].x = P->ncode; /* where a satisfied negative look-ahead continues */
@@ -774,6 +797,10 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
                 ++pc; continue;
             }
             case I_NLOOK_BEGIN: push(st, F_NLOOK_MARK, in->x, pos, 0); ++pc; continue;
+            case I_BACK: /* (the mark pushed just before holds the position the assertion stands at; I_*LOOK_END goes back to it) */
+                if (pos < (long)in->x) goto backtrack;
+                pos -= (long)in->x;
+                ++pc; continue;
             case I_NLOOK_END: {
                 /* body matched, so the assertion fails: unwind everything the body did, mark included, and backtrack */
                 for (;;) {

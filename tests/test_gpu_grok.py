@@ -92,6 +92,45 @@ def test_random_values_against_the_oracle(torch_dev, match):
         assert nmulti > 50   # several matches per value really happen (FindNextMatch path)
 
 
+MONGO_PATTERNS = {  # example_config/processor_grok_patterns/mongodb:2-4, verbatim
+    "MONGO_QUERY": r"\{ (?<={ ).*(?= } ntoreturn:) \}",
+    "MONGO_SLOWQUERY": r"%{WORD} %{MONGO_WORDDASH:database}\.%{MONGO_WORDDASH:collection} %{WORD}: %{MONGO_QUERY:query} %{WORD}:%{NONNEGINT:ntoreturn} "
+                       r"%{WORD}:%{NONNEGINT:ntoskip} %{WORD}:%{NONNEGINT:nscanned}.*nreturned:%{NONNEGINT:nreturned}..+ (?<duration>[0-9]+)ms",
+    "MONGO_WORDDASH": r"\b[\w-]+\b",
+}
+
+
+def test_the_library_patterns_with_multi_byte_lookarounds(torch_dev):
+    """MONGO_SLOWQUERY / MONGO_QUERY (mongodb:2-3) failed Init through round 4: "(?<={ )" is decided by the literal in front of it,
+    "(?= } ntoreturn:)" is a window the rest of the entry does not decide (the word behind the query is any %{WORD}) -- a product of
+    the automaton with the window's chain.  Slow-query lines, near misses and nested braces, on the device against the Grok oracle."""
+    rng = random.Random(7)
+    match = ["%{MONGO_SLOWQUERY}", "%{MONGO_QUERY:q}"]
+    g = Grok(Match=match, CustomPatterns=MONGO_PATTERNS)
+    o = GrokOracle(match, custom_patterns=MONGO_PATTERNS)
+    values = []
+    for k in range(600):
+        q = rng.choice([b"a: 1", b"_id: { $gt: 5 }", b"x: { y: { z: 1 } }, w: 2", b"", b"name: \"ab } cd\""])
+        word = rng.choice([b"ntoreturn", b"ntoreturn", b"ntoreturns", b"limit"])
+        tail = b" ntoskip:%d nscanned:%d keyUpdates:0 locks(micros) r:%d nreturned:%d reslen:20 %dms" % (
+            rng.randint(0, 9), rng.randint(0, 99999), rng.randint(1, 999), rng.randint(0, 50), rng.randint(1, 9000))
+        line = b"query db-%d.coll_%d query: { " % (k % 7, k % 5) + q + b" } " + word + b":%d" % rng.randint(0, 100) + tail
+        if k % 11 == 0:
+            line = line.replace(b" } ntoreturn:", b" }ntoreturn:")
+        if k % 13 == 0:
+            line = b"junk " + line + b" trailing"
+        values.append(line)
+    pattern, fields = g.match_host(values)
+    won = [0, 0]
+    for v, p, f in zip(values, pattern, fields):
+        res, want = o.process_value(v)
+        assert f == want, v
+        assert (p >= 0) == (res == 0)
+        if p >= 0:
+            won[int(p)] += 1
+    assert won[0] > 250 and won[1] > 20, won
+
+
 def test_device_resident_entry_and_extra_row_overflow(torch_dev):
     torch = torch_dev
     dev = torch.device("cuda:0")

@@ -418,6 +418,35 @@ def test_atomic_groups_and_possessive_quantifiers_on_both_kernels(torch_dev, gol
     assert not bad, bad[:5]
 
 
+def test_fixed_length_lookarounds_on_both_kernels(torch_dev, golden_dir):
+    """(?=lit) (?!lit) (?<=lit) (?<!lit) vectors (regex module ∧ PCRE1, tests/golden/gen_lookaround_golden.py) through the C ABI, full
+    match and search, on every engine the handle has: the product positions of a look-ahead window are ordinary positions to the kernels."""
+    with open(os.path.join(golden_dir, "regex_lookaround_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH)):
+        for c in golden[kind]:
+            try:
+                rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+            except B.RegexUnsupportedError:
+                continue
+            subs = [s.encode("latin-1") for s, _ in c["subs"]]
+            data, off, length = pack(subs)
+            engines = ([B.LC_ENGINE_TDFA] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + (
+                [B.LC_ENGINE_NFA] if rx.has_nfa_program() else [])
+            for eng in engines:
+                caps, status = run_device(torch_dev, rx, data, off, length, engine=eng)
+                for i, (_, flat) in enumerate(c["subs"]):
+                    checked += 1
+                    exp = flat if kind == "search" or flat is None else flat[2:]
+                    ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
+                        status[i] == B.LC_MATCH and list(caps[i]) == exp)
+                    if not ok:
+                        bad.append((kind, eng, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
+    assert checked > 6000
+    assert not bad, bad[:5]
+
+
 def test_prefix_mode_on_both_kernels(torch_dev, golden_dir):
     """LC_SYNTAX_PREFIX (regex_search with match_continuous, the multiline splitter's per-line question) vs the oracle"""
     from oracle.oracle import OracleRegex

@@ -46,7 +46,7 @@ def test_survey_known_answer_vectors():
                                     (99, 103), (105, 128), (131, 172)]
 
 
-@pytest.mark.parametrize("pat", [r"(a)\1", r"(?<!ab)c", r"(?R)b", r"(?(1)a|b)", r"(", r"a)", r"[a", r"a**", r"\p{L}"])
+@pytest.mark.parametrize("pat", [r"(a)\1", r"(?<!a+b)c", r"(?R)b", r"(?(1)a|b)", r"(", r"a)", r"[a", r"a**", r"\p{L}"])
 def test_unsupported_or_invalid_patterns_fail_to_compile(pat):
     with pytest.raises(ValueError):
         OracleRegex(pat)
@@ -90,6 +90,27 @@ def test_oracle_matches_atomic_and_possessive_vectors(golden_dir):
     with open(os.path.join(golden_dir, "regex_atomic_golden.json")) as f:
         d = json.load(f)
     assert d["n_full"] > 2500 and d["n_search"] > 1000
+    bad = []
+    for kind in ("full", "search"):
+        for c in d[kind]:
+            rx = OracleRegex(c["p"].encode("latin-1"))
+            assert rx.groups == c["g"], c["p"]
+            for subj, flat in c["subs"]:
+                s = subj.encode("latin-1")
+                got = rx.fullmatch(s) if kind == "full" else rx.search(s)
+                got_flat = None if got is None else [v for ab in got for v in ab]
+                if got_flat != flat:
+                    bad.append((kind, c["p"], subj, got_flat, flat))
+    assert not bad, bad[:5]
+
+
+def test_oracle_matches_fixed_length_lookaround_vectors(golden_dir):
+    """(?=lit) (?!lit) (?<=lit) (?<!lit) with a fixed-length body: vectors on which the `regex` module and PCRE1 agree
+    (tests/golden/gen_lookaround_golden.py; the library's MONGO_QUERY shape among them).  The look-behind form is new in round 5
+    (bt_regex.c I_BACK: the body runs k bytes back, as the backtracking engines do it)."""
+    with open(os.path.join(golden_dir, "regex_lookaround_golden.json")) as f:
+        d = json.load(f)
+    assert d["n_full"] > 2000 and d["n_search"] > 1000 and d["dropped_disagreements"] == 0
     bad = []
     for kind in ("full", "search"):
         for c in d[kind]:
