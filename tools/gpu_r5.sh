@@ -2,6 +2,7 @@
 # tools/gpu_r5.sh STAGE: the GPU calls of round 5 (profiles/round5_* come from them; profiles/ROUND5.md indexes the files).
 #   first    full GPU suite, configs[3] (packed multi-pipeline launch) bench line + kernel trace, the Grok step's profile
 #   multi    configs[3] only
+#   second   full GPU suite, configs[3], bench.py's end_to_end block (in-agent legs incl. the reference-shaped build)
 #   grok     Grok GPU tests + the Grok step's profile (bench lines, phase trace, kernel trace, timeline)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; O=gpurun_out/r5_$1; mkdir -p $O scratch
@@ -17,6 +18,11 @@ first)
   multi
   GPU_MAX_HW_QUEUES=16 bash tools/gpu_grok_profile.sh r5_first_grok 16384 2>&1 | head -12 | cut -c1-250 ;;
 multi) multi ;;
+second)
+  timeout 500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 | cut -c1-300 | tee $O/pytest_gpu.txt
+  multi
+  timeout 400 python bench.py --lines 262144 --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/bench_e2e.json 2> $O/bench_e2e.err
+  echo "bench rc $?"; tail -c 6000 $O/bench_e2e.json | tr ',' '\n' | grep -A5 '"in_agent' | head -60; tail -3 $O/bench_e2e.err | cut -c1-300 ;;
 grok)
   timeout 120 python -m pytest tests/test_gpu_grok.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-200 | tee $O/pytest_grok.txt
   GPU_MAX_HW_QUEUES=16 bash tools/gpu_grok_profile.sh r5_grok_$2 16384 2>&1 | head -14 | cut -c1-250 ;;
