@@ -175,6 +175,12 @@ int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, 
  * whole-line language unchanged and prefix-free, nothing captured or asserted inside).  Diagnostics and tests. */
 void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided);
 
+/* Ask that SMALL batches of this handle (<= 16 Ki lines) walk one value per WAVEFRONT with the tables in global memory
+ * (tdfa_wave_kernel: quiet runs crossed 256 bytes at a time) even when the automaton fits LDS -- what the Grok matcher asks for
+ * its entries, whose batches are a few hundred long values.  Packs the global-memory table form if the handle has none yet.
+ * Returns 1 when the handle will take that kernel, 0 when it cannot (no tagged DFA, tables too large).  Results are unchanged. */
+int lc_regex_prefer_wave_tdfa(lc_regex_t* re);
+
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int lc_device_count(void);
 

@@ -262,6 +262,12 @@ class GpuRegex:
             d_status.data_ptr(), d_scratch.data_ptr(), d_scratch.numel() * d_scratch.element_size(), stream)
         _check(rc, "lc_regex_match_device_ragged")
 
+    def prefer_wave_tdfa(self):
+        """lc_regex_prefer_wave_tdfa: small batches of this handle take tdfa_wave_kernel (and the handle gets its global-memory tables)"""
+        self._L.lc_regex_prefer_wave_tdfa.restype = ctypes.c_int
+        self._L.lc_regex_prefer_wave_tdfa.argtypes = [ctypes.c_void_p]
+        return bool(self._L.lc_regex_prefer_wave_tdfa(self._h))
+
     def required_literal(self):
         n = ctypes.c_size_t()
         p = self._L.lc_regex_required_literal(self._h, ctypes.byref(n))

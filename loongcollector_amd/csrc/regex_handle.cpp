@@ -1413,6 +1413,12 @@ void lcPreferWaveTdfa(lc_regex* re) {
     re->preferWave = !re->tdfaL2Blob.empty();
 }
 
+extern "C" int lc_regex_prefer_wave_tdfa(lc_regex_t* re) {
+    if (!re) return 0;
+    lcPreferWaveTdfa(re);
+    return re->preferWave ? 1 : 0;
+}
+
 extern "C" void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided) {
     if (kept) *kept = re ? uint32_t(re->nfa.atomicCount) : 0u;
     if (elided) *elided = re ? re->atomicsElided : 0u;
