@@ -817,9 +817,10 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                           gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
                 if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]));
                 if (trace)
-                    fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d\n", e.p, e.cand, e.stream,
-                            first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2", gp.anchored ? " (anchored)" : "",
-                            first->nfa.positions.size(), first->nfa.slotCount());
+                    fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
+                            e.p, e.cand, e.stream, first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2",
+                            gp.anchored ? " (anchored)" : "", first->nfa.positions.size(), first->nfa.slotCount(), first->nfa.atomicCount, e.cost0 * 1e-6,
+                            e.cost1 * 1e-6);
             }
             rc = join(rc);
             if (rc != LC_OK) return rc;

@@ -119,6 +119,8 @@ def test_the_library_patterns_with_multi_byte_lookarounds(torch_dev):
             line = line.replace(b" } ntoreturn:", b" }ntoreturn:")
         if k % 13 == 0:
             line = b"junk " + line + b" trailing"
+        if k % 7 == 3:   # the slow-query format broken behind the query: only the second entry (the query alone) can match
+            line = line.replace(b" nreturned:", b" returned:")
         values.append(line)
     pattern, fields = g.match_host(values)
     won = [0, 0]
@@ -128,7 +130,7 @@ def test_the_library_patterns_with_multi_byte_lookarounds(torch_dev):
         assert (p >= 0) == (res == 0)
         if p >= 0:
             won[int(p)] += 1
-    assert won[0] > 250 and won[1] > 20, won
+    assert won[0] > 200 and won[1] > 30, won
 
 
 def test_device_resident_entry_and_extra_row_overflow(torch_dev):
