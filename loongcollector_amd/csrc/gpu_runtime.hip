@@ -610,23 +610,24 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
 // or the second chance only (nfa_wide_kernel + the depth-first decide kernels, for the lines that still say LC_OVERFLOW)
 enum { kNfaWholeChain = 0, kNfaFirstChance = 1, kNfaSecondChance = 2 };
 
-template <int NS, bool ATOMIC, bool GLOBAL>
+template <int NS, bool ATOMIC, bool GLOBAL, int BLOCK = kNfaBlock>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
                           const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                           int32_t* d_caps, uint8_t* d_status, hipStream_t stream, uint32_t* overflowFlag, uint32_t seq,
-                          const uint32_t* pendingFlag, int chance = 0) {
+                          const uint32_t* pendingFlag, int chance = 0, int wideLdsMode = 0) {
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};  // the attribute belongs to (function, device)
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
     if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS, ATOMIC, GLOBAL>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_match_kernel<NS, ATOMIC, GLOBAL, BLOCK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ldsAttrSet[devNow] = lds;
     }
-    const uint32_t grid = (n + kNfaWaves - 1) / kNfaWaves;
+    constexpr uint32_t kWaves = BLOCK / 64;
+    const uint32_t grid = (n + kWaves - 1) / kWaves;
     if (chance != kNfaSecondChance) {
         noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
-        hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL>), dim3(grid), dim3(kNfaBlock), lds, stream, d_data, d_off, d_len, sep, n,
+        hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL, BLOCK>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
                            d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
                            seq, pendingFlag);
         HIP_TRY(hipGetLastError());
@@ -640,8 +641,24 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
         const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4;
         if (!wideOff && overflowFlag && wideLds <= 64 * 1024) {
             noteKernel("nfa_wide_kernel");
-            hipLaunchKernelGGL((nfa_wide_kernel<NS>), dim3(n), dim3(64), wideLds, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
-                               d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, overflowFlag, seq);
+            // (wideLdsMode: the batch is small and program + scratch fit the CU's LDS -- the program is staged, launchNfa decides)
+            if (wideLdsMode && wideLds + blobBytes <= kLcLdsPerCu) {
+                static thread_local size_t wideAttrSet[kLcMaxDevices] = {};
+                const size_t need = wideLds + blobBytes;
+                if (need > 64 * 1024) {
+                    HIP_TRY(hipGetDevice(&devNow));
+                    if (devNow < kLcMaxDevices && need > wideAttrSet[devNow]) {
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nfa_wide_kernel<NS, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(need)));
+                        wideAttrSet[devNow] = need;
+                    }
+                }
+                hipLaunchKernelGGL((nfa_wide_kernel<NS, true>), dim3(n), dim3(64), need, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
+                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq);
+            } else {
+                hipLaunchKernelGGL((nfa_wide_kernel<NS, false>), dim3(n), dim3(64), wideLds, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
+                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq);
+            }
             HIP_TRY(hipGetLastError());
         }
     }
@@ -678,7 +695,32 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         return uint32_t(e ? atol(e) : 0);  // (measured on configs[2], round 4: 4.57 vs 4.84 ms at 1000 values, 8.16 vs 8.18 ms at 16 Ki -- staging
                                            // 100+ KiB per workgroup of four values eats what the faster steps save: off by default)
     }();
-    const bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
+    // (round 5) What kept the r4 experiment from paying: the entries that ARE the long poles of a Grok step (CISCOFW313005 and its
+    // kin: 3 200 positions, 127 KB of program) do not fit LDS next to FOUR waves' election marks (4 x 14 KB) and stayed in L2.  Two or
+    // one value per workgroup do fit.  A batch that the chip takes in ONE round of such workgroups stages its program: block 256 if
+    // that fits, else 128, else 64 lanes.  LC_NFA_STAGE_SMALL=0 switches it off (A/B measurements).
+    static const bool stageSmall = [] {
+        const char* e = getenv("LC_NFA_STAGE_SMALL");
+        return !(e && e[0] == '0');
+    }();
+    int block = kNfaBlock;
+    bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
+    const uint32_t nPosAll = uint32_t(re->nfa.positions.size());
+    if (global && stageSmall) {
+        for (int waves : {4, 2, 1}) {
+            const size_t need = lcNfaLdsBytes(blobBytes, nPosAll, atomic, uint32_t(waves));
+            if (need > kLcLdsPerCu) continue;
+            const size_t perCu = kLcLdsPerCu / need;                   // workgroups a CU holds
+            const size_t oneRound = size_t(256) * perCu * size_t(waves);  // values the chip walks at once
+            if (n <= oneRound) {
+                block = 64 * waves;
+                lds = need;
+                global = false;
+            }
+            break;  // (fewer values per workgroup only where more do not fit)
+        }
+    }
+    const bool wideStage = stageSmall && n <= 4096;  // (the second chance walks one value per workgroup anyway)
     if (global) lds -= blobBytes;
     if (lds > 160 * 1024) {
         tlsError = "nfa tables exceed LDS";
@@ -760,9 +802,17 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     auto launch = [&](auto ns) {
         constexpr int NS = decltype(ns)::value;
         auto go = [&](auto a, auto g) {
-            return launchNfaSlots<NS, decltype(a)::value, decltype(g)::value>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n,
-                                                                              d_n, d_order, d_resume, ngroups, d_caps, d_status,
-                                                                              stream, overflowFlag, seq, pendingFlag, chance);
+            constexpr bool A = decltype(a)::value, G = decltype(g)::value;
+            if constexpr (!G) {  // (staged programs only: with the tables in L2 four values per workgroup stay)
+                if (block == 128)
+                    return launchNfaSlots<NS, A, G, 128>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                                                         d_caps, d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
+                if (block == 64)
+                    return launchNfaSlots<NS, A, G, 64>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                                                        d_caps, d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
+            }
+            return launchNfaSlots<NS, A, G>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps,
+                                            d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
         };
         if (atomic && global) return go(std::true_type{}, std::true_type{});
         if (atomic) return go(std::true_type{}, std::false_type{});

@@ -309,8 +309,14 @@ __device__ inline uint32_t nfaAtomicStep(const NfaAtomicCtx& c, uint32_t nThread
     return nKept;
 }
 
-template <int NS, bool ATOMIC, bool GLOBAL>
-__global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __restrict__ data,
+// BLOCK: 256 (four values per workgroup share one LDS copy of the program: large batches) or 128 / 64 (round 5).  A SMALL batch -- a
+// Grok entry's few hundred candidates -- waits for its longest value, i.e. for the latency of a byte step, and a step is a chain of
+// dependent table reads (follow-list bounds -> path -> its conditions -> the target's class mask -> the tags): from L2 that chain is
+// most of the step (measured: 300 ns a byte for CISCOFW313005, 3 219 positions, 127 KB of program).  With fewer values per workgroup
+// the per-wave election marks shrink and programs up to ~145 KB fit the CU's 160 KB of LDS next to them: the launcher picks the
+// largest BLOCK whose LDS need fits (gpu_runtime.hip launchNfa).
+template <int NS, bool ATOMIC, bool GLOBAL, int BLOCK = kNfaBlock>
+__global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restrict__ data,
                                                               const uint32_t* __restrict__ off,
                                                               const uint32_t* __restrict__ len, uint32_t sepBytes,
                                                               uint32_t nLines, const uint32_t* __restrict__ nLinesPtr,
@@ -340,7 +346,17 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     } else {
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < blobBytes / 16; i += kNfaBlock) dst[i] = src[i];
+        const uint32_t nQuads = blobBytes / 16;
+        // (eight loads in flight per lane: a workgroup of one wavefront stages 127 KB in 16 round trips, not 124)
+        uint32_t i = tid;
+        for (; i + 7 * BLOCK < nQuads; i += 8 * BLOCK) {
+            uint4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = src[i + uint32_t(k) * BLOCK];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[i + uint32_t(k) * BLOCK] = q[k];
+        }
+        for (; i < nQuads; i += BLOCK) dst[i] = src[i];
         __syncthreads();
         tbl = smem;
         scratchBase = blobBytes;
@@ -378,8 +394,9 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
     NfaAtomicCtx actx{};
     const uint32_t* atomicPos = nullptr;
     const uint32_t* touchyMask = nullptr;
+    constexpr uint32_t kWaves = BLOCK / 64;
     if constexpr (ATOMIC) {
-        uint32_t* a = reinterpret_cast<uint32_t*>(smem + scratchBase) + kNfaWaves * scratchWords + wave * kNfaAtomicScratchWords;
+        uint32_t* a = reinterpret_cast<uint32_t*>(smem + scratchBase) + kWaves * scratchWords + wave * kNfaAtomicScratchWords;
         actx.tb = tb;
         actx.events = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_EVENTS]);
         actx.tPos = a;
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(kNfaBlock) void nfa_match_kernel(const uint8_t* __r
         touchyMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_TOUCHY]);
     }
 
-    const uint32_t slot = blockIdx.x * kNfaWaves + wave;
+    const uint32_t slot = blockIdx.x * kWaves + wave;
     if (slot >= nLines) return;  // wave-uniform (the block never synchronises again)
     const uint32_t line = order ? order[slot] : slot;
     if (pendingFlag && status[line] != 4 /* LC_PENDING */) return;  // settled by the depth-first walk

@@ -29,13 +29,16 @@ __device__ __forceinline__ void nfaWideScan(uint32_t v0, uint32_t v1, uint32_t l
     total = t0 + t1;
 }
 
-template <int NS>
+// STAGE (round 5): the program is staged into LDS (blobBytes of it, in front of the scratch) -- a value comes here to be walked to its
+// end at the latency of a byte step, and from L2 the step's dependent table reads are most of that latency (nfa_kernel.hpp BLOCK).  The
+// launcher stages when program + scratch fit the CU's LDS and the batch is small.
+template <int NS, bool STAGE = false>
 __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                       const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
                                                       const uint32_t* __restrict__ nLinesPtr,
                                                       const uint32_t* __restrict__ order,
                                                       const uint32_t* __restrict__ resume,
-                                                      const uint32_t* __restrict__ blob, uint32_t nGroupsOut,
+                                                      const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t nGroupsOut,
                                                       int32_t* __restrict__ caps, uint8_t* __restrict__ status,
                                                       const uint32_t* __restrict__ overflowFlag, uint32_t launchSeq) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -50,7 +53,25 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     if (status[line] != LC_OVERFLOW) return;
 
     const uint8_t* tbl = reinterpret_cast<const uint8_t*>(blob);
-    const uint32_t* hdr = blob;
+    uint32_t scratchBase = 0;
+    if constexpr (STAGE) {  // (only the workgroups that have a value to decide get here)
+        const uint4* src = reinterpret_cast<const uint4*>(blob);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const uint32_t nQuads = blobBytes / 16;
+        uint32_t i = lane;
+        for (; i + 7 * 64 < nQuads; i += 8 * 64) {
+            uint4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = src[i + uint32_t(k) * 64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[i + uint32_t(k) * 64] = q[k];
+        }
+        for (; i < nQuads; i += 64) dst[i] = src[i];
+        waveLdsSync();
+        tbl = smem;
+        scratchBase = blobBytes;
+    }
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(tbl);
     const uint32_t nPos = hdr[NF_NPOS];
     const uint32_t nSlots = hdr[NF_NSLOTS];
     const uint8_t* classMap = tbl + hdr[NF_OFF_CLASSMAP];
@@ -67,7 +88,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
 
     // LDS: best[nPos] then newPos / newSrc / newAux for 128 threads
-    uint32_t* best = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* best = reinterpret_cast<uint32_t*>(smem + scratchBase);
     uint32_t* newPos = best + ((nPos + 3) & ~3u);
     uint32_t* newSrc = newPos + kNfaWideThreads;
     uint32_t* newAux = newSrc + kNfaWideThreads;

@@ -118,8 +118,9 @@ inline int lcTdfaPickBlock(uint32_t blobBytes, uint32_t nRegs) {
     return 0;
 }
 // 4 waves x (best[nPos] + 4x64 words) [+ 4 x the atomic path's scratch, nfa_kernel.hpp kNfaAtomicScratchWords = 1344]
-inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos, bool atomic) {
-    return size_t(blobBytes) + size_t(4) * (((nPos + 3) & ~3u) + 256) * 4 + (atomic ? size_t(4) * 1344 * 4 : 0);
+// (waves: values per workgroup -- 4, or 2 / 1 for small batches whose program then fits LDS, nfa_kernel.hpp BLOCK)
+inline size_t lcNfaLdsBytes(uint32_t blobBytes, uint32_t nPos, bool atomic, uint32_t waves = 4) {
+    return size_t(blobBytes) + size_t(waves) * (((nPos + 3) & ~3u) + 256) * 4 + (atomic ? size_t(waves) * 1344 * 4 : 0);
 }
 
 // regex_handle.cpp: TDFA-only handle for the longest prefix of the pattern's top-level concatenation whose automaton stays
