@@ -638,7 +638,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
     // once unless the launch above raised the overflow flag.
     if constexpr (!ATOMIC && NS <= 64) {
         static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
-        const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4;
+        const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4;
         if (!wideOff && overflowFlag && wideLds <= 64 * 1024) {
             noteKernel("nfa_wide_kernel");
             // (wideLdsMode: the batch is small and program + scratch fit the CU's LDS -- the program is staged, launchNfa decides)
@@ -699,9 +699,13 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // kin: 3 200 positions, 127 KB of program) do not fit LDS next to FOUR waves' election marks (4 x 14 KB) and stayed in L2.  Two or
     // one value per workgroup do fit.  A batch that the chip takes in ONE round of such workgroups stages its program: block 256 if
     // that fits, else 128, else 64 lanes.  LC_NFA_STAGE_SMALL=0 switches it off (A/B measurements).
+    // Measured (profiles/round5_nfa_staging.txt): alone on the chip, CISCOFW313005's launch gains 7 % from the staged program (2.75 ->
+    // 2.56 ms) -- the step was not the table reads but the candidate-owner loop (nfa_kernel.hpp, fixed in the same round); inside a Grok
+    // step, where sixteen such entries run side by side, a 155 KB workgroup per CU serialises them (16 Ki values: 5.3 -> 6.2 ms).
+    // So: OFF by default, LC_NFA_STAGE_SMALL=1 switches it on (A/B measurements).
     static const bool stageSmall = [] {
         const char* e = getenv("LC_NFA_STAGE_SMALL");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     int block = kNfaBlock;
     bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
@@ -829,7 +833,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     else rc = launch(std::integral_constant<int, 320>{});
     if (rc != LC_OK) return rc;
     // Can a thread list overflow at all?  Without atomic groups a list holds at most one thread per position.
-    const bool wideApplies = !atomic && slots <= 64 && (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads) * 4 <= 64 * 1024;
+    const bool wideApplies = !atomic && slots <= 64 && (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4 <= 64 * 1024;
     const bool canOverflow = atomic || nPos > (wideApplies ? uint32_t(kNfaWideThreads) : 64u);
     if (!canOverflow || chance == kNfaFirstChance) return LC_OK;
     return launchDecide(re, dev, dBlob, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,

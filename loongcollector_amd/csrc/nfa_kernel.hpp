@@ -388,6 +388,7 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
     uint32_t* newPos = best + ((nPos + 3) & ~3u);
     uint32_t* newSrc = newPos + 64;
     uint32_t* newAux = newSrc + 64;
+    uint32_t* ownerMark = newAux + 64;  // (the fourth 64-word array: candidate -> owning thread, per election round)
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
     // atomic path: its per-wave scratch sits behind the scratch of all waves
@@ -617,13 +618,25 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
         uint32_t totalWins = 0;
         for (uint32_t r0 = 0; r0 < totalCand; r0 += 64) {
             const uint32_t cand = r0 + lane;
+            // Which thread owns candidate `cand` (round 5).  The ranges [rankBase, rankBase + cnt) tile [0, totalCand) in thread order:
+            // every thread whose range reaches into this round leaves its number at the first candidate of the round it owns, and a
+            // candidate's owner is the nearest mark at or below it -- one LDS store, one load, a ballot and three lane reads per round.
+            // (Before: a loop over all live threads with three lane reads each; with 40 threads alive and follow lists of a hundred
+            // paths -- an IP address behind a lazy field -- that loop WAS the byte step: 4 us a byte on CISCOFW313005.)
+            ownerMark[lane] = 0xFFFFFFFFu;
+            waveLdsSync();
+            if (liveLane && cnt) {
+                const uint32_t lo = rankBase > r0 ? rankBase : r0;
+                if (lo < rankBase + cnt && lo < r0 + 64) ownerMark[lo - r0] = lane;
+            }
+            waveLdsSync();
             uint32_t src = 0, q = 0;
-            for (uint32_t t = 0; t < nThreads; ++t) {  // which thread owns candidate `cand`
-                const uint32_t tb = __shfl(rankBase, int(t), 64), tn = __shfl(cnt, int(t), 64), tf = __shfl(fs, int(t), 64);
-                if (cand >= tb && cand < tb + tn) {
-                    src = t;
-                    q = tf + (cand - tb);
-                }
+            {
+                const uint32_t m = ownerMark[lane];
+                const uint64_t marks = __ballot(m != 0xFFFFFFFFu) & ((uint64_t(2) << lane) - 1);  // (lane 63: 2 << 63 = 0, minus 1 = all)
+                if (cand < totalCand) src = uint32_t(__shfl(int(m), 63 - __clzll((long long)marks), 64));
+                const uint32_t tb = uint32_t(__shfl(int(rankBase), int(src), 64)), tf = uint32_t(__shfl(int(fs), int(src), 64));
+                q = tf + (cand - tb);
             }
             bool pass = false;
             uint4 p{0, 0, 0, 0};

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     uint32_t* newPos = best + ((nPos + 3) & ~3u);
     uint32_t* newSrc = newPos + kNfaWideThreads;
     uint32_t* newAux = newSrc + kNfaWideThreads;
+    uint32_t* ownerMark = newAux + kNfaWideThreads;  // 64 words: candidate -> owning thread, per election round
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
 
@@ -193,16 +194,27 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         uint32_t totalWins = 0;
         for (uint32_t r0 = 0; r0 < totalCand && !overflow; r0 += 64) {
             const uint32_t cand = r0 + lane;  // one candidate (thread, path) per lane, in priority order
+            // its owner: the nearest mark at or below it (nfa_kernel.hpp, round 5) -- threads 0..127 leave their marks, slot 0 first
+            ownerMark[lane] = 0xFFFFFFFFu;
+            waveLdsSync();
+            if (live0 && cnt0) {
+                const uint32_t lo = rank0 > r0 ? rank0 : r0;
+                if (lo < rank0 + cnt0 && lo < r0 + 64) ownerMark[lo - r0] = lane;
+            }
+            if (live1 && cnt1) {
+                const uint32_t lo = rank1 > r0 ? rank1 : r0;
+                if (lo < rank1 + cnt1 && lo < r0 + 64) ownerMark[lo - r0] = lane + 64;
+            }
+            waveLdsSync();
             uint32_t src = 0, q = 0;
-            for (uint32_t t = 0; t < nThreads; ++t) {
-                const int l = int(t & 63u);
-                const uint32_t tb0 = t < 64 ? __shfl(rank0, l, 64) : __shfl(rank1, l, 64);
-                const uint32_t tn = t < 64 ? __shfl(cnt0, l, 64) : __shfl(cnt1, l, 64);
-                const uint32_t tf = t < 64 ? __shfl(fs0, l, 64) : __shfl(fs1, l, 64);
-                if (cand >= tb0 && cand < tb0 + tn) {
-                    src = t;
-                    q = tf + (cand - tb0);
-                }
+            {
+                const uint32_t m = ownerMark[lane];
+                const uint64_t marks = __ballot(m != 0xFFFFFFFFu) & ((uint64_t(2) << lane) - 1);
+                if (cand < totalCand) src = uint32_t(__shfl(int(m), 63 - __clzll((long long)marks), 64));
+                const int l = int(src & 63u);
+                const uint32_t tbA = uint32_t(__shfl(int(rank0), l, 64)), tbB = uint32_t(__shfl(int(rank1), l, 64));
+                const uint32_t tfA = uint32_t(__shfl(int(fs0), l, 64)), tfB = uint32_t(__shfl(int(fs1), l, 64));
+                q = (src < 64 ? tfA : tfB) + (cand - (src < 64 ? tbA : tbB));
             }
             bool pass = false;
             uint4 p{0, 0, 0, 0};
