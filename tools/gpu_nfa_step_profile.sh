@@ -7,10 +7,10 @@ TAG=$1; PAT=${2:-%{HAPROXYHTTP\}}
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 export LC_BENCH_ANCHORED=1 LC_BENCH_ENGINE=nfa LC_BENCH_REPS=5
 {
-echo "## time per launch, program in L2 (default for n > LC_NFA_SMALL_BATCH = 0)"
+echo "## time per launch, program in L2 (default)"
 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -6
-echo "## time per launch, program staged in LDS (LC_NFA_SMALL_BATCH=100000)"
-LC_NFA_SMALL_BATCH=100000 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -6
+echo "## time per launch, program staged in LDS (LC_NFA_STAGE_SMALL=1)"
+LC_NFA_STAGE_SMALL=1 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -6
 } > $O.txt
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"
@@ -19,7 +19,7 @@ i=0
 for MODE in l2 lds; do
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  if [ $MODE = lds ]; then export LC_NFA_SMALL_BATCH=100000; else unset LC_NFA_SMALL_BATCH; fi
+  if [ $MODE = lds ]; then export LC_NFA_STAGE_SMALL=1; else unset LC_NFA_STAGE_SMALL; fi
   LC_BENCH_REPS=1 timeout 300 rocprofv3 --pmc $P -d $O/p$i -o r --output-format csv -- python $R/tools/grok_pattern_bench.py "$PAT" > $O/run$i.log 2>&1
   echo $MODE > $O/p$i/mode.txt 2>/dev/null
 done
