@@ -36,6 +36,65 @@ __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t lane,
     return incl - v;
 }
 
+// OR over the 64 lanes of a wavefront, wave-uniform result: six DPP steps (two quad permutes, two row rotations, the two row
+// broadcasts of GFX9) and one lane read -- no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ uint32_t waveOrStep(uint32_t v) {
+    return v | uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t waveOr(uint32_t v) {
+    v = waveOrStep<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v = waveOrStep<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v = waveOrStep<0x124>(v);  // row_ror:4
+    v = waveOrStep<0x128>(v);  // row_ror:8
+    v = waveOrStep<0x142>(v);  // row_bcast:15
+    v = waveOrStep<0x143>(v);  // row_bcast:31
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
+
+// ---- capture transfer of one step (round 5).  New thread j takes over the offsets of its source thread and stamps the slots its path
+// tags.  Done slot by slot with one lane permute each, that was most of a byte step's instructions (CISCOFW313005, 40 slots: 328 VALU
+// and 45 LDS-pipe instructions per byte, profiles/round5_nfa_step_counters.txt).  But the threads alive at one offset descend from
+// common paths: nearly all of their offsets are the SAME in every thread -- the fields already behind them -- and only the slots of
+// the field being decided differ.  So the wave keeps, per slot, whether all 64 lanes hold one value (uniform): a uniform slot needs no
+// permute -- nothing to do when no new thread stamps it, one move when all do; it turns "diverged" when only some stamp it, and a
+// diverged slot is permuted as before and turns uniform again as soon as the live threads agree.  `div` is wave-uniform (SGPRs).
+template <int NS>
+__device__ __forceinline__ void nfaTransferCaptures(int32_t (&cap)[NS], uint64_t& div, uint32_t src, const uint32_t (&tags)[2], uint32_t lane,
+                                                    uint32_t nThreads, int32_t offset) {
+    static_assert(NS <= 64, "two tag words");
+    const bool live = lane < nThreads;
+    const uint64_t orT = uint64_t(waveOr(live ? tags[0] : 0u)) | (NS > 32 ? uint64_t(waveOr(live ? tags[1] : 0u)) << 32 : 0ull);
+    const uint64_t andT = ~(uint64_t(waveOr(live ? ~tags[0] : 0u)) | (NS > 32 ? uint64_t(waveOr(live ? ~tags[1] : 0u)) << 32 : 0ull));
+    const uint64_t act = orT | div;
+#pragma unroll
+    for (int g = 0; g < (NS + 7) / 8; ++g) {
+        if (((act >> (8 * g)) & 0xFFull) == 0) continue;  // (wave-uniform: a scalar branch over eight slots)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = 8 * g + k;
+            if (s >= NS) break;
+            const uint64_t bit = uint64_t(1) << s;
+            if (!(act & bit)) continue;
+            const bool tagged = (tags[s >> 5] >> (s & 31)) & 1u;
+            if (div & bit) {
+                const int32_t v = __shfl(cap[s], int(src), 64);
+                cap[s] = tagged ? offset : v;
+                const int32_t f = __builtin_amdgcn_readfirstlane(cap[s]);  // (lane 0 is alive whenever anything is)
+                if (__all(!live || cap[s] == f)) {
+                    cap[s] = f;
+                    div &= ~bit;
+                }
+            } else if (andT & bit) {
+                cap[s] = offset;  // every new thread stamps it: every lane takes it, the slot stays uniform
+            } else {
+                if (tagged) cap[s] = offset;  // (the old value is the same in every lane: nothing to fetch)
+                div |= bit;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- atomic groups / possessive quantifiers
 // A thread of a pattern with atomic groups also carries its unsettled atomic-segment memberships (its LINEAGE), and a
 // step has to look at ALL epsilon paths in priority order, viable or not: a path that leaves a group commits it and
@@ -425,6 +484,7 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
     int32_t cap[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) cap[s] = -1;
+    uint64_t capDiverged = 0;  // slots in which the lanes do not all hold one value (nfaTransferCaptures)
     uint32_t nThreads = 1;
     uint32_t myPos = nPos;  // lane 0: the start pseudo-position
     bool overflow = false;
@@ -682,11 +742,15 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
 #pragma unroll
             for (int k = 0; k < TW; ++k) tags[k] = a[k];
         }
+        if constexpr (NS <= 64 && !ATOMIC) {
+            nfaTransferCaptures<NS>(cap, capDiverged, src, tags, lane, nThreads, int32_t(i));
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (uint32_t(s) < nSlots) {
-                const int32_t v = __shfl(cap[s], int(src), 64);
-                cap[s] = ((tags[s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : v;
+            for (int s = 0; s < NS; ++s) {
+                if (uint32_t(s) < nSlots) {
+                    const int32_t v = __shfl(cap[s], int(src), 64);
+                    cap[s] = ((tags[s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : v;
+                }
             }
         }
         waveLdsSync();  // newPos/newSrc are rewritten by the next byte's scatter
