@@ -812,10 +812,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (e.level) continue;  // (waits for the entries that shadow it: phase 2c)
                 lcSetDecideSlot(1 + e.stream);
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * a], T.workers[e.stream]));
-                rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
-                                          gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
-                if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]));
+                // (failures inside the forked region become rc: the workers are always joined below)
+                if (calibrate && hipEventRecord(T.tick[2 * a], T.workers[e.stream]) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
+                if (rc == LC_OK)
+                    rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
+                                              gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
+                if (calibrate) (void)hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]);
                 if (trace)
                     fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
                             e.p, e.cand, e.stream, first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2",
@@ -825,7 +827,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             rc = join(rc);
             if (rc != LC_OK) return rc;
         }
-        // 2b
+        // 2b: round 0's results of the level-0 entries; the values won so far
         const uint32_t gridCand0 = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
         lcNoteKernel("grok_post_kernel");
         const uint32_t nLevel0 = nAct - nSecond;  // (the table lists the entries by level)
@@ -833,10 +835,116 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nLevel0), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u,
                                static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap,
                                xstride, xcount);
+        uint32_t maxLevel = 0;
+        for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
+        // (atomicMin per value: idempotent, finishAll runs it again at the end)
+        hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                           static_cast<const uint32_t*>(nullptr), 0u);
         HIP_TRY(hipGetLastError());
+        // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
+        // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
+        // entries on the values nobody before them has won.  Their chains are queued whole: they are few.
+        // Round 5: the chains of LEVEL 1 need nothing the host has to read first -- their list lengths stay on the device -- so they are
+        // queued BEFORE the host waits for round 0's counts: the device works on them while the host reads, and while it queues the
+        // leftovers of level 0 behind (in round 4's timeline the level-1 kernels started 1.2 ms after the fork, behind sixty launches
+        // of mostly empty leftover chains: they, not the second-chance kernel, ended the phase).
+        auto queueChain = [&](size_t a, int& rc) {  // the 2c chain of active entry a on its stream; rc: first failure (the caller joins)
+            PlanEntry& e = act[a];
+            const GrokDevicePattern& gp = patterns[e.p];
+            const uint32_t level = e.level;
+            if (level >= 2) {  // behind its main shadower
+                uint32_t best = 0, bestF = 0;
+                for (uint32_t f = 0; f < e.p; ++f)
+                    if (T.hostWords[HW_SHADOW + e.p * 64 + f] > best && map.activeOfBit[f] >= 0) {
+                        best = T.hostWords[HW_SHADOW + e.p * 64 + f];
+                        bestF = f;
+                    }
+                if (best) {
+                    const size_t sa = size_t(map.activeOfBit[bestF]);
+                    e.stream = act[sa].stream;
+                    hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
+                                       0, T.workers[e.stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
+                }
+            }
+            hipStream_t ws = T.workers[e.stream];
+            if (calibrate && hipEventRecord(T.tick[2 * nAct + 2 * a], ws) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
+            const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+            auto post = [&](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
+                hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a), in, inCount, flags, xtmp,
+                                   xcap, xstride, xcount);
+            };
+            // the search proper over the slots in `list`, minus the values an earlier entry has won; then its post step
+            auto searchProper = [&](const uint32_t* list, const uint32_t* count) -> int {
+                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner), list,
+                                   count, e.listB, e.dev.cnt + GC_FILTERED);
+                int r2 = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_FILTERED, e.listB,
+                                         e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                if (r2 != LC_OK) return r2;
+                post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
+                return LC_OK;
+            };
+            if (rc == LC_OK && level == 0) {
+                const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
+                if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
+                lcSetDecideSlot(1 + e.stream);
+                if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
+                    lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                    rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
+                                                     e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
+                    if (rc == LC_OK) post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                }
+                // (round 5: only when the anchored search left any value unmatched -- the host knows the count; the six launches of an
+                // empty search chain were queued for every entry that had an overflow)
+                if (rc == LC_OK && gp.anchored && un) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
+            } else if (rc == LC_OK) {
+                if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u stream %d\n", e.p, e.level, e.cand, e.stream);
+                lcSetDecideSlot(1 + e.stream);
+                // every slot whose value nobody before has won: the anchored search (or the search) in full, then the rest
+                uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
+                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner),
+                                   static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), mine, e.dev.cnt + GC_OVERFLOW);
+                lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                rc = lcMatchOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW, mine,
+                                     gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
+                if (rc == LC_OK) {
+                    post(mine, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                    if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
+                }
+            }
+            if (calibrate) (void)hipEventRecord(T.tick[2 * nAct + 2 * a + 1], ws);  // (whichever way the chain ended)
+        };
+        bool forked = false;
+        int rc2c = LC_OK;
+        if (maxLevel) {
+            rc2c = fork();
+            if (rc2c != LC_OK) return rc2c;  // (nothing queued on the workers yet)
+            forked = true;
+            // level 1 goes to the streams that carry the least of round 0's expected leftovers (an expensive second chance must not
+            // find a shadowed entry's chain queued in front of it)
+            for (size_t a = 0; a < nAct; ++a) busy2c[a] = act[a].level == 1 ? 1 : 0;
+            double load[kGrokMaxStreams] = {};
+            for (size_t a = 0; a < nAct; ++a)
+                if (!act[a].level) load[act[a].stream] += act[a].cost1;
+            std::vector<size_t> lvl1;
+            for (size_t a = 0; a < nAct; ++a)
+                if (act[a].level == 1) lvl1.push_back(a);
+            auto costOf = [&](size_t a) { return act[a].cost1 > 0 ? act[a].cost1 : act[a].cost * 50.0; };
+            std::stable_sort(lvl1.begin(), lvl1.end(), [&](size_t x, size_t y) { return costOf(x) > costOf(y); });
+            for (size_t a : lvl1) {
+                uint32_t best = 0;
+                for (uint32_t s2 = 1; s2 < used; ++s2)
+                    if (load[s2] < load[best]) best = s2;
+                act[a].stream = int(best);
+                load[best] += costOf(a) + 20000.0;
+                if (rc2c == LC_OK) queueChain(a, rc2c);
+            }
+        }
         {
-            int rc = readCounts();  // sync 2
-            if (rc != LC_OK) return rc;
+            int rc = readCounts();  // sync 2 (the level-1 chains are running meanwhile)
+            if (rc != LC_OK) {
+                if (forked) (void)join(rc);
+                return rc;
+            }
         }
         auto learn = [&](std::atomic<uint32_t>& slot, hipEvent_t b, hipEvent_t e2, uint32_t cand) {
             float ms = 0;
@@ -851,100 +959,32 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
                 if (!act[a].level) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
-        // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
-        // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
-        // entries on the values nobody before them has won.  Their chains are queued whole: they are few.
         {
-            uint32_t maxLevel = 0;
-            for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
             bool any0 = false;
-            for (size_t a = 0; a < nAct; ++a) any0 = any0 || cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED);
-            if (any0 || maxLevel) {
-                // the values won so far (atomicMin per value: idempotent, finishAll runs it again at the end)
-                hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
-                                   static_cast<const uint32_t*>(nullptr), 0u);
-                int rc = fork();
-                if (rc != LC_OK) return rc;
-                for (size_t a = 0; a < nAct; ++a) busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
-                const std::vector<size_t> order1 = deal(true);
-                // ONE fork for all of it: the leftovers of level 0 and the entries of level 1 depend on round 0 only; an entry of level
-                // 2 or 3 is queued on the stream of the entry that shadows most of its candidates, behind that entry's chain and a
-                // finish step for it -- stream order instead of a barrier per level.
-                for (uint32_t level = 0; level <= maxLevel && rc == LC_OK; ++level)
-                for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
-                    const size_t a = order1[i];
-                    PlanEntry& e = act[a];
-                    if (e.level != level || !busy2c[a]) continue;
-                    const GrokDevicePattern& gp = patterns[e.p];
-                    struct Tock {  // (the entry's chain, timed on calibration batches -- whichever way the iteration is left)
-                        hipEvent_t ev;
-                        hipStream_t* ws;
-                        ~Tock() {
-                            if (ev) (void)hipEventRecord(ev, *ws);
-                        }
-                    };
-                    if (level >= 2) {  // behind its main shadower
-                        uint32_t best = 0, bestF = 0;
-                        for (uint32_t f = 0; f < e.p; ++f)
-                            if (T.hostWords[HW_SHADOW + e.p * 64 + f] > best && map.activeOfBit[f] >= 0) {
-                                best = T.hostWords[HW_SHADOW + e.p * 64 + f];
-                                bestF = f;
-                            }
-                        if (best) {
-                            const size_t sa = size_t(map.activeOfBit[bestF]);
-                            e.stream = act[sa].stream;
-                            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
-                                               0, T.workers[e.stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
-                        }
-                    }
-                    hipStream_t ws = T.workers[e.stream];
-                    if (calibrate) HIP_TRY(hipEventRecord(T.tick[2 * nAct + 2 * a], ws));
-                    Tock tock{calibrate ? T.tick[2 * nAct + 2 * a + 1] : nullptr, &ws};
-                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-                    auto post = [&](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
-                        hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a), in, inCount, flags, xtmp,
-                                           xcap, xstride, xcount);
-                    };
-                    // the search proper over the slots in `list`, minus the values an earlier entry has won; then its post step
-                    auto searchProper = [&](const uint32_t* list, const uint32_t* count) -> int {
-                        hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner), list,
-                                           count, e.listB, e.dev.cnt + GC_FILTERED);
-                        int r2 = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_FILTERED, e.listB,
-                                                 e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                        if (r2 != LC_OK) return r2;
-                        post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
-                        return LC_OK;
-                    };
-                    if (level == 0) {
-                        const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
-                        if (!ov && !un) continue;
-                        if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
-                        lcSetDecideSlot(1 + e.stream);
-                        if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
-                            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                            rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
-                                                             e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
-                            if (rc != LC_OK) break;
-                            post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
-                        }
-                        if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
-                    } else {
-                        if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u stream %d\n", e.p, e.level, e.cand, e.stream);
-                        lcSetDecideSlot(1 + e.stream);
-                        // every slot whose value nobody before has won: the anchored search (or the search) in full, then the rest
-                        uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
-                        hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner),
-                                           static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), mine, e.dev.cnt + GC_OVERFLOW);
-                        lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                        rc = lcMatchOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW, mine,
-                                             gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                        if (rc != LC_OK) break;
-                        post(mine, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
-                        if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
-                    }
+            for (size_t a = 0; a < nAct; ++a) any0 = any0 || (!act[a].level && (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)));
+            if (any0 || maxLevel >= 2) {
+                if (!forked) {
+                    rc2c = fork();
+                    if (rc2c != LC_OK) return rc2c;
+                    forked = true;
                 }
-                rc = join(rc);
-                if (rc != LC_OK) return rc;
+                // the leftovers of level 0 on the streams round 0 put their entries on; then the entries of level 2 and 3, each behind
+                // the entry that shadows most of its candidates (stream order instead of a barrier per level)
+                for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
+                    if (act[a].level || !(cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED))) continue;
+                    busy2c[a] = 1;
+                    queueChain(a, rc2c);
+                }
+                for (uint32_t level = 2; level <= maxLevel && rc2c == LC_OK; ++level)
+                    for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
+                        if (act[a].level != level) continue;
+                        busy2c[a] = 1;
+                        queueChain(a, rc2c);
+                    }
+            }
+            if (forked) {
+                rc2c = join(rc2c);  // (always: a failure inside the forked region must not leave the worker streams unjoined)
+                if (rc2c != LC_OK) return rc2c;
             }
         }
         // 2d
