@@ -487,6 +487,7 @@ struct PlanEntry {
     uint32_t level = 0;   // 0: evaluated at once; L > 0: most of its candidates have an EARLIER candidate entry (of level < L) -- it waits
                           // for those and only looks at the values none of them has won (a general format behind specific ones)
     bool queued = false;  // rounds behind the first match were queued for this entry
+    uint32_t earlyOv = 0, earlyUn = 0;  // phase 2c: the second chance / the search proper were queued by the entry's history, before the counts
     uint32_t seq0 = 0;    // launch sequence of round 0's first-chance kernel (lcMatchSecondChanceOnStream)
     const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
     int stream = 0;
@@ -848,10 +849,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // queued BEFORE the host waits for round 0's counts: the device works on them while the host reads, and while it queues the
         // leftovers of level 0 behind (in round 4's timeline the level-1 kernels started 1.2 ms after the fork, behind sixty launches
         // of mostly empty leftover chains: they, not the second-chance kernel, ended the phase).
-        auto queueChain = [&](size_t a, int& rc) {  // the 2c chain of active entry a on its stream; rc: first failure (the caller joins)
+        auto queueChain = [&](size_t a, int& rc, bool early) {  // the 2c chain of active entry a on its stream; rc: first failure (the caller joins)
             PlanEntry& e = act[a];
             const GrokDevicePattern& gp = patterns[e.p];
             const uint32_t level = e.level;
+            // level 0 -- early: queued by the entry's history before the counts are known (1 = wanted); late: by the counts, minus what
+            // went early
+            const uint32_t ov = level ? 0u : early ? e.earlyOv : (e.earlyOv ? 0u : cnt(a, GC_OVERFLOW));
+            const uint32_t un = level ? 0u : early ? e.earlyUn : (e.earlyUn ? 0u : cnt(a, GC_UNANCHORED));
+            if (!level && !ov && !un) return;
             if (level >= 2) {  // behind its main shadower
                 uint32_t best = 0, bestF = 0;
                 for (uint32_t f = 0; f < e.p; ++f)
@@ -884,8 +890,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 return LC_OK;
             };
             if (rc == LC_OK && level == 0) {
-                const uint32_t ov = cnt(a, GC_OVERFLOW), un = cnt(a, GC_UNANCHORED);
-                if (trace) fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u in play %u\n", e.p, ov, un, cnt(a, GC_ROUND0));
+                if (trace)
+                    fprintf(stderr, "grok plan 2c%s: entry %u overflowed %u unanchored %u\n", early ? " (early, by history)" : "", e.p,
+                            early ? 0u : cnt(a, GC_OVERFLOW), early ? 0u : cnt(a, GC_UNANCHORED));
                 lcSetDecideSlot(1 + e.stream);
                 if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
                     lc_regex* first = gp.anchored ? gp.anchored : gp.re;
@@ -915,13 +922,31 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         };
         bool forked = false;
         int rc2c = LC_OK;
-        if (maxLevel) {
+        bool anyEarly = false;
+        for (size_t a = 0; a < nAct; ++a) {
+            PlanEntry& e = act[a];
+            if (e.level) continue;
+            const GrokDevicePattern& gp = patterns[e.p];
+            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+            e.earlyOv = e.seq0 && first->grokOverflowSeen.load(std::memory_order_relaxed) ? 1u : 0u;
+            e.earlyUn = gp.anchored && first->grokUnanchoredSeen.load(std::memory_order_relaxed) ? 1u : 0u;
+            anyEarly = anyEarly || e.earlyOv || e.earlyUn;
+        }
+        if (maxLevel || anyEarly) {
             rc2c = fork();
             if (rc2c != LC_OK) return rc2c;  // (nothing queued on the workers yet)
             forked = true;
+            // first what round 0 is expected to have left behind (the second chance is the longest kernel of the phase), each on the
+            // stream round 0 put its entry on
+            for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a)
+                if (!act[a].level && (act[a].earlyOv || act[a].earlyUn)) {
+                    busy2c[a] = 1;
+                    queueChain(a, rc2c, true);
+                }
             // level 1 goes to the streams that carry the least of round 0's expected leftovers (an expensive second chance must not
             // find a shadowed entry's chain queued in front of it)
-            for (size_t a = 0; a < nAct; ++a) busy2c[a] = act[a].level == 1 ? 1 : 0;
+            for (size_t a = 0; a < nAct; ++a)
+                if (act[a].level == 1) busy2c[a] = 1;
             double load[kGrokMaxStreams] = {};
             for (size_t a = 0; a < nAct; ++a)
                 if (!act[a].level) load[act[a].stream] += act[a].cost1;
@@ -936,7 +961,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (load[s2] < load[best]) best = s2;
                 act[a].stream = int(best);
                 load[best] += costOf(a) + 20000.0;
-                if (rc2c == LC_OK) queueChain(a, rc2c);
+                if (rc2c == LC_OK) queueChain(a, rc2c, true);
             }
         }
         {
@@ -959,9 +984,23 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
                 if (!act[a].level) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
+        for (size_t a = 0; a < nAct; ++a) {  // the entries' histories: seen now = 8, else forgotten a batch at a time
+            PlanEntry& e = act[a];
+            if (e.level) continue;
+            const GrokDevicePattern& gp = patterns[e.p];
+            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+            auto note = [](std::atomic<uint32_t>& h, bool seen) {
+                const uint32_t v = h.load(std::memory_order_relaxed);
+                if (seen) h.store(8, std::memory_order_relaxed);
+                else if (v) h.store(v - 1, std::memory_order_relaxed);
+            };
+            note(first->grokOverflowSeen, cnt(a, GC_OVERFLOW) != 0);
+            note(first->grokUnanchoredSeen, cnt(a, GC_UNANCHORED) != 0);
+        }
         {
             bool any0 = false;
-            for (size_t a = 0; a < nAct; ++a) any0 = any0 || (!act[a].level && (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)));
+            for (size_t a = 0; a < nAct; ++a)
+                any0 = any0 || (!act[a].level && ((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn)));
             if (any0 || maxLevel >= 2) {
                 if (!forked) {
                     rc2c = fork();
@@ -971,15 +1010,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 // the leftovers of level 0 on the streams round 0 put their entries on; then the entries of level 2 and 3, each behind
                 // the entry that shadows most of its candidates (stream order instead of a barrier per level)
                 for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
-                    if (act[a].level || !(cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED))) continue;
+                    if (act[a].level || !((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn))) continue;
                     busy2c[a] = 1;
-                    queueChain(a, rc2c);
+                    queueChain(a, rc2c, false);
                 }
                 for (uint32_t level = 2; level <= maxLevel && rc2c == LC_OK; ++level)
                     for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
                         if (act[a].level != level) continue;
                         busy2c[a] = 1;
-                        queueChain(a, rc2c);
+                        queueChain(a, rc2c, false);
                     }
             }
             if (forked) {

@@ -58,6 +58,10 @@ struct lc_regex {
     // candidate, as measured with events on calibration batches (0 = not measured yet): the matcher deals the entries to its worker
     // streams longest-first by these
     std::atomic<uint32_t> grokCost0Ns{0}, grokCost1Ns{0}, grokBatches{0};
+    // what round 0 of recent batches left behind for this entry (grok_device.hip phase 2c): values that needed the second chance,
+    // values the anchored search did not match.  An entry with such a history gets those chains queued BEFORE the host has read this
+    // batch's counts (their list lengths are on the device; an empty list costs a few empty launches).  Decays: 8 quiet batches.
+    std::atomic<uint32_t> grokOverflowSeen{0}, grokUnanchoredSeen{0};
 };
 
 // Values a consumer without a parse-failure notion of its own (filter leaves, multiline flags, the Go regex plugin) had to take as
