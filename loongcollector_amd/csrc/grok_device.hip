@@ -838,9 +838,18 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                xstride, xcount);
         uint32_t maxLevel = 0;
         for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
-        // (atomicMin per value: idempotent, finishAll runs it again at the end)
-        hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
-                           static_cast<const uint32_t*>(nullptr), 0u);
+        // LC_GROK_EARLY=1 (experiment, measured and left off: profiles/round5_grok_steps.txt): the chains of level 1 and -- by the
+        // entries' history -- the second chances / unanchored searches of level 0 are queued BEFORE the host reads round 0's counts.
+        // The device has them earlier, but a batch is bound by the rate at which the host can queue launches, and the extra
+        // (mostly empty) chains cost more than the earlier start gains: 16 Ki values 4.76 -> 5.4 ms, 1000 values 3.9 -> 5.2 ms.
+        static const bool earlyChains = getenv("LC_GROK_EARLY") != nullptr;
+        bool finishQueued = false;
+        auto queueFinish = [&] {  // the values won so far (atomicMin per value: idempotent, finishAll runs it again at the end)
+            if (finishQueued) return;
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                               static_cast<const uint32_t*>(nullptr), 0u);
+            finishQueued = true;
+        };
         HIP_TRY(hipGetLastError());
         // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
         // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
@@ -928,11 +937,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             if (e.level) continue;
             const GrokDevicePattern& gp = patterns[e.p];
             lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-            e.earlyOv = e.seq0 && first->grokOverflowSeen.load(std::memory_order_relaxed) ? 1u : 0u;
-            e.earlyUn = gp.anchored && first->grokUnanchoredSeen.load(std::memory_order_relaxed) ? 1u : 0u;
+            e.earlyOv = earlyChains && e.seq0 && first->grokOverflowSeen.load(std::memory_order_relaxed) ? 1u : 0u;
+            e.earlyUn = earlyChains && gp.anchored && first->grokUnanchoredSeen.load(std::memory_order_relaxed) ? 1u : 0u;
             anyEarly = anyEarly || e.earlyOv || e.earlyUn;
         }
-        if (maxLevel || anyEarly) {
+        if (earlyChains && (maxLevel || anyEarly)) {
+            queueFinish();
             rc2c = fork();
             if (rc2c != LC_OK) return rc2c;  // (nothing queued on the workers yet)
             forked = true;
@@ -1001,25 +1011,40 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             bool any0 = false;
             for (size_t a = 0; a < nAct; ++a)
                 any0 = any0 || (!act[a].level && ((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn)));
-            if (any0 || maxLevel >= 2) {
+            if (any0 || maxLevel >= (earlyChains ? 2u : 1u)) {
                 if (!forked) {
+                    queueFinish();
                     rc2c = fork();
                     if (rc2c != LC_OK) return rc2c;
                     forked = true;
                 }
-                // the leftovers of level 0 on the streams round 0 put their entries on; then the entries of level 2 and 3, each behind
-                // the entry that shadows most of its candidates (stream order instead of a barrier per level)
-                for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
-                    if (act[a].level || !((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn))) continue;
-                    busy2c[a] = 1;
-                    queueChain(a, rc2c, false);
-                }
-                for (uint32_t level = 2; level <= maxLevel && rc2c == LC_OK; ++level)
+                if (!earlyChains) {
+                    // ONE fork for all of it: the leftovers of level 0 and the entries of level 1 depend on round 0 only -- dealt together,
+                    // dearest first, each to the least loaded stream; an entry of level 2 or 3 is queued on the stream of the entry that
+                    // shadows most of its candidates, behind that entry's chain and a finish step for it (stream order instead of a
+                    // barrier per level)
+                    for (size_t a = 0; a < nAct; ++a)
+                        busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
+                    const std::vector<size_t> order1 = deal(true);
+                    for (uint32_t level = 0; level <= maxLevel && rc2c == LC_OK; ++level)
+                        for (size_t i = 0; i < nAct && rc2c == LC_OK; ++i) {
+                            const size_t a = order1[i];
+                            if (act[a].level == level && busy2c[a]) queueChain(a, rc2c, false);
+                        }
+                } else {
+                    // (what did not go early) the leftovers of level 0 on the streams round 0 put their entries on; then levels 2 and 3
                     for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
-                        if (act[a].level != level) continue;
+                        if (act[a].level || !((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn))) continue;
                         busy2c[a] = 1;
                         queueChain(a, rc2c, false);
                     }
+                    for (uint32_t level = 2; level <= maxLevel && rc2c == LC_OK; ++level)
+                        for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
+                            if (act[a].level != level) continue;
+                            busy2c[a] = 1;
+                            queueChain(a, rc2c, false);
+                        }
+                }
             }
             if (forked) {
                 rc2c = join(rc2c);  // (always: a failure inside the forked region must not leave the worker streams unjoined)
