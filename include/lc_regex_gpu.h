@@ -175,6 +175,16 @@ int lc_regex_run_captures(const lc_regex_t* re, int32_t* groups, uint8_t* sets, 
  * whole-line language unchanged and prefix-free, nothing captured or asserted inside).  Diagnostics and tests. */
 void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elided);
 
+/* Compiled automata across process restarts.  Determinising a large pattern costs seconds of a host core (an anchored Grok format: 2-8 s;
+ * finding out that one does NOT fit the limits: as long), and the agent pays it at every start and every pipeline reload in a new
+ * process.  With a cache directory set, every tagged-DFA / screen-DFA construction is looked up first -- under a hash of its input (the
+ * follow NFA, the limits, the stamp of this build of the library) -- and stored afterwards: tables, or the verdict of a construction
+ * that ran into its limits.  Tables are bit-identical to a fresh construction; a missing, truncated or foreign file is ignored.
+ * dir = NULL or "" switches the cache off (default).  Process-wide.  Environment: LC_TABLE_CACHE_DIR.  Grok config key: "CacheDir".
+ * lc_runtime_table_cache_stats: {hits, misses, files stored, failures recalled} of this process. */
+int lc_runtime_set_table_cache_dir(const char* dir);
+void lc_runtime_table_cache_stats(uint64_t out[4]);
+
 /* Ask that SMALL batches of this handle (<= 16 Ki lines) walk one value per WAVEFRONT with the tables in global memory
  * (tdfa_wave_kernel: quiet runs crossed 256 bytes at a time) even when the automaton fits LDS -- what the Grok matcher asks for
  * its entries, whose batches are a few hundred long values.  Packs the global-memory table form if the handle has none yet.

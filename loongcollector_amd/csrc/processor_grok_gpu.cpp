@@ -390,6 +390,12 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
             if (v->isNumber()) g->p.PrefixScreenAbove = v->isInt ? v->inum : int64_t(v->num);
         if (const lcjson::Value* v = cfg.find("Streams"))
             if (v->isNumber()) g->p.Streams = v->isInt ? v->inum : int64_t(v->num);
+        // CacheDir: compiled automata (and the verdicts of constructions that ran into their limits) are kept there across process
+        // restarts -- include/lc_regex_gpu.h lc_runtime_set_table_cache_dir.  Process-wide: the last processor to name one wins.
+        if (const lcjson::Value* v = cfg.find("CacheDir")) {
+            if (!v->isString()) throw lcgrok::GrokError("CacheDir must be a string");
+            lc_runtime_set_table_cache_dir(v->str.c_str());
+        }
         boolean("NoKeyError", g->p.NoKeyError);
         boolean("NoMatchError", g->p.NoMatchError);
         boolean("TimeoutError", g->p.TimeoutError);

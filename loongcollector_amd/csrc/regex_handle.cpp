@@ -1413,6 +1413,19 @@ void lcPreferWaveTdfa(lc_regex* re) {
     re->preferWave = !re->tdfaL2Blob.empty();
 }
 
+extern "C" int lc_runtime_set_table_cache_dir(const char* dir) {
+    lcregex::lcSetTableCacheDir(dir);
+    return LC_OK;
+}
+extern "C" void lc_runtime_table_cache_stats(uint64_t out[4]) {
+    if (!out) return;
+    const lcregex::TableCacheStats s = lcregex::lcTableCacheStats();
+    out[0] = s.hits;
+    out[1] = s.misses;
+    out[2] = s.stored;
+    out[3] = s.failuresRecalled;
+}
+
 extern "C" int lc_regex_prefer_wave_tdfa(lc_regex_t* re) {
     if (!re) return 0;
     lcPreferWaveTdfa(re);

@@ -16,7 +16,7 @@
 
 namespace lcregex {
 
-TdfaTables buildScreenDfa(const FollowNfa& nfa, const TdfaLimits& limits) {
+TdfaTables buildScreenDfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
     if (nfa.condsUsed != 0 || nfa.atomicCount > 0) throw RegexError("screen dfa: assertions / atomic groups are not relaxed away");
     const int npos = int(nfa.positions.size());
     const int startNode = npos, exitNode = npos + 1, nNodes = npos + 2;

@@ -510,7 +510,7 @@ void minimizeTdfaStates(TdfaTables& T) {
     T.nStates = uint32_t(rep.size());
 }
 
-TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits) {
+TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
     const int npos = int(nfa.positions.size());
     const int nslots = nfa.slotCount();
     TdfaTables T;

@@ -46,6 +46,24 @@ struct TdfaLimits {
 // Throws RegexError("tdfa: ...") when the automaton exceeds the limits (caller falls back to the NFA engine).
 TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits());
 
+// The constructions themselves (buildTdfa / buildScreenDfa go through the table cache, table_cache.cpp, when a cache directory is set)
+TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits);
+TdfaTables buildScreenDfaUncached(const FollowNfa& nfa, const TdfaLimits& limits);
+
+// table_cache.cpp -- compiled automata across process restarts (round 5).  Determinising an anchored Grok format costs seconds (and
+// finding out that one does NOT determinise within the limits costs as much: 16 of the 50 entries of BASELINE configs[2]); an agent
+// that restarts, or reloads a pipeline in a new process, pays that again -- 8-10 s on the MI355X box's host.  With a cache directory
+// set, every construction is looked up first under a hash of its INPUT -- the follow NFA itself (positions, paths, tags, conditions,
+// atomic events, search wrapper), the limits and the stamp of this build of the library -- and stored afterwards: the tables, or the
+// verdict of a construction that ran into its limits.  Same tables bit for bit (tools/table_snapshot.py); a file that is missing,
+// short or from another build is ignored.  Process-wide; empty = off (default).  Also: environment LC_TABLE_CACHE_DIR.
+void lcSetTableCacheDir(const char* dir);
+const char* lcTableCacheDir();
+struct TableCacheStats {
+    uint64_t hits = 0, misses = 0, stored = 0, failuresRecalled = 0;
+};
+TableCacheStats lcTableCacheStats();
+
 // tdfa.cpp: merges states that behave alike (same final row, same register programs into equivalent states); buildTdfa and
 // buildScreenDfa end with it
 void minimizeTdfaStates(TdfaTables& tables);
