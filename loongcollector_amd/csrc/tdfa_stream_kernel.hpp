@@ -424,11 +424,17 @@ __device__ __forceinline__ void tdfaStreamBody(
                 if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + (srcOff[i] + nextOff));
             }
         }
+        // Round 5 (profiles/round5_tdfa_isa_budget.md): whether the NEXT chunk lies wholly inside the line used to be asked per chunk and
+        // lane -- six VALU and three SALU instructions per chunk, 0.75 VALU per line byte -- although for all but the first and the last
+        // stage of a line the answer is "yes" for the whole stage.  One test per stage and wave picks a copy of the chunk loop
+        // that does not ask (ALLFULL); the other copy is the loop as it was.
+        auto runChunks = [&](auto allFullTag) {
+        constexpr bool ALLFULL = decltype(allFullTag)::value;
 #pragma unroll
         for (int c = 0; c < kChunksPerStage; ++c) {
             const uint32_t base = s * kTdfaStageBytes + uint32_t(c) * NB - head;  // line offset of byte 0 (wraps in the head)
             const uint32_t nbase = base + NB;
-            const bool fullNext = nbase < L && L - nbase >= uint32_t(NB);
+            const bool fullNext = ALLFULL || (nbase < L && L - nbase >= uint32_t(NB));
             const uint32_t entry = t;
             // the NB bytes after this chunk (the first chunk of stage s+1 after the last one of stage s: its row words were
             // re-read from the tile when chunk 0 of this stage was done)
@@ -442,7 +448,7 @@ __device__ __forceinline__ void tdfaStreamBody(
             bool general;
             if constexpr (PAIR1) {
                 uint32_t na[NC], nc[NC];
-                if (__all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                if (ALLFULL || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
                 else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
                 tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
 #pragma unroll
@@ -490,6 +496,16 @@ __device__ __forceinline__ void tdfaStreamBody(
                 ptt[j] = tt[j];
             }
             pbase = base;
+        }
+        };  // runChunks
+        if constexpr (PAIR1 && (LAB & kLabNoStageFull) == 0) {
+            // every chunk of this stage has its next chunk wholly inside the line: chunk 0's next does not start in the head
+            // (s * stage + NB >= head) and chunk 7's next ends inside the line ((s + 1) * stage + NB <= L + head)
+            const bool stageFull = s * kTdfaStageBytes + uint32_t(NB) >= head && (s + 1) * kTdfaStageBytes + uint32_t(NB) <= L + head;
+            if (__all(stageFull)) runChunks(std::true_type{});
+            else runChunks(std::false_type{});
+        } else {
+            runChunks(std::false_type{});
         }
         if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
