@@ -32,3 +32,16 @@ sed -n '/== PMC pass/,$p' $O/summary_all.txt > $O/sq_counters.txt
 rm -rf $O/prof_*
 head -8 $O/tdfa_kernel_rocprofv3.txt | cut -c1-150
 cat $O/sq_counters.txt | cut -c1-150
+# batch-size sweep (round 5): the same kernel on batches whose payload fits the Infinity Cache (256 MB) and on ones that do not -- if a
+# line costs the same either way, what the kernel fetches twice through the fabric (the second 64-byte half of each 128-byte L2 line)
+# is served in front of HBM and is not what bounds it  -> gpurun_out/evidence/size_sweep.txt
+{
+echo "# lines  payload_MiB  ms/step  ns/line  roofline.frac   (python bench.py --lines N --steps 20 --warmup 3, HBM-resident batch re-read every step)"
+for N in 65536 131072 262144 524288 1048576 2097152; do
+  timeout 300 $BENCH --lines $N --steps 20 --warmup 3 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); n = $N
+print('%8d  %8.0f  %.4f  %.2f  %.4f' % (n, n * 513 / 2**20, d['ms_per_step'], d['ms_per_step'] * 1e6 / n, d['roofline']['frac']))"
+done
+} > $O/size_sweep.txt
+cat $O/size_sweep.txt
