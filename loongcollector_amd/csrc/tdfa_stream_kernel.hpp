@@ -433,6 +433,14 @@ __device__ __forceinline__ void tdfaStreamBody(
 #pragma unroll
         for (int c = 0; c < kChunksPerStage; ++c) {
             const uint32_t base = s * kTdfaStageBytes + uint32_t(c) * NB - head;  // line offset of byte 0 (wraps in the head)
+            if constexpr (!ALLFULL && PAIR1) {
+                // Every line of the wave ends before this chunk: nothing is left to walk (the stamps of the chunk before are still
+                // pending and are issued behind the loop, as at a regular end).  Lines are rarely a multiple of the stage behind their
+                // 16-byte row start: 512-byte lines take 8 stages and `head` (0..15) bytes of a ninth -- of whose eight chunks six or
+                // seven were walked on the identity column, in the copy of the loop that tests every byte (round 5: 11 % of the
+                // kernel's VALU instructions, profiles/round5_tdfa_isa_budget.md).
+                if (c > 0 && __all(s * kTdfaStageBytes + uint32_t(c) * NB >= head + L)) return;
+            }
             const uint32_t nbase = base + NB;
             const bool fullNext = ALLFULL || (nbase < L && L - nbase >= uint32_t(NB));
             const uint32_t entry = t;
