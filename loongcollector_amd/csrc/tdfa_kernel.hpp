@@ -93,9 +93,7 @@ enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 
        kLabDmaStage = 256 /* tdfa_stream_kernel, COMPACT: the staging tile is filled by global_load_lds_dwordx4 (no staging VGPRs) */,
        kLabWaves5 = 512 /* tdfa_stream_kernel: register budget of 5 waves per SIMD (96 VGPRs) */,
        kLabNoDmaWait = 1024 /* DMA staging without the wait for the stage (wrong bytes: timing only -- what the wave loses there) */,
-       kLabPairOne = 4096 /* byte-pair chunks on a ONE-STAMP pair table (device_tables.h TP1_*, LC_TDFA_PAIR=2): exact */,
-       kLabNoStageFull = 8192 /* tdfa_stream_kernel, one-stamp tables: no per-stage "every next chunk is inside the line" copy of the chunk
-                                 loop (round 4's loop; A/B measurements) */ };
+       kLabPairOne = 4096 /* byte-pair chunks on a ONE-STAMP pair table (device_tables.h TP1_*, LC_TDFA_PAIR=2): exact */ };
 constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 
 // general register program (a list of moves); rare for log regexes

@@ -318,11 +318,18 @@ __device__ __forceinline__ void tdfaStreamBody(
     const uint32_t span = L ? head + L : 0;
     const uint32_t myStages = (span + kTdfaStageBytes - 1) / kTdfaStageBytes;
     uint32_t maxStages = myStages;
+    // the wave's largest head and smallest head + length (a lane without a line makes the wave "never full": its bytes are not a line's)
+    uint32_t waveMaxHead = head, waveMinSpan = live ? span : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t other = __shfl_xor(maxStages, d, 64);
         maxStages = other > maxStages ? other : maxStages;
+        const uint32_t oh = __shfl_xor(waveMaxHead, d, 64), os = __shfl_xor(waveMinSpan, d, 64);
+        waveMaxHead = oh > waveMaxHead ? oh : waveMaxHead;
+        waveMinSpan = os < waveMinSpan ? os : waveMinSpan;
     }
+    waveMaxHead = __builtin_amdgcn_readfirstlane(waveMaxHead);
+    waveMinSpan = __builtin_amdgcn_readfirstlane(waveMinSpan);
 
     const uint32_t seg = (lane % kLoads) * 16;
     // loads are addressed as (16-byte aligned buffer base, wave-uniform) + a 32-bit offset per lane: half the address registers
@@ -424,10 +431,7 @@ __device__ __forceinline__ void tdfaStreamBody(
                 if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + (srcOff[i] + nextOff));
             }
         }
-        // Round 5 (profiles/round5_tdfa_isa_budget.md): whether the NEXT chunk lies wholly inside the line used to be asked per chunk and
-        // lane -- six VALU and three SALU instructions per chunk, 0.75 VALU per line byte -- although for all but the first and the last
-        // stage of a line the answer is "yes" for the whole stage.  One test per stage and wave picks a copy of the chunk loop
-        // that does not ask (ALLFULL); the other copy is the loop as it was.
+        // (the chunk loop as a callable: ends early -- `return` -- when every line of the wave has ended; ALLFULL = false in the product)
         auto runChunks = [&](auto allFullTag) {
         constexpr bool ALLFULL = decltype(allFullTag)::value;
 #pragma unroll
@@ -442,7 +446,12 @@ __device__ __forceinline__ void tdfaStreamBody(
                 if (c > 0 && __all(s * kTdfaStageBytes + uint32_t(c) * NB >= head + L)) return;
             }
             const uint32_t nbase = base + NB;
-            const bool fullNext = ALLFULL || (nbase < L && L - nbase >= uint32_t(NB));
+            // Round 5: "the next chunk lies wholly inside the line, for every line of the wave" is a question about the wave's largest
+            // head and smallest head + length -- two numbers taken once per kernel -- and the chunk's position: scalar arithmetic.  (It
+            // was asked per chunk AND lane: six VALU instructions per chunk, 0.75 per line byte.)
+            const bool waveFull = PAIR1 && waveMaxHead <= s * kTdfaStageBytes + uint32_t(c + 1) * NB &&
+                                  waveMinSpan >= s * kTdfaStageBytes + uint32_t(c + 2) * NB;
+            const bool fullNext = ALLFULL || waveFull || (nbase < L && L - nbase >= uint32_t(NB));
             const uint32_t entry = t;
             // the NB bytes after this chunk (the first chunk of stage s+1 after the last one of stage s: its row words were
             // re-read from the tile when chunk 0 of this stage was done)
@@ -456,7 +465,7 @@ __device__ __forceinline__ void tdfaStreamBody(
             bool general;
             if constexpr (PAIR1) {
                 uint32_t na[NC], nc[NC];
-                if (ALLFULL || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                if (ALLFULL || waveFull || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
                 else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
                 tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
 #pragma unroll
@@ -506,15 +515,7 @@ __device__ __forceinline__ void tdfaStreamBody(
             pbase = base;
         }
         };  // runChunks
-        if constexpr (PAIR1 && (LAB & kLabNoStageFull) == 0) {
-            // every chunk of this stage has its next chunk wholly inside the line: chunk 0's next does not start in the head
-            // (s * stage + NB >= head) and chunk 7's next ends inside the line ((s + 1) * stage + NB <= L + head)
-            const bool stageFull = s * kTdfaStageBytes + uint32_t(NB) >= head && (s + 1) * kTdfaStageBytes + uint32_t(NB) <= L + head;
-            if (__all(stageFull)) runChunks(std::true_type{});
-            else runChunks(std::false_type{});
-        } else {
-            runChunks(std::false_type{});
-        }
+        runChunks(std::false_type{});
         if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
     if constexpr (DMA) tdfaDmaWait();  // (a stage in flight when the loop was left would land in the result tile)
