@@ -431,11 +431,18 @@ __device__ __forceinline__ void tdfaStreamBody(
                 if (nextOff + seg < srcSpan[i]) in[i] = *reinterpret_cast<GlobalQuadPtr>(dataAligned + (srcOff[i] + nextOff));
             }
         }
-        // (the chunk loop as a callable: ends early -- `return` -- when every line of the wave has ended; ALLFULL = false in the product)
-        auto runChunks = [&](auto allFullTag) {
+        // Round 5 (profiles/round5_tdfa_isa_budget.md).  Whether the NEXT chunk lies wholly inside the line used to be asked per chunk
+        // and lane -- six VALU and three SALU instructions per chunk, 0.75 VALU per line byte, and a branch per chunk that kept the
+        // compiler from scheduling across chunks.  It is a question about the wave's largest head and smallest head + length (taken
+        // once per kernel) and the chunk's position: scalar arithmetic.  A stage all of whose chunks pass runs a copy of the chunk loop
+        // that does not ask (ALLFULL: straight-line code, eight chunks scheduled as one); the first stage of a line (head bytes in
+        // chunks 0-1) and the last full one (only chunk 7's next chunk is short) run the asking copy for those chunks and the straight
+        // copy for the rest.  Returns true when every line of the wave has ended inside [C0, C1).
+        auto runChunks = [&](auto allFullTag, auto c0Tag, auto c1Tag) -> bool {
         constexpr bool ALLFULL = decltype(allFullTag)::value;
+        constexpr int C0 = decltype(c0Tag)::value, C1 = decltype(c1Tag)::value;
 #pragma unroll
-        for (int c = 0; c < kChunksPerStage; ++c) {
+        for (int c = C0; c < C1; ++c) {
             const uint32_t base = s * kTdfaStageBytes + uint32_t(c) * NB - head;  // line offset of byte 0 (wraps in the head)
             if constexpr (!ALLFULL && PAIR1) {
                 // Every line of the wave ends before this chunk: nothing is left to walk (the stamps of the chunk before are still
@@ -443,7 +450,7 @@ __device__ __forceinline__ void tdfaStreamBody(
                 // 16-byte row start: 512-byte lines take 8 stages and `head` (0..15) bytes of a ninth -- of whose eight chunks six or
                 // seven were walked on the identity column, in the copy of the loop that tests every byte (round 5: 11 % of the
                 // kernel's VALU instructions, profiles/round5_tdfa_isa_budget.md).
-                if (c > 0 && __all(s * kTdfaStageBytes + uint32_t(c) * NB >= head + L)) return;
+                if (c > 0 && __all(s * kTdfaStageBytes + uint32_t(c) * NB >= head + L)) return true;
             }
             const uint32_t nbase = base + NB;
             // Round 5: "the next chunk lies wholly inside the line, for every line of the wave" is a question about the wave's largest
@@ -514,8 +521,32 @@ __device__ __forceinline__ void tdfaStreamBody(
             }
             pbase = base;
         }
+        return false;
         };  // runChunks
-        runChunks(std::false_type{});
+        {
+            using std::integral_constant;
+            constexpr integral_constant<int, 0> k0{};
+            constexpr integral_constant<int, 2> k2{};
+            constexpr integral_constant<int, kChunksPerStage - 1> kLast{};
+            constexpr integral_constant<int, kChunksPerStage> kEnd{};
+            const uint32_t s0 = s * kTdfaStageBytes;
+            // chunk c's next chunk starts at s0 + (c + 1) * NB - head (not inside the head: maxHead <= ...) and ends at s0 + (c + 2) * NB
+            // - head (inside the line: minSpan >= ...)
+            const bool headsPastChunk0 = PAIR1 && waveMaxHead <= s0 + uint32_t(NB);
+            const bool headsPastChunk2 = PAIR1 && waveMaxHead <= s0 + 3u * uint32_t(NB);
+            const bool allNextInside = PAIR1 && waveMinSpan >= s0 + kTdfaStageBytes + uint32_t(NB);
+            const bool nextInsideButLast = PAIR1 && waveMinSpan >= s0 + kTdfaStageBytes;
+            if (headsPastChunk0 && allNextInside) {
+                (void)runChunks(std::true_type{}, k0, kEnd);
+            } else if (kChunksPerStage == 8 && headsPastChunk2 && allNextInside) {
+                if (!runChunks(std::false_type{}, k0, k2)) (void)runChunks(std::true_type{}, k2, kEnd);
+            } else if (kChunksPerStage == 8 && headsPastChunk0 && nextInsideButLast) {
+                (void)runChunks(std::true_type{}, k0, kLast);
+                (void)runChunks(std::false_type{}, kLast, kEnd);
+            } else {
+                (void)runChunks(std::false_type{}, k0, kEnd);
+            }
+        }
         if (__all((t & 0xFFFFu) == deadRow || s + 1 >= myStages)) break;
     }
     if constexpr (DMA) tdfaDmaWait();  // (a stage in flight when the loop was left would land in the result tile)
