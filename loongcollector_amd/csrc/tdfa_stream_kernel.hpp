@@ -313,7 +313,18 @@ __device__ __forceinline__ void tdfaStreamBody(
         }
     }
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
-    const uint32_t head = uint32_t(addr & 15);
+    // Round 5: a line's tile rows start AT its first byte (LC_TDFA_ROW_ALIGN = 1: head = 0).  Through round 4 they started at the
+    // 16-byte boundary below it, so that every 16-byte load was aligned -- and 15 of 16 lines began with junk bytes in their first two
+    // chunks (the copy of the chunk loop that tests every byte) and needed one stage more than their length: a 512-byte line took 9
+    // stages, the ninth for its last `head` bytes.  gfx950 takes the misaligned 16-byte loads (global_load_dwordx4 and the LDS-DMA form
+    // alike: ROCm runs compute queues in unaligned-access mode) at no measurable cost: 512-byte lines 0.1816 -> 0.1720 ms per Mi lines,
+    // roofline.frac 0.433 -> 0.458; the parity suites (ragged, unaligned, empty, 64 KiB+ lines) pass either way.  -DLC_TDFA_ROW_ALIGN=16
+    // restores the aligned rows.
+#ifndef LC_TDFA_ROW_ALIGN
+#define LC_TDFA_ROW_ALIGN 1
+#endif
+    static_assert(LC_TDFA_ROW_ALIGN == 1 || LC_TDFA_ROW_ALIGN == 4 || LC_TDFA_ROW_ALIGN == 16, "row alignment");
+    const uint32_t head = uint32_t(addr & (LC_TDFA_ROW_ALIGN - 1));
     const uintptr_t rowStart = addr - head;
     const uint32_t span = L ? head + L : 0;
     const uint32_t myStages = (span + kTdfaStageBytes - 1) / kTdfaStageBytes;
