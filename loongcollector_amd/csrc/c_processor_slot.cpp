@@ -279,8 +279,20 @@ extern "C" int lc_processor_parse_columnar(lc_processor_t* p, lc_event_group_t* 
     st->spans.assign(n * 2 * K, -1);
     st->state.assign(n, LC_COL_SKIPPED);
     st->contentBytes.assign(n, 0);
-    std::vector<const uint8_t*> linePtr;
-    std::vector<uint32_t> lineLen, lineEvent;
+    // (the call's scratch lives with the runner thread: five heap blocks per group, taken and given back by 32 threads at once, met
+    // in the allocator -- the leg lost throughput from 16 to 32 threads)
+    struct Scratch {
+        std::vector<const uint8_t*> linePtr;
+        std::vector<uint32_t> lineLen, lineEvent;
+        std::vector<int32_t> caps;
+        std::vector<uint8_t> status;
+    };
+    static thread_local Scratch tScratch;
+    std::vector<const uint8_t*>& linePtr = tScratch.linePtr;
+    std::vector<uint32_t>&lineLen = tScratch.lineLen, &lineEvent = tScratch.lineEvent;
+    linePtr.clear();
+    lineLen.clear();
+    lineEvent.clear();
     for (size_t i = 0; i < n; ++i) {
         if (!events[i].Is<logtail::LogEvent>()) continue;
         const logtail::LogEvent& ev = events[i].Cast<logtail::LogEvent>();
@@ -294,8 +306,10 @@ extern "C" int lc_processor_parse_columnar(lc_processor_t* p, lc_event_group_t* 
     }
     const uint32_t nLines = uint32_t(linePtr.size());
     if (nLines) {
-        std::vector<int32_t> caps(size_t(nLines) * 2 * G);
-        std::vector<uint8_t> status(nLines);
+        std::vector<int32_t>& caps = tScratch.caps;
+        std::vector<uint8_t>& status = tScratch.status;
+        caps.resize(size_t(nLines) * 2 * G);
+        status.resize(nLines);
         const int rc = lc_regex_match_host_views(const_cast<lc_regex_t*>(p->impl.Regex()), linePtr.data(), lineLen.data(), nLines, G,
                                                  caps.data(), status.data());
         if (rc != LC_OK) return rc;

@@ -340,6 +340,7 @@ struct DoneRequest {
     bool armed = false, consumed = false;
 };
 static thread_local DoneRequest tlsDone;
+static thread_local bool tlsJobTableInPlace = false;  // lcSetJobTableInPlace (zero-copy trips of the processors, below)
 
 // The kernel behind a (workgroup size, table format) pair: the interleaved-issue kernel (tdfa_stream_kernel.hpp) for the
 // class-indexed tables with or without the byte-pair extension, the phase-separated one (tdfa_kernel.hpp) for byte-indexed
@@ -1218,6 +1219,7 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
         JobTableRing::Table& tab = *hit;
         if (!tab.done) HIP_TRY(hipEventCreateWithFlags(&tab.done, hipEventDisableTiming));
         const bool reuse = tab.dev && tab.bytes == tableBytes && std::memcmp(tab.host, image.data(), tableBytes) == 0;
+        const bool inPlace = tlsJobTableInPlace && blocks <= 64;
         if (!reuse) {
             if (tab.inFlight) {
                 HIP_TRY(hipEventSynchronize(tab.done));
@@ -1235,12 +1237,16 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
                 tab.cap = cap;
             }
             std::memcpy(tab.host, image.data(), tableBytes);
-            HIP_TRY(hipMemcpyAsync(tab.dev, tab.host, tableBytes, hipMemcpyHostToDevice, stream));
-            tab.bytes = tableBytes;
+            if (!inPlace) {
+                HIP_TRY(hipMemcpyAsync(tab.dev, tab.host, tableBytes, hipMemcpyHostToDevice, stream));
+                tab.bytes = tableBytes;
+            }
         }
         tab.stream = stream;
-        const TdfaJob* dJobs = reinterpret_cast<const TdfaJob*>(tab.dev);
-        const uint16_t* dMap = reinterpret_cast<const uint16_t*>(tab.dev + mapAt);
+        // (in place: the pinned image itself -- valid for this launch only, so it is never taken for a device copy later: bytes = 0)
+        const uint8_t* tableAt = (inPlace && !reuse) ? tab.host : tab.dev;
+        const TdfaJob* dJobs = reinterpret_cast<const TdfaJob*>(tableAt);
+        const uint16_t* dMap = reinterpret_cast<const uint16_t*>(tableAt + mapAt);
         int rc = LC_OK;
         switch (variant) {
             case 0: rc = launchTdfaMulti<256, false>(dJobs, dMap, blocks, lds, stream); break;
@@ -1464,6 +1470,47 @@ namespace {
 __global__ void lc_signal_kernel(uint32_t* flag, uint32_t seq) {
     __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
 }
+std::atomic<int> gZeroCopyWaiters{0};
+}  // namespace
+
+// The two halves of a ZERO-COPY device trip's ending, for the processors that run one outside runHostPipeline (filter, columnar,
+// multiline: round 5).  Their kernels read the thread's pinned staging and write its pinned result block through the mapping; what is
+// left of a trip is to learn that the last kernel is done.  lcQueueTripSignal puts a one-lane kernel behind everything queued on the
+// stream that stores `seq` into the pinned word; lcAwaitTripSignal spins on the word while few threads wait and blocks in the runtime
+// when many do (a spinning thread burns a core the others stitch on) -- the policy runHostPipeline measured in round 2.
+int lcQueueTripSignal(uint32_t* hFlag, uint32_t seq, hipStream_t stream) {
+    void* fargs[] = {&hFlag, &seq};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(lc_signal_kernel), dim3(1), dim3(1), fargs, 0, stream));
+    return LC_OK;
+}
+int lcAwaitTripSignal(const uint32_t* hFlag, uint32_t seq, hipStream_t stream) {
+    static const bool pollOff = getenv("LC_HOST_NO_POLL") != nullptr;
+    const int ahead = gZeroCopyWaiters.fetch_add(1, std::memory_order_relaxed);
+    hipError_t waitErr = hipSuccess;
+    if (pollOff || ahead >= 4) {
+        waitErr = hipStreamSynchronize(stream);
+    } else {
+        const volatile uint32_t* flag = hFlag;
+        unsigned spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if (++spins > 40000u) {  // ~1 ms: a long kernel, or something is wrong -- the runtime's wait reports errors
+                waitErr = hipStreamSynchronize(stream);
+                break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    gZeroCopyWaiters.fetch_sub(1, std::memory_order_relaxed);
+    HIP_TRY(waitErr);
+    return LC_OK;
+}
+// lc_regex_match_device_multi on behalf of a zero-copy trip: the (small) job table is read by the kernel where the host wrote it, in
+// pinned memory -- no copy command per group on the SDMA queue, where the groups of all runner threads would meet.  A dozen workgroups
+// fetching 80 bytes over PCIe is nothing like the 250 that searched the table there in round 4.
+void lcSetJobTableInPlace(bool on) { tlsJobTableInPlace = on; }
+
+namespace {
 
 struct Slot {
     uint32_t* hFlag = nullptr;  // pinned: sequence number of the last finished zero-copy batch
@@ -1705,7 +1752,7 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
             // a 1000-line group last ~60 us; the runtime's wait costs ~40 us more per group than a spin: 2.5 vs 2.1 GB/s with one
             // thread).  Many: spinning threads burn the cores the others stitch on, and the runtime's blocking wait scales better
             // (20.0 vs 16.6 GB/s with 16 threads on a 16-core quota) -- tools/inagent_bench.cpp, profiles/round2_inagent.txt.
-            static std::atomic<int> waiters{0};
+            std::atomic<int>& waiters = gZeroCopyWaiters;
             const int ahead = waiters.fetch_add(1, std::memory_order_relaxed);
             hipError_t waitErr = hipSuccess;
             if (pollOff || ahead >= 4) {

@@ -22,6 +22,12 @@ void lcFilterThreadRelease();                          // processor_filter_gpu.c
 int lcHostEntryDevice(int* dev);
 // The device a DEVICE-pointer entry point runs on: the caller's current HIP device; LC_ERR_ARG when d_ptr lives on another device.
 int lcDeviceEntryDevice(const void* d_ptr, int* dev);
+// the ending of a zero-copy device trip (gpu_runtime.hip): a one-lane kernel behind everything on `stream` stores seq into the pinned word;
+// the host spins on it (few waiters) or blocks in the runtime (many)
+int lcQueueTripSignal(uint32_t* hFlag, uint32_t seq, hipStream_t stream);
+int lcAwaitTripSignal(const uint32_t* hFlag, uint32_t seq, hipStream_t stream);
+// the calling thread's next lc_regex_match_device_multi calls let the kernel read their (small) job tables from pinned memory
+void lcSetJobTableInPlace(bool on);
 // the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
 void lcSetDecideSlot(int slot);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)
