@@ -558,7 +558,9 @@ def run_headline(args):
     info = rx.info()
 
     n = args.lines
-    data, off, length = corpus.apache_batch(n, args.regex, args.line_bytes, seed=corpus.SEED + 1000 * rank)
+    # SURVEY.md section 8(d)'s recipe: every line generated on its own from one std::mt19937_64 stream, seed 20260921 (+ 1000 per rank);
+    # no line occurs twice (through round 4: 1 Mi draws from a pool of 8 192 numpy-made lines)
+    data, off, length = corpus.apache_lines(n, args.regex, args.line_bytes, seed=corpus.SEED + 1000 * rank)
     parsed_bytes_per_step = int(length.sum())
     d_data = torch.from_numpy(data).to(dev)
     d_off = torch.from_numpy(off.view(np.int32)).to(dev)
@@ -707,6 +709,8 @@ def run_headline(args):
             "data": "synthetic",
             "config": {"workload": "configs[1]: Apache-combined %dB lines, %d-group regex %s, %d-line batches resident in HBM"
                                    % (args.line_bytes, G, args.regex, n),
+                       "corpus": "every line generated on its own: std::mt19937_64, seed 20260921 (+1000 per rank), SURVEY.md section 8(d) field "
+                                 "distributions (tools/corpus_gen.cpp); all lines distinct, all match",
                        "engine": {1: "tdfa", 2: "nfa"}[info["engine"]], "lines_per_batch": n,
                        "tdfa_states": info["states"], "byte_classes": info["classes"],
                        "lds_table_bytes": info["table_bytes"], "parallelism": "line-shard x%d" % world,

@@ -49,6 +49,20 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+CORPUS_SRC = os.path.join(HERE, "..", "tools", "corpus_gen.cpp")
+CORPUS_LIB = os.path.join(LIBDIR, "libcorpus_gen.so")
+
+
+def build_corpus_gen():
+    """tools/corpus_gen.cpp (bench / test tooling: the headline corpus generated line by line from std::mt19937_64) -> lib/libcorpus_gen.so"""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if os.path.exists(CORPUS_LIB) and os.path.getmtime(CORPUS_LIB) > os.path.getmtime(CORPUS_SRC):
+        return CORPUS_LIB
+    cxx = shutil.which("g++") or _hipcc()
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", CORPUS_LIB, CORPUS_SRC])
+    return CORPUS_LIB
+
+
 def build_native(force=False, verbose=False, force_sources=()):
     """force_sources: basenames of sources to recompile even if their objects look current (smoke() uses it to show a real
     gfx950 compile on the GPU box)."""

@@ -105,6 +105,27 @@ def apache_batch(n_lines, kind="A", line_bytes=512, seed=SEED, pool_lines=8192, 
     return buf.reshape(-1), off, length
 
 
+def apache_lines(n_lines, kind="A", line_bytes=512, seed=SEED, poison_every=0):
+    """The headline corpus by SURVEY.md section 8(d)'s recipe: EVERY line generated on its own from one std::mt19937_64 stream (seed
+    20260921), field distributions as stated there (tools/corpus_gen.cpp; apache_batch draws from a pool of 8 192 numpy-made lines
+    instead, which the round-4 review flagged).  Same layout as apache_batch: (data uint8[n * (line_bytes + 1)], off uint32[n + 1],
+    len uint32[n]); poison_every=k makes every k-th line fail to match."""
+    import ctypes
+    from . import build as _build
+    lib = ctypes.CDLL(_build.build_corpus_gen())
+    lib.lc_corpus_apache_lines.restype = ctypes.c_int
+    lib.lc_corpus_apache_lines.argtypes = [ctypes.c_char, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    buf = np.empty((n_lines, line_bytes + 1), dtype=np.uint8)
+    rc = lib.lc_corpus_apache_lines(kind.encode(), n_lines, line_bytes, seed + (0 if kind == "A" else 1), buf.ctypes.data)
+    if rc != 0:
+        raise ValueError("line_bytes too small")
+    if poison_every:
+        buf[::poison_every, 0] = ord("{")
+    off = (np.arange(n_lines + 1, dtype=np.uint64) * (line_bytes + 1)).astype(np.uint32)
+    length = np.full((n_lines,), line_bytes, dtype=np.uint32)
+    return buf.reshape(-1), off, length
+
+
 def mixed_batch(n_lines, seed=SEED + 3, min_len=128, max_len=2048, json_fraction=0.3):
     """Config-5 style corpus: nginx-combined lines (match REGEX_B) mixed with JSON lines (must fail), log-uniform
     lengths.  -> (data, off[n+1], len[n])"""

@@ -146,3 +146,26 @@ def test_reference_boost_regex_search_vectors(golden_dir):
                 n += 1
                 assert (it.fullmatch(s) is not None) == want, (c["cite"], subj, type(it).__name__)
     assert n >= 16
+
+
+def test_headline_corpus_is_generated_line_by_line_and_every_line_matches():
+    """SURVEY.md section 8(d): std::mt19937_64, seed 20260921, every line generated on its own, exactly 512 bytes, every line a full
+    match of its regex (tools/corpus_gen.cpp behind corpus.apache_lines) -- and reproducible: a prefix of a longer run is the shorter run."""
+    from loongcollector_amd import corpus
+    for kind, rx, groups in (("A", corpus.REGEX_A, 10), ("B", corpus.REGEX_B, 11)):
+        data, off, length = corpus.apache_lines(20000, kind)
+        assert data.shape == (20000 * 513,) and (length == 512).all() and int(off[-1]) == 20000 * 513
+        raw = data.tobytes()
+        lines = [raw[i * 513:i * 513 + 512] for i in range(20000)]
+        assert all(raw[i * 513 + 512] == 10 for i in range(0, 20000, 97))
+        assert len(set(lines)) == 20000                                   # no line occurs twice
+        caps, status = OracleRegex(rx).fullmatch_batch(data, off[:-1], length)
+        assert status.all() and caps.shape == (20000, 2 * groups)
+        short, _, _ = corpus.apache_lines(500, kind)
+        assert short.tobytes() == raw[:500 * 513]
+        methods = [l.split(b'"')[1].split(b" ")[0] for l in lines]
+        share = {m: methods.count(m) / 20000 for m in (b"GET", b"POST", b"PUT", b"DELETE")}
+        assert abs(share[b"GET"] - 0.70) < 0.02 and abs(share[b"POST"] - 0.20) < 0.02 and abs(share[b"PUT"] - 0.05) < 0.01
+    poisoned, off, length = corpus.apache_lines(100, "A", poison_every=7)
+    _, status = OracleRegex(corpus.REGEX_A).fullmatch_batch(poisoned, off[:-1], length)
+    assert [int(s) for s in status] == [0 if i % 7 == 0 else 1 for i in range(100)]
