@@ -260,7 +260,7 @@ def measure_pipeline(thread_counts, buffer_bytes=512 << 10, n_buffers=64):
         assert pipe.fused == fused
         res = {}
         for t in thread_counts:
-            per_thread = max(4, n_buffers // t)
+            per_thread = max(8, n_buffers // t)
             gate = threading.Barrier(t + 1)
             ends = [0.0] * t
             kept = [0] * t
@@ -345,7 +345,7 @@ def measure_multiline(thread_counts, buffer_bytes=512 << 10, n_buffers=48):
            "reference_MBps": 238.0, "reference_what": "LoongCollector's published multi-line figure (README.md:66-67), whole agent, 1 thread"}
     res = {}
     for t in thread_counts:
-        per_thread = max(4, n_buffers // t)
+        per_thread = max(8, n_buffers // t)
         dt = _run_threads(t, per_thread, lambda tid, k: buffers[(tid + k) % len(buffers)], lambda tid, b: m.split_count(b))
         nbytes = sum(len(buffers[(tid + k) % len(buffers)]) for tid in range(t) for k in range(1, per_thread + 1))
         res[str(t)] = round(nbytes / dt / 1e6, 1)
@@ -400,7 +400,9 @@ def measure_filter(thread_counts, group_lines=1000, n_groups=128):
                    % (group_lines, 100.0 * sum(value_bytes) / sum(group_bytes))}
     res = {}
     for t in thread_counts:
-        per_thread = max(4, n_groups // t)
+        # (at least 16 timed groups per runner thread: with 4 -- 128 groups over 32 threads -- the timed window was a millisecond, of the
+        # order of the time Python needs to release 33 threads from the barrier, and the 32-thread figure measured that)
+        per_thread = max(16, n_groups // t)
         dt = _run_threads(t, per_thread, lambda tid, k: EventGroup(fixtures[(tid + k) % 4]), lambda tid, g: f.process(g))
         nbytes = sum(group_bytes[(tid + k) % 4] for tid in range(t) for k in range(1, per_thread + 1))
         res[str(t)] = round(nbytes / dt / 1e6, 1)
@@ -456,7 +458,7 @@ def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_count
     colp = Processor({"SourceKey": "content", "Regex": pattern, "Keys": keys})
     col = {}
     for t in thread_counts:
-        per_thread = max(4, (m // group_lines) // t)
+        per_thread = max(8, (m // group_lines) // t)
 
         def mk(tid, k):
             lo = ((tid * per_thread + k) * group_lines) % (m - group_lines + 1)
