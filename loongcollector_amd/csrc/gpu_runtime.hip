@@ -711,7 +711,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     int block = kNfaBlock;
     bool global = lds > kLcLdsPerCu || (lds > globalAbove && n > smallBatch);
     const uint32_t nPosAll = uint32_t(re->nfa.positions.size());
-    if (global && stageSmall) {
+    if (global && stageSmall && !atomic && re->nfa.slotCount() <= 64) {
         for (int waves : {4, 2, 1}) {
             const size_t need = lcNfaLdsBytes(blobBytes, nPosAll, atomic, uint32_t(waves));
             if (need > kLcLdsPerCu) continue;
@@ -808,7 +808,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         constexpr int NS = decltype(ns)::value;
         auto go = [&](auto a, auto g) {
             constexpr bool A = decltype(a)::value, G = decltype(g)::value;
-            if constexpr (!G) {  // (staged programs only: with the tables in L2 four values per workgroup stay)
+            if constexpr (!G && !A && NS <= 64) {  // (staged programs without atomic groups only -- an opt-in experiment does not get 24 more instantiations)
                 if (block == 128)
                     return launchNfaSlots<NS, A, G, 128>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
                                                          d_caps, d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
