@@ -609,7 +609,12 @@ static int launchDecide(lc_regex* re, int dev, const void* dBlob, const uint8_t*
 
 // which part of the NFA engine's chain a launch queues: all of it, the thread-list kernel only (lines that overflow keep LC_OVERFLOW),
 // or the second chance only (nfa_wide_kernel + the depth-first decide kernels, for the lines that still say LC_OVERFLOW)
-enum { kNfaWholeChain = 0, kNfaFirstChance = 1, kNfaSecondChance = 2 };
+// round 5 -- kNfaWideFirst: nfa_wide_kernel over EVERY line as the first chance (lines that need more than 128 threads keep
+// LC_OVERFLOW); kNfaDecideOnly: what is left behind a wide-first launch (the decide kernels alone); kNfaWideChain: both.  For
+// callers that know the pattern overflows 64 threads on their data; programs the wide kernel cannot run take the usual kernels.
+enum { kNfaWholeChain = 0, kNfaFirstChance = 1, kNfaSecondChance = 2, kNfaWideFirst = 3, kNfaDecideOnly = 4, kNfaWideChain = 5 };
+static thread_local uint32_t* tlsWideNote = nullptr;  // lcSetWideNote: where the next wide launch reports "more than 64 threads were needed"
+void lcSetWideNote(uint32_t* note) { tlsWideNote = note; }
 
 template <int NS, bool ATOMIC, bool GLOBAL, int BLOCK = kNfaBlock>
 static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, size_t lds, const uint8_t* d_data,
@@ -626,14 +631,24 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
     }
     constexpr uint32_t kWaves = BLOCK / 64;
     const uint32_t grid = (n + kWaves - 1) / kWaves;
-    if (chance != kNfaSecondChance) {
+    uint32_t* const wideNote = tlsWideNote;
+    tlsWideNote = nullptr;
+    if (chance == kNfaDecideOnly) return LC_OK;
+    bool wideFirst = chance == kNfaWideFirst || chance == kNfaWideChain;
+    if constexpr (ATOMIC || NS > 64) wideFirst = false;
+    {
+        static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
+        const size_t wideLds0 = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4;
+        if (wideOff || !overflowFlag || wideLds0 > 64 * 1024) wideFirst = false;
+    }
+    if (chance != kNfaSecondChance && !wideFirst) {
         noteKernel(ATOMIC ? "nfa_match_kernel<atomic>" : "nfa_match_kernel");
         hipLaunchKernelGGL((nfa_match_kernel<NS, ATOMIC, GLOBAL, BLOCK>), dim3(grid), dim3(BLOCK), lds, stream, d_data, d_off, d_len, sep, n,
                            d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag,
                            seq, pendingFlag);
         HIP_TRY(hipGetLastError());
     }
-    if (chance == kNfaFirstChance) return LC_OK;
+    if (chance == kNfaFirstChance || (chance == kNfaWideFirst && !wideFirst)) return LC_OK;
     // Second chance for the lines that needed more than 64 live threads (nfa_wide_kernel.hpp: two threads per lane), for
     // patterns without atomic groups whose capture offsets fit twice into a lane's registers.  Its workgroups return at
     // once unless the launch above raised the overflow flag.
@@ -641,7 +656,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
         static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
         const size_t wideLds = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4;
         if (!wideOff && overflowFlag && wideLds <= 64 * 1024) {
-            noteKernel("nfa_wide_kernel");
+            noteKernel(wideFirst ? "nfa_wide_kernel:first" : "nfa_wide_kernel");
             // (wideLdsMode: the batch is small and program + scratch fit the CU's LDS -- the program is staged, launchNfa decides)
             if (wideLdsMode && wideLds + blobBytes <= kLcLdsPerCu) {
                 static thread_local size_t wideAttrSet[kLcMaxDevices] = {};
@@ -655,10 +670,12 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
                     }
                 }
                 hipLaunchKernelGGL((nfa_wide_kernel<NS, true>), dim3(n), dim3(64), need, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
-                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq);
+                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq,
+                                   wideFirst ? 1u : 0u, wideNote);
             } else {
                 hipLaunchKernelGGL((nfa_wide_kernel<NS, false>), dim3(n), dim3(64), wideLds, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
-                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq);
+                                   d_resume, static_cast<const uint32_t*>(dBlob), blobBytes, ngroups, d_caps, d_status, overflowFlag, seq,
+                                   wideFirst ? 1u : 0u, wideNote);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -672,6 +689,10 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     if (re->nfaBlob.empty()) {
         tlsError = "pattern has no NFA program";
         return LC_ERR_UNSUPPORTED;
+    }
+    if (chance == kNfaWholeChain) {  // LC_NFA_WIDE_FIRST=1: every whole chain starts with the wide kernel (parity tests; read per launch)
+        const char* wf = getenv("LC_NFA_WIDE_FIRST");
+        if (wf && wf[0] == '1') chance = kNfaWideChain;
     }
     void* dBlob = nullptr;
     int rc = ensureUploaded(re, dev, kBlobNfa, &dBlob);
@@ -736,7 +757,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // one word behind the tables (ensureUploaded): raised by the kernel to this launch's sequence number when a line overflows
     uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dBlob) + blobBytes);
     uint32_t seq;
-    if (chance == kNfaSecondChance) {
+    if (chance == kNfaSecondChance || chance == kNfaDecideOnly) {
         seq = seqInOut ? *seqInOut : 0;  // the first-chance launch's number: its overflow flag is what the kernels test
         if (!seq) return LC_OK;
     } else {
@@ -836,7 +857,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // Can a thread list overflow at all?  Without atomic groups a list holds at most one thread per position.
     const bool wideApplies = !atomic && slots <= 64 && (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4 <= 64 * 1024;
     const bool canOverflow = atomic || nPos > (wideApplies ? uint32_t(kNfaWideThreads) : 64u);
-    if (!canOverflow || chance == kNfaFirstChance) return LC_OK;
+    if (!canOverflow || chance == kNfaFirstChance || chance == kNfaWideFirst) return LC_OK;
     return launchDecide(re, dev, dBlob, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream,
                         overflowFlag, seq);
 }
@@ -961,6 +982,28 @@ int lcMatchSecondChanceOnStream(lc_regex* re, int engine, int dev, const uint8_t
     if (!seq || engine != LC_ENGINE_NFA) return LC_OK;
     return lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, streamPtr,
                                 kNfaSecondChance, &seq);
+}
+
+int lcMatchWideFirstOnStream(int part, lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                             uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                             uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, uint32_t* seq, uint32_t* wideNote, void* streamPtr) {
+    if (part == 1) {
+        if (!seq || !*seq || engine != LC_ENGINE_NFA) return LC_OK;
+        return lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, streamPtr,
+                                    kNfaDecideOnly, seq);
+    }
+    if (seq) *seq = 0;
+    if (engine == LC_ENGINE_NFA) lcSetWideNote(wideNote);
+    const int rc = lcMatchChainOnStream(re, engine, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status,
+                                        streamPtr, part == 0 ? kNfaWideFirst : kNfaWideChain, seq);
+    lcSetWideNote(nullptr);
+    return rc;
+}
+bool lcNfaWideApplies(const lc_regex* re) {
+    static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
+    if (!re || wideOff || re->nfaBlob.empty() || re->nfa.atomicCount > 0 || re->nfa.slotCount() > 64) return false;
+    const uint32_t nPos = uint32_t(re->nfa.positions.size());
+    return (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4 <= 64 * 1024;
 }
 
 static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -71,6 +72,8 @@ struct GrokDeviceState {
     void* dScreens[kLcMaxDevices] = {};
     uint32_t nScreens[kLcMaxDevices] = {};
     uint32_t screenLdsBytes[kLcMaxDevices] = {};  // largest staged table
+    uint32_t nBigScreens[kLcMaxDevices] = {};     // the table's first entries: screens too large for that, see GrokScreenDev::bigBytes
+    uint32_t bigScreenLdsBytes[kLcMaxDevices] = {};
     std::vector<GrokScreenDev> hostScreens[kLcMaxDevices];  // the same table on the host (kernel arguments of the remainder screens)
     // lcGrokMatchHost: groups of runner threads that arrive while a batch is on the device travel together (group commit)
     struct HostJob;
@@ -330,7 +333,8 @@ static int grokMatchSequential(const std::vector<GrokDevicePattern>& patterns, G
 namespace {
 constexpr int kGrokMaxStreams = 16;  // (LC_GROK_STREAMS; the default stays opts.streams = 8)
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
-constexpr uint32_t kGrokMaxRounds = GC_REMAINDER - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
+constexpr uint32_t kGrokScreenBigMax = 150 * 1024;   // ... and up to this size by a workgroup that has its CU's LDS to itself (small batches)
+constexpr uint32_t kGrokMaxRounds = GC_WIDE - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
 constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
@@ -446,7 +450,7 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
     if (!state->screensBuilt[dev]) {
         static const bool noStage = getenv("LC_GROK_SCREEN_NO_LDS") != nullptr;
         std::vector<GrokScreenDev> host;
-        uint32_t maxStage = 0;
+        uint32_t maxStage = 0, maxBig = 0;
         for (size_t p = 0; p < patterns.size(); ++p) {
             lc_regex* scr = planScreenOf(patterns[p]);
             if (!scr) continue;
@@ -456,9 +460,16 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
             d.bit = uint32_t(p);
             const uint32_t stage = scr->screenBlob[SC_TOTAL_BYTES] - scr->screenBlob[SC_OFF_ACCEPT];
             d.ldsBytes = (!noStage && stage <= kGrokScreenStageMax) ? (stage + 3u) & ~3u : 0u;
+            d.bigBytes = (!noStage && !d.ldsBytes && stage <= kGrokScreenBigMax) ? (stage + 3u) & ~3u : 0u;
             maxStage = std::max(maxStage, d.ldsBytes);
+            maxBig = std::max(maxBig, d.bigBytes);
             host.push_back(d);
         }
+        std::stable_sort(host.begin(), host.end(), [](const GrokScreenDev& x, const GrokScreenDev& y) { return (x.bigBytes != 0) > (y.bigBytes != 0); });
+        uint32_t nBig = 0;
+        for (const GrokScreenDev& d : host) nBig += d.bigBytes != 0;
+        state->nBigScreens[dev] = nBig;
+        state->bigScreenLdsBytes[dev] = maxBig;
         if (!host.empty()) {
             void* p = nullptr;
             HIP_TRY(hipMalloc(&p, host.size() * sizeof(GrokScreenDev)));
@@ -487,8 +498,9 @@ struct PlanEntry {
     uint32_t level = 0;   // 0: evaluated at once; L > 0: most of its candidates have an EARLIER candidate entry (of level < L) -- it waits
                           // for those and only looks at the values none of them has won (a general format behind specific ones)
     bool queued = false;  // rounds behind the first match were queued for this entry
-    uint32_t earlyOv = 0, earlyUn = 0;  // phase 2c: the second chance / the search proper were queued by the entry's history, before the counts
+    bool wideFirst = false;  // round 0 ran nfa_wide_kernel over every candidate (the entry's history says its values overflow 64 threads)
     uint32_t seq0 = 0;    // launch sequence of round 0's first-chance kernel (lcMatchSecondChanceOnStream)
+    uint32_t seqS = 0;    // ... and of the search proper's (phase 2c)
     const GrokScreenDev* remainderScreen = nullptr;  // the entry's screen (host copy), walked over what is left behind a first match
     int stream = 0;
     double cost = 0, cost0 = 0, cost1 = 0;  // heuristic; measured round 0 / leftovers (ns, 0 = unknown)
@@ -568,9 +580,37 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         sliceLen = std::max(256u, std::min(small ? 4096u : 1024u, sliceLen));
         const uint32_t slices = (n + sliceLen - 1) / sliceLen;
         lcNoteKernel("grok_screen_all_kernel");
-        hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + (small ? screenLds : 0),
-                           st, d_data, d_off, d_len, n, sliceLen, screens, reinterpret_cast<unsigned long long*>(masks),
-                           static_cast<const uint32_t*>(order), small ? 1u : 0u);
+        // Round 5: a relaxed whole-pattern screen of 1 000-2 000 states (70-130 KB) does not fit beside other workgroups and walked its
+        // table through L2 -- 120 ns a byte, 0.5 ms for a 4 KiB value: the whole screen phase of a small batch waited for three such
+        // screens (profiles/round5_grok_timeline.txt).  They now run in a launch of their own, on a worker stream beside the other
+        // screens' launch, each workgroup with the table staged into a CU's whole LDS.  LC_GROK_BIG_SCREENS=0: as before.
+        static const bool bigOff = [] {
+            const char* v = getenv("LC_GROK_BIG_SCREENS");
+            return v && v[0] == '0';
+        }();
+        const uint32_t nBig = (small && !bigOff) ? state->nBigScreens[dev] : 0u;
+        if (nBig) {
+            const size_t bigLds = size_t(sliceLen) * 4 + state->bigScreenLdsBytes[dev];
+            static thread_local size_t attrSet[kLcMaxDevices] = {};
+            if (bigLds > 48 * 1024 && dev < kLcMaxDevices && bigLds > attrSet[dev]) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grok_screen_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            int(bigLds)));
+                attrSet[dev] = bigLds;
+            }
+            HIP_TRY(hipEventRecord(T.fork, st));
+            HIP_TRY(hipStreamWaitEvent(T.workers[0], T.fork, 0));
+            hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nBig), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, d_off, d_len, n,
+                               sliceLen, screens, reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), 2u);
+            HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
+        }
+        if (nScreens > nBig)
+            hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens - nBig), dim3(kGrokPlanBlock),
+                               size_t(sliceLen) * 4 + (small ? screenLds : 0), st, d_data, d_off, d_len, n, sliceLen, screens + nBig,
+                               reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), small ? 1u : 0u);
+        if (nBig) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
+        if (trace && nBig)
+            fprintf(stderr, "grok plan 1: %u big screens in a launch of their own (%u KB of LDS per workgroup)\n", nBig,
+                    unsigned((size_t(sliceLen) * 4 + state->bigScreenLdsBytes[dev]) >> 10));
     }
     uint32_t* firstOf = orderWork + 512;  // [64]
     HIP_TRY(hipMemsetAsync(firstOf, 0, 256, st));
@@ -709,7 +749,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         e.dev.columns = e.columns;
         e.dev.anchored = patterns[e.p].anchored ? 1u : 0u;
         T.hostEntries[a] = e.dev;
-        T.hostRemScreens[a] = e.remainderScreen ? *e.remainderScreen : GrokScreenDev{nullptr, e.p, 0u};
+        T.hostRemScreens[a] = e.remainderScreen ? *e.remainderScreen : GrokScreenDev{nullptr, e.p, 0u, 0u, 0u};
         if (e.remainderScreen) {
             ++nRemScreens;
             remScreenLds = std::max(remScreenLds, e.remainderScreen->ldsBytes);
@@ -801,6 +841,46 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             }
             return idx;
         };
+        // ---- round 5's plan knobs (each one can be switched off for A/B measurements; read per batch: the GPU tests flip them)
+        auto envInt = [](const char* name, int dflt) {
+            const char* v = getenv(name);
+            return v ? atoi(v) : dflt;
+        };
+        const int wideFirstMode = envInt("LC_GROK_WIDE_FIRST", 1);      // 0 off, 1 by the entry's history, 2 always
+        const bool breadthFirst = envInt("LC_GROK_BREADTH", 1) != 0;    // phase 2c queues the chains' launches round-robin, heavy kernels first
+        const int earlyRoundsMode = envInt("LC_GROK_EARLY_ROUNDS", 1);  // 0 off, 1 by the entry's history, 2 always
+        const bool remainderLiteral = envInt("LC_GROK_REMAINDER_LITERAL", 1) != 0 && literalIndex != nullptr;
+        // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
+        // first chance is nfa_wide_kernel over every candidate, and what is left behind it are the decide kernels alone.  Round 4's
+        // timeline: the longest entry's first chance 1.0 ms + its second chance (14 values restarted from byte 0) 1.1 ms, back to back
+        // on the critical path of the batch; now 1.1 ms.
+        auto wantsWideFirst = [&](lc_regex* h) {
+            if (!wideFirstMode || h->engine != LC_ENGINE_NFA || !lcNfaWideApplies(h)) return false;
+            return wideFirstMode >= 2 || h->grokOverflowSeen.load(std::memory_order_relaxed) != 0;
+        };
+        // one engine call of entry e on stream ws: the first-chance kernel ...
+        auto runFirst = [&](PlanEntry& e, lc_regex* h, bool wide, const uint32_t* count, const uint32_t* list, bool withFrom, uint32_t* seq,
+                            hipStream_t ws) -> int {
+            const uint32_t* resume = withFrom ? e.dev.from : nullptr;
+            if (wide)
+                return lcMatchWideFirstOnStream(0, h, h->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count, list, resume, e.capsRow / 2,
+                                                e.caps, e.status, seq, e.dev.cnt + GC_WIDE, ws);
+            return lcMatchFirstOnStream(h, h->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count, list, resume, e.capsRow / 2, e.caps,
+                                        e.status, seq, ws);
+        };
+        // ... and what is left behind it (note: the entry's GC_WIDE word, set when the wide kernel had anything to do)
+        auto runSecond = [&](PlanEntry& e, lc_regex* h, bool wide, const uint32_t* count, const uint32_t* list, bool withFrom, uint32_t seq,
+                             uint32_t* note, hipStream_t ws) -> int {
+            const uint32_t* resume = withFrom ? e.dev.from : nullptr;
+            if (wide)
+                return lcMatchWideFirstOnStream(1, h, h->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count, list, resume, e.capsRow / 2,
+                                                e.caps, e.status, &seq, nullptr, ws);
+            lcSetWideNote(note);
+            const int r = lcMatchSecondChanceOnStream(h, h->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, count, list, resume,
+                                                      e.capsRow / 2, e.caps, e.status, seq, ws);
+            lcSetWideNote(nullptr);
+            return r;
+        };
         // 2a
         {
             int rc = fork();
@@ -813,17 +893,16 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (e.level) continue;  // (waits for the entries that shadow it: phase 2c)
                 lcSetDecideSlot(1 + e.stream);
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                e.wideFirst = wantsWideFirst(first);
                 // (failures inside the forked region become rc: the workers are always joined below)
                 if (calibrate && hipEventRecord(T.tick[2 * a], T.workers[e.stream]) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
-                if (rc == LC_OK)
-                    rc = lcMatchFirstOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, nullptr, nullptr,
-                                              gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, &e.seq0, T.workers[e.stream]);
+                if (rc == LC_OK) rc = runFirst(e, first, e.wideFirst, nullptr, nullptr, !gp.anchored, &e.seq0, T.workers[e.stream]);
                 if (calibrate) (void)hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]);
                 if (trace)
-                    fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
+                    fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
                             e.p, e.cand, e.stream, first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2",
-                            gp.anchored ? " (anchored)" : "", first->nfa.positions.size(), first->nfa.slotCount(), first->nfa.atomicCount, e.cost0 * 1e-6,
-                            e.cost1 * 1e-6);
+                            gp.anchored ? " (anchored)" : "", e.wideFirst ? " (wide first)" : "", first->nfa.positions.size(), first->nfa.slotCount(),
+                            first->nfa.atomicCount, e.cost0 * 1e-6, e.cost1 * 1e-6);
             }
             rc = join(rc);
             if (rc != LC_OK) return rc;
@@ -838,148 +917,14 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                xstride, xcount);
         uint32_t maxLevel = 0;
         for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
-        // LC_GROK_EARLY=1 (experiment, measured and left off: profiles/round5_grok_steps.txt): the chains of level 1 and -- by the
-        // entries' history -- the second chances / unanchored searches of level 0 are queued BEFORE the host reads round 0's counts.
-        // The device has them earlier, but a batch is bound by the rate at which the host can queue launches, and the extra
-        // (mostly empty) chains cost more than the earlier start gains: 16 Ki values 4.76 -> 5.4 ms, 1000 values 3.9 -> 5.2 ms.
-        static const bool earlyChains = getenv("LC_GROK_EARLY") != nullptr;
-        bool finishQueued = false;
-        auto queueFinish = [&] {  // the values won so far (atomicMin per value: idempotent, finishAll runs it again at the end)
-            if (finishQueued) return;
-            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
-                               static_cast<const uint32_t*>(nullptr), 0u);
-            finishQueued = true;
-        };
+        // (Tried in round 5 and dropped -- profiles/round5_grok_steps.txt: the chains of level 1, and by the entries' history the
+        // leftovers of level 0, queued BEFORE the host reads round 0's counts.  The device has them earlier, but a batch is bound by
+        // the rate at which the host can queue launches, and the extra, mostly empty chains cost more than the earlier start gained:
+        // 16 Ki values 4.76 -> 5.4 ms, 1000 values 3.9 -> 5.2 ms.)
         HIP_TRY(hipGetLastError());
-        // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
-        // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
-        // entries on the values nobody before them has won.  Their chains are queued whole: they are few.
-        // Round 5: the chains of LEVEL 1 need nothing the host has to read first -- their list lengths stay on the device -- so they are
-        // queued BEFORE the host waits for round 0's counts: the device works on them while the host reads, and while it queues the
-        // leftovers of level 0 behind (in round 4's timeline the level-1 kernels started 1.2 ms after the fork, behind sixty launches
-        // of mostly empty leftover chains: they, not the second-chance kernel, ended the phase).
-        auto queueChain = [&](size_t a, int& rc, bool early) {  // the 2c chain of active entry a on its stream; rc: first failure (the caller joins)
-            PlanEntry& e = act[a];
-            const GrokDevicePattern& gp = patterns[e.p];
-            const uint32_t level = e.level;
-            // level 0 -- early: queued by the entry's history before the counts are known (1 = wanted); late: by the counts, minus what
-            // went early
-            const uint32_t ov = level ? 0u : early ? e.earlyOv : (e.earlyOv ? 0u : cnt(a, GC_OVERFLOW));
-            const uint32_t un = level ? 0u : early ? e.earlyUn : (e.earlyUn ? 0u : cnt(a, GC_UNANCHORED));
-            if (!level && !ov && !un) return;
-            if (level >= 2) {  // behind its main shadower
-                uint32_t best = 0, bestF = 0;
-                for (uint32_t f = 0; f < e.p; ++f)
-                    if (T.hostWords[HW_SHADOW + e.p * 64 + f] > best && map.activeOfBit[f] >= 0) {
-                        best = T.hostWords[HW_SHADOW + e.p * 64 + f];
-                        bestF = f;
-                    }
-                if (best) {
-                    const size_t sa = size_t(map.activeOfBit[bestF]);
-                    e.stream = act[sa].stream;
-                    hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
-                                       0, T.workers[e.stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
-                }
-            }
-            hipStream_t ws = T.workers[e.stream];
-            if (calibrate && hipEventRecord(T.tick[2 * nAct + 2 * a], ws) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
-            const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-            auto post = [&](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
-                hipLaunchKernelGGL(grok_post_kernel, dim3(grid, 1), dim3(kGrokPlanBlock), 0, ws, T.dEntries, uint32_t(a), in, inCount, flags, xtmp,
-                                   xcap, xstride, xcount);
-            };
-            // the search proper over the slots in `list`, minus the values an earlier entry has won; then its post step
-            auto searchProper = [&](const uint32_t* list, const uint32_t* count) -> int {
-                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner), list,
-                                   count, e.listB, e.dev.cnt + GC_FILTERED);
-                int r2 = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_FILTERED, e.listB,
-                                         e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                if (r2 != LC_OK) return r2;
-                post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
-                return LC_OK;
-            };
-            if (rc == LC_OK && level == 0) {
-                if (trace)
-                    fprintf(stderr, "grok plan 2c%s: entry %u overflowed %u unanchored %u\n", early ? " (early, by history)" : "", e.p,
-                            early ? 0u : cnt(a, GC_OVERFLOW), early ? 0u : cnt(a, GC_UNANCHORED));
-                lcSetDecideSlot(1 + e.stream);
-                if (ov) {  // the second chance of round 0's engine over the overflow list, then the post step over that list
-                    lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                    rc = lcMatchSecondChanceOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW,
-                                                     e.dev.ovList, gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, e.seq0, ws);
-                    if (rc == LC_OK) post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
-                }
-                // (round 5: only when the anchored search left any value unmatched -- the host knows the count; the six launches of an
-                // empty search chain were queued for every entry that had an overflow)
-                if (rc == LC_OK && gp.anchored && un) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
-            } else if (rc == LC_OK) {
-                if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u stream %d\n", e.p, e.level, e.cand, e.stream);
-                lcSetDecideSlot(1 + e.stream);
-                // every slot whose value nobody before has won: the anchored search (or the search) in full, then the rest
-                uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
-                hipLaunchKernelGGL(grok_filter_won_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, e.dev, static_cast<const uint32_t*>(winner),
-                                   static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), mine, e.dev.cnt + GC_OVERFLOW);
-                lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-                rc = lcMatchOnStream(first, first->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, e.dev.cnt + GC_OVERFLOW, mine,
-                                     gp.anchored ? nullptr : e.dev.from, e.capsRow / 2, e.caps, e.status, ws);
-                if (rc == LC_OK) {
-                    post(mine, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
-                    if (gp.anchored) rc = searchProper(e.dev.unanchored, e.dev.cnt + GC_UNANCHORED);
-                }
-            }
-            if (calibrate) (void)hipEventRecord(T.tick[2 * nAct + 2 * a + 1], ws);  // (whichever way the chain ended)
-        };
-        bool forked = false;
-        int rc2c = LC_OK;
-        bool anyEarly = false;
-        for (size_t a = 0; a < nAct; ++a) {
-            PlanEntry& e = act[a];
-            if (e.level) continue;
-            const GrokDevicePattern& gp = patterns[e.p];
-            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-            e.earlyOv = earlyChains && e.seq0 && first->grokOverflowSeen.load(std::memory_order_relaxed) ? 1u : 0u;
-            e.earlyUn = earlyChains && gp.anchored && first->grokUnanchoredSeen.load(std::memory_order_relaxed) ? 1u : 0u;
-            anyEarly = anyEarly || e.earlyOv || e.earlyUn;
-        }
-        if (earlyChains && (maxLevel || anyEarly)) {
-            queueFinish();
-            rc2c = fork();
-            if (rc2c != LC_OK) return rc2c;  // (nothing queued on the workers yet)
-            forked = true;
-            // first what round 0 is expected to have left behind (the second chance is the longest kernel of the phase), each on the
-            // stream round 0 put its entry on
-            for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a)
-                if (!act[a].level && (act[a].earlyOv || act[a].earlyUn)) {
-                    busy2c[a] = 1;
-                    queueChain(a, rc2c, true);
-                }
-            // level 1 goes to the streams that carry the least of round 0's expected leftovers (an expensive second chance must not
-            // find a shadowed entry's chain queued in front of it)
-            for (size_t a = 0; a < nAct; ++a)
-                if (act[a].level == 1) busy2c[a] = 1;
-            double load[kGrokMaxStreams] = {};
-            for (size_t a = 0; a < nAct; ++a)
-                if (!act[a].level) load[act[a].stream] += act[a].cost1;
-            std::vector<size_t> lvl1;
-            for (size_t a = 0; a < nAct; ++a)
-                if (act[a].level == 1) lvl1.push_back(a);
-            auto costOf = [&](size_t a) { return act[a].cost1 > 0 ? act[a].cost1 : act[a].cost * 50.0; };
-            std::stable_sort(lvl1.begin(), lvl1.end(), [&](size_t x, size_t y) { return costOf(x) > costOf(y); });
-            for (size_t a : lvl1) {
-                uint32_t best = 0;
-                for (uint32_t s2 = 1; s2 < used; ++s2)
-                    if (load[s2] < load[best]) best = s2;
-                act[a].stream = int(best);
-                load[best] += costOf(a) + 20000.0;
-                if (rc2c == LC_OK) queueChain(a, rc2c, true);
-            }
-        }
         {
-            int rc = readCounts();  // sync 2 (the level-1 chains are running meanwhile)
-            if (rc != LC_OK) {
-                if (forked) (void)join(rc);
-                return rc;
-            }
+            int rc = readCounts();  // sync 2
+            if (rc != LC_OK) return rc;
         }
         auto learn = [&](std::atomic<uint32_t>& slot, hipEvent_t b, hipEvent_t e2, uint32_t cand) {
             float ms = 0;
@@ -994,56 +939,200 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
                 if (!act[a].level) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
-        for (size_t a = 0; a < nAct; ++a) {  // the entries' histories: seen now = 8, else forgotten a batch at a time
-            PlanEntry& e = act[a];
-            if (e.level) continue;
+        // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
+        // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
+        // entries on the values nobody before them has won.  ONE fork for all of it: the leftovers of level 0 and the entries of
+        // level 1 depend on round 0 only; an entry of level 2 or 3 goes behind the chain of the entry that shadows most of its
+        // candidates, on that entry's stream (stream order instead of a barrier per level).
+        //
+        // Round 5: a chain is built as a list of STEPS (one to three launches each) and the steps of all chains are queued round-robin,
+        // dearest chain first.  Round 4 queued chain after chain: a dozen launches each, 15-20 us a launch -- the third shadowed
+        // entry's kernel started 0.8 ms after the fork, behind sixty launches of other entries' mostly empty follow-up steps, and it,
+        // not the second-chance kernel, ended the phase.  And an entry whose remainders mostly pass its screen (by its history:
+        // grokRemainderSeen) gets its search rounds behind the first match queued HERE, at the end of its chain, unscreened: they run
+        // in the shadow of this phase instead of in a phase of their own behind the remainder screens and another host round trip.
+        using Step = std::function<void(int&)>;
+        std::vector<std::vector<Step>> chains(nAct);
+        std::vector<size_t> chainOwner(nAct);  // whose list an entry's steps went to (itself; a level >= 2 entry: its shadower's owner)
+        for (size_t a = 0; a < nAct; ++a) chainOwner[a] = a;
+        unsigned long long earlyMask = 0;  // active entries whose rounds were queued in this phase
+        auto wantsEarlyRounds = [&](const PlanEntry& e) {
             const GrokDevicePattern& gp = patterns[e.p];
-            lc_regex* first = gp.anchored ? gp.anchored : gp.re;
-            auto note = [](std::atomic<uint32_t>& h, bool seen) {
-                const uint32_t v = h.load(std::memory_order_relaxed);
-                if (seen) h.store(8, std::memory_order_relaxed);
-                else if (v) h.store(v - 1, std::memory_order_relaxed);
-            };
-            note(first->grokOverflowSeen, cnt(a, GC_OVERFLOW) != 0);
-            note(first->grokUnanchoredSeen, cnt(a, GC_UNANCHORED) != 0);
-        }
-        {
-            bool any0 = false;
-            for (size_t a = 0; a < nAct; ++a)
-                any0 = any0 || (!act[a].level && ((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn)));
-            if (any0 || maxLevel >= (earlyChains ? 2u : 1u)) {
-                if (!forked) {
-                    queueFinish();
-                    rc2c = fork();
-                    if (rc2c != LC_OK) return rc2c;
-                    forked = true;
+            if (!earlyRoundsMode || e.rounds < 2 || gp.re->engine != LC_ENGINE_TDFA) return false;
+            if (earlyRoundsMode >= 2) return true;
+            return !calibrate && gp.re->grokRemainderSeen.load(std::memory_order_relaxed) != 0;
+        };
+        // rounds 1 .. of entry a (FindNextMatch from the end of the previous match; the list lengths stay on the device), one step per
+        // round.  screened: round 1 reads the survivors of the remainder screen (phase 2e); else every slot in play (queued ahead)
+        auto roundSteps = [&](size_t a, bool screened, std::vector<Step>& out) {
+            PlanEntry& e0 = act[a];
+            e0.queued = true;
+            for (uint32_t r = 1; r < e0.rounds; ++r)
+                out.push_back([&, a, r, screened](int& rc) {
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    hipStream_t ws = T.workers[e.stream];
+                    lcSetDecideSlot(1 + e.stream);
+                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+                    const uint32_t* list = r == 1 ? (screened ? e.unanchored : e.listA) : (r & 1) ? e.listA : e.listB;
+                    uint32_t* out2 = (r & 1) ? e.listB : e.listA;
+                    const uint32_t* countPtr = r == 1 ? e.dev.cnt + (screened ? GC_REMAINDER : GC_ROUND0) : e.dev.cnt + GC_ROUND0 + r - 1;
+                    rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
+                                         e.capsRow / 2, e.caps, e.status, ws);
+                    if (rc != LC_OK) return;
+                    hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
+                                       e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out2, e.dev.cnt + GC_ROUND0 + r,
+                                       r + 1 == e.rounds ? gate : static_cast<uint32_t*>(nullptr));
+                });
+        };
+        auto buildChain = [&](size_t a) {
+            PlanEntry& e0 = act[a];
+            const uint32_t level = e0.level;
+            const uint32_t ov = level ? 0u : cnt(a, GC_OVERFLOW);
+            const uint32_t un = level ? 0u : cnt(a, GC_UNANCHORED);
+            const bool early = wantsEarlyRounds(e0);
+            if (!level && !ov && !un && !early) return;
+            size_t owner = a;  // whose list the steps go to
+            if (level >= 2) {  // behind its main shadower
+                uint32_t best = 0, bestF = 0;
+                for (uint32_t f = 0; f < e0.p; ++f)
+                    if (T.hostWords[HW_SHADOW + e0.p * 64 + f] > best && map.activeOfBit[f] >= 0) {
+                        best = T.hostWords[HW_SHADOW + e0.p * 64 + f];
+                        bestF = f;
+                    }
+                if (best) {
+                    const size_t sa = size_t(map.activeOfBit[bestF]);
+                    e0.stream = act[sa].stream;
+                    owner = chainOwner[sa];
+                    chainOwner[a] = owner;
+                    chains[owner].push_back([&, a, sa](int& rc) {
+                        if (rc != LC_OK) return;
+                        hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
+                                           0, T.workers[act[a].stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
+                    });
                 }
-                if (!earlyChains) {
-                    // ONE fork for all of it: the leftovers of level 0 and the entries of level 1 depend on round 0 only -- dealt together,
-                    // dearest first, each to the least loaded stream; an entry of level 2 or 3 is queued on the stream of the entry that
-                    // shadows most of its candidates, behind that entry's chain and a finish step for it (stream order instead of a
-                    // barrier per level)
-                    for (size_t a = 0; a < nAct; ++a)
-                        busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
-                    const std::vector<size_t> order1 = deal(true);
-                    for (uint32_t level = 0; level <= maxLevel && rc2c == LC_OK; ++level)
-                        for (size_t i = 0; i < nAct && rc2c == LC_OK; ++i) {
+            }
+            std::vector<Step>& out = chains[owner];
+            busy2c[a] = (level || ov || un) ? 1 : 0;
+            if (trace) {
+                if (level) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u stream %d%s\n", e0.p, e0.level, e0.cand, e0.stream, early ? " + rounds" : "");
+                else fprintf(stderr, "grok plan 2c: entry %u overflowed %u unanchored %u%s\n", e0.p, ov, un, early ? " + rounds" : "");
+            }
+            auto post = [&, a](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
+                PlanEntry& e = act[a];
+                hipLaunchKernelGGL(grok_post_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0, T.workers[e.stream],
+                                   T.dEntries, uint32_t(a), in, inCount, flags, xtmp, xcap, xstride, xcount);
+            };
+            auto tick = [&, a](int which, int& rc) {
+                if (!calibrate || !busy2c[a]) return;
+                if (hipEventRecord(T.tick[2 * nAct + 2 * a + size_t(which)], T.workers[act[a].stream]) != hipSuccess && rc == LC_OK && which == 0)
+                    rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
+            };
+            // the search proper over the slots in `list`, minus the values an earlier entry has won: two steps
+            auto searchProperSteps = [&, a, post](const uint32_t* list, const uint32_t* count) {
+                out.push_back([&, a, list, count](int& rc) {
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    hipStream_t ws = T.workers[e.stream];
+                    lcSetDecideSlot(1 + e.stream);
+                    hipLaunchKernelGGL(grok_filter_won_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, ws, e.dev,
+                                       static_cast<const uint32_t*>(winner), list, count, e.listB, e.dev.cnt + GC_FILTERED);
+                    rc = runFirst(e, gp.re, false, e.dev.cnt + GC_FILTERED, e.listB, true, &e.seqS, ws);
+                });
+                out.push_back([&, a, post](int& rc) {
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    lcSetDecideSlot(1 + e.stream);
+                    rc = runSecond(e, gp.re, false, e.dev.cnt + GC_FILTERED, e.listB, true, e.seqS, nullptr, T.workers[e.stream]);
+                    if (rc == LC_OK) post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
+                });
+            };
+            if (level == 0) {
+                if (ov) {  // the second chance of round 0's engine over the overflow list (the longest kernel of the phase: first), then the post step
+                    out.push_back([&, a, tick](int& rc) {
+                        tick(0, rc);
+                        if (rc != LC_OK) return;
+                        PlanEntry& e = act[a];
+                        const GrokDevicePattern& gp = patterns[e.p];
+                        lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                        lcSetDecideSlot(1 + e.stream);
+                        rc = runSecond(e, first, e.wideFirst, e.dev.cnt + GC_OVERFLOW, e.dev.ovList, !gp.anchored, e.seq0, e.dev.cnt + GC_WIDE,
+                                       T.workers[e.stream]);
+                    });
+                    out.push_back([&, a, post](int& rc) {
+                        if (rc != LC_OK) return;
+                        PlanEntry& e = act[a];
+                        post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                    });
+                } else if (un) {
+                    out.push_back([tick](int& rc) { tick(0, rc); });
+                }
+                // (only when the anchored search left any value unmatched -- the host knows the count)
+                if (patterns[e0.p].anchored && un) searchProperSteps(e0.dev.unanchored, e0.dev.cnt + GC_UNANCHORED);
+            } else {
+                // every slot whose value nobody before has won: the anchored search (or the search) in full, then the rest
+                out.push_back([&, a, tick](int& rc) {
+                    tick(0, rc);
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    hipStream_t ws = T.workers[e.stream];
+                    lcSetDecideSlot(1 + e.stream);
+                    uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
+                    hipLaunchKernelGGL(grok_filter_won_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, ws, e.dev,
+                                       static_cast<const uint32_t*>(winner), static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
+                                       mine, e.dev.cnt + GC_OVERFLOW);
+                    lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                    e.wideFirst = wantsWideFirst(first);
+                    rc = runFirst(e, first, e.wideFirst, e.dev.cnt + GC_OVERFLOW, mine, !gp.anchored, &e.seq0, ws);
+                });
+                out.push_back([&, a, post](int& rc) {
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    const GrokDevicePattern& gp = patterns[e.p];
+                    lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                    lcSetDecideSlot(1 + e.stream);
+                    rc = runSecond(e, first, e.wideFirst, e.dev.cnt + GC_OVERFLOW, e.dev.ovList, !gp.anchored, e.seq0, e.dev.cnt + GC_WIDE,
+                                   T.workers[e.stream]);
+                    if (rc == LC_OK) post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
+                });
+                if (patterns[e0.p].anchored) searchProperSteps(e0.dev.unanchored, e0.dev.cnt + GC_UNANCHORED);
+            }
+            if (busy2c[a]) out.push_back([tick](int& rc) { int ignored = LC_OK; tick(1, ignored); (void)rc; });  // (whichever way the chain ended)
+            if (early) {
+                earlyMask |= 1ull << a;
+                roundSteps(a, false, out);
+            }
+        };
+        bool forked = false;
+        int rc2c = LC_OK;
+        {
+            for (size_t a = 0; a < nAct; ++a)
+                busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
+            const std::vector<size_t> order1 = deal(true);
+            for (uint32_t level = 0; level <= maxLevel; ++level)
+                for (size_t i = 0; i < nAct; ++i)
+                    if (act[order1[i]].level == level) buildChain(order1[i]);
+            size_t longest = 0;
+            for (size_t a = 0; a < nAct; ++a) longest = std::max(longest, chains[a].size());
+            if (longest) {
+                hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                                   static_cast<const uint32_t*>(nullptr), 0u);  // the values won so far (atomicMin per value: idempotent, finishAll runs it again)
+                rc2c = fork();
+                if (rc2c != LC_OK) return rc2c;
+                forked = true;
+                if (breadthFirst) {
+                    for (size_t k = 0; k < longest; ++k)
+                        for (size_t i = 0; i < nAct; ++i) {
                             const size_t a = order1[i];
-                            if (act[a].level == level && busy2c[a]) queueChain(a, rc2c, false);
+                            if (k < chains[a].size()) chains[a][k](rc2c);
                         }
                 } else {
-                    // (what did not go early) the leftovers of level 0 on the streams round 0 put their entries on; then levels 2 and 3
-                    for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
-                        if (act[a].level || !((cnt(a, GC_OVERFLOW) && !act[a].earlyOv) || (cnt(a, GC_UNANCHORED) && !act[a].earlyUn))) continue;
-                        busy2c[a] = 1;
-                        queueChain(a, rc2c, false);
-                    }
-                    for (uint32_t level = 2; level <= maxLevel && rc2c == LC_OK; ++level)
-                        for (size_t a = 0; a < nAct && rc2c == LC_OK; ++a) {
-                            if (act[a].level != level) continue;
-                            busy2c[a] = 1;
-                            queueChain(a, rc2c, false);
-                        }
+                    for (size_t i = 0; i < nAct; ++i)
+                        for (Step& s : chains[order1[i]]) s(rc2c);
                 }
             }
             if (forked) {
@@ -1052,9 +1141,43 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             }
         }
         // 2d
+        if (remainderLiteral) {
+            lcNoteKernel("grok_remainder_literal_kernel");
+            hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((maxCand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct), dim3(kGrokPlanBlock),
+                               0, st, d_data, T.dEntries, literalIndex, earlyMask);
+        }
         lcNoteKernel("grok_remainder_all_kernel");
-        hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
-                           static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u);
+        {
+            // (the entries whose screens are BIG -- phase 1 -- in a launch of their own beside the others', table in a CU's whole LDS)
+            unsigned long long bigMask = 0;
+            uint32_t bigLds = 0;
+            static const bool bigOff = [] {
+                const char* v = getenv("LC_GROK_BIG_SCREENS");
+                return v && v[0] == '0';
+            }();
+            if (small && !bigOff)
+                for (size_t a = 0; a < nAct; ++a)
+                    if (act[a].remainderScreen && act[a].remainderScreen->bigBytes && !((earlyMask >> a) & 1ull)) {
+                        bigMask |= 1ull << a;
+                        bigLds = std::max(bigLds, act[a].remainderScreen->bigBytes);
+                    }
+            if (bigMask) {
+                static thread_local size_t attrSet[kLcMaxDevices] = {};
+                if (bigLds > 48 * 1024 && dev < kLcMaxDevices && bigLds > attrSet[dev]) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grok_remainder_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(bigLds)));
+                    attrSet[dev] = bigLds;
+                }
+                HIP_TRY(hipEventRecord(T.fork, st));
+                HIP_TRY(hipStreamWaitEvent(T.workers[0], T.fork, 0));
+                hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, T.dEntries,
+                                   static_cast<const GrokScreenDev*>(T.dRemScreens), 2u, ~bigMask);
+                HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
+            }
+            hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
+                               static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u, earlyMask | bigMask);
+            if (bigMask) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
+        }
         HIP_TRY(hipGetLastError());
         {
             int rc = readCounts();  // sync 3
@@ -1063,35 +1186,28 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
                 if (busy2c[a]) learn(patterns[act[a].p].re->grokCost1Ns, T.tick[2 * nAct + 2 * a], T.tick[2 * nAct + 2 * a + 1], act[a].cand);
+        // (the entries' histories: do most of the slots in play pass the remainder screen?  Judged on the batches that ran the screen
+        // for the entry -- every calibration batch does)
+        for (size_t a = 0; a < nAct; ++a) {
+            if ((earlyMask >> a) & 1ull) continue;
+            const uint32_t inPlay = cnt(a, GC_ROUND0), survivors = cnt(a, GC_REMAINDER);
+            if (inPlay) patterns[act[a].p].re->grokRemainderSeen.store(survivors * 4 >= inPlay * 3 ? 1u : 0u, std::memory_order_relaxed);
+        }
         // 2e
         {
             bool any = false;
-            for (size_t a = 0; a < nAct; ++a) any = any || cnt(a, GC_REMAINDER);
+            for (size_t a = 0; a < nAct; ++a) any = any || (cnt(a, GC_REMAINDER) && !act[a].queued);
             if (any) {
                 int rc = fork();
                 if (rc != LC_OK) return rc;
                 for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
                     const size_t a = byCost[i];
                     PlanEntry& e = act[a];
-                    if (!cnt(a, GC_REMAINDER)) continue;
+                    if (!cnt(a, GC_REMAINDER) || e.queued) continue;
                     if (trace) fprintf(stderr, "grok plan 2e: entry %u in play %u survivors %u\n", e.p, cnt(a, GC_ROUND0), cnt(a, GC_REMAINDER));
-                    const GrokDevicePattern& gp = patterns[e.p];
-                    hipStream_t ws = T.workers[e.stream];
-                    lcSetDecideSlot(1 + e.stream);
-                    const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-                    e.queued = true;
-                    // rounds 1 .. : FindNextMatch from the end of the previous match; the list lengths stay on the device
-                    for (uint32_t r = 1; r < e.rounds && rc == LC_OK; ++r) {
-                        const uint32_t* list = r == 1 ? e.unanchored : (r & 1) ? e.listA : e.listB;
-                        uint32_t* out = (r & 1) ? e.listB : e.listA;
-                        const uint32_t* countPtr = r == 1 ? e.dev.cnt + GC_REMAINDER : e.dev.cnt + GC_ROUND0 + r - 1;
-                        rc = lcMatchOnStream(gp.re, gp.re->engine, dev, d_data, e.dev.off, e.dev.len, 0, e.cand, countPtr, list, e.dev.from,
-                                             e.capsRow / 2, e.caps, e.status, ws);
-                        if (rc != LC_OK) break;
-                        hipLaunchKernelGGL(grok_advance2_kernel, dim3(grid), dim3(kGrokPlanBlock), 0, ws, list, e.cand, countPtr, e.status, e.caps,
-                                           e.capsRow, e.columns, e.dev, xtmp, xcap, xstride, xcount, out, e.dev.cnt + GC_ROUND0 + r,
-                                           r + 1 == e.rounds ? gate : static_cast<uint32_t*>(nullptr));
-                    }
+                    std::vector<Step> steps;
+                    roundSteps(a, true, steps);
+                    for (Step& s : steps) s(rc);
                 }
                 rc = join(rc);
                 if (rc != LC_OK) return rc;
@@ -1176,6 +1292,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     // ---- how many rounds each entry should queue ahead next time: what this batch needed, forgotten slowly
     for (size_t a = 0; a < nAct; ++a) {
         PlanEntry& e = act[a];
+        {  // did any of its values need more than 64 threads (GC_WIDE: set by the wide kernel)?  seen now = 8, else forgotten a batch at a time
+            lc_regex* first = patterns[e.p].anchored ? patterns[e.p].anchored : patterns[e.p].re;
+            const uint32_t v = first->grokOverflowSeen.load(std::memory_order_relaxed);
+            if (T.hostWords[HW_CNT + a * GC_WORDS + GC_WIDE]) first->grokOverflowSeen.store(8, std::memory_order_relaxed);
+            else if (v) first->grokOverflowSeen.store(v - 1, std::memory_order_relaxed);
+        }
         uint32_t needed = 1;  // rounds that had any value to search
         for (uint32_t r = 0; r + 1 < e.rounds && e.ran == 0; ++r)
             if (T.hostWords[HW_CNT + a * GC_WORDS + GC_ROUND0 + r]) needed = r + 2;

@@ -39,6 +39,7 @@ enum {
     GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
     GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
     GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
+    GC_WIDE = 60,       // set by a wide-first launch of round 0 when some value did need more than 64 threads (nfa_wide_kernel.hpp)
     GC_OVERFLOW = 61,   // slots whose thread lists overflowed in the first-chance kernel of round 0 (they get the second chance)
     GC_REMAINDER = 62,  // slots still in play after round 0 whose REMAINDER passes the entry's screen (grok_remainder_all_kernel)
     GC_FILTERED = 63,   // second-pass entries: slots left after grok_filter_won_kernel
@@ -50,6 +51,9 @@ struct GrokScreenDev {
     const uint32_t* blob;  // screen_kernel_layout.h
     uint32_t bit;          // Match index
     uint32_t ldsBytes;     // bytes of (accept flags + table) staged into LDS; 0 = walk the table in global memory
+    uint32_t bigBytes;     // != 0: too large to be staged beside other workgroups, small enough for a workgroup that has a CU's LDS to
+                           // itself -- small batches walk these screens in a launch of their own (grok_device.hip phase 1)
+    uint32_t pad;
 };
 
 // One ACTIVE entry (device table): the entry's private batch.
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
                                                                         const GrokScreenDev* __restrict__ screens,
                                                                         unsigned long long* __restrict__ masks,
                                                                         const uint32_t* __restrict__ order, uint32_t stage) {
+    // stage: 0 = tables through L2, 1 = the screens' ldsBytes staged, 2 = the launch of the BIG screens: bigBytes staged
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     __shared__ uint32_t sCount;
@@ -170,11 +175,20 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
     const uint8_t* accept = reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_ACCEPT];
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
-    const bool staged = stage && sc.ldsBytes != 0;
+    const uint32_t stageBytes = stage == 2 ? sc.bigBytes : stage ? sc.ldsBytes : 0u;
+    const bool staged = stageBytes != 0;
     if (staged) {  // accept flags .. end of table are contiguous in the blob (4-byte aligned start)
         uint32_t* dst = ldsWords + sliceLen;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
-        for (uint32_t i = tid; i < sc.ldsBytes / 4; i += kGrokPlanBlock) dst[i] = src[i];
+        uint32_t i = tid;
+        for (; i + 3 * kGrokPlanBlock < stageBytes / 4; i += 4 * kGrokPlanBlock) {  // (four loads in flight: a big table is 100+ KB)
+            const uint32_t a = src[i], b = src[i + kGrokPlanBlock], c = src[i + 2 * kGrokPlanBlock], d = src[i + 3 * kGrokPlanBlock];
+            dst[i] = a;
+            dst[i + kGrokPlanBlock] = b;
+            dst[i + 2 * kGrokPlanBlock] = c;
+            dst[i + 3 * kGrokPlanBlock] = d;
+        }
+        for (; i < stageBytes / 4; i += kGrokPlanBlock) dst[i] = src[i];
     }
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) : accept;
@@ -371,13 +385,60 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEnt
     }
 }
 
+// ---- round 5: in front of the remainder screens, the LITERAL index over the remainders (grid.y = entries, one slot in play per
+// wavefront, chunk-parallel like grok_literal_chunk_kernel).  A value is a candidate of an entry only if it contains the entry's
+// required literal, and every match of the entry contains it: a further match needs an occurrence INSIDE the remainder.  The typical
+// slot in play -- a format matched at the head of a 4 KiB value, free text behind -- has none, and is settled by 95 dependent steps
+// of the literal automaton instead of 4 000 of the screen's.  Such a slot gets from = len (nothing left to search: the screen kernel
+// below rejects it without a walk).  Entries without a literal (the index's ALWAYS bits) are left to the screen.  skip: bit a = the
+// entry's rounds were queued ahead by its history (grok_device.hip) -- nothing to do here.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(const uint8_t* __restrict__ data,
+                                                                               const GrokEntryDev* __restrict__ entries,
+                                                                               const uint32_t* __restrict__ blob, unsigned long long skip) {
+    __shared__ uint8_t cmap[256];
+    if ((skip >> blockIdx.y) & 1ull) return;
+    const GrokEntryDev& e = entries[blockIdx.y];
+    const uint64_t always = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
+    if ((always >> e.bit) & 1ull) return;
+    uint32_t nIn = e.cnt[GC_ROUND0];
+    nIn = nIn < e.cand ? nIn : e.cand;
+    if (blockIdx.x * (kGrokPlanBlock / 64) >= nIn) return;
+    cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6);
+    if (k >= nIn) return;  // wave-uniform
+    const uint32_t slot = e.listA[k];
+    const uint32_t from = e.from[slot], len = e.len[slot];
+    if (from >= len) return;
+    const uint32_t L = len - from, ncls = blob[GL_NCLASSES];
+    const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);
+    const uint8_t* p = data + e.off[slot] + from;
+    uint32_t hit = 0;
+    for (uint32_t c0 = lane * kGrokChunk; c0 < L; c0 += 64 * kGrokChunk) {
+        const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
+        const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
+        uint32_t state = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t t = table[state * ncls + cmap[p[i]]];
+            state = t & 0x7FFFu;
+            if ((t & 0x8000u) && ((outMask[state] >> e.bit) & 1ull)) hit = 1;
+        }
+    }
+    if (!__any(hit != 0) && lane == 0) e.from[slot] = len;
+}
+
 // ---- the remainder screens of ALL entries in one launch (grid.y = entries): see above.  screens[a].blob ==
 // nullptr: the entry has no screen, every slot in play goes on.  In: e.listA / GC_ROUND0; out: e.unanchored / GC_REMAINDER.
+// skip: see grok_remainder_literal_kernel.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(const uint8_t* __restrict__ data,
                                                                            const GrokEntryDev* __restrict__ entries,
-                                                                           const GrokScreenDev* __restrict__ screens, uint32_t stage) {
+                                                                           const GrokScreenDev* __restrict__ screens, uint32_t stage,
+                                                                           unsigned long long skip) {
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
+    if ((skip >> blockIdx.y) & 1ull) return;
     const GrokEntryDev& e = entries[blockIdx.y];
     const GrokScreenDev sc = screens[blockIdx.y];
     const uint32_t tid = threadIdx.x;
@@ -386,7 +447,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     if (blockIdx.x * kGrokPlanBlock >= nIn) return;
     const uint32_t k = blockIdx.x * kGrokPlanBlock + tid;
     if (!sc.blob) {
-        if (k < nIn) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = e.listA[k];
+        if (k < nIn) {
+            const uint32_t slot = e.listA[k];
+            if (e.from[slot] < e.len[slot]) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+        }
         return;
     }
     const uint32_t* blob = sc.blob;
@@ -394,10 +458,19 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     const uint32_t ncls = blob[SC_NCLASSES], sink = blob[SC_SINK], start = blob[SC_START];
     const uint8_t* accept = reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_ACCEPT];
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
-    const bool staged = stage && sc.ldsBytes != 0;
+    const uint32_t stageBytes = stage == 2 ? sc.bigBytes : stage ? sc.ldsBytes : 0u;  // (2: the launch of the entries with BIG screens)
+    const bool staged = stageBytes != 0;
     if (staged) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
-        for (uint32_t i = tid; i < sc.ldsBytes / 4; i += kGrokPlanBlock) ldsWords[i] = src[i];
+        uint32_t i = tid;
+        for (; i + 3 * kGrokPlanBlock < stageBytes / 4; i += 4 * kGrokPlanBlock) {
+            const uint32_t a = src[i], b = src[i + kGrokPlanBlock], c = src[i + 2 * kGrokPlanBlock], d = src[i + 3 * kGrokPlanBlock];
+            ldsWords[i] = a;
+            ldsWords[i + kGrokPlanBlock] = b;
+            ldsWords[i + 2 * kGrokPlanBlock] = c;
+            ldsWords[i + 3 * kGrokPlanBlock] = d;
+        }
+        for (; i < stageBytes / 4; i += kGrokPlanBlock) ldsWords[i] = src[i];
     }
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;

@@ -40,9 +40,15 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
                                                       const uint32_t* __restrict__ resume,
                                                       const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t nGroupsOut,
                                                       int32_t* __restrict__ caps, uint8_t* __restrict__ status,
-                                                      const uint32_t* __restrict__ overflowFlag, uint32_t launchSeq) {
+                                                      uint32_t* __restrict__ overflowFlag, uint32_t launchSeq, uint32_t first,
+                                                      uint32_t* __restrict__ wideNote) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (__atomic_load_n(overflowFlag, __ATOMIC_RELAXED) < launchSeq) return;  // the NFA kernel decided every line
+    // first != 0 (round 5, "wide first"): this kernel is the FIRST chance of the launch -- every line is walked, whatever its status
+    // says, and a line that needs more than 128 threads raises the overflow flag itself (the decide kernels behind look at it).  A
+    // host that knows the pattern overflows 64 threads on its data (the Grok matcher: by the entry's history) saves the narrow kernel's
+    // walk up to the overflow and the restart from byte 0 -- on configs[2] the longest entry's 1.0 ms + 1.1 ms became 1.1 ms.
+    // wideNote (optional): set to 1 when some line of this launch did need more than 64 threads (the history stays honest).
+    if (!first && __atomic_load_n(overflowFlag, __ATOMIC_RELAXED) < launchSeq) return;  // the NFA kernel decided every line
     if (nLinesPtr) {
         const uint32_t dyn = *nLinesPtr;
         nLines = dyn < nLines ? dyn : nLines;
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     const uint32_t slot = blockIdx.x, lane = threadIdx.x;
     if (slot >= nLines) return;
     const uint32_t line = order ? order[slot] : slot;
-    if (status[line] != LC_OVERFLOW) return;
+    if (!first && status[line] != LC_OVERFLOW) return;
 
     const uint8_t* tbl = reinterpret_cast<const uint8_t*>(blob);
     uint32_t scratchBase = 0;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         }
     }
     uint32_t nThreads = 1;
-    bool overflow = false;
+    bool overflow = false, sawWide = false;
     // Round 4: a value lands here because ONE stretch of it (an IPv6 address) needs more than 64 threads; the rest of it is the same
     // walk as in nfa_match_kernel and takes the same shortcuts -- bytes come from a 256-byte chunk held one dword per lane, a thread
     // list that is the suffix thread alone ends the walk, and a steady byte (every live thread on a tag-free self loop) starts a scan
@@ -243,7 +249,9 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         waveLdsSync();
         for (uint32_t w = lane; w < totalWins; w += 64) best[newPos[w]] = 0xFFFFFFFFu;  // clear the election marks
         waveLdsSync();
+        const uint32_t prevThreads = nThreads;
         nThreads = totalWins;
+        sawWide = sawWide || totalWins > 64;
         if (hdr[NF_SUFFIX]) {  // nothing ranked below a thread on the wrapper's suffix position can win (nfa_kernel.hpp)
             const uint64_t s0 = __ballot(lane < nThreads && newPos[lane] == nPos - 1);
             const uint64_t s1 = __ballot(lane + 64 < nThreads && newPos[(lane + 64) & 127u] == nPos - 1);
@@ -268,13 +276,25 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
                 for (int j = 0; j < TW; ++j) tags[k][j] = a[j];
             }
         }
+        if (prevThreads <= 64 && nThreads <= 64) {
+            // (round 5) the list fits one slot per lane before and after the step -- what a value does on all but the few bytes that
+            // brought it here: every source is a slot-0 thread and no slot-1 thread is written; a quarter of the shuffles
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {  // slot by slot: all four reads of the old values happen before the two writes
-            if (uint32_t(s) < nSlots) {
-                const int32_t a0 = __shfl(cap[0][s], srcLane[0], 64), a1 = __shfl(cap[1][s], srcLane[0], 64);
-                const int32_t b0 = __shfl(cap[0][s], srcLane[1], 64), b1 = __shfl(cap[1][s], srcLane[1], 64);
-                cap[0][s] = ((tags[0][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[0] ? a1 : a0);
-                cap[1][s] = ((tags[1][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[1] ? b1 : b0);
+            for (int s = 0; s < NS; ++s) {
+                if (uint32_t(s) < nSlots) {
+                    const int32_t a0 = __shfl(cap[0][s], srcLane[0], 64);
+                    cap[0][s] = ((tags[0][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : a0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {  // slot by slot: all four reads of the old values happen before the two writes
+                if (uint32_t(s) < nSlots) {
+                    const int32_t a0 = __shfl(cap[0][s], srcLane[0], 64), a1 = __shfl(cap[1][s], srcLane[0], 64);
+                    const int32_t b0 = __shfl(cap[0][s], srcLane[1], 64), b1 = __shfl(cap[1][s], srcLane[1], 64);
+                    cap[0][s] = ((tags[0][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[0] ? a1 : a0);
+                    cap[1][s] = ((tags[1][s >> 5] >> (s & 31)) & 1u) ? int32_t(i) : (srcHi[1] ? b1 : b0);
+                }
             }
         }
         waveLdsSync();
@@ -319,6 +339,8 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
             }
         }
         status[line] = overflow ? LC_OVERFLOW : (matched ? LC_MATCH : LC_NOMATCH);
+        if (first && overflow) atomicMax(overflowFlag, launchSeq);
+        if (wideNote && (sawWide || overflow || !first)) __atomic_store_n(wideNote, 1u, __ATOMIC_RELAXED);  // (second chance: the narrow kernel overflowed on this line)
     }
     for (uint32_t s = NS + lane; s < 2 * nGroupsOut; s += 64) out[s] = -1;
 }

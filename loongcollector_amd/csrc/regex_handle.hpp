@@ -58,10 +58,11 @@ struct lc_regex {
     // candidate, as measured with events on calibration batches (0 = not measured yet): the matcher deals the entries to its worker
     // streams longest-first by these
     std::atomic<uint32_t> grokCost0Ns{0}, grokCost1Ns{0}, grokBatches{0};
-    // what round 0 of recent batches left behind for this entry (grok_device.hip phase 2c): values that needed the second chance,
-    // values the anchored search did not match.  An entry with such a history gets those chains queued BEFORE the host has read this
-    // batch's counts (their list lengths are on the device; an empty list costs a few empty launches).  Decays: 8 quiet batches.
-    std::atomic<uint32_t> grokOverflowSeen{0}, grokUnanchoredSeen{0};
+    // what recent batches of this entry looked like (grok_device.hip): values that needed more than 64 threads on the thread-list
+    // engine (8 = seen in the last batch, forgotten a batch at a time: such an entry's first chance is the wide kernel), and whether
+    // most of the slots in play behind a first match pass the entry's remainder screen (then its search rounds are queued ahead,
+    // unscreened)
+    std::atomic<uint32_t> grokOverflowSeen{0}, grokRemainderSeen{0};
 };
 
 // Values a consumer without a parse-failure notion of its own (filter leaves, multiline flags, the Go regex plugin) had to take as
@@ -155,3 +156,15 @@ int lcMatchFirstOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_dat
 int lcMatchSecondChanceOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
                                 uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
                                 uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, uint32_t seq, void* streamPtr);
+// Round 5, "wide first" (nfa_wide_kernel.hpp): for a caller that knows the pattern needs more than 64 threads on its data.
+//   part 0: the wide kernel over every line as the first chance (*seq as above; lines beyond 128 threads keep LC_OVERFLOW);
+//   part 1: what is left behind part 0 -- the decide kernels alone (seq: what part 0 returned);
+//   part 2: both in one call.
+// Engines and programs the wide kernel does not run (tagged DFAs, atomic groups, more than 64 capture slots) take their usual
+// kernels: part 0 = lcMatchFirstOnStream, part 2 = lcMatchOnStream.  wideNote (optional, device word): set to 1 by the launch when
+// some line did need more than 64 threads.
+int lcMatchWideFirstOnStream(int part, lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                             uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume,
+                             uint32_t ngroups, int32_t* d_caps, uint8_t* d_status, uint32_t* seq, uint32_t* wideNote, void* streamPtr);
+// does the wide kernel run this handle's thread-list program at all?
+bool lcNfaWideApplies(const lc_regex* re);

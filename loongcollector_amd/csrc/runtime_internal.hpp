@@ -30,6 +30,8 @@ int lcAwaitTripSignal(const uint32_t* hFlag, uint32_t seq, hipStream_t stream);
 void lcSetJobTableInPlace(bool on);
 // the decide pool the calling thread's next NFA launches use (0 = default; 1.. = worker streams of the Grok matcher)
 void lcSetDecideSlot(int slot);
+// where the calling thread's NEXT wide-kernel launch reports that it had work (a device word set to 1; nullptr = nowhere)
+void lcSetWideNote(uint32_t* note);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)
 int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out);
 

@@ -412,3 +412,44 @@ def test_large_batch_prefix_screen_first_branch(torch_dev, golden_dir):
     for i, p, f in zip(idx, ph, fh):
         res, want = o.process_value(values[i])
         assert (p >= 0) == (res == 0) and f == want, values[i]
+
+
+def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, monkeypatch):
+    """Round 5's plan decides by an entry's HISTORY which kernel is its first chance (nfa_wide_kernel for an entry whose values needed
+    more than 64 threads in recent batches) and whether its search rounds behind the first match are queued ahead, unscreened; it
+    queues phase 2c's launches round-robin; and it runs the literal index over the remainders in front of the remainder screens.
+    None of that may change a row: the 50-entry list of configs[2] on corpus lines -- every knob forced on, every knob off, and the
+    default three batches in a row (no history, history, history) -- gives the rows of the sequential walk, and the oracle's fields."""
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    values = grok_lines(2500) + [b"", b"x" * 4096]
+    seq = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"], Speculative=False).wait_ready()
+    want = _device_rows(torch_dev, seq, values)
+    spec = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()
+
+    def same(got, what):
+        assert np.array_equal(got[0], want[0]), what
+        assert np.array_equal(got[1], want[1]), what
+        assert np.array_equal(got[2], want[2]), what
+
+    for k in range(3):   # batch 0 has no history; 1 and 2 go wide first / queue rounds ahead where batch 0 saw reason to
+        B.launched_kernels()
+        same(_device_rows(torch_dev, spec, values), "default, batch %d" % k)
+    assert "nfa_wide_kernel:first" in B.launched_kernels()          # (CISCOFW formats on IPv6 addresses overflow 64 threads)
+    forced = {"LC_GROK_WIDE_FIRST": "2", "LC_GROK_EARLY_ROUNDS": "2"}
+    off = {"LC_GROK_WIDE_FIRST": "0", "LC_GROK_EARLY_ROUNDS": "0", "LC_GROK_BREADTH": "0", "LC_GROK_REMAINDER_LITERAL": "0"}
+    for knobs in (forced, off):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        fresh = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()
+        same(_device_rows(torch_dev, fresh, values), knobs)
+        same(_device_rows(torch_dev, fresh, values), knobs)
+        for k in knobs:
+            monkeypatch.delenv(k)
+    o = GrokOracle(cfg["match"], custom_patterns=cfg["custom_patterns"])
+    pattern, fields = spec.match_host(values)
+    assert np.array_equal(np.asarray(pattern), want[0])
+    for v, p, f in zip(values[::5], pattern[::5], fields[::5]):
+        res, exp = o.process_value(v)
+        assert f == exp and (p >= 0) == (res == 0), v

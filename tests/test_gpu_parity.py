@@ -916,3 +916,61 @@ def test_doomed_spawn_skipping_on_the_device(torch_dev):
                     exp = [v for be in want for v in be]
                     assert status[i] == B.LC_MATCH and list(caps[i]) == (exp if flags else exp[2:]), (pat, flags, s[:80])
     assert checked == 2 * 300 * len(QUASI_PATTERNS)
+
+
+def test_wide_kernel_as_the_first_chance(torch_dev, golden_dir, monkeypatch):
+    """Round 5, "wide first" (nfa_wide_kernel.hpp `first`): the two-threads-per-lane kernel walks EVERY line instead of only the lines
+    the one-thread-per-lane kernel gave up on.  LC_NFA_WIDE_FIRST=1 sends every whole chain that way: the golden vectors, the bench
+    corpus with poisoned lines, lines beyond 64 and beyond 128 threads, a resumed search -- all equal to the oracle, and to what the
+    usual order of the kernels gives."""
+    monkeypatch.setenv("LC_NFA_WIDE_FIRST", "1")
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for c in golden["cases"][::3]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"))
+        if not rx.has_nfa_program():
+            continue
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            if flat is None:
+                ok = status[i] == B.LC_NOMATCH and (caps[i] == -1).all()
+            else:
+                ok = status[i] == B.LC_MATCH and list(caps[i]) == flat[2:]
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 1300 and not bad, bad[:5]
+    B.launched_kernels()
+    for kind in ("A", "B"):
+        pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+        data, off, length = corpus.apache_batch(3000, kind, poison_every=11)
+        exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+        rx = B.GpuRegex(pattern)
+        caps_n, status_n = run_device(torch_dev, rx, data, off, None, sep=1, engine=B.LC_ENGINE_NFA)
+        assert np.array_equal(status_n, exp_status) and np.array_equal(caps_n, exp_caps)
+    launched = B.launched_kernels()
+    assert "nfa_wide_kernel" in launched and "nfa_match_kernel" not in launched, launched
+    # more than 64 threads (decided here), more than 128 (goes on to the decide kernels: this kernel raises the flag itself)
+    for pattern, subs in ((r"(.*)a(.{70})", [b"a" * 100, b"b" * 10, b"a" + b"b" * 70, b"xa" * 80, b"a" * 71, b""]),
+                          (r"(.*)a.{140}", [b"a" * 200, b"a" + b"b" * 140, b"a" * 140, b"b"])):
+        data, off, length = pack(subs)
+        exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+        rx = B.GpuRegex(pattern, engine=B.LC_ENGINE_NFA)
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+        assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps), pattern
+    srx = B.GpuRegex(r"a(.{70})b", syntax_flags=B.LC_SYNTAX_SEARCH, engine=B.LC_ENGINE_NFA)
+    line = b"b" + b"a" * 90 + b"b" + b"a" * 80 + b"b"
+    d_data = torch_dev.from_numpy(np.frombuffer(line + b"\0" * 16, np.uint8).copy()).cuda()
+    d_off = torch_dev.zeros(1, dtype=torch_dev.int32, device="cuda")
+    d_len = torch_dev.tensor([len(line)], dtype=torch_dev.int32, device="cuda")
+    for frm in (0, 21):
+        d_from = torch_dev.tensor([frm], dtype=torch_dev.int32, device="cuda")
+        d_caps = torch_dev.full((1, 2 * srx.groups), -7, dtype=torch_dev.int32, device="cuda")
+        d_status = torch_dev.full((1,), 9, dtype=torch_dev.uint8, device="cuda")
+        srx.match_device_from(d_data, d_off, d_len, 1, d_caps, d_status, d_from=d_from, engine=B.LC_ENGINE_NFA)
+        torch_dev.cuda.synchronize()
+        o = OracleRegex(r"a(.{70})b").search(line, frm)
+        assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)

@@ -26,5 +26,30 @@ second)
 grok)
   timeout 120 python -m pytest tests/test_gpu_grok.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-200 | tee $O/pytest_grok.txt
   GPU_MAX_HW_QUEUES=16 bash tools/gpu_grok_profile.sh r5_grok_$2 16384 2>&1 | head -14 | cut -c1-250 ;;
-*) echo "usage: $0 first|multi|grok"; exit 2 ;;
+plan)
+  # round 5's Grok plan: the knobs one by one (LC_GROK_WIDE_FIRST / BREADTH / EARLY_ROUNDS / REMAINDER_LITERAL / BIG_SCREENS), then the profile
+  export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
+  timeout 700 python -m pytest tests/test_gpu_grok.py tests/test_gpu_decide.py -m gpu -q -x 2>&1 | tail -4 | cut -c1-300 | tee $O/pytest_grok.txt
+  timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "nfa or wide or overflow or golden or search or atomic or lookaround or resumed or doomed or run_capt" 2>&1 | tail -4 | cut -c1-300 | tee $O/pytest_parity.txt
+  ab() {
+    name=$1; shift
+    env "$@" timeout 200 python tools/grok_bench.py --lines 1000,16384 --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 > $O/ab_$name.json 2> $O/ab_$name.err
+    python - <<PY
+import json
+out = []
+for l in open("$O/ab_$name.json"):
+    if l.startswith("{"):
+        d = json.loads(l); out.append("%s lines %.3f ms" % (d["config"]["workload"].split("), ")[1].split(" lines")[0], d["ms_per_step"]))
+print("%-12s" % "$name", " | ".join(out))
+PY
+  }
+  ab default
+  ab no_wide LC_GROK_WIDE_FIRST=0
+  ab no_breadth LC_GROK_BREADTH=0
+  ab no_early LC_GROK_EARLY_ROUNDS=0
+  ab no_remlit LC_GROK_REMAINDER_LITERAL=0
+  ab no_big LC_GROK_BIG_SCREENS=0
+  ab all_off LC_GROK_WIDE_FIRST=0 LC_GROK_BREADTH=0 LC_GROK_EARLY_ROUNDS=0 LC_GROK_REMAINDER_LITERAL=0 LC_GROK_BIG_SCREENS=0
+  bash tools/gpu_grok_profile.sh r5_plan 16384 2>&1 | head -14 | cut -c1-250 ;;
+*) echo "usage: $0 first|multi|grok|plan"; exit 2 ;;
 esac
