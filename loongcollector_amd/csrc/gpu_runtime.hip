@@ -1034,22 +1034,35 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
         size_t lds = perWave ? size_t(re->tdfa.nRegs) * kTdfaWaveValues * 4 : size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
         // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
         uint32_t stageBytes = 0;
+        static const bool stageOffAll = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
         {
-            static const bool stageOff = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
+            static const bool stageOff = stageOffAll;
             const uint32_t progBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_OPSSTART] + 3u) & ~3u;
             if (!stageOff && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stageBytes = progBytes;
         }
         if (perWave) {
+            // (round 5) a small automaton rides in LDS whole: transition table + register programs (tdfa_l2_kernel.hpp LT)
+            static const bool transOff = getenv("LC_TDFA_WAVE_NO_LDS_TRANS") != nullptr;
+            const uint32_t allBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_TRANS] + 3u) & ~3u;
+            const bool ldsTrans = !transOff && !stageOffAll && n <= 32768 && allBytes <= 48 * 1024 && lds + allBytes <= 60 * 1024;
+            if (ldsTrans) stageBytes = allBytes;
             lds += stageBytes;
-            static thread_local size_t waveLdsAttrSet[kLcMaxDevices] = {};
-            if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > waveLdsAttrSet[dev]) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-                waveLdsAttrSet[dev] = lds;
+            static thread_local size_t waveLdsAttrSet[2][kLcMaxDevices] = {};
+            if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > waveLdsAttrSet[ldsTrans][dev]) {
+                HIP_TRY(hipFuncSetAttribute(ldsTrans ? reinterpret_cast<const void*>(tdfa_wave_kernel<true>)
+                                                     : reinterpret_cast<const void*>(tdfa_wave_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                waveLdsAttrSet[ldsTrans][dev] = lds;
             }
-            noteKernel("tdfa_l2_kernel:wave");
-            hipLaunchKernelGGL(tdfa_wave_kernel, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream, d_data,
-                               d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status,
-                               stageBytes);
+            noteKernel(ldsTrans ? "tdfa_l2_kernel:wave:lds" : "tdfa_l2_kernel:wave");
+            if (ldsTrans)
+                hipLaunchKernelGGL(tdfa_wave_kernel<true>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
+                                   d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
+                                   d_status, stageBytes);
+            else
+                hipLaunchKernelGGL(tdfa_wave_kernel<false>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
+                                   d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
+                                   d_status, stageBytes);
             HIP_TRY(hipGetLastError());
         } else {
         lds += stageBytes;

@@ -132,6 +132,41 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_chunk_kernel(cons
     if (lane == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
 }
 
+// The walk of a yes/no screen DFA over [p, p + L): one value per lane, 16 bytes per global load.  Round 5: the NEXT 16 bytes are
+// loaded while these are walked, their 16 classes are looked up before the chain starts (independent LDS reads), and a chunk that
+// lies wholly inside the value takes a copy of the chain without per-byte bounds tests -- what remains per byte is the one dependent
+// table read.  (Before: load, wait, then per byte a class lookup, two compares and the table read -- 117 ns a byte with the table in
+// LDS, 0.48 ms for a 4 KiB value: the whole screen phase of a small batch; profiles/round5_grok_timeline.txt.)
+__device__ __forceinline__ uint32_t grokScreenWalk(const uint8_t* p, uint32_t L, uint32_t start, uint32_t sink, uint32_t ncls,
+                                                   const uint8_t* cmap, const uint16_t* table) {
+    uint32_t state = start;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+    const uint32_t total = L ? head + L : 0;
+    uint4 cur = total ? q[0] : uint4{0, 0, 0, 0};
+    for (uint32_t pos = 0; pos < total && state != sink && state != 0; pos += 16) {
+        ++q;
+        const uint4 nxt = pos + 16 < total ? *q : uint4{0, 0, 0, 0};
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t cls[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) cls[j] = cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+        if (pos >= head && pos + 16 <= total) {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) state = table[state * ncls + cls[j]];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t bi = pos + j;
+                if (bi >= head && bi < total) state = table[state * ncls + cls[j]];
+            }
+        }
+        cur = nxt;
+    }
+    return state;
+}
+
 // ---- all screens in one launch.  grid = (slices, screens); dynamic LDS = candidate list [sliceLen] u32 + staged table.
 // A slice is a run of values in LENGTH order (order[]: the lanes of a wavefront then walk values of about the same length); the
 // workgroup compacts the slice's carriers of the entry's bit into LDS (ballot), then walks them one value per lane.  Table entries
@@ -192,27 +227,14 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     }
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) : accept;
-    const uint16_t* lTable = staged ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) +
-                                                                         (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]))
-                                    : table;
+    // (an LDS pointer the compiler can see is one: ds_read instead of flat loads in the walk)
+    const uint16_t* ldsTable = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) +
+                                                                 (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]));
     // 3. walk
     for (uint32_t k = tid; k < count; k += kGrokPlanBlock) {
         const uint32_t v = cand[k];
-        const uint32_t L = len[v];
-        uint32_t state = start;
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + off[v];
-        const uint32_t head = uint32_t(addr & 15);
-        const uint4* q = reinterpret_cast<const uint4*>(addr - head);
-        const uint32_t total = L ? head + L : 0;
-        for (uint32_t pos = 0; pos < total && state != sink && state != 0; pos += 16) {
-            const uint4 w4 = *q++;
-            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) {
-                const uint32_t bi = pos + j;
-                if (bi >= head && bi < total) state = lTable[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
-            }
-        }
+        const uint32_t state = staged ? grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, ldsTable)
+                                      : grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, table);
         const bool pass = state == sink || (state != 0 && lAccept[state]);
         if (!pass) atomicAnd(&masks[v], ~(1ull << sc.bit));
     }
@@ -474,25 +496,13 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     }
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;
-    const uint16_t* lTable = staged ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]))
-                                    : table;
+    const uint16_t* ldsTable = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]));
     if (k >= nIn) return;
     const uint32_t slot = e.listA[k];
     const uint32_t L = e.len[slot], from = e.from[slot];
-    uint32_t state = start;
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + e.off[slot] + from;
-    const uint32_t head = uint32_t(addr & 15);
-    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
-    const uint32_t total = L > from ? head + (L - from) : 0;
-    for (uint32_t pos = 0; pos < total && state != sink && state != 0; pos += 16) {
-        const uint4 w4 = *q++;
-        const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t bi = pos + j;
-            if (bi >= head && bi < total) state = lTable[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
-        }
-    }
+    const uint32_t rem = L > from ? L - from : 0;
+    const uint32_t state = staged ? grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, ldsTable)
+                                  : grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, table);
     if (state == sink || (state != 0 && lAccept[state])) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
 }
 

@@ -124,6 +124,11 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
 constexpr int kTdfaWaveBlock = 256;
 constexpr int kTdfaWaveValues = kTdfaWaveBlock / 64;
 
+// LT (round 5): the automaton is small (transition table + register programs <= 48 KB: the LDS-size automata of handles that ASK for
+// this kernel -- lcPreferWaveTdfa, the Grok matcher's entries): the transition table is staged too, and a byte that is not part of a
+// quiet run costs an LDS read instead of a read through L2 (a search wrapper's lazy prefix makes EVERY byte such a byte: 146 -> ~40 ns).
+// stageBytes then counts from TL_OFF_TRANS (trans, opsStart, ops are contiguous in the blob).
+template <bool LT>
 __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                   const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
                                                                   const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     for (uint32_t r = lane; r < nRegs; r += 64) regs[r] = 0xFFFFFFFFu;  // unset = -1
     if (stageBytes) {
         uint32_t* dst = wregs + kTdfaWaveValues * nRegs;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[TL_OFF_OPSSTART]);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[LT ? TL_OFF_TRANS : TL_OFF_OPSSTART]);
         for (uint32_t i = tid; i < stageBytes / 4; i += kTdfaWaveBlock) dst[i] = src[i];
     }
     __syncthreads();
@@ -148,13 +153,21 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     if (slot >= nLines) return;  // wave-uniform; the workgroup does not synchronise again
     const uint32_t line = order ? order[slot] : slot;
     const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
-    const uint32_t* trans = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_TRANS]);
     const uint2* quietTab = reinterpret_cast<const uint2*>(base + blob[TL_OFF_QUIET]);
     const uint8_t* staged = reinterpret_cast<const uint8_t*>(wregs + kTdfaWaveValues * nRegs);
-    const uint32_t* opsStart = stageBytes ? reinterpret_cast<const uint32_t*>(staged)
-                                          : reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
-    const uint16_t* ops = stageBytes ? reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]))
-                                     : reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
+    const uint32_t* trans;
+    const uint32_t* opsStart;
+    const uint16_t* ops;
+    if constexpr (LT) {
+        trans = reinterpret_cast<const uint32_t*>(staged);
+        opsStart = reinterpret_cast<const uint32_t*>(staged + (blob[TL_OFF_OPSSTART] - blob[TL_OFF_TRANS]));
+        ops = reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_TRANS]));
+    } else {
+        trans = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_TRANS]);
+        opsStart = stageBytes ? reinterpret_cast<const uint32_t*>(staged) : reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]);
+        ops = stageBytes ? reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]))
+                         : reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
+    }
     const uint32_t o = off[line];
     const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
     uint32_t state = blob[TL_START], from = 0;

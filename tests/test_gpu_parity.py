@@ -974,3 +974,53 @@ def test_wide_kernel_as_the_first_chance(torch_dev, golden_dir, monkeypatch):
         torch_dev.cuda.synchronize()
         o = OracleRegex(r"a(.{70})b").search(line, frm)
         assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)
+
+
+def test_small_automata_on_the_wave_kernel_with_their_tables_in_lds(torch_dev, golden_dir):
+    """Round 5: a handle that asks for the wave-per-value kernel (lc_regex_prefer_wave_tdfa: the Grok matcher's entries) and whose
+    transition table + register programs fit 48 KB gets them staged into LDS (tdfa_wave_kernel<LT>).  Same results as the oracle on
+    the bench corpora (poisoned lines included), on the golden full-match vectors, and on resumed searches."""
+    for kind in ("A", "B"):
+        pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
+        rx = B.GpuRegex(pattern)
+        assert rx.prefer_wave_tdfa()
+        data, off, length = corpus.apache_batch(3000, kind, poison_every=11)
+        exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+        B.launched_kernels()
+        caps, status = run_device(torch_dev, rx, data, off, None, sep=1, engine=B.LC_ENGINE_TDFA)
+        assert "tdfa_l2_kernel:wave:lds" in B.launched_kernels()
+        assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for c in golden["cases"][::4]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"))
+        if rx.info()["engine"] != B.LC_ENGINE_TDFA or not rx.prefer_wave_tdfa():
+            continue
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if flat is None else \
+                 (status[i] == B.LC_MATCH and list(caps[i]) == flat[2:])
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 800 and not bad, bad[:5]
+    srx = B.GpuRegex(r"(\d+)-([a-z]+)", syntax_flags=B.LC_SYNTAX_SEARCH)
+    assert srx.prefer_wave_tdfa()
+    line = b"xx 12-ab 345-cde " + b"y" * 600 + b" 6-f"
+    d_data = torch_dev.from_numpy(np.frombuffer(line + b"\0" * 16, np.uint8).copy()).cuda()
+    d_off = torch_dev.zeros(1, dtype=torch_dev.int32, device="cuda")
+    d_len = torch_dev.tensor([len(line)], dtype=torch_dev.int32, device="cuda")
+    for frm in (0, 4, 9, 20, len(line) - 3):
+        d_from = torch_dev.tensor([frm], dtype=torch_dev.int32, device="cuda")
+        d_caps = torch_dev.full((1, 2 * srx.groups), -7, dtype=torch_dev.int32, device="cuda")
+        d_status = torch_dev.full((1,), 9, dtype=torch_dev.uint8, device="cuda")
+        srx.match_device_from(d_data, d_off, d_len, 1, d_caps, d_status, d_from=d_from, engine=B.LC_ENGINE_TDFA)
+        torch_dev.cuda.synchronize()
+        o = OracleRegex(r"(\d+)-([a-z]+)").search(line, frm)
+        if o is None:
+            assert int(d_status[0]) == B.LC_NOMATCH, frm
+        else:
+            assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)

@@ -30,7 +30,7 @@ plan)
   # round 5's Grok plan: the knobs one by one (LC_GROK_WIDE_FIRST / BREADTH / EARLY_ROUNDS / REMAINDER_LITERAL / BIG_SCREENS), then the profile
   export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
   timeout 700 python -m pytest tests/test_gpu_grok.py tests/test_gpu_decide.py -m gpu -q -x 2>&1 | tail -4 | cut -c1-300 | tee $O/pytest_grok.txt
-  timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "nfa or wide or overflow or golden or search or atomic or lookaround or resumed or doomed or run_capt" 2>&1 | tail -4 | cut -c1-300 | tee $O/pytest_parity.txt
+  timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "nfa or wide or overflow or golden or search or atomic or lookaround or resumed or doomed or run_capt or wave or small_automata or global_memory" 2>&1 | tail -4 | cut -c1-300 | tee $O/pytest_parity.txt
   ab() {
     name=$1; shift
     env "$@" timeout 200 python tools/grok_bench.py --lines 1000,16384 --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 > $O/ab_$name.json 2> $O/ab_$name.err
@@ -49,6 +49,7 @@ PY
   ab no_early LC_GROK_EARLY_ROUNDS=0
   ab no_remlit LC_GROK_REMAINDER_LITERAL=0
   ab no_big LC_GROK_BIG_SCREENS=0
+  ab no_wavelds LC_TDFA_WAVE_NO_LDS_TRANS=1
   ab all_off LC_GROK_WIDE_FIRST=0 LC_GROK_BREADTH=0 LC_GROK_EARLY_ROUNDS=0 LC_GROK_REMAINDER_LITERAL=0 LC_GROK_BIG_SCREENS=0
   bash tools/gpu_grok_profile.sh r5_plan 16384 2>&1 | head -14 | cut -c1-250 ;;
 *) echo "usage: $0 first|multi|grok|plan"; exit 2 ;;
