@@ -440,7 +440,9 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
     const uint32_t maskShift = tb.maskShift;
     const uint32_t* followStart = tb.followStart;
 
-    const uint32_t wave = tid >> 6, lane = tid & 63;
+    // (round 5: what is wave-uniform is SAID to be -- readfirstlane -- or the compiler, for which anything derived from threadIdx or read
+    // from LDS is divergent, keeps the line's offsets, the byte position and the loop conditions in VGPRs and steers the walk with exec masks)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // per-wave scratch: best[nPos] then 4 x 64 words (newPos, newSrc, newAux, spare)
     const uint32_t scratchWords = ((nPos + 3) & ~3u) + 256;
     uint32_t* best = reinterpret_cast<uint32_t*>(smem + scratchBase) + wave * scratchWords;
@@ -476,10 +478,10 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
 
     const uint32_t slot = blockIdx.x * kWaves + wave;
     if (slot >= nLines) return;  // wave-uniform (the block never synchronises again)
-    const uint32_t line = order ? order[slot] : slot;
+    const uint32_t line = __builtin_amdgcn_readfirstlane(order ? order[slot] : slot);
     if (pendingFlag && status[line] != 4 /* LC_PENDING */) return;  // settled by the depth-first walk
-    const uint32_t o = off[line];
-    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    const uint32_t o = __builtin_amdgcn_readfirstlane(off[line]);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(len ? len[line] : off[line + 1] - o - sepBytes);
 
     int32_t cap[NS];
 #pragma unroll
@@ -499,11 +501,11 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
     uint32_t prevCls = edgeClass;
     uint32_t from = 0;  // search patterns: resume the search here (the next match of an iterate-all-matches caller)
     if (resume) {
-        from = resume[line];
+        from = __builtin_amdgcn_readfirstlane(resume[line]);
         from = from < L ? from : L;
         if (from) {  // one thread, on the wrapper's prefix position, which has just consumed the byte before `from`
             myPos = 0;
-            prevCls = classMap[data[size_t(o) + from - 1]];
+            prevCls = __builtin_amdgcn_readfirstlane(classMap[data[size_t(o) + from - 1]]);
         }
     }
     const bool searchSkip = hdr[NF_SEARCH] != 0;
@@ -558,14 +560,14 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
             stop = __builtin_amdgcn_readfirstlane(stop);
             if (stop > idx) {  // bytes [idx, stop) only feed the prefix loop; remember the class of the last one
                 const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
-                prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                prevCls = __builtin_amdgcn_readfirstlane(classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu]);
                 i = stop - head - 1;
                 continue;
             }
         }
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
         const int b = int((wsel >> ((idx & 3u) * 8)) & 0xFFu);
-        const uint32_t cls = classMap[b];
+        const uint32_t cls = __builtin_amdgcn_readfirstlane(classMap[b]);
         const uint32_t cw = cls >> 5, cb = cls & 31u;
         const bool liveLane = lane < nThreads;
         // steady state: every live thread sits on a position whose only move on this byte class is its own
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
             uint32_t clsNext = 0xFFFFFFFFu;
             if (quasi.idx && i + 1 < L && ((idx + 1) >> 8) == (idx >> 8)) {
                 const uint32_t wn = __builtin_amdgcn_readlane(curWord, ((idx + 1) >> 2) & 63u);
-                clsNext = classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu];
+                clsNext = __builtin_amdgcn_readfirstlane(classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu]);
             }
             const bool bit = liveLane && nfaQuiet(stable, maskShift, quasi, myPos, cls, clsNext);
             if (__all(!liveLane || bit)) {
@@ -609,14 +611,14 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
                     stop = __builtin_amdgcn_readfirstlane(stop);
                     if (stop > idx + 1) {  // bytes (idx, stop) are steady too; remember the class of the last one
                         const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
-                        prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                        prevCls = __builtin_amdgcn_readfirstlane(classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu]);
                         i = stop - head - 1;
                     }
                 }
                 continue;
             }
         }
-        const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];  // look assertions that hold at this offset
+        const uint32_t ctrue = __builtin_amdgcn_readfirstlane(behindBits[prevCls] | aheadBits[cls]);  // look assertions that hold at this offset
         prevCls = cls;
 
         if constexpr (ATOMIC) {
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
                 waveLdsSync();
                 uint32_t kept = 0;
                 if (lane == 0) kept = nfaAtomicStep(actx, nThreads, cls, ctrue, i, false);
-                kept = __shfl(kept, 0, 64);
+                kept = __builtin_amdgcn_readfirstlane(kept);
                 waveLdsSync();
                 if (kept == 0xFFFFFFFFu) {
                     overflow = true;
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
         const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
         uint32_t totalCand;
         const uint32_t rankBase = waveExclusiveScan(cnt, lane, totalCand);
+        totalCand = __builtin_amdgcn_readfirstlane(totalCand);
         // One CANDIDATE (thread, path) per lane, 64 per round, in priority order (rank = lexicographic (thread, path index)
         // = the candidate's index).  A thread with a long follow list -- the search prefix of a pattern that can start in
         // dozens of ways -- no longer walks it serially in one lane while 60 lanes idle.

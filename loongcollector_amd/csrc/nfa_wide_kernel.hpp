@@ -102,8 +102,8 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     for (uint32_t i = lane; i < nPos; i += 64) best[i] = 0xFFFFFFFFu;
     waveLdsSync();
 
-    const uint32_t o = off[line];
-    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    const uint32_t o = __builtin_amdgcn_readfirstlane(off[line]);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(len ? len[line] : off[line + 1] - o - sepBytes);
     uint32_t from = 0;
     uint32_t prevCls = edgeClass;
     // thread T = lane + 64 * k: position pos[k], capture offsets cap[k][]
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
 #pragma unroll
     for (int s = 0; s < NS; ++s) cap[0][s] = cap[1][s] = -1;
     if (resume) {
-        from = resume[line];
+        from = __builtin_amdgcn_readfirstlane(resume[line]);
         from = from < L ? from : L;
         if (from) {
             pos[0] = 0;
-            prevCls = classMap[data[size_t(o) + from - 1]];
+            prevCls = __builtin_amdgcn_readfirstlane(classMap[data[size_t(o) + from - 1]]);
         }
     }
     uint32_t nThreads = 1;
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
             curWord = (w < nWords) ? words[w] : 0;
         }
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
-        const uint32_t cls = classMap[(wsel >> ((idx & 3u) * 8)) & 0xFFu];
+        const uint32_t cls = __builtin_amdgcn_readfirstlane(classMap[(wsel >> ((idx & 3u) * 8)) & 0xFFu]);
         const uint32_t cw = cls >> 5, cb = cls & 31u;
         if (nThreads <= 64) {  // steady byte: nothing moves (nfa_kernel.hpp); with few threads, look for the end of the run
             uint32_t clsNext = 0xFFFFFFFFu;
             if (quasi.idx && i + 1 < L && ((idx + 1) >> 8) == (idx >> 8)) {
                 const uint32_t wn = __builtin_amdgcn_readlane(curWord, ((idx + 1) >> 2) & 63u);
-                clsNext = classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu];
+                clsNext = __builtin_amdgcn_readfirstlane(classMap[(wn >> (((idx + 1) & 3u) * 8)) & 0xFFu]);
             }
             const bool bit = lane < nThreads && nfaQuiet(stable, maskShift, quasi, pos[0], cls, clsNext);
             if (__all(lane >= nThreads || bit)) {
@@ -183,20 +183,21 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
                     stop = __builtin_amdgcn_readfirstlane(stop);
                     if (stop > idx + 1) {
                         const uint32_t w = __builtin_amdgcn_readlane(curWord, ((stop - 1) >> 2) & 63u);
-                        prevCls = classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu];
+                        prevCls = __builtin_amdgcn_readfirstlane(classMap[(w >> (((stop - 1) & 3u) * 8)) & 0xFFu]);
                         i = stop - head - 1;
                     }
                 }
                 continue;
             }
         }
-        const uint32_t ctrue = behindBits[prevCls] | aheadBits[cls];
+        const uint32_t ctrue = __builtin_amdgcn_readfirstlane(behindBits[prevCls] | aheadBits[cls]);
         prevCls = cls;
         const bool live0 = lane < nThreads, live1 = lane + 64 < nThreads;
         const uint32_t fs0 = live0 ? tb.followStart[pos[0]] : 0, fs1 = live1 ? tb.followStart[pos[1]] : 0;
         const uint32_t cnt0 = live0 ? tb.followStart[pos[0] + 1] - fs0 : 0, cnt1 = live1 ? tb.followStart[pos[1] + 1] - fs1 : 0;
         uint32_t rank0, rank1, totalCand;
         nfaWideScan(cnt0, cnt1, lane, rank0, rank1, totalCand);
+        totalCand = __builtin_amdgcn_readfirstlane(totalCand);
         uint32_t totalWins = 0;
         for (uint32_t r0 = 0; r0 < totalCand && !overflow; r0 += 64) {
             const uint32_t cand = r0 + lane;  // one candidate (thread, path) per lane, in priority order

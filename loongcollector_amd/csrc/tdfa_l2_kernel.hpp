@@ -137,7 +137,9 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
                                                                   uint8_t* __restrict__ status, uint32_t stageBytes) {
     extern __shared__ uint32_t wregs[];  // [kTdfaWaveValues][nRegs], then (stageBytes != 0) opsStart, ops
     __shared__ uint8_t cmap[256];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (wave-uniform values are SAID to be: the compiler takes anything derived from threadIdx or from an LDS read for divergent, kept the
+    // state, the position and every loop condition of the walk in VGPRs and steered it with exec masks -- 15 VALU + 13 SALU per byte)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cmap[tid] = reinterpret_cast<const uint8_t*>(blob + TL_HEADER_WORDS)[tid];
     const uint32_t nRegs = blob[TL_NREGS], ncls = blob[TL_NCLASSES], nSlots = blob[TL_NSLOTS];
     uint32_t* regs = wregs + wave * nRegs;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     if (nLinesPtr) nLines = *nLinesPtr < nLines ? *nLinesPtr : nLines;
     const uint32_t slot = blockIdx.x * kTdfaWaveValues + wave;
     if (slot >= nLines) return;  // wave-uniform; the workgroup does not synchronise again
-    const uint32_t line = order ? order[slot] : slot;
+    const uint32_t line = __builtin_amdgcn_readfirstlane(order ? order[slot] : slot);
     const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
     const uint2* quietTab = reinterpret_cast<const uint2*>(base + blob[TL_OFF_QUIET]);
     const uint8_t* staged = reinterpret_cast<const uint8_t*>(wregs + kTdfaWaveValues * nRegs);
@@ -168,13 +170,15 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
         ops = stageBytes ? reinterpret_cast<const uint16_t*>(staged + (blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]))
                          : reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]);
     }
-    const uint32_t o = off[line];
-    const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
+    const uint32_t o = __builtin_amdgcn_readfirstlane(off[line]);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(len ? len[line] : off[line + 1] - o - sepBytes);
     uint32_t state = blob[TL_START], from = 0;
     if (resume) {
-        from = resume[line];
+        from = __builtin_amdgcn_readfirstlane(resume[line]);
         from = from < L ? from : L;
-        if (from) state = reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_STARTAFTER])[cmap[data[size_t(o) + from - 1]]];
+        if (from)
+            state = __builtin_amdgcn_readfirstlane(
+                reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_STARTAFTER])[cmap[data[size_t(o) + from - 1]]]);
     }
     const uint32_t absorb = blob[TL_ABSORB];
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
@@ -183,34 +187,42 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     const uint32_t nWords = L ? (head + L + 3) / 4 : 0;
     const uint32_t end = head + L;
     uint32_t chunk = ((head + from) >> 8);  // index of the 256-byte chunk held in curWord
+    // (round 5) ... as CLASSES: every lane maps its four bytes once per chunk (independent LDS reads); the walk's dependent chain per
+    // byte is then readlane + the table read, and the run scan tests the four classes it already holds.  The step was bound by the
+    // latency of its instructions (profiles/round5_wave_step.txt: 350 cycles a byte for 15 VALU + 13 SALU + 1.8 LDS reads, one wave
+    // per SIMD with nothing to hide behind); the class lookup was one of the two LDS reads in the chain.
+    auto classesOf = [&](uint32_t w4) {
+        return uint32_t(cmap[w4 & 0xFFu]) | (uint32_t(cmap[(w4 >> 8) & 0xFFu]) << 8) | (uint32_t(cmap[(w4 >> 16) & 0xFFu]) << 16) |
+               (uint32_t(cmap[w4 >> 24]) << 24);
+    };
     uint32_t curWord;
     {
         const uint32_t w = (chunk << 6) + lane;
-        curWord = (w < nWords) ? words[w] : 0;
+        curWord = classesOf((w < nWords) ? words[w] : 0);
     }
     uint32_t idx = head + from;  // position in the word-aligned view
     while (idx < end && state != 0 && state != absorb) {
         if ((idx >> 8) != chunk) {
             chunk = idx >> 8;
             const uint32_t w = (chunk << 6) + lane;
-            curWord = (w < nWords) ? words[w] : 0;
+            curWord = classesOf((w < nWords) ? words[w] : 0);
         }
         const uint32_t wsel = __builtin_amdgcn_readlane(curWord, (idx >> 2) & 63u);
-        const uint32_t cls = cmap[(wsel >> ((idx & 3u) * 8)) & 0xFFu];
-        const uint32_t t = trans[__builtin_amdgcn_readfirstlane(state * ncls + cls)];
+        const uint32_t cls = (wsel >> ((idx & 3u) * 8)) & 0xFFu;
+        const uint32_t t = __builtin_amdgcn_readfirstlane(trans[state * ncls + cls]);
         const uint32_t prog = t >> 16, next = t & 0xFFFFu;
         if (prog) {
             const uint32_t pos = idx - head;
-            uint32_t at = opsStart[prog];
-            const uint32_t n = ops[at];
+            uint32_t at = __builtin_amdgcn_readfirstlane(opsStart[prog]);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(ops[at]);
             for (uint32_t k = 0; k < n; ++k) {  // (every lane stores the same word: one LDS write)
-                const uint32_t op = ops[++at];
+                const uint32_t op = __builtin_amdgcn_readfirstlane(ops[++at]);
                 const uint32_t src = op >> 8;
                 regs[op & 0xFFu] = src == TD_REG_POS ? pos : regs[src];
             }
         } else if (next == state) {
             // a quiet byte: find the end of the run -- every lane tests its 4 bytes of the chunk, chunk after chunk
-            const uint2 q2 = quietTab[__builtin_amdgcn_readfirstlane(state)];
+            const uint2 q2 = quietTab[state];
             const uint64_t quiet = (uint64_t(q2.y) << 32) | q2.x;
             uint32_t stop = end;
             for (;;) {
@@ -219,20 +231,20 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
-                    const uint32_t c = cmap[(curWord >> (8 * j)) & 0xFFu];
+                    const uint32_t c = (curWord >> (8 * j)) & 0xFFu;
                     const bool isQuiet = c < 64 && ((quiet >> c) & 1ull);
                     if (bi > idx && bi < end && !isQuiet) firstHit = uint32_t(j);
                 }
                 const uint64_t hit = __ballot(firstHit < 4);
                 if (hit) {
                     const int l = __ffsll((long long)hit) - 1;
-                    stop = __builtin_amdgcn_readfirstlane(chunkBase + uint32_t(l) * 4 + uint32_t(__shfl(int(firstHit), l, 64)));
+                    stop = chunkBase + uint32_t(l) * 4 + uint32_t(__builtin_amdgcn_readlane(int(firstHit), l));
                     break;
                 }
                 if (chunkBase + 256 >= end) break;  // the run reaches the end of the value
                 ++chunk;
                 const uint32_t w = (chunk << 6) + lane;
-                curWord = (w < nWords) ? words[w] : 0;
+                curWord = classesOf((w < nWords) ? words[w] : 0);
             }
             idx = stop;
             continue;

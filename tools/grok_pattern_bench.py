@@ -58,6 +58,8 @@ def run(rx, subset, label):
 
 for name in names:
     rx = B.GpuRegex(lib.denormalize(name).encode("utf-8"), syntax_flags=F, engine=ENGINE)
+    if os.environ.get("LC_BENCH_PREFER_WAVE"):   # what the Grok matcher asks for its entries: one value per wavefront on small batches
+        rx.prefer_wave_tdfa()
     info = rx.info()
     lit = rx.required_literal()
     print(name, "engine", info["engine"], "table_bytes", info["table_bytes"], "groups", rx.groups, "literal", lit, "kernels", B.launched_kernels())
@@ -66,3 +68,4 @@ for name in names:
     run(rx, [v for v in hits if len(v) <= 256], "  of those <= 256 B")
     run(rx, [v for v in hits if len(v) >= 2048], "  of those >= 2 KiB")
     run(rx, lines, "all lines")
+    print("  kernels:", B.launched_kernels())
