@@ -1042,7 +1042,13 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
         }
         if (perWave) {
             // (round 5) a small automaton rides in LDS whole: transition table + register programs (tdfa_l2_kernel.hpp LT)
-            static const bool transOff = getenv("LC_TDFA_WAVE_NO_LDS_TRANS") != nullptr;
+            // MEASURED AND LEFT OFF (LC_TDFA_WAVE_LDS_TRANS=1 switches it on): once the walk's state lives in SGPRs the transition read is a
+            // scalar load through the scalar cache, as fast as the LDS read + readfirstlane, without staging up to 48 KB per four values
+            // (CISCOFW105003 on its 314 values: 0.389 ms from L2, 0.411 ms from LDS; profiles/round5_wave_step.txt)
+            const bool transOff = [] {  // (read per launch: the GPU tests run both forms)
+                const char* v = getenv("LC_TDFA_WAVE_LDS_TRANS");
+                return !(v && v[0] == '1');
+            }();
             const uint32_t allBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_TRANS] + 3u) & ~3u;
             const bool ldsTrans = !transOff && !stageOffAll && n <= 32768 && allBytes <= 48 * 1024 && lds + allBytes <= 60 * 1024;
             if (ldsTrans) stageBytes = allBytes;

@@ -334,7 +334,7 @@ namespace {
 constexpr int kGrokMaxStreams = 16;  // (LC_GROK_STREAMS; the default stays opts.streams = 8)
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
 constexpr uint32_t kGrokScreenBigMax = 150 * 1024;   // ... and up to this size by a workgroup that has its CU's LDS to itself (small batches)
-constexpr uint32_t kGrokMaxRounds = GC_WIDE - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
+constexpr uint32_t kGrokMaxRounds = GC_BOUND - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
 constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
@@ -578,15 +578,25 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // slices: short enough that a small batch still spreads over the chip, long enough that the table staging is amortised
         uint32_t sliceLen = ((n / 64 + 255) / 256) * 256;
         sliceLen = std::max(256u, std::min(small ? 4096u : 1024u, sliceLen));
+        // (round 5) small batches: never more than one value per lane -- the slices are in length order, the first one holds the 4 KiB
+        // values, and a screen that half of them carry walked two of them per lane, one after the other (LC_GROK_SLICE: A/B)
+        static const uint32_t sliceEnv = [] {
+            const char* v = getenv("LC_GROK_SLICE");
+            return uint32_t(v ? atoi(v) : 0);
+        }();
+        if (small) sliceLen = sliceEnv ? std::max(256u, sliceEnv / 256 * 256) : 256u;
         const uint32_t slices = (n + sliceLen - 1) / sliceLen;
         lcNoteKernel("grok_screen_all_kernel");
         // Round 5: a relaxed whole-pattern screen of 1 000-2 000 states (70-130 KB) does not fit beside other workgroups and walked its
         // table through L2 -- 120 ns a byte, 0.5 ms for a 4 KiB value: the whole screen phase of a small batch waited for three such
         // screens (profiles/round5_grok_timeline.txt).  They now run in a launch of their own, on a worker stream beside the other
-        // screens' launch, each workgroup with the table staged into a CU's whole LDS.  LC_GROK_BIG_SCREENS=0: as before.
-        static const bool bigOff = [] {
+        // screens' launch, each workgroup with the table staged into a CU's whole LDS.  MEASURED AND LEFT OFF (LC_GROK_BIG_SCREENS=1
+        // switches it on): what the phase waited for was not the table reads of those three screens but the walk itself, in every
+        // screen (two values per lane of 4 KiB each); with the walk fixed (grokScreenWalk) a 106 KB workgroup per CU costs more than
+        // its faster table reads gain: 16 Ki values 3.92 ms without, 4.13 ms with (profiles/round5_grok_steps.txt).
+        const bool bigOff = [] {  // (measured and left off: see above; read per batch -- the GPU tests switch it on)
             const char* v = getenv("LC_GROK_BIG_SCREENS");
-            return v && v[0] == '0';
+            return !(v && v[0] == '1');
         }();
         const uint32_t nBig = (small && !bigOff) ? state->nBigScreens[dev] : 0u;
         if (nBig) {
@@ -917,6 +927,16 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                xstride, xcount);
         uint32_t maxLevel = 0;
         for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
+        // the values won so far, and for the entries of level >= 1 how many of their slots are still open: an entry all of whose
+        // candidates an entry of level 0 has won (COMBINEDAPACHELOG behind COMMONAPACHELOG on a corpus without referrers) queues nothing
+        // in phase 2c -- its dozen launches over empty lists were the tail of the phase
+        const bool boundKnown = nSecond != 0 && envInt("LC_GROK_BOUND", 1) != 0;
+        if (boundKnown) {
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                               static_cast<const uint32_t*>(nullptr), 0u);
+            hipLaunchKernelGGL(grok_bound_kernel, dim3(gridCand0, nSecond), dim3(kGrokPlanBlock), 0, st, T.dEntries, nLevel0,
+                               static_cast<const uint32_t*>(winner));
+        }
         // (Tried in round 5 and dropped -- profiles/round5_grok_steps.txt: the chains of level 1, and by the entries' history the
         // leftovers of level 0, queued BEFORE the host reads round 0's counts.  The device has them earlier, but a batch is bound by
         // the rate at which the host can queue launches, and the extra, mostly empty chains cost more than the earlier start gained:
@@ -993,6 +1013,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             const uint32_t un = level ? 0u : cnt(a, GC_UNANCHORED);
             const bool early = wantsEarlyRounds(e0);
             if (!level && !ov && !un && !early) return;
+            if (level && boundKnown && cnt(a, GC_BOUND) == 0) {  // nothing left for it (values are only ever won, never lost)
+                busy2c[a] = 0;
+                if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u: every value already won\n", e0.p, e0.level, e0.cand);
+                return;
+            }
             size_t owner = a;  // whose list the steps go to
             if (level >= 2) {  // behind its main shadower
                 uint32_t best = 0, bestF = 0;
@@ -1111,7 +1136,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         int rc2c = LC_OK;
         {
             for (size_t a = 0; a < nAct; ++a)
-                busy2c[a] = act[a].level ? 1 : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
+                busy2c[a] = act[a].level ? ((boundKnown && cnt(a, GC_BOUND) == 0) ? 0 : 1) : (cnt(a, GC_OVERFLOW) || cnt(a, GC_UNANCHORED)) ? 1 : 0;
             const std::vector<size_t> order1 = deal(true);
             for (uint32_t level = 0; level <= maxLevel; ++level)
                 for (size_t i = 0; i < nAct; ++i)
@@ -1119,8 +1144,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             size_t longest = 0;
             for (size_t a = 0; a < nAct; ++a) longest = std::max(longest, chains[a].size());
             if (longest) {
-                hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
-                                   static_cast<const uint32_t*>(nullptr), 0u);  // the values won so far (atomicMin per value: idempotent, finishAll runs it again)
+                if (!boundKnown)
+                    hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                                       static_cast<const uint32_t*>(nullptr), 0u);  // the values won so far (atomicMin per value: idempotent, finishAll runs it again)
                 rc2c = fork();
                 if (rc2c != LC_OK) return rc2c;
                 forked = true;
@@ -1141,19 +1167,24 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             }
         }
         // 2d
-        if (remainderLiteral) {
+        const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;
+        if (remainderWon)  // (the values won by now, phase 2c included: a slot in play whose value an earlier entry has won is finished)
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                               static_cast<const uint32_t*>(nullptr), 0u);
+        if (remainderLiteral || remainderWon) {
             lcNoteKernel("grok_remainder_literal_kernel");
             hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((maxCand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct), dim3(kGrokPlanBlock),
-                               0, st, d_data, T.dEntries, literalIndex, earlyMask);
+                               0, st, d_data, T.dEntries, remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), earlyMask,
+                               remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
         }
         lcNoteKernel("grok_remainder_all_kernel");
         {
             // (the entries whose screens are BIG -- phase 1 -- in a launch of their own beside the others', table in a CU's whole LDS)
             unsigned long long bigMask = 0;
             uint32_t bigLds = 0;
-            static const bool bigOff = [] {
+            const bool bigOff = [] {
                 const char* v = getenv("LC_GROK_BIG_SCREENS");
-                return v && v[0] == '0';
+                return !(v && v[0] == '1');
             }();
             if (small && !bigOff)
                 for (size_t a = 0; a < nAct; ++a)
@@ -1186,6 +1217,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
                 if (busy2c[a]) learn(patterns[act[a].p].re->grokCost1Ns, T.tick[2 * nAct + 2 * a], T.tick[2 * nAct + 2 * a + 1], act[a].cand);
+        if (trace)
+            for (size_t a = 0; a < nAct; ++a)
+                if (cnt(a, GC_ROUND0))
+                    fprintf(stderr, "grok plan 2d: entry %u in play %u, remainder passes the screen %u%s\n", act[a].p, cnt(a, GC_ROUND0),
+                            cnt(a, GC_REMAINDER), ((earlyMask >> a) & 1ull) ? " (rounds queued ahead)" : "");
         // (the entries' histories: do most of the slots in play pass the remainder screen?  Judged on the batches that ran the screen
         // for the entry -- every calibration batch does)
         for (size_t a = 0; a < nAct; ++a) {

@@ -39,6 +39,8 @@ enum {
     GC_FILL = 0,        // slots filled by the scatter kernel (== candidates)
     GC_UNANCHORED = 1,  // slots the anchored search of round 0 did not match
     GC_ROUND0 = 2,      // GC_ROUND0 + r: slots still in play after round r
+    GC_BOUND = 59,      // entries of level >= 1: slots whose value no entry of level 0 had won after round 0 (an upper bound of what the
+                        // entry will have to search in phase 2c: 0 = its chain is not queued at all)
     GC_WIDE = 60,       // set by a wide-first launch of round 0 when some value did need more than 64 threads (nfa_wide_kernel.hpp)
     GC_OVERFLOW = 61,   // slots whose thread lists overflowed in the first-chance kernel of round 0 (they get the second chance)
     GC_REMAINDER = 62,  // slots still in play after round 0 whose REMAINDER passes the entry's screen (grok_remainder_all_kernel)
@@ -343,6 +345,16 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_filter_won_kernel(GrokEnt
     if (keep) out[at + __popcll(b & ((1ull << (threadIdx.x & 63u)) - 1ull))] = k;
 }
 
+// Entries of level >= 1 (grid.y = entries from entryBase): how many of their slots hold a value nobody has won so far -> GC_BOUND.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_bound_kernel(const GrokEntryDev* __restrict__ entries, uint32_t entryBase,
+                                                                   const uint32_t* __restrict__ winner) {
+    const GrokEntryDev& e = entries[entryBase + blockIdx.y];
+    const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
+    const bool open = k < e.cand && winner[e.line[k]] >= e.bit;
+    const uint64_t b = __ballot(open);
+    if (b && (threadIdx.x & 63u) == 0) atomicAdd(&e.cnt[GC_BOUND], uint32_t(__popcll(b)));
+}
+
 // FindNextMatch (processor_grok.go:176) searches what is left of the value behind a match -- for a format that ends 150 bytes into a
 // 4 KiB value that is 3.9 KiB in which nothing will be found, on the slowest engine there is (an unanchored search on the thread-list
 // kernel starts an attempt at every byte the format can begin with).  A further match lies entirely inside [from, len), and every
@@ -414,18 +426,22 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEnt
 // of the literal automaton instead of 4 000 of the screen's.  Such a slot gets from = len (nothing left to search: the screen kernel
 // below rejects it without a walk).  Entries without a literal (the index's ALWAYS bits) are left to the screen.  skip: bit a = the
 // entry's rounds were queued ahead by its history (grok_device.hip) -- nothing to do here.
+// winner (optional): the values won so far -- a slot whose value an EARLIER entry has won is finished too (nothing this entry finds in it is
+// ever looked at); blob == nullptr: that test alone.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(const uint8_t* __restrict__ data,
                                                                                const GrokEntryDev* __restrict__ entries,
-                                                                               const uint32_t* __restrict__ blob, unsigned long long skip) {
+                                                                               const uint32_t* __restrict__ blob, unsigned long long skip,
+                                                                               const uint32_t* __restrict__ winner) {
     __shared__ uint8_t cmap[256];
     if ((skip >> blockIdx.y) & 1ull) return;
     const GrokEntryDev& e = entries[blockIdx.y];
-    const uint64_t always = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
-    if ((always >> e.bit) & 1ull) return;
     uint32_t nIn = e.cnt[GC_ROUND0];
     nIn = nIn < e.cand ? nIn : e.cand;
     if (blockIdx.x * (kGrokPlanBlock / 64) >= nIn) return;
-    cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
+    const uint64_t always = blob ? uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32) : ~0ull;
+    const bool hasLiteral = !((always >> e.bit) & 1ull);
+    if (!hasLiteral && !winner) return;
+    if (hasLiteral) cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6);
@@ -433,6 +449,11 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(
     const uint32_t slot = e.listA[k];
     const uint32_t from = e.from[slot], len = e.len[slot];
     if (from >= len) return;
+    if (winner && winner[e.line[slot]] < e.bit) {
+        if (lane == 0) e.from[slot] = len;
+        return;
+    }
+    if (!hasLiteral) return;
     const uint32_t L = len - from, ncls = blob[GL_NCLASSES];
     const uint64_t* outMask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_MASKS]);
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[GL_OFF_TABLE]);

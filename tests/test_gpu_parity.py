@@ -976,10 +976,13 @@ def test_wide_kernel_as_the_first_chance(torch_dev, golden_dir, monkeypatch):
         assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)
 
 
-def test_small_automata_on_the_wave_kernel_with_their_tables_in_lds(torch_dev, golden_dir):
-    """Round 5: a handle that asks for the wave-per-value kernel (lc_regex_prefer_wave_tdfa: the Grok matcher's entries) and whose
-    transition table + register programs fit 48 KB gets them staged into LDS (tdfa_wave_kernel<LT>).  Same results as the oracle on
-    the bench corpora (poisoned lines included), on the golden full-match vectors, and on resumed searches."""
+@pytest.mark.parametrize("lds", ["0", "1"])
+def test_small_automata_on_the_wave_kernel(torch_dev, golden_dir, monkeypatch, lds):
+    """Round 5: a handle that asks for the wave-per-value kernel (lc_regex_prefer_wave_tdfa: the Grok matcher's entries) -- the walk
+    with its state in SGPRs and the classes of a chunk looked up once; and, LC_TDFA_WAVE_LDS_TRANS=1 (measured, left off), transition
+    table + register programs staged into LDS when they fit 48 KB (tdfa_wave_kernel<LT>).  Same results as the oracle on the bench
+    corpora (poisoned lines included), on the golden full-match vectors, and on resumed searches."""
+    monkeypatch.setenv("LC_TDFA_WAVE_LDS_TRANS", lds)
     for kind in ("A", "B"):
         pattern = corpus.REGEX_A if kind == "A" else corpus.REGEX_B
         rx = B.GpuRegex(pattern)
@@ -988,7 +991,7 @@ def test_small_automata_on_the_wave_kernel_with_their_tables_in_lds(torch_dev, g
         exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
         B.launched_kernels()
         caps, status = run_device(torch_dev, rx, data, off, None, sep=1, engine=B.LC_ENGINE_TDFA)
-        assert "tdfa_l2_kernel:wave:lds" in B.launched_kernels()
+        assert ("tdfa_l2_kernel:wave:lds" in B.launched_kernels()) == (lds == "1")
         assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
     with open(os.path.join(golden_dir, "regex_golden.json")) as f:
         golden = json.load(f)

@@ -7,10 +7,10 @@ TAG=$1; PAT=${2:-%{CISCOFW105003\}}
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 export LC_BENCH_PREFER_WAVE=1 LC_BENCH_REPS=5
 {
-echo "## time per launch, tables in LDS (default for small automata)"
+echo "## time per launch, tables in LDS (LC_TDFA_WAVE_LDS_TRANS=1)"
+LC_TDFA_WAVE_LDS_TRANS=1 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -7
+echo "## time per launch, tables in L2 (default)"
 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -7
-echo "## time per launch, tables in L2 (LC_TDFA_WAVE_NO_LDS_TRANS=1)"
-LC_TDFA_WAVE_NO_LDS_TRANS=1 timeout 200 python tools/grok_pattern_bench.py "$PAT" 2>&1 | grep -v Warning | tail -7
 } > $O.txt
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"
@@ -28,7 +28,7 @@ for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
         k = row.get("Kernel_Name", "")
         if "tdfa_wave" not in k: continue
         acc[k[:40] + " grid=" + row.get("Grid_Size", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
-print("## SQ counters per dispatch (tables in LDS)")
+print("## SQ counters per dispatch (tables in L2: the default)")
 for k in sorted(acc):
     print(k)
     for c in sorted(acc[k]):
