@@ -860,6 +860,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool breadthFirst = envInt("LC_GROK_BREADTH", 1) != 0;    // phase 2c queues the chains' launches round-robin, heavy kernels first
         const int earlyRoundsMode = envInt("LC_GROK_EARLY_ROUNDS", 1);  // 0 off, 1 by the entry's history, 2 always
         const bool remainderLiteral = envInt("LC_GROK_REMAINDER_LITERAL", 1) != 0 && literalIndex != nullptr;
+        const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;      // slots of values an earlier entry has won drop out in front of the screens
+        const bool remainderInChain = envInt("LC_GROK_REMAINDER_INCHAIN", 1) != 0;  // the remainder screens per entry, at the end of its chain in phase 2c
+        const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 1) != 0;      // an entry with a BIG screen stages it for its remainder screen
         // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
         // first chance is nfa_wide_kernel over every candidate, and what is left behind it are the decide kernels alone.  Round 4's
         // timeline: the longest entry's first chance 1.0 ms + its second chance (14 values restarted from byte 0) 1.1 ms, back to back
@@ -976,6 +979,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         std::vector<size_t> chainOwner(nAct);  // whose list an entry's steps went to (itself; a level >= 2 entry: its shadower's owner)
         for (size_t a = 0; a < nAct; ++a) chainOwner[a] = a;
         unsigned long long earlyMask = 0;  // active entries whose rounds were queued in this phase
+        unsigned long long coveredMask = 0;  // ... whose remainder screens were
         auto wantsEarlyRounds = [&](const PlanEntry& e) {
             const GrokDevicePattern& gp = patterns[e.p];
             if (!earlyRoundsMode || e.rounds < 2 || gp.re->engine != LC_ENGINE_TDFA) return false;
@@ -1012,7 +1016,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             const uint32_t ov = level ? 0u : cnt(a, GC_OVERFLOW);
             const uint32_t un = level ? 0u : cnt(a, GC_UNANCHORED);
             const bool early = wantsEarlyRounds(e0);
-            if (!level && !ov && !un && !early) return;
+            // (round 0 left slots in play: their remainders are screened at the end of this chain, see remainderSteps)
+            const bool inPlay0 = remainderInChain && !level && cnt(a, GC_ROUND0) != 0;
+            if (!level && !ov && !un && !early && !inPlay0) return;
             if (level && boundKnown && cnt(a, GC_BOUND) == 0) {  // nothing left for it (values are only ever won, never lost)
                 busy2c[a] = 0;
                 if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u: every value already won\n", e0.p, e0.level, e0.cand);
@@ -1130,6 +1136,39 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             if (early) {
                 earlyMask |= 1ull << a;
                 roundSteps(a, false, out);
+            } else if (remainderInChain) {
+                // Round 5: the remainder screens of THIS entry, here -- on its stream, as soon as its own chain is through -- instead of
+                // one launch for all entries behind the join of the phase (that launch, 0.4-0.5 ms for a few hundred 4 KiB remainders of
+                // one shadowed entry, sat between two host round trips on every batch's critical path).  Same kernels, the other
+                // entries' workgroups leave at once (skip mask).
+                coveredMask |= 1ull << a;
+                out.push_back([&, a](int& rc) {
+                    if (rc != LC_OK) return;
+                    PlanEntry& e = act[a];
+                    hipStream_t ws = T.workers[e.stream];
+                    const unsigned long long others = ~(1ull << a);
+                    if (remainderLiteral || remainderWon)
+                        hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((e.cand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct),
+                                           dim3(kGrokPlanBlock), 0, ws, d_data, T.dEntries,
+                                           remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), others,
+                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
+                    const GrokScreenDev* sc = e.remainderScreen;
+                    const bool big = small && bigRemainder && sc && sc->bigBytes;
+                    const uint32_t lds = big ? sc->bigBytes : (small && sc) ? sc->ldsBytes : 0u;
+                    if (big) {
+                        static thread_local size_t attrSet[kLcMaxDevices] = {};
+                        if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > attrSet[dev]) {
+                            if (hipFuncSetAttribute(reinterpret_cast<const void*>(grok_remainder_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    int(lds)) != hipSuccess) {
+                                rc = lcHipFail(hipGetLastError(), "hipFuncSetAttribute(grok_remainder_all_kernel)");
+                                return;
+                            }
+                            attrSet[dev] = lds;
+                        }
+                    }
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, nAct), dim3(kGrokPlanBlock), lds, ws,
+                                       d_data, T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), big ? 2u : small ? 1u : 0u, others);
+                });
             }
         };
         bool forked = false;
@@ -1166,8 +1205,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (rc2c != LC_OK) return rc2c;
             }
         }
-        // 2d
-        const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;
+        // 2d (LC_GROK_REMAINDER_INCHAIN=0 only: by default every entry that can have a slot in play screened its remainders in its chain)
+        if (!remainderInChain) {
         if (remainderWon)  // (the values won by now, phase 2c included: a slot in play whose value an earlier entry has won is finished)
             hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
                                static_cast<const uint32_t*>(nullptr), 0u);
@@ -1208,6 +1247,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
                                static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u, earlyMask | bigMask);
             if (bigMask) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
+        }
         }
         HIP_TRY(hipGetLastError());
         {

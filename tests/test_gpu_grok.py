@@ -439,7 +439,7 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
     assert "nfa_wide_kernel:first" in B.launched_kernels()          # (CISCOFW formats on IPv6 addresses overflow 64 threads)
     forced = {"LC_GROK_WIDE_FIRST": "2", "LC_GROK_EARLY_ROUNDS": "2", "LC_GROK_BIG_SCREENS": "1", "LC_TDFA_WAVE_LDS_TRANS": "1"}
     off = {"LC_GROK_WIDE_FIRST": "0", "LC_GROK_EARLY_ROUNDS": "0", "LC_GROK_BREADTH": "0", "LC_GROK_REMAINDER_LITERAL": "0",
-           "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512"}
+           "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512", "LC_GROK_REMAINDER_INCHAIN": "0"}
     for knobs in (forced, off):
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)
