@@ -862,7 +862,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool remainderLiteral = envInt("LC_GROK_REMAINDER_LITERAL", 1) != 0 && literalIndex != nullptr;
         const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;      // slots of values an earlier entry has won drop out in front of the screens
         const bool remainderInChain = envInt("LC_GROK_REMAINDER_INCHAIN", 1) != 0;  // the remainder screens per entry, at the end of its chain in phase 2c
-        const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 1) != 0;      // an entry with a BIG screen stages it for its remainder screen
+        const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 0) != 0;      // an entry with a BIG screen stages it for its remainder screen (measured: slower)
         // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
         // first chance is nfa_wide_kernel over every candidate, and what is left behind it are the decide kernels alone.  Round 4's
         // timeline: the longest entry's first chance 1.0 ms + its second chance (14 values restarted from byte 0) 1.1 ms, back to back
@@ -980,6 +980,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         for (size_t a = 0; a < nAct; ++a) chainOwner[a] = a;
         unsigned long long earlyMask = 0;  // active entries whose rounds were queued in this phase
         unsigned long long coveredMask = 0;  // ... whose remainder screens were
+        unsigned long long groupMask = 0;    // ... of those, the entries of level 0 that have nothing else to do in this phase
         auto wantsEarlyRounds = [&](const PlanEntry& e) {
             const GrokDevicePattern& gp = patterns[e.p];
             if (!earlyRoundsMode || e.rounds < 2 || gp.re->engine != LC_ENGINE_TDFA) return false;
@@ -1019,6 +1020,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             // (round 0 left slots in play: their remainders are screened at the end of this chain, see remainderSteps)
             const bool inPlay0 = remainderInChain && !level && cnt(a, GC_ROUND0) != 0;
             if (!level && !ov && !un && !early && !inPlay0) return;
+            if (!level && !ov && !un && !early) {  // nothing but remainders to screen: with the others of its kind, in ONE launch at the fork
+                groupMask |= 1ull << a;
+                coveredMask |= 1ull << a;
+                return;
+            }
             if (level && boundKnown && cnt(a, GC_BOUND) == 0) {  // nothing left for it (values are only ever won, never lost)
                 busy2c[a] = 0;
                 if (trace) fprintf(stderr, "grok plan 2c: entry %u level %u cand %u: every value already won\n", e0.p, e0.level, e0.cand);
@@ -1146,11 +1152,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (rc != LC_OK) return;
                     PlanEntry& e = act[a];
                     hipStream_t ws = T.workers[e.stream];
-                    const unsigned long long others = ~(1ull << a);
+                    // (grid.y = 1 over a table that begins at this entry)
+                    const GrokEntryDev* mine = static_cast<const GrokEntryDev*>(T.dEntries) + a;
                     if (remainderLiteral || remainderWon)
-                        hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((e.cand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct),
-                                           dim3(kGrokPlanBlock), 0, ws, d_data, T.dEntries,
-                                           remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), others,
+                        hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((e.cand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), 1),
+                                           dim3(kGrokPlanBlock), 0, ws, d_data, mine,
+                                           remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), 0ull,
                                            remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
                     const GrokScreenDev* sc = e.remainderScreen;
                     const bool big = small && bigRemainder && sc && sc->bigBytes;
@@ -1166,8 +1173,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                             attrSet[dev] = lds;
                         }
                     }
-                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, nAct), dim3(kGrokPlanBlock), lds, ws,
-                                       d_data, T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), big ? 2u : small ? 1u : 0u, others);
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), lds, ws,
+                                       d_data, mine, static_cast<const GrokScreenDev*>(T.dRemScreens) + a, big ? 2u : small ? 1u : 0u, 0ull);
                 });
             }
         };
@@ -1182,13 +1189,23 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (act[order1[i]].level == level) buildChain(order1[i]);
             size_t longest = 0;
             for (size_t a = 0; a < nAct; ++a) longest = std::max(longest, chains[a].size());
-            if (longest) {
+            if (longest || groupMask) {
                 if (!boundKnown)
                     hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
                                        static_cast<const uint32_t*>(nullptr), 0u);  // the values won so far (atomicMin per value: idempotent, finishAll runs it again)
                 rc2c = fork();
                 if (rc2c != LC_OK) return rc2c;
                 forked = true;
+                if (groupMask) {  // the entries that only have remainders to screen: one launch pair, beside the chains
+                    hipStream_t gs = T.workers[used - 1];
+                    if (remainderLiteral || remainderWon)
+                        hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((maxCand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct),
+                                           dim3(kGrokPlanBlock), 0, gs, d_data, T.dEntries,
+                                           remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), ~groupMask,
+                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, gs, d_data,
+                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u, ~groupMask);
+                }
                 if (breadthFirst) {
                     for (size_t k = 0; k < longest; ++k)
                         for (size_t i = 0; i < nAct; ++i) {
