@@ -771,6 +771,35 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     uint32_t* gate = tail + TW_GATE;
     uint32_t* xcount = tail + TW_XCOUNT;
     const uint32_t nAct = uint32_t(act.size());
+    // ---- phase 3: the first contributing entry per value; its rows go out.  All of it returns at once when values are still in
+    // play somewhere (gate != 0): the host then finishes those entries and queues it again
+    const uint32_t gridCand = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
+    auto finishAll = [&](const uint32_t* g) -> int {
+        if (nAct) {
+            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, g, 0u);
+        }
+        hipLaunchKernelGGL(grok_resolve_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, n, winner, undecided, d_pattern, g);
+        if (nAct) {
+            hipLaunchKernelGGL(grok_commit_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, d_pattern, d_first, row, g);
+            hipLaunchKernelGGL(grok_commit_extra_kernel, dim3(64), dim3(kGrokPlanBlock), 0, st, xtmp, xcount, xcap, xstride, T.dEntries, map,
+                               d_pattern, d_extra, extraCap, row, d_nextra, g);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, tail, TW_WORDS * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS, d_nextra, 4, hipMemcpyDeviceToHost, st));
+        if (nAct) HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
+        if (tlsTail.armed) {
+            HIP_TRY(hipMemcpyAsync(tlsTail.hPattern, d_pattern, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(tlsTail.hFirst, d_first, size_t(n) * row * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(syncCounted(st));
+        if (tlsTail.armed) {
+            tlsTail.done = true;
+            tlsTail.nextra = T.hostWords[HW_TAIL + TW_WORDS];
+        }
+        return LC_OK;
+    };
+    bool finished = false;  // finishAll has run (phase 2 ended with it: see the end of phase 2c)
     if (nAct) {
         HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(T.dRemScreens, T.hostRemScreens, nAct * sizeof(GrokScreenDev), hipMemcpyHostToDevice, st));
@@ -862,6 +891,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool remainderLiteral = envInt("LC_GROK_REMAINDER_LITERAL", 1) != 0 && literalIndex != nullptr;
         const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;      // slots of values an earlier entry has won drop out in front of the screens
         const bool remainderInChain = envInt("LC_GROK_REMAINDER_INCHAIN", 1) != 0;  // the remainder screens per entry, at the end of its chain in phase 2c
+        const bool postInStream = envInt("LC_GROK_POST_IN_STREAM", 1) != 0;    // round 0's post step behind each entry's kernel, on its stream
         const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 0) != 0;      // an entry with a BIG screen stages it for its remainder screen (measured: slower)
         // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
         // first chance is nfa_wide_kernel over every candidate, and what is left behind it are the decide kernels alone.  Round 4's
@@ -911,6 +941,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (calibrate && hipEventRecord(T.tick[2 * a], T.workers[e.stream]) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
                 if (rc == LC_OK) rc = runFirst(e, first, e.wideFirst, nullptr, nullptr, !gp.anchored, &e.seq0, T.workers[e.stream]);
                 if (calibrate) (void)hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]);
+                // (round 5) the entry's post step right behind its kernel: the one launch for all entries behind the join (0.12 ms) waited
+                // for the slowest entry and then stood between it and the host's read of the counts
+                if (rc == LC_OK && postInStream)
+                    hipLaunchKernelGGL(grok_post_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0,
+                                       T.workers[e.stream], T.dEntries, uint32_t(a), static_cast<const uint32_t*>(nullptr),
+                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
                 if (trace)
                     fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
                             e.p, e.cand, e.stream, first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2",
@@ -924,7 +960,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const uint32_t gridCand0 = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
         lcNoteKernel("grok_post_kernel");
         const uint32_t nLevel0 = nAct - nSecond;  // (the table lists the entries by level)
-        if (nLevel0)
+        if (nLevel0 && !postInStream)
             hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nLevel0), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u,
                                static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap,
                                xstride, xcount);
@@ -1267,76 +1303,76 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         }
         }
         HIP_TRY(hipGetLastError());
-        {
-            int rc = readCounts();  // sync 3
-            if (rc != LC_OK) return rc;
-        }
-        if (calibrate)
-            for (size_t a = 0; a < nAct; ++a)
-                if (busy2c[a]) learn(patterns[act[a].p].re->grokCost1Ns, T.tick[2 * nAct + 2 * a], T.tick[2 * nAct + 2 * a + 1], act[a].cand);
-        if (trace)
-            for (size_t a = 0; a < nAct; ++a)
-                if (cnt(a, GC_ROUND0))
-                    fprintf(stderr, "grok plan 2d: entry %u in play %u, remainder passes the screen %u%s\n", act[a].p, cnt(a, GC_ROUND0),
-                            cnt(a, GC_REMAINDER), ((earlyMask >> a) & 1ull) ? " (rounds queued ahead)" : "");
-        // (the entries' histories: do most of the slots in play pass the remainder screen?  Judged on the batches that ran the screen
-        // for the entry -- every calibration batch does)
-        for (size_t a = 0; a < nAct; ++a) {
-            if ((earlyMask >> a) & 1ull) continue;
-            const uint32_t inPlay = cnt(a, GC_ROUND0), survivors = cnt(a, GC_REMAINDER);
-            if (inPlay) patterns[act[a].p].re->grokRemainderSeen.store(survivors * 4 >= inPlay * 3 ? 1u : 0u, std::memory_order_relaxed);
-        }
-        // 2e
-        {
+        // What is left of phase 2 needs the survivors of the remainder screens -- almost always none.  Round 5: the host no longer waits
+        // to learn that.  A one-wave kernel adds the survivors to the gate word, the finish of the batch is queued behind it (it returns at
+        // once if the gate is up), and the host reads everything in ONE round trip: gate down = done (three host synchronisations per batch
+        // instead of four); gate up = the search rounds of the entries with survivors, then the finish again.  LC_GROK_LAZY_SYNC3=0: as before.
+        const bool lazy = envInt("LC_GROK_LAZY_SYNC3", 1) != 0;
+        auto afterCounts = [&] {
+            if (calibrate)
+                for (size_t a = 0; a < nAct; ++a)
+                    if (busy2c[a]) learn(patterns[act[a].p].re->grokCost1Ns, T.tick[2 * nAct + 2 * a], T.tick[2 * nAct + 2 * a + 1], act[a].cand);
+            if (trace)
+                for (size_t a = 0; a < nAct; ++a)
+                    if (cnt(a, GC_ROUND0))
+                        fprintf(stderr, "grok plan 2d: entry %u in play %u, remainder passes the screen %u%s\n", act[a].p, cnt(a, GC_ROUND0),
+                                cnt(a, GC_REMAINDER), ((earlyMask >> a) & 1ull) ? " (rounds queued ahead)" : "");
+            // (the entries' histories: do most of the slots in play pass the remainder screen?  Judged on the batches that ran the screen
+            // for the entry -- every calibration batch does)
+            for (size_t a = 0; a < nAct; ++a) {
+                if ((earlyMask >> a) & 1ull) continue;
+                const uint32_t inPlay = cnt(a, GC_ROUND0), survivors = cnt(a, GC_REMAINDER);
+                if (inPlay) patterns[act[a].p].re->grokRemainderSeen.store(survivors * 4 >= inPlay * 3 ? 1u : 0u, std::memory_order_relaxed);
+            }
+        };
+        // 2e: the search rounds of the entries with survivors (-> true if there were any)
+        auto rounds2e = [&](bool& ran) -> int {
+            ran = false;
             bool any = false;
             for (size_t a = 0; a < nAct; ++a) any = any || (cnt(a, GC_REMAINDER) && !act[a].queued);
-            if (any) {
-                int rc = fork();
+            if (!any) return LC_OK;
+            ran = true;
+            int rc = fork();
+            if (rc != LC_OK) return rc;
+            for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+                const size_t a = byCost[i];
+                PlanEntry& e = act[a];
+                if (!cnt(a, GC_REMAINDER) || e.queued) continue;
+                if (trace) fprintf(stderr, "grok plan 2e: entry %u in play %u survivors %u\n", e.p, cnt(a, GC_ROUND0), cnt(a, GC_REMAINDER));
+                std::vector<Step> steps;
+                roundSteps(a, true, steps);
+                for (Step& s2 : steps) s2(rc);
+            }
+            return join(rc);
+        };
+        if (!lazy) {
+            int rc = readCounts();  // sync 3
+            if (rc != LC_OK) return rc;
+            afterCounts();
+            bool ran = false;
+            rc = rounds2e(ran);
+            if (rc != LC_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(grok_survivor_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const GrokEntryDev*>(T.dEntries), nAct, gate, 1u);
+            int rc = finishAll(gate);  // sync 3 = the last one, unless the gate is up
+            if (rc != LC_OK) return rc;
+            finished = true;
+            afterCounts();
+            if (T.hostWords[HW_TAIL + TW_GATE] != 0) {
+                // (the survivors' share leaves the gate again: what stays up is what the queued rounds left in play)
+                hipLaunchKernelGGL(grok_survivor_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const GrokEntryDev*>(T.dEntries), nAct, gate, 0u);
+                bool ran = false;
+                rc = rounds2e(ran);
                 if (rc != LC_OK) return rc;
-                for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
-                    const size_t a = byCost[i];
-                    PlanEntry& e = act[a];
-                    if (!cnt(a, GC_REMAINDER) || e.queued) continue;
-                    if (trace) fprintf(stderr, "grok plan 2e: entry %u in play %u survivors %u\n", e.p, cnt(a, GC_ROUND0), cnt(a, GC_REMAINDER));
-                    std::vector<Step> steps;
-                    roundSteps(a, true, steps);
-                    for (Step& s : steps) s(rc);
+                if (ran) {
+                    rc = finishAll(gate);
+                    if (rc != LC_OK) return rc;
                 }
-                rc = join(rc);
-                if (rc != LC_OK) return rc;
             }
         }
     }
-    // ---- phase 3: the first contributing entry per value; its rows go out.  All of it returns at once when values are still in
-    // play somewhere (gate != 0): the host then finishes those entries and queues it again
-    const uint32_t gridCand = (maxCand + kGrokPlanBlock - 1) / kGrokPlanBlock;
-    auto finishAll = [&](const uint32_t* g) -> int {
-        if (nAct) {
-            hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided, g, 0u);
-        }
-        hipLaunchKernelGGL(grok_resolve_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, n, winner, undecided, d_pattern, g);
-        if (nAct) {
-            hipLaunchKernelGGL(grok_commit_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, d_pattern, d_first, row, g);
-            hipLaunchKernelGGL(grok_commit_extra_kernel, dim3(64), dim3(kGrokPlanBlock), 0, st, xtmp, xcount, xcap, xstride, T.dEntries, map,
-                               d_pattern, d_extra, extraCap, row, d_nextra, g);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, tail, TW_WORDS * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS, d_nextra, 4, hipMemcpyDeviceToHost, st));
-        if (nAct) HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
-        if (tlsTail.armed) {
-            HIP_TRY(hipMemcpyAsync(tlsTail.hPattern, d_pattern, size_t(n) * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(tlsTail.hFirst, d_first, size_t(n) * row * 4, hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(syncCounted(st));
-        if (tlsTail.armed) {
-            tlsTail.done = true;
-            tlsTail.nextra = T.hostWords[HW_TAIL + TW_WORDS];
-        }
-        return LC_OK;
-    };
-    {
-        int rc = finishAll(gate);  // sync 2
+    if (!finished) {
+        int rc = finishAll(gate);  // the last sync
         if (rc != LC_OK) return rc;
     }
     const double tPhase3 = msNow();

@@ -578,6 +578,18 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_advance2_kernel(
     }
 }
 
+// One wavefront: the survivors of the remainder screens (GC_REMAINDER of every active entry) go onto the gate word (add != 0) or come
+// off it again (add == 0) -- see the end of phase 2c in grok_device.hip.
+__global__ __launch_bounds__(64) void grok_survivor_gate_kernel(const GrokEntryDev* __restrict__ entries, uint32_t nAct, uint32_t* __restrict__ gate,
+                                                                uint32_t add) {
+    const uint32_t a = threadIdx.x;
+    const uint32_t c = a < nAct ? entries[a].cnt[GC_REMAINDER] : 0u;
+    if (c) {
+        if (add) atomicAdd(gate, c);
+        else atomicSub(gate, c);
+    }
+}
+
 // grid = (ceil(max cand / block), active entries).  gate (optional): leave at once while values are still in play somewhere.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_entry_finish_kernel(const GrokEntryDev* __restrict__ entries,
                                                                           uint32_t* __restrict__ winner, uint32_t* __restrict__ undecided,

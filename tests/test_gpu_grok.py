@@ -364,10 +364,11 @@ def test_speculative_and_sequential_paths_agree(torch_dev, match):
     # screens' survivors, the end (round 4: the two in the middle replaced ~400 launches over lists that turn out empty)
     p3, f3, x3, s3 = _device_rows(torch_dev, spec, values)
     assert np.array_equal(p1, p3) and np.array_equal(f1, f3) and np.array_equal(x1, x3)
+    # (round 5: THREE when no slot's remainder passes its entry's screen -- the host reads the survivors together with the results)
     assert s3["host_syncs"] <= 8, s3      # (an entry with dozens of matches per value goes on in stretches of rounds)
-    assert s3["host_syncs"] == 4 or s3["deferred_entries"] > 0, s3
+    assert s3["host_syncs"] in (3, 4) or s3["deferred_entries"] > 0, s3
     if match[0] != "%{IPV4:ip}":          # (up to 36 addresses per value there)
-        assert s3["host_syncs"] == 4, s3
+        assert s3["host_syncs"] in (3, 4), s3
     assert s2["host_syncs"] > s3["host_syncs"]
     o = GrokOracle(match)
     pattern, fields = spec.match_host(values)
@@ -439,7 +440,8 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
     assert "nfa_wide_kernel:first" in B.launched_kernels()          # (CISCOFW formats on IPv6 addresses overflow 64 threads)
     forced = {"LC_GROK_WIDE_FIRST": "2", "LC_GROK_EARLY_ROUNDS": "2", "LC_GROK_BIG_SCREENS": "1", "LC_TDFA_WAVE_LDS_TRANS": "1"}
     off = {"LC_GROK_WIDE_FIRST": "0", "LC_GROK_EARLY_ROUNDS": "0", "LC_GROK_BREADTH": "0", "LC_GROK_REMAINDER_LITERAL": "0",
-           "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512", "LC_GROK_REMAINDER_INCHAIN": "0"}
+           "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512", "LC_GROK_REMAINDER_INCHAIN": "0", "LC_GROK_POST_IN_STREAM": "0",
+           "LC_GROK_LAZY_SYNC3": "0"}
     for knobs in (forced, off):
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)

@@ -52,10 +52,9 @@ PY
   ab no_won LC_GROK_REMAINDER_WON=0
   ab slice512 LC_GROK_SLICE=512
   ab no_inchain LC_GROK_REMAINDER_INCHAIN=0
-  ab bigrem_on LC_GROK_BIG_REMAINDER=1
-  ab big_on LC_GROK_BIG_SCREENS=1
-  ab wavelds_on LC_TDFA_WAVE_LDS_TRANS=1
-  ab all_off LC_GROK_WIDE_FIRST=0 LC_GROK_BREADTH=0 LC_GROK_EARLY_ROUNDS=0 LC_GROK_REMAINDER_LITERAL=0 LC_GROK_BOUND=0 LC_GROK_REMAINDER_WON=0 LC_GROK_SLICE=512 LC_GROK_REMAINDER_INCHAIN=0
+  ab no_poststream LC_GROK_POST_IN_STREAM=0
+  ab no_lazy LC_GROK_LAZY_SYNC3=0
+  ab all_off LC_GROK_WIDE_FIRST=0 LC_GROK_BREADTH=0 LC_GROK_EARLY_ROUNDS=0 LC_GROK_REMAINDER_LITERAL=0 LC_GROK_BOUND=0 LC_GROK_REMAINDER_WON=0 LC_GROK_SLICE=512 LC_GROK_REMAINDER_INCHAIN=0 LC_GROK_POST_IN_STREAM=0 LC_GROK_LAZY_SYNC3=0
   bash tools/gpu_grok_profile.sh r5_plan 16384 2>&1 | head -14 | cut -c1-250 ;;
 *) echo "usage: $0 first|multi|grok|plan"; exit 2 ;;
 esac
