@@ -335,7 +335,10 @@ constexpr int kGrokMaxStreams = 16;  // (LC_GROK_STREAMS; the default stays opts
 constexpr uint32_t kGrokScreenStageMax = 44 * 1024;  // a screen's accept flags + table are staged into LDS up to this size
 constexpr uint32_t kGrokScreenBigMax = 150 * 1024;   // ... and up to this size by a workgroup that has its CU's LDS to itself (small batches)
 constexpr uint32_t kGrokMaxRounds = GC_BOUND - GC_ROUND0 - 1;  // search rounds that can be queued ahead per entry
-constexpr uint32_t kGrokSmallBatch = 32768;  // up to here a batch is latency-bound: see phase 1
+constexpr uint32_t kGrokSmallBatch = 262144;  // up to here phase 1 takes the chunk-parallel literal pass and LDS-staged screens, one value per
+                                              // lane (round 5: measured better than the lane-per-value passes at 64 Ki (9.3 -> 7.3 ms), 128 Ki
+                                              // (14.0 -> 12.1) and 256 Ki values (21.6 -> 20.6); round 4 drew the line at 32 Ki)
+constexpr uint32_t kGrokWideFirstBatch = 32768;  // ... and up to here a batch waits for its longest value: wide first pays (16 Ki: -0.3 ms; 64 Ki: +0.5 ms)
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
 enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_FIRST = 128 + 64 * GC_WORDS, HW_SHADOW = 192 + 64 * GC_WORDS,
@@ -543,7 +546,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     // ---- phase 1: length order, literal index, all screens, candidate counts
     // Small batches wait for their LONGEST value (every kernel below is a dependent chain per value): chunk-parallel literal pass,
     // screen tables in LDS.  Large batches are about values in flight and equal work per wavefront: lane-per-value in length order.
-    const bool small = n <= kGrokSmallBatch;
+    static const uint32_t smallBatch = [] {  // LC_GROK_SMALL_BATCH: A/B measurements
+        const char* v = getenv("LC_GROK_SMALL_BATCH");
+        return v ? uint32_t(atol(v)) : kGrokSmallBatch;
+    }();
+    const bool small = n <= smallBatch;
     uint32_t* order = reinterpret_cast<uint32_t*>(head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256));
     uint32_t* orderWork = reinterpret_cast<uint32_t*>(tailAt + 512 + alignUp(size_t(n) * 8, 256));  // work words behind the masks
     HIP_TRY(hipMemsetAsync(tailAt, 0, 512, st));
@@ -899,7 +906,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // on the critical path of the batch; now 1.1 ms.
         auto wantsWideFirst = [&](lc_regex* h) {
             if (!wideFirstMode || h->engine != LC_ENGINE_NFA || !lcNfaWideApplies(h)) return false;
-            return wideFirstMode >= 2 || h->grokOverflowSeen.load(std::memory_order_relaxed) != 0;
+            if (wideFirstMode >= 2) return true;
+            return n <= kGrokWideFirstBatch && h->grokOverflowSeen.load(std::memory_order_relaxed) != 0;
         };
         // one engine call of entry e on stream ws: the first-chance kernel ...
         auto runFirst = [&](PlanEntry& e, lc_regex* h, bool wide, const uint32_t* count, const uint32_t* list, bool withFrom, uint32_t* seq,

@@ -56,5 +56,43 @@ PY
   ab no_lazy LC_GROK_LAZY_SYNC3=0
   ab all_off LC_GROK_WIDE_FIRST=0 LC_GROK_BREADTH=0 LC_GROK_EARLY_ROUNDS=0 LC_GROK_REMAINDER_LITERAL=0 LC_GROK_BOUND=0 LC_GROK_REMAINDER_WON=0 LC_GROK_SLICE=512 LC_GROK_REMAINDER_INCHAIN=0 LC_GROK_POST_IN_STREAM=0 LC_GROK_LAZY_SYNC3=0
   bash tools/gpu_grok_profile.sh r5_plan 16384 2>&1 | head -14 | cut -c1-250 ;;
-*) echo "usage: $0 first|multi|grok|plan"; exit 2 ;;
+big)
+  # the 64 Ki-value batch: the phase trace, and the small-batch path forced onto it (LC_GROK_SMALL_BATCH)
+  export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
+  for SB in 32768 65536; do
+    echo "## LC_GROK_SMALL_BATCH=$SB"
+    LC_GROK_SMALL_BATCH=$SB timeout 300 python tools/grok_bench.py --lines 65536 --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('  %.3f ms/step  %s' % (d['ms_per_step'], d['config']['batch']))"
+    LC_GROK_SMALL_BATCH=$SB LC_GROK_TRACE=1 timeout 300 python tools/grok_bench.py --lines 65536 --steps 1 --warmup 8 --no-sequential-check --cpu-sample-lines 50 2>&1 >/dev/null | grep "grok plan" | tail -60 | cut -c1-170 > $O/trace_$SB.txt
+    grep "plan 2a" $O/trace_$SB.txt | sort -t'|' -k2 | awk -F'measured round 0 ' '{print $2" | "$1}' | sort -g -r | head -8 | cut -c1-150
+    tail -1 $O/trace_$SB.txt
+  done
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o r1 -- python $R/tools/grok_bench.py --lines 65536 --steps 3 --warmup 8 --no-sequential-check --cpu-sample-lines 50 > $R/$O/prof.log 2>&1
+  cd $R; python tools/grok_timeline.py $O/prof 900 > $O/grok_timeline_64k.txt 2>&1; python tools/grok_prof_summary.py $O/prof > $O/grok_rocprofv3_64k.txt 2>&1; rm -rf $O/prof
+  head -30 $O/grok_rocprofv3_64k.txt | cut -c1-140 ;;
+big2)
+  export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
+  run() { echo "## $*"; env "$@" timeout 300 python tools/grok_bench.py --lines ${LINES:-65536} --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('  %.3f ms/step' % d['ms_per_step'])"; }
+  run LC_GROK_SMALL_BATCH=65536
+  run LC_GROK_SMALL_BATCH=65536 LC_GROK_SLICE=512
+  run LC_GROK_SMALL_BATCH=65536 LC_GROK_SLICE=1024
+  run LC_GROK_SMALL_BATCH=65536 LC_GROK_WIDE_FIRST=0
+  run LC_GROK_SMALL_BATCH=65536 LC_TDFA_WAVE_MAX=32768
+  LINES=131072 run LC_GROK_SMALL_BATCH=65536
+  LINES=131072 run LC_GROK_SMALL_BATCH=131072
+  LINES=262144 run LC_GROK_SMALL_BATCH=65536
+  LINES=262144 run LC_GROK_SMALL_BATCH=262144
+  cd /tmp && export TMPDIR=/tmp
+  LC_GROK_SMALL_BATCH=65536 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o r1 -- python $R/tools/grok_bench.py --lines 65536 --steps 3 --warmup 8 --no-sequential-check --cpu-sample-lines 50 > $R/$O/prof.log 2>&1
+  cd $R; python tools/grok_timeline.py $O/prof 900 > $O/grok_timeline_64k.txt 2>&1; python tools/grok_prof_summary.py $O/prof > $O/grok_rocprofv3_64k.txt 2>&1; rm -rf $O/prof
+  head -16 $O/grok_rocprofv3_64k.txt | cut -c1-140 ;;
+*) echo "usage: $0 first|multi|grok|plan|big|big2"; exit 2 ;;
 esac
