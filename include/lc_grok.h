@@ -88,9 +88,10 @@ int lc_grok_row_ints(const lc_grok_t* g);                          /* ints per c
  *                                the number reported with LC_ERR_OVERFLOW can exceed the rows finally written)
  * d_scratch  lc_grok_scratch_bytes(g, n) bytes
  * The call enqueues on `stream` (and on a few worker streams of its own that fork from it and join it) and returns after the
- * last kernel has finished.  Default path: TWO host synchronisations per batch (candidates per entry; results) -- the number of
- * values still in play after each search round stays on the device; an entry that needs more rounds than it queued ahead costs
- * one more per extra round, once (csrc/grok_device.hip).  Config key "Speculative": false (or a list of more than 64 entries)
+ * last kernel has finished.  Default path: THREE host synchronisations per batch (candidates per entry; round 0's counts; results) --
+ * a fourth when a value's remainder behind a first match passes its entry's screen; the number of values still in play after each
+ * search round stays on the device; an entry that needs more rounds than it queued ahead costs one more per extra round, once
+ * (csrc/grok_device.hip).  Config key "Speculative": false (or a list of more than 64 entries)
  * selects the sequential walk of the list with a host round trip per filter / screen / round. */
 size_t lc_grok_scratch_bytes(const lc_grok_t* g, uint32_t n);
 int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,
