@@ -94,5 +94,23 @@ for l in sys.stdin:
   LC_GROK_SMALL_BATCH=65536 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o r1 -- python $R/tools/grok_bench.py --lines 65536 --steps 3 --warmup 8 --no-sequential-check --cpu-sample-lines 50 > $R/$O/prof.log 2>&1
   cd $R; python tools/grok_timeline.py $O/prof 900 > $O/grok_timeline_64k.txt 2>&1; python tools/grok_prof_summary.py $O/prof > $O/grok_rocprofv3_64k.txt 2>&1; rm -rf $O/prof
   head -16 $O/grok_rocprofv3_64k.txt | cut -c1-140 ;;
-*) echo "usage: $0 first|multi|grok|plan|big|big2"; exit 2 ;;
+ab64)
+  # the plan's knobs on a 64 Ki-value batch
+  export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
+  run() { printf "%-44s" "$*"; env "$@" timeout 300 python tools/grok_bench.py --lines 65536 --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('  %.3f ms/step' % d['ms_per_step'])"; }
+  run X=default
+  run LC_GROK_POST_IN_STREAM=0
+  run LC_GROK_BREADTH=0
+  run LC_GROK_REMAINDER_INCHAIN=0
+  run LC_GROK_LAZY_SYNC3=0
+  run LC_GROK_BOUND=0
+  run LC_GROK_STREAMS=8
+  run LC_TDFA_WAVE_MAX=16384
+  run LC_NFA_GLOBAL_KB=160
+  run X=default ;;
+*) echo "usage: $0 first|multi|grok|plan|big|big2|ab64"; exit 2 ;;
 esac
