@@ -122,7 +122,17 @@ enum {
                           // whose follow paths takes d -- a thread that would live for exactly one byte and touch nothing
                           // (the " SA (SPI=" behind a GREEDYDATA tried at every space; the lazy search prefix tried at every byte a
                           // format can begin with).  Such a byte is as steady as one whose only move is the self loop.
-    NF_HEADER_WORDS = 24
+    // Round 5: the follow lists BY BYTE CLASS.  A step's candidates are the (thread, follow path) pairs of the live threads, 64 per
+    // election round -- and a thread inside an IP address alternation has a follow list of a hundred paths of which the byte takes two:
+    // on CISCOFW313005 a step ran thirty rounds (13 000 cycles) to find a handful of survivors.  cstart[(p * nClasses + c)] ..
+    // cstart[.. + 1] = the range in cpaths[] of the indices (into NF_OFF_PATHS, priority order kept) of position p's paths whose
+    // target takes byte class c (MATCH paths take no byte: never listed).  Always read from global memory (L2), also by kernels that
+    // stage the program in LDS: the tables lie BEHIND NF_STAGE_BYTES, the part of the blob those kernels stage.  0 = not packed
+    // (the tables would exceed 16 MiB).
+    NF_OFF_CSTART = 24,   // u32[(nPos + 1) * nClasses + 1]
+    NF_OFF_CPATHS = 25,   // u32[]
+    NF_STAGE_BYTES = 26,  // bytes of the blob in front of the class tables (a multiple of 16)
+    NF_HEADER_WORDS = 28
 };
 #define NF_MAGIC_VALUE 0x3141464Eu
 #define NF_TARGET_MATCH 0xFFFFFFFFu

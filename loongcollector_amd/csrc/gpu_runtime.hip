@@ -697,9 +697,11 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     void* dBlob = nullptr;
     int rc = ensureUploaded(re, dev, kBlobNfa, &dBlob);
     if (rc != LC_OK) return rc;
-    const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);
+    const uint32_t blobBytes = uint32_t(re->nfaBlob.size() * 4);  // the whole upload: the overflow flag sits behind it
+    // what a kernel that keeps the program in LDS stages: everything in front of the class lists (device_tables.h NF_STAGE_BYTES)
+    const uint32_t stageBytes = re->nfaBlob[NF_STAGE_BYTES] ? re->nfaBlob[NF_STAGE_BYTES] : blobBytes;
     const bool atomic = re->nfa.atomicCount > 0;
-    size_t lds = lcNfaLdsBytes(blobBytes, uint32_t(re->nfa.positions.size()), atomic);
+    size_t lds = lcNfaLdsBytes(stageBytes, uint32_t(re->nfa.positions.size()), atomic);
     // Program too big for LDS -- or so big that fewer than three workgroups would fit per CU: the tables stay in HBM (L2) and
     // only the scratch is LDS; four or eight lines per CU with LDS-speed tables lose against a dozen with L2-speed tables
     // (configs[2], 256 Ki lines: CISCOFW106001, 89.6 KB with its tables, 32 -> 9.4 ms; CRONLOG 6.2 -> 3.2 ms; below 52 KB
@@ -734,7 +736,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     const uint32_t nPosAll = uint32_t(re->nfa.positions.size());
     if (global && stageSmall && !atomic && re->nfa.slotCount() <= 64) {
         for (int waves : {4, 2, 1}) {
-            const size_t need = lcNfaLdsBytes(blobBytes, nPosAll, atomic, uint32_t(waves));
+            const size_t need = lcNfaLdsBytes(stageBytes, nPosAll, atomic, uint32_t(waves));
             if (need > kLcLdsPerCu) continue;
             const size_t perCu = kLcLdsPerCu / need;                   // workgroups a CU holds
             const size_t oneRound = size_t(256) * perCu * size_t(waves);  // values the chip walks at once
@@ -747,7 +749,7 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
         }
     }
     const bool wideStage = stageSmall && n <= 4096;  // (the second chance walks one value per workgroup anyway)
-    if (global) lds -= blobBytes;
+    if (global) lds -= stageBytes;
     if (lds > 160 * 1024) {
         tlsError = "nfa tables exceed LDS";
         return LC_ERR_UNSUPPORTED;
@@ -831,13 +833,13 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
             constexpr bool A = decltype(a)::value, G = decltype(g)::value;
             if constexpr (!G && !A && NS <= 64) {  // (staged programs without atomic groups only -- an opt-in experiment does not get 24 more instantiations)
                 if (block == 128)
-                    return launchNfaSlots<NS, A, G, 128>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                    return launchNfaSlots<NS, A, G, 128>(dBlob, stageBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
                                                          d_caps, d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
                 if (block == 64)
-                    return launchNfaSlots<NS, A, G, 64>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                    return launchNfaSlots<NS, A, G, 64>(dBlob, stageBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
                                                         d_caps, d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
             }
-            return launchNfaSlots<NS, A, G>(dBlob, blobBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps,
+            return launchNfaSlots<NS, A, G>(dBlob, stageBytes, nPos, lds, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps,
                                             d_status, stream, overflowFlag, seq, pendingFlag, chance, wideStage);
         };
         if (atomic && global) return go(std::true_type{}, std::true_type{});

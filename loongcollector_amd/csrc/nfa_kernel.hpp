@@ -439,6 +439,10 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
     tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
     const uint32_t maskShift = tb.maskShift;
     const uint32_t* followStart = tb.followStart;
+    // follow lists by byte class (device_tables.h NF_OFF_CSTART): in global memory also when the program is staged
+    const uint32_t* cstart = hdr[NF_OFF_CSTART] ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + hdr[NF_OFF_CSTART]) : nullptr;
+    const uint32_t* cpaths = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + hdr[NF_OFF_CPATHS]);
+    const uint32_t nClasses = hdr[NF_NCLASSES];
 
     // (round 5: what is wave-uniform is SAID to be -- readfirstlane -- or the compiler, for which anything derived from threadIdx or read
     // from LDS is divergent, keeps the line's offsets, the byte position and the loop conditions in VGPRs and steers the walk with exec masks)
@@ -670,8 +674,13 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
             }
         }
 
-        const uint32_t fs = liveLane ? followStart[myPos] : 0;
-        const uint32_t cnt = liveLane ? followStart[myPos + 1] - fs : 0;
+        // (round 5) this thread's paths whose target takes THIS byte: the class list where the blob has one, else the whole follow list
+        uint32_t fs = 0, cnt = 0;
+        if (liveLane) {
+            const uint32_t* rowStart = cstart ? cstart + (myPos * nClasses + cls) : followStart + myPos;
+            fs = rowStart[0];
+            cnt = rowStart[1] - fs;
+        }
         uint32_t totalCand;
         const uint32_t rankBase = waveExclusiveScan(cnt, lane, totalCand);
         totalCand = __builtin_amdgcn_readfirstlane(totalCand);
@@ -704,8 +713,13 @@ __global__ __launch_bounds__(BLOCK) void nfa_match_kernel(const uint8_t* __restr
             bool pass = false;
             uint4 p{0, 0, 0, 0};
             if (cand < totalCand) {
-                p = nfaPath(tb, q);
-                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, maskShift, p.x, cw, cb);
+                if (cstart) {  // (listed = the target takes the byte; MATCH paths are not listed)
+                    p = nfaPath(tb, cpaths[q]);
+                    pass = (p.y & ~ctrue) == 0;
+                } else {
+                    p = nfaPath(tb, q);
+                    if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, maskShift, p.x, cw, cb);
+                }
                 if (pass) atomicMin(&best[p.x], cand);  // per target, the candidate of highest priority
             }
             waveLdsSync();

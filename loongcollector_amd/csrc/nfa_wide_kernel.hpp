@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
     tb.auxShift = TW == 10 ? 4 : (TW == 4 ? 3 : 2);
     tb.posMask = reinterpret_cast<const uint32_t*>(tbl + hdr[NF_OFF_POSMASK]);
     tb.maskShift = hdr[NF_MASK_WORDS] == 4 ? 2 : 1;
+    // follow lists by byte class (device_tables.h NF_OFF_CSTART; nfa_kernel.hpp): always read from global memory
+    const uint32_t* cstart = hdr[NF_OFF_CSTART] ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + hdr[NF_OFF_CSTART]) : nullptr;
+    const uint32_t* cpaths = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + hdr[NF_OFF_CPATHS]);
+    const uint32_t nClasses = hdr[NF_NCLASSES];
 
     // LDS: best[nPos] then newPos / newSrc / newAux for 128 threads
     uint32_t* best = reinterpret_cast<uint32_t*>(smem + scratchBase);
@@ -193,8 +197,17 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
         const uint32_t ctrue = __builtin_amdgcn_readfirstlane(behindBits[prevCls] | aheadBits[cls]);
         prevCls = cls;
         const bool live0 = lane < nThreads, live1 = lane + 64 < nThreads;
-        const uint32_t fs0 = live0 ? tb.followStart[pos[0]] : 0, fs1 = live1 ? tb.followStart[pos[1]] : 0;
-        const uint32_t cnt0 = live0 ? tb.followStart[pos[0] + 1] - fs0 : 0, cnt1 = live1 ? tb.followStart[pos[1] + 1] - fs1 : 0;
+        uint32_t fs0 = 0, fs1 = 0, cnt0 = 0, cnt1 = 0;
+        if (live0) {
+            const uint32_t* r0 = cstart ? cstart + (pos[0] * nClasses + cls) : tb.followStart + pos[0];
+            fs0 = r0[0];
+            cnt0 = r0[1] - fs0;
+        }
+        if (live1) {
+            const uint32_t* r1 = cstart ? cstart + (pos[1] * nClasses + cls) : tb.followStart + pos[1];
+            fs1 = r1[0];
+            cnt1 = r1[1] - fs1;
+        }
         uint32_t rank0, rank1, totalCand;
         nfaWideScan(cnt0, cnt1, lane, rank0, rank1, totalCand);
         totalCand = __builtin_amdgcn_readfirstlane(totalCand);
@@ -226,8 +239,13 @@ __global__ __launch_bounds__(64) void nfa_wide_kernel(const uint8_t* __restrict_
             bool pass = false;
             uint4 p{0, 0, 0, 0};
             if (cand < totalCand) {
-                p = nfaPath(tb, q);
-                if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, tb.maskShift, p.x, cw, cb);
+                if (cstart) {
+                    p = nfaPath(tb, cpaths[q]);
+                    pass = (p.y & ~ctrue) == 0;
+                } else {
+                    p = nfaPath(tb, q);
+                    if (p.x != NF_TARGET_MATCH && (p.y & ~ctrue) == 0) pass = nfaMaskBit(tb.posMask, tb.maskShift, p.x, cw, cb);
+                }
                 if (pass) atomicMin(&best[p.x], cand);
             }
             waveLdsSync();

@@ -875,6 +875,35 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
         hdr[NF_OFF_EVENTS] = w.put(events);
         hdr[NF_OFF_ATOMICPOS] = w.put(atomicPos);
     }
+    // ---- follow lists by byte class (device_tables.h NF_OFF_CSTART): behind everything the LDS kernels stage
+    hdr[NF_STAGE_BYTES] = uint32_t((w.bytes.size() + 15) & ~size_t(15));
+    {
+        static const bool off = getenv("LC_NFA_NO_CLASS_LISTS") != nullptr;  // (A/B measurements; read when a pattern is compiled)
+        const size_t nc = rep.size();
+        std::vector<uint32_t> cstart, cpaths;
+        bool fits = !off;
+        if (fits) {
+            cstart.reserve(size_t(npos + 1) * nc + 1);
+            for (int p = 0; p <= npos && fits; ++p) {
+                const uint32_t base = followStart[size_t(p)];
+                for (size_t c = 0; c < nc; ++c) {
+                    cstart.push_back(uint32_t(cpaths.size()));
+                    uint32_t k = 0;
+                    for (const auto& path : nfa.follow[size_t(p)]) {
+                        if (path.target >= 0 && nfa.positions[size_t(path.target)].has(rep[c])) cpaths.push_back(base + k);
+                        ++k;
+                    }
+                }
+                fits = (cstart.size() + cpaths.size()) * 4 <= (size_t(16) << 20);
+            }
+            cstart.push_back(uint32_t(cpaths.size()));
+        }
+        if (fits) {
+            if (cpaths.empty()) cpaths.push_back(0);
+            hdr[NF_OFF_CSTART] = w.put(cstart);
+            hdr[NF_OFF_CPATHS] = w.put(cpaths);
+        }
+    }
     std::memcpy(w.bytes.data(), hdr, sizeof hdr);
     return w.finish(NF_TOTAL_BYTES);
 }

@@ -627,3 +627,37 @@ def test_a_construction_that_failed_on_its_limits_is_not_repeated(golden_dir):
         rx = B.GpuRegex(g.expanded(1).encode(), syntax_flags=flags, engine=B.LC_ENGINE_TDFA)
         sizes.append(rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32).tobytes())
     assert sizes[0] == sizes[1] and len(sizes[0]) > 100000
+
+
+def test_follow_lists_by_byte_class_are_the_follow_lists_filtered(golden_dir):
+    """device_tables.h NF_OFF_CSTART / NF_OFF_CPATHS (round 5): for every position p and byte class c the class list is exactly the
+    sub-list of p's follow paths whose target takes c -- same order (the order is the priority), MATCH paths left out -- and the part
+    of the blob in front of the lists (NF_STAGE_BYTES: what an LDS kernel stages) holds every other table."""
+    from loongcollector_amd import corpus
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    patterns = [c["p"].encode("latin-1") for c in golden["cases"][::9]]
+    patterns += [corpus.REGEX_A.encode() if isinstance(corpus.REGEX_A, str) else corpus.REGEX_A,
+                 rb"(?:(?:[0-9a-f]{1,4}:){7}[0-9a-f]{1,4}|(?:\d{1,3}\.){3}\d{1,3}) (\w+)=(\S*)", rb"(a|ab|abc)*(?>x+)y"]
+    checked = 0
+    for pat in patterns:
+        for flags in (0, B.LC_SYNTAX_SEARCH):
+            try:
+                rx = B.GpuRegex(pat, syntax_flags=flags, engine=B.LC_ENGINE_NFA)
+            except Exception:
+                continue
+            blob = rx.table(B.LC_TABLE_NFA_BLOB, np.uint32)
+            it = NfaInterp(rx)
+            off_cs, off_cp, stage = int(blob[24]), int(blob[25]), int(blob[26])
+            assert off_cs and off_cp and stage % 16 == 0 and stage <= off_cs < off_cp
+            assert all(int(blob[k]) < stage for k in (4, 5, 6, 7, 11, 12, 13, 17))      # every other table lies in the staged part
+            fs = blob[int(blob[6]) // 4:int(blob[6]) // 4 + it.npos + 2]
+            cstart = blob[off_cs // 4:off_cs // 4 + (it.npos + 1) * it.ncls + 1]
+            cpaths = blob[off_cp // 4:]
+            for p in range(it.npos + 1):
+                for c in range(it.ncls):
+                    want = [int(fs[p]) + k for k, (tgt, _, _) in enumerate(it.follow[p]) if tgt >= 0 and (it.posmask[tgt] >> c) & 1]
+                    lo, hi = int(cstart[p * it.ncls + c]), int(cstart[p * it.ncls + c + 1])
+                    assert [int(x) for x in cpaths[lo:hi]] == want, (pat, p, c)
+                    checked += 1
+    assert checked > 20000

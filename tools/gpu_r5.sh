@@ -112,5 +112,19 @@ for l in sys.stdin:
   run LC_TDFA_WAVE_MAX=16384
   run LC_NFA_GLOBAL_KB=160
   run X=default ;;
-*) echo "usage: $0 first|multi|grok|plan|big|big2|ab64"; exit 2 ;;
+classlists)
+  # the thread-list kernels on follow lists by byte class (device_tables.h NF_OFF_CSTART) against the whole follow lists
+  export LC_TABLE_CACHE_DIR=/tmp/lctab GPU_MAX_HW_QUEUES=16
+  timeout 700 python -m pytest tests/test_gpu_grok.py tests/test_gpu_decide.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
+  timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_processor.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
+  for V in "X=classlists" "LC_NFA_NO_CLASS_LISTS=1"; do
+    echo "## $V"
+    env $V LC_BENCH_ANCHORED=1 LC_BENCH_ENGINE=nfa LC_BENCH_REPS=5 timeout 200 python tools/grok_pattern_bench.py '%{CISCOFW313005}' '%{CISCOFW302013_302014_302015_302016}' '%{HAPROXYHTTP}' 2>&1 | grep -v "Warning\|amdgpu.ids" | grep "engine\|with literal\|>= 2 KiB" | cut -c1-150
+    env $V timeout 300 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 8 --no-sequential-check --cpu-sample-lines 100 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('  grok %s: %.3f ms/step' % (d['config']['workload'].split('), ')[1].split(' lines')[0], d['ms_per_step']))"
+  done ;;
+*) echo "usage: $0 first|multi|grok|plan|big|big2|ab64|classlists"; exit 2 ;;
 esac
