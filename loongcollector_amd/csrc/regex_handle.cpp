@@ -878,7 +878,11 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
     // ---- follow lists by byte class (device_tables.h NF_OFF_CSTART): behind everything the LDS kernels stage
     hdr[NF_STAGE_BYTES] = uint32_t((w.bytes.size() + 15) & ~size_t(15));
     {
-        static const bool off = getenv("LC_NFA_NO_CLASS_LISTS") != nullptr;  // (A/B measurements; read when a pattern is compiled)
+        // MEASURED AND LEFT OFF (LC_NFA_CLASS_LISTS=1 packs them; read when a pattern is compiled): on the Grok entries that are the long
+        // poles of a batch a step has ~14 candidates in ONE election round either way -- what a step costs there is the latency of its
+        // own ~650 instructions, not the number of candidates (profiles/round5_grok_steps.txt); the lists add up to 1.6 MB per pattern.
+        const char* on = getenv("LC_NFA_CLASS_LISTS");
+        const bool off = !(on && on[0] == '1');
         const size_t nc = rep.size();
         std::vector<uint32_t> cstart, cpaths;
         bool fits = !off;

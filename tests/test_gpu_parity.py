@@ -1027,3 +1027,42 @@ def test_small_automata_on_the_wave_kernel(torch_dev, golden_dir, monkeypatch, l
             assert int(d_status[0]) == B.LC_NOMATCH, frm
         else:
             assert int(d_status[0]) == 1 and d_caps.cpu().numpy()[0].tolist() == [v for be in o for v in be], (frm, o)
+
+
+def test_thread_list_kernels_on_follow_lists_by_byte_class(torch_dev, golden_dir, monkeypatch):
+    """LC_NFA_CLASS_LISTS=1 (device_tables.h NF_OFF_CSTART: measured on configs[2], no gain, left off): a step's candidates come from
+    the lists of the paths whose target takes the byte instead of the whole follow lists -- the narrow kernel, the wide kernel
+    (second chance and first chance), atomic groups; all equal to the oracle."""
+    monkeypatch.setenv("LC_NFA_CLASS_LISTS", "1")
+    with open(os.path.join(golden_dir, "regex_golden.json")) as f:
+        golden = json.load(f)
+    bad, checked = [], 0
+    for c in golden["cases"][::4]:
+        rx = B.GpuRegex(c["p"].encode("latin-1"))
+        if not rx.has_nfa_program():
+            continue
+        assert int(rx.table(B.LC_TABLE_NFA_BLOB, np.uint32)[24]) != 0
+        subs = [s.encode("latin-1") for s, _ in c["subs"]]
+        data, off, length = pack(subs)
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+        for i, (_, flat) in enumerate(c["subs"]):
+            checked += 1
+            ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if flat is None else \
+                 (status[i] == B.LC_MATCH and list(caps[i]) == flat[2:])
+            if not ok:
+                bad.append((c["p"], subs[i], int(status[i]), list(caps[i]), flat))
+    assert checked > 1000 and not bad, bad[:5]
+    for wide_first in ("0", "1"):
+        monkeypatch.setenv("LC_NFA_WIDE_FIRST", wide_first)
+        for pattern, subs in ((r"(.*)a(.{70})", [b"a" * 100, b"b" * 10, b"a" + b"b" * 70, b"xa" * 80, b"a" * 71, b""]),
+                              (r"(.*)a.{140}", [b"a" * 200, b"a" + b"b" * 140, b"a" * 140, b"b"]),
+                              (r"(?>a+)(b|bc)+d", [b"aaabbcd", b"abcbcd", b"aab", b"d"])):
+            data, off, length = pack(subs)
+            exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+            rx = B.GpuRegex(pattern, engine=B.LC_ENGINE_NFA)
+            caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_NFA)
+            assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps), (pattern, wide_first)
+        data, off, length = corpus.apache_batch(2000, "A", poison_every=11)
+        exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
+        caps_n, status_n = run_device(torch_dev, B.GpuRegex(corpus.REGEX_A), data, off, None, sep=1, engine=B.LC_ENGINE_NFA)
+        assert np.array_equal(status_n, exp_status) and np.array_equal(caps_n, exp_caps)

@@ -629,11 +629,15 @@ def test_a_construction_that_failed_on_its_limits_is_not_repeated(golden_dir):
     assert sizes[0] == sizes[1] and len(sizes[0]) > 100000
 
 
-def test_follow_lists_by_byte_class_are_the_follow_lists_filtered(golden_dir):
-    """device_tables.h NF_OFF_CSTART / NF_OFF_CPATHS (round 5): for every position p and byte class c the class list is exactly the
-    sub-list of p's follow paths whose target takes c -- same order (the order is the priority), MATCH paths left out -- and the part
-    of the blob in front of the lists (NF_STAGE_BYTES: what an LDS kernel stages) holds every other table."""
+def test_follow_lists_by_byte_class_are_the_follow_lists_filtered(golden_dir, monkeypatch):
+    """device_tables.h NF_OFF_CSTART / NF_OFF_CPATHS (round 5, opt-in LC_NFA_CLASS_LISTS=1: measured, no gain on configs[2]): for every
+    position p and byte class c the class list is exactly the sub-list of p's follow paths whose target takes c -- same order (the order
+    is the priority), MATCH paths left out -- and the part of the blob in front of the lists (NF_STAGE_BYTES: what an LDS kernel stages)
+    holds every other table.  Without the variable no lists are packed."""
     from loongcollector_amd import corpus
+    plain = B.GpuRegex(rb"(a|ab)*c", engine=B.LC_ENGINE_NFA).table(B.LC_TABLE_NFA_BLOB, np.uint32)
+    assert int(plain[24]) == 0 and int(plain[26]) == len(plain) * 4
+    monkeypatch.setenv("LC_NFA_CLASS_LISTS", "1")
     with open(os.path.join(golden_dir, "regex_golden.json")) as f:
         golden = json.load(f)
     patterns = [c["p"].encode("latin-1") for c in golden["cases"][::9]]
