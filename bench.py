@@ -465,9 +465,17 @@ def end_to_end(rx, pattern, keys, data, off, length, exp_caps, dev, thread_count
             return EventGroup.from_lines(data, off[lo:lo + group_lines], length[lo:lo + group_lines])
 
         seen = []
+        counted = set()
 
         def work(tid, g):
-            seen.append(colp.parse_columnar_count(g))
+            # (the first group of every thread is counted -- events, parsed events -- through numpy views of the table; the others are
+            # parse + free only: the conversions cost 60-80 us per group under the GIL, and from 16 threads on they, not the library,
+            # were what this leg measured: round 4's "columnar dips past 16 threads")
+            if tid not in counted:
+                counted.add(tid)
+                seen.append(colp.parse_columnar_count(g))
+            else:
+                colp.parse_columnar_discard(g)
 
         dt = _run_threads(t, per_thread, mk, work)
         if any(n != group_lines or ok != group_lines for n, ok, _ in seen):
