@@ -1586,6 +1586,10 @@ namespace {
 // the merged batch of `jobs` (one or more groups) on the calling thread's stream; fills pattern / firstSrc / extraRows of every job
 int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
                      const std::vector<GrokDeviceState::HostJob*>& jobs) {
+    static const bool traceHost = getenv("LC_GROK_TRACE") != nullptr;
+    const auto th0 = std::chrono::steady_clock::now();
+    auto hostMs = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count(); };
+    double tGather = 0, tMatch = 0, tExtra = 0;
     int devNo = 0;
     {
         const int rcDev = lcHostEntryDevice(&devNo);
@@ -1634,6 +1638,7 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
     int32_t* hFirst = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(H.hOut.p) + alignUp(size_t(n) * 4, 256));
     const uint8_t* dIn = static_cast<const uint8_t*>(H.dIn.p);
     HIP_TRY(hipMemcpyAsync(H.dIn.p, hIn, inBytes, hipMemcpyHostToDevice, H.stream));
+    tGather = hostMs();
     uint32_t nExtra = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(H.dExtra.ensure(size_t(extraCap) * (row + 2) * 4));
@@ -1664,6 +1669,7 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
         }
         break;
     }
+    tMatch = hostMs();
     const size_t w = row + 2;
     std::vector<uint32_t> idx(nExtra);
     const int32_t* raw = nullptr;
@@ -1693,6 +1699,10 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
         }
         base += j->n;
     }
+    tExtra = hostMs();
+    if (traceHost)
+        fprintf(stderr, "grok host batch: %u values %zu bytes | gather + H2D queued %.3f ms, device match %.3f ms, extra rows + hand-out %.3f ms\n", n, bytes,
+                tGather, tMatch - tGather, tExtra - tMatch);
     return LC_OK;
 }
 }  // namespace

