@@ -9,6 +9,8 @@
 #include "spdlog/spdlog.h"
 
 namespace Json {
+const Value& Value::operator[](const char*) const { return *this; }   // (CommonParserOptions::Init reads config["SourceKey"]: compiled, never called)
+std::string Value::asString() const { return std::string(); }
 Value::Value(ValueType) {}
 Value::Value(Int64) {}
 Value::Value(const std::string&) {}
@@ -34,4 +36,11 @@ extern const std::string DEFAULT_TRACE_TAG_TRACE_STATE = "traceState";
 extern const std::string DEFAULT_TRACE_TAG_TIMESTAMP = "timestamp";
 extern const std::string DEFAULT_TRACE_TAG_ATTRIBUTES = "attributes";
 extern const std::string DEFAULT_TRACE_TAG_SPAN_EVENT_NAME = "name";
+}  // namespace logtail
+
+// core/plugin/processor/inner/ProcessorParseContainerLogNative.cpp:41-42 -- the values come from that file at build time (Makefile)
+#include "plugin/processor/inner/ProcessorParseContainerLogNative.h"
+namespace logtail {
+const std::string ProcessorParseContainerLogNative::containerTimeKey = LC_REF_CONTAINER_TIME_KEY;
+const std::string ProcessorParseContainerLogNative::containerSourceKey = LC_REF_CONTAINER_SOURCE_KEY;
 }  // namespace logtail

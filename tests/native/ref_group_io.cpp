@@ -117,3 +117,68 @@ std::string hdGroupToJson(const logtail::PipelineEventGroup& group) {
     }
     return lcjson::dump(root);
 }
+
+// ---- the parser plugins' source-key / erase policy: the REFERENCE's own CommonParserOptions (plugin/processor/CommonParserOptions.cpp,
+// compiled into oracle/_ref/libref_models.so) against the product's restatement (csrc/processor_parse_regex_gpu.cpp GpuCommonParserOptions),
+// on the same events of the reference's event model.  -> number of (option set, outcome, event shape, function) cases compared;
+// *mismatches = how many differed, `first` (optional) describes the first one.
+#include "../../loongcollector_amd/csrc/processor_parse_regex_gpu.hpp"
+#include "plugin/processor/CommonParserOptions.h"
+#include "plugin/processor/inner/ProcessorParseContainerLogNative.h"
+
+extern "C" int hd_policy_matrix_vs_reference(int* mismatches, char* first, size_t firstCap) {
+    using namespace logtail;
+    int cases = 0, bad = 0;
+    if (first && firstCap) first[0] = 0;
+    const std::string offsetKeyName = "__file_offset__";
+    const std::string& tKey = ProcessorParseContainerLogNative::containerTimeKey;
+    const std::string& sKey = ProcessorParseContainerLogNative::containerSourceKey;
+    const std::vector<std::vector<std::pair<std::string, std::string>>> shapes = {
+        {},
+        {{offsetKeyName, "123"}},
+        {{tKey, "2024-01-01T00:00:00Z"}, {sKey, "stdout"}},
+        {{sKey, "stderr"}, {tKey, "t"}},
+        {{"other", "x"}},
+        {{tKey, "t"}, {"other", "x"}},
+        {{offsetKeyName, "1"}, {"other", "x"}},
+        {{tKey, "t"}, {sKey, "stdout"}, {"third", "3"}},
+        {{"a", "1"}, {"b", "2"}},
+        {{"__file_offset__x", "1"}},
+    };
+    for (int bits = 0; bits < 16; ++bits) {
+        const bool keepFail = bits & 1, keepSucceed = bits & 2, copingRaw = bits & 4, success = bits & 8;
+        CommonParserOptions ref;
+        GpuCommonParserOptions mine;
+        ref.mKeepingSourceWhenParseFail = mine.mKeepingSourceWhenParseFail = keepFail;
+        ref.mKeepingSourceWhenParseSucceed = mine.mKeepingSourceWhenParseSucceed = keepSucceed;
+        ref.mCopingRawLog = mine.mCopingRawLog = copingRaw;
+        for (int withMeta = 0; withMeta < 2; ++withMeta)
+            for (size_t sh = 0; sh < shapes.size(); ++sh) {
+                PipelineEventGroup group(std::make_shared<SourceBuffer>());
+                if (withMeta) group.SetMetadata(EventGroupMetaKey::LOG_FILE_OFFSET_KEY, offsetKeyName);
+                LogEvent* ev = group.AddLogEvent();
+                for (const auto& kv : shapes[sh]) ev->SetContent(kv.first, kv.second);
+                const bool r[3] = {ref.ShouldAddSourceContent(success), ref.ShouldAddLegacyUnmatchedRawLog(success),
+                                   ref.ShouldEraseEvent(success, *ev, group.GetAllMetadata())};
+                const bool m[3] = {mine.ShouldAddSourceContent(success), mine.ShouldAddLegacyUnmatchedRawLog(success),
+                                   mine.ShouldEraseEvent(success, *ev, group.GetAllMetadata())};
+                for (int f = 0; f < 3; ++f) {
+                    ++cases;
+                    if (r[f] != m[f]) {
+                        if (!bad && first && firstCap)
+                            snprintf(first, firstCap, "options %d metadata %d shape %zu function %d: reference %d, product %d", bits, withMeta, sh, f,
+                                     int(r[f]), int(m[f]));
+                        ++bad;
+                    }
+                }
+            }
+    }
+    // the legacy key's name is the same constant
+    ++cases;
+    if (CommonParserOptions::legacyUnmatchedRawLogKey != GpuCommonParserOptions::legacyUnmatchedRawLogKey) {
+        if (!bad && first && firstCap) snprintf(first, firstCap, "legacyUnmatchedRawLogKey differs");
+        ++bad;
+    }
+    if (mismatches) *mismatches = bad;
+    return cases;
+}

@@ -336,3 +336,23 @@ def test_contents_container_in_the_arena_and_on_the_heap(double):
         pytest.skip("ArenaVector belongs to the stand-in event model")
     double.hd_contents_container_check.restype = ctypes.c_int
     assert double.hd_contents_container_check() == 0
+
+
+def test_source_key_and_erase_policy_against_the_reference_s_own_common_parser_options():
+    """Round 5 (late): core/plugin/processor/CommonParserOptions.cpp of the reference -- ShouldAddSourceContent,
+    ShouldAddLegacyUnmatchedRawLog, ShouldEraseEvent (:91-117) -- is compiled from where it lies into oracle/_ref/libref_models.so (the
+    two container keys' values read out of the reference's ProcessorParseContainerLogNative.cpp by the Makefile) and compared with the
+    product's restatement on the reference's own LogEvent: 16 option/outcome sets x with and without the file-offset metadata x ten
+    event shapes (empty, only the offset key, the container pair in both orders, one / two other keys, ...) x the three functions."""
+    if not os.path.isdir(REF):
+        pytest.skip("needs the reference tree (/root/reference)")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    L = ctypes.CDLL(_build_reference(out_dir))
+    L.hd_policy_matrix_vs_reference.restype = ctypes.c_int
+    L.hd_policy_matrix_vs_reference.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
+    bad = ctypes.c_int(-1)
+    first = ctypes.create_string_buffer(256)
+    cases = L.hd_policy_matrix_vs_reference(ctypes.byref(bad), first, 256)
+    assert cases == 16 * 2 * 10 * 3 + 1
+    assert bad.value == 0, first.value.decode()
