@@ -1,0 +1,188 @@
+// oracle/ref_processor/shims.cpp -- TEST INFRASTRUCTURE.  What the reference sources compiled into oracle/_ref/libref_processor.so
+// (Makefile: ProcessorParseRegexNative.cpp, CommonParserOptions.cpp, ParamExtractor.cpp, Processor.cpp, the constants) reference at link
+// time from parts of the agent that are not compiled here, in the smallest form that lets the processor run:
+//   * AppConfig: one process thread, parse alarms on;  ProcessorRunner::sThreadNo = 0
+//   * AlarmManager: SendAlarm RECORDS (type, level, message) -- the harness below hands them to the test;  no low-level logging
+//   * MetricsRecordRef::CreateCounter: a plain Counter, remembered by name for the harness
+//   * CollectionPipelineContext::GetProjectName / GetLogstoreName / GetRegion: empty strings
+//   * common/StringTools.cpp is NOT compiled (boost::split, boost::filesystem, regex_replace ...): the two functions of it the processor
+//     calls are restated here -- SplitString (:118-123) and BoostRegexMatch (:183-211), the latter over stubs/boost/regex.hpp, i.e. the
+//     oracle's matcher (oracle/bt_regex.c)
+// and the C harness tests/test_processor_host_double.py drives (refp_*).
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "app_config/AppConfig.h"
+#include "collection_pipeline/CollectionPipelineContext.h"
+#include "common/StringTools.h"
+#include "monitor/AlarmManager.h"
+#include "monitor/MetricManager.h"
+#include "plugin/processor/ProcessorParseRegexNative.h"
+#include "runner/ProcessorRunner.h"
+
+// tests/native/ref_group_io.cpp (fixture JSON <-> the reference's PipelineEventGroup), compiled into this library too
+bool hdGroupFromJson(logtail::PipelineEventGroup& group, const std::string& json, std::string* error);
+std::string hdGroupToJson(const logtail::PipelineEventGroup& group);
+
+namespace {
+struct Alarm {
+    int type, level;
+    std::string message;
+};
+std::mutex gMutex;
+std::vector<Alarm> gAlarms;
+std::map<std::string, logtail::CounterPtr> gCounters;  // by metric name: the counters of the processor created last
+const std::string kEmpty;
+}  // namespace
+
+namespace logtail {
+AppConfig::AppConfig() {
+    mProcessThreadCount = 1;
+    mLogParseAlarmFlag = true;
+}
+thread_local uint32_t ProcessorRunner::sThreadNo = 0;
+
+AlarmManager::AlarmManager() {}
+void AlarmManager::SendAlarm(const AlarmType& alarmType, const AlarmLevel& level, const std::string& message, const std::string&,
+                             const std::string&, const std::string&, const std::string&) {
+    std::lock_guard<std::mutex> g(gMutex);
+    gAlarms.push_back({int(alarmType), int(level), message});
+}
+bool AlarmManager::IsLowLevelAlarmValid() { return false; }
+
+MetricsRecordRef::~MetricsRecordRef() {}
+CounterPtr MetricsRecordRef::CreateCounter(const std::string& name) {
+    CounterPtr c = std::make_shared<Counter>(name);
+    std::lock_guard<std::mutex> g(gMutex);
+    gCounters[name] = c;
+    return c;
+}
+
+const std::string& CollectionPipelineContext::GetProjectName() const { return kEmpty; }
+const std::string& CollectionPipelineContext::GetLogstoreName() const { return kEmpty; }
+const std::string& CollectionPipelineContext::GetRegion() const { return kEmpty; }
+
+// common/StringTools.cpp:118-123 (boost::split on any character of delim; empty tokens kept)
+std::vector<std::string> SplitString(const std::string& str, const std::string& delim) {
+    std::vector<std::string> tokens;
+    size_t begin = 0;
+    for (size_t i = 0; i <= str.size(); ++i)
+        if (i == str.size() || delim.find(str[i]) != std::string::npos) {
+            tokens.push_back(str.substr(begin, i - begin));
+            begin = i + 1;
+        }
+    return tokens;
+}
+// common/StringTools.cpp:183-211
+bool BoostRegexMatch(const char* buffer, size_t length, const boost::regex& reg, std::string& exception, boost::match_results<const char*>& what,
+                     boost::match_flag_type flags) {
+    try {
+        if (boost::regex_match(buffer, buffer + length, what, reg, flags)) return true;
+        return false;
+    } catch (boost::regex_error& e) {
+        exception.append("regex_error code is ");
+        exception.append(e.what());
+        return false;
+    } catch (std::exception& e) {
+        exception.append("exception message: ");
+        exception.append(e.what());
+        return false;
+    } catch (...) {
+        exception.append("unknown exception");
+        return false;
+    }
+}
+}  // namespace logtail
+
+// ------------------------------------------------------------------------------------------------ harness
+namespace {
+struct RefProcessor {
+    logtail::CollectionPipelineContext ctx;
+    logtail::ProcessorParseRegexNative proc;
+    std::map<std::string, logtail::CounterPtr> counters;
+};
+char* dup(const std::string& s) {
+    char* p = static_cast<char*>(std::malloc(s.size() + 1));
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+}  // namespace
+
+extern "C" {
+// ProcessorParseRegexNative on a context of its own: SetContext + Init(config).  nullptr + err when Init returns false.
+void* refp_create(const char* config_json, char* err, size_t errcap) {
+    auto p = std::make_unique<RefProcessor>();
+    p->ctx.SetConfigName("test_config");
+    p->proc.SetContext(p->ctx);
+    Json::Value config;
+    try {
+        config = Json::Value::fromText(config_json);
+    } catch (const std::exception& e) {
+        if (err && errcap) snprintf(err, errcap, "%s", e.what());
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> g(gMutex);
+        gCounters.clear();
+    }
+    if (!p->proc.Init(config)) {
+        if (err && errcap) {
+            std::lock_guard<std::mutex> g(gMutex);
+            snprintf(err, errcap, "%s", gAlarms.empty() ? "Init returned false" : gAlarms.back().message.c_str());
+        }
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(gMutex);
+    p->counters = gCounters;
+    return p.release();
+}
+void refp_destroy(void* h) { delete static_cast<RefProcessor*>(h); }
+// Process(group) through the public interface (Processor::Process(std::vector<PipelineEventGroup>&)) -> the group as fixture JSON
+char* refp_process_json(void* h, const char* group_json, char* err, size_t errcap) {
+    auto* p = static_cast<RefProcessor*>(h);
+    std::vector<logtail::PipelineEventGroup> groups;
+    groups.emplace_back(std::make_shared<logtail::SourceBuffer>());
+    std::string error;
+    if (!hdGroupFromJson(groups[0], group_json, &error)) {
+        if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    static_cast<logtail::Processor&>(p->proc).Process(groups);
+    return dup(hdGroupToJson(groups[0]));
+}
+// discarded, out_failed, out_key_not_found, out_successful
+void refp_counters(void* h, uint64_t out[4]) {
+    auto* p = static_cast<RefProcessor*>(h);
+    const std::string* names[4] = {&logtail::METRIC_PLUGIN_DISCARDED_EVENTS_TOTAL, &logtail::METRIC_PLUGIN_OUT_FAILED_EVENTS_TOTAL,
+                                   &logtail::METRIC_PLUGIN_OUT_KEY_NOT_FOUND_EVENTS_TOTAL, &logtail::METRIC_PLUGIN_OUT_SUCCESSFUL_EVENTS_TOTAL};
+    for (int i = 0; i < 4; ++i) {
+        auto it = p->counters.find(*names[i]);
+        out[i] = it == p->counters.end() ? 0 : it->second->GetValue();
+    }
+}
+// the alarms recorded since the last call: [[type, level, message], ...]
+char* refp_take_alarms() {
+    std::vector<Alarm> taken;
+    {
+        std::lock_guard<std::mutex> g(gMutex);
+        taken.swap(gAlarms);
+    }
+    lcjson::Value arr = lcjson::Value::makeArray();
+    for (const Alarm& a : taken) {
+        lcjson::Value e = lcjson::Value::makeArray();
+        e.arr.push_back(lcjson::Value::makeInt(a.type));
+        e.arr.push_back(lcjson::Value::makeInt(a.level));
+        e.arr.push_back(lcjson::Value::makeString(a.message));
+        arr.arr.push_back(std::move(e));
+    }
+    return dup(lcjson::dump(arr));
+}
+int refp_regex_match_alarm_type() { return int(logtail::REGEX_MATCH_ALARM); }
+void refp_free(char* p) { std::free(p); }
+}

@@ -118,6 +118,7 @@ std::string hdGroupToJson(const logtail::PipelineEventGroup& group) {
     return lcjson::dump(root);
 }
 
+#ifndef LC_REF_GROUP_IO_ONLY  // (oracle/ref_processor builds this file for the fixture reader / writer alone)
 // ---- the parser plugins' source-key / erase policy: the REFERENCE's own CommonParserOptions (plugin/processor/CommonParserOptions.cpp,
 // compiled into oracle/_ref/libref_models.so) against the product's restatement (csrc/processor_parse_regex_gpu.cpp GpuCommonParserOptions),
 // on the same events of the reference's event model.  -> number of (option set, outcome, event shape, function) cases compared;
@@ -176,9 +177,12 @@ extern "C" int hd_policy_matrix_vs_reference(int* mismatches, char* first, size_
     // the legacy key's name is the same constant
     ++cases;
     if (CommonParserOptions::legacyUnmatchedRawLogKey != GpuCommonParserOptions::legacyUnmatchedRawLogKey) {
-        if (!bad && first && firstCap) snprintf(first, firstCap, "legacyUnmatchedRawLogKey differs");
+        if (!bad && first && firstCap)
+            snprintf(first, firstCap, "legacyUnmatchedRawLogKey differs: reference '%s', product '%s'", CommonParserOptions::legacyUnmatchedRawLogKey.c_str(),
+                     GpuCommonParserOptions::legacyUnmatchedRawLogKey.c_str());
         ++bad;
     }
     if (mismatches) *mismatches = bad;
     return cases;
 }
+#endif  // LC_REF_GROUP_IO_ONLY

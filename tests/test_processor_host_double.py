@@ -145,7 +145,15 @@ class HostProcessor:
             text = ctypes.string_at(p)
         finally:
             self.L.hd_free(p)
-        return [(int(l.split(b"\t", 1)[0]), l.split(b"\t", 1)[1]) for l in text.split(b"\n") if l]
+        # ("kind<TAB>message<NL>" per alarm; a message may hold line feeds of its own: a line that does not begin "digits<TAB>" goes on)
+        import re
+        out = []
+        for l in text.split(b"\n")[:-1] if text.endswith(b"\n") else text.split(b"\n"):
+            if re.match(rb"^\d+\t", l):
+                out.append((int(l.split(b"\t", 1)[0]), l.split(b"\t", 1)[1]))
+            elif out:
+                out[-1] = (out[-1][0], out[-1][1] + b"\n" + l)
+        return out
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -356,3 +364,128 @@ def test_source_key_and_erase_policy_against_the_reference_s_own_common_parser_o
     cases = L.hd_policy_matrix_vs_reference(ctypes.byref(bad), first, 256)
     assert cases == 16 * 2 * 10 * 3 + 1
     assert bad.value == 0, first.value.decode()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The REFERENCE's own processor_parse_regex_native, compiled from /root/reference (oracle/ref_processor: ProcessorParseRegexNative.cpp,
+# CommonParserOptions.cpp, ParamExtractor.cpp, Processor.cpp against the reference's real headers; boost::regex answered by the
+# oracle's matcher, the agent around the plugin by shims) -- and the product's host code beside it, group by group.
+class RefProcessor:
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_models")])
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_processor")])
+            L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_processor.so"))
+            vp, cp = ctypes.c_void_p, ctypes.c_char_p
+            L.refp_create.restype = vp
+            L.refp_create.argtypes = [cp, cp, ctypes.c_size_t]
+            L.refp_destroy.argtypes = [vp]
+            L.refp_process_json.restype = vp
+            L.refp_process_json.argtypes = [vp, cp, cp, ctypes.c_size_t]
+            L.refp_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+            L.refp_take_alarms.restype = vp
+            L.refp_free.argtypes = [vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, config):
+        self.L = self.lib()
+        err = ctypes.create_string_buffer(512)
+        self.h = self.L.refp_create(json.dumps(config).encode(), err, 512)
+        self.take_alarms()          # (a failed Init reports through the alarm manager: not part of a group's alarms)
+        if not self.h:
+            raise ValueError(err.value.decode())
+
+    def process(self, fixture):
+        err = ctypes.create_string_buffer(512)
+        p = self.L.refp_process_json(self.h, json.dumps(fixture).encode(), err, 512)
+        assert p, err.value
+        try:
+            d = json.loads(ctypes.string_at(p).decode(), object_pairs_hook=list)
+        finally:
+            self.L.refp_free(p)
+        return [list(dict(ev).get("contents", [])) if dict(ev).get("type") == 1 else None for ev in dict(d).get("events", [])]
+
+    def counters(self):
+        c = (ctypes.c_uint64 * 4)()
+        self.L.refp_counters(self.h, c)
+        return dict(zip(["discarded", "out_failed", "out_key_not_found", "out_successful"], [int(x) for x in c]))
+
+    def take_alarms(self):
+        p = self.L.refp_take_alarms()
+        try:
+            return [(t, m.encode("latin-1")) for t, _, m in json.loads(ctypes.string_at(p).decode("latin-1"))]
+        finally:
+            self.L.refp_free(p)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.refp_destroy(self.h)
+            self.h = None
+
+
+def _same_as_reference(double, cfg, fixture, what):
+    ref, mine = RefProcessor(cfg), HostProcessor(double, cfg)
+    double.hd_want_alarms(mine.h)
+    want, got = ref.process(fixture), mine.process(fixture)
+    assert got == want, (what, cfg)
+    c = mine.counters()
+    assert {k: c[k] for k in ("discarded", "out_failed", "out_key_not_found", "out_successful")} == ref.counters(), (what, cfg)
+    assert [m for _, m in mine.alarms()] == [m for _, m in ref.take_alarms()], (what, cfg)
+
+
+def test_the_reference_s_own_processor_beside_the_product(double, golden_dir):
+    """oracle/_ref/libref_processor.so is the reference's ProcessorParseRegexNative -- Init, Process, ProcessEvent, RegexLogLineParser,
+    AddLog, CommonParserOptions and the parameter readers -- compiled from its sources; only the regex match itself is answered by the
+    oracle (on both sides: the product's test double asks the oracle too).  Same events, contents, order, counters and alarm texts on:
+    every case of the reference's unit test; the option matrix (2 x 2 x 2 x 4 option values x 5 key lists) on random event shapes
+    incl. non-log events, missing source keys, pre-existing keys, the file-offset key and the container pair; the alarm cases; and
+    the configs either side must refuse."""
+    if not os.path.isdir(REF):
+        pytest.skip("needs the reference tree (/root/reference): its processor is compiled from there")
+    with open(os.path.join(golden_dir, "reference_unittest_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    ran = 0
+    for case in cases:
+        if case["events"]:
+            _same_as_reference(double, case["config"], {"events": case["events"]}, case["name"])
+            ran += 1
+    assert ran >= 7
+    rng = np.random.default_rng(29)
+    lines = ["v1\tv2", "value3\tvalue4 tail", "nomatch", "", "a\tb\nc", "x\t", "\ty", "k\tv"]
+    combos = 0
+    for keep_fail, keep_ok, coping, renamed, keys in itertools.product(
+            [False, True], [False, True], [False, True], ["", "rawLog", "content", "key2"],
+            [["key1", "key2"], ["content", "key2"], ["key1", "key2", "key3"], ["rawLog", "x"], ["key1", "key1"]]):
+        cfg = {"SourceKey": "content", "Regex": r"(\w+)\t(\w*).*", "Keys": keys, "KeepingSourceWhenParseFail": keep_fail,
+               "KeepingSourceWhenParseSucceed": keep_ok, "CopingRawLog": coping, "RenamedSourceKey": renamed}
+        events, _ = _matrix_group(rng, lines)
+        for meta in ({"log.file.offset": "__file_offset__"}, {}):
+            _same_as_reference(double, cfg, {"events": events, "metadata": meta}, "matrix")
+        combos += 1
+    assert combos == 160
+    # whole-line mode, the ["k1,k2"] legacy form of Keys, an optional group that does not take part, an empty group
+    for cfg, values in (({"SourceKey": "content", "Regex": "(.*)", "Keys": ["all"]}, ["a b", "", "x\ny"]),
+                        ({"SourceKey": "content", "Regex": "(.*)", "Keys": []}, ["whole"]),
+                        ({"SourceKey": "content", "Regex": r"(\w+) (\w+)", "Keys": ["k1,k2"]}, ["a b", "ab"]),
+                        ({"SourceKey": "content", "Regex": r"(\d+)(?: (\w+))?", "Keys": ["num", "word"]}, ["12", "12 ab", "x"]),
+                        ({"SourceKey": "content", "Regex": r"(\w*)-(\w*)", "Keys": ["l", "r"], "KeepingSourceWhenParseSucceed": True}, ["-", "a-", "-b"])):
+        if not cfg["Keys"]:
+            with pytest.raises(ValueError):
+                RefProcessor(cfg)
+            with pytest.raises(ValueError):
+                HostProcessor(double, cfg)
+            continue
+        _same_as_reference(double, cfg, {"events": [{"contents": {"content": v}, "timestamp": 1, "type": 1} for v in values]}, "shapes")
+    # what Init refuses, it refuses on both sides
+    for bad in ({"Regex": "a", "Keys": ["k"]}, {"SourceKey": "content", "Keys": ["k"]}, {"SourceKey": "content", "Regex": "(", "Keys": ["k"]},
+                {"SourceKey": "content", "Regex": "a"}, {"SourceKey": "", "Regex": "a", "Keys": ["k"]}, {"SourceKey": 1, "Regex": "a", "Keys": ["k"]},
+                {"SourceKey": "content", "Regex": "a", "Keys": "k"}, {"SourceKey": "content", "Regex": "a", "Keys": [1]}):
+        with pytest.raises(ValueError):
+            RefProcessor(bad)
+        with pytest.raises(ValueError):
+            HostProcessor(double, bad)
