@@ -23,7 +23,10 @@
 #include "common/StringTools.h"
 #include "monitor/AlarmManager.h"
 #include "monitor/MetricManager.h"
+#include "plugin/processor/ProcessorFilterNative.h"
 #include "plugin/processor/ProcessorParseRegexNative.h"
+#include "plugin/processor/inner/ProcessorSplitLogStringNative.h"
+#include "plugin/processor/inner/ProcessorSplitMultilineLogStringNative.h"
 #include "runner/ProcessorRunner.h"
 
 // tests/native/ref_group_io.cpp (fixture JSON <-> the reference's PipelineEventGroup), compiled into this library too
@@ -98,13 +101,39 @@ bool BoostRegexMatch(const char* buffer, size_t length, const boost::regex& reg,
         return false;
     }
 }
+// common/StringTools.cpp:213-236 (the filter's leaves) and :263-288 (the multiline processor's start / continue / end patterns:
+// regex_search with match_continuous -- the match must begin at the buffer's first byte); :30-34
+bool BoostRegexMatch(const char* buffer, size_t size, const boost::regex& reg, std::string& exception) {
+    try {
+        return boost::regex_match(buffer, buffer + size, reg);
+    } catch (std::exception& e) {
+        exception.append("exception message: ");
+        exception.append(e.what());
+        return false;
+    }
+}
+bool BoostRegexSearch(const char* buffer, size_t size, const boost::regex& reg, std::string& exception) {
+    try {
+        boost::match_results<const char*> what;
+        return boost::regex_search(buffer, buffer + size, what, reg, boost::match_continuous);
+    } catch (std::exception& e) {
+        exception.append("exception message: ");
+        exception.append(e.what());
+        return false;
+    }
+}
+std::string ToLowerCaseString(const std::string& orig) {
+    std::string copy = orig;
+    for (char& c : copy) c = char(::tolower(static_cast<unsigned char>(c)));
+    return copy;
+}
 }  // namespace logtail
 
 // ------------------------------------------------------------------------------------------------ harness
 namespace {
 struct RefProcessor {
     logtail::CollectionPipelineContext ctx;
-    logtail::ProcessorParseRegexNative proc;
+    std::unique_ptr<logtail::Processor> proc;
     std::map<std::string, logtail::CounterPtr> counters;
 };
 char* dup(const std::string& s) {
@@ -116,10 +145,21 @@ char* dup(const std::string& s) {
 
 extern "C" {
 // ProcessorParseRegexNative on a context of its own: SetContext + Init(config).  nullptr + err when Init returns false.
-void* refp_create(const char* config_json, char* err, size_t errcap) {
+// kind: the reference plugin's name -- processor_parse_regex_native, processor_split_string_native,
+// processor_split_multiline_log_string_native, processor_filter_regex_native
+void* refp_create_kind(const char* kind, const char* config_json, char* err, size_t errcap) {
     auto p = std::make_unique<RefProcessor>();
+    const std::string k = kind ? kind : "";
+    if (k == logtail::ProcessorParseRegexNative::sName) p->proc = std::make_unique<logtail::ProcessorParseRegexNative>();
+    else if (k == logtail::ProcessorSplitLogStringNative::sName) p->proc = std::make_unique<logtail::ProcessorSplitLogStringNative>();
+    else if (k == logtail::ProcessorSplitMultilineLogStringNative::sName) p->proc = std::make_unique<logtail::ProcessorSplitMultilineLogStringNative>();
+    else if (k == logtail::ProcessorFilterNative::sName) p->proc = std::make_unique<logtail::ProcessorFilterNative>();
+    else {
+        if (err && errcap) snprintf(err, errcap, "unknown processor %s", k.c_str());
+        return nullptr;
+    }
     p->ctx.SetConfigName("test_config");
-    p->proc.SetContext(p->ctx);
+    p->proc->SetContext(p->ctx);
     Json::Value config;
     try {
         config = Json::Value::fromText(config_json);
@@ -131,7 +171,7 @@ void* refp_create(const char* config_json, char* err, size_t errcap) {
         std::lock_guard<std::mutex> g(gMutex);
         gCounters.clear();
     }
-    if (!p->proc.Init(config)) {
+    if (!p->proc->Init(config)) {
         if (err && errcap) {
             std::lock_guard<std::mutex> g(gMutex);
             snprintf(err, errcap, "%s", gAlarms.empty() ? "Init returned false" : gAlarms.back().message.c_str());
@@ -141,6 +181,9 @@ void* refp_create(const char* config_json, char* err, size_t errcap) {
     std::lock_guard<std::mutex> g(gMutex);
     p->counters = gCounters;
     return p.release();
+}
+void* refp_create(const char* config_json, char* err, size_t errcap) {
+    return refp_create_kind(logtail::ProcessorParseRegexNative::sName.c_str(), config_json, err, errcap);
 }
 void refp_destroy(void* h) { delete static_cast<RefProcessor*>(h); }
 // Process(group) through the public interface (Processor::Process(std::vector<PipelineEventGroup>&)) -> the group as fixture JSON
@@ -153,7 +196,7 @@ char* refp_process_json(void* h, const char* group_json, char* err, size_t errca
         if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
         return nullptr;
     }
-    static_cast<logtail::Processor&>(p->proc).Process(groups);
+    p->proc->Process(groups);
     return dup(hdGroupToJson(groups[0]));
 }
 // discarded, out_failed, out_key_not_found, out_successful
@@ -182,6 +225,13 @@ char* refp_take_alarms() {
         arr.arr.push_back(std::move(e));
     }
     return dup(lcjson::dump(arr));
+}
+// every counter the processor created, by metric name: {"name": value, ...}
+char* refp_counters_json(void* h) {
+    auto* p = static_cast<RefProcessor*>(h);
+    lcjson::Value obj = lcjson::Value::makeObject();
+    for (const auto& kv : p->counters) obj.set(kv.first, lcjson::Value::makeInt(int64_t(kv.second->GetValue())));
+    return dup(lcjson::dump(obj));
 }
 int refp_regex_match_alarm_type() { return int(logtail::REGEX_MATCH_ALARM); }
 void refp_free(char* p) { std::free(p); }

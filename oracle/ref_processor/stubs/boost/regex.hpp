@@ -12,6 +12,12 @@
 
 #include "bt_regex.h"  // oracle/
 
+// (boost/config: ProcessorFilterNative.cpp uses the branch hints)
+#ifndef BOOST_LIKELY
+#define BOOST_LIKELY(x) __builtin_expect(!!(x), 1)
+#define BOOST_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+
 namespace boost {
 typedef unsigned match_flag_type;
 constexpr match_flag_type match_default = 0, match_continuous = 1;
@@ -74,6 +80,37 @@ inline bool regex_match(const char* first, const char* last, match_results<const
             s.matched = true;
         } else {
             s.first = s.second = last;
+        }
+    }
+    return true;
+}
+// whole-sequence match without sub-matches
+inline bool regex_match(const char* first, const char* last, const regex& re, match_flag_type flags = match_default) {
+    match_results<const char*> what;
+    return regex_match(first, last, what, re, flags);
+}
+// boost::regex_search(first, last, what, re, match_continuous): the match must begin at `first` (what the multiline processor asks);
+// without the flag: leftmost match anywhere
+inline bool regex_search(const char* first, const char* last, match_results<const char*>& what, const regex& re,
+                         match_flag_type flags = match_default) {
+    what.mSubs.clear();
+    if (!re.prog()) return false;
+    const int groups = orx_mark_count(re.prog());
+    std::vector<int32_t> caps(size_t(2) * size_t(groups + 1), -1);
+    const uint8_t* s = reinterpret_cast<const uint8_t*>(first);
+    const int r = (flags & match_continuous) ? orx_prefixmatch(re.prog(), s, size_t(last - first), caps.data())
+                                             : orx_search(re.prog(), s, size_t(last - first), 0, caps.data());
+    if (r < 0) throw std::runtime_error("The complexity of matching the regular expression exceeded predefined bounds.");
+    if (r == 0) return false;
+    what.mSubs.resize(size_t(groups + 1));
+    for (int g = 0; g <= groups; ++g) {
+        sub_match<const char*>& m = what.mSubs[size_t(g)];
+        if (caps[size_t(2 * g)] >= 0) {
+            m.first = first + caps[size_t(2 * g)];
+            m.second = first + caps[size_t(2 * g + 1)];
+            m.matched = true;
+        } else {
+            m.first = m.second = last;
         }
     }
     return true;
