@@ -25,6 +25,7 @@
 #include "monitor/MetricManager.h"
 #include "plugin/processor/ProcessorFilterNative.h"
 #include "plugin/processor/ProcessorParseRegexNative.h"
+#include "plugin/processor/inner/ProcessorMergeMultilineLogNative.h"
 #include "plugin/processor/inner/ProcessorSplitLogStringNative.h"
 #include "plugin/processor/inner/ProcessorSplitMultilineLogStringNative.h"
 #include "runner/ProcessorRunner.h"
@@ -146,7 +147,7 @@ char* dup(const std::string& s) {
 extern "C" {
 // ProcessorParseRegexNative on a context of its own: SetContext + Init(config).  nullptr + err when Init returns false.
 // kind: the reference plugin's name -- processor_parse_regex_native, processor_split_string_native,
-// processor_split_multiline_log_string_native, processor_filter_regex_native
+// processor_split_multiline_log_string_native, processor_filter_regex_native, processor_merge_multiline_log_native
 void* refp_create_kind(const char* kind, const char* config_json, char* err, size_t errcap) {
     auto p = std::make_unique<RefProcessor>();
     const std::string k = kind ? kind : "";
@@ -154,6 +155,7 @@ void* refp_create_kind(const char* kind, const char* config_json, char* err, siz
     else if (k == logtail::ProcessorSplitLogStringNative::sName) p->proc = std::make_unique<logtail::ProcessorSplitLogStringNative>();
     else if (k == logtail::ProcessorSplitMultilineLogStringNative::sName) p->proc = std::make_unique<logtail::ProcessorSplitMultilineLogStringNative>();
     else if (k == logtail::ProcessorFilterNative::sName) p->proc = std::make_unique<logtail::ProcessorFilterNative>();
+    else if (k == logtail::ProcessorMergeMultilineLogNative::sName) p->proc = std::make_unique<logtail::ProcessorMergeMultilineLogNative>();
     else {
         if (err && errcap) snprintf(err, errcap, "unknown processor %s", k.c_str());
         return nullptr;
@@ -197,6 +199,20 @@ char* refp_process_json(void* h, const char* group_json, char* err, size_t errca
         return nullptr;
     }
     p->proc->Process(groups);
+    return dup(hdGroupToJson(groups[0]));
+}
+// the same group through two processors, one after the other (the line splitter, then the merge processor: the merge works on events
+// that lie back to back in the group's buffer, which is what the splitter leaves)
+char* refp_process_chain_json(void* h1, void* h2, const char* group_json, char* err, size_t errcap) {
+    std::vector<logtail::PipelineEventGroup> groups;
+    groups.emplace_back(std::make_shared<logtail::SourceBuffer>());
+    std::string error;
+    if (!hdGroupFromJson(groups[0], group_json, &error)) {
+        if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    static_cast<RefProcessor*>(h1)->proc->Process(groups);
+    static_cast<RefProcessor*>(h2)->proc->Process(groups);
     return dup(hdGroupToJson(groups[0]));
 }
 // discarded, out_failed, out_key_not_found, out_successful

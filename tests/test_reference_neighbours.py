@@ -209,3 +209,34 @@ def test_regex_filter_on_the_reference_unit_test_vectors_and_random_groups(golde
         got = p.process({"events": [{"contents": [[k, v] for k, v in e.items()], "timestamp": 1, "type": 1} for e in events]})
         assert 0 < len(want) < len(events)
         assert [dict(ev["contents"]) for ev in got] == [{k: v.decode("utf-8") for k, v in e.items()} for e in want], config
+
+
+def test_merge_processor_reproduces_the_imported_unit_test_cases(golden_dir):
+    """ProcessorMergeMultilineLogNative.cpp (MergeType regex) behind the reference's own line splitter, on the cases imported from its
+    unit test into tests/golden/multiline_merge_vectors.json -- the vectors the product's merge processor is compared with on the GPU
+    are what the reference's code produces."""
+    L = RefPlugin.lib()
+    L.refp_process_chain_json.restype = ctypes.c_void_p
+    L.refp_process_chain_json.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    with open(os.path.join(golden_dir, "multiline_merge_vectors.json"), encoding="utf-8") as f:
+        mv = json.load(f)
+    split = RefPlugin("processor_split_string_native", {})
+    ran = 0
+    for c in mv["cases"]:
+        if not c["in"]:
+            continue
+        value = "\n".join(mv["lines"][t] for t in c["in"])
+        if not value:
+            continue
+        merge = RefPlugin("processor_merge_multiline_log_native", dict(c["config"], MergeType="regex"))
+        err = ctypes.create_string_buffer(512)
+        p = L.refp_process_chain_json(split.h, merge.h, json.dumps(_one_event(value)).encode(), err, 512)
+        assert p, err.value
+        try:
+            d = json.loads(ctypes.string_at(p).decode("utf-8"), object_pairs_hook=list)
+        finally:
+            L.refp_free(p)
+        got = [dict(dict(ev)["contents"])["content"] for ev in dict(d or []).get("events", [])]
+        assert got == ["\n".join(mv["lines"][t] for t in ev) for ev in c["out"]], c["cite"]
+        ran += 1
+    assert ran >= 40
