@@ -109,6 +109,14 @@ int lc_multiline_counters(const lc_multiline_t* m, uint64_t counters[3]);
 typedef struct lc_merge_multiline lc_merge_multiline_t;
 int lc_merge_multiline_create(const char* config_json, size_t config_len, lc_merge_multiline_t** out, char* err, size_t errcap);
 void lc_merge_multiline_free(lc_merge_multiline_t* p);
+/* "regex": the patterns the processor matches with (bit 0 start, bit 1 continue, bit 2 end; 0 in flag mode), and the warnings of its
+ * Init.  NOT the splitter's rule: this processor matches with MultilineOptions' own regexes (Get*PatternReg(), :219-224,244-262), i.e.
+ * with what ParseRegex (MultilineOptions.cpp:250-266) leaves of a pattern after stripping one trailing '$' and all trailing ".*" --
+ * "END$" accepts a line that merely begins with END, ".*" is no pattern at all -- and without ContinuePattern when all three are given
+ * (:185-200: a warning, listed by lc_merge_multiline_warnings).  ProcessorSplitMultilineLogStringNative compiles the strings as
+ * written (:66-76) and keeps all three; the two processors differ on such configs in the reference, and they differ here. */
+int lc_merge_multiline_patterns(const lc_merge_multiline_t* p);
+const char* lc_merge_multiline_warnings(const lc_merge_multiline_t* p);
 int lc_merge_multiline_process_group(lc_merge_multiline_t* p, void* pipeline_event_group);
 int lc_merge_multiline_counters(const lc_merge_multiline_t* p, uint64_t counters[2]);
 

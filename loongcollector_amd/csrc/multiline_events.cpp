@@ -159,7 +159,8 @@ extern "C" int lc_merge_multiline_create(const char* config_json, size_t config_
         if (mt->str == "flag") p->byFlag = true;
         else if (mt->str == "regex") {
             char buf[512];
-            const int rc = lc_multiline_create(config_json, config_len, &p->ml, buf, sizeof buf);
+            // the merge processor matches with MultilineOptions' own regexes, not with the strings as written (:219-224)
+            const int rc = lcMultilineCreateForMerge(config_json, config_len, &p->ml, buf, sizeof buf);
             if (rc != LC_OK) throw std::runtime_error(buf);
             if (const lcjson::Value* v = cfg.find("IgnoringUnmatchWarning"))
                 if (v->isBool()) p->ignoringUnmatchWarning = v->b;
@@ -173,6 +174,8 @@ extern "C" int lc_merge_multiline_create(const char* config_json, size_t config_
     return LC_OK;
 }
 extern "C" void lc_merge_multiline_free(lc_merge_multiline_t* p) { delete p; }
+extern "C" int lc_merge_multiline_patterns(const lc_merge_multiline_t* p) { return p && p->ml ? lc_multiline_patterns(p->ml) : 0; }
+extern "C" const char* lc_merge_multiline_warnings(const lc_merge_multiline_t* p) { return p && p->ml ? lc_multiline_warnings(p->ml) : ""; }
 extern "C" int lc_merge_multiline_counters(const lc_merge_multiline_t* p, uint64_t counters[2]) {
     if (!p || !counters) return LC_ERR_ARG;
     counters[0] = p->mergedEventsTotal;
@@ -285,6 +288,12 @@ int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
     if (rc != LC_OK) return rc;
 
     size_t newSize = 0, prevEvent = 0;
+    // Only an end pattern: the walk never leaves the partial state and a closed log restarts `begin` at cur + 1 (:283), which is the
+    // next EVENT, not the next item -- when that event has no contents (:190 skips it without touching `begin`), the log that follows
+    // is merged into its first item but the event moved to the output is sourceEvents[begin], the one without contents (:279).  Such
+    // events do not come out of the line splitter; the reference's behaviour is kept as it is.
+    const bool endOnly = !ml.start && !ml.cont && ml.end;
+    size_t endOnlyBegin = 0;
     std::vector<LogEvent*> events;
     auto handleUnmatch = [&](size_t b, size_t e) {  // HandleUnmatchLogs :360-392 (without the alarms)
         p.unmatchedEventsTotal += e - b + 1;
@@ -297,18 +306,20 @@ int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
             events.clear();
             for (uint32_t k = first; k < first + cnt; ++k) events.push_back(&sourceEvents[itemEvent[k]].Cast<LogEvent>());
             mergeEvents(p, events, true);
-            sourceEvents[newSize++] = std::move(sourceEvents[itemEvent[first]]);
+            sourceEvents[newSize++] = std::move(sourceEvents[endOnly ? endOnlyBegin : size_t(itemEvent[first])]);
+            endOnlyBegin = size_t(itemEvent[first + cnt - 1]) + 1;
             continue;
         }
         size_t b = itemEvent[first], e = b;
         if (recs[r].matched & LC_ML_RUN) b = prevEvent + 1;  // one [begin, cur] call: the empty events in between go with it
+        else if (endOnly) b = endOnlyBegin;                  // (the flush runs from `begin`, :321)
         if ((recs[r].matched & LC_ML_LAST) && r + 1 == recs.size()) e = sourceEvents.size() - 1;  // the flush runs to the group's end (:321)
         handleUnmatch(b, e);
         prevEvent = e;
     }
     if (truncated) {  // the rest passes through, from the log under construction on (`if (events.empty()) begin = cur`)
         const bool open = counts[ML_CNT_FINAL_PARTIAL] && counts[ML_CNT_FINAL_START] < n;
-        for (size_t i = open ? itemEvent[counts[ML_CNT_FINAL_START]] : stopAt; i < sourceEvents.size(); ++i)
+        for (size_t i = open ? (endOnly ? endOnlyBegin : size_t(itemEvent[counts[ML_CNT_FINAL_START]])) : stopAt; i < sourceEvents.size(); ++i)
             sourceEvents[newSize++] = std::move(sourceEvents[i]);
     } else if (counts[ML_CNT_FINAL_PARTIAL] && counts[ML_CNT_FINAL_START] >= n) {
         // only an end pattern, and the last item closed a log (begin = cur + 1): events behind it -- empty ones -- are what

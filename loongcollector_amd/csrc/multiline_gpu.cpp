@@ -59,9 +59,36 @@ static int parseRegex(const std::string& pattern, lc_regex_t** out, std::string&
     if (rc != LC_OK) err = buf;
     return rc;
 }
+// The MERGE processor does not compile the strings: it matches with the regexes MultilineOptions itself holds
+// (mMultiline.Get*PatternReg(), ProcessorMergeMultilineLogNative.cpp:219-224,244-262) -- the STRIPPED forms of ParseRegex :250-266.
+// A pattern that is empty after the stripping is not there ("END$" matches a line that merely begins with END, ".*" is no start
+// pattern).  Behind a prefix search  X(.*)*  and  X  decide alike, so the string as written is compiled when only ".*"s went (the
+// same automaton as the splitter's); the stripped form when a '$' went, or when only the stripped form is a valid regex.
+static int parseRegexStripped(const std::string& pattern, lc_regex_t** out, std::string& err) {
+    const std::string t = trimmed(pattern);
+    if (t.empty()) return LC_OK;
+    char buf[256];
+    lc_regex_t* stripped = nullptr;  // validity is the stripped form's ("a\\.*" is ignored with a warning: "a\\" is no regex)
+    const int rcT = lc_regex_compile(t.data(), t.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, &stripped, buf, sizeof buf);
+    if (rcT == LC_ERR_SYNTAX) {
+        err = buf;
+        return rcT;
+    }
+    if (!endsWith(pattern, "$")) {
+        lc_regex_t* written = nullptr;
+        if (lc_regex_compile(pattern.data(), pattern.size(), LC_SYNTAX_PREFIX, LC_ENGINE_AUTO, &written, buf, sizeof buf) == LC_OK) {
+            lc_regex_free(stripped);
+            *out = written;
+            return LC_OK;
+        }
+    }
+    if (rcT != LC_OK) err = buf;
+    *out = stripped;
+    return rcT;
+}
 
-extern "C" int lc_multiline_create(const char* config_json, size_t config_len, lc_multiline_t** out, char* err,
-                                   size_t errcap) {
+// regPtrForm: the patterns as MultilineOptions' own regexes hold them (the merge processor); otherwise as the splitter compiles them
+static int createMultiline(const char* config_json, size_t config_len, bool regPtrForm, lc_multiline_t** out, char* err, size_t errcap) {
     if (!config_json || !out) return LC_ERR_ARG;
     *out = nullptr;
     auto set = [&](const std::string& m) {
@@ -81,13 +108,25 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
         for (int i = 0; i < 3; ++i) {
             std::string why;
             const std::string pattern = str(names[i]);
-            const int rc = parseRegex(pattern, regs[i], why);
+            const int rc = regPtrForm ? parseRegexStripped(pattern, regs[i], why) : parseRegex(pattern, regs[i], why);
             if (rc == LC_OK) {
                 kept[i] = pattern;
             } else if (rc == LC_ERR_SYNTAX) {  // :109-118 -- a warning, the pattern counts as not given
                 m->warnings += std::string("string param Multiline.") + names[i] + " is not a valid regex: " + why + "\n";
             } else {
                 throw std::runtime_error(std::string("Multiline.") + names[i] + ": " + why);
+            }
+        }
+        if (regPtrForm) {  // MultilineOptions::Init :170-200, which the splitter's own regex vectors do not see
+            if (m->start && m->cont && m->end) {
+                lc_regex_free(m->cont);
+                m->cont = nullptr;
+                m->warnings += "none of param Multiline.StartPattern, Multiline.ContinuePattern and Multiline.EndPattern are empty: ignore param "
+                               "Multiline.ContinuePattern\n";
+            } else if (!m->start && !m->end && m->cont) {
+                lc_regex_free(m->cont);
+                m->cont = nullptr;
+                m->warnings += "param Multiline.StartPattern and EndPattern are empty but ContinuePattern is not: ignore multiline config\n";
             }
         }
         // The reference's state machine indexes an empty regex vector when it is handed ContinuePattern alone or no
@@ -112,6 +151,12 @@ extern "C" int lc_multiline_create(const char* config_json, size_t config_len, l
     set("");
     *out = m.release();
     return LC_OK;
+}
+extern "C" int lc_multiline_create(const char* config_json, size_t config_len, lc_multiline_t** out, char* err, size_t errcap) {
+    return createMultiline(config_json, config_len, false, out, err, errcap);
+}
+int lcMultilineCreateForMerge(const char* config_json, size_t config_len, lc_multiline_t** out, char* err, size_t errcap) {
+    return createMultiline(config_json, config_len, true, out, err, errcap);
 }
 extern "C" void lc_multiline_free(lc_multiline_t* m) { delete m; }
 extern "C" int lc_multiline_is_multiline(const lc_multiline_t* m) { return m && m->isMultiline; }

@@ -26,6 +26,10 @@ struct lc_multiline {
     }
 };
 
+// lc_multiline_create for the merge processor: the patterns in the form MultilineOptions' own regexes have (ParseRegex :250-266 strips a
+// trailing '$' and ".*"s; Init :170-200 drops ContinuePattern when all three are given) -- multiline_gpu.cpp
+int lcMultilineCreateForMerge(const char* config_json, size_t config_len, lc_multiline_t** out, char* err, size_t errcap);
+
 // multiline_device.hip -- the device trips (one upload, one synchronisation); counts: ML_CNT_* of multiline_scan.hpp
 int lcMultilineSplitTrip(lc_multiline* m, const uint8_t* data, uint32_t nbytes, std::vector<lc_ml_record_t>& out, uint32_t counts[8]);
 // records carry ITEM indices (begin = first item, length = number of items); flush = false leaves the log under construction open

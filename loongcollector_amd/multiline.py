@@ -139,6 +139,17 @@ class MergeMultiline:
         binding._check(self._L.lc_merge_multiline_process_group(self._h, _lib().lc_group_native(group._h)),
                        "lc_merge_multiline_process_group")
 
+    def patterns(self):
+        """bit 0 start, bit 1 continue, bit 2 end: the patterns the processor matches with -- MultilineOptions' own regexes (a trailing
+        '$' and ".*"s stripped, ContinuePattern dropped when all three are given), not the splitter's reading; 0 in flag mode"""
+        self._L.lc_merge_multiline_patterns.argtypes = [ctypes.c_void_p]
+        return int(self._L.lc_merge_multiline_patterns(self._h))
+
+    def warnings(self):
+        self._L.lc_merge_multiline_warnings.restype = ctypes.c_char_p
+        self._L.lc_merge_multiline_warnings.argtypes = [ctypes.c_void_p]
+        return self._L.lc_merge_multiline_warnings(self._h).decode("utf-8", "replace")
+
     def counters(self):
         """-> (merged events, unmatched events)"""
         c = (ctypes.c_uint64 * 2)()

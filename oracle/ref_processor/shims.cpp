@@ -215,6 +215,45 @@ char* refp_process_chain_json(void* h1, void* h2, const char* group_json, char* 
     static_cast<RefProcessor*>(h2)->proc->Process(groups);
     return dup(hdGroupToJson(groups[0]));
 }
+// What the line splitter leaves, built directly: ONE copy of `data` in the group's source buffer, one log event per line whose `key`
+// content is a view of its line (timestamp = 1 + the line's index); an event WITHOUT contents in front of every line listed in
+// emptyBefore (ascending; the line count = behind the last line), the key "other" on the lines listed in otherKey -- the same group tests/native/multiline_double.cpp builds for the
+// product's merge processor.  -> the group after Process, as fixture JSON.
+char* refp_process_lines(void* h, const uint8_t* data, size_t nbytes, const char* key, const uint32_t* emptyBefore, uint32_t nEmpty,
+                         const uint32_t* otherKey, uint32_t nOther) {
+    std::vector<logtail::PipelineEventGroup> groups;
+    auto sb = std::make_shared<logtail::SourceBuffer>();
+    groups.emplace_back(sb);
+    logtail::PipelineEventGroup& group = groups[0];
+    const logtail::StringBuffer copy = sb->CopyString(reinterpret_cast<const char*>(data), nbytes);
+    const logtail::StringBuffer k = sb->CopyString(key, strlen(key));
+    const logtail::StringBuffer other = sb->CopyString("other", 5);
+    uint32_t o = 0;
+    uint32_t line = 0, e = 0, ts = 1000;
+    auto empties = [&] {
+        while (e < nEmpty && emptyBefore[e] == line) {
+            group.AddLogEvent()->SetTimestamp(++ts);
+            ++e;
+        }
+    };
+    size_t at = 0;
+    while (at < nbytes) {
+        const void* nl = memchr(copy.data + at, '\n', nbytes - at);
+        const size_t end = nl ? size_t(static_cast<const char*>(nl) - copy.data) : nbytes;
+        empties();
+        logtail::LogEvent* ev = group.AddLogEvent();
+        const bool keyless = o < nOther && otherKey[o] == line;  // (an event that does not carry the source key)
+        if (keyless) ++o;
+        ev->SetContentNoCopy(keyless ? logtail::StringView(other.data, other.size) : logtail::StringView(k.data, k.size),
+                             logtail::StringView(copy.data + at, end - at));
+        ev->SetTimestamp(1 + line);
+        ++line;
+        at = end + 1;
+    }
+    empties();
+    static_cast<RefProcessor*>(h)->proc->Process(groups);
+    return dup(hdGroupToJson(groups[0]));
+}
 // discarded, out_failed, out_key_not_found, out_successful
 void refp_counters(void* h, uint64_t out[4]) {
     auto* p = static_cast<RefProcessor*>(h);

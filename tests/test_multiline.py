@@ -193,6 +193,40 @@ def test_merge_processor_regex_mode_on_the_reference_cases(golden_dir):
     assert merged_total > 40
 
 
+def _merge_pattern_cases(golden_dir):
+    with open(os.path.join(golden_dir, "multiline_merge_pattern_vectors.json"), encoding="utf-8") as f:
+        mv = json.load(f)
+    assert len(mv["cases"]) >= 400
+    return mv
+
+
+@pytest.mark.gpu
+def test_merge_processor_reads_the_patterns_as_the_reference_s_merge_processor_does(golden_dir):
+    """The merge processor matches with MultilineOptions' OWN regexes (Get*PatternReg(), ProcessorMergeMultilineLogNative.cpp:219-224,
+    244-262): what ParseRegex (MultilineOptions.cpp:250-266) leaves after stripping a trailing '$' and ".*"s, and without ContinuePattern
+    when all three are given (:185-200) -- the splitter compiles the strings as written.  tests/golden/multiline_merge_pattern_vectors.json
+    is the OUTPUT of the reference's merge processor (compiled from source in the build container) on 408 line groups under 17 configs;
+    the product's, on the device: the same events, contents and counters.  (tests/test_multiline_host_double.py runs the product's host
+    code beside the reference's processor itself.)"""
+    from loongcollector_amd.multiline import MergeMultiline
+    mv = _merge_pattern_cases(golden_dir)
+    procs = {}
+    for c in mv["cases"]:
+        key = json.dumps(c["config"], sort_keys=True)
+        if key not in procs:
+            procs[key] = MergeMultiline(MergeType="regex", **c["config"])
+        p = procs[key]
+        before = p.counters()
+        g, n = _events_of_lines("\n".join(mv["lines"][t] for t in c["in"]).encode("utf-8"))
+        assert n == len(c["in"])
+        p.process(g)
+        events = g.to_dict().get("events", []) if g.to_json() != "null" else []
+        # (the vectors also name the event kept by its timestamp; lc_group_from_lines stamps every event alike)
+        assert [e["contents"]["content"] for e in events] == [content for _, content in c["out"]], (c["config"], c["in"])
+        now = p.counters()
+        assert [now[0] - before[0], now[1] - before[1]] == c["counters"], (c["config"], c["in"])
+
+
 @pytest.mark.gpu
 def test_merge_processor_flag_mode():
     """MergeLogsByFlag :113-159: events that carry the "P" content are partial logs (container runtimes split long lines); runs of
@@ -200,17 +234,10 @@ def test_merge_processor_flag_mode():
     from loongcollector_amd.multiline import MergeMultiline
     from loongcollector_amd.processor import EventGroup
 
+    import merge_fixtures as mf
+
     def group(with_meta):
-        evs = [{"contents": [["content", "aaa"], ["P", ""]], "timestamp": 1, "type": 1},
-               {"contents": [["content", "bbb"], ["P", ""]], "timestamp": 2, "type": 1},
-               {"contents": [["content", "ccc"]], "timestamp": 3, "type": 1},
-               {"contents": [["content", "single"]], "timestamp": 4, "type": 1},
-               {"contents": [["content", "tail1"], ["P", ""]], "timestamp": 5, "type": 1},
-               {"contents": [["content", "tail2"], ["P", ""]], "timestamp": 6, "type": 1}]
-        g = {"events": evs}
-        if with_meta:
-            g["metadata"] = {"has.part.log": "P"}
-        return EventGroup(g)
+        return EventGroup(mf.flag_group(with_meta))
 
     p = MergeMultiline(MergeType="flag")
     g = group(False)
@@ -222,10 +249,11 @@ def test_merge_processor_flag_mode():
     out = g.to_dict()
     assert "metadata" not in out or "has.part.log" not in out.get("metadata", {})
     ev = out["events"]
-    assert [e["timestamp"] for e in ev] == [1, 4, 5]               # first event of every merged run survives
+    # (the same group goes through the reference's own merge processor in tests/test_reference_neighbours.py)
+    assert [e["timestamp"] for e in ev] == mf.FLAG_TIMESTAMPS      # first event of every merged run survives
     assert all("P" not in e["contents"] for e in ev[:2])
-    assert [len(e["contents"]["content"]) for e in ev] == [9, 6, 10]
-    assert p.counters() == (6, 0)
+    assert [len(e["contents"]["content"]) for e in ev] == [len(c) for c in mf.FLAG_CONTENTS]
+    assert p.counters() == mf.FLAG_COUNTERS
     with pytest.raises(MultilineInitError):
         MergeMultiline(MergeType="nope")
     with pytest.raises(MultilineInitError):
@@ -370,28 +398,15 @@ def test_merge_processor_counts_empty_events_like_the_reference():
     from loongcollector_amd.multiline import MergeMultiline
     from loongcollector_amd.processor import EventGroup
 
-    def ev(text, ts):
-        return {"contents": [["content", text]] if text is not None else [], "timestamp": ts, "type": 1}
-
-    # continue + end: " a", (empty), " b", "x" -- "x" is neither continuation nor end: the three events before it and "x" go to
-    # HandleUnmatchLogs as ONE range of 4 events
-    g = EventGroup({"events": [ev(" a", 1), ev(None, 2), ev(" b", 3), ev("x", 4), ev(" c", 5), ev(None, 6)]})
-    p = MergeMultiline(MergeType="regex", ContinuePattern=r"\s+.*", EndPattern="END")
-    p.process(g)
-    assert [e.get("timestamp") for e in g.to_dict()["events"]] == [1, 2, 3, 4, 5, 6]
-    assert p.counters() == (0, 6)   # [1..4] one call, then the flush [5..6] with the empty event behind the last item
-    # discard: the same events are counted and dropped
-    g = EventGroup({"events": [ev(" a", 1), ev(None, 2), ev(" b", 3), ev("x", 4), ev(" c", 5), ev(None, 6)]})
-    p = MergeMultiline(MergeType="regex", ContinuePattern=r"\s+.*", EndPattern="END", UnmatchedContentTreatment="discard")
-    p.process(g)
-    assert g.to_json() == "null" or not g.to_dict().get("events")
-    assert p.counters() == (0, 6)
-    # only an end pattern: the last item closes a log, empty events behind it still reach HandleUnmatchLogs (:316)
-    g = EventGroup({"events": [ev("END", 1), ev(None, 2)]})
-    p = MergeMultiline(MergeType="regex", EndPattern="END")
-    p.process(g)
-    assert [e["timestamp"] for e in g.to_dict()["events"]] == [1, 2]
-    assert p.counters() == (1, 1)
+    import merge_fixtures as mf
+    # (the same groups go through the reference's own merge processor in tests/test_reference_neighbours.py)
+    for events, config, timestamps, counters in mf.EMPTY_EVENT_CASES:
+        g = EventGroup(mf.empty_event_group(events))
+        p = MergeMultiline(MergeType="regex", **config)
+        p.process(g)
+        left = [] if g.to_json() == "null" else [e.get("timestamp") for e in (g.to_dict().get("events") or [])]
+        assert left == timestamps, (events, config)
+        assert p.counters() == counters, (events, config)
 
 
 def _events_of_lines(val):
@@ -462,3 +477,39 @@ def test_merge_processor_shared_by_threads_with_discard():
     for th in threads:
         th.join()
     assert not bad, bad[:4]
+
+
+def test_the_patterns_the_merge_processor_compiles_walk_like_the_oracle(golden_dir):
+    """The forms the merge processor hands to lc_regex_compile (csrc/multiline_gpu.cpp parseRegexStripped: the string as written, or --
+    when it ends in '$' -- what MultilineOptions::ParseRegex leaves of it) for every config of the committed merge vectors: the product's
+    tables (tagged DFA and thread-list program, walked by tests/helpers/table_interp.py as the kernels walk them) answer the prefix question
+    as the oracle does, on every line of the vectors."""
+    from oracle.oracle import OracleRegex
+    from tests.helpers.table_interp import NfaInterp, TdfaInterp
+    mv = _merge_pattern_cases(golden_dir)
+    lines = [ln.encode("utf-8") for ln in mv["lines"]]
+
+    def compiled_form(pattern):
+        t = pattern[:-1] if pattern.endswith("$") else pattern
+        while t.endswith(".*"):
+            t = t[:-2]
+        return None if not t else (t if pattern.endswith("$") else pattern)
+
+    seen, walked = set(), 0
+    for c in mv["cases"]:
+        for k in ("StartPattern", "ContinuePattern", "EndPattern"):
+            form = compiled_form(c["config"].get(k, ""))
+            if not form or form in seen:
+                continue
+            seen.add(form)
+            rx = B.GpuRegex(form.encode(), syntax_flags=B.LC_SYNTAX_PREFIX)
+            o = OracleRegex(form.encode())
+            its = ([NfaInterp(rx)] if rx.has_nfa_program() else []) + ([TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else [])
+            assert its, form
+            for ln in lines:
+                want = o.prefixmatch(ln) is not None
+                for it in its:
+                    walked += 1
+                    assert (it.fullmatch(ln) is not None) == want, (form, ln)
+    assert len(seen) >= 12 and walked > 300
+    assert ";" in seen and r"\}" in seen and r"\[\w+\]" in seen and "END" in seen   # (what is left of ";$", "\}$", "\[\w+\]$", "END.*$")

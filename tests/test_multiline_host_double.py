@@ -1,0 +1,375 @@
+"""The HOST translation units of the two multiline processors (csrc/multiline_events.cpp: which events come out, the in-place merge, the
+event counting of HandleUnmatchLogs; csrc/multiline_gpu.cpp: the Multiline options, the record scan's host model) on a machine without a
+GPU, beside the REFERENCE's own processors compiled from /root/reference (oracle/_ref/libref_processor.so: ProcessorMergeMultilineLogNative.cpp,
+ProcessorSplitMultilineLogStringNative.cpp, MultilineOptions.cpp).
+
+The product's code reaches the device through two internal calls (lcMultilineSplitTrip, lcMultilineViewsTrip); tests/native/multiline_double.cpp
+answers them from the CPU oracle's regex and the scan's own code run on the host.  What is compared: the events left, their contents and
+timestamps, their order, the counters -- on the imported unit-test cases, random line groups with events without contents in between, the
+hand-written groups of tests/merge_fixtures.py, and configs whose patterns end in '$' or ".*" or give all three patterns, where the
+reference's two processors themselves differ (the merge processor matches with MultilineOptions' stripped regexes, the splitter with the
+strings as written).  CPU only; skipped where the reference tree is not present (the GPU box)."""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+from test_reference_neighbours import RefPlugin, _one_event
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/core"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (/root/reference): its processors are compiled from there")
+
+_LIB = None
+
+
+def _double():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libmultiline_double.so")
+    csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "native", "multiline_double.cpp")] + [os.path.join(csrc, f) for f in ("multiline_events.cpp", "multiline_gpu.cpp", "event_model.cpp")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("event_model.hpp", "multiline_gpu.hpp", "multiline_scan.hpp", "json_min.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so] + srcs +
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined"])
+    L = ctypes.CDLL(so)
+    vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
+    for name in ("lc_merge_multiline_create", "lc_multiline_create"):
+        getattr(L, name).argtypes = [cp, sz, ctypes.POINTER(vp), cp, sz]
+    L.lc_merge_multiline_free.argtypes = [vp]
+    L.lc_multiline_free.argtypes = [vp]
+    L.lc_merge_multiline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.lc_multiline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.lc_merge_multiline_patterns.argtypes = [vp]
+    L.lc_multiline_patterns.argtypes = [vp]
+    L.lc_merge_multiline_warnings.restype = cp
+    L.lc_merge_multiline_warnings.argtypes = [vp]
+    L.md_merge_json.restype = vp
+    L.md_merge_json.argtypes = [vp, cp, cp, sz]
+    L.md_split_json.restype = vp
+    L.md_split_json.argtypes = [vp, cp, cp, sz]
+    L.md_merge_lines.restype = vp
+    L.md_merge_lines.argtypes = [vp, cp, sz, cp, vp, ctypes.c_uint32, vp, ctypes.c_uint32, cp, sz]
+    L.md_free.argtypes = [vp]
+    R = RefPlugin.lib()
+    R.refp_process_lines.restype = vp
+    R.refp_process_lines.argtypes = [vp, cp, sz, cp, vp, ctypes.c_uint32, vp, ctypes.c_uint32]
+    _LIB = L
+    return L
+
+
+def _events(text):
+    """fixture JSON -> [(timestamp, [(key, value) ...])]"""
+    d = json.loads(text, object_pairs_hook=list)
+    evs = dict(d or []).get("events", [])
+    out = []
+    for ev in evs:
+        ev = dict(ev)
+        out.append((ev.get("timestamp"), [tuple(kv) for kv in ev.get("contents", [])]))
+    return out
+
+
+def _whole_events(evs):
+    """events as the fixture writers print them -> every field (type, timestamps, position, contents in order / the raw content)"""
+    out = []
+    for ev in evs:
+        ev = dict(ev)
+        if isinstance(ev.get("contents"), list):
+            ev["contents"] = [tuple(kv) for kv in ev["contents"]]
+        out.append(sorted(ev.items(), key=lambda kv: kv[0]))
+    return out
+
+
+class _Product:
+    create, free, count, n = None, None, None, 0
+
+    def __init__(self, **config):
+        self.L = _double()
+        text = json.dumps(config).encode()
+        self.h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if getattr(self.L, self.create)(text, len(text), ctypes.byref(self.h), err, 512) != 0:
+            self.h = None
+            raise ValueError(err.value.decode("utf-8", "replace"))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.L, self.free)(self.h)
+            self.h = None
+
+    def counters(self):
+        c = (ctypes.c_uint64 * self.n)()
+        getattr(self.L, self.count)(self.h, c)
+        return tuple(int(x) for x in c)
+
+    def _take(self, p, err):
+        assert p, err.value
+        try:
+            return ctypes.string_at(p).decode("utf-8")
+        finally:
+            self.L.md_free(p)
+
+
+class ProductMerge(_Product):
+    create, free, count, n = "lc_merge_multiline_create", "lc_merge_multiline_free", "lc_merge_multiline_counters", 2
+
+    def patterns(self):
+        return self.L.lc_merge_multiline_patterns(self.h)
+
+    def warnings(self):
+        return self.L.lc_merge_multiline_warnings(self.h).decode()
+
+    def json(self, fixture):
+        err = ctypes.create_string_buffer(512)
+        return _events(self._take(self.L.md_merge_json(self.h, json.dumps(fixture).encode(), err, 512), err))
+
+    def lines(self, data, empty_before=(), key="content", other_key=()):
+        err = ctypes.create_string_buffer(512)
+        eb = (ctypes.c_uint32 * max(1, len(empty_before)))(*empty_before)
+        ok = (ctypes.c_uint32 * max(1, len(other_key)))(*other_key)
+        return _events(self._take(self.L.md_merge_lines(self.h, data, len(data), key.encode(), eb, len(empty_before), ok, len(other_key), err, 512), err))
+
+
+class ProductSplit(_Product):
+    create, free, count, n = "lc_multiline_create", "lc_multiline_free", "lc_multiline_counters", 3
+
+    def json(self, fixture):
+        err = ctypes.create_string_buffer(512)
+        return _events(self._take(self.L.md_split_json(self.h, json.dumps(fixture).encode(), err, 512), err))
+
+    def whole(self, fixture):
+        err = ctypes.create_string_buffer(512)
+        d = json.loads(self._take(self.L.md_split_json(self.h, json.dumps(fixture).encode(), err, 512), err), object_pairs_hook=list)
+        return _whole_events(dict(d or []).get("events", []))
+
+
+def _ref_lines(ref, data, empty_before=(), key="content", other_key=()):
+    R = RefPlugin.lib()
+    eb = (ctypes.c_uint32 * max(1, len(empty_before)))(*empty_before)
+    ok = (ctypes.c_uint32 * max(1, len(other_key)))(*other_key)
+    p = R.refp_process_lines(ref.h, data, len(data), key.encode(), eb, len(empty_before), ok, len(other_key))
+    assert p
+    try:
+        return _events(ctypes.string_at(p).decode("utf-8"))
+    finally:
+        R.refp_free(p)
+
+
+def _ref_merge_counters(ref):
+    c = ref.counters()
+    return (c["merged_events_total"], c["unmatched_events_total"])
+
+
+POOL = [b"2024-01-04 boom", b"  at com.example.A.b(A.java:1)", b"[ERROR] x", b"BEGIN tx", b"END7", b"END", b"END7x", b"ENDx", b"}x", b"}", b"{",
+        b"stmt;", b"stmt; -- tail", b"noise", b"\tcontinued", b"2024-13-99 not checked", b"[WARN]", b"x [ERROR] inside"]
+
+# (the merge processor's reading of the patterns differs from the splitter's on the configs marked *: a trailing '$' is stripped, ".*"
+# alone is no pattern, ContinuePattern is dropped when all three are given -- MultilineOptions.cpp:170-200,250-266)
+MERGE_CONFIGS = [
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*"},
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": "BEGIN.*", "EndPattern": r"END\d*"},
+    {"StartPattern": "BEGIN.*", "EndPattern": r"END\d*", "UnmatchedContentTreatment": "discard"},
+    {"ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}"},
+    {"ContinuePattern": r"\s+.*", "EndPattern": "END", "UnmatchedContentTreatment": "discard"},
+    {"EndPattern": r"END\d"},
+    {"EndPattern": ";$", "UnmatchedContentTreatment": "discard"},                                        # *
+    {"EndPattern": ";$"},                                                                                # *
+    {"StartPattern": r"\[\w+\]$", "ContinuePattern": r"\s+at\s.*"},                                      # *
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}$"},               # * (all three)
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}", "UnmatchedContentTreatment": "discard"},  # *
+    {"StartPattern": ".*", "EndPattern": r"END\d*"},                                                     # * (start is no pattern)
+    {"StartPattern": "BEGIN.*.*$", "EndPattern": "END.*$"},                                              # *
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": ".*", "EndPattern": r"\}"},                        # * (continue is no pattern)
+]
+
+
+def test_merge_processor_host_code_on_the_imported_unit_test_cases(golden_dir):
+    """the `// case:` blocks of ProcessorMergeMultilineLogNativeUnittest.cpp through the product's MergeLogsByRegex restatement (the device
+    answered by the oracle's regex) and through the reference's own: the same events, the same counters"""
+    with open(os.path.join(golden_dir, "multiline_merge_vectors.json"), encoding="utf-8") as f:
+        mv = json.load(f)
+    for c in mv["cases"]:
+        data = "\n".join(mv["lines"][t] for t in c["in"]).encode("utf-8")
+        if not data:
+            continue
+        p = ProductMerge(MergeType="regex", **c["config"])
+        ref = RefPlugin("processor_merge_multiline_log_native", dict(c["config"], MergeType="regex"))
+        got = p.lines(data)
+        assert [dict(kv)["content"] for _, kv in got] == ["\n".join(mv["lines"][t] for t in ev) for ev in c["out"]], c["cite"]
+        assert got == _ref_lines(ref, data), c["cite"]
+        assert p.counters() == _ref_merge_counters(ref), c["cite"]
+
+
+def test_merge_processor_host_code_beside_the_reference_on_random_groups():
+    """random line groups, events without contents strewn in between (they are counted by HandleUnmatchLogs and skipped by the walk), under
+    seventeen configs -- among them those on which the reference's merge processor and its splitter read the patterns differently"""
+    rng = random.Random(20260922)
+    for config in MERGE_CONFIGS:
+        p = ProductMerge(MergeType="regex", **config)
+        ref = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        for trial in range(160):
+            n = rng.randint(1, 18)
+            lines = [rng.choice(POOL) for _ in range(n)]
+            data = b"\n".join(lines) + (b"\n" if rng.random() < 0.5 else b"")
+            empties = sorted(rng.randint(0, n) for _ in range(rng.choice([0, 0, 1, 2, 4])))
+            # (now and then an event that does not carry the source key: the walk ends there and the rest passes through, :193-216)
+            keyless = [rng.randrange(n)] if rng.random() < 0.15 else []
+            got, want = p.lines(data, empties, other_key=keyless), _ref_lines(ref, data, empties, other_key=keyless)
+            assert got == want, (config, data, empties, keyless)
+            assert p.counters() == _ref_merge_counters(ref), (config, data, empties, keyless)
+    # long groups: thousands of events, joins of hundreds of lines
+    for config in (MERGE_CONFIGS[0], MERGE_CONFIGS[3], MERGE_CONFIGS[12]):
+        p = ProductMerge(MergeType="regex", **config)
+        ref = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        lines = [rng.choice(POOL[:3] * 4 + POOL) for _ in range(6000)]
+        data = b"\n".join(lines)
+        assert p.lines(data) == _ref_lines(ref, data), config
+        assert p.counters() == _ref_merge_counters(ref), config
+
+
+def test_the_committed_merge_pattern_vectors_are_what_the_reference_and_the_product_s_host_code_leave(golden_dir):
+    """tests/golden/multiline_merge_pattern_vectors.json (the GPU test's expectation, test_multiline.py) against the reference's processor
+    run again here, and against the product's host code"""
+    with open(os.path.join(golden_dir, "multiline_merge_pattern_vectors.json"), encoding="utf-8") as f:
+        mv = json.load(f)
+    assert len(mv["cases"]) >= 400
+    procs = {}
+    for c in mv["cases"]:
+        key = json.dumps(c["config"], sort_keys=True)
+        if key not in procs:
+            procs[key] = (ProductMerge(MergeType="regex", **c["config"]), RefPlugin("processor_merge_multiline_log_native", dict(c["config"], MergeType="regex")))
+        p, ref = procs[key]
+        data = "\n".join(mv["lines"][t] for t in c["in"]).encode("utf-8")
+        before = p.counters()
+        got = [[ts, dict(kv)["content"]] for ts, kv in p.lines(data)]
+        assert got == c["out"] == [[ts, dict(kv)["content"]] for ts, kv in _ref_lines(ref, data)], (c["config"], c["in"])
+        now = p.counters()
+        assert [now[0] - before[0], now[1] - before[1]] == c["counters"], (c["config"], c["in"])
+
+
+def test_merge_processor_reads_the_patterns_as_the_reference_s_merge_processor_does():
+    """MultilineOptions::ParseRegex :250-266 / Init :170-200 as the merge processor sees them"""
+    cases = [
+        ({"StartPattern": "a.*", "ContinuePattern": "b", "EndPattern": "c$"}, 5, "ignore param Multiline.ContinuePattern"),
+        ({"StartPattern": ".*", "EndPattern": "END"}, 4, ""),
+        ({"StartPattern": "$", "EndPattern": "END"}, 4, ""),
+        ({"StartPattern": "a", "ContinuePattern": ".*.*$", "EndPattern": "c"}, 5, ""),
+        ({"StartPattern": "a", "ContinuePattern": "b"}, 3, ""),
+        ({"ContinuePattern": "b", "EndPattern": "c"}, 6, ""),
+        ({"StartPattern": r"a\.*", "EndPattern": "c"}, 4, "Multiline.StartPattern is not a valid regex"),   # "a\" is what ParseRegex compiles
+        ({"StartPattern": "(", "EndPattern": "c"}, 4, "Multiline.StartPattern is not a valid regex"),
+    ]
+    for config, mask, warning in cases:
+        p = ProductMerge(MergeType="regex", **config)
+        assert p.patterns() == mask, config
+        assert warning in p.warnings() and (warning or not p.warnings()), (config, p.warnings())
+        # ... and the reference's processor behaves as one with exactly those patterns: a probe line per pattern
+        ref = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        for data in (b"a\nb\nc\nx\na\nc", b"c\na\na\nb\nb\nc\nc", b"x\nb\nb\nc"):
+            assert p.lines(data) == _ref_lines(ref, data), (config, data)
+    # the splitter compiles the strings as written and keeps all three (ProcessorSplitMultilineLogStringNative.cpp:66-76)
+    s = ProductSplit(StartPattern="a.*", ContinuePattern="b", EndPattern="c$")
+    assert s.L.lc_multiline_patterns(s.h) == 7
+    for config in ({"MergeType": "nope"}, {}, {"MergeType": 3}):
+        with pytest.raises(ValueError):
+            ProductMerge(**config)
+        with pytest.raises(ValueError):
+            RefPlugin("processor_merge_multiline_log_native", config)
+    # a source key of its own
+    p = ProductMerge(MergeType="regex", SourceKey="msg", StartPattern="BEGIN")
+    ref = RefPlugin("processor_merge_multiline_log_native", {"MergeType": "regex", "SourceKey": "msg", "StartPattern": "BEGIN"})
+    assert p.lines(b"x\nBEGIN\ny\nz\nBEGIN", key="msg") == _ref_lines(ref, b"x\nBEGIN\ny\nz\nBEGIN", key="msg")
+    # events that do not carry the source key end the walk (:193-216): what was gathered passes through
+    got, want = p.lines(b"BEGIN\na\nb", key="other"), _ref_lines(ref, b"BEGIN\na\nb", key="other")
+    assert got == want and len(got) == 3
+
+
+def test_merge_processor_host_code_on_the_hand_written_groups():
+    """tests/merge_fixtures.py: the partial-log flags and the events without contents, through the product's host code (the GPU tests run
+    the same groups through the whole product)"""
+    import merge_fixtures as mf
+    p = ProductMerge(MergeType="flag")
+    assert [ts for ts, _ in p.json(mf.flag_group(False))] == [1, 2, 3, 4, 5, 6] and p.counters() == (0, 0)
+    out = p.json(mf.flag_group(True))
+    assert [ts for ts, _ in out] == mf.FLAG_TIMESTAMPS
+    assert [len(dict(kv)["content"]) for _, kv in out] == [len(c) for c in mf.FLAG_CONTENTS]
+    assert all("P" not in dict(kv) for _, kv in out)
+    assert p.counters() == mf.FLAG_COUNTERS
+    for events, config, timestamps, counters in mf.EMPTY_EVENT_CASES:
+        p = ProductMerge(MergeType="regex", **config)
+        assert [ts for ts, _ in p.json(mf.empty_event_group(events))] == timestamps, (events, config)
+        assert p.counters() == counters, (events, config)
+    # flag mode on adjacent values, against the reference: joined without line feeds
+    p = ProductMerge(MergeType="flag")
+    ref = RefPlugin("processor_merge_multiline_log_native", {"MergeType": "flag"})
+    g = {"metadata": {"has.part.log": "P"},
+         "events": [{"contents": [["content", t]] + ([["P", ""]] if part else []), "timestamp": i + 1, "type": 1}
+                    for i, (t, part) in enumerate([("a", True), ("b", False), ("c", False), ("d", True), ("e", True), ("f", True)])]}
+    got = p.json(g)
+    want = [(dict(e)["timestamp"], [tuple(kv) for kv in dict(e)["contents"]]) for e in ref.process(g)]
+    assert [(ts, dict(kv)["content"]) for ts, kv in got] == [(ts, dict(kv)["content"]) for ts, kv in want] == [(1, "ab"), (3, "c"), (4, "def")]
+    assert p.counters() == _ref_merge_counters(ref) == (6, 0)
+
+
+SPLIT_CONFIGS = [
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*"},
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*"},
+    {"StartPattern": "BEGIN.*", "EndPattern": r"END\d*"},
+    {"ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}"},
+    {"EndPattern": ";$", "UnmatchedContentTreatment": "discard"},
+    {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}$"},
+    {"StartPattern": r"\[\w+\]$", "ContinuePattern": r"\s+at\s.*"},
+    {"StartPattern": "BEGIN.*", "EndPattern": r"END\d*", "EnableRawContent": True},
+    {"StartPattern": r"\d{4}-\d{2}-\d{2} .*", "SourceKey": "msg"},
+]
+
+
+def test_multiline_splitter_host_code_beside_the_reference_on_random_groups():
+    """lc_multiline_process_group (ProcessEvent :126-160 + CreateNewEvent :302-339: one event per record, a view of the source value, the
+    source event's timestamp, position = where the record lies in the file, the file-offset content when the group carries that metadata;
+    other events pass through) beside the reference's own splitter on groups of several events: every field the fixture writers print"""
+    rng = random.Random(7)
+    for config in SPLIT_CONFIGS:
+        p = ProductSplit(**config)
+        ref = RefPlugin("processor_split_multiline_log_string_native", config)
+        key = config.get("SourceKey", "content")
+        for trial in range(80):
+            events = []
+            for k in range(rng.randint(1, 3)):
+                val = b"\n".join(rng.choice(POOL) for _ in range(rng.randint(1, 10))).decode() + ("\n" if rng.random() < 0.3 else "")
+                # (EnableRawContent: only events the splitter replaces -- the reference's group destroys its events by the type of the
+                # first one, PipelineEventGroup.cpp:109-131, and a raw event released into the log events' pool takes the next group down)
+                kind = 0.0 if config.get("EnableRawContent") else rng.random()
+                if kind < 0.75:
+                    contents = [[key, val]]
+                elif kind < 0.85:
+                    contents = [[key, val], ["extra", "1"]]       # more than the source content: passes through
+                elif kind < 0.95:
+                    contents = [["elsewhere", val]]               # no source content: passes through
+                else:
+                    contents = []
+                ev = {"contents": contents, "timestamp": 1700000000 + k, "type": 1}
+                if rng.random() < 0.7:
+                    ev["timestampNanosecond"] = 5 * k
+                if rng.random() < 0.7:                            # where the read buffer lies in the file: the records' positions
+                    ev["fileOffset"], ev["rawSize"] = 4096 * k + rng.randrange(100), len(val.encode()) + rng.randrange(3)
+                events.append(ev)
+            g = {"events": events}
+            if rng.random() < 0.4:
+                g["metadata"] = {"log.file.offset": "__file_offset__"}
+            got, want = p.whole(g), _whole_events(ref.process(g))
+            assert got == want, (config, g)
+        c = ref.counters()
+        assert p.counters() == (c["matched_lines_total"], c["unmatched_lines_total"], c["matched_events_total"]), config

@@ -240,3 +240,98 @@ def test_merge_processor_reproduces_the_imported_unit_test_cases(golden_dir):
         assert got == ["\n".join(mv["lines"][t] for t in ev) for ev in c["out"]], c["cite"]
         ran += 1
     assert ran >= 40
+
+
+def test_merge_processor_on_the_groups_the_product_s_gpu_tests_use():
+    """The hand-written groups of tests/merge_fixtures.py -- partial-log flags (MergeLogsByFlag :113-159), events without contents inside
+    and behind unmatched ranges (HandleUnmatchLogs :360-392) -- through the reference's own merge processor: the events left, the joined
+    values and the two counters the product's GPU tests (tests/test_multiline.py) expect are what the reference's code leaves."""
+    import merge_fixtures as mf
+    p = RefPlugin("processor_merge_multiline_log_native", {"MergeType": "flag"})
+    untouched = p.process(mf.flag_group(False))                       # no HAS_PART_LOG metadata: nothing happens
+    assert [e["timestamp"] for e in untouched] == [1, 2, 3, 4, 5, 6] and p.counters()["merged_events_total"] == 0
+    out = p.process(mf.flag_group(True))
+    assert [e["timestamp"] for e in out] == mf.FLAG_TIMESTAMPS
+    # (the fixture reader copies every key and value separately, so the in-place memmove runs over dead keys of the merged-away events:
+    # the value under "content" and the absence of the flag are what carries over)
+    assert [dict(e["contents"])["content"] for e in out] == mf.FLAG_CONTENTS
+    assert all("P" not in dict(e["contents"]) for e in out)
+    cnt = p.counters()
+    assert (cnt["merged_events_total"], cnt["unmatched_events_total"]) == mf.FLAG_COUNTERS
+    for kind, config in (("nope", {"MergeType": "nope"}), ("none", {})):
+        with pytest.raises(ValueError):
+            RefPlugin("processor_merge_multiline_log_native", config)
+    for events, config, timestamps, counters in mf.EMPTY_EVENT_CASES:
+        p = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        out = p.process(mf.empty_event_group(events))
+        assert [e.get("timestamp") for e in out] == timestamps, (events, config)
+        cnt = p.counters()
+        assert (cnt["merged_events_total"], cnt["unmatched_events_total"]) == counters, (events, config)
+
+
+def _split_then_merge(L, split, merge, value):
+    err = ctypes.create_string_buffer(512)
+    p = L.refp_process_chain_json(split.h, merge.h, json.dumps(_one_event(value)).encode(), err, 512)
+    assert p, err.value
+    try:
+        d = json.loads(ctypes.string_at(p).decode("utf-8"), object_pairs_hook=list)
+    finally:
+        L.refp_free(p)
+    return [dict(dict(ev)["contents"])["content"] for ev in dict(d or []).get("events", [])]
+
+
+def test_merge_behind_the_splitter_leaves_the_multiline_oracle_s_records():
+    """The product's merge processor is checked on the GPU against oracle/multiline_oracle.py's records of the same buffer
+    (test_merge_processor_on_thousands_of_adjacent_events): here the REFERENCE's splitter + merge processor on random buffers under six
+    pattern sets (those the two processors read alike), and on the corpus buffer of that GPU test, leave exactly those records (the last one without its final line feed) and
+    count merged + unmatched = the lines."""
+    from loongcollector_amd import corpus
+    L = RefPlugin.lib()
+    L.refp_process_chain_json.restype = ctypes.c_void_p
+    L.refp_process_chain_json.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    split = RefPlugin("processor_split_string_native", {})
+
+    def want(config, val):
+        recs, counters = MultilineOracle(**config).split(val)
+        texts = [val[b:b + l].decode("utf-8") for b, l, *_ in recs]
+        if texts and texts[-1].endswith("\n"):
+            texts[-1] = texts[-1][:-1]
+        return texts, counters
+
+    rng = random.Random(43)
+    pool = ["2024-01-04 boom", "  at com.example.A.b(A.java:1)", "[ERROR] x", "BEGIN tx", "END7", "END", "END7x", "}x", "}", "{",
+            "stmt;", "noise", "\tcontinued", "2024-13-99 not checked"]
+    configs = [
+        {"StartPattern": r"\d{4}-\d{2}-\d{2} .*"},
+        {"StartPattern": r"\d{4}-\d{2}-\d{2} .*", "UnmatchedContentTreatment": "discard"},
+        {"StartPattern": r"\[\w+\].*", "ContinuePattern": r"\s+at\s.*"},
+        {"StartPattern": "BEGIN.*", "EndPattern": r"END\d*"},
+        {"ContinuePattern": r"\s+at\s.*", "EndPattern": r"\}"},
+        {"EndPattern": r"END\d", "UnmatchedContentTreatment": "discard"},
+    ]
+    # (configs whose patterns end in '$', consist of ".*" only, or give all three patterns are NOT here: on those the reference's merge
+    # processor -- MultilineOptions' stripped regexes -- and its splitter -- the strings as written -- part ways, and the oracle follows the
+    # splitter.  tests/test_multiline_host_double.py and tests/golden/multiline_merge_pattern_vectors.json hold the merge processor's reading.)
+    for config in configs:
+        merge = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        before = merge.counters()
+        for _ in range(120):
+            lines = [rng.choice(pool) for _ in range(rng.randint(1, 14))]
+            val = "\n".join(lines).encode()
+            got = _split_then_merge(L, split, merge, val.decode())
+            texts, counters = want(config, val)
+            assert got == texts, (config, val)
+            cnt = merge.counters()
+            assert (cnt["merged_events_total"] - before["merged_events_total"]) + (cnt["unmatched_events_total"] - before["unmatched_events_total"]) == len(lines), (config, val)
+            assert cnt["unmatched_events_total"] - before["unmatched_events_total"] == counters[1], (config, val)
+            before = cnt
+    for treatment in ("single_line", "discard"):                       # the GPU test's own buffer
+        val = corpus.multiline_buffer(384 << 10, unmatched_head=5)
+        config = {"StartPattern": corpus.MULTILINE_START, "UnmatchedContentTreatment": treatment}
+        merge = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        got = _split_then_merge(L, split, merge, val.decode("utf-8"))
+        texts, counters = want(config, val)
+        assert got == texts and len(got) > 100
+        n = len(val.rstrip(b"\n").split(b"\n"))
+        cnt = merge.counters()
+        assert cnt["unmatched_events_total"] == 5 and cnt["merged_events_total"] + cnt["unmatched_events_total"] == n
