@@ -8,6 +8,8 @@
 // lc_regex_compile from the oracle's compiler, so that tests/test_multiline_host_double.py can build
 //     multiline_events.cpp + multiline_gpu.cpp + event_model.cpp + this file  ->  tests/_build/libmultiline_double.so
 // and run the PRODUCT's host translation units beside the reference's own processors (oracle/_ref/libref_processor.so) here.
+// Second variant (-DLC_USE_REFERENCE_HEADERS): the same product sources on the reference's OWN event model (oracle/_ref/libref_models.so,
+// fixtures through tests/native/ref_group_io.cpp) -> tests/_build/libmultiline_double_ref.so.
 // What it does not cover is the device: the match kernels and the scan kernel are held to the same oracle by the -m gpu tests.
 //
 // It lives under tests/, is built only by the test that uses it and is never linked into loongcollector_amd/lib.
@@ -20,7 +22,15 @@
 
 #include "../../include/lc_multiline.h"
 #include "../../include/lc_regex_gpu.h"
+#ifdef LC_USE_REFERENCE_HEADERS  // second variant: the same product sources on the reference's OWN event model (oracle/_ref/libref_models.so)
+#include "models/LogEvent.h"
+#include "models/PipelineEventGroup.h"
+#include "models/RawEvent.h"
+bool hdGroupFromJson(logtail::PipelineEventGroup& g, const std::string& json, std::string* error);  // tests/native/ref_group_io.cpp
+std::string hdGroupToJson(const logtail::PipelineEventGroup& g);
+#else
 #include "../../loongcollector_amd/csrc/event_model.hpp"
+#endif
 #include "../../loongcollector_amd/csrc/multiline_gpu.hpp"
 #include "../../loongcollector_amd/csrc/multiline_scan.hpp"
 #include "../../oracle/bt_regex.h"
@@ -113,7 +123,11 @@ extern "C" {
 static char* processJson(int (*fn)(void*, void*), void* h, const char* groupJson, char* err, size_t errcap) {
     logtail::PipelineEventGroup group(std::make_shared<logtail::SourceBuffer>());
     std::string error;
+#ifdef LC_USE_REFERENCE_HEADERS
+    if (!hdGroupFromJson(group, groupJson, &error)) {
+#else
     if (!group.FromJsonString(groupJson, &error)) {
+#endif
         std::snprintf(err, errcap, "%s", error.c_str());
         return nullptr;
     }
@@ -122,7 +136,11 @@ static char* processJson(int (*fn)(void*, void*), void* h, const char* groupJson
         std::snprintf(err, errcap, "process_group failed: %d", rc);
         return nullptr;
     }
+#ifdef LC_USE_REFERENCE_HEADERS
+    return strdup(hdGroupToJson(group).c_str());
+#else
     return strdup(group.ToJsonString().c_str());
+#endif
 }
 char* md_split_json(lc_multiline_t* m, const char* groupJson, char* err, size_t errcap) {
     return processJson([](void* h, void* g) { return lc_multiline_process_group(static_cast<lc_multiline_t*>(h), g); }, m, groupJson, err, errcap);
@@ -169,7 +187,16 @@ char* md_merge_lines(lc_merge_multiline_t* p, const uint8_t* data, size_t nbytes
         std::snprintf(err, errcap, "lc_merge_multiline_process_group failed: %d", rc);
         return nullptr;
     }
+#ifdef LC_USE_REFERENCE_HEADERS
+    return strdup(hdGroupToJson(group).c_str());
+#else
     return strdup(group.ToJsonString().c_str());
+#endif
 }
+#ifdef LC_USE_REFERENCE_HEADERS
+int md_event_model_is_reference(void) { return 1; }
+#else
+int md_event_model_is_reference(void) { return 0; }
+#endif
 void md_free(void* p) { std::free(p); }
 }  // extern "C"
