@@ -384,7 +384,11 @@ extern "C" void lc_free(void* p) { std::free(p); }
 // Call protocol (core/plugin/processor/DynamicCProcessorProxy.cpp:25-40): init(ins, &config, &context) must set
 // ins->plugin_state and return 0; process(plugin_state, &group) mutates the group in place; finalize(plugin_state).
 static int slotInit(processor_instance_t* ins, void* config, void* context) {
-    if (!ins || !config) return -1;
+    if (!ins) return -1;
+    // DynamicCProcessorProxy allocates the instance without initialising it and its destructor calls finalize(plugin_state) whether or
+    // not init succeeded (DynamicCProcessorProxy.cpp:21-28): a refused config must not leave a wild pointer for that call
+    ins->plugin_state = nullptr;
+    if (!config) return -1;
     lc_processor_t* p = nullptr;
     char err[256];
 #ifdef LC_USE_REFERENCE_HEADERS

@@ -24,6 +24,11 @@
 #include "monitor/AlarmManager.h"
 #include "monitor/MetricManager.h"
 #include "plugin/processor/ProcessorFilterNative.h"
+#include "collection_pipeline/plugin/creator/CProcessor.h"
+#include "collection_pipeline/plugin/creator/DynamicCProcessorCreator.h"
+#include "collection_pipeline/plugin/instance/ProcessorInstance.h"
+#include "common/DynamicLibHelper.h"
+#include "monitor/MetricManager.h"
 #include "plugin/processor/ProcessorParseRegexNative.h"
 #include "plugin/processor/inner/ProcessorMergeMultilineLogNative.h"
 #include "plugin/processor/inner/ProcessorSplitLogStringNative.h"
@@ -67,6 +72,18 @@ CounterPtr MetricsRecordRef::CreateCounter(const std::string& name) {
     gCounters[name] = c;
     return c;
 }
+
+// (ProcessorInstance's own counters, ProcessorInstance.cpp:29-44)
+TimeCounterPtr MetricsRecordRef::CreateTimeCounter(const std::string& name) {
+    TimeCounterPtr c = std::make_shared<TimeCounter>(name);
+    std::lock_guard<std::mutex> g(gMutex);
+    gCounters[name] = c;
+    return c;
+}
+const std::string MetricCategory::METRIC_CATEGORY_PLUGIN = "plugin";
+WriteMetrics::~WriteMetrics() {}
+void WriteMetrics::CreateMetricsRecordRef(MetricsRecordRef&, const std::string&, MetricLabels&&, DynamicMetricLabels&&) {}
+void WriteMetrics::CommitMetricsRecordRef(MetricsRecordRef&) {}
 
 const std::string& CollectionPipelineContext::GetProjectName() const { return kEmpty; }
 const std::string& CollectionPipelineContext::GetLogstoreName() const { return kEmpty; }
@@ -253,6 +270,115 @@ char* refp_process_lines(void* h, const uint8_t* data, size_t nbytes, const char
     empties();
     static_cast<RefProcessor*>(h)->proc->Process(groups);
     return dup(hdGroupToJson(groups[0]));
+}
+// ------------------------------------------------------------------------------------------------ the C-processor slot (section 8 b)
+// A dynamic plugin loaded and driven by the reference's OWN code: the directory rule of PluginRegistry::LoadDynamicPlugins (:239:
+// GetProcessExecutionDir() + "/plugins", handed to LoadDynLib as the PREFIX of "lib<type>.so") -> DynamicLibLoader::LoadDynLib / LoadMethod
+// (common/DynamicLibHelper.cpp:68-98, compiled) -> the symbol and version check of PluginRegistry::LoadProcessorPlugin (:270-290,
+// restated: PluginRegistry.cpp registers every plugin of the agent and is not compiled) -> DynamicCProcessorCreator::Create
+// (compiled) -> ProcessorInstance::Init -> DynamicCProcessorProxy::Init hands the plugin &config (a Json::Value) and &context
+// (compiled) -> ProcessorInstance::Process with its in / out counters (compiled).
+namespace {
+struct RefDynamic {
+    logtail::CollectionPipelineContext ctx;
+    std::unique_ptr<logtail::DynamicCProcessorCreator> creator;
+    std::unique_ptr<logtail::PluginInstance> instance;
+    std::map<std::string, logtail::CounterPtr> counters;
+    std::string pathTried;
+};
+}  // namespace
+void* refp_dyn_load(const char* process_execution_dir, const char* plugin_type, const char* config_json, char* err, size_t errcap) {
+    auto fail = [&](const std::string& m) -> void* {
+        if (err && errcap) snprintf(err, errcap, "%s", m.c_str());
+        return nullptr;
+    };
+    auto d = std::make_unique<RefDynamic>();
+    logtail::AppConfig::GetInstance()->SetProcessExecutionDir(process_execution_dir);
+    const std::string pluginType = plugin_type;
+    std::string error;
+    const std::string pluginDir = logtail::AppConfig::GetInstance()->GetProcessExecutionDir() + "/plugins";  // PluginRegistry.cpp:239
+    logtail::DynamicLibLoader loader;
+    if (!loader.LoadDynLib(pluginType, error, pluginDir)) return fail("open plugin " + pluginType + ": " + error);  // :241-244
+    auto* plugin = static_cast<processor_interface_t*>(loader.LoadMethod("processor_interface", error));          // :272
+    if (!error.empty() || !plugin) return fail("load method plugin_interface: " + error);                          // :279-282
+    if (plugin->version != PROCESSOR_INTERFACE_VERSION)                                                            // :283-288
+        return fail("plugin interface version mismatch: expected " + std::to_string(PROCESSOR_INTERFACE_VERSION) + ", actual " +
+                    std::to_string(plugin->version));
+    d->creator = std::make_unique<logtail::DynamicCProcessorCreator>(plugin, loader.Release());                    // :289
+    d->instance = d->creator->Create(logtail::PluginInstance::PluginMeta("1"));
+    d->ctx.SetConfigName("test_config");
+    Json::Value config;
+    try {
+        config = Json::Value::fromText(config_json);
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+    {
+        std::lock_guard<std::mutex> g(gMutex);
+        gCounters.clear();
+    }
+    if (!static_cast<logtail::ProcessorInstance*>(d->instance.get())->Init(config, d->ctx)) {
+        // (d goes: ~DynamicCProcessorProxy calls finalize(plugin_state) also after a failed init, DynamicCProcessorProxy.cpp:25-28 -- the
+        // plugin must have left a state that call can take)
+        return fail("ProcessorInstance::Init returned false");
+    }
+    std::lock_guard<std::mutex> g(gMutex);
+    d->counters = gCounters;
+    return d.release();
+}
+// the reference's own processor_parse_regex_native in the same wrapper (ProcessorInstance), for the side-by-side: what the pipeline sees
+// of a static plugin -- events and in / out counters -- is what it sees of the dynamic one.  Driven by the refp_dyn_* calls.
+void* refp_static_instance(const char* config_json, char* err, size_t errcap) {
+    auto d = std::make_unique<RefDynamic>();
+    d->instance = std::make_unique<logtail::ProcessorInstance>(new logtail::ProcessorParseRegexNative, logtail::PluginInstance::PluginMeta("1"));
+    d->ctx.SetConfigName("test_config");
+    Json::Value config;
+    try {
+        config = Json::Value::fromText(config_json);
+    } catch (const std::exception& e) {
+        if (err && errcap) snprintf(err, errcap, "%s", e.what());
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> g(gMutex);
+        gCounters.clear();
+    }
+    if (!static_cast<logtail::ProcessorInstance*>(d->instance.get())->Init(config, d->ctx)) {
+        if (err && errcap) snprintf(err, errcap, "ProcessorInstance::Init returned false");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(gMutex);
+    d->counters = gCounters;
+    return d.release();
+}
+const char* refp_dyn_name(void* h) { return static_cast<RefDynamic*>(h)->instance->Name().c_str(); }
+void refp_dyn_unload(void* h) {
+    auto* d = static_cast<RefDynamic*>(h);
+    d->instance.reset();  // ~DynamicCProcessorProxy: finalize(plugin_state)
+    d->creator.reset();   // ~DynamicCProcessorCreator: CloseLib
+    delete d;
+}
+char* refp_dyn_process_json(void* h, const char* group_json, char* err, size_t errcap) {
+    auto* d = static_cast<RefDynamic*>(h);
+    std::vector<logtail::PipelineEventGroup> groups;
+    groups.emplace_back(std::make_shared<logtail::SourceBuffer>());
+    std::string error;
+    if (!hdGroupFromJson(groups[0], group_json, &error)) {
+        if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    static_cast<logtail::ProcessorInstance*>(d->instance.get())->Process(groups);
+    return dup(hdGroupToJson(groups[0]));
+}
+// {"in_events_total": .., "out_events_total": .., "in_size_bytes": .., "out_size_bytes": .., "total_process_time_ms": ..}: ProcessorInstance's
+char* refp_dyn_counters_json(void* h) {
+    auto* d = static_cast<RefDynamic*>(h);
+    std::string out = "{";
+    for (const auto& kv : d->counters) {
+        if (out.size() > 1) out += ",";
+        out += "\"" + kv.first + "\":" + std::to_string(kv.second->GetValue());
+    }
+    return dup(out + "}");
 }
 // discarded, out_failed, out_key_not_found, out_successful
 void refp_counters(void* h, uint64_t out[4]) {

@@ -4,6 +4,7 @@
 // under JsonCpp's names for the calls those files make (isMember, find, begin/end, is*/as*, operator[]).  The model headers only name
 // the type (ToJson / FromJson declarations).
 #pragma once
+#include <cstdio>
 #include <cstdint>
 #include <string>
 #include <utility>
@@ -95,6 +96,13 @@ public:
         for (const auto& kv : mObj) m.push_back(kv.first);
         return m;
     }
+    // JSON text of the tree (JsonCpp's writer formats with indentation; a reader cannot tell)
+    std::string toStyledString() const {
+        std::string out;
+        write(out);
+        out += '\n';
+        return out;
+    }
     class const_iterator {
     public:
         const_iterator(const Value* owner, size_t i) : mOwner(owner), mI(i) {}
@@ -118,6 +126,55 @@ public:
     const_iterator end() const { return const_iterator(this, size()); }
 
 private:
+    static void quote(std::string& out, const std::string& s) {
+        out += '"';
+        for (unsigned char c : s) {
+            if (c == '"' || c == '\\') {
+                out += '\\';
+                out += char(c);
+            } else if (c < 0x20) {
+                char buf[8];
+                std::snprintf(buf, sizeof buf, "\\u%04x", unsigned(c));
+                out += buf;
+            } else {
+                out += char(c);
+            }
+        }
+        out += '"';
+    }
+    void write(std::string& out) const {
+        switch (mType) {
+            case nullValue: out += "null"; break;
+            case booleanValue: out += mBool ? "true" : "false"; break;
+            case intValue:
+            case uintValue: out += std::to_string(mInt); break;
+            case realValue: {
+                char buf[40];
+                std::snprintf(buf, sizeof buf, "%.17g", mDouble);
+                out += buf;
+                break;
+            }
+            case stringValue: quote(out, mStr); break;
+            case arrayValue:
+                out += '[';
+                for (size_t i = 0; i < mArr.size(); ++i) {
+                    if (i) out += ',';
+                    mArr[i].write(out);
+                }
+                out += ']';
+                break;
+            case objectValue:
+                out += '{';
+                for (size_t i = 0; i < mObj.size(); ++i) {
+                    if (i) out += ',';
+                    quote(out, mObj[i].first);
+                    out += ':';
+                    mObj[i].second.write(out);
+                }
+                out += '}';
+                break;
+        }
+    }
     static const Value& null() {
         static const Value v;
         return v;

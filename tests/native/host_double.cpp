@@ -91,6 +91,9 @@ extern "C" int lc_regex_match_host_views(lc_regex_t* re, const uint8_t* const* l
     return LC_OK;
 }
 
+// -DHD_DOUBLES_ONLY: nothing but the five doubles above -- tests/test_plugin_slot_reference.py links them under the product's dlsym slot
+// (csrc/c_processor_slot.cpp in the agent's form) to get a plugin the REFERENCE's own loader and proxy can drive on a box without a GPU
+#ifndef HD_DOUBLES_ONLY
 #ifdef LC_USE_REFERENCE_HEADERS
 bool hdGroupFromJson(logtail::PipelineEventGroup& group, const std::string& json, std::string* error);  // ref_group_io.cpp
 std::string hdGroupToJson(const logtail::PipelineEventGroup& group);
@@ -354,3 +357,4 @@ extern "C" double hd_bench_stitch(hd_processor* p, const uint8_t* data, const ui
     if (dataSizeUs) *dataSizeUs = bestSize;
     return best;
 }
+#endif  // HD_DOUBLES_ONLY
