@@ -232,6 +232,19 @@ char* refp_process_chain_json(void* h1, void* h2, const char* group_json, char* 
     static_cast<RefProcessor*>(h2)->proc->Process(groups);
     return dup(hdGroupToJson(groups[0]));
 }
+// ... and through up to four, for the benchmark pipeline split -> parse -> filter (a null handle is skipped)
+char* refp_process_chain4_json(void* h1, void* h2, void* h3, void* h4, const char* group_json, char* err, size_t errcap) {
+    std::vector<logtail::PipelineEventGroup> groups;
+    groups.emplace_back(std::make_shared<logtail::SourceBuffer>());
+    std::string error;
+    if (!hdGroupFromJson(groups[0], group_json, &error)) {
+        if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    for (void* h : {h1, h2, h3, h4})
+        if (h) static_cast<RefProcessor*>(h)->proc->Process(groups);
+    return dup(hdGroupToJson(groups[0]));
+}
 // What the line splitter leaves, built directly: ONE copy of `data` in the group's source buffer, one log event per line whose `key`
 // content is a view of its line (timestamp = 1 + the line's index); an event WITHOUT contents in front of every line listed in
 // emptyBefore (ascending; the line count = behind the last line), the key "other" on the lines listed in otherKey -- the same group tests/native/multiline_double.cpp builds for the

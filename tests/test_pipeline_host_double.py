@@ -1,0 +1,231 @@
+"""The HOST translation unit of the fused benchmark pipeline (csrc/processor_pipeline_gpu.cpp: split -> processor_parse_regex -> processor_filter
+in one device trip per read buffer -- which configs and groups may travel fused, the events built from the survivors' rows, the three
+processors' counters reconstructed from the trip's counts -- and the chained path through the parser's and the filter's own classes) on a
+machine without a GPU, beside the REFERENCE's own three processors run one after the other (ProcessorSplitLogStringNative.cpp,
+ProcessorParseRegexNative.cpp, ProcessorFilterNative.cpp compiled from /root/reference: oracle/_ref/libref_processor.so).
+
+tests/native/pipeline_double.cpp stands in for the HIP runtime and the four device steps (restated from their contracts in
+include/lc_regex_gpu.h over the CPU oracle's regex).  Compared on generated pipeline configs and random groups of read buffers: the events
+left -- every field the fixture writers print, contents in order -- the parser's four counters and the filter's in / out counts.
+CPU only; skipped where the reference tree is not present (the GPU box)."""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+from test_reference_neighbours import RefPlugin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/core"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (/root/reference): its processors are compiled from there")
+
+_LIB = None
+
+
+def _double():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libpipeline_double.so")
+    csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
+    native = os.path.join(ROOT, "tests", "native")
+    srcs = [os.path.join(native, "pipeline_double.cpp")] + [os.path.join(csrc, f) for f in (
+        "c_processor_slot.cpp", "processor_pipeline_gpu.cpp", "processor_parse_regex_gpu.cpp", "processor_filter_gpu.cpp", "event_model.cpp")]
+    deps = srcs + [os.path.join(native, "filter_double.cpp")] + [os.path.join(csrc, h) for h in (
+        "event_model.hpp", "processor_pipeline_gpu.hpp", "processor_parse_regex_gpu.hpp", "processor_filter_gpu.hpp", "json_min.hpp", "trip_buffers.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        from loongcollector_amd import build as native_build
+        objdir = os.path.join(ROOT, "loongcollector_amd", "lib", "obj")
+        if not os.path.exists(os.path.join(objdir, "grok_defaults.inc")):
+            native_build.build_native()
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                               "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", objdir, "-o", so] + srcs +
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined"])
+    L = ctypes.CDLL(so)
+    vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
+    L.lc_pipeline_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
+    L.lc_pipeline_destroy.argtypes = [vp]
+    L.lc_pipeline_is_fused.argtypes = [vp]
+    L.lc_pipeline_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.pd_process_json.restype = vp
+    L.pd_process_json.argtypes = [vp, cp, cp, sz]
+    L.lc_free.argtypes = [vp]
+    R = RefPlugin.lib()
+    R.refp_process_chain4_json.restype = vp
+    R.refp_process_chain4_json.argtypes = [vp, vp, vp, vp, cp, cp, sz]
+    _LIB = L
+    return L
+
+
+def _whole(text):
+    d = json.loads(text, object_pairs_hook=list)
+    out = []
+    for ev in dict(d or []).get("events", []):
+        ev = dict(ev)
+        ev["contents"] = [tuple(kv) for kv in ev.get("contents", [])]
+        out.append(sorted(ev.items(), key=lambda kv: kv[0]))
+    return out
+
+
+class ProductPipeline:
+    def __init__(self, config):
+        self.L = _double()
+        self.h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if self.L.lc_pipeline_create(json.dumps(config).encode(), ctypes.byref(self.h), err, 512) != 0:
+            self.h = None
+            raise ValueError(err.value.decode("utf-8", "replace"))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lc_pipeline_destroy(self.h)
+            self.h = None
+
+    def fused(self):
+        return bool(self.L.lc_pipeline_is_fused(self.h))
+
+    def process(self, fixture):
+        err = ctypes.create_string_buffer(512)
+        p = self.L.pd_process_json(self.h, json.dumps(fixture).encode(), err, 512)
+        assert p, err.value
+        try:
+            return _whole(ctypes.string_at(p).decode("utf-8"))
+        finally:
+            self.L.lc_free(p)
+
+    def counters(self):
+        """-> ({the parser's four counters by the reference's names}, {filter_in, filter_out, groups_fused, groups_chained, lines, survivors})"""
+        parse = (ctypes.c_uint64 * 16)()
+        pipe = (ctypes.c_uint64 * 8)()
+        assert self.L.lc_pipeline_counters(self.h, parse, pipe) == 0
+        names = ("filter_in", "filter_out", "groups_fused", "groups_chained", "lines", "survivors")
+        return {k: int(parse[i]) for k, i in self._parse_index().items()}, {k: int(pipe[i]) for i, k in enumerate(names)}
+
+    _index = None
+
+    @classmethod
+    def _parse_index(cls):
+        """LC_CNT_* of include/lc_processor.h, read from the header: `NAME = value, /* reference counter name */`"""
+        if cls._index is None:
+            import re
+            with open(os.path.join(ROOT, "include", "lc_processor.h"), encoding="utf-8") as f:
+                text = f.read()
+            found = {m.group(3): int(m.group(2)) for m in re.finditer(r"(LC_CNT_\w+) = (\d+),\s*/\* (\w+_total) \*/", text)}
+            cls._index = {k: found[k] for k in ("discarded_events_total", "out_failed_events_total", "out_key_not_found_events_total",
+                                                "out_successful_events_total")}
+        return cls._index
+
+
+def _ref_chain(handles, fixture):
+    R = RefPlugin.lib()
+    err = ctypes.create_string_buffer(512)
+    hs = [h.h if h is not None else None for h in handles] + [None] * (4 - len(handles))
+    p = R.refp_process_chain4_json(hs[0], hs[1], hs[2], hs[3], json.dumps(fixture).encode(), err, 512)
+    assert p, err.value
+    try:
+        return _whole(ctypes.string_at(p).decode("utf-8"))
+    finally:
+        R.refp_free(p)
+
+
+LINES = ["GET 200 curl/8.1", "POST 404 Mozilla/5.0", "GET 301 Googlebot/2.1", "HEAD 204 bot", "garbage", "", "GET 2000 x", "PUT 500 ", "GET  200 two spaces",
+         "DELETE 200 café/1.0", "GET 200", " GET 200 lead"]
+PARSE_BASE = {"SourceKey": "content", "Regex": r"(\w+) (\d{3}) (.*)", "Keys": ["method", "status", "ua"]}
+PARSE_OPTIONS = [{}, {"KeepingSourceWhenParseFail": True}, {"KeepingSourceWhenParseSucceed": True, "RenamedSourceKey": "raw"},
+                 {"KeepingSourceWhenParseFail": True, "KeepingSourceWhenParseSucceed": True}, {"KeepingSourceWhenParseFail": True, "CopingRawLog": True},
+                 {"Keys": ["method", "status", "ua", "extra"], "KeepingSourceWhenParseFail": True},      # more keys than groups: never fused
+                 {"Keys": ["method", "status", "method"]},                                               # a key twice: never fused
+                 {"Regex": "(.*)", "Keys": ["whole"]}]                                                    # whole-line mode: never fused
+FILTERS = [None,
+           {"FilterKey": ["ua"], "FilterRegex": [".*(?:bot|curl).*"]},
+           {"FilterKey": ["status", "method"], "FilterRegex": ["2\\d\\d|30[14]", "GET|HEAD"]},
+           {"Include": {"status": "[23]\\d\\d"}},
+           {"FilterKey": ["ua"], "FilterRegex": [""]},                                                    # only an empty value passes
+           {"FilterKey": ["content"], "FilterRegex": ["GET.*"]},                                          # a rule on the source key: chained
+           {"FilterKey": ["raw"], "FilterRegex": [".*200.*"]},                                            # ... on the renamed source: chained
+           {"FilterKey": ["nokey"], "FilterRegex": [".*"]},                                               # ... on a key nobody writes: chained
+           {"FilterKey": ["ua"], "FilterRegex": [".*caf.*"], "DiscardingNonUTF8": True},                  # chained
+           {"ConditionExp": {"operator": "or", "operands": [{"type": "regex", "key": "status", "exp": "404"},
+                                                            {"operator": "not", "operands": [{"type": "regex", "key": "method", "exp": "GET"}]}]}}]
+
+
+def _group(rng):
+    events = []
+    for k in range(rng.randint(1, 3)):
+        val = "\n".join(rng.choice(LINES) for _ in range(rng.randint(0, 14))) + ("\n" if rng.random() < 0.4 else "")
+        kind = rng.random()
+        contents = [["content", val]] if kind < 0.9 else [["content", val], ["extra", "1"]] if kind < 0.95 else [["elsewhere", val]]
+        ev = {"contents": contents, "timestamp": 1700000000 + k, "type": 1}
+        if rng.random() < 0.6:
+            ev["timestampNanosecond"] = 7 * k
+        if rng.random() < 0.7:
+            ev["fileOffset"], ev["rawSize"] = 8192 * k + rng.randrange(50), len(val.encode("utf-8")) + rng.randrange(2)
+        events.append(ev)
+    g = {"events": events}
+    if rng.random() < 0.4:
+        g["metadata"] = {"log.file.offset": "__file_offset__"}
+    if rng.random() < 0.4:
+        g["tags"] = {"host": "h1", "path": "/var/log/x"}
+    return g
+
+
+def test_generated_pipelines_beside_the_reference_s_three_processors():
+    rng = random.Random(20260922)
+    fused_configs = chained_configs = fused_groups = chained_groups = 0
+    for options in PARSE_OPTIONS:
+        for filt in FILTERS:
+            parse = dict(PARSE_BASE, **options)
+            config = {"Split": {"SourceKey": "content", "SplitChar": "\n"}, "Parse": parse, "Fused": True}
+            if filt is not None:
+                config["Filter"] = filt
+            prod = ProductPipeline(config)
+            split = RefPlugin("processor_split_string_native", {"SplitChar": 10})
+            rparse = RefPlugin("processor_parse_regex_native", parse)
+            rfilter = RefPlugin("processor_filter_regex_native", filt) if filt is not None else None
+            fused_configs += prod.fused()
+            chained_configs += not prod.fused()
+            filter_in = filter_out = 0
+            for _ in range(40):
+                g = _group(rng)
+                RefPlugin.lib().refp_free(RefPlugin.lib().refp_take_alarms())
+                got = prod.process(g)
+                want = _ref_chain([split, rparse, rfilter], g)
+                assert got == want, (config, g)
+                if rfilter is not None:      # what the reference's filter saw: the same group through a second splitter + parser
+                    s2, p2 = RefPlugin("processor_split_string_native", {"SplitChar": 10}), RefPlugin("processor_parse_regex_native", parse)
+                    filter_in += len(_ref_chain([s2, p2], g))
+                    filter_out += len(want)
+            pc, pipe = prod.counters()
+            rc = rparse.counters()
+            assert pc == {k: rc[k] for k in pc}, (config, pc, rc)
+            if rfilter is not None:
+                assert (pipe["filter_in"], pipe["filter_out"]) == (filter_in, filter_out), (config, pipe)
+            assert pipe["groups_fused"] + pipe["groups_chained"] == 40
+            assert prod.fused() or pipe["groups_fused"] == 0
+            fused_groups += pipe["groups_fused"]
+            chained_groups += pipe["groups_chained"]
+    # both paths were really taken: configs that may travel fused and configs that may not; fused groups, and groups that a fused config
+    # had to send down the chained path (an event that is no plain read buffer)
+    assert fused_configs >= 15 and chained_configs >= 40 and fused_groups > 300 and chained_groups > 1300
+
+
+def test_fused_and_chained_give_the_same_group():
+    """"Fused": false forces the three steps one after the other on a config that may travel fused: the same events and counters"""
+    rng = random.Random(3)
+    parse = dict(PARSE_BASE, KeepingSourceWhenParseFail=True)
+    filt = {"FilterKey": ["status", "ua"], "FilterRegex": ["2\\d\\d", ".*(?:bot|curl|x).*"]}
+    a = ProductPipeline({"Split": {"SourceKey": "content", "SplitChar": "\n"}, "Parse": parse, "Filter": filt, "Fused": True})
+    b = ProductPipeline({"Split": {"SourceKey": "content", "SplitChar": "\n"}, "Parse": parse, "Filter": filt, "Fused": False})
+    assert a.fused() and not b.fused()
+    for _ in range(60):
+        g = _group(rng)
+        assert a.process(g) == b.process(g), g
+    (pa, qa), (pb, qb) = a.counters(), b.counters()
+    assert pa == pb and (qa["filter_in"], qa["filter_out"]) == (qb["filter_in"], qb["filter_out"])
+    assert qa["groups_fused"] > 30 and qb["groups_fused"] == 0
