@@ -37,7 +37,7 @@ def _double():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
                                "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so] + srcs +
-                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined"])
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
     L = ctypes.CDLL(so)
     vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
     L.lc_filter_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]

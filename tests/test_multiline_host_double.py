@@ -47,7 +47,7 @@ def _double():
     os.makedirs(out_dir, exist_ok=True)
     csrc = os.path.join(ROOT, "loongcollector_amd", "csrc")
     native = os.path.join(ROOT, "tests", "native")
-    common = ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined"]
+    common = ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined", "-Wl,-Bsymbolic"]
     if _VARIANT == "reference":
         so = os.path.join(out_dir, "libmultiline_double_ref.so")
         ref_lib = os.path.join(ROOT, "oracle", "_ref")

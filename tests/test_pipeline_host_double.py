@@ -46,7 +46,7 @@ def _double():
             native_build.build_native()
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
                                "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", objdir, "-o", so] + srcs +
-                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined"])
+                              ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
     L = ctypes.CDLL(so)
     vp, cp, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t
     L.lc_pipeline_create.argtypes = [cp, ctypes.POINTER(vp), cp, sz]
