@@ -30,6 +30,7 @@
 #include "common/DynamicLibHelper.h"
 #include "monitor/MetricManager.h"
 #include "plugin/processor/ProcessorParseRegexNative.h"
+#include "protobuf/sls/LogGroupSerializer.h"
 #include "plugin/processor/inner/ProcessorMergeMultilineLogNative.h"
 #include "plugin/processor/inner/ProcessorSplitLogStringNative.h"
 #include "plugin/processor/inner/ProcessorSplitMultilineLogStringNative.h"
@@ -139,6 +140,12 @@ bool BoostRegexSearch(const char* buffer, size_t size, const boost::regex& reg, 
         exception.append(e.what());
         return false;
     }
+}
+// common/TimeUtil.cpp:440-448 (only the metric-event writer of LogGroupSerializer.cpp calls it: the last `length` digits, zero-padded)
+std::string NumberToDigitString(uint32_t number, uint8_t length) {
+    std::string digits = std::to_string(number);
+    if (digits.size() < length) digits.insert(0, length - digits.size(), '0');
+    return digits.substr(digits.size() - length);
 }
 std::string ToLowerCaseString(const std::string& orig) {
     std::string copy = orig;
@@ -392,6 +399,75 @@ char* refp_dyn_counters_json(void* h) {
         out += "\"" + kv.first + "\":" + std::to_string(kv.second->GetValue());
     }
     return dup(out + "}");
+}
+// ------------------------------------------------------------------------------------------------ the serializer side (section 8 f, rank 4)
+// The log events of a group on the SLS wire, by the reference's own writer (protobuf/sls/LogGroupSerializer.cpp, compiled): the two passes
+// of SLSEventGroupSerializer -- CalculateLogEventSize (SLSSerializer.cpp:254-268) and SerializeLogEvent (:377-395), restated here because
+// SLSSerializer.cpp itself needs the compressor, the batch types and the flusher's context -- over the events a processor left.
+// h: a processor to run first, or null.  -> malloc'ed bytes, *out_len
+char* refp_sls_serialize_group_json(void* h, const char* group_json, int enable_ns, size_t* out_len, char* err, size_t errcap) {
+    std::vector<logtail::PipelineEventGroup> groups;
+    groups.emplace_back(std::make_shared<logtail::SourceBuffer>());
+    std::string error;
+    if (!hdGroupFromJson(groups[0], group_json, &error)) {
+        if (err && errcap) snprintf(err, errcap, "%s", error.c_str());
+        return nullptr;
+    }
+    if (h) static_cast<RefProcessor*>(h)->proc->Process(groups);
+    const auto& events = groups[0].GetEvents();
+    size_t logGroupSZ = 0;
+    std::vector<size_t> logSZ(events.size());
+    for (size_t i = 0; i < events.size(); ++i) {  // CalculateLogEventSize
+        const auto& e = events[i].Cast<logtail::LogEvent>();
+        if (e.Empty()) continue;
+        size_t contentSZ = 0;
+        for (const auto& kv : e) contentSZ += logtail::GetLogContentSize(kv.first.size(), kv.second.size());
+        logGroupSZ += logtail::GetLogSize(contentSZ, enable_ns && e.GetTimestampNanosecond(), logSZ[i]);
+    }
+    logtail::LogGroupSerializer serializer;
+    serializer.Prepare(logGroupSZ);
+    for (size_t i = 0; i < events.size(); ++i) {  // SerializeLogEvent
+        const auto& e = events[i].Cast<logtail::LogEvent>();
+        if (e.Empty()) continue;
+        serializer.StartToAddLog(logSZ[i]);
+        serializer.AddLogTime(e.GetTimestamp());
+        for (const auto& kv : e) serializer.AddLogContent(kv.first, kv.second);
+        if (enable_ns && e.GetTimestampNanosecond()) serializer.AddLogTimeNs(e.GetTimestampNanosecond().value());
+    }
+    const std::string& res = serializer.GetResult();
+    char* out = static_cast<char*>(malloc(res.size() + 1));
+    memcpy(out, res.data(), res.size());
+    *out_len = res.size();
+    return out;
+}
+// The same writer fed from a COLUMNAR table (the product's lc_columnar_t, include/lc_processor.h, passed as plain arrays): no LogEvent
+// holds the fields; the size pass is content_bytes[i] as the product computed it, the write pass takes key k and the span
+// [begin, end) of the event's source value.  state[i] == 1: parsed (others are not written).  ns[i] < 0: no nanosecond part.
+char* refp_sls_serialize_columnar(uint32_t n_events, uint32_t n_keys, const char* const* keys, const uint32_t* key_len,
+                                  const uint8_t* const* base, const int32_t* spans, const uint8_t* state, const uint64_t* content_bytes,
+                                  const uint32_t* timestamps, const int64_t* ns, int enable_ns, size_t* out_len) {
+    size_t logGroupSZ = 0;
+    std::vector<size_t> logSZ(n_events);
+    for (uint32_t i = 0; i < n_events; ++i)
+        if (state[i] == 1) logGroupSZ += logtail::GetLogSize(size_t(content_bytes[i]), enable_ns && ns[i] >= 0, logSZ[i]);
+    logtail::LogGroupSerializer serializer;
+    serializer.Prepare(logGroupSZ);
+    for (uint32_t i = 0; i < n_events; ++i) {
+        if (state[i] != 1) continue;
+        serializer.StartToAddLog(logSZ[i]);
+        serializer.AddLogTime(timestamps[i]);
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            const int32_t b = spans[(size_t(i) * n_keys + k) * 2], e = spans[(size_t(i) * n_keys + k) * 2 + 1];
+            const logtail::StringView value = b < 0 ? logtail::StringView() : logtail::StringView(reinterpret_cast<const char*>(base[i]) + b, size_t(e - b));
+            serializer.AddLogContent(logtail::StringView(keys[k], key_len[k]), value);
+        }
+        if (enable_ns && ns[i] >= 0) serializer.AddLogTimeNs(uint32_t(ns[i]));
+    }
+    const std::string& res = serializer.GetResult();
+    char* out = static_cast<char*>(malloc(res.size() + 1));
+    memcpy(out, res.data(), res.size());
+    *out_len = res.size();
+    return out;
 }
 // discarded, out_failed, out_key_not_found, out_successful
 void refp_counters(void* h, uint64_t out[4]) {
