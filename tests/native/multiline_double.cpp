@@ -36,6 +36,7 @@ std::string hdGroupToJson(const logtail::PipelineEventGroup& g);
 #include "../../oracle/bt_regex.h"
 
 // ---------------------------------------------------------------------------------------------- the doubles
+#ifndef MD_NO_REGEX_DOUBLES  // (tests/native/race_driver.cpp links this file next to filter_double.cpp, which has the regex doubles)
 struct lc_regex {
     orx_prog* prog = nullptr;
     std::string pattern;
@@ -61,6 +62,7 @@ extern "C" void lc_regex_free(lc_regex_t* re) {
     delete re;
 }
 extern "C" const char* lc_last_error(void) { return tLastError.c_str(); }
+#endif  // MD_NO_REGEX_DOUBLES
 
 namespace {
 uint8_t answers(const lc_multiline* m, const uint8_t* s, uint32_t n) {
