@@ -188,8 +188,12 @@ namespace {
 const char kPartLogFlag[] = "P";  // ProcessorMergeMultilineLogNative::PartLogFlag :31
 
 // MergeEvents :332-358: the first event's value is extended IN PLACE over the following ones (the events of one read buffer
-// lie back to back in the group's source buffer, each followed by the byte its line feed occupied)
-void mergeEvents(lc_merge_multiline& p, std::vector<LogEvent*>& logEvents, bool insertLineBreak) {
+// lie back to back in the group's source buffer, each followed by the byte its line feed occupied).  That is the layout the line
+// splitter leaves, and the reference relies on it: its memmove runs over whatever lies between two values.  Here the in-place join is
+// taken when the values DO lie that way -- value, one byte, value -- and the same bytes are put together in a fresh block of the
+// group's source buffer when they do not (values a fixture reader or another processor copied one by one: between them lie keys,
+// and, in the stand-in event model, the events' own contents arrays).  The merged value is the same either way.
+void mergeEvents(lc_merge_multiline& p, PipelineEventGroup& logGroup, std::vector<LogEvent*>& logEvents, bool insertLineBreak) {
     if (logEvents.empty()) return;
     p.mergedEventsTotal += logEvents.size();
     if (logEvents.size() == 1) {
@@ -199,7 +203,21 @@ void mergeEvents(lc_merge_multiline& p, std::vector<LogEvent*>& logEvents, bool 
     const StringView key(p.sourceKey.data(), p.sourceKey.size());
     LogEvent* target = logEvents[0];
     const StringView targetValue = target->GetContent(key);
+    bool backToBack = true;
+    size_t total = targetValue.size();
+    const char* prevEnd = targetValue.data() + targetValue.size();
+    for (size_t i = 1; i < logEvents.size(); ++i) {
+        const StringView cur = logEvents[i]->GetContent(key);
+        backToBack = backToBack && cur.data() == prevEnd + 1;
+        prevEnd = cur.data() + cur.size();
+        total += cur.size() + (insertLineBreak ? 1 : 0);
+    }
     char* begin = const_cast<char*>(targetValue.data());
+    if (!backToBack) {
+        const StringBuffer block = logGroup.GetSourceBuffer()->AllocateStringBuffer(total);
+        begin = block.data;
+        std::memcpy(begin, targetValue.data(), targetValue.size());
+    }
     char* end = begin + targetValue.size();
     for (size_t i = 1; i < logEvents.size(); ++i) {
         if (insertLineBreak) *end++ = '\n';
@@ -230,7 +248,7 @@ void mergeLogsByFlag(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
         events.emplace_back(sourceEvent);
         if (isPartialLog) {
             if (!sourceEvent->HasContent(flag)) {  // p p p ... p(last) notP(cur)
-                mergeEvents(p, events, false);
+                mergeEvents(p, logGroup, events, false);
                 sourceEvents[size++] = std::move(sourceEvents[begin]);
                 begin = cur + 1;
                 isPartialLog = false;
@@ -239,13 +257,13 @@ void mergeLogsByFlag(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
             sourceEvent->DelContent(flag);
             isPartialLog = true;
         } else {
-            mergeEvents(p, events, false);
+            mergeEvents(p, logGroup, events, false);
             sourceEvents[size++] = std::move(sourceEvents[begin]);
             begin = cur + 1;
         }
     }
     if (isPartialLog) {
-        mergeEvents(p, events, false);
+        mergeEvents(p, logGroup, events, false);
         sourceEvents[size++] = std::move(sourceEvents[begin]);
     }
     sourceEvents.resize(size);
@@ -305,7 +323,7 @@ int mergeLogsByRegex(lc_merge_multiline& p, PipelineEventGroup& logGroup) {  // 
         if (recs[r].matched & 1u) {  // MergeEvents :332-358 + the move of the log's first event
             events.clear();
             for (uint32_t k = first; k < first + cnt; ++k) events.push_back(&sourceEvents[itemEvent[k]].Cast<LogEvent>());
-            mergeEvents(p, events, true);
+            mergeEvents(p, logGroup, events, true);
             sourceEvents[newSize++] = std::move(sourceEvents[endOnly ? endOnlyBegin : size_t(itemEvent[first])]);
             endOnlyBegin = size_t(itemEvent[first + cnt - 1]) + 1;
             continue;

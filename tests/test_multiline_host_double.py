@@ -397,3 +397,35 @@ def test_multiline_splitter_host_code_beside_the_reference_on_random_groups():
             assert got == want, (config, g)
         c = ref.counters()
         assert p.counters() == (c["matched_lines_total"], c["unmatched_lines_total"], c["matched_events_total"]), config
+
+
+def test_merge_of_values_that_do_not_lie_back_to_back():
+    """The reference's MergeEvents memmoves in place and relies on the splitter's layout (:332-358).  Values a fixture reader copied one by
+    one have keys between them -- and, in the stand-in event model, the events' own contents arrays: the product joins such values in a
+    fresh block of the group's source buffer.  The merged values are what the reference's code leaves under the source key (what it
+    leaves of the OTHER strings of such a group is an accident of the layout and is not compared)."""
+    rng = random.Random(99)
+    lines = [ln.decode() for ln in POOL]
+    for config in (MERGE_CONFIGS[0], MERGE_CONFIGS[2], MERGE_CONFIGS[4], MERGE_CONFIGS[8]):
+        p = ProductMerge(MergeType="regex", **config)
+        ref = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+        for _ in range(60):
+            vals = [rng.choice(lines) for _ in range(rng.randint(1, 12))]
+            g = {"events": [{"contents": [["content", v]] + ([["k%d" % (i % 3), "other"]] if rng.random() < 0.5 else []), "timestamp": i + 1, "type": 1}
+                            for i, v in enumerate(vals)]}
+            got = p.json(g)
+            want = [(dict(e)["timestamp"], dict(dict(e)["contents"]).get("content")) for e in ref.process(g)]
+            assert [(ts, dict(kv).get("content")) for ts, kv in got] == want, (config, vals)
+            # ... and nothing else of the surviving events was touched
+            for ts, kv in got:
+                extra = [(k, v) for k, v in kv if k != "content"]
+                assert extra == [(k, v) for k, v in (tuple(x) for x in g["events"][ts - 1]["contents"]) if k != "content"], (config, vals)
+        assert p.counters() == _ref_merge_counters(ref)
+    # flag mode: partial logs whose values are NOT neighbours (a container runtime's lines carry a prefix between them)
+    p = ProductMerge(MergeType="flag")
+    parts = [("a" * 40, True), ("b" * 3, True), ("c", False), ("solo", False), ("d" * 100, True), ("e", False)]
+    g = {"metadata": {"has.part.log": "P"},
+         "events": [{"contents": [["content", t], ["stream", "stdout"]] + ([["P", ""]] if part else []), "timestamp": i + 1, "type": 1} for i, (t, part) in enumerate(parts)]}
+    got = p.json(g)
+    assert [(ts, dict(kv)) for ts, kv in got] == [(1, {"content": "a" * 40 + "bbb" + "c", "stream": "stdout"}), (4, {"content": "solo", "stream": "stdout"}),
+                                                   (5, {"content": "d" * 100 + "e", "stream": "stdout"})]
