@@ -429,3 +429,82 @@ def test_merge_of_values_that_do_not_lie_back_to_back():
     got = p.json(g)
     assert [(ts, dict(kv)) for ts, kv in got] == [(1, {"content": "a" * 40 + "bbb" + "c", "stream": "stdout"}), (4, {"content": "solo", "stream": "stdout"}),
                                                    (5, {"content": "d" * 100 + "e", "stream": "stdout"})]
+
+
+PATTERN_POOL = [r"\d{4}-\d{2}-\d{2} .*", r"\[\w+\].*", "BEGIN.*", r"END\d*", r"\s+at\s.*", r"\}", ";$", r"\}$", r"\[\w+\]$", ".*", "END", "stmt;.*$", "x.*", "$",
+                ".*.*$", r"END\d$", "(", r"a\.*"]
+
+
+def _generated_multiline_config(rng):
+    config = {}
+    if rng.random() < 0.7:
+        config["StartPattern"] = rng.choice(PATTERN_POOL)
+    if rng.random() < 0.4:
+        config["ContinuePattern"] = rng.choice(PATTERN_POOL)
+    if rng.random() < 0.5:
+        config["EndPattern"] = rng.choice(PATTERN_POOL)
+    if rng.random() < 0.4:
+        config["UnmatchedContentTreatment"] = rng.choice(["discard", "single_line"])
+    return config
+
+
+def test_generated_pattern_combinations_through_both_processors():
+    """Random combinations of start / continue / end patterns -- with and without trailing '$' and ".*", patterns that are nothing but
+    those, patterns that are no regex -- through the merge processor (which reads them as MultilineOptions' stripped regexes) and through
+    the splitter (which compiles the strings as written), each beside the reference's: which patterns the merge processor keeps, the
+    events, the counters.  A config that leaves the merge processor neither a start nor an end pattern is refused by the product; the
+    reference's Init accepts it and its walk dereferences a null regex (ProcessorMergeMultilineLogNative.cpp:219-224)."""
+    import re
+
+    def stripped(p):
+        if p.endswith("$"):
+            p = p[:-1]
+        while p.endswith(".*"):
+            p = p[:-2]
+        return p
+
+    def is_regex(p):
+        try:
+            re.compile(p)
+            return True
+        except re.error:
+            return False
+
+    rng = random.Random(2026)
+    merged_groups = refused = split_groups = 0
+    for trial in range(400):
+        config = _generated_multiline_config(rng)
+        eff = {k: stripped(v) for k, v in config.items() if k.endswith("Pattern")}
+
+        def usable(k):
+            return k in eff and eff[k] != "" and is_regex(eff[k])
+        if not (usable("StartPattern") or usable("EndPattern")):
+            with pytest.raises(ValueError):
+                ProductMerge(MergeType="regex", **config)
+            refused += 1
+        else:
+            p = ProductMerge(MergeType="regex", **config)
+            ref = RefPlugin("processor_merge_multiline_log_native", dict(config, MergeType="regex"))
+            mask = (1 if usable("StartPattern") else 0) | (2 if usable("ContinuePattern") else 0) | (4 if usable("EndPattern") else 0)
+            assert p.patterns() == (5 if mask == 7 else mask), config
+            for _ in range(8):
+                k = rng.randint(1, 20)
+                data = b"\n".join(rng.choice(POOL) for _ in range(k))
+                empties = sorted(rng.randint(0, k) for _ in range(rng.choice([0, 0, 1, 3])))
+                assert p.lines(data, empties) == _ref_lines(ref, data, empties), (config, data, empties)
+                merged_groups += 1
+            assert p.counters() == _ref_merge_counters(ref), config
+        # the splitter: the strings as written, all three kept; refused by the product without a start or an end pattern that is a regex
+        try:
+            s = ProductSplit(**config)
+        except ValueError:
+            continue
+        sref = RefPlugin("processor_split_multiline_log_string_native", config)
+        for _ in range(6):
+            val = b"\n".join(rng.choice(POOL) for _ in range(rng.randint(1, 14))).decode() + ("\n" if rng.random() < 0.3 else "")
+            g = _one_event(val)
+            assert s.whole(g) == _whole_events(sref.process(g)), (config, val)
+            split_groups += 1
+        c = sref.counters()
+        assert s.counters() == (c["matched_lines_total"], c["unmatched_lines_total"], c["matched_events_total"]), config
+    assert merged_groups > 1500 and refused > 50 and split_groups > 1200
