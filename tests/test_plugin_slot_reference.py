@@ -231,3 +231,62 @@ def test_the_plugin_beside_the_static_processor_in_the_reference_s_processor_ins
     assert cd["in_events_total"] == cd["out_events_total"] if options.get("KeepingSourceWhenParseFail") else cd["in_events_total"] > cd["out_events_total"]
     dyn.unload()
     sta.unload()
+
+
+def test_generated_parser_configs_through_the_slot_beside_the_static_processor(agent):
+    """Generated configs -- regexes with groups that may not take part, none, or whole-line mode; fewer / more Keys than groups; Keys that
+    collide with the source key, the renamed source key and the legacy raw-log keys; every option on and off; other source keys -- accepted
+    or refused alike by the plugin's init (through the reference's proxy) and the reference's own Init, and on accepted ones: the same events,
+    the same alarms, the same instance counters.  (A 10 000-group run of the same generator: no difference.)"""
+    rng = random.Random(1)
+    regexes = [(r"(\w+)\t(\w+).*", 2), (r"(\w+) (\d{3}) (.*)", 3), (r"(\S+)", 1), ("(.*)", 1), (r"(a)|(b)", 2), (r"(\w+)\t?(\w*)", 2), (r"no groups", 0),
+               (r"(?:x)(\d+)y", 1)]
+    key_pool = ["k1", "k2", "k3", "content", "raw", "__raw_log__", "__raw__", "other"]
+    lines = ["GET\t200 rest", "POST 404 ua", "nomatch", "", "a\tb", "x\ty z", "a", "b", "x12y", "no groups", "GET 200 curl", "ünï\tcödé"]
+    groups = refused = 0
+    for trial in range(300):
+        rx, ngroups = rng.choice(regexes)
+        nkeys = rng.choice([ngroups, ngroups, ngroups, max(0, ngroups - 1), ngroups + 1, 0])
+        config = {"SourceKey": rng.choice(["content", "content", "other"]), "Regex": rx, "Keys": [rng.choice(key_pool) for _ in range(nkeys)]}
+        for opt in ("KeepingSourceWhenParseFail", "KeepingSourceWhenParseSucceed", "CopingRawLog"):
+            if rng.random() < 0.5:
+                config[opt] = rng.random() < 0.7
+        if rng.random() < 0.4:
+            config["RenamedSourceKey"] = rng.choice(key_pool + [""])
+        try:
+            sta = Slot.static(agent, config)
+        except ValueError:
+            sta = None
+        try:
+            dyn = Slot.dynamic(agent, config)
+        except ValueError:
+            dyn = None
+        assert (sta is None) == (dyn is None), (config, "the reference refuses" if sta is None else "the reference accepts")
+        if sta is None:
+            refused += 1
+            continue
+        dyn.alarms()
+        for _ in range(4):
+            events = []
+            for k in range(rng.randint(0, 10)):
+                kind = rng.random()
+                contents = [[config["SourceKey"], rng.choice(lines)]]
+                if kind > 0.8:
+                    contents.append([rng.choice(key_pool), "pre-existing"])
+                if kind > 0.95:
+                    contents = [["elsewhere", "v"]]
+                events.append({"contents": contents, "timestamp": 1 + k, "type": 1})
+            g = {"events": events}
+            if rng.random() < 0.3:
+                g["metadata"] = {"log.file.offset": "__file_offset__"}
+            a = dyn.process(g)
+            alarms_dyn = dyn.alarms()
+            b = sta.process(g)
+            assert a == b, (config, g)
+            assert alarms_dyn == sta.alarms(), (config, g)
+            groups += 1
+        cd, cs = dyn.counters(), sta.counters()
+        assert cd == {k: cs[k] for k in cd}, config
+        dyn.unload()
+        sta.unload()
+    assert groups > 800 and refused > 50
