@@ -16,6 +16,7 @@ import ctypes
 import itertools
 import json
 import os
+import random
 import subprocess
 
 import numpy as np
@@ -489,3 +490,60 @@ def test_the_reference_s_own_processor_beside_the_product(double, golden_dir):
             RefProcessor(bad)
         with pytest.raises(ValueError):
             HostProcessor(double, bad)
+
+
+def test_generated_configs_beside_the_reference_s_processor(double):
+    """Generated parser configs (the generator of tests/test_plugin_slot_reference.py: groups that may not take part, fewer / more Keys than
+    groups, Keys colliding with the source key, the renamed source key and the raw-log keys, every option on and off) through this build
+    of the product's host code -- the bulk stitch of the stand-in, the per-key stitch of the reference-shaped and reference-model builds --
+    beside the reference's own processor: refused alike, the same events, counters and alarm texts.  (A 7 000-group run: no difference.)"""
+    if not os.path.isdir(REF):
+        pytest.skip("needs the reference tree (/root/reference)")
+    rng = random.Random(4)
+    regexes = [(r"(\w+)\t(\w+).*", 2), (r"(\w+) (\d{3}) (.*)", 3), (r"(\S+)", 1), ("(.*)", 1), (r"(a)|(b)", 2), (r"(\w+)\t?(\w*)", 2), (r"no groups", 0),
+               (r"(?:x)(\d+)y", 1)]
+    key_pool = ["k1", "k2", "k3", "content", "raw", "__raw_log__", "__raw__", "other"]
+    lines = ["GET\t200 rest", "POST 404 ua", "nomatch", "", "a\tb", "x\ty z", "a", "b", "x12y", "no groups", "GET 200 curl", "ünï\tcödé"]
+    groups = refused = 0
+    for trial in range(200):
+        rx, ngroups = rng.choice(regexes)
+        nkeys = rng.choice([ngroups, ngroups, ngroups, max(0, ngroups - 1), ngroups + 1, 0])
+        config = {"SourceKey": rng.choice(["content", "content", "other"]), "Regex": rx, "Keys": [rng.choice(key_pool) for _ in range(nkeys)]}
+        for opt in ("KeepingSourceWhenParseFail", "KeepingSourceWhenParseSucceed", "CopingRawLog"):
+            if rng.random() < 0.5:
+                config[opt] = rng.random() < 0.7
+        if rng.random() < 0.4:
+            config["RenamedSourceKey"] = rng.choice(key_pool + [""])
+        try:
+            ref = RefProcessor(config)
+        except ValueError:
+            ref = None
+        try:
+            mine = HostProcessor(double, config)
+        except ValueError:
+            mine = None
+        assert (mine is None) == (ref is None), config
+        if ref is None:
+            refused += 1
+            continue
+        double.hd_want_alarms(mine.h)
+        for _ in range(3):
+            events = []
+            for j in range(rng.randint(0, 10)):
+                kind = rng.random()
+                contents = [[config["SourceKey"], rng.choice(lines)]]
+                if kind > 0.8:
+                    contents.append([rng.choice(key_pool), "pre-existing"])
+                if kind > 0.95:
+                    contents = [["elsewhere", "v"]]
+                events.append({"contents": contents, "timestamp": 1 + j, "type": 1})
+            g = {"events": events}
+            if rng.random() < 0.3:
+                g["metadata"] = {"log.file.offset": "__file_offset__"}
+            want, got = ref.process(g), mine.process(g)
+            assert got == want, (config, g)
+            assert [m for _, m in mine.alarms()] == [m for _, m in ref.take_alarms()], (config, g)
+            groups += 1
+        c = mine.counters()
+        assert {k: c[k] for k in ("discarded", "out_failed", "out_key_not_found", "out_successful")} == ref.counters(), config
+    assert groups > 400 and refused > 30
