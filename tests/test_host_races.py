@@ -42,8 +42,9 @@ def test_runner_threads_on_shared_instances_under_thread_sanitizer():
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-w", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
                                "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", objdir, "-o", exe] + srcs + ["-lpthread"])
-    r = subprocess.run([exe, "8", "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    env.pop("LD_PRELOAD", None)   # (tools/asan_check.sh runs the suite with ASan's runtime preloaded: two sanitizer runtimes do not share a process)
+    r = subprocess.run([exe, "8", "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     assert "0 mismatching groups, 0 counters off" in r.stdout, r.stdout
