@@ -26,6 +26,7 @@ struct FilterThread {
     ~FilterThread();
 };
 thread_local FilterThread tlsFilter;
+constexpr size_t kFlagBytes = 64;  // hStatus: [completion word, one cache line][status bytes]
 }  // namespace
 void lcRegisterExitHook();
 bool lcRuntimeUsable();  // gpu_runtime.hip
@@ -336,7 +337,7 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
         FILTER_TRY(T.hIn.ensure(upBytes));
         if (getenv("LC_FILTER_COPY_TRIP")) FILTER_TRY(T.dIn.ensure(upBytes));
         FILTER_TRY(T.dStatus.ensure(totalVals + 64));
-        FILTER_TRY(T.hStatus.ensure(totalVals + 192));
+        FILTER_TRY(T.hStatus.ensure(kFlagBytes + totalVals + 192));
         uint8_t* h = static_cast<uint8_t*>(T.hIn.p);
         uint32_t* hOff = reinterpret_cast<uint32_t*>(h + dataBytes);
         uint32_t* hLen = hOff + totalVals;
@@ -358,8 +359,15 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
         // thread met: 11.3 GB/s with 16 threads, 8.4 with 32.  LC_FILTER_COPY_TRIP=1 keeps the copies (A/B measurements).
         static const bool copyTrip = getenv("LC_FILTER_COPY_TRIP") != nullptr;
         const uint8_t* dData = h;
-        uint8_t* dStatus = static_cast<uint8_t*>(T.hStatus.p);
-        uint32_t* hFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(T.hStatus.p) + ((totalVals + 63) & ~size_t(63)));  // (ensure: + 64)
+        // The completion word has a home of its own, the FIRST 64 bytes of the block, and the status bytes lie behind it: through
+        // round 5 it sat behind the status bytes, i.e. it moved with the group's size, and a shorter group found an earlier group's
+        // status bytes (0..3 each: 0x00000100 = trip 256, 0x00000101 = 257 ...) where it expected its own trip number -- the wait
+        // could return before the kernels had finished.  It is also cleared before every trip: a block that `ensure` has just
+        // grown is fresh pinned memory with whatever it held.
+        uint8_t* const hStatusBytes = static_cast<uint8_t*>(T.hStatus.p) + kFlagBytes;
+        uint8_t* dStatus = hStatusBytes;
+        volatile uint32_t* hFlag = reinterpret_cast<volatile uint32_t*>(T.hStatus.p);
+        *hFlag = 0;
         if (copyTrip) {
             if (lc_upload_pinned(T.hIn.p, T.dIn.p, upBytes, T.stream) != LC_OK) return fail(lc_last_error());
             dData = static_cast<const uint8_t*>(T.dIn.p);
@@ -383,17 +391,18 @@ bool ProcessorFilterGpu::Process(PipelineEventGroup& logGroup, std::string& erro
             return fail(lc_last_error());
         }
         if (copyTrip) {
-            FILTER_TRY(hipMemcpyAsync(T.hStatus.p, dStatus, totalVals, hipMemcpyDeviceToHost, T.stream));
+            FILTER_TRY(hipMemcpyAsync(hStatusBytes, dStatus, totalVals, hipMemcpyDeviceToHost, T.stream));
             FILTER_TRY(hipStreamSynchronize(T.stream));
         } else {
             const uint32_t seq = ++T.tripSeq ? T.tripSeq : ++T.tripSeq;  // (never 0: the word starts as 0)
-            if (lcQueueTripSignal(hFlag, seq, T.stream) != LC_OK || lcAwaitTripSignal(hFlag, seq, T.stream) != LC_OK) {
+            uint32_t* const flagWord = const_cast<uint32_t*>(hFlag);
+            if (lcQueueTripSignal(flagWord, seq, T.stream) != LC_OK || lcAwaitTripSignal(flagWord, seq, T.stream) != LC_OK) {
                 (void)hipStreamSynchronize(T.stream);  // (nothing queued here may still write the status block when the next trip reuses it)
                 return fail(lc_last_error());
             }
         }
 #undef FILTER_TRY
-        const uint8_t* status = static_cast<const uint8_t*>(T.hStatus.p);
+        const uint8_t* status = hStatusBytes;
         k = 0;
         for (size_t l = 0; l < mLeaves.size(); ++l)
             for (const Val& v : vals[l]) {

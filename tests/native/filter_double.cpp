@@ -34,14 +34,17 @@ hipError_t hipFree(void* p) {
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
-    *p = std::calloc(1, n ? n : 1);
+    *p = std::malloc(n ? n : 1);
+    if (*p) std::memset(*p, 0x01, n ? n : 1);  // pinned memory is NOT handed out zeroed: every byte reads LC_MATCH / 0x01010101
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipHostFree(void* p) {
     std::free(p);
     return hipSuccess;
 }
+static void runQueued();
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) {
+    runQueued();  // (stream order: the copy sits behind the kernels queued before it)
     std::memcpy(dst, src, n);
     return hipSuccess;
 }
@@ -53,7 +56,10 @@ hipError_t hipStreamDestroy(hipStream_t s) {
     std::free(s);
     return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) {
+    runQueued();
+    return hipSuccess;
+}
 const char* hipGetErrorString(hipError_t) { return "fake HIP runtime of the test double"; }
 }  // extern "C"
 
@@ -73,11 +79,42 @@ int lcHostEntryDevice(int* dev) {
     if (dev) *dev = 0;
     return LC_OK;
 }
+// The device is ASYNCHRONOUS here too: a match call and the trip's signal are QUEUED, and run when the host waits for them -- unless
+// the word the host waits on ALREADY reads the trip's number, in which case the wait returns at once and the host reads whatever the
+// status block holds, exactly what a spinning runner thread would do on the device (the completion word used to lie
+// behind the status bytes, where an earlier, longer group's bytes could spell the number).  The queued work is then dropped.
+struct QueuedJob {
+    lc_match_job job;
+};
+struct QueuedSignal {
+    uint32_t* flag;
+    uint32_t seq;
+};
+static thread_local std::vector<QueuedJob> tQueuedJobs;
+static thread_local std::vector<QueuedSignal> tQueuedSignals;
+static void runJob(const lc_match_job& J);
+static void runQueued() {
+    for (const QueuedJob& q : tQueuedJobs) runJob(q.job);
+    tQueuedJobs.clear();
+    for (const QueuedSignal& s : tQueuedSignals) *s.flag = s.seq;
+    tQueuedSignals.clear();
+}
+static uint64_t gEarlyReturns = 0;
+extern "C" uint64_t fd_early_returns(void) { return gEarlyReturns; }
 int lcQueueTripSignal(uint32_t* hFlag, uint32_t seq, hipStream_t) {
-    *hFlag = seq;  // (everything "queued" before it has already run)
+    tQueuedSignals.push_back({hFlag, seq});
     return LC_OK;
 }
-int lcAwaitTripSignal(const uint32_t* hFlag, uint32_t seq, hipStream_t) { return *hFlag == seq ? LC_OK : LC_ERR_ARG; }
+int lcAwaitTripSignal(const uint32_t* hFlag, uint32_t seq, hipStream_t) {
+    if (*hFlag == seq) {  // the host saw "done" before the device has run anything
+        ++gEarlyReturns;
+        tQueuedJobs.clear();
+        tQueuedSignals.clear();
+        return LC_OK;
+    }
+    runQueued();
+    return *hFlag == seq ? LC_OK : LC_ERR_ARG;
+}
 
 extern "C" int lc_device_count(void) { return 1; }
 extern "C" const char* lc_last_error(void) { return tLastError.c_str(); }
@@ -104,8 +141,11 @@ extern "C" int lc_upload_pinned(const void* src, void* dst, size_t nbytes, void*
     return LC_OK;
 }
 extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t njobs, void*) {
-    for (uint32_t j = 0; j < njobs; ++j) {
-        const lc_match_job& J = jobs[j];
+    for (uint32_t j = 0; j < njobs; ++j) tQueuedJobs.push_back({jobs[j]});
+    return LC_OK;
+}
+static void runJob(const lc_match_job& J) {
+    {
         std::vector<int32_t> what(size_t(J.re->marks + 1) * 2);
         for (uint32_t i = 0; i < J.n; ++i) {
             const uint32_t len = J.d_len ? J.d_len[i] : J.d_off[i + 1] - J.d_off[i] - J.sep_bytes;
@@ -118,7 +158,6 @@ extern "C" int lc_regex_match_device_multi(const lc_match_job* jobs, uint32_t nj
             }
         }
     }
-    return LC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- the harness

@@ -133,3 +133,25 @@ def test_random_event_groups_against_the_oracle(config):
     got = [e["contents"] for e in d["events"]] if d else []
     assert 0 < len(want) < len(events)
     assert got == [{k: v.decode("utf-8") for k, v in e.items()} for e in want]
+
+
+@pytest.mark.gpu
+def test_groups_of_alternating_sizes_over_more_than_257_trips():
+    """The zero-copy trip's completion word must not be reachable by status bytes: long and short groups in
+    turn on ONE runner thread, the long group's verdicts at [64..68) spelling the short group's trip number where bytes allow, well past
+    trips 256 / 257 (the first numbers two or three status bytes can spell).  tests/test_filter_host_double.py holds the CPU twin."""
+    f = Filter({"Include": {"k": "yes.*"}})
+    rng = random.Random(7)
+    trip = 0
+    for _ in range(300):
+        nxt = trip + 2
+        flags = [rng.random() < 0.5 for _ in range(200)]
+        for b in range(4):
+            flags[64 + b] = ((nxt >> (8 * b)) & 0xFF) == 1
+        for flags_now in (flags, [rng.random() < 0.5 for _ in range(64)]):
+            trip += 1
+            g = _group([{"k": ("yes%d" if fl else "no%d") % i} for i, fl in enumerate(flags_now)])
+            f.process(g)
+            d = g.to_dict()
+            got = [e["contents"]["k"] for e in d["events"]] if d else []
+            assert got == ["yes%d" % i for i, fl in enumerate(flags_now) if fl], trip

@@ -226,3 +226,35 @@ def test_the_imported_unit_test_vectors_through_the_product_s_host_code(golden_d
             ProductFilter(c["config"])
     for c in vectors["init_ok"]:
         ProductFilter(c["config"])
+
+
+def test_the_trip_s_completion_word_is_never_spelled_by_an_earlier_group_s_status_bytes():
+    """the zero-copy trip's completion word lay BEHIND the status bytes, at roundup64(values), so it moved with
+    the group's size; a shorter group found there the status bytes of an earlier, longer one -- and bytes (1,1,0,0) read as a word are
+    257, trip 257's own number: the host's wait returned before the device had run.  The double's device is asynchronous (queued work
+    runs when the host waits, and a wait that finds its number already there returns at once and drops the work), its pinned memory is
+    handed out dirty; groups alternate between 200 and 64 events over 600 trips, the long ones carrying at [64..68) every byte pattern
+    that spells one of the coming trip numbers."""
+    L = _double()
+    L.fd_early_returns.restype = ctypes.c_uint64
+    before = L.fd_early_returns()
+    prod = ProductFilter({"Include": {"k": "yes.*"}})
+    rng = random.Random(7)
+
+    def group(flags):
+        return json.dumps({"events": [{"contents": [["k", ("yes%d" if f else "no%d") % i]], "timestamp": i, "type": 1}
+                                      for i, f in enumerate(flags)]}).encode()
+
+    trip = 0
+    for _ in range(300):
+        nxt = trip + 2                                   # the SHORT group's trip number
+        flags = [rng.random() < 0.5 for _ in range(200)]
+        for b in range(4):                               # statuses 64..67 of the long group = the bytes of `nxt`, where they are 0 / 1
+            byte = (nxt >> (8 * b)) & 0xFF
+            flags[64 + b] = byte == 1
+        for flags_now in (flags, [rng.random() < 0.5 for _ in range(64)]):
+            trip += 1
+            got = prod.process(group(flags_now))
+            want = [i for i, f in enumerate(flags_now) if f]
+            assert [int(dict(ev)["contents"][0][1][3:]) for ev in got] == want, trip
+    assert trip == 600 and L.fd_early_returns() == before
