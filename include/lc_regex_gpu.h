@@ -181,9 +181,14 @@ void lc_regex_atomic_groups(const lc_regex_t* re, uint32_t* kept, uint32_t* elid
  * follow NFA, the limits, the stamp of this build of the library) -- and stored afterwards: tables, or the verdict of a construction
  * that ran into its limits.  Tables are bit-identical to a fresh construction; a missing, truncated or foreign file is ignored.
  * dir = NULL or "" switches the cache off (default).  Process-wide.  Environment: LC_TABLE_CACHE_DIR.  Grok config key: "CacheDir".
- * lc_runtime_table_cache_stats: {hits, misses, files stored, failures recalled} of this process. */
+ * lc_runtime_table_cache_stats: {hits, misses, files stored, failures recalled} of this process.
+ * lc_runtime_table_cache_stamp: the stamp that is part of every key -- a hash of the library SOURCES that shape the tables (the
+ * constructions, their structures, the file format), so that files written by a library with another construction are never read.
+ * A file also carries its key and a checksum of its payload, and every index in it is range-checked on load: anything else is a miss.
+ * A process under the construction's A/B switches (LC_TDFA_NO_DSE, LC_TDFA_NO_MINIMIZE) bypasses the cache. */
 int lc_runtime_set_table_cache_dir(const char* dir);
 void lc_runtime_table_cache_stats(uint64_t out[4]);
+const char* lc_runtime_table_cache_stamp(void);
 
 /* Ask that SMALL batches of this handle (<= 16 Ki lines) walk one value per WAVEFRONT with the tables in global memory
  * (tdfa_wave_kernel: quiet runs crossed 256 bytes at a time) even when the automaton fits LDS -- what the Grok matcher asks for
@@ -359,7 +364,9 @@ const char* lc_last_error(void);
 
 /* Frees the device resources the CALLING thread accumulated inside the match entry points (pinned staging slots, streams,
  * the decide kernel's scratch pool).  They are otherwise released when the thread ends; a host that recycles runner threads
- * (ProcessorRunner, core/runner/ProcessorRunner.cpp:138-142) may call this when a thread goes idle.  Safe to call any time. */
+ * (ProcessorRunner, core/runner/ProcessorRunner.cpp:138-142) may call this when a thread goes idle.  Safe to call any time.
+ * A thread that was dealt to a device by LC_BIND_ROUND_ROBIN also gives its ORDINAL back (here, and when it ends): the next thread
+ * that enters takes the lowest free one, so helper threads that come and go do not skew the deal of the runner threads. */
 void lc_thread_release(void);
 
 /* Statistics of the calling thread's decide passes since the last call: lines[0] = lines the thread-list kernels left

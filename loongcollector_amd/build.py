@@ -22,6 +22,10 @@ SOURCES = ["regex_parse.cpp", "atomic_elide.cpp", "follow_nfa.cpp", "tdfa.cpp", 
 OPTIONAL_SOURCES = ["event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "grok_literal_index.cpp", "processor_grok_gpu.cpp", "processor_filter_gpu.cpp", "processor_go_regex_gpu.cpp", "multiline_gpu.cpp", "multiline_events.cpp", "processor_pipeline_gpu.cpp", "c_processor_slot.cpp"]
 
 
+# what the on-disk table cache's stamp is made of: the constructions, the structures they read and write, the cache's own format
+TABLE_SHAPING_SOURCES = ["tdfa.cpp", "screen_dfa.cpp", "tdfa.hpp", "follow_nfa.hpp", "regex_ast.hpp", "table_cache.cpp"]
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -80,6 +84,18 @@ def build_native(force=False, verbose=False, force_sources=()):
     if not os.path.exists(inc) or open(inc, encoding="utf-8").read() != blob:
         with open(inc, "w", encoding="utf-8") as f:
             f.write(blob)
+    # the stamp of the on-disk table cache (csrc/table_cache.cpp): a hash of every source that shapes the compiled tables, so that an
+    # edit of tdfa.cpp alone also invalidates what an older build of the library has written
+    import hashlib
+    hh = hashlib.sha256()
+    for name in TABLE_SHAPING_SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            hh.update(name.encode() + b"\0" + f.read() + b"\0")
+    stamp = '"lc-tables-%s"\n' % hh.hexdigest()[:32]
+    stamp_inc = os.path.join(objdir, "table_sources_stamp.inc")
+    if not os.path.exists(stamp_inc) or open(stamp_inc).read() != stamp:
+        with open(stamp_inc, "w") as f:
+            f.write(stamp)
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include"),
               "-I", CSRC, "-I", objdir] + os.environ.get("LC_EXTRA_CXXFLAGS", "").split()
     procs = []
@@ -87,6 +103,7 @@ def build_native(force=False, verbose=False, force_sources=()):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if (not force and os.path.basename(src) not in force_sources and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and (os.path.basename(src) != "table_cache.cpp" or os.path.getmtime(obj) > os.path.getmtime(stamp_inc))
                 and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h))
                         for h in os.listdir(CSRC) if h.endswith((".h", ".hpp")))):
             continue

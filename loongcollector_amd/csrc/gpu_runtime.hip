@@ -133,13 +133,40 @@ extern "C" int lc_device_count(void) {
 namespace {
 std::atomic<int> gBindPolicy{-1};  // -1: not decided yet (LC_BIND_POLICY is read at first use)
 std::atomic<int> gBindFixedDevice{0};
-std::atomic<uint32_t> gThreadOrdinals{0};
+// Ordinals are dealt lowest-free-first and come BACK: when a thread releases its resources (lc_thread_release) or ends.  Through
+// round 5 an ordinal was the order of first entry, for good -- a short-lived helper thread that entered once consumed one and skewed
+// the deal for every runner thread behind it (review of round 5, design item 11).  With runner threads that live as long as the
+// process the deal is still ProcessorRunner's threadNo % nGPU.
+std::mutex gOrdinalMutex;
+uint32_t gNextOrdinal = 0;
+std::vector<uint32_t> gFreeOrdinals;  // kept sorted descending: back() is the lowest free one
+uint32_t takeOrdinal() {
+    std::lock_guard<std::mutex> g(gOrdinalMutex);
+    if (!gFreeOrdinals.empty()) {
+        const uint32_t o = gFreeOrdinals.back();
+        gFreeOrdinals.pop_back();
+        return o;
+    }
+    return gNextOrdinal++ & 0x7FFFFFFFu;
+}
+void returnOrdinal(uint32_t o) {
+    std::lock_guard<std::mutex> g(gOrdinalMutex);
+    gFreeOrdinals.insert(std::upper_bound(gFreeOrdinals.begin(), gFreeOrdinals.end(), o, std::greater<uint32_t>()), o);
+}
 struct ThreadBinding {
     int device = -1;       // bound device, -1 = not bound
-    int ordinal = -1;      // this thread's ordinal (order of first host entry), -1 = none taken
-    unsigned age = 0;
+    int ordinal = -1;      // this thread's ordinal (lowest free one at its first host entry), -1 = none taken
     int inherited = -1;    // LC_BIND_INHERIT: the current device as last asked from the runtime
     bool inheritOnly = false;  // this thread asked for LC_BIND_INHERIT itself: the process-wide policy does not bind it
+    void unbind() {  // (a device the host chose itself -- lc_runtime_set_thread_device, LC_BIND_FIXED -- holds no ordinal and stays)
+        if (ordinal < 0) return;
+        returnOrdinal(uint32_t(ordinal));
+        ordinal = -1;
+        device = -1;
+    }
+    ~ThreadBinding() {
+        if (ordinal >= 0) returnOrdinal(uint32_t(ordinal));  // (plain host state: safe at any point of a process's life)
+    }
 };
 thread_local ThreadBinding tlsBind;
 
@@ -176,7 +203,6 @@ int applyBinding(int device) {
     HIP_TRY(hipSetDevice(device));
     tlsBind.device = device;
     tlsBind.inheritOnly = false;
-    tlsBind.age = 0;
     return LC_OK;
 }
 }  // namespace
@@ -225,7 +251,7 @@ extern "C" int lc_runtime_bind_thread(int policy) {
         if (hipGetDevice(&cur) != hipSuccess) return -LC_ERR_HIP;
         if (cur != 0) want = cur;
         else {
-            if (b.ordinal < 0) b.ordinal = int(gThreadOrdinals.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu);
+            if (b.ordinal < 0) b.ordinal = int(takeOrdinal());
             want = lc_runtime_device_for_ordinal(uint32_t(b.ordinal), n);
         }
     } else {
@@ -242,17 +268,18 @@ extern "C" int lc_runtime_thread_device(void) { return tlsBind.device; }
 int lcHostEntryDevice(int* dev) {
     ThreadBinding& b = tlsBind;
     if (b.device >= 0) {
-        // (a host library may have moved the thread's current device under us: looked at once in a while, not per group)
-        if ((++b.age & 255u) == 0) {
-            int cur = -1;
-            HIP_TRY(hipGetDevice(&cur));
-            if (cur != b.device) HIP_TRY(hipSetDevice(b.device));
-        }
+        // A host library (torch, another plugin) may have moved the thread's current device since the last group: asked PER CALL --
+        // hipGetDevice reads a thread-local of the runtime, no lock -- because up to round 5 it was asked every 256th call, and the
+        // groups in between were launched on the thread's cached streams of device A while device B was current.
+        // The bound device is made current again and STAYS current behind the call: INTEGRATION.md section 11 says so.
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if (cur != b.device) HIP_TRY(hipSetDevice(b.device));
         *dev = b.device;
         return LC_OK;
     }
     if (b.inheritOnly || bindPolicyNow() == LC_BIND_INHERIT) {
-        if (b.inherited < 0 || (++b.age & 255u) == 0) HIP_TRY(hipGetDevice(&b.inherited));
+        HIP_TRY(hipGetDevice(&b.inherited));
         *dev = b.inherited;
         return *dev < kLcMaxDevices ? LC_OK : LC_ERR_ARG;
     }
@@ -1906,6 +1933,7 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
 }  // namespace
 
 extern "C" void lc_thread_release(void) {
+    tlsBind.unbind();  // the thread's ordinal goes back to the deal; its next host entry binds it afresh
     tlsDfsPool.release();
     if (tlsPipe) tlsPipe->release();
     tlsJobTables.release();

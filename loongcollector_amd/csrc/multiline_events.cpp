@@ -203,7 +203,11 @@ void mergeEvents(lc_merge_multiline& p, PipelineEventGroup& logGroup, std::vecto
     const StringView key(p.sourceKey.data(), p.sourceKey.size());
     LogEvent* target = logEvents[0];
     const StringView targetValue = target->GetContent(key);
-    bool backToBack = true;
+    // In place only when the first value has bytes of its own to grow from: an empty value may carry a null pointer (`nullptr + 1`
+    // below, memcpy from null: undefined whatever the length), and "one byte behind an empty value" says nothing about where the next
+    // value lies.  (The in-place branch writes only inside [first value's begin, last value's end): the bytes of the values and the
+    // one-byte gaps between neighbours, which cur.data() == prevEnd + 1 has just shown to exist in the same block.)
+    bool backToBack = targetValue.data() != nullptr && targetValue.size() != 0;
     size_t total = targetValue.size();
     const char* prevEnd = targetValue.data() + targetValue.size();
     for (size_t i = 1; i < logEvents.size(); ++i) {
@@ -216,13 +220,13 @@ void mergeEvents(lc_merge_multiline& p, PipelineEventGroup& logGroup, std::vecto
     if (!backToBack) {
         const StringBuffer block = logGroup.GetSourceBuffer()->AllocateStringBuffer(total);
         begin = block.data;
-        std::memcpy(begin, targetValue.data(), targetValue.size());
+        if (targetValue.size()) std::memcpy(begin, targetValue.data(), targetValue.size());
     }
     char* end = begin + targetValue.size();
     for (size_t i = 1; i < logEvents.size(); ++i) {
         if (insertLineBreak) *end++ = '\n';
         const StringView cur = logEvents[i]->GetContent(key);
-        std::memmove(end, cur.data(), cur.size());
+        if (cur.size()) std::memmove(end, cur.data(), cur.size());
         end += cur.size();
     }
     target->SetContentNoCopy(key, StringView(begin, size_t(end - begin)));

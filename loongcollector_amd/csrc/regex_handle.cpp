@@ -1450,6 +1450,7 @@ extern "C" int lc_runtime_set_table_cache_dir(const char* dir) {
     lcregex::lcSetTableCacheDir(dir);
     return LC_OK;
 }
+extern "C" const char* lc_runtime_table_cache_stamp(void) { return lcregex::lcTableCacheStamp(); }
 extern "C" void lc_runtime_table_cache_stats(uint64_t out[4]) {
     if (!out) return;
     const lcregex::TableCacheStats s = lcregex::lcTableCacheStats();

@@ -63,6 +63,7 @@ struct TableCacheStats {
     uint64_t hits = 0, misses = 0, stored = 0, failuresRecalled = 0;
 };
 TableCacheStats lcTableCacheStats();
+const char* lcTableCacheStamp();  // what stands for "this build's constructions" in every key (build.py: a hash of the shaping sources)
 
 // tdfa.cpp: merges states that behave alike (same final row, same register programs into equivalent states); buildTdfa and
 // buildScreenDfa end with it

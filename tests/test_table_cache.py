@@ -81,8 +81,50 @@ def test_damaged_or_foreign_cache_files_are_ignored(tmp_path):
         f.write(os.urandom(4096))
     with open(os.path.join(cache, files[2]), "wb") as f:
         pass
+    # round 6 (ADVICE): ONE flipped bit deep inside a table (the file keeps its length and its header: only the checksum can tell), a
+    # truncated file padded back to its length, and a whole, valid file under ANOTHER key's name (the key travels in the file)
+    big = sorted(files[3:], key=lambda f: -os.path.getsize(os.path.join(cache, f)))
+    with open(os.path.join(cache, big[0]), "r+b") as f:
+        size = os.path.getsize(os.path.join(cache, big[0]))
+        f.seek(size // 2)
+        b = f.read(1)
+        f.seek(size // 2)
+        f.write(bytes([b[0] ^ 0x10]))
+    with open(os.path.join(cache, big[1]), "r+b") as f:
+        size = os.path.getsize(os.path.join(cache, big[1]))
+        f.truncate(size - 64)
+        f.seek(0, 2)
+        f.write(b"\0" * 64)
+    with open(os.path.join(cache, big[2]), "rb") as f:
+        foreign = f.read()
+    with open(os.path.join(cache, big[3]), "wb") as f:
+        f.write(foreign)
     again = _run(SNAP, cache)
     assert again["tables"] == first["tables"]
-    assert again["stats"][1] >= 3 and again["stats"][2] >= 3, again["stats"]   # looked up, found unusable, rebuilt and stored again
+    assert again["stats"][1] >= 6 and again["stats"][2] >= 6, again["stats"]   # looked up, found unusable, rebuilt and stored again
     final = _run(SNAP, cache)
     assert final["tables"] == first["tables"] and final["stats"][1] == 0
+
+
+def test_the_stamp_follows_the_sources_that_shape_the_tables_and_the_ab_switches_bypass_the_cache(tmp_path):
+    """the cache key's build stamp was table_cache.cpp's own compile time -- an edit of tdfa.cpp alone did not change it.
+    build.py now hashes every table-shaping source into obj/table_sources_stamp.inc; and a process under LC_TDFA_NO_DSE /
+    LC_TDFA_NO_MINIMIZE (they change the construction's output) neither reads nor writes the cache."""
+    import hashlib
+    from loongcollector_amd import build as native_build
+    native_build.build_native()
+    inc = os.path.join(native_build.LIBDIR, "obj", "table_sources_stamp.inc")
+    assert os.path.exists(inc)
+    hh = hashlib.sha256()
+    for name in native_build.TABLE_SHAPING_SOURCES:
+        with open(os.path.join(native_build.CSRC, name), "rb") as f:
+            hh.update(name.encode() + b"\0" + f.read() + b"\0")
+    assert open(inc).read().strip() == '"lc-tables-%s"' % hh.hexdigest()[:32]
+    assert {"tdfa.cpp", "screen_dfa.cpp", "tdfa.hpp", "table_cache.cpp"} <= set(native_build.TABLE_SHAPING_SOURCES)
+    out = subprocess.run([sys.executable, "-c", "import ctypes\nfrom loongcollector_amd import binding as B\nL = B.load()\n"
+                          "L.lc_runtime_table_cache_stamp.restype = ctypes.c_char_p\nprint(L.lc_runtime_table_cache_stamp().decode())"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == open(inc).read().strip().strip('"'), out.stderr[-500:]   # the library that is loaded carries this stamp
+    cache = str(tmp_path / "tables")
+    switched = _run(SNAP, cache, env={"LC_TDFA_NO_MINIMIZE": "1"})
+    assert switched["stats"] == [0, 0, 0, 0] and not os.path.exists(cache)
