@@ -103,7 +103,15 @@ int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const uint32_t* d_
  * [3] entries that needed more rounds than queued ahead, [4] 1 = speculative path */
 void lc_grok_last_batch_stats(uint32_t out[5]);
 
-/* ---- host batch: copies in, matches on the device, returns the fields of every value in emission order --------------- */
+/* ---- host batch: copies in, matches on the device, returns the fields of every value in emission order ---------------
+ * Callable from any number of runner threads on ONE handle, one group per call, synchronous -- the contract of
+ * core/runner/ProcessorRunner.cpp:138-142.  Groups of threads that call in together travel as ONE device batch (group commit:
+ * csrc/group_combiner.hpp; a batch costs the device about the same from 1 000 to 16 000 values): a worker thread per (handle, device)
+ * runs the batches, one at a time; a batch starts when the device is free and the threads seen in the last three batches have arrived,
+ * or 100 us after the last arrival (LC_GROK_GAP_US), at most 500 us after the device became free (LC_GROK_LINGER_US).  One thread
+ * alone never waits.  lc_grok_combiner_stats: out = {batches, groups, values, most groups in one batch, batches started by the
+ * linger's timeout} since the handle was created. */
+int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[5]);
 int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
                        int32_t* pattern /* [n], as d_pattern */, lc_grok_result_t** result);
 /* fields of value i: indices field_off[i] .. field_off[i+1]) into key[] / begin[] / end[] (byte range inside value i) */

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -27,6 +28,7 @@
 #include "grok_kernel.hpp"
 #include "grok_plan_kernel.hpp"
 #include "grok_runtime.hpp"
+#include "group_combiner.hpp"
 #include "regex_handle.hpp"
 #include "runtime_internal.hpp"
 
@@ -75,17 +77,18 @@ struct GrokDeviceState {
     uint32_t nBigScreens[kLcMaxDevices] = {};     // the table's first entries: screens too large for that, see GrokScreenDev::bigBytes
     uint32_t bigScreenLdsBytes[kLcMaxDevices] = {};
     std::vector<GrokScreenDev> hostScreens[kLcMaxDevices];  // the same table on the host (kernel arguments of the remainder screens)
-    // lcGrokMatchHost: groups of runner threads that arrive while a batch is on the device travel together (group commit)
+    // lcGrokMatchHost: the groups of concurrent runner threads travel as ONE batch per device (group_combiner.hpp): a worker thread
+    // per (processor, device) owns the plan, the streams and the pinned staging
     struct HostJob;
-    std::mutex jobsMutex;
-    std::condition_variable jobsCv;
-    std::vector<HostJob*> pending;  // groups waiting for a leader
-    int running = 0;                // merged batches in flight
+    struct HostCombiner;
+    HostCombiner* combiner[kLcMaxDevices] = {};
 };
 
+static void grokFreeCombiners(GrokDeviceState* s);
 GrokDeviceState* lcGrokStateCreate() { return new GrokDeviceState(); }
 void lcGrokStateFree(GrokDeviceState* s) {
     if (!s) return;
+    grokFreeCombiners(s);  // (the worker threads end first: they use the tables freed below)
     if (lcRuntimeUsable()) {
         int cur = 0;
         const bool haveCur = hipGetDevice(&cur) == hipSuccess;
@@ -1575,57 +1578,114 @@ struct GrokDeviceState::HostJob {
     int32_t* pattern;
     std::vector<int32_t>* first;      // the group's own rows (filled by its thread from firstSrc)
     std::vector<int32_t>* extraRows;  // [line, seq, row...] sorted, lines relative to the group
-    const int32_t* firstSrc = nullptr;  // the group's rows in the leader's pinned staging
-    int rc = LC_OK;
-    std::string error;
-    bool ready = false;               // results are there (firstSrc may be read)
-    std::atomic<int>* copying = nullptr;  // the leader waits until every group has taken its rows
+    const std::vector<GrokDevicePattern>* patterns;  // the call's view of the processor (anchored forms appear as the warm-up goes on)
+    const GrokOptions* opts;
+    uint32_t row;
+    size_t bytes = 0;                 // sum of the group's value lengths (taken by its own thread before it queues)
+    // where the group's values go in the batch's pinned staging (the worker's `place`), filled by the group's own thread (`gather`)
+    uint8_t* hData = nullptr;
+    uint32_t* hOff = nullptr;
+    uint32_t* hLen = nullptr;
+    uint32_t byteBase = 0;
+    // results in the batch's pinned staging (the worker's `run`), taken out by the group's own thread
+    const int32_t* patternSrc = nullptr;
+    const int32_t* firstSrc = nullptr;
+    std::string* error = nullptr;     // the batch's message (the worker's last error is thread-local to the worker)
+    const GrokBatchStats* stats = nullptr;  // what the batch did (lc_grok_last_batch_stats is per calling thread)
+    uint32_t lines() const { return n; }
 };
 
 namespace {
-// the merged batch of `jobs` (one or more groups) on the calling thread's stream; fills pattern / firstSrc / extraRows of every job
-int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
-                     const std::vector<GrokDeviceState::HostJob*>& jobs) {
+// what the worker thread of one (processor, device) keeps between `place` and `run` of a batch
+struct HostBatch {
+    uint32_t n = 0;
+    size_t bytes = 0, offAt = 0, lenAt = 0, inBytes = 0;
+    std::string error;
+    GrokBatchStats stats;
+};
+}  // namespace
+
+struct GrokDeviceState::HostCombiner {
+    GrokDeviceState* state = nullptr;
+    int device = 0;
+    HostBatch batch;
+    std::unique_ptr<lccombine::GroupCombiner<HostJob>> combiner;
+};
+
+namespace {
+using HostJob = GrokDeviceState::HostJob;
+
+// `place`: the batch is fixed -- the values of all groups packed back to back (they may come from anywhere), then offsets and lengths:
+// one pinned block, one copy.  Runs on the worker thread; every group's own thread then copies its values in (grokGatherJob).
+int grokPlaceHostBatch(GrokDeviceState::HostCombiner& C, std::vector<HostJob*>& jobs) {
+    HostBatch& B = C.batch;
+    B = HostBatch{};
+    GrokHostThread& H = tlsGrokHost;
+    auto fail = [&](int rc) {
+        B.error = lc_last_error();
+        for (HostJob* j : jobs) j->error = &B.error;
+        return rc;
+    };
+    {
+        const int rc = H.ensure(C.device);
+        if (rc != LC_OK) return fail(rc);
+    }
+    size_t n64 = 0;
+    for (const HostJob* j : jobs) {
+        B.bytes += j->bytes;
+        n64 += j->n;
+    }
+    if (B.bytes > 0xFFFFFFF0ull || n64 > 0x7FFFFFFFull) {
+        lcSetLastError("grok: more than 4 GiB of values in one batch");
+        return fail(LC_ERR_ARG);
+    }
+    B.n = uint32_t(n64);
+    B.offAt = alignUp(B.bytes + 16, 256);
+    B.lenAt = B.offAt + alignUp(size_t(B.n) * 4, 256);
+    B.inBytes = B.lenAt + size_t(B.n) * 4;
+    if (H.hIn.ensure(B.inBytes) != hipSuccess || H.dIn.ensure(B.inBytes) != hipSuccess) {
+        lcSetLastError("grok: staging allocation failed");
+        return fail(LC_ERR_HIP);
+    }
+    uint8_t* hIn = static_cast<uint8_t*>(H.hIn.p);
+    size_t at = 0;
+    uint32_t k = 0;
+    for (HostJob* j : jobs) {
+        j->hData = hIn + at;
+        j->byteBase = uint32_t(at);
+        j->hOff = reinterpret_cast<uint32_t*>(hIn + B.offAt) + k;
+        j->hLen = reinterpret_cast<uint32_t*>(hIn + B.lenAt) + k;
+        at += j->bytes;
+        k += j->n;
+    }
+    std::memset(hIn + at, 0, 16);
+    return LC_OK;
+}
+
+// `gather`: on the group's OWN thread, all groups of a batch side by side
+void grokGatherJob(HostJob& j) {
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < j.n; ++i) {
+        j.hOff[i] = j.byteBase + at;
+        j.hLen[i] = j.len[i];
+        std::memcpy(j.hData + at, j.data + j.off[i], j.len[i]);
+        at += j.len[i];
+    }
+}
+
+// `run`: the merged batch on the worker thread's stream; sets patternSrc / firstSrc / extraRows of every job
+int grokRunHostBatch(GrokDeviceState::HostCombiner& C, std::vector<HostJob*>& jobs) {
     static const bool traceHost = getenv("LC_GROK_TRACE") != nullptr;
     const auto th0 = std::chrono::steady_clock::now();
     auto hostMs = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count(); };
-    double tGather = 0, tMatch = 0, tExtra = 0;
-    int devNo = 0;
-    {
-        const int rcDev = lcHostEntryDevice(&devNo);
-        if (rcDev != LC_OK) return rcDev;
-    }
+    HostBatch& B = C.batch;
     GrokHostThread& H = tlsGrokHost;
-    {
-        int rc = H.ensure(devNo);
-        if (rc != LC_OK) return rc;
-    }
-    // the values of all groups packed back to back (they may come from anywhere), then offsets and lengths: one block, one copy
-    size_t bytes = 0, n64 = 0;
-    for (const auto* j : jobs) {
-        for (uint32_t i = 0; i < j->n; ++i) bytes += j->len[i];
-        n64 += j->n;
-    }
-    if (bytes > 0xFFFFFFF0ull || n64 > 0x7FFFFFFFull) return LC_ERR_ARG;
-    const uint32_t n = uint32_t(n64);
-    const size_t offAt = alignUp(bytes + 16, 256), lenAt = offAt + alignUp(size_t(n) * 4, 256), inBytes = lenAt + size_t(n) * 4;
-    HIP_TRY(H.hIn.ensure(inBytes));
-    HIP_TRY(H.dIn.ensure(inBytes));
-    uint8_t* hIn = static_cast<uint8_t*>(H.hIn.p);
-    uint32_t* hOff = reinterpret_cast<uint32_t*>(hIn + offAt);
-    uint32_t* hLen = reinterpret_cast<uint32_t*>(hIn + lenAt);
-    {
-        size_t at = 0;
-        uint32_t k = 0;
-        for (const auto* j : jobs)
-            for (uint32_t i = 0; i < j->n; ++i, ++k) {
-                hOff[k] = uint32_t(at);
-                hLen[k] = j->len[i];
-                std::memcpy(hIn + at, j->data + j->off[i], j->len[i]);
-                at += j->len[i];
-            }
-        std::memset(hIn + at, 0, 16);
-    }
+    const std::vector<GrokDevicePattern>& patterns = *jobs.front()->patterns;
+    const GrokOptions& opts = *jobs.front()->opts;
+    const uint32_t row = jobs.front()->row, n = B.n;
+    const size_t offAt = B.offAt, lenAt = B.lenAt, inBytes = B.inBytes;
+    int rcAll = LC_OK;
+    auto body = [&]() -> int {
     const size_t scratch = lcGrokScratchBytes(n, row);
     uint32_t extraCap = n / 4 + 1024;
     const size_t firstBytes = size_t(n) * row * 4;
@@ -1637,15 +1697,15 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
     int32_t* hPattern = static_cast<int32_t*>(H.hOut.p);
     int32_t* hFirst = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(H.hOut.p) + alignUp(size_t(n) * 4, 256));
     const uint8_t* dIn = static_cast<const uint8_t*>(H.dIn.p);
-    HIP_TRY(hipMemcpyAsync(H.dIn.p, hIn, inBytes, hipMemcpyHostToDevice, H.stream));
-    tGather = hostMs();
+    HIP_TRY(hipMemcpyAsync(H.dIn.p, H.hIn.p, inBytes, hipMemcpyHostToDevice, H.stream));
+    const double tGather = hostMs();
     uint32_t nExtra = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(H.dExtra.ensure(size_t(extraCap) * (row + 2) * 4));
         // (the speculative path queues the copies of the pattern ids and the first rows behind its last kernels: its second sync
         // covers them)
         tlsTail = GrokTailCopy{hPattern, hFirst, true, false};
-        int rc = lcGrokMatchDevice(patterns, state, opts, row, dIn, reinterpret_cast<const uint32_t*>(dIn + offAt),
+        int rc = lcGrokMatchDevice(patterns, C.state, opts, row, dIn, reinterpret_cast<const uint32_t*>(dIn + offAt),
                                    reinterpret_cast<const uint32_t*>(dIn + lenAt), n, static_cast<int32_t*>(H.dPattern.p),
                                    static_cast<int32_t*>(H.dFirst.p), static_cast<int32_t*>(H.dExtra.p), extraCap,
                                    static_cast<uint32_t*>(H.dNextra.p), H.dScratch.p, scratch, H.stream);
@@ -1669,7 +1729,7 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
         }
         break;
     }
-    tMatch = hostMs();
+    const double tMatch = hostMs();
     const size_t w = row + 2;
     std::vector<uint32_t> idx(nExtra);
     const int32_t* raw = nullptr;
@@ -1686,8 +1746,10 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
         });
     }
     uint32_t base = 0, x = 0;
-    for (auto* j : jobs) {
-        std::memcpy(j->pattern, hPattern + base, size_t(j->n) * 4);
+    B.stats = tlsStats;
+    for (HostJob* j : jobs) {
+        j->stats = &B.stats;
+        j->patternSrc = hPattern + base;
         j->firstSrc = hFirst + size_t(base) * row;
         j->extraRows->clear();
         while (x < nExtra && uint32_t(raw[idx[x] * w]) < base + j->n) {
@@ -1699,13 +1761,75 @@ int grokRunHostBatch(const std::vector<GrokDevicePattern>& patterns, GrokDeviceS
         }
         base += j->n;
     }
-    tExtra = hostMs();
     if (traceHost)
-        fprintf(stderr, "grok host batch: %u values %zu bytes | gather + H2D queued %.3f ms, device match %.3f ms, extra rows + hand-out %.3f ms\n", n, bytes,
-                tGather, tMatch - tGather, tExtra - tMatch);
+        fprintf(stderr, "grok host batch: %zu groups %u values %zu bytes | H2D queued %.3f ms, device match %.3f ms, extra rows + hand-out %.3f ms\n",
+                jobs.size(), n, B.bytes, tGather, tMatch - tGather, hostMs() - tMatch);
     return LC_OK;
+    };
+    rcAll = body();
+    if (rcAll != LC_OK) {
+        B.error = lc_last_error();
+        for (HostJob* j : jobs) j->error = &B.error;
+        (void)hipStreamSynchronize(H.stream);  // (nothing of a failed batch may still write the staging the next one reuses)
+    }
+    return rcAll;
+}
+
+GrokDeviceState::HostCombiner* grokCombinerFor(GrokDeviceState* state, int dev) {
+    std::lock_guard<std::mutex> g(state->m);
+    if (state->combiner[dev]) return state->combiner[dev];
+    auto* C = new GrokDeviceState::HostCombiner();
+    C->state = state;
+    C->device = dev;
+    lccombine::GroupCombiner<HostJob>::Hooks hooks;
+    hooks.threadStart = [dev] { (void)lc_runtime_set_thread_device(dev); };  // the worker runs on the device of the threads it serves
+    hooks.threadEnd = [] {
+        if (lcRuntimeUsable()) lc_thread_release();  // the worker's plan, streams, pools and staging
+    };
+    hooks.place = [C](std::vector<HostJob*>& jobs) { return grokPlaceHostBatch(*C, jobs); };
+    hooks.gather = [](HostJob& j) { grokGatherJob(j); };
+    hooks.run = [C](std::vector<HostJob*>& jobs) { return grokRunHostBatch(*C, jobs); };
+    lccombine::CombinerOptions o;
+    if (const char* e = getenv("LC_GROK_LINGER_US")) o.lingerUs = unsigned(atoi(e));   // (A/B measurements)
+    if (const char* e = getenv("LC_GROK_GAP_US")) o.gapUs = unsigned(atoi(e));
+    C->combiner.reset(new lccombine::GroupCombiner<HostJob>(std::move(hooks), o));
+    state->combiner[dev] = C;
+    return C;
 }
 }  // namespace
+
+static void grokFreeCombiners(GrokDeviceState* s) {
+    for (int d = 0; d < kLcMaxDevices; ++d) {
+        GrokDeviceState::HostCombiner* C = nullptr;
+        {
+            std::lock_guard<std::mutex> g(s->m);
+            std::swap(C, s->combiner[d]);
+        }
+        if (!C) continue;
+        C->combiner->stop();  // (groups still inside are answered first; the worker then releases what it holds on the device)
+        delete C;
+    }
+}
+
+int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[5]) {
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!state) return LC_ERR_ARG;
+    for (int d = 0; d < kLcMaxDevices; ++d) {
+        GrokDeviceState::HostCombiner* C = nullptr;
+        {
+            std::lock_guard<std::mutex> g(state->m);
+            C = state->combiner[d];
+        }
+        if (!C) continue;
+        const lccombine::CombinerStats st = C->combiner->stats();
+        out[0] += st.batches;
+        out[1] += st.jobs;
+        out[2] += st.lines;
+        out[3] = std::max<uint64_t>(out[3], st.largestBatchJobs);
+        out[4] += st.lingerExpired;
+    }
+    return LC_OK;
+}
 
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t row,
                     const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
@@ -1718,77 +1842,33 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
         lcSetLastError("no HIP device");
         return LC_ERR_NO_DEVICE;
     }
-    // Group commit.  ProcessorRunner hands over ONE ~1000-log group per call, from several threads that share the plugin instance
-    // (core/runner/ProcessorRunner.cpp:138-142), and a batch costs the device about the same from 1 000 to 16 000 values (it waits
-    // for its longest value, not for the chip).  So: a thread that finds nothing in flight runs its group at once; groups that
-    // arrive while a batch is on the device wait together and travel as ONE batch led by the first of them.  No timers.
-    using HostJob = GrokDeviceState::HostJob;
-    thread_local std::vector<int32_t> tlsFirst;
-    HostJob job{data, off, len, n, pattern, &tlsFirst, &extraRows};
-    constexpr int kMaxInFlight = 2;            // one batch on the device, one being packed
-    constexpr size_t kMaxMergedLines = 65536;  // (beyond this a batch is throughput-bound anyway)
-    std::vector<HostJob*> mine;
+    // Group commit (group_combiner.hpp).  ProcessorRunner hands over ONE ~1000-log group per call, from several threads that share the
+    // plugin instance (core/runner/ProcessorRunner.cpp:138-142), and a batch costs the device about the same from 1 000 to 16 000 values
+    // (it waits for its longest value, not for the chip).  The groups of the threads that call in together travel as ONE batch, run by
+    // the worker thread of (this processor, the calling thread's device); the caller copies its own values in and its own rows out.
+    int dev = 0;
     {
-        std::unique_lock<std::mutex> lk(state->jobsMutex);
-        state->pending.push_back(&job);
-        for (;;) {
-            if (job.ready) break;
-            const bool queued = std::find(state->pending.begin(), state->pending.end(), &job) != state->pending.end();
-            if (queued && state->running < kMaxInFlight) {  // lead: take what has gathered (in arrival order)
-                size_t lines = 0;
-                while (!state->pending.empty() && (mine.empty() || lines + state->pending.front()->n <= kMaxMergedLines)) {
-                    lines += state->pending.front()->n;
-                    mine.push_back(state->pending.front());
-                    state->pending.erase(state->pending.begin());
-                }
-                if (std::find(mine.begin(), mine.end(), &job) == mine.end()) {  // (cannot happen: arrival order) -- never lead others only
-                    for (auto it = mine.rbegin(); it != mine.rend(); ++it) state->pending.insert(state->pending.begin(), *it);
-                    mine.clear();
-                    state->jobsCv.wait(lk);
-                    continue;
-                }
-                ++state->running;
-                break;
-            }
-            state->jobsCv.wait(lk);
-        }
+        const int rcDev = lcHostEntryDevice(&dev);  // the calling thread's binding decides the device
+        if (rcDev != LC_OK) return rcDev;
     }
-    if (!mine.empty()) {
-        std::atomic<int> copying{int(mine.size())};
-        int rc = grokRunHostBatch(patterns, state, opts, row, mine);
-        const std::string err = rc == LC_OK ? std::string() : std::string(lc_last_error());
-        {
-            std::lock_guard<std::mutex> lk(state->jobsMutex);
-            for (HostJob* j : mine) {
-                j->rc = rc;
-                j->error = err;
-                j->copying = &copying;
-                j->ready = true;
-            }
+    thread_local std::vector<int32_t> tlsFirst;
+    HostJob job{data, off, len, n, pattern, &tlsFirst, &extraRows, &patterns, &opts, row};
+    for (uint32_t i = 0; i < n; ++i) job.bytes += len[i];
+    GrokDeviceState::HostCombiner* C = grokCombinerFor(state, dev);
+    const int rc = C->combiner->submit(job, [row](HostJob& j) {
+        std::memcpy(j.pattern, j.patternSrc, size_t(j.n) * 4);
+        j.first->resize(size_t(j.n) * row);
+        std::memcpy(j.first->data(), j.firstSrc, size_t(j.n) * row * 4);
+        if (j.stats) tlsStats = *j.stats;
+    });
+    if (rc != LC_OK) {
+        if (rc < 0) {
+            lcSetLastError("grok: the processor is shutting down");
+            return LC_ERR_ARG;
         }
-        state->jobsCv.notify_all();
-        // my own rows, then wait until the other groups have taken theirs out of my staging
-        if (rc == LC_OK) {
-            tlsFirst.resize(size_t(n) * row);
-            std::memcpy(tlsFirst.data(), job.firstSrc, size_t(n) * row * 4);
-        }
-        copying.fetch_sub(1);
-        while (copying.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-        {
-            std::lock_guard<std::mutex> lk(state->jobsMutex);
-            --state->running;
-        }
-        state->jobsCv.notify_all();
-    } else {
-        if (job.rc == LC_OK) {
-            tlsFirst.resize(size_t(n) * row);
-            std::memcpy(tlsFirst.data(), job.firstSrc, size_t(n) * row * 4);
-        } else {
-            lcSetLastError(job.error);
-        }
-        job.copying->fetch_sub(1, std::memory_order_release);
+        if (job.error) lcSetLastError(*job.error);
+        return rc;
     }
-    if (job.rc != LC_OK) return job.rc;
     *firstRows = tlsFirst.data();
     return LC_OK;
 }

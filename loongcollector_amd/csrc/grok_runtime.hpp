@@ -66,3 +66,6 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t rowInts,
                     const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
                     const int32_t** firstRows, std::vector<int32_t>& extraRows);
+// the group commit behind lcGrokMatchHost (group_combiner.hpp), summed over the devices of `state`:
+// out = {batches, groups, values, most groups in one batch, batches started by the linger's timeout}
+int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[5]);

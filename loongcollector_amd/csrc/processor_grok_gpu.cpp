@@ -555,6 +555,11 @@ extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint3
     return LC_OK;
 }
 
+extern "C" int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[5]) {
+    if (!g || !out) return LC_ERR_ARG;
+    return g->p.CombinerStats(out);
+}
+
 extern "C" void lc_grok_result_arrays(const lc_grok_result_t* r, const uint32_t** field_off, const uint32_t** key,
                                       const uint32_t** begin, const uint32_t** end) {
     if (!r) return;

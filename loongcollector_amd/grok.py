@@ -159,6 +159,13 @@ class Grok:
                                           d_scratch.numel() * d_scratch.element_size(), stream)
         binding._check(rc, "lc_grok_match_device")
 
+    def combiner_stats(self):
+        """the group commit behind match_host (csrc/group_combiner.hpp) since the handle was created"""
+        w = (ctypes.c_uint64 * 5)()
+        self._L.lc_grok_combiner_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._L.lc_grok_combiner_stats(self._h, ctypes.cast(w, ctypes.c_void_p))
+        return {"batches": int(w[0]), "groups": int(w[1]), "values": int(w[2]), "largest_batch_groups": int(w[3]), "linger_expired": int(w[4])}
+
     def last_batch_stats(self):
         """what the calling thread's last device batch did: host syncs, active entries, (entry, value) pairs, deferred entries, path"""
         w = (ctypes.c_uint32 * 5)()

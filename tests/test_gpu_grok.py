@@ -215,6 +215,60 @@ def test_config3_supported_patterns_on_generated_lines(torch_dev, golden_dir):
     assert list(pattern0) == list(pattern) and fields0 == fields
 
 
+def test_sixteen_runner_threads_share_device_batches(torch_dev, golden_dir):
+    """core/runner/ProcessorRunner.cpp:138-142: one group per call, synchronous, from process_thread_count threads on ONE plugin
+    instance.  Sixteen threads, twelve 250-value groups each (different sizes at the ends), through lc_grok_match_host: every group's
+    pattern ids and fields equal what the same group gives alone (and a third of them, the oracle); the groups did travel together
+    (csrc/group_combiner.hpp) -- far fewer batches than groups, a batch of at least twelve groups seen."""
+    import threading
+    from loongcollector_amd.grok_corpus import grok_lines
+    with open(os.path.join(golden_dir, "grok_config3.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    g = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()
+    o = GrokOracle(cfg["match"], custom_patterns=cfg["custom_patterns"])
+    lines = grok_lines(2400)
+    rng = random.Random(11)
+    groups = []
+    at = 0
+    while at < len(lines):
+        n = rng.choice([1, 7, 250, 250, 250, 250, 400])
+        groups.append(lines[at:at + n])
+        at += n
+    alone = [g.match_host(gr) for gr in groups]
+    for k in range(0, len(groups), 3):
+        for v, f in zip(groups[k], alone[k][1]):
+            assert f == o.process_value(v)[1], v
+    before = g.combiner_stats()
+    T, rounds = 16, 12
+    errors = []
+    barrier = threading.Barrier(T)
+
+    def runner(t):
+        try:
+            barrier.wait()
+            for r in range(rounds):
+                k = (t * 5 + r * 7) % len(groups)
+                pattern, fields = g.match_host(groups[k])
+                if list(pattern) != list(alone[k][0]) or fields != alone[k][1]:
+                    errors.append((t, r, k))
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+        finally:
+            B.load().lc_thread_release()
+
+    threads = [threading.Thread(target=runner, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    st = g.combiner_stats()
+    n_groups, n_batches = st["groups"] - before["groups"], st["batches"] - before["batches"]
+    assert n_groups == T * rounds
+    assert n_batches <= n_groups // 4, st
+    assert st["largest_batch_groups"] >= 12, st
+
+
 def test_relaxed_screens_on_the_device(torch_dev, golden_dir):
     """lc_regex_screen_device (dfa_screen_kernel: one value per lane, the yes/no DFA's table in L2) against the same tables
     walked on the CPU, and against the oracle: a value the pattern matches somewhere is never rejected.  Whole list and a

@@ -48,3 +48,26 @@ def test_runner_threads_on_shared_instances_under_thread_sanitizer():
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     assert "0 mismatching groups, 0 counters off" in r.stdout, r.stdout
+
+
+@pytest.mark.skipif(not _tsan_usable(), reason="needs g++ with libtsan")
+def test_the_group_commit_of_concurrent_runner_threads_under_thread_sanitizer():
+    """csrc/group_combiner.hpp (round 6): the groups of the runner threads that call lc_grok_match_host together travel as ONE device
+    batch (core/runner/ProcessorRunner.cpp:138-142: synchronous, one group per call, concurrent callers on one instance).  The combiner
+    holds no HIP: tests/native/combiner_race.cpp gives it a device that is a function and runs 16 threads x 200 groups through it under
+    ThreadSanitizer -- every job gets the rows of ITS values whatever batch it travelled in, batches never overlap, one thread alone
+    never lingers, sixteen find each other (> 0.6 x 16 jobs per batch), a failing batch fails exactly its jobs, stop() with callers in
+    flight answers or refuses every one of them."""
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "combiner_race")
+    src = os.path.join(ROOT, "tests", "native", "combiner_race.cpp")
+    hdr = os.path.join(ROOT, "loongcollector_amd", "csrc", "group_combiner.hpp")
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in (src, hdr)):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", os.path.dirname(hdr), "-o", exe, src, "-lpthread"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe, "16", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-800:], r.stderr[-2000:])
+    assert "0 checks failed" in r.stdout, r.stdout
