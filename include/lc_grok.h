@@ -110,8 +110,9 @@ void lc_grok_last_batch_stats(uint32_t out[5]);
  * runs the batches, one at a time; a batch starts when the device is free and the threads seen in the last three batches have arrived,
  * or 100 us after the last arrival (LC_GROK_GAP_US), at most 500 us after the device became free (LC_GROK_LINGER_US).  One thread
  * alone never waits.  lc_grok_combiner_stats: out = {batches, groups, values, most groups in one batch, batches started by the
- * linger's timeout} since the handle was created. */
-int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[5]);
+ * linger's timeout; then the worker's microseconds: idle, lingering, laying out the staging, the callers' gather,
+ * the device trip, the callers taking their rows} since the handle was created. */
+int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[11]);
 int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
                        int32_t* pattern /* [n], as d_pattern */, lc_grok_result_t** result);
 /* fields of value i: indices field_off[i] .. field_off[i+1]) into key[] / begin[] / end[] (byte range inside value i) */

@@ -1592,6 +1592,7 @@ struct GrokDeviceState::HostJob {
     const int32_t* firstSrc = nullptr;
     std::string* error = nullptr;     // the batch's message (the worker's last error is thread-local to the worker)
     const GrokBatchStats* stats = nullptr;  // what the batch did (lc_grok_last_batch_stats is per calling thread)
+    const std::string* kernels = nullptr;   // ... and which kernels it launched (lc_launched_kernels is per calling thread)
     uint32_t lines() const { return n; }
 };
 
@@ -1600,7 +1601,7 @@ namespace {
 struct HostBatch {
     uint32_t n = 0;
     size_t bytes = 0, offAt = 0, lenAt = 0, inBytes = 0;
-    std::string error;
+    std::string error, kernels;
     GrokBatchStats stats;
 };
 }  // namespace
@@ -1685,6 +1686,7 @@ int grokRunHostBatch(GrokDeviceState::HostCombiner& C, std::vector<HostJob*>& jo
     const uint32_t row = jobs.front()->row, n = B.n;
     const size_t offAt = B.offAt, lenAt = B.lenAt, inBytes = B.inBytes;
     int rcAll = LC_OK;
+    (void)lc_launched_kernels(nullptr, 0);  // (the worker's log: what THIS batch launches goes to the callers' logs)
     auto body = [&]() -> int {
     const size_t scratch = lcGrokScratchBytes(n, row);
     uint32_t extraCap = n / 4 + 1024;
@@ -1747,8 +1749,14 @@ int grokRunHostBatch(GrokDeviceState::HostCombiner& C, std::vector<HostJob*>& jo
     }
     uint32_t base = 0, x = 0;
     B.stats = tlsStats;
+    {
+        char names[1024];
+        (void)lc_launched_kernels(names, sizeof names);
+        B.kernels = names;
+    }
     for (HostJob* j : jobs) {
         j->stats = &B.stats;
+        j->kernels = &B.kernels;
         j->patternSrc = hPattern + base;
         j->firstSrc = hFirst + size_t(base) * row;
         j->extraRows->clear();
@@ -1811,8 +1819,8 @@ static void grokFreeCombiners(GrokDeviceState* s) {
     }
 }
 
-int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[5]) {
-    for (int i = 0; i < 5; ++i) out[i] = 0;
+int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[11]) {
+    for (int i = 0; i < 11; ++i) out[i] = 0;
     if (!state) return LC_ERR_ARG;
     for (int d = 0; d < kLcMaxDevices; ++d) {
         GrokDeviceState::HostCombiner* C = nullptr;
@@ -1827,6 +1835,12 @@ int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[5]) {
         out[2] += st.lines;
         out[3] = std::max<uint64_t>(out[3], st.largestBatchJobs);
         out[4] += st.lingerExpired;
+        out[5] += st.usIdle;
+        out[6] += st.usLinger;
+        out[7] += st.usPlace;
+        out[8] += st.usGather;
+        out[9] += st.usRun;
+        out[10] += st.usTakeOut;
     }
     return LC_OK;
 }
@@ -1860,6 +1874,15 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
         j.first->resize(size_t(j.n) * row);
         std::memcpy(j.first->data(), j.firstSrc, size_t(j.n) * row * 4);
         if (j.stats) tlsStats = *j.stats;
+        if (j.kernels) {
+            size_t at = 0;
+            while (at < j.kernels->size()) {
+                size_t end = j.kernels->find(", ", at);
+                if (end == std::string::npos) end = j.kernels->size();
+                lcNoteKernel(j.kernels->substr(at, end - at).c_str());
+                at = end + 2;
+            }
+        }
     });
     if (rc != LC_OK) {
         if (rc < 0) {

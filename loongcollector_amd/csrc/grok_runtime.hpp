@@ -68,4 +68,4 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
                     const int32_t** firstRows, std::vector<int32_t>& extraRows);
 // the group commit behind lcGrokMatchHost (group_combiner.hpp), summed over the devices of `state`:
 // out = {batches, groups, values, most groups in one batch, batches started by the linger's timeout}
-int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[5]);
+int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[11]);

@@ -42,6 +42,9 @@ struct CombinerOptions {
 
 struct CombinerStats {
     uint64_t batches = 0, jobs = 0, lines = 0, largestBatchJobs = 0, lingerExpired = 0;
+    // where the worker's time went, microseconds: waiting for the first caller, lingering for the others, laying out the staging,
+    // the callers' gather, the device trip, the callers taking their rows
+    uint64_t usIdle = 0, usLinger = 0, usPlace = 0, usGather = 0, usRun = 0, usTakeOut = 0;
 };
 
 // Job: anything with  uint32_t lines() const.  The combiner owns nothing of a job; a job lives on its caller's stack.
@@ -155,9 +158,12 @@ class GroupCombiner {
         std::unique_lock<std::mutex> lk(mMutex);
         std::vector<Slot*> batch;
         std::vector<Job*> jobs;
+        auto us = [](Clock::time_point a, Clock::time_point b) { return uint64_t(std::chrono::duration_cast<std::chrono::microseconds>(b - a).count()); };
         for (;;) {
+            const auto tIdle = Clock::now();
             mWorkerCv.wait(lk, [&] { return mStopping || !mPending.empty(); });
             if (mPending.empty()) break;  // (stopping, and nobody is waiting)
+            if (mStats.batches) mStats.usIdle += us(tIdle, Clock::now());
             // the linger: the callers of the previous batch are on their way back
             const auto first = Clock::now();
             bool expired = false;
@@ -185,7 +191,10 @@ class GroupCombiner {
             }
             ++mBatchNo;
             lk.unlock();
+            const auto t0 = Clock::now();
+            auto t1 = t0, t2 = t0;
             int rc = mHooks.place ? mHooks.place(jobs) : 0;
+            t1 = t2 = Clock::now();
             if (rc == 0) {
                 lk.lock();
                 mGathering = batch.size();
@@ -193,9 +202,15 @@ class GroupCombiner {
                 mCallerCv.notify_all();
                 mWorkerCv.wait(lk, [&] { return mGathering == 0; });
                 lk.unlock();
+                t2 = Clock::now();
                 rc = mHooks.run(jobs);
             }
+            const auto t3 = Clock::now();
             lk.lock();
+            mStats.usLinger += us(first, t0);
+            mStats.usPlace += us(t0, t1);
+            mStats.usGather += us(t1, t2);
+            mStats.usRun += us(t2, t3);
             ++mStats.batches;
             mStats.jobs += batch.size();
             mStats.lines += lines;
@@ -209,6 +224,7 @@ class GroupCombiner {
             // the staging is the batch's until every caller has taken its rows (the slots live on the callers' stacks: not touched
             // after this wait)
             mWorkerCv.wait(lk, [&] { return mTakingOut == 0; });
+            mStats.usTakeOut += us(t3, Clock::now());
         }
         lk.unlock();
         if (mHooks.threadEnd) mHooks.threadEnd();

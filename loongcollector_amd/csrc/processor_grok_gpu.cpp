@@ -555,7 +555,7 @@ extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint3
     return LC_OK;
 }
 
-extern "C" int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[5]) {
+extern "C" int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[11]) {
     if (!g || !out) return LC_ERR_ARG;
     return g->p.CombinerStats(out);
 }

@@ -80,7 +80,7 @@ public:
     uint32_t rowInts() const { return mRowInts; }
     uint64_t anchoredBytes() const { return mAnchoredBytes.load(); }
     GrokDeviceState* deviceState() { return mState; }
-    int CombinerStats(uint64_t out[5]) { return lcGrokCombinerStats(mState, out); }  // lc_grok_combiner_stats
+    int CombinerStats(uint64_t out[11]) { return lcGrokCombinerStats(mState, out); }  // lc_grok_combiner_stats
     GrokOptions options() const;
     int engine(size_t i) const;
 

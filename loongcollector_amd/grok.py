@@ -161,10 +161,12 @@ class Grok:
 
     def combiner_stats(self):
         """the group commit behind match_host (csrc/group_combiner.hpp) since the handle was created"""
-        w = (ctypes.c_uint64 * 5)()
+        w = (ctypes.c_uint64 * 11)()
         self._L.lc_grok_combiner_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self._L.lc_grok_combiner_stats(self._h, ctypes.cast(w, ctypes.c_void_p))
-        return {"batches": int(w[0]), "groups": int(w[1]), "values": int(w[2]), "largest_batch_groups": int(w[3]), "linger_expired": int(w[4])}
+        out = {"batches": int(w[0]), "groups": int(w[1]), "values": int(w[2]), "largest_batch_groups": int(w[3]), "linger_expired": int(w[4])}
+        out["worker_us"] = dict(zip(("idle", "linger", "place", "gather", "run", "take_out"), (int(x) for x in w[5:11])))
+        return out
 
     def last_batch_stats(self):
         """what the calling thread's last device batch did: host syncs, active entries, (entry, value) pairs, deferred entries, path"""

@@ -71,16 +71,22 @@ def measure(args):
         if (pattern[i] >= 0) != (res == 0) or fields[i] != want:
             raise SystemExit("PARITY FAILURE: in-agent group, value %d" % i)
 
+    # (the arguments of every call are made once: sixteen Python threads share one interpreter lock, and what a thread does under it
+    # between two calls -- numpy's .ctypes objects, byref -- is time the fifteen others wait before they can call in again)
+    group_args = [(d.ctypes.data, o.ctypes.data, ln.ctypes.data, len(o)) for d, o, ln, _ in groups]
+    match_host, result_free, handle = L.lc_grok_match_host, L.lc_grok_result_free, g._h
+
     def worker(tid, n_groups, barrier, out):
         pattern = np.empty(args.group, dtype=np.int32)
+        pattern_ptr = pattern.ctypes.data
         res = ctypes.c_void_p()
+        res_ref = ctypes.byref(res)
         def one(k):
-            data, off, length, _ = groups[(tid + k) % n_groups_pool]
-            rc = L.lc_grok_match_host(g._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, len(off), pattern.ctypes.data,
-                                      ctypes.byref(res))
+            a = group_args[(tid + k) % n_groups_pool]
+            rc = match_host(handle, a[0], a[1], a[2], a[3], pattern_ptr, res_ref)
             if rc != 0:
                 raise RuntimeError("lc_grok_match_host rc=%d" % rc)
-            L.lc_grok_result_free(res)
+            result_free(res)
         for k in range(3):
             one(k)
         barrier.wait()
@@ -91,6 +97,7 @@ def measure(args):
         binding.load().lc_thread_release()
 
     for t in [int(x) for x in args.threads.split(",")]:
+        cs0 = g.combiner_stats()
         barrier = threading.Barrier(t + 1)
         out = [0.0] * t
         threads = [threading.Thread(target=worker, args=(i, args.groups, barrier, out)) for i in range(t)]
@@ -107,8 +114,14 @@ def measure(args):
         wall = max(out)
         lines = t * args.groups * args.group
         mean_bytes = float(np.mean([gr[2].sum() for gr in groups])) / args.group
+        cs1 = g.combiner_stats()
+        nb = max(1, cs1["batches"] - cs0["batches"])
+        combiner = {"batches": cs1["batches"] - cs0["batches"], "groups_per_batch": round((cs1["groups"] - cs0["groups"]) / nb, 2),
+                    "linger_expired": cs1["linger_expired"] - cs0["linger_expired"],
+                    "worker_ms_per_batch": {k: round((cs1["worker_us"][k] - cs0["worker_us"][k]) / nb / 1e3, 3) for k in cs1["worker_us"]}}
         results.append({
             "metric": "Grok lines/s, in-agent shape (%d-line groups through lc_grok_match_host)" % args.group,
+            "combiner": combiner,
             "value": round(lines / wall, 1), "unit": "lines/s", "runner_threads": t, "groups_per_thread": args.groups,
             "ms_per_group": round(wall / args.groups * 1e3, 3), "MBps": round(lines * mean_bytes / wall / 1e6, 2),
             "config": {"workload": "configs[2] corpus in %d-line groups, %d Match entries, host memory in, fields out" % (args.group, len(supported)),
