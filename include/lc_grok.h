@@ -113,6 +113,16 @@ void lc_grok_last_batch_stats(uint32_t out[5]);
  * linger's timeout; then the worker's microseconds: idle, lingering, laying out the staging, the callers' gather,
  * the device trip, the callers taking their rows} since the handle was created. */
 int lc_grok_combiner_stats(lc_grok_t* g, uint64_t out[11]);
+
+/* The LAZY automata of the entries that do not determinise (include/lc_regex_gpu.h lc_regex_lazy_train; config key "LazyTdfa", default
+ * true).  A background thread of the handle builds them along the handle's own traffic: lc_grok_match_host / lc_grok_match_device OFFER
+ * a copy of up to 4 096 values of a batch (a window that moves through the batch from offer to offer) when the trainer is idle -- the
+ * first 64 batches at once, later ones every 200 ms at most.
+ * Results never depend on it.  lc_grok_lazy_settle blocks until the trainer has nothing to do (LC_OK) or the timeout is over (LC_ERR_ARG):
+ * benchmarks and tests call it between warm-up batches.  lc_grok_lazy_stats: out = {automata with a lazy front in use, builds, values
+ * offered (summed over the automata), values kept in their samples, batches the trainer has taken}. */
+int lc_grok_lazy_settle(lc_grok_t* g, uint32_t timeout_ms);
+int lc_grok_lazy_stats(lc_grok_t* g, uint64_t out[5]);
 int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n,
                        int32_t* pattern /* [n], as d_pattern */, lc_grok_result_t** result);
 /* fields of value i: indices field_off[i] .. field_off[i+1]) into key[] / begin[] / end[] (byte range inside value i) */

@@ -133,10 +133,25 @@ enum {
                                     of the byte before the resume point (lc_regex_match_device_from) */
     LC_TABLE_TDFA_BLOB = 9,      /* the packed TDFA tables uploaded to the device (csrc/device_tables.h) */
     LC_TABLE_TDFA_WIDE_BLOB = 10, /* small automata only: the same with byte-indexed rows, for the 1024-lane kernel */
-    LC_TABLE_TDFA_L2_BLOB = 11   /* automata too large for the LDS kernels: the tables as the global-memory kernel reads them
+    LC_TABLE_TDFA_L2_BLOB = 11,  /* automata too large for the LDS kernels: the tables as the global-memory kernel reads them
                                     (csrc/tdfa_l2_layout.h); such a handle has no LC_TABLE_TDFA_BLOB */
+    LC_TABLE_LAZY_TDFA_BLOB = 12 /* thread-list handles that have been trained (lc_regex_lazy_train): the partial automaton in the same
+                                    layout, TL_MISS != 0; valid until the handle's next training call */
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
+
+/* A LAZY / partial tagged DFA in front of the thread-list engine.  A pattern whose automaton does not determinise within the limits
+ * (LC_ENGINE_NFA handles: log formats of 170 000+ states) runs the thread-list kernels, two orders of magnitude slower per byte than a
+ * table walk -- but the values it sees visit a few thousand states.  lc_regex_lazy_train adds `n` values in HOST memory to the handle's
+ * sample (bounded: 8 192 values, 12 MiB) and (re)builds the automaton ALONG them: only the transitions the sample takes are computed,
+ * every other one leads to a MISS state (csrc/tdfa.cpp buildTdfaLazy).  Every match call on the handle then walks all values through the
+ * partial automaton first; only values that step on a MISS are walked by the thread-list kernels of the same call, from their first
+ * byte.  Results never depend on the sample: what the partial automaton decides it decides as the complete one would, and as the
+ * thread-list engine does.  Handles of other engines: LC_OK, nothing done.  Safe beside match calls on other threads.
+ * out (optional) = {states, transitions computed, sample values, sample values the tables still miss, 1 = in use}.
+ * LC_LAZY_TDFA=0 (environment, read per call) takes the partial automata out of every call (A/B, parity tests).
+ * Replaces nothing in the reference: boost and regexp2 backtrack (core/common/StringTools.cpp:183-211, processor_grok.go:156-176). */
+int lc_regex_lazy_train(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, uint64_t out[5]);
 
 /* A SCREEN for a pattern whose own tagged DFA is too large for LDS: a TDFA-engine handle for the longest prefix of the
  * pattern's top-level concatenation (captures dropped) that stays within max_states / max_table_bytes, compiled as a

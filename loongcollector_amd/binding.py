@@ -23,6 +23,7 @@ LC_SYNTAX_PREFIX = 128
 (LC_TABLE_CLASSMAP, LC_TABLE_TDFA_TRANS, LC_TABLE_TDFA_OPSSTART, LC_TABLE_TDFA_OPS, LC_TABLE_TDFA_FINALID,
  LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB, LC_TABLE_TDFA_STARTAFTER, LC_TABLE_TDFA_BLOB,
  LC_TABLE_TDFA_WIDE_BLOB, LC_TABLE_TDFA_L2_BLOB) = range(12)
+LC_TABLE_LAZY_TDFA_BLOB = 12
 
 
 class LcRegexInfo(ctypes.Structure):
@@ -231,6 +232,22 @@ class GpuRegex:
     def group_name(self, g):
         r = self._L.lc_regex_group_name(self._h, g)
         return r.decode() if r else None
+
+    def lazy_train(self, values):
+        """lc_regex_lazy_train: adds `values` (bytes objects) to the handle's sample and (re)builds its partial tagged DFA along them.
+        -> {"states", "transitions", "sample", "sample_misses", "in_use"}"""
+        n = len(values)
+        length = np.array([len(v) for v in values], dtype=np.uint32)
+        off = np.zeros(max(n, 1), dtype=np.uint32)
+        if n > 1:
+            off[1:n] = np.cumsum(length[:-1], dtype=np.uint64).astype(np.uint32)
+        data = np.frombuffer(b"".join(values) + b"\0" * 16, dtype=np.uint8).copy()
+        out = (ctypes.c_uint64 * 5)()
+        self._L.lc_regex_lazy_train.restype = ctypes.c_int
+        self._L.lc_regex_lazy_train.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_void_p]
+        _check(self._L.lc_regex_lazy_train(self._h, data.ctypes.data, off.ctypes.data, length.ctypes.data, n, ctypes.cast(out, ctypes.c_void_p)),
+               "lc_regex_lazy_train")
+        return dict(zip(("states", "transitions", "sample", "sample_misses", "in_use"), (int(x) for x in out)))
 
     def table(self, which, dtype):
         p = ctypes.c_void_p()

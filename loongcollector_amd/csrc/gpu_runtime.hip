@@ -339,9 +339,47 @@ static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     return LC_OK;
 }
 
+// The lazy automaton's device copy for `dev` (regex_handle.hpp LcLazyTdfa): uploaded when the handle's version is newer than the copy;
+// the older copy retires -- launches of other threads may still read it -- and is freed with the handle.  hostBlobOut: the header words.
+static int ensureLazyUploaded(lc_regex* re, int dev, void** out, std::vector<uint32_t>* hostHeader) {
+    LcLazyTdfa& Z = re->lazy;
+    std::lock_guard<std::mutex> g(Z.m);
+    if (Z.blob.empty() || Z.disabled) {
+        *out = nullptr;
+        return LC_OK;
+    }
+    if (!Z.dBlob[dev] || Z.dVersion[dev] != Z.version) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, Z.blob.size() * 4 + 16));
+        const hipError_t e = hipMemcpy(p, Z.blob.data(), Z.blob.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return hipFail(e, "hipMemcpy(lazy tables)");
+        }
+        if (Z.dBlob[dev]) Z.retired.emplace_back(dev, Z.dBlob[dev]);
+        Z.dBlob[dev] = p;
+        Z.dVersion[dev] = Z.version;
+    }
+    *out = Z.dBlob[dev];
+    hostHeader->assign(Z.blob.begin(), Z.blob.begin() + TL_HEADER_WORDS);
+    Z.launches.fetch_add(1, std::memory_order_relaxed);
+    return LC_OK;
+}
+
 void lcReleaseDeviceTables(lc_regex* re) {
     int cur = 0;
     bool haveCur = hipGetDevice(&cur) == hipSuccess;
+    {
+        LcLazyTdfa& Z = re->lazy;
+        for (int d = 0; d < kLcMaxDevices; ++d)
+            if (Z.dBlob[d]) {
+                Z.retired.emplace_back(d, Z.dBlob[d]);
+                Z.dBlob[d] = nullptr;
+            }
+        for (const auto& r : Z.retired)
+            if (hipSetDevice(r.first) == hipSuccess) (void)hipFree(r.second);
+        Z.retired.clear();
+    }
     for (int d = 0; d < kLcMaxDevices; ++d) {
         if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d] || re->dTdfaL2Blob[d]) {
             if (hipSetDevice(d) == hipSuccess) {
@@ -465,6 +503,82 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
 static bool lcPairOneFormat(const std::vector<uint32_t>& blob) {
     const uint32_t po = blob[TD_OFF_PAIR];
     return po != 0 && po / 4 + TP_FORMAT < blob.size() && blob[po / 4 + TP_FORMAT] == 1;
+}
+
+// The two walks of an automaton whose tables live in global memory (tdfa_l2_kernel.hpp), chosen per launch.  `hostBlob`: the blob's
+// words on the host (header fields); `dBlob`: its device copy.  pendingFlag / seq: lazy automata only (TL_MISS) -- where a line that
+// stepped on an uncomputed transition raises the launch's pending flag.  launchTdfa (the LDS kernels) serves a handle that asked for the
+// wave walk (`waveByChoice`) when LC_TDFA_WAVE_MAX=0 takes the wave walk away.
+static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
+                      uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps,
+                      uint8_t* d_status, hipStream_t stream);
+static int launchTdfaL2Family(lc_regex* re, const uint32_t* hostBlob, const void* dBlob, bool waveByChoice, int dev, const uint8_t* d_data,
+                              const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n,
+                              const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
+                              hipStream_t stream, uint32_t* pendingFlag, uint32_t seq) {
+    const uint32_t nRegs = hostBlob[TL_NREGS];
+    // Small and medium batches wait for their longest value: ONE VALUE PER WAVEFRONT (tdfa_wave_kernel: wave-uniform state, quiet
+    // runs crossed 256 bytes at a time).  Large batches are about values in flight: one value per lane.  LC_TDFA_WAVE_MAX: the
+    // largest batch that takes the wave kernel (0 = never; A/B measurements).
+    // (read at every launch: the GPU tests run both kernels in one process)
+    const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
+    const uint32_t waveMax = uint32_t(waveEnv ? atol(waveEnv) : 65536);
+    const bool perWave = n <= waveMax && (waveMax != 0 || !waveByChoice);
+    if (waveByChoice && !perWave)  // (LC_TDFA_WAVE_MAX=0: the LDS kernels, as if the handle had not asked)
+        return launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    size_t lds = perWave ? size_t(nRegs) * kTdfaWaveValues * 4 : size_t(nRegs) * kTdfaL2Block * 4;
+    // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
+    uint32_t stageBytes = 0;
+    static const bool stageOffAll = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
+    {
+        const uint32_t progBytes = (hostBlob[TL_OFF_FINALID] - hostBlob[TL_OFF_OPSSTART] + 3u) & ~3u;
+        if (!stageOffAll && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stageBytes = progBytes;
+    }
+    if (perWave) {
+        // (round 5) a small automaton rides in LDS whole: transition table + register programs (tdfa_l2_kernel.hpp LT)
+        // MEASURED AND LEFT OFF (LC_TDFA_WAVE_LDS_TRANS=1 switches it on): once the walk's state lives in SGPRs the transition read is a
+        // scalar load through the scalar cache, as fast as the LDS read + readfirstlane, without staging up to 48 KB per four values
+        // (CISCOFW105003 on its 314 values: 0.389 ms from L2, 0.411 ms from LDS; profiles/round5_wave_step.txt)
+        const bool transOff = [] {  // (read per launch: the GPU tests run both forms)
+            const char* v = getenv("LC_TDFA_WAVE_LDS_TRANS");
+            return !(v && v[0] == '1');
+        }();
+        const uint32_t allBytes = (hostBlob[TL_OFF_FINALID] - hostBlob[TL_OFF_TRANS] + 3u) & ~3u;
+        const bool ldsTrans = !transOff && !stageOffAll && n <= 32768 && allBytes <= 48 * 1024 && lds + allBytes <= 60 * 1024;
+        if (ldsTrans) stageBytes = allBytes;
+        lds += stageBytes;
+        static thread_local size_t waveLdsAttrSet[2][kLcMaxDevices] = {};
+        if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > waveLdsAttrSet[ldsTrans][dev]) {
+            HIP_TRY(hipFuncSetAttribute(ldsTrans ? reinterpret_cast<const void*>(tdfa_wave_kernel<true>)
+                                                 : reinterpret_cast<const void*>(tdfa_wave_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            waveLdsAttrSet[ldsTrans][dev] = lds;
+        }
+        noteKernel(pendingFlag ? "tdfa_l2_kernel:wave:lazy" : ldsTrans ? "tdfa_l2_kernel:wave:lds" : "tdfa_l2_kernel:wave");
+        if (ldsTrans)
+            hipLaunchKernelGGL(tdfa_wave_kernel<true>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
+                               d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
+                               d_status, stageBytes, pendingFlag, seq);
+        else
+            hipLaunchKernelGGL(tdfa_wave_kernel<false>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
+                               d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
+                               d_status, stageBytes, pendingFlag, seq);
+        HIP_TRY(hipGetLastError());
+        return LC_OK;
+    }
+    lds += stageBytes;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
+    if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > ldsAttrSet[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        ldsAttrSet[dev] = lds;
+    }
+    noteKernel(pendingFlag ? "tdfa_l2_kernel:lazy" : "tdfa_l2_kernel");
+    // (no completion signal of its own: a caller that polls queues lc_signal_kernel behind it, see tlsDone)
+    hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
+                       d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, stageBytes,
+                       pendingFlag, seq);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
 }
 
 static int launchTdfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len,
@@ -663,6 +777,10 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
     if (chance == kNfaDecideOnly) return LC_OK;
     bool wideFirst = chance == kNfaWideFirst || chance == kNfaWideChain;
     if constexpr (ATOMIC || NS > 64) wideFirst = false;
+    // behind a first engine that left lines pending (the lazy automaton, the depth-first walk) the narrow kernel takes exactly those
+    // lines and the wide kernel is its second chance, as in the whole chain -- "wide first" walks every line whatever its status says
+    const bool behindFirstEngine = pendingFlag != nullptr && wideFirst;
+    if (behindFirstEngine) wideFirst = false;
     {
         static const bool wideOff = getenv("LC_NFA_NO_WIDE") != nullptr;
         const size_t wideLds0 = (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4;
@@ -675,7 +793,7 @@ static int launchNfaSlots(const void* dBlob, uint32_t blobBytes, uint32_t nPos, 
                            seq, pendingFlag);
         HIP_TRY(hipGetLastError());
     }
-    if (chance == kNfaFirstChance || (chance == kNfaWideFirst && !wideFirst)) return LC_OK;
+    if (chance == kNfaFirstChance || (chance == kNfaWideFirst && !wideFirst && !behindFirstEngine)) return LC_OK;
     // Second chance for the lines that needed more than 64 live threads (nfa_wide_kernel.hpp: two threads per lane), for
     // patterns without atomic groups whose capture offsets fit twice into a lane's registers.  Its workgroups return at
     // once unless the launch above raised the overflow flag.
@@ -802,12 +920,33 @@ static int launchNfa(lc_regex* re, int dev, const uint8_t* d_data, const uint32_
     // against ~2 us for a thread-list byte-step, and on the batch sizes measured (8-64 Ki lines, where every launch is bound by
     // its longest line) it loses 5-10x (profiles/round2_grok_dfs_vs_threadlist.txt).  LC_NFA_DFS=1 or lc_nfa_set_dfs(1).
     const uint32_t* pendingFlag = nullptr;
+    // ---- the LAZY automaton first (round 6, regex_handle.hpp LcLazyTdfa): every value walks the partial tagged DFA -- a table read
+    // per byte instead of a thread-list step -- and only the values that step on an uncomputed transition (LC_PENDING, the launch's
+    // pending flag raised) are this launch's business for the kernels below.  Same protocol as the depth-first walk's.
+    bool lazyFront = false;
+    if (!decideOnly && chance != kNfaSecondChance && chance != kNfaDecideOnly && re->lazyReady.load(std::memory_order_acquire)) {
+        const char* lazyEnv = getenv("LC_LAZY_TDFA");  // (read per launch: the parity tests run with and without in one process)
+        if (!(lazyEnv && lazyEnv[0] == '0')) {
+            void* dLazy = nullptr;
+            std::vector<uint32_t> lazyHeader;
+            rc = ensureLazyUploaded(re, dev, &dLazy, &lazyHeader);
+            if (rc != LC_OK) return rc;
+            if (dLazy) {
+                uint32_t* pf = overflowFlag + 1;
+                rc = launchTdfaL2Family(re, lazyHeader.data(), dLazy, false, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                                        d_caps, d_status, stream, pf, seq);
+                if (rc != LC_OK) return rc;
+                pendingFlag = pf;
+                lazyFront = true;
+            }
+        }
+    }
     static const bool dfsEnv = [] {
         const char* e = getenv("LC_NFA_DFS");
         return e && e[0] == '1';
     }();
     const int dfsMode = gNfaDfsMode.load(std::memory_order_relaxed);
-    if (!decideOnly && (dfsMode < 0 ? dfsEnv : dfsMode != 0)) {
+    if (!decideOnly && !lazyFront && (dfsMode < 0 ? dfsEnv : dfsMode != 0)) {
         static const size_t poolCap = [] {
             const char* e = getenv("LC_NFA_DFS_POOL_MB");
             long mb = e ? atol(e) : 4096;
@@ -1050,69 +1189,8 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
         void* dBlob = nullptr;
         rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
         if (rc != LC_OK) return rc;
-        // Small and medium batches wait for their longest value: ONE VALUE PER WAVEFRONT (tdfa_wave_kernel: wave-uniform state, quiet
-        // runs crossed 256 bytes at a time).  Large batches are about values in flight: one value per lane.  LC_TDFA_WAVE_MAX: the
-        // largest batch that takes the wave kernel (0 = never; A/B measurements).
-        // (read at every launch: the GPU tests run both kernels in one process)
-        const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
-        const uint32_t waveMax = uint32_t(waveEnv ? atol(waveEnv) : 65536);
-        const bool perWave = n <= waveMax && (waveMax != 0 || !waveByChoice);
-        if (waveByChoice && !perWave) {  // (LC_TDFA_WAVE_MAX=0: the LDS kernels, as if the handle had not asked)
-            rc = launchTdfa(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
-        } else {
-        size_t lds = perWave ? size_t(re->tdfa.nRegs) * kTdfaWaveValues * 4 : size_t(re->tdfa.nRegs) * kTdfaL2Block * 4;
-        // the register programs (opsStart + ops, contiguous in the blob) ride in LDS when the batch is small (tdfa_l2_kernel.hpp)
-        uint32_t stageBytes = 0;
-        static const bool stageOffAll = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
-        {
-            static const bool stageOff = stageOffAll;
-            const uint32_t progBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_OPSSTART] + 3u) & ~3u;
-            if (!stageOff && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stageBytes = progBytes;
-        }
-        if (perWave) {
-            // (round 5) a small automaton rides in LDS whole: transition table + register programs (tdfa_l2_kernel.hpp LT)
-            // MEASURED AND LEFT OFF (LC_TDFA_WAVE_LDS_TRANS=1 switches it on): once the walk's state lives in SGPRs the transition read is a
-            // scalar load through the scalar cache, as fast as the LDS read + readfirstlane, without staging up to 48 KB per four values
-            // (CISCOFW105003 on its 314 values: 0.389 ms from L2, 0.411 ms from LDS; profiles/round5_wave_step.txt)
-            const bool transOff = [] {  // (read per launch: the GPU tests run both forms)
-                const char* v = getenv("LC_TDFA_WAVE_LDS_TRANS");
-                return !(v && v[0] == '1');
-            }();
-            const uint32_t allBytes = (re->tdfaL2Blob[TL_OFF_FINALID] - re->tdfaL2Blob[TL_OFF_TRANS] + 3u) & ~3u;
-            const bool ldsTrans = !transOff && !stageOffAll && n <= 32768 && allBytes <= 48 * 1024 && lds + allBytes <= 60 * 1024;
-            if (ldsTrans) stageBytes = allBytes;
-            lds += stageBytes;
-            static thread_local size_t waveLdsAttrSet[2][kLcMaxDevices] = {};
-            if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > waveLdsAttrSet[ldsTrans][dev]) {
-                HIP_TRY(hipFuncSetAttribute(ldsTrans ? reinterpret_cast<const void*>(tdfa_wave_kernel<true>)
-                                                     : reinterpret_cast<const void*>(tdfa_wave_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-                waveLdsAttrSet[ldsTrans][dev] = lds;
-            }
-            noteKernel(ldsTrans ? "tdfa_l2_kernel:wave:lds" : "tdfa_l2_kernel:wave");
-            if (ldsTrans)
-                hipLaunchKernelGGL(tdfa_wave_kernel<true>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
-                                   d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
-                                   d_status, stageBytes);
-            else
-                hipLaunchKernelGGL(tdfa_wave_kernel<false>, dim3((n + kTdfaWaveValues - 1) / kTdfaWaveValues), dim3(kTdfaWaveBlock), lds, stream,
-                                   d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps,
-                                   d_status, stageBytes);
-            HIP_TRY(hipGetLastError());
-        } else {
-        lds += stageBytes;
-        static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
-        if (lds > 48 * 1024 && dev < kLcMaxDevices && lds > ldsAttrSet[dev]) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            ldsAttrSet[dev] = lds;
-        }
-        noteKernel("tdfa_l2_kernel");
-        // (no completion signal of its own: a caller that polls queues lc_signal_kernel behind it, see tlsDone)
-        hipLaunchKernelGGL(tdfa_l2_kernel, dim3((n + kTdfaL2Block - 1) / kTdfaL2Block), dim3(kTdfaL2Block), lds, stream, d_data, d_off,
-                           d_len, sep, n, d_n, d_order, d_resume, static_cast<const uint32_t*>(dBlob), ngroups, d_caps, d_status, stageBytes);
-        HIP_TRY(hipGetLastError());
-        }
-        }
+        rc = launchTdfaL2Family(re, re->tdfaL2Blob.data(), dBlob, waveByChoice, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups,
+                                d_caps, d_status, stream, nullptr, 0u);
     } else if (engine == LC_ENGINE_TDFA) {
         if (!re->hasTdfa) {
             tlsError = "pattern has no TDFA: " + re->tdfaError;

@@ -1509,6 +1509,39 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
                                d_scratch, st, dev);
 }
 
+int lcGrokSampleDevice(const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, uint32_t maxValues, void* streamPtr,
+                       std::vector<uint8_t>& data, std::vector<uint32_t>& off, std::vector<uint32_t>& len) {
+    data.clear();
+    off.clear();
+    len.clear();
+    const uint32_t take = std::min(n, maxValues);
+    if (!take) return LC_OK;
+    int dev = 0;
+    {
+        const int rcDev = lcDeviceEntryDevice(d_data, &dev);
+        if (rcDev != LC_OK) return rcDev;
+    }
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(streamPtr)));  // (what the caller queued before the call has produced the batch)
+    std::vector<uint32_t> o(take), l(take);
+    HIP_TRY(hipMemcpy(o.data(), d_off, size_t(take) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(l.data(), d_len, size_t(take) * 4, hipMemcpyDeviceToHost));
+    // one copy of the byte range the values span (batches are packed: the range is the values themselves)
+    uint64_t lo = ~uint64_t(0), hi = 0;
+    for (uint32_t i = 0; i < take; ++i) {
+        lo = std::min<uint64_t>(lo, o[i]);
+        hi = std::max<uint64_t>(hi, uint64_t(o[i]) + l[i]);
+    }
+    if (hi <= lo || hi - lo > (uint64_t(64) << 20)) return LC_OK;  // (nothing, or values strewn over more than is worth a sample)
+    std::vector<uint8_t> range(size_t(hi - lo));
+    HIP_TRY(hipMemcpy(range.data(), d_data + lo, range.size(), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < take; ++i) {
+        off.push_back(uint32_t(data.size()));
+        len.push_back(l[i]);
+        data.insert(data.end(), range.begin() + long(o[i] - lo), range.begin() + long(o[i] - lo + l[i]));
+    }
+    return LC_OK;
+}
+
 // What a thread that calls lcGrokMatchHost keeps between calls (ProcessLogs hands over group after group): a stream of its own
 // (runner threads must not meet on the null stream), pinned staging for the way in and the way out, device buffers; grow-only.
 namespace {

@@ -66,6 +66,10 @@ int lcGrokMatchDevice(const std::vector<GrokDevicePattern>& patterns, GrokDevice
 int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceState* state, const GrokOptions& opts, uint32_t rowInts,
                     const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, int32_t* pattern,
                     const int32_t** firstRows, std::vector<int32_t>& extraRows);
+// up to `maxValues` of a DEVICE-resident batch's first values, copied to host memory (offsets rebased to the copy): the lazy automata's
+// trainer (processor_grok_gpu.cpp) takes its sample of a device-fed handle this way.  Synchronises `stream` (rare: see OfferDeviceBatch).
+int lcGrokSampleDevice(const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, uint32_t maxValues, void* stream,
+                       std::vector<uint8_t>& data, std::vector<uint32_t>& off, std::vector<uint32_t>& len);
 // the group commit behind lcGrokMatchHost (group_combiner.hpp), summed over the devices of `state`:
 // out = {batches, groups, values, most groups in one batch, batches started by the linger's timeout}
 int lcGrokCombinerStats(GrokDeviceState* state, uint64_t out[11]);

@@ -71,6 +71,7 @@ GrokOptions ProcessorGrokGpu::options() const {
 }
 
 ProcessorGrokGpu::~ProcessorGrokGpu() {
+    stopTrainer();
     stopWarmup();
     lcGrokStateFree(mState);
     for (lc_regex* re : mCompiled) lc_regex_free(re);
@@ -80,6 +81,7 @@ ProcessorGrokGpu::~ProcessorGrokGpu() {
 int ProcessorGrokGpu::engine(size_t i) const { return i < mCompiled.size() ? mCompiled[i]->engine : 0; }
 
 void ProcessorGrokGpu::Init() {
+    stopTrainer();
     stopWarmup();
     lcGrokStateFree(mState);
     mState = lcGrokStateCreate();
@@ -245,6 +247,137 @@ void ProcessorGrokGpu::startWarmup() {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the lazy automata's trainer
+// Entries whose automaton does not determinise run the thread-list kernels (12 000 cycles per byte step) -- unless a LAZY automaton
+// stands in front of them (regex_handle.hpp LcLazyTdfa: built along sample values; a value that steps on a transition nobody has
+// computed falls through to the thread-list kernels).  The sample is the processor's own traffic: a batch is OFFERED -- a copy of at
+// most kLazyOfferValues of its values, a window that moves through the batch from offer to offer -- when the trainer is idle: the first
+// 64 batches at once, later ones every 200 ms at most
+// (a log source drifts: new hosts, new message kinds).  The trainer walks the copy through every such entry's current tables on the
+// host, keeps what misses and rebuilds (lcRegexLazyTrain): tens of milliseconds per entry, off the data path.
+bool ProcessorGrokGpu::wantsOffer() {
+    if (!LazyTdfa) return false;
+    static const bool envOff = [] {
+        const char* e = getenv("LC_LAZY_TDFA");
+        return e && e[0] == '0';
+    }();
+    if (envOff) return false;
+    std::lock_guard<std::mutex> g(mTrainerMutex);
+    if (mTrainerStop || mTrainerBusy || mTrainerMail) return false;
+    if (mTrainerTaken < 64) return true;
+    return std::chrono::steady_clock::now() - mLastOffer >= std::chrono::milliseconds(200);
+}
+
+// the window of a batch an offer copies: it moves on with every offer, so a source that sends the same kinds of lines in the same places
+// of its batches is seen whole
+uint32_t ProcessorGrokGpu::offerWindow(uint32_t n, uint32_t take) {
+    if (n <= take) return 0;
+    const uint32_t windows = (n + take - 1) / take;
+    const uint32_t w = mOfferRotor.fetch_add(1, std::memory_order_relaxed) % windows;
+    return std::min(w * take, n - take);
+}
+
+void ProcessorGrokGpu::postOffer(std::unique_ptr<LazyBatch> b) {
+    std::lock_guard<std::mutex> g(mTrainerMutex);
+    if (mTrainerStop || mTrainerMail) return;
+    mTrainerMail = std::move(b);
+    mLastOffer = std::chrono::steady_clock::now();
+    if (!mTrainer.joinable()) mTrainer = std::thread([this] { trainerLoop(); });
+    mTrainerCv.notify_all();
+}
+
+void ProcessorGrokGpu::OfferBatch(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n) {
+    if (!n || !wantsOffer()) return;
+    auto b = std::make_unique<LazyBatch>();
+    const uint32_t take = std::min(n, kLazyOfferValues);
+    const uint32_t first = offerWindow(n, take);
+    size_t bytes = 0;
+    for (uint32_t i = first; i < first + take; ++i) bytes += len[i];
+    b->data.reserve(bytes + 16);
+    for (uint32_t i = first; i < first + take; ++i) {
+        b->off.push_back(uint32_t(b->data.size()));
+        b->len.push_back(len[i]);
+        b->data.insert(b->data.end(), data + off[i], data + off[i] + len[i]);
+    }
+    postOffer(std::move(b));
+}
+
+void ProcessorGrokGpu::OfferDeviceBatch(const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, void* stream) {
+    if (!n || !wantsOffer()) return;
+    auto b = std::make_unique<LazyBatch>();
+    const uint32_t take = std::min(n, kLazyOfferValues);
+    const uint32_t first = offerWindow(n, take);
+    if (lcGrokSampleDevice(d_data, d_off + first, d_len + first, take, take, stream, b->data, b->off, b->len) != LC_OK || b->len.empty()) return;
+    postOffer(std::move(b));
+}
+
+void ProcessorGrokGpu::trainerLoop() {
+    for (;;) {
+        std::unique_ptr<LazyBatch> b;
+        {
+            std::unique_lock<std::mutex> lk(mTrainerMutex);
+            mTrainerCv.wait(lk, [&] { return mTrainerStop || mTrainerMail; });
+            if (mTrainerStop) return;
+            b = std::move(mTrainerMail);
+            mTrainerBusy = true;
+        }
+        const uint32_t n = uint32_t(b->len.size());
+        for (size_t i = 0; i < mCompiled.size(); ++i) {
+            {
+                std::lock_guard<std::mutex> lk(mTrainerMutex);
+                if (mTrainerStop) break;
+            }
+            // the search itself, and its anchored form when the warm-up thread has delivered one (round 0 runs that)
+            (void)lcRegexLazyTrain(mCompiled[i], b->data.data(), b->off.data(), b->len.data(), n, nullptr);
+            if (mAnchored)
+                if (lc_regex* a = mAnchored[i].load(std::memory_order_acquire))
+                    (void)lcRegexLazyTrain(a, b->data.data(), b->off.data(), b->len.data(), n, nullptr);
+        }
+        {
+            std::lock_guard<std::mutex> lk(mTrainerMutex);
+            mTrainerBusy = false;
+            ++mTrainerTaken;
+        }
+        mTrainerCv.notify_all();
+    }
+}
+
+void ProcessorGrokGpu::stopTrainer() {
+    {
+        std::lock_guard<std::mutex> g(mTrainerMutex);
+        mTrainerStop = true;
+    }
+    mTrainerCv.notify_all();
+    if (mTrainer.joinable()) mTrainer.join();
+    std::lock_guard<std::mutex> g(mTrainerMutex);
+    mTrainerStop = false;
+    mTrainerBusy = false;
+    mTrainerMail.reset();
+    mTrainerTaken = 0;
+}
+
+bool ProcessorGrokGpu::LazySettle(uint32_t timeoutMs) {
+    std::unique_lock<std::mutex> lk(mTrainerMutex);
+    return mTrainerCv.wait_for(lk, std::chrono::milliseconds(timeoutMs), [&] { return !mTrainerBusy && !mTrainerMail; });
+}
+
+void ProcessorGrokGpu::LazyStats(uint64_t out[5]) {
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    auto add = [&](lc_regex* re) {
+        if (!re) return;
+        out[0] += re->lazyReady.load() ? 1 : 0;
+        out[1] += re->lazy.builds.load();
+        out[2] += re->lazy.offered.load();
+        out[3] += re->lazy.kept.load();
+    };
+    for (size_t i = 0; i < mCompiled.size(); ++i) {
+        add(mCompiled[i]);
+        if (mAnchored) add(mAnchored[i].load(std::memory_order_acquire));
+    }
+    std::lock_guard<std::mutex> g(mTrainerMutex);
+    out[4] = mTrainerTaken;
+}
+
 // named non-empty groups of one match, in Groups() order (:167-175)
 void ProcessorGrokGpu::emitRow(size_t p, const int32_t* row, std::vector<Field>& out) const {
     for (const auto& f : mFields[p]) {
@@ -271,6 +404,7 @@ void ProcessorGrokGpu::MatchValues(const uint8_t* data, const uint32_t* off, con
     }
     std::vector<int32_t> extra;
     const int32_t* first = nullptr;
+    OfferBatch(data, off, len, n);  // (the lazy automata's trainer: a copy now and then, see above)
     int rc = lcGrokMatchHost(devicePatterns(), mState, options(), mRowInts, data, off, len, n, pattern, &first, extra);
     if (rc != LC_OK) throw GrokError(std::string("grok device match failed: ") + lc_last_error());
     const size_t w = mRowInts + 2;
@@ -386,6 +520,7 @@ extern "C" int lc_grok_create(const char* config_json, size_t config_len, lc_gro
         boolean("KeepSource", g->p.KeepSource);
         boolean("AnchoredFirst", g->p.AnchoredFirst);
         boolean("Speculative", g->p.Speculative);
+        boolean("LazyTdfa", g->p.LazyTdfa);
         if (const lcjson::Value* v = cfg.find("AnchoredBudgetMB"))
             if (v->isNumber()) g->p.AnchoredBudgetMB = v->isInt ? v->inum : int64_t(v->num);
         if (const lcjson::Value* v = cfg.find("PrefixScreenAbove"))
@@ -511,6 +646,7 @@ extern "C" int lc_grok_match_device(lc_grok_t* g, const uint8_t* d_data, const u
                                     uint32_t* d_nextra, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!g) return LC_ERR_ARG;
     if (!g->p.deviceState()) return LC_ERR_ARG;
+    g->p.OfferDeviceBatch(d_data, d_off, d_len, n, stream);  // (the lazy automata's trainer: a copy now and then)
     return lcGrokMatchDevice(g->p.devicePatterns(), g->p.deviceState(), g->p.options(), g->p.rowInts(), d_data, d_off, d_len, n,
                              d_pattern, d_first, d_extra, extra_cap, d_nextra, d_scratch, scratch_bytes, stream);
 }
@@ -552,6 +688,16 @@ extern "C" int lc_grok_match_host(lc_grok_t* g, const uint8_t* data, const uint3
         return lc_device_count() <= 0 ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
     }
     *result = r.release();
+    return LC_OK;
+}
+
+extern "C" int lc_grok_lazy_settle(lc_grok_t* g, uint32_t timeout_ms) {
+    if (!g) return LC_ERR_ARG;
+    return g->p.LazySettle(timeout_ms) ? LC_OK : LC_ERR_ARG;
+}
+extern "C" int lc_grok_lazy_stats(lc_grok_t* g, uint64_t out[5]) {
+    if (!g || !out) return LC_ERR_ARG;
+    g->p.LazyStats(out);
     return LC_OK;
 }
 

@@ -7,6 +7,8 @@
 #pragma once
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <thread>
 #include <map>
 #include <mutex>
@@ -51,6 +53,10 @@ public:
     bool Speculative = true;
     int64_t PrefixScreenAbove = 65536;
     int64_t Streams = 16;  // worker streams of a batch's entries (1..16; see gpu_runtime.hip on GPU_MAX_HW_QUEUES)
+    // not a reference key: the entries whose automaton does not determinise get a LAZY one (regex_handle.hpp LcLazyTdfa), built by a
+    // background thread along the values the processor is handed -- the first batches at once, later ones now and then (results never
+    // depend on it; "LazyTdfa": false, or LC_LAZY_TDFA=0 in the environment, leaves those entries to the thread-list kernels alone)
+    bool LazyTdfa = true;
     bool NoKeyError = false;
     bool NoMatchError = true;
     bool TimeoutError = true;
@@ -81,6 +87,13 @@ public:
     uint64_t anchoredBytes() const { return mAnchoredBytes.load(); }
     GrokDeviceState* deviceState() { return mState; }
     int CombinerStats(uint64_t out[11]) { return lcGrokCombinerStats(mState, out); }  // lc_grok_combiner_stats
+    // the lazy automata's trainer: a batch in host memory is offered (copied, at most kLazyOfferValues of its values, when the trainer is
+    // idle and the last offer is old enough); OfferDeviceBatch fetches them from the device first.  LazySettle waits until the trainer
+    // has nothing to do; LazyStats: {handles with a lazy automaton in use, builds, values offered, values kept in samples, batches taken}
+    void OfferBatch(const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n);
+    void OfferDeviceBatch(const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n, void* stream);
+    bool LazySettle(uint32_t timeoutMs);
+    void LazyStats(uint64_t out[5]);
     GrokOptions options() const;
     int engine(size_t i) const;
 
@@ -98,6 +111,25 @@ private:
     std::vector<size_t> mWarmupWant;                   // the entries the warm-up thread compiles an anchored search for
     void startWarmup();
     void stopWarmup();
+    // ---- lazy-automaton trainer
+    static constexpr uint32_t kLazyOfferValues = 4096;
+    struct LazyBatch {
+        std::vector<uint8_t> data;
+        std::vector<uint32_t> off, len;
+    };
+    std::thread mTrainer;
+    std::mutex mTrainerMutex;
+    std::condition_variable mTrainerCv;
+    std::unique_ptr<LazyBatch> mTrainerMail;   // the batch waiting for the trainer (at most one)
+    bool mTrainerBusy = false, mTrainerStop = false;
+    uint64_t mTrainerTaken = 0;                // batches the trainer has worked through
+    std::chrono::steady_clock::time_point mLastOffer{};
+    std::atomic<uint32_t> mOfferRotor{0};
+    uint32_t offerWindow(uint32_t n, uint32_t take);
+    bool wantsOffer();                         // cheap test on the caller's thread
+    void postOffer(std::unique_ptr<LazyBatch> b);
+    void stopTrainer();
+    void trainerLoop();
     std::vector<GrokDevicePattern> mDevice;
     GrokDeviceState* mState = nullptr;                 // literal index + screen table on the device(s), built on first use
     std::vector<std::string> mKeys;                    // distinct emitted keys

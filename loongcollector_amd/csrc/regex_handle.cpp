@@ -642,8 +642,9 @@ std::vector<uint32_t> packTdfaL2Blob(const TdfaTables& t) {
                 if (t.trans[size_t(st) * t.nClasses + c] == st) quiet[st] |= uint64_t(1) << c;
         hdr[TL_OFF_QUIET] = w.put(quiet);
     }
+    hdr[TL_MISS] = t.missState;
     for (uint32_t st = 1; st < t.nStates && !hdr[TL_ABSORB]; ++st) {
-        bool self = t.finalId[st] != 0xFFFF;
+        bool self = t.finalId[st] != 0xFFFF && st != t.missState;  // (the MISS sink of a lazy automaton decides nothing)
         for (uint32_t c = 0; c < t.nClasses && self; ++c) self = t.trans[size_t(st) * t.nClasses + c] == st;  // (next = st, program 0)
         if (self) hdr[TL_ABSORB] = st;
     }
@@ -1446,6 +1447,105 @@ void lcPreferWaveTdfa(lc_regex* re) {
     re->preferWave = !re->tdfaL2Blob.empty();
 }
 
+// ------------------------------------------------------------------------------------------------ lazy automata (round 6)
+int lcRegexLazyTrain(lc_regex* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, uint64_t out[5]) {
+    if (out)
+        for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!re || (n && (!data || !off || !len))) return LC_ERR_ARG;
+    if (re->engine != LC_ENGINE_NFA || re->nfaBlob.empty()) return LC_OK;  // a complete automaton, or nothing to stand in front of
+    LcLazyTdfa& Z = re->lazy;
+    std::lock_guard<std::mutex> train(Z.trainMutex);
+    {
+        std::lock_guard<std::mutex> g(Z.m);
+        if (Z.disabled) return LC_OK;
+    }
+    constexpr size_t kMaxSampleValues = 8192, kMaxSampleBytes = size_t(12) << 20;
+    constexpr uint32_t kPerRound = 256;  // values added between two rebuilds
+    Z.offered.fetch_add(n, std::memory_order_relaxed);
+    // where a value ends on the current tables: 0 = dead, missState = undecided, anything else = decided
+    auto endsInMiss = [&](const uint8_t* p, uint32_t L) {
+        if (!Z.haveTables) return true;
+        const lcregex::TdfaTables& t = Z.tables;
+        uint32_t st = t.startState;
+        for (uint32_t i = 0; i < L && st != 0 && st != t.missState; ++i) st = t.trans[size_t(st) * t.nClasses + t.classMap[p[i]]] & 0xFFFFu;
+        return st == t.missState;
+    };
+    auto sampleFull = [&](uint32_t L) { return Z.sampleLen.size() >= kMaxSampleValues || Z.sampleData.size() + L > kMaxSampleBytes; };
+    uint32_t stillMissing = 0;
+    bool built = false;
+    for (uint32_t next = 0, rounds = 0; rounds < 64; ++rounds) {
+        // the offered values the tables do not decide join the sample, a few hundred at a time (most of a round's misses are decided
+        // by what the round's first values add)
+        uint32_t added = 0;
+        stillMissing = 0;
+        if (!Z.frozen)
+            for (; next < n && added < kPerRound; ++next) {
+                if (!endsInMiss(data + off[next], len[next])) continue;
+                if (sampleFull(len[next])) {
+                    ++stillMissing;
+                    continue;
+                }
+                Z.sampleOff.push_back(uint32_t(Z.sampleData.size()));
+                Z.sampleLen.push_back(len[next]);
+                Z.sampleData.insert(Z.sampleData.end(), data + off[next], data + off[next] + len[next]);
+                ++added;
+            }
+        if (!added) break;
+        Z.kept.fetch_add(added, std::memory_order_relaxed);
+        lcregex::TdfaLimits lim;
+        lim.maxStates = 60000;
+        lim.ldsWindow = false;
+        lim.maxPathWork = uint64_t(1) << 31;   // (a step of a 3 000-position format looks at a few hundred paths: room for millions of steps)
+        lim.maxCommitWork = uint64_t(1) << 30;
+        lcregex::TdfaLazyGuide guide;
+        guide.data = Z.sampleData.data();
+        guide.off = Z.sampleOff.data();
+        guide.len = Z.sampleLen.data();
+        guide.n = uint32_t(Z.sampleLen.size());
+        guide.maxTableBytes = size_t(8) << 20;
+        lcregex::TdfaTables t;
+        lcregex::TdfaLazyReport rep;
+        bool failed = false;
+        try {
+            t = lcregex::buildTdfaLazy(re->nfa, lim, guide, &rep);
+        } catch (const lcregex::RegexError&) {  // (register limit, layout limits: this pattern stays on the thread-list engine alone)
+            failed = true;
+        }
+        if (failed || t.missState == 0 || t.nRegs > 250 || (rep.stopped && rep.transitionsComputed < 64)) {
+            std::lock_guard<std::mutex> g(Z.m);
+            Z.disabled = true;
+            Z.blob.clear();
+            re->lazyReady.store(false, std::memory_order_release);
+            return LC_OK;
+        }
+        Z.tables = std::move(t);
+        Z.haveTables = true;
+        Z.report = rep;
+        Z.frozen = rep.stopped;  // a limit: what is there stays in use, nothing is added any more
+        built = true;  // (the values in front of `next` are decided by the new tables: they were decided before, or have just joined the sample)
+    }
+    if (built) {
+        std::vector<uint32_t> blob = lcregex::packTdfaL2Blob(Z.tables);
+        std::lock_guard<std::mutex> g(Z.m);
+        Z.blob.swap(blob);
+        ++Z.version;
+        Z.builds.fetch_add(1, std::memory_order_relaxed);
+        re->lazyReady.store(true, std::memory_order_release);
+    }
+    if (out && Z.haveTables) {
+        out[0] = Z.tables.nStates;
+        out[1] = Z.report.transitionsComputed;
+        out[2] = Z.sampleLen.size();
+        out[3] = stillMissing;
+        out[4] = 1;
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_regex_lazy_train(lc_regex_t* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, uint64_t out[5]) {
+    return lcRegexLazyTrain(re, data, off, len, n, out);
+}
+
 extern "C" int lc_runtime_set_table_cache_dir(const char* dir) {
     lcregex::lcSetTableCacheDir(dir);
     return LC_OK;
@@ -1759,6 +1859,12 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
     if (which == LC_TABLE_NFA_BLOB) {
         if (re->nfaBlob.empty()) return LC_ERR_ARG;
         return view(re->nfaBlob.data(), re->nfaBlob.size() * 4);
+    }
+    if (which == LC_TABLE_LAZY_TDFA_BLOB) {
+        lc_regex* mre = const_cast<lc_regex*>(re);
+        std::lock_guard<std::mutex> g(mre->lazy.m);
+        if (mre->lazy.blob.empty()) return LC_ERR_ARG;
+        return view(mre->lazy.blob.data(), mre->lazy.blob.size() * 4);
     }
     if (!re->hasTdfa && re->screenBlob.empty() && re->tdfaL2Blob.empty()) return LC_ERR_ARG;  // (logical tables: all three)
     const TdfaTables& t = re->tdfa;

@@ -13,6 +13,32 @@
 
 constexpr int kLcMaxDevices = 16;
 
+// A LAZY / partial tagged DFA in front of the thread-list engine (round 6; tdfa.hpp buildTdfaLazy).  Handles whose automaton does not
+// determinise within the limits (170 000 to 600 000 states for the log formats of BASELINE configs[2]) run the thread-list kernels at
+// ~12 000 cycles per byte step; the values they see visit a few thousand of those states.  lcRegexLazyTrain builds the automaton along
+// SAMPLE values (host memory); the launchers then walk every value through it first (tdfa_wave_kernel / tdfa_l2_kernel) and leave
+// only the values that step on an uncomputed transition (LC_PENDING) to the thread-list kernels of the same launch.  Results do not
+// depend on the sample: what the partial automaton decides it decides as the complete one would.
+struct LcLazyTdfa {
+    // ---- the trainer's side: one training call at a time (a call may take tens of milliseconds; launches never wait for it)
+    std::mutex trainMutex;
+    std::vector<uint8_t> sampleData;   // the values the tables are built from: only values that MISSED the tables of their time are
+    std::vector<uint32_t> sampleOff, sampleLen;  // kept, so the sample stays small and still covers everything ever offered
+    lcregex::TdfaTables tables;        // the logical tables of the current build (the trainer walks offered values through them)
+    bool haveTables = false;
+    bool frozen = false;               // a limit ended a construction: the tables stay as they are
+    lcregex::TdfaLazyReport report;
+    // ---- published: read by the launch path (short critical sections)
+    std::mutex m;
+    std::vector<uint32_t> blob;        // tdfa_l2_layout.h with TL_MISS != 0; empty: none
+    uint32_t version = 0;              // bumped by every (re)build: device copies of older versions retire
+    bool disabled = false;             // the construction does not get anywhere (register limit, a limit hit at once): never launched
+    void* dBlob[kLcMaxDevices] = {};
+    uint32_t dVersion[kLcMaxDevices] = {};
+    std::vector<std::pair<int, void*>> retired;  // (device, pointer): copies of older versions, freed with the handle
+    std::atomic<uint64_t> launches{0}, builds{0}, offered{0}, kept{0};
+};
+
 struct lc_regex {
     std::string pattern;
     uint32_t syntaxFlags = 0;
@@ -51,6 +77,8 @@ struct lc_regex {
     void* dNfaBlob[kLcMaxDevices] = {};
     void* dScreenBlob[kLcMaxDevices] = {};
     void* dTdfaL2Blob[kLcMaxDevices] = {};
+    LcLazyTdfa lazy;
+    std::atomic<bool> lazyReady{false};  // lazy.blob is there (checked without the lock on the launch path)
     // Grok (grok_device.hip): search rounds this Match entry queues ahead per batch (FindStringMatch + FindNextMatch ...); follows
     // what the batches turn out to need
     std::atomic<uint32_t> grokRounds{2}, grokRoundsSlack{0};
@@ -64,6 +92,11 @@ struct lc_regex {
     // unscreened)
     std::atomic<uint32_t> grokOverflowSeen{0}, grokRemainderSeen{0};
 };
+
+// regex_handle.cpp: walks `n` values (host memory) through the handle's lazy automaton, keeps the ones that miss in its sample and
+// rebuilds until none does (or a limit is reached); thread-list handles only (others: LC_OK, nothing done).  Safe beside launches on
+// other threads.  out (optional) = {states, transitions computed, sample values kept, offered values the tables still miss, 1 = in use}.
+int lcRegexLazyTrain(lc_regex* re, const uint8_t* data, const uint32_t* off, const uint32_t* len, uint32_t n, uint64_t out[5]);
 
 // Values a consumer without a parse-failure notion of its own (filter leaves, multiline flags, the Go regex plugin) had to take as
 // "no match" because the decide kernel gave up on them (LC_GAVE_UP: boost's complexity exception -- BoostRegexMatch / BoostRegexSearch

@@ -504,13 +504,29 @@ void minimizeTdfaStates(TdfaTables& T) {
         }
     }
     T.startState = map(T.startState);
+    if (T.missState) T.missState = map(T.missState);
     for (auto& st : T.startAfter) st = map(st);
     T.trans.swap(trans);
     T.finalId.swap(finalId);
     T.nStates = uint32_t(rep.size());
 }
 
-TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
+static TdfaTables buildTdfaImpl(const FollowNfa& nfa, const TdfaLimits& limits, const TdfaLazyGuide* guide, TdfaLazyReport* report);
+
+TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) { return buildTdfaImpl(nfa, limits, nullptr, nullptr); }
+
+// The LAZY / data-guided form (round 6).  The 36 search forms and 9 anchored forms of BASELINE configs[2] that stay on the thread-list
+// engine need 170 000 to more than 600 000 states when every (state, byte class) is explored -- but real log lines visit a few thousand
+// of them.  Here the same construction (same steps, same register programs, same dead-store and minimisation passes) computes only the
+// transitions that the SAMPLE values take, value by value from the start state; every other transition leads to the MISS state, a
+// sink the kernels report (csrc/tdfa_l2_kernel.hpp: the value is then walked by the thread-list kernels from its first byte, as
+// before).  On every path it knows the partial automaton IS the full one, so a value it decides is decided as the full tagged DFA --
+// and as the thread-list engine built from the same follow NFA -- would.  Nothing is cached on disk: the tables depend on the sample.
+TdfaTables buildTdfaLazy(const FollowNfa& nfa, const TdfaLimits& limits, const TdfaLazyGuide& guide, TdfaLazyReport* report) {
+    return buildTdfaImpl(nfa, limits, &guide, report);
+}
+
+static TdfaTables buildTdfaImpl(const FollowNfa& nfa, const TdfaLimits& limits, const TdfaLazyGuide* guide, TdfaLazyReport* report) {
     const int npos = int(nfa.positions.size());
     const int nslots = nfa.slotCount();
     TdfaTables T;
@@ -782,49 +798,41 @@ TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
         if (tid > 0xFFFF) throw RegexError("tdfa: state limit exceeded");
         return tid | (listId << 16);
     };
-    while (!atomicPattern && !work.empty()) {
-        const uint32_t sid = work.front();
-        work.pop_front();
-        std::vector<uint32_t> row(size_t(ncls), 0u);
-        for (int c = 0; c < ncls; ++c) {
-            const unsigned b = classRep[size_t(c)];
-            const uint32_t holds = states[sid].prevCtx | nfa.aheadBits(int(b));
-            ++seenStamp;
-            survivors.clear();
-            {
-                const State& S = states[sid];
-                for (size_t k = 0; k < S.items.size(); ++k) {
-                    const size_t p = size_t(S.items[k].pos);
-                    const auto& lst = nfa.follow[p];
-                    pathWork += lst.size();
-                    const size_t v0 = viableStart[p * size_t(ncls) + size_t(c)], v1 = viableStart[p * size_t(ncls) + size_t(c) + 1];
-                    for (size_t v = v0; v < v1; ++v) {
-                        const FollowPath& path = lst[viablePath[v]];
-                        if (path.cond & ~holds) continue;
-                        if (targetSeen[size_t(path.target)] == seenStamp) continue;
-                        targetSeen[size_t(path.target)] = seenStamp;
-                        survivors.push_back({path.target, int(k), &path.tags, nullptr});
-                    }
+    // one (state, byte class) of a pattern without atomic groups -> the transition word (0: dead)
+    auto stepFast = [&](uint32_t sid, int c) -> uint32_t {
+        const unsigned b = classRep[size_t(c)];
+        const uint32_t holds = states[sid].prevCtx | nfa.aheadBits(int(b));
+        ++seenStamp;
+        survivors.clear();
+        {
+            const State& S = states[sid];
+            for (size_t k = 0; k < S.items.size(); ++k) {
+                const size_t p = size_t(S.items[k].pos);
+                const auto& lst = nfa.follow[p];
+                pathWork += lst.size();
+                const size_t v0 = viableStart[p * size_t(ncls) + size_t(c)], v1 = viableStart[p * size_t(ncls) + size_t(c) + 1];
+                for (size_t v = v0; v < v1; ++v) {
+                    const FollowPath& path = lst[viablePath[v]];
+                    if (path.cond & ~holds) continue;
+                    if (targetSeen[size_t(path.target)] == seenStamp) continue;
+                    targetSeen[size_t(path.target)] = seenStamp;
+                    survivors.push_back({path.target, int(k), &path.tags, nullptr});
                 }
             }
-            if (pathWork > limits.maxPathWork)
-                throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
-            if (survivors.empty()) continue;  // -> dead
-            row[size_t(c)] = emitTransition(sid, b);
         }
-        if (transRows.size() <= sid) transRows.resize(sid + 1);
-        transRows[sid] = std::move(row);
-    }
-    while (!work.empty()) {
-        uint32_t sid = work.front();
-        work.pop_front();
-        if (transRows.size() <= sid) transRows.resize(sid + 1);
-        std::vector<uint32_t> row(size_t(ncls), 0u);
-        for (int c = 0; c < ncls; ++c) {
-            const State& S = states[sid];  // re-fetched each class: intern() may reallocate `states`
-            const unsigned b = classRep[c];
-            const uint32_t holds = S.prevCtx | nfa.aheadBits(int(b));
-            std::vector<Cand> cands;
+        if (pathWork > limits.maxPathWork)
+            throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
+        if (survivors.empty()) return 0u;  // -> dead
+        return emitTransition(sid, b);
+    };
+    // ... and of a pattern with atomic groups (the ordered commit)
+    auto stepGeneral = [&](uint32_t sid, int c) -> uint32_t {
+        const unsigned b = classRep[size_t(c)];
+        std::vector<Cand> cands;
+        uint32_t holds;
+        {
+            const State& S = states[sid];  // (not held across emitTransition: intern() may reallocate `states`)
+            holds = S.prevCtx | nfa.aheadBits(int(b));
             const bool atomic = nfa.atomicCount > 0;
             ++seenStamp;
             for (size_t k = 0; k < S.items.size(); ++k) {
@@ -844,22 +852,113 @@ TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
                                          atomic ? &path.atoms : nullptr, targetOk, path.cond});
                 }
             }
-            if (pathWork > limits.maxPathWork)
-                throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
-            std::vector<Cand> ni = commitAtomic(std::move(cands), holds);
-            if (ni.empty()) continue;  // -> dead
-            survivors.clear();
-            for (const auto& n : ni) survivors.push_back({n.pos, n.src, &n.tags, n.lin.empty() ? nullptr : &n.lin});
-            row[size_t(c)] = emitTransition(sid, b);
         }
+        if (pathWork > limits.maxPathWork)
+            throw RegexError("tdfa: construction work limit (the automaton is too dense for a table; NFA engine)");
+        std::vector<Cand> ni = commitAtomic(std::move(cands), holds);
+        if (ni.empty()) return 0u;  // -> dead
+        survivors.clear();
+        for (const auto& n : ni) survivors.push_back({n.pos, n.src, &n.tags, n.lin.empty() ? nullptr : &n.lin});
+        return emitTransition(sid, b);
+    };
+    auto step = [&](uint32_t sid, int c) -> uint32_t { return atomicPattern ? stepGeneral(sid, c) : stepFast(sid, c); };
+    constexpr uint32_t kUnknown = 0xFFFFFFFFu;  // lazy form: a transition nobody has asked for yet
+    uint64_t lazyComputed = 0, lazySteps = 0;
+    bool lazyStopped = false;
+    if (guide) {
+        // the sample values, one after the other from the start state: only what they take is computed
+        work.clear();
+        auto rowOf = [&](uint32_t sid) -> std::vector<uint32_t>& {
+            if (transRows.size() <= sid) transRows.resize(size_t(sid) + 1);
+            if (transRows[sid].empty()) transRows[sid].assign(size_t(ncls), kUnknown);
+            return transRows[sid];
+        };
+        transRows[0].assign(size_t(ncls), 0u);
+        const size_t maxTableBytes = guide->maxTableBytes ? guide->maxTableBytes : (size_t(8) << 20);
+        for (uint32_t v = 0; v < guide->n && !lazyStopped; ++v) {
+            const uint8_t* p = guide->data + guide->off[v];
+            const uint32_t L = guide->len[v];
+            uint32_t st = T.startState;
+            for (uint32_t i = 0; i < L && st != 0; ++i) {
+                const int c = int(T.classMap[p[i]]);
+                uint32_t w = rowOf(st)[size_t(c)];
+                ++lazySteps;
+                if (w == kUnknown) {
+                    if ((states.size() + 2) * size_t(ncls) * 4 > maxTableBytes) {
+                        lazyStopped = true;
+                        break;
+                    }
+                    try {
+                        w = step(st, c);
+                    } catch (const RegexError&) {  // a limit: the table stays as far as it got
+                        lazyStopped = true;
+                        break;
+                    }
+                    rowOf(st)[size_t(c)] = w;
+                    ++lazyComputed;
+                }
+                st = w & 0xFFFFu;
+            }
+        }
+        // ... and every state a sample value has BEEN IN gets its whole row: a log line that takes the path of a sample value but
+        // carries another byte class somewhere along it (a letter where the sample had digits, a rarer punctuation mark inside free
+        // text) steps on a transition of a visited state -- which mostly leads back into visited states.  Without this a format's
+        // table was still missing a fifth of its fresh values after 700 sample values of that format; the states this adds are not
+        // walked further (their rows stay unknown until a value gets there).
+        if (guide->completeRows && !lazyStopped) {
+            const size_t visited = transRows.size();
+            for (uint32_t sid = 1; sid < visited && !lazyStopped; ++sid) {
+                if (transRows[sid].empty()) continue;
+                for (int c = 0; c < ncls && !lazyStopped; ++c) {
+                    if (transRows[sid][size_t(c)] != kUnknown) continue;
+                    if ((states.size() + 2) * size_t(ncls) * 4 > maxTableBytes) {
+                        lazyStopped = true;
+                        break;
+                    }
+                    uint32_t w;
+                    try {
+                        w = step(sid, c);
+                    } catch (const RegexError&) {
+                        lazyStopped = true;
+                        break;
+                    }
+                    transRows[sid][size_t(c)] = w;
+                    ++lazyComputed;
+                }
+            }
+        }
+        work.clear();
+    }
+    while (!work.empty()) {
+        const uint32_t sid = work.front();
+        work.pop_front();
+        std::vector<uint32_t> row(size_t(ncls), 0u);
+        for (int c = 0; c < ncls; ++c) row[size_t(c)] = step(sid, c);
         if (transRows.size() <= sid) transRows.resize(sid + 1);
         transRows[sid] = std::move(row);
     }
-
-    T.nStates = uint32_t(states.size());
+    const uint32_t nReal = uint32_t(states.size());
+    T.nStates = nReal + (guide ? 1u : 0u);  // lazy form: one more state, the MISS sink
+    if (T.nStates > 0xFFFFu) throw RegexError("tdfa: state limit exceeded");
     T.trans.resize(size_t(T.nStates) * size_t(ncls));
-    for (uint32_t s = 0; s < T.nStates; ++s)
-        for (int c = 0; c < ncls; ++c) T.trans[size_t(s) * size_t(ncls) + size_t(c)] = transRows[s][size_t(c)];
+    uint64_t lazyUnknown = 0;
+    for (uint32_t s = 0; s < nReal; ++s)
+        for (int c = 0; c < ncls; ++c) {
+            uint32_t w = 0;
+            if (!guide) w = transRows[s][size_t(c)];
+            else if (s == 0) w = 0;
+            else if (s < transRows.size() && !transRows[s].empty()) w = transRows[s][size_t(c)];
+            else w = kUnknown;
+            if (w == kUnknown) {
+                w = nReal;  // -> MISS, no register program
+                ++lazyUnknown;
+            }
+            T.trans[size_t(s) * size_t(ncls) + size_t(c)] = w;
+        }
+    if (guide) {
+        for (int c = 0; c < ncls; ++c) T.trans[size_t(nReal) * size_t(ncls) + size_t(c)] = nReal;  // a sink
+        T.missState = nReal;
+    }
 
     const int tmpReg = maxRegs;
     T.nRegs = uint32_t(maxRegs + (usedTmp ? 1 : 0));
@@ -882,7 +981,7 @@ TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
     // ---- acceptance at end of input: first item (priority order) with a MATCH path whose assertions hold at END
     T.finalId.assign(T.nStates, 0xFFFF);
     std::map<std::vector<uint8_t>, uint16_t> finIds;
-    for (uint32_t s = 1; s < T.nStates; ++s) {
+    for (uint32_t s = 1; s < nReal; ++s) {
         const State& S = states[s];
         const uint32_t holds = S.prevCtx | nfa.aheadBits(kEdge);
         std::vector<Cand> cands;
@@ -913,8 +1012,23 @@ TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits) {
         }
     }
     if (T.finalMap.empty()) T.finalMap.assign(size_t(nslots) ? size_t(nslots) : 1, kRegNone);
+    if (guide) {
+        // the MISS state gets a final row of its OWN NUMBER (content: nothing captured): the minimisation tells states apart by that
+        // number first, so the sink is never merged with the dead state or an absorbing accept; the kernels test for the MISS state
+        // before they look at final rows
+        T.finalId[T.missState] = uint16_t(T.finalMap.size() / (size_t(nslots) ? size_t(nslots) : 1));
+        T.finalMap.insert(T.finalMap.end(), size_t(nslots) ? size_t(nslots) : 1, kRegNone);
+    }
     eliminateDeadStores(T);
     minimizeTdfaStates(T);
+    if (report) {
+        report->statesBuilt = nReal;
+        report->statesKept = T.nStates;
+        report->transitionsComputed = lazyComputed;
+        report->transitionsUnknown = lazyUnknown;
+        report->stepsWalked = lazySteps;
+        report->stopped = lazyStopped;
+    }
     return T;
 }
 

@@ -29,6 +29,23 @@ struct TdfaTables {
     // search patterns only: [nClasses] state to RESUME a search in when the byte before the resume point has class c
     // (only the wrapper's prefix thread is alive, no register is set); empty otherwise
     std::vector<uint32_t> startAfter;
+    // lazy form only (buildTdfaLazy): the state that stands for "a transition nobody has computed"; 0 = a complete automaton
+    uint32_t missState = 0;
+};
+
+// buildTdfaLazy: the values the construction follows (host memory) and what it may grow to
+struct TdfaLazyGuide {
+    const uint8_t* data = nullptr;
+    const uint32_t* off = nullptr;
+    const uint32_t* len = nullptr;
+    uint32_t n = 0;
+    size_t maxTableBytes = 0;  // states x classes x 4 (0: 8 MiB)
+    bool completeRows = true;  // every state a sample value has been in gets its whole row (tdfa.cpp)
+};
+struct TdfaLazyReport {
+    uint32_t statesBuilt = 0, statesKept = 0;
+    uint64_t transitionsComputed = 0, transitionsUnknown = 0, stepsWalked = 0;
+    bool stopped = false;  // a limit ended the exploration: the table is as far as it got
 };
 
 struct TdfaLimits {
@@ -48,6 +65,8 @@ TdfaTables buildTdfa(const FollowNfa& nfa, const TdfaLimits& limits = TdfaLimits
 
 // The constructions themselves (buildTdfa / buildScreenDfa go through the table cache, table_cache.cpp, when a cache directory is set)
 TdfaTables buildTdfaUncached(const FollowNfa& nfa, const TdfaLimits& limits);
+// tdfa.cpp: the data-guided partial automaton (never cached: it depends on the sample)
+TdfaTables buildTdfaLazy(const FollowNfa& nfa, const TdfaLimits& limits, const TdfaLazyGuide& guide, TdfaLazyReport* report = nullptr);
 TdfaTables buildScreenDfaUncached(const FollowNfa& nfa, const TdfaLimits& limits);
 
 // table_cache.cpp -- compiled automata across process restarts (round 5).  Determinising an anchored Grok format costs seconds (and

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
                                                                const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
                                                                uint32_t nGroupsOut, int32_t* __restrict__ caps,
-                                                               uint8_t* __restrict__ status, uint32_t stageBytes) {
+                                                               uint8_t* __restrict__ status, uint32_t stageBytes,
+                                                               uint32_t* __restrict__ pendingFlag, uint32_t launchSeq) {
     extern __shared__ uint32_t regs[];  // [nRegs][64], then (stageBytes != 0) the register programs: opsStart, ops
     __shared__ uint8_t cmap[256];
     const uint32_t tid = threadIdx.x;
@@ -68,13 +69,15 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
     const uint32_t total = L > from ? head + (L - from) : 0;
     // (a line in the absorbing state is decided: nothing it still holds can change its state or a register -- TL_ABSORB)
     const uint32_t absorb = blob[TL_ABSORB];
-    for (uint32_t p0 = 0; p0 < total && state != 0 && state != absorb; p0 += 16) {
+    // (lazy automata, TL_MISS: a line that steps on a transition nobody has computed is left to the thread-list kernels)
+    const uint32_t miss = blob[TL_MISS];
+    for (uint32_t p0 = 0; p0 < total && state != 0 && state != absorb && state != miss; p0 += 16) {
         const uint4 v = *q++;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t bi = p0 + j;
-            if (bi >= head && bi < total && state != 0 && state != absorb) {
+            if (bi >= head && bi < total && state != 0 && state != absorb && state != miss) {
                 const uint32_t t = trans[state * ncls + cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]];
                 const uint32_t prog = t >> 16;
                 if (prog) {
@@ -90,6 +93,11 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
                 state = t & 0xFFFFu;
             }
         }
+    }
+    if (miss && state == miss) {
+        status[line] = 4;  // LC_PENDING (nfa_decide_kernel.hpp): the thread-list kernels of the same launch take the line
+        if (pendingFlag) atomicMax(pendingFlag, launchSeq);
+        return;
     }
     const uint16_t* finalId = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_FINALID]);
     const uint8_t* finalMap = base + blob[TL_OFF_FINALMAP];
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
                                                                   const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
                                                                   const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
                                                                   uint32_t nGroupsOut, int32_t* __restrict__ caps,
-                                                                  uint8_t* __restrict__ status, uint32_t stageBytes) {
+                                                                  uint8_t* __restrict__ status, uint32_t stageBytes,
+                                                                  uint32_t* __restrict__ pendingFlag, uint32_t launchSeq) {
     extern __shared__ uint32_t wregs[];  // [kTdfaWaveValues][nRegs], then (stageBytes != 0) opsStart, ops
     __shared__ uint8_t cmap[256];
     // (wave-uniform values are SAID to be: the compiler takes anything derived from threadIdx or from an LDS read for divergent, kept the
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
                 reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_STARTAFTER])[cmap[data[size_t(o) + from - 1]]]);
     }
     const uint32_t absorb = blob[TL_ABSORB];
+    const uint32_t miss = blob[TL_MISS];  // (lazy automata: see tdfa_l2_kernel)
     const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + o;
     const uint32_t head = uint32_t(addr & 3);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
         curWord = classesOf((w < nWords) ? words[w] : 0);
     }
     uint32_t idx = head + from;  // position in the word-aligned view
-    while (idx < end && state != 0 && state != absorb) {
+    while (idx < end && state != 0 && state != absorb && state != miss) {
         if ((idx >> 8) != chunk) {
             chunk = idx >> 8;
             const uint32_t w = (chunk << 6) + lane;
@@ -251,6 +261,13 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
         }
         state = next;
         ++idx;
+    }
+    if (miss && state == miss) {
+        if (lane == 0) {
+            status[line] = 4;  // LC_PENDING
+            if (pendingFlag) atomicMax(pendingFlag, launchSeq);
+        }
+        return;
     }
     const uint16_t* finalId = reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_FINALID]);
     const uint8_t* finalMap = base + blob[TL_OFF_FINALMAP];

@@ -19,6 +19,9 @@ enum {
                            // suffix (?s:.*) on its own), or 0: a line that reaches it is decided -- the kernel stops reading it
     TL_OFF_QUIET = 14,     // u64[nStates]: bit c = byte class c (< 64) keeps the state and runs no register program -- the bytes the
                            // wave-per-value kernel crosses without a table read (tdfa_wave_kernel)
+    TL_MISS = 15,          // lazy / partial automata (tdfa.hpp buildTdfaLazy): the state that stands for "this transition was never
+                           // computed", or 0 (a complete automaton): a line that reaches it is NOT decided -- the kernel leaves it
+                           // LC_PENDING and raises the launch's pending flag; the thread-list kernels behind take it from its first byte
     TL_HEADER_WORDS = 16   // the class map (u8[256]) follows the header
 };
 #define TL_MAGIC_VALUE 0x324C4454u

@@ -27,6 +27,12 @@
 #ifndef LC_TDFA_STREAM_CHUNK
 #define LC_TDFA_STREAM_CHUNK 8  // bytes per chunk (8 or 16): col / ncol / ptt / tt hold one value per byte of a chunk
 #endif
+#ifndef LC_TDFA_STAMP_ISA
+#define LC_TDFA_STAMP_ISA 1  // hand-picked instructions for the one-stamp pair kernel's stamp (0: the compiler's)
+#endif
+#ifndef LC_TDFA_ROW_ALIGN
+#define LC_TDFA_ROW_ALIGN 1
+#endif
 #ifndef LC_TDFA_STREAM_WAVES
 #define LC_TDFA_STREAM_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -157,8 +163,25 @@ __device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint3
             nc[p] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b1);
         }
         // the previous chunk's pair p: ONE stamp
-        const uint32_t ra = (ptt[p] >> 16) & 0x7Fu;
-        *reinterpret_cast<LdsRegPtr>(regAddr0 + (ra << kRegShift)) = TdfaReg(pbase + uint32_t(2 * p) + ((ptt[p] >> 23) & 1u));
+#if LC_TDFA_STAMP_ISA
+        // Round 6: the stamp's address and value in FOUR instructions instead of the six the compiler picks (v_lshrrev 6, v_and
+        // 0x1fc00, v_add | v_lshrrev 23, v_and_or, v_or: profiles/round5_tdfa_isa_budget.md, 3.25 of the kernel's 7.47 VALU per line
+        // byte): register index and +1 flag by v_bfe_u32, row address by v_lshl_add_u32, and the pair's position -- wave-uniform
+        // when rows start at the line's first byte -- added on the scalar unit.
+        if constexpr (LC_TDFA_ROW_ALIGN == 1) {
+            uint32_t ra, delta, addr, val;
+            asm("v_bfe_u32 %0, %1, 16, 7" : "=v"(ra) : "v"(ptt[p]));
+            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(addr) : "v"(ra), "n"(kRegShift), "v"(regAddr0));
+            asm("v_bfe_u32 %0, %1, 23, 1" : "=v"(delta) : "v"(ptt[p]));
+            const uint32_t posU = __builtin_amdgcn_readfirstlane(pbase) + uint32_t(2 * p);
+            asm("v_add_u32 %0, %1, %2" : "=v"(val) : "s"(posU), "v"(delta));
+            *reinterpret_cast<LdsRegPtr>(addr) = TdfaReg(val);
+        } else
+#endif
+        {
+            const uint32_t ra = (ptt[p] >> 16) & 0x7Fu;
+            *reinterpret_cast<LdsRegPtr>(regAddr0 + (ra << kRegShift)) = TdfaReg(pbase + uint32_t(2 * p) + ((ptt[p] >> 23) & 1u));
+        }
 #ifndef LC_TDFA_STREAM_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif

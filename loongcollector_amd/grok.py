@@ -159,6 +159,17 @@ class Grok:
                                           d_scratch.numel() * d_scratch.element_size(), stream)
         binding._check(rc, "lc_grok_match_device")
 
+    def lazy_settle(self, timeout_ms=60000):
+        """block until the lazy automata's trainer has nothing to do (include/lc_grok.h); -> True if it settled in time"""
+        self._L.lc_grok_lazy_settle.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        return self._L.lc_grok_lazy_settle(self._h, timeout_ms) == 0
+
+    def lazy_stats(self):
+        w = (ctypes.c_uint64 * 5)()
+        self._L.lc_grok_lazy_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._L.lc_grok_lazy_stats(self._h, ctypes.cast(w, ctypes.c_void_p))
+        return dict(zip(("automata_in_use", "builds", "values_offered", "values_kept", "batches_taken"), (int(x) for x in w)))
+
     def combiner_stats(self):
         """the group commit behind match_host (csrc/group_combiner.hpp) since the handle was created"""
         w = (ctypes.c_uint64 * 11)()

@@ -319,8 +319,10 @@ class TdfaL2BlobInterp:
     """Walks the blob of the global-memory TDFA kernel (csrc/tdfa_l2_layout.h) exactly as tdfa_l2_kernel does: automata too
     large for the LDS kernels."""
 
-    def __init__(self, rx):
-        blob = rx.table(B.LC_TABLE_TDFA_L2_BLOB, np.uint32)
+    MISS = "miss"   # lazy automata: the value stepped on a transition nobody has computed (the kernels leave it LC_PENDING)
+
+    def __init__(self, rx, which=None):
+        blob = rx.table(B.LC_TABLE_TDFA_L2_BLOB if which is None else which, np.uint32)
         assert blob is not None
         raw = blob.view(np.uint8)
         (magic, self.nstates, self.ncls, self.nregs, self.nslots, self.start, o_trans, o_opsstart, o_ops, o_finalid, o_finalmap,
@@ -336,6 +338,7 @@ class TdfaL2BlobInterp:
         self.runs = rx.run_captures()
         self.compact = False
         self.absorb = int(blob[13])                                                     # TL_ABSORB
+        self.miss = int(blob[15])                                                       # TL_MISS (0: a complete automaton)
         o_quiet = int(blob[14])                                                         # TL_OFF_QUIET: u64[nStates]
         self.quiet = raw[o_quiet:o_quiet + 8 * self.nstates].view(np.uint64)
 
@@ -346,7 +349,7 @@ class TdfaL2BlobInterp:
         state = self.start if start == 0 else int(self.start_after[int(self.cmap[s[start - 1]])])
         regs = [-1] * max(self.nregs, 1)
         pos, n = start, len(s)
-        while pos < n and state != 0 and state != self.absorb:
+        while pos < n and state != 0 and state != self.absorb and state != self.miss:
             t = int(self.trans[state * self.ncls + int(self.cmap[s[pos]])])
             if t >> 16:
                 at = int(self.ops_start[t >> 16])
@@ -362,6 +365,8 @@ class TdfaL2BlobInterp:
             pos += 1
         if state == 0:
             return None
+        if self.miss and state == self.miss:
+            return self.MISS
         fid = int(self.final_id[state])
         if fid == 0xFFFF:
             return None
@@ -384,6 +389,8 @@ class TdfaL2BlobInterp:
             state = t & 0xFFFF
             if state == 0:
                 return None
+            if self.miss and state == self.miss:
+                return self.MISS
         fid = int(self.final_id[state])
         if fid == 0xFFFF:
             return None

@@ -138,6 +138,18 @@ def measure(args, device_index=0):
         values = grok_lines(n_lines)
         n = len(values)
         batch = DeviceBatch(torch, dev, g, values)
+        # the lazy automata of the entries that do not determinise learn from the handle's own traffic (include/lc_grok.h): batches are
+        # offered to a background trainer; the steps that are CHECKED and TIMED below run behind it, as an agent's steady state does
+        # (an offer is a 4 096-value window that moves through the batch: the loop ends when a whole pass over the batch added nothing)
+        lazy_rounds, windows, quiet = 0, (n + 4095) // 4096, 0
+        for lazy_rounds in range(1, 3 * windows + 8):
+            kept = g.lazy_stats()["values_kept"]
+            batch.step(g)
+            torch.cuda.synchronize()
+            g.lazy_settle()
+            quiet = quiet + 1 if g.lazy_stats()["values_kept"] == kept else 0
+            if quiet >= windows + 1:
+                break
         batch.step(g)
         torch.cuda.synchronize()
         stats = g.last_batch_stats()
@@ -219,6 +231,7 @@ def measure(args, device_index=0):
                        "patterns_hit": int((hist > 0).sum()),
                        "parity": {"oracle_sample": "%d lines strided across the batch" % len(idx),
                                   "both_paths_agree_on_every_line": seq_checked},
+                       "lazy_automata": dict(g.lazy_stats(), warm_up_steps=lazy_rounds),
                        "warm_up_s": round(warm_s, 2)},
             # algorithmic HBM bytes of one step: every value read once + 4 B offset + 4 B length + the result row (pattern id +
             # first-match row) written once per line.  The automaton kernels are nowhere near it: they are bound by the dependent

@@ -65,6 +65,11 @@ def measure(args):
     # parity gate: one group through the host entry against the oracle (strided)
     from oracle.grok_oracle import GrokOracle
     o = GrokOracle(supported, custom_patterns=cfg["custom_patterns"])
+    # the lazy automata learn from the handle's traffic (include/lc_grok.h): the groups go through once or twice behind the trainer first
+    for _ in range(3):
+        for gr in groups:
+            g.match_host(gr[3])
+            g.lazy_settle()
     pattern, fields = g.match_host(groups[0][3])
     for i in range(0, args.group, 10):
         res, want = o.process_value(groups[0][3][i])
