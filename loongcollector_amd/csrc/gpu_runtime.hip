@@ -1128,6 +1128,85 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr, int chance, uint32_t* seqInOut);
 
+// ---- several automata over their own values in ONE launch (runtime_internal.hpp; the Grok plan's round 0)
+bool lcNfaWideApplies(const lc_regex* re);
+bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc) {
+    *rc = LC_OK;
+    *seqOut = 0;
+    if (!re || n == 0 || !re->nfa.runGroups.empty()) return false;  // (run captures: a kernel of the handle's own behind the match)
+    {
+        const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
+        if (n > uint32_t(waveEnv ? atol(waveEnv) : 65536)) return false;
+        static const bool multiOff = getenv("LC_GROK_FUSED_ROUND0") != nullptr && getenv("LC_GROK_FUSED_ROUND0")[0] == '0';
+        if (multiOff) return false;
+    }
+    const uint32_t* hostHdr = nullptr;
+    std::vector<uint32_t> lazyHeader;
+    void* dBlob = nullptr;
+    job->missFlag = nullptr;
+    job->seq = 0;
+    job->missStatus = 4;
+    if (re->engine == LC_ENGINE_TDFA) {
+        if (re->tdfaL2Blob.empty() || !(re->preferWave || !re->hasTdfa)) return false;
+        *rc = ensureUploaded(re, dev, kBlobTdfaL2, &dBlob);
+        if (*rc != LC_OK) return false;
+        hostHdr = re->tdfaL2Blob.data();
+    } else if (re->engine == LC_ENGINE_NFA) {
+        const char* lazyEnv = getenv("LC_LAZY_TDFA");
+        if ((lazyEnv && lazyEnv[0] == '0') || !re->lazyReady.load(std::memory_order_acquire) || !lcNfaWideApplies(re)) return false;
+        // the thread-list program too: its overflow word is what a miss raises, and the second chance reads its tables
+        void* dNfa = nullptr;
+        *rc = ensureUploaded(re, dev, kBlobNfa, &dNfa);
+        if (*rc != LC_OK) return false;
+        *rc = ensureLazyUploaded(re, dev, &dBlob, &lazyHeader);
+        if (*rc != LC_OK || !dBlob) return false;
+        hostHdr = lazyHeader.data();
+        uint32_t* overflowFlag = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(dNfa) + re->nfaBlob.size() * 4);
+        uint32_t seq = ++re->nfaSeq[dev];
+        if (seq == 0) return false;  // (the sequence wrapped: this batch goes the usual way, which resets the words)
+        job->missFlag = overflowFlag;
+        job->seq = seq;
+        job->missStatus = LC_OVERFLOW;
+        *seqOut = seq;
+    } else {
+        return false;
+    }
+    const uint32_t nRegs = hostHdr[TL_NREGS];
+    uint32_t lds = nRegs * kTdfaWaveValues * 4, stage = 0;
+    static const bool stageOffAll = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
+    const uint32_t progBytes = (hostHdr[TL_OFF_FINALID] - hostHdr[TL_OFF_OPSSTART] + 3u) & ~3u;
+    if (!stageOffAll && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stage = progBytes;
+    if (lds + stage > 60 * 1024) return false;
+    job->blob = static_cast<const uint32_t*>(dBlob);
+    job->stageBytes = stage;
+    *ldsBytes = lds + stage;
+    return true;
+}
+
+size_t lcWaveJobTableBytes() { return kTdfaWaveMaxJobs * 4 + kTdfaWaveMaxJobs * sizeof(TdfaWaveJob); }
+
+int lcLaunchWaveJobs(const uint8_t* d_data, const TdfaWaveJob* jobs, uint32_t nJobs, uint32_t totalBlocks, uint32_t ldsBytes, void* hTable,
+                     void* dTable, int dev, hipStream_t st) {
+    if (!nJobs || !totalBlocks) return LC_OK;
+    if (nJobs > kTdfaWaveMaxJobs) {
+        tlsError = "wave jobs: more than 64 in one launch";
+        return LC_ERR_ARG;
+    }
+    uint32_t* first = static_cast<uint32_t*>(hTable);
+    for (uint32_t j = 0; j < kTdfaWaveMaxJobs; ++j) first[j] = j < nJobs ? jobs[j].firstBlock : 0xFFFFFFFFu;
+    std::memcpy(first + kTdfaWaveMaxJobs, jobs, size_t(nJobs) * sizeof(TdfaWaveJob));
+    HIP_TRY(hipMemcpyAsync(dTable, hTable, kTdfaWaveMaxJobs * 4 + size_t(nJobs) * sizeof(TdfaWaveJob), hipMemcpyHostToDevice, st));
+    static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
+    if (ldsBytes > 48 * 1024 && dev < kLcMaxDevices && ldsBytes > ldsAttrSet[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_wave_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+        ldsAttrSet[dev] = ldsBytes;
+    }
+    noteKernel("tdfa_wave_multi_kernel");
+    hipLaunchKernelGGL(tdfa_wave_multi_kernel, dim3(totalBlocks), dim3(kTdfaWaveBlock), ldsBytes, st, d_data, static_cast<const uint32_t*>(dTable), nJobs);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
+}
+
 int lcMatchOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr) {

@@ -31,6 +31,7 @@
 #include "group_combiner.hpp"
 #include "regex_handle.hpp"
 #include "runtime_internal.hpp"
+#include "tdfa_l2_layout.h"
 
 #define HIP_TRY LC_HIP_TRY
 
@@ -361,6 +362,8 @@ struct PlanThread {
     GrokScreenDev* hostRemScreens = nullptr;  // pinned [64]: per ACTIVE entry, its screen (blob == nullptr: none)
     GrokScreenDev* dRemScreens = nullptr;     // device [64]
     uint32_t* dShadow = nullptr;              // device [64][64]: candidates of entry p whose value's first candidate is entry f
+    void* hostJobs = nullptr;                 // pinned / device: the job table of round 0's fused launch (runtime_internal.hpp lcLaunchWaveJobs)
+    void* dJobs = nullptr;
     void* arena = nullptr;                // device, grow-only: the per-entry arrays of the batch in flight
     size_t arenaCap = 0;
     ~PlanThread() { release(); }
@@ -386,6 +389,8 @@ struct PlanThread {
                 if (hostRemScreens) (void)hipHostFree(hostRemScreens);
                 if (dRemScreens) (void)hipFree(dRemScreens);
                 if (dShadow) (void)hipFree(dShadow);
+                if (hostJobs) (void)hipHostFree(hostJobs);
+                if (dJobs) (void)hipFree(dJobs);
                 if (arena) (void)hipFree(arena);
             }
             if (haveCur) (void)hipSetDevice(cur);
@@ -401,6 +406,8 @@ struct PlanThread {
         hostRemScreens = nullptr;
         dRemScreens = nullptr;
         dShadow = nullptr;
+        hostJobs = nullptr;
+        dJobs = nullptr;
         arena = nullptr;
         arenaCap = 0;
         device = -1;
@@ -418,6 +425,8 @@ struct PlanThread {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostRemScreens), 64 * sizeof(GrokScreenDev), hipHostMallocDefault));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dRemScreens), 64 * sizeof(GrokScreenDev)));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dShadow), 64 * 64 * 4));
+            HIP_TRY(hipHostMalloc(&hostJobs, lcWaveJobTableBytes(), hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&dJobs, lcWaveJobTableBytes()));
         }
         for (uint32_t s = 0; s < nStreams; ++s)
             if (!workers[s]) {
@@ -936,15 +945,70 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             return r;
         };
         // 2a
+        // Round 6: the entries whose round 0 is a walk of tables in global memory -- a complete tagged DFA, or the LAZY automaton of an
+        // entry that does not determinise -- go in ONE launch (tdfa_wave_multi_kernel) with ONE post launch behind it.  Round 0 used to
+        // be ~46 kernels of 30-100 us each plus their 46 post kernels, and lasted as long as the host needed to queue them: the last one
+        // started 1.4 ms after the first (profiles/round6_grok_timeline_lazy.txt).  LC_GROK_FUSED_ROUND0=0: one launch per entry.
+        std::vector<char> fused(nAct, 0);
         {
-            int rc = fork();
+            std::vector<TdfaWaveJob> jobs;
+            std::vector<size_t> jobEntry;
+            uint32_t blocks = 0, ldsMax = 0;
+            for (size_t a = 0; a < nAct && jobs.size() < kTdfaWaveMaxJobs; ++a) {
+                PlanEntry& e = act[a];
+                const GrokDevicePattern& gp = patterns[e.p];
+                if (e.level || !e.cand) continue;
+                lc_regex* first = gp.anchored ? gp.anchored : gp.re;
+                if (wideFirstMode >= 2 && first->engine == LC_ENGINE_NFA) continue;  // (the knob forces the wide kernel: A/B, parity tests)
+                TdfaWaveJob j{};
+                uint32_t lds = 0, seq = 0;
+                int rcJob = LC_OK;
+                if (!lcWaveJobPrepare(first, dev, e.cand, &j, &lds, &seq, &rcJob)) {
+                    if (rcJob != LC_OK) return rcJob;
+                    continue;
+                }
+                j.off = e.dev.off;
+                j.len = e.dev.len;
+                j.resume = gp.anchored ? nullptr : e.dev.from;
+                j.caps = e.caps;
+                j.status = e.status;
+                j.n = e.cand;
+                j.nGroupsOut = e.capsRow / 2;
+                j.firstBlock = blocks;
+                blocks += (e.cand + kTdfaWaveValues - 1) / kTdfaWaveValues;
+                ldsMax = std::max(ldsMax, lds);
+                e.seq0 = seq;        // (a lazy automaton's misses are LC_OVERFLOW under this number: the second chance of phase 2c takes them)
+                e.wideFirst = false;
+                fused[a] = 1;
+                jobs.push_back(j);
+                jobEntry.push_back(a);
+            }
+            bool others = false;
+            for (size_t a = 0; a < nAct; ++a) others = others || (!act[a].level && !fused[a]);
+            int rc = LC_OK;
+            if (others) rc = fork();
             if (rc != LC_OK) return rc;
+            hipStream_t fusedStream = others ? T.workers[0] : st;
+            if (!jobs.empty()) {
+                rc = lcLaunchWaveJobs(d_data, jobs.data(), uint32_t(jobs.size()), blocks, ldsMax, T.hostJobs, T.dJobs, dev, fusedStream);
+                // the post step of the fused entries: one launch per run of neighbours in the entry table (usually one run)
+                for (size_t k = 0; k < jobEntry.size() && rc == LC_OK;) {
+                    size_t k2 = k + 1;
+                    uint32_t most = act[jobEntry[k]].cand;
+                    while (k2 < jobEntry.size() && jobEntry[k2] == jobEntry[k2 - 1] + 1) most = std::max(most, act[jobEntry[k2++]].cand);
+                    hipLaunchKernelGGL(grok_post_kernel, dim3((most + kGrokPlanBlock - 1) / kGrokPlanBlock, uint32_t(k2 - k)), dim3(kGrokPlanBlock), 0,
+                                       fusedStream, T.dEntries, uint32_t(jobEntry[k]), static_cast<const uint32_t*>(nullptr),
+                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
+                    k = k2;
+                }
+                if (trace) fprintf(stderr, "grok plan 2a: %zu entries in one launch (%u workgroups, %u B of LDS)\n", jobs.size(), blocks, ldsMax);
+            }
             const std::vector<size_t> order0 = deal(false);
-            for (size_t i = 0; i < nAct && rc == LC_OK; ++i) {
+            for (size_t i = 0; i < nAct && rc == LC_OK && others; ++i) {
                 const size_t a = order0[i];
                 PlanEntry& e = act[a];
                 const GrokDevicePattern& gp = patterns[e.p];
-                if (e.level) continue;  // (waits for the entries that shadow it: phase 2c)
+                if (e.level || fused[a]) continue;  // (level >= 1: waits for the entries that shadow it, phase 2c)
                 lcSetDecideSlot(1 + e.stream);
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
                 e.wideFirst = wantsWideFirst(first);
@@ -964,7 +1028,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                             gp.anchored ? " (anchored)" : "", e.wideFirst ? " (wide first)" : "", first->nfa.positions.size(), first->nfa.slotCount(),
                             first->nfa.atomicCount, e.cost0 * 1e-6, e.cost1 * 1e-6);
             }
-            rc = join(rc);
+            if (others) rc = join(rc);
+            else if (rc == LC_OK && hipGetLastError() != hipSuccess) rc = lcHipFail(hipGetLastError(), "grok round 0");
             if (rc != LC_OK) return rc;
         }
         // 2b: round 0's results of the level-0 entries; the values won so far
@@ -972,9 +1037,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         lcNoteKernel("grok_post_kernel");
         const uint32_t nLevel0 = nAct - nSecond;  // (the table lists the entries by level)
         if (nLevel0 && !postInStream)
-            hipLaunchKernelGGL(grok_post_kernel, dim3(gridCand0, nLevel0), dim3(kGrokPlanBlock), 0, st, T.dEntries, 0u,
-                               static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap,
-                               xstride, xcount);
+            for (uint32_t a = 0; a < nLevel0; ++a)  // (the entries of the fused launch have had their post step behind it)
+                if (!fused[a])
+                    hipLaunchKernelGGL(grok_post_kernel, dim3((act[a].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0, st,
+                                       T.dEntries, a, static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
+                                       uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
         uint32_t maxLevel = 0;
         for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
         // the values won so far, and for the entries of level >= 1 how many of their slots are still open: an entry all of whose
@@ -1008,7 +1075,10 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         };
         if (calibrate)
             for (size_t a = 0; a < nAct; ++a)
-                if (!act[a].level) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
+                if (!act[a].level && !fused[a]) learn(patterns[act[a].p].re->grokCost0Ns, T.tick[2 * a], T.tick[2 * a + 1], act[a].cand);
+        for (size_t a = 0; a < nAct; ++a)  // (an entry of the fused launch has no kernel of its own to time: a nominal cost keeps the handle "known")
+            if (fused[a] && patterns[act[a].p].re->grokCost0Ns.load(std::memory_order_relaxed) == 0)
+                patterns[act[a].p].re->grokCost0Ns.store(100, std::memory_order_relaxed);
         // 2c: what round 0 left undone on the entries of level 0 (second chance of overflowed slots; the search proper for what the
         // anchored search did not match -- minus the values an earlier entry has won meanwhile), and, level by level, the shadowed
         // entries on the values nobody before them has won.  ONE fork for all of it: the leftovers of level 0 and the entries of

@@ -35,6 +35,19 @@ void lcSetWideNote(uint32_t* note);
 // device copy of a screen handle's yes/no DFA (screen_kernel_layout.h)
 int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out);
 
+// ---- several automata over their own values in ONE launch (tdfa_l2_kernel.hpp tdfa_wave_multi_kernel; the Grok plan's round 0)
+// lcWaveJobPrepare: can `re` walk `n` values one per wavefront from tables in global memory -- a complete automaton that lives there
+// (or asked for the wave walk), or a thread-list handle with a lazy automaton whose misses the WIDE kernel can take as a second chance?
+// If so fills the job's engine side (tables on `dev`, staging, and for lazy automata the flag word / sequence number / LC_OVERFLOW its
+// misses raise: what lcMatchSecondChanceOnStream takes as `seq`) and returns true; the caller fills off / len / resume / caps / status /
+// n / nGroupsOut / firstBlock.  false: the handle goes its usual way (lcMatchFirstOnStream).  rc != LC_OK: a device error.
+struct TdfaWaveJob;
+bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc);
+// the jobs (firstBlock ascending, at most 64) as one launch on `st`; dTable / hTable: device and pinned buffers of lcWaveJobTableBytes()
+size_t lcWaveJobTableBytes();
+int lcLaunchWaveJobs(const uint8_t* d_data, const TdfaWaveJob* jobs, uint32_t nJobs, uint32_t totalBlocks, uint32_t ldsBytes, void* hTable,
+                     void* dTable, int dev, hipStream_t st);
+
 // order[] = the lines 0..n-1 sorted by length bucket (32 bytes), longest first (sched_kernel.hpp); work: 512 words
 int lcLengthOrderOnStream(const uint32_t* d_off, const uint32_t* d_len, uint32_t sep_bytes, uint32_t n, uint32_t* work, uint32_t* order,
                           hipStream_t st);

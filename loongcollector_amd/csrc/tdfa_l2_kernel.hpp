@@ -129,21 +129,19 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
 // log line is ~150 bytes of structure and the rest runs; the absorbing state (TL_ABSORB) ends the walk.
 // Semantics: exactly tdfa_l2_kernel's (same blob, same results -- tests/test_gpu_parity.py runs both on the same lines).
 // LDS: cmap[256] | per wave: registers [nRegs] | (stageBytes != 0) the register programs.
-constexpr int kTdfaWaveBlock = 256;
-constexpr int kTdfaWaveValues = kTdfaWaveBlock / 64;
 
 // LT (round 5): the automaton is small (transition table + register programs <= 48 KB: the LDS-size automata of handles that ASK for
 // this kernel -- lcPreferWaveTdfa, the Grok matcher's entries): the transition table is staged too, and a byte that is not part of a
 // quiet run costs an LDS read instead of a read through L2 (a search wrapper's lazy prefix makes EVERY byte such a byte: 146 -> ~40 ns).
 // stageBytes then counts from TL_OFF_TRANS (trans, opsStart, ops are contiguous in the blob).
 template <bool LT>
-__global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
-                                                                  const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
-                                                                  const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
-                                                                  const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
-                                                                  uint32_t nGroupsOut, int32_t* __restrict__ caps,
-                                                                  uint8_t* __restrict__ status, uint32_t stageBytes,
-                                                                  uint32_t* __restrict__ pendingFlag, uint32_t launchSeq) {
+__device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                             const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                             const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+                                             const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
+                                             uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                             uint8_t* __restrict__ status, uint32_t stageBytes,
+                                             uint32_t* __restrict__ pendingFlag, uint32_t launchSeq, uint32_t missStatus, uint32_t blockId) {
     extern __shared__ uint32_t wregs[];  // [kTdfaWaveValues][nRegs], then (stageBytes != 0) opsStart, ops
     __shared__ uint8_t cmap[256];
     // (wave-uniform values are SAID to be: the compiler takes anything derived from threadIdx or from an LDS read for divergent, kept the
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     }
     __syncthreads();
     if (nLinesPtr) nLines = *nLinesPtr < nLines ? *nLinesPtr : nLines;
-    const uint32_t slot = blockIdx.x * kTdfaWaveValues + wave;
+    const uint32_t slot = blockId * kTdfaWaveValues + wave;
     if (slot >= nLines) return;  // wave-uniform; the workgroup does not synchronise again
     const uint32_t line = __builtin_amdgcn_readfirstlane(order ? order[slot] : slot);
     const uint8_t* base = reinterpret_cast<const uint8_t*>(blob);
@@ -264,7 +262,7 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
     }
     if (miss && state == miss) {
         if (lane == 0) {
-            status[line] = 4;  // LC_PENDING
+            status[line] = uint8_t(missStatus);  // LC_PENDING (the handle's own chain), or LC_OVERFLOW (the Grok plan's second chance)
             if (pendingFlag) atomicMax(pendingFlag, launchSeq);
         }
         return;
@@ -284,4 +282,37 @@ __global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t
         out[s] = val;
     }
     if (lane == 0) status[line] = matched ? LC_MATCH : LC_NOMATCH;
+}
+
+template <bool LT>
+__global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                  const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
+                                                                  const uint32_t* __restrict__ nLinesPtr, const uint32_t* __restrict__ order,
+                                                                  const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
+                                                                  uint32_t nGroupsOut, int32_t* __restrict__ caps,
+                                                                  uint8_t* __restrict__ status, uint32_t stageBytes,
+                                                                  uint32_t* __restrict__ pendingFlag, uint32_t launchSeq) {
+    tdfaWaveBody<LT>(data, off, len, sepBytes, nLines, nLinesPtr, order, resume, blob, nGroupsOut, caps, status, stageBytes, pendingFlag,
+                     launchSeq, 4u /* LC_PENDING */, blockIdx.x);
+}
+
+// ---- several automata, each over its OWN values, in ONE launch (round 6).  Round 0 of a Grok batch is ~46 of these walks, one per
+// Match entry over that entry's few hundred candidates: each a launch of 30-100 us that the host needs 15 us to queue, plus a post
+// launch per entry -- the round lasted as long as queueing its launches did (profiles/round6_grok_timeline_lazy.txt: the 46th kernel
+// started 1.4 ms after the first).  Here workgroup b belongs to the job whose [firstBlock, next firstBlock) holds b (a binary search
+// over at most 64 words in device memory), takes that job's tables, values and outputs, and walks as tdfa_wave_kernel does.
+// Jobs of lazy automata (TL_MISS) name the flag word and the status their misses raise.
+// jobTable: u32 firstBlock[kTdfaWaveMaxJobs] (ascending; unused = 0xFFFFFFFF), then TdfaWaveJob[nJobs] (8-byte aligned)
+__global__ __launch_bounds__(kTdfaWaveBlock) void tdfa_wave_multi_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ jobTable,
+                                                                        uint32_t nJobs) {
+    const uint32_t b = blockIdx.x;
+    uint32_t lo = 0, hi = nJobs;  // the last job whose firstBlock <= b
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobTable[mid] <= b) lo = mid;
+        else hi = mid;
+    }
+    const TdfaWaveJob j = reinterpret_cast<const TdfaWaveJob*>(jobTable + kTdfaWaveMaxJobs)[lo];  // (wave-uniform: scalar loads)
+    tdfaWaveBody<false>(data, j.off, j.len, 0u, j.n, nullptr, nullptr, j.resume, j.blob, j.nGroupsOut, j.caps, j.status, j.stageBytes, j.missFlag,
+                        j.seq, j.missStatus, b - j.firstBlock);
 }

@@ -25,3 +25,20 @@ enum {
     TL_HEADER_WORDS = 16   // the class map (u8[256]) follows the header
 };
 #define TL_MAGIC_VALUE 0x324C4454u
+
+// ---- launch shapes shared with the host (gpu_runtime.hip, grok_device.hip)
+#include <stdint.h>
+constexpr int kTdfaWaveBlock = 256;                    // tdfa_wave_kernel: one value per wavefront
+constexpr int kTdfaWaveValues = kTdfaWaveBlock / 64;   // ... four values per workgroup
+// one job of tdfa_wave_multi_kernel (several automata, each over its own values, in one launch: tdfa_l2_kernel.hpp)
+struct TdfaWaveJob {
+    const uint32_t* blob;
+    const uint32_t* off;
+    const uint32_t* len;
+    const uint32_t* resume;   // or nullptr
+    int32_t* caps;
+    uint8_t* status;
+    uint32_t* missFlag;       // or nullptr
+    uint32_t n, nGroupsOut, stageBytes, seq, missStatus, firstBlock;
+};
+constexpr uint32_t kTdfaWaveMaxJobs = 64;

@@ -481,7 +481,8 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
     values = grok_lines(2500) + [b"", b"x" * 4096]
     seq = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"], Speculative=False).wait_ready()
     want = _device_rows(torch_dev, seq, values)
-    spec = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()
+    # (the history rules are about the thread-list kernels: this handle keeps the lazy automata out of their way; they get their turn below)
+    spec = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"], LazyTdfa=False).wait_ready()
 
     def same(got, what):
         assert np.array_equal(got[0], want[0]), what
@@ -504,9 +505,29 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
         same(_device_rows(torch_dev, fresh, values), knobs)
         for k in knobs:
             monkeypatch.delenv(k)
+    # Round 6: the LAZY automata in front of the entries that do not determinise (include/lc_grok.h).  Batches behind a settled trainer
+    # -- the automata grow from batch to batch --, then the same handle with LC_LAZY_TDFA=0 (the thread-list kernels alone) and on again.
+    lazy = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()
+    for k in range(4):
+        B.launched_kernels()
+        same(_device_rows(torch_dev, lazy, values), "lazy automata, batch %d" % k)
+        assert lazy.lazy_settle(120000)
+    st = lazy.lazy_stats()
+    assert st["automata_in_use"] >= 30 and st["values_kept"] > 0 and st["batches_taken"] >= 1, st
+    B.launched_kernels()
+    same(_device_rows(torch_dev, lazy, values), "lazy automata, settled")
+    assert "tdfa_l2_kernel:wave:lazy" in B.launched_kernels()
+    monkeypatch.setenv("LC_LAZY_TDFA", "0")
+    B.launched_kernels()
+    same(_device_rows(torch_dev, lazy, values), "LC_LAZY_TDFA=0")
+    assert "lazy" not in B.launched_kernels()
+    monkeypatch.delenv("LC_LAZY_TDFA")
+    same(_device_rows(torch_dev, lazy, values), "LC_LAZY_TDFA back on")
     o = GrokOracle(cfg["match"], custom_patterns=cfg["custom_patterns"])
     pattern, fields = spec.match_host(values)
     assert np.array_equal(np.asarray(pattern), want[0])
+    pattern_l, fields_l = lazy.match_host(values)
+    assert list(pattern_l) == list(pattern) and fields_l == fields
     for v, p, f in zip(values[::5], pattern[::5], fields[::5]):
         res, exp = o.process_value(v)
         assert f == exp and (p >= 0) == (res == 0), v
