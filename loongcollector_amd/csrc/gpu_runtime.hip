@@ -1130,7 +1130,7 @@ static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t
 
 // ---- several automata over their own values in ONE launch (runtime_internal.hpp; the Grok plan's round 0)
 bool lcNfaWideApplies(const lc_regex* re);
-bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc) {
+bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, bool stagePrograms, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc) {
     *rc = LC_OK;
     *seqOut = 0;
     if (!re || n == 0 || !re->nfa.runGroups.empty()) return false;  // (run captures: a kernel of the handle's own behind the match)
@@ -1175,7 +1175,7 @@ bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, TdfaWaveJob* job, uint3
     uint32_t lds = nRegs * kTdfaWaveValues * 4, stage = 0;
     static const bool stageOffAll = getenv("LC_TDFA_L2_NO_STAGE") != nullptr;
     const uint32_t progBytes = (hostHdr[TL_OFF_FINALID] - hostHdr[TL_OFF_OPSSTART] + 3u) & ~3u;
-    if (!stageOffAll && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stage = progBytes;
+    if (!stageOffAll && stagePrograms && n <= 32768 && progBytes <= 40 * 1024 && lds + progBytes <= 60 * 1024) stage = progBytes;
     if (lds + stage > 60 * 1024) return false;
     job->blob = static_cast<const uint32_t*>(dBlob);
     job->stageBytes = stage;

@@ -604,6 +604,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             return uint32_t(v ? atoi(v) : 0);
         }();
         if (small) sliceLen = sliceEnv ? std::max(256u, sliceEnv / 256 * 256) : 256u;
+        // (round 6) TRIED AND LEFT OFF (LC_GROK_SCREEN_WAVE=1 switches it on): one value per WAVEFRONT (grokScreenWalkWave: a run of bytes
+        // that keep the state is crossed 256 bytes at a time).  A relaxed screen takes 130-400 real steps and 80-130 run scans per value
+        // (mean 1.1 KB): 50-250 us of a wavefront -- fine for the screens whose literal leaves eight candidates per slice, hopeless for
+        // the five whose entries have no literal and see EVERY value: 64 values per wavefront one after the other, 31 ms for a
+        // 1000-value batch against 0.44 ms one value per lane (profiles/round6_grok_screen_wave_negative.txt).
+        const uint32_t screenWalk = [&] {
+            const char* v = getenv("LC_GROK_SCREEN_WAVE");
+            return (small && v && v[0] == '1') ? 16u : 0u;
+        }();
         const uint32_t slices = (n + sliceLen - 1) / sliceLen;
         lcNoteKernel("grok_screen_all_kernel");
         // Round 5: a relaxed whole-pattern screen of 1 000-2 000 states (70-130 KB) does not fit beside other workgroups and walked its
@@ -629,13 +638,13 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             HIP_TRY(hipEventRecord(T.fork, st));
             HIP_TRY(hipStreamWaitEvent(T.workers[0], T.fork, 0));
             hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nBig), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, d_off, d_len, n,
-                               sliceLen, screens, reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), 2u);
+                               sliceLen, screens, reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), 2u | screenWalk);
             HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
         }
         if (nScreens > nBig)
             hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens - nBig), dim3(kGrokPlanBlock),
                                size_t(sliceLen) * 4 + (small ? screenLds : 0), st, d_data, d_off, d_len, n, sliceLen, screens + nBig,
-                               reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), small ? 1u : 0u);
+                               reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), (small ? 1u : 0u) | screenWalk);
         if (nBig) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
         if (trace && nBig)
             fprintf(stderr, "grok plan 1: %u big screens in a launch of their own (%u KB of LDS per workgroup)\n", nBig,
@@ -910,6 +919,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool remainderLiteral = envInt("LC_GROK_REMAINDER_LITERAL", 1) != 0 && literalIndex != nullptr;
         const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;      // slots of values an earlier entry has won drop out in front of the screens
         const bool remainderInChain = envInt("LC_GROK_REMAINDER_INCHAIN", 1) != 0;  // the remainder screens per entry, at the end of its chain in phase 2c
+        const bool screenWave = small && envInt("LC_GROK_SCREEN_WAVE", 0) != 0;  // remainder screens: one slot per wavefront (grokScreenWalkWave; off: see phase 1)
+        const uint32_t remWalk = screenWave ? 16u : 0u;
+        auto remGrid = [&](uint32_t slots) { return screenWave ? (slots + kGrokRemWaveSlots - 1) / kGrokRemWaveSlots : (slots + kGrokPlanBlock - 1) / kGrokPlanBlock; };
         const bool postInStream = envInt("LC_GROK_POST_IN_STREAM", 1) != 0;    // round 0's post step behind each entry's kernel, on its stream
         const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 0) != 0;      // an entry with a BIG screen stages it for its remainder screen (measured: slower)
         // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
@@ -954,6 +966,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             std::vector<TdfaWaveJob> jobs;
             std::vector<size_t> jobEntry;
             uint32_t blocks = 0, ldsMax = 0;
+            const bool stagePrograms = stats.pairs <= 32768;  // (all entries' candidates together: what the ONE launch walks)
             for (size_t a = 0; a < nAct && jobs.size() < kTdfaWaveMaxJobs; ++a) {
                 PlanEntry& e = act[a];
                 const GrokDevicePattern& gp = patterns[e.p];
@@ -963,7 +976,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 TdfaWaveJob j{};
                 uint32_t lds = 0, seq = 0;
                 int rcJob = LC_OK;
-                if (!lcWaveJobPrepare(first, dev, e.cand, &j, &lds, &seq, &rcJob)) {
+                if (!lcWaveJobPrepare(first, dev, e.cand, stagePrograms, &j, &lds, &seq, &rcJob)) {
                     if (rcJob != LC_OK) return rcJob;
                     continue;
                 }
@@ -1290,8 +1303,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                             attrSet[dev] = lds;
                         }
                     }
-                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), lds, ws,
-                                       d_data, mine, static_cast<const GrokScreenDev*>(T.dRemScreens) + a, big ? 2u : small ? 1u : 0u, 0ull);
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(e.cand), 1), dim3(kGrokPlanBlock), lds, ws,
+                                       d_data, mine, static_cast<const GrokScreenDev*>(T.dRemScreens) + a, (big ? 2u : small ? 1u : 0u) | remWalk, 0ull);
                 });
             }
         };
@@ -1320,8 +1333,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                            dim3(kGrokPlanBlock), 0, gs, d_data, T.dEntries,
                                            remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), ~groupMask,
                                            remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
-                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, gs, d_data,
-                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u, ~groupMask);
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, gs, d_data,
+                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, ~groupMask);
                 }
                 if (breadthFirst) {
                     for (size_t k = 0; k < longest; ++k)
@@ -1374,12 +1387,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 }
                 HIP_TRY(hipEventRecord(T.fork, st));
                 HIP_TRY(hipStreamWaitEvent(T.workers[0], T.fork, 0));
-                hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, T.dEntries,
-                                   static_cast<const GrokScreenDev*>(T.dRemScreens), 2u, ~bigMask);
+                hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, T.dEntries,
+                                   static_cast<const GrokScreenDev*>(T.dRemScreens), 2u | remWalk, ~bigMask);
                 HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
             }
-            hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
-                               static_cast<const GrokScreenDev*>(T.dRemScreens), small ? 1u : 0u, earlyMask | bigMask);
+            hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
+                               static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, earlyMask | bigMask);
             if (bigMask) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
         }
         }

@@ -29,6 +29,7 @@
 #include "screen_kernel_layout.h"
 
 constexpr int kGrokPlanBlock = 256;
+constexpr uint32_t kGrokRemWaveSlots = 16;  // grok_remainder_all_kernel, wave walk: slots per workgroup
 constexpr uint32_t kGrokNone = 0xFFFFFFFFu;
 // nmatch word of a slot: low bits = contributing matches so far, high bits = the entry could not decide the value
 constexpr uint32_t kGrokSlotOverflow = 0x80000000u;  // thread lists overflowed and nothing settled it
@@ -169,6 +170,69 @@ __device__ __forceinline__ uint32_t grokScreenWalk(const uint8_t* p, uint32_t L,
     return state;
 }
 
+// The same walk by a whole WAVEFRONT (round 6).  A screen is a relaxed whole-pattern automaton: between the few bytes that move it,
+// it sits in states that loop on nearly everything ("X.*Y.*Z").  One value per lane paid a dependent table read for every one of a
+// value's bytes -- 110 ns each, 0.44 ms for a 4 KiB value: the screen phase of a small batch, and again the remainder screens of phase
+// 2c (profiles/round5_grok_timeline.txt).  Here the state is wave-uniform, the wave holds 256 bytes of the value as classes (4 per
+// lane), and a byte that keeps the state starts a scan: every lane asks the table whether ITS four bytes keep it too, a ballot finds
+// the first one that does not -- 256 bytes per step instead of one.  Same states as grokScreenWalk, byte for byte.
+template <typename TablePtr>
+__device__ __forceinline__ uint32_t grokScreenWalkWave(const uint8_t* p, uint32_t L, uint32_t start, uint32_t sink, uint32_t ncls,
+                                                       const uint8_t* cmap, TablePtr table, uint32_t lane) {
+    uint32_t state = start;
+    if (L == 0) return state;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t head = uint32_t(addr & 3);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - head);
+    const uint32_t end = head + L, nWords = (end + 3) / 4;
+    auto classesOf = [&](uint32_t w4) {
+        return uint32_t(cmap[w4 & 0xFFu]) | (uint32_t(cmap[(w4 >> 8) & 0xFFu]) << 8) | (uint32_t(cmap[(w4 >> 16) & 0xFFu]) << 16) |
+               (uint32_t(cmap[w4 >> 24]) << 24);
+    };
+    uint32_t chunk = 0, idx = head;
+    uint32_t cur = classesOf(lane < nWords ? words[lane] : 0u);
+    while (idx < end && state != sink && state != 0) {
+        if ((idx >> 8) != chunk) {
+            chunk = idx >> 8;
+            const uint32_t w = (chunk << 6) + lane;
+            cur = classesOf(w < nWords ? words[w] : 0u);
+        }
+        const uint32_t wsel = uint32_t(__builtin_amdgcn_readlane(int(cur), int((idx >> 2) & 63u)));
+        const uint32_t cls = (wsel >> ((idx & 3u) * 8)) & 0xFFu;
+        const uint32_t row = state * ncls;
+        const uint32_t next = uint32_t(__builtin_amdgcn_readfirstlane(int(table[row + cls])));
+        if (next != state) {
+            state = next;
+            ++idx;
+            continue;
+        }
+        // a byte that keeps the state: where does the run of such bytes end?
+        uint32_t stop = end;
+        for (;;) {
+            const uint32_t chunkBase = chunk << 8;
+            uint32_t firstHit = 4;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                const uint32_t c = (cur >> (8 * j)) & 0xFFu;
+                if (bi > idx && bi < end && uint32_t(table[row + c]) != state) firstHit = uint32_t(j);
+            }
+            const uint64_t hit = __ballot(firstHit < 4);
+            if (hit) {
+                const int l = __ffsll(static_cast<long long>(hit)) - 1;
+                stop = chunkBase + uint32_t(l) * 4 + uint32_t(__builtin_amdgcn_readlane(int(firstHit), l));
+                break;
+            }
+            if (chunkBase + 256 >= end) break;  // the run reaches the end of the value
+            ++chunk;
+            const uint32_t w = (chunk << 6) + lane;
+            cur = classesOf(w < nWords ? words[w] : 0u);
+        }
+        idx = stop;
+    }
+    return state;
+}
+
 // ---- all screens in one launch.  grid = (slices, screens); dynamic LDS = candidate list [sliceLen] u32 + staged table.
 // A slice is a run of values in LENGTH order (order[]: the lanes of a wavefront then walk values of about the same length); the
 // workgroup compacts the slice's carriers of the entry's bit into LDS (ballot), then walks them one value per lane.  Table entries
@@ -178,8 +242,11 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
                                                                         const uint32_t* __restrict__ len, uint32_t n, uint32_t sliceLen,
                                                                         const GrokScreenDev* __restrict__ screens,
                                                                         unsigned long long* __restrict__ masks,
-                                                                        const uint32_t* __restrict__ order, uint32_t stage) {
+                                                                        const uint32_t* __restrict__ order, uint32_t stageAndWalk) {
     // stage: 0 = tables through L2, 1 = the screens' ldsBytes staged, 2 = the launch of the BIG screens: bigBytes staged
+    // + 16: one value per WAVEFRONT (grokScreenWalkWave) instead of one per lane
+    const uint32_t stage = stageAndWalk & 15u;
+    const bool waveWalk = (stageAndWalk & 16u) != 0;
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     __shared__ uint32_t sCount;
@@ -233,6 +300,18 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     const uint16_t* ldsTable = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) +
                                                                  (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]));
     // 3. walk
+    if (waveWalk) {  // one value per wavefront (grokScreenWalkWave): small batches wait for their longest value
+        const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (uint32_t k = wave; k < count; k += kGrokPlanBlock / 64) {
+            const uint32_t v = __builtin_amdgcn_readfirstlane(cand[k]);
+            const uint32_t o = __builtin_amdgcn_readfirstlane(off[v]), L = __builtin_amdgcn_readfirstlane(len[v]);
+            const uint32_t state = staged ? grokScreenWalkWave(data + o, L, start, sink, ncls, cmap, ldsTable, lane)
+                                          : grokScreenWalkWave(data + o, L, start, sink, ncls, cmap, table, lane);
+            const bool pass = state == sink || (state != 0 && lAccept[state]);
+            if (!pass && lane == 0) atomicAnd(&masks[v], ~(1ull << sc.bit));
+        }
+        return;
+    }
     for (uint32_t k = tid; k < count; k += kGrokPlanBlock) {
         const uint32_t v = cand[k];
         const uint32_t state = staged ? grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, ldsTable)
@@ -477,8 +556,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(
 // skip: see grok_remainder_literal_kernel.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(const uint8_t* __restrict__ data,
                                                                            const GrokEntryDev* __restrict__ entries,
-                                                                           const GrokScreenDev* __restrict__ screens, uint32_t stage,
+                                                                           const GrokScreenDev* __restrict__ screens, uint32_t stageAndWalk,
                                                                            unsigned long long skip) {
+    const uint32_t stage = stageAndWalk & 15u;          // (as grok_screen_all_kernel)
+    const bool waveWalk = (stageAndWalk & 16u) != 0;    // one slot per WAVEFRONT: the workgroup takes the slots of its 256-slot window in turn
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     if ((skip >> blockIdx.y) & 1ull) return;
@@ -487,7 +568,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     const uint32_t tid = threadIdx.x;
     uint32_t nIn = e.cnt[GC_ROUND0];
     nIn = nIn < e.cand ? nIn : e.cand;
-    if (blockIdx.x * kGrokPlanBlock >= nIn) return;
+    // (wave walk: a workgroup takes kGrokRemWaveSlots slots, four at a time -- the host sizes the grid by the same number)
+    const uint32_t perBlock = (waveWalk && sc.blob) ? kGrokRemWaveSlots : uint32_t(kGrokPlanBlock);
+    if (!sc.blob && waveWalk && blockIdx.x * kGrokPlanBlock >= nIn) return;
+    if (blockIdx.x * perBlock >= nIn) return;
     const uint32_t k = blockIdx.x * kGrokPlanBlock + tid;
     if (!sc.blob) {
         if (k < nIn) {
@@ -518,6 +602,20 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;
     const uint16_t* ldsTable = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]));
+    if (waveWalk) {
+        const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t k0 = blockIdx.x * kGrokRemWaveSlots, k1 = k0 + kGrokRemWaveSlots < nIn ? k0 + kGrokRemWaveSlots : nIn;
+        for (uint32_t kk = k0 + wave; kk < k1; kk += kGrokPlanBlock / 64) {
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(e.listA[kk]);
+            const uint32_t L = __builtin_amdgcn_readfirstlane(e.len[slot]), from = __builtin_amdgcn_readfirstlane(e.from[slot]);
+            const uint32_t o = __builtin_amdgcn_readfirstlane(e.off[slot]);
+            const uint32_t rem = L > from ? L - from : 0;
+            const uint32_t state = staged ? grokScreenWalkWave(data + o + from, rem, start, sink, ncls, cmap, ldsTable, lane)
+                                          : grokScreenWalkWave(data + o + from, rem, start, sink, ncls, cmap, table, lane);
+            if ((state == sink || (state != 0 && lAccept[state])) && lane == 0) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+        }
+        return;
+    }
     if (k >= nIn) return;
     const uint32_t slot = e.listA[k];
     const uint32_t L = e.len[slot], from = e.from[slot];

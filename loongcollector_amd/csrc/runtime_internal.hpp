@@ -42,7 +42,9 @@ int lcEnsureScreenUploaded(lc_regex* re, int dev, const uint32_t** out);
 // misses raise: what lcMatchSecondChanceOnStream takes as `seq`) and returns true; the caller fills off / len / resume / caps / status /
 // n / nGroupsOut / firstBlock.  false: the handle goes its usual way (lcMatchFirstOnStream).  rc != LC_OK: a device error.
 struct TdfaWaveJob;
-bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc);
+// stagePrograms: the register programs ride in LDS (a launch of a few thousand values waits for its longest value; a launch that fills the
+// chip several times over is better off with the waves the LDS would cost)
+bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, bool stagePrograms, TdfaWaveJob* job, uint32_t* ldsBytes, uint32_t* seqOut, int* rc);
 // the jobs (firstBlock ascending, at most 64) as one launch on `st`; dTable / hTable: device and pinned buffers of lcWaveJobTableBytes()
 size_t lcWaveJobTableBytes();
 int lcLaunchWaveJobs(const uint8_t* d_data, const TdfaWaveJob* jobs, uint32_t nJobs, uint32_t totalBlocks, uint32_t ldsBytes, void* hTable,

@@ -22,6 +22,22 @@ lazy)
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('lazy=$lz', d['config']['workload'][-60:-20], d['ms_per_step'], 'ms', d['config']['batch'], d['config'].get('lazy_automata'))"; done ;;
+kprof)
+  # per-kernel times of a 1000-value Grok step (rocprofv3 kernel trace)
+  cd /tmp && export TMPDIR=/tmp
+  GPU_MAX_HW_QUEUES=16 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r6/kprof -o r1 -- python $R/tools/grok_bench.py --lines ${KPROF_LINES:-1000} --steps 3 --warmup 2 --no-sequential-check --cpu-sample-lines 50 > $R/gpurun_out/r6/kprof.log 2>&1
+  cd $R; python tools/grok_prof_summary.py gpurun_out/r6/kprof 2>&1 | head -30 | cut -c1-150; rm -rf gpurun_out/r6/kprof ;;
+screenab)
+  for rep in 1 2; do for sw in 1 0; do LC_GROK_SCREEN_WAVE=$sw GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 2 --cpu-sample-lines 300 --no-sequential-check 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('screen_wave=$sw', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms')"; done; done ;;
+fusedab)
+  for rep in 1 2; do for fz in 1 0; do LC_GROK_FUSED_ROUND0=$fz GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 2 --cpu-sample-lines 300 --no-sequential-check 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('fused=$fz', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms')"; done; done
+  LC_GROK_TRACE=1 GPU_MAX_HW_QUEUES=16 timeout 300 python tools/grok_bench.py --lines 16384 --steps 2 --warmup 1 --no-sequential-check --cpu-sample-lines 50 2>&1 >/dev/null | grep "grok plan: n\|in one launch\|grok plan 2a: entry" | tail -12 | cut -c1-230 ;;
 groktests)
   timeout 1500 python -m pytest tests/test_gpu_grok.py tests/test_go_regex.py -m gpu -q -x 2>&1 | tail -5 | cut -c1-300 | tee gpurun_out/r6/pytest_grok.txt ;;
 esac
