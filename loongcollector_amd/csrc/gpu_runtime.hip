@@ -39,6 +39,8 @@
 #include "split_kernel.hpp"
 #include "pipeline_kernel.hpp"
 #include "tdfa_stream_kernel.hpp"
+#include "gather_pool.hpp"
+#include "device_binding.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string tlsError;
@@ -122,171 +124,59 @@ extern "C" int lc_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ thread -> device
-// "In-agent: map runner thread -> GPU (threadNo % nGPU)".  The reference calls Process from
-// process_thread_count runner threads (core/runner/ProcessorRunner.cpp:138-142; the index is ProcessorRunner::GetThreadNo,
-// ProcessorRunner.h:40, and selects the thread's regex copy, ProcessorParseRegexNative.cpp:255-257).  The index does not cross the
-// C slot, and an agent never calls hipSetDevice: a fresh thread's current HIP device is 0, so through round 4 a plugin on an
-// 8-GPU node ran on GPU 0.  Now every HOST entry point (processors, lc_*_match_host, multiline, filter, pipeline) asks
-// lcHostEntryDevice: the first call of a thread binds it -- by the process-wide policy -- and makes that device current for
-// the thread; the thread's staging, streams and table uploads follow (they are per device already).  Entry points that take DEVICE
-// pointers never switch devices: the caller owns the placement, and lcDeviceEntryDevice refuses a pointer of another device.
+// The policy lives in device_binding.hpp (HIP-free: tests/native/binding_race.cpp runs it against a two-device double under
+// ThreadSanitizer); here it meets the HIP runtime.  Entry points that take DEVICE pointers never switch devices: the caller owns
+// the placement, and lcDeviceEntryDevice refuses a pointer of another device.
 namespace {
-std::atomic<int> gBindPolicy{-1};  // -1: not decided yet (LC_BIND_POLICY is read at first use)
-std::atomic<int> gBindFixedDevice{0};
-// Ordinals are dealt lowest-free-first and come BACK: when a thread releases its resources (lc_thread_release) or ends.  Through
-// round 5 an ordinal was the order of first entry, for good -- a short-lived helper thread that entered once consumed one and skewed
-// the deal for every runner thread behind it (review of round 5, design item 11).  With runner threads that live as long as the
-// process the deal is still ProcessorRunner's threadNo % nGPU.
-std::mutex gOrdinalMutex;
-uint32_t gNextOrdinal = 0;
-std::vector<uint32_t> gFreeOrdinals;  // kept sorted descending: back() is the lowest free one
-uint32_t takeOrdinal() {
-    std::lock_guard<std::mutex> g(gOrdinalMutex);
-    if (!gFreeOrdinals.empty()) {
-        const uint32_t o = gFreeOrdinals.back();
-        gFreeOrdinals.pop_back();
-        return o;
+struct HipDeviceApi {
+    static int count() { return lc_device_count(); }
+    static bool get(int* dev) {
+        const hipError_t e = hipGetDevice(dev);
+        if (e != hipSuccess) (void)hipFail(e, "hipGetDevice");
+        return e == hipSuccess;
     }
-    return gNextOrdinal++ & 0x7FFFFFFFu;
-}
-void returnOrdinal(uint32_t o) {
-    std::lock_guard<std::mutex> g(gOrdinalMutex);
-    gFreeOrdinals.insert(std::upper_bound(gFreeOrdinals.begin(), gFreeOrdinals.end(), o, std::greater<uint32_t>()), o);
-}
-struct ThreadBinding {
-    int device = -1;       // bound device, -1 = not bound
-    int ordinal = -1;      // this thread's ordinal (lowest free one at its first host entry), -1 = none taken
-    int inherited = -1;    // LC_BIND_INHERIT: the current device as last asked from the runtime
-    bool inheritOnly = false;  // this thread asked for LC_BIND_INHERIT itself: the process-wide policy does not bind it
-    void unbind() {  // (a device the host chose itself -- lc_runtime_set_thread_device, LC_BIND_FIXED -- holds no ordinal and stays)
-        if (ordinal < 0) return;
-        returnOrdinal(uint32_t(ordinal));
-        ordinal = -1;
-        device = -1;
-    }
-    ~ThreadBinding() {
-        if (ordinal >= 0) returnOrdinal(uint32_t(ordinal));  // (plain host state: safe at any point of a process's life)
+    static bool set(int dev) {
+        const hipError_t e = hipSetDevice(dev);
+        if (e != hipSuccess) (void)hipFail(e, "hipSetDevice");
+        return e == hipSuccess;
     }
 };
-thread_local ThreadBinding tlsBind;
-
-int bindPolicyNow() {
-    int p = gBindPolicy.load(std::memory_order_relaxed);
-    if (p >= 0) return p;
-    p = LC_BIND_ROUND_ROBIN;
-    int fixedDev = 0;
-    if (const char* e = getenv("LC_BIND_POLICY")) {  // inherit | rr | fixed:<d>
-        if (!strcmp(e, "inherit")) p = LC_BIND_INHERIT;
-        else if (!strncmp(e, "fixed:", 6)) {
-            p = LC_BIND_FIXED;
-            fixedDev = atoi(e + 6);
-        }
-    }
-    int expected = -1;
-    if (gBindPolicy.compare_exchange_strong(expected, p)) {
-        if (p == LC_BIND_FIXED) gBindFixedDevice.store(fixedDev);
-        return p;
-    }
-    return expected;
+typedef lcbind::Binder<HipDeviceApi, kLcMaxDevices> DeviceBinder;
+DeviceBinder& binder() {
+    static DeviceBinder* b = new DeviceBinder();  // (never destroyed: threads that end during process exit still return their ordinals)
+    return *b;
 }
-
-int applyBinding(int device) {
-    const int n = lc_device_count();
-    if (n <= 0) {
-        tlsError = "no HIP device";
-        return LC_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= n || device >= kLcMaxDevices) {
-        tlsError = "thread binding: device " + std::to_string(device) + " of " + std::to_string(n) + " visible";
-        return LC_ERR_ARG;
-    }
-    HIP_TRY(hipSetDevice(device));
-    tlsBind.device = device;
-    tlsBind.inheritOnly = false;
-    return LC_OK;
+thread_local DeviceBinder::Thread tlsBind;
+static_assert(lcbind::kInherit == LC_BIND_INHERIT && lcbind::kRoundRobin == LC_BIND_ROUND_ROBIN && lcbind::kFixed == LC_BIND_FIXED, "policy values");
+int bindRc(int rc, const std::string& err) {  // device_binding.hpp's codes -> the C ABI's
+    if (rc >= 0) return LC_OK;
+    if (!err.empty()) tlsError = err;
+    return rc == lcbind::kErrArg ? LC_ERR_ARG : rc == lcbind::kErrNoDevice ? LC_ERR_NO_DEVICE : LC_ERR_HIP;
 }
 }  // namespace
 
-extern "C" int lc_runtime_device_for_ordinal(uint32_t ordinal, int ndevices) {
-    return ndevices > 0 ? int(ordinal % uint32_t(ndevices)) : -1;
-}
+extern "C" int lc_runtime_device_for_ordinal(uint32_t ordinal, int ndevices) { return DeviceBinder::deviceForOrdinal(ordinal, ndevices); }
 
-extern "C" int lc_runtime_set_bind_policy(int policy, int device) {
-    if (policy != LC_BIND_INHERIT && policy != LC_BIND_ROUND_ROBIN && policy != LC_BIND_FIXED) return LC_ERR_ARG;
-    if (policy == LC_BIND_FIXED && device < 0) return LC_ERR_ARG;
-    if (policy == LC_BIND_FIXED) gBindFixedDevice.store(device);
-    gBindPolicy.store(policy);
-    return LC_OK;
-}
+extern "C" int lc_runtime_set_bind_policy(int policy, int device) { return binder().setPolicy(policy, device) == lcbind::kOk ? LC_OK : LC_ERR_ARG; }
 
-extern "C" int lc_runtime_bind_policy(void) { return bindPolicyNow(); }
+extern "C" int lc_runtime_bind_policy(void) { return binder().policy(); }
 
 extern "C" int lc_runtime_bind_thread(int policy) {
-    if (policy < 0) policy = bindPolicyNow();
-    ThreadBinding& b = tlsBind;
-    if (policy == LC_BIND_INHERIT) {
-        b.device = -1;
-        b.inheritOnly = true;
-        int cur = 0;
-        if (lc_device_count() <= 0) {
-            tlsError = "no HIP device";
-            return -LC_ERR_NO_DEVICE;
-        }
-        if (hipGetDevice(&cur) != hipSuccess) return -LC_ERR_HIP;
-        b.inherited = cur;
-        return cur;
-    }
-    int want = 0;
-    if (policy == LC_BIND_FIXED) {
-        want = gBindFixedDevice.load();
-    } else if (policy == LC_BIND_ROUND_ROBIN) {
-        const int n = lc_device_count();
-        if (n <= 0) {
-            tlsError = "no HIP device";
-            return -LC_ERR_NO_DEVICE;
-        }
-        // a thread whose current device is not the runtime's default has been placed by its host (hipSetDevice, torch.cuda.set_device):
-        // that is kept.  Device 0 is what a thread gets without asking -- those threads are dealt out by their ordinal.
-        int cur = 0;
-        if (hipGetDevice(&cur) != hipSuccess) return -LC_ERR_HIP;
-        if (cur != 0) want = cur;
-        else {
-            if (b.ordinal < 0) b.ordinal = int(takeOrdinal());
-            want = lc_runtime_device_for_ordinal(uint32_t(b.ordinal), n);
-        }
-    } else {
-        return -LC_ERR_ARG;
-    }
-    const int rc = applyBinding(want);
-    return rc == LC_OK ? want : -rc;
+    std::string err;
+    const int d = binder().bindThread(tlsBind, policy, &err);
+    return d >= 0 ? d : -bindRc(d, err);
 }
 
-extern "C" int lc_runtime_set_thread_device(int device) { return applyBinding(device); }
+extern "C" int lc_runtime_set_thread_device(int device) {
+    std::string err;
+    return bindRc(binder().setThreadDevice(tlsBind, device, &err), err);
+}
 
 extern "C" int lc_runtime_thread_device(void) { return tlsBind.device; }
 
 int lcHostEntryDevice(int* dev) {
-    ThreadBinding& b = tlsBind;
-    if (b.device >= 0) {
-        // A host library (torch, another plugin) may have moved the thread's current device since the last group: asked PER CALL --
-        // hipGetDevice reads a thread-local of the runtime, no lock -- because up to round 5 it was asked every 256th call, and the
-        // groups in between were launched on the thread's cached streams of device A while device B was current.
-        // The bound device is made current again and STAYS current behind the call: INTEGRATION.md section 11 says so.
-        int cur = -1;
-        HIP_TRY(hipGetDevice(&cur));
-        if (cur != b.device) HIP_TRY(hipSetDevice(b.device));
-        *dev = b.device;
-        return LC_OK;
-    }
-    if (b.inheritOnly || bindPolicyNow() == LC_BIND_INHERIT) {
-        HIP_TRY(hipGetDevice(&b.inherited));
-        *dev = b.inherited;
-        return *dev < kLcMaxDevices ? LC_OK : LC_ERR_ARG;
-    }
-    const int d = lc_runtime_bind_thread(-1);
-    if (d < 0) return -d;
-    *dev = d;
-    return LC_OK;
+    std::string err;
+    return bindRc(binder().hostEntryDevice(tlsBind, dev, &err), err);
 }
 
 int lcDeviceEntryDevice(const void* d_ptr, int* dev) {
@@ -1780,6 +1670,7 @@ struct Slot {
     // what is in flight
     uint32_t first = 0, count = 0;
     bool busy = false;
+    unsigned gatherWays = 1;  // gather_pool.hpp: how many ways the chunk's host copies are split (1: the calling thread alone)
 };
 
 struct HostPipeline {
@@ -1857,7 +1748,7 @@ int growSlot(Slot& s, size_t dataBytes, size_t lines, size_t capsInts) {
 int drainSlot(Slot& s, uint32_t ngroups, int32_t* caps, uint8_t* status) {
     if (!s.busy) return LC_OK;
     HIP_TRY(hipEventSynchronize(s.done));
-    if (ngroups) std::memcpy(caps + size_t(s.first) * 2 * ngroups, s.hCaps, size_t(s.count) * 2 * ngroups * 4);
+    if (ngroups) lcgather::parallelCopy(caps + size_t(s.first) * 2 * ngroups, s.hCaps, size_t(s.count) * 2 * ngroups * 4, s.gatherWays);
     std::memcpy(status + s.first, s.hStatus, s.count);
     s.busy = false;
     return LC_OK;
@@ -2052,12 +1943,41 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
         }
         const size_t stageBytes = contiguous ? size_t(hi - lo) : bytes;
         if ((rc = growSlot(s, stageBytes + 16, cnt, size_t(cnt) * 2 * ngroups)) != LC_OK) return rc;
+        // Round 6: the chunk's host copies split over a few helper threads (gather_pool.hpp): one thread gathers ~10 GB/s, the bus
+        // takes 55 -- the path was gather-bound at 16-20 GB/s for three rounds
+        const unsigned ways = (n > cnt || next > 0) ? lcgather::GatherPool::instance().width() : 1u;  // (only batches of several chunks)
+        s.gatherWays = ways;
         if (contiguous) {
-            std::memcpy(s.hData, lo, stageBytes);
+            lcgather::parallelCopy(s.hData, lo, stageBytes, ways);
             for (uint32_t i = 0; i < cnt; ++i) {
                 s.hOff[i] = uint32_t(src.at(next + i) - lo);
                 s.hLen[i] = src.len[next + i];
             }
+        } else if (ways > 1 && bytes >= (size_t(1) << 20)) {
+            // per-line gather: the lines dealt in runs of equal byte count, each run to its place
+            std::vector<uint32_t> cut(ways + 1, cnt);
+            std::vector<size_t> cutAt(ways + 1, bytes);
+            {
+                size_t at = 0;
+                unsigned w = 0;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    while (w < ways && at >= bytes / ways * w) {
+                        cut[w] = i;
+                        cutAt[w] = at;
+                        ++w;
+                    }
+                    s.hOff[i] = uint32_t(at);
+                    s.hLen[i] = src.len[next + i];
+                    at += src.len[next + i];
+                }
+            }
+            lcgather::GatherPool::instance().run(ways, [&](unsigned w) {
+                size_t at = cutAt[w];
+                for (uint32_t i = cut[w]; i < cut[w + 1]; ++i) {
+                    std::memcpy(s.hData + at, src.at(next + i), src.len[next + i]);
+                    at += src.len[next + i];
+                }
+            });
         } else {
             size_t at = 0;
             for (uint32_t i = 0; i < cnt; ++i) {

@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 
+#include "gather_pool.hpp"
 #include "group_combiner.hpp"
 
 namespace {
@@ -147,6 +148,24 @@ int main(int argc, char** argv) {
         for (auto& th : pool) th.join();
         printf("stop in flight: %d answered, %d refused\n", answered.load(), refused.load());
         if (answered.load() + refused.load() != threads * 30 || refused.load() == 0) ++bad;
+    }
+    // (d) csrc/gather_pool.hpp: four runner threads at once split their copies over the shared helpers
+    {
+        std::vector<std::thread> pool;
+        std::atomic<int> wrong{0};
+        for (int t = 0; t < 4; ++t)
+            pool.emplace_back([&, t] {
+                std::vector<uint8_t> src(size_t(3) << 20), dst(src.size() + 64);
+                for (int r = 0; r < 12; ++r) {
+                    for (size_t i = 0; i < src.size(); i += 4096) src[i] = uint8_t(i >> 12) ^ uint8_t(t * 16 + r);
+                    std::fill(dst.begin(), dst.end(), 0xEE);
+                    lcgather::parallelCopy(dst.data(), src.data(), src.size() - size_t(r), 4);
+                    if (std::memcmp(dst.data(), src.data(), src.size() - size_t(r)) != 0 || dst[src.size() - size_t(r)] != 0xEE) wrong.fetch_add(1);
+                }
+            });
+        for (auto& th : pool) th.join();
+        printf("gather pool: %u wide, %d wrong copies\n", lcgather::GatherPool::instance().width(), wrong.load());
+        if (wrong.load()) ++bad;
     }
     if (!started.load() || !ended.load()) ++bad;
     printf("%d checks failed\n", bad);

@@ -63,7 +63,8 @@ def test_the_group_commit_of_concurrent_runner_threads_under_thread_sanitizer():
     exe = os.path.join(out_dir, "combiner_race")
     src = os.path.join(ROOT, "tests", "native", "combiner_race.cpp")
     hdr = os.path.join(ROOT, "loongcollector_amd", "csrc", "group_combiner.hpp")
-    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in (src, hdr)):
+    hdr2 = os.path.join(ROOT, "loongcollector_amd", "csrc", "gather_pool.hpp")   # (part (d) of the driver: the host-fed path's gather helpers)
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in (src, hdr, hdr2)):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", os.path.dirname(hdr), "-o", exe, src, "-lpthread"])
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
     env.pop("LD_PRELOAD", None)
@@ -71,3 +72,25 @@ def test_the_group_commit_of_concurrent_runner_threads_under_thread_sanitizer():
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, (r.returncode, r.stdout[-800:], r.stderr[-2000:])
     assert "0 checks failed" in r.stdout, r.stdout
+
+
+@pytest.mark.skipif(not _tsan_usable(), reason="needs g++ with libtsan")
+def test_thread_to_gpu_placement_on_a_two_device_double_under_thread_sanitizer():
+    """csrc/device_binding.hpp (ProcessorRunner.h:40: runner thread k -> GPU k mod n): no box of this project has
+    ever shown more than one GPU, so the multi-device branches of tests/test_gpu_binding.py have never run.  Their CPU twin:
+    tests/native/binding_race.cpp gives the policy a HIP double with TWO devices -- the deal in order of first entry, ordinals that come
+    back with lc_thread_release and at thread exit (200 helper threads do not skew the deal), a host library that moves the thread's
+    current device between two calls, the fixed / inherit policies, a thread its host has placed, devices out of range, no device --
+    and sixteen threads that enter, release and re-enter at once, under ThreadSanitizer."""
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "binding_race")
+    src = os.path.join(ROOT, "tests", "native", "binding_race.cpp")
+    hdr = os.path.join(ROOT, "loongcollector_amd", "csrc", "device_binding.hpp")
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in (src, hdr)):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", os.path.dirname(hdr), "-o", exe, src, "-lpthread"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "0 checks failed" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
