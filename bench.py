@@ -228,7 +228,8 @@ def measure_in_agent_reference_shape(thread_counts, dev, lines, group_lines):
             raise SystemExit((r.stderr + r.stdout).strip().splitlines()[-1])
         return {"error": (r.stderr or r.stdout).strip()[-300:]}
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    return {"window16": d["window16_MBps"], "all_groups_alive": d["all_groups_alive_MBps"], "lib": d["lib"]}
+    return {"window16": d["window16_MBps"], "all_groups_alive": d["all_groups_alive_MBps"], "lib": d["lib"],
+            "window16_one_thread": {"median_of": d.get("window16_one_thread_runs_MBps", [])}}
 
 
 def measure_pipeline(thread_counts, buffer_bytes=512 << 10, n_buffers=64):
@@ -255,7 +256,9 @@ def measure_pipeline(thread_counts, buffer_bytes=512 << 10, n_buffers=64):
                    "instance" % (buffer_bytes >> 10, per),
            "reference_MBps": 68.0, "reference_what": "LoongCollector's published single-thread figure for this pipeline (BASELINE.md)"}
     expect = None
-    for label, fused in (("fused_MBps", True), ("three_steps_MBps", False)):
+    # (round 6: the three-steps-in-a-row form -- "Fused": false, what a pipeline that cannot travel fused falls back to -- is no longer a
+    # leg of this line: it was an A/B of the fused trip, and its 16 -> 32 thread figures said nothing the fused leg does not)
+    for label, fused in (("fused_MBps", True),):
         pipe = Pipeline({"Parse": parse, "Filter": filt, "Fused": fused})
         assert pipe.fused == fused
         res = {}

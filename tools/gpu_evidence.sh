@@ -45,3 +45,15 @@ print('%8d  %8.0f  %.4f  %.2f  %.4f' % (n, n * 513 / 2**20, d['ms_per_step'], d[
 done
 } > $O/size_sweep.txt
 cat $O/size_sweep.txt
+# occupancy probe (round 6): the same launch with ONE resident workgroup per CU instead of two (LC_TDFA_EXTRA_LDS pads the workgroup's LDS) --
+# how the time scales with the waves in flight says whether the kernel waits for a pipe or for latency  -> gpurun_out/evidence/occupancy_probe.txt
+{
+echo "# LC_TDFA_EXTRA_LDS  workgroups/CU  ms/step  roofline.frac   (python bench.py --steps 20 --warmup 3)"
+for X in 0 8192; do
+  LC_TDFA_EXTRA_LDS=$X timeout 300 $BENCH --steps 20 --warmup 3 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%8d  %d  %.4f  %.4f' % ($X, 1 if $X else 2, d['ms_per_step'], d['roofline']['frac']))"
+done
+} > $O/occupancy_probe.txt
+cat $O/occupancy_probe.txt

@@ -38,11 +38,20 @@ def main():
     raw = data[int(off[0]):int(off[0]) + int(length[0])].tobytes()
     want = [(k, raw[exp_caps[0][2 * i]:exp_caps[0][2 * i + 1]].decode("latin-1")) for i, k in enumerate(keys)]
     out = {"lib": os.path.basename(binding.LIB_PATH), "window16_MBps": {}, "all_groups_alive_MBps": {}}
+    out["window16_one_thread_runs_MBps"] = []
     for t in [int(x) for x in args.threads.split(",")]:
-        mbps, first = bench.measure_in_agent_window(pattern, keys, data, off, length, args.group_lines, m // args.group_lines, t)
-        if [tuple(kv) for kv in first] != want:
-            raise SystemExit("PARITY FAILURE (in-agent path, %s): stitched fields differ from the oracle's captures" % out["lib"])
-        out["window16_MBps"][str(t)] = round(mbps, 1)
+        # one runner thread on this event model moves 2.3-4.5 GB/s between runs (heap behaviour of 1000 x std::vector per group): the
+        # figure in the line is the MEDIAN of five repetitions in this process, the five are listed beside it
+        reps = 5 if t == 1 else 1
+        runs = []
+        for _ in range(reps):
+            mbps, first = bench.measure_in_agent_window(pattern, keys, data, off, length, args.group_lines, m // args.group_lines, t)
+            if [tuple(kv) for kv in first] != want:
+                raise SystemExit("PARITY FAILURE (in-agent path, %s): stitched fields differ from the oracle's captures" % out["lib"])
+            runs.append(round(mbps, 1))
+        out["window16_MBps"][str(t)] = sorted(runs)[len(runs) // 2]
+        if t == 1:
+            out["window16_one_thread_runs_MBps"] = runs
     t0 = int(args.threads.split(",")[0])
     out["all_groups_alive_MBps"][str(t0)] = round(bench.measure_in_agent(pattern, keys, data, off, length, args.group_lines, m // args.group_lines, t0)[0], 1)
     print(json.dumps(out))
