@@ -966,7 +966,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             std::vector<TdfaWaveJob> jobs;
             std::vector<size_t> jobEntry;
             uint32_t blocks = 0, ldsMax = 0;
-            const bool stagePrograms = stats.pairs <= 32768;  // (all entries' candidates together: what the ONE launch walks)
+            // (all entries' candidates together are what the ONE launch walks; LC_GROK_FUSED_STAGE=0/1 forces it: A/B)
+            const bool stagePrograms = envInt("LC_GROK_FUSED_STAGE", stats.pairs <= 32768 ? 1 : 0) != 0;
             for (size_t a = 0; a < nAct && jobs.size() < kTdfaWaveMaxJobs; ++a) {
                 PlanEntry& e = act[a];
                 const GrokDevicePattern& gp = patterns[e.p];
