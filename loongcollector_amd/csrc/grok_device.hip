@@ -612,6 +612,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const uint32_t screenWalk = [&] {
             const char* v = getenv("LC_GROK_SCREEN_WAVE");
             return (small && v && v[0] == '1') ? 16u : 0u;
+        }() | [&] {  // (round 6) staged tables are staged SCALED (grok_plan_kernel.hpp grokScreenWalkScaled); LC_GROK_SCREEN_SCALED=0: as before
+            const char* v = getenv("LC_GROK_SCREEN_SCALED");
+            return (v && v[0] == '0') ? 0u : 32u;
         }();
         const uint32_t slices = (n + sliceLen - 1) / sliceLen;
         lcNoteKernel("grok_screen_all_kernel");
@@ -920,7 +923,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool remainderWon = envInt("LC_GROK_REMAINDER_WON", 1) != 0;      // slots of values an earlier entry has won drop out in front of the screens
         const bool remainderInChain = envInt("LC_GROK_REMAINDER_INCHAIN", 1) != 0;  // the remainder screens per entry, at the end of its chain in phase 2c
         const bool screenWave = small && envInt("LC_GROK_SCREEN_WAVE", 0) != 0;  // remainder screens: one slot per wavefront (grokScreenWalkWave; off: see phase 1)
-        const uint32_t remWalk = screenWave ? 16u : 0u;
+        const uint32_t remWalk = (screenWave ? 16u : 0u) | (envInt("LC_GROK_SCREEN_SCALED", 1) != 0 ? 32u : 0u);
         auto remGrid = [&](uint32_t slots) { return screenWave ? (slots + kGrokRemWaveSlots - 1) / kGrokRemWaveSlots : (slots + kGrokPlanBlock - 1) / kGrokPlanBlock; };
         const bool postInStream = envInt("LC_GROK_POST_IN_STREAM", 1) != 0;    // round 0's post step behind each entry's kernel, on its stream
         const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 0) != 0;      // an entry with a BIG screen stages it for its remainder screen (measured: slower)

@@ -170,6 +170,59 @@ __device__ __forceinline__ uint32_t grokScreenWalk(const uint8_t* p, uint32_t L,
     return state;
 }
 
+// Round 6: the same walk over a table whose entries were SCALED when the table was staged into LDS -- an entry is the byte offset of the
+// next state's row (next x classes x 2) instead of its index.  The dependent chain of a byte was  ds_read_u16 -> v_mul_lo_u32 (quarter
+// rate) -> v_lshlrev -> v_add3 -> ds_read_u16 : 110 ns a byte, 0.44 ms for a 4 KiB value -- the screen phase of every small batch,
+// and once more the remainder screens of phase 2c.  Scaled it is  ds_read_u16 -> v_add3 -> ds_read_u16.  Tables of up to 64 KiB
+// (offsets fit 16 bits: every staged table).  `state` in and out: row byte offsets (0 = dead).
+__device__ __forceinline__ uint32_t grokScreenWalkScaled(const uint8_t* p, uint32_t L, uint32_t startOff, uint32_t sinkOff, const uint8_t* cmap,
+                                                         const uint16_t* ldsTable) {
+    uint32_t state = startOff;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t head = uint32_t(addr & 15);
+    const uint4* q = reinterpret_cast<const uint4*>(addr - head);
+    const uint32_t total = L ? head + L : 0;
+    const uint8_t* tableBytes = reinterpret_cast<const uint8_t*>(ldsTable);
+    uint4 cur = total ? q[0] : uint4{0, 0, 0, 0};
+    for (uint32_t pos = 0; pos < total && state != sinkOff && state != 0; pos += 16) {
+        ++q;
+        const uint4 nxt = pos + 16 < total ? *q : uint4{0, 0, 0, 0};
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t cls2[16];  // class x 2: the byte offset inside a row
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) cls2[j] = uint32_t(cmap[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]) << 1;
+        if (pos >= head && pos + 16 <= total) {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) state = *reinterpret_cast<const uint16_t*>(tableBytes + state + cls2[j]);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t bi = pos + j;
+                if (bi >= head && bi < total) state = *reinterpret_cast<const uint16_t*>(tableBytes + state + cls2[j]);
+            }
+        }
+        cur = nxt;
+    }
+    return state;
+}
+// staging a screen's [accept flags | table] block into LDS; scale: the table's entries become row byte offsets (see above)
+__device__ __forceinline__ void grokStageScreen(uint32_t* dst, const uint32_t* src, uint32_t stageBytes, uint32_t tableAt, uint32_t rowBytes,
+                                                bool scale, uint32_t tid) {
+    uint32_t i = tid;
+    auto conv = [&](uint32_t w, uint32_t wordIndex) {
+        if (!scale || wordIndex * 4 < tableAt) return w;
+        return ((w & 0xFFFFu) * rowBytes) | (((w >> 16) * rowBytes) << 16);
+    };
+    for (; i + 3 * kGrokPlanBlock < stageBytes / 4; i += 4 * kGrokPlanBlock) {  // (four loads in flight: a big table is 100+ KB)
+        const uint32_t a = src[i], b = src[i + kGrokPlanBlock], c = src[i + 2 * kGrokPlanBlock], d = src[i + 3 * kGrokPlanBlock];
+        dst[i] = conv(a, i);
+        dst[i + kGrokPlanBlock] = conv(b, i + kGrokPlanBlock);
+        dst[i + 2 * kGrokPlanBlock] = conv(c, i + 2 * kGrokPlanBlock);
+        dst[i + 3 * kGrokPlanBlock] = conv(d, i + 3 * kGrokPlanBlock);
+    }
+    for (; i < stageBytes / 4; i += kGrokPlanBlock) dst[i] = conv(src[i], i);
+}
+
 // The same walk by a whole WAVEFRONT (round 6).  A screen is a relaxed whole-pattern automaton: between the few bytes that move it,
 // it sits in states that loop on nearly everything ("X.*Y.*Z").  One value per lane paid a dependent table read for every one of a
 // value's bytes -- 110 ns each, 0.44 ms for a 4 KiB value: the screen phase of a small batch, and again the remainder screens of phase
@@ -281,19 +334,11 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
     const uint32_t stageBytes = stage == 2 ? sc.bigBytes : stage ? sc.ldsBytes : 0u;
     const bool staged = stageBytes != 0;
-    if (staged) {  // accept flags .. end of table are contiguous in the blob (4-byte aligned start)
-        uint32_t* dst = ldsWords + sliceLen;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
-        uint32_t i = tid;
-        for (; i + 3 * kGrokPlanBlock < stageBytes / 4; i += 4 * kGrokPlanBlock) {  // (four loads in flight: a big table is 100+ KB)
-            const uint32_t a = src[i], b = src[i + kGrokPlanBlock], c = src[i + 2 * kGrokPlanBlock], d = src[i + 3 * kGrokPlanBlock];
-            dst[i] = a;
-            dst[i + kGrokPlanBlock] = b;
-            dst[i + 2 * kGrokPlanBlock] = c;
-            dst[i + 3 * kGrokPlanBlock] = d;
-        }
-        for (; i < stageBytes / 4; i += kGrokPlanBlock) dst[i] = src[i];
-    }
+    // (round 6) a staged table of up to 64 KiB is staged SCALED: entries = row byte offsets (grokScreenWalkScaled); the wave walk and
+    // LC_GROK_SCREEN_SCALED=0 (the launcher clears bit 5 of stageAndWalk) keep the indices
+    const uint32_t tableAt = blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT], rowBytes = ncls * 2;
+    const bool scaled = staged && !waveWalk && (stageAndWalk & 32u) != 0 && (tableAt & 3u) == 0 && blob[SC_NSTATES] * rowBytes <= 0xFFFFu;
+    if (staged) grokStageScreen(ldsWords + sliceLen, reinterpret_cast<const uint32_t*>(accept), stageBytes, tableAt, rowBytes, scaled, tid);
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords + sliceLen) : accept;
     // (an LDS pointer the compiler can see is one: ds_read instead of flat loads in the walk)
@@ -314,8 +359,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     }
     for (uint32_t k = tid; k < count; k += kGrokPlanBlock) {
         const uint32_t v = cand[k];
-        const uint32_t state = staged ? grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, ldsTable)
-                                      : grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, table);
+        uint32_t state;
+        if (scaled) state = grokScreenWalkScaled(data + off[v], len[v], start * rowBytes, sink == 0xFFFFFFFFu ? 0xFFFFFFFFu : sink * rowBytes, cmap, ldsTable) / rowBytes;
+        else state = staged ? grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, ldsTable)
+                            : grokScreenWalk(data + off[v], len[v], start, sink, ncls, cmap, table);
         const bool pass = state == sink || (state != 0 && lAccept[state]);
         if (!pass) atomicAnd(&masks[v], ~(1ull << sc.bit));
     }
@@ -587,18 +634,9 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + blob[SC_OFF_TABLE]);
     const uint32_t stageBytes = stage == 2 ? sc.bigBytes : stage ? sc.ldsBytes : 0u;  // (2: the launch of the entries with BIG screens)
     const bool staged = stageBytes != 0;
-    if (staged) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(accept);
-        uint32_t i = tid;
-        for (; i + 3 * kGrokPlanBlock < stageBytes / 4; i += 4 * kGrokPlanBlock) {
-            const uint32_t a = src[i], b = src[i + kGrokPlanBlock], c = src[i + 2 * kGrokPlanBlock], d = src[i + 3 * kGrokPlanBlock];
-            ldsWords[i] = a;
-            ldsWords[i + kGrokPlanBlock] = b;
-            ldsWords[i + 2 * kGrokPlanBlock] = c;
-            ldsWords[i + 3 * kGrokPlanBlock] = d;
-        }
-        for (; i < stageBytes / 4; i += kGrokPlanBlock) ldsWords[i] = src[i];
-    }
+    const uint32_t tableAt = blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT], rowBytes = ncls * 2;
+    const bool scaled = staged && !waveWalk && (stageAndWalk & 32u) != 0 && (tableAt & 3u) == 0 && blob[SC_NSTATES] * rowBytes <= 0xFFFFu;  // (as grok_screen_all_kernel)
+    if (staged) grokStageScreen(ldsWords, reinterpret_cast<const uint32_t*>(accept), stageBytes, tableAt, rowBytes, scaled, tid);
     __syncthreads();
     const uint8_t* lAccept = staged ? reinterpret_cast<const uint8_t*>(ldsWords) : accept;
     const uint16_t* ldsTable = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ldsWords) + (blob[SC_OFF_TABLE] - blob[SC_OFF_ACCEPT]));
@@ -620,8 +658,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     const uint32_t slot = e.listA[k];
     const uint32_t L = e.len[slot], from = e.from[slot];
     const uint32_t rem = L > from ? L - from : 0;
-    const uint32_t state = staged ? grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, ldsTable)
-                                  : grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, table);
+    uint32_t state;
+    if (scaled) state = grokScreenWalkScaled(data + e.off[slot] + from, rem, start * rowBytes, sink == 0xFFFFFFFFu ? 0xFFFFFFFFu : sink * rowBytes, cmap, ldsTable) / rowBytes;
+    else state = staged ? grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, ldsTable)
+                        : grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, table);
     if (state == sink || (state != 0 && lAccept[state])) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
 }
 
