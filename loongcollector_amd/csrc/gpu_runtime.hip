@@ -1027,8 +1027,8 @@ bool lcWaveJobPrepare(lc_regex* re, int dev, uint32_t n, bool stagePrograms, Tdf
     {
         const char* waveEnv = getenv("LC_TDFA_WAVE_MAX");
         if (n > uint32_t(waveEnv ? atol(waveEnv) : 65536)) return false;
-        static const bool multiOff = getenv("LC_GROK_FUSED_ROUND0") != nullptr && getenv("LC_GROK_FUSED_ROUND0")[0] == '0';
-        if (multiOff) return false;
+        const char* fusedEnv = getenv("LC_GROK_FUSED_ROUND0");  // (read per batch: the parity tests run both forms in one process)
+        if (fusedEnv && fusedEnv[0] == '0') return false;
     }
     const uint32_t* hostHdr = nullptr;
     std::vector<uint32_t> lazyHeader;

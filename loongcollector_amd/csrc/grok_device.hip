@@ -1710,7 +1710,8 @@ struct GrokDeviceState::HostJob {
     // results in the batch's pinned staging (the worker's `run`), taken out by the group's own thread
     const int32_t* patternSrc = nullptr;
     const int32_t* firstSrc = nullptr;
-    std::string* error = nullptr;     // the batch's message (the worker's last error is thread-local to the worker)
+    const std::string* error = nullptr;  // the batch's message in the worker's batch state (the worker's last error is thread-local to the worker) ...
+    std::string errorText;            // ... copied here by the job's own thread while the batch's state is still the batch's
     const GrokBatchStats* stats = nullptr;  // what the batch did (lc_grok_last_batch_stats is per calling thread)
     const std::string* kernels = nullptr;   // ... and which kernels it launched (lc_launched_kernels is per calling thread)
     uint32_t lines() const { return n; }
@@ -1989,7 +1990,11 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
     HostJob job{data, off, len, n, pattern, &tlsFirst, &extraRows, &patterns, &opts, row};
     for (uint32_t i = 0; i < n; ++i) job.bytes += len[i];
     GrokDeviceState::HostCombiner* C = grokCombinerFor(state, dev);
-    const int rc = C->combiner->submit(job, [row](HostJob& j) {
+    const int rc = C->combiner->submit(job, [row](HostJob& j, int rcBatch) {
+        if (rcBatch != LC_OK) {
+            if (j.error) j.errorText = *j.error;
+            return;
+        }
         std::memcpy(j.pattern, j.patternSrc, size_t(j.n) * 4);
         j.first->resize(size_t(j.n) * row);
         std::memcpy(j.first->data(), j.firstSrc, size_t(j.n) * row * 4);
@@ -2006,10 +2011,10 @@ int lcGrokMatchHost(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
     });
     if (rc != LC_OK) {
         if (rc < 0) {
-            lcSetLastError("grok: the processor is shutting down");
+            lcSetLastError(rc == -1 ? "grok: the processor is shutting down" : "grok: the batch failed on the host (out of memory?)");
             return LC_ERR_ARG;
         }
-        if (job.error) lcSetLastError(*job.error);
+        if (!job.errorText.empty()) lcSetLastError(job.errorText);
         return rc;
     }
     *firstRows = tlsFirst.data();

@@ -65,9 +65,10 @@ class GroupCombiner {
     GroupCombiner(const GroupCombiner&) = delete;
     GroupCombiner& operator=(const GroupCombiner&) = delete;
 
-    // Blocks until the job's batch has run and `takeOut(job)` has copied the job's results out of the batch's staging (on the
-    // caller's thread, while the staging is still the batch's).  Returns the batch's code.
-    int submit(Job& job, const std::function<void(Job&)>& takeOut) {
+    // Blocks until the job's batch has run and `takeOut(job, rc)` has copied the job's results -- or, rc != 0, the batch's error text --
+    // out of the batch's staging (on the caller's thread, while the staging is still the batch's: the worker does not touch it before
+    // every caller of the batch is through).  Returns the batch's code.  A hook that throws fails the batch (-2), it never strands it.
+    int submit(Job& job, const std::function<void(Job&, int)>& takeOut) {
         Slot slot;
         slot.job = &job;
         std::unique_lock<std::mutex> lk(mMutex);
@@ -81,17 +82,27 @@ class GroupCombiner {
         mCallerCv.wait(lk, [&] { return slot.phase != Phase::QUEUED; });
         if (slot.phase == Phase::GATHER) {
             lk.unlock();
-            mHooks.gather(job);
+            bool gathered = true;
+            try {
+                mHooks.gather(job);
+            } catch (...) {
+                gathered = false;
+            }
             lk.lock();
+            if (!gathered) mGatherFailed = true;
             slot.phase = Phase::GATHERED;
             if (--mGathering == 0) mWorkerCv.notify_one();
             // 2. the batch has run
             mCallerCv.wait(lk, [&] { return slot.phase == Phase::DONE; });
         }
-        const int rc = slot.rc;
-        if (rc == 0 && takeOut) {
+        int rc = slot.rc;
+        if (takeOut) {
             lk.unlock();
-            takeOut(job);
+            try {
+                takeOut(job, rc);
+            } catch (...) {
+                if (rc == 0) rc = -2;
+            }
             lk.lock();
         }
         if (--mTakingOut == 0) mWorkerCv.notify_one();
@@ -193,17 +204,28 @@ class GroupCombiner {
             lk.unlock();
             const auto t0 = Clock::now();
             auto t1 = t0, t2 = t0;
-            int rc = mHooks.place ? mHooks.place(jobs) : 0;
+            int rc = 0;
+            try {
+                rc = mHooks.place ? mHooks.place(jobs) : 0;
+            } catch (...) {
+                rc = -2;
+            }
             t1 = t2 = Clock::now();
             if (rc == 0) {
                 lk.lock();
                 mGathering = batch.size();
+                mGatherFailed = false;
                 for (Slot* s : batch) s->phase = Phase::GATHER;
                 mCallerCv.notify_all();
                 mWorkerCv.wait(lk, [&] { return mGathering == 0; });
+                const bool gatherFailed = mGatherFailed;
                 lk.unlock();
                 t2 = Clock::now();
-                rc = mHooks.run(jobs);
+                try {
+                    rc = gatherFailed ? -2 : mHooks.run(jobs);
+                } catch (...) {
+                    rc = -2;
+                }
             }
             const auto t3 = Clock::now();
             lk.lock();
@@ -240,6 +262,7 @@ class GroupCombiner {
     std::vector<std::pair<uint64_t, uint64_t>> mCallers;  // (caller id, number of the batch being formed when it last came in)
     uint64_t mBatchNo = 3;
     size_t mGathering = 0, mTakingOut = 0;
+    bool mGatherFailed = false;
     Clock::time_point mLastArrival{};
     CombinerStats mStats;
 };

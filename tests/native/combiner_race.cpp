@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct Job {
     uint32_t* staged = nullptr;     // place(): where the values go
     const uint64_t* rowsSrc = nullptr;
     bool poison = false;            // the batch that carries this job fails
+    bool throws = false;            // ... its gather throws (a hook that throws fails the batch, it never strands it)
     uint32_t lines() const { return uint32_t(values.size()); }
 };
 uint64_t rowOf(uint32_t v) { return uint64_t(v) * 0x9E3779B97F4A7C15ull ^ (v >> 3); }
@@ -57,7 +59,10 @@ int main(int argc, char** argv) {
         }
         return 0;
     };
-    hooks.gather = [&](Job& j) { std::memcpy(j.staged, j.values.data(), j.values.size() * 4); };
+    hooks.gather = [&](Job& j) {
+        if (j.throws) throw std::bad_alloc();
+        std::memcpy(j.staged, j.values.data(), j.values.size() * 4);
+    };
     hooks.run = [&](std::vector<Job*>& jobs) {
         if (dev.inFlight.fetch_add(1) != 0) dev.overlaps.fetch_add(1);   // batches never overlap on the device
         std::this_thread::sleep_for(std::chrono::microseconds(dev.batchUs));
@@ -67,7 +72,9 @@ int main(int argc, char** argv) {
         dev.inFlight.fetch_sub(1);
         return rc;
     };
-    auto takeOut = [](Job& j) { j.rows.assign(j.rowsSrc, j.rowsSrc + j.values.size()); };
+    auto takeOut = [](Job& j, int rc) {
+        if (rc == 0) j.rows.assign(j.rowsSrc, j.rowsSrc + j.values.size());
+    };
     int bad = 0;
 
     // (a) one thread: never lingers (nobody else is expected)
@@ -148,6 +155,27 @@ int main(int argc, char** argv) {
         for (auto& th : pool) th.join();
         printf("stop in flight: %d answered, %d refused\n", answered.load(), refused.load());
         if (answered.load() + refused.load() != threads * 30 || refused.load() == 0) ++bad;
+    }
+    // (c2) a hook that throws on a caller's thread: the batch fails with -2 for everyone in it, the next batch runs
+    {
+        Combiner c(hooks);
+        std::atomic<int> failed{0}, fine{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < 8; ++t)
+            pool.emplace_back([&, t] {
+                for (int r = 0; r < 40; ++r) {
+                    Job j;
+                    j.values = {uint32_t(t), uint32_t(r)};
+                    j.throws = (t == 2 && r == 7);
+                    const int rc = c.submit(j, takeOut);
+                    if (rc == -2) failed.fetch_add(1);
+                    else if (rc == 0 && j.rows.size() == 2 && j.rows[1] == rowOf(uint32_t(r))) fine.fetch_add(1);
+                    else ++bad;
+                }
+            });
+        for (auto& th : pool) th.join();
+        printf("throwing gather: %d jobs failed with it, %d fine\n", failed.load(), fine.load());
+        if (failed.load() < 1 || failed.load() + fine.load() != 8 * 40) ++bad;
     }
     // (d) csrc/gather_pool.hpp: four runner threads at once split their copies over the shared helpers
     {
