@@ -727,7 +727,17 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // levels: an entry half of whose candidates have an earlier candidate entry waits for the entries that shadow a quarter of
         // them or more (SYSLOGLINE behind CRONLOG / HTTPD_ERRORLOG; SHOREWALL behind SYSLOGLINE; COMBINEDAPACHELOG behind
         // COMMONAPACHELOG): what those win it never looks at.  Results do not depend on the order -- only the work does.
-        if (shadowed * 2 >= c) {
+        // (round 6) ... unless the entry's round 0 is a TABLE WALK (a complete automaton in global memory, or a lazy one): then looking at
+        // values an earlier entry will win costs a few microseconds of a wavefront each, while waiting costs the batch a host round
+        // trip and the entry's longest walk a second time (0.4 ms in phase 2c, profiles/round6_grok_timeline.txt).  LC_GROK_FLAT=0: levels as in round 5.
+        const bool flat = [&] {
+            const char* v = getenv("LC_GROK_FLAT");
+            if (v && v[0] == '0') return false;
+            const lc_regex* first = patterns[p].anchored ? patterns[p].anchored : patterns[p].re;
+            if (first->engine == LC_ENGINE_TDFA) return !first->tdfaL2Blob.empty() && (first->preferWave || !first->hasTdfa);
+            return first->engine == LC_ENGINE_NFA && first->lazyReady.load(std::memory_order_acquire);
+        }();
+        if (shadowed * 2 >= c && !flat) {
             uint32_t lv = 1;
             for (uint32_t f = 0; f < p; ++f)
                 if (T.hostWords[HW_SHADOW + p * 64 + f] * 4 >= c) lv = std::max(lv, levelOf[f] + 1);

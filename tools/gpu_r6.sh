@@ -32,6 +32,11 @@ screenab)
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('screen_wave=$sw', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms')"; done; done ;;
+flatab)
+  for rep in 1 2; do for fz in 1 0; do LC_GROK_FLAT=$fz GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 2 --cpu-sample-lines 300 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('flat=$fz', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config']['parity']['both_paths_agree_on_every_line'])"; done; done ;;
 scaledab)
   for rep in 1 2; do for fz in 1 0; do LC_GROK_SCREEN_SCALED=$fz GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 2 --cpu-sample-lines 300 --no-sequential-check 2>/dev/null | python -c "
 import sys,json
