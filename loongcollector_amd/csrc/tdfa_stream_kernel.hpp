@@ -27,6 +27,9 @@
 #ifndef LC_TDFA_STREAM_CHUNK
 #define LC_TDFA_STREAM_CHUNK 8  // bytes per chunk (8 or 16): col / ncol / ptt / tt hold one value per byte of a chunk
 #endif
+#ifndef LC_TDFA_GCLASS
+#define LC_TDFA_GCLASS 0  // 1: the one-stamp pair kernel reads the second byte's class through the vector L1 instead of LDS (experiment)
+#endif
 #ifndef LC_TDFA_STAMP_ISA
 #define LC_TDFA_STAMP_ISA 1  // hand-picked instructions for the one-stamp pair kernel's stamp (0: the compiler's)
 #endif
@@ -144,7 +147,7 @@ __device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint3
                                                          uint32_t (&nc)[NB / 2], const uint32_t (&nwords)[NB / 4], uint32_t nbase,
                                                          uint32_t L, uint32_t cmapA, uint32_t idAAddr,
                                                          const uint32_t (&ptt)[NB / 2], uint32_t (&tt)[NB / 2], uint32_t pbase,
-                                                         uint32_t regAddr0) {
+                                                         uint32_t regAddr0, const uint8_t* __restrict__ gcmap8 = nullptr) {
     typedef LdsRegPtrT<TdfaReg> LdsRegPtr;
     constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
                                    (sizeof(TdfaReg) == 2 ? 1 : 0);  // log2(BLOCK * sizeof(TdfaReg))
@@ -160,7 +163,14 @@ __device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint3
             nc[p] = *reinterpret_cast<LdsBytePtr>((nbase + 2 * p + 1 < L) ? TD_CMAP_OFFSET + b1 : kTdfaIdColByteAddr);
         } else {
             na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
+#if LC_TDFA_GCLASS
+            // Round 6 experiment: the SECOND byte's class from the table's copy in global memory (256 bytes: two cache lines that never
+            // leave the vector L1) -- the texture path is idle in this kernel, the LDS queue is what the chain link waits in
+            // (profiles/round6_tdfa_why_not.md): one LDS instruction of four per byte pair moves off it.
+            nc[p] = gcmap8[b1];
+#else
             nc[p] = *reinterpret_cast<LdsBytePtr>(TD_CMAP_OFFSET + b1);
+#endif
         }
         // the previous chunk's pair p: ONE stamp
 #if LC_TDFA_STAMP_ISA
@@ -506,7 +516,7 @@ __device__ __forceinline__ void tdfaStreamBody(
             bool general;
             if constexpr (PAIR1) {
                 uint32_t na[NC], nc[NC];
-                if (ALLFULL || waveFull || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                if (ALLFULL || waveFull || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, reinterpret_cast<const uint8_t*>(blob) + TD_CMAP_OFFSET);
                 else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
                 tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
 #pragma unroll
