@@ -324,6 +324,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         return e && e[0] == '0';
     }();
     const bool dma = COMPACT && !PAIR && !BYTEROWS && !streamOff && !dmaOff;
+    bool cmapA8 = false;
     auto kern = tdfa_match_kernel<BLOCK, PAIR, COMPACT, BYTEROWS>;
     if constexpr (!BYTEROWS) {
         if (!streamOff) kern = tdfa_stream_kernel<BLOCK, COMPACT, PAIR>;
@@ -341,11 +342,22 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
                     return LC_ERR_UNSUPPORTED;
                 }
                 kern = tdfa_stream_kernel<BLOCK, COMPACT, true, kTdfaNoGeneralPrograms | kLabPairOne | (COMPACT ? kLabDmaStage : 0)>;
+                // (round 6) ... with the first byte's class from a u8 copy of cmapA that the workgroup builds behind its tiles (272 bytes):
+                // ASCII bytes then sit on 32 different banks, where the u16 table put b and b + 64 on one.  Only where the extra LDS does
+                // not cost a resident workgroup.  MEASURED AND LEFT OFF (LC_TDFA_CMAPA8=1 switches it on): 0.1753 against 0.1719 ms per 1 Mi
+                // lines -- the conflicts of the class map are not what the chain link waits for (profiles/round6_tdfa_why_not.md section 8).
+                const char* a8Env = getenv("LC_TDFA_CMAPA8");
+                const size_t half = kLcLdsPerCu / 2;
+                if (a8Env && a8Env[0] == '1' && (lds + kTdfaCmapA8Bytes <= half || lds > half) && lds + kTdfaCmapA8Bytes <= kLcLdsPerCu) {
+                    kern = tdfa_stream_kernel<BLOCK, COMPACT, true, kTdfaNoGeneralPrograms | kLabPairOne | kLabCmapA8 | (COMPACT ? kLabDmaStage : 0)>;
+                    lds += kTdfaCmapA8Bytes;
+                    cmapA8 = true;
+                }
             }
         }
     }
-    static thread_local size_t ldsAttrSet[kLcMaxDevices][6] = {};  // the attribute belongs to (function, device)
-    const int which = (PAIR && pairOne) ? 5 : dma ? (noGen ? 4 : 3) : noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
+    static thread_local size_t ldsAttrSet[kLcMaxDevices][7] = {};  // the attribute belongs to (function, device)
+    const int which = cmapA8 ? 6 : (PAIR && pairOne) ? 5 : dma ? (noGen ? 4 : 3) : noGen ? 2 : (!BYTEROWS && !streamOff) ? 1 : 0;
     int devNow = 0;
     if (lds > 64 * 1024) HIP_TRY(hipGetDevice(&devNow));
     if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > ldsAttrSet[devNow][which]) {
@@ -363,7 +375,8 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     const uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    noteKernel((PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
+    noteKernel(cmapA8 ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,a8>" : "tdfa_stream_kernel<nogeneral,pair1,a8>")
+               : (PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
     // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)
     const uint32_t* blobArg = static_cast<const uint32_t*>(dBlob);

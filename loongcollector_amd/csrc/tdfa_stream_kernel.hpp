@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t tdfaStreamPairChunk(uint32_t t, const uint32
 // max(register, pos + 1) -- only in chunks in which some lane of the wavefront met a DOUBLE.  Positions only grow along a line
 // and registers start at 0, so "latest" is "largest" and the order of the two kinds of store among themselves does not matter:
 // tests/helpers/table_interp.py TdfaPair1Interp is this function, store for store.
-template <int BLOCK, int NB, bool CHECKED, typename TdfaReg>
+template <int BLOCK, int NB, bool CHECKED, typename TdfaReg, bool A8 = false>
 __device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint32_t (&colp)[NB / 2], uint32_t (&na)[NB / 2],
                                                          uint32_t (&nc)[NB / 2], const uint32_t (&nwords)[NB / 4], uint32_t nbase,
                                                          uint32_t L, uint32_t cmapA, uint32_t idAAddr,
@@ -159,10 +159,12 @@ __device__ __forceinline__ uint32_t tdfaStreamPair1Chunk(uint32_t t, const uint3
         asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b0) : "v"(nwords[p >> 1]), "n"((p & 1) * 16));
         asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(b1) : "v"(nwords[p >> 1]), "n"((p & 1) * 16 + 8));
         if constexpr (CHECKED) {
-            na[p] = *reinterpret_cast<LdsHalfPtr>((nbase + 2 * p < L) ? cmapA + b0 * 2 : idAAddr);
+            if constexpr (A8) na[p] = *reinterpret_cast<LdsBytePtr>((nbase + 2 * p < L) ? cmapA + b0 : idAAddr);  // (cmapA / idAAddr: the u8 copy, its 257th byte)
+            else na[p] = *reinterpret_cast<LdsHalfPtr>((nbase + 2 * p < L) ? cmapA + b0 * 2 : idAAddr);
             nc[p] = *reinterpret_cast<LdsBytePtr>((nbase + 2 * p + 1 < L) ? TD_CMAP_OFFSET + b1 : kTdfaIdColByteAddr);
         } else {
-            na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
+            if constexpr (A8) na[p] = *reinterpret_cast<LdsBytePtr>(cmapA + b0);
+            else na[p] = *reinterpret_cast<LdsHalfPtr>(cmapA + b0 * 2);
 #if LC_TDFA_GCLASS
             // Round 6 experiment: the SECOND byte's class from the table's copy in global memory (256 bytes: two cache lines that never
             // leave the vector L1) -- the texture path is idle in this kernel, the LDS queue is what the chain link waits in
@@ -289,6 +291,16 @@ __device__ __forceinline__ void tdfaStreamBody(
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < blobBytes / 16; i += BLOCK) dst[i] = src[i];
         tdfaClearRegisters<BLOCK>(smem, blob, blobBytes, regBytes);
+        if constexpr (PAIR1 && (LAB & kLabCmapA8) != 0) {
+            // the u8 copy of the first-byte class map, behind the tiles: class INDEX = cmapA[b] / (the first byte's stride); byte 256 = the
+            // identity class (a byte outside the line)
+            const uint32_t po = blob[TD_OFF_PAIR];
+            const uint32_t* gph = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(blob) + po);
+            const uint16_t* gA = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(blob) + gph[TP_OFF_CMAPA]);
+            const uint32_t strideA = blob[TD_ID_COL] + 4;  // (classes + 1) * 4
+            uint8_t* a8 = smem + blobBytes + regBytes + (BLOCK / 64) * 64 * (COMPACT ? kTdfaStageBytes : kTdfaRowStride);
+            for (uint32_t i = tid; i < 257; i += BLOCK) a8[i] = uint8_t((i < 256 ? uint32_t(gA[i]) : gph[TP_ID_A]) / strideA);
+        }
         if constexpr (PAIR1) {  // ("latest stamp" = "largest offset" for the settled doubles: every register starts at 0)
             if (((blob[TD_NREGS] >> 16) & 0x1FFFu) == 0) {
                 uint32_t* regs = reinterpret_cast<uint32_t*>(smem + blobBytes);
@@ -320,6 +332,9 @@ __device__ __forceinline__ void tdfaStreamBody(
 
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stageBase = blobBytes + regBytes + wave * kStagePerWave;
+    // (kLabCmapA8) LDS address of the u8 first-byte class map and the stride a class index scales by
+    const uint32_t cmapA8 = blobBytes + regBytes + (BLOCK / 64) * kStagePerWave;
+    const uint32_t strideA8 = idCol + 4;
 
     const uint32_t slot = blockId * BLOCK + tid;
     bool live = slot < nLines;
@@ -516,11 +531,13 @@ __device__ __forceinline__ void tdfaStreamBody(
             bool general;
             if constexpr (PAIR1) {
                 uint32_t na[NC], nc[NC];
-                if (ALLFULL || waveFull || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0, reinterpret_cast<const uint8_t*>(blob) + TD_CMAP_OFFSET);
-                else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg>(t, col, na, nc, nwords, nbase, L, pi.cmapA, idAAddr, ptt, tt, pbase, regAddr0);
+                constexpr bool A8 = (LAB & kLabCmapA8) != 0;
+                const uint32_t mapA = A8 ? cmapA8 : pi.cmapA, idA = A8 ? cmapA8 + 256u : idAAddr;
+                if (ALLFULL || waveFull || __all(fullNext)) t = tdfaStreamPair1Chunk<BLOCK, NB, false, TdfaReg, A8>(t, col, na, nc, nwords, nbase, L, mapA, idA, ptt, tt, pbase, regAddr0, reinterpret_cast<const uint8_t*>(blob) + TD_CMAP_OFFSET);
+                else t = tdfaStreamPair1Chunk<BLOCK, NB, true, TdfaReg, A8>(t, col, na, nc, nwords, nbase, L, mapA, idA, ptt, tt, pbase, regAddr0);
                 tdfaSettleDoubles<BLOCK, NC, TdfaReg>(ptt, pbase, regAddr0);
 #pragma unroll
-                for (int j = 0; j < NC; ++j) ncol[j] = na[j] + nc[j];
+                for (int j = 0; j < NC; ++j) ncol[j] = A8 ? __umul24(na[j], strideA8) + nc[j] : na[j] + nc[j];
                 seen = 0;
                 general = false;
             } else if constexpr (PAIR) {

@@ -13,6 +13,10 @@ inagent_trace)
   grep "grok host batch" gpurun_out/r6/inagent_trace.txt | tail -30 | cut -c1-250 ;;
 inagent)
   timeout 600 python tools/grok_inagent_bench.py --threads 1,4,16,32 --groups 40 2>/dev/null | cut -c1-330 | tee gpurun_out/r6/inagent_$(date +%H%M).json ;;
+a8ab)
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_pair1_tables.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
+  for rep in 1 2; do for a8 in 1 0; do LC_TDFA_CMAPA8=$a8 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cmapa8=$a8', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernels_launched'])"; done; done
+  LC_TDFA_CMAPA8=1 timeout 300 python bench.py --regex B --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('regexB a8=1', d['ms_per_step'], d['roofline']['frac'])" ;;
 headline)
   timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
   for i in 1 2; do timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline'])"; done ;;
