@@ -345,8 +345,10 @@ constexpr uint32_t kGrokSmallBatch = 262144;  // up to here phase 1 takes the ch
 constexpr uint32_t kGrokWideFirstBatch = 32768;  // ... and up to here a batch waits for its longest value: wide first pays (16 Ki: -0.3 ms; 64 Ki: +0.5 ms)
 
 // Pinned host words of a thread: what the two syncs of a batch read back.
-enum { HW_CAND = 0, HW_TAIL = 64, HW_CNT = 128, HW_FIRST = 128 + 64 * GC_WORDS, HW_SHADOW = 192 + 64 * GC_WORDS,
-       HW_WORDS = 192 + 64 * GC_WORDS + 64 * 64 };
+// (HW_CAND | HW_FIRST | HW_SHADOW mirror the device block dPlanWords: one copy brings all three)
+enum { HW_CAND = 0, HW_FIRST = 64, HW_SHADOW = 128, HW_TAIL = 128 + 64 * 64, HW_CNT = 192 + 64 * 64,
+       HW_WORDS = 192 + 64 * 64 + 64 * GC_WORDS };
+constexpr uint32_t kPlanWords = 64 + 64 + 64 * 64;  // device: candidates per entry | first-candidate counts | who shadows whom
 // device tail words (scratch `counters`): [0] gate  [1] xcount (extra rows wanted in xtmp)
 enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16 };
 
@@ -361,7 +363,8 @@ struct PlanThread {
     uint32_t* dCnt = nullptr;             // device [64][GC_WORDS]
     GrokScreenDev* hostRemScreens = nullptr;  // pinned [64]: per ACTIVE entry, its screen (blob == nullptr: none)
     GrokScreenDev* dRemScreens = nullptr;     // device [64]
-    uint32_t* dShadow = nullptr;              // device [64][64]: candidates of entry p whose value's first candidate is entry f
+    uint32_t* dPlanWords = nullptr;           // device [kPlanWords]: perEntry[64] | firstOf[64] | shadow[64][64] (candidates of entry p whose
+                                              // value's first candidate is entry f)
     void* hostJobs = nullptr;                 // pinned / device: the job table of round 0's fused launch (runtime_internal.hpp lcLaunchWaveJobs)
     void* dJobs = nullptr;
     void* arena = nullptr;                // device, grow-only: the per-entry arrays of the batch in flight
@@ -388,7 +391,7 @@ struct PlanThread {
                 if (dCnt) (void)hipFree(dCnt);
                 if (hostRemScreens) (void)hipHostFree(hostRemScreens);
                 if (dRemScreens) (void)hipFree(dRemScreens);
-                if (dShadow) (void)hipFree(dShadow);
+                if (dPlanWords) (void)hipFree(dPlanWords);
                 if (hostJobs) (void)hipHostFree(hostJobs);
                 if (dJobs) (void)hipFree(dJobs);
                 if (arena) (void)hipFree(arena);
@@ -405,7 +408,7 @@ struct PlanThread {
         dCnt = nullptr;
         hostRemScreens = nullptr;
         dRemScreens = nullptr;
-        dShadow = nullptr;
+        dPlanWords = nullptr;
         hostJobs = nullptr;
         dJobs = nullptr;
         arena = nullptr;
@@ -424,7 +427,7 @@ struct PlanThread {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dCnt), 64 * GC_WORDS * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostRemScreens), 64 * sizeof(GrokScreenDev), hipHostMallocDefault));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dRemScreens), 64 * sizeof(GrokScreenDev)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dShadow), 64 * 64 * 4));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dPlanWords), kPlanWords * 4));
             HIP_TRY(hipHostMalloc(&hostJobs, lcWaveJobTableBytes(), hipHostMallocDefault));
             HIP_TRY(hipMalloc(&dJobs, lcWaveJobTableBytes()));
         }
@@ -551,7 +554,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     uint32_t* undecided = winner + n;
     uint8_t* tailAt = head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256) + 7 * alignUp(size_t(n) * 4, 256);
     uint32_t* tail = reinterpret_cast<uint32_t*>(tailAt);            // TW_*
-    uint32_t* perEntry = reinterpret_cast<uint32_t*>(tailAt + 256);  // [64]
+    uint32_t* perEntry = T.dPlanWords;                               // [64] (then firstOf[64], shadow[64][64]: one block, one copy back)
     uint64_t* masks = reinterpret_cast<uint64_t*>(tailAt + 512);
 
     const uint32_t gridAll = (n + kGrokPlanBlock - 1) / kGrokPlanBlock;
@@ -565,7 +568,23 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     const bool small = n <= smallBatch;
     uint32_t* order = reinterpret_cast<uint32_t*>(head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256));
     uint32_t* orderWork = reinterpret_cast<uint32_t*>(tailAt + 512 + alignUp(size_t(n) * 8, 256));  // work words behind the masks
-    HIP_TRY(hipMemsetAsync(tailAt, 0, 512, st));
+    {   // everything the batch needs cleared, in one launch (round 6: seven hipMemsetAsync calls between the kernels of phase 1)
+        GrokInitJobs J{};
+        auto fill = [&](void* p, size_t bytes, uint32_t value) {
+            J.p[J.n] = static_cast<uint32_t*>(p);
+            J.words[J.n] = uint32_t(bytes / 4);
+            J.value[J.n] = value;
+            ++J.n;
+        };
+        fill(tailAt, 512, 0u);
+        fill(T.dPlanWords, size_t(kPlanWords) * 4, 0u);
+        fill(winner, size_t(n) * 8, 0xFFFFFFFFu);
+        fill(d_first, size_t(n) * row * 4, 0xFFFFFFFFu);
+        fill(d_nextra, 4, 0u);
+        fill(T.dCnt, size_t(64) * GC_WORDS * 4, 0u);
+        const uint32_t most = uint32_t(std::max(size_t(n) * 2, size_t(n) * row));
+        hipLaunchKernelGGL(grok_init_kernel, dim3(std::min(2048u, (most + kGrokPlanBlock - 1) / kGrokPlanBlock)), dim3(kGrokPlanBlock), 0, st, J);
+    }
     {
         int rc = lcLengthOrderOnStream(d_off, d_len, 0, n, orderWork, order, st);
         if (rc != LC_OK) return rc;
@@ -653,17 +672,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             fprintf(stderr, "grok plan 1: %u big screens in a launch of their own (%u KB of LDS per workgroup)\n", nBig,
                     unsigned((size_t(sliceLen) * 4 + state->bigScreenLdsBytes[dev]) >> 10));
     }
-    uint32_t* firstOf = orderWork + 512;  // [64]
-    HIP_TRY(hipMemsetAsync(firstOf, 0, 256, st));
-    HIP_TRY(hipMemsetAsync(T.dShadow, 0, 64 * 64 * 4, st));
-    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry, firstOf, T.dShadow);
+    uint32_t* firstOf = T.dPlanWords + 64;   // [64]
+    uint32_t* shadowBy = T.dPlanWords + 128;  // [64][64]
+    hipLaunchKernelGGL(grok_count_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, perEntry, firstOf, shadowBy);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CAND, perEntry, 256, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_FIRST, firstOf, 256, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_SHADOW, T.dShadow, 64 * 64 * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemsetAsync(winner, 0xFF, size_t(n) * 8, st));
-    HIP_TRY(hipMemsetAsync(d_first, 0xFF, size_t(n) * row * 4, st));
-    HIP_TRY(hipMemsetAsync(d_nextra, 0, 4, st));
+    HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CAND, T.dPlanWords, size_t(kPlanWords) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(syncCounted(st));  // sync 1: candidates per entry
     const double tPhase1 = msNow();
 
@@ -844,8 +857,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     if (nAct) {
         HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(T.dRemScreens, T.hostRemScreens, nAct * sizeof(GrokScreenDev), hipMemcpyHostToDevice, st));
-        (void)nRemScreens;
-        HIP_TRY(hipMemsetAsync(T.dCnt, 0, size_t(nAct) * GC_WORDS * 4, st));
+        (void)nRemScreens;  // (dCnt: cleared by grok_init_kernel at the start of the batch)
         hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries,
                            static_cast<const uint32_t*>(order));
         HIP_TRY(hipGetLastError());

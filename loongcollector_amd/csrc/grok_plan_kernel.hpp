@@ -89,6 +89,19 @@ struct GrokSlotMap {
     int8_t activeOfBit[64];  // Match index -> index into the GrokEntryDev table (-1: not active)
 };
 
+// ---- every buffer a batch needs cleared, in ONE launch at its start (round 6: they were seven hipMemsetAsync calls strewn over phase 1,
+// each a dispatch of its own between the kernels that matter)
+struct GrokInitJobs {
+    uint32_t* p[8];
+    uint32_t words[8];
+    uint32_t value[8];
+    uint32_t n;
+};
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_init_kernel(GrokInitJobs J) {
+    for (uint32_t j = 0; j < J.n; ++j)
+        for (uint32_t i = blockIdx.x * kGrokPlanBlock + threadIdx.x; i < J.words[j]; i += gridDim.x * kGrokPlanBlock) J.p[j][i] = J.value[j];
+}
+
 // no literal index for this list (fewer than two literals): every entry is a candidate for every value
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_mask_fill_kernel(uint64_t* __restrict__ masks, uint32_t n, uint64_t all) {
     const uint32_t i = blockIdx.x * kGrokPlanBlock + threadIdx.x;
