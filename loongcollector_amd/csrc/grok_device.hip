@@ -350,7 +350,11 @@ enum { HW_CAND = 0, HW_FIRST = 64, HW_SHADOW = 128, HW_TAIL = 128 + 64 * 64, HW_
        HW_WORDS = 192 + 64 * 64 + 64 * GC_WORDS };
 constexpr uint32_t kPlanWords = 64 + 64 + 64 * 64;  // device: candidates per entry | first-candidate counts | who shadows whom
 // device tail words (scratch `counters`): [0] gate  [1] xcount (extra rows wanted in xtmp)
-enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16 };
+// [16] a copy of the caller's nextra word (grok_commit_extra_kernel counts into both)
+enum { TW_GATE = 0, TW_XCOUNT = 1, TW_WORDS = 16, TW_NEXTRA = 16 };
+static_assert(HW_CNT - HW_TAIL == 64, "hostWords[HW_TAIL ..] mirrors the device block dTail | dCnt");
+
+constexpr size_t kEntryBlockBytes = 64 * sizeof(GrokEntryDev) + 64 * sizeof(GrokScreenDev);
 
 struct PlanThread {
     int device = -1;
@@ -358,9 +362,12 @@ struct PlanThread {
     hipEvent_t fork = nullptr, join[kGrokMaxStreams] = {};
     hipEvent_t tick[2 * 64 + 2 * 64] = {};  // calibration batches: [2a begin/end per entry | 2c begin/end per entry], created on first use
     uint32_t* hostWords = nullptr;        // pinned, HW_*
-    GrokEntryDev* hostEntries = nullptr;  // pinned [64]
-    GrokEntryDev* dEntries = nullptr;     // device [64]
-    uint32_t* dCnt = nullptr;             // device [64][GC_WORDS]
+    // (round 6: the entry table and the remainder screens are ONE pinned block and ONE device block -- one copy per batch;
+    // the tail words and the entries' counters likewise, mirrored by hostWords[HW_TAIL ..] -- one copy back per host synchronisation)
+    GrokEntryDev* hostEntries = nullptr;  // pinned [64], then hostRemScreens
+    GrokEntryDev* dEntries = nullptr;     // device [64], then dRemScreens
+    uint32_t* dTail = nullptr;            // device [64] tail words (TW_*), then dCnt
+    uint32_t* dCnt = nullptr;             // device [64][GC_WORDS] (inside dTail's block)
     GrokScreenDev* hostRemScreens = nullptr;  // pinned [64]: per ACTIVE entry, its screen (blob == nullptr: none)
     GrokScreenDev* dRemScreens = nullptr;     // device [64]
     uint32_t* dPlanWords = nullptr;           // device [kPlanWords]: perEntry[64] | firstOf[64] | shadow[64][64] (candidates of entry p whose
@@ -388,9 +395,7 @@ struct PlanThread {
                 if (hostWords) (void)hipHostFree(hostWords);
                 if (hostEntries) (void)hipHostFree(hostEntries);
                 if (dEntries) (void)hipFree(dEntries);
-                if (dCnt) (void)hipFree(dCnt);
-                if (hostRemScreens) (void)hipHostFree(hostRemScreens);
-                if (dRemScreens) (void)hipFree(dRemScreens);
+                if (dTail) (void)hipFree(dTail);
                 if (dPlanWords) (void)hipFree(dPlanWords);
                 if (hostJobs) (void)hipHostFree(hostJobs);
                 if (dJobs) (void)hipFree(dJobs);
@@ -405,6 +410,7 @@ struct PlanThread {
         hostWords = nullptr;
         hostEntries = nullptr;
         dEntries = nullptr;
+        dTail = nullptr;
         dCnt = nullptr;
         hostRemScreens = nullptr;
         dRemScreens = nullptr;
@@ -422,11 +428,13 @@ struct PlanThread {
             device = dev;
             HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostWords), HW_WORDS * 4, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostEntries), 64 * sizeof(GrokEntryDev), hipHostMallocDefault));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dEntries), 64 * sizeof(GrokEntryDev)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dCnt), 64 * GC_WORDS * 4));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostRemScreens), 64 * sizeof(GrokScreenDev), hipHostMallocDefault));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dRemScreens), 64 * sizeof(GrokScreenDev)));
+            static_assert((64 * sizeof(GrokEntryDev)) % alignof(GrokScreenDev) == 0, "the remainder screens sit behind the entry table");
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hostEntries), kEntryBlockBytes, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dEntries), kEntryBlockBytes));
+            hostRemScreens = reinterpret_cast<GrokScreenDev*>(hostEntries + 64);
+            dRemScreens = reinterpret_cast<GrokScreenDev*>(dEntries + 64);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dTail), (64 + 64 * GC_WORDS) * 4));
+            dCnt = dTail + 64;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dPlanWords), kPlanWords * 4));
             HIP_TRY(hipHostMalloc(&hostJobs, lcWaveJobTableBytes(), hipHostMallocDefault));
             HIP_TRY(hipMalloc(&dJobs, lcWaveJobTableBytes()));
@@ -553,7 +561,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
     uint32_t* winner = reinterpret_cast<uint32_t*>(head);
     uint32_t* undecided = winner + n;
     uint8_t* tailAt = head + alignUp(size_t(n) * row * 4, 256) + alignUp(n, 256) + 7 * alignUp(size_t(n) * 4, 256);
-    uint32_t* tail = reinterpret_cast<uint32_t*>(tailAt);            // TW_*
+    uint32_t* tail = T.dTail;                                        // TW_* (the entries' counters behind them: one block, one copy back)
     uint32_t* perEntry = T.dPlanWords;                               // [64] (then firstOf[64], shadow[64][64]: one block, one copy back)
     uint64_t* masks = reinterpret_cast<uint64_t*>(tailAt + 512);
 
@@ -576,12 +584,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             J.value[J.n] = value;
             ++J.n;
         };
-        fill(tailAt, 512, 0u);
+        fill(T.dTail, size_t(64 + 64 * GC_WORDS) * 4, 0u);
         fill(T.dPlanWords, size_t(kPlanWords) * 4, 0u);
         fill(winner, size_t(n) * 8, 0xFFFFFFFFu);
         fill(d_first, size_t(n) * row * 4, 0xFFFFFFFFu);
         fill(d_nextra, 4, 0u);
-        fill(T.dCnt, size_t(64) * GC_WORDS * 4, 0u);
         const uint32_t most = uint32_t(std::max(size_t(n) * 2, size_t(n) * row));
         hipLaunchKernelGGL(grok_init_kernel, dim3(std::min(2048u, (most + kGrokPlanBlock - 1) / kGrokPlanBlock)), dim3(kGrokPlanBlock), 0, st, J);
     }
@@ -834,14 +841,13 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         }
         hipLaunchKernelGGL(grok_resolve_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, n, winner, undecided, d_pattern, g);
         if (nAct) {
-            hipLaunchKernelGGL(grok_commit_kernel, dim3(gridCand, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, d_pattern, d_first, row, g);
-            hipLaunchKernelGGL(grok_commit_extra_kernel, dim3(64), dim3(kGrokPlanBlock), 0, st, xtmp, xcount, xcap, xstride, T.dEntries, map,
-                               d_pattern, d_extra, extraCap, row, d_nextra, g);
+            // (row nAct of the grid: the extra rows of the winners -- grok_commit_extra_kernel's launch until round 6)
+            hipLaunchKernelGGL(grok_commit_kernel, dim3(std::max(gridCand, 64u), nAct + 1), dim3(kGrokPlanBlock), 0, st, T.dEntries, nAct, d_pattern,
+                               d_first, row, g, xtmp, xcount, xcap, xstride, map, d_extra, extraCap, d_nextra, tail + TW_NEXTRA);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, tail, TW_WORDS * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL + TW_WORDS, d_nextra, 4, hipMemcpyDeviceToHost, st));
-        if (nAct) HIP_TRY(hipMemcpyAsync(T.hostWords + HW_CNT, T.dCnt, size_t(nAct) * GC_WORDS * 4, hipMemcpyDeviceToHost, st));
+        // (tail words, the copy of nextra among them, and the entries' counters: one block)
+        HIP_TRY(hipMemcpyAsync(T.hostWords + HW_TAIL, T.dTail, (64 + size_t(nAct) * GC_WORDS) * 4, hipMemcpyDeviceToHost, st));
         if (tlsTail.armed) {
             HIP_TRY(hipMemcpyAsync(tlsTail.hPattern, d_pattern, size_t(n) * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(tlsTail.hFirst, d_first, size_t(n) * row * 4, hipMemcpyDeviceToHost, st));
@@ -849,14 +855,14 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         HIP_TRY(syncCounted(st));
         if (tlsTail.armed) {
             tlsTail.done = true;
-            tlsTail.nextra = T.hostWords[HW_TAIL + TW_WORDS];
+            tlsTail.nextra = T.hostWords[HW_TAIL + TW_NEXTRA];
         }
         return LC_OK;
     };
     bool finished = false;  // finishAll has run (phase 2 ended with it: see the end of phase 2c)
     if (nAct) {
-        HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, nAct * sizeof(GrokEntryDev), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(T.dRemScreens, T.hostRemScreens, nAct * sizeof(GrokScreenDev), hipMemcpyHostToDevice, st));
+        // (the entry table and, behind it, the remainder screens: one block)
+        HIP_TRY(hipMemcpyAsync(T.dEntries, T.hostEntries, 64 * sizeof(GrokEntryDev) + nAct * sizeof(GrokScreenDev), hipMemcpyHostToDevice, st));
         (void)nRemScreens;  // (dCnt: cleared by grok_init_kernel at the start of the batch)
         hipLaunchKernelGGL(grok_scatter_kernel, dim3(gridAll), dim3(kGrokPlanBlock), 0, st, masks, n, nP, d_off, d_len, map, T.dEntries,
                            static_cast<const uint32_t*>(order));
@@ -875,10 +881,24 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         for (size_t a = 0; a < nAct; ++a) byCost[a] = a;
         std::sort(byCost.begin(), byCost.end(), [&](size_t x, size_t y) { return act[x].cost > act[y].cost; });
         const uint32_t used = std::min<uint32_t>(nStreams, nAct);
+        // (round 6) A worker stream waits for the fork when it first GETS work (W), and only the streams that got any are joined: a
+        // phase forks into sixteen streams and usually uses three, and the thirteen idle ones cost the host 26 calls per fork / join
+        // and the batch's stream thirteen barrier packets that it works through one after the other (0.09 ms between the end of round
+        // 0 and the first kernel behind the join, profiles/round6_grok_timeline.txt).
+        uint32_t waitedMask = 0, touchedMask = 0;
         auto fork = [&]() -> int {
             HIP_TRY(hipEventRecord(T.fork, st));
-            for (uint32_t s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(T.workers[s], T.fork, 0));
+            waitedMask = 0;  // (everybody waits for THIS fork from now on; what was touched before stays to be joined)
             return LC_OK;
+        };
+        auto W = [&](int s) -> hipStream_t {  // (a failure surfaces at the join: hipGetLastError)
+            const uint32_t bit = 1u << uint32_t(s);
+            if (!(waitedMask & bit)) {
+                (void)hipStreamWaitEvent(T.workers[s], T.fork, 0);
+                waitedMask |= bit;
+            }
+            touchedMask |= bit;
+            return T.workers[s];
         };
         auto join = [&](int rc) -> int {
             lcSetDecideSlot(0);
@@ -888,9 +908,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 return rc;
             }
             for (uint32_t s = 0; s < used; ++s) {
+                if (!((touchedMask >> s) & 1u)) continue;
                 HIP_TRY(hipEventRecord(T.join[s], T.workers[s]));
                 HIP_TRY(hipStreamWaitEvent(st, T.join[s], 0));
             }
+            touchedMask = 0;
             return LC_OK;
         };
         auto readCounts = [&]() -> int {
@@ -947,6 +969,13 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         const bool screenWave = small && envInt("LC_GROK_SCREEN_WAVE", 0) != 0;  // remainder screens: one slot per wavefront (grokScreenWalkWave; off: see phase 1)
         const uint32_t remWalk = (screenWave ? 16u : 0u) | (envInt("LC_GROK_SCREEN_SCALED", 1) != 0 ? 32u : 0u);
         auto remGrid = [&](uint32_t slots) { return screenWave ? (slots + kGrokRemWaveSlots - 1) / kGrokRemWaveSlots : (slots + kGrokPlanBlock - 1) / kGrokPlanBlock; };
+        // (round 5) the host reads the survivors of the remainder screens together with the finish of the batch (three synchronisations
+        // instead of four: see the end of phase 2c).  Round 6: the screens count their survivors onto the gate word themselves.
+        const bool lazy = envInt("LC_GROK_LAZY_SYNC3", 1) != 0;
+        uint32_t* remGate = lazy ? gate : nullptr;
+        // (round 6) the remainder screens of the entries round 0 leaves nothing else to do for are queued BEFORE the host reads round 0's
+        // counts, on a stream beside it (the kernels test the entry's overflow / unanchored counts themselves): see phase 2b
+        const bool remainderAhead = remainderInChain && envInt("LC_GROK_REMAINDER_AHEAD", 1) != 0;
         const bool postInStream = envInt("LC_GROK_POST_IN_STREAM", 1) != 0;    // round 0's post step behind each entry's kernel, on its stream
         const bool bigRemainder = envInt("LC_GROK_BIG_REMAINDER", 0) != 0;      // an entry with a BIG screen stages it for its remainder screen (measured: slower)
         // An entry whose values needed more than 64 threads in recent batches (GC_WIDE, noted behind the batch) goes WIDE FIRST: its
@@ -1027,18 +1056,22 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             int rc = LC_OK;
             if (others) rc = fork();
             if (rc != LC_OK) return rc;
-            hipStream_t fusedStream = others ? T.workers[0] : st;
+            hipStream_t fusedStream = others ? W(0) : st;
             if (!jobs.empty()) {
                 rc = lcLaunchWaveJobs(d_data, jobs.data(), uint32_t(jobs.size()), blocks, ldsMax, T.hostJobs, T.dJobs, dev, fusedStream);
-                // the post step of the fused entries: one launch per run of neighbours in the entry table (usually one run)
-                for (size_t k = 0; k < jobEntry.size() && rc == LC_OK;) {
-                    size_t k2 = k + 1;
-                    uint32_t most = act[jobEntry[k]].cand;
-                    while (k2 < jobEntry.size() && jobEntry[k2] == jobEntry[k2 - 1] + 1) most = std::max(most, act[jobEntry[k2++]].cand);
-                    hipLaunchKernelGGL(grok_post_kernel, dim3((most + kGrokPlanBlock - 1) / kGrokPlanBlock, uint32_t(k2 - k)), dim3(kGrokPlanBlock), 0,
-                                       fusedStream, T.dEntries, uint32_t(jobEntry[k]), static_cast<const uint32_t*>(nullptr),
-                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
-                    k = k2;
+                // the post step of the fused entries: ONE launch over their span of the entry table (the entries in between that are not
+                // the fused launch's leave at once: skip mask)
+                if (rc == LC_OK) {
+                    const size_t lo = jobEntry.front(), hi = jobEntry.back();
+                    unsigned long long skip = 0;
+                    uint32_t most = 0;
+                    for (size_t a = lo; a <= hi; ++a) {
+                        if (fused[a]) most = std::max(most, act[a].cand);
+                        else skip |= 1ull << a;
+                    }
+                    hipLaunchKernelGGL(grok_post_kernel, dim3((most + kGrokPlanBlock - 1) / kGrokPlanBlock, uint32_t(hi - lo + 1)), dim3(kGrokPlanBlock), 0,
+                                       fusedStream, T.dEntries, uint32_t(lo), static_cast<const uint32_t*>(nullptr),
+                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount, skip);
                 }
                 if (trace) fprintf(stderr, "grok plan 2a: %zu entries in one launch (%u workgroups, %u B of LDS)\n", jobs.size(), blocks, ldsMax);
             }
@@ -1052,15 +1085,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 lc_regex* first = gp.anchored ? gp.anchored : gp.re;
                 e.wideFirst = wantsWideFirst(first);
                 // (failures inside the forked region become rc: the workers are always joined below)
-                if (calibrate && hipEventRecord(T.tick[2 * a], T.workers[e.stream]) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
-                if (rc == LC_OK) rc = runFirst(e, first, e.wideFirst, nullptr, nullptr, !gp.anchored, &e.seq0, T.workers[e.stream]);
-                if (calibrate) (void)hipEventRecord(T.tick[2 * a + 1], T.workers[e.stream]);
+                if (calibrate && hipEventRecord(T.tick[2 * a], W(e.stream)) != hipSuccess) rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
+                if (rc == LC_OK) rc = runFirst(e, first, e.wideFirst, nullptr, nullptr, !gp.anchored, &e.seq0, W(e.stream));
+                if (calibrate) (void)hipEventRecord(T.tick[2 * a + 1], W(e.stream));
                 // (round 5) the entry's post step right behind its kernel: the one launch for all entries behind the join (0.12 ms) waited
                 // for the slowest entry and then stood between it and the host's read of the counts
                 if (rc == LC_OK && postInStream)
                     hipLaunchKernelGGL(grok_post_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0,
-                                       T.workers[e.stream], T.dEntries, uint32_t(a), static_cast<const uint32_t*>(nullptr),
-                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
+                                       W(e.stream), T.dEntries, uint32_t(a), static_cast<const uint32_t*>(nullptr),
+                                       static_cast<const uint32_t*>(nullptr), uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount, 0ull);
                 if (trace)
                     fprintf(stderr, "grok plan 2a: entry %u cand %u stream %d engine %s%s%s positions %zu slots %d atomic %d | measured round 0 %.3f ms, leftovers %.3f ms\n",
                             e.p, e.cand, e.stream, first->engine == LC_ENGINE_NFA ? "nfa" : first->hasTdfa ? "tdfa-lds" : "tdfa-l2",
@@ -1080,7 +1113,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 if (!fused[a])
                     hipLaunchKernelGGL(grok_post_kernel, dim3((act[a].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0, st,
                                        T.dEntries, a, static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
-                                       uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount);
+                                       uint32_t(GP_ANCHORED_PASS), xtmp, xcap, xstride, xcount, 0ull);
         uint32_t maxLevel = 0;
         for (size_t a = 0; a < nAct; ++a) maxLevel = std::max(maxLevel, act[a].level);
         // the values won so far, and for the entries of level >= 1 how many of their slots are still open: an entry all of whose
@@ -1097,6 +1130,49 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // leftovers of level 0, queued BEFORE the host reads round 0's counts.  The device has them earlier, but a batch is bound by
         // the rate at which the host can queue launches, and the extra, mostly empty chains cost more than the earlier start gained:
         // 16 Ki values 4.76 -> 5.4 ms, 1000 values 3.9 -> 5.2 ms.)
+        // (round 6) The remainder screens, AHEAD of the host's read of round 0's counts.  Round 5 queued them behind it -- the entries
+        // with nothing else to do in phase 2c in one launch pair at the fork -- and that pair (0.5 ms: a few thousand remainders of up to
+        // 4 KiB, one lane each) started 0.16 ms after round 0 had ended: a copy, a host round trip and the host's planning of phase 2c
+        // (profiles/round6_grok_timeline.txt).  Which entries those are is a test of two counters the device has: the launch pair goes out
+        // now, on a worker stream beside the copy, and leaves the entries with overflowed or unanchored slots (and the shadowed ones, and
+        // the ones whose search rounds their history queues ahead: `skip`) to their chains.  LC_GROK_REMAINDER_AHEAD=0: as before.
+        // (an entry's search rounds are queued ahead by its history; decided ONCE per batch -- another runner thread's batch on the same
+        // handle may rewrite that history between here and phase 2c)
+        std::vector<char> earlyOf(nAct, 0);
+        for (size_t a = 0; a < nAct; ++a) {
+            const GrokDevicePattern& gp = patterns[act[a].p];
+            earlyOf[a] = (earlyRoundsMode && act[a].rounds >= 2 && gp.re->engine == LC_ENGINE_TDFA &&
+                          (earlyRoundsMode >= 2 || (!calibrate && gp.re->grokRemainderSeen.load(std::memory_order_relaxed) != 0))) ? 1 : 0;
+        }
+        bool aheadLaunched = false;
+        if (remainderAhead && nLevel0) {
+            unsigned long long skip = 0;
+            uint32_t most = 0, ldsAhead = 0;
+            for (size_t a = 0; a < nAct; ++a) {
+                if (act[a].level || earlyOf[a]) skip |= 1ull << a;
+                else {
+                    most = std::max(most, act[a].cand);
+                    if (act[a].remainderScreen) ldsAhead = std::max(ldsAhead, act[a].remainderScreen->ldsBytes);
+                }
+            }
+            if (most) {
+                if (!boundKnown)  // the values won so far (the literal pass drops the slots of values an earlier entry has won)
+                    hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
+                                       static_cast<const uint32_t*>(nullptr), 0u);
+                {
+                    int rcFork = fork();
+                    if (rcFork != LC_OK) return rcFork;
+                }
+                hipStream_t gs = W(int(used) - 1);
+                if (remainderLiteral || remainderWon)
+                    hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((most + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct), dim3(kGrokPlanBlock),
+                                       0, gs, d_data, T.dEntries, remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), skip,
+                                       remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 1u);
+                hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(most), nAct), dim3(kGrokPlanBlock), small ? ldsAhead : 0, gs, d_data, T.dEntries,
+                                   static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk | 64u, skip, remGate);
+                aheadLaunched = true;
+            }
+        }
         HIP_TRY(hipGetLastError());
         {
             int rc = readCounts();  // sync 2
@@ -1137,12 +1213,6 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         unsigned long long earlyMask = 0;  // active entries whose rounds were queued in this phase
         unsigned long long coveredMask = 0;  // ... whose remainder screens were
         unsigned long long groupMask = 0;    // ... of those, the entries of level 0 that have nothing else to do in this phase
-        auto wantsEarlyRounds = [&](const PlanEntry& e) {
-            const GrokDevicePattern& gp = patterns[e.p];
-            if (!earlyRoundsMode || e.rounds < 2 || gp.re->engine != LC_ENGINE_TDFA) return false;
-            if (earlyRoundsMode >= 2) return true;
-            return !calibrate && gp.re->grokRemainderSeen.load(std::memory_order_relaxed) != 0;
-        };
         // rounds 1 .. of entry a (FindNextMatch from the end of the previous match; the list lengths stay on the device), one step per
         // round.  screened: round 1 reads the survivors of the remainder screen (phase 2e); else every slot in play (queued ahead)
         auto roundSteps = [&](size_t a, bool screened, std::vector<Step>& out) {
@@ -1153,7 +1223,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (rc != LC_OK) return;
                     PlanEntry& e = act[a];
                     const GrokDevicePattern& gp = patterns[e.p];
-                    hipStream_t ws = T.workers[e.stream];
+                    hipStream_t ws = W(e.stream);
                     lcSetDecideSlot(1 + e.stream);
                     const uint32_t grid = (e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock;
                     const uint32_t* list = r == 1 ? (screened ? e.unanchored : e.listA) : (r & 1) ? e.listA : e.listB;
@@ -1172,7 +1242,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             const uint32_t level = e0.level;
             const uint32_t ov = level ? 0u : cnt(a, GC_OVERFLOW);
             const uint32_t un = level ? 0u : cnt(a, GC_UNANCHORED);
-            const bool early = wantsEarlyRounds(e0);
+            const bool early = earlyOf[a] != 0;
             // (round 0 left slots in play: their remainders are screened at the end of this chain, see remainderSteps)
             const bool inPlay0 = remainderInChain && !level && cnt(a, GC_ROUND0) != 0;
             if (!level && !ov && !un && !early && !inPlay0) return;
@@ -1202,7 +1272,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     chains[owner].push_back([&, a, sa](int& rc) {
                         if (rc != LC_OK) return;
                         hipLaunchKernelGGL(grok_entry_finish_kernel, dim3((act[sa].cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock),
-                                           0, T.workers[act[a].stream], T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
+                                           0, W(act[a].stream), T.dEntries, winner, undecided, static_cast<const uint32_t*>(nullptr), uint32_t(sa));
                     });
                 }
             }
@@ -1214,12 +1284,12 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             }
             auto post = [&, a](const uint32_t* in, const uint32_t* inCount, uint32_t flags) {
                 PlanEntry& e = act[a];
-                hipLaunchKernelGGL(grok_post_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0, T.workers[e.stream],
-                                   T.dEntries, uint32_t(a), in, inCount, flags, xtmp, xcap, xstride, xcount);
+                hipLaunchKernelGGL(grok_post_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock, 1), dim3(kGrokPlanBlock), 0, W(e.stream),
+                                   T.dEntries, uint32_t(a), in, inCount, flags, xtmp, xcap, xstride, xcount, 0ull);
             };
             auto tick = [&, a](int which, int& rc) {
                 if (!calibrate || !busy2c[a]) return;
-                if (hipEventRecord(T.tick[2 * nAct + 2 * a + size_t(which)], T.workers[act[a].stream]) != hipSuccess && rc == LC_OK && which == 0)
+                if (hipEventRecord(T.tick[2 * nAct + 2 * a + size_t(which)], W(act[a].stream)) != hipSuccess && rc == LC_OK && which == 0)
                     rc = lcHipFail(hipGetLastError(), "hipEventRecord(calibration)");
             };
             // the search proper over the slots in `list`, minus the values an earlier entry has won: two steps
@@ -1228,7 +1298,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (rc != LC_OK) return;
                     PlanEntry& e = act[a];
                     const GrokDevicePattern& gp = patterns[e.p];
-                    hipStream_t ws = T.workers[e.stream];
+                    hipStream_t ws = W(e.stream);
                     lcSetDecideSlot(1 + e.stream);
                     hipLaunchKernelGGL(grok_filter_won_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, ws, e.dev,
                                        static_cast<const uint32_t*>(winner), list, count, e.listB, e.dev.cnt + GC_FILTERED);
@@ -1239,7 +1309,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     PlanEntry& e = act[a];
                     const GrokDevicePattern& gp = patterns[e.p];
                     lcSetDecideSlot(1 + e.stream);
-                    rc = runSecond(e, gp.re, false, e.dev.cnt + GC_FILTERED, e.listB, true, e.seqS, nullptr, T.workers[e.stream]);
+                    rc = runSecond(e, gp.re, false, e.dev.cnt + GC_FILTERED, e.listB, true, e.seqS, nullptr, W(e.stream));
                     if (rc == LC_OK) post(e.listB, e.dev.cnt + GC_FILTERED, uint32_t(GP_OVERFLOW_FINAL));
                 });
             };
@@ -1253,7 +1323,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                         lc_regex* first = gp.anchored ? gp.anchored : gp.re;
                         lcSetDecideSlot(1 + e.stream);
                         rc = runSecond(e, first, e.wideFirst, e.dev.cnt + GC_OVERFLOW, e.dev.ovList, !gp.anchored, e.seq0, e.dev.cnt + GC_WIDE,
-                                       T.workers[e.stream]);
+                                       W(e.stream));
                     });
                     out.push_back([&, a, post](int& rc) {
                         if (rc != LC_OK) return;
@@ -1272,7 +1342,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (rc != LC_OK) return;
                     PlanEntry& e = act[a];
                     const GrokDevicePattern& gp = patterns[e.p];
-                    hipStream_t ws = T.workers[e.stream];
+                    hipStream_t ws = W(e.stream);
                     lcSetDecideSlot(1 + e.stream);
                     uint32_t* mine = e.dev.ovList;  // (a level > 0 entry has no first-chance pass: its overflow list is free)
                     hipLaunchKernelGGL(grok_filter_won_kernel, dim3((e.cand + kGrokPlanBlock - 1) / kGrokPlanBlock), dim3(kGrokPlanBlock), 0, ws, e.dev,
@@ -1289,7 +1359,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     lc_regex* first = gp.anchored ? gp.anchored : gp.re;
                     lcSetDecideSlot(1 + e.stream);
                     rc = runSecond(e, first, e.wideFirst, e.dev.cnt + GC_OVERFLOW, e.dev.ovList, !gp.anchored, e.seq0, e.dev.cnt + GC_WIDE,
-                                   T.workers[e.stream]);
+                                   W(e.stream));
                     if (rc == LC_OK) post(e.dev.ovList, e.dev.cnt + GC_OVERFLOW, uint32_t(GP_ANCHORED_PASS | GP_OVERFLOW_FINAL));
                 });
                 if (patterns[e0.p].anchored) searchProperSteps(e0.dev.unanchored, e0.dev.cnt + GC_UNANCHORED);
@@ -1307,14 +1377,14 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 out.push_back([&, a](int& rc) {
                     if (rc != LC_OK) return;
                     PlanEntry& e = act[a];
-                    hipStream_t ws = T.workers[e.stream];
+                    hipStream_t ws = W(e.stream);
                     // (grid.y = 1 over a table that begins at this entry)
                     const GrokEntryDev* mine = static_cast<const GrokEntryDev*>(T.dEntries) + a;
                     if (remainderLiteral || remainderWon)
                         hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((e.cand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), 1),
                                            dim3(kGrokPlanBlock), 0, ws, d_data, mine,
                                            remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), 0ull,
-                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
+                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 0u);
                     const GrokScreenDev* sc = e.remainderScreen;
                     const bool big = small && bigRemainder && sc && sc->bigBytes;
                     const uint32_t lds = big ? sc->bigBytes : (small && sc) ? sc->ldsBytes : 0u;
@@ -1330,7 +1400,8 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                         }
                     }
                     hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(e.cand), 1), dim3(kGrokPlanBlock), lds, ws,
-                                       d_data, mine, static_cast<const GrokScreenDev*>(T.dRemScreens) + a, (big ? 2u : small ? 1u : 0u) | remWalk, 0ull);
+                                       d_data, mine, static_cast<const GrokScreenDev*>(T.dRemScreens) + a, (big ? 2u : small ? 1u : 0u) | remWalk, 0ull,
+                                       remGate);
                 });
             }
         };
@@ -1345,22 +1416,22 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (act[order1[i]].level == level) buildChain(order1[i]);
             size_t longest = 0;
             for (size_t a = 0; a < nAct; ++a) longest = std::max(longest, chains[a].size());
-            if (longest || groupMask) {
-                if (!boundKnown)
+            if (longest || groupMask || aheadLaunched) {
+                if (!boundKnown && !aheadLaunched)
                     hipLaunchKernelGGL(grok_entry_finish_kernel, dim3(gridCand0, nAct), dim3(kGrokPlanBlock), 0, st, T.dEntries, winner, undecided,
                                        static_cast<const uint32_t*>(nullptr), 0u);  // the values won so far (atomicMin per value: idempotent, finishAll runs it again)
                 rc2c = fork();
                 if (rc2c != LC_OK) return rc2c;
                 forked = true;
-                if (groupMask) {  // the entries that only have remainders to screen: one launch pair, beside the chains
-                    hipStream_t gs = T.workers[used - 1];
+                if (groupMask && !aheadLaunched) {  // the entries that only have remainders to screen: one launch pair, beside the chains
+                    hipStream_t gs = W(int(used) - 1);
                     if (remainderLiteral || remainderWon)
                         hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((maxCand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct),
                                            dim3(kGrokPlanBlock), 0, gs, d_data, T.dEntries,
                                            remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), ~groupMask,
-                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
+                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 0u);
                     hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, gs, d_data,
-                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, ~groupMask);
+                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, ~groupMask, remGate);
                 }
                 if (breadthFirst) {
                     for (size_t k = 0; k < longest; ++k)
@@ -1387,7 +1458,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             lcNoteKernel("grok_remainder_literal_kernel");
             hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((maxCand + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct), dim3(kGrokPlanBlock),
                                0, st, d_data, T.dEntries, remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), earlyMask,
-                               remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr));
+                               remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 0u);
         }
         lcNoteKernel("grok_remainder_all_kernel");
         {
@@ -1414,11 +1485,11 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 HIP_TRY(hipEventRecord(T.fork, st));
                 HIP_TRY(hipStreamWaitEvent(T.workers[0], T.fork, 0));
                 hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), bigLds, T.workers[0], d_data, T.dEntries,
-                                   static_cast<const GrokScreenDev*>(T.dRemScreens), 2u | remWalk, ~bigMask);
+                                   static_cast<const GrokScreenDev*>(T.dRemScreens), 2u | remWalk, ~bigMask, remGate);
                 HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
             }
             hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(maxCand), nAct), dim3(kGrokPlanBlock), small ? remScreenLds : 0, st, d_data, T.dEntries,
-                               static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, earlyMask | bigMask);
+                               static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk, earlyMask | bigMask, remGate);
             if (bigMask) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
         }
         }
@@ -1427,7 +1498,6 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         // to learn that.  A one-wave kernel adds the survivors to the gate word, the finish of the batch is queued behind it (it returns at
         // once if the gate is up), and the host reads everything in ONE round trip: gate down = done (three host synchronisations per batch
         // instead of four); gate up = the search rounds of the entries with survivors, then the finish again.  LC_GROK_LAZY_SYNC3=0: as before.
-        const bool lazy = envInt("LC_GROK_LAZY_SYNC3", 1) != 0;
         auto afterCounts = [&] {
             if (calibrate)
                 for (size_t a = 0; a < nAct; ++a)
@@ -1473,7 +1543,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
             rc = rounds2e(ran);
             if (rc != LC_OK) return rc;
         } else {
-            hipLaunchKernelGGL(grok_survivor_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const GrokEntryDev*>(T.dEntries), nAct, gate, 1u);
+            // (the survivors are on the gate word already: grok_remainder_all_kernel counts them there)
             int rc = finishAll(gate);  // sync 3 = the last one, unless the gate is up
             if (rc != LC_OK) return rc;
             finished = true;
@@ -1568,7 +1638,7 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         fprintf(stderr, "grok plan: n %u entries %u (second pass %u) pairs %u screens %u | phase1 %.3f ms, entries+finish %.3f ms, total %.3f ms, syncs %u, deferred %u\n",
                 n, nAct, nSecond, stats.pairs, nScreens, tPhase1, tPhase3 - tPhase1, msNow(), stats.hostSyncs, stats.deferredEntries);
     const uint32_t xWanted = T.hostWords[HW_TAIL + TW_XCOUNT];
-    const uint32_t nextra = T.hostWords[HW_TAIL + TW_WORDS];
+    const uint32_t nextra = T.hostWords[HW_TAIL + TW_NEXTRA];
     if (xWanted > xcap) {
         // the temporary rows themselves did not fit: report an upper bound of what is needed (winners' rows <= all rows)
         HIP_TRY(hipMemcpy(d_nextra, &xWanted, 4, hipMemcpyHostToDevice));

@@ -421,6 +421,19 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_scatter_kernel(const uint
     const uint32_t v = i < n ? (order ? order[i] : i) : n;
     const uint64_t m = v < n ? masks[v] : 0;
     const uint32_t o = v < n ? off[v] : 0, L = v < n ? len[v] : 0;
+    // (round 6) the wavefront's places in ALL entries behind one round trip: lane p adds the wavefront's number of candidates of
+    // pattern p to that entry's fill count (round 5: one atomic with a return value per pattern, 46 round trips one after the other)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t mine = 0;
+    for (uint32_t p = 0; p < nPatterns; ++p) {
+        const uint64_t b = __ballot((m >> p) & 1ull);
+        if (lane == p) mine = uint32_t(__popcll(b));
+    }
+    uint32_t myAt = 0;
+    if (mine) {
+        const int a = map.activeOfBit[lane];
+        if (a >= 0) myAt = atomicAdd(&entries[a].cnt[GC_FILL], mine);
+    }
     for (uint32_t p = 0; p < nPatterns; ++p) {
         const bool has = (m >> p) & 1ull;
         const uint64_t b = __ballot(has);
@@ -428,11 +441,9 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_scatter_kernel(const uint
         const int a = map.activeOfBit[p];
         if (a < 0) continue;
         const GrokEntryDev& e = entries[a];
-        uint32_t at = 0;
-        if ((threadIdx.x & 63u) == 0) at = atomicAdd(&e.cnt[GC_FILL], uint32_t(__popcll(b)));
-        at = __shfl(at, 0, 64);
+        const uint32_t at = __shfl(myAt, int(p), 64);
         if (has) {
-            const uint32_t slot = at + __popcll(b & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            const uint32_t slot = at + __popcll(b & ((1ull << lane) - 1ull));
             if (slot < e.cand) {
                 e.off[slot] = o;
                 e.len[slot] = L;
@@ -500,62 +511,86 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_bound_kernel(const GrokEn
 // match of the entry contains a match of the entry's screen (the relaxed whole pattern, or the prefix; no assertions), so the slots
 // whose remainder the screen rejects are done: grok_remainder_all_kernel below, one lane per slot, the yes/no DFA walked from `from`.
 
+// One list append per WAVEFRONT: the lanes that want a place (all lanes of the wavefront call this, converged, with the same counter)
+// take consecutive places behind one atomic add of their number.  -> the lane's place (undefined for a lane that does not want one)
+__device__ __forceinline__ uint32_t grokAppend(uint32_t* counter, bool want) {
+    const uint64_t b = __ballot(want);
+    if (!b) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll(static_cast<long long>(b)) - 1;
+    uint32_t base = 0;
+    if (int(lane) == leader) base = atomicAdd(counter, uint32_t(__popcll(b)));
+    base = __shfl(base, leader, 64);
+    return base + uint32_t(__popcll(b & ((1ull << lane) - 1ull)));
+}
+
 // ---- round 0 in ONE launch for all entries (grid.y = entries from entryBase): what grok_unmatched2_kernel + grok_advance2_kernel did
 // per entry.  in / inCount (single-entry launches only): the slots to look at and their number on the device; nullptr = every slot.
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEntryDev* __restrict__ entries, uint32_t entryBase,
                                                                   const uint32_t* __restrict__ in, const uint32_t* __restrict__ inCount,
                                                                   uint32_t flags, int32_t* __restrict__ xtmp, uint32_t xcap, uint32_t xstride,
-                                                                  uint32_t* __restrict__ xcount) {
+                                                                  uint32_t* __restrict__ xcount, unsigned long long skip) {
+    if ((skip >> (entryBase + blockIdx.y)) & 1ull) return;  // (bit a: entry a of the table is not this launch's)
     const GrokEntryDev& e = entries[entryBase + blockIdx.y];
     uint32_t nIn = e.cand;
     if (inCount) {
         const uint32_t dyn = *inCount;
         nIn = dyn < nIn ? dyn : nIn;
     }
+    if (blockIdx.x * kGrokPlanBlock >= nIn) return;  // (workgroup-uniform)
+    // (round 6) No lane leaves before the lists are appended to: a wavefront appends with ONE atomic per list (grokAppend).  Round 0 of
+    // a general format leaves ten thousand slots in play, and ten thousand atomics with a return value on one word took 0.14 ms between
+    // the end of round 0 and everything behind it (profiles/round6_grok_timeline.txt).
     const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
-    if (k >= nIn) return;
-    const uint32_t slot = in ? in[k] : k;
-    const uint8_t st = e.status[slot];
-    if (st == LC_OVERFLOW && !(flags & GP_OVERFLOW_FINAL)) {
-        e.ovList[atomicAdd(&e.cnt[GC_OVERFLOW], 1u)] = slot;
-        return;
+    const bool live = k < nIn;
+    const uint32_t slot = live ? (in ? in[k] : k) : 0u;
+    const uint8_t st = live ? e.status[slot] : uint8_t(LC_NOMATCH);
+    const bool toOverflow = live && st == LC_OVERFLOW && !(flags & GP_OVERFLOW_FINAL);
+    {
+        const uint32_t at = grokAppend(&e.cnt[GC_OVERFLOW], toOverflow);
+        if (toOverflow) e.ovList[at] = slot;
     }
-    if (st == LC_OVERFLOW || st == LC_GAVE_UP) {
-        e.nmatch[slot] |= st == LC_OVERFLOW ? kGrokSlotOverflow : kGrokSlotGaveUp;
-        return;
+    const bool undecidedSlot = live && !toOverflow && (st == LC_OVERFLOW || st == LC_GAVE_UP);
+    if (undecidedSlot) e.nmatch[slot] |= st == LC_OVERFLOW ? kGrokSlotOverflow : kGrokSlotGaveUp;
+    const bool matched = live && st == LC_MATCH;
+    const bool toUnanchored = live && !toOverflow && !undecidedSlot && !matched && (flags & GP_ANCHORED_PASS) && e.anchored;
+    {
+        const uint32_t at = grokAppend(&e.cnt[GC_UNANCHORED], toUnanchored);
+        if (toUnanchored) e.unanchored[at] = slot;
     }
-    if (st != LC_MATCH) {
-        if ((flags & GP_ANCHORED_PASS) && e.anchored) e.unanchored[atomicAdd(&e.cnt[GC_UNANCHORED], 1u)] = slot;
-        return;
-    }
-    const uint32_t capsRow = e.capsRow;
-    const int32_t* c = e.caps + size_t(slot) * capsRow;
-    bool contributes = false;
-    for (uint32_t g = 1; g <= e.columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
-    if (contributes) {
-        const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
-        int32_t* dst = nullptr;
-        if (seq == 0) {
-            dst = e.first + size_t(slot) * capsRow;
-        } else {
-            const uint32_t at = atomicAdd(xcount, 1u);
-            if (at < xcap) {
-                dst = xtmp + size_t(at) * xstride;
-                dst[0] = int32_t(e.line[slot]);
-                dst[1] = int32_t(seq);
-                dst[2] = int32_t(e.bit);
-                dst += 3;
+    bool inPlay = false;
+    if (matched) {
+        const uint32_t capsRow = e.capsRow;
+        const int32_t* c = e.caps + size_t(slot) * capsRow;
+        bool contributes = false;
+        for (uint32_t g = 1; g <= e.columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
+        if (contributes) {
+            const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
+            int32_t* dst = nullptr;
+            if (seq == 0) {
+                dst = e.first + size_t(slot) * capsRow;
+            } else {
+                const uint32_t at = atomicAdd(xcount, 1u);
+                if (at < xcap) {
+                    dst = xtmp + size_t(at) * xstride;
+                    dst[0] = int32_t(e.line[slot]);
+                    dst[1] = int32_t(seq);
+                    dst[2] = int32_t(e.bit);
+                    dst += 3;
+                }
             }
+            if (dst)
+                for (uint32_t s = 0; s < capsRow; ++s) dst[s] = c[s];
         }
-        if (dst)
-            for (uint32_t s = 0; s < capsRow; ++s) dst[s] = c[s];
+        const uint32_t b = uint32_t(c[0]), en = uint32_t(c[1]);
+        const uint32_t next = en > b ? en : en + 1;
+        if (next < e.len[slot]) {
+            e.from[slot] = next;
+            inPlay = true;
+        }
     }
-    const uint32_t b = uint32_t(c[0]), en = uint32_t(c[1]);
-    const uint32_t next = en > b ? en : en + 1;
-    if (next < e.len[slot]) {
-        e.from[slot] = next;
-        e.listA[atomicAdd(&e.cnt[GC_ROUND0], 1u)] = slot;
-    }
+    const uint32_t at = grokAppend(&e.cnt[GC_ROUND0], inPlay);
+    if (inPlay) e.listA[at] = slot;
 }
 
 // ---- round 5: in front of the remainder screens, the LITERAL index over the remainders (grid.y = entries, one slot in play per
@@ -570,10 +605,13 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEnt
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(const uint8_t* __restrict__ data,
                                                                                const GrokEntryDev* __restrict__ entries,
                                                                                const uint32_t* __restrict__ blob, unsigned long long skip,
-                                                                               const uint32_t* __restrict__ winner) {
+                                                                               const uint32_t* __restrict__ winner, uint32_t quietOnly) {
     __shared__ uint8_t cmap[256];
     if ((skip >> blockIdx.y) & 1ull) return;
     const GrokEntryDev& e = entries[blockIdx.y];
+    // quietOnly: the launch queued BEFORE the host has read round 0's counts takes the entries round 0 left nothing else to do for; an
+    // entry with overflowed or unanchored slots screens its remainders at the end of its chain in phase 2c (grok_device.hip)
+    if (quietOnly && (e.cnt[GC_OVERFLOW] | e.cnt[GC_UNANCHORED])) return;
     uint32_t nIn = e.cnt[GC_ROUND0];
     nIn = nIn < e.cand ? nIn : e.cand;
     if (blockIdx.x * (kGrokPlanBlock / 64) >= nIn) return;
@@ -617,13 +655,15 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(const uint8_t* __restrict__ data,
                                                                            const GrokEntryDev* __restrict__ entries,
                                                                            const GrokScreenDev* __restrict__ screens, uint32_t stageAndWalk,
-                                                                           unsigned long long skip) {
+                                                                           unsigned long long skip, uint32_t* __restrict__ gate) {
+    // gate (optional): every survivor counts onto the batch's gate word (round 6: grok_survivor_gate_kernel's launch behind the screens)
     const uint32_t stage = stageAndWalk & 15u;          // (as grok_screen_all_kernel)
     const bool waveWalk = (stageAndWalk & 16u) != 0;    // one slot per WAVEFRONT: the workgroup takes the slots of its 256-slot window in turn
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     if ((skip >> blockIdx.y) & 1ull) return;
     const GrokEntryDev& e = entries[blockIdx.y];
+    if ((stageAndWalk & 64u) && (e.cnt[GC_OVERFLOW] | e.cnt[GC_UNANCHORED])) return;  // quietOnly: see grok_remainder_literal_kernel
     const GrokScreenDev sc = screens[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     uint32_t nIn = e.cnt[GC_ROUND0];
@@ -636,7 +676,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     if (!sc.blob) {
         if (k < nIn) {
             const uint32_t slot = e.listA[k];
-            if (e.from[slot] < e.len[slot]) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+            if (e.from[slot] < e.len[slot]) {
+                e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+                if (gate) atomicAdd(gate, 1u);
+            }
         }
         return;
     }
@@ -663,7 +706,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
             const uint32_t rem = L > from ? L - from : 0;
             const uint32_t state = staged ? grokScreenWalkWave(data + o + from, rem, start, sink, ncls, cmap, ldsTable, lane)
                                           : grokScreenWalkWave(data + o + from, rem, start, sink, ncls, cmap, table, lane);
-            if ((state == sink || (state != 0 && lAccept[state])) && lane == 0) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+            if ((state == sink || (state != 0 && lAccept[state])) && lane == 0) {
+                e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+                if (gate) atomicAdd(gate, 1u);
+            }
         }
         return;
     }
@@ -675,7 +721,10 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_all_kernel(cons
     if (scaled) state = grokScreenWalkScaled(data + e.off[slot] + from, rem, start * rowBytes, sink == 0xFFFFFFFFu ? 0xFFFFFFFFu : sink * rowBytes, cmap, ldsTable) / rowBytes;
     else state = staged ? grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, ldsTable)
                         : grokScreenWalk(data + e.off[slot] + from, rem, start, sink, ncls, cmap, table);
-    if (state == sink || (state != 0 && lAccept[state])) e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+    if (state == sink || (state != 0 && lAccept[state])) {
+        e.unanchored[atomicAdd(&e.cnt[GC_REMAINDER], 1u)] = slot;
+        if (gate) atomicAdd(gate, 1u);
+    }
 }
 
 // After one search round over the slots in `in` (nullptr: all slots below the bound); see grok_advance_kernel (grok_kernel.hpp)
@@ -772,11 +821,36 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_resolve_kernel(uint32_t n
     pattern[v] = p;
 }
 
-// the winner's first row goes out (d_first was preset to -1: only the entry's own columns are written)
-__global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_kernel(const GrokEntryDev* __restrict__ entries,
+// the winner's first row goes out (d_first was preset to -1: only the entry's own columns are written); grid.y = active entries + 1.
+// Row nAct of the grid (round 6: grok_commit_extra_kernel's launch): the further matches of the winners,
+// [line, seq, bit, row...] -> [line, seq, row... padded with -1]; nextra = rows wanted, counted into the caller's word and into the
+// batch's tail words (nextraCopy: what the host reads back with them).
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_kernel(const GrokEntryDev* __restrict__ entries, uint32_t nAct,
                                                                     const int32_t* __restrict__ pattern, int32_t* __restrict__ first,
-                                                                    uint32_t row, const uint32_t* __restrict__ gate) {
+                                                                    uint32_t row, const uint32_t* __restrict__ gate,
+                                                                    const int32_t* __restrict__ xtmp, const uint32_t* __restrict__ xcount,
+                                                                    uint32_t xcap, uint32_t xstride, GrokSlotMap map,
+                                                                    int32_t* __restrict__ extra, uint32_t extraCap,
+                                                                    uint32_t* __restrict__ nextra, uint32_t* __restrict__ nextraCopy) {
     if (gate && *gate) return;
+    if (blockIdx.y == nAct) {
+        uint32_t total = *xcount;
+        total = total < xcap ? total : xcap;
+        for (uint32_t r = blockIdx.x * kGrokPlanBlock + threadIdx.x; r < total; r += gridDim.x * kGrokPlanBlock) {
+            const int32_t* src = xtmp + size_t(r) * xstride;
+            const int32_t line = src[0], bit = src[2];
+            if (pattern[line] != bit) continue;
+            const uint32_t at = atomicAdd(nextra, 1u);
+            atomicAdd(nextraCopy, 1u);
+            if (at >= extraCap) continue;
+            const uint32_t capsRow = entries[map.activeOfBit[bit]].capsRow;
+            int32_t* dst = extra + size_t(at) * (row + 2);
+            dst[0] = line;
+            dst[1] = src[1];
+            for (uint32_t s = 0; s < row; ++s) dst[2 + s] = s < capsRow ? src[3 + s] : -1;
+        }
+        return;
+    }
     const GrokEntryDev& e = entries[blockIdx.y];
     const uint32_t k = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     if (k >= e.cand) return;
@@ -787,27 +861,4 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_kernel(const GrokE
     const int32_t* src = e.first + size_t(k) * e.capsRow;
     int32_t* dst = first + size_t(line) * row;
     for (uint32_t s = 0; s < e.capsRow; ++s) dst[s] = src[s];
-}
-
-// further matches of the winners: [line, seq, bit, row...] -> [line, seq, row... padded with -1]; nextra = rows wanted
-__global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_extra_kernel(const int32_t* __restrict__ xtmp, const uint32_t* __restrict__ xcount,
-                                                                          uint32_t xcap, uint32_t xstride, const GrokEntryDev* __restrict__ entries,
-                                                                          GrokSlotMap map, const int32_t* __restrict__ pattern,
-                                                                          int32_t* __restrict__ extra, uint32_t extraCap, uint32_t row,
-                                                                          uint32_t* __restrict__ nextra, const uint32_t* __restrict__ gate) {
-    if (gate && *gate) return;
-    uint32_t total = *xcount;
-    total = total < xcap ? total : xcap;
-    for (uint32_t r = blockIdx.x * kGrokPlanBlock + threadIdx.x; r < total; r += gridDim.x * kGrokPlanBlock) {
-        const int32_t* src = xtmp + size_t(r) * xstride;
-        const int32_t line = src[0], bit = src[2];
-        if (pattern[line] != bit) continue;
-        const uint32_t at = atomicAdd(nextra, 1u);
-        if (at >= extraCap) continue;
-        const uint32_t capsRow = entries[map.activeOfBit[bit]].capsRow;
-        int32_t* dst = extra + size_t(at) * (row + 2);
-        dst[0] = line;
-        dst[1] = src[1];
-        for (uint32_t s = 0; s < row; ++s) dst[2 + s] = s < capsRow ? src[3 + s] : -1;
-    }
 }

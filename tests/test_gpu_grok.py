@@ -498,7 +498,12 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
     off = {"LC_GROK_WIDE_FIRST": "0", "LC_GROK_EARLY_ROUNDS": "0", "LC_GROK_BREADTH": "0", "LC_GROK_REMAINDER_LITERAL": "0",
            "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512", "LC_GROK_REMAINDER_INCHAIN": "0", "LC_GROK_POST_IN_STREAM": "0",
            "LC_GROK_LAZY_SYNC3": "0", "LC_GROK_FUSED_ROUND0": "0", "LC_GROK_SCREEN_SCALED": "0", "LC_GROK_FLAT": "0"}
-    for knobs in (forced, off):
+    # (round 6) the remainder screens queued ahead of the host's read of round 0's counts: off alone (everything else as shipped), and
+    # with the search rounds forced ahead (the entries then leave the launch through its skip mask)
+    ahead_off = {"LC_GROK_REMAINDER_AHEAD": "0"}
+    ahead_rounds = {"LC_GROK_EARLY_ROUNDS": "2"}
+    ahead_levels = {"LC_GROK_FLAT": "0"}   # (shadowed entries wait for the entries of level 0: not in the launch either)
+    for knobs in (forced, off, ahead_off, ahead_rounds, ahead_levels):
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)
         fresh = Grok(Match=cfg["match"], CustomPatterns=cfg["custom_patterns"]).wait_ready()

@@ -57,6 +57,12 @@ import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('fused=$fz', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms')"; done; done
   LC_GROK_TRACE=1 GPU_MAX_HW_QUEUES=16 timeout 300 python tools/grok_bench.py --lines 16384 --steps 2 --warmup 1 --no-sequential-check --cpu-sample-lines 50 2>&1 >/dev/null | grep "grok plan: n\|in one launch\|grok plan 2a: entry" | tail -12 | cut -c1-230 ;;
+aheadab)
+  # the remainder screens queued ahead of the host's read of round 0's counts, on / off (parity gates of grok_bench.py included)
+  for rep in 1 2; do for ah in 1 0; do LC_GROK_REMAINDER_AHEAD=$ah GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 8 --cpu-sample-lines 300 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('ahead=$ah', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config'].get('parity_ok', d['config'].get('parity')))"; done; done | tee gpurun_out/r6/aheadab.txt ;;
 groktests)
   timeout 1500 python -m pytest tests/test_gpu_grok.py tests/test_go_regex.py -m gpu -q -x 2>&1 | tail -5 | cut -c1-300 | tee gpurun_out/r6/pytest_grok.txt ;;
 esac
