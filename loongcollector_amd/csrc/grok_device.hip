@@ -465,6 +465,21 @@ thread_local PlanThread tlsPlan;
 // the screen the merged launch walks for an entry: the relaxed whole-pattern screen when there is one (it rejects nearly
 // everything the prefix screen rejects), else the prefix screen
 lc_regex* planScreenOf(const GrokDevicePattern& gp) {
+    // (round 6) ... unless the relaxed screen is too big to be staged into LDS and the prefix screen is not: a table walked through L2
+    // costs 100 ns a byte -- CISCOFW106006_106007_106010's 2 115 states x 57 classes (243 KB) were the longest walk of the screen
+    // launch AND of the remainder screens, 0.42 + 0.44 ms of every batch for 345 candidates (profiles/round6_grok_screen_split.txt) --
+    // against 45 ns a byte in LDS.  Either screen is a necessary condition; the prefix screen lets more values through to round 0.
+    // LC_GROK_SCREEN_PREFIX: 0 (default) never, 1 whenever the relaxed screen is not LDS-staged, 2 only beyond kGrokScreenBigMax.
+    // MEASURED AND LEFT OFF: the prefix screen of that entry lets 5 % more (entry, value) pairs through, and those are long values that
+    // walk a whole automaton in round 0 -- 16 Ki values 2.31 -> 2.73 ms (mode 2), 2.60 ms (mode 1); profiles/round6_grok_steps.txt.
+    static const int prefixMode = [] {
+        const char* v = getenv("LC_GROK_SCREEN_PREFIX");
+        return v ? atoi(v) : 0;
+    }();
+    auto stageBytesOf = [](const lc_regex* r) { return r->screenBlob[SC_TOTAL_BYTES] - r->screenBlob[SC_OFF_ACCEPT]; };
+    if (prefixMode && gp.relaxed && !gp.relaxed->screenBlob.empty() && gp.screen && !gp.screen->screenBlob.empty() &&
+        stageBytesOf(gp.relaxed) > (prefixMode == 1 ? kGrokScreenStageMax : kGrokScreenBigMax) && stageBytesOf(gp.screen) <= kGrokScreenStageMax)
+        return gp.screen;
     if (gp.relaxed && !gp.relaxed->screenBlob.empty()) return gp.relaxed;
     if (gp.screen && !gp.screen->screenBlob.empty()) return gp.screen;
     return nullptr;
@@ -489,6 +504,11 @@ int grokScreenTable(const std::vector<GrokDevicePattern>& patterns, GrokDeviceSt
             d.bigBytes = (!noStage && !d.ldsBytes && stage <= kGrokScreenBigMax) ? (stage + 3u) & ~3u : 0u;
             maxStage = std::max(maxStage, d.ldsBytes);
             maxBig = std::max(maxBig, d.bigBytes);
+            if (getenv("LC_GROK_TRACE"))
+                fprintf(stderr, "grok screen of entry %zu: %u states x %u classes, %u bytes (%s)%s; prefix screen %u states\n", p, scr->screenBlob[SC_NSTATES],
+                        scr->screenBlob[SC_NCLASSES], stage, d.ldsBytes ? "staged in LDS" : d.bigBytes ? "big: through L2" : "through L2",
+                        scr == patterns[p].relaxed ? " relaxed" : " prefix",
+                        (patterns[p].screen && !patterns[p].screen->screenBlob.empty()) ? patterns[p].screen->screenBlob[SC_NSTATES] : 0u);
             host.push_back(d);
         }
         std::stable_sort(host.begin(), host.end(), [](const GrokScreenDev& x, const GrokScreenDev& y) { return (x.bigBytes != 0) > (y.bigBytes != 0); });
@@ -670,7 +690,13 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                                sliceLen, screens, reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), 2u | screenWalk);
             HIP_TRY(hipEventRecord(T.join[0], T.workers[0]));
         }
-        if (nScreens > nBig)
+        static const bool splitScreens = getenv("LC_GROK_SCREEN_SPLIT") != nullptr;  // diagnosis: one launch per screen (a kernel trace then times each)
+        if (splitScreens) {
+            for (uint32_t k = nBig; k < nScreens; ++k)
+                hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, 1), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + (small ? screenLds : 0), st,
+                                   d_data, d_off, d_len, n, sliceLen, screens + k, reinterpret_cast<unsigned long long*>(masks),
+                                   static_cast<const uint32_t*>(order), (small ? 1u : 0u) | screenWalk);
+        } else if (nScreens > nBig)
             hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens - nBig), dim3(kGrokPlanBlock),
                                size_t(sliceLen) * 4 + (small ? screenLds : 0), st, d_data, d_off, d_len, n, sliceLen, screens + nBig,
                                reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), (small ? 1u : 0u) | screenWalk);
@@ -1164,12 +1190,18 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                     if (rcFork != LC_OK) return rcFork;
                 }
                 hipStream_t gs = W(int(used) - 1);
-                if (remainderLiteral || remainderWon)
-                    hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((most + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct), dim3(kGrokPlanBlock),
-                                       0, gs, d_data, T.dEntries, remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), skip,
-                                       remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 1u);
-                hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(most), nAct), dim3(kGrokPlanBlock), small ? ldsAhead : 0, gs, d_data, T.dEntries,
-                                   static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk | 64u, skip, remGate);
+                static const bool splitRem = getenv("LC_GROK_REM_SPLIT") != nullptr;  // diagnosis: one launch pair per entry (a kernel trace then times each)
+                for (uint32_t a1 = 0; a1 < (splitRem ? nAct : 1u); ++a1) {
+                    const unsigned long long skip1 = splitRem ? ~(1ull << a1) : skip;
+                    if (splitRem && ((skip >> a1) & 1ull)) continue;
+                    if (remainderLiteral || remainderWon)
+                        hipLaunchKernelGGL(grok_remainder_literal_kernel, dim3((most + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64), nAct),
+                                           dim3(kGrokPlanBlock), 0, gs, d_data, T.dEntries,
+                                           remainderLiteral ? literalIndex : static_cast<const uint32_t*>(nullptr), skip1,
+                                           remainderWon ? static_cast<const uint32_t*>(winner) : static_cast<const uint32_t*>(nullptr), 1u);
+                    hipLaunchKernelGGL(grok_remainder_all_kernel, dim3(remGrid(most), nAct), dim3(kGrokPlanBlock), small ? ldsAhead : 0, gs, d_data,
+                                       T.dEntries, static_cast<const GrokScreenDev*>(T.dRemScreens), (small ? 1u : 0u) | remWalk | 64u, skip1, remGate);
+                }
                 aheadLaunched = true;
             }
         }

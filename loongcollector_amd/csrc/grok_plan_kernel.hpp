@@ -560,29 +560,34 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEnt
     }
     bool inPlay = false;
     if (matched) {
-        const uint32_t capsRow = e.capsRow;
-        const int32_t* c = e.caps + size_t(slot) * capsRow;
-        bool contributes = false;
-        for (uint32_t g = 1; g <= e.columns; ++g) contributes |= c[2 * g] >= 0 && c[2 * g + 1] > c[2 * g];
+        // (round 6: a row is read as (begin, end) PAIRS -- capsRow is even, rows are 8-byte aligned -- and without a branch between the
+        // loads: `c[2g] >= 0 && c[2g+1] > c[2g]` was twenty dependent round trips to L2 per slot, the post step of a general format 0.1 ms)
+        const uint32_t capsRow = e.capsRow, pairs = capsRow >> 1;
+        const int2* c2 = reinterpret_cast<const int2*>(e.caps + size_t(slot) * capsRow);
+        uint32_t contributes = 0;
+        for (uint32_t g = 1; g < pairs; ++g) {
+            const int2 be = c2[g];
+            contributes |= uint32_t(be.x >= 0) & uint32_t(be.y > be.x);
+        }
+        const int2 whole = c2[0];
         if (contributes) {
             const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
-            int32_t* dst = nullptr;
             if (seq == 0) {
-                dst = e.first + size_t(slot) * capsRow;
+                int2* dst = reinterpret_cast<int2*>(e.first + size_t(slot) * capsRow);
+                for (uint32_t g = 0; g < pairs; ++g) dst[g] = c2[g];
             } else {
                 const uint32_t at = atomicAdd(xcount, 1u);
                 if (at < xcap) {
-                    dst = xtmp + size_t(at) * xstride;
+                    int32_t* dst = xtmp + size_t(at) * xstride;
                     dst[0] = int32_t(e.line[slot]);
                     dst[1] = int32_t(seq);
                     dst[2] = int32_t(e.bit);
-                    dst += 3;
+                    const int32_t* c = reinterpret_cast<const int32_t*>(c2);
+                    for (uint32_t s = 0; s < capsRow; ++s) dst[3 + s] = c[s];
                 }
             }
-            if (dst)
-                for (uint32_t s = 0; s < capsRow; ++s) dst[s] = c[s];
         }
-        const uint32_t b = uint32_t(c[0]), en = uint32_t(c[1]);
+        const uint32_t b = uint32_t(whole.x), en = uint32_t(whole.y);
         const uint32_t next = en > b ? en : en + 1;
         if (next < e.len[slot]) {
             e.from[slot] = next;

@@ -149,7 +149,15 @@ void ProcessorGrokGpu::Init() {
         if (extras[t].second == 0) {
             c.screen = lcCompilePrefixScreen(pat, len, kGrokSyntax, 1024, 32 * 1024);
         } else if (!noRelaxed) {
-            c.relaxed = lcCompileRelaxedScreen(pat, len, kGrokSyntax, 20000, 2u << 20);
+            // (round 6) ... and preferably until its table can be staged into LDS (grok_device.hip kGrokScreenStageMax = 44 KiB);
+            // LC_GROK_RELAX_PREFER_BYTES: 0 = the first automaton that fits at all, as in round 5.  Measured (profiles/round6_grok_steps.txt):
+            // the same (entry, value) pairs reach round 0 on the bench corpus, 16 Ki values 2.31 -> 2.02 ms -- the four screens that were
+            // walked through L2 were the longest walks of the screen launch and of the remainder screens
+            static const size_t preferBytes = [] {
+                const char* v = getenv("LC_GROK_RELAX_PREFER_BYTES");
+                return v ? size_t(atol(v)) : size_t(44 * 1024);
+            }();
+            c.relaxed = lcCompileRelaxedScreenPreferring(pat, len, kGrokSyntax, 20000, 2u << 20, preferBytes);
         }
     });
     for (size_t i = 0; i < Match.size(); ++i) {  // everything that was compiled is owned from here on, whatever happens next

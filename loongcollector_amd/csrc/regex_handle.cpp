@@ -1333,6 +1333,15 @@ static std::string dumpNode(const Node& n) {
 }
 
 lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes) {
+    return lcCompileRelaxedScreenPreferring(pattern, len, syntax_flags, maxStates, maxBlobBytes, 0);
+}
+
+// preferStageBytes != 0 (round 6): the automaton whose [accept flags | table] block is at most this large is preferred -- the Grok plan
+// stages such a screen into LDS (45 ns a byte) and walks a larger one through L2 (100 ns a byte: grok_device.hip kGrokScreenStageMax).
+// The budgets go on shrinking behind the first automaton that fits at all; the first one that fits the preference wins, and if none
+// does the first one is kept.  A smaller budget forgets more of the pattern: the screen lets more values through.
+lc_regex* lcCompileRelaxedScreenPreferring(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes,
+                                           size_t preferStageBytes) {
     ParsedRegex parsed;
     try {
         parsed = parseForScreen(pattern, len, syntax_flags);
@@ -1344,6 +1353,7 @@ lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t synta
     if (const char* e = getenv("LC_RELAX_BUDGET")) firstBudget = size_t(std::max(1, atoi(e)));
     std::vector<size_t> budgets;
     for (size_t b = firstBudget; b >= 1 && budgets.size() < 5; b = b > 6 ? b / 2 : (b > 1 ? b - 1 : 0)) budgets.push_back(b);
+    lc_regex* firstFit = nullptr;  // (preferStageBytes: the automaton of the largest budget that fits at all)
     for (size_t budget : budgets) {
         Relaxer rx{budget};
         std::unique_ptr<Node> node = rx.relax(*parsed.root);
@@ -1353,10 +1363,17 @@ lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t synta
         if (lc_regex* re = compileScreenNode(std::move(node), syntax_flags, maxStates, maxBlobBytes,
                                              "<relaxed screen: budget " + std::to_string(budget) + ", " + std::to_string(npos) +
                                                  " positions>",
-                                             uint32_t(budget), uint32_t(npos), true))
-            return re;
+                                             uint32_t(budget), uint32_t(npos), true)) {
+            const size_t stage = re->screenBlob.empty() ? 0 : size_t(re->screenBlob[SC_TOTAL_BYTES] - re->screenBlob[SC_OFF_ACCEPT]);
+            if (!preferStageBytes || (stage && stage <= preferStageBytes)) {
+                if (firstFit) lc_regex_free(firstFit);
+                return re;
+            }
+            if (!firstFit) firstFit = re;
+            else lc_regex_free(re);
+        }
     }
-    return nullptr;
+    return firstFit;
 }
 
 lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates,

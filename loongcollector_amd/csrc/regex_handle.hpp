@@ -168,6 +168,8 @@ lc_regex* lcCompilePrefixScreen(const char* pattern, size_t len, uint32_t syntax
 // regex_handle.cpp: TDFA-only handle for the WHOLE pattern relaxed until its automaton is small (sub-expressions that are too
 // large become "any of their bytes, repeated"); a necessary condition over the whole line (nullptr if there is none)
 lc_regex* lcCompileRelaxedScreen(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes);
+lc_regex* lcCompileRelaxedScreenPreferring(const char* pattern, size_t len, uint32_t syntax_flags, uint32_t maxStates, size_t maxBlobBytes,
+                                           size_t preferStageBytes);
 // implemented in gpu_runtime.hip: one pass of a screen handle that carries a screenBlob (dfa_screen_kernel) over the values
 // listed in d_in (nullptr: all n); accepted values are appended to d_out, their number added to d_counters[0]
 int lcScreenOnStream(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t n,

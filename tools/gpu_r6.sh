@@ -63,6 +63,24 @@ aheadab)
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('ahead=$ah', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config'].get('parity_ok', d['config'].get('parity')))"; done; done | tee gpurun_out/r6/aheadab.txt ;;
+bigab)
+  # the 70-130 KB screens staged into a CU's whole LDS (phase 1: LC_GROK_BIG_SCREENS; remainder screens: LC_GROK_BIG_REMAINDER), measured again
+  for rep in 1 2; do for cfg in "0 0" "1 0" "0 1" "1 1"; do set -- $cfg; LC_GROK_BIG_SCREENS=$1 LC_GROK_BIG_REMAINDER=$2 GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 8 --cpu-sample-lines 100 --no-sequential-check 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('big_screens=$1 big_remainder=$2', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms')"; done; done | tee gpurun_out/r6/bigab.txt ;;
+prefixab)
+  # the prefix screen instead of a relaxed screen that is not staged into LDS (LC_GROK_SCREEN_PREFIX 0 / 1 / 2), with and without the big screens staged
+  for rep in 1 2; do for cfg in "0 0" "2 0" "2 1" "1 0"; do set -- $cfg; LC_GROK_SCREEN_PREFIX=$1 LC_GROK_BIG_SCREENS=$2 LC_GROK_BIG_REMAINDER=$2 GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 8 --cpu-sample-lines 300 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('screen_prefix=$1 big=$2', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config']['batch']['pairs'], d['config']['parity']['both_paths_agree_on_every_line'])"; done; done | tee gpurun_out/r6/prefixab.txt ;;
+relaxab)
+  # relaxed screens relaxed further until their table can be staged into LDS (LC_GROK_RELAX_PREFER_BYTES), with and without the big screens staged
+  for rep in 1 2; do for cfg in "0 0" "45056 0" "153600 1" "45056 1"; do set -- $cfg; LC_GROK_RELAX_PREFER_BYTES=$1 LC_GROK_BIG_SCREENS=$2 LC_GROK_BIG_REMAINDER=$2 GPU_MAX_HW_QUEUES=16 timeout 900 python tools/grok_bench.py --lines 1000,16384,65536 --steps 10 --warmup 8 --cpu-sample-lines 300 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('relax_prefer=$1 big=$2', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config']['batch']['pairs'], d['config']['parity']['both_paths_agree_on_every_line'])"; done; done | tee gpurun_out/r6/relaxab.txt ;;
 groktests)
   timeout 1500 python -m pytest tests/test_gpu_grok.py tests/test_go_regex.py -m gpu -q -x 2>&1 | tail -5 | cut -c1-300 | tee gpurun_out/r6/pytest_grok.txt ;;
 esac
