@@ -511,6 +511,20 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_bound_kernel(const GrokEn
 // match of the entry contains a match of the entry's screen (the relaxed whole pattern, or the prefix; no assertions), so the slots
 // whose remainder the screen rejects are done: grok_remainder_all_kernel below, one lane per slot, the yes/no DFA walked from `from`.
 
+// a row of (begin, end) pairs from one array to another, four pairs in flight (the arrays never overlap; a plain loop waits for
+// every load before its store: a 60-word row was 60 round trips to L2, grok_commit_kernel 0.08 ms)
+__device__ __forceinline__ void grokCopyPairs(int2* __restrict__ dst, const int2* __restrict__ src, uint32_t pairs) {
+    uint32_t g = 0;
+    for (; g + 4 <= pairs; g += 4) {
+        const int2 a = src[g], b = src[g + 1], c = src[g + 2], d = src[g + 3];
+        dst[g] = a;
+        dst[g + 1] = b;
+        dst[g + 2] = c;
+        dst[g + 3] = d;
+    }
+    for (; g < pairs; ++g) dst[g] = src[g];
+}
+
 // One list append per WAVEFRONT: the lanes that want a place (all lanes of the wavefront call this, converged, with the same counter)
 // take consecutive places behind one atomic add of their number.  -> the lane's place (undefined for a lane that does not want one)
 __device__ __forceinline__ uint32_t grokAppend(uint32_t* counter, bool want) {
@@ -565,16 +579,21 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_post_kernel(const GrokEnt
         const uint32_t capsRow = e.capsRow, pairs = capsRow >> 1;
         const int2* c2 = reinterpret_cast<const int2*>(e.caps + size_t(slot) * capsRow);
         uint32_t contributes = 0;
-        for (uint32_t g = 1; g < pairs; ++g) {
-            const int2 be = c2[g];
-            contributes |= uint32_t(be.x >= 0) & uint32_t(be.y > be.x);
+        auto test = [&](const int2 be) { contributes |= uint32_t(be.x >= 0) & uint32_t(be.y > be.x); };
+        uint32_t g = 1;
+        for (; g + 4 <= pairs; g += 4) {  // (four loads in flight)
+            const int2 p0 = c2[g], p1 = c2[g + 1], p2 = c2[g + 2], p3 = c2[g + 3];
+            test(p0);
+            test(p1);
+            test(p2);
+            test(p3);
         }
+        for (; g < pairs; ++g) test(c2[g]);
         const int2 whole = c2[0];
         if (contributes) {
             const uint32_t seq = e.nmatch[slot]++ & kGrokSlotCount;
             if (seq == 0) {
-                int2* dst = reinterpret_cast<int2*>(e.first + size_t(slot) * capsRow);
-                for (uint32_t g = 0; g < pairs; ++g) dst[g] = c2[g];
+                grokCopyPairs(reinterpret_cast<int2*>(e.first + size_t(slot) * capsRow), c2, pairs);
             } else {
                 const uint32_t at = atomicAdd(xcount, 1u);
                 if (at < xcap) {
@@ -865,5 +884,8 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_commit_kernel(const GrokE
     if (pattern[line] != int32_t(e.bit)) return;
     const int32_t* src = e.first + size_t(k) * e.capsRow;
     int32_t* dst = first + size_t(line) * row;
-    for (uint32_t s = 0; s < e.capsRow; ++s) dst[s] = src[s];
+    // (capsRow and row are even and the plan's own arrays 256-byte aligned; the caller's `first` is int32 by contract: tested)
+    if ((reinterpret_cast<uintptr_t>(first) & 7u) == 0) grokCopyPairs(reinterpret_cast<int2*>(dst), reinterpret_cast<const int2*>(src), e.capsRow >> 1);
+    else
+        for (uint32_t s = 0; s < e.capsRow; ++s) dst[s] = src[s];
 }
