@@ -134,6 +134,31 @@ __global__ __launch_bounds__(kTdfaL2Block) void tdfa_l2_kernel(const uint8_t* __
 // this kernel -- lcPreferWaveTdfa, the Grok matcher's entries): the transition table is staged too, and a byte that is not part of a
 // quiet run costs an LDS read instead of a read through L2 (a search wrapper's lazy prefix makes EVERY byte such a byte: 146 -> ~40 ns).
 // stageBytes then counts from TL_OFF_TRANS (trans, opsStart, ops are contiguous in the blob).
+// (round 6) scalar loads for the walk of tdfaWaveBody<false>: the table word of a wave-uniform (state, class) through the scalar cache
+// into an SGPR.  The compiler's own choice for these reads -- the pointers come out of a job table, so their address space is unknown
+// to it -- was flat_load_dword + v_readfirstlane with the state and the position in VGPRs and every loop condition an exec mask:
+// 45 instructions per byte (profiles/round6_wave_walk_isa.md).  The tables are read-only for the kernel's lifetime.
+template <typename T>
+__device__ __forceinline__ const T* lcUniformPtr(const T* p) {  // (said to be wave-uniform: both halves through v_readfirstlane)
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return reinterpret_cast<const T*>((uint64_t(hi) << 32) | lo);
+}
+__device__ __forceinline__ uint32_t lcScalarLoad32(const void* base, uint32_t byteOff) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byteOff) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint64_t lcScalarLoad64(const void* base, uint32_t byteOff) {
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byteOff) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t lcScalarLoad16(const void* base, uint32_t index) {  // element `index` of a u16 array
+    const uint32_t w = lcScalarLoad32(base, (index << 1) & ~3u);
+    return (index & 1u) ? (w >> 16) : (w & 0xFFFFu);
+}
+
 template <bool LT>
 __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                              const uint32_t* __restrict__ len, uint32_t sepBytes, uint32_t nLines,
@@ -209,6 +234,103 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
         curWord = classesOf((w < nWords) ? words[w] : 0);
     }
     uint32_t idx = head + from;  // position in the word-aligned view
+    if constexpr (!LT) {
+        // ---- the walk, every control value in an SGPR (round 6; see lcScalarLoad32).  Same steps as the loop below, byte for byte.
+        const uint32_t uNcls = __builtin_amdgcn_readfirstlane(ncls), uAbsorb = __builtin_amdgcn_readfirstlane(absorb),
+                       uMiss = __builtin_amdgcn_readfirstlane(miss), uEnd = __builtin_amdgcn_readfirstlane(end),
+                       uHead = __builtin_amdgcn_readfirstlane(head), uWords = __builtin_amdgcn_readfirstlane(nWords);
+        uint32_t uState = __builtin_amdgcn_readfirstlane(state), uIdx = __builtin_amdgcn_readfirstlane(idx),
+                 uChunk = __builtin_amdgcn_readfirstlane(chunk);
+        const bool staged = __builtin_amdgcn_readfirstlane(stageBytes) != 0;
+        const uint32_t* gOpsStart = lcUniformPtr(reinterpret_cast<const uint32_t*>(base + blob[TL_OFF_OPSSTART]));
+        const uint16_t* gOps = lcUniformPtr(reinterpret_cast<const uint16_t*>(base + blob[TL_OFF_OPS]));
+        const uint32_t* uTrans = lcUniformPtr(trans);
+        const uint2* uQuiet = lcUniformPtr(quietTab);
+        const uint32_t* lOpsStart = wregs + kTdfaWaveValues * nRegs;  // (staged: opsStart, then ops, as in the blob)
+        const uint32_t opsDelta = __builtin_amdgcn_readfirstlane(blob[TL_OFF_OPS] - blob[TL_OFF_OPSSTART]);
+        auto stops = [&](uint32_t st) { return st == 0u || st == uAbsorb || st == uMiss; };
+        // (no branch around the load -- a divergent branch inside the loop makes the compiler steer the WHOLE loop with mask registers:
+        // a word index beyond the value reads the value's last word and is replaced by zero)
+        auto classesAt = [&](uint32_t w) {
+            const uint32_t got = words[w < uWords ? w : uWords - 1u];
+            return classesOf(w < uWords ? got : 0u);
+        };
+        if (uIdx < uEnd && !stops(uState)) {
+            for (;;) {  // (one byte per turn; leaves by break only)
+                if ((uIdx >> 8) != uChunk) {
+                    uChunk = uIdx >> 8;
+                    const uint32_t w = (uChunk << 6) + lane;
+                    curWord = classesAt(w);
+                }
+                const uint32_t wsel = uint32_t(__builtin_amdgcn_readlane(int(curWord), int((uIdx >> 2) & 63u)));
+                const uint32_t cls = (wsel >> ((uIdx & 3u) * 8u)) & 0xFFu;
+                const uint32_t t = lcScalarLoad32(uTrans, (uState * uNcls + cls) << 2);
+                const uint32_t prog = t >> 16, next = t & 0xFFFFu;
+                if (prog) {
+                    const uint32_t pos = uIdx - uHead;
+                    if (staged) {
+                        uint32_t at = __builtin_amdgcn_readfirstlane(lOpsStart[prog]);
+                        const uint16_t* lOps = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lOpsStart) + opsDelta);
+                        const uint32_t n = __builtin_amdgcn_readfirstlane(lOps[at]);
+                        for (uint32_t k = 0; k < n; ++k) {  // (every lane stores the same word: one LDS write)
+                            const uint32_t op = __builtin_amdgcn_readfirstlane(lOps[++at]);
+                            const uint32_t src = op >> 8;
+                            regs[op & 0xFFu] = src == TD_REG_POS ? pos : regs[src];
+                        }
+                    } else {
+                        uint32_t at = lcScalarLoad32(gOpsStart, prog << 2);
+                        const uint32_t n = lcScalarLoad16(gOps, at);
+                        for (uint32_t k = 0; k < n; ++k) {
+                            const uint32_t op = lcScalarLoad16(gOps, ++at);
+                            const uint32_t src = op >> 8;
+                            regs[op & 0xFFu] = src == TD_REG_POS ? pos : regs[src];
+                        }
+                    }
+                    uState = next;
+                    ++uIdx;
+                    if (uIdx >= uEnd || uState == 0u) break;
+                    continue;
+                }
+                if (next == uState) {
+                    if (stops(uState)) break;
+                    // a quiet byte: find the end of the run -- every lane tests its 4 bytes of the chunk, chunk after chunk
+                    const uint64_t quiet = lcScalarLoad64(uQuiet, uState << 3);
+                    uint32_t stop = uEnd;
+                    for (;;) {
+                        const uint32_t chunkBase = uChunk << 8;
+                        uint32_t firstHit = 4;
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) {
+                            const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                            const uint32_t c = (curWord >> (8 * j)) & 0xFFu;
+                            const bool isQuiet = c < 64 && ((quiet >> c) & 1ull);
+                            if (bi > uIdx && bi < uEnd && !isQuiet) firstHit = uint32_t(j);
+                        }
+                        const uint64_t hit = __ballot(firstHit < 4);
+                        if (hit) {
+                            const int l = __ffsll((long long)hit) - 1;
+                            stop = chunkBase + uint32_t(l) * 4 + uint32_t(__builtin_amdgcn_readlane(int(firstHit), l));
+                            break;
+                        }
+                        if (chunkBase + 256 >= uEnd) break;  // the run reaches the end of the value
+                        ++uChunk;
+                        const uint32_t w = (uChunk << 6) + lane;
+                        curWord = classesAt(w);
+                    }
+                    uIdx = stop;
+                    if (uIdx >= uEnd) break;
+                    continue;
+                }
+                // (the dead state ends the walk at once; the absorbing state and the MISS sink keep themselves on every class without a
+                // program -- regex_handle.cpp packTdfaL2Blob, tdfa.cpp -- and end it at the next byte, in the branch above)
+                uState = next;
+                ++uIdx;
+                if (uIdx >= uEnd || uState == 0u) break;
+            }
+        }
+        state = uState;
+        idx = uIdx;
+    } else
     while (idx < end && state != 0 && state != absorb && state != miss) {
         if ((idx >> 8) != chunk) {
             chunk = idx >> 8;
