@@ -374,7 +374,9 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         lds += extraLds;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
-    const uint32_t grid = (n + BLOCK - 1) / BLOCK;
+    uint32_t grid = (n + BLOCK - 1) / BLOCK;
+    // (the mop-up launch of tdfa_stream_kernel takes its blocks in turn: tdfa_stream_kernel.hpp)
+    if (minLen && !COMPACT && !BYTEROWS && !streamOff) grid = std::min(grid, 256u);
     noteKernel(cmapA8 ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,a8>" : "tdfa_stream_kernel<nogeneral,pair1,a8>")
                : (PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));

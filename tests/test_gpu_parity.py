@@ -609,6 +609,29 @@ def test_one_stamp_pair_tables_forced_on_every_table_format(torch_dev, golden_di
     assert exp_status.sum() >= 7
 
 
+def test_long_lines_behind_the_first_256_blocks_of_a_large_batch(torch_dev):
+    """Round 6: the second launch behind the COMPACT kernel (the lines of 64 KiB and more) comes with at most 256 workgroups that take
+    the line blocks in turn.  A batch of 80 000 lines (313 blocks of 256: the COMPACT kernel is what a batch of 64 Ki lines and more
+    gets) with such lines in the first block, beyond the 256th, and in the last one; and a batch without any."""
+    from oracle.oracle import OracleRegex
+    pattern = rb"(\w+) (\d+) (.*)\|(\w*)"
+    rx = B.GpuRegex(pattern)
+    assert rx.table(B.LC_TABLE_TDFA_WIDE_BLOB, np.uint32) is not None
+    n = 80000
+    subs = [b"k%d %d some text|e%d" % (i, i * 7, i % 10) if i % 9 else b"no separator here %d" % i for i in range(n)]
+    for where, size in ((3, 65536), (66000, 70001), (79999, 65600), (70123, 131072)):
+        subs[where] = b"key 12345 " + b"x" * (size - 14) + b"|end"
+    subs[66001] = b"nothing " * 9000  # 72 000 bytes that do not match
+    for lines in (subs, [s for s in subs if len(s) < 60000]):
+        data, off, length = pack(lines)
+        exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+        B.launched_kernels()
+        caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+        assert "compact" in str(B.launched_kernels())
+        assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    assert exp_status.sum() > n // 2
+
+
 def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
     """lc_regex_match_device_from: a subset of the lines, each search resumed at its own offset (also beyond the first
     256-byte chunk of the NFA kernel and across the TDFA kernel's 64-byte stages), against the oracle's search(start)."""
