@@ -375,8 +375,22 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     uint32_t grid = (n + BLOCK - 1) / BLOCK;
-    // (the mop-up launch of tdfa_stream_kernel takes its blocks in turn: tdfa_stream_kernel.hpp)
-    if (minLen && !COMPACT && !BYTEROWS && !streamOff) grid = std::min(grid, 256u);
+    // (the mop-up launch behind a COMPACT one: an instantiation whose workgroups take the line blocks in turn, tdfa_stream_kernel.hpp
+    // kLabMopUp -- for the workgroup size such a launch has in practice)
+    if constexpr (BLOCK == 256 && !COMPACT && !BYTEROWS) {
+        if (minLen && !streamOff && !cmapA8) {
+            if constexpr (PAIR) kern = pairOne ? tdfa_stream_kernel<256, false, true, kTdfaNoGeneralPrograms | kLabPairOne | kLabMopUp>
+                                               : tdfa_stream_kernel<256, false, true, kLabMopUp>;
+            else kern = noGen ? tdfa_stream_kernel<256, false, false, kTdfaNoGeneralPrograms | kLabMopUp> : tdfa_stream_kernel<256, false, false, kLabMopUp>;
+            grid = std::min(grid, 256u);
+            static thread_local size_t mopAttrSet[kLcMaxDevices][4] = {};  // (function, device), as above
+            const int mopWhich = PAIR ? (pairOne ? 0 : 1) : (noGen ? 2 : 3);
+            if (lds > 64 * 1024 && devNow < kLcMaxDevices && lds > mopAttrSet[devNow][mopWhich]) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                mopAttrSet[devNow][mopWhich] = lds;
+            }
+        }
+    }
     noteKernel(cmapA8 ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,a8>" : "tdfa_stream_kernel<nogeneral,pair1,a8>")
                : (PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));

@@ -650,11 +650,12 @@ __global__ __launch_bounds__(BLOCK, (LAB & kLabWaves5) ? 5 : LC_TDFA_STREAM_WAVE
     const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob, uint32_t blobBytes, uint32_t regBytes,
     uint32_t nGroupsOut, int32_t* __restrict__ caps, uint8_t* __restrict__ status, uint32_t* __restrict__ longFlag,
     uint32_t launchSeq, uint32_t* __restrict__ doneCounter, uint32_t* __restrict__ doneFlag, uint32_t doneSeq) {
-    if constexpr (!COMPACT) {
+    if constexpr (!COMPACT && (LAB & kLabMopUp) != 0) {
         // (round 6) The MOP-UP launch behind a COMPACT one (minLen != 0: only the lines of 64 KiB and more are this launch's) comes with a
         // grid of at most 256 workgroups that take the line blocks in turn.  It used to come with one workgroup per block -- 4 096 for
         // the headline batch, every one of them reading the flag and leaving: 4.5 us behind each 168 us launch, on a corpus without
-        // a single such line (profiles/round6_tdfa_kernel_rocprofv3.txt).
+        // a single such line (profiles/round6_tdfa_kernel_rocprofv3.txt).  An instantiation of its own (kLabMopUp): the loop costs 12
+        // VGPRs and 32 SGPRs, and the same kernel without it is what every 1000-line event group of an agent runs.
         if (minLen) {
             if (longFlag && __atomic_load_n(longFlag, __ATOMIC_RELAXED) < launchSeq) return;  // nothing was flagged by the COMPACT launch
             const uint32_t nBlocks = (nLines + BLOCK - 1) / BLOCK;
