@@ -375,6 +375,39 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     uint32_t grid = (n + BLOCK - 1) / BLOCK;
+    bool persistSel = false;
+    // (round 6) PERSISTENT WAVEFRONTS for the one-stamp COMPACT kernel on batches of several rounds of workgroups: the launch holds as
+    // many workgroups as the chip does at once, each wavefront goes on with its lines of the next block (tdfa_stream_kernel.hpp
+    // kLabPersist).  MEASURED AND LEFT OFF (LC_TDFA_PERSIST=1 switches it on; the GPU parity suite runs it): 0.1825 against 0.1700 ms per
+    // 1 Mi lines, 0.344 against 0.316 ms per 2 Mi -- as with round 3's persistent workgroups, the dispatcher starting a new workgroup in
+    // the middle of the resident ones' loops beats 4 096 wavefronts that start together and stay in step through every block
+    // (profiles/round6_tdfa_why_not.md section 9).
+    if constexpr (COMPACT && PAIR && !BYTEROWS && BLOCK == 512) {
+        const char* pe = getenv("LC_TDFA_PERSIST");
+        const bool persistOn = pe && pe[0] == '1';
+        if (persistOn && pairOne && !streamOff && !cmapA8 && !extraLds && minLen == 0) {
+            static thread_local uint32_t resident[kLcMaxDevices] = {};  // workgroups the device holds at once (LDS-bound: per CU)
+            int devP = 0;
+            HIP_TRY(hipGetDevice(&devP));
+            if (devP < kLcMaxDevices && !resident[devP]) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, devP));
+                // (LDS-bound, and never more than the 32 wavefronts of a CU: four workgroups of 512)
+                resident[devP] = uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(4, std::max<size_t>(1, kLcLdsPerCu / lds)));
+            }
+            const uint32_t slots = devP < kLcMaxDevices ? resident[devP] : 0u;
+            if (slots && grid > slots) {
+                kern = tdfa_stream_kernel<512, true, true, kTdfaNoGeneralPrograms | kLabPairOne | kLabDmaStage | kLabPersist>;
+                static thread_local size_t persistAttr[kLcMaxDevices] = {};
+                if (lds > 64 * 1024 && lds > persistAttr[devP]) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                    persistAttr[devP] = lds;
+                }
+                grid = slots;
+                persistSel = true;
+            }
+        }
+    }
     // (the mop-up launch behind a COMPACT one: an instantiation whose workgroups take the line blocks in turn, tdfa_stream_kernel.hpp
     // kLabMopUp -- for the workgroup size such a launch has in practice)
     if constexpr (BLOCK == 256 && !COMPACT && !BYTEROWS) {
@@ -391,7 +424,7 @@ static int launchTdfaBlock(const void* dBlob, uint32_t blobBytes, uint32_t regBy
             }
         }
     }
-    noteKernel(cmapA8 ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,a8>" : "tdfa_stream_kernel<nogeneral,pair1,a8>")
+    noteKernel(persistSel ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,persist>" : cmapA8 ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma,a8>" : "tdfa_stream_kernel<nogeneral,pair1,a8>")
                : (PAIR && pairOne) ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral,pair1,dma>" : "tdfa_stream_kernel<nogeneral,pair1>") : dma ? (noGen ? "tdfa_stream_kernel<compact,nogeneral,dma>" : "tdfa_stream_kernel<compact,dma>") : noGen ? (COMPACT ? "tdfa_stream_kernel<compact,nogeneral>" : "tdfa_stream_kernel<nogeneral>") : which ? (PAIR ? (COMPACT ? "tdfa_stream_kernel<compact,pair>" : "tdfa_stream_kernel<pair>") : (COMPACT ? "tdfa_stream_kernel<compact>" : "tdfa_stream_kernel"))
                      : (BYTEROWS ? "tdfa_match_kernel<byterows>" : "tdfa_match_kernel"));
     // (hipLaunchKernel reports the launch's own status: no second runtime call to fetch it)

@@ -96,7 +96,10 @@ enum { kLabNoStamp = 1, kLabPreClass = 2, kLabGlobalClass = 4, kLabReplicated = 
        kLabCmapA8 = 2048 /* one-stamp pair kernel: the first byte's class from a u8 copy of cmapA built in LDS (class INDEX, scaled on the
                             VALU): 128 ASCII bytes = 32 dwords = 32 banks, where the u16 table puts byte b and b+64 on one bank (round 6) */,
        kLabPairOne = 4096 /* byte-pair chunks on a ONE-STAMP pair table (device_tables.h TP1_*, LC_TDFA_PAIR=2): exact */,
-       kLabMopUp = 8192 /* tdfa_stream_kernel: the launch behind a COMPACT one -- a small grid whose workgroups take the line blocks in turn */ };
+       kLabMopUp = 8192 /* tdfa_stream_kernel: the launch behind a COMPACT one -- a small grid whose workgroups take the line blocks in turn */,
+       kLabPersist = 16384 /* tdfa_stream_kernel, one-stamp pair tables: the launch is sized to the workgroups the chip holds, and every
+                              WAVEFRONT goes on with the lines of its place in the next block (tables staged once, no wait for the slowest
+                              wave of a workgroup before the slot is used again) */ };
 constexpr uint32_t kTdfaCmapA8Bytes = 272;  // 256 class indices + the identity class's index (a byte outside the line) + padding
 constexpr int kTdfaNoGeneralPrograms = kLabNoGeneral;  // the product's second instantiation (gpu_runtime.hip launchTdfaBlock)
 

@@ -336,7 +336,11 @@ __device__ __forceinline__ void tdfaStreamBody(
     const uint32_t cmapA8 = blobBytes + regBytes + (BLOCK / 64) * kStagePerWave;
     const uint32_t strideA8 = idCol + 4;
 
-    const uint32_t slot = blockId * BLOCK + tid;
+    const uint32_t tStart = t;
+    // ---- one block of BLOCK lines (everything from here on is the wavefront's own: its tile, its lanes' register columns)
+    auto walkBlock = [&](const uint32_t blockNow) {
+    t = tStart;
+    const uint32_t slot = blockNow * BLOCK + tid;
     bool live = slot < nLines;
     const uint32_t line = (live && order) ? order[slot] : slot;
     uint32_t o = 0, L = 0;
@@ -641,6 +645,30 @@ __device__ __forceinline__ void tdfaStreamBody(
     const uint32_t state = PAIR ? ((t & 0xFFFFu) - pi.base) / pi.rowBytes : ((t & 0xFFFFu) - TD_TRANS_OFFSET) / rowBytes;
     tdfaWriteResults<BLOCK, TdfaReg, LAB>(smem, stageBase, regsBase, state, live, line, L, from, order != nullptr, nGroupsOut, caps,
                                      status);
+    };  // walkBlock
+    if constexpr ((LAB & kLabPersist) != 0) {
+        // (round 6) PERSISTENT WAVEFRONTS.  The launch has as many workgroups as the chip holds (gpu_runtime.hip); workgroup b walks
+        // blocks b, b + grid, b + 2 grid, ... -- and since nothing below the table staging is shared between the wavefronts of a
+        // workgroup, every wavefront goes on with ITS 64 lines of the next block the moment it has written its results: no wait for
+        // the slowest of the eight before the slot is used again, tables staged once.  (Round 3 tried persistent WORKGROUPS on the
+        // kernel of that time and dropped them: 0.243 against 0.227 ms.)  Between blocks the wavefront zeroes its lanes' register
+        // columns ("every register starts at 0", above) behind its own LDS reads of the result tile.
+        static_assert(PAIR1 && COMPACT, "persistent wavefronts: the one-stamp COMPACT kernel only");
+        constexpr uint32_t kRegShift = (BLOCK == 1024 ? 12 : BLOCK == 512 ? 11 : BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8) -
+                                       (sizeof(TdfaReg) == 2 ? 1 : 0);
+        const uint32_t nBlocks = (nLines + BLOCK - 1) / BLOCK;
+        const uint32_t regRows = regBytes / (uint32_t(BLOCK) * uint32_t(sizeof(TdfaReg)));
+        const uint32_t myRegs = regsBase + tdfaRegLane<TdfaReg>(tid) * uint32_t(sizeof(TdfaReg));
+        for (uint32_t b = blockId; b < nBlocks; b += gridDim.x) {
+            walkBlock(b);
+            if (b + gridDim.x < nBlocks) {
+                tdfaLdsDrain();
+                for (uint32_t r = 0; r < regRows; ++r) *reinterpret_cast<LdsRegPtr>(myRegs + (r << kRegShift)) = TdfaReg(0);
+            }
+        }
+    } else {
+        walkBlock(blockId);
+    }
 }
 
 template <int BLOCK, bool COMPACT, bool PAIR = false, int LAB = 0>

@@ -632,6 +632,33 @@ def test_long_lines_behind_the_first_256_blocks_of_a_large_batch(torch_dev):
     assert exp_status.sum() > n // 2
 
 
+def test_persistent_wavefronts_of_the_one_stamp_kernel(torch_dev, monkeypatch):
+    """Round 6, measured and left off (LC_TDFA_PERSIST=1): the COMPACT one-stamp kernel launched with as many workgroups as the chip
+    holds, every wavefront going on with its 64 lines of the next block.  600 000 ragged lines (the launch needs two rounds of resident
+    workgroups to take this form), failing lines, empty lines and lines of 64 KiB and more among them, against the oracle."""
+    from oracle.oracle import OracleRegex
+    monkeypatch.setenv("LC_TDFA_PERSIST", "1")
+    pattern = rb"(\w+) (\d+) (.*)\|(\w*)"
+    rx = B.GpuRegex(pattern)
+    n = 600000
+    rng = random.Random(5)
+    subs = []
+    for i in range(n):
+        k = rng.randrange(12)
+        if k == 0: subs.append(b"")
+        elif k == 1: subs.append(b"no separator %d" % i)
+        else: subs.append(b"k%d %d %s|e%d" % (i, i * 3, b"x" * rng.randrange(0, 90), i % 7))
+    for where, size in ((5, 65536), (300001, 70001), (599999, 66000)):
+        subs[where] = b"key 12345 " + b"y" * (size - 14) + b"|end"
+    data, off, length = pack(subs)
+    exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off, length)
+    B.launched_kernels()
+    caps, status = run_device(torch_dev, rx, data, off, length, engine=B.LC_ENGINE_TDFA)
+    assert "persist" in str(B.launched_kernels())
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+    assert exp_status.sum() > n // 2
+
+
 def test_resumed_searches_on_long_lines_both_kernels(torch_dev):
     """lc_regex_match_device_from: a subset of the lines, each search resumed at its own offset (also beyond the first
     256-byte chunk of the NFA kernel and across the TDFA kernel's 64-byte stages), against the oracle's search(start)."""

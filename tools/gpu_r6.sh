@@ -81,6 +81,12 @@ relaxab)
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('relax_prefer=$1 big=$2', d['config']['workload'][-60:-40], d['ms_per_step'], 'ms', d['config']['batch']['pairs'], d['config']['parity']['both_paths_agree_on_every_line'])"; done; done | tee gpurun_out/r6/relaxab.txt ;;
+persistab)
+  # the headline kernel with persistent wavefronts (default) and with one workgroup per block (LC_TDFA_PERSIST=0): parity first, then A/B
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pair1_tables.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
+  for rep in 1 2; do for pz in 1 0; do LC_TDFA_PERSIST=$pz timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('persist=$pz', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernels_launched'], d['config'].get('parity'))"; done; done | tee gpurun_out/r6/persistab.txt
+  for L in 2097152 524288 300000; do LC_TDFA_PERSIST=1 timeout 300 python bench.py --lines $L --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('persist=1 lines $L', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernels_launched'])"; done | tee -a gpurun_out/r6/persistab.txt
+  LC_TDFA_PERSIST=1 timeout 300 python bench.py --regex B --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('regexB persist=1', d['ms_per_step'], d['roofline']['frac'])" | tee -a gpurun_out/r6/persistab.txt ;;
 groktests)
   timeout 1500 python -m pytest tests/test_gpu_grok.py tests/test_go_regex.py -m gpu -q -x 2>&1 | tail -5 | cut -c1-300 | tee gpurun_out/r6/pytest_grok.txt ;;
 esac
