@@ -1148,6 +1148,9 @@ int lcLaunchWaveJobs(const uint8_t* d_data, const TdfaWaveJob* jobs, uint32_t nJ
     for (uint32_t j = 0; j < kTdfaWaveMaxJobs; ++j) first[j] = j < nJobs ? jobs[j].firstBlock : 0xFFFFFFFFu;
     std::memcpy(first + kTdfaWaveMaxJobs, jobs, size_t(nJobs) * sizeof(TdfaWaveJob));
     HIP_TRY(hipMemcpyAsync(dTable, hTable, kTdfaWaveMaxJobs * 4 + size_t(nJobs) * sizeof(TdfaWaveJob), hipMemcpyHostToDevice, st));
+    // (LC_GROK_FUSED_LDS=<bytes>: at least that much LDS per workgroup -- fewer workgroups, so fewer wavefronts, per CU: the walk is scalar
+    // code, and a SIMD issues one scalar instruction every four cycles for ALL its wavefronts; A/B measurements)
+    if (const char* padEnv = getenv("LC_GROK_FUSED_LDS")) ldsBytes = std::max<uint32_t>(ldsBytes, uint32_t(atol(padEnv)));
     static thread_local size_t ldsAttrSet[kLcMaxDevices] = {};
     if (ldsBytes > 48 * 1024 && dev < kLcMaxDevices && ldsBytes > ldsAttrSet[dev]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tdfa_wave_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));

@@ -255,6 +255,9 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
             const uint32_t got = words[w < uWords ? w : uWords - 1u];
             return classesOf(w < uWords ? got : 0u);
         };
+#ifdef LC_WAVE_DEBUG  // (-DLC_WAVE_DEBUG: what the walk does on long values, one printf per wavefront; profiles/round6_wave_walk_counts.txt)
+        uint32_t dbgMoves = 0, dbgRuns = 0, dbgProgs = 0, dbgOps = 0, dbgScans = 0;
+#endif
         if (uIdx < uEnd && !stops(uState)) {
             for (;;) {  // (one byte per turn; leaves by break only)
                 if ((uIdx >> 8) != uChunk) {
@@ -267,12 +270,18 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
                 const uint32_t t = lcScalarLoad32(uTrans, (uState * uNcls + cls) << 2);
                 const uint32_t prog = t >> 16, next = t & 0xFFFFu;
                 if (prog) {
+#ifdef LC_WAVE_DEBUG
+                    ++dbgProgs;
+#endif
                     const uint32_t pos = uIdx - uHead;
                     if (staged) {
                         uint32_t at = __builtin_amdgcn_readfirstlane(lOpsStart[prog]);
                         const uint16_t* lOps = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lOpsStart) + opsDelta);
                         const uint32_t n = __builtin_amdgcn_readfirstlane(lOps[at]);
                         for (uint32_t k = 0; k < n; ++k) {  // (every lane stores the same word: one LDS write)
+#ifdef LC_WAVE_DEBUG
+                            ++dbgOps;
+#endif
                             const uint32_t op = __builtin_amdgcn_readfirstlane(lOps[++at]);
                             const uint32_t src = op >> 8;
                             regs[op & 0xFFu] = src == TD_REG_POS ? pos : regs[src];
@@ -294,9 +303,15 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
                 if (next == uState) {
                     if (stops(uState)) break;
                     // a quiet byte: find the end of the run -- every lane tests its 4 bytes of the chunk, chunk after chunk
+#ifdef LC_WAVE_DEBUG
+                    ++dbgRuns;
+#endif
                     const uint64_t quiet = lcScalarLoad64(uQuiet, uState << 3);
                     uint32_t stop = uEnd;
                     for (;;) {
+#ifdef LC_WAVE_DEBUG
+                        ++dbgScans;
+#endif
                         const uint32_t chunkBase = uChunk << 8;
                         uint32_t firstHit = 4;
 #pragma unroll
@@ -323,11 +338,19 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
                 }
                 // (the dead state ends the walk at once; the absorbing state and the MISS sink keep themselves on every class without a
                 // program -- regex_handle.cpp packTdfaL2Blob, tdfa.cpp -- and end it at the next byte, in the branch above)
+#ifdef LC_WAVE_DEBUG
+                ++dbgMoves;
+#endif
                 uState = next;
                 ++uIdx;
                 if (uIdx >= uEnd || uState == 0u) break;
             }
         }
+#ifdef LC_WAVE_DEBUG
+        if (lane == 0 && L >= 2500)
+            printf("wavewalk L %u walked %u moves %u runs %u scans %u progs %u ops %u staged %u ncls %u nstates %u\n", L, uIdx - uHead, dbgMoves, dbgRuns, dbgScans,
+                   dbgProgs, dbgOps, staged ? 1u : 0u, uNcls, blob[TL_NSTATES]);
+#endif
         state = uState;
         idx = uIdx;
     } else
