@@ -308,20 +308,28 @@ __device__ __forceinline__ void tdfaWaveBody(const uint8_t* __restrict__ data, c
 #endif
                     const uint64_t quiet = lcScalarLoad64(uQuiet, uState << 3);
                     uint32_t stop = uEnd;
+                    const uint32_t qlo = uint32_t(quiet), qhi = uint32_t(quiet >> 32);
                     for (;;) {
 #ifdef LC_WAVE_DEBUG
                         ++dbgScans;
 #endif
                         const uint32_t chunkBase = uChunk << 8;
-                        uint32_t firstHit = 4;
+                        // (32-bit tests: the 64-bit shifts and compares the compiler made of `(quiet >> c) & 1` run at a quarter of the rate)
+                        uint32_t notQuiet = 0;  // bit j: byte j of the lane's four is of a class outside the mask
 #pragma unroll
-                        for (int j = 3; j >= 0; --j) {
-                            const uint32_t bi = chunkBase + lane * 4 + uint32_t(j);
+                        for (int j = 0; j < 4; ++j) {
                             const uint32_t c = (curWord >> (8 * j)) & 0xFFu;
-                            const bool isQuiet = c < 64 && ((quiet >> c) & 1ull);
-                            if (bi > uIdx && bi < uEnd && !isQuiet) firstHit = uint32_t(j);
+                            const uint32_t qw = (c & 32u) ? qhi : qlo;
+                            const uint32_t q = (c < 64u) ? ((qw >> (c & 31u)) & 1u) : 0u;
+                            notQuiet |= (q ^ 1u) << j;
                         }
-                        const uint64_t hit = __ballot(firstHit < 4);
+                        // bytes behind the position and inside the value: j > idx - base and j < end - base
+                        const int32_t base = int32_t(chunkBase + lane * 4u);
+                        const int32_t lo = int32_t(uIdx) + 1 - base, hi = int32_t(uEnd) - base;
+                        const uint32_t loC = uint32_t(lo < 0 ? 0 : lo > 4 ? 4 : lo), hiC = uint32_t(hi < 0 ? 0 : hi > 4 ? 4 : hi);
+                        notQuiet &= ((1u << hiC) - 1u) & ~((1u << loC) - 1u);
+                        const uint32_t firstHit = notQuiet ? uint32_t(__ffs(int(notQuiet))) - 1u : 4u;
+                        const uint64_t hit = __ballot(notQuiet != 0u);
                         if (hit) {
                             const int l = __ffsll((long long)hit) - 1;
                             stop = chunkBase + uint32_t(l) * 4 + uint32_t(__builtin_amdgcn_readlane(int(firstHit), l));
