@@ -696,10 +696,15 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
                 hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, 1), dim3(kGrokPlanBlock), size_t(sliceLen) * 4 + (small ? screenLds : 0), st,
                                    d_data, d_off, d_len, n, sliceLen, screens + k, reinterpret_cast<unsigned long long*>(masks),
                                    static_cast<const uint32_t*>(order), (small ? 1u : 0u) | screenWalk);
-        } else if (nScreens > nBig)
-            hipLaunchKernelGGL(grok_screen_all_kernel, dim3(slices, nScreens - nBig), dim3(kGrokPlanBlock),
+        } else if (nScreens > nBig) {
+            // (grid (screens, slices): the slices of the longest values first -- grok_plan_kernel.hpp; LC_GROK_SCREEN_TRANSPOSED=0: as before)
+            const char* tv = getenv("LC_GROK_SCREEN_TRANSPOSED");
+            const bool transposed = !(tv && tv[0] == '0') && slices <= 65535u;
+            hipLaunchKernelGGL(grok_screen_all_kernel, transposed ? dim3(nScreens - nBig, slices) : dim3(slices, nScreens - nBig), dim3(kGrokPlanBlock),
                                size_t(sliceLen) * 4 + (small ? screenLds : 0), st, d_data, d_off, d_len, n, sliceLen, screens + nBig,
-                               reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order), (small ? 1u : 0u) | screenWalk);
+                               reinterpret_cast<unsigned long long*>(masks), static_cast<const uint32_t*>(order),
+                               (small ? 1u : 0u) | screenWalk | (transposed ? 128u : 0u));
+        }
         if (nBig) HIP_TRY(hipStreamWaitEvent(st, T.join[0], 0));
         if (trace && nBig)
             fprintf(stderr, "grok plan 1: %u big screens in a launch of their own (%u KB of LDS per workgroup)\n", nBig,

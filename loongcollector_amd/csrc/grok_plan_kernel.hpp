@@ -316,9 +316,14 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint8_t cmap[256];
     __shared__ uint32_t sCount;
-    const GrokScreenDev sc = screens[blockIdx.y];
+    // (round 6) + 128: the grid is (screens, slices) instead of (slices, screens) -- workgroups are dispatched x first, the slices are in
+    // LENGTH order, and a launch lasts as long as its longest value: slice 0 of EVERY screen goes out first, instead of the last
+    // screens' slice 0 behind two thousand workgroups of short values
+    const bool transposed = (stageAndWalk & 128u) != 0;
+    const uint32_t sliceIdx = transposed ? blockIdx.y : blockIdx.x;
+    const GrokScreenDev sc = screens[transposed ? blockIdx.x : blockIdx.y];
     const uint32_t tid = threadIdx.x;
-    const uint32_t lo = blockIdx.x * sliceLen;
+    const uint32_t lo = sliceIdx * sliceLen;
     const uint32_t hi = lo + sliceLen < n ? lo + sliceLen : n;
     if (tid == 0) sCount = 0;
     __syncthreads();
