@@ -621,7 +621,30 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         int rc = grokLiteralIndex(patterns, state, dev, &literalIndex);
         if (rc != LC_OK) return rc;
     }
-    if (literalIndex && small) {
+    // (round 6) the index's tables in LDS when two workgroups of them fit a CU: grok_literal_lds_kernel.  LC_GROK_LITERAL_LDS=0: through L2.
+    const uint32_t litStageBytes = [&]() -> uint32_t {
+        const char* v = getenv("LC_GROK_LITERAL_LDS");
+        if (!literalIndex || !small || (v && v[0] == '0')) return 0u;
+        const uint32_t bytes = uint32_t(state->literalBlob.size() * 4) - state->literalBlob[GL_OFF_MASKS];
+        return ((state->literalBlob[GL_OFF_MASKS] & 7u) == 0 && bytes <= 78 * 1024) ? bytes : 0u;
+    }();
+    if (litStageBytes) {
+        static thread_local size_t litAttr[kLcMaxDevices] = {};
+        if (litStageBytes > 48 * 1024 && dev < kLcMaxDevices && litStageBytes > litAttr[dev]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grok_literal_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(litStageBytes)));
+            litAttr[dev] = litStageBytes;
+        }
+        static thread_local uint32_t cus[kLcMaxDevices] = {};
+        if (dev < kLcMaxDevices && !cus[dev]) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            cus[dev] = uint32_t(prop.multiProcessorCount);
+        }
+        const uint32_t slots = 2u * (dev < kLcMaxDevices && cus[dev] ? cus[dev] : 256u);
+        lcNoteKernel("grok_literal_lds_kernel");
+        hipLaunchKernelGGL(grok_literal_lds_kernel, dim3(std::min(slots, (n + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64))), dim3(kGrokPlanBlock),
+                           litStageBytes, st, d_data, d_off, d_len, n, literalIndex, masks, litStageBytes);
+    } else if (literalIndex && small) {
         lcNoteKernel("grok_literal_chunk_kernel");
         hipLaunchKernelGGL(grok_literal_chunk_kernel, dim3((n + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64)), dim3(kGrokPlanBlock), 0, st,
                            d_data, d_off, d_len, n, literalIndex, masks);

@@ -148,6 +148,68 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_chunk_kernel(cons
     if (lane == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
 }
 
+// ---- the same index with its tables in LDS (round 6).  The index of configs[2] is 547 states x 61 classes (67 KB) + 4 KB of output
+// masks: every step of a lane's chunk was a dependent u16 load through L1 / L2 behind a byte load -- 95 steps of ~450 cycles, 0.14 ms
+// for a 16 Ki-value batch of which a fifth was the literal pass.  Here the launch has as many workgroups as the chip holds (two per
+// CU at 71 KB), each stages [masks | table] once and takes values in turn, one per wavefront; a chunk's bytes are loaded and mapped to
+// classes sixteen at a time, in front of the sixteen dependent LDS reads.  stageBytes = the blob from GL_OFF_MASKS to its end.
+__global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_lds_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
+                                                                         const uint32_t* __restrict__ len, uint32_t n,
+                                                                         const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks,
+                                                                         uint32_t stageBytes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t litWords[];
+    __shared__ uint8_t cmap[256];
+    cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
+    {
+        const uint32_t* src = blob + blob[GL_OFF_MASKS] / 4;
+        for (uint32_t i = threadIdx.x; i < stageBytes / 4; i += kGrokPlanBlock) litWords[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, ncls = blob[GL_NCLASSES];
+    const uint64_t* outMask = reinterpret_cast<const uint64_t*>(litWords);
+    const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(litWords) + (blob[GL_OFF_TABLE] - blob[GL_OFF_MASKS]));
+    const uint64_t always = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
+    for (uint32_t v = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6); v < n; v += gridDim.x * (kGrokPlanBlock / 64)) {  // wave-uniform
+        const uint32_t L = len[v];
+        const uint8_t* p = data + off[v];
+        uint64_t mask = 0;
+        for (uint32_t c0 = lane * kGrokChunk; c0 < L; c0 += 64 * kGrokChunk) {
+            const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
+            const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
+            uint32_t state = 0;
+            uint32_t i = lo;
+            // (16 bytes per load: the lanes' chunks are 64 bytes apart, so every load instruction of the wavefront is 64 cache-line requests
+            // whatever its width -- byte loads made the pass 95 x 64 requests per value, and the request rate of the vector L1, not a
+            // latency, was what the pass waited for.  gfx950 takes the unaligned 16-byte loads, as in tdfa_stream_kernel.)
+            for (; i + 16 <= hi; i += 16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                uint32_t cls[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) cls[k] = cmap[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t e = table[state * ncls + cls[k]];
+                    state = e & 0x7FFFu;
+                    if (e & 0x8000u) mask |= outMask[state];
+                }
+            }
+            for (; i < hi; ++i) {
+                const uint32_t e = table[state * ncls + cmap[p[i]]];
+                state = e & 0x7FFFu;
+                if (e & 0x8000u) mask |= outMask[state];
+            }
+        }
+        uint32_t mlo = uint32_t(mask), mhi = uint32_t(mask >> 32);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mlo |= uint32_t(__shfl_xor(int(mlo), d, 64));
+            mhi |= uint32_t(__shfl_xor(int(mhi), d, 64));
+        }
+        if (lane == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | always;
+    }
+}
+
 // The walk of a yes/no screen DFA over [p, p + L): one value per lane, 16 bytes per global load.  Round 5: the NEXT 16 bytes are
 // loaded while these are walked, their 16 classes are looked up before the chain starts (independent LDS reads), and a chunk that
 // lies wholly inside the value takes a copy of the chain without per-byte bounds tests -- what remains per byte is the one dependent
@@ -393,6 +455,16 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_screen_all_kernel(const u
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_count_kernel(const uint64_t* __restrict__ masks, uint32_t n, uint32_t nPatterns,
                                                                    uint32_t* __restrict__ perEntry, uint32_t* __restrict__ firstOf,
                                                                    uint32_t* __restrict__ shadowBy) {
+    // (round 6) The counts gather in LDS and leave the workgroup as ONE add per cell: a hot cell (a general format behind a specific one:
+    // a thousand values) used to take a thousand device-wide adds on one word, one after the other at the L2 -- 0.06 ms for a launch
+    // that reads 128 KB.
+    __shared__ uint32_t sPer[64], sFirst[64], sShadow[64 * 64];
+    for (uint32_t i = threadIdx.x; i < 64 * 64; i += kGrokPlanBlock) sShadow[i] = 0;
+    if (threadIdx.x < 64) {
+        sPer[threadIdx.x] = 0;
+        sFirst[threadIdx.x] = 0;
+    }
+    __syncthreads();
     const uint32_t v = blockIdx.x * kGrokPlanBlock + threadIdx.x;
     const uint64_t m = v < n ? masks[v] : 0;
     const uint32_t lowest = m ? uint32_t(__ffsll(static_cast<long long>(m))) - 1u : 64u;
@@ -401,18 +473,29 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_count_kernel(const uint64
         while (rest) {
             const uint32_t p = uint32_t(__ffsll(static_cast<long long>(rest))) - 1u;
             rest &= rest - 1;
-            atomicAdd(&shadowBy[p * 64 + lowest], 1u);
+            atomicAdd(&sShadow[p * 64 + lowest], 1u);
         }
     }
-    for (uint32_t p = 0; p < nPatterns; ++p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t mine = 0, mineFirst = 0;
+    for (uint32_t p = 0; p < nPatterns; ++p) {  // lane p holds the wavefront's counts of pattern p
         const uint64_t has = __ballot((m >> p) & 1ull);
-        if (!has) continue;
         const uint64_t isFirst = __ballot(lowest == p);
-        if ((threadIdx.x & 63u) == 0) {
-            atomicAdd(&perEntry[p], uint32_t(__popcll(has)));
-            if (isFirst) atomicAdd(&firstOf[p], uint32_t(__popcll(isFirst)));
+        if (lane == p) {
+            mine = uint32_t(__popcll(has));
+            mineFirst = uint32_t(__popcll(isFirst));
         }
     }
+    if (mine) atomicAdd(&sPer[lane], mine);
+    if (mineFirst) atomicAdd(&sFirst[lane], mineFirst);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        if (sPer[threadIdx.x]) atomicAdd(&perEntry[threadIdx.x], sPer[threadIdx.x]);
+        if (sFirst[threadIdx.x]) atomicAdd(&firstOf[threadIdx.x], sFirst[threadIdx.x]);
+    }
+    if (shadowBy)
+        for (uint32_t i = threadIdx.x; i < 64 * 64; i += kGrokPlanBlock)
+            if (sShadow[i]) atomicAdd(&shadowBy[i], sShadow[i]);
 }
 
 // every (entry, value) pair that passed becomes a slot of the entry

@@ -497,7 +497,7 @@ def test_plan_knobs_and_histories_do_not_change_a_result(torch_dev, golden_dir, 
               "LC_GROK_SCREEN_WAVE": "1"}
     off = {"LC_GROK_WIDE_FIRST": "0", "LC_GROK_EARLY_ROUNDS": "0", "LC_GROK_BREADTH": "0", "LC_GROK_REMAINDER_LITERAL": "0",
            "LC_GROK_BOUND": "0", "LC_GROK_REMAINDER_WON": "0", "LC_GROK_SLICE": "512", "LC_GROK_REMAINDER_INCHAIN": "0", "LC_GROK_POST_IN_STREAM": "0",
-           "LC_GROK_LAZY_SYNC3": "0", "LC_GROK_FUSED_ROUND0": "0", "LC_GROK_SCREEN_SCALED": "0", "LC_GROK_FLAT": "0", "LC_GROK_SCREEN_TRANSPOSED": "0"}
+           "LC_GROK_LAZY_SYNC3": "0", "LC_GROK_FUSED_ROUND0": "0", "LC_GROK_SCREEN_SCALED": "0", "LC_GROK_FLAT": "0", "LC_GROK_SCREEN_TRANSPOSED": "0", "LC_GROK_LITERAL_LDS": "0"}
     # (round 6) the remainder screens queued ahead of the host's read of round 0's counts: off alone (everything else as shipped), and
     # with the search rounds forced ahead (the entries then leave the launch through its skip mask)
     ahead_off = {"LC_GROK_REMAINDER_AHEAD": "0"}

@@ -13,7 +13,7 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
 sel = 'select name, start, "end", grid_x, %s from kernels order by start' % (qcol or "0")
 rows = list(cur.execute(sel))
-starts = [i for i, r in enumerate(rows) if r[0].startswith(("grok_literal_index_kernel", "grok_literal_chunk_kernel", "grok_mask_fill_kernel"))]
+starts = [i for i, r in enumerate(rows) if r[0].startswith(("grok_literal_index_kernel", "grok_literal_chunk_kernel", "grok_literal_lds_kernel", "grok_mask_fill_kernel"))]
 if not starts:
     raise SystemExit("no Grok batch in the trace")
 first = starts[-1]
