@@ -642,8 +642,9 @@ int grokMatchSpeculative(const std::vector<GrokDevicePattern>& patterns, GrokDev
         }
         const uint32_t slots = 2u * (dev < kLcMaxDevices && cus[dev] ? cus[dev] : 256u);
         lcNoteKernel("grok_literal_lds_kernel");
-        hipLaunchKernelGGL(grok_literal_lds_kernel, dim3(std::min(slots, (n + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64))), dim3(kGrokPlanBlock),
-                           litStageBytes, st, d_data, d_off, d_len, n, literalIndex, masks, litStageBytes);
+        const uint32_t quadBlocks = ((n + 3) / 4 + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64);  // (a wavefront takes four values at a time)
+        hipLaunchKernelGGL(grok_literal_lds_kernel, dim3(std::min(slots, quadBlocks)), dim3(kGrokPlanBlock), litStageBytes, st, d_data, d_off, d_len, n,
+                           literalIndex, masks, litStageBytes, static_cast<const uint32_t*>(order));
     } else if (literalIndex && small) {
         lcNoteKernel("grok_literal_chunk_kernel");
         hipLaunchKernelGGL(grok_literal_chunk_kernel, dim3((n + kGrokPlanBlock / 64 - 1) / (kGrokPlanBlock / 64)), dim3(kGrokPlanBlock), 0, st,

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_chunk_kernel(cons
 __global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_lds_kernel(const uint8_t* __restrict__ data, const uint32_t* __restrict__ off,
                                                                          const uint32_t* __restrict__ len, uint32_t n,
                                                                          const uint32_t* __restrict__ blob, uint64_t* __restrict__ masks,
-                                                                         uint32_t stageBytes) {
+                                                                         uint32_t stageBytes, const uint32_t* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) uint32_t litWords[];
     __shared__ uint8_t cmap[256];
     cmap[threadIdx.x] = reinterpret_cast<const uint8_t*>(blob + GL_HEADER_WORDS)[threadIdx.x];
@@ -169,44 +169,63 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_literal_lds_kernel(const 
     const uint64_t* outMask = reinterpret_cast<const uint64_t*>(litWords);
     const uint16_t* table = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(litWords) + (blob[GL_OFF_TABLE] - blob[GL_OFF_MASKS]));
     const uint64_t always = uint64_t(blob[GL_ALWAYS_LO]) | (uint64_t(blob[GL_ALWAYS_HI]) << 32);
-    for (uint32_t v = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6); v < n; v += gridDim.x * (kGrokPlanBlock / 64)) {  // wave-uniform
-        const uint32_t L = len[v];
-        const uint8_t* p = data + off[v];
-        uint64_t mask = 0;
-        for (uint32_t c0 = lane * kGrokChunk; c0 < L; c0 += 64 * kGrokChunk) {
-            const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
-            const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
-            uint32_t state = 0;
-            uint32_t i = lo;
-            // (16 bytes per load: the lanes' chunks are 64 bytes apart, so every load instruction of the wavefront is 64 cache-line requests
-            // whatever its width -- byte loads made the pass 95 x 64 requests per value, and the request rate of the vector L1, not a
-            // latency, was what the pass waited for.  gfx950 takes the unaligned 16-byte loads, as in tdfa_stream_kernel.)
-            for (; i + 16 <= hi; i += 16) {
-                const uint4 q = *reinterpret_cast<const uint4*>(p + i);
-                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-                uint32_t cls[16];
+    // A wavefront takes FOUR values at a time, neighbours in the length order: a lane's work is one 64-byte chunk whatever the value's
+    // length, and the mean value (1.1 KB) kept 18 of 64 lanes busy.  Four values of up to 1 KiB share the wavefront (16 lanes each), of
+    // up to 2 KiB two by two, longer ones take it in turn.
+    const uint32_t nQuads = (n + 3u) / 4u;
+    for (uint32_t quad = blockIdx.x * (kGrokPlanBlock / 64) + (threadIdx.x >> 6); quad < nQuads; quad += gridDim.x * (kGrokPlanBlock / 64)) {  // wave-uniform
+        uint32_t myLen = 0;
+        if (lane < 4u && quad * 4u + lane < n) myLen = len[order ? order[quad * 4u + lane] : quad * 4u + lane];
+        uint32_t longest = myLen;
+        longest = max(longest, uint32_t(__shfl_xor(int(longest), 1, 64)));
+        longest = max(longest, uint32_t(__shfl_xor(int(longest), 2, 64)));
+        longest = uint32_t(__builtin_amdgcn_readfirstlane(longest));
+        const uint32_t groupLanes = longest <= 16u * kGrokChunk ? 16u : longest <= 32u * kGrokChunk ? 32u : 64u;
+        const uint32_t perPass = 64u / groupLanes;
+        for (uint32_t first = 0; first < 4u; first += perPass) {
+            const uint32_t at = quad * 4u + first + lane / groupLanes;
+            const bool have = at < n && lane / groupLanes < perPass;
+            const uint32_t v = have ? (order ? order[at] : at) : 0u;
+            const uint32_t L = have ? len[v] : 0u;
+            const uint8_t* p = data + (have ? off[v] : 0u);
+            const uint32_t lg = lane % groupLanes;
+            uint64_t mask = 0;
+            for (uint32_t c0 = lg * kGrokChunk; c0 < L; c0 += groupLanes * kGrokChunk) {
+                const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
+                const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
+                uint32_t state = 0;
+                uint32_t i = lo;
+                // (16 bytes per load: the lanes' chunks are 64 bytes apart, so every load instruction of the wavefront is 64 cache-line
+                // requests whatever its width.  gfx950 takes the unaligned 16-byte loads, as in tdfa_stream_kernel.)
+                for (; i + 16 <= hi; i += 16) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                    uint32_t cls[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) cls[k] = cmap[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+                    for (int k = 0; k < 16; ++k) cls[k] = cmap[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t e = table[state * ncls + cls[k]];
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t e = table[state * ncls + cls[k]];
+                        state = e & 0x7FFFu;
+                        if (e & 0x8000u) mask |= outMask[state];
+                    }
+                }
+                for (; i < hi; ++i) {
+                    const uint32_t e = table[state * ncls + cmap[p[i]]];
                     state = e & 0x7FFFu;
                     if (e & 0x8000u) mask |= outMask[state];
                 }
             }
-            for (; i < hi; ++i) {
-                const uint32_t e = table[state * ncls + cmap[p[i]]];
-                state = e & 0x7FFFu;
-                if (e & 0x8000u) mask |= outMask[state];
-            }
-        }
-        uint32_t mlo = uint32_t(mask), mhi = uint32_t(mask >> 32);
+            uint32_t mlo = uint32_t(mask), mhi = uint32_t(mask >> 32);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            mlo |= uint32_t(__shfl_xor(int(mlo), d, 64));
-            mhi |= uint32_t(__shfl_xor(int(mhi), d, 64));
+            for (int d = 32; d >= 1; d >>= 1) {
+                if (uint32_t(d) < groupLanes) {  // (wave-uniform: the OR stays inside the value's lanes)
+                    mlo |= uint32_t(__shfl_xor(int(mlo), d, 64));
+                    mhi |= uint32_t(__shfl_xor(int(mhi), d, 64));
+                }
+            }
+            if (have && lg == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | always;
         }
-        if (lane == 0) masks[v] = (uint64_t(mhi) << 32) | mlo | always;
     }
 }
 
@@ -752,7 +771,23 @@ __global__ __launch_bounds__(kGrokPlanBlock) void grok_remainder_literal_kernel(
         const uint32_t lo = c0 >= kGrokLookBehind ? c0 - kGrokLookBehind : 0;
         const uint32_t hi = c0 + kGrokChunk < L ? c0 + kGrokChunk : L;
         uint32_t state = 0;
-        for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t i = lo;
+        // (round 6: sixteen bytes per load and their classes looked up in front of the chain, as in grok_literal_lds_kernel -- what is left
+        // per byte is the table read)
+        for (; i + 16 <= hi; i += 16) {
+            const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t cls[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cls[k] = cmap[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t t = table[state * ncls + cls[k]];
+                state = t & 0x7FFFu;
+                if ((t & 0x8000u) && ((outMask[state] >> e.bit) & 1ull)) hit = 1;
+            }
+        }
+        for (; i < hi; ++i) {
             const uint32_t t = table[state * ncls + cmap[p[i]]];
             state = t & 0x7FFFu;
             if ((t & 0x8000u) && ((outMask[state] >> e.bit) & 1ull)) hit = 1;
