@@ -68,9 +68,14 @@ enum {
     LC_ENGINE_AUTO = 0,  /* TDFA if it fits the limits, else NFA */
     LC_ENGINE_TDFA = 1,  /* tagged DFA: one line per lane, tables in LDS */
     LC_ENGINE_NFA = 2,   /* follow NFA: one line per wavefront, one lane per live thread */
-    LC_ENGINE_DECIDE = 3 /* match calls only (not lc_regex_compile): skip the thread-list kernels and settle EVERY line with the
+    LC_ENGINE_DECIDE = 3, /* match calls only (not lc_regex_compile): skip the thread-list kernels and settle EVERY line with the
                             depth-first decide kernel that normally only sees the lines they overflow on.  Slow (one lane per
                             line); for cross-checking the engines against each other and for diagnosis */
+    LC_ENGINE_BT = 4      /* round 6: the device BACKTRACKING engine (csrc/bt_vm.hpp): one line per lane, an instruction program and
+                            an explicit stack in HBM -- what boost::regex_match itself does (StringTools.cpp:183-211).  Chosen by
+                            LC_ENGINE_AUTO for patterns that are not regular (back-references \1 .. \N); may be asked for any
+                            pattern it can run, which is how the tests cross-check it against the automata.  A line that runs out
+                            of its step budget or stack is LC_GAVE_UP */
 };
 
 /* per-line status bytes */
@@ -98,7 +103,7 @@ enum {
 };
 
 typedef struct lc_regex_info {
-    int engine;            /* LC_ENGINE_TDFA or LC_ENGINE_NFA */
+    int engine;            /* LC_ENGINE_TDFA, LC_ENGINE_NFA or LC_ENGINE_BT */
     int mark_count;        /* capture groups */
     uint32_t positions;    /* follow-NFA positions (byte-consuming steps) */
     uint32_t states;       /* TDFA states (0 for NFA engine) */
@@ -135,8 +140,9 @@ enum {
     LC_TABLE_TDFA_WIDE_BLOB = 10, /* small automata only: the same with byte-indexed rows, for the 1024-lane kernel */
     LC_TABLE_TDFA_L2_BLOB = 11,  /* automata too large for the LDS kernels: the tables as the global-memory kernel reads them
                                     (csrc/tdfa_l2_layout.h); such a handle has no LC_TABLE_TDFA_BLOB */
-    LC_TABLE_LAZY_TDFA_BLOB = 12 /* thread-list handles that have been trained (lc_regex_lazy_train): the partial automaton in the same
+    LC_TABLE_LAZY_TDFA_BLOB = 12, /* thread-list handles that have been trained (lc_regex_lazy_train): the partial automaton in the same
                                     layout, TL_MISS != 0; valid until the handle's next training call */
+    LC_TABLE_BT_BLOB = 13        /* LC_ENGINE_BT handles: the backtracking program uploaded to the device (csrc/bt_vm.hpp) */
 };
 int lc_regex_table(const lc_regex_t* re, int which, const void** data, size_t* bytes);
 

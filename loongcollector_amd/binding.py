@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LC_REGEX_GPU_LIB", os.path.join(_HERE, "lib", "liblc_regex_gpu.so"))
 
-LC_ENGINE_AUTO, LC_ENGINE_TDFA, LC_ENGINE_NFA, LC_ENGINE_DECIDE = 0, 1, 2, 3
+LC_ENGINE_AUTO, LC_ENGINE_TDFA, LC_ENGINE_NFA, LC_ENGINE_DECIDE, LC_ENGINE_BT = 0, 1, 2, 3, 4
 LC_NOMATCH, LC_MATCH, LC_OVERFLOW, LC_GAVE_UP = 0, 1, 2, 3
 LC_OK, LC_ERR_SYNTAX, LC_ERR_UNSUPPORTED, LC_ERR_NO_DEVICE, LC_ERR_HIP, LC_ERR_ARG = range(6)
 LC_SYNTAX_ICASE, LC_SYNTAX_NO_DOTALL, LC_SYNTAX_NO_MULTILINE, LC_SYNTAX_EXTENDED, LC_SYNTAX_NAMED_ONLY = 1, 2, 4, 8, 16
@@ -24,6 +24,7 @@ LC_SYNTAX_PREFIX = 128
  LC_TABLE_TDFA_FINALMAP, LC_TABLE_TDFA_HEADER, LC_TABLE_NFA_BLOB, LC_TABLE_TDFA_STARTAFTER, LC_TABLE_TDFA_BLOB,
  LC_TABLE_TDFA_WIDE_BLOB, LC_TABLE_TDFA_L2_BLOB) = range(12)
 LC_TABLE_LAZY_TDFA_BLOB = 12
+LC_TABLE_BT_BLOB = 13
 
 
 class LcRegexInfo(ctypes.Structure):

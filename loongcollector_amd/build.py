@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "liblc_regex_gpu.so")
 # end_to_end.in_agent_reference_shape_MBps -- what an agent build's event model lets one runner thread do; never the default.
 LIB_REFSHAPE = os.path.join(LIBDIR, "liblc_regex_gpu_refshape.so")
 
-SOURCES = ["regex_parse.cpp", "atomic_elide.cpp", "follow_nfa.cpp", "tdfa.cpp", "table_cache.cpp", "screen_dfa.cpp", "regex_handle.cpp", "gpu_runtime.hip", "grok_device.hip", "multiline_device.hip"]
+SOURCES = ["regex_parse.cpp", "atomic_elide.cpp", "follow_nfa.cpp", "tdfa.cpp", "table_cache.cpp", "screen_dfa.cpp", "bt_program.cpp", "regex_handle.cpp", "gpu_runtime.hip", "grok_device.hip", "multiline_device.hip"]
 OPTIONAL_SOURCES = ["event_model.cpp", "processor_parse_regex_gpu.cpp", "grok.cpp", "grok_literal_index.cpp", "processor_grok_gpu.cpp", "processor_filter_gpu.cpp", "processor_go_regex_gpu.cpp", "multiline_gpu.cpp", "multiline_events.cpp", "processor_pipeline_gpu.cpp", "c_processor_slot.cpp"]
 
 

@@ -31,6 +31,7 @@
 #include "nfa_kernel.hpp"
 #include "nfa_wide_kernel.hpp"
 #include "nfa_decide_kernel.hpp"
+#include "bt_kernel.hpp"
 #include "regex_handle.hpp"
 #include "sched_kernel.hpp"
 #include "screen_kernel.hpp"
@@ -203,18 +204,20 @@ int lcDeviceEntryDevice(const void* d_ptr, int* dev) {
 }
 
 // ------------------------------------------------------------------------------------------------ device tables
-enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3, kBlobTdfaL2 = 4 };
+enum { kBlobNfa = 0, kBlobTdfa = 1, kBlobTdfaWide = 2, kBlobScreen = 3, kBlobTdfaL2 = 4, kBlobBt = 5 };
 static int ensureUploaded(lc_regex* re, int dev, int which, void** out) {
     std::lock_guard<std::mutex> g(re->deviceMutex);
     void** slot = which == kBlobTdfa ? &re->dTdfaBlob[dev]
                   : which == kBlobTdfaWide ? &re->dTdfaWideBlob[dev]
                   : which == kBlobScreen ? &re->dScreenBlob[dev]
-                  : which == kBlobTdfaL2 ? &re->dTdfaL2Blob[dev] : &re->dNfaBlob[dev];
+                  : which == kBlobTdfaL2 ? &re->dTdfaL2Blob[dev]
+                  : which == kBlobBt ? &re->dBtBlob[dev] : &re->dNfaBlob[dev];
     if (!*slot) {
         const std::vector<uint32_t>& blob = which == kBlobTdfa ? re->tdfaBlob
                                             : which == kBlobTdfaWide ? re->tdfaWideBlob
                                             : which == kBlobScreen ? re->screenBlob
-                                            : which == kBlobTdfaL2 ? re->tdfaL2Blob : re->nfaBlob;
+                                            : which == kBlobTdfaL2 ? re->tdfaL2Blob
+                                            : which == kBlobBt ? re->btBlob : re->nfaBlob;
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, blob.size() * 4 + 16));  // + one word behind the tables: the compact kernel's long-line flag
         hipError_t e = hipMemset(p, 0, blob.size() * 4 + 16);
@@ -271,15 +274,16 @@ void lcReleaseDeviceTables(lc_regex* re) {
         Z.retired.clear();
     }
     for (int d = 0; d < kLcMaxDevices; ++d) {
-        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d] || re->dTdfaL2Blob[d]) {
+        if (re->dTdfaBlob[d] || re->dNfaBlob[d] || re->dTdfaWideBlob[d] || re->dScreenBlob[d] || re->dTdfaL2Blob[d] || re->dBtBlob[d]) {
             if (hipSetDevice(d) == hipSuccess) {
+                if (re->dBtBlob[d]) (void)hipFree(re->dBtBlob[d]);
                 if (re->dTdfaL2Blob[d]) (void)hipFree(re->dTdfaL2Blob[d]);
                 if (re->dScreenBlob[d]) (void)hipFree(re->dScreenBlob[d]);
                 if (re->dTdfaBlob[d]) (void)hipFree(re->dTdfaBlob[d]);
                 if (re->dTdfaWideBlob[d]) (void)hipFree(re->dTdfaWideBlob[d]);
                 if (re->dNfaBlob[d]) (void)hipFree(re->dNfaBlob[d]);
             }
-            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = re->dScreenBlob[d] = re->dTdfaL2Blob[d] = nullptr;
+            re->dTdfaBlob[d] = re->dNfaBlob[d] = re->dTdfaWideBlob[d] = re->dScreenBlob[d] = re->dTdfaL2Blob[d] = re->dBtBlob[d] = nullptr;
         }
     }
     if (haveCur) (void)hipSetDevice(cur);
@@ -1208,11 +1212,51 @@ bool lcNfaWideApplies(const lc_regex* re) {
     return (size_t((nPos + 3) & ~3u) + 3 * kNfaWideThreads + 64) * 4 <= 64 * 1024;
 }
 
+// The backtracking engine (bt_kernel.hpp): patterns with back-references.  The scratch pool of the launch -- 64 KB per lane in flight
+// -- is allocated and freed in stream order, so concurrent callers of one handle never share a stack.
+static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n,
+                    const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
+                    hipStream_t stream) {
+    if (re->btBlob.empty()) {
+        tlsError = "pattern has no backtracking program";
+        return LC_ERR_UNSUPPORTED;
+    }
+    void* dBlob = nullptr;
+    const int rc = ensureUploaded(re, dev, kBlobBt, &dBlob);
+    if (rc != LC_OK) return rc;
+    const uint32_t blobWords = uint32_t(re->btBlob.size());
+    const uint32_t stageWords = blobWords * 4 <= kBtStageMaxBytes ? blobWords : 0u;
+    const uint32_t blocks = std::min<uint32_t>((n + kBtBlock - 1) / kBtBlock, kBtMaxLanes / kBtBlock);
+    uint32_t budget = kBtDefaultBudget;
+    if (const char* e = getenv("LC_BT_BUDGET")) budget = uint32_t(strtoul(e, nullptr, 10));  // (read per launch: tests)
+    const uint32_t need = re->btBlob[BT_NCAPS] + re->btBlob[BT_NLOOP] + 64u;
+    if (need > kBtSliceWords) {
+        tlsError = "backtracking program: captures and loop registers exceed a lane's scratch";
+        return LC_ERR_UNSUPPORTED;
+    }
+    uint32_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), size_t(blocks) * kBtBlock * kBtSliceWords * 4, stream));
+    lcNoteKernel("bt_match_kernel");
+    hipLaunchKernelGGL(bt_match_kernel, dim3(blocks), dim3(kBtBlock), stageWords * 4, stream, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume,
+                       static_cast<const uint32_t*>(dBlob), blobWords, stageWords, ngroups, d_caps, d_status, scratch, kBtSliceWords, budget);
+    const hipError_t launched = hipGetLastError();
+    (void)hipFreeAsync(scratch, stream);
+    HIP_TRY(launched);
+    return LC_OK;
+}
+
 static int lcMatchChainOnStream(lc_regex* re, int engine, int dev, const uint8_t* d_data, const uint32_t* d_off,
                          const uint32_t* d_len, uint32_t sep, uint32_t n, const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups,
                          int32_t* d_caps, uint8_t* d_status, void* streamPtr, int chance, uint32_t* seqInOut) {
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int rc;
+    if (engine == LC_ENGINE_BT || re->engine == LC_ENGINE_BT) {
+        if (engine != LC_ENGINE_BT) {
+            tlsError = "pattern runs on the backtracking engine only (back-references)";
+            return LC_ERR_UNSUPPORTED;
+        }
+        return launchBt(re, dev, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume, ngroups, d_caps, d_status, stream);
+    }
     if (!re->nfa.runGroups.empty()) tlsDone.armed = false;  // run_capture_kernel runs behind the match: it cannot signal
     // (a handle that asked for it -- lcPreferWaveTdfa: the Grok matcher's entries -- takes the wave-per-value kernel on small batches
     // even though its automaton fits the LDS kernels: those walk one value per lane, and a batch of a few hundred 4 KiB values waits

@@ -3,9 +3,9 @@
 // Replaces the *compile* half of boost::regex on the reference hot path:
 //   mReg.emplace_back(mRegex)            core/plugin/processor/ProcessorParseRegexNative.cpp:64-67
 //   IsRegexValid(regex)                   core/common/ParamExtractor.cpp:199-209
-// The accepted language is the subset of Boost.Regex Perl syntax that is regular (no back-references,
-// look-around, atomic groups or recursion); anything else is reported as RegexError so that plugin Init
-// fails loudly, exactly where the reference would reject an invalid regex.
+// The accepted language is the subset of Boost.Regex Perl syntax that is regular, plus back-references (round 6: those
+// patterns run on the device backtracking engine, bt_vm.hpp); recursion, conditionals and look-arounds of variable width are
+// reported as RegexError so that plugin Init fails loudly, exactly where the reference would reject an invalid regex.
 #pragma once
 
 #include <array>
@@ -73,12 +73,12 @@ struct LookAssert {
 };
 
 struct Node {
-    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic } kind = Empty;
+    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic, BackRef } kind = Empty;
     std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group/Atomic: 1
     ByteSet set;                               // Set
     int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
     bool greedy = true;                        // Repeat
-    int capture = 0;                           // Group: 1-based capture index, 0 = non-capturing
+    int capture = 0;                           // Group: 1-based capture index, 0 = non-capturing; BackRef: the group referred to
     LookAssert look;                           // Assert
     // parser-internal: a look-AHEAD whose body is a sequence of >= 2 character classes.  It never reaches the automata:
     // the parser drops it when what follows already implies it, and refuses the pattern otherwise (regex_parse.cpp).
@@ -103,6 +103,9 @@ struct ParsedRegex {
     std::unique_ptr<Node> root;
     int groupCount = 0;                    // == boost::basic_regex::mark_count()
     std::vector<std::string> groupNames;   // [0] unused; "" when unnamed
+    // round 6: the pattern holds back-references (\1 .. \N): not a regular language -- no automaton is built, the handle runs the
+    // device backtracking engine (bt_program.hpp, bt_vm.hpp: LC_ENGINE_BT)
+    bool hasBackRef = false;
 };
 
 ParsedRegex parseRegex(std::string_view pattern, Syntax syntax = Syntax());

@@ -1,5 +1,6 @@
 // regex_handle.cpp -- host half of the C ABI: compile a pattern into device table blobs (no HIP calls here).
 #include "regex_handle.hpp"
+#include "bt_program.hpp"
 
 #include <cstdlib>
 #include <functional>
@@ -923,7 +924,7 @@ using namespace lcregex;
 // (Go processor_regex without FullMatch: plugins/processor/regex/regex.go:105-129; regexp2.FindStringMatch in
 // plugins/processor/grok/processor_grok.go:156.)
 static void shiftCaptures(Node& n) {
-    if (n.kind == Node::Group && n.capture) ++n.capture;
+    if ((n.kind == Node::Group || n.kind == Node::BackRef) && n.capture) ++n.capture;
     for (auto& k : n.kids) shiftCaptures(*k);
 }
 // The longest byte string every match of the sub-expression must contain (possibly empty).  A line without it cannot
@@ -1613,7 +1614,7 @@ void lcRememberTdfaFailure(const std::string& key, const std::string& suffix) {
 
 extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_t syntax_flags, int engine,
                                 lc_regex_t** out, char* err, size_t errcap) {
-    if (!pattern || !out || engine < LC_ENGINE_AUTO || engine > LC_ENGINE_NFA) {
+    if (!pattern || !out || engine < LC_ENGINE_AUTO || (engine > LC_ENGINE_NFA && engine != LC_ENGINE_BT)) {
         setErr(err, errcap, "bad argument");
         return LC_ERR_ARG;
     }
@@ -1637,6 +1638,22 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
             setErr(err, errcap, e.what());
             delete re;
             return unsupported ? LC_ERR_UNSUPPORTED : LC_ERR_SYNTAX;
+        }
+        // Not regular (back-references), or the caller asked for it: the device backtracking engine (bt_vm.hpp).  No automaton is
+        // built; a search / prefix match is the same wrapped whole-value pattern the automata get.
+        if (parsed.hasBackRef || engine == LC_ENGINE_BT) {
+            if (engine == LC_ENGINE_TDFA || engine == LC_ENGINE_NFA)
+                throw RegexError("back-references need the backtracking engine (LC_ENGINE_AUTO / LC_ENGINE_BT): unsupported on this engine");
+            const bool anchored = (syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX);
+            if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed, anchored);
+            else if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
+            re->btBlob = lcregex::buildBtProgram(parsed, syn.icase);
+            re->engine = LC_ENGINE_BT;
+            re->nfa.groupCount = parsed.groupCount;  // (mark count and names are read off the handle's nfa member by every consumer)
+            re->nfa.groupNames = parsed.groupNames;
+            setErr(err, errcap, "");
+            *out = re;
+            return LC_OK;
         }
         // atomic groups that provably change nothing become plain groups (atomic_elide.cpp); LC_NO_ATOMIC_ELIDE: A/B measurements
         {
@@ -1843,6 +1860,7 @@ extern "C" int lc_regex_info(const lc_regex_t* re, lc_regex_info_t* out) {
     out->registers = tables ? re->tdfa.nRegs : 0;
     out->table_bytes = uint32_t((!re->hasTdfa && !re->screenBlob.empty() ? re->screenBlob.size()
                                  : !re->tdfaL2Blob.empty() ? re->tdfaL2Blob.size()
+                                 : re->engine == LC_ENGINE_BT ? re->btBlob.size()
                                  : re->engine == LC_ENGINE_TDFA ? re->tdfaBlob.size() : re->nfaBlob.size()) * 4);
     return LC_OK;
 }
@@ -1876,6 +1894,10 @@ extern "C" int lc_regex_table(const lc_regex_t* re, int which, const void** data
     if (which == LC_TABLE_NFA_BLOB) {
         if (re->nfaBlob.empty()) return LC_ERR_ARG;
         return view(re->nfaBlob.data(), re->nfaBlob.size() * 4);
+    }
+    if (which == LC_TABLE_BT_BLOB) {
+        if (re->btBlob.empty()) return LC_ERR_ARG;
+        return view(re->btBlob.data(), re->btBlob.size() * 4);
     }
     if (which == LC_TABLE_LAZY_TDFA_BLOB) {
         lc_regex* mre = const_cast<lc_regex*>(re);

@@ -58,6 +58,7 @@ struct lc_regex {
                                         // for the LDS kernels (then hasTdfa is false and tdfaBlob empty) and small enough for L2
     std::vector<uint32_t> screenBlob;   // screen_kernel.hpp layout: a yes/no DFA too large for LDS (relaxed screens), or empty
     std::vector<uint32_t> nfaBlob;      // device_tables.h NFA layout
+    std::vector<uint32_t> btBlob;       // bt_vm.hpp: the backtracking program (engine LC_ENGINE_BT: back-references), or empty
     std::vector<uint8_t> nfaClassMap;
     std::string tdfaError;              // why the TDFA was not built (AUTO fell back to NFA)
     std::string requiredLiteral;        // longest byte string every match must contain ("" if none is certain)
@@ -77,6 +78,7 @@ struct lc_regex {
     void* dNfaBlob[kLcMaxDevices] = {};
     void* dScreenBlob[kLcMaxDevices] = {};
     void* dTdfaL2Blob[kLcMaxDevices] = {};
+    void* dBtBlob[kLcMaxDevices] = {};
     LcLazyTdfa lazy;
     std::atomic<bool> lazyReady{false};  // lazy.blob is there (checked without the lock on the launch path)
     // Grok (grok_device.hip): search rounds this Match entry queues ahead per batch (FindStringMatch + FindNextMatch ...); follows

@@ -107,6 +107,10 @@ public:
         out.root = std::move(root);
         out.groupCount = mGroups;
         out.groupNames = std::move(mNames);
+        for (int r : mBackRefs) {  // (boost: error_backref at compile time)
+            if (r > mGroups) throw RegexError("invalid back reference: \\" + std::to_string(r) + " with " + std::to_string(mGroups) + " groups");
+        }
+        out.hasBackRef = !mBackRefs.empty();
         return out;
     }
 
@@ -116,6 +120,7 @@ private:
     Syntax mSyn;
     int mGroups = 0;
     std::vector<std::string> mNames;
+    std::vector<int> mBackRefs;
 
     bool atEnd() const { return mPos >= mPat.size(); }
     unsigned peek(size_t ahead = 0) const { return static_cast<unsigned char>(mPat[mPos + ahead]); }
@@ -585,7 +590,21 @@ private:
                 break;
             default: break;
         }
-        if (e >= '1' && e <= '9') bail("back-references unsupported");
+        if (e >= '1' && e <= '9') {
+            // \N: a back-reference (boost perl_matcher::match_backref; regexp2 likewise): the bytes group N matched last, again.  Not
+            // regular: the pattern goes to the device backtracking engine (bt_vm.hpp).  Under Grok's named-only numbering the digits
+            // would not count the groups the author sees: refused there.
+            if (mSyn.namedOnly) bail("back-references with named-only captures unsupported");
+            unsigned v = e - '0';
+            while (has(0) && peek() >= '0' && peek() <= '9' && v * 10 + (peek() - '0') <= 999) {
+                v = v * 10 + (peek() - '0');
+                ++mPos;
+            }
+            auto n = mk(Node::BackRef);
+            n->capture = int(v);
+            mBackRefs.push_back(int(v));
+            return n;
+        }
         int v = byteEscape(e);
         return literal(v >= 0 ? unsigned(v) : e);
     }
@@ -839,6 +858,9 @@ private:
             }
             case Node::Group:
             case Node::Atomic: return firstOf(*n.kids[0], out);
+            case Node::BackRef:  // (whatever the group held, the empty string included)
+                for (int w = 0; w < 4; ++w) out.w[w] = ~uint64_t(0);
+                return true;
         }
         return true;
     }

@@ -13,8 +13,10 @@
  *   - a repeat whose body last matched the empty string stops iterating (match_rep's null check);
  *   - a state-count budget; exceeding it returns -1 (boost throws std::runtime_error, which the
  *     reference swallows into "parse failed", StringTools.cpp:200-205).
- * Unsupported (compile error): back-references, look-behind bodies of variable length, atomic/possessive, recursion,
- * conditionals, \p{..}, collating elements.
+ *   - back-references \1 .. \N (round 6; perl_matcher::match_backref): the bytes group N matched last, again; a group that took
+ *     no part fails the reference; under ORX_ICASE the comparison folds ASCII case.  Pinned against CPython's `re` on the vectors of
+ *     tests/golden/backref_vectors.json (tools/gen_backref_golden.py); boost itself is on neither box.
+ * Unsupported (compile error): look-behind bodies of variable length, recursion, conditionals, \p{..}, collating elements.
  */
 #include "bt_regex.h"
 
@@ -77,7 +79,8 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 
 /* ------------------------------------------------------------------ AST */
 enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC,
-       N_LOOKAHEAD /* general (?=X) (?!X): max = negative; min = k > 0: the look-BEHIND (?<=X) (?<!X) of a body of fixed length k */ };
+       N_LOOKAHEAD /* general (?=X) (?!X): max = negative; min = k > 0: the look-BEHIND (?<=X) (?<!X) of a body of fixed length k */,
+       N_BACKREF /* cap = the group referred to */ };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
     A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
@@ -95,7 +98,8 @@ typedef struct {
 
 #define ORX_MAX_GROUPS 1023
 enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END, I_LOOK_BEGIN, I_LOOK_END, I_NLOOK_BEGIN, I_NLOOK_END,
-       I_BACK /* x = k: step back k bytes (inside a look-behind, right behind its mark); fewer than k behind: backtrack */ };
+       I_BACK /* x = k: step back k bytes (inside a look-behind, right behind its mark); fewer than k behind: backtrack */,
+       I_BACKREF /* x = group */ };
 typedef struct { int op, x, y, z, w; } inst;
 /* I_REPSET: x=set, y=min, z=max(-1 inf), w=greedy */
 
@@ -105,6 +109,7 @@ struct orx_prog {
     node* nodes; int nnodes, capnodes;
     int ngroups;
     int nloopregs;
+    int maxbackref;
     char* names[ORX_MAX_GROUPS + 1];
     /* parser state */
     const unsigned char* p; size_t n, i;
@@ -465,7 +470,14 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                     fail(P, "unsupported escape"); return -1;
                 default: break;
             }
-            if (e >= '1' && e <= '9') { fail(P, "back-references unsupported"); return -1; }
+            if (e >= '1' && e <= '9') {
+                int v = e - '0';
+                while (P->i < P->n && P->p[P->i] >= '0' && P->p[P->i] <= '9' && v * 10 + (P->p[P->i] - '0') <= 999) v = v * 10 + (P->p[P->i++] - '0');
+                int b = new_node(P, N_BACKREF);
+                P->nodes[b].cap = v;
+                if (v > P->maxbackref) P->maxbackref = v;
+                return b;
+            }
             int v = escape_byte(P, e);
             if (P->failed) return -1;
             return lit_node(P, v >= 0 ? v : e);
@@ -574,6 +586,7 @@ static int nullable(const orx_prog* P, int n) {
         case N_GROUP: return nullable(P, nd->l);
         case N_ATOMIC: return nullable(P, nd->l);
         case N_LOOKAHEAD: return 1;
+        case N_BACKREF: return 1;
     }
     return 1;
 }
@@ -599,6 +612,7 @@ static void gen(orx_prog* P, int n) {
             gen(P, nd.l);
             if (nd.cap) emit(P, I_SAVE, 2 * nd.cap + 1, 0);
             break;
+        case N_BACKREF: emit(P, I_BACKREF, nd.cap, 0); break;
         case N_ATOMIC:
             emit(P, I_ATOM_BEGIN, 0, 0);
             gen(P, nd.l);
@@ -661,6 +675,7 @@ orx_prog* orx_compile(const char* pattern, size_t len, unsigned flags, char* err
     P->p = (const unsigned char*)pattern; P->n = len; P->i = 0; P->flags = flags;
     int root = parse_alt(P, 0);
     if (!P->failed && P->i < P->n) fail(P, P->p[P->i] == ')' ? "unmatched )" : "unexpected character");
+    if (!P->failed && P->maxbackref > P->ngroups) fail(P, "invalid back reference");
     if (!P->failed) {
         emit(P, I_SAVE, 0, 0);
         gen(P, root);
@@ -821,6 +836,24 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
                 }
                 if (check_assert(in->x, s, n, pos)) { ++pc; continue; }
                 goto backtrack;
+            case I_BACKREF: {
+                long b = caps[2 * in->x], e = caps[2 * in->x + 1];
+                if (b < 0 || e < 0 || e < b || e - b > n - pos) goto backtrack;
+                long k = 0, len = e - b;
+                if (P->flags & ORX_ICASE) {
+                    while (k < len) {
+                        int c1 = s[b + k], c2 = s[pos + k];
+                        if (c1 >= 'A' && c1 <= 'Z') c1 += 32;
+                        if (c2 >= 'A' && c2 <= 'Z') c2 += 32;
+                        if (c1 != c2) break;
+                        ++k;
+                    }
+                } else {
+                    while (k < len && s[b + k] == s[pos + k]) ++k;
+                }
+                if (k < len) goto backtrack;
+                pos += len; ++pc; continue;
+            }
             case I_MATCH:
                 if (full && pos != n) goto backtrack;
                 return 1;

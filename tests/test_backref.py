@@ -1,0 +1,282 @@
+"""Back-references (\\1 .. \\N) -- the device BACKTRACKING engine (csrc/bt_vm.hpp, LC_ENGINE_BT; round 6).
+
+What the reference does: boost::regex_match backtracks, so a pattern with back-references is just another pattern
+(core/common/StringTools.cpp:183-211; Init accepts whatever boost compiles, core/common/ParamExtractor.cpp:199-209).
+
+CPU tests (no GPU): the oracle against the vectors three independent engines agree on (tests/golden/gen_backref_golden.py), and the
+product's PROGRAMS (lc_regex_table LC_TABLE_BT_BLOB) walked by the very routine the kernel runs per lane, compiled for the host
+(tests/native/bt_host_check.cpp) -- on the back-reference vectors, and, with the engine asked for explicitly, on every regular golden
+set the automata are pinned on.  GPU tests: the kernel through the C ABI on the same vectors, against the oracle on generated values,
+and through the processor.
+"""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from loongcollector_amd import binding as B
+from oracle.oracle import OracleRegex
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vectors(golden_dir):
+    with open(os.path.join(golden_dir, "backref_vectors.json")) as f:
+        d = json.load(f)
+    assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["dropped_disagreements"] == 0
+    return d
+
+
+@pytest.fixture(scope="module")
+def host_vm():
+    """tests/native/bt_host_check.cpp -> tests/_build/libbt_host_check.so (g++, host only)"""
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(ROOT, "tests", "native", "bt_host_check.cpp")
+    hdr = os.path.join(ROOT, "loongcollector_amd", "csrc", "bt_vm.hpp")
+    lib = os.path.join(out_dir, "libbt_host_check.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", lib, src])
+    L = ctypes.CDLL(lib)
+    L.bt_host_run.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                              ctypes.c_uint32, ctypes.c_uint32]
+    L.bt_host_run.restype = ctypes.c_int
+
+    def run(rx, subject, budget=1 << 22, scratch_words=16384):
+        blob = rx.table(B.LC_TABLE_BT_BLOB, np.uint32)
+        assert blob is not None and len(blob) > 8
+        ncaps = int(blob[2])
+        caps = np.full(ncaps, -9, dtype=np.int32)
+        r = L.bt_host_run(blob.ctypes.data, subject, len(subject), 0, caps.ctypes.data, ncaps, scratch_words, budget)
+        return r, caps.tolist()
+    return run
+
+
+def _flat(got):
+    return None if got is None else [v for ab in got for v in ab]
+
+
+# ------------------------------------------------------------------------------------------------ the oracle is pinned first
+def test_oracle_matches_the_backreference_vectors(vectors):
+    bad = []
+    for kind in ("full", "search", "icase_full"):
+        for c in vectors[kind]:
+            rx = OracleRegex(c["p"].encode("latin-1"), flags=(1 if kind == "icase_full" else 0))   # ORX_ICASE
+            assert rx.groups == c["g"], c["p"]
+            for subj, flat in c["subs"]:
+                s = subj.encode("latin-1")
+                got = rx.search(s) if kind == "search" else rx.fullmatch(s)
+                if _flat(got) != flat:
+                    bad.append((kind, c["p"], subj, _flat(got), flat))
+    assert not bad, bad[:5]
+
+
+# ------------------------------------------------------------------------------------------------ the product's compile half
+def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
+    rx = B.GpuRegex(rb'(\w+) \1')
+    assert rx.info()["engine"] == B.LC_ENGINE_BT and rx.groups == 1
+    assert not rx.has_nfa_program()
+    # a search shifts the references with the groups: group 1 is the whole match, \1 now names group 2
+    rs = B.GpuRegex(rb'(a)\1', syntax_flags=B.LC_SYNTAX_SEARCH)
+    assert rs.info()["engine"] == B.LC_ENGINE_BT and rs.groups == 2
+    # boost: error_backref at compile time -> Init fails as for any invalid regex
+    with pytest.raises(B.RegexSyntaxError):
+        B.GpuRegex(rb'(a)\2')
+    # an automaton cannot run it: asking for one is refused, never approximated
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(rb'(a)\1', engine=B.LC_ENGINE_TDFA)
+    # regular patterns still get their automata
+    assert B.GpuRegex(rb'(a)b').info()["engine"] == B.LC_ENGINE_TDFA
+
+
+def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
+    bad, checked = [], 0
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE)):
+        for c in vectors[kind]:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+            assert rx.info()["engine"] == B.LC_ENGINE_BT
+            assert rx.groups == c["g"] + (1 if kind == "search" else 0)
+            for subj, flat in c["subs"]:
+                s = subj.encode("latin-1")
+                r, caps = host_vm(rx, s)
+                checked += 1
+                if flat is None:
+                    ok = r == 0
+                else:  # slots 0/1 are the wrapped whole-value match; a search's group 1 is the golden group 0
+                    ok = r == 1 and caps[:2] == [0, len(s)] and caps[2:] == (flat if kind == "search" else flat[2:])
+                if not ok:
+                    bad.append((kind, c["p"], subj, r, caps, flat))
+    assert checked > 5000
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("name,key", [("regex_golden.json", "cases"), ("regex_atomic_golden.json", "full"), ("regex_atomic_golden.json", "search"),
+                                      ("regex_search_golden.json", "cases")])
+def test_backtracking_programs_agree_with_the_goldens_of_the_automata(golden_dir, host_vm, name, key):
+    """LC_ENGINE_BT asked for explicitly: the same vectors the tagged DFA and the thread-list engine are pinned on (CPython re ∧ PCRE1,
+    regex ∧ PCRE1).  Patterns the engine does not run (multi-byte look-around windows) are refused at compile time and skipped."""
+    with open(os.path.join(golden_dir, name)) as f:
+        d = json.load(f)
+    search = key == "search" or "search" in name
+    bad, checked, refused, gave_up = [], 0, 0, 0
+    for c in d[key]:
+        try:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=B.LC_SYNTAX_SEARCH if search else 0, engine=B.LC_ENGINE_BT)
+        except B.RegexUnsupportedError:
+            refused += 1
+            continue
+        for subj, flat in c["subs"]:
+            s = subj.encode("latin-1")
+            r, caps = host_vm(rx, s)
+            checked += 1
+            if r == -1:  # (the fuzzed sets hold patterns that backtrack exponentially: out of the device's step budget = reported)
+                gave_up += 1
+                continue
+            ok = (r == 0) if flat is None else (r == 1 and caps[2:] == (flat if search else flat[2:]))
+            if not ok:
+                bad.append((c["p"], subj, r, caps, flat))
+    assert checked > 1000 and refused * 10 < len(d[key]) and gave_up * 200 < checked, (checked, refused, gave_up)
+    assert not bad, bad[:5]
+
+
+def test_budget_and_stack_are_reported_never_guessed(host_vm):
+    rx = B.GpuRegex(rb'(a|aa)+\1b')
+    s = b'a' * 40 + b'c'
+    assert host_vm(rx, s, budget=1 << 14)[0] == -1          # exponential: out of steps -> gave up
+    assert host_vm(B.GpuRegex(rb'(?:(a)|b)*\1'), b'ab' * 600 + b'a', scratch_words=256)[0] == -1   # out of stack -> gave up
+    r, caps = host_vm(B.GpuRegex(rb'(?:(a)|b)*\1'), b'ab' * 600 + b'a')   # (with the whole slice it is decided)
+    assert r == 1 and caps == [0, 1201, 1198, 1199]
+
+
+# ------------------------------------------------------------------------------------------------ the kernel
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.mark.gpu
+def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
+    from test_gpu_parity import pack, run_device
+    bad, checked = [], 0
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE)):
+        for c in vectors[kind]:
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
+            subs = [s.encode("latin-1") for s, _ in c["subs"]]
+            data, off, length = pack(subs)
+            caps, status = run_device(torch_dev, rx, data, off, length)
+            for i, (_, flat) in enumerate(c["subs"]):
+                checked += 1
+                exp = flat if kind == "search" or flat is None else flat[2:]
+                ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
+                    status[i] == B.LC_MATCH and list(caps[i]) == exp)
+                if not ok:
+                    bad.append((kind, c["p"], subs[i], int(status[i]), list(caps[i]), exp))
+    assert checked > 5000
+    assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_backtracking_kernel_against_the_oracle_on_generated_lines(torch_dev):
+    """20 000 lines of 40-600 B per pattern: key=value records whose values repeat or do not; bit-exact status and offsets; both input
+    forms (offsets + separator, offsets + lengths); a batch beyond the 8 192 lanes of a launch (grid-stride)."""
+    from test_gpu_parity import run_device
+    rng = random.Random(7)
+    words = [b"alpha", b"beta", b"gamma", b"x1", b"req-42", b"GET", b"POST", b"a.b.c", b"0a:1b"]
+    for pattern in (rb'(\S+) (\S+) \[(\w+)\] "(\S+) (.*?)" (\d+) \1 (.*)', rb'(\w+)=(\w+);(?:\w+=\w+;)*?\1=\2;.*',
+                    rb'(["\'])(.*?)\1 (\S+) \3( .*)?'):
+        lines = []
+        for _ in range(20000):
+            a, b, c = rng.choice(words), rng.choice(words), rng.choice(words)
+            pad = b" ".join(rng.choice(words) for _ in range(rng.randint(0, 80)))
+            shape = rng.randint(0, 5)
+            if shape == 0:
+                lines.append(a + b" " + b + b" [" + c.replace(b".", b"").replace(b"-", b"").replace(b":", b"") + b"] \"" + a + b" /p?" + pad + b"\" 200 " +
+                             (a if rng.random() < 0.7 else b) + b" " + pad)
+            elif shape == 1:
+                k, v = rng.choice([b"k", b"key", b"id"]), rng.choice([b"v", b"7", b"val"])
+                mid = b"".join(rng.choice([b"p=q;", b"id=8;", b"k=v;"]) for _ in range(rng.randint(0, 6)))
+                lines.append(k + b"=" + v + b";" + mid + (k + b"=" + v if rng.random() < 0.6 else b"z=z") + b";" + pad)
+            elif shape == 2:
+                q = rng.choice([b'"', b"'"])
+                lines.append(q + pad[:rng.randint(0, 40)] + (q if rng.random() < 0.8 else b"`") + b" " + a + b" " + (a if rng.random() < 0.7 else b) +
+                             (b" " + pad if rng.random() < 0.5 else b""))
+            else:
+                lines.append(pad)
+        data = np.frombuffer(b"\n".join(lines) + b"\n", dtype=np.uint8)
+        length = np.array([len(x) for x in lines], dtype=np.uint32)
+        off = np.zeros(len(lines) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum(length + 1)
+        exp_caps, exp_status = OracleRegex(pattern).fullmatch_batch(data, off[:-1], length)
+        rx = B.GpuRegex(pattern)
+        assert rx.info()["engine"] == B.LC_ENGINE_BT
+        caps, status = run_device(torch_dev, rx, data, off, None, sep=1)
+        assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps), pattern
+        caps2, status2 = run_device(torch_dev, rx, data, off[:-1], length)
+        assert np.array_equal(status2, exp_status) and np.array_equal(caps2, exp_caps), pattern
+        assert 1000 < int((exp_status == 1).sum()) < 19000
+
+
+@pytest.mark.gpu
+def test_the_backtracking_engine_agrees_with_the_automata_on_the_bench_corpus(torch_dev):
+    """Regex A of the headline on 20 000 corpus lines (every seventh poisoned): LC_ENGINE_BT asked for explicitly against the oracle."""
+    from loongcollector_amd import corpus
+    from test_gpu_parity import run_device
+    data, off, length = corpus.apache_batch(20000, "A", poison_every=7)
+    exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
+    rx = B.GpuRegex(corpus.REGEX_A, engine=B.LC_ENGINE_BT)
+    caps, status = run_device(torch_dev, rx, data, off, None, sep=1)
+    assert np.array_equal(status, exp_status) and np.array_equal(caps, exp_caps)
+
+
+@pytest.mark.gpu
+def test_a_value_that_exhausts_the_budget_is_reported_gave_up(torch_dev, monkeypatch):
+    from test_gpu_parity import pack, run_device
+    monkeypatch.setenv("LC_BT_BUDGET", str(1 << 14))
+    rx = B.GpuRegex(rb'(a|aa)+\1b')
+    subs = [b'a' * 40 + b'c', b'aab', b'aaab', b'c']
+    data, off, length = pack(subs)
+    caps, status = run_device(torch_dev, rx, data, off, length)
+    assert list(status) == [B.LC_GAVE_UP, B.LC_MATCH, B.LC_MATCH, B.LC_NOMATCH]
+    assert (caps[0] == -1).all() and (caps[3] == -1).all()
+    o = OracleRegex(rb'(a|aa)+\1b')
+    assert list(caps[1]) == list(o.fullmatch(subs[1])[1]) and list(caps[2]) == list(o.fullmatch(subs[2])[1])
+
+
+@pytest.mark.gpu
+def test_the_parse_processor_with_a_backreference_regex_against_the_processor_oracle():
+    """ProcessorParseRegexNative::Init accepts what boost compiles (ProcessorParseRegexNative.cpp:64-67): a Regex with \\1 initialises, and
+    1 000-event groups go through gather -> bt_match_kernel -> stitch with the reference's key / policy behaviour (the processor oracle)."""
+    from loongcollector_amd.processor import EventGroup, Processor
+    from oracle.processor_oracle import LogEventModel, ProcessorOracle
+    rng = random.Random(3)
+    cfg = {"SourceKey": "content", "Regex": r'(\w+)=(["\'])(.*?)\2 (\w+) \1:(\d+)(?: .*)?', "Keys": ["key", "quote", "value", "verb", "n"],
+           "KeepingSourceWhenParseFail": True, "KeepingSourceWhenParseSucceed": False, "CopingRawLog": False, "RenamedSourceKey": "rawLog"}
+    p = Processor(cfg)
+    po = ProcessorOracle(cfg)
+    total_ok = 0
+    for _ in range(3):
+        events, models = [], []
+        for _ in range(1000):
+            k = rng.choice(["id", "user", "k9"])
+            q = rng.choice(['"', "'"])
+            v = "".join(rng.choice("abc \"'=") for _ in range(rng.randint(0, 30)))
+            line = "%s=%s%s%s %s %s:%d%s" % (k, q, v, q if rng.random() < 0.85 else "`", rng.choice(["GET", "PUT"]),
+                                             k if rng.random() < 0.8 else "zz", rng.randint(0, 999), " tail " * rng.randint(0, 3))
+            contents = [["content", line]]
+            events.append({"contents": contents, "timestamp": 1, "type": 1})
+            models.append(LogEventModel([(a, b.encode()) for a, b in contents]))
+        g = EventGroup({"events": events})
+        p.process(g)
+        out = po.process_group(models)
+        want = [None if ev is None else [(a, b.decode()) for a, b in ev.live()] for ev in out]
+        assert g.contents() == want
+        total_ok += sum(1 for ev in want if ev and any(a == "verb" for a, _ in ev))
+    assert 500 < total_ok < 2900
