@@ -280,3 +280,20 @@ def test_the_parse_processor_with_a_backreference_regex_against_the_processor_or
         assert g.contents() == want
         total_ok += sum(1 for ev in want if ev and any(a == "verb" for a, _ in ev))
     assert 500 < total_ok < 2900
+
+
+@pytest.mark.gpu
+def test_multiline_split_with_backreference_patterns_against_the_oracle():
+    """ProcessorSplitMultilineLogStringNative's patterns are boost regexes like any other (MultilineOptions.cpp:203-266): a StartPattern /
+    EndPattern with a back-reference flags the lines through bt_match_kernel (prefix match, LC_SYNTAX_PREFIX) and the records are the
+    multiline oracle's."""
+    from loongcollector_amd.multiline import Multiline
+    from oracle.multiline_oracle import MultilineOracle
+    rng = random.Random(5)
+    pool = [b"<a> open", b"</a>", b"</b>", b"<bb> x", b"</bb> tail", b"11-11 start", b"12-11 not", b"  cont", b"", b"77-77", b"x=1;x=1", b"x=1;y=1"]
+    for config in ({"StartPattern": r"(\d\d)-\1.*"}, {"StartPattern": r"<(\w+)>.*", "EndPattern": r"</(\w)\1?>.*"},
+                   {"EndPattern": r"(\w)=(\d);\1=\2", "UnmatchedContentTreatment": "discard"}):
+        o, m = MultilineOracle(**config), Multiline(**config)
+        for _ in range(150):
+            val = b"\n".join(rng.choice(pool) for _ in range(rng.randint(0, 14)))
+            assert m.split(val) == o.split(val), (config, val)

@@ -30,7 +30,8 @@ def test_reference_init_cases(golden_dir):
     ({"SourceKey": "c", "Regex": "a", "Keys": []}, "mandatory list param Keys is empty"),
     ({"SourceKey": "", "Regex": "a", "Keys": ["k"]}, "mandatory string param SourceKey is empty"),
     ({"SourceKey": 3, "Regex": "a", "Keys": ["k"]}, "param SourceKey is not of type string"),
-    ({"SourceKey": "c", "Regex": r"(a)\1", "Keys": ["k"]}, "cannot be executed by the GPU engines"),
+    # (round 6: r"(a)\1" initialises -- back-references run on the device backtracking engine, tests/test_backref.py)
+    ({"SourceKey": "c", "Regex": r"(?R)a", "Keys": ["k"]}, "cannot be executed by the GPU engines"),
 ])
 def test_init_failures_mirror_the_reference(cfg, msg):
     with pytest.raises(ProcessorInitError, match=msg):
