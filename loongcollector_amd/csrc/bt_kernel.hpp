@@ -13,8 +13,14 @@
 #include "bt_vm.hpp"
 
 constexpr uint32_t kBtBlock = 64;
-constexpr uint32_t kBtMaxLanes = 8192;           // lanes of a launch (128 wavefronts)
-constexpr uint32_t kBtSliceWords = 16384;        // 64 KB of scratch per lane: ~8 000 stack entries
+// Two passes share one scratch pool (512 MB at most).  Pass 1: up to 65 536 lanes in flight (eight wavefronts per SIMD hide the latency of
+// a step) with 8 KB of scratch each -- ~1 000 stack entries, a log line's counted repeats and captures need a few dozen.  A value that
+// fills its slice is left LC_PENDING and raises the pool's flag word; pass 2 (8 192 lanes x 64 KB, ~8 000 entries) takes the pending
+// values and returns at once when the flag is down.
+constexpr uint32_t kBtMaxLanes = 65536, kBtSliceWords = 2048;
+constexpr uint32_t kBtRetryLanes = 8192, kBtRetrySliceWords = 16384;
+constexpr uint32_t kBtPoolHeaderWords = 64;      // the flag word, in front of the slices
+constexpr uint8_t kBtPending = 4;                // (LC_PENDING of the other engines' protocols: transient, inside one match call)
 constexpr uint32_t kBtStageMaxBytes = 48 * 1024;  // programs up to this size are walked from LDS
 // Steps per value before it is reported LC_GAVE_UP.  boost's BOOST_REGEX_MAX_STATE_COUNT is 100 000 000 states per match; a lane
 // that took that many steps would hold its wavefront for minutes, so the device bound is lower (LC_BT_BUDGET overrides it): values
@@ -27,8 +33,10 @@ __global__ __launch_bounds__(kBtBlock) void bt_match_kernel(const uint8_t* __res
                                                             const uint32_t* __restrict__ resume, const uint32_t* __restrict__ blob,
                                                             uint32_t blobWords, uint32_t stageWords, uint32_t nGroupsOut,
                                                             int32_t* __restrict__ caps, uint8_t* __restrict__ status,
-                                                            uint32_t* __restrict__ scratch, uint32_t sliceWords, uint32_t budget) {
+                                                            uint32_t* __restrict__ pool, uint32_t sliceWords, uint32_t budget, uint32_t retryPass) {
     extern __shared__ uint32_t btStaged[];
+    if (retryPass && __atomic_load_n(pool, __ATOMIC_RELAXED) == 0u) return;  // nothing was left pending
+    uint32_t* scratch = pool + kBtPoolHeaderWords;
     for (uint32_t i = threadIdx.x; i < stageWords; i += kBtBlock) btStaged[i] = blob[i];
     __syncthreads();
     const uint32_t* prog = stageWords ? btStaged : blob;
@@ -39,6 +47,7 @@ __global__ __launch_bounds__(kBtBlock) void bt_match_kernel(const uint8_t* __res
     const uint32_t nCaps = prog[BT_NCAPS];
     for (uint32_t slot = lane; slot < nLines; slot += lanes) {
         const uint32_t line = order ? order[slot] : slot;
+        if (retryPass && status[line] != kBtPending) continue;
         const uint32_t o = off[line];
         const uint32_t L = len ? len[line] : off[line + 1] - o - sepBytes;
         uint32_t from = 0;
@@ -49,6 +58,11 @@ __global__ __launch_bounds__(kBtBlock) void bt_match_kernel(const uint8_t* __res
         const int r = btRun(prog, data + o, L, from, mine, sliceWords, budget);
         int32_t* out = caps + size_t(line) * 2 * nGroupsOut;
         for (uint32_t s = 0; s < 2 * nGroupsOut; ++s) out[s] = (r == 1 && s + 2 < nCaps) ? int32_t(mine[s + 2]) : -1;  // (slot 0/1: the whole match)
-        status[line] = r == 1 ? LC_MATCH : r == 0 ? LC_NOMATCH : LC_GAVE_UP;
+        if (r == -2 && !retryPass) {
+            status[line] = kBtPending;
+            atomicOr(pool, 1u);
+        } else {
+            status[line] = r == 1 ? LC_MATCH : r == 0 ? LC_NOMATCH : LC_GAVE_UP;
+        }
     }
 }

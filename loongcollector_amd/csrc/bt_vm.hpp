@@ -55,9 +55,26 @@ enum { BT_K_ALT = 0 /* a = pc, b = position */, BT_K_UNDO_CAP = 1 /* a = slot, b
 
 LC_BT_HD bool btHas(const uint32_t* sets, uint32_t set, uint32_t c) { return (sets[set * 8u + (c >> 5)] >> (c & 31u)) & 1u; }
 LC_BT_HD uint32_t btFold(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32u : c; }
+// how many of the bytes s[0, limit) are in `set`, from the front: eight bytes per load (gfx950 takes the unaligned load), their eight
+// class tests issued side by side -- a counted repeat is where a log line's bytes go, and byte loads in a dependent chain were its cost
+LC_BT_HD uint32_t btRun8(const uint32_t* sets, uint32_t set, const uint8_t* s, uint32_t limit) {
+    uint32_t k = 0;
+    while (k + 8u <= limit) {
+        uint64_t w;
+        __builtin_memcpy(&w, s + k, 8);
+        uint32_t ok = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) ok |= uint32_t(btHas(sets, set, uint32_t(w >> (8u * j)) & 0xFFu)) << j;
+        if (ok != 0xFFu) return k + uint32_t(__builtin_ctz(~ok));
+        k += 8u;
+    }
+    while (k < limit && btHas(sets, set, s[k])) ++k;
+    return k;
+}
 
 // Walks value s[0, n) from offset `from`.  scratch: [captures][loop registers][stack].  Returns 1: match (capture slots in scratch[0 ..
-// BT_NCAPS), slot 2g / 2g + 1 = group g, group 0 = the whole match); 0: no match; -1: gave up (budget or stack).
+// BT_NCAPS), slot 2g / 2g + 1 = group g, group 0 = the whole match); 0: no match; -1: out of steps; -2: out of stack (the launch
+// gives such a value a second pass with a larger slice before it reports LC_GAVE_UP).
 LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t from, uint32_t* scratch, uint32_t scratchWords, uint32_t budget) {
     const uint32_t nCaps = blob[BT_NCAPS], nLoop = blob[BT_NLOOP];
     const uint32_t* sets = blob + blob[BT_OFF_SETS];
@@ -72,7 +89,7 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
     uint32_t sp = 0, pc = 0, pos = from;
 #define BT_PUSH(kind, a, b)                                 \
     do {                                                    \
-        if (sp >= cap) return -1;                           \
+        if (sp >= cap) return -2;                           \
         st[2u * sp] = uint32_t(kind) | (uint32_t(a) << 4);  \
         st[2u * sp + 1u] = uint32_t(b);                     \
         ++sp;                                               \
@@ -97,7 +114,7 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                 if (mx > n - pos) mx = n - pos;
                 uint32_t k = 0;
                 if (fl & 1u) {
-                    while (k < mx && btHas(sets, in[1], s[pos + k])) ++k;
+                    k = btRun8(sets, in[1], s + pos, mx);
                     if (k < mn) {
                         fail = true;
                         break;
@@ -230,25 +247,44 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                 sp = top;
                 break;
             }
-            if (kind == BT_K_REP_GREEDY) {  // one byte less
-                const uint32_t cur = b - 1u, low = st[2u * (top - 1u) + 1u];
+            if (kind == BT_K_REP_GREEDY) {  // one byte less ...
+                uint32_t cur = b - 1u;
+                const uint32_t low = st[2u * (top - 1u) + 1u];
+                // ... and on, past the ends behind which what follows cannot start (perl_matcher::unwind_greedy_single_repeat's
+                // can_start test): a byte class behind the repeat would fail there at once and come straight back -- same result,
+                // without a step per byte.  A line that does NOT match its pattern is mostly this.
+                const uint32_t* nx = code + (a + 1u) * 4u;
+                if ((nx[0] & 0xFFu) == BT_SET)
+                    while (cur > low && !btHas(sets, nx[1], s[cur])) --cur;
                 st[2u * top + 1u] = cur;
                 pc = a + 1u;
                 pos = cur;
                 if (cur <= low) sp = top - 1u;
                 break;
             }
-            {  // BT_K_REP_LAZY: one byte more
+            {  // BT_K_REP_LAZY: one byte more -- and on, while what follows cannot start there (as above)
                 const uint32_t* rep = code + a * 4u;
-                const uint32_t count = st[2u * (top - 1u) + 1u];
-                if ((rep[3] != BT_INF && count >= rep[3]) || b >= n || !btHas(sets, rep[1], s[b])) {
+                const uint32_t* nx = rep + 4u;
+                const bool skip = (nx[0] & 0xFFu) == BT_SET;
+                uint32_t cur = b, count = st[2u * (top - 1u) + 1u];
+                bool dead = false;
+                for (;;) {
+                    if ((rep[3] != BT_INF && count >= rep[3]) || cur >= n || !btHas(sets, rep[1], s[cur])) {
+                        dead = true;
+                        break;
+                    }
+                    ++cur;
+                    ++count;
+                    if (!skip || cur >= n || btHas(sets, nx[1], s[cur])) break;
+                }
+                if (dead) {
                     sp = top - 1u;
                     continue;
                 }
-                st[2u * top + 1u] = b + 1u;
-                st[2u * (top - 1u) + 1u] = count + 1u;
+                st[2u * top + 1u] = cur;
+                st[2u * (top - 1u) + 1u] = count;
                 pc = a + 1u;
-                pos = b + 1u;
+                pos = cur;
                 break;
             }
         }

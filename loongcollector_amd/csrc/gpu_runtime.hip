@@ -1227,19 +1227,33 @@ static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t
     const uint32_t blobWords = uint32_t(re->btBlob.size());
     const uint32_t stageWords = blobWords * 4 <= kBtStageMaxBytes ? blobWords : 0u;
     const uint32_t blocks = std::min<uint32_t>((n + kBtBlock - 1) / kBtBlock, kBtMaxLanes / kBtBlock);
+    const uint32_t retryBlocks = std::min<uint32_t>(blocks, kBtRetryLanes / kBtBlock);
     uint32_t budget = kBtDefaultBudget;
     if (const char* e = getenv("LC_BT_BUDGET")) budget = uint32_t(strtoul(e, nullptr, 10));  // (read per launch: tests)
     const uint32_t need = re->btBlob[BT_NCAPS] + re->btBlob[BT_NLOOP] + 64u;
-    if (need > kBtSliceWords) {
+    uint32_t sliceWords = kBtSliceWords;
+    if (need + 256u > sliceWords) sliceWords = kBtRetrySliceWords;  // (hundreds of groups: every lane gets the large slice; fewer lanes)
+    const uint32_t firstBlocks = sliceWords == kBtSliceWords ? blocks : retryBlocks;
+    if (need > kBtRetrySliceWords) {
         tlsError = "backtracking program: captures and loop registers exceed a lane's scratch";
         return LC_ERR_UNSUPPORTED;
     }
     uint32_t* scratch = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), size_t(blocks) * kBtBlock * kBtSliceWords * 4, stream));
+    const size_t poolWords = kBtPoolHeaderWords + std::max(size_t(firstBlocks) * kBtBlock * sliceWords, size_t(retryBlocks) * kBtBlock * kBtRetrySliceWords);
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), poolWords * 4, stream));
+    hipError_t launched = hipMemsetAsync(scratch, 0, kBtPoolHeaderWords * 4, stream);
     lcNoteKernel("bt_match_kernel");
-    hipLaunchKernelGGL(bt_match_kernel, dim3(blocks), dim3(kBtBlock), stageWords * 4, stream, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume,
-                       static_cast<const uint32_t*>(dBlob), blobWords, stageWords, ngroups, d_caps, d_status, scratch, kBtSliceWords, budget);
-    const hipError_t launched = hipGetLastError();
+    if (launched == hipSuccess) {
+        hipLaunchKernelGGL(bt_match_kernel, dim3(firstBlocks), dim3(kBtBlock), stageWords * 4, stream, d_data, d_off, d_len, sep, n, d_n, d_order, d_resume,
+                           static_cast<const uint32_t*>(dBlob), blobWords, stageWords, ngroups, d_caps, d_status, scratch, sliceWords, budget, 0u);
+        launched = hipGetLastError();
+    }
+    if (launched == hipSuccess && sliceWords != kBtRetrySliceWords) {  // pass 2: the values that filled their slice (none: the kernel returns at once)
+        hipLaunchKernelGGL(bt_match_kernel, dim3(retryBlocks), dim3(kBtBlock), stageWords * 4, stream, d_data, d_off, d_len, sep, n, d_n, d_order,
+                           d_resume, static_cast<const uint32_t*>(dBlob), blobWords, stageWords, ngroups, d_caps, d_status, scratch,
+                           kBtRetrySliceWords, budget, 1u);
+        launched = hipGetLastError();
+    }
     (void)hipFreeAsync(scratch, stream);
     HIP_TRY(launched);
     return LC_OK;

@@ -1,5 +1,6 @@
 // regex_parse.cpp -- recursive-descent parser: pattern bytes -> lcregex::Node tree.
 // See regex_ast.hpp for what this replaces on the reference path.
+#include <cstdlib>
 #include <cstring>
 
 #include "regex_ast.hpp"
@@ -583,7 +584,42 @@ private:
                 return g;
             }
             case 'E': return mk(Node::Empty);
-            case 'k': case 'g': case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
+            case 'k': case 'g': {
+                // \k<name> \k{name} \k'name' \g{name}: a back-reference by name; \gN \g{N} \g{-N}: by number / relative to here (boost
+                // Perl syntax).  Only to groups opened in front of the reference; not under Grok's dialect (see \N below).
+                if (mSyn.namedOnly || mSyn.regexp2 || atEnd()) bail("unsupported escape");
+                const unsigned open = peek();
+                const unsigned close = open == '<' ? '>' : open == '{' ? '}' : open == '\'' ? '\'' : 0;
+                std::string word;
+                if (close) {
+                    ++mPos;
+                    while (!atEnd() && peek() != close) word.push_back(char(peek())), ++mPos;
+                    if (atEnd() || word.empty()) bail("unterminated back-reference name");
+                    ++mPos;
+                } else if (e == 'g') {
+                    if (peek() == '-') word.push_back('-'), ++mPos;
+                    while (!atEnd() && peek() >= '0' && peek() <= '9') word.push_back(char(peek())), ++mPos;
+                    if (word.empty() || word == "-") bail("unsupported escape");
+                } else {
+                    bail("unsupported escape");
+                }
+                int v = 0;
+                const bool numeric = word.find_first_not_of("-0123456789") == std::string::npos;
+                if (numeric && (e == 'g')) {
+                    const int k = std::atoi(word.c_str());
+                    v = k < 0 ? mGroups + 1 + k : k;
+                    if (k == 0 || v < 1) bail("invalid back reference");
+                } else {
+                    for (int g = 1; g <= mGroups && !v; ++g)
+                        if (mNames[size_t(g)] == word) v = g;
+                    if (!v) bail("back-reference to a group name that is not defined in front of it: unsupported");
+                }
+                auto n = mk(Node::BackRef);
+                n->capture = v;
+                mBackRefs.push_back(v);
+                return n;
+            }
+            case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
                 bail("unsupported escape");
             case 'u':
                 if (mSyn.regexp2) bail("unsupported escape");  // \uXXXX

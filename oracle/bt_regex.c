@@ -466,7 +466,37 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                     return g;
                 }
                 case 'E': return new_node(P, N_EMPTY);
-                case 'k': case 'g': case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
+                case 'k': case 'g': {
+                    /* \k<name> \k{name} \k'name' \g{name}; \gN \g{N} \g{-N} (boost Perl syntax): groups opened in front of the reference */
+                    if ((P->flags & ORX_REGEXP2) || P->i >= P->n) { fail(P, "unsupported escape"); return -1; }
+                    int open = P->p[P->i], close = open == '<' ? '>' : open == '{' ? '}' : open == '\'' ? '\'' : 0;
+                    char word[128]; size_t wl = 0;
+                    if (close) {
+                        ++P->i;
+                        while (P->i < P->n && P->p[P->i] != close && wl + 1 < sizeof word) word[wl++] = (char)P->p[P->i++];
+                        if (P->i >= P->n || P->p[P->i] != close || wl == 0) { fail(P, "unterminated back-reference name"); return -1; }
+                        ++P->i;
+                    } else if (e == 'g') {
+                        if (P->p[P->i] == '-') word[wl++] = (char)P->p[P->i++];
+                        while (P->i < P->n && P->p[P->i] >= '0' && P->p[P->i] <= '9' && wl + 1 < sizeof word) word[wl++] = (char)P->p[P->i++];
+                        if (wl == 0 || (wl == 1 && word[0] == '-')) { fail(P, "unsupported escape"); return -1; }
+                    } else { fail(P, "unsupported escape"); return -1; }
+                    word[wl] = 0;
+                    int v = 0, numeric = strspn(word, "-0123456789") == wl;
+                    if (numeric && e == 'g') {
+                        int k = atoi(word);
+                        v = k < 0 ? P->ngroups + 1 + k : k;
+                        if (k == 0 || v < 1) { fail(P, "invalid back reference"); return -1; }
+                    } else {
+                        for (int g = 1; g <= P->ngroups && !v; ++g) if (P->names[g] && strcmp(P->names[g], word) == 0) v = g;
+                        if (!v) { fail(P, "back-reference to a group name that is not defined in front of it: unsupported"); return -1; }
+                    }
+                    int b = new_node(P, N_BACKREF);
+                    P->nodes[b].cap = v;
+                    if (v > P->maxbackref) P->maxbackref = v;
+                    return b;
+                }
+                case 'p': case 'P': case 'X': case 'C': case 'R': case 'K': case 'G': case 'N':
                     fail(P, "unsupported escape"); return -1;
                 default: break;
             }

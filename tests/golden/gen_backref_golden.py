@@ -9,7 +9,10 @@ quantifiers: 3.10) is pinned by the other two.  Vectors on which the engines dis
 Left out on purpose: a group that refers to ITSELF from inside ("(a\\1?)"), where Perl-family engines differ in what the half-open
 group holds.
 
-Writes tests/golden/backref_vectors.json: {"full": [...], "search": [...], "icase_full": [...]}, each list of
+Named and relative references (\\k<name>, \\g{-1} ...) are read by PCRE1 alone of the three: each such pattern is listed beside its \\N
+spelling and must give what all three engines give for that ("named_full").
+
+Writes tests/golden/backref_vectors.json: {"full": [...], "search": [...], "icase_full": [...], "named_full": [...]}, each list of
 {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]} (latin-1 strings).
 Run from the repo root:  python tests/golden/gen_backref_golden.py
 """
@@ -57,6 +60,21 @@ CURATED = [
     (rb'(a++)b\1', [b'aabaa', b'aaba']),
     (rb'(\w+)@\1\.(com|org)', [b'foo@foo.com', b'foo@bar.com', b'x@x.org', b'x@x.net']),
     (rb'([0-9a-f]{2})(?::\1){2}', [b'ab:ab:ab', b'ab:ab:ac', b'00:00:00']),
+]
+
+
+# named and relative forms (boost Perl syntax: \k<name> \k{name} \k'name' \g{name} \g{N} \gN \g{-N}).  Of the three engines only PCRE1
+# reads them all; each is listed beside its \N spelling and must give what the three engines give for THAT.
+NAMED = [
+    (rb'(?<q>["\'])(.*?)\k<q>', rb'(["\'])(.*?)\1', [b'"x"', b"'it'", b'"a\'', b'""', b'"a"b"']),
+    (rb"(?<w>\w+) \k{w}", rb"(\w+) \1", [b"abc abc", b"abc abd", b"a a", b"ab abab"]),
+    (rb"(?<w>\w+) \k'w'", rb"(\w+) \1", [b"abc abc", b"abc abd"]),
+    (rb"(?<w>\w+) \g{w}", rb"(\w+) \1", [b"abc abc", b"abc abd"]),
+    (rb"(\d\d)-\g{1}-\g1", rb"(\d\d)-\1-\1", [b"12-12-12", b"12-12-13", b"1-1-1"]),
+    (rb"(a)(?<x>b+)\g{-1}\g{-2}", rb"(a)(b+)\2\1", [b"abba", b"abbbba", b"abb", b"abab"]),
+    (rb"(\w)(\w)\g{-1}\g{-2}", rb"(\w)(\w)\2\1", [b"abba", b"abab", b"aaaa"]),
+    (rb"<(?<tag>\w+)>(.*)</\k<tag>>", rb"<(\w+)>(.*)</\1>", [b"<a>x</a>", b"<a>x</b>", b"<ab><ab>y</ab></ab>"]),
+    (rb"(?<k>\w+)=(?<v>\w+);\k<k>=\k<v>", rb"(\w+)=(\w+);\1=\2", [b"k=v;k=v", b"k=v;k=w", b"ab=c;ab=c"]),
 ]
 
 
@@ -153,6 +171,18 @@ def main():
                     (rb'(k)=(v) \2\1', [b'K=v VK', b'k=V vk', b'k=v kv'])]:
         for s in subs:
             add("icase_full", p, s)
+    out["named_full"] = []
+    for named, numeric, subs in NAMED:
+        for s_ in subs:
+            outs, ng = engines_full(numeric, s_, re.S | re.M, regex.S | regex.M, pcre, False)
+            assert len(outs) == 3 and all(o == outs[0] for o in outs), (numeric, s_)
+            exp = pcre.fullmatch(named, s_, ng)
+            assert exp == outs[0], (named, s_, exp, outs[0])
+            ent = next((c for c in out["named_full"] if c["p"] == named.decode("latin-1")), None)
+            if ent is None:
+                ent = {"p": named.decode("latin-1"), "g": ng, "numeric": numeric.decode("latin-1"), "subs": []}
+                out["named_full"].append(ent)
+            ent["subs"].append([s_.decode("latin-1"), None if exp is None else [v for ab in exp for v in ab]])
     n = 0
     while n < 500:
         groups = [0]
@@ -176,8 +206,9 @@ def main():
            "dropped_disagreements": dropped,
            "n_full": sum(len(c["subs"]) for c in out["full"]), "n_search": sum(len(c["subs"]) for c in out["search"]),
            "n_icase_full": sum(len(c["subs"]) for c in out["icase_full"]),
+           "n_named_full": sum(len(c["subs"]) for c in out["named_full"]),
            "format": "full/search/icase_full[i] = {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]}",
-           "full": out["full"], "search": out["search"], "icase_full": out["icase_full"]}
+           "full": out["full"], "search": out["search"], "icase_full": out["icase_full"], "named_full": out["named_full"]}
     with open(os.path.join(HERE, "backref_vectors.json"), "w") as f:
         json.dump(res, f, separators=(",", ":"))
     print("full", res["n_full"], "search", res["n_search"], "icase", res["n_icase_full"], "dropped", dropped,

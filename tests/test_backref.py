@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def vectors(golden_dir):
     with open(os.path.join(golden_dir, "backref_vectors.json")) as f:
         d = json.load(f)
-    assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["dropped_disagreements"] == 0
+    assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["n_named_full"] >= 29 and d["dropped_disagreements"] == 0
     return d
 
 
@@ -64,7 +64,7 @@ def _flat(got):
 # ------------------------------------------------------------------------------------------------ the oracle is pinned first
 def test_oracle_matches_the_backreference_vectors(vectors):
     bad = []
-    for kind in ("full", "search", "icase_full"):
+    for kind in ("full", "search", "icase_full", "named_full"):
         for c in vectors[kind]:
             rx = OracleRegex(c["p"].encode("latin-1"), flags=(1 if kind == "icase_full" else 0))   # ORX_ICASE
             assert rx.groups == c["g"], c["p"]
@@ -90,13 +90,20 @@ def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
     # an automaton cannot run it: asking for one is refused, never approximated
     with pytest.raises(B.RegexUnsupportedError):
         B.GpuRegex(rb'(a)\1', engine=B.LC_ENGINE_TDFA)
+    # by name and relative (boost Perl syntax): resolved to the group's number at compile time
+    assert B.GpuRegex(rb'(?<w>\w+) \k<w>').info()["engine"] == B.LC_ENGINE_BT
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(rb'\k<later>(?<later>a)')
+    # Grok's dialect (named-only numbering, regexp2 escapes) keeps refusing them: its matcher plans automata
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(rb'(?<w>\w+) \1', syntax_flags=B.LC_SYNTAX_NAMED_ONLY)
     # regular patterns still get their automata
     assert B.GpuRegex(rb'(a)b').info()["engine"] == B.LC_ENGINE_TDFA
 
 
 def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
     bad, checked = [], 0
-    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE)):
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0)):
         for c in vectors[kind]:
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
             assert rx.info()["engine"] == B.LC_ENGINE_BT
@@ -148,7 +155,7 @@ def test_budget_and_stack_are_reported_never_guessed(host_vm):
     rx = B.GpuRegex(rb'(a|aa)+\1b')
     s = b'a' * 40 + b'c'
     assert host_vm(rx, s, budget=1 << 14)[0] == -1          # exponential: out of steps -> gave up
-    assert host_vm(B.GpuRegex(rb'(?:(a)|b)*\1'), b'ab' * 600 + b'a', scratch_words=256)[0] == -1   # out of stack -> gave up
+    assert host_vm(B.GpuRegex(rb'(?:(a)|b)*\1'), b'ab' * 600 + b'a', scratch_words=256)[0] == -2   # out of stack: a second pass, then gave up
     r, caps = host_vm(B.GpuRegex(rb'(?:(a)|b)*\1'), b'ab' * 600 + b'a')   # (with the whole slice it is decided)
     assert r == 1 and caps == [0, 1201, 1198, 1199]
 
@@ -166,7 +173,7 @@ def torch_dev():
 def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
     from test_gpu_parity import pack, run_device
     bad, checked = [], 0
-    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE)):
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0)):
         for c in vectors[kind]:
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
             subs = [s.encode("latin-1") for s, _ in c["subs"]]
@@ -297,3 +304,19 @@ def test_multiline_split_with_backreference_patterns_against_the_oracle():
         for _ in range(150):
             val = b"\n".join(rng.choice(pool) for _ in range(rng.randint(0, 14)))
             assert m.split(val) == o.split(val), (config, val)
+
+
+@pytest.mark.gpu
+def test_values_that_fill_their_first_slice_are_decided_by_the_second_pass(torch_dev):
+    """(?:(a)|b)*\\1 keeps an alternative and an undo record per byte: 3 000-byte values overflow the 8 KB slices of pass 1, are left
+    pending and decided by pass 2 (64 KB slices); a 40 000-byte value overflows those too and is reported LC_GAVE_UP."""
+    from test_gpu_parity import pack, run_device
+    rx = B.GpuRegex(rb'(?:(a)|b)*\1')
+    o = OracleRegex(rb'(?:(a)|b)*\1')
+    subs = [b'ab' * 1500 + b'a', b'ab' * 1500 + b'b', b'aa', b'ab' * 20000 + b'a', b'b' * 3000, b'']
+    data, off, length = pack(subs)
+    caps, status = run_device(torch_dev, rx, data, off, length)
+    for i in (0, 1, 2, 4, 5):
+        want = o.fullmatch(subs[i])
+        assert (status[i] == B.LC_MATCH and list(caps[i]) == list(want[1])) if want else (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()), i
+    assert status[3] == B.LC_GAVE_UP
