@@ -254,6 +254,7 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                 // can_start test): a byte class behind the repeat would fail there at once and come straight back -- same result,
                 // without a step per byte.  A line that does NOT match its pattern is mostly this.
                 const uint32_t* nx = code + (a + 1u) * 4u;
+                while ((nx[0] & 0xFFu) == BT_SAVE) nx += 4;  // (a group that closes behind the repeat: zero-width, never fails)
                 if ((nx[0] & 0xFFu) == BT_SET)
                     while (cur > low && !btHas(sets, nx[1], s[cur])) --cur;
                 st[2u * top + 1u] = cur;
@@ -265,6 +266,7 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
             {  // BT_K_REP_LAZY: one byte more -- and on, while what follows cannot start there (as above)
                 const uint32_t* rep = code + a * 4u;
                 const uint32_t* nx = rep + 4u;
+                while ((nx[0] & 0xFFu) == BT_SAVE) nx += 4;
                 const bool skip = (nx[0] & 0xFFu) == BT_SET;
                 uint32_t cur = b, count = st[2u * (top - 1u) + 1u];
                 bool dead = false;

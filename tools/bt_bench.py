@@ -47,7 +47,7 @@ def main():
         total = int(length.sum())
         for name, pattern, engine in (("regex A, tagged DFA (the handle's engine)", corpus.REGEX_A, B.LC_ENGINE_AUTO),
                                       ("regex A, LC_ENGINE_BT", corpus.REGEX_A, B.LC_ENGINE_BT),
-                                      ("regex A with a back-reference (\\1 inside the referer), LC_ENGINE_BT", backref, B.LC_ENGINE_AUTO)):
+                                      ("regex A with a back-reference (\\1 at the head of the user agent), LC_ENGINE_BT", backref, B.LC_ENGINE_AUTO)):
             rx = B.GpuRegex(pattern, engine=engine if engine == B.LC_ENGINE_BT else B.LC_ENGINE_AUTO)
             G = rx.groups
             d_caps = torch.empty((n, 2 * G), dtype=torch.int32, device=dev)
