@@ -45,6 +45,7 @@ struct Builder {
         switch (n.kind) {
             case Node::Empty:
             case Node::Assert:
+            case Node::Look:
             case Node::BackRef: return true;  // (a group that matched the empty string refers to the empty string)
             case Node::Set: return false;
             case Node::Cat:
@@ -98,10 +99,24 @@ struct Builder {
                 emit(BT_ATOM_END);
                 break;
             case Node::Assert:
-                if (!n.aheadSeq.empty() || !n.behindSeq.empty() || n.window)
-                    throw RegexError("multi-byte look-around next to back-references: unsupported");
+                if (!n.behindSeq.empty()) throw RegexError("undecided look-behind sequence in the tree: unsupported");  // (the parser decides or converts them)
+                if (!n.aheadSeq.empty()) {  // a look-ahead over a sequence of byte classes (a window to the automata): the body in place
+                    const uint32_t begin = emit(n.aheadNegative ? BT_NLOOK_BEGIN : BT_LOOK_BEGIN);
+                    for (const ByteSet& b : n.aheadSeq) emit(BT_SET, 0, setId(b));
+                    emit(n.aheadNegative ? BT_NLOOK_END : BT_LOOK_END);
+                    x(begin) = here();
+                    break;
+                }
                 emit(BT_ASSERT, (n.look.behind ? 1u : 0u) | (n.look.edgeOk ? 2u : 0u), setId(n.look.set));
                 break;
+            case Node::Look: {
+                const uint32_t begin = emit(n.aheadNegative ? BT_NLOOK_BEGIN : BT_LOOK_BEGIN);
+                if (n.look.behind && n.min > 0) emit(BT_BACK, 0, uint32_t(n.min));
+                gen(*n.kids[0]);
+                emit(n.aheadNegative ? BT_NLOOK_END : BT_LOOK_END);
+                x(begin) = here();  // where a negative assertion that holds goes on
+                break;
+            }
             case Node::BackRef: emit(BT_BACKREF, 0, uint32_t(n.capture)); break;
             case Node::Repeat: genRepeat(n); break;
         }

@@ -12,6 +12,8 @@
 //   * a repeat whose body last matched the empty string stops iterating (match_rep's null check: MARK / CHK);
 //   * a back-reference to a group that took no part fails; under LC_SYNTAX_ICASE it compares ASCII-folded bytes;
 //   * an atomic group drops the alternatives opened inside it when it is left, and keeps the undo records;
+//   * a look-around's body runs in place (a look-behind's of fixed length k from k bytes back): a positive one is committed like an
+//     atomic group and gives the input back, its captures stay; a negative one holds when its body cannot match;
 //   * a step budget and the stack's capacity: a value that exhausts either is reported LC_GAVE_UP -- boost's complexity exception,
 //     which the reference counts as a parse failure (StringTools.cpp:200-205) -- never guessed.
 //
@@ -43,7 +45,12 @@ enum {
     BT_BACKREF = 8,  // x = group
     BT_ATOM_BEGIN = 9,
     BT_ATOM_END = 10,
-    BT_MATCH = 11
+    BT_MATCH = 11,
+    BT_LOOK_BEGIN = 12,   // a positive look-around: the body runs in place, then the position comes back (its captures stay)
+    BT_LOOK_END = 13,
+    BT_NLOOK_BEGIN = 14,  // a negative one; x = where the walk goes on when the body cannot match
+    BT_NLOOK_END = 15,    // the body matched: the assertion fails
+    BT_BACK = 16          // x = k: k bytes back (a look-behind's body of fixed length k runs forward from there); fewer behind: fail
 };
 constexpr uint32_t BT_INF = 0xFFFFFFFFu;
 constexpr uint32_t BT_NONE = 0xFFFFFFFFu;  // unset capture slot (-1 in the result row)
@@ -51,7 +58,8 @@ constexpr uint32_t BT_NONE = 0xFFFFFFFFu;  // unset capture slot (-1 in the resu
 // ---- stack entries: two words, kind | a << 4, b
 enum { BT_K_ALT = 0 /* a = pc, b = position */, BT_K_UNDO_CAP = 1 /* a = slot, b = old */, BT_K_UNDO_LOOP = 2, BT_K_ATOM_MARK = 3,
        BT_K_REP_GREEDY = 4 /* a = pc of the repeat, b = current end; the entry below (AUX) holds the lowest end */,
-       BT_K_REP_LAZY = 5 /* a = pc of the repeat, b = next byte to take; AUX below: bytes taken */, BT_K_AUX = 6 };
+       BT_K_REP_LAZY = 5 /* a = pc of the repeat, b = next byte to take; AUX below: bytes taken */, BT_K_AUX = 6,
+       BT_K_LOOK_MARK = 7 /* b = position the assertion stands at */, BT_K_NLOOK_MARK = 8 /* a = pc behind the assertion, b = position */ };
 
 LC_BT_HD bool btHas(const uint32_t* sets, uint32_t set, uint32_t c) { return (sets[set * 8u + (c >> 5)] >> (c & 31u)) & 1u; }
 LC_BT_HD uint32_t btFold(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32u : c; }
@@ -215,6 +223,55 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                 ++pc;
                 break;
             }
+            case BT_LOOK_BEGIN:
+                BT_PUSH(BT_K_LOOK_MARK, 0, pos);
+                ++pc;
+                break;
+            case BT_LOOK_END: {
+                // the body matched: committed like an atomic group (no way back into it, its captures stay), the input given back
+                uint32_t m = sp;
+                while (m > 0u && (st[2u * (m - 1u)] & 15u) != BT_K_LOOK_MARK) --m;
+                if (m == 0u) return -1;
+                --m;
+                pos = st[2u * m + 1u];
+                uint32_t w = m;
+                for (uint32_t r = m + 1u; r < sp; ++r) {
+                    const uint32_t kind = st[2u * r] & 15u;
+                    if (kind == BT_K_UNDO_CAP || kind == BT_K_UNDO_LOOP) {
+                        st[2u * w] = st[2u * r];
+                        st[2u * w + 1u] = st[2u * r + 1u];
+                        ++w;
+                    }
+                }
+                sp = w;
+                ++pc;
+                break;
+            }
+            case BT_NLOOK_BEGIN:
+                BT_PUSH(BT_K_NLOOK_MARK, in[1], pos);
+                ++pc;
+                break;
+            case BT_NLOOK_END:
+                // the body matched, so the assertion fails: everything the body did is undone, its mark goes, and the walk backtracks
+                for (;;) {
+                    if (sp == 0u) return -1;
+                    const uint32_t top = sp - 1u;
+                    const uint32_t kind = st[2u * top] & 15u, a = st[2u * top] >> 4, b = st[2u * top + 1u];
+                    if (kind == BT_K_UNDO_CAP) caps[a] = b;
+                    else if (kind == BT_K_UNDO_LOOP) loop[a] = b;
+                    sp = top;
+                    if (kind == BT_K_NLOOK_MARK) break;
+                }
+                fail = true;
+                break;
+            case BT_BACK:
+                if (pos < in[1]) {
+                    fail = true;
+                } else {
+                    pos -= in[1];
+                    ++pc;
+                }
+                break;
             case BT_MATCH:
                 if (pos == n) return 1;
                 fail = true;
@@ -237,9 +294,15 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                 sp = top;
                 continue;
             }
-            if (kind == BT_K_ATOM_MARK || kind == BT_K_AUX) {
+            if (kind == BT_K_ATOM_MARK || kind == BT_K_AUX || kind == BT_K_LOOK_MARK) {
                 sp = top;
                 continue;
+            }
+            if (kind == BT_K_NLOOK_MARK) {  // the body cannot match: the assertion holds, the walk goes on behind it
+                pc = a;
+                pos = b;
+                sp = top;
+                break;
             }
             if (kind == BT_K_ALT) {
                 pc = a;

@@ -73,7 +73,7 @@ struct LookAssert {
 };
 
 struct Node {
-    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic, BackRef } kind = Empty;
+    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic, BackRef, Look } kind = Empty;
     std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group/Atomic: 1
     ByteSet set;                               // Set
     int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
@@ -97,6 +97,10 @@ struct Node {
     // automata stamp the BEGIN slot only; the end is a function of the begin and is filled in after the match
     // (gpu_runtime.hip run_capture_kernel).  kids[0] is an Empty node.
     bool runCapture = false;
+    // Look (round 6): a GENERAL look-around -- kids[0] is the body, aheadNegative its sign, look.behind its direction, min the body's
+    // fixed length for a look-behind (the walk steps that many bytes back and runs the body forward, as the backtracking engines do).
+    // What the one-byte and class-sequence forms above do not cover ("(?=a+b)", "(?<=ab|cd)", a look-behind the text in front of it does
+    // not decide): no automaton is built for such a tree, it runs on the device backtracking engine (bt_vm.hpp).
 };
 
 struct ParsedRegex {
@@ -106,6 +110,7 @@ struct ParsedRegex {
     // round 6: the pattern holds back-references (\1 .. \N): not a regular language -- no automaton is built, the handle runs the
     // device backtracking engine (bt_program.hpp, bt_vm.hpp: LC_ENGINE_BT)
     bool hasBackRef = false;
+    bool hasGeneralLook = false;           // ... or general look-arounds (Node::Look): the same engine
 };
 
 ParsedRegex parseRegex(std::string_view pattern, Syntax syntax = Syntax());

@@ -1641,9 +1641,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         }
         // Not regular (back-references), or the caller asked for it: the device backtracking engine (bt_vm.hpp).  No automaton is
         // built; a search / prefix match is the same wrapped whole-value pattern the automata get.
-        if (parsed.hasBackRef || engine == LC_ENGINE_BT) {
+        if (parsed.hasBackRef || parsed.hasGeneralLook || engine == LC_ENGINE_BT) {
             if (engine == LC_ENGINE_TDFA || engine == LC_ENGINE_NFA)
-                throw RegexError("back-references need the backtracking engine (LC_ENGINE_AUTO / LC_ENGINE_BT): unsupported on this engine");
+                throw RegexError("back-references and general look-arounds need the backtracking engine (LC_ENGINE_AUTO / LC_ENGINE_BT): unsupported on this engine");
             const bool anchored = (syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX);
             if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed, anchored);
             else if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
@@ -1666,7 +1666,26 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         const bool anchoredSearch = (syntax_flags & LC_SYNTAX_SEARCH) && (syntax_flags & LC_SYNTAX_PREFIX);
         if (syntax_flags & LC_SYNTAX_SEARCH) wrapForSearch(parsed, anchoredSearch);
         else if (syntax_flags & LC_SYNTAX_PREFIX) wrapForPrefix(parsed);
-        re->nfa = buildFollowNfa(parsed);
+        try {
+            re->nfa = buildFollowNfa(parsed);
+        } catch (const RegexError& nfaError) {
+            // A tree the parser accepts and the position automaton cannot express ("(a*)*": an unbounded repeat of a body that may match
+            // nothing): boost backtracks through it like through anything else, and so does the device backtracking engine -- unless the
+            // caller asked for an automaton, or the pattern comes in Grok's dialect (its matcher plans automata).
+            if (engine != LC_ENGINE_AUTO || syn.namedOnly || syn.regexp2) throw;
+            try {
+                re->btBlob = lcregex::buildBtProgram(parsed, syn.icase);
+            } catch (const RegexError&) {
+                throw nfaError;
+            }
+            re->engine = LC_ENGINE_BT;
+            re->nfa = lcregex::FollowNfa();
+            re->nfa.groupCount = parsed.groupCount;
+            re->nfa.groupNames = parsed.groupNames;
+            setErr(err, errcap, "");
+            *out = re;
+            return LC_OK;
+        }
         if (syntax_flags & LC_SYNTAX_SEARCH) {  // wrapForSearch generates its prefix '.' first and its suffix '.' last
             re->nfa.searchPrefix = anchoredSearch ? -1 : 0;
             re->nfa.searchSuffix = int(re->nfa.positions.size()) - 1;

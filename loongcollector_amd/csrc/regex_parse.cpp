@@ -112,6 +112,7 @@ public:
             if (r > mGroups) throw RegexError("invalid back reference: \\" + std::to_string(r) + " with " + std::to_string(mGroups) + " groups");
         }
         out.hasBackRef = !mBackRefs.empty();
+        out.hasGeneralLook = mGeneralLook;
         return out;
     }
 
@@ -122,6 +123,59 @@ private:
     int mGroups = 0;
     std::vector<std::string> mNames;
     std::vector<int> mBackRefs;
+    bool mGeneralLook = false;
+
+    // every match of `n` has this length, or -1 (a look-behind body must have one: Perl, PCRE, regexp2 and boost agree)
+    static int fixedLen(const Node& n) {
+        switch (n.kind) {
+            case Node::Empty:
+            case Node::Assert:
+            case Node::Look: return 0;
+            case Node::Set: return 1;
+            case Node::Cat: {
+                int sum = 0;
+                for (const auto& k : n.kids) {
+                    const int a = fixedLen(*k);
+                    if (a < 0) return -1;
+                    sum += a;
+                }
+                return sum;
+            }
+            case Node::Alt: {
+                int len = -2;
+                for (const auto& k : n.kids) {
+                    const int a = fixedLen(*k);
+                    if (a < 0 || (len != -2 && a != len)) return -1;
+                    len = a;
+                }
+                return len < 0 ? 0 : len;
+            }
+            case Node::Repeat: {
+                const int a = fixedLen(*n.kids[0]);
+                return (a < 0 || n.min != n.max) ? -1 : a * n.min;
+            }
+            case Node::Group: return n.runCapture ? -1 : fixedLen(*n.kids[0]);
+            case Node::Atomic: return fixedLen(*n.kids[0]);
+            case Node::BackRef: return -1;
+        }
+        return -1;
+    }
+    // the general form (Node::Look): runs on the device backtracking engine.  Not under Grok's dialect: its matcher plans automata.
+    NodePtr generalLook(NodePtr body, bool behind, bool negative, const char* why) {
+        if (mSyn.namedOnly || mSyn.regexp2) bail(why);
+        int k = 0;
+        if (behind) {
+            k = fixedLen(*body);
+            if (k < 0) bail("unsupported: look-behind body of variable length");  // (boost refuses it too)
+        }
+        auto n = mk(Node::Look);
+        n->look.behind = behind;
+        n->aheadNegative = negative;
+        n->min = k;
+        n->kids.push_back(std::move(body));
+        mGeneralLook = true;
+        return n;
+    }
 
     bool atEnd() const { return mPos >= mPat.size(); }
     unsigned peek(size_t ahead = 0) const { return static_cast<unsigned char>(mPat[mPos + ahead]); }
@@ -410,7 +464,7 @@ private:
             for (const auto& k : n->kids) {
                 const Node* e = k.get();
                 while ((e->kind == Node::Group && e->capture == 0) && e->kids.size() == 1) e = e->kids[0].get();
-                if (e->kind != Node::Set) bail("unsupported: look-ahead body must be a sequence of character classes");
+                if (e->kind != Node::Set) return generalLook(std::move(body), false, negative, "unsupported: look-ahead body must be a sequence of character classes");
                 a->aheadSeq.push_back(e->set);
             }
             a->aheadNegative = negative;
@@ -421,13 +475,13 @@ private:
             for (const auto& k : n->kids) {
                 const Node* e = k.get();
                 while ((e->kind == Node::Group && e->capture == 0) && e->kids.size() == 1) e = e->kids[0].get();
-                if (e->kind != Node::Set) bail("unsupported: look-behind body must be a sequence of character classes");
+                if (e->kind != Node::Set) return generalLook(std::move(body), true, negative, "unsupported: look-behind body must be a sequence of character classes");
                 a->behindSeq.push_back(e->set);
             }
             a->behindNegative = negative;
             return a;
         }
-        if (n->kind != Node::Set) bail("unsupported: look-around body must be a single character class");
+        if (n->kind != Node::Set) return generalLook(std::move(body), behind, negative, "unsupported: look-around body must be a single character class");
         ByteSet set = n->set;
         if (negative) set.invert();
         return look(behind, set, negative);
@@ -630,7 +684,8 @@ private:
             // \N: a back-reference (boost perl_matcher::match_backref; regexp2 likewise): the bytes group N matched last, again.  Not
             // regular: the pattern goes to the device backtracking engine (bt_vm.hpp).  Under Grok's named-only numbering the digits
             // would not count the groups the author sees: refused there.
-            if (mSyn.namedOnly) bail("back-references with named-only captures unsupported");
+            // Nor in the Go plugins' escape dialect: processor_regex compiles with Go's regexp (RE2), which has no back-references.
+            if (mSyn.namedOnly || mSyn.regexp2) bail("back-references with named-only captures / in the Go plugins' dialect unsupported");
             unsigned v = e - '0';
             while (has(0) && peek() >= '0' && peek() <= '9' && v * 10 + (peek() - '0') <= 999) {
                 v = v * 10 + (peek() - '0');
@@ -803,8 +858,20 @@ private:
                 if (!fixedWidthSets(*seq->kids[j], w)) break;
                 for (size_t q = w.size(); q-- > 0;) before.push_back(w[q]);
             }
-            if (before.size() < k.behindSeq.size())
-                bail("unsupported: multi-byte look-behind that the preceding sub-expression does not decide");
+            auto asGeneral = [&]() {  // the class sequence as a body the backtracking engine runs k bytes back
+                auto body = mk(Node::Cat);
+                for (const ByteSet& b : k.behindSeq) {
+                    auto e = mk(Node::Set);
+                    e->set = b;
+                    body->kids.push_back(std::move(e));
+                }
+                seq->kids[i] = generalLook(std::move(body), true, k.behindNegative,
+                                           "unsupported: multi-byte look-behind that the preceding sub-expression does not decide");
+            };
+            if (before.size() < k.behindSeq.size()) {
+                asGeneral();
+                continue;
+            }
             bool holds = true, fails = false;
             const size_t n = k.behindSeq.size();
             for (size_t d = 0; d < n; ++d) {
@@ -818,7 +885,10 @@ private:
                 holds = holds && subset;
                 fails = fails || !meet;
             }
-            if (!holds && !fails) bail("unsupported: multi-byte look-behind that the preceding sub-expression does not decide");
+            if (!holds && !fails) {
+                asGeneral();
+                continue;
+            }
             const bool truth = k.behindNegative ? fails : holds;
             if (truth) seq->kids[i] = mk(Node::Empty);
             else seq->kids[i] = mk(Node::Set);  // empty class: this branch cannot match
@@ -865,6 +935,7 @@ private:
                 return true;
             }
             case Node::Assert: return n.aheadSeq.empty() && n.behindSeq.empty();  // (one-byte assertions are zero-width: transparent)
+            case Node::Look: return true;  // (zero-width)
             case Node::Atomic: return false;
         }
         return false;
@@ -875,6 +946,7 @@ private:
     static bool firstOf(const Node& n, ByteSet& out) {
         switch (n.kind) {
             case Node::Empty:
+            case Node::Look:
             case Node::Assert: return true;
             case Node::Set:
                 for (int w = 0; w < 4; ++w) out.w[w] |= n.set.w[w];

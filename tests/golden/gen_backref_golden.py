@@ -78,6 +78,29 @@ NAMED = [
 ]
 
 
+# general look-arounds (round 6, the same engine): bodies that are not a byte class or a sequence of byte classes -- repeats, alternations,
+# captures, back-references inside; look-behinds of fixed length.  All three engines read them.
+LOOK = [
+    (rb'(?=a+b)(\w+)', [b'aab', b'aaab1', b'aac', b'b']),
+    (rb'(\w+?)(?=\d+$)(\d+)', [b'abc123', b'a1', b'abc', b'12']),
+    (rb'(?!\d+x)(\w+)', [b'12x', b'12y', b'x', b'1x2']),
+    (rb'(\w+) (?=(\w+) \2)(.*)', [b'a b b', b'a b c', b'k vv vv z']),
+    (rb'(\w+)(?= \1) .*', [b'ab ab', b'ab abc', b'ab cd']),
+    (rb'(?=(a+))a*b\1', [b'aaba', b'aabaa', b'ab', b'aab']),
+    (rb'(.*)(?<=ab|cd)(x*)', [b'abx', b'cdxx', b'acx', b'ab', b'zzcd']),
+    (rb'(\w+)(?<!\d\d)-(\w+)', [b'ab-c', b'a12-c', b'a1-c', b'12-3']),
+    (rb'(?<=(?:ab){2})c(.*)', [b'ababc', b'abc']),
+    (rb'(.*?)(?<=[a-c]{2}\d)!(.*)', [b'ab1!x', b'ad1!x', b'zzbc9!', b'c9!']),
+    (rb'((?:(?!<b>).)*)<b>(.*)', [b'abc<b>x', b'<b>', b'a<b<b>y', b'abc']),
+    (rb'(?:(?=\w+:)(\w+):|(\d+))+', [b'k:12', b'12k:', b'a:b:', b'a:b']),
+    (rb'(?=.*\d)(?=.*[a-z])(\S{4,})', [b'abc1', b'abcd', b'1234', b'a1', b'xx9yy']),
+    (rb'(a|ab)(?=c|bc)(.*)', [b'abc', b'ac', b'abbc', b'ab']),
+    (rb'(?!(a)\1)(\w+)', [b'aab', b'aba', b'ab']),
+    (rb'(\d+)(?<=[13579])(\w*)', [b'123x', b'124x', b'9', b'12']),
+    (rb'(?<=,|;)(\w+)(?=,|$)(.*)', [b',ab,cd', b';ab', b',ab cd', b'ab']),
+]
+
+
 def engines_full(p, s, flags_re, flags_rx, pcre, icase):
     r2 = regex.compile(p, flags_rx)
     m2 = r2.fullmatch(s)
@@ -140,7 +163,7 @@ def main():
     def add(kind, p, s):
         nonlocal dropped
         try:
-            if kind == "full":
+            if kind in ("full", "look_full"):
                 outs, ng = engines_full(p, s, re.S | re.M, regex.S | regex.M, pcre, False)
             elif kind == "icase_full":
                 outs, ng = engines_full(p, s, re.S | re.M | re.I, regex.S | regex.M | regex.I, pcre, True)
@@ -171,6 +194,12 @@ def main():
                     (rb'(k)=(v) \2\1', [b'K=v VK', b'k=V vk', b'k=v kv'])]:
         for s in subs:
             add("icase_full", p, s)
+    out["look_full"], out["look_search"] = [], []
+    for p, subs in LOOK:
+        for s_ in subs:
+            add("look_full", p, s_)
+            add("look_search", p, b"zz " + s_ + b" !")
+            add("look_search", p, s_)
     out["named_full"] = []
     for named, numeric, subs in NAMED:
         for s_ in subs:
@@ -207,8 +236,10 @@ def main():
            "n_full": sum(len(c["subs"]) for c in out["full"]), "n_search": sum(len(c["subs"]) for c in out["search"]),
            "n_icase_full": sum(len(c["subs"]) for c in out["icase_full"]),
            "n_named_full": sum(len(c["subs"]) for c in out["named_full"]),
+           "n_look_full": sum(len(c["subs"]) for c in out["look_full"]), "n_look_search": sum(len(c["subs"]) for c in out["look_search"]),
            "format": "full/search/icase_full[i] = {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]}",
-           "full": out["full"], "search": out["search"], "icase_full": out["icase_full"], "named_full": out["named_full"]}
+           "full": out["full"], "search": out["search"], "icase_full": out["icase_full"], "named_full": out["named_full"],
+           "look_full": out["look_full"], "look_search": out["look_search"]}
     with open(os.path.join(HERE, "backref_vectors.json"), "w") as f:
         json.dump(res, f, separators=(",", ":"))
     print("full", res["n_full"], "search", res["n_search"], "icase", res["n_icase_full"], "dropped", dropped,

@@ -28,7 +28,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def vectors(golden_dir):
     with open(os.path.join(golden_dir, "backref_vectors.json")) as f:
         d = json.load(f)
-    assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["n_named_full"] >= 29 and d["dropped_disagreements"] == 0
+    # (the 7 dropped vectors: PCRE1 8.45 takes "(?=.*\\d)..." for an anchored pattern and misses two searches; the `regex` module keeps a
+    # capture made inside a NEGATIVE look-ahead where CPython and PCRE1 -- and the oracle -- undo it)
+    assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["n_named_full"] >= 29 and d["dropped_disagreements"] <= 7
+    assert d["n_look_full"] >= 60 and d["n_look_search"] >= 120
     return d
 
 
@@ -64,13 +67,13 @@ def _flat(got):
 # ------------------------------------------------------------------------------------------------ the oracle is pinned first
 def test_oracle_matches_the_backreference_vectors(vectors):
     bad = []
-    for kind in ("full", "search", "icase_full", "named_full"):
+    for kind in ("full", "search", "icase_full", "named_full", "look_full", "look_search"):
         for c in vectors[kind]:
             rx = OracleRegex(c["p"].encode("latin-1"), flags=(1 if kind == "icase_full" else 0))   # ORX_ICASE
             assert rx.groups == c["g"], c["p"]
             for subj, flat in c["subs"]:
                 s = subj.encode("latin-1")
-                got = rx.search(s) if kind == "search" else rx.fullmatch(s)
+                got = rx.search(s) if kind.endswith("search") else rx.fullmatch(s)
                 if _flat(got) != flat:
                     bad.append((kind, c["p"], subj, _flat(got), flat))
     assert not bad, bad[:5]
@@ -103,11 +106,13 @@ def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
 
 def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
     bad, checked = [], 0
-    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0)):
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
+                        ("look_search", B.LC_SYNTAX_SEARCH)):
         for c in vectors[kind]:
-            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
-            assert rx.info()["engine"] == B.LC_ENGINE_BT
-            assert rx.groups == c["g"] + (1 if kind == "search" else 0)
+            # (a look-around the automata can run -- a window of byte classes -- keeps its automaton: here the engine is asked for)
+            rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags, engine=B.LC_ENGINE_AUTO if "look" not in kind else B.LC_ENGINE_BT)
+            assert rx.info()["engine"] == B.LC_ENGINE_BT, c["p"]
+            assert rx.groups == c["g"] + (1 if kind.endswith("search") else 0)
             for subj, flat in c["subs"]:
                 s = subj.encode("latin-1")
                 r, caps = host_vm(rx, s)
@@ -115,7 +120,7 @@ def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
                 if flat is None:
                     ok = r == 0
                 else:  # slots 0/1 are the wrapped whole-value match; a search's group 1 is the golden group 0
-                    ok = r == 1 and caps[:2] == [0, len(s)] and caps[2:] == (flat if kind == "search" else flat[2:])
+                    ok = r == 1 and caps[:2] == [0, len(s)] and caps[2:] == (flat if kind.endswith("search") else flat[2:])
                 if not ok:
                     bad.append((kind, c["p"], subj, r, caps, flat))
     assert checked > 5000
@@ -123,7 +128,8 @@ def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
 
 
 @pytest.mark.parametrize("name,key", [("regex_golden.json", "cases"), ("regex_atomic_golden.json", "full"), ("regex_atomic_golden.json", "search"),
-                                      ("regex_search_golden.json", "cases")])
+                                      ("regex_search_golden.json", "cases"), ("regex_lookaround_golden.json", "full"),
+                                      ("regex_lookaround_golden.json", "search")])
 def test_backtracking_programs_agree_with_the_goldens_of_the_automata(golden_dir, host_vm, name, key):
     """LC_ENGINE_BT asked for explicitly: the same vectors the tagged DFA and the thread-list engine are pinned on (CPython re ∧ PCRE1,
     regex ∧ PCRE1).  Patterns the engine does not run (multi-byte look-around windows) are refused at compile time and skipped."""
@@ -173,7 +179,8 @@ def torch_dev():
 def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
     from test_gpu_parity import pack, run_device
     bad, checked = [], 0
-    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0)):
+    for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
+                        ("look_search", B.LC_SYNTAX_SEARCH)):
         for c in vectors[kind]:
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
             subs = [s.encode("latin-1") for s, _ in c["subs"]]
@@ -181,7 +188,7 @@ def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
             caps, status = run_device(torch_dev, rx, data, off, length)
             for i, (_, flat) in enumerate(c["subs"]):
                 checked += 1
-                exp = flat if kind == "search" or flat is None else flat[2:]
+                exp = flat if kind.endswith("search") or flat is None else flat[2:]
                 ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (
                     status[i] == B.LC_MATCH and list(caps[i]) == exp)
                 if not ok:

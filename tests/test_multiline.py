@@ -51,7 +51,7 @@ def test_init_rules():
     assert m.patterns == {"start": False, "continue": False, "end": True} and "StartPattern is not a valid regex" in m.warnings
     assert MultilineOracle(StartPattern="(", EndPattern="x").start is None
     with pytest.raises(MultilineInitError):
-        Multiline(StartPattern=r"(?=a+b)a")
+        Multiline(StartPattern=r"(?<=a+)b")
     # (round 6: back-references run on the device backtracking engine -- tests/test_backref.py has the split on the device)
     assert Multiline(StartPattern=r"(a)\1").patterns["start"] is True
     o = MultilineOracle(StartPattern="a", ContinuePattern="b", EndPattern="c")
