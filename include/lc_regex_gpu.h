@@ -73,9 +73,11 @@ enum {
                             line); for cross-checking the engines against each other and for diagnosis */
     LC_ENGINE_BT = 4      /* round 6: the device BACKTRACKING engine (csrc/bt_vm.hpp): one line per lane, an instruction program and
                             an explicit stack in HBM -- what boost::regex_match itself does (StringTools.cpp:183-211).  Chosen by
-                            LC_ENGINE_AUTO for patterns that are not regular (back-references \1 .. \N); may be asked for any
-                            pattern it can run, which is how the tests cross-check it against the automata.  A line that runs out
-                            of its step budget or stack is LC_GAVE_UP */
+                            LC_ENGINE_AUTO for patterns no automaton runs: back-references (\1 .. \N, \k<name>, \g{-1}), general
+                            look-arounds ((?=a+b), (?<=ab|cd)), trees the position automaton cannot express ((a*)*); may be asked
+                            for any pattern it can run, which is how the tests cross-check it against the automata.  A line that
+                            runs out of its step budget or stack is LC_GAVE_UP.  Not under LC_SYNTAX_NAMED_ONLY / LC_SYNTAX_REGEXP2
+                            (the Go plugins' dialects) */
 };
 
 /* per-line status bytes */
