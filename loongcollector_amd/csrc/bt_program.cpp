@@ -59,6 +59,7 @@ struct Builder {
             case Node::Repeat: return n.min == 0 || nullable(*n.kids[0]);
             case Node::Group:
             case Node::Atomic: return nullable(*n.kids[0]);
+            case Node::Cond: return nullable(*n.kids[0]) || nullable(*n.kids[1]);
         }
         return true;
     }
@@ -118,6 +119,15 @@ struct Builder {
                 break;
             }
             case Node::BackRef: emit(BT_BACKREF, 0, uint32_t(n.capture)); break;
+            case Node::Cond: {
+                const uint32_t c = emit(BT_COND, 0, uint32_t(n.capture));
+                gen(*n.kids[0]);
+                const uint32_t j = emit(BT_JMP);
+                y(c) = here();
+                gen(*n.kids[1]);
+                x(j) = here();
+                break;
+            }
             case Node::Repeat: genRepeat(n); break;
         }
     }

@@ -50,7 +50,8 @@ enum {
     BT_LOOK_END = 13,
     BT_NLOOK_BEGIN = 14,  // a negative one; x = where the walk goes on when the body cannot match
     BT_NLOOK_END = 15,    // the body matched: the assertion fails
-    BT_BACK = 16          // x = k: k bytes back (a look-behind's body of fixed length k runs forward from there); fewer behind: fail
+    BT_BACK = 16,         // x = k: k bytes back (a look-behind's body of fixed length k runs forward from there); fewer behind: fail
+    BT_COND = 17          // x = group, y = where the "no" branch starts: group x has taken part -> go on (the "yes" branch), else y
 };
 constexpr uint32_t BT_INF = 0xFFFFFFFFu;
 constexpr uint32_t BT_NONE = 0xFFFFFFFFu;  // unset capture slot (-1 in the result row)
@@ -263,6 +264,10 @@ LC_BT_HD int btRun(const uint32_t* blob, const uint8_t* s, uint32_t n, uint32_t 
                     if (kind == BT_K_NLOOK_MARK) break;
                 }
                 fail = true;
+                break;
+            case BT_COND:
+                if (caps[2u * in[1] + 1u] != BT_NONE) ++pc;
+                else pc = in[2];
                 break;
             case BT_BACK:
                 if (pos < in[1]) {

@@ -73,7 +73,7 @@ struct LookAssert {
 };
 
 struct Node {
-    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic, BackRef, Look } kind = Empty;
+    enum Kind : uint8_t { Empty, Set, Cat, Alt, Repeat, Group, Assert, Atomic, BackRef, Look, Cond } kind = Empty;
     std::vector<std::unique_ptr<Node>> kids;  // Cat/Alt: n children; Repeat/Group/Atomic: 1
     ByteSet set;                               // Set
     int min = 0, max = -1;                     // Repeat (max < 0: unbounded)
@@ -97,6 +97,8 @@ struct Node {
     // automata stamp the BEGIN slot only; the end is a function of the begin and is filled in after the match
     // (gpu_runtime.hip run_capture_kernel).  kids[0] is an Empty node.
     bool runCapture = false;
+    // Cond (round 6): "(?(N)yes|no)" -- capture = the group asked about, kids[0] = yes, kids[1] = no (Empty when absent); runs on the
+    // device backtracking engine like Look (below)
     // Look (round 6): a GENERAL look-around -- kids[0] is the body, aheadNegative its sign, look.behind its direction, min the body's
     // fixed length for a look-behind (the walk steps that many bytes back and runs the body forward, as the backtracking engines do).
     // What the one-byte and class-sequence forms above do not cover ("(?=a+b)", "(?<=ab|cd)", a look-behind the text in front of it does

@@ -156,6 +156,10 @@ private:
             }
             case Node::Group: return n.runCapture ? -1 : fixedLen(*n.kids[0]);
             case Node::Atomic: return fixedLen(*n.kids[0]);
+            case Node::Cond: {
+                const int a = fixedLen(*n.kids[0]), b = fixedLen(*n.kids[1]);
+                return (a < 0 || a != b) ? -1 : a;
+            }
             case Node::BackRef: return -1;
         }
         return -1;
@@ -517,6 +521,31 @@ private:
                 auto a = mk(Node::Atomic);
                 a->kids.push_back(std::move(inner));
                 return a;
+            } else if (d == '(' && has(1) && peek(1) >= '1' && peek(1) <= '9' && !mSyn.namedOnly && !mSyn.regexp2) {
+                // (?(N)yes|no): yes when group N has taken part, else no (absent: nothing).  Not regular bookkeeping: the device
+                // backtracking engine (bt_vm.hpp BT_COND).  Conditions on names, look-arounds or recursion stay refused.
+                ++mPos;
+                int v = 0;
+                while (!atEnd() && peek() >= '0' && peek() <= '9' && v < 1000) v = v * 10 + int(peek() - '0'), ++mPos;
+                if (atEnd() || peek() != ')') bail("unsupported group construct (recursion/conditional)");
+                ++mPos;
+                NodePtr inner = alternation(depth + 1);
+                if (atEnd() || peek() != ')') bail("missing )");
+                ++mPos;
+                mSyn = saved;
+                auto c = mk(Node::Cond);
+                c->capture = v;
+                if (inner->kind == Node::Alt) {
+                    if (inner->kids.size() > 2) bail("a conditional has at most two alternatives");
+                    c->kids.push_back(std::move(inner->kids[0]));
+                    c->kids.push_back(std::move(inner->kids[1]));
+                } else {
+                    c->kids.push_back(std::move(inner));
+                    c->kids.push_back(mk(Node::Empty));
+                }
+                mBackRefs.push_back(v);   // (validated like a reference: the group has to exist)
+                mGeneralLook = true;
+                return c;
             } else if (d == '|' || d == '(' || d == 'R' || d == '&' || d == '+' || (d >= '0' && d <= '9')) {
                 bail("unsupported group construct (recursion/conditional)");
             } else if (d == '<' || d == 'P' || d == '\'') {
@@ -969,6 +998,10 @@ private:
             case Node::BackRef:  // (whatever the group held, the empty string included)
                 for (int w = 0; w < 4; ++w) out.w[w] = ~uint64_t(0);
                 return true;
+            case Node::Cond: {
+                const bool a = firstOf(*n.kids[0], out), b = firstOf(*n.kids[1], out);
+                return a || b;
+            }
         }
         return true;
     }

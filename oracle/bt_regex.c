@@ -16,7 +16,8 @@
  *   - back-references \1 .. \N (round 6; perl_matcher::match_backref): the bytes group N matched last, again; a group that took
  *     no part fails the reference; under ORX_ICASE the comparison folds ASCII case.  Pinned against CPython's `re` on the vectors of
  *     tests/golden/backref_vectors.json (tools/gen_backref_golden.py); boost itself is on neither box.
- * Unsupported (compile error): look-behind bodies of variable length, recursion, conditionals, \p{..}, collating elements.
+ *   - conditionals on a group (?(N)yes|no) (round 6).
+ * Unsupported (compile error): look-behind bodies of variable length, recursion, conditions on names / look-arounds, \p{..}, collating elements.
  */
 #include "bt_regex.h"
 
@@ -80,7 +81,7 @@ static int cs_posix(cset* s, const char* name, size_t n) {
 /* ------------------------------------------------------------------ AST */
 enum { N_EMPTY, N_SET, N_CAT, N_ALT, N_REP, N_GROUP, N_ASSERT, N_ATOMIC,
        N_LOOKAHEAD /* general (?=X) (?!X): max = negative; min = k > 0: the look-BEHIND (?<=X) (?<!X) of a body of fixed length k */,
-       N_BACKREF /* cap = the group referred to */ };
+       N_BACKREF /* cap = the group referred to */, N_COND /* (?(cap)l|r) */ };
 enum {
     A_BOL_ML, A_BOL_SL, A_EOL_ML, A_EOL_SL, A_BUF_START, A_BUF_END, A_BUF_END_NL,
     A_WORDB, A_NWORDB, A_WORD_START, A_WORD_END,
@@ -99,7 +100,7 @@ typedef struct {
 #define ORX_MAX_GROUPS 1023
 enum { I_SET, I_SPLIT, I_JMP, I_SAVE, I_ASSERT, I_MATCH, I_MARK, I_CHK, I_REPSET, I_ATOM_BEGIN, I_ATOM_END, I_LOOK_BEGIN, I_LOOK_END, I_NLOOK_BEGIN, I_NLOOK_END,
        I_BACK /* x = k: step back k bytes (inside a look-behind, right behind its mark); fewer than k behind: backtrack */,
-       I_BACKREF /* x = group */ };
+       I_BACKREF /* x = group */, I_COND /* x = group, y = pc of the "no" branch */ };
 typedef struct { int op, x, y, z, w; } inst;
 /* I_REPSET: x=set, y=min, z=max(-1 inf), w=greedy */
 
@@ -295,6 +296,7 @@ static int fixed_len(const orx_prog* P, int n) {
         case N_ALT: { int a = fixed_len(P, nd->l), b = fixed_len(P, nd->r); return (a < 0 || a != b) ? -1 : a; }
         case N_REP: { int a = fixed_len(P, nd->l); return (a < 0 || nd->min != nd->max) ? -1 : a * nd->min; }
         case N_GROUP: case N_ATOMIC: return fixed_len(P, nd->l);
+        case N_COND: { int a = fixed_len(P, nd->l), b = fixed_len(P, nd->r); return (a < 0 || a != b) ? -1 : a; }
     }
     return -1;
 }
@@ -362,6 +364,29 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                     int a = new_node(P, N_ATOMIC);
                     P->nodes[a].l = inner;
                     return a;
+                } else if (d == '(' && P->i + 1 < P->n && P->p[P->i + 1] >= '1' && P->p[P->i + 1] <= '9' && !(P->flags & ORX_REGEXP2)) {
+                    /* (?(N)yes|no): yes when group N has taken part (perl_matcher::match_assert_backref's sub-expression test) */
+                    ++P->i;
+                    int v = 0;
+                    while (P->i < P->n && P->p[P->i] >= '0' && P->p[P->i] <= '9' && v < 1000) v = v * 10 + (P->p[P->i++] - '0');
+                    if (P->i >= P->n || P->p[P->i] != ')') { fail(P, "unsupported group construct (recursion/conditional)"); return -1; }
+                    ++P->i;
+                    int inner = parse_alt(P, depth + 1);
+                    if (P->failed) return -1;
+                    if (P->i >= P->n || P->p[P->i] != ')') { fail(P, "missing )"); return -1; }
+                    ++P->i;
+                    P->flags = saved;
+                    int c = new_node(P, N_COND);
+                    P->nodes[c].cap = v;
+                    if (P->nodes[inner].kind == N_ALT) {
+                        int yes = P->nodes[inner].l, no = P->nodes[inner].r;
+                        if (P->nodes[yes].kind == N_ALT || P->nodes[no].kind == N_ALT) { fail(P, "a conditional has at most two alternatives"); return -1; }
+                        P->nodes[c].l = yes; P->nodes[c].r = no;
+                    } else {
+                        P->nodes[c].l = inner; P->nodes[c].r = new_node(P, N_EMPTY);
+                    }
+                    if (v > P->maxbackref) P->maxbackref = v;
+                    return c;
                 } else if (d == '|' || d == '(' || d == 'R' || d == '&' || (d >= '0' && d <= '9') || d == '+') {
                     fail(P, "unsupported group construct (recursion/conditional)");
                     return -1;
@@ -617,6 +642,7 @@ static int nullable(const orx_prog* P, int n) {
         case N_ATOMIC: return nullable(P, nd->l);
         case N_LOOKAHEAD: return 1;
         case N_BACKREF: return 1;
+        case N_COND: return nullable(P, nd->l) || nullable(P, nd->r);
     }
     return 1;
 }
@@ -643,6 +669,15 @@ static void gen(orx_prog* P, int n) {
             if (nd.cap) emit(P, I_SAVE, 2 * nd.cap + 1, 0);
             break;
         case N_BACKREF: emit(P, I_BACKREF, nd.cap, 0); break;
+        case N_COND: {
+            int c = emit(P, I_COND, nd.cap, 0);
+            gen(P, nd.l);
+            int j = emit(P, I_JMP, 0, 0);
+            P->code[c].y = P->ncode;
+            gen(P, nd.r);
+            P->code[j].x = P->ncode;
+            break;
+        }
         case N_ATOMIC:
             emit(P, I_ATOM_BEGIN, 0, 0);
             gen(P, nd.l);
@@ -866,6 +901,7 @@ static int run(const orx_prog* P, const uint8_t* s, long n, long start, int full
                 }
                 if (check_assert(in->x, s, n, pos)) { ++pc; continue; }
                 goto backtrack;
+            case I_COND: if (caps[2 * in->x + 1] >= 0) ++pc; else pc = in->y; continue;
             case I_BACKREF: {
                 long b = caps[2 * in->x], e = caps[2 * in->x + 1];
                 if (b < 0 || e < 0 || e < b || e - b > n - pos) goto backtrack;

@@ -101,6 +101,17 @@ LOOK = [
 ]
 
 
+# conditionals on a group (?(N)yes|no): all three engines read them
+COND = [
+    (rb'(\()?\w+(?(1)\))', [b'(ab)', b'ab', b'(ab', b'ab)']),
+    (rb'(<)?(\w+)(?(1)>|;)(.*)', [b'<a>x', b'a;x', b'<a;x', b'a>x']),
+    (rb'^(?:(a)|b)(?(1)c|d)$', [b'ac', b'bd', b'ad', b'bc']),
+    (rb'(")?(\w+)(?(1)")=(\d+)', [b'"k"=1', b'k=1', b'"k=1', b'k"=1']),
+    (rb'(a)?(b)?(?(1)x|y)(?(2)z)', [b'abxz', b'ax', b'byz', b'y', b'bxz']),
+    (rb'(?:(\d+)|(\w+))-(?(1)\d|\w)+', [b'12-34', b'ab-cd', b'12-ab', b'ab-12']),
+]
+
+
 def engines_full(p, s, flags_re, flags_rx, pcre, icase):
     r2 = regex.compile(p, flags_rx)
     m2 = r2.fullmatch(s)
@@ -163,7 +174,7 @@ def main():
     def add(kind, p, s):
         nonlocal dropped
         try:
-            if kind in ("full", "look_full"):
+            if kind in ("full", "look_full", "cond_full"):
                 outs, ng = engines_full(p, s, re.S | re.M, regex.S | regex.M, pcre, False)
             elif kind == "icase_full":
                 outs, ng = engines_full(p, s, re.S | re.M | re.I, regex.S | regex.M | regex.I, pcre, True)
@@ -200,6 +211,10 @@ def main():
             add("look_full", p, s_)
             add("look_search", p, b"zz " + s_ + b" !")
             add("look_search", p, s_)
+    out["cond_full"] = []
+    for p, subs in COND:
+        for s_ in subs:
+            add("cond_full", p, s_)
     out["named_full"] = []
     for named, numeric, subs in NAMED:
         for s_ in subs:
@@ -236,10 +251,11 @@ def main():
            "n_full": sum(len(c["subs"]) for c in out["full"]), "n_search": sum(len(c["subs"]) for c in out["search"]),
            "n_icase_full": sum(len(c["subs"]) for c in out["icase_full"]),
            "n_named_full": sum(len(c["subs"]) for c in out["named_full"]),
+           "n_cond_full": sum(len(c["subs"]) for c in out["cond_full"]),
            "n_look_full": sum(len(c["subs"]) for c in out["look_full"]), "n_look_search": sum(len(c["subs"]) for c in out["look_search"]),
            "format": "full/search/icase_full[i] = {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]}",
            "full": out["full"], "search": out["search"], "icase_full": out["icase_full"], "named_full": out["named_full"],
-           "look_full": out["look_full"], "look_search": out["look_search"]}
+           "look_full": out["look_full"], "look_search": out["look_search"], "cond_full": out["cond_full"]}
     with open(os.path.join(HERE, "backref_vectors.json"), "w") as f:
         json.dump(res, f, separators=(",", ":"))
     print("full", res["n_full"], "search", res["n_search"], "icase", res["n_icase_full"], "dropped", dropped,

@@ -31,7 +31,7 @@ def vectors(golden_dir):
     # (the 7 dropped vectors: PCRE1 8.45 takes "(?=.*\\d)..." for an anchored pattern and misses two searches; the `regex` module keeps a
     # capture made inside a NEGATIVE look-ahead where CPython and PCRE1 -- and the oracle -- undo it)
     assert d["n_full"] > 3500 and d["n_search"] > 1500 and d["n_named_full"] >= 29 and d["dropped_disagreements"] <= 7
-    assert d["n_look_full"] >= 60 and d["n_look_search"] >= 120
+    assert d["n_look_full"] >= 60 and d["n_look_search"] >= 120 and d["n_cond_full"] >= 25
     return d
 
 
@@ -67,7 +67,7 @@ def _flat(got):
 # ------------------------------------------------------------------------------------------------ the oracle is pinned first
 def test_oracle_matches_the_backreference_vectors(vectors):
     bad = []
-    for kind in ("full", "search", "icase_full", "named_full", "look_full", "look_search"):
+    for kind in ("full", "search", "icase_full", "named_full", "look_full", "look_search", "cond_full"):
         for c in vectors[kind]:
             rx = OracleRegex(c["p"].encode("latin-1"), flags=(1 if kind == "icase_full" else 0))   # ORX_ICASE
             assert rx.groups == c["g"], c["p"]
@@ -107,7 +107,7 @@ def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
 def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
     bad, checked = [], 0
     for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
-                        ("look_search", B.LC_SYNTAX_SEARCH)):
+                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0)):
         for c in vectors[kind]:
             # (a look-around the automata can run -- a window of byte classes -- keeps its automaton: here the engine is asked for)
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags, engine=B.LC_ENGINE_AUTO if "look" not in kind else B.LC_ENGINE_BT)
@@ -180,7 +180,7 @@ def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
     from test_gpu_parity import pack, run_device
     bad, checked = [], 0
     for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
-                        ("look_search", B.LC_SYNTAX_SEARCH)):
+                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0)):
         for c in vectors[kind]:
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
             subs = [s.encode("latin-1") for s, _ in c["subs"]]
