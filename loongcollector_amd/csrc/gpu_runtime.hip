@@ -1226,14 +1226,17 @@ static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t
     if (rc != LC_OK) return rc;
     const uint32_t blobWords = uint32_t(re->btBlob.size());
     const uint32_t stageWords = blobWords * 4 <= kBtStageMaxBytes ? blobWords : 0u;
-    const uint32_t blocks = std::min<uint32_t>((n + kBtBlock - 1) / kBtBlock, kBtMaxLanes / kBtBlock);
+    uint32_t maxLanes = kBtMaxLanes, firstSlice = kBtSliceWords;
+    if (const char* e = getenv("LC_BT_LANES")) maxLanes = std::max<uint32_t>(kBtBlock, uint32_t(strtoul(e, nullptr, 10)) / kBtBlock * kBtBlock);  // (A/B measurements)
+    if (const char* e = getenv("LC_BT_SLICE_WORDS")) firstSlice = std::max<uint32_t>(256u, uint32_t(strtoul(e, nullptr, 10)));
+    const uint32_t blocks = std::min<uint32_t>((n + kBtBlock - 1) / kBtBlock, maxLanes / kBtBlock);
     const uint32_t retryBlocks = std::min<uint32_t>(blocks, kBtRetryLanes / kBtBlock);
     uint32_t budget = kBtDefaultBudget;
     if (const char* e = getenv("LC_BT_BUDGET")) budget = uint32_t(strtoul(e, nullptr, 10));  // (read per launch: tests)
     const uint32_t need = re->btBlob[BT_NCAPS] + re->btBlob[BT_NLOOP] + 64u;
-    uint32_t sliceWords = kBtSliceWords;
-    if (need + 256u > sliceWords) sliceWords = kBtRetrySliceWords;  // (hundreds of groups: every lane gets the large slice; fewer lanes)
-    const uint32_t firstBlocks = sliceWords == kBtSliceWords ? blocks : retryBlocks;
+    uint32_t sliceWords = firstSlice;
+    if (need + 128u > sliceWords) sliceWords = kBtRetrySliceWords;  // (hundreds of groups: every lane gets the large slice; fewer lanes)
+    const uint32_t firstBlocks = sliceWords != kBtRetrySliceWords ? blocks : retryBlocks;
     if (need > kBtRetrySliceWords) {
         tlsError = "backtracking program: captures and loop registers exceed a lane's scratch";
         return LC_ERR_UNSUPPORTED;
