@@ -13,11 +13,12 @@
 #include "bt_vm.hpp"
 
 constexpr uint32_t kBtBlock = 64;
-// Two passes share one scratch pool (512 MB at most).  Pass 1: up to 65 536 lanes in flight (eight wavefronts per SIMD hide the latency of
-// a step) with 8 KB of scratch each -- ~1 000 stack entries, a log line's counted repeats and captures need a few dozen.  A value that
-// fills its slice is left LC_PENDING and raises the pool's flag word; pass 2 (8 192 lanes x 64 KB, ~8 000 entries) takes the pending
-// values and returns at once when the flag is down.
-constexpr uint32_t kBtMaxLanes = 65536, kBtSliceWords = 2048;
+// Two passes share one scratch pool (1 GB at most).  Pass 1: up to 131 072 lanes in flight (two wavefronts per SIMD: more hide more of a
+// step's latency on lines that backtrack, but their lines no longer fit L2 together -- measured, profiles/round6_bt_engine.txt) with 8 KB
+// of scratch each -- ~1 000 stack entries, a log line's counted repeats and captures need a few dozen.  A value that fills its slice is
+// left LC_PENDING and raises the pool's flag word; pass 2 (8 192 lanes x 64 KB, ~8 000 entries) takes the pending values and returns at
+// once when the flag is down.
+constexpr uint32_t kBtMaxLanes = 131072, kBtSliceWords = 2048;
 constexpr uint32_t kBtRetryLanes = 8192, kBtRetrySliceWords = 16384;
 constexpr uint32_t kBtPoolHeaderWords = 64;      // the flag word, in front of the slices
 constexpr uint8_t kBtPending = 4;                // (LC_PENDING of the other engines' protocols: transient, inside one match call)
