@@ -678,6 +678,19 @@ def run_headline(args):
                 extra["configs[2]"] = {"error": "tools/grok_config2.py did not finish in 900 s"}
             except Exception as ex:  # noqa: BLE001 -- reported, not fatal
                 extra["configs[2]"] = {"error": "tools/grok_config2.py: %r" % (ex,)}
+            # (round 6) patterns no automaton runs -- back-references, general look-arounds: the device backtracking engine beside the
+            # tagged DFA on the headline's line shape (tools/bt_bench.py; no BASELINE config holds such a pattern, so this is a leg
+            # beside the configs, bounded to 65 536 lines; every leg's first 4 096 lines are compared with the oracle before it is timed)
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bt_bench.py"), "--lines", "65536", "--steps", "5"],
+                                     env=dict(os.environ), capture_output=True, text=True, timeout=300)
+                rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+                extra["backtracking_engine"] = ({"what": "LC_ENGINE_BT (csrc/bt_vm.hpp): one line per lane, program in LDS, explicit stack in HBM; "
+                                                          "512 B Apache lines resident in HBM", "legs": rows}
+                                                 if out.returncode == 0 and rows else
+                                                 {"error": "tools/bt_bench.py failed (rc %d): %s" % (out.returncode, (out.stdout + out.stderr)[-400:])})
+            except Exception as ex:  # noqa: BLE001 -- reported, not fatal
+                extra["backtracking_engine"] = {"error": "tools/bt_bench.py: %r" % (ex,)}
     # the job's only collective: ONE all-gather of the per-GPU counters (RCCL); the data path has none
     per_gpu = gather_job({"bytes": parsed_bytes_per_step * args.steps, "lines": n * args.steps, "matched_last": matched,
                           "elapsed_us": int(elapsed * 1e6), "kernel_us_per_step": int(kernel_ms * 1e3)}, device=dev)
