@@ -924,7 +924,7 @@ using namespace lcregex;
 // (Go processor_regex without FullMatch: plugins/processor/regex/regex.go:105-129; regexp2.FindStringMatch in
 // plugins/processor/grok/processor_grok.go:156.)
 static void shiftCaptures(Node& n) {
-    if ((n.kind == Node::Group || n.kind == Node::BackRef) && n.capture) ++n.capture;
+    if ((n.kind == Node::Group || n.kind == Node::BackRef || n.kind == Node::Cond) && n.capture) ++n.capture;
     for (auto& k : n.kids) shiftCaptures(*k);
 }
 // The longest byte string every match of the sub-expression must contain (possibly empty).  A line without it cannot

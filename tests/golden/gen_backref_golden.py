@@ -212,9 +212,12 @@ def main():
             add("look_search", p, b"zz " + s_ + b" !")
             add("look_search", p, s_)
     out["cond_full"] = []
+    out["cond_search"] = []
     for p, subs in COND:
         for s_ in subs:
             add("cond_full", p, s_)
+            add("cond_search", p, b"zz " + s_ + b" !")
+            add("cond_search", p, s_)
     out["named_full"] = []
     for named, numeric, subs in NAMED:
         for s_ in subs:
@@ -251,11 +254,12 @@ def main():
            "n_full": sum(len(c["subs"]) for c in out["full"]), "n_search": sum(len(c["subs"]) for c in out["search"]),
            "n_icase_full": sum(len(c["subs"]) for c in out["icase_full"]),
            "n_named_full": sum(len(c["subs"]) for c in out["named_full"]),
-           "n_cond_full": sum(len(c["subs"]) for c in out["cond_full"]),
+           "n_cond_full": sum(len(c["subs"]) for c in out["cond_full"]), "n_cond_search": sum(len(c["subs"]) for c in out["cond_search"]),
            "n_look_full": sum(len(c["subs"]) for c in out["look_full"]), "n_look_search": sum(len(c["subs"]) for c in out["look_search"]),
            "format": "full/search/icase_full[i] = {p, g, subs: [[subject, flat caps incl. group 0 or null], ...]}",
            "full": out["full"], "search": out["search"], "icase_full": out["icase_full"], "named_full": out["named_full"],
-           "look_full": out["look_full"], "look_search": out["look_search"], "cond_full": out["cond_full"]}
+           "look_full": out["look_full"], "look_search": out["look_search"], "cond_full": out["cond_full"],
+           "cond_search": out["cond_search"]}
     with open(os.path.join(HERE, "backref_vectors.json"), "w") as f:
         json.dump(res, f, separators=(",", ":"))
     print("full", res["n_full"], "search", res["n_search"], "icase", res["n_icase_full"], "dropped", dropped,

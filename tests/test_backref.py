@@ -67,7 +67,7 @@ def _flat(got):
 # ------------------------------------------------------------------------------------------------ the oracle is pinned first
 def test_oracle_matches_the_backreference_vectors(vectors):
     bad = []
-    for kind in ("full", "search", "icase_full", "named_full", "look_full", "look_search", "cond_full"):
+    for kind in ("full", "search", "icase_full", "named_full", "look_full", "look_search", "cond_full", "cond_search"):
         for c in vectors[kind]:
             rx = OracleRegex(c["p"].encode("latin-1"), flags=(1 if kind == "icase_full" else 0))   # ORX_ICASE
             assert rx.groups == c["g"], c["p"]
@@ -107,7 +107,7 @@ def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
 def test_backtracking_programs_on_the_backreference_vectors(vectors, host_vm):
     bad, checked = [], 0
     for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
-                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0)):
+                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0), ("cond_search", B.LC_SYNTAX_SEARCH)):
         for c in vectors[kind]:
             # (a look-around the automata can run -- a window of byte classes -- keeps its automaton: here the engine is asked for)
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags, engine=B.LC_ENGINE_AUTO if "look" not in kind else B.LC_ENGINE_BT)
@@ -180,7 +180,7 @@ def test_backreference_vectors_through_the_c_abi(torch_dev, vectors):
     from test_gpu_parity import pack, run_device
     bad, checked = [], 0
     for kind, flags in (("full", 0), ("search", B.LC_SYNTAX_SEARCH), ("icase_full", B.LC_SYNTAX_ICASE), ("named_full", 0), ("look_full", 0),
-                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0)):
+                        ("look_search", B.LC_SYNTAX_SEARCH), ("cond_full", 0), ("cond_search", B.LC_SYNTAX_SEARCH)):
         for c in vectors[kind]:
             rx = B.GpuRegex(c["p"].encode("latin-1"), syntax_flags=flags)
             subs = [s.encode("latin-1") for s, _ in c["subs"]]
@@ -327,3 +327,29 @@ def test_values_that_fill_their_first_slice_are_decided_by_the_second_pass(torch
         want = o.fullmatch(subs[i])
         assert (status[i] == B.LC_MATCH and list(caps[i]) == list(want[1])) if want else (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()), i
     assert status[3] == B.LC_GAVE_UP
+
+
+@pytest.mark.gpu
+def test_the_filter_with_backreference_and_lookaround_leaves_against_the_filter_oracle():
+    """processor_filter_regex_native's leaves are boost regexes too (ProcessorFilterNative.cpp): leaves the automata run and leaves only
+    the backtracking engine runs share one group trip (lc_regex_match_device_multi falls back per job)."""
+    from loongcollector_amd.processor import EventGroup, Filter
+    from oracle.filter_oracle import FilterOracle
+    rng = random.Random(23)
+    config = {"ConditionExp": {"operator": "and", "operands": [
+        {"type": "regex", "key": "path", "exp": r"/(\w+)/\1(?:/.*)?"},
+        {"operator": "or", "operands": [{"type": "regex", "key": "ua", "exp": r"(?=.*\d)[A-Za-z/.\d]+"},
+                                        {"type": "regex", "key": "status", "exp": r"[23]\d\d"}]}]}}
+    fields = {"path": ["/a/a", "/api/api/x", "/a/b", "/x/x/", "/xy/x", ""], "ua": ["curl/8.1", "Mozilla", "bot", "Go-http/2"],
+              "status": ["200", "404", "301", "500"]}
+    events = []
+    for _ in range(2000):
+        events.append({k: rng.choice(v) for k, v in fields.items() if rng.random() < 0.9})
+    want = FilterOracle(config).process([{k: v.encode("utf-8") for k, v in e.items()} for e in events])
+    f = Filter(config)
+    g = EventGroup({"events": [{"contents": e, "timestamp": 1, "type": 1} for e in events]})
+    f.process(g)
+    d = g.to_dict()
+    got = [e["contents"] for e in d["events"]] if d else []
+    assert 100 < len(want) < len(events)
+    assert got == [{k: v.decode("utf-8") for k, v in e.items()} for e in want]
