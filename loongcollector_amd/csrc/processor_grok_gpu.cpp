@@ -199,6 +199,11 @@ void ProcessorGrokGpu::Init() {
         mFields.push_back(std::move(fields));
     }
     mRowInts = 2 * (1 + maxColumns);
+    // (round 6) an entry no automaton runs -- a back-reference by name, a general look-around: regexp2 backtracks through them -- is on
+    // the device backtracking engine (bt_vm.hpp).  The speculative plan is built from automata (screens, literal index, lazy tables): a
+    // handle with such an entry walks its list entry by entry instead (grok_device.hip grokMatchSequential: engine-agnostic).
+    for (lc_regex_t* re : mCompiled)
+        if (re->engine == LC_ENGINE_BT) Speculative = false;
     // 3. the anchored searches, behind Init
     mAnchored.reset(new std::atomic<lc_regex*>[Match.size() ? Match.size() : 1]);
     for (size_t i = 0; i < Match.size(); ++i) mAnchored[i].store(nullptr);

@@ -1671,8 +1671,9 @@ extern "C" int lc_regex_compile(const char* pattern, size_t pattern_len, uint32_
         } catch (const RegexError& nfaError) {
             // A tree the parser accepts and the position automaton cannot express ("(a*)*": an unbounded repeat of a body that may match
             // nothing): boost backtracks through it like through anything else, and so does the device backtracking engine -- unless the
-            // caller asked for an automaton, or the pattern comes in Grok's dialect (its matcher plans automata).
-            if (engine != LC_ENGINE_AUTO || syn.namedOnly || syn.regexp2) throw;
+            // caller asked for an automaton, or the pattern comes in the Go regex plugin's dialect (RE2 backtracks nowhere).  A Grok
+            // handle that holds such an entry walks its list entry by entry (processor_grok_gpu.cpp: the speculative plan is automata).
+            if (engine != LC_ENGINE_AUTO || (syn.regexp2 && !syn.namedOnly)) throw;
             try {
                 re->btBlob = lcregex::buildBtProgram(parsed, syn.icase);
             } catch (const RegexError&) {

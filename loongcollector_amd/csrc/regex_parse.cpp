@@ -111,6 +111,11 @@ public:
         for (int r : mBackRefs) {  // (boost: error_backref at compile time)
             if (r > mGroups) throw RegexError("invalid back reference: \\" + std::to_string(r) + " with " + std::to_string(mGroups) + " groups");
         }
+        for (const std::string& w : mNamedRefs) {  // (same-named groups are ONE group to regexp2 and boost: which text would come back?)
+            int count = 0;
+            for (const std::string& nm : out.groupNames) count += nm == w;
+            if (count != 1) throw RegexError("back-reference to a name that several groups carry: unsupported");
+        }
         out.hasBackRef = !mBackRefs.empty();
         out.hasGeneralLook = mGeneralLook;
         return out;
@@ -123,6 +128,7 @@ private:
     int mGroups = 0;
     std::vector<std::string> mNames;
     std::vector<int> mBackRefs;
+    std::vector<std::string> mNamedRefs;
     bool mGeneralLook = false;
 
     // every match of `n` has this length, or -1 (a look-behind body must have one: Perl, PCRE, regexp2 and boost agree)
@@ -166,7 +172,7 @@ private:
     }
     // the general form (Node::Look): runs on the device backtracking engine.  Not under Grok's dialect: its matcher plans automata.
     NodePtr generalLook(NodePtr body, bool behind, bool negative, const char* why) {
-        if (mSyn.namedOnly || mSyn.regexp2) bail(why);
+        if (mSyn.regexp2 && !mSyn.namedOnly) bail(why);  // (the Go regex plugin: RE2 has no look-arounds beyond what the parser decides)
         int k = 0;
         if (behind) {
             k = fixedLen(*body);
@@ -670,7 +676,10 @@ private:
             case 'k': case 'g': {
                 // \k<name> \k{name} \k'name' \g{name}: a back-reference by name; \gN \g{N} \g{-N}: by number / relative to here (boost
                 // Perl syntax).  Only to groups opened in front of the reference; not under Grok's dialect (see \N below).
-                if (mSyn.namedOnly || mSyn.regexp2 || atEnd()) bail("unsupported escape");
+                // Grok (regexp2, named-only numbering here): by NAME only -- regexp2 numbers unnamed groups first, so a number written
+                // in a Grok pattern does not name the group it names there.  The Go regex plugin (RE2): none at all.
+                if ((mSyn.regexp2 && !mSyn.namedOnly) || atEnd()) bail("unsupported escape");
+                if (mSyn.namedOnly && (e != 'k' || (peek() != '<' && peek() != '{' && peek() != '\''))) bail("unsupported escape");
                 const unsigned open = peek();
                 const unsigned close = open == '<' ? '>' : open == '{' ? '}' : open == '\'' ? '\'' : 0;
                 std::string word;
@@ -696,6 +705,7 @@ private:
                     for (int g = 1; g <= mGroups && !v; ++g)
                         if (mNames[size_t(g)] == word) v = g;
                     if (!v) bail("back-reference to a group name that is not defined in front of it: unsupported");
+                    mNamedRefs.push_back(word);
                 }
                 auto n = mk(Node::BackRef);
                 n->capture = v;

@@ -493,7 +493,7 @@ static int parse_atom(orx_prog* P, int depth, int* is_assert) {
                 case 'E': return new_node(P, N_EMPTY);
                 case 'k': case 'g': {
                     /* \k<name> \k{name} \k'name' \g{name}; \gN \g{N} \g{-N} (boost Perl syntax): groups opened in front of the reference */
-                    if ((P->flags & ORX_REGEXP2) || P->i >= P->n) { fail(P, "unsupported escape"); return -1; }
+                    if (((P->flags & ORX_REGEXP2) && !((P->flags & ORX_NAMED_BACKREFS) && e == 'k')) || P->i >= P->n) { fail(P, "unsupported escape"); return -1; }
                     int open = P->p[P->i], close = open == '<' ? '>' : open == '{' ? '}' : open == '\'' ? '\'' : 0;
                     char word[128]; size_t wl = 0;
                     if (close) {

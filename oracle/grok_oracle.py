@@ -20,7 +20,7 @@ processor_grok_test.go:119-373 replayed in tests/test_grok_host.py) and on vecto
 import os
 import re
 
-from oracle.oracle import ORX_NO_MOD_M, ORX_NO_MOD_S, ORX_REGEXP2, OracleRegex
+from oracle.oracle import ORX_NAMED_BACKREFS, ORX_NO_MOD_M, ORX_NO_MOD_S, ORX_REGEXP2, OracleRegex
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULTS_PATH = os.path.join(_HERE, "..", "loongcollector_amd", "data", "grok_default_patterns.txt")
@@ -70,7 +70,7 @@ class GrokOracle:
         self.processed = {}
         self._build()                                                        # :84
         self.expanded = [self._denormalize(m) for m in match]                # :335-341
-        self.compiled = [OracleRegex(e.encode("utf-8"), ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2) for e in self.expanded]
+        self.compiled = [OracleRegex(e.encode("utf-8"), ORX_NO_MOD_S | ORX_NO_MOD_M | ORX_REGEXP2 | ORX_NAMED_BACKREFS) for e in self.expanded]
         # Groups() order of the named groups: first appearance; same-named groups are merged
         self.fields = []
         for rx in self.compiled:

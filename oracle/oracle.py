@@ -17,6 +17,7 @@ ORX_NO_MOD_S = 2
 ORX_NO_MOD_M = 4
 ORX_EXTENDED = 8
 ORX_REGEXP2 = 16
+ORX_NAMED_BACKREFS = 32
 
 
 def build(force=False):

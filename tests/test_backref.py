@@ -97,9 +97,15 @@ def test_patterns_with_backreferences_compile_to_the_backtracking_engine():
     assert B.GpuRegex(rb'(?<w>\w+) \k<w>').info()["engine"] == B.LC_ENGINE_BT
     with pytest.raises(B.RegexUnsupportedError):
         B.GpuRegex(rb'\k<later>(?<later>a)')
-    # Grok's dialect (named-only numbering, regexp2 escapes) keeps refusing them: its matcher plans automata
+    # Grok's dialect (named-only numbering here, regexp2 numbers unnamed groups first): by NAME only, and one group per name
     with pytest.raises(B.RegexUnsupportedError):
-        B.GpuRegex(rb'(?<w>\w+) \1', syntax_flags=B.LC_SYNTAX_NAMED_ONLY)
+        B.GpuRegex(rb'(?<w>\w+) \1', syntax_flags=B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2)
+    assert B.GpuRegex(rb'(?<w>\w+) \k<w>', syntax_flags=B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2).info()["engine"] == B.LC_ENGINE_BT
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(rb'(?<w>a)|(?<w>b)\k<w>', syntax_flags=B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2)
+    # the Go regex plugin compiles with Go's regexp (RE2): no back-references at all
+    with pytest.raises(B.RegexUnsupportedError):
+        B.GpuRegex(rb'(?<w>\w+) \k<w>', syntax_flags=B.LC_SYNTAX_REGEXP2)
     # regular patterns still get their automata
     assert B.GpuRegex(rb'(a)b').info()["engine"] == B.LC_ENGINE_TDFA
 
@@ -353,3 +359,31 @@ def test_the_filter_with_backreference_and_lookaround_leaves_against_the_filter_
     got = [e["contents"] for e in d["events"]] if d else []
     assert 100 < len(want) < len(events)
     assert got == [{k: v.decode("utf-8") for k, v in e.items()} for e in want]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("match", [
+    [r"%{WORD:a} \k<a>( %{GREEDYDATA:rest})?", r"(?P<k>\w+)=(?P<v>\S*)", "%{INT:n}"],                # a back-reference by name in front
+    [r"%{LOGLEVEL:level}:? %{GREEDYDATA:msg}", r"(?P<q>[\"'])(?P<body>.*?)\k<q>", r"%{NOTSPACE:first}"],  # ... and behind a plain entry
+    [r"%{WORD:w}(?= \d+x)", r"%{WORD:other}"],                                                          # a general look-ahead
+])
+def test_grok_lists_with_entries_on_the_backtracking_engine_against_the_grok_oracle(torch_dev, match):
+    """regexp2 backtracks (plugins/processor/grok/processor_grok.go:148-194, :343): a Match entry with \\k<name> or a general look-around is
+    an entry like any other.  Such an entry runs bt_match_kernel; the handle walks its list entry by entry (the speculative plan is built
+    from automata).  Fields, first-match-wins order and the FindNextMatch rounds against the Grok oracle."""
+    from loongcollector_amd.grok import Grok
+    from oracle.grok_oracle import GrokOracle
+    rng = random.Random(77)
+    words = [b"GET", b"GET", b"err", b"err", b"x=1", b"k=", b"'q s'", b"\"a\"", b"'mixed\"", b"abc_9", b"7", b"12x", b"ERROR", b"info:", b""]
+    values = [rng.choice([b" ", b"  ", b","]).join(rng.choice(words) for _ in range(rng.randint(0, 8))) for _ in range(3000)]
+    g = Grok(Match=match)
+    assert B.LC_ENGINE_BT in [g.engine(i) for i in range(len(match))]
+    o = GrokOracle(match)
+    pattern, fields = g.match_host(values)
+    won = 0
+    for v, p, f in zip(values, pattern, fields):
+        res, want = o.process_value(v)
+        assert f == want, (match, v)
+        assert (p >= 0) == (res == 0)
+        won += p >= 0
+    assert 300 < won

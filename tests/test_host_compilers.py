@@ -285,10 +285,11 @@ def test_fixed_length_lookarounds_on_both_engines_tables(golden_dir):
         for it in ([TdfaInterp(rx)] if rx.info()["engine"] == B.LC_ENGINE_TDFA else []) + ([NfaInterp(rx)] if rx.has_nfa_program() else []):
             assert it.fullmatch(s) == want, (flags, it.fullmatch(s))
     # where the automaton would need the history of the input -- a look-behind behind a field of variable width -- the pattern goes to
-    # the device backtracking engine (round 6; refused under Grok's dialect, whose matcher plans automata)
+    # the device backtracking engine (round 6; also under Grok's dialect -- regexp2 backtracks --, refused under the Go regex plugin's: RE2)
     assert B.GpuRegex(rb"\w+(?<!ab)c").info()["engine"] == B.LC_ENGINE_BT
+    assert B.GpuRegex(rb"\w+(?<!ab)c", syntax_flags=B.LC_SYNTAX_NAMED_ONLY | B.LC_SYNTAX_REGEXP2).info()["engine"] == B.LC_ENGINE_BT
     with pytest.raises(B.RegexUnsupportedError, match="look-behind that the preceding sub-expression does not decide"):
-        B.GpuRegex(rb"\w+(?<!ab)c", syntax_flags=B.LC_SYNTAX_NAMED_ONLY)
+        B.GpuRegex(rb"\w+(?<!ab)c", syntax_flags=B.LC_SYNTAX_REGEXP2)
     # ... and a window in a pattern that keeps atomic groups: no automaton, the backtracking engine
     with pytest.raises(B.RegexUnsupportedError, match="look-ahead in a pattern with atomic groups"):
         B.GpuRegex(rb"(?>a+|ab)(?=bc)\w+", engine=B.LC_ENGINE_TDFA)
