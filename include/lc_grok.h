@@ -12,9 +12,11 @@
  *
  * What is matched on the device: each Match entry is expanded (%{SYNTAX:alias} -> (?P<alias>...)) and compiled with
  * LC_SYNTAX_SEARCH | LC_SYNTAX_NAMED_ONLY | LC_SYNTAX_NO_DOTALL | LC_SYNTAX_NO_MULTILINE | LC_SYNTAX_REGEXP2 -- the
- * semantics of regexp2.Compile(pattern, regexp2.RE2) as far as byte-oriented automata can give them (bytes
- * not runes, no back-references, one-byte look-arounds, no time-outs because nothing backtracks).  A Match entry the
- * device engines cannot run makes lc_grok_create FAIL with the reason: there is no CPU path.
+ * semantics of regexp2.Compile(pattern, regexp2.RE2) as far as byte-oriented engines can give them (bytes
+ * not runes, no time-outs).  Round 6: an entry with a back-reference BY NAME (\k<name>) or a general look-around runs on the
+ * device backtracking engine (LC_ENGINE_BT) and the handle walks its list entry by entry; numbered back-references stay
+ * refused (regexp2 numbers unnamed groups first).  A Match entry the device engines cannot run makes lc_grok_create FAIL
+ * with the reason: there is no CPU path.
  */
 #ifndef LC_GROK_H
 #define LC_GROK_H
