@@ -1214,6 +1214,49 @@ bool lcNfaWideApplies(const lc_regex* re) {
 
 // The backtracking engine (bt_kernel.hpp): patterns with back-references.  The scratch pool of the launch -- 64 KB per lane in flight
 // -- is allocated and freed in stream order, so concurrent callers of one handle never share a stack.
+// Scratch of the SMALL launches (an event group's thousand lines: a few MB), kept per calling thread and stream: launches on one
+// stream are ordered, so the block is never shared by two kernels in flight.  (Stream-ordered allocation from a pool -- the large
+// launches' way, below -- hands a block just freed on another stream to the next caller WITH a dependency on that stream: sixteen
+// runner threads with a group each ran one after the other, 2.3 ms per group where one thread took 0.14.)
+namespace {
+struct BtScratchCache {
+    struct Entry {
+        int dev;
+        hipStream_t stream;
+        uint32_t* p;
+        size_t words;
+    };
+    std::vector<Entry> entries;
+    ~BtScratchCache() {
+        if (!lcRuntimeUsable()) return;
+        for (const Entry& e : entries)
+            if (hipSetDevice(e.dev) == hipSuccess) (void)hipFree(e.p);
+    }
+    uint32_t* get(int dev, hipStream_t stream, size_t words) {
+        for (Entry& e : entries)
+            if (e.dev == dev && e.stream == stream) {
+                if (e.words >= words) return e.p;
+                (void)hipFree(e.p);  // (waits for what is in flight)
+                e.p = nullptr;
+                e.words = 0;
+                if (hipMalloc(reinterpret_cast<void**>(&e.p), words * 4) != hipSuccess) return nullptr;
+                e.words = words;
+                return e.p;
+            }
+        if (entries.size() >= 8) {  // (a thread that walks through many streams: the oldest block goes)
+            (void)hipFree(entries.front().p);
+            entries.erase(entries.begin());
+        }
+        uint32_t* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), words * 4) != hipSuccess) return nullptr;
+        entries.push_back({dev, stream, p, words});
+        return p;
+    }
+};
+thread_local BtScratchCache tlsBtScratch;
+constexpr size_t kBtCachedWordsMax = size_t(64) << 18;  // 64 MB: above it the pool
+}  // namespace
+
 static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t* d_off, const uint32_t* d_len, uint32_t sep, uint32_t n,
                     const uint32_t* d_n, const uint32_t* d_order, const uint32_t* d_resume, uint32_t ngroups, int32_t* d_caps, uint8_t* d_status,
                     hipStream_t stream) {
@@ -1230,7 +1273,8 @@ static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t
     if (const char* e = getenv("LC_BT_LANES")) maxLanes = std::max<uint32_t>(kBtBlock, uint32_t(strtoul(e, nullptr, 10)) / kBtBlock * kBtBlock);  // (A/B measurements)
     if (const char* e = getenv("LC_BT_SLICE_WORDS")) firstSlice = std::max<uint32_t>(256u, uint32_t(strtoul(e, nullptr, 10)));
     const uint32_t blocks = std::min<uint32_t>((n + kBtBlock - 1) / kBtBlock, maxLanes / kBtBlock);
-    const uint32_t retryBlocks = std::min<uint32_t>(blocks, kBtRetryLanes / kBtBlock);
+    // (pass 2 takes the few values that filled their slice: an eighth of pass 1's lanes with eight times the slice -- the same pool)
+    const uint32_t retryBlocks = std::max<uint32_t>(1u, std::min<uint32_t>(blocks / 8u, kBtRetryLanes / kBtBlock));
     uint32_t budget = kBtDefaultBudget;
     if (const char* e = getenv("LC_BT_BUDGET")) budget = uint32_t(strtoul(e, nullptr, 10));  // (read per launch: tests)
     const uint32_t need = re->btBlob[BT_NCAPS] + re->btBlob[BT_NLOOP] + 64u;
@@ -1241,9 +1285,39 @@ static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t
         tlsError = "backtracking program: captures and loop registers exceed a lane's scratch";
         return LC_ERR_UNSUPPORTED;
     }
+    // The scratch comes from a memory pool of the library's own, which KEEPS what launches give back (release threshold: none): with
+    // the runtime's default pool every synchronisation trimmed the pool -- a device-wide free -- and sixteen runner threads with a
+    // 1000-line group each took 2.3 ms per group where one took 0.14 (profiles/round6_bt_engine.txt).
+    static hipMemPool_t btPool[kLcMaxDevices] = {};
+    static std::once_flag btPoolOnce[kLcMaxDevices];
+    if (dev >= 0 && dev < kLcMaxDevices)
+        std::call_once(btPoolOnce[dev], [&] {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t pool = nullptr;
+            if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+                uint64_t keep = ~uint64_t(0);
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                btPool[dev] = pool;
+            } else {
+                (void)hipGetLastError();  // (no pool of our own: the runtime's default one)
+            }
+        });
+    hipMemPool_t pool = dev >= 0 && dev < kLcMaxDevices ? btPool[dev] : nullptr;
     uint32_t* scratch = nullptr;
     const size_t poolWords = kBtPoolHeaderWords + std::max(size_t(firstBlocks) * kBtBlock * sliceWords, size_t(retryBlocks) * kBtBlock * kBtRetrySliceWords);
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), poolWords * 4, stream));
+    const bool cached = poolWords <= kBtCachedWordsMax;
+    if (cached) {
+        scratch = tlsBtScratch.get(dev, stream, poolWords);
+        if (!scratch) return hipFail(hipErrorOutOfMemory, "hipMalloc(backtracking scratch)");
+    } else if (pool) {
+        HIP_TRY(hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), poolWords * 4, pool, stream));
+    } else {
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), poolWords * 4, stream));
+    }
     hipError_t launched = hipMemsetAsync(scratch, 0, kBtPoolHeaderWords * 4, stream);
     lcNoteKernel("bt_match_kernel");
     if (launched == hipSuccess) {
@@ -1257,7 +1331,7 @@ static int launchBt(lc_regex* re, int dev, const uint8_t* d_data, const uint32_t
                            kBtRetrySliceWords, budget, 1u);
         launched = hipGetLastError();
     }
-    (void)hipFreeAsync(scratch, stream);
+    if (!cached) (void)hipFreeAsync(scratch, stream);
     HIP_TRY(launched);
     return LC_OK;
 }
@@ -2001,7 +2075,9 @@ int runHostPipeline(lc_regex_t* re, const LineSource& src, uint32_t n, uint32_t 
             } zc{s.stream};
             tlsDone = DoneRequest{s.dDone, s.hFlag, doneSeqNo, !pollOff, false};
             zc.queued = true;
-            if (zeroCopyEnv == 2) {
+            // (the backtracking engine reads a value in small steps, some of them more than once: through the pinned mapping every
+            // step would be a PCIe read of its own -- its group is copied up first, in one piece)
+            if (zeroCopyEnv == 2 || re->engine == LC_ENGINE_BT) {
                 HIP_TRY(hipMemcpyAsync(s.dData, s.hData, blockBytes, hipMemcpyHostToDevice, s.stream));
                 rc = lcMatchOnStream(re, re->engine, dev, s.dData, reinterpret_cast<uint32_t*>(s.dData + tableAt),
                                      reinterpret_cast<uint32_t*>(s.dData + tableAt) + n, 0, n, nullptr, nullptr, nullptr, ngroups,

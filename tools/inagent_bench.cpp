@@ -59,6 +59,8 @@ struct StartGate {
 };
 
 int main(int argc, char** argv) {
+    // INAGENT_REGEX: another pattern with ten groups over the same lines (round 6: one that runs on the device backtracking engine)
+    if (const char* alt = getenv("INAGENT_REGEX")) kRegexA = alt;
     const unsigned nLines = argc > 1 ? unsigned(atoi(argv[1])) : 256000;
     const unsigned groupLines = argc > 2 ? unsigned(atoi(argv[2])) : 1000;
     std::vector<int> threadCounts;
