@@ -1,7 +1,8 @@
 // bt_kernel.hpp -- launch form of the device backtracking engine (bt_vm.hpp; included by gpu_runtime.hip only).
 //
-// One value per LANE; a lane owns a slice of the launch's scratch pool in HBM (captures, loop registers, stack) and takes values in
-// turn (grid-stride), so the pool is sized by the lanes in flight, not by the batch.  The program (a few KB: byte classes + 16 B per
+// One value per LANE; a lane owns a slice of the launch's scratch in HBM (captures, loop registers, stack) and takes values in turn
+// (grid-stride), so the scratch is sized by the lanes in flight, not by the batch (gpu_runtime.hip launchBt: cached per calling thread
+// and stream for small launches, stream-ordered from a pool of the library's own for large ones).  The program (a few KB: byte classes + 16 B per
 // instruction) is staged into LDS when it fits 48 KB -- every step is a dependent read of it.  The lanes of a wavefront walk
 // different paths: the engine is the drop-in answer for patterns no automaton can run (back-references), not a throughput path; what
 // bounds it is the latency of a step (program word from LDS, value byte and stack entry from L2 / HBM).
@@ -16,8 +17,8 @@ constexpr uint32_t kBtBlock = 64;
 // Two passes share one scratch pool (1 GB at most).  Pass 1: up to 131 072 lanes in flight (two wavefronts per SIMD: more hide more of a
 // step's latency on lines that backtrack, but their lines no longer fit L2 together -- measured, profiles/round6_bt_engine.txt) with 8 KB
 // of scratch each -- ~1 000 stack entries, a log line's counted repeats and captures need a few dozen.  A value that fills its slice is
-// left LC_PENDING and raises the pool's flag word; pass 2 (8 192 lanes x 64 KB, ~8 000 entries) takes the pending values and returns at
-// once when the flag is down.
+// left LC_PENDING and raises the pool's flag word; pass 2 (an eighth of pass 1's lanes, at most 8 192, x 64 KB: ~8 000 entries) takes
+// the pending values and returns at once when the flag is down.
 constexpr uint32_t kBtMaxLanes = 131072, kBtSliceWords = 2048;
 constexpr uint32_t kBtRetryLanes = 8192, kBtRetrySliceWords = 16384;
 constexpr uint32_t kBtPoolHeaderWords = 64;      // the flag word, in front of the slices
