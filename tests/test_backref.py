@@ -387,3 +387,53 @@ def test_grok_lists_with_entries_on_the_backtracking_engine_against_the_grok_ora
         assert (p >= 0) == (res == 0)
         won += p >= 0
     assert 300 < won
+
+
+@pytest.mark.gpu
+def test_concurrent_runner_threads_on_one_backtracking_handle():
+    """Eight runner threads call Process on ONE instance whose Regex runs on the backtracking engine (the contract of
+    core/collection_pipeline/queue/ProcessQueueManager.cpp:167-205): the program on the device is shared, every thread's launches have
+    a scratch block of their own (gpu_runtime.hip launchBt: cached per thread and stream) -- a stack shared by two launches in flight
+    would show as wrong captures here.  Groups of different sizes, so that a thread's block grows while others are in flight."""
+    import threading
+    from loongcollector_amd import corpus
+    from loongcollector_amd.processor import EventGroup, Processor
+    from oracle.processor_oracle import LogEventModel, ProcessorOracle
+    n_threads, groups_per_thread = 8, 6
+    sizes = [300, 1500, 700, 64, 2000, 900]
+    per_thread = sum(sizes)
+    data, off, length = corpus.apache_batch(n_threads * per_thread, "B", poison_every=23)
+    raw = data.tobytes()
+    lines = [raw[off[i]:off[i] + length[i]].decode("latin-1") for i in range(len(length))]
+    regex = corpus.REGEX_B + r"(?:\1)?"       # (an optional back-reference behind regex B: the whole pattern on LC_ENGINE_BT)
+    cfg = {"SourceKey": "content", "Regex": regex, "Keys": corpus.KEYS_B}
+    p = Processor(cfg)
+    groups, at = [], 0
+    for t in range(n_threads):
+        mine = []
+        for g in range(groups_per_thread):
+            mine.append((at, EventGroup({"events": [{"contents": {"content": s}, "timestamp": 1, "type": 1} for s in lines[at:at + sizes[g]]]})))
+            at += sizes[g]
+        groups.append(mine)
+    errors = []
+
+    def run(t):
+        try:
+            for _, g in groups[t]:
+                p.process(g)
+        except Exception as e:  # noqa
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors
+    po = ProcessorOracle(cfg)
+    for t in range(n_threads):
+        for g, (start, grp) in enumerate(groups[t]):
+            out = po.process_group([LogEventModel([("content", s.encode("latin-1"))]) for s in lines[start:start + sizes[g]]])
+            assert grp.contents() == [[(k, v.decode("latin-1")) for k, v in ev.live()] for ev in out], (t, g)
+    c = p.counters()
+    assert c["in_events_total"] == len(lines) and c["out_failed_events_total"] == po.counters["out_failed"]
