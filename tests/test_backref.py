@@ -437,3 +437,54 @@ def test_concurrent_runner_threads_on_one_backtracking_handle():
             assert grp.contents() == [[(k, v.decode("latin-1")) for k, v in ev.live()] for ev in out], (t, g)
     c = p.counters()
     assert c["in_events_total"] == len(lines) and c["out_failed_events_total"] == po.counters["out_failed"]
+
+
+def test_generated_patterns_on_the_backtracking_engine_against_the_oracle(host_vm):
+    """A bounded round of tools/fuzz_bt.py: 400 generated patterns (back-references, look-arounds, conditionals, atomic groups, lazy and
+    greedy repeats), full match and search, six subjects each -- the product's program walked by the kernel's routine against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_bt", os.path.join(ROOT, "tools", "fuzz_bt.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    checked, compiled, gave_up, bad = fz.main(1, 400)
+    assert checked > 4000 and compiled > 700 and gave_up * 100 < checked
+    assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_generated_patterns_through_the_kernel_against_the_oracle(torch_dev):
+    """The generator of tools/fuzz_bt.py on the device: 250 patterns, full match and search, 48 subjects each (up to 40 bytes, so that the
+    eight-byte loads of the counted repeats and every alignment of a value's first byte are exercised), bt_match_kernel against the oracle."""
+    import importlib.util
+    from test_gpu_parity import pack, run_device
+    spec = importlib.util.spec_from_file_location("fuzz_bt", os.path.join(ROOT, "tools", "fuzz_bt.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = random.Random(11)
+    checked, bad, gave_up = 0, [], 0
+    for _ in range(250):
+        p = fz.gen(rng, [0]).encode()
+        for flags, search in ((0, False), (B.LC_SYNTAX_SEARCH, True)):
+            try:
+                o = OracleRegex(p)
+                rx = B.GpuRegex(p, syntax_flags=flags, engine=B.LC_ENGINE_BT)
+            except (ValueError, B.RegexUnsupportedError, B.RegexSyntaxError):
+                continue
+            subs = [bytes(rng.choice(b'abc1 ') for _ in range(rng.randint(0, 40))) for _ in range(48)]
+            data, off, length = pack(subs)
+            caps, status = run_device(torch_dev, rx, data, off, length)
+            for i, s in enumerate(subs):
+                checked += 1
+                if status[i] == B.LC_GAVE_UP:
+                    gave_up += 1
+                    continue
+                try:
+                    w = o.search(s) if search else o.fullmatch(s)
+                except Exception:   # (the oracle's own complexity bound)
+                    continue
+                exp = None if w is None else [v for ab in w for v in ab][0 if search else 2:]
+                ok = (status[i] == B.LC_NOMATCH and (caps[i] == -1).all()) if exp is None else (status[i] == B.LC_MATCH and list(caps[i]) == exp)
+                if not ok:
+                    bad.append((p, search, s, int(status[i]), list(caps[i]), exp))
+    assert checked > 15000 and gave_up * 50 < checked, (checked, gave_up)
+    assert not bad, bad[:5]
