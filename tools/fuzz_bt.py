@@ -4,7 +4,8 @@ lazy repeats, nested) compiled for the device backtracking engine (LC_ENGINE_BT)
 by the kernel's own routine compiled for the host (csrc/bt_vm.hpp btRun through tests/native/bt_host_check.cpp -- build it by running
 tests/test_backref.py once) over short subjects and compared with the oracle (oracle/bt_regex.c): result and every capture offset.
 The oracle is the checker; nothing here is a product path.  tests/test_backref.py runs a bounded round of it (seed 1, 400 patterns);
-the round's runs: seeds 1 and 2, 7 000 patterns, 84 000 checks, no difference (docs/NEXT.md)."""
+the round's runs: seeds 1-9, 450 000 host checks, and 3.96 million checks through the kernel on the MI355X, no difference
+(profiles/round6_bt_fuzz_gpu.txt)."""
 import ctypes, os, random, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
