@@ -734,11 +734,16 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
                 if (g.target >= 0)
                     for (size_t d = 0; d < rep.size(); ++d)
                         if (nfa.positions[size_t(g.target)].has(rep[d])) cont[size_t(t)] |= ClassMask(1) << d;
+        // (a spawned thread that LEAVES an atomic group on its next step commits the group and ends the threads behind it -- p's self
+        // loop among them -- whatever byte follows: such a spawn is not "gone again", found by the forced-engine device fuzz of round 6,
+        // '(?>a+?.)' on "aa1", profiles/round6_bt_fuzz_gpu.txt D)
+        std::vector<char> leavesPos(size_t(npos), 0);
+        for (int t = 0; t < npos; ++t)
+            for (const auto& path : nfa.follow[size_t(t)])
+                for (const auto& ev : path.atoms)
+                    if (ev.code < 0) leavesPos[size_t(t)] = 1;
         for (int p = 0; p < npos && !off; ++p) {
-            bool leaves = false;
-            for (const auto& path : nfa.follow[size_t(p)])
-                for (const auto& ev : path.atoms) leaves = leaves || ev.code < 0;
-            if (leaves) continue;
+            if (leavesPos[size_t(p)]) continue;
             std::vector<ClassMask> row(rep.size(), 0);
             bool any = false;
             for (size_t c = 0; c < rep.size(); ++c) {
@@ -755,6 +760,7 @@ std::vector<uint32_t> packNfaBlob(const FollowNfa& nfa, std::vector<uint8_t>& cl
                         if (path.tags.any() || path.cond != 0) plain = false;  // (a tagged or conditional self loop is a real move)
                         ++selfLoops;
                     } else {
+                        if (leavesPos[size_t(path.target)]) plain = false;
                         survive |= cont[size_t(path.target)];
                     }
                 }

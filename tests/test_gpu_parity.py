@@ -1116,3 +1116,24 @@ def test_thread_list_kernels_on_follow_lists_by_byte_class(torch_dev, golden_dir
         exp_caps, exp_status = OracleRegex(corpus.REGEX_A).fullmatch_batch(data, off[:-1], length)
         caps_n, status_n = run_device(torch_dev, B.GpuRegex(corpus.REGEX_A), data, off, None, sep=1, engine=B.LC_ENGINE_NFA)
         assert np.array_equal(status_n, exp_status) and np.array_equal(caps_n, exp_caps)
+
+
+def test_atomic_lazy_loop_commits_on_the_thread_list_engine(torch_dev):
+    """A lazy loop inside an atomic group whose exit leaves the group: '(?>a+?.)' takes "a" + one byte and is committed -- "aa1" is no
+    full match.  The thread-list kernel's doomed-spawn rows once skipped the step that commits (found by the forced-engine device fuzz of
+    round 6, profiles/round6_bt_fuzz_gpu.txt D).  Every engine the handle can be asked for, against the oracle."""
+    subs = [b'aa1', b'aa', b'a1', b'aaa', b'', b'a', b'ca', b'c1', b'aaaa1', b'xby', b'xbby', b'xaby', b'xbay', b'xy'] * 5
+    for p in (b'(?>a+?.)', b'(?>(?:(c)|(?:a)+?).)', b'(?>(?:c|a+?).)', b'x(?>b*?[ab])y'):
+        o = OracleRegex(p)
+        for eng in (B.LC_ENGINE_NFA, B.LC_ENGINE_AUTO, B.LC_ENGINE_TDFA, B.LC_ENGINE_BT):
+            for flags, search in ((0, False), (B.LC_SYNTAX_SEARCH, True)):
+                rx = B.GpuRegex(p, syntax_flags=flags, engine=eng)
+                data, off, length = pack(subs)
+                caps, status = run_device(torch_dev, rx, data, off, length)
+                for i, s in enumerate(subs):
+                    w = o.search(s) if search else o.fullmatch(s)
+                    exp = None if w is None else [v for ab in w for v in ab][0 if search else 2:]
+                    if exp is None:
+                        assert status[i] == B.LC_NOMATCH and (caps[i] == -1).all(), (p, eng, search, s)
+                    else:
+                        assert status[i] == B.LC_MATCH and list(caps[i]) == exp, (p, eng, search, s, list(caps[i]), exp)

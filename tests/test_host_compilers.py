@@ -685,3 +685,15 @@ def test_follow_lists_by_byte_class_are_the_follow_lists_filtered(golden_dir, mo
                     assert [int(x) for x in cpaths[lo:hi]] == want, (pat, p, c)
                     checked += 1
     assert checked > 20000
+
+
+def test_a_spawn_that_leaves_an_atomic_group_is_not_a_doomed_spawn():
+    """Round 6's forced-engine device fuzz (profiles/round6_bt_fuzz_gpu.txt D): '(?>a+?.)' on "aa1" matched on the thread-list kernel
+    because the doomed-spawn row of the loop position skipped the step on which the spawned '.' thread leaves -- commits -- the atomic
+    group and ends the loop's thread.  The rows (regex_handle.cpp packNfaBlob, NF_OFF_QUASI) must not cover such a spawn; the plain form
+    keeps its row.  The device side of this is tests/test_gpu_parity.py::test_atomic_lazy_loop_commits_on_the_thread_list_engine."""
+    for p in (b'(?>a+?.)', b'(?>(?:(c)|(?:a)+?).)', b'(?>(?:c|a+?).)', b'x(?>b*?[ab])y'):
+        rx = B.GpuRegex(p, engine=B.LC_ENGINE_NFA)
+        assert rx.atomic_groups()[0] >= 1
+        assert NfaInterp(rx).quasi_rows is None, p
+    assert NfaInterp(B.GpuRegex(b'a+?.', engine=B.LC_ENGINE_NFA)).quasi_rows is not None
